@@ -1,0 +1,123 @@
+"""Deterministic parameter recipe shared by the fixture generator and the parity tests.
+
+TEST INFRASTRUCTURE ONLY (see oracle/sea_oracle.py header).
+
+The golden fixtures under tests/golden/ store inputs and expected outputs but not the
+model weights: weights are regenerated from the parameter NAME with this recipe, so the
+reference (in the build container), the oracle and the HIP path (on the GPU box) all see
+bit-identical parameters without shipping megabytes of weights.
+
+``param_schema`` restates the reference's parameter set (names and shapes of
+``TemporalModel(...).named_parameters()``, models/temporal.py:326-403 with the blocks of
+:21-192 and the layers of models/base_blocks.py); tests/golden/make_fixtures.py asserts it equals
+the reference's own, key for key.
+"""
+from __future__ import annotations
+
+import zlib
+from collections import OrderedDict
+from typing import Dict, Tuple
+
+import numpy as np
+import torch
+
+from .sea_oracle import OracleConfig
+
+Schema = "OrderedDict[str, Tuple[Tuple[int, ...], str]]"
+
+
+def _adaln(s, pre: str, d: int):
+    s[pre + "weight"] = ((d,), "norm_w")
+    s[pre + "bias"] = ((d,), "norm_b")
+    s[pre + "cond_mlp.0.weight"] = ((2 * d, 1), "lin_w")
+    s[pre + "cond_mlp.0.bias"] = ((2 * d,), "lin_b")
+    s[pre + "cond_mlp.2.weight"] = ((2 * d, 2 * d), "lin_w")
+    s[pre + "cond_mlp.2.bias"] = ((2 * d,), "lin_b")
+
+
+def _norm(s, pre: str, d: int, ln_type: str):
+    if ln_type.lower() == "adaln":
+        _adaln(s, pre, d)
+    else:
+        s[pre + "weight"] = ((d,), "norm_w")  # custom LayerNorm(bias=False), base_blocks.py:82-85
+
+
+def _linear(s, pre: str, out_f: int, in_f: int, bias: bool = True):
+    s[pre + "weight"] = ((out_f, in_f), "lin_w")
+    if bias:
+        s[pre + "bias"] = ((out_f,), "lin_b")
+
+
+def _attention(s, pre: str, d: int):
+    for n in ("k", "q", "v"):
+        _linear(s, f"{pre}{n}.", d, d)
+    _linear(s, pre + "projection.", d, d, bias=False)
+
+
+def param_schema(cfg: OracleConfig) -> "OrderedDict[str, Tuple[Tuple[int, ...], str]]":
+    E, D, F = cfg.embed_dim, cfg.down_dim, cfg.num_variables
+    S = max(1, int(E * cfg.scale_ratio))
+    sr = max(1, int(1 * cfg.scale_ratio))  # ib MLP hidden: dim_in = ib_num = 1
+    s: "OrderedDict[str, Tuple[Tuple[int, ...], str]]" = OrderedDict()
+    for layer in range(cfg.num_layers):
+        b = f"blocks.{layer}."
+        _linear(s, b + "ib.residual_projection.", E, 1)
+        _linear(s, b + "ib.layers.0.", sr, 1)
+        s[b + "ib.layers.1.weight"] = ((sr,), "norm_w")
+        s[b + "ib.layers.1.bias"] = ((sr,), "norm_b")
+        _linear(s, b + "ib.layers.3.", E, sr)
+        for i in range(F):
+            for n in range(3):
+                _norm(s, f"{b}ln.exp.{i}.{n}.", E, cfg.LN_type)
+        _norm(s, b + "ln.cross.", D, cfg.LN_type)
+        for i in range(F):
+            _attention(s, f"{b}attn.self.{i}.", E)
+        for i in range(F):
+            _linear(s, f"{b}mlp.{i}.layers.0.", S, E)
+            s[f"{b}mlp.{i}.layers.1.weight"] = ((S,), "norm_w")
+            s[f"{b}mlp.{i}.layers.1.bias"] = ((S,), "norm_b")
+            _linear(s, f"{b}mlp.{i}.layers.3.", E, S)
+        for i in range(F):
+            _linear(s, f"{b}proj.{i}.", E, E)
+        for i in range(F):
+            _linear(s, f"{b}cross_down.{i}.", D, E)
+        for i in range(F):
+            _linear(s, f"{b}cross_up.{i}.", E, D)
+        for i in range(F):
+            for j in range(F):
+                _attention(s, f"{b}cross_attn.{i}.{j}.", D)
+        for i in range(F):
+            _norm(s, f"{b}ln_cross.{i}.", D, cfg.LN_type)
+    for i in range(F):
+        _norm(s, f"ln.{i}.", E, cfg.LN_type)
+    return s
+
+
+def recipe_tensor(key: str, shape: Tuple[int, ...], kind: str) -> np.ndarray:
+    """Values depend only on (key, shape, kind).  Scales are chosen so that activations stay O(1)
+    and every term (biases, norm gains, modulation) is visibly exercised, unlike the reference's
+    N(0, 0.02) init under which softmax is near-uniform."""
+    rng = np.random.Generator(np.random.PCG64(zlib.crc32(key.encode("utf-8"))))
+    if kind == "lin_w":
+        fan_in = shape[1]
+        return (rng.standard_normal(shape) * (0.8 / np.sqrt(fan_in))).astype(np.float32)
+    if kind == "lin_b":
+        return (rng.standard_normal(shape) * 0.1).astype(np.float32)
+    if kind == "norm_w":
+        return (1.0 + 0.1 * rng.standard_normal(shape)).astype(np.float32)
+    if kind == "norm_b":
+        return (0.1 * rng.standard_normal(shape)).astype(np.float32)
+    raise ValueError(kind)
+
+
+def recipe_params(cfg: OracleConfig, dtype=torch.float32) -> Dict[str, torch.Tensor]:
+    return {k: torch.from_numpy(recipe_tensor(k, shp, kind)).to(dtype) for k, (shp, kind) in param_schema(cfg).items()}
+
+
+def recipe_inputs(B: int, T: int, cfg: OracleConfig, seed: int = 1234) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    """Synthetic encoded fields x ~ N(0,1) [B,T,F,E], target ~ N(0,1), condition ib ~ U(0,1) [B,T,1]."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    x = rng.standard_normal((B, T, cfg.num_variables, cfg.embed_dim)).astype(np.float32)
+    tgt = rng.standard_normal((B, T, cfg.num_variables, cfg.embed_dim)).astype(np.float32)
+    ib = rng.random((B, T, 1)).astype(np.float32)
+    return torch.from_numpy(x), torch.from_numpy(tgt), torch.from_numpy(ib)

@@ -1,0 +1,303 @@
+"""CPU oracle for SEA's temporal-rollout hot path.
+
+TEST INFRASTRUCTURE ONLY.  Nothing under ``sea_amd/`` may import this file; only
+``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg do,
+and there only as the checker / the timed CPU baseline — never as the product.
+
+This is a from-spec, functional restatement (plain tensor algebra on the CPU, no
+``nn.Module``) of what the reference computes on the path named by
+BASELINE.json:north_star.  Every function cites the reference lines it follows
+(paths are relative to the reference repository root).  Parameters are addressed
+by the reference's ``state_dict`` key names, so a reference-trained checkpoint
+can be fed to it unchanged.
+
+Pinning: the reference ships no tests or golden vectors for this path
+(SURVEY.md §4), so the oracle is pinned against outputs of the reference itself,
+generated in the build container by ``tests/golden/make_fixtures.py`` and
+committed as ``tests/golden/*.npz``; ``tests/test_oracle_golden.py`` checks every
+function here against them.
+
+The arithmetic is floating point; ``dtype`` may be ``torch.float32`` (what the
+reference computes in) or ``torch.float64`` (a tighter truth for tolerance
+studies).  Gradients come from autograd over these functions.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+
+Params = Dict[str, torch.Tensor]
+
+
+@dataclass(frozen=True)
+class OracleConfig:
+    """Constructor arguments of the reference ``TemporalModel`` that shape the
+    computation (models/temporal.py:327-344).  Only the combination both shipped
+    configs select is restated: exchange_mode='sea', ib_scale_mode='mlp',
+    ib_addition_mode='add', ib_mlp_layers=1, ib_num=1."""
+
+    num_layers: int
+    embed_dim: int
+    n_heads: int
+    max_len: int
+    scale_ratio: int
+    src_len: int
+    num_variables: int
+    down_proj: int = 2
+    add_info_after_cross: bool = True
+    LN_type: str = "adaln"
+
+    @property
+    def down_dim(self) -> int:  # models/temporal.py:58-59
+        return self.embed_dim // self.down_proj
+
+
+# --------------------------------------------------------------------------- primitives
+def linear(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """nn.Linear: y = x W^T + b with W stored [out, in]."""
+    y = x @ w.t()
+    return y if b is None else y + b
+
+
+def gelu_erf(x: torch.Tensor) -> torch.Tensor:
+    """nn.GELU() default = exact erf form (models/base_blocks.py:24,74)."""
+    return 0.5 * x * (1.0 + torch.erf(x * (1.0 / math.sqrt(2.0))))
+
+
+def silu(x: torch.Tensor) -> torch.Tensor:
+    return x / (1.0 + torch.exp(-x))
+
+
+def layer_norm(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor], eps: float = 1e-5) -> torch.Tensor:
+    """F.layer_norm over the last dim, biased variance (models/base_blocks.py:87-88 and the
+    nn.LayerNorm inside MLP, :23)."""
+    mean = x.mean(dim=-1, keepdim=True)
+    var = ((x - mean) ** 2).mean(dim=-1, keepdim=True)
+    y = (x - mean) / torch.sqrt(var + eps) * w
+    return y if b is None else y + b
+
+
+def adaln(x: torch.Tensor, cond: torch.Tensor, p: Params, pre: str) -> torch.Tensor:
+    """AdaLN.forward (models/base_blocks.py:343-350)."""
+    h = silu(linear(cond, p[pre + "cond_mlp.0.weight"], p[pre + "cond_mlp.0.bias"]))
+    c = linear(h, p[pre + "cond_mlp.2.weight"], p[pre + "cond_mlp.2.bias"])
+    d = x.shape[-1]
+    w, b = c[..., :d], c[..., d:]
+    mean = x.mean(dim=-1, keepdim=True)
+    var = ((x - mean) ** 2).mean(dim=-1, keepdim=True)
+    xn = (x - mean) / torch.sqrt(var + 1e-5)
+    return xn * (p[pre + "weight"] + (w + 1.0)) + (p[pre + "bias"] + b)
+
+
+def norm(x: torch.Tensor, cond: torch.Tensor, p: Params, pre: str, ln_type: str) -> torch.Tensor:
+    """Dispatch on LN_type (models/temporal.py:61-72): 'adaln' -> AdaLN, 'ln' -> the custom
+    bias-free LayerNorm that ignores cond (models/base_blocks.py:80-88)."""
+    if ln_type.lower() == "adaln":
+        return adaln(x, cond, p, pre)
+    return layer_norm(x, p[pre + "weight"], None)
+
+
+def rope_tables(head_dim: int, length: int, theta: float = 10000.0, dtype=torch.float32) -> Tuple[torch.Tensor, torch.Tensor]:
+    """precompute_freqs_cis (models/base_blocks.py:300-305) as separate cos/sin tables
+    [length, head_dim/2]; frequencies and angles are formed in fp32 as the reference does."""
+    freqs = 1.0 / (theta ** (torch.arange(0, head_dim, 2)[: head_dim // 2].float() / head_dim))
+    ang = torch.outer(torch.arange(length, dtype=torch.float32), freqs)
+    return torch.cos(ang).to(dtype), torch.sin(ang).to(dtype)
+
+
+def rope(x: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor) -> torch.Tensor:
+    """apply_rotary_emb (models/base_blocks.py:314-324): consecutive (even, odd) pairs of the
+    head dim are complex numbers multiplied by e^{i t f_k}.  x: [B, T, H, hd]."""
+    xe, xo = x[..., 0::2], x[..., 1::2]
+    c = cos[None, :, None, :]
+    s = sin[None, :, None, :]
+    out = torch.stack((xe * c - xo * s, xe * s + xo * c), dim=-1)
+    return out.flatten(-2)
+
+
+def masked_attention(x_q: torch.Tensor, x_kv: torch.Tensor, p: Params, pre: str, n_heads: int, src_len: int,
+                     pos0: int = 0) -> torch.Tensor:
+    """MaskedMultiHeadAttention.forward (x_q is x_kv; models/base_blocks.py:175-203) and
+    MaskedMultiHeadCrossAttention.forward (:267-295): q from x_q, k/v from x_kv, the same RoPE
+    positions for q and k, causal mask tril(diagonal=src_len), softmax, projection without bias."""
+    B, T, C = x_q.shape
+    hd = C // n_heads
+    q = linear(x_q, p[pre + "q.weight"], p[pre + "q.bias"]).view(B, T, n_heads, hd)
+    k = linear(x_kv, p[pre + "k.weight"], p[pre + "k.bias"]).view(B, T, n_heads, hd)
+    v = linear(x_kv, p[pre + "v.weight"], p[pre + "v.bias"]).view(B, T, n_heads, hd)
+    cos, sin = rope_tables(hd, pos0 + T, dtype=x_q.dtype)
+    q = rope(q, cos[pos0:], sin[pos0:])
+    k = rope(k, cos[pos0:], sin[pos0:])
+    q, k, v = q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2)
+    att = (q @ k.transpose(-2, -1)) * hd ** -0.5
+    i = torch.arange(T)
+    allowed = i[None, :] <= i[:, None] + src_len  # tril(ones, diagonal=src_len) != 0
+    att = att.masked_fill(~allowed, float("-inf"))
+    att = att - att.max(dim=-1, keepdim=True).values
+    e = torch.exp(att)
+    att = e / e.sum(dim=-1, keepdim=True)
+    out = (att @ v).transpose(1, 2).reshape(B, T, C)
+    return linear(out, p[pre + "projection.weight"])
+
+
+def mlp(x: torch.Tensor, p: Params, pre: str) -> torch.Tensor:
+    """MLP with num_layers None/1: Linear -> nn.LayerNorm(hidden, affine) -> GELU(erf) -> Linear
+    (models/base_blocks.py:22-26, 44-47); dropout is identity in eval / p=0."""
+    h = linear(x, p[pre + "layers.0.weight"], p[pre + "layers.0.bias"])
+    h = layer_norm(h, p[pre + "layers.1.weight"], p[pre + "layers.1.bias"])
+    h = gelu_erf(h)
+    return linear(h, p[pre + "layers.3.weight"], p[pre + "layers.3.bias"])
+
+
+# --------------------------------------------------------------------------- block / model
+def sea_exchange(xs: List[torch.Tensor], cond: torch.Tensor, p: Params, pre: str, cfg: OracleConfig) -> List[torch.Tensor]:
+    """SEABlockTemporal._apply_exchange / _apply_cross_attention (models/temporal.py:176-192).
+
+    Gauss-Seidel: the list is updated in place while it is iterated, so field i is exchanged
+    against the ALREADY UPDATED fields j < i and the not-yet-updated fields j > i; x_i itself
+    enters as its pre-exchange value."""
+    F = cfg.num_variables
+    xs = list(xs)
+    for i in range(F):
+        x_i = xs[i]
+        acc = None
+        for j in range(F):
+            if j == i:
+                continue
+            d_i = linear(x_i, p[f"{pre}cross_down.{i}.weight"], p[f"{pre}cross_down.{i}.bias"])
+            d_j = linear(xs[j], p[f"{pre}cross_down.{j}.weight"], p[f"{pre}cross_down.{j}.bias"])
+            n_i = norm(d_i, cond, p, f"{pre}ln_cross.{i}.", cfg.LN_type)
+            n_j = norm(d_j, cond, p, f"{pre}ln_cross.{j}.", cfg.LN_type)
+            a = masked_attention(n_i, n_j, p, f"{pre}cross_attn.{i}.{j}.", cfg.n_heads, cfg.src_len)
+            u = linear(gelu_erf(a), p[f"{pre}cross_up.{i}.weight"], p[f"{pre}cross_up.{i}.bias"])
+            acc = u if acc is None else acc + u
+        xs[i] = x_i if acc is None else x_i + acc
+    return xs
+
+
+def info_bottleneck(cond: torch.Tensor, p: Params, pre: str) -> torch.Tensor:
+    """BaseBlockTemporal._add_info with ib_scale_mode='mlp', ib_addition_mode='add'
+    (models/temporal.py:111-116): MLP(1 -> scale_ratio -> E); its residual_projection is
+    created but never used (models/base_blocks.py:15-17)."""
+    return mlp(cond, p, pre + "ib.")
+
+
+def block_forward(xs: Sequence[torch.Tensor], cond: torch.Tensor, p: Params, pre: str, cfg: OracleConfig) -> List[torch.Tensor]:
+    """BaseBlockTemporal.forward (models/temporal.py:126-148)."""
+    F = cfg.num_variables
+    assert len(xs) == F
+    xs = list(xs)
+    if not cfg.add_info_after_cross:
+        ib = info_bottleneck(cond, p, pre)
+        xs = [x + ib for x in xs]
+    for i in range(F):
+        n = norm(xs[i], cond, p, f"{pre}ln.exp.{i}.0.", cfg.LN_type)
+        xs[i] = xs[i] + masked_attention(n, n, p, f"{pre}attn.self.{i}.", cfg.n_heads, cfg.src_len)
+    xs = sea_exchange(xs, cond, p, pre, cfg)
+    if cfg.add_info_after_cross:
+        ib = info_bottleneck(cond, p, pre)
+        xs = [x + ib for x in xs]
+    for i in range(F):
+        n = norm(xs[i], cond, p, f"{pre}ln.exp.{i}.2.", cfg.LN_type)
+        xs[i] = xs[i] + mlp(n, p, f"{pre}mlp.{i}.")
+        xs[i] = linear(xs[i], p[f"{pre}proj.{i}.weight"], p[f"{pre}proj.{i}.bias"])
+    return xs
+
+
+def model_forward(x: torch.Tensor, cond: torch.Tensor, p: Params, cfg: OracleConfig) -> torch.Tensor:
+    """TemporalModel.forward (models/temporal.py:405-416).  x: [B, T, F, E], cond: [B, T, 1]."""
+    assert x.shape[2] == cfg.num_variables
+    xs = [x[:, :, i, :] for i in range(cfg.num_variables)]
+    for layer in range(cfg.num_layers):
+        xs = block_forward(xs, cond, p, f"blocks.{layer}.", cfg)
+    xs = [norm(xs[i], cond, p, f"ln.{i}.", cfg.LN_type) for i in range(cfg.num_variables)]
+    return torch.stack(xs, dim=2)
+
+
+# --------------------------------------------------------------------------- loss / metrics / loops
+def mse_loss(out: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
+    """nn.MSELoss() (train/train_temporal.py:221,256)."""
+    return ((out - target) ** 2).mean()
+
+
+def relative_mse(pred: torch.Tensor, truth: torch.Tensor, dim: int = -1) -> torch.Tensor:
+    """relativeMSE (utils/train_utils.py:112-116)."""
+    return ((pred - truth) ** 2).sum(dim=dim) / ((truth ** 2).sum(dim=dim) + 1e-8)
+
+
+def rollout(x0: torch.Tensor, cond: torch.Tensor, n_steps: int, p: Params, cfg: OracleConfig) -> torch.Tensor:
+    """The autoregressive loop of full_autoregressive_evaluation / autoregressive_validation
+    (utils/train_utils.py:202-209, :170-177): start from step 0, run the FULL forward on the
+    growing prefix, append the last predicted step.  x0: [B, 1, F, E]; cond: [B, >=n_steps, 1].
+    Returns the n_steps predictions [B, n_steps, F, E]."""
+    a = x0
+    with torch.no_grad():
+        for i in range(n_steps):
+            out = model_forward(a, cond[:, : i + 1], p, cfg)
+            a = torch.cat((a, out[:, -1:]), dim=1)
+    return a[:, 1:]
+
+
+def live_param_keys(p: Params, cfg: OracleConfig) -> List[str]:
+    """Parameters that receive a gradient on this path: everything except
+    ln.exp.{i}.1, ln.cross, the diagonal cross_attn.{i}.{i}, ib.residual_projection."""
+    dead_marks = []
+    for layer in range(cfg.num_layers):
+        pre = f"blocks.{layer}."
+        dead_marks.append(pre + "ln.cross.")
+        dead_marks.append(pre + "ib.residual_projection.")
+        for i in range(cfg.num_variables):
+            dead_marks.append(f"{pre}ln.exp.{i}.1.")
+            dead_marks.append(f"{pre}cross_attn.{i}.{i}.")
+    return [k for k in p if not any(k.startswith(d) for d in dead_marks)]
+
+
+def loss_and_grads(x: torch.Tensor, cond: torch.Tensor, target: torch.Tensor, p: Params, cfg: OracleConfig
+                   ) -> Tuple[torch.Tensor, torch.Tensor, Dict[str, torch.Tensor]]:
+    """One forward + MSE + backward (train/train_temporal.py:255-257).  Returns (out, loss, grads of
+    live parameters)."""
+    keys = live_param_keys(p, cfg)
+    q = dict(p)
+    for k in keys:
+        q[k] = p[k].detach().clone().requires_grad_(True)
+    out = model_forward(x, cond, q, cfg)
+    loss = mse_loss(out, target)
+    gs = torch.autograd.grad(loss, [q[k] for k in keys], allow_unused=True)
+    grads = {k: g for k, g in zip(keys, gs) if g is not None}
+    return out.detach(), loss.detach(), grads
+
+
+def adamw_update(param: torch.Tensor, grad: torch.Tensor, m: torch.Tensor, v: torch.Tensor, step: int, lr: float,
+                 beta1: float = 0.9, beta2: float = 0.999, eps: float = 1e-8, weight_decay: float = 0.0
+                 ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    """torch.optim.AdamW as configured by initialize_optimizer (utils/train_utils.py:33-34):
+    decoupled weight decay, bias-corrected moments.  ``step`` counts from 1."""
+    param = param * (1.0 - lr * weight_decay)
+    m = beta1 * m + (1.0 - beta1) * grad
+    v = beta2 * v + (1.0 - beta2) * grad * grad
+    bc1 = 1.0 - beta1 ** step
+    bc2 = 1.0 - beta2 ** step
+    denom = torch.sqrt(v) / math.sqrt(bc2) + eps
+    param = param - (lr / bc1) * m / denom
+    return param, m, v
+
+
+def train_steps(x: torch.Tensor, cond: torch.Tensor, target: torch.Tensor, p: Params, cfg: OracleConfig, n_steps: int,
+                lr: float, weight_decay: float = 0.0) -> Tuple[Params, List[float]]:
+    """n_steps iterations of the reference train step (train/train_temporal.py:254-258) on one batch."""
+    p = {k: v.clone() for k, v in p.items()}
+    ms: Dict[str, torch.Tensor] = {}
+    vs: Dict[str, torch.Tensor] = {}
+    losses = []
+    for step in range(1, n_steps + 1):
+        _, loss, grads = loss_and_grads(x, cond, target, p, cfg)
+        losses.append(float(loss))
+        for k, g in grads.items():
+            if k not in ms:
+                ms[k] = torch.zeros_like(p[k])
+                vs[k] = torch.zeros_like(p[k])
+            p[k], ms[k], vs[k] = adamw_update(p[k], g, ms[k], vs[k], step, lr, weight_decay=weight_decay)
+    return p, losses

@@ -1,0 +1,37 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def load_golden(name):
+    path = os.path.join(GOLDEN, name + ".npz")
+    if not os.path.exists(path):
+        pytest.skip(f"golden fixture {name}.npz not present")
+    return np.load(path, allow_pickle=False)
+
+
+def cfg_from_meta(meta):
+    from oracle.sea_oracle import OracleConfig
+
+    m = [int(v) for v in meta]
+    return OracleConfig(num_layers=m[0], embed_dim=m[1], n_heads=m[2], max_len=m[3], scale_ratio=m[4], src_len=m[5],
+                        num_variables=m[6], down_proj=m[7], add_info_after_cross=bool(m[8]),
+                        LN_type="adaln" if m[9] else "ln")
+
+
+def rel_l2(a, b):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))

@@ -1,0 +1,281 @@
+"""Generate the golden vectors under tests/golden/ by RUNNING THE REFERENCE on CPU.
+
+Runs only in the build container (it imports /root/reference, which never travels to the GPU
+box); the .npz files it writes are committed.  Fixtures are data only: inputs, expected outputs,
+and the names of parameters without gradients.  Weights are not stored — they are regenerated
+from parameter names by oracle/recipe.py on both sides.
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_fixtures.py [--only NAME] [--big]
+"""
+import argparse
+import os
+import sys
+
+sys.dont_write_bytecode = True
+REF = "/root/reference"
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, REF)
+
+import numpy as np
+import torch
+
+from oracle.recipe import param_schema, recipe_inputs, recipe_tensor
+from oracle.sea_oracle import OracleConfig
+
+from models.temporal import TemporalModel  # reference
+from models import base_blocks as ref_bb  # reference
+from utils import train_utils as ref_tu  # reference
+
+torch.set_num_threads(8)
+
+
+def build_reference(cfg: OracleConfig, dropout=0.0):
+    m = TemporalModel(cfg.num_layers, cfg.embed_dim, cfg.n_heads, cfg.max_len, cfg.scale_ratio, cfg.src_len,
+                      cfg.num_variables, cfg.down_proj, dropout, "sea", "learnable", "mlp", "add", 1, 1,
+                      cfg.add_info_after_cross, cfg.LN_type)
+    schema = param_schema(cfg)
+    named = dict(m.named_parameters())
+    assert list(named.keys()) == list(schema.keys()), (
+        "schema/key-order mismatch", [k for k in named if k not in schema], [k for k in schema if k not in named])
+    with torch.no_grad():
+        for k, prm in named.items():
+            shp, kind = schema[k]
+            assert tuple(prm.shape) == tuple(shp), (k, prm.shape, shp)
+            prm.copy_(torch.from_numpy(recipe_tensor(k, shp, kind)))
+    return m
+
+
+def cfg_meta(cfg: OracleConfig):
+    return np.array([cfg.num_layers, cfg.embed_dim, cfg.n_heads, cfg.max_len, cfg.scale_ratio, cfg.src_len,
+                     cfg.num_variables, cfg.down_proj, int(cfg.add_info_after_cross),
+                     1 if cfg.LN_type == "adaln" else 0], dtype=np.int64)
+
+
+def save(name, **arrs):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez(path, **arrs)
+    print(f"  wrote {name}.npz  {os.path.getsize(path) / 1024:.1f} KiB")
+
+
+def n(t):
+    return t.detach().cpu().numpy().copy()  # copy: parameters are updated in place later
+
+
+def model_case(name, cfg, B, T, train=False, lr=1e-3, seed=1234):
+    print(name)
+    m = build_reference(cfg)
+    x, tgt, ib = recipe_inputs(B, T, cfg, seed)
+    m.eval()
+    with torch.no_grad():
+        out = m(x, ib)
+    arrs = dict(cfg=cfg_meta(cfg), x=n(x), tgt=n(tgt), ib=n(ib), out=n(out))
+    if train:
+        m.train()
+        loss_fn = torch.nn.MSELoss()
+        opt = ref_tu.initialize_optimizer(m, {"learning_rate": lr})
+        losses = []
+        for step in range(1, 4):
+            opt.zero_grad()
+            o = m(x, ib)
+            loss = loss_fn(o, tgt)
+            loss.backward()
+            if step == 1:
+                dead = [k for k, p in m.named_parameters() if p.grad is None]
+                arrs["dead_keys"] = np.array(dead)
+                arrs["out_train"] = n(o)
+                for k, p in m.named_parameters():
+                    if p.grad is not None:
+                        arrs["grad:" + k] = n(p.grad)
+            opt.step()
+            losses.append(loss.item())
+            if step in (1, 3):
+                for k, p in m.named_parameters():
+                    if p.grad is not None:
+                        arrs[f"param{step}:" + k] = n(p)
+        arrs["losses"] = np.array(losses, dtype=np.float64)
+        arrs["lr"] = np.array(lr)
+        n_state = sum(1 for p in m.parameters() if p in opt.state)
+        arrs["n_opt_state"] = np.array(n_state)
+    save(name, **arrs)
+
+
+def rollout_case(name, cfg, B, n_steps, seed=99):
+    print(name)
+    m = build_reference(cfg)
+    m.eval()
+    x, tgt, ib = recipe_inputs(B, n_steps, cfg, seed)
+    # the loop of utils/train_utils.py:202-209, driven here so that the trajectory can be captured
+    with torch.no_grad():
+        a = x[:, 0:1]
+        for i in range(n_steps):
+            o = m(a, ib[:, : i + 1])
+            a = torch.cat((a, o[:, -1:]), dim=1)
+        pred = a[:, 1:]
+        rel = ref_tu.relativeMSE(pred, tgt).mean()
+    # the reference's own loop (first sample only) for its scalars
+    loader = [(x, tgt, None, ib)]
+    v_loss, v_rel = ref_tu.autoregressive_validation(m, loader, torch.nn.MSELoss(), torch.device("cpu"))
+    with torch.no_grad():
+        chk = torch.nn.functional.mse_loss(pred[0:1], tgt[0:1]).item()
+    assert abs(chk - v_loss) <= 1e-6 * max(1.0, abs(chk)), (chk, v_loss)
+    save(name, cfg=cfg_meta(cfg), x0=n(x[:, 0:1]), tgt=n(tgt), ib=n(ib), pred=n(pred),
+         rel_mse=np.array(rel.item()), val_loss=np.array(v_loss), val_rel_mse_time=np.array(v_rel))
+
+
+def module_cases():
+    print("modules")
+    rng = np.random.Generator(np.random.PCG64(7))
+    arrs = {}
+
+    def rnd(*shape):
+        return torch.from_numpy(rng.standard_normal(shape).astype(np.float32))
+
+    def kinds(mod, prefix):
+        # store the (key, kind) list so the test can rebuild identical weights
+        out = []
+        for k, p in mod.named_parameters():
+            if k.endswith("weight") and p.dim() == 2:
+                kind = "lin_w"
+            elif k.endswith("bias") and p.dim() == 1 and _is_linear_bias(mod, k):
+                kind = "lin_b"
+            elif k.endswith("weight"):
+                kind = "norm_w"
+            else:
+                kind = "norm_b"
+            out.append((prefix + k, kind, tuple(p.shape)))
+        return out
+
+    def _is_linear_bias(mod, k):
+        sub = mod.get_submodule(k.rsplit(".", 1)[0]) if "." in k else mod
+        return isinstance(sub, torch.nn.Linear)
+
+    def load(mod, prefix):
+        ks = kinds(mod, prefix)
+        with torch.no_grad():
+            for (key, kind, shp), (_, p) in zip(ks, mod.named_parameters()):
+                p.copy_(torch.from_numpy(recipe_tensor(key, shp, kind)))
+        arrs["kinds:" + prefix] = np.array([f"{k}|{kind}|{','.join(map(str, shp))}" for k, kind, shp in ks])
+
+    for d in (64, 128):
+        mod = ref_bb.AdaLN(d, 1)
+        load(mod, f"adaln{d}.")
+        x, c = rnd(2, 5, d) * 1.7 + 0.3, torch.from_numpy(rng.random((2, 5, 1)).astype(np.float32))
+        arrs[f"adaln{d}.x"], arrs[f"adaln{d}.c"], arrs[f"adaln{d}.y"] = n(x), n(c), n(mod(x, c))
+    mod = ref_bb.LayerNorm(64)
+    load(mod, "ln64.")
+    x = rnd(2, 5, 64) * 2.0 - 0.5
+    arrs["ln64.x"], arrs["ln64.y"] = n(x), n(mod(x, None))
+    for T in (1, 7, 16):
+        mod = ref_bb.MaskedMultiHeadAttention(4, 64, 32, 0, 0.0)
+        load(mod, "self64.")
+        x = rnd(2, T, 64)
+        arrs[f"self64.T{T}.x"], arrs[f"self64.T{T}.y"] = n(x), n(mod(x))
+    mod = ref_bb.MaskedMultiHeadAttention(4, 64, 32, 3, 0.0)
+    load(mod, "self64s3.")
+    x = rnd(1, 11, 64)
+    arrs["self64s3.x"], arrs["self64s3.y"] = n(x), n(mod(x))
+    mod = ref_bb.MaskedMultiHeadCrossAttention(4, 32, 32, 0, 0.0)
+    load(mod, "cross32.")
+    x1, x2 = rnd(2, 9, 32), rnd(2, 9, 32)
+    arrs["cross32.x1"], arrs["cross32.x2"], arrs["cross32.y"] = n(x1), n(x2), n(mod(x1, x2))
+    mod = ref_bb.MLP(64, 0.0, 8)
+    load(mod, "mlp64.")
+    x = rnd(2, 5, 64)
+    arrs["mlp64.x"], arrs["mlp64.y"] = n(x), n(mod(x))
+    mod = ref_bb.MLP(1, 0.0, 8, 64, 1)
+    load(mod, "ibmlp.")
+    c = torch.from_numpy(rng.random((2, 5, 1)).astype(np.float32))
+    arrs["ibmlp.c"], arrs["ibmlp.y"] = n(c), n(mod(c))
+    fc = ref_bb.precompute_freqs_cis(16, 32)
+    arrs["rope16.cos"], arrs["rope16.sin"] = n(fc.real), n(fc.imag)
+    q, k = rnd(2, 6, 4, 16), rnd(2, 6, 4, 16)
+    qo, ko = ref_bb.apply_rotary_emb(q, k, fc[:6])
+    arrs["rope16.q"], arrs["rope16.k"], arrs["rope16.qo"], arrs["rope16.ko"] = n(q), n(k), n(qo), n(ko)
+    p, t = rnd(2, 4, 3, 8), rnd(2, 4, 3, 8)
+    arrs["relmse.p"], arrs["relmse.t"], arrs["relmse.y"] = n(p), n(t), n(ref_tu.relativeMSE(p, t))
+    with torch.no_grad():
+        save("modules", **{k: (v if isinstance(v, np.ndarray) else np.asarray(v)) for k, v in arrs.items()})
+
+
+def exchange_cases():
+    """One SEA block's exchange step alone (pins the Gauss-Seidel order, models/temporal.py:187-192)."""
+    print("exchange")
+    arrs = {}
+    for F, ln in ((2, "adaln"), (3, "adaln"), (3, "ln")):
+        cfg = OracleConfig(1, 64, 4, 16, 8, 0, F, 2, True, ln)
+        m = build_reference(cfg)
+        m.eval()
+        x, _, ib = recipe_inputs(2, 10, cfg, seed=5 + F)
+        xs = [x[:, :, i, :].clone() for i in range(F)]
+        with torch.no_grad():
+            ys = m.blocks[0]._apply_exchange(list(xs), ib)
+            blk = m.blocks[0](*[x[:, :, i, :] for i in range(F)], x_add=ib)
+        tag = f"F{F}{ln}"
+        arrs[tag + ".cfg"] = cfg_meta(cfg)
+        arrs[tag + ".x"], arrs[tag + ".ib"] = n(x), n(ib)
+        arrs[tag + ".y"] = np.stack([n(y) for y in ys], axis=2)
+        arrs[tag + ".block"] = np.stack([n(y) for y in blk], axis=2)
+    save("exchange", **arrs)
+
+
+def big_cases():
+    # cfg2 shape (BASELINE.json configs[1]): E=256, H=8, F=3, T=2024, B=1
+    print("cfg2_shape")
+    cfg = OracleConfig(1, 256, 8, 2024, 8, 0, 3, 2, True, "adaln")
+    m = build_reference(cfg)
+    m.eval()
+    x, _, ib = recipe_inputs(1, 2024, cfg, seed=1234)
+    with torch.no_grad():
+        out = m(x, ib)
+    save("cfg2_shape", cfg=cfg_meta(cfg), seed=np.array(1234), out_sub=n(out[:, ::97, :, ::13]),
+         out_l2=n(out.pow(2).sum(dim=(0, 1, 3)).sqrt()), out_mean=n(out.mean(dim=(0, 1, 3))),
+         out_last=n(out[:, -1]))
+    del m
+    # cfg5-like (multiphase structure): LN_type='ln', F=2, 100-step rollout at E=256
+    rollout_case("rollout100_ln_f2_e256", OracleConfig(1, 256, 8, 128, 8, 0, 2, 2, True, "ln"), 1, 100, seed=77)
+    # cfg1 (BASELINE.json configs[0]): shipped cylinder dims E=1024, F=2, 1 trajectory, 8-step rollout
+    print("cfg1_cylinder_rollout8")
+    cfg = OracleConfig(1, 1024, 8, 2024, 8, 0, 2, 2, True, "adaln")
+    m = build_reference(cfg)
+    m.eval()
+    x, tgt, ib = recipe_inputs(1, 8, cfg, seed=4321)
+    with torch.no_grad():
+        a = x[:, 0:1]
+        for i in range(8):
+            o = m(a, ib[:, : i + 1])
+            a = torch.cat((a, o[:, -1:]), dim=1)
+        pred = a[:, 1:]
+    save("cfg1_cylinder_rollout8", cfg=cfg_meta(cfg), seed=np.array(4321), pred_sub=n(pred[:, :, :, ::37]),
+         pred_l2=n(pred.pow(2).sum(dim=(0, 3)).sqrt()))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default=None)
+    ap.add_argument("--big", action="store_true", help="also the cfg1/cfg2-shaped cases (slow, ~GBs of RAM)")
+    args = ap.parse_args()
+
+    cases = {
+        "model_tiny_adaln_f3": lambda: model_case("model_tiny_adaln_f3", OracleConfig(1, 32, 2, 24, 8, 0, 3, 2, True, "adaln"), 2, 16, train=True),
+        "model_tiny_ln_f2": lambda: model_case("model_tiny_ln_f2", OracleConfig(2, 32, 2, 24, 8, 0, 2, 2, True, "ln"), 2, 12, train=True),
+        "model_tiny_adaln_f2_pre": lambda: model_case("model_tiny_adaln_f2_pre", OracleConfig(1, 32, 2, 24, 8, 0, 2, 2, False, "adaln"), 2, 8, train=True),
+        "model_small_srclen2": lambda: model_case("model_small_srclen2", OracleConfig(1, 64, 4, 16, 8, 2, 2, 2, True, "adaln"), 2, 9),
+        "rollout8_adaln_f3": lambda: rollout_case("rollout8_adaln_f3", OracleConfig(1, 64, 4, 16, 8, 0, 3, 2, True, "adaln"), 2, 8),
+        "rollout100_ln_f2": lambda: rollout_case("rollout100_ln_f2", OracleConfig(1, 64, 4, 128, 8, 0, 2, 2, True, "ln"), 1, 100),
+        "modules": module_cases,
+        "exchange": exchange_cases,
+    }
+    for T in (1, 7, 16, 65):
+        cases[f"model_small_adaln_f3_T{T}"] = (lambda T=T: model_case(
+            f"model_small_adaln_f3_T{T}", OracleConfig(1, 64, 4, 80, 8, 0, 3, 2, True, "adaln"), 2, T))
+    for name, fn in cases.items():
+        if args.only is None or args.only == name:
+            fn()
+    if args.big and args.only is None or args.only == "big":
+        big_cases()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,184 @@
+"""Pin the CPU oracle (oracle/sea_oracle.py) against golden vectors produced by the reference itself
+(tests/golden/make_fixtures.py).  CPU only."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import sea_oracle as O
+from oracle.recipe import param_schema, recipe_params, recipe_tensor
+from tests.conftest import cfg_from_meta, load_golden, rel_l2
+
+TOL = 2e-6  # fp32 accumulation-order noise between two CPU restatements
+
+
+def T(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def module_params(g, prefix):
+    out = {}
+    for row in g["kinds:" + prefix]:
+        key, kind, shp = str(row).split("|")
+        shape = tuple(int(s) for s in shp.split(",")) if shp else ()
+        out[key] = T(recipe_tensor(key, shape, kind))
+    return out
+
+
+@pytest.mark.parametrize("d", [64, 128])
+def test_adaln(d):
+    g = load_golden("modules")
+    p = module_params(g, f"adaln{d}.")
+    y = O.adaln(T(g[f"adaln{d}.x"]), T(g[f"adaln{d}.c"]), p, f"adaln{d}.")
+    assert rel_l2(y, g[f"adaln{d}.y"]) < TOL
+
+
+def test_layernorm():
+    g = load_golden("modules")
+    p = module_params(g, "ln64.")
+    y = O.layer_norm(T(g["ln64.x"]), p["ln64.weight"], None)
+    assert rel_l2(y, g["ln64.y"]) < TOL
+
+
+@pytest.mark.parametrize("T_", [1, 7, 16])
+def test_self_attention(T_):
+    g = load_golden("modules")
+    p = module_params(g, "self64.")
+    x = T(g[f"self64.T{T_}.x"])
+    y = O.masked_attention(x, x, p, "self64.", 4, 0)
+    assert rel_l2(y, g[f"self64.T{T_}.y"]) < TOL
+
+
+def test_self_attention_src_len():
+    g = load_golden("modules")
+    p = module_params(g, "self64s3.")
+    x = T(g["self64s3.x"])
+    y = O.masked_attention(x, x, p, "self64s3.", 4, 3)
+    assert rel_l2(y, g["self64s3.y"]) < TOL
+
+
+def test_cross_attention():
+    g = load_golden("modules")
+    p = module_params(g, "cross32.")
+    y = O.masked_attention(T(g["cross32.x1"]), T(g["cross32.x2"]), p, "cross32.", 4, 0)
+    assert rel_l2(y, g["cross32.y"]) < TOL
+
+
+def test_mlp_and_ib_mlp():
+    g = load_golden("modules")
+    y = O.mlp(T(g["mlp64.x"]), module_params(g, "mlp64."), "mlp64.")
+    assert rel_l2(y, g["mlp64.y"]) < TOL
+    y = O.mlp(T(g["ibmlp.c"]), module_params(g, "ibmlp."), "ibmlp.")
+    assert rel_l2(y, g["ibmlp.y"]) < TOL
+
+
+def test_rope():
+    g = load_golden("modules")
+    cos, sin = O.rope_tables(16, 32)
+    # torch.polar and torch.cos/sin may differ in the last ulp
+    assert np.allclose(cos.numpy(), g["rope16.cos"], atol=2e-7, rtol=0)
+    assert np.allclose(sin.numpy(), g["rope16.sin"], atol=2e-7, rtol=0)
+    qo = O.rope(T(g["rope16.q"]), cos[:6], sin[:6])
+    ko = O.rope(T(g["rope16.k"]), cos[:6], sin[:6])
+    assert rel_l2(qo, g["rope16.qo"]) < 1e-7 and rel_l2(ko, g["rope16.ko"]) < 1e-7
+
+
+def test_relative_mse():
+    g = load_golden("modules")
+    y = O.relative_mse(T(g["relmse.p"]), T(g["relmse.t"]))
+    assert rel_l2(y, g["relmse.y"]) < 1e-6
+
+
+@pytest.mark.parametrize("tag", ["F2adaln", "F3adaln", "F3ln"])
+def test_exchange_is_gauss_seidel(tag):
+    g = load_golden("exchange")
+    cfg = cfg_from_meta(g[tag + ".cfg"])
+    p = recipe_params(cfg)
+    x, ib = T(g[tag + ".x"]), T(g[tag + ".ib"])
+    xs = [x[:, :, i, :] for i in range(cfg.num_variables)]
+    ys = torch.stack(O.sea_exchange(xs, ib, p, "blocks.0.", cfg), dim=2)
+    assert rel_l2(ys, g[tag + ".y"]) < TOL
+    blk = torch.stack(O.block_forward(xs, ib, p, "blocks.0.", cfg), dim=2)
+    assert rel_l2(blk, g[tag + ".block"]) < TOL
+
+
+MODEL_CASES = ["model_tiny_adaln_f3", "model_tiny_ln_f2", "model_tiny_adaln_f2_pre", "model_small_srclen2",
+               "model_small_adaln_f3_T1", "model_small_adaln_f3_T7", "model_small_adaln_f3_T16",
+               "model_small_adaln_f3_T65"]
+
+
+@pytest.mark.parametrize("name", MODEL_CASES)
+def test_model_forward(name):
+    g = load_golden(name)
+    cfg = cfg_from_meta(g["cfg"])
+    p = recipe_params(cfg)
+    out = O.model_forward(T(g["x"]), T(g["ib"]), p, cfg)
+    assert rel_l2(out, g["out"]) < TOL
+
+
+@pytest.mark.parametrize("name", ["model_tiny_adaln_f3", "model_tiny_ln_f2", "model_tiny_adaln_f2_pre"])
+def test_model_grads_and_adamw(name):
+    g = load_golden(name)
+    cfg = cfg_from_meta(g["cfg"])
+    p = recipe_params(cfg)
+    x, tgt, ib = T(g["x"]), T(g["tgt"]), T(g["ib"])
+    out, loss, grads = O.loss_and_grads(x, ib, tgt, p, cfg)
+    assert rel_l2(out, g["out_train"]) < TOL
+    assert abs(float(loss) - float(g["losses"][0])) < 1e-6 * abs(float(g["losses"][0]))
+    # the set of parameters without gradient is exactly the reference's
+    dead = set(str(k) for k in g["dead_keys"])
+    assert set(p.keys()) - set(O.live_param_keys(p, cfg)) == dead
+    assert set(grads.keys()) == set(p.keys()) - dead
+    assert int(g["n_opt_state"]) == len(grads)
+    worst = max(rel_l2(grads[k], g["grad:" + k]) for k in grads)
+    assert worst < 2e-5, worst
+    # 3 AdamW steps
+    lr = float(g["lr"])
+    p3, losses = O.train_steps(x, ib, tgt, p, cfg, 3, lr)
+    assert np.allclose(losses, g["losses"], rtol=2e-5)
+    p1, _ = O.train_steps(x, ib, tgt, p, cfg, 1, lr)
+    for k in grads:
+        assert rel_l2(p1[k], g["param1:" + k]) < 1e-5, k
+        assert rel_l2(p3[k], g["param3:" + k]) < 1e-4, k
+    for k in dead:
+        assert torch.equal(p3[k], p[k])
+
+
+@pytest.mark.parametrize("name", ["rollout8_adaln_f3", "rollout100_ln_f2", "rollout100_ln_f2_e256"])
+def test_rollout(name):
+    g = load_golden(name)
+    cfg = cfg_from_meta(g["cfg"])
+    p = recipe_params(cfg)
+    tgt = T(g["tgt"])
+    pred = O.rollout(T(g["x0"]), T(g["ib"]), tgt.shape[1], p, cfg)
+    assert rel_l2(pred, g["pred"]) < 1e-4  # autoregressive: per-step 1e-6 noise compounds
+    rel = O.relative_mse(pred, tgt).mean()
+    assert abs(float(rel) - float(g["rel_mse"])) < 1e-4 * float(g["rel_mse"])
+    v_loss = O.mse_loss(pred[0:1], tgt[0:1])
+    assert abs(float(v_loss) - float(g["val_loss"])) < 1e-4 * float(g["val_loss"])
+    v_rel = O.relative_mse(pred[0:1], tgt[0:1], dim=3).mean()
+    assert abs(float(v_rel) - float(g["val_rel_mse_time"])) < 1e-4 * float(g["val_rel_mse_time"])
+
+
+def test_cfg2_shape_forward():
+    """BASELINE.json configs[1] shape (E=256, H=8, F=3, T=2024, B=1) against the reference's strided sample."""
+    g = load_golden("cfg2_shape")
+    cfg = cfg_from_meta(g["cfg"])
+    from oracle.recipe import recipe_inputs
+
+    p = recipe_params(cfg)
+    x, _, ib = recipe_inputs(1, 2024, cfg, seed=int(g["seed"]))
+    with torch.no_grad():
+        out = O.model_forward(x, ib, p, cfg)
+    assert rel_l2(out[:, ::97, :, ::13], g["out_sub"]) < 5e-6
+    assert rel_l2(out[:, -1], g["out_last"]) < 5e-6
+    assert np.allclose(out.pow(2).sum(dim=(0, 1, 3)).sqrt().numpy(), g["out_l2"], rtol=1e-5)
+
+
+def test_schema_counts():
+    cfg = O.OracleConfig(1, 256, 8, 2024, 8, 0, 3, 2, True, "adaln")
+    s = param_schema(cfg)
+    n = sum(int(np.prod(shp)) for shp, _ in s.values())
+    assert len(s) == 224 and n == 8_381_472
+    live = O.live_param_keys({k: None for k in s}, cfg)
+    n_dead = sum(int(np.prod(s[k][0])) for k in s if k not in live)
+    assert n_dead == 1_057_408
