@@ -1,0 +1,216 @@
+/*
+ * sea_hip.h — C ABI of libsea_hip.so, the MI355X (gfx950) kernels under the SEA temporal-rollout path.
+ *
+ * The reference (ParsaEsmati/SEA) has no FFI: its boundary is the Python class surface of
+ * models/temporal.py + models/base_blocks.py, whose forward()s dispatch eager ATen ops.  Each entry point
+ * below replaces the ATen work of the reference lines it cites; sea_amd/ (the host-side mirror of that class
+ * surface) binds them with ctypes.  All paths are relative to the reference repository root.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every pointer is DEVICE memory owned by the caller; the library never
+ *     allocates, frees or retains device memory;
+ *   - every call is asynchronous on `stream` (a hipStream_t passed as void*), re-entrant, graph-capturable;
+ *   - return 0 on success, a negative SEA_E* code on failure (nothing was launched); the message is available
+ *     from sea_last_error() (thread-local); the library never throws and never exits;
+ *   - `dtype` selects the ACTIVATION/WEIGHT operand type of the matrix contractions: SEA_F32 uses the exact-f32
+ *     MFMA (v_mfma_f32_16x16x4_f32), SEA_BF16 the bf16 MFMA (v_mfma_f32_16x16x32_bf16); accumulation, softmax,
+ *     normalisation statistics, residual stream and optimizer state are always fp32;
+ *   - "act" tensors have element type `dtype`; "f32" tensors are float.
+ */
+#ifndef SEA_HIP_H
+#define SEA_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SEA_ABI_VERSION 1
+
+enum { SEA_F32 = 0, SEA_BF16 = 1 };
+
+enum {
+    SEA_OK = 0,
+    SEA_EINVAL = -1,   /* bad argument (null, misaligned, unsupported shape) */
+    SEA_ELAUNCH = -2,  /* HIP reported a launch error */
+    SEA_EUNSUPPORTED = -3
+};
+
+int sea_abi_version(void);
+const char* sea_last_error(void);
+/* sizeof of every ABI struct in declaration order (SeaGemmGroup, SeaQkvGroup, SeaQkvCommon, SeaAttnProblem,
+ * SeaAttnParams, SeaNormGroup, SeaSiluGroup, SeaIbParams, ...): lets a binding verify its layout.  Host only. */
+int sea_struct_sizes(int* out, int cap);
+/* Number of compute units / name of device 0's architecture as HIP reports them (diagnostics for bench.py). */
+int sea_device_info(int* cu_count, char* arch, int arch_len);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Grouped GEMM with fused epilogue:  for each group g
+ *     acc = sum_{s < n_seg} A_s[M,K] . W[N,K]^T                      (W in nn.Linear layout [out, in])
+ *     v   = acc + bias_scale * bias                                    (bias may be NULL)
+ *     v   = act ? gelu_erf(v) : v
+ *     v   = v + R                                                      (R fp32 residual, may be NULL)
+ *     C32 = v (fp32, may be NULL);  Cact = (act dtype) v (may be NULL)
+ * Replaces nn.Linear / `+` / nn.GELU call sites: attention output projection + residual
+ * (models/base_blocks.py:201,293; models/temporal.py:136), cross_down / cross_up (+GELU, + sum over j, + residual;
+ * models/temporal.py:177-178,185,189-191), MLP Linear layers (models/base_blocks.py:22,25; models/temporal.py:145),
+ * proj (models/temporal.py:146), AdaLN cond_mlp.2 (models/base_blocks.py:339,344).
+ * n_seg > 1 sums several A operands against the same W (sum_j cross_up(GELU(a_ij)) = cross_up applied to the
+ * sum, done inside the MFMA accumulation): segment s is at A + s * a_seg_stride elements.
+ * Requirements: K % 8 == 0; lda, ldw multiples of 8; A, W 16-byte aligned.
+ */
+#define SEA_MAX_GROUPS 16
+typedef struct {
+    const void* A;      /* act [M, K], row stride lda */
+    const void* W;      /* act [N, K], row stride ldw */
+    const float* bias;  /* f32 [N] or NULL */
+    const float* R;     /* f32 [M, N] row stride ldr, or NULL */
+    float* C32;         /* f32 [M, N] row stride ldc32, or NULL */
+    void* Cact;         /* act [M, N] row stride ldcact, or NULL */
+    int64_t a_seg_stride;
+    int32_t lda, ldw, ldr, ldc32, ldcact;
+    int32_t M, N, K, n_seg;
+    int32_t act;        /* 0 none, 1 GELU(erf) */
+    float bias_scale;
+} SeaGemmGroup;
+
+int sea_gemm_grouped(const SeaGemmGroup* groups, int n_groups, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Q/K/V projection + bias + rotary embedding, written in the layouts the attention kernel consumes.
+ * Replaces models/base_blocks.py:179-188 (self) and :271-280 (cross): three nn.Linear, view to heads,
+ * apply_rotary_emb (:314-324) on q and k in fp32, transposes.
+ * The virtual output row is [q | k | v] (3 * H*hd columns); a group computes columns [col0, col0 + N) of it from
+ * its own A and W (self-attention: one group, col0 = 0, N = 3*H*hd, W = [Wq;Wk;Wv]; cross-attention: a q group
+ * from x_i with col0 = 0, N = H*hd and a k,v group from x_j with col0 = H*hd, N = 2*H*hd).
+ * Row m of A is (trajectory b = m / T, step t = m % T) at absolute position pos0 + t.
+ *   Qout  : act [B, H, T,   hd]   (scaled by q_scale = hd^-1/2 after rotation)
+ *   Kout  : act [B, H, cap, hd]   written at row pos0 + t
+ *   Vtout : act [B, H, hd, cap]   written at column pos0 + t  (V transposed: keys contiguous)
+ * rope: f32 [>= pos0 + T, hd/2, 2] (cos, sin) — the reference's freqs_cis buffer viewed as real.
+ */
+typedef struct {
+    const void* A;
+    const void* W;
+    const float* bias; /* f32 [N] */
+    void* Qout;
+    void* Kout;
+    void* Vtout;
+    int32_t lda, ldw;
+    int32_t M, N, K;
+    int32_t col0;
+} SeaQkvGroup;
+
+typedef struct {
+    const float* rope;
+    int32_t H, hd, T, pos0, cap;
+    float q_scale;
+} SeaQkvCommon;
+
+int sea_qkv_rope_grouped(const SeaQkvGroup* groups, int n_groups, const SeaQkvCommon* common, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Causal flash attention forward, several independent problems (fields / field pairs) per launch.
+ * Replaces models/base_blocks.py:191-198 and :283-290: (q k^T) * hd^-1/2 (scale already folded into Q),
+ * masked_fill(tril(diagonal=src_len) == 0, -inf), softmax, @ v, merge heads — without materialising [T, T].
+ * Query row i (absolute position q_pos0 + i) attends keys j <= q_pos0 + i + src_len, j < Tk.
+ *   O   : act [B, Tq, H*hd] row stride ldo
+ *   LSE : f32 [B, H, Tq] log-sum-exp of the scaled scores (for the backward pass), may be NULL
+ */
+#define SEA_MAX_ATTN_PROBLEMS 8
+typedef struct {
+    const void* Q;
+    const void* K;
+    const void* Vt;
+    void* O;
+    float* LSE;
+} SeaAttnProblem;
+
+typedef struct {
+    SeaAttnProblem p[SEA_MAX_ATTN_PROBLEMS];
+    int32_t n_problems;
+    int32_t B, H, hd, Tq, Tk, cap, q_pos0, src_len, ldo;
+} SeaAttnParams;
+
+int sea_attention_fwd(const SeaAttnParams* params, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Row normalisation with optional adaptive modulation and GELU, several groups per launch:
+ *     xhat = (x - mean) / sqrt(var_biased + eps)
+ *     y    = xhat * (gamma + (mod ? 1 + mod[:, :d] : 0)) + (beta + (mod ? mod[:, d:] : 0));  y = gelu ? gelu_erf(y) : y
+ * Replaces AdaLN.forward's normalisation + modulation (models/base_blocks.py:345-350; `mod` is the cond_mlp
+ * output), the custom LayerNorm (models/base_blocks.py:87-88: beta NULL, mod NULL) and nn.LayerNorm + nn.GELU inside
+ * MLP (models/base_blocks.py:23-24).
+ * x is f32 (x_is_act = 0) or act (x_is_act = 1); y is written as f32 (Y32) and/or act (Yact).
+ * mean/rstd (f32 [M]) are saved for the backward pass when non-NULL.
+ */
+typedef struct {
+    const void* X;
+    const void* mod;    /* act [M, 2d] row stride ldmod, or NULL */
+    const float* gamma; /* f32 [d] */
+    const float* beta;  /* f32 [d] or NULL */
+    float* Y32;
+    void* Yact;
+    float* mean;
+    float* rstd;
+    int32_t ldx, ldmod, ldy32, ldyact;
+} SeaNormGroup;
+
+int sea_rownorm(const SeaNormGroup* groups, int n_groups, int M, int d, int x_is_act, int gelu, float eps,
+                int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Hidden layer of the AdaLN condition MLP for a scalar condition: Hid[m, k] = silu(w1[k] * c[m] + b1[k]).
+ * Replaces cond_mlp.0 (Linear(1, 2d)) + nn.SiLU (models/base_blocks.py:337-338, 344); cond_mlp.2 is a
+ * sea_gemm_grouped group.  c: f32 [M]; w1, b1: f32 [K2]; Hid: act [M, K2] row stride ld.
+ */
+typedef struct {
+    const float* w1;
+    const float* b1;
+    void* Hid;
+    int32_t K2, ld;
+} SeaSiluGroup;
+
+int sea_silu_outer(const SeaSiluGroup* groups, int n_groups, const float* c, int M, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Information-bottleneck add: ib = W2 . gelu(LN_h(w1 * c + b1)) + b2, then X_f += ib for every field f.
+ * Replaces BaseBlockTemporal._add_info with ib_scale_mode='mlp', ib_addition_mode='add'
+ * (models/temporal.py:111-116,140-142) = MLP(1 -> h -> E) of models/base_blocks.py:22-26 with h = scale_ratio.
+ * X: n_fields f32 [M, E] matrices (row stride ldx); all parameters f32; h <= 64.
+ */
+typedef struct {
+    float* X[8];
+    int32_t n_fields, ldx;
+    const float* c;   /* [M] */
+    const float* w1;  /* [h] (Linear(1,h).weight) */
+    const float* b1;  /* [h] */
+    const float* lnw; /* [h] */
+    const float* lnb; /* [h] */
+    const float* w2;  /* [E, h] */
+    const float* b2;  /* [E] */
+    int32_t M, E, h;
+} SeaIbParams;
+
+int sea_ib_add(const SeaIbParams* params, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Strided 2-D conversions between fp32 and the activation dtype (weights shadow copy, model input split).
+ * dst[r, c] = (dst type) src[r, c] for r < rows, c < cols (cols % 4 == 0).
+ */
+int sea_convert_f32_to_act(const float* src, int64_t lds, void* dst, int64_t ldd, int64_t rows, int64_t cols, int dtype,
+                           void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Self-test of the MFMA fragment maps this library relies on (16x16x32 bf16 and 16x16x4 f32, A/B/C lane maps):
+ * multiplies exact small-integer matrices on the device and checks every element on the host.  Synchronous.
+ * Returns 0 when both maps are as documented in cdna_hip_programming.md §3.
+ */
+int sea_selftest_mfma(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SEA_HIP_H */

@@ -1,0 +1,146 @@
+"""ctypes binding of libsea_hip.so (C ABI: include/sea_hip.h).
+
+The library is the product's only compute path: if it is missing or cannot be loaded, every operator raises —
+there is no CPU or eager-PyTorch fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import torch  # imported first so that the HIP runtime torch ships is the one the library binds to
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libsea_hip.so")
+
+SEA_F32, SEA_BF16 = 0, 1
+MAX_GROUPS = 16
+MAX_ATTN_PROBLEMS = 8
+MAX_NORM_GROUPS = 16
+MAX_SILU_GROUPS = 24
+
+_vp, _i32, _i64, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+
+
+class SeaGemmGroup(C.Structure):
+    _fields_ = [("A", _vp), ("W", _vp), ("bias", _vp), ("R", _vp), ("C32", _vp), ("Cact", _vp),
+                ("a_seg_stride", _i64),
+                ("lda", _i32), ("ldw", _i32), ("ldr", _i32), ("ldc32", _i32), ("ldcact", _i32),
+                ("M", _i32), ("N", _i32), ("K", _i32), ("n_seg", _i32),
+                ("act", _i32), ("bias_scale", _f32)]
+
+
+class SeaQkvGroup(C.Structure):
+    _fields_ = [("A", _vp), ("W", _vp), ("bias", _vp), ("Qout", _vp), ("Kout", _vp), ("Vtout", _vp),
+                ("lda", _i32), ("ldw", _i32), ("M", _i32), ("N", _i32), ("K", _i32), ("col0", _i32)]
+
+
+class SeaQkvCommon(C.Structure):
+    _fields_ = [("rope", _vp), ("H", _i32), ("hd", _i32), ("T", _i32), ("pos0", _i32), ("cap", _i32), ("q_scale", _f32)]
+
+
+class SeaAttnProblem(C.Structure):
+    _fields_ = [("Q", _vp), ("K", _vp), ("Vt", _vp), ("O", _vp), ("LSE", _vp)]
+
+
+class SeaAttnParams(C.Structure):
+    _fields_ = [("p", SeaAttnProblem * MAX_ATTN_PROBLEMS), ("n_problems", _i32),
+                ("B", _i32), ("H", _i32), ("hd", _i32), ("Tq", _i32), ("Tk", _i32), ("cap", _i32),
+                ("q_pos0", _i32), ("src_len", _i32), ("ldo", _i32)]
+
+
+class SeaNormGroup(C.Structure):
+    _fields_ = [("X", _vp), ("mod", _vp), ("gamma", _vp), ("beta", _vp), ("Y32", _vp), ("Yact", _vp),
+                ("mean", _vp), ("rstd", _vp),
+                ("ldx", _i32), ("ldmod", _i32), ("ldy32", _i32), ("ldyact", _i32)]
+
+
+class SeaSiluGroup(C.Structure):
+    _fields_ = [("w1", _vp), ("b1", _vp), ("Hid", _vp), ("K2", _i32), ("ld", _i32)]
+
+
+class SeaIbParams(C.Structure):
+    _fields_ = [("X", _vp * 8), ("n_fields", _i32), ("ldx", _i32),
+                ("c", _vp), ("w1", _vp), ("b1", _vp), ("lnw", _vp), ("lnb", _vp), ("w2", _vp), ("b2", _vp),
+                ("M", _i32), ("E", _i32), ("h", _i32)]
+
+
+_lib: Optional[C.CDLL] = None
+
+
+class NativeLibraryError(RuntimeError):
+    pass
+
+
+def lib() -> C.CDLL:
+    """Load (once) and return the shared library; raise loudly if it is not there."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise NativeLibraryError(
+            f"{LIB_PATH} is missing: build it with `python -m sea_amd.build` (hipcc, gfx950). "
+            "sea_amd has no CPU or eager fallback.")
+    try:
+        L = C.CDLL(LIB_PATH)
+    except OSError as e:  # pragma: no cover
+        raise NativeLibraryError(f"cannot load {LIB_PATH}: {e}") from e
+    L.sea_abi_version.restype = C.c_int
+    L.sea_last_error.restype = C.c_char_p
+    L.sea_struct_sizes.argtypes = [C.POINTER(C.c_int), C.c_int]
+    L.sea_struct_sizes.restype = C.c_int
+    L.sea_device_info.argtypes = [C.POINTER(C.c_int), C.c_char_p, C.c_int]
+    L.sea_gemm_grouped.argtypes = [C.POINTER(SeaGemmGroup), C.c_int, C.c_int, _vp]
+    L.sea_qkv_rope_grouped.argtypes = [C.POINTER(SeaQkvGroup), C.c_int, C.POINTER(SeaQkvCommon), C.c_int, _vp]
+    L.sea_attention_fwd.argtypes = [C.POINTER(SeaAttnParams), C.c_int, _vp]
+    L.sea_rownorm.argtypes = [C.POINTER(SeaNormGroup), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, _vp]
+    L.sea_silu_outer.argtypes = [C.POINTER(SeaSiluGroup), C.c_int, _vp, C.c_int, C.c_int, _vp]
+    L.sea_ib_add.argtypes = [C.POINTER(SeaIbParams), _vp]
+    L.sea_convert_f32_to_act.argtypes = [_vp, _i64, _vp, _i64, _i64, _i64, C.c_int, _vp]
+    L.sea_selftest_mfma.restype = C.c_int
+    for name in ("sea_gemm_grouped", "sea_qkv_rope_grouped", "sea_attention_fwd", "sea_rownorm", "sea_silu_outer",
+                 "sea_ib_add", "sea_convert_f32_to_act", "sea_device_info"):
+        getattr(L, name).restype = C.c_int
+    if L.sea_abi_version() != 1:
+        raise NativeLibraryError(f"{LIB_PATH}: ABI version {L.sea_abi_version()} != 1; rebuild")
+    _lib = L
+    return L
+
+
+ABI_STRUCTS = (SeaGemmGroup, SeaQkvGroup, SeaQkvCommon, SeaAttnProblem, SeaAttnParams, SeaNormGroup, SeaSiluGroup,
+               SeaIbParams)
+
+EXPORTED_SYMBOLS = (
+    "sea_abi_version", "sea_last_error", "sea_struct_sizes", "sea_device_info", "sea_gemm_grouped", "sea_qkv_rope_grouped",
+    "sea_attention_fwd", "sea_rownorm", "sea_silu_outer", "sea_ib_add", "sea_convert_f32_to_act", "sea_selftest_mfma",
+)
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = lib().sea_last_error()
+        raise RuntimeError(f"libsea_hip {what} failed (code {rc}): {msg.decode() if msg else '?'}")
+
+
+def dtype_code(dt: torch.dtype) -> int:
+    if dt == torch.float32:
+        return SEA_F32
+    if dt == torch.bfloat16:
+        return SEA_BF16
+    raise ValueError(f"sea_amd: activation dtype must be float32 or bfloat16, got {dt}")
+
+
+def require_gpu(t: torch.Tensor, name: str = "tensor") -> None:
+    if not t.is_cuda:
+        raise RuntimeError(
+            f"sea_amd: {name} is on {t.device}; this path runs only on an MI355X through libsea_hip.so "
+            "(no CPU fallback — the CPU oracle lives under oracle/ for tests only)")
+
+
+def stream_ptr() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()

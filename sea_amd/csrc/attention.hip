@@ -1,0 +1,233 @@
+// Causal flash attention forward for SEA's self- and cross-attention (gfx950): sea_attention_fwd.
+//
+// One workgroup = 4 waves = 64 query rows of one (trajectory, head); wave w owns rows 16w..16w+15.  K/V tiles of 64
+// keys are staged through LDS and shared by the 4 waves.  Everything is computed TRANSPOSED so that a query is a
+// lane (lane & 15) in every accumulator and no row statistic ever crosses lanes except the 4 lane groups of a
+// query (two __shfl_xor):
+//     S^T = K . Q^T      MFMA A = K rows (from LDS), B = Q (registers, loaded once)      C[key][query]
+//     O^T = V^T . P^T    MFMA A = V^T rows (from LDS; V is kept transposed in HBM), B = P^T C[d][query]
+// The S^T accumulator of lane (g = lane >> 4, q = lane & 15) holds, per 16-key MFMA block, rows 4g..4g+3.  MFMA row
+// 4y+i of block beta of a key chunk is assigned key  y*(4*NB) + 4*beta + i  (NB = blocks per chunk), so after the
+// NB blocks of a chunk lane group g holds the EPC = 4*NB CONSECUTIVE keys g*EPC .. g*EPC+EPC-1: exactly the
+// B-operand fragment (k = g*EPC + j) of the O^T product — P goes from accumulator to operand with a pack, no
+// shuffle, no LDS.
+// Head dims 8..128 (multiples of 8); contraction padded with zero lanes when hd < CK (hd = 16 bf16, hd = 8).
+#include "sea_common.hpp"
+
+template <typename T, int HD>
+struct AttnCfg {
+    static constexpr int EPC = ActTraits<T>::EPC;
+    static constexpr int CK = ActTraits<T>::CK;              // keys per key chunk = contraction per mma16
+    static constexpr int NB = CK / 16;                       // 16-key MFMA blocks per key chunk
+    static constexpr int KCH = 64 / CK;                      // key chunks per 64-key tile
+    static constexpr int NCH = (HD + CK - 1) / CK;           // head-dim chunks of the S^T contraction
+    static constexpr int NDB = (HD + 15) / 16;               // 16-row d blocks of O^T
+    static constexpr int K_ROW = HD * (int)sizeof(T);        // bytes per key row
+    static constexpr int K_STRIDE = K_ROW + 16;              // padded LDS stride
+    static constexpr int V_ROW = 64 * (int)sizeof(T);        // bytes per d row of the V^T tile
+    static constexpr int V_STRIDE = V_ROW + 16;
+    static constexpr int K_BYTES = 64 * K_STRIDE;
+    static constexpr int V_BYTES = HD * V_STRIDE;
+    static constexpr int LDS_BYTES = K_BYTES + V_BYTES;
+};
+
+template <typename T, int HD>
+__global__ __launch_bounds__(256) void attention_fwd_kernel(const SeaAttnParams P) {
+    using C = AttnCfg<T, HD>;
+    __shared__ __attribute__((aligned(16))) char smem[C::LDS_BYTES];
+    char* sK = smem;
+    char* sV = smem + C::K_BYTES;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 15, g = lane >> 4;
+    const int n_qt = gridDim.x;
+    const int qt = n_qt - 1 - (int)blockIdx.x;  // heaviest (latest) query tiles first
+    const int bh = blockIdx.y;
+    const int b = bh / P.H, h = bh - b * P.H;
+    const SeaAttnProblem& pr = P.p[blockIdx.z];
+    const T* Qg = static_cast<const T*>(pr.Q) + (int64_t)bh * P.Tq * HD;
+    const T* Kg = static_cast<const T*>(pr.K) + (int64_t)bh * P.cap * HD;
+    const T* Vg = static_cast<const T*>(pr.Vt) + (int64_t)bh * HD * P.cap;
+    const int Tq = P.Tq, Tk = P.Tk, cap = P.cap;
+
+    const int q_row0 = qt * 64 + wave * 16;
+    const int q_idx = q_row0 + r;
+    const int q_ld = q_idx < Tq ? q_idx : Tq - 1;
+
+    // Q fragments (B operand of S^T): lane holds Q[q][c*CK + g*EPC .. +EPC)
+    uint4 qf[C::NCH];
+#pragma unroll
+    for (int c = 0; c < C::NCH; ++c) {
+        const int d0 = c * C::CK + g * C::EPC;
+        qf[c] = d0 < HD ? *reinterpret_cast<const uint4*>(Qg + (int64_t)q_ld * HD + d0) : make_uint4(0, 0, 0, 0);
+    }
+
+    f32x4 oacc[C::NDB];
+#pragma unroll
+    for (int d = 0; d < C::NDB; ++d) oacc[d] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float m_i = -INFINITY, l_i = 0.f;
+
+    const int limit = P.q_pos0 + q_idx + P.src_len;                       // keys j <= limit are visible to this lane's query
+    const int blk_last = P.q_pos0 + qt * 64 + 63 + P.src_len;             // last key any row of the workgroup may see
+    int n_kt = blk_last / 64 + 1;
+    const int n_kt_all = (Tk + 63) / 64;
+    n_kt = n_kt < n_kt_all ? n_kt : n_kt_all;
+    const int wave_last = P.q_pos0 + q_row0 + 15 + P.src_len;             // last key this wave's rows may see
+
+    for (int kt = 0; kt < n_kt; ++kt) {
+        __syncthreads();  // everyone is done reading the previous tile
+        // ---- stage K tile: 64 keys x HD
+        {
+            constexpr int CPR = HD / C::EPC;  // 16-byte chunks per key row
+            for (int idx = tid; idx < 64 * CPR; idx += 256) {
+                const int rr = idx / CPR, cc = idx - rr * CPR;
+                const int key = kt * 64 + rr;
+                uint4 v = make_uint4(0, 0, 0, 0);
+                if (key < Tk) v = *reinterpret_cast<const uint4*>(Kg + (int64_t)key * HD + cc * C::EPC);
+                *reinterpret_cast<uint4*>(sK + rr * C::K_STRIDE + cc * 16) = v;
+            }
+        }
+        // ---- stage V^T tile: HD rows x 64 keys (zero beyond Tk: 0 * garbage must stay 0)
+        {
+            constexpr int CPR = 64 / C::EPC;
+            for (int idx = tid; idx < HD * CPR; idx += 256) {
+                const int d = idx / CPR, cc = idx - d * CPR;
+                const int key0 = kt * 64 + cc * C::EPC;
+                uint4 v = make_uint4(0, 0, 0, 0);
+                if (key0 + C::EPC <= Tk) {
+                    v = *reinterpret_cast<const uint4*>(Vg + (int64_t)d * cap + key0);
+                } else if (key0 < Tk) {
+                    T tmp[C::EPC];
+#pragma unroll
+                    for (int e = 0; e < C::EPC; ++e) tmp[e] = key0 + e < Tk ? Vg[(int64_t)d * cap + key0 + e] : from_f32<T>(0.f);
+                    v = *reinterpret_cast<const uint4*>(tmp);
+                }
+                *reinterpret_cast<uint4*>(sV + d * C::V_STRIDE + cc * 16) = v;
+            }
+        }
+        __syncthreads();
+        if (kt * 64 > wave_last) continue;  // wave-uniform: nothing visible to this wave in this tile
+
+        // ---- S^T = K . Q^T
+        f32x4 s[C::KCH][C::NB];
+#pragma unroll
+        for (int kc = 0; kc < C::KCH; ++kc) {
+#pragma unroll
+            for (int be = 0; be < C::NB; ++be) {
+                s[kc][be] = f32x4{0.f, 0.f, 0.f, 0.f};
+                const int key_local = kc * C::CK + (r >> 2) * (4 * C::NB) + be * 4 + (r & 3);
+#pragma unroll
+                for (int c = 0; c < C::NCH; ++c) {
+                    const int d0 = c * C::CK + g * C::EPC;
+                    uint4 a = make_uint4(0, 0, 0, 0);
+                    if (d0 < HD) a = *reinterpret_cast<const uint4*>(sK + key_local * C::K_STRIDE + d0 * (int)sizeof(T));
+                    mma16<T>(a, qf[c], s[kc][be]);
+                }
+            }
+        }
+        // ---- mask, online softmax (this lane: query q_idx, keys kt*64 + kc*CK + g*EPC + be*4 + reg)
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kc = 0; kc < C::KCH; ++kc)
+#pragma unroll
+            for (int be = 0; be < C::NB; ++be)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int key = kt * 64 + kc * C::CK + g * C::EPC + be * 4 + q;
+                    const bool ok = key <= limit && key < Tk;
+                    const float v = ok ? s[kc][be][q] : -INFINITY;
+                    s[kc][be][q] = v;
+                    mx = fmaxf(mx, v);
+                }
+        mx = fmaxf(mx, __shfl_xor(mx, 16));
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const float m_new = fmaxf(m_i, mx);
+        const float alpha = __expf(m_i - m_new);  // first visible tile: exp(-inf) = 0
+        float psum = 0.f;
+#pragma unroll
+        for (int kc = 0; kc < C::KCH; ++kc)
+#pragma unroll
+            for (int be = 0; be < C::NB; ++be)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float p = __expf(s[kc][be][q] - m_new);
+                    s[kc][be][q] = p;
+                    psum += p;
+                }
+        l_i = l_i * alpha + psum;
+        m_i = m_new;
+#pragma unroll
+        for (int d = 0; d < C::NDB; ++d) oacc[d] *= alpha;
+
+        // ---- O^T += V^T . P^T
+#pragma unroll
+        for (int kc = 0; kc < C::KCH; ++kc) {
+            uint4 pf;
+            if constexpr (sizeof(T) == 2) {
+                bf16x8 pv = {(__bf16)s[kc][0][0], (__bf16)s[kc][0][1], (__bf16)s[kc][0][2], (__bf16)s[kc][0][3],
+                             (__bf16)s[kc][1][0], (__bf16)s[kc][1][1], (__bf16)s[kc][1][2], (__bf16)s[kc][1][3]};
+                pf = __builtin_bit_cast(uint4, pv);
+            } else {
+                pf = __builtin_bit_cast(uint4, s[kc][0]);
+            }
+#pragma unroll
+            for (int d = 0; d < C::NDB; ++d) {
+                const int drow = d * 16 + r;
+                uint4 a = make_uint4(0, 0, 0, 0);
+                if (drow < HD) a = *reinterpret_cast<const uint4*>(sV + drow * C::V_STRIDE + (kc * C::CK + g * C::EPC) * (int)sizeof(T));
+                mma16<T>(a, pf, oacc[d]);
+            }
+        }
+    }
+
+    // ---- finalize: this lane holds O^T[d = 16*db + 4g + reg][query q_idx]
+    float l = l_i + __shfl_xor(l_i, 16);
+    l += __shfl_xor(l, 32);
+    const float inv = 1.0f / l;
+    if (q_idx < Tq) {
+        T* Og = static_cast<T*>(pr.O) + ((int64_t)b * Tq + q_idx) * P.ldo + h * HD;
+#pragma unroll
+        for (int d = 0; d < C::NDB; ++d) {
+            const int d0 = d * 16 + g * 4;
+            if (d0 < HD) store4(Og + d0, oacc[d][0] * inv, oacc[d][1] * inv, oacc[d][2] * inv, oacc[d][3] * inv);
+        }
+        if (pr.LSE != nullptr && g == 0) pr.LSE[(int64_t)bh * Tq + q_idx] = m_i + __logf(l);
+    }
+}
+
+template <typename T>
+static int launch_attention(const SeaAttnParams& P, hipStream_t s) {
+    const dim3 grid((P.Tq + 63) / 64, P.B * P.H, P.n_problems), block(256);
+    switch (P.hd) {
+        case 8: attention_fwd_kernel<T, 8><<<grid, block, 0, s>>>(P); break;
+        case 16: attention_fwd_kernel<T, 16><<<grid, block, 0, s>>>(P); break;
+        case 32: attention_fwd_kernel<T, 32><<<grid, block, 0, s>>>(P); break;
+        case 64: attention_fwd_kernel<T, 64><<<grid, block, 0, s>>>(P); break;
+        case 128: attention_fwd_kernel<T, 128><<<grid, block, 0, s>>>(P); break;
+        default: return -1;
+    }
+    return 0;
+}
+
+extern "C" int sea_attention_fwd(const SeaAttnParams* params, int dtype, void* stream) {
+    SEA_REQUIRE(params != nullptr, "sea_attention_fwd: null params");
+    const SeaAttnParams& P = *params;
+    SEA_REQUIRE(dtype == SEA_F32 || dtype == SEA_BF16, "sea_attention_fwd: bad dtype %d", dtype);
+    SEA_REQUIRE(P.n_problems >= 1 && P.n_problems <= SEA_MAX_ATTN_PROBLEMS, "sea_attention_fwd: n_problems=%d", P.n_problems);
+    SEA_REQUIRE(P.B >= 1 && P.H >= 1 && P.Tq >= 1 && P.Tk >= 1 && P.cap >= P.Tk && P.q_pos0 >= 0 && P.src_len >= 0,
+                "sea_attention_fwd: bad sizes B=%d H=%d Tq=%d Tk=%d cap=%d q_pos0=%d src_len=%d", P.B, P.H, P.Tq, P.Tk, P.cap, P.q_pos0, P.src_len);
+    SEA_REQUIRE(P.hd == 8 || P.hd == 16 || P.hd == 32 || P.hd == 64 || P.hd == 128, "sea_attention_fwd: unsupported head dim %d", P.hd);
+    SEA_REQUIRE(P.cap % 8 == 0, "sea_attention_fwd: cap=%d must be a multiple of 8", P.cap);
+    SEA_REQUIRE(P.ldo >= P.H * P.hd && P.ldo % 4 == 0, "sea_attention_fwd: bad ldo=%d", P.ldo);
+    SEA_REQUIRE((long)P.B * P.H <= 65535, "sea_attention_fwd: B*H too large for grid.y");
+    for (int i = 0; i < P.n_problems; ++i) {
+        SEA_REQUIRE(P.p[i].Q && P.p[i].K && P.p[i].Vt && P.p[i].O, "sea_attention_fwd[%d]: null pointer", i);
+        SEA_REQUIRE(sea_aligned16(P.p[i].Q) && sea_aligned16(P.p[i].K) && sea_aligned16(P.p[i].Vt) && sea_aligned16(P.p[i].O),
+                    "sea_attention_fwd[%d]: pointers must be 16-byte aligned", i);
+    }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int rc = dtype == SEA_BF16 ? launch_attention<__bf16>(P, s) : launch_attention<float>(P, s);
+    SEA_REQUIRE(rc == 0, "sea_attention_fwd: no kernel for hd=%d", P.hd);
+    SEA_CHECK_LAUNCH("sea_attention_fwd");
+    return SEA_OK;
+}

@@ -1,0 +1,102 @@
+// ABI plumbing of libsea_hip.so: version, thread-local error string, device info, MFMA fragment-map self-test.
+#include "sea_common.hpp"
+
+static thread_local char g_err[512] = "";
+
+void sea_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" int sea_abi_version(void) { return SEA_ABI_VERSION; }
+extern "C" const char* sea_last_error(void) { return g_err; }
+
+// sizeof of every ABI struct, in header order, so that a binding can verify its own layout (returns the count).
+extern "C" int sea_struct_sizes(int* out, int cap) {
+    const int sizes[] = {(int)sizeof(SeaGemmGroup), (int)sizeof(SeaQkvGroup), (int)sizeof(SeaQkvCommon), (int)sizeof(SeaAttnProblem),
+                         (int)sizeof(SeaAttnParams), (int)sizeof(SeaNormGroup), (int)sizeof(SeaSiluGroup), (int)sizeof(SeaIbParams)};
+    const int n = (int)(sizeof(sizes) / sizeof(sizes[0]));
+    for (int i = 0; i < n && i < cap; ++i) out[i] = sizes[i];
+    return n;
+}
+
+extern "C" int sea_device_info(int* cu_count, char* arch, int arch_len) {
+    hipDeviceProp_t prop;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) {
+        sea_set_error("sea_device_info: no HIP device");
+        return SEA_ELAUNCH;
+    }
+    if (cu_count) *cu_count = prop.multiProcessorCount;
+    if (arch && arch_len > 0) {
+        strncpy(arch, prop.gcnArchName, arch_len - 1);
+        arch[arch_len - 1] = 0;
+    }
+    return SEA_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ MFMA self-test
+// C[16x16] = A[16xCK] . B[CKx16] with exact small integers through mma16<T>, operands gathered with the lane maps
+// the library assumes (A[row = lane&15][k = (lane>>4)*EPC + j], B[k][col = lane&15], C: col = lane&15,
+// row = 4*(lane>>4) + reg).  A and B are asymmetric so that a transposed map cannot pass.
+template <typename T>
+__global__ void mfma_selftest_kernel(const T* A, const T* Bm, float* Cout) {
+    constexpr int EPC = ActTraits<T>::EPC, CK = ActTraits<T>::CK;
+    const int lane = threadIdx.x, r = lane & 15, g = lane >> 4;
+    T af[EPC], bf[EPC];
+    for (int j = 0; j < EPC; ++j) {
+        af[j] = A[r * CK + g * EPC + j];       // A[row r][k]
+        bf[j] = Bm[(g * EPC + j) * 16 + r];    // B[k][col r]
+    }
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    mma16<T>(*reinterpret_cast<const uint4*>(af), *reinterpret_cast<const uint4*>(bf), acc);
+    for (int q = 0; q < 4; ++q) Cout[(g * 4 + q) * 16 + r] = acc[q];
+}
+
+template <typename T>
+static int run_selftest(const char* name) {
+    constexpr int CK = ActTraits<T>::CK;
+    float hA[16 * CK], hB[CK * 16], hC[256], ref[256];
+    for (int i = 0; i < 16; ++i)
+        for (int k = 0; k < CK; ++k) hA[i * CK + k] = (float)((i * 3 + k * 5) % 7 - 3);
+    for (int k = 0; k < CK; ++k)
+        for (int j = 0; j < 16; ++j) hB[k * 16 + j] = (float)((k * 2 + j * 7 + 1) % 5 - 2);
+    for (int i = 0; i < 16; ++i)
+        for (int j = 0; j < 16; ++j) {
+            float s = 0.f;
+            for (int k = 0; k < CK; ++k) s += hA[i * CK + k] * hB[k * 16 + j];
+            ref[i * 16 + j] = s;
+        }
+    T tA[16 * CK], tB[CK * 16];
+    for (int i = 0; i < 16 * CK; ++i) { tA[i] = (T)hA[i]; tB[i] = (T)hB[i]; }
+    T *dA = nullptr, *dB = nullptr;
+    float* dC = nullptr;
+    if (hipMalloc(&dA, sizeof(tA)) != hipSuccess || hipMalloc(&dB, sizeof(tB)) != hipSuccess || hipMalloc(&dC, sizeof(hC)) != hipSuccess) {
+        sea_set_error("sea_selftest_mfma: hipMalloc failed");
+        return SEA_ELAUNCH;
+    }
+    (void)hipMemcpy(dA, tA, sizeof(tA), hipMemcpyHostToDevice);
+    (void)hipMemcpy(dB, tB, sizeof(tB), hipMemcpyHostToDevice);
+    mfma_selftest_kernel<T><<<1, 64>>>(dA, dB, dC);
+    hipError_t e = hipDeviceSynchronize();
+    (void)hipMemcpy(hC, dC, sizeof(hC), hipMemcpyDeviceToHost);
+    (void)hipFree(dA); (void)hipFree(dB); (void)hipFree(dC);
+    if (e != hipSuccess) {
+        sea_set_error("sea_selftest_mfma(%s): %s", name, hipGetErrorString(e));
+        return SEA_ELAUNCH;
+    }
+    for (int i = 0; i < 256; ++i)
+        if (hC[i] != ref[i]) {
+            sea_set_error("sea_selftest_mfma(%s): C[%d][%d] = %g, expected %g — fragment map differs from the documented one", name, i / 16, i % 16, hC[i], ref[i]);
+            return SEA_EUNSUPPORTED;
+        }
+    return SEA_OK;
+}
+
+extern "C" int sea_selftest_mfma(void) {
+    int rc = run_selftest<__bf16>("bf16 16x16x32");
+    if (rc != SEA_OK) return rc;
+    return run_selftest<float>("f32 16x16x4");
+}

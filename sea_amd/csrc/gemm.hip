@@ -1,0 +1,253 @@
+// Grouped NT GEMM kernels with fused epilogues (gfx950): sea_gemm_grouped, sea_qkv_rope_grouped.
+#include "gemm_core.hpp"
+
+struct GemmLaunch {
+    SeaGemmGroup g[SEA_MAX_GROUPS];
+    int tile_start[SEA_MAX_GROUPS + 1];
+    int n_groups;
+};
+
+struct QkvLaunch {
+    SeaQkvGroup g[SEA_MAX_GROUPS];
+    int tile_start[SEA_MAX_GROUPS + 1];
+    int n_groups;
+    SeaQkvCommon c;
+};
+
+template <typename L>
+__device__ __forceinline__ int find_group(const L& launch, int bid) {
+    int gi = 0;
+    while (gi + 1 < launch.n_groups && bid >= launch.tile_start[gi + 1]) ++gi;
+    return gi;
+}
+
+// ---------------------------------------------------------------------------------------------- standard epilogue
+template <typename T, int BM, int BN>
+__global__ __launch_bounds__(256) void gemm_grouped_kernel(const GemmLaunch L) {
+    using C = GemmCfg<T, BM, BN>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int gi = find_group(L, blockIdx.x);
+    const SeaGemmGroup& G = L.g[gi];
+    const int t = blockIdx.x - L.tile_start[gi];
+    const int tiles_n = (G.N + BN - 1) / BN;
+    const int tm = t / tiles_n, tn = t - tm * tiles_n;
+
+    GemmMainloop<T, BM, BN> ml;
+    ml.A = static_cast<const T*>(G.A);
+    ml.W = static_cast<const T*>(G.W);
+    ml.a_seg_stride = G.a_seg_stride;
+    ml.lda = G.lda; ml.ldw = G.ldw; ml.M = G.M; ml.N = G.N; ml.K = G.K; ml.n_seg = G.n_seg;
+    ml.m0 = tm * BM; ml.n0 = tn * BN;
+    f32x4 acc[C::MI][C::NI];
+    ml.run(smem, acc);
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave >> 1, wn = wave & 1, r = lane & 15, g = lane >> 4;
+    const float* bias = G.bias;
+    const float* R = G.R;
+    float* C32 = G.C32;
+    T* Cact = static_cast<T*>(G.Cact);
+    const bool do_gelu = G.act == 1;
+#pragma unroll
+    for (int j = 0; j < C::NI; ++j) {
+        const int n = ml.n0 + wn * C::WTN + j * 16 + r;
+        const bool nok = n < G.N;
+        const float bv = (bias != nullptr && nok) ? bias[n] * G.bias_scale : 0.f;
+#pragma unroll
+        for (int i = 0; i < C::MI; ++i) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int m = ml.m0 + wm * C::WTM + i * 16 + g * 4 + q;
+                if (nok && m < G.M) {
+                    float v = acc[i][j][q] + bv;
+                    if (do_gelu) v = gelu_erf(v);
+                    if (R != nullptr) v += R[(int64_t)m * G.ldr + n];
+                    if (C32 != nullptr) C32[(int64_t)m * G.ldc32 + n] = v;
+                    if (Cact != nullptr) Cact[(int64_t)m * G.ldcact + n] = from_f32<T>(v);
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- QKV + RoPE epilogue
+template <typename T, int BM, int BN>
+__global__ __launch_bounds__(256) void qkv_rope_kernel(const QkvLaunch L) {
+    using C = GemmCfg<T, BM, BN>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int gi = find_group(L, blockIdx.x);
+    const SeaQkvGroup& G = L.g[gi];
+    const int t = blockIdx.x - L.tile_start[gi];
+    const int tiles_n = (G.N + BN - 1) / BN;
+    const int tm = t / tiles_n, tn = t - tm * tiles_n;
+
+    GemmMainloop<T, BM, BN> ml;
+    ml.A = static_cast<const T*>(G.A);
+    ml.W = static_cast<const T*>(G.W);
+    ml.a_seg_stride = 0;
+    ml.lda = G.lda; ml.ldw = G.ldw; ml.M = G.M; ml.N = G.N; ml.K = G.K; ml.n_seg = 1;
+    ml.m0 = tm * BM; ml.n0 = tn * BN;
+    f32x4 acc[C::MI][C::NI];
+    ml.run(smem, acc);
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave >> 1, wn = wave & 1, r = lane & 15, g = lane >> 4;
+    const int H = L.c.H, hd = L.c.hd, Tlen = L.c.T, cap = L.c.cap;
+    const int Ea = H * hd, hd2 = hd >> 1;
+    const float2* rope = reinterpret_cast<const float2*>(L.c.rope);
+    T* Qo = static_cast<T*>(G.Qout);
+    T* Ko = static_cast<T*>(G.Kout);
+    T* Vo = static_cast<T*>(G.Vtout);
+#pragma unroll
+    for (int j = 0; j < C::NI; ++j) {
+        const int n = ml.n0 + wn * C::WTN + j * 16 + r;
+        const bool nok = n < G.N;
+        const int nc = nok ? n : G.N - 1;
+        const float bv = G.bias != nullptr ? G.bias[nc] : 0.f;
+        const int nn = G.col0 + nc;      // column in the virtual [q | k | v] row
+        const int part = nn / Ea;        // 0 q, 1 k, 2 v
+        const int hcol = nn - part * Ea;
+        const int h = hcol / hd;
+        const int dd = hcol - h * hd;
+        const bool odd = (dd & 1) != 0;
+#pragma unroll
+        for (int i = 0; i < C::MI; ++i) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int m = ml.m0 + wm * C::WTM + i * 16 + g * 4 + q;
+                const int mc = m < G.M ? m : G.M - 1;
+                const int b = mc / Tlen;
+                const int tt = mc - b * Tlen;
+                const int pos = L.c.pos0 + tt;
+                float v = acc[i][j][q] + bv;
+                // the (even, odd) pair of a rotation sits in adjacent lanes (columns n, n^1): every lane takes part
+                const float partner = __shfl_xor(v, 1);
+                if (part < 2) {
+                    const float2 cs = rope[(int64_t)pos * hd2 + (dd >> 1)];
+                    // (xe + i xo)(c + i s): even' = xe c - xo s ; odd' = xe s + xo c
+                    v = odd ? (partner * cs.y + v * cs.x) : (v * cs.x - partner * cs.y);
+                    if (part == 0) v *= L.c.q_scale;
+                }
+                if (nok && m < G.M) {
+                    const int64_t bh = (int64_t)b * H + h;
+                    if (part == 0) {
+                        Qo[(bh * Tlen + tt) * hd + dd] = from_f32<T>(v);
+                    } else if (part == 1) {
+                        Ko[(bh * cap + pos) * hd + dd] = from_f32<T>(v);
+                    } else {
+                        Vo[(bh * hd + dd) * cap + pos] = from_f32<T>(v);
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- host side
+template <typename K>
+static int set_lds(K kernel, int bytes) {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess
+               ? 0 : -1;
+}
+
+static int pick_tile(long tiles128, long tiles64) {
+    // 128x128 tiles once they fill most of the 256 CUs, else 64x64 (more, smaller workgroups)
+    (void)tiles64;
+    return tiles128 >= 192 ? 128 : 64;
+}
+
+extern "C" int sea_gemm_grouped(const SeaGemmGroup* groups, int n_groups, int dtype, void* stream) {
+    SEA_REQUIRE(groups != nullptr && n_groups >= 1 && n_groups <= SEA_MAX_GROUPS, "sea_gemm_grouped: n_groups=%d out of range", n_groups);
+    SEA_REQUIRE(dtype == SEA_F32 || dtype == SEA_BF16, "sea_gemm_grouped: bad dtype %d", dtype);
+    const int epc = dtype == SEA_BF16 ? 8 : 4;
+    long t128 = 0, t64 = 0;
+    for (int i = 0; i < n_groups; ++i) {
+        const SeaGemmGroup& G = groups[i];
+        SEA_REQUIRE(G.A && G.W, "sea_gemm_grouped[%d]: null operand", i);
+        SEA_REQUIRE(G.M >= 1 && G.N >= 1 && G.K >= 8 && G.n_seg >= 1, "sea_gemm_grouped[%d]: bad shape M=%d N=%d K=%d n_seg=%d", i, G.M, G.N, G.K, G.n_seg);
+        SEA_REQUIRE(G.K % 8 == 0 && G.lda % epc == 0 && G.ldw % epc == 0 && G.a_seg_stride % epc == 0,
+                    "sea_gemm_grouped[%d]: K=%d lda=%d ldw=%d must be multiples of 8/%d", i, G.K, G.lda, G.ldw, epc);
+        SEA_REQUIRE(sea_aligned16(G.A) && sea_aligned16(G.W), "sea_gemm_grouped[%d]: A/W not 16-byte aligned", i);
+        SEA_REQUIRE(G.lda >= G.K && G.ldw >= G.K, "sea_gemm_grouped[%d]: leading dimension smaller than K", i);
+        SEA_REQUIRE(G.C32 || G.Cact, "sea_gemm_grouped[%d]: no output", i);
+        SEA_REQUIRE((!G.R || G.ldr >= G.N) && (!G.C32 || G.ldc32 >= G.N) && (!G.Cact || G.ldcact >= G.N), "sea_gemm_grouped[%d]: output stride < N", i);
+        t128 += (long)((G.M + 127) / 128) * ((G.N + 127) / 128);
+        t64 += (long)((G.M + 63) / 64) * ((G.N + 63) / 64);
+    }
+    const int tile = pick_tile(t128, t64);
+    GemmLaunch L;
+    memset(&L, 0, sizeof(L));
+    L.n_groups = n_groups;
+    int total = 0;
+    for (int i = 0; i < n_groups; ++i) {
+        L.g[i] = groups[i];
+        L.tile_start[i] = total;
+        total += ((groups[i].M + tile - 1) / tile) * ((groups[i].N + tile - 1) / tile);
+    }
+    L.tile_start[n_groups] = total;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+#define LAUNCH_GEMM(TT, BMN)                                                                          \
+    do {                                                                                              \
+        static int once = set_lds(gemm_grouped_kernel<TT, BMN, BMN>, GemmCfg<TT, BMN, BMN>::LDS_BYTES); \
+        (void)once;                                                                                   \
+        gemm_grouped_kernel<TT, BMN, BMN><<<dim3(total), dim3(256), GemmCfg<TT, BMN, BMN>::LDS_BYTES, s>>>(L); \
+    } while (0)
+    if (dtype == SEA_BF16) {
+        if (tile == 128) LAUNCH_GEMM(__bf16, 128); else LAUNCH_GEMM(__bf16, 64);
+    } else {
+        if (tile == 128) LAUNCH_GEMM(float, 128); else LAUNCH_GEMM(float, 64);
+    }
+#undef LAUNCH_GEMM
+    SEA_CHECK_LAUNCH("sea_gemm_grouped");
+    return SEA_OK;
+}
+
+extern "C" int sea_qkv_rope_grouped(const SeaQkvGroup* groups, int n_groups, const SeaQkvCommon* common, int dtype, void* stream) {
+    SEA_REQUIRE(groups != nullptr && common != nullptr && n_groups >= 1 && n_groups <= SEA_MAX_GROUPS, "sea_qkv_rope_grouped: bad arguments");
+    SEA_REQUIRE(dtype == SEA_F32 || dtype == SEA_BF16, "sea_qkv_rope_grouped: bad dtype %d", dtype);
+    const SeaQkvCommon& c = *common;
+    SEA_REQUIRE(c.rope != nullptr && c.H >= 1 && c.hd >= 2 && c.hd % 2 == 0 && c.T >= 1 && c.pos0 >= 0 && c.cap >= c.pos0 + c.T,
+                "sea_qkv_rope_grouped: bad common H=%d hd=%d T=%d pos0=%d cap=%d", c.H, c.hd, c.T, c.pos0, c.cap);
+    const int epc = dtype == SEA_BF16 ? 8 : 4;
+    const int Ea = c.H * c.hd;
+    long t128 = 0, t64 = 0;
+    for (int i = 0; i < n_groups; ++i) {
+        const SeaQkvGroup& G = groups[i];
+        SEA_REQUIRE(G.A && G.W, "sea_qkv_rope_grouped[%d]: null operand", i);
+        SEA_REQUIRE(G.M >= 1 && G.M % c.T == 0 && G.N >= 2 && G.N % 2 == 0 && G.K >= 8 && G.K % 8 == 0, "sea_qkv_rope_grouped[%d]: bad shape M=%d N=%d K=%d T=%d", i, G.M, G.N, G.K, c.T);
+        SEA_REQUIRE(G.lda % epc == 0 && G.ldw % epc == 0 && G.lda >= G.K && G.ldw >= G.K, "sea_qkv_rope_grouped[%d]: bad strides", i);
+        SEA_REQUIRE(sea_aligned16(G.A) && sea_aligned16(G.W), "sea_qkv_rope_grouped[%d]: A/W not 16-byte aligned", i);
+        SEA_REQUIRE(G.col0 >= 0 && G.col0 % 2 == 0 && G.col0 + G.N <= 3 * Ea, "sea_qkv_rope_grouped[%d]: columns [%d,%d) outside [0,%d)", i, G.col0, G.col0 + G.N, 3 * Ea);
+        const bool hasq = G.col0 < Ea, hask = G.col0 < 2 * Ea && G.col0 + G.N > Ea, hasv = G.col0 + G.N > 2 * Ea;
+        SEA_REQUIRE((!hasq || G.Qout) && (!hask || G.Kout) && (!hasv || G.Vtout), "sea_qkv_rope_grouped[%d]: missing output pointer", i);
+        t128 += (long)((G.M + 127) / 128) * ((G.N + 127) / 128);
+        t64 += (long)((G.M + 63) / 64) * ((G.N + 63) / 64);
+    }
+    const int tile = pick_tile(t128, t64);
+    QkvLaunch L;
+    memset(&L, 0, sizeof(L));
+    L.n_groups = n_groups;
+    L.c = c;
+    int total = 0;
+    for (int i = 0; i < n_groups; ++i) {
+        L.g[i] = groups[i];
+        L.tile_start[i] = total;
+        total += ((groups[i].M + tile - 1) / tile) * ((groups[i].N + tile - 1) / tile);
+    }
+    L.tile_start[n_groups] = total;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+#define LAUNCH_QKV(TT, BMN)                                                                        \
+    do {                                                                                           \
+        static int once = set_lds(qkv_rope_kernel<TT, BMN, BMN>, GemmCfg<TT, BMN, BMN>::LDS_BYTES);  \
+        (void)once;                                                                                \
+        qkv_rope_kernel<TT, BMN, BMN><<<dim3(total), dim3(256), GemmCfg<TT, BMN, BMN>::LDS_BYTES, s>>>(L); \
+    } while (0)
+    if (dtype == SEA_BF16) {
+        if (tile == 128) LAUNCH_QKV(__bf16, 128); else LAUNCH_QKV(__bf16, 64);
+    } else {
+        if (tile == 128) LAUNCH_QKV(float, 128); else LAUNCH_QKV(float, 64);
+    }
+#undef LAUNCH_QKV
+    SEA_CHECK_LAUNCH("sea_qkv_rope_grouped");
+    return SEA_OK;
+}

@@ -1,0 +1,127 @@
+// LDS-tiled MFMA main loop shared by the grouped GEMM kernels (gfx950).
+//
+// C[BM x BN] tile of  sum_s A_s[M,K] . W[N,K]^T  — both operands are K-contiguous ("NT" GEMM, the nn.Linear
+// layout), so A and B fragments are both 16-byte loads along K.
+//
+// Block = 256 threads = 4 waves in a 2 x 2 grid; each wave owns (BM/2) x (BN/2) as MI x NI tiles of 16 x 16.
+// LDS: per K-tile every row holds 128 bytes of K (64 bf16 / 32 f32) as eight 16-byte chunks; chunk c of row r is
+// stored at chunk position c ^ (r & 7): the ds_read_b128 of a fragment (16 rows x the same chunk) then covers all
+// 16 bank slots of the 256-byte bank row (conflict-free; MI355X_MICROARCH.md §LDS, cdna_hip_programming.md T2)
+// and the ds_write_b128 of the staging pass (8 lanes per row) stays a permutation of one row's 32 banks.
+// Staging is through registers (global_load_dwordx4 -> ds_write_b128) with the split of T14: the loads of tile
+// k+1 are issued before the MFMAs of tile k and written to the other LDS buffer after them; one barrier per
+// K-tile.
+#pragma once
+#include "sea_common.hpp"
+
+template <typename T, int BM_, int BN_>
+struct GemmCfg {
+    static constexpr int BM = BM_, BN = BN_;
+    static constexpr int BKB = 128;                         // bytes of K per row per K-tile
+    static constexpr int EPC = ActTraits<T>::EPC;           // elements per 16-byte chunk
+    static constexpr int BK = BKB / (int)sizeof(T);         // K elements per K-tile
+    static constexpr int WTM = BM / 2, WTN = BN / 2;        // wave tile
+    static constexpr int MI = WTM / 16, NI = WTN / 16;      // 16x16 tiles per wave
+    static constexpr int A_CH = BM * 8 / 256;               // 16-byte chunks staged per thread (A)
+    static constexpr int B_CH = BN * 8 / 256;               // (W)
+    static constexpr int BUF_BYTES = (BM + BN) * BKB;
+    static constexpr int LDS_BYTES = 2 * BUF_BYTES;
+};
+
+template <typename T, int BM, int BN>
+struct GemmMainloop {
+    using C = GemmCfg<T, BM, BN>;
+
+    const T* A;
+    const T* W;
+    int64_t a_seg_stride;
+    int lda, ldw, M, N, K, n_seg, m0, n0;
+
+    uint4 ra[C::A_CH], rb[C::B_CH];
+
+    __device__ __forceinline__ void load_tile(int kt, int tid) {
+        const int c = tid & 7;
+        const int rr = tid >> 3;
+        const int kk = kt * C::BK + c * C::EPC;
+        const int k_total = K * n_seg;
+        const bool kvalid = kk < k_total;
+        int seg = 0, kin = kk;
+        if (n_seg > 1) {
+            seg = kk / K;
+            kin = kk - seg * K;
+        }
+        const T* a_base = A + seg * a_seg_stride + kin;
+        const T* w_base = W + kin;
+#pragma unroll
+        for (int i = 0; i < C::A_CH; ++i) {
+            int row = m0 + rr + 32 * i;
+            row = row < M ? row : M - 1;
+            ra[i] = kvalid ? *reinterpret_cast<const uint4*>(a_base + (int64_t)row * lda) : make_uint4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < C::B_CH; ++i) {
+            int row = n0 + rr + 32 * i;
+            row = row < N ? row : N - 1;
+            rb[i] = kvalid ? *reinterpret_cast<const uint4*>(w_base + (int64_t)row * ldw) : make_uint4(0, 0, 0, 0);
+        }
+    }
+
+    __device__ __forceinline__ void store_tile(char* buf, int tid) {
+        const int c = tid & 7;
+        const int rr = tid >> 3;
+        char* sA = buf;
+        char* sB = buf + BM * C::BKB;
+#pragma unroll
+        for (int i = 0; i < C::A_CH; ++i) {
+            const int row = rr + 32 * i;
+            *reinterpret_cast<uint4*>(sA + row * C::BKB + ((c ^ (row & 7)) << 4)) = ra[i];
+        }
+#pragma unroll
+        for (int i = 0; i < C::B_CH; ++i) {
+            const int row = rr + 32 * i;
+            *reinterpret_cast<uint4*>(sB + row * C::BKB + ((c ^ (row & 7)) << 4)) = rb[i];
+        }
+    }
+
+    __device__ __forceinline__ void compute_tile(const char* buf, int wm, int wn, int lane, f32x4 (&acc)[C::MI][C::NI]) {
+        const int r = lane & 15, g = lane >> 4;
+        const char* sA = buf + (wm * C::WTM + r) * C::BKB;
+        const char* sB = buf + BM * C::BKB + (wn * C::WTN + r) * C::BKB;
+#pragma unroll
+        for (int kc = 0; kc < 2; ++kc) {
+            const int off = ((kc * 4 + g) ^ (r & 7)) << 4;  // (row & 7) == (r & 7): tile rows start at multiples of 16
+            uint4 af[C::MI], bf[C::NI];
+#pragma unroll
+            for (int i = 0; i < C::MI; ++i) af[i] = *reinterpret_cast<const uint4*>(sA + i * 16 * C::BKB + off);
+#pragma unroll
+            for (int j = 0; j < C::NI; ++j) bf[j] = *reinterpret_cast<const uint4*>(sB + j * 16 * C::BKB + off);
+#pragma unroll
+            for (int i = 0; i < C::MI; ++i)
+#pragma unroll
+                for (int j = 0; j < C::NI; ++j) mma16<T>(af[i], bf[j], acc[i][j]);
+        }
+    }
+
+    __device__ __forceinline__ void run(char* smem, f32x4 (&acc)[C::MI][C::NI]) {
+        const int tid = threadIdx.x;
+        const int lane = tid & 63, wave = tid >> 6;
+        const int wm = wave >> 1, wn = wave & 1;
+#pragma unroll
+        for (int i = 0; i < C::MI; ++i)
+#pragma unroll
+            for (int j = 0; j < C::NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int nk = (K * n_seg + C::BK - 1) / C::BK;
+        load_tile(0, tid);
+        store_tile(smem, tid);
+        __syncthreads();
+        for (int kt = 0; kt < nk; ++kt) {
+            char* cur = smem + (kt & 1) * C::BUF_BYTES;
+            char* nxt = smem + ((kt + 1) & 1) * C::BUF_BYTES;
+            const bool more = kt + 1 < nk;
+            if (more) load_tile(kt + 1, tid);
+            compute_tile(cur, wm, wn, lane, acc);
+            if (more) store_tile(nxt, tid);
+            __syncthreads();
+        }
+    }
+};

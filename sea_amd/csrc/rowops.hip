@@ -1,0 +1,227 @@
+// Row-wise kernels of the SEA temporal path (gfx950): sea_rownorm, sea_silu_outer, sea_ib_add, sea_convert_f32_to_act.
+// All of them are HBM/L2-bandwidth-bound element/row passes: 16-byte vector accesses, one wave per row, statistics in
+// fp32 with the two-pass (mean, then centred variance) form the reference uses.
+#include "sea_common.hpp"
+
+#define SEA_MAX_NORM_GROUPS 16
+
+struct NormLaunch {
+    SeaNormGroup g[SEA_MAX_NORM_GROUPS];
+    int M, d, gelu;
+    float eps;
+};
+
+// One wave per row, 4 rows per workgroup, grid = (ceil(M/4), n_groups).
+template <typename T, bool X_IS_ACT>
+__global__ __launch_bounds__(256) void rownorm_kernel(const NormLaunch L) {
+    const SeaNormGroup& G = L.g[blockIdx.y];
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= L.M) return;
+    const int d = L.d;
+    using XT = typename std::conditional<X_IS_ACT, T, float>::type;
+    const XT* x = static_cast<const XT*>(G.X) + (int64_t)row * G.ldx;
+
+    float sum = 0.f;
+    for (int i = lane * 4; i < d; i += 256) {
+        float v[4];
+        load4(x + i, v);
+        sum += (v[0] + v[1]) + (v[2] + v[3]);
+    }
+    const float mean = wave_sum(sum) / (float)d;
+    float sq = 0.f;
+    for (int i = lane * 4; i < d; i += 256) {
+        float v[4];
+        load4(x + i, v);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float c = v[e] - mean;
+            sq += c * c;
+        }
+    }
+    const float var = wave_sum(sq) / (float)d;
+    const float rstd = 1.0f / sqrtf(var + L.eps);
+    if (lane == 0) {
+        if (G.mean != nullptr) G.mean[row] = mean;
+        if (G.rstd != nullptr) G.rstd[row] = rstd;
+    }
+    const T* mod = G.mod != nullptr ? static_cast<const T*>(G.mod) + (int64_t)row * G.ldmod : nullptr;
+    float* y32 = G.Y32 != nullptr ? G.Y32 + (int64_t)row * G.ldy32 : nullptr;
+    T* yact = G.Yact != nullptr ? static_cast<T*>(G.Yact) + (int64_t)row * G.ldyact : nullptr;
+    for (int i = lane * 4; i < d; i += 256) {
+        float v[4], gm[4], bt[4] = {0.f, 0.f, 0.f, 0.f};
+        load4(x + i, v);
+        load4(G.gamma + i, gm);
+        if (G.beta != nullptr) load4(G.beta + i, bt);
+        if (mod != nullptr) {
+            float mw[4], mb[4];
+            load4(mod + i, mw);
+            load4(mod + d + i, mb);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                gm[e] += 1.0f + mw[e];
+                bt[e] += mb[e];
+            }
+        }
+        float o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            o[e] = (v[e] - mean) * rstd * gm[e] + bt[e];
+            if (L.gelu) o[e] = gelu_erf(o[e]);
+        }
+        if (y32 != nullptr) store4(y32 + i, o[0], o[1], o[2], o[3]);
+        if (yact != nullptr) store4(yact + i, o[0], o[1], o[2], o[3]);
+    }
+}
+
+extern "C" int sea_rownorm(const SeaNormGroup* groups, int n_groups, int M, int d, int x_is_act, int gelu, float eps,
+                           int dtype, void* stream) {
+    SEA_REQUIRE(groups != nullptr && n_groups >= 1 && n_groups <= SEA_MAX_NORM_GROUPS, "sea_rownorm: n_groups=%d", n_groups);
+    SEA_REQUIRE(dtype == SEA_F32 || dtype == SEA_BF16, "sea_rownorm: bad dtype %d", dtype);
+    SEA_REQUIRE(M >= 1 && d >= 4 && d % 4 == 0, "sea_rownorm: bad M=%d d=%d (d must be a multiple of 4)", M, d);
+    NormLaunch L;
+    memset(&L, 0, sizeof(L));
+    for (int i = 0; i < n_groups; ++i) {
+        const SeaNormGroup& G = groups[i];
+        SEA_REQUIRE(G.X && G.gamma && (G.Y32 || G.Yact), "sea_rownorm[%d]: null pointer", i);
+        SEA_REQUIRE(G.ldx % 4 == 0 && G.ldx >= d, "sea_rownorm[%d]: bad ldx=%d", i, G.ldx);
+        SEA_REQUIRE(!G.mod || (G.ldmod % 4 == 0 && G.ldmod >= 2 * d), "sea_rownorm[%d]: bad ldmod=%d", i, G.ldmod);
+        SEA_REQUIRE(!G.Y32 || (G.ldy32 % 4 == 0 && G.ldy32 >= d), "sea_rownorm[%d]: bad ldy32=%d", i, G.ldy32);
+        SEA_REQUIRE(!G.Yact || (G.ldyact % 4 == 0 && G.ldyact >= d), "sea_rownorm[%d]: bad ldyact=%d", i, G.ldyact);
+        SEA_REQUIRE(sea_aligned16(G.X) && sea_aligned16(G.gamma) && sea_aligned16(G.beta) && sea_aligned16(G.mod) &&
+                        sea_aligned16(G.Y32) && sea_aligned16(G.Yact), "sea_rownorm[%d]: pointers must be 16-byte aligned", i);
+        L.g[i] = G;
+    }
+    L.M = M; L.d = d; L.gelu = gelu; L.eps = eps;
+    const dim3 grid((M + 3) / 4, n_groups), block(256);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (dtype == SEA_BF16) {
+        if (x_is_act) rownorm_kernel<__bf16, true><<<grid, block, 0, s>>>(L);
+        else rownorm_kernel<__bf16, false><<<grid, block, 0, s>>>(L);
+    } else {
+        // f32 activations: x is float either way
+        rownorm_kernel<float, false><<<grid, block, 0, s>>>(L);
+    }
+    SEA_CHECK_LAUNCH("sea_rownorm");
+    return SEA_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ silu outer product
+#define SEA_MAX_SILU_GROUPS 24
+struct SiluLaunch {
+    SeaSiluGroup g[SEA_MAX_SILU_GROUPS];
+    const float* c;
+    int M;
+};
+
+// grid = (ceil(M/4), n_groups): one wave per row, lanes stride over the K2 columns 4 at a time.
+template <typename T>
+__global__ __launch_bounds__(256) void silu_outer_kernel(const SiluLaunch L) {
+    const SeaSiluGroup& G = L.g[blockIdx.y];
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= L.M) return;
+    const float cv = L.c[row];
+    T* out = static_cast<T*>(G.Hid) + (int64_t)row * G.ld;
+    for (int i = lane * 4; i < G.K2; i += 256) {
+        float w[4], bb[4];
+        load4(G.w1 + i, w);
+        load4(G.b1 + i, bb);
+        store4(out + i, silu_f(w[0] * cv + bb[0]), silu_f(w[1] * cv + bb[1]), silu_f(w[2] * cv + bb[2]), silu_f(w[3] * cv + bb[3]));
+    }
+}
+
+extern "C" int sea_silu_outer(const SeaSiluGroup* groups, int n_groups, const float* c, int M, int dtype, void* stream) {
+    SEA_REQUIRE(groups != nullptr && c != nullptr && n_groups >= 1 && n_groups <= SEA_MAX_SILU_GROUPS && M >= 1, "sea_silu_outer: bad arguments (n_groups=%d, M=%d)", n_groups, M);
+    SEA_REQUIRE(dtype == SEA_F32 || dtype == SEA_BF16, "sea_silu_outer: bad dtype %d", dtype);
+    SiluLaunch L;
+    memset(&L, 0, sizeof(L));
+    for (int i = 0; i < n_groups; ++i) {
+        const SeaSiluGroup& G = groups[i];
+        SEA_REQUIRE(G.w1 && G.b1 && G.Hid && G.K2 >= 4 && G.K2 % 4 == 0 && G.ld >= G.K2 && G.ld % 4 == 0, "sea_silu_outer[%d]: bad group", i);
+        SEA_REQUIRE(sea_aligned16(G.w1) && sea_aligned16(G.b1) && sea_aligned16(G.Hid), "sea_silu_outer[%d]: pointers must be 16-byte aligned", i);
+        L.g[i] = G;
+    }
+    L.c = c; L.M = M;
+    const dim3 grid((M + 3) / 4, n_groups), block(256);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (dtype == SEA_BF16) silu_outer_kernel<__bf16><<<grid, block, 0, s>>>(L);
+    else silu_outer_kernel<float><<<grid, block, 0, s>>>(L);
+    SEA_CHECK_LAUNCH("sea_silu_outer");
+    return SEA_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ information bottleneck add
+// One wave per row.  Lanes 0..h-1 compute the hidden vector gelu(LN_h(w1 c + b1)) (h <= 64), the wave shares it by
+// __shfl, then every lane produces 4 consecutive output columns at a time and adds them to all fields.
+__global__ __launch_bounds__(256) void ib_add_kernel(const SeaIbParams P) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= P.M) return;
+    const int h = P.h;
+    const float cv = P.c[row];
+    const bool act = lane < h;
+    const float pre = act ? P.w1[lane] * cv + P.b1[lane] : 0.f;
+    const float mean = wave_sum(pre) / (float)h;
+    const float cen = act ? pre - mean : 0.f;
+    const float var = wave_sum(cen * cen) / (float)h;
+    const float rstd = 1.0f / sqrtf(var + 1e-5f);
+    const float hid = act ? gelu_erf(cen * rstd * P.lnw[lane] + P.lnb[lane]) : 0.f;
+    for (int e0 = lane * 4; e0 < P.E; e0 += 256) {
+        float o[4];
+        load4(P.b2 + e0, o);
+        for (int k = 0; k < h; ++k) {
+            const float hk = __shfl(hid, k);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] += P.w2[(int64_t)(e0 + e) * h + k] * hk;
+        }
+        for (int f = 0; f < P.n_fields; ++f) {
+            float* x = P.X[f] + (int64_t)row * P.ldx + e0;
+            float v[4];
+            load4(x, v);
+            store4(x, v[0] + o[0], v[1] + o[1], v[2] + o[2], v[3] + o[3]);
+        }
+    }
+}
+
+extern "C" int sea_ib_add(const SeaIbParams* params, void* stream) {
+    SEA_REQUIRE(params != nullptr, "sea_ib_add: null params");
+    const SeaIbParams& P = *params;
+    SEA_REQUIRE(P.n_fields >= 1 && P.n_fields <= 8 && P.M >= 1 && P.E >= 4 && P.E % 4 == 0 && P.h >= 1 && P.h <= 64 && P.ldx >= P.E && P.ldx % 4 == 0,
+                "sea_ib_add: bad sizes n_fields=%d M=%d E=%d h=%d ldx=%d", P.n_fields, P.M, P.E, P.h, P.ldx);
+    SEA_REQUIRE(P.c && P.w1 && P.b1 && P.lnw && P.lnb && P.w2 && P.b2, "sea_ib_add: null parameter pointer");
+    SEA_REQUIRE(sea_aligned16(P.b2), "sea_ib_add: b2 must be 16-byte aligned");
+    for (int f = 0; f < P.n_fields; ++f) SEA_REQUIRE(P.X[f] && sea_aligned16(P.X[f]), "sea_ib_add: X[%d] null or misaligned", f);
+    ib_add_kernel<<<dim3((P.M + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream)>>>(P);
+    SEA_CHECK_LAUNCH("sea_ib_add");
+    return SEA_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ conversion
+template <typename T>
+__global__ __launch_bounds__(256) void convert_kernel(const float* __restrict__ src, int64_t lds, T* __restrict__ dst, int64_t ldd,
+                                                      int64_t rows, int64_t cols4) {
+    const int64_t total = rows * cols4;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / cols4, c = (i - r * cols4) * 4;
+        float v[4];
+        load4(src + r * lds + c, v);
+        store4(dst + r * ldd + c, v[0], v[1], v[2], v[3]);
+    }
+}
+
+extern "C" int sea_convert_f32_to_act(const float* src, int64_t lds, void* dst, int64_t ldd, int64_t rows, int64_t cols, int dtype,
+                                      void* stream) {
+    SEA_REQUIRE(src && dst && rows >= 1 && cols >= 4 && cols % 4 == 0 && lds >= cols && ldd >= cols && lds % 4 == 0 && ldd % 4 == 0,
+                "sea_convert_f32_to_act: bad arguments rows=%lld cols=%lld lds=%lld ldd=%lld", (long long)rows, (long long)cols, (long long)lds, (long long)ldd);
+    SEA_REQUIRE(dtype == SEA_F32 || dtype == SEA_BF16, "sea_convert_f32_to_act: bad dtype %d", dtype);
+    SEA_REQUIRE(sea_aligned16(src) && sea_aligned16(dst), "sea_convert_f32_to_act: pointers must be 16-byte aligned");
+    const int64_t total = rows * (cols / 4);
+    int64_t blocks = (total + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (dtype == SEA_BF16) convert_kernel<__bf16><<<dim3((unsigned)blocks), dim3(256), 0, s>>>(src, lds, static_cast<__bf16*>(dst), ldd, rows, cols / 4);
+    else convert_kernel<float><<<dim3((unsigned)blocks), dim3(256), 0, s>>>(src, lds, static_cast<float*>(dst), ldd, rows, cols / 4);
+    SEA_CHECK_LAUNCH("sea_convert_f32_to_act");
+    return SEA_OK;
+}

@@ -1,0 +1,107 @@
+// Shared device helpers for libsea_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+#include <string.h>
+#include <math.h>
+#include <type_traits>
+
+#include "../../include/sea_hip.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+// ------------------------------------------------------------------------------------------------ errors
+void sea_set_error(const char* fmt, ...);
+#define SEA_REQUIRE(cond, ...)            \
+    do {                                  \
+        if (!(cond)) {                    \
+            sea_set_error(__VA_ARGS__);   \
+            return SEA_EINVAL;            \
+        }                                 \
+    } while (0)
+#define SEA_CHECK_LAUNCH(name)                                                     \
+    do {                                                                           \
+        hipError_t e_ = hipGetLastError();                                         \
+        if (e_ != hipSuccess) {                                                    \
+            sea_set_error("%s: launch failed: %s", name, hipGetErrorString(e_));   \
+            return SEA_ELAUNCH;                                                    \
+        }                                                                          \
+    } while (0)
+
+static inline bool sea_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+// ------------------------------------------------------------------------------------------------ dtype traits
+// One "fragment" is 16 bytes per lane along the contraction dimension: 8 bf16 or 4 f32.
+// mma16(a, b, acc) contracts CK = 4 * EPC elements (the 4 lane groups g = lane >> 4 each hold EPC of them):
+//   bf16: one v_mfma_f32_16x16x32_bf16 (lane holds k = 8g + j);
+//   f32 : four v_mfma_f32_16x16x4_f32, the j-th taking element j of every lane (k = 4g + j).
+// Operand maps (cdna_hip_programming.md §3): A[row = lane & 15][k], B[k][col = lane & 15],
+// C/D: col = lane & 15, row = 4 * (lane >> 4) + reg.
+template <typename T>
+struct ActTraits;
+template <>
+struct ActTraits<float> {
+    static constexpr int EPC = 4;  // elements per 16-byte chunk
+    static constexpr int CK = 16;  // contraction elements per mma16
+};
+template <>
+struct ActTraits<__bf16> {
+    static constexpr int EPC = 8;
+    static constexpr int CK = 32;
+};
+
+template <typename T>
+__device__ __forceinline__ void mma16(const uint4& a, const uint4& b, f32x4& acc);
+
+template <>
+__device__ __forceinline__ void mma16<__bf16>(const uint4& a, const uint4& b, f32x4& acc) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
+}
+template <>
+__device__ __forceinline__ void mma16<float>(const uint4& a, const uint4& b, f32x4& acc) {
+    const f32x4 fa = __builtin_bit_cast(f32x4, a);
+    const f32x4 fb = __builtin_bit_cast(f32x4, b);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[0], fb[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[1], fb[1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[2], fb[2], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[3], fb[3], acc, 0, 0, 0);
+}
+
+__device__ __forceinline__ float to_f32(float v) { return v; }
+__device__ __forceinline__ float to_f32(__bf16 v) { return (float)v; }
+template <typename T>
+__device__ __forceinline__ T from_f32(float v);
+template <>
+__device__ __forceinline__ float from_f32<float>(float v) { return v; }
+template <>
+__device__ __forceinline__ __bf16 from_f32<__bf16>(float v) { return (__bf16)v; }
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// Pack 4 fp32 values into 4 consecutive act elements and store them (8 B for bf16, 16 B for f32).
+__device__ __forceinline__ void store4(float* dst, float a, float b, float c, float d) {
+    *reinterpret_cast<float4*>(dst) = make_float4(a, b, c, d);
+}
+__device__ __forceinline__ void store4(__bf16* dst, float a, float b, float c, float d) {
+    bf16x4 v = {(__bf16)a, (__bf16)b, (__bf16)c, (__bf16)d};
+    *reinterpret_cast<bf16x4*>(dst) = v;
+}
+__device__ __forceinline__ void load4(const float* src, float (&o)[4]) {
+    float4 v = *reinterpret_cast<const float4*>(src);
+    o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
+}
+__device__ __forceinline__ void load4(const __bf16* src, float (&o)[4]) {
+    bf16x4 v = *reinterpret_cast<const bf16x4*>(src);
+    o[0] = (float)v[0]; o[1] = (float)v[1]; o[2] = (float)v[2]; o[3] = (float)v[3];
+}

@@ -1,0 +1,472 @@
+"""Whole-model execution engine for TemporalModel on MI355X.
+
+The reference runs TemporalModel.forward (models/temporal.py:405-416) as ~130 eager ATen calls per layer from Python
+loops.  Here the same computation is a PLAN: a fixed list of ~30 grouped kernel launches per layer over
+pre-allocated HBM workspaces, with every ABI struct filled once (include/sea_hip.h).  A plan is replayed either launch by
+launch (a few microseconds of ctypes per launch) or, for the hot loops, as a captured HIP graph.
+
+Memory layout (all in HBM, allocated through torch):
+  * parameters: ONE fp32 buffer `flat32`; every nn.Parameter of the model is a view into it (the reference's state_dict
+    schema is unchanged).  Live parameters first, the ~12 % that never receive a gradient at the tail, so
+    the optimizer and the gradient all-reduce run over one contiguous prefix.  q/k/v weights of an attention module are
+    adjacent in q,k,v order, so the fused [3E, E] projection is a plain view.
+  * `flat_act`: the same layout in the activation dtype (bf16 shadow; aliases flat32 in fp32 mode).
+  * residual stream: fp32 [M, E] per field (M = B*T rows); matrix-operand activations in the activation dtype.
+  * Q [B,H,T,hd], K [B,H,cap,hd], V^T [B,H,hd,cap] per attention problem (written by the QKV epilogue).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import re
+from typing import Dict, List, Optional, Tuple
+
+import torch
+
+from . import _native as N
+
+_QKV = re.compile(r"^(.*\.)(k|q|v)\.(weight|bias)$")
+_QKV_RANK = {("q", "weight"): 0, ("k", "weight"): 1, ("v", "weight"): 2, ("q", "bias"): 3, ("k", "bias"): 4, ("v", "bias"): 5}
+
+
+def _round_up(x: int, m: int) -> int:
+    return (x + m - 1) // m * m
+
+
+def dead_prefixes(num_layers: int, F: int) -> List[str]:
+    """Parameter-name prefixes that never receive a gradient on this path."""
+    out = []
+    for layer in range(num_layers):
+        pre = f"blocks.{layer}."
+        out += [pre + "ln.cross.", pre + "ib.residual_projection."]
+        for i in range(F):
+            out += [f"{pre}ln.exp.{i}.1.", f"{pre}cross_attn.{i}.{i}."]
+    return out
+
+
+class FlatParams:
+    """One contiguous fp32 buffer holding every parameter of the model (+ the activation-dtype shadow)."""
+
+    def __init__(self, model: torch.nn.Module, device: torch.device, act_dtype: torch.dtype):
+        named = list(model.named_parameters())
+        first_idx: Dict[str, int] = {}
+        keyed = []
+        for idx, (name, p) in enumerate(named):
+            m = _QKV.match(name)
+            if m:
+                base = first_idx.setdefault(m.group(1), idx)
+                keyed.append(((base, _QKV_RANK[(m.group(2), m.group(3))]), name, p))
+            else:
+                keyed.append(((idx, 0), name, p))
+        dead = dead_prefixes(model.num_layers, model.num_variables)
+        is_dead = lambda n: any(n.startswith(d) for d in dead)  # noqa: E731
+        keyed.sort(key=lambda t: (is_dead(t[1]), t[0]))
+        self.offsets: Dict[str, Tuple[int, Tuple[int, ...]]] = {}
+        off = 0
+        self.n_live = 0
+        for _, name, p in keyed:
+            if is_dead(name) and self.n_live == 0 and off > 0:
+                self.n_live = off
+            self.offsets[name] = (off, tuple(p.shape))
+            off += _round_up(p.numel(), 8)
+        if self.n_live == 0:
+            self.n_live = off
+        self.n_total = off
+        self.device, self.act_dtype = device, act_dtype
+        self.flat32 = torch.zeros(self.n_total, device=device, dtype=torch.float32)
+        with torch.no_grad():
+            for _, name, p in keyed:
+                o, shp = self.offsets[name]
+                view = self.flat32[o:o + p.numel()].view(shp)
+                view.copy_(p.detach().to(device=device, dtype=torch.float32))
+                p.data = view  # the module's parameter now aliases the flat buffer
+        self.live_names = [n for _, n, _ in keyed if not is_dead(n)]
+        self.flat_act = self.flat32 if act_dtype == torch.float32 else torch.empty(self.n_total, device=device, dtype=act_dtype)
+        self._synced_version = -1
+        self.sync()
+
+    # -- views
+    def f32(self, name: str) -> torch.Tensor:
+        o, shp = self.offsets[name]
+        n = 1
+        for s in shp:
+            n *= s
+        return self.flat32[o:o + n].view(shp)
+
+    def act(self, name: str, rows: Optional[int] = None) -> torch.Tensor:
+        """Activation-dtype view of a 2-D weight; rows > shape[0] extends over the adjacent tensors (fused q|k|v)."""
+        o, shp = self.offsets[name]
+        r = shp[0] if rows is None else rows
+        return self.flat_act[o:o + r * shp[1]].view(r, shp[1])
+
+    def f32_vec(self, name: str, n: Optional[int] = None) -> torch.Tensor:
+        o, shp = self.offsets[name]
+        k = shp[0] if n is None else n
+        return self.flat32[o:o + k]
+
+    def sync(self, force: bool = False) -> None:
+        """Refresh the activation-dtype shadow if any parameter view was modified in place since the last sync."""
+        if self.act_dtype == torch.float32:
+            return
+        v = self.flat32._version
+        if force or v != self._synced_version:
+            N.check(N.lib().sea_convert_f32_to_act(self.flat32.data_ptr(), self.n_total, self.flat_act.data_ptr(), self.n_total, 1,
+                                                   self.n_total, N.dtype_code(self.act_dtype), N.stream_ptr()), "weight shadow")
+            self._synced_version = v
+
+
+class _Rec:
+    """One pre-built launch: C function + argument list (the stream is appended at run time)."""
+    __slots__ = ("fn", "args", "name", "keep")
+
+    def __init__(self, fn, args, name, keep=None):
+        self.fn, self.args, self.name, self.keep = fn, list(args), name, keep
+
+
+class Plan:
+    """Launch list for one (B, T, mode) of TemporalModel.forward."""
+
+    def __init__(self, eng: "TemporalEngine", B: int, T: int, mode: str = "full", save_for_backward: bool = False):
+        assert mode in ("full", "step")
+        self.eng, self.B, self.T, self.mode = eng, B, T, mode
+        m = eng.model
+        self.F, self.E, self.H, self.L = m.num_variables, m.embed_dim, m.n_heads, m.num_layers
+        self.D = m.down_dim
+        self.S = m.mlp_hidden
+        self.M = B * T
+        self.dt = eng.act_dtype
+        self.code = N.dtype_code(self.dt)
+        self.adaln = m.LN_type.lower() == "adaln"
+        self.cap = _round_up(m.max_len, 8) if mode == "step" else _round_up(T, 8)
+        self.pos0 = 0
+        self.records: List[_Rec] = []
+        self._keep: List[object] = []
+        self._x_patches: List[Tuple[object, str, int]] = []   # (struct, field, byte offset from x base)
+        self._out_patches: List[Tuple[object, str, int]] = []
+        self._c_patches: List[Tuple[object, object]] = []      # (container, key) receiving the condition pointer
+        self._pos_structs: List[object] = []                   # SeaQkvCommon / SeaAttnParams to update per step
+        self._bound = (None, None, None)
+        self._build()
+
+    # ------------------------------------------------------------------ allocation helpers
+    def _buf(self, *shape, dtype=None, zero=False) -> torch.Tensor:
+        dt = self.dt if dtype is None else dtype
+        t = (torch.zeros if zero else torch.empty)(*shape, device=self.eng.device, dtype=dt)
+        self._keep.append(t)
+        return t
+
+    # ------------------------------------------------------------------ record builders
+    def _gemm(self, groups: List[dict], name: str) -> None:
+        L = N.lib()
+        for s in range(0, len(groups), N.MAX_GROUPS):
+            chunk = groups[s:s + N.MAX_GROUPS]
+            arr = (N.SeaGemmGroup * len(chunk))()
+            for g, d in zip(arr, chunk):
+                _fill_gemm(g, **d)
+            self.records.append(_Rec(L.sea_gemm_grouped, [arr, len(chunk), self.code], name, arr))
+            for g, d in zip(arr, chunk):
+                if d.get("R_is_x") is not None:
+                    self._x_patches.append((g, "R", d["R_is_x"]))
+
+    def _norm(self, groups: List[dict], d: int, name: str, x_is_act=False, gelu=False) -> None:
+        L = N.lib()
+        for s in range(0, len(groups), N.MAX_NORM_GROUPS):
+            chunk = groups[s:s + N.MAX_NORM_GROUPS]
+            arr = (N.SeaNormGroup * len(chunk))()
+            for g, gd in zip(arr, chunk):
+                X = gd["X"]
+                g.X, g.ldx = X.data_ptr(), gd.get("ldx", X.stride(0) if X.dim() == 2 else 0)
+                mod = gd.get("mod")
+                g.mod, g.ldmod = N.ptr(mod), (mod.stride(0) if mod is not None else 0)
+                g.gamma, g.beta = gd["gamma"].data_ptr(), N.ptr(gd.get("beta"))
+                y32, yact = gd.get("Y32"), gd.get("Yact")
+                g.Y32, g.ldy32 = N.ptr(y32), gd.get("ldy32", y32.stride(0) if y32 is not None else 0)
+                g.Yact, g.ldyact = N.ptr(yact), (yact.stride(0) if yact is not None else 0)
+                g.mean, g.rstd = N.ptr(gd.get("mean")), N.ptr(gd.get("rstd"))
+                if gd.get("X_is_x") is not None:
+                    self._x_patches.append((g, "X", gd["X_is_x"]))
+                if gd.get("Y_is_out") is not None:
+                    self._out_patches.append((g, "Y32", gd["Y_is_out"]))
+            self.records.append(_Rec(L.sea_rownorm, [arr, len(chunk), self.M, d, int(x_is_act), int(gelu), 1e-5, self.code], name, arr))
+
+    def _qkv(self, groups: List[dict], rope: torch.Tensor, hd: int, name: str) -> None:
+        L = N.lib()
+        arr = (N.SeaQkvGroup * len(groups))()
+        for g, d in zip(arr, groups):
+            A, W = d["A"], d["W"]
+            g.A, g.W, g.bias = A.data_ptr(), W.data_ptr(), d["bias"].data_ptr()
+            g.Qout, g.Kout, g.Vtout = N.ptr(d.get("Q")), N.ptr(d.get("K")), N.ptr(d.get("Vt"))
+            g.lda, g.ldw = A.stride(0), W.stride(0)
+            g.M, g.N, g.K, g.col0 = self.M, W.shape[0], W.shape[1], d["col0"]
+        common = N.SeaQkvCommon(rope.data_ptr(), self.H, hd, self.T, self.pos0, self.cap, float(hd) ** -0.5)
+        self._pos_structs.append(common)
+        self.records.append(_Rec(L.sea_qkv_rope_grouped, [arr, len(groups), C.byref(common), self.code], name, (arr, common)))
+
+    def _attn(self, problems: List[dict], hd: int, ldo: int, name: str) -> None:
+        L = N.lib()
+        for s in range(0, len(problems), N.MAX_ATTN_PROBLEMS):
+            chunk = problems[s:s + N.MAX_ATTN_PROBLEMS]
+            P = N.SeaAttnParams()
+            P.n_problems = len(chunk)
+            for i, d in enumerate(chunk):
+                P.p[i].Q, P.p[i].K, P.p[i].Vt, P.p[i].O = d["Q"].data_ptr(), d["K"].data_ptr(), d["Vt"].data_ptr(), d["O"].data_ptr()
+                P.p[i].LSE = N.ptr(d.get("LSE"))
+            P.B, P.H, P.hd, P.Tq, P.Tk, P.cap = self.B, self.H, hd, self.T, self.pos0 + self.T, self.cap
+            P.q_pos0, P.src_len, P.ldo = self.pos0, self.eng.model.src_len, ldo
+            self._pos_structs.append(P)
+            self.records.append(_Rec(L.sea_attention_fwd, [C.byref(P), self.code], name, P))
+
+    # ------------------------------------------------------------------ the plan
+    def _build(self) -> None:
+        eng, P = self.eng, self.eng.params
+        F, E, D, S, M, B, T, H = self.F, self.E, self.D, self.S, self.M, self.B, self.T, self.H
+        dt, L = self.dt, N.lib()
+        hd_s, hd_c = E // H, D // H
+        cap = self.cap
+        f32 = torch.float32
+
+        # ---- AdaLN condition MLPs for the WHOLE model: one silu launch + one grouped GEMM (cond_mlp.2)
+        mods: Dict[str, torch.Tensor] = {}
+        if self.adaln:
+            inst = []
+            for l in range(self.L):
+                pre = f"blocks.{l}."
+                for i in range(F):
+                    inst += [(f"{pre}ln.exp.{i}.0.", E), (f"{pre}ln.exp.{i}.2.", E)]
+                for i in range(F):
+                    inst.append((f"{pre}ln_cross.{i}.", D))
+            for i in range(F):
+                inst.append((f"ln.{i}.", E))
+            silu_groups, gemm_groups = [], []
+            for pre, d in inst:
+                hid = self._buf(M, 2 * d)
+                mod = self._buf(M, 2 * d)
+                mods[pre] = mod
+                silu_groups.append((P.f32_vec(pre + "cond_mlp.0.weight", 2 * d), P.f32_vec(pre + "cond_mlp.0.bias"), hid))
+                gemm_groups.append(dict(A=hid, W=P.act(pre + "cond_mlp.2.weight"), bias=P.f32_vec(pre + "cond_mlp.2.bias"), Cact=mod))
+            for s in range(0, len(silu_groups), N.MAX_SILU_GROUPS):
+                chunk = silu_groups[s:s + N.MAX_SILU_GROUPS]
+                arr = (N.SeaSiluGroup * len(chunk))()
+                for g, (w1, b1, hid) in zip(arr, chunk):
+                    g.w1, g.b1, g.Hid, g.K2, g.ld = w1.data_ptr(), b1.data_ptr(), hid.data_ptr(), hid.shape[1], hid.stride(0)
+                rec = _Rec(L.sea_silu_outer, [arr, len(chunk), None, M, self.code], "adaln.silu", arr)
+                self._c_patches.append((rec.args, 2))
+                self.records.append(rec)
+            self._gemm(gemm_groups, "adaln.cond_gemm")
+
+        def norm_params(pre, d):
+            if self.adaln:
+                return dict(mod=mods[pre], gamma=P.f32_vec(pre + "weight"), beta=P.f32_vec(pre + "bias"))
+            return dict(gamma=P.f32_vec(pre + "weight"))
+
+        rope_s, rope_c = eng.rope_self, eng.rope_cross
+        FE = F * E
+        xr = [self._buf(M, E, dtype=f32) for _ in range(F)]     # fp32 residual stream
+        xa = [self._buf(M, E) for _ in range(F)]                # act-dtype copy (GEMM A operand)
+        n_e = [self._buf(M, E) for _ in range(F)]               # normalised rows, dim E
+        att_e = [self._buf(M, E) for _ in range(F)]
+        Qs = [self._buf(B, H, T, hd_s) for _ in range(F)]
+        Ks = [[self._buf(B, H, cap, hd_s, zero=True) for _ in range(F)] for _ in range(self.L)]
+        Vs = [[self._buf(B, H, hd_s, cap, zero=True) for _ in range(F)] for _ in range(self.L)]
+        dn = [self._buf(M, D, dtype=f32) for _ in range(F)]
+        nd_old = [self._buf(M, D) for _ in range(F)]
+        nd_new = [self._buf(M, D) for _ in range(F)]
+        Qc = [self._buf(B, H, T, hd_c) for _ in range(max(F - 1, 1))]
+        Kc = [[[self._buf(B, H, cap, hd_c, zero=True) for _ in range(F)] for _ in range(F)] for _ in range(self.L)]
+        Vc = [[[self._buf(B, H, hd_c, cap, zero=True) for _ in range(F)] for _ in range(F)] for _ in range(self.L)]
+        att_c = [self._buf(M, D) for _ in range(max(F - 1, 1))]
+        gp = self._buf(max(F - 1, 1), M, D)
+        hbuf = [self._buf(M, S) for _ in range(F)]
+        hg = [self._buf(M, S) for _ in range(F)]
+        self.ws = dict(xr=xr, xa=xa, n_e=n_e, att_e=att_e, hbuf=hbuf, hg=hg)
+
+        first = True  # the residual stream still lives in the caller's x [B,T,F,E]
+        for l in range(self.L):
+            pre = f"blocks.{l}."
+            if first and not eng.model.add_info_after_cross:
+                # the info-bottleneck add comes first and must not modify the caller's tensor: copy x into xr
+                for i in range(F):
+                    rec = _Rec(L.sea_convert_f32_to_act, [None, FE, xr[i].data_ptr(), E, M, E, N.SEA_F32], "x.copy")
+                    self._x_patches.append((rec.args, 0, i * E * 4))
+                    self.records.append(rec)
+                first = False
+            if not eng.model.add_info_after_cross:
+                self._ib(pre, xr)
+            # -- self attention: x_i += proj(attn(AdaLN_0(x_i)))
+            groups = []
+            for i in range(F):
+                g = dict(Yact=n_e[i], **norm_params(f"{pre}ln.exp.{i}.0.", E))
+                if first:
+                    g.update(X=xr[i], ldx=FE, X_is_x=i * E * 4)
+                else:
+                    g.update(X=xr[i])
+                groups.append(g)
+            self._norm(groups, E, "self.adaln0")
+            self._qkv([dict(A=n_e[i], W=P.act(f"{pre}attn.self.{i}.q.weight", 3 * E), bias=P.f32_vec(f"{pre}attn.self.{i}.q.bias", 3 * E),
+                            col0=0, Q=Qs[i], K=Ks[l][i], Vt=Vs[l][i]) for i in range(F)], rope_s, hd_s, "self.qkv_rope")
+            self._attn([dict(Q=Qs[i], K=Ks[l][i], Vt=Vs[l][i], O=att_e[i]) for i in range(F)], hd_s, E, "self.attention")
+            groups = []
+            for i in range(F):
+                g = dict(A=att_e[i], W=P.act(f"{pre}attn.self.{i}.projection.weight"), C32=xr[i], Cact=xa[i])
+                if first:
+                    g.update(R=xr[i], ldr=FE, R_is_x=i * E * 4)
+                else:
+                    g.update(R=xr[i])
+                groups.append(g)
+            self._gemm(groups, "self.out_proj")
+            first = False
+            # -- state exchange (Gauss-Seidel over i, models/temporal.py:187-192)
+            if F > 1:
+                self._gemm([dict(A=xa[j], W=P.act(f"{pre}cross_down.{j}.weight"), bias=P.f32_vec(f"{pre}cross_down.{j}.bias"), C32=dn[j])
+                            for j in range(F)], "cross.down_old")
+                self._norm([dict(X=dn[j], Yact=nd_old[j], **norm_params(f"{pre}ln_cross.{j}.", D)) for j in range(F)], D, "cross.norm_old")
+                for i in range(F):
+                    others = [j for j in range(F) if j != i]
+                    qkv_groups, probs, proj_groups = [], [], []
+                    for s, j in enumerate(others):
+                        src = nd_new[j] if j < i else nd_old[j]
+                        ca = f"{pre}cross_attn.{i}.{j}."
+                        qkv_groups.append(dict(A=nd_old[i], W=P.act(ca + "q.weight"), bias=P.f32_vec(ca + "q.bias"), col0=0, Q=Qc[s]))
+                        qkv_groups.append(dict(A=src, W=P.act(ca + "k.weight", 2 * D), bias=P.f32_vec(ca + "k.bias", 2 * D), col0=D,
+                                               K=Kc[l][i][j], Vt=Vc[l][i][j]))
+                        probs.append(dict(Q=Qc[s], K=Kc[l][i][j], Vt=Vc[l][i][j], O=att_c[s]))
+                        proj_groups.append(dict(A=att_c[s], W=P.act(ca + "projection.weight"), Cact=gp[s], act=1))
+                    self._qkv(qkv_groups, rope_c, hd_c, f"cross{i}.qkv_rope")
+                    self._attn(probs, hd_c, D, f"cross{i}.attention")
+                    self._gemm(proj_groups, f"cross{i}.proj_gelu")
+                    self._gemm([dict(A=gp[0], W=P.act(f"{pre}cross_up.{i}.weight"), bias=P.f32_vec(f"{pre}cross_up.{i}.bias"),
+                                     bias_scale=float(F - 1), n_seg=F - 1, a_seg_stride=M * D, R=xr[i], C32=xr[i],
+                                     Cact=(xa[i] if i < F - 1 else None))], f"cross{i}.up_sum")
+                    if i < F - 1:
+                        self._gemm([dict(A=xa[i], W=P.act(f"{pre}cross_down.{i}.weight"), bias=P.f32_vec(f"{pre}cross_down.{i}.bias"), C32=dn[i])],
+                                   f"cross{i}.down_new")
+                        self._norm([dict(X=dn[i], Yact=nd_new[i], **norm_params(f"{pre}ln_cross.{i}.", D))], D, f"cross{i}.norm_new")
+            if eng.model.add_info_after_cross:
+                self._ib(pre, xr)
+            # -- MLP: x_i += W2 gelu(LN(W1 AdaLN_2(x_i))) ; x_i = proj_i(x_i)
+            self._norm([dict(X=xr[i], Yact=n_e[i], **norm_params(f"{pre}ln.exp.{i}.2.", E)) for i in range(F)], E, "mlp.adaln2")
+            self._gemm([dict(A=n_e[i], W=P.act(f"{pre}mlp.{i}.layers.0.weight"), bias=P.f32_vec(f"{pre}mlp.{i}.layers.0.bias"), Cact=hbuf[i])
+                        for i in range(F)], "mlp.fc1")
+            self._norm([dict(X=hbuf[i], gamma=P.f32_vec(f"{pre}mlp.{i}.layers.1.weight"), beta=P.f32_vec(f"{pre}mlp.{i}.layers.1.bias"), Yact=hg[i])
+                        for i in range(F)], S, "mlp.ln_gelu", x_is_act=True, gelu=True)
+            self._gemm([dict(A=hg[i], W=P.act(f"{pre}mlp.{i}.layers.3.weight"), bias=P.f32_vec(f"{pre}mlp.{i}.layers.3.bias"), R=xr[i], Cact=xa[i])
+                        for i in range(F)], "mlp.fc2")
+            self._gemm([dict(A=xa[i], W=P.act(f"{pre}proj.{i}.weight"), bias=P.f32_vec(f"{pre}proj.{i}.bias"), C32=xr[i]) for i in range(F)], "proj")
+        # -- final per-field norm, written straight into out[B,T,F,E]
+        self._norm([dict(X=xr[i], Y32=xr[i], ldy32=FE, Y_is_out=i * E * 4, **norm_params(f"ln.{i}.", E)) for i in range(F)], E, "final.norm")
+
+    def _ib(self, pre: str, xr: List[torch.Tensor]) -> None:
+        P = self.eng.params
+        ib = N.SeaIbParams()
+        for i, x in enumerate(xr):
+            ib.X[i] = x.data_ptr()
+        ib.n_fields, ib.ldx = len(xr), xr[0].stride(0)
+        ib.w1 = P.f32_vec(pre + "ib.layers.0.weight").data_ptr()
+        ib.b1 = P.f32_vec(pre + "ib.layers.0.bias").data_ptr()
+        ib.lnw = P.f32_vec(pre + "ib.layers.1.weight").data_ptr()
+        ib.lnb = P.f32_vec(pre + "ib.layers.1.bias").data_ptr()
+        ib.w2 = P.f32(pre + "ib.layers.3.weight").data_ptr()
+        ib.b2 = P.f32_vec(pre + "ib.layers.3.bias").data_ptr()
+        ib.M, ib.E, ib.h = self.M, self.E, self.eng.model.ib_hidden
+        self._c_patches.append((ib, "c"))
+        self.records.append(_Rec(N.lib().sea_ib_add, [C.byref(ib)], "ib_add", ib))
+
+    # ------------------------------------------------------------------ binding and replay
+    def bind(self, x: torch.Tensor, ib: torch.Tensor, out: torch.Tensor) -> None:
+        key = (x.data_ptr(), ib.data_ptr(), out.data_ptr())
+        if key == self._bound:
+            return
+        xp, cp, op = key
+        for tgt, field, off in self._x_patches:
+            if isinstance(tgt, list):
+                tgt[field] = xp + off
+            else:
+                setattr(tgt, field, xp + off)
+        for tgt, field, off in self._out_patches:
+            setattr(tgt, field, op + off)
+        for tgt, field in self._c_patches:
+            if isinstance(tgt, list):
+                tgt[field] = cp
+            else:
+                setattr(tgt, field, cp)
+        self._bound = key
+
+    def set_position(self, pos0: int) -> None:
+        """Step mode: the T rows of this call sit at absolute positions pos0 .. pos0 + T - 1 of the K/V caches."""
+        assert pos0 + self.T <= self.cap
+        self.pos0 = pos0
+        for s in self._pos_structs:
+            if isinstance(s, N.SeaQkvCommon):
+                s.pos0 = pos0
+            else:
+                s.q_pos0, s.Tk = pos0, pos0 + self.T
+
+    def run(self) -> None:
+        stream = N.stream_ptr()
+        for r in self.records:
+            rc = r.fn(*r.args, stream)
+            if rc != 0:
+                N.check(rc, r.name)
+
+
+def _fill_gemm(g, A, W, bias=None, R=None, C32=None, Cact=None, n_seg=1, a_seg_stride=0, act=0, bias_scale=1.0, ldr=None,
+               R_is_x=None) -> None:
+    g.A, g.W = A.data_ptr(), W.data_ptr()
+    g.bias, g.R, g.C32, g.Cact = N.ptr(bias), N.ptr(R), N.ptr(C32), N.ptr(Cact)
+    g.a_seg_stride = a_seg_stride
+    g.lda, g.ldw = A.stride(-2), W.stride(0)
+    g.ldr = (ldr if ldr is not None else R.stride(0)) if R is not None else 0
+    g.ldc32 = C32.stride(0) if C32 is not None else 0
+    g.ldcact = Cact.stride(0) if Cact is not None else 0
+    g.M, g.N, g.K = A.shape[-2], W.shape[0], W.shape[1]
+    g.n_seg, g.act, g.bias_scale = n_seg, act, bias_scale
+
+
+class TemporalEngine:
+    """Owns the flat parameter buffers of one TemporalModel on one GPU and the plans built over them."""
+
+    def __init__(self, model: torch.nn.Module, device: torch.device, act_dtype: torch.dtype):
+        N.lib()
+        if device.type != "cuda":
+            raise RuntimeError("sea_amd: TemporalModel runs only on an MI355X (no CPU fallback)")
+        m = model
+        if m.exchange_mode != "sea" or m.ib_scale_mode != "mlp" or m.ib_addition_mode != "add" or m.ib_mlp_layers != 1 or m.ib_num != 1:
+            raise NotImplementedError(
+                "sea_amd native path covers exchange_mode='sea', ib_scale_mode='mlp', ib_addition_mode='add', ib_mlp_layers=1, "
+                "ib_num=1 (the combination both shipped configs select); got "
+                f"{m.exchange_mode}/{m.ib_scale_mode}/{m.ib_addition_mode}/{m.ib_mlp_layers}/{m.ib_num}")
+        E, H, D = m.embed_dim, m.n_heads, m.down_dim
+        for hd, what in ((E // H, "self"), (D // H, "cross")):
+            if hd not in (8, 16, 32, 64, 128) or hd * H != (E if what == "self" else D):
+                raise NotImplementedError(f"sea_amd: unsupported {what}-attention head dim {hd} (supported: 8, 16, 32, 64, 128)")
+        if m.src_len < 0:
+            raise NotImplementedError("sea_amd: src_len must be >= 0")
+        if m.ib_hidden > 64:
+            raise NotImplementedError("sea_amd: info-bottleneck hidden width (scale_ratio) must be <= 64")
+        self.model, self.device, self.act_dtype = model, device, act_dtype
+        self.params = FlatParams(model, device, act_dtype)
+        blk = model.blocks[0]
+        self.rope_self = torch.view_as_real(blk.attn["self"][0].freqs_cis.to(device)).contiguous()
+        self.rope_cross = torch.view_as_real(blk.cross_attn[0][0].freqs_cis.to(device)).contiguous()
+        self._plans: Dict[Tuple, Plan] = {}
+
+    def plan(self, B: int, T: int, mode: str = "full") -> Plan:
+        key = (B, T, mode)
+        p = self._plans.get(key)
+        if p is None:
+            if T > self.model.max_len:
+                raise ValueError(f"sequence length {T} exceeds max_len {self.model.max_len}")
+            p = Plan(self, B, T, mode)
+            self._plans[key] = p
+        return p
+
+    def forward(self, x: torch.Tensor, ib: torch.Tensor) -> torch.Tensor:
+        """TemporalModel.forward: x [B,T,F,E] fp32, ib [B,T,1] fp32 -> [B,T,F,E] fp32."""
+        B, T, F, E = x.shape
+        x = x.contiguous()
+        ib = ib.contiguous()
+        out = torch.empty_like(x)
+        self.params.sync()
+        p = self.plan(B, T, "full")
+        p.bind(x, ib, out)
+        p.run()
+        return out

@@ -1,0 +1,161 @@
+"""Tensor-level wrappers over the C ABI (include/sea_hip.h).
+
+Each function fills the ABI structs from torch tensors (device memory owned by PyTorch) and launches on the current
+stream.  They are the un-fused building blocks used by the module mirrors in sea_amd/models/base_blocks.py and by the
+operator tests; sea_amd/engine.py pre-builds the same structs once per plan for the whole-model path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Optional, Sequence
+
+import torch
+
+from . import _native as N
+
+
+def _mat(t: torch.Tensor, name: str) -> torch.Tensor:
+    N.require_gpu(t, name)
+    if t.dim() != 2 or t.stride(1) != 1:
+        raise ValueError(f"{name}: need a 2-D tensor with unit inner stride, got shape {tuple(t.shape)} strides {t.stride()}")
+    return t
+
+
+def fill_gemm_group(g: N.SeaGemmGroup, A, W, bias=None, R=None, C32=None, Cact=None, n_seg=1, a_seg_stride=0, act=0,
+                    bias_scale=1.0, M=None, N_=None, K=None) -> None:
+    g.A, g.W = A.data_ptr(), W.data_ptr()
+    g.bias = N.ptr(bias)
+    g.R, g.C32, g.Cact = N.ptr(R), N.ptr(C32), N.ptr(Cact)
+    g.a_seg_stride = a_seg_stride
+    g.lda, g.ldw = A.stride(0), W.stride(0)
+    g.ldr = R.stride(0) if R is not None else 0
+    g.ldc32 = C32.stride(0) if C32 is not None else 0
+    g.ldcact = Cact.stride(0) if Cact is not None else 0
+    g.M = A.shape[0] if M is None else M
+    g.N = W.shape[0] if N_ is None else N_
+    g.K = W.shape[1] if K is None else K
+    g.n_seg = n_seg
+    g.act = act
+    g.bias_scale = bias_scale
+
+
+def gemm_grouped(groups: Sequence[Dict], dtype: torch.dtype) -> None:
+    """groups: dicts with A [M,K] act, W [N,K] act, optional bias f32 [N], R f32 [M,N], C32 f32 [M,N], Cact act [M,N],
+    n_seg, a_seg_stride, act (0|1), bias_scale."""
+    n = len(groups)
+    arr = (N.SeaGemmGroup * n)()
+    for i, d in enumerate(groups):
+        A, W = _mat(d["A"], "A"), _mat(d["W"], "W")
+        if A.dtype != dtype or W.dtype != dtype:
+            raise ValueError(f"gemm group {i}: A/W dtype {A.dtype}/{W.dtype} != activation dtype {dtype}")
+        for k in ("bias", "R", "C32"):
+            if d.get(k) is not None and d[k].dtype != torch.float32:
+                raise ValueError(f"gemm group {i}: {k} must be float32")
+        if d.get("Cact") is not None and d["Cact"].dtype != dtype:
+            raise ValueError(f"gemm group {i}: Cact dtype mismatch")
+        fill_gemm_group(arr[i], A, W, d.get("bias"), d.get("R"), d.get("C32"), d.get("Cact"), d.get("n_seg", 1),
+                        d.get("a_seg_stride", 0), d.get("act", 0), d.get("bias_scale", 1.0), K=d.get("K"))
+    N.check(N.lib().sea_gemm_grouped(arr, n, N.dtype_code(dtype), N.stream_ptr()), "sea_gemm_grouped")
+
+
+def qkv_rope_grouped(groups: Sequence[Dict], rope: torch.Tensor, H: int, hd: int, T: int, pos0: int, cap: int,
+                     q_scale: float, dtype: torch.dtype) -> None:
+    """groups: dicts with A [M,K], W [N,K], bias f32 [N], col0, Q/K/Vt output tensors (see sea_hip.h)."""
+    n = len(groups)
+    arr = (N.SeaQkvGroup * n)()
+    for i, d in enumerate(groups):
+        A, W = _mat(d["A"], "A"), _mat(d["W"], "W")
+        if A.dtype != dtype or W.dtype != dtype:
+            raise ValueError(f"qkv group {i}: dtype mismatch")
+        g = arr[i]
+        g.A, g.W, g.bias = A.data_ptr(), W.data_ptr(), N.ptr(d.get("bias"))
+        g.Qout, g.Kout, g.Vtout = N.ptr(d.get("Q")), N.ptr(d.get("K")), N.ptr(d.get("Vt"))
+        g.lda, g.ldw = A.stride(0), W.stride(0)
+        g.M, g.N, g.K = A.shape[0], W.shape[0], W.shape[1]
+        g.col0 = d.get("col0", 0)
+    N.require_gpu(rope, "rope")
+    assert rope.dtype == torch.float32 and rope.is_contiguous() and rope.shape[-1] == 2 and rope.shape[-2] == hd // 2
+    assert rope.shape[0] >= pos0 + T, "rope table shorter than pos0 + T"
+    common = N.SeaQkvCommon(rope.data_ptr(), H, hd, T, pos0, cap, q_scale)
+    N.check(N.lib().sea_qkv_rope_grouped(arr, n, C.byref(common), N.dtype_code(dtype), N.stream_ptr()), "sea_qkv_rope_grouped")
+
+
+def attention_fwd(problems: Sequence[Dict], B: int, H: int, hd: int, Tq: int, Tk: int, cap: int, q_pos0: int,
+                  src_len: int, dtype: torch.dtype) -> None:
+    """problems: dicts with Q [B,H,Tq,hd], K [B,H,cap,hd], Vt [B,H,hd,cap], O [B,Tq,H*hd] (row stride = O.stride(1)),
+    optional LSE f32 [B,H,Tq]."""
+    P = N.SeaAttnParams()
+    P.n_problems = len(problems)
+    ldo = None
+    for i, d in enumerate(problems):
+        for k in ("Q", "K", "Vt", "O"):
+            N.require_gpu(d[k], k)
+            assert d[k].dtype == dtype, f"attention problem {i}: {k} dtype"
+        assert d["Q"].is_contiguous() and d["K"].is_contiguous() and d["Vt"].is_contiguous()
+        O = d["O"]
+        assert O.dim() == 3 and O.stride(2) == 1 and O.stride(0) == Tq * O.stride(1)
+        ldo = O.stride(1) if ldo is None else ldo
+        assert O.stride(1) == ldo
+        P.p[i].Q, P.p[i].K, P.p[i].Vt, P.p[i].O = d["Q"].data_ptr(), d["K"].data_ptr(), d["Vt"].data_ptr(), O.data_ptr()
+        P.p[i].LSE = N.ptr(d.get("LSE"))
+    P.B, P.H, P.hd, P.Tq, P.Tk, P.cap, P.q_pos0, P.src_len, P.ldo = B, H, hd, Tq, Tk, cap, q_pos0, src_len, ldo
+    N.check(N.lib().sea_attention_fwd(C.byref(P), N.dtype_code(dtype), N.stream_ptr()), "sea_attention_fwd")
+
+
+def rownorm(groups: Sequence[Dict], M: int, d: int, x_is_act: bool, gelu: bool, eps: float, dtype: torch.dtype) -> None:
+    """groups: dicts with X [M,d], optional mod act [M,2d], gamma f32 [d], optional beta f32 [d], Y32 and/or Yact,
+    optional mean/rstd f32 [M]."""
+    n = len(groups)
+    arr = (N.SeaNormGroup * n)()
+    for i, gd in enumerate(groups):
+        X = _mat(gd["X"], "X")
+        assert X.dtype == (dtype if x_is_act else torch.float32)
+        g = arr[i]
+        g.X, g.ldx = X.data_ptr(), X.stride(0)
+        mod = gd.get("mod")
+        g.mod, g.ldmod = N.ptr(mod), (mod.stride(0) if mod is not None else 0)
+        g.gamma, g.beta = gd["gamma"].data_ptr(), N.ptr(gd.get("beta"))
+        y32, yact = gd.get("Y32"), gd.get("Yact")
+        g.Y32, g.ldy32 = N.ptr(y32), (y32.stride(0) if y32 is not None else 0)
+        g.Yact, g.ldyact = N.ptr(yact), (yact.stride(0) if yact is not None else 0)
+        g.mean, g.rstd = N.ptr(gd.get("mean")), N.ptr(gd.get("rstd"))
+    N.check(N.lib().sea_rownorm(arr, n, M, d, int(x_is_act), int(gelu), eps, N.dtype_code(dtype), N.stream_ptr()), "sea_rownorm")
+
+
+def silu_outer(groups: Sequence[Dict], c: torch.Tensor, M: int, dtype: torch.dtype) -> None:
+    """groups: dicts with w1 f32 [K2], b1 f32 [K2], Hid act [M,K2]."""
+    n = len(groups)
+    arr = (N.SeaSiluGroup * n)()
+    for i, gd in enumerate(groups):
+        g = arr[i]
+        H = _mat(gd["Hid"], "Hid")
+        g.w1, g.b1, g.Hid, g.K2, g.ld = gd["w1"].data_ptr(), gd["b1"].data_ptr(), H.data_ptr(), H.shape[1], H.stride(0)
+    N.require_gpu(c, "c")
+    assert c.dtype == torch.float32 and c.is_contiguous() and c.numel() == M
+    N.check(N.lib().sea_silu_outer(arr, n, c.data_ptr(), M, N.dtype_code(dtype), N.stream_ptr()), "sea_silu_outer")
+
+
+def ib_add(xs: Sequence[torch.Tensor], c: torch.Tensor, w1, b1, lnw, lnb, w2, b2) -> None:
+    """xs: f32 [M,E] matrices (equal row stride) updated in place: x += W2 gelu(LN(w1 c + b1)) + b2."""
+    P = N.SeaIbParams()
+    M, E = xs[0].shape
+    for i, x in enumerate(xs):
+        _mat(x, "x")
+        assert x.dtype == torch.float32 and x.shape == (M, E) and x.stride(0) == xs[0].stride(0)
+        P.X[i] = x.data_ptr()
+    P.n_fields, P.ldx = len(xs), xs[0].stride(0)
+    for t in (c, w1, b1, lnw, lnb, w2, b2):
+        N.require_gpu(t, "ib parameter")
+        assert t.dtype == torch.float32 and t.is_contiguous()
+    P.c, P.w1, P.b1, P.lnw, P.lnb, P.w2, P.b2 = (t.data_ptr() for t in (c, w1, b1, lnw, lnb, w2, b2))
+    P.M, P.E, P.h = M, E, w1.numel()
+    assert c.numel() == M and w2.shape == (E, P.h)
+    N.check(N.lib().sea_ib_add(C.byref(P), N.stream_ptr()), "sea_ib_add")
+
+
+def convert(src: torch.Tensor, dst: torch.Tensor) -> None:
+    """dst[r, c] = (dst dtype) src[r, c]; src float32, 2-D with unit inner stride."""
+    src, dst = _mat(src, "src"), _mat(dst, "dst")
+    assert src.dtype == torch.float32 and src.shape == dst.shape
+    N.check(N.lib().sea_convert_f32_to_act(src.data_ptr(), src.stride(0), dst.data_ptr(), dst.stride(0), src.shape[0],
+                                           src.shape[1], N.dtype_code(dst.dtype), N.stream_ptr()), "sea_convert_f32_to_act")
