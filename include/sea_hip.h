@@ -204,6 +204,32 @@ int sea_convert_f32_to_act(const float* src, int64_t lds, void* dst, int64_t ldd
                            void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
+ * Mean-squared-error loss and its gradient in one pass: loss[0] = mean((out - tgt)^2),
+ * dout = 2 * grad_scale / n * (out - tgt) (dout may be NULL for evaluation).  Replaces nn.MSELoss forward + backward
+ * (train/train_temporal.py:221,256-257).  `partial` is an f32 workspace of n_partial_cap >= 1 elements (<= 1024 used); the
+ * reduction order is fixed, so the loss is bitwise reproducible.  n % 4 == 0.
+ */
+int sea_mse_fwd_bwd(const float* out, const float* tgt, float* dout, float* loss, float* partial, int n_partial_cap,
+                    int64_t n, float grad_scale, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * relativeMSE (utils/train_utils.py:112-116) over the last dimension:
+ * y[row] = sum_d (pred - truth)^2 / (sum_d truth^2 + 1e-8), rows = product of the leading dimensions, d % 4 == 0.
+ */
+int sea_relative_mse(const float* pred, const float* truth, float* y, int64_t rows, int d, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * One AdamW step over a flat fp32 parameter buffer (torch.optim.AdamW as configured by initialize_optimizer,
+ * utils/train_utils.py:33-34: decoupled weight decay, bias-corrected moments; `step` counts from 1):
+ *     g' = grad_scale * g;  p *= 1 - lr*wd;  m = b1 m + (1-b1) g';  v = b2 v + (1-b2) g'^2;
+ *     p -= lr/(1-b1^step) * m / (sqrt(v)/sqrt(1-b2^step) + eps)
+ * and, in the same pass, the refreshed activation-dtype shadow of the parameters (shadow may be NULL).
+ * grad_scale = 1/world_size folds the data-parallel mean into the step.  n % 4 == 0.
+ */
+int sea_adamw_flat(float* p, const float* g, float* m, float* v, void* shadow, int shadow_dtype, int64_t n, float lr, float beta1,
+                   float beta2, float eps, float weight_decay, int step, float grad_scale, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
  * Self-test of the MFMA fragment maps this library relies on (16x16x32 bf16 and 16x16x4 f32, A/B/C lane maps):
  * multiplies exact small-integer matrices on the device and checks every element on the host.  Synchronous.
  * Returns 0 when both maps are as documented in cdna_hip_programming.md §3.

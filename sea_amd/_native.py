@@ -99,8 +99,13 @@ def lib() -> C.CDLL:
     L.sea_ib_add.argtypes = [C.POINTER(SeaIbParams), _vp]
     L.sea_convert_f32_to_act.argtypes = [_vp, _i64, _vp, _i64, _i64, _i64, C.c_int, _vp]
     L.sea_selftest_mfma.restype = C.c_int
+    L.sea_mse_fwd_bwd.argtypes = [_vp, _vp, _vp, _vp, _vp, C.c_int, _i64, C.c_float, _vp]
+    L.sea_relative_mse.argtypes = [_vp, _vp, _vp, _i64, C.c_int, _vp]
+    L.sea_adamw_flat.argtypes = [_vp, _vp, _vp, _vp, _vp, C.c_int, _i64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
+                                 C.c_int, C.c_float, _vp]
     for name in ("sea_gemm_grouped", "sea_qkv_rope_grouped", "sea_attention_fwd", "sea_rownorm", "sea_silu_outer",
-                 "sea_ib_add", "sea_convert_f32_to_act", "sea_device_info"):
+                 "sea_ib_add", "sea_convert_f32_to_act", "sea_device_info", "sea_mse_fwd_bwd", "sea_relative_mse",
+                 "sea_adamw_flat"):
         getattr(L, name).restype = C.c_int
     if L.sea_abi_version() != 1:
         raise NativeLibraryError(f"{LIB_PATH}: ABI version {L.sea_abi_version()} != 1; rebuild")
@@ -114,6 +119,7 @@ ABI_STRUCTS = (SeaGemmGroup, SeaQkvGroup, SeaQkvCommon, SeaAttnProblem, SeaAttnP
 EXPORTED_SYMBOLS = (
     "sea_abi_version", "sea_last_error", "sea_struct_sizes", "sea_device_info", "sea_gemm_grouped", "sea_qkv_rope_grouped",
     "sea_attention_fwd", "sea_rownorm", "sea_silu_outer", "sea_ib_add", "sea_convert_f32_to_act", "sea_selftest_mfma",
+    "sea_mse_fwd_bwd", "sea_relative_mse", "sea_adamw_flat",
 )
 
 

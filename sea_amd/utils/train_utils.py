@@ -1,0 +1,138 @@
+"""Host-side mirror of the hot-path half of the reference's utils/train_utils.py.
+
+Mirrored (same names and argument meaning): initialize_optimizer (:33-39), relativeMSE (:112-116),
+relativeMSE_with_time (:124-150), autoregressive_validation (:154-184), full_autoregressive_evaluation (:186-212, the
+encoded half; decoding through the spatial autoencoder, CSV and plots are out of scope — SURVEY.md §2), the
+error-tracker duck type (:50-110).  `rollout` is the loop both evaluation functions share (:202-209), with the
+reference-equivalent recompute mode and an exact KV-cache mode.
+"""
+from __future__ import annotations
+
+from typing import Any, Dict
+
+import torch
+
+from .. import _native as N
+
+
+# ------------------------------------------------------------------------------------------------ metrics
+def relativeMSE(predictions: torch.Tensor, truth: torch.Tensor, dim: int = -1) -> torch.Tensor:
+    """sum((p - t)^2, dim) / (sum(t^2, dim) + 1e-8) through sea_relative_mse (reference :112-116)."""
+    N.require_gpu(predictions, "predictions")
+    assert predictions.shape == truth.shape, "Predictions and truth must have the same shape"
+    nd = predictions.dim()
+    dim = dim % nd
+    p, t = predictions.float(), truth.float()
+    if dim != nd - 1:
+        p, t = p.movedim(dim, -1), t.movedim(dim, -1)
+    p, t = p.contiguous(), t.contiguous()
+    d = p.shape[-1]
+    rows = p.numel() // d
+    y = torch.empty(p.shape[:-1], device=p.device, dtype=torch.float32)
+    N.check(N.lib().sea_relative_mse(p.data_ptr(), t.data_ptr(), y.data_ptr(), rows, d, N.stream_ptr()), "sea_relative_mse")
+    return y
+
+
+def relativeMSE_with_time(predictions: torch.Tensor, truth: torch.Tensor, dim=2) -> torch.Tensor:
+    """Same ratio, summed over `dim` (reference :124-150)."""
+    return relativeMSE(predictions, truth, dim=dim)
+
+
+class SeaMSELoss(torch.nn.Module):
+    """nn.MSELoss() replacement whose forward AND backward are one fused kernel (sea_mse_fwd_bwd)."""
+
+    def forward(self, output: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
+        from ..autograd import MSELossFn
+
+        return MSELossFn.apply(output, target)
+
+
+# ------------------------------------------------------------------------------------------------ optimizer
+def initialize_optimizer(model, config):
+    """AdamW(lr=config['learning_rate'], betas=(0.9, 0.999), eps=1e-8, weight_decay=config.get('weight_decay', 0.0)) as one fused
+    kernel over the model's flat parameter buffer (reference :33-39).  Returns (optimizer, scheduler) when
+    config['scheduler'] == 'linear', like the reference."""
+    from ..optim import FlatAdamW
+
+    opt = FlatAdamW(model, lr=config['learning_rate'], betas=(0.9, 0.999), eps=1e-8, weight_decay=config.get('weight_decay', 0.0))
+    if config.get('scheduler', None) == 'linear':
+        sched = torch.optim.lr_scheduler.LinearLR(opt, start_factor=0.1, end_factor=1.0, total_iters=config['epoch_num'])
+        return opt, sched
+    return opt
+
+
+# ------------------------------------------------------------------------------------------------ rollout
+def rollout(model, x0: torch.Tensor, ib: torch.Tensor, n_steps: int, mode: str = "kv") -> torch.Tensor:
+    """Autoregressive rollout (reference :202-209): start from step 0 (x0 [B,1,F,E]), predict n_steps steps with
+    conditions ib[:, :n_steps].  Returns the predictions [B, n_steps, F, E].
+
+    mode='recompute' — what the reference does: the full forward over the growing prefix every step (O(N^2) token-forwards);
+    mode='kv'        — exact incremental decode with per-layer K/V caches (the model is strictly causal and
+                        prefix-consistent), O(N) token-forwards.
+    """
+    assert mode in ("recompute", "kv")
+    was_training = model.training
+    model.eval()
+    try:
+        with torch.no_grad():
+            if mode == "recompute":
+                a = x0
+                for i in range(n_steps):
+                    out = model(a, ib[:, : i + 1])
+                    a = torch.cat((a, out[:, -1:]), dim=1)
+                return a[:, 1:]
+            return model.engine(x0.device).rollout_kv(x0.float(), ib.float(), n_steps)
+    finally:
+        model.train(was_training)
+
+
+def autoregressive_validation(model, validationLoader, loss_fn, device):
+    """Autoregressive validation on the first sample of the first batch (reference :154-184)."""
+    model.eval()
+    with torch.no_grad():
+        data, target, _, ib = next(iter(validationLoader))
+        data, target, ib = data[0:1].to(device), target[0:1].to(device), ib[0:1].to(device)
+        pred = rollout(model, data[:, 0:1].contiguous(), ib, target.shape[1], mode=getattr(model, "rollout_mode", "kv"))
+        v_loss = loss_fn(pred, target)
+        v_rel_mse = relativeMSE_with_time(pred, target, dim=3).mean()
+    return v_loss.item(), v_rel_mse.item()
+
+
+def full_autoregressive_evaluation(model, dataLoader, loss_fn, device, processor, mesh_processor, config, epoch, plot_traj=True):
+    """Encoded-space half of the reference's evaluation (:186-212): rollout every batch and average relativeMSE.  The decoded
+    metric needs the spatial autoencoder and mesh un-patching (out of scope): `decoded_rel_mse` is NaN unless a
+    `processor` with a `decode_rollout(pred, target_original)` method is supplied."""
+    model.eval()
+    enc_sum, dec_sum, n_batches = 0.0, 0.0, 0
+    with torch.no_grad():
+        for data, target, original_data, ib in dataLoader:
+            data, target, ib = data.to(device), target.to(device), ib.to(device)
+            pred = rollout(model, data[:, 0:1].contiguous(), ib, target.shape[1], mode=getattr(model, "rollout_mode", "kv"))
+            enc_sum += relativeMSE(pred, target).mean().item()
+            if processor is not None and hasattr(processor, "decode_rollout"):
+                dec_sum += float(processor.decode_rollout(pred, original_data))
+            else:
+                dec_sum = float("nan")
+            n_batches += 1
+    n_batches = max(n_batches, 1)
+    return {"encoded_rel_mse": enc_sum / n_batches, "decoded_rel_mse": dec_sum / n_batches}
+
+
+# ------------------------------------------------------------------------------------------------ error trackers (duck type, :50-110)
+class NoOpErrorTracker:
+    def __init__(self, *args, **kwargs):
+        pass
+
+    def record_error(self, phase, epoch, metrics):
+        pass
+
+    def log_model(self, model, criterion, optimizer):
+        pass
+
+    def finish(self):
+        pass
+
+
+def create_error_tracker(use_wandb, project_name, run_name=None, config: Dict[str, Any] = None):
+    """wandb is not part of this build: always the no-op tracker (the reference falls back to it when wandb is missing)."""
+    return NoOpErrorTracker()
