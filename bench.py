@@ -1,0 +1,247 @@
+"""Benchmark of the SEA temporal-rollout hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`, one rank per GPU)
+
+Workload (BASELINE.json configs[1], "cfg2"): TemporalModel(1 layer, embed_dim 256, 8 heads, max_len 2024, scale_ratio 8,
+3 field groups, AdaLN, SEA exchange), synthetic cylinder_flow-shaped encoded fields x ~ N(0,1) [B, 2024, 3, 256] with one
+scalar condition per step, random-init weights (reference init N(0,0.02), seed 42), bf16 compute.
+One STEP = one full-context forward of the model over the 2024-step window = one iteration of the reference's rollout loop
+(utils/train_utils.py:203-207) at prefix length 2024 in its own recompute mode; it advances every trajectory of the batch by
+one time step.  value = trajectory-steps per second over all GPUs (weak scaling: B trajectories per GPU, no collective —
+rollout shards by trajectory).  The K timed steps replay the step's captured HIP graph.
+
+Extra objects in the JSON line:
+  roofline     — the dominant kernel of the step (largest share of device time): algorithmic FLOPs of one launch divided
+                 by its average launch duration, measured here with HIP events on the launch stream around every launch of
+                 the plan (a separate instrumented pass of the same K steps), against the dense bf16 MFMA peak (2.5 PFLOP/s,
+                 MI355X_MICROARCH.md).  traffic: HBM bytes per launch from rocprofv3 PMC passes when profiles/ holds them, else null.
+  cpu_baseline — the CPU oracle (oracle/sea_oracle.py, a restatement of the reference pinned by its golden vectors) timed on
+                 this host's cores on the same workload (bounded sample: 1 warm-up + 3 forwards), rank 0, N = 1 only.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA, MI355X (MI355X_MICROARCH.md "Chip-level parameters")
+
+
+def algorithmic_gflop(B, T, F, E, H, D, S, L, adaln=True):
+    """GEMM = 2mnk, causal attention over T(T+1)/2 pairs, redundant recomputation removed."""
+    M = B * T
+    A = (lambda d: 2 * M * (2 * d) + 2 * M * (2 * d) ** 2) if adaln else (lambda d: 0)
+    Q = lambda d: 4 * B * (T * (T + 1) // 2) * d  # noqa: E731
+    per_layer = (F * 8 * M * E * E + F * Q(E) + 2 * F * A(E) + (2 * F - 1) * 2 * M * E * D + F * A(D)
+                 + F * (F - 1) * (8 * M * D * D + Q(D) + 2 * M * D * E) + (16 * M + 16 * M * E) + F * 4 * M * E * S + F * 2 * M * E * E)
+    return (L * per_layer + F * A(E)) / 1e9
+
+
+def kernel_flops(name, B, T, F, E, H, D, S):
+    """Algorithmic FLOPs of ONE launch of the named plan record (per launch, all groups of the launch)."""
+    M = B * T
+    tri = T * (T + 1) // 2
+    table = {
+        "adaln.cond_gemm": 2 * M * ((2 * F + F) * (2 * E) ** 2 + F * (2 * D) ** 2),
+        "self.qkv_rope": F * 2 * M * E * 3 * E,
+        "self.attention": F * 4 * B * tri * E,
+        "self.out_proj": F * 2 * M * E * E,
+        "cross.down_old": F * 2 * M * E * D,
+        "mlp.fc1": F * 2 * M * E * S,
+        "mlp.fc2": F * 2 * M * E * S,
+        "proj": F * 2 * M * E * E,
+    }
+    if name in table:
+        return table[name]
+    if name.startswith("cross") and name.endswith("qkv_rope"):
+        return (F - 1) * 2 * M * D * 3 * D
+    if name.startswith("cross") and name.endswith("attention"):
+        return (F - 1) * 4 * B * tri * D
+    if name.startswith("cross") and name.endswith("proj_gelu"):
+        return (F - 1) * 2 * M * D * D
+    if name.startswith("cross") and name.endswith("up_sum"):
+        return (F - 1) * 2 * M * D * E
+    if name.startswith("cross") and name.endswith("down_new"):
+        return 2 * M * E * D
+    return 0
+
+
+def log(msg):
+    print(f"[bench] {msg}", file=sys.stderr, flush=True)
+
+
+def host_cores() -> int:
+    """CPU threads this process may really use: scheduler affinity, capped by the cgroup CPU quota when one is set."""
+    n = os.cpu_count() or 1
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                    n = min(n, max(1, q // per))
+            break
+        except Exception:
+            continue
+    return min(n, 64)
+
+
+def cpu_baseline(cfg_args, B, T):
+    """Oracle forward on the host cores (bounded: 1 warm-up + 3 timed forwards at the bench shape)."""
+    from oracle import sea_oracle as O
+
+    L, E, H, max_len, sr, src, F = cfg_args
+    cfg = O.OracleConfig(L, E, H, max_len, sr, src, F, 2, True, "adaln")
+    from oracle.recipe import param_schema
+
+    g = torch.Generator().manual_seed(42)
+    p = {}
+    for k, (shp, kind) in param_schema(cfg).items():
+        if kind == "lin_w":
+            p[k] = torch.randn(shp, generator=g) * 0.02
+        elif kind == "norm_w":
+            p[k] = torch.ones(shp)
+        else:
+            p[k] = torch.zeros(shp)
+    x = torch.randn(B, T, F, E, generator=torch.Generator().manual_seed(1234))
+    ib = torch.rand(B, T, 1, generator=torch.Generator().manual_seed(1235))
+    cores = host_cores()
+    torch.set_num_threads(cores)
+    log(f"cpu_baseline: oracle forward on {cores} host threads ...")
+    with torch.no_grad():
+        O.model_forward(x, ib, p, cfg)
+        n = 3
+        t0 = time.perf_counter()
+        for _ in range(n):
+            O.model_forward(x, ib, p, cfg)
+        dt = (time.perf_counter() - t0) / n
+    return {"value": B / dt, "unit": "trajectory-steps/s", "cores": cores, "kind": "port",
+            "sample": f"oracle fp32 forward, B={B}, T={T}, 1 warm-up + {n} timed passes, {dt:.3f} s/pass, torch CPU threads={cores}"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=1, help="trajectories per GPU")
+    ap.add_argument("--seq", type=int, default=2024)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-graph", action="store_true", help="replay launch by launch instead of the captured HIP graph")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus} (WORLD_SIZE={world})")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no GPU visible (the product path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist_mod.init_process_group("nccl", device_id=dev)
+        dist = dist_mod
+
+    from sea_amd.models.temporal import TemporalModel
+
+    L, E, H, max_len, sr, src, F = 1, 256, 8, 2024, 8, 0, 3
+    B, T = args.batch, args.seq
+    D, S = E // 2, E * sr
+    torch.manual_seed(42)
+    model = TemporalModel(L, E, H, max_len, sr, src, F, 2, 0.0, "sea", "learnable", "mlp", "add", 1, 1, True, "adaln")
+    model.set_compute_dtype(args.dtype)
+    model = model.to(dev).eval()
+    x = torch.randn(B, T, F, E, generator=torch.Generator().manual_seed(1234 + rank)).to(dev)
+    ib = torch.rand(B, T, 1, generator=torch.Generator().manual_seed(1235 + rank)).to(dev)
+    eng = model.engine(dev)
+
+    def step():
+        return eng.forward(x, ib) if args.no_graph else eng.forward_graphed(x, ib)
+
+    log(f"model built on {dev}; warm-up ({args.warmup} steps, {'plain' if args.no_graph else 'hip-graph'} replay)")
+    with torch.no_grad():
+        for _ in range(max(args.warmup, 1)):
+            out = step()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            out = step()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    assert torch.isfinite(out).all()
+
+    log(f"timed {args.steps} steps in {elapsed:.4f} s; per-launch event timing ...")
+    # ---- per-launch device times (HIP events on the launch stream), same number of steps
+    with torch.no_grad():
+        plan = eng.plan(B, T, "full")
+        plan.bind(x, ib, torch.empty_like(x))
+        plan.run()
+        torch.cuda.synchronize()
+        times = plan.time_records(iters=max(args.steps, 5))
+    total_ms = sum(t for _, t in times)
+    name, dom_ms = max(times, key=lambda nt: nt[1])
+    dom_flops = kernel_flops(name, B, T, F, E, H, D, S)
+    achieved = dom_flops / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        value = world * B * args.steps / elapsed
+        gflop = algorithmic_gflop(B, T, F, E, H, D, S, L)
+        line = {
+            "metric": "rollout steps/sec (full-context forward, recompute mode) on cylinder_flow-shaped fields",
+            "value": value, "unit": "trajectory-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": "cfg2: cylinder_flow temporal model E=256 H=8 F=3 L=1 adaln, forward-only rollout step at T=2024",
+                       "trajectories_per_gpu": B, "seq_len": T, "fields": F, "embed_dim": E, "replay": "plain" if args.no_graph else "hip-graph",
+                       "parallelism": f"replicas x{world} (rollout shards by trajectory, no collective)"},
+            "model_algorithmic_gflop_per_step": gflop,
+            "model_mfma_frac": gflop / (ms_per_step * 1e-3) / 1e3 / PEAK_BF16_TFLOPS,
+            "roofline": {"kernel": name, "bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / PEAK_BF16_TFLOPS, "traffic": None,
+                         "launch_ms": dom_ms, "launch_gflop": dom_flops / 1e9, "device_ms_all_launches": total_ms,
+                         "timing": "HIP events around every launch of the plan, separate instrumented pass"},
+            "launch_breakdown_ms": {n: round(t, 4) for n, t in times},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline((L, E, H, max_len, sr, src, F), B, T)
+        print(json.dumps(line))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -372,10 +372,13 @@ class Plan:
 
     # ------------------------------------------------------------------ binding and replay
     def bind(self, x: torch.Tensor, ib: torch.Tensor, out: torch.Tensor) -> None:
-        key = (x.data_ptr(), ib.data_ptr(), out.data_ptr())
+        self.bind_ptrs(x.data_ptr(), ib.data_ptr(), out.data_ptr())
+
+    def bind_ptrs(self, xp: int, cp: int, op: int) -> None:
+        """Point the plan at the caller's buffers: x [M, F, E] fp32, condition [M] fp32, out [M, F, E] fp32 (row m = b*T + t)."""
+        key = (xp, cp, op)
         if key == self._bound:
             return
-        xp, cp, op = key
         for tgt, field, off in self._x_patches:
             if isinstance(tgt, list):
                 tgt[field] = xp + off
@@ -406,6 +409,25 @@ class Plan:
             rc = r.fn(*r.args, stream)
             if rc != 0:
                 N.check(rc, r.name)
+
+    def time_records(self, iters: int = 10) -> List[Tuple[str, float]]:
+        """Average device time of every launch of the plan, in milliseconds, from HIP events recorded on the launch stream
+        around each launch (diagnostics / bench roofline)."""
+        stream = N.stream_ptr()
+        n = len(self.records)
+        tot = [0.0] * n
+        for _ in range(iters):
+            evs = [torch.cuda.Event(enable_timing=True) for _ in range(n + 1)]
+            evs[0].record()
+            for k, r in enumerate(self.records):
+                rc = r.fn(*r.args, stream)
+                if rc != 0:
+                    N.check(rc, r.name)
+                evs[k + 1].record()
+            torch.cuda.synchronize()
+            for k in range(n):
+                tot[k] += evs[k].elapsed_time(evs[k + 1])
+        return [(r.name, t / iters) for r, t in zip(self.records, tot)]
 
 
 def _fill_gemm(g, A, W, bias=None, R=None, C32=None, Cact=None, n_seg=1, a_seg_stride=0, act=0, bias_scale=1.0, ldr=None,
@@ -448,6 +470,7 @@ class TemporalEngine:
         self.rope_self = torch.view_as_real(blk.attn["self"][0].freqs_cis.to(device)).contiguous()
         self.rope_cross = torch.view_as_real(blk.cross_attn[0][0].freqs_cis.to(device)).contiguous()
         self._plans: Dict[Tuple, Plan] = {}
+        self._graphs: Dict[Tuple, Tuple] = {}
 
     def plan(self, B: int, T: int, mode: str = "full") -> Plan:
         key = (B, T, mode)
@@ -470,3 +493,50 @@ class TemporalEngine:
         p.bind(x, ib, out)
         p.run()
         return out
+
+    def forward_graphed(self, x: torch.Tensor, ib: torch.Tensor) -> torch.Tensor:
+        """Same forward replayed as ONE captured HIP graph (launch-bound regime: ~30 short kernels per layer).  The graph is
+        keyed on the input tensors' addresses: write new data INTO x / ib, the returned tensor is reused between calls."""
+        B, T, F, E = x.shape
+        assert x.is_contiguous() and ib.is_contiguous()
+        self.params.sync()
+        key = (B, T, x.data_ptr(), ib.data_ptr())
+        hit = self._graphs.get(key)
+        if hit is None:
+            out = torch.empty_like(x)
+            p = Plan(self, B, T, "full")  # a private plan: its workspace addresses are baked into the graph
+            p.bind(x, ib, out)
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                p.run()  # warm-up outside capture (one-time function attributes, lazy module loading)
+            torch.cuda.current_stream().wait_stream(side)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                p.run()
+            hit = (graph, out, p, x, ib)
+            self._graphs[key] = hit
+        hit[0].replay()
+        return hit[1]
+
+    def rollout_kv(self, x0: torch.Tensor, ib: torch.Tensor, n_steps: int) -> torch.Tensor:
+        """Exact KV-cache rollout (the loop of utils/train_utils.py:202-209 without recomputing the prefix): step s feeds the row
+        at position s, appends its K/V to the per-layer caches and attends over positions <= s.  x0 [B,1,F,E], ib [B,>=n_steps,1]
+        -> [B, n_steps, F, E].  The trajectory is kept time-major [n_steps+1, B, F, E] so that every step reads and writes
+        contiguous [B, F, E] slabs with no copies."""
+        B, one, F, E = x0.shape
+        assert one == 1 and ib.shape[0] == B and ib.shape[1] >= n_steps
+        if n_steps > self.model.max_len:
+            raise ValueError(f"rollout of {n_steps} steps exceeds max_len {self.model.max_len}")
+        self.params.sync()
+        traj = torch.empty(n_steps + 1, B, F, E, device=self.device, dtype=torch.float32)
+        traj[0].copy_(x0[:, 0])
+        cond = ib[:, :n_steps, 0].t().contiguous()  # [n_steps, B]
+        p = self.plan(B, 1, "step")
+        slab = B * F * E * 4
+        base, cbase = traj.data_ptr(), cond.data_ptr()
+        for s in range(n_steps):
+            p.set_position(s)
+            p.bind_ptrs(base + s * slab, cbase + s * B * 4, base + (s + 1) * slab)
+            p.run()
+        return traj[1:].permute(1, 0, 2, 3).contiguous()

@@ -184,3 +184,48 @@ def test_block_forward_unfused_matches_reference_golden(tag):
         blk = m.blocks[0](*[x[:, :, i] for i in range(F)], x_add=ib)
     assert rel_l2(torch.stack(ys, 2).cpu().numpy(), g[tag + ".y"]) < FP32_TOL
     assert rel_l2(torch.stack(blk, 2).cpu().numpy(), g[tag + ".block"]) < FP32_TOL
+
+
+@pytest.mark.parametrize("name", ["rollout8_adaln_f3", "rollout100_ln_f2", "rollout100_ln_f2_e256"])
+def test_rollout_kv_cache_matches_reference_golden(name):
+    """KV-cache decode is exact: it must reproduce the reference's recompute rollout."""
+    from sea_amd.utils.train_utils import rollout
+
+    g = load_golden(name)
+    cfg = cfg_from_meta(g["cfg"])
+    m = build(cfg, "fp32")
+    n = g["tgt"].shape[1]
+    pred = rollout(m, gpu(g["x0"]), gpu(g["ib"]), n, mode="kv")
+    assert pred.shape == g["pred"].shape
+    assert rel_l2(pred.cpu().numpy(), g["pred"]) < 2e-4
+    again = rollout(m, gpu(g["x0"]), gpu(g["ib"]), n, mode="kv")  # caches are reused: a second rollout must not see stale keys
+    assert torch.equal(pred, again)
+
+
+def test_rollout_kv_bf16_error_is_reported_and_bounded():
+    """bf16 tolerance over a 100-step autoregressive rollout (north_star: 'stated bf16 tolerance'): rel-L2 <= 1e-1 at 100 steps
+    on the E=256 multiphase-like model; the measured value is printed."""
+    from sea_amd.utils.train_utils import rollout
+
+    g = load_golden("rollout100_ln_f2_e256")
+    cfg = cfg_from_meta(g["cfg"])
+    m = build(cfg, "bf16")
+    pred = rollout(m, gpu(g["x0"]), gpu(g["ib"]), 100, mode="kv").cpu().numpy()
+    e8, e100 = rel_l2(pred[:, :8], g["pred"][:, :8]), rel_l2(pred, g["pred"])
+    print(f"bf16 KV rollout rel-L2: 8 steps {e8:.3e}, 100 steps {e100:.3e}")
+    assert e8 < 3e-2 and e100 < 1e-1
+
+
+def test_graph_replay_equals_plain_replay():
+    cfg = O.OracleConfig(1, 64, 4, 96, 8, 0, 3, 2, True, "adaln")
+    m = build(cfg, "bf16")
+    x, _, ib = recipe_inputs(2, 80, cfg, seed=11)
+    x, ib = x.cuda(), ib.cuda()
+    eng = m.engine()
+    with torch.no_grad():
+        a = eng.forward(x, ib).clone()
+        b = eng.forward_graphed(x, ib).clone()
+        x.add_(0.5)  # new data written into the same buffers is picked up by the replay
+        c = eng.forward_graphed(x, ib).clone()
+        d = eng.forward(x, ib)
+    assert torch.equal(a, b) and torch.equal(c, d) and not torch.equal(a, c)
