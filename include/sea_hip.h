@@ -50,8 +50,9 @@ int sea_device_info(int* cu_count, char* arch, int arch_len);
  * Grouped GEMM with fused epilogue:  for each group g
  *     acc = sum_{s < n_seg} A_s[M,K] . W[N,K]^T                      (W in nn.Linear layout [out, in])
  *     v   = acc + bias_scale * bias                                    (bias may be NULL)
- *     v   = act ? gelu_erf(v) : v
- *     v   = v + R                                                      (R fp32 residual, may be NULL)
+ *     act = 1 (forward GELU):   Z = (act dtype) v if Z != NULL (pre-activation kept for the backward); v = gelu_erf(v)
+ *     act = 2 (backward GELU):  v = v * gelu_erf'(Z)                   (Z = the saved pre-activation, required)
+ *     v   = v + R                                                      (R fp32 residual, may be NULL; R == C32 accumulates in place)
  *     C32 = v (fp32, may be NULL);  Cact = (act dtype) v (may be NULL)
  * Replaces nn.Linear / `+` / nn.GELU call sites: attention output projection + residual
  * (models/base_blocks.py:201,293; models/temporal.py:136), cross_down / cross_up (+GELU, + sum over j, + residual;
@@ -59,7 +60,9 @@ int sea_device_info(int* cu_count, char* arch, int arch_len);
  * proj (models/temporal.py:146), AdaLN cond_mlp.2 (models/base_blocks.py:339,344).
  * n_seg > 1 sums several A operands against the same W (sum_j cross_up(GELU(a_ij)) = cross_up applied to the
  * sum, done inside the MFMA accumulation): segment s is at A + s * a_seg_stride elements.
- * Requirements: K % 8 == 0; lda, ldw multiples of 8; A, W 16-byte aligned.
+ * The same entry point runs the data-gradient GEMMs of the backward pass (dX = dY . W with W^T kept as a shadow copy).
+ * Requirements: K % 8 == 0; N % 4 == 0; lda, ldw multiples of 8; ldr, ldc32, ldcact, ldz multiples of 4; all pointers
+ * 16-byte aligned.
  */
 #define SEA_MAX_GROUPS 16
 typedef struct {
@@ -69,10 +72,11 @@ typedef struct {
     const float* R;     /* f32 [M, N] row stride ldr, or NULL */
     float* C32;         /* f32 [M, N] row stride ldc32, or NULL */
     void* Cact;         /* act [M, N] row stride ldcact, or NULL */
+    void* Z;            /* act [M, N] row stride ldz: pre-activation out (act = 1, optional) / in (act = 2) */
     int64_t a_seg_stride;
-    int32_t lda, ldw, ldr, ldc32, ldcact;
+    int32_t lda, ldw, ldr, ldc32, ldcact, ldz;
     int32_t M, N, K, n_seg;
-    int32_t act;        /* 0 none, 1 GELU(erf) */
+    int32_t act;        /* 0 none, 1 GELU(erf) forward, 2 multiply by GELU'(Z) */
     float bias_scale;
 } SeaGemmGroup;
 
@@ -89,6 +93,7 @@ int sea_gemm_grouped(const SeaGemmGroup* groups, int n_groups, int dtype, void* 
  *   Qout  : act [B, H, T,   hd]   (scaled by q_scale = hd^-1/2 after rotation)
  *   Kout  : act [B, H, cap, hd]   written at row pos0 + t
  *   Vtout : act [B, H, hd, cap]   written at column pos0 + t  (V transposed: keys contiguous)
+ *   Vout  : act [B, H, cap, hd]   optional row-major copy of V (training: the attention backward reads it)
  * rope: f32 [>= pos0 + T, hd/2, 2] (cos, sin) — the reference's freqs_cis buffer viewed as real.
  */
 typedef struct {
@@ -98,6 +103,7 @@ typedef struct {
     void* Qout;
     void* Kout;
     void* Vtout;
+    void* Vout;
     int32_t lda, ldw;
     int32_t M, N, K;
     int32_t col0;

@@ -24,15 +24,15 @@ _vp, _i32, _i64, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 
 
 class SeaGemmGroup(C.Structure):
-    _fields_ = [("A", _vp), ("W", _vp), ("bias", _vp), ("R", _vp), ("C32", _vp), ("Cact", _vp),
+    _fields_ = [("A", _vp), ("W", _vp), ("bias", _vp), ("R", _vp), ("C32", _vp), ("Cact", _vp), ("Z", _vp),
                 ("a_seg_stride", _i64),
-                ("lda", _i32), ("ldw", _i32), ("ldr", _i32), ("ldc32", _i32), ("ldcact", _i32),
+                ("lda", _i32), ("ldw", _i32), ("ldr", _i32), ("ldc32", _i32), ("ldcact", _i32), ("ldz", _i32),
                 ("M", _i32), ("N", _i32), ("K", _i32), ("n_seg", _i32),
                 ("act", _i32), ("bias_scale", _f32)]
 
 
 class SeaQkvGroup(C.Structure):
-    _fields_ = [("A", _vp), ("W", _vp), ("bias", _vp), ("Qout", _vp), ("Kout", _vp), ("Vtout", _vp),
+    _fields_ = [("A", _vp), ("W", _vp), ("bias", _vp), ("Qout", _vp), ("Kout", _vp), ("Vtout", _vp), ("Vout", _vp),
                 ("lda", _i32), ("ldw", _i32), ("M", _i32), ("N", _i32), ("K", _i32), ("col0", _i32)]
 
 

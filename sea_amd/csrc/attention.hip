@@ -34,9 +34,7 @@ struct AttnCfg {
 template <typename T, int HD>
 __global__ __launch_bounds__(256) void attention_fwd_kernel(const SeaAttnParams P) {
     using C = AttnCfg<T, HD>;
-    __shared__ __attribute__((aligned(16))) char smem[C::LDS_BYTES];
-    char* sK = smem;
-    char* sV = smem + C::K_BYTES;
+    __shared__ __attribute__((aligned(16))) char smem[2 * C::LDS_BYTES];  // double-buffered K and V^T tiles
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 15, g = lane >> 4;
@@ -65,49 +63,98 @@ __global__ __launch_bounds__(256) void attention_fwd_kernel(const SeaAttnParams 
     f32x4 oacc[C::NDB];
 #pragma unroll
     for (int d = 0; d < C::NDB; ++d) oacc[d] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float m_i = -INFINITY, l_i = 0.f;
+    float m_i = -INFINITY, l_i = 0.f;  // running max of the scores and this lane's partial row sum
 
     const int limit = P.q_pos0 + q_idx + P.src_len;                       // keys j <= limit are visible to this lane's query
     const int blk_last = P.q_pos0 + qt * 64 + 63 + P.src_len;             // last key any row of the workgroup may see
     int n_kt = blk_last / 64 + 1;
     const int n_kt_all = (Tk + 63) / 64;
     n_kt = n_kt < n_kt_all ? n_kt : n_kt_all;
-    const int wave_last = P.q_pos0 + q_row0 + 15 + P.src_len;             // last key this wave's rows may see
+    const int wave_first = P.q_pos0 + q_row0 + P.src_len;                 // last key the wave's FIRST row may see
+    const int wave_last = wave_first + 15;                                // last key any of the wave's rows may see
 
-    for (int kt = 0; kt < n_kt; ++kt) {
-        __syncthreads();  // everyone is done reading the previous tile
-        // ---- stage K tile: 64 keys x HD
-        {
-            constexpr int CPR = HD / C::EPC;  // 16-byte chunks per key row
-            for (int idx = tid; idx < 64 * CPR; idx += 256) {
-                const int rr = idx / CPR, cc = idx - rr * CPR;
-                const int key = kt * 64 + rr;
-                uint4 v = make_uint4(0, 0, 0, 0);
-                if (key < Tk) v = *reinterpret_cast<const uint4*>(Kg + (int64_t)key * HD + cc * C::EPC);
-                *reinterpret_cast<uint4*>(sK + rr * C::K_STRIDE + cc * 16) = v;
-            }
-        }
-        // ---- stage V^T tile: HD rows x 64 keys (zero beyond Tk: 0 * garbage must stay 0)
-        {
-            constexpr int CPR = 64 / C::EPC;
-            for (int idx = tid; idx < HD * CPR; idx += 256) {
-                const int d = idx / CPR, cc = idx - d * CPR;
-                const int key0 = kt * 64 + cc * C::EPC;
-                uint4 v = make_uint4(0, 0, 0, 0);
-                if (key0 + C::EPC <= Tk) {
-                    v = *reinterpret_cast<const uint4*>(Vg + (int64_t)d * cap + key0);
-                } else if (key0 < Tk) {
-                    T tmp[C::EPC];
+    // ---- K/V tile staging through registers (issue-early / write-late, cdna_hip_programming.md T14): the global loads of
+    // tile kt+1 are issued before the MFMAs of tile kt and written to the OTHER LDS buffer after them; one barrier per tile.
+    constexpr int K_CPR = HD / C::EPC;                       // 16-byte chunks per key row
+    constexpr int V_CPR = 64 / C::EPC;                       // 16-byte chunks per d row of the V^T tile
+    constexpr int NKR = (64 * K_CPR + 255) / 256;            // chunks per thread
+    constexpr int NVR = (HD * V_CPR + 255) / 256;
+    uint4 rk[NKR], rv[NVR];
+    // per-thread chunk coordinates, fixed for the whole kernel
+    int k_row[NKR], k_goff[NKR], k_soff[NKR], v_key[NVR], v_soff[NVR];
+    int64_t v_goff[NVR];
 #pragma unroll
-                    for (int e = 0; e < C::EPC; ++e) tmp[e] = key0 + e < Tk ? Vg[(int64_t)d * cap + key0 + e] : from_f32<T>(0.f);
-                    v = *reinterpret_cast<const uint4*>(tmp);
+    for (int u = 0; u < NKR; ++u) {
+        const int idx = tid + u * 256;
+        const int rr = idx / K_CPR, cc = idx - rr * K_CPR;
+        k_row[u] = idx < 64 * K_CPR ? rr : -1;
+        k_goff[u] = rr * HD + cc * C::EPC;
+        k_soff[u] = rr * C::K_STRIDE + cc * 16;
+    }
+#pragma unroll
+    for (int u = 0; u < NVR; ++u) {
+        const int idx = tid + u * 256;
+        const int d = idx / V_CPR, cc = idx - d * V_CPR;
+        v_key[u] = idx < HD * V_CPR ? cc * C::EPC : -1;
+        v_goff[u] = (int64_t)d * cap + cc * C::EPC;
+        v_soff[u] = d * C::V_STRIDE + cc * 16;
+    }
+    auto load_tile = [&](int kt) {
+        const T* Kt = Kg + (int64_t)kt * 64 * HD;
+        const T* Vt = Vg + kt * 64;
+        if ((kt + 1) * 64 <= Tk) {  // block-uniform fast path: the whole tile is inside the key range
+#pragma unroll
+            for (int u = 0; u < NKR; ++u)
+                if (k_row[u] >= 0) rk[u] = *reinterpret_cast<const uint4*>(Kt + k_goff[u]);
+#pragma unroll
+            for (int u = 0; u < NVR; ++u)
+                if (v_key[u] >= 0) rv[u] = *reinterpret_cast<const uint4*>(Vt + v_goff[u]);
+        } else {  // last, partial tile: zero beyond Tk (0 * garbage must stay 0)
+#pragma unroll
+            for (int u = 0; u < NKR; ++u) {
+                rk[u] = make_uint4(0, 0, 0, 0);
+                if (k_row[u] >= 0 && kt * 64 + k_row[u] < Tk) rk[u] = *reinterpret_cast<const uint4*>(Kt + k_goff[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < NVR; ++u) {
+                rv[u] = make_uint4(0, 0, 0, 0);
+                const int key0 = kt * 64 + v_key[u];
+                if (v_key[u] >= 0 && key0 < Tk) {
+                    if (key0 + C::EPC <= Tk) {
+                        rv[u] = *reinterpret_cast<const uint4*>(Vt + v_goff[u]);
+                    } else {
+                        T tmp[C::EPC];
+#pragma unroll
+                        for (int e = 0; e < C::EPC; ++e) tmp[e] = key0 + e < Tk ? Vt[v_goff[u] + e] : from_f32<T>(0.f);
+                        rv[u] = *reinterpret_cast<const uint4*>(tmp);
+                    }
                 }
-                *reinterpret_cast<uint4*>(sV + d * C::V_STRIDE + cc * 16) = v;
             }
         }
-        __syncthreads();
-        if (kt * 64 > wave_last) continue;  // wave-uniform: nothing visible to this wave in this tile
+    };
+    auto store_tile = [&](int buf) {
+        char* dK = smem + buf * C::LDS_BYTES;
+        char* dV = dK + C::K_BYTES;
+#pragma unroll
+        for (int u = 0; u < NKR; ++u)
+            if (k_row[u] >= 0) *reinterpret_cast<uint4*>(dK + k_soff[u]) = rk[u];
+#pragma unroll
+        for (int u = 0; u < NVR; ++u)
+            if (v_key[u] >= 0) *reinterpret_cast<uint4*>(dV + v_soff[u]) = rv[u];
+    };
 
+    // lane-constant LDS offsets of the fragments
+    int k_frag_off[C::KCH][C::NB];
+#pragma unroll
+    for (int kc = 0; kc < C::KCH; ++kc)
+#pragma unroll
+        for (int be = 0; be < C::NB; ++be)
+            k_frag_off[kc][be] = (kc * C::CK + (r >> 2) * (4 * C::NB) + be * 4 + (r & 3)) * C::K_STRIDE + g * 16;
+    const int v_frag_off = r * C::V_STRIDE + g * 16;
+
+    // one 64-key tile for this wave; MASK = the tile crosses the causal diagonal or the end of the keys
+    auto process = [&](const char* sK, const char* sV, int kt, auto mask_tag) {
+        constexpr bool MASK = decltype(mask_tag)::value;
         // ---- S^T = K . Q^T
         f32x4 s[C::KCH][C::NB];
 #pragma unroll
@@ -115,17 +162,15 @@ __global__ __launch_bounds__(256) void attention_fwd_kernel(const SeaAttnParams 
 #pragma unroll
             for (int be = 0; be < C::NB; ++be) {
                 s[kc][be] = f32x4{0.f, 0.f, 0.f, 0.f};
-                const int key_local = kc * C::CK + (r >> 2) * (4 * C::NB) + be * 4 + (r & 3);
 #pragma unroll
                 for (int c = 0; c < C::NCH; ++c) {
-                    const int d0 = c * C::CK + g * C::EPC;
                     uint4 a = make_uint4(0, 0, 0, 0);
-                    if (d0 < HD) a = *reinterpret_cast<const uint4*>(sK + key_local * C::K_STRIDE + d0 * (int)sizeof(T));
+                    if (c * C::CK + g * C::EPC < HD) a = *reinterpret_cast<const uint4*>(sK + k_frag_off[kc][be] + c * C::CK * (int)sizeof(T));
                     mma16<T>(a, qf[c], s[kc][be]);
                 }
             }
         }
-        // ---- mask, online softmax (this lane: query q_idx, keys kt*64 + kc*CK + g*EPC + be*4 + reg)
+        // ---- online softmax, exp(s - m) evaluated as 2^(s*log2e - m*log2e): one v_fma + one v_exp per score (this lane: query q_idx, keys kt*64 + kc*CK + g*EPC + be*4 + reg)
         float mx = -INFINITY;
 #pragma unroll
         for (int kc = 0; kc < C::KCH; ++kc)
@@ -133,16 +178,18 @@ __global__ __launch_bounds__(256) void attention_fwd_kernel(const SeaAttnParams 
             for (int be = 0; be < C::NB; ++be)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const int key = kt * 64 + kc * C::CK + g * C::EPC + be * 4 + q;
-                    const bool ok = key <= limit && key < Tk;
-                    const float v = ok ? s[kc][be][q] : -INFINITY;
-                    s[kc][be][q] = v;
-                    mx = fmaxf(mx, v);
+                    if constexpr (MASK) {
+                        const int key = kt * 64 + kc * C::CK + g * C::EPC + be * 4 + q;
+                        if (!(key <= limit && key < Tk)) s[kc][be][q] = -INFINITY;
+                    }
+                    mx = fmaxf(mx, s[kc][be][q]);
                 }
         mx = fmaxf(mx, __shfl_xor(mx, 16));
         mx = fmaxf(mx, __shfl_xor(mx, 32));
         const float m_new = fmaxf(m_i, mx);
-        const float alpha = __expf(m_i - m_new);  // first visible tile: exp(-inf) = 0
+        constexpr float LOG2E = 1.4426950408889634f;
+        const float alpha = __builtin_amdgcn_exp2f((m_i - m_new) * LOG2E);  // first visible tile: 2^(-inf) = 0
+        const float neg_ms = -m_new * LOG2E;
         float psum = 0.f;
 #pragma unroll
         for (int kc = 0; kc < C::KCH; ++kc)
@@ -150,7 +197,7 @@ __global__ __launch_bounds__(256) void attention_fwd_kernel(const SeaAttnParams 
             for (int be = 0; be < C::NB; ++be)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const float p = __expf(s[kc][be][q] - m_new);
+                    const float p = __builtin_amdgcn_exp2f(fmaf(s[kc][be][q], LOG2E, neg_ms));
                     s[kc][be][q] = p;
                     psum += p;
                 }
@@ -158,7 +205,6 @@ __global__ __launch_bounds__(256) void attention_fwd_kernel(const SeaAttnParams 
         m_i = m_new;
 #pragma unroll
         for (int d = 0; d < C::NDB; ++d) oacc[d] *= alpha;
-
         // ---- O^T += V^T . P^T
 #pragma unroll
         for (int kc = 0; kc < C::KCH; ++kc) {
@@ -172,12 +218,29 @@ __global__ __launch_bounds__(256) void attention_fwd_kernel(const SeaAttnParams 
             }
 #pragma unroll
             for (int d = 0; d < C::NDB; ++d) {
-                const int drow = d * 16 + r;
                 uint4 a = make_uint4(0, 0, 0, 0);
-                if (drow < HD) a = *reinterpret_cast<const uint4*>(sV + drow * C::V_STRIDE + (kc * C::CK + g * C::EPC) * (int)sizeof(T));
+                if (d * 16 + r < HD) a = *reinterpret_cast<const uint4*>(sV + v_frag_off + d * 16 * C::V_STRIDE + kc * C::CK * (int)sizeof(T));
                 mma16<T>(a, pf, oacc[d]);
             }
         }
+    };
+
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+    for (int kt = 0; kt < n_kt; ++kt) {
+        const char* sK = smem + (kt & 1) * C::LDS_BYTES;
+        const char* sV = sK + C::K_BYTES;
+        const bool more = kt + 1 < n_kt;
+        if (more) load_tile(kt + 1);
+        const int tile_last = kt * 64 + 63;
+        if (tile_last <= wave_first && tile_last < Tk) {
+            process(sK, sV, kt, std::false_type{});   // fully visible to every row of the wave: no masking
+        } else if (kt * 64 <= wave_last) {
+            process(sK, sV, kt, std::true_type{});    // diagonal / last tile
+        }                                             // else: nothing visible to this wave (wave-uniform)
+        if (more) store_tile((kt + 1) & 1);
+        __syncthreads();
     }
 
     // ---- finalize: this lane holds O^T[d = 16*db + 4g + reg][query q_idx]

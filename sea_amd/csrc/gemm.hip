@@ -47,25 +47,43 @@ __global__ __launch_bounds__(256) void gemm_grouped_kernel(const GemmLaunch L) {
     const float* R = G.R;
     float* C32 = G.C32;
     T* Cact = static_cast<T*>(G.Cact);
-    const bool do_gelu = G.act == 1;
+    T* Z = static_cast<T*>(G.Z);
+    const int act = G.act;
 #pragma unroll
     for (int j = 0; j < C::NI; ++j) {
-        const int n = ml.n0 + wn * C::WTN + j * 16 + r;
-        const bool nok = n < G.N;
-        const float bv = (bias != nullptr && nok) ? bias[n] * G.bias_scale : 0.f;
+        const int n = ml.n0 + wn * C::WTN + j * 16 + g * 4;  // this lane's 4 consecutive output columns
+        if (n >= G.N) continue;                               // N % 4 == 0: the 4 columns are valid together
+        float bv[4] = {0.f, 0.f, 0.f, 0.f};
+        if (bias != nullptr) {
+            load4(bias + n, bv);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) bv[q] *= G.bias_scale;
+        }
 #pragma unroll
         for (int i = 0; i < C::MI; ++i) {
+            const int m = ml.m0 + wm * C::WTM + i * 16 + r;
+            if (m >= G.M) continue;
+            float v[4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int m = ml.m0 + wm * C::WTM + i * 16 + g * 4 + q;
-                if (nok && m < G.M) {
-                    float v = acc[i][j][q] + bv;
-                    if (do_gelu) v = gelu_erf(v);
-                    if (R != nullptr) v += R[(int64_t)m * G.ldr + n];
-                    if (C32 != nullptr) C32[(int64_t)m * G.ldc32 + n] = v;
-                    if (Cact != nullptr) Cact[(int64_t)m * G.ldcact + n] = from_f32<T>(v);
-                }
+            for (int q = 0; q < 4; ++q) v[q] = acc[i][j][q] + bv[q];
+            if (act == 1) {
+                if (Z != nullptr) store4(Z + (int64_t)m * G.ldz + n, v[0], v[1], v[2], v[3]);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] = gelu_erf(v[q]);
+            } else if (act == 2) {
+                float z[4];
+                load4(Z + (int64_t)m * G.ldz + n, z);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] *= gelu_erf_grad(z[q]);
             }
+            if (R != nullptr) {
+                float rv[4];
+                load4(R + (int64_t)m * G.ldr + n, rv);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] += rv[q];
+            }
+            if (C32 != nullptr) store4(C32 + (int64_t)m * G.ldc32 + n, v[0], v[1], v[2], v[3]);
+            if (Cact != nullptr) store4(Cact + (int64_t)m * G.ldcact + n, v[0], v[1], v[2], v[3]);
         }
     }
 }
@@ -97,47 +115,45 @@ __global__ __launch_bounds__(256) void qkv_rope_kernel(const QkvLaunch L) {
     const float2* rope = reinterpret_cast<const float2*>(L.c.rope);
     T* Qo = static_cast<T*>(G.Qout);
     T* Ko = static_cast<T*>(G.Kout);
-    T* Vo = static_cast<T*>(G.Vtout);
+    T* Vto = static_cast<T*>(G.Vtout);
+    T* Vo = static_cast<T*>(G.Vout);
 #pragma unroll
     for (int j = 0; j < C::NI; ++j) {
-        const int n = ml.n0 + wn * C::WTN + j * 16 + r;
-        const bool nok = n < G.N;
-        const int nc = nok ? n : G.N - 1;
-        const float bv = G.bias != nullptr ? G.bias[nc] : 0.f;
-        const int nn = G.col0 + nc;      // column in the virtual [q | k | v] row
+        const int n = ml.n0 + wn * C::WTN + j * 16 + g * 4;  // 4 consecutive columns = two (even, odd) rotation pairs
+        if (n >= G.N) continue;
+        float bv[4] = {0.f, 0.f, 0.f, 0.f};
+        if (G.bias != nullptr) load4(G.bias + n, bv);
+        const int nn = G.col0 + n;       // column in the virtual [q | k | v] row; hd % 4 == 0 keeps the 4 columns in one head
         const int part = nn / Ea;        // 0 q, 1 k, 2 v
         const int hcol = nn - part * Ea;
         const int h = hcol / hd;
         const int dd = hcol - h * hd;
-        const bool odd = (dd & 1) != 0;
 #pragma unroll
         for (int i = 0; i < C::MI; ++i) {
+            const int m = ml.m0 + wm * C::WTM + i * 16 + r;
+            if (m >= G.M) continue;
+            const int b = m / Tlen;
+            const int tt = m - b * Tlen;
+            const int pos = L.c.pos0 + tt;
+            float v[4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int m = ml.m0 + wm * C::WTM + i * 16 + g * 4 + q;
-                const int mc = m < G.M ? m : G.M - 1;
-                const int b = mc / Tlen;
-                const int tt = mc - b * Tlen;
-                const int pos = L.c.pos0 + tt;
-                float v = acc[i][j][q] + bv;
-                // the (even, odd) pair of a rotation sits in adjacent lanes (columns n, n^1): every lane takes part
-                const float partner = __shfl_xor(v, 1);
-                if (part < 2) {
-                    const float2 cs = rope[(int64_t)pos * hd2 + (dd >> 1)];
-                    // (xe + i xo)(c + i s): even' = xe c - xo s ; odd' = xe s + xo c
-                    v = odd ? (partner * cs.y + v * cs.x) : (v * cs.x - partner * cs.y);
-                    if (part == 0) v *= L.c.q_scale;
+            for (int q = 0; q < 4; ++q) v[q] = acc[i][j][q] + bv[q];
+            const int64_t bh = (int64_t)b * H + h;
+            if (part < 2) {
+                // (xe + i xo)(c + i s): even' = xe c - xo s ; odd' = xe s + xo c   (fp32, before rounding)
+                const float2 c0 = rope[(int64_t)pos * hd2 + (dd >> 1)];
+                const float2 c1 = rope[(int64_t)pos * hd2 + (dd >> 1) + 1];
+                float o[4] = {v[0] * c0.x - v[1] * c0.y, v[0] * c0.y + v[1] * c0.x, v[2] * c1.x - v[3] * c1.y, v[2] * c1.y + v[3] * c1.x};
+                if (part == 0) {
+                    const float sc = L.c.q_scale;
+                    store4(Qo + (bh * Tlen + tt) * hd + dd, o[0] * sc, o[1] * sc, o[2] * sc, o[3] * sc);
+                } else {
+                    store4(Ko + (bh * cap + pos) * hd + dd, o[0], o[1], o[2], o[3]);
                 }
-                if (nok && m < G.M) {
-                    const int64_t bh = (int64_t)b * H + h;
-                    if (part == 0) {
-                        Qo[(bh * Tlen + tt) * hd + dd] = from_f32<T>(v);
-                    } else if (part == 1) {
-                        Ko[(bh * cap + pos) * hd + dd] = from_f32<T>(v);
-                    } else {
-                        Vo[(bh * hd + dd) * cap + pos] = from_f32<T>(v);
-                    }
-                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) Vto[(bh * hd + dd + q) * cap + pos] = from_f32<T>(v[q]);
+                if (Vo != nullptr) store4(Vo + (bh * cap + pos) * hd + dd, v[0], v[1], v[2], v[3]);
             }
         }
     }
@@ -170,6 +186,11 @@ extern "C" int sea_gemm_grouped(const SeaGemmGroup* groups, int n_groups, int dt
         SEA_REQUIRE(sea_aligned16(G.A) && sea_aligned16(G.W), "sea_gemm_grouped[%d]: A/W not 16-byte aligned", i);
         SEA_REQUIRE(G.lda >= G.K && G.ldw >= G.K, "sea_gemm_grouped[%d]: leading dimension smaller than K", i);
         SEA_REQUIRE(G.C32 || G.Cact, "sea_gemm_grouped[%d]: no output", i);
+        SEA_REQUIRE(G.N % 4 == 0, "sea_gemm_grouped[%d]: N=%d must be a multiple of 4", i, G.N);
+        SEA_REQUIRE(G.act >= 0 && G.act <= 2 && (G.act != 2 || G.Z) && (!G.Z || (G.ldz >= G.N && G.ldz % 4 == 0)), "sea_gemm_grouped[%d]: bad act/Z", i);
+        SEA_REQUIRE(sea_aligned16(G.bias) && sea_aligned16(G.R) && sea_aligned16(G.C32) && sea_aligned16(G.Cact) && sea_aligned16(G.Z),
+                    "sea_gemm_grouped[%d]: bias/R/C32/Cact/Z must be 16-byte aligned", i);
+        SEA_REQUIRE((!G.R || G.ldr % 4 == 0) && (!G.C32 || G.ldc32 % 4 == 0) && (!G.Cact || G.ldcact % 4 == 0), "sea_gemm_grouped[%d]: output strides must be multiples of 4", i);
         SEA_REQUIRE((!G.R || G.ldr >= G.N) && (!G.C32 || G.ldc32 >= G.N) && (!G.Cact || G.ldcact >= G.N), "sea_gemm_grouped[%d]: output stride < N", i);
         t128 += (long)((G.M + 127) / 128) * ((G.N + 127) / 128);
         t64 += (long)((G.M + 63) / 64) * ((G.N + 63) / 64);
@@ -206,7 +227,7 @@ extern "C" int sea_qkv_rope_grouped(const SeaQkvGroup* groups, int n_groups, con
     SEA_REQUIRE(groups != nullptr && common != nullptr && n_groups >= 1 && n_groups <= SEA_MAX_GROUPS, "sea_qkv_rope_grouped: bad arguments");
     SEA_REQUIRE(dtype == SEA_F32 || dtype == SEA_BF16, "sea_qkv_rope_grouped: bad dtype %d", dtype);
     const SeaQkvCommon& c = *common;
-    SEA_REQUIRE(c.rope != nullptr && c.H >= 1 && c.hd >= 2 && c.hd % 2 == 0 && c.T >= 1 && c.pos0 >= 0 && c.cap >= c.pos0 + c.T,
+    SEA_REQUIRE(c.rope != nullptr && c.H >= 1 && c.hd >= 4 && c.hd % 4 == 0 && c.T >= 1 && c.pos0 >= 0 && c.cap >= c.pos0 + c.T,
                 "sea_qkv_rope_grouped: bad common H=%d hd=%d T=%d pos0=%d cap=%d", c.H, c.hd, c.T, c.pos0, c.cap);
     const int epc = dtype == SEA_BF16 ? 8 : 4;
     const int Ea = c.H * c.hd;
@@ -214,12 +235,14 @@ extern "C" int sea_qkv_rope_grouped(const SeaQkvGroup* groups, int n_groups, con
     for (int i = 0; i < n_groups; ++i) {
         const SeaQkvGroup& G = groups[i];
         SEA_REQUIRE(G.A && G.W, "sea_qkv_rope_grouped[%d]: null operand", i);
-        SEA_REQUIRE(G.M >= 1 && G.M % c.T == 0 && G.N >= 2 && G.N % 2 == 0 && G.K >= 8 && G.K % 8 == 0, "sea_qkv_rope_grouped[%d]: bad shape M=%d N=%d K=%d T=%d", i, G.M, G.N, G.K, c.T);
+        SEA_REQUIRE(G.M >= 1 && G.M % c.T == 0 && G.N >= 4 && G.N % 4 == 0 && G.K >= 8 && G.K % 8 == 0, "sea_qkv_rope_grouped[%d]: bad shape M=%d N=%d K=%d T=%d", i, G.M, G.N, G.K, c.T);
         SEA_REQUIRE(G.lda % epc == 0 && G.ldw % epc == 0 && G.lda >= G.K && G.ldw >= G.K, "sea_qkv_rope_grouped[%d]: bad strides", i);
         SEA_REQUIRE(sea_aligned16(G.A) && sea_aligned16(G.W), "sea_qkv_rope_grouped[%d]: A/W not 16-byte aligned", i);
-        SEA_REQUIRE(G.col0 >= 0 && G.col0 % 2 == 0 && G.col0 + G.N <= 3 * Ea, "sea_qkv_rope_grouped[%d]: columns [%d,%d) outside [0,%d)", i, G.col0, G.col0 + G.N, 3 * Ea);
+        SEA_REQUIRE(G.col0 >= 0 && G.col0 % 4 == 0 && G.col0 + G.N <= 3 * Ea, "sea_qkv_rope_grouped[%d]: columns [%d,%d) outside [0,%d)", i, G.col0, G.col0 + G.N, 3 * Ea);
         const bool hasq = G.col0 < Ea, hask = G.col0 < 2 * Ea && G.col0 + G.N > Ea, hasv = G.col0 + G.N > 2 * Ea;
         SEA_REQUIRE((!hasq || G.Qout) && (!hask || G.Kout) && (!hasv || G.Vtout), "sea_qkv_rope_grouped[%d]: missing output pointer", i);
+        SEA_REQUIRE(sea_aligned16(G.bias) && sea_aligned16(G.Qout) && sea_aligned16(G.Kout) && sea_aligned16(G.Vtout) && sea_aligned16(G.Vout),
+                    "sea_qkv_rope_grouped[%d]: pointers must be 16-byte aligned", i);
         t128 += (long)((G.M + 127) / 128) * ((G.N + 127) / 128);
         t64 += (long)((G.M + 63) / 64) * ((G.N + 63) / 64);
     }

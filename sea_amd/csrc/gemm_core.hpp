@@ -8,6 +8,10 @@
 // stored at chunk position c ^ (r & 7): the ds_read_b128 of a fragment (16 rows x the same chunk) then covers all
 // 16 bank slots of the 256-byte bank row (conflict-free; MI355X_MICROARCH.md §LDS, cdna_hip_programming.md T2)
 // and the ds_write_b128 of the staging pass (8 lanes per row) stays a permutation of one row's 32 banks.
+// The MFMA computes the TRANSPOSED 16x16 tile (W fragment as the A operand, activation fragment as B): in the C/D map
+// (col = lane & 15, row = 4*(lane >> 4) + reg) the lane's column is then an output ROW m and its 4 registers are 4
+// CONSECUTIVE output columns n, so every epilogue access is a 16-byte (f32) or 8-byte (bf16) vector and a RoPE pair sits
+// in one lane.  acc[i][j][q] = C[m0 + wm*WTM + 16 i + (lane & 15)][n0 + wn*WTN + 16 j + 4 (lane >> 4) + q].
 // Staging is through registers (global_load_dwordx4 -> ds_write_b128) with the split of T14: the loads of tile
 // k+1 are issued before the MFMAs of tile k and written to the other LDS buffer after them; one barrier per
 // K-tile.
@@ -98,7 +102,7 @@ struct GemmMainloop {
 #pragma unroll
             for (int i = 0; i < C::MI; ++i)
 #pragma unroll
-                for (int j = 0; j < C::NI; ++j) mma16<T>(af[i], bf[j], acc[i][j]);
+                for (int j = 0; j < C::NI; ++j) mma16<T>(bf[j], af[i], acc[i][j]);  // W rows as MFMA-A: C^T, see below
         }
     }
 

@@ -81,6 +81,10 @@ template <>
 __device__ __forceinline__ __bf16 from_f32<__bf16>(float v) { return (__bf16)v; }
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// d/dx gelu_erf(x) = Phi(x) + x phi(x)
+__device__ __forceinline__ float gelu_erf_grad(float x) {
+    return 0.5f * (1.0f + erff(x * 0.70710678118654752440f)) + x * 0.39894228040143267794f * __expf(-0.5f * x * x);
+}
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
 
 __device__ __forceinline__ float wave_sum(float v) {

@@ -194,7 +194,7 @@ class Plan:
         for g, d in zip(arr, groups):
             A, W = d["A"], d["W"]
             g.A, g.W, g.bias = A.data_ptr(), W.data_ptr(), d["bias"].data_ptr()
-            g.Qout, g.Kout, g.Vtout = N.ptr(d.get("Q")), N.ptr(d.get("K")), N.ptr(d.get("Vt"))
+            g.Qout, g.Kout, g.Vtout, g.Vout = N.ptr(d.get("Q")), N.ptr(d.get("K")), N.ptr(d.get("Vt")), N.ptr(d.get("V"))
             g.lda, g.ldw = A.stride(0), W.stride(0)
             g.M, g.N, g.K, g.col0 = self.M, W.shape[0], W.shape[1], d["col0"]
         common = N.SeaQkvCommon(rope.data_ptr(), self.H, hd, self.T, self.pos0, self.cap, float(hd) ** -0.5)
@@ -431,13 +431,14 @@ class Plan:
 
 
 def _fill_gemm(g, A, W, bias=None, R=None, C32=None, Cact=None, n_seg=1, a_seg_stride=0, act=0, bias_scale=1.0, ldr=None,
-               R_is_x=None) -> None:
+               R_is_x=None, Z=None, ldc32=None) -> None:
     g.A, g.W = A.data_ptr(), W.data_ptr()
+    g.Z, g.ldz = N.ptr(Z), (Z.stride(0) if Z is not None else 0)
     g.bias, g.R, g.C32, g.Cact = N.ptr(bias), N.ptr(R), N.ptr(C32), N.ptr(Cact)
     g.a_seg_stride = a_seg_stride
     g.lda, g.ldw = A.stride(-2), W.stride(0)
     g.ldr = (ldr if ldr is not None else R.stride(0)) if R is not None else 0
-    g.ldc32 = C32.stride(0) if C32 is not None else 0
+    g.ldc32 = (ldc32 if ldc32 is not None else C32.stride(0)) if C32 is not None else 0
     g.ldcact = Cact.stride(0) if Cact is not None else 0
     g.M, g.N, g.K = A.shape[-2], W.shape[0], W.shape[1]
     g.n_seg, g.act, g.bias_scale = n_seg, act, bias_scale

@@ -22,10 +22,11 @@ def _mat(t: torch.Tensor, name: str) -> torch.Tensor:
 
 
 def fill_gemm_group(g: N.SeaGemmGroup, A, W, bias=None, R=None, C32=None, Cact=None, n_seg=1, a_seg_stride=0, act=0,
-                    bias_scale=1.0, M=None, N_=None, K=None) -> None:
+                    bias_scale=1.0, M=None, N_=None, K=None, Z=None) -> None:
     g.A, g.W = A.data_ptr(), W.data_ptr()
     g.bias = N.ptr(bias)
     g.R, g.C32, g.Cact = N.ptr(R), N.ptr(C32), N.ptr(Cact)
+    g.Z, g.ldz = N.ptr(Z), (Z.stride(0) if Z is not None else 0)
     g.a_seg_stride = a_seg_stride
     g.lda, g.ldw = A.stride(0), W.stride(0)
     g.ldr = R.stride(0) if R is not None else 0
@@ -54,7 +55,7 @@ def gemm_grouped(groups: Sequence[Dict], dtype: torch.dtype) -> None:
         if d.get("Cact") is not None and d["Cact"].dtype != dtype:
             raise ValueError(f"gemm group {i}: Cact dtype mismatch")
         fill_gemm_group(arr[i], A, W, d.get("bias"), d.get("R"), d.get("C32"), d.get("Cact"), d.get("n_seg", 1),
-                        d.get("a_seg_stride", 0), d.get("act", 0), d.get("bias_scale", 1.0), K=d.get("K"))
+                        d.get("a_seg_stride", 0), d.get("act", 0), d.get("bias_scale", 1.0), K=d.get("K"), Z=d.get("Z"))
     N.check(N.lib().sea_gemm_grouped(arr, n, N.dtype_code(dtype), N.stream_ptr()), "sea_gemm_grouped")
 
 
@@ -69,7 +70,7 @@ def qkv_rope_grouped(groups: Sequence[Dict], rope: torch.Tensor, H: int, hd: int
             raise ValueError(f"qkv group {i}: dtype mismatch")
         g = arr[i]
         g.A, g.W, g.bias = A.data_ptr(), W.data_ptr(), N.ptr(d.get("bias"))
-        g.Qout, g.Kout, g.Vtout = N.ptr(d.get("Q")), N.ptr(d.get("K")), N.ptr(d.get("Vt"))
+        g.Qout, g.Kout, g.Vtout, g.Vout = N.ptr(d.get("Q")), N.ptr(d.get("K")), N.ptr(d.get("Vt")), N.ptr(d.get("V"))
         g.lda, g.ldw = A.stride(0), W.stride(0)
         g.M, g.N, g.K = A.shape[0], W.shape[0], W.shape[1]
         g.col0 = d.get("col0", 0)

@@ -334,3 +334,45 @@ def test_bad_arguments_raise():
         ops.gemm_grouped([dict(A=A, W=W, C32=torch.empty(10, 16, device=dev()))], torch.float32)
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         ops.gemm_grouped([dict(A=torch.zeros(8, 8), W=torch.zeros(8, 8), C32=torch.zeros(8, 8))], torch.float32)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gemm_gelu_preactivation_and_backward_epilogue(dtype):
+    """act=1 keeps the pre-activation in Z; act=2 multiplies by GELU'(Z) (backward of the fused GELU)."""
+    from sea_amd import ops
+
+    M, K, N_ = 200, 128, 96
+    A = rnd(M, K, dtype=dtype, seed=200)
+    W = rnd(N_, K, dtype=dtype, scale=K ** -0.5, seed=201)
+    Z = torch.empty(M, N_, device=dev(), dtype=dtype)
+    G = torch.empty(M, N_, device=dev(), dtype=dtype)
+    ops.gemm_grouped([dict(A=A, W=W, Cact=G, Z=Z, act=1)], dtype)
+    pre = A.float() @ W.float().t()
+    assert rel(Z.float(), pre) < tol(dtype) and rel(G.float(), gelu(pre)) < tol(dtype)
+    # backward: dA' = (dG . W2) * gelu'(Z)
+    dG = rnd(M, 64, dtype=dtype, seed=202)
+    W2t = rnd(N_, 64, dtype=dtype, seed=203)  # plays W^T: [N_out = N_, K = 64]
+    out = torch.empty(M, N_, device=dev())
+    ops.gemm_grouped([dict(A=dG, W=W2t, C32=out, Z=Z, act=2)], dtype)
+    z = Z.float().requires_grad_(True)
+    (gelu(z)).backward(dG.float() @ W2t.float().t())
+    assert rel(out, z.grad) < tol(dtype, f32=2e-5, bf16=2e-5)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_qkv_rope_row_major_v_copy(dtype):
+    from sea_amd import ops
+
+    B, T, H, hd = 2, 33, 4, 16
+    E, M, cap = H * hd, B * T, 40
+    x = rnd(M, E, dtype=dtype, seed=210)
+    W = rnd(3 * E, E, dtype=dtype, scale=E ** -0.5, seed=211)
+    bias = rnd(3 * E, seed=212)
+    Q = torch.zeros(B, H, T, hd, device=dev(), dtype=dtype)
+    K = torch.zeros(B, H, cap, hd, device=dev(), dtype=dtype)
+    Vt = torch.zeros(B, H, hd, cap, device=dev(), dtype=dtype)
+    V = torch.zeros(B, H, cap, hd, device=dev(), dtype=dtype)
+    ops.qkv_rope_grouped([dict(A=x, W=W, bias=bias, col0=0, Q=Q, K=K, Vt=Vt, V=V)], rope_table(hd, T), H, hd, T, 0, cap, hd ** -0.5, dtype)
+    assert torch.equal(V.transpose(2, 3), Vt)
+    v = (x.float() @ W.float().t() + bias)[:, 2 * E:].view(B, T, H, hd).permute(0, 2, 1, 3)
+    assert rel(V[:, :, :T].float(), v) < tol(dtype)
