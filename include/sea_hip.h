@@ -235,6 +235,111 @@ int sea_relative_mse(const float* pred, const float* truth, float* y, int64_t ro
 int sea_adamw_flat(float* p, const float* g, float* m, float* v, void* shadow, int shadow_dtype, int64_t n, float lr, float beta1,
                    float beta2, float eps, float weight_decay, int step, float grad_scale, void* stream);
 
+/* ============================================================================================================
+ * Backward pass.  The reference gets it from autograd (loss.backward(), train/train_temporal.py:257); here every
+ * operator has a hand-written backward.  Data gradients of the Linear layers reuse sea_gemm_grouped with the W^T shadow
+ * (sea_transpose_weights); parameter gradients are ACCUMULATED (fp32 atomics) into buffers the caller zeroes each step.
+ * ============================================================================================================ */
+
+/* Weight gradient of y = x W^T + b for several layers per launch: dW[N,K] += dY[M,N]^T . X[M,K]; db[N] += sum_m dY[m,:]
+ * (db may be NULL).  The contraction over M is split across workgroups.  N % 8 == 0, K % 8 == 0. */
+typedef struct {
+    const void* dY; /* act [M, N] row stride lddy */
+    const void* X;  /* act [M, K] row stride ldx */
+    float* dW;      /* f32 [N, K] row stride lddw, accumulated */
+    float* db;      /* f32 [N] accumulated, or NULL */
+    int32_t lddy, ldx, lddw;
+    int32_t M, N, K;
+} SeaWgradGroup;
+int sea_wgrad_grouped(const SeaWgradGroup* groups, int n_groups, int dtype, void* stream);
+
+/* Activation-dtype TRANSPOSED shadow of weight matrices: for each descriptor {src_off, dst_off, rows, cols} (int64 x 4, in
+ * elements, DEVICE memory) dst[dst_off + c*rows + r] = src[src_off + r*cols + c].  tile_start (int32 [n_desc+1], DEVICE) is the
+ * prefix sum of ceil(rows/32)*ceil(cols/32). */
+int sea_transpose_weights(const float* src, void* dst, int dst_dtype, const int64_t* desc, const int32_t* tile_start, int n_desc,
+                          int total_tiles, void* stream);
+
+/* Backward of sea_rownorm.  Given dY, the forward input X, the saved mean/rstd and the modulation:
+ *   dX   = rstd * (dxhat - mean_d(dxhat) - xhat * mean_d(dxhat * xhat)),  dxhat = dY' * (gamma (+ 1 + mod_w)),
+ *          dY' = dY * gelu'(y_pre) when gelu (beta is needed only then); written to dX32 (added to it when accumulate) and/or dXact;
+ *   dmod = [dY' * xhat | dY'] (act, optional);  dgamma += sum_m dY' * xhat;  dbeta += sum_m dY' (dbeta may be NULL). */
+typedef struct {
+    const void* dY;     /* f32 or act [M, d] */
+    const void* X;      /* f32 or act [M, d] */
+    const void* mod;    /* act [M, 2d] or NULL */
+    const float* gamma; /* [d] */
+    const float* beta;  /* [d] or NULL */
+    const float* mean;  /* [M] */
+    const float* rstd;  /* [M] */
+    float* dX32;
+    void* dXact;
+    void* dmod;
+    float* dgamma;
+    float* dbeta;
+    int32_t lddy, ldx, ldmod, lddx32, lddxact, lddmod;
+} SeaNormBwdGroup;
+int sea_rownorm_bwd(const SeaNormBwdGroup* groups, int n_groups, int M, int d, int dy_is_act, int x_is_act, int gelu,
+                    int accumulate, int dtype, void* stream);
+
+/* Backward of sea_attention_fwd + the rotary embedding of sea_qkv_rope_grouped (flash-style: P is recomputed from Q, K and the
+ * forward's LSE).  For each problem, from dO (gradient of the attention output, [B, Tq, H*hd] row stride lddo):
+ *   dQ [B*Tq, H*hd] (row stride lddq), dK, dV [B*Tk, H*hd] (lddk, lddv) = gradients with respect to the OUTPUTS of the q / k / v
+ *   Linear layers (RoPE and the q scale are undone in the epilogue), i.e. the dY operands of sea_wgrad_grouped / the dgrad GEMM.
+ * V is the row-major copy written by sea_qkv_rope_grouped (Vout); delta (f32 [B, H, Tq]) is workspace.  Deterministic. */
+typedef struct {
+    const void* Q;   /* act [B, H, Tq, hd]  (rotated, scaled) */
+    const void* K;   /* act [B, H, cap, hd] (rotated) */
+    const void* V;   /* act [B, H, cap, hd] */
+    const void* O;   /* act [B, Tq, H*hd] row stride ldo */
+    const void* dO;  /* act [B, Tq, H*hd] row stride lddo */
+    const float* LSE;
+    float* delta;
+    void* dQ;
+    void* dK;
+    void* dV;
+} SeaAttnBwdProblem;
+
+typedef struct {
+    SeaAttnBwdProblem p[SEA_MAX_ATTN_PROBLEMS];
+    const float* rope; /* f32 [>= max(q_pos0 + Tq, Tk), hd/2, 2] */
+    int32_t n_problems;
+    int32_t B, H, hd, Tq, Tk, cap, q_pos0, src_len;
+    int32_t ldo, lddo, lddq, lddk, lddv;
+    float q_scale;
+} SeaAttnBwdParams;
+int sea_attention_bwd(const SeaAttnBwdParams* params, int dtype, void* stream);
+
+/* Backward of sea_silu_outer: dpre = dHid * silu'(w1 c + b1); dw1[k] += sum_m dpre * c[m]; db1[k] += sum_m dpre. */
+typedef struct {
+    const void* dHid; /* act [M, K2] row stride ld */
+    const float* w1;
+    const float* b1;
+    float* dw1;
+    float* db1;
+    int32_t K2, ld;
+} SeaSiluBwdGroup;
+int sea_silu_outer_bwd(const SeaSiluBwdGroup* groups, int n_groups, const float* c, int M, int dtype, void* stream);
+
+/* Parameter gradients of the information-bottleneck MLP (sea_ib_add) from dib = sum_f dX_f; dX itself passes through. */
+typedef struct {
+    const float* dX[8];
+    int32_t n_fields, ldx;
+    const float* c;
+    const float* w1;
+    const float* b1;
+    const float* lnw;
+    const float* lnb;
+    const float* w2;
+    float* dw1;
+    float* db1;
+    float* dlnw;
+    float* dlnb;
+    float* dw2;
+    float* db2;
+    int32_t M, E, h;
+} SeaIbBwdParams;
+int sea_ib_bwd(const SeaIbBwdParams* params, void* stream);
+
 /* ------------------------------------------------------------------------------------------------------------
  * Self-test of the MFMA fragment maps this library relies on (16x16x32 bf16 and 16x16x4 f32, A/B/C lane maps):
  * multiplies exact small-integer matrices on the device and checks every element on the host.  Synchronous.

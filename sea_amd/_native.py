@@ -66,6 +66,43 @@ class SeaIbParams(C.Structure):
                 ("M", _i32), ("E", _i32), ("h", _i32)]
 
 
+class SeaWgradGroup(C.Structure):
+    _fields_ = [("dY", _vp), ("X", _vp), ("dW", _vp), ("db", _vp), ("lddy", _i32), ("ldx", _i32), ("lddw", _i32),
+                ("M", _i32), ("N", _i32), ("K", _i32)]
+
+
+class SeaNormBwdGroup(C.Structure):
+    _fields_ = [("dY", _vp), ("X", _vp), ("mod", _vp), ("gamma", _vp), ("beta", _vp), ("mean", _vp), ("rstd", _vp),
+                ("dX32", _vp), ("dXact", _vp), ("dmod", _vp), ("dgamma", _vp), ("dbeta", _vp),
+                ("lddy", _i32), ("ldx", _i32), ("ldmod", _i32), ("lddx32", _i32), ("lddxact", _i32), ("lddmod", _i32)]
+
+
+class SeaSiluBwdGroup(C.Structure):
+    _fields_ = [("dHid", _vp), ("w1", _vp), ("b1", _vp), ("dw1", _vp), ("db1", _vp), ("K2", _i32), ("ld", _i32)]
+
+
+class SeaIbBwdParams(C.Structure):
+    _fields_ = [("dX", _vp * 8), ("n_fields", _i32), ("ldx", _i32),
+                ("c", _vp), ("w1", _vp), ("b1", _vp), ("lnw", _vp), ("lnb", _vp), ("w2", _vp),
+                ("dw1", _vp), ("db1", _vp), ("dlnw", _vp), ("dlnb", _vp), ("dw2", _vp), ("db2", _vp),
+                ("M", _i32), ("E", _i32), ("h", _i32)]
+
+
+class SeaAttnBwdProblem(C.Structure):
+    _fields_ = [("Q", _vp), ("K", _vp), ("V", _vp), ("O", _vp), ("dO", _vp), ("LSE", _vp), ("delta", _vp), ("dQ", _vp), ("dK", _vp),
+                ("dV", _vp)]
+
+
+class SeaAttnBwdParams(C.Structure):
+    _fields_ = [("p", SeaAttnBwdProblem * MAX_ATTN_PROBLEMS), ("rope", _vp), ("n_problems", _i32),
+                ("B", _i32), ("H", _i32), ("hd", _i32), ("Tq", _i32), ("Tk", _i32), ("cap", _i32), ("q_pos0", _i32), ("src_len", _i32),
+                ("ldo", _i32), ("lddo", _i32), ("lddq", _i32), ("lddk", _i32), ("lddv", _i32), ("q_scale", _f32)]
+
+
+MAX_WGRAD_GROUPS = 16
+MAX_NORM_BWD_GROUPS = 8
+MAX_SILU_BWD_GROUPS = 24
+
 _lib: Optional[C.CDLL] = None
 
 
@@ -99,6 +136,14 @@ def lib() -> C.CDLL:
     L.sea_ib_add.argtypes = [C.POINTER(SeaIbParams), _vp]
     L.sea_convert_f32_to_act.argtypes = [_vp, _i64, _vp, _i64, _i64, _i64, C.c_int, _vp]
     L.sea_selftest_mfma.restype = C.c_int
+    L.sea_wgrad_grouped.argtypes = [C.POINTER(SeaWgradGroup), C.c_int, C.c_int, _vp]
+    L.sea_transpose_weights.argtypes = [_vp, _vp, C.c_int, _vp, _vp, C.c_int, C.c_int, _vp]
+    L.sea_rownorm_bwd.argtypes = [C.POINTER(SeaNormBwdGroup), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp]
+    L.sea_silu_outer_bwd.argtypes = [C.POINTER(SeaSiluBwdGroup), C.c_int, _vp, C.c_int, C.c_int, _vp]
+    L.sea_ib_bwd.argtypes = [C.POINTER(SeaIbBwdParams), _vp]
+    L.sea_attention_bwd.argtypes = [C.POINTER(SeaAttnBwdParams), C.c_int, _vp]
+    for name in ("sea_attention_bwd", "sea_wgrad_grouped", "sea_transpose_weights", "sea_rownorm_bwd", "sea_silu_outer_bwd", "sea_ib_bwd"):
+        getattr(L, name).restype = C.c_int
     L.sea_mse_fwd_bwd.argtypes = [_vp, _vp, _vp, _vp, _vp, C.c_int, _i64, C.c_float, _vp]
     L.sea_relative_mse.argtypes = [_vp, _vp, _vp, _i64, C.c_int, _vp]
     L.sea_adamw_flat.argtypes = [_vp, _vp, _vp, _vp, _vp, C.c_int, _i64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
@@ -114,12 +159,14 @@ def lib() -> C.CDLL:
 
 
 ABI_STRUCTS = (SeaGemmGroup, SeaQkvGroup, SeaQkvCommon, SeaAttnProblem, SeaAttnParams, SeaNormGroup, SeaSiluGroup,
-               SeaIbParams)
+               SeaIbParams, SeaWgradGroup, SeaNormBwdGroup, SeaSiluBwdGroup, SeaIbBwdParams, SeaAttnBwdProblem, SeaAttnBwdParams)
 
 EXPORTED_SYMBOLS = (
     "sea_abi_version", "sea_last_error", "sea_struct_sizes", "sea_device_info", "sea_gemm_grouped", "sea_qkv_rope_grouped",
     "sea_attention_fwd", "sea_rownorm", "sea_silu_outer", "sea_ib_add", "sea_convert_f32_to_act", "sea_selftest_mfma",
     "sea_mse_fwd_bwd", "sea_relative_mse", "sea_adamw_flat",
+    "sea_wgrad_grouped", "sea_transpose_weights", "sea_rownorm_bwd", "sea_silu_outer_bwd", "sea_ib_bwd",
+    "sea_attention_bwd",
 )
 
 

@@ -1,0 +1,421 @@
+// Causal flash attention backward for SEA's self- and cross-attention (gfx950): sea_attention_bwd.
+//
+// Two kernels, both recomputing P = exp(S - LSE) from Q, K and the forward's log-sum-exp instead of storing [T, T]:
+//   attn_bwd_dq_kernel   one workgroup per 64 QUERIES (lane = query), loops over key tiles:      dQ, delta = rowsum(dO . O)
+//   attn_bwd_dkv_kernel  one workgroup per 64 KEYS (lane = key), loops over query tiles:         dK, dV
+// No atomics, bitwise reproducible.  The same transposed formulation as the forward: every accumulator has the lane's own
+// query (or key) as its MFMA column, and a score block goes accumulator -> operand with a pack (the 16 MFMA rows of a block
+// are assigned to keys/queries so that a lane ends up with EPC consecutive ones).  Products that contract over the tile's
+// ROW index read the row-major LDS tile through transposed fragments (ds_read_b64_tr_b16 for bf16).
+// The epilogues undo RoPE (and the q scale) and write gradients of the q/k/v projections' outputs in [M, H*hd] layout.
+#include "sea_common.hpp"
+
+typedef short s16x4b __attribute__((ext_vector_type(4)));
+
+template <typename T>
+__device__ __forceinline__ uint4 frag_T(const char* tile, int pitch, int m0, int c0, int lane);
+template <>
+__device__ __forceinline__ uint4 frag_T<__bf16>(const char* tile, int pitch, int m0, int c0, int lane) {
+    const int idx = lane & 15, gg = lane >> 4, q = idx >> 2, p = idx & 3;
+    const char* base = tile + (m0 + 8 * gg + q) * pitch + (c0 + 4 * p) * 2;
+    typedef s16x4b __attribute__((address_space(3))) * lds_p;
+    const s16x4b lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(base));
+    const s16x4b hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(base + 4 * pitch));
+    uint4 out;
+    out.x = (unsigned)(unsigned short)lo[0] | ((unsigned)(unsigned short)lo[1] << 16);
+    out.y = (unsigned)(unsigned short)lo[2] | ((unsigned)(unsigned short)lo[3] << 16);
+    out.z = (unsigned)(unsigned short)hi[0] | ((unsigned)(unsigned short)hi[1] << 16);
+    out.w = (unsigned)(unsigned short)hi[2] | ((unsigned)(unsigned short)hi[3] << 16);
+    return out;
+}
+template <>
+__device__ __forceinline__ uint4 frag_T<float>(const char* tile, int pitch, int m0, int c0, int lane) {
+    const int idx = lane & 15, gg = lane >> 4;
+    const char* base = tile + (m0 + 4 * gg) * pitch + (c0 + idx) * 4;
+    f32x4 v = {*reinterpret_cast<const float*>(base), *reinterpret_cast<const float*>(base + pitch),
+               *reinterpret_cast<const float*>(base + 2 * pitch), *reinterpret_cast<const float*>(base + 3 * pitch)};
+    return __builtin_bit_cast(uint4, v);
+}
+
+template <typename T, int HD>
+struct BwdCfg {
+    static constexpr int EPC = ActTraits<T>::EPC;
+    static constexpr int CK = ActTraits<T>::CK;
+    static constexpr int NB = CK / 16;
+    static constexpr int KCH = 64 / CK;                      // chunks of the 64-row tile
+    static constexpr int NCH = (HD + CK - 1) / CK;           // head-dim chunks of a contraction over d
+    static constexpr int NDB = (HD + 15) / 16;               // 16-wide d blocks
+    static constexpr int ROW = HD * (int)sizeof(T);
+    static constexpr int PITCH = (NDB * 16) * (int)sizeof(T) + 16;  // rows padded to whole 16-column blocks (+16 B)
+    static constexpr int TILE = 64 * PITCH;
+    static constexpr int CPR = HD / EPC;                     // 16-byte chunks per row
+    static constexpr int NR = (64 * CPR + 255) / 256;        // chunks per thread per tile
+};
+
+template <typename T>
+__device__ __forceinline__ uint4 pack_frag(const f32x4& lo, const f32x4& hi) {
+    if constexpr (sizeof(T) == 2) {
+        bf16x8 pv = {(__bf16)lo[0], (__bf16)lo[1], (__bf16)lo[2], (__bf16)lo[3], (__bf16)hi[0], (__bf16)hi[1], (__bf16)hi[2], (__bf16)hi[3]};
+        return __builtin_bit_cast(uint4, pv);
+    } else {
+        return __builtin_bit_cast(uint4, lo);
+    }
+}
+
+// stage a [64 rows][HD] row-major tile (rows row0.. of a [n_rows, HD] matrix with row stride ld elements) through registers
+template <typename T, int HD>
+struct TileStager {
+    using C = BwdCfg<T, HD>;
+    uint4 r[C::NR];
+    __device__ __forceinline__ void load(const T* base, int64_t ld, int row0, int n_rows, int tid) {
+#pragma unroll
+        for (int u = 0; u < C::NR; ++u) {
+            const int idx = tid + u * 256;
+            const int rr = idx / C::CPR, cc = idx - rr * C::CPR;
+            r[u] = make_uint4(0, 0, 0, 0);
+            if (idx < 64 * C::CPR && row0 + rr < n_rows) r[u] = *reinterpret_cast<const uint4*>(base + (int64_t)(row0 + rr) * ld + cc * C::EPC);
+        }
+    }
+    __device__ __forceinline__ void store(char* tile, int tid) const {
+#pragma unroll
+        for (int u = 0; u < C::NR; ++u) {
+            const int idx = tid + u * 256;
+            const int rr = idx / C::CPR, cc = idx - rr * C::CPR;
+            if (idx < 64 * C::CPR) *reinterpret_cast<uint4*>(tile + rr * C::PITCH + cc * 16) = r[u];
+        }
+    }
+};
+
+// inverse rotation of one (even, odd) pair: the forward was (e', o') = (e c - o s, e s + o c)
+__device__ __forceinline__ void unrope(float& e, float& o, const float2 cs) {
+    const float ne = e * cs.x + o * cs.y;
+    const float no = o * cs.x - e * cs.y;
+    e = ne;
+    o = no;
+}
+
+// ---------------------------------------------------------------------------------------------- dQ (+ delta)
+template <typename T, int HD>
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const SeaAttnBwdParams P) {
+    using C = BwdCfg<T, HD>;
+    __shared__ __attribute__((aligned(16))) char smem[4 * C::TILE];  // 2 buffers x (K tile, V tile)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, g = lane >> 4;
+    const int qt = gridDim.x - 1 - (int)blockIdx.x;
+    const int bh = blockIdx.y, b = bh / P.H, h = bh - b * P.H;
+    const SeaAttnBwdProblem& pr = P.p[blockIdx.z];
+    const int Tq = P.Tq, Tk = P.Tk;
+    const T* Qg = static_cast<const T*>(pr.Q) + (int64_t)bh * Tq * HD;
+    const T* Kg = static_cast<const T*>(pr.K) + (int64_t)bh * P.cap * HD;
+    const T* Vg = static_cast<const T*>(pr.V) + (int64_t)bh * P.cap * HD;
+    const int q_row0 = qt * 64 + wave * 16, q_idx = q_row0 + r, q_ld = q_idx < Tq ? q_idx : Tq - 1;
+    const T* Og = static_cast<const T*>(pr.O) + ((int64_t)b * Tq + q_ld) * P.ldo + h * HD;
+    const T* dOg = static_cast<const T*>(pr.dO) + ((int64_t)b * Tq + q_ld) * P.lddo + h * HD;
+
+    uint4 qf[C::NCH], dof[C::NCH];
+    float delta = 0.f;
+#pragma unroll
+    for (int c = 0; c < C::NCH; ++c) {
+        const int d0 = c * C::CK + g * C::EPC;
+        qf[c] = make_uint4(0, 0, 0, 0);
+        dof[c] = make_uint4(0, 0, 0, 0);
+        if (d0 < HD) {
+            qf[c] = *reinterpret_cast<const uint4*>(Qg + (int64_t)q_ld * HD + d0);
+            dof[c] = *reinterpret_cast<const uint4*>(dOg + d0);
+            T ov[C::EPC], dv[C::EPC];
+            *reinterpret_cast<uint4*>(ov) = *reinterpret_cast<const uint4*>(Og + d0);
+            *reinterpret_cast<uint4*>(dv) = dof[c];
+#pragma unroll
+            for (int e = 0; e < C::EPC; ++e) delta += to_f32(ov[e]) * to_f32(dv[e]);
+        }
+    }
+    delta += __shfl_xor(delta, 16);
+    delta += __shfl_xor(delta, 32);
+    const float lse = pr.LSE[(int64_t)bh * Tq + q_ld];
+    if (g == 0 && q_idx < Tq) pr.delta[(int64_t)bh * Tq + q_idx] = delta;
+
+    f32x4 dq[C::NDB];
+#pragma unroll
+    for (int d = 0; d < C::NDB; ++d) dq[d] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int limit = P.q_pos0 + q_idx + P.src_len;
+    int n_kt = (P.q_pos0 + qt * 64 + 63 + P.src_len) / 64 + 1;
+    const int n_kt_all = (Tk + 63) / 64;
+    n_kt = n_kt < n_kt_all ? n_kt : n_kt_all;
+    const int wave_first = P.q_pos0 + q_row0 + P.src_len, wave_last = wave_first + 15;
+
+    int frag_off[C::KCH][C::NB];
+#pragma unroll
+    for (int kc = 0; kc < C::KCH; ++kc)
+#pragma unroll
+        for (int be = 0; be < C::NB; ++be) frag_off[kc][be] = (kc * C::CK + (r >> 2) * (4 * C::NB) + be * 4 + (r & 3)) * C::PITCH + g * 16;
+
+    TileStager<T, HD> stK, stV;
+    stK.load(Kg, HD, 0, Tk, tid);
+    stV.load(Vg, HD, 0, Tk, tid);
+    stK.store(smem, tid);
+    stV.store(smem + C::TILE, tid);
+    __syncthreads();
+    for (int kt = 0; kt < n_kt; ++kt) {
+        const char* sK = smem + (kt & 1) * 2 * C::TILE;
+        const char* sV = sK + C::TILE;
+        const bool more = kt + 1 < n_kt;
+        if (more) {
+            stK.load(Kg, HD, (kt + 1) * 64, Tk, tid);
+            stV.load(Vg, HD, (kt + 1) * 64, Tk, tid);
+        }
+        if (kt * 64 <= wave_last) {
+            const bool need_mask = !(kt * 64 + 63 <= wave_first && kt * 64 + 63 < Tk);
+            f32x4 ds[C::KCH][C::NB];
+#pragma unroll
+            for (int kc = 0; kc < C::KCH; ++kc) {
+#pragma unroll
+                for (int be = 0; be < C::NB; ++be) {
+                    f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int c = 0; c < C::NCH; ++c) {
+                        uint4 ak = make_uint4(0, 0, 0, 0), av = make_uint4(0, 0, 0, 0);
+                        if (c * C::CK + g * C::EPC < HD) {
+                            ak = *reinterpret_cast<const uint4*>(sK + frag_off[kc][be] + c * C::CK * (int)sizeof(T));
+                            av = *reinterpret_cast<const uint4*>(sV + frag_off[kc][be] + c * C::CK * (int)sizeof(T));
+                        }
+                        mma16<T>(ak, qf[c], s);
+                        mma16<T>(av, dof[c], dp);
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        float p = __expf(s[q] - lse);
+                        if (need_mask) {
+                            const int key = kt * 64 + kc * C::CK + g * C::EPC + be * 4 + q;
+                            if (!(key <= limit && key < Tk)) p = 0.f;
+                        }
+                        ds[kc][be][q] = p * (dp[q] - delta);
+                    }
+                }
+            }
+            // dQ^T[d][q] += K^T[d][key] . dS^T[key][q]
+#pragma unroll
+            for (int kc = 0; kc < C::KCH; ++kc) {
+                const uint4 bfrag = pack_frag<T>(ds[kc][0], ds[kc][C::NB - 1]);
+#pragma unroll
+                for (int d = 0; d < C::NDB; ++d) {
+                    const uint4 a = frag_T<T>(sK, C::PITCH, kc * C::CK, d * 16, lane);
+                    mma16<T>(a, bfrag, dq[d]);
+                }
+            }
+        }
+        if (more) {
+            stK.store(smem + ((kt + 1) & 1) * 2 * C::TILE, tid);
+            stV.store(smem + ((kt + 1) & 1) * 2 * C::TILE + C::TILE, tid);
+        }
+        __syncthreads();
+    }
+    if (q_idx < Tq) {
+        T* out = static_cast<T*>(pr.dQ) + ((int64_t)b * Tq + q_idx) * P.lddq + h * HD;
+        const float2* rope = reinterpret_cast<const float2*>(P.rope) + (int64_t)(P.q_pos0 + q_idx) * (HD / 2);
+#pragma unroll
+        for (int d = 0; d < C::NDB; ++d) {
+            const int d0 = d * 16 + g * 4;
+            if (d0 < HD) {
+                float v[4] = {dq[d][0], dq[d][1], dq[d][2], dq[d][3]};
+                unrope(v[0], v[1], rope[d0 >> 1]);
+                unrope(v[2], v[3], rope[(d0 >> 1) + 1]);
+                store4(out + d0, v[0] * P.q_scale, v[1] * P.q_scale, v[2] * P.q_scale, v[3] * P.q_scale);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- dK, dV
+template <typename T, int HD>
+__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const SeaAttnBwdParams P) {
+    using C = BwdCfg<T, HD>;
+    __shared__ __attribute__((aligned(16))) char smem[4 * C::TILE + 2 * 2 * 64 * 4];  // 2 x (Q tile, dO tile) + 2 x (lse, delta)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, g = lane >> 4;
+    const int kb = blockIdx.x;  // key tile
+    const int bh = blockIdx.y, b = bh / P.H, h = bh - b * P.H;
+    const SeaAttnBwdProblem& pr = P.p[blockIdx.z];
+    const int Tq = P.Tq, Tk = P.Tk;
+    const T* Qg = static_cast<const T*>(pr.Q) + (int64_t)bh * Tq * HD;
+    const T* Kg = static_cast<const T*>(pr.K) + (int64_t)bh * P.cap * HD;
+    const T* Vg = static_cast<const T*>(pr.V) + (int64_t)bh * P.cap * HD;
+    const T* dOg = static_cast<const T*>(pr.dO) + (int64_t)b * Tq * P.lddo + h * HD;
+    const float* lse_g = pr.LSE + (int64_t)bh * Tq;
+    const float* del_g = pr.delta + (int64_t)bh * Tq;
+    const int k_row0 = kb * 64 + wave * 16, k_idx = k_row0 + r, k_ld = k_idx < Tk ? k_idx : Tk - 1;
+
+    uint4 kf[C::NCH], vf[C::NCH];
+#pragma unroll
+    for (int c = 0; c < C::NCH; ++c) {
+        const int d0 = c * C::CK + g * C::EPC;
+        kf[c] = d0 < HD ? *reinterpret_cast<const uint4*>(Kg + (int64_t)k_ld * HD + d0) : make_uint4(0, 0, 0, 0);
+        vf[c] = d0 < HD ? *reinterpret_cast<const uint4*>(Vg + (int64_t)k_ld * HD + d0) : make_uint4(0, 0, 0, 0);
+    }
+    f32x4 dk[C::NDB], dv[C::NDB];
+#pragma unroll
+    for (int d = 0; d < C::NDB; ++d) {
+        dk[d] = f32x4{0.f, 0.f, 0.f, 0.f};
+        dv[d] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    // query q sees key j iff j <= q_pos0 + q + src_len  <=>  q >= j - src_len - q_pos0
+    const int q_min_lane = k_idx - P.src_len - P.q_pos0;          // first query that sees this lane's key
+    const int q_min_blk = kb * 64 - P.src_len - P.q_pos0;         // first query that sees any key of the workgroup
+    const int qt0 = q_min_blk > 0 ? q_min_blk / 64 : 0;
+    const int n_qt = (Tq + 63) / 64;
+    const int wave_qmin = k_row0 - P.src_len - P.q_pos0;          // first query that sees the wave's FIRST key
+    const int wave_qmax_need = wave_qmin + 15;                    // queries >= this see ALL the wave's keys
+
+    int frag_off[C::KCH][C::NB];
+#pragma unroll
+    for (int qc = 0; qc < C::KCH; ++qc)
+#pragma unroll
+        for (int be = 0; be < C::NB; ++be) frag_off[qc][be] = (qc * C::CK + (r >> 2) * (4 * C::NB) + be * 4 + (r & 3)) * C::PITCH + g * 16;
+
+    TileStager<T, HD> stQ, stO;
+    float r_lse = 0.f, r_del = 0.f;
+    auto load_vec = [&](int qt) {
+        if (tid < 64) {
+            const int q = qt * 64 + tid;
+            r_lse = q < Tq ? lse_g[q] : 0.f;
+            r_del = q < Tq ? del_g[q] : 0.f;
+        }
+    };
+    auto store_vec = [&](int buf) {
+        float* sl = reinterpret_cast<float*>(smem + 4 * C::TILE) + buf * 128;
+        if (tid < 64) {
+            sl[tid] = r_lse;
+            sl[64 + tid] = r_del;
+        }
+    };
+    if (qt0 < n_qt) {
+        stQ.load(Qg, HD, qt0 * 64, Tq, tid);
+        stO.load(dOg, P.lddo, qt0 * 64, Tq, tid);
+        load_vec(qt0);
+        stQ.store(smem, tid);
+        stO.store(smem + C::TILE, tid);
+        store_vec(0);
+    }
+    __syncthreads();
+    for (int qt = qt0; qt < n_qt; ++qt) {
+        const int bi = (qt - qt0) & 1;
+        const char* sQ = smem + bi * 2 * C::TILE;
+        const char* sO = sQ + C::TILE;
+        const float* sL = reinterpret_cast<const float*>(smem + 4 * C::TILE) + bi * 128;
+        const bool more = qt + 1 < n_qt;
+        if (more) {
+            stQ.load(Qg, HD, (qt + 1) * 64, Tq, tid);
+            stO.load(dOg, P.lddo, (qt + 1) * 64, Tq, tid);
+            load_vec(qt + 1);
+        }
+        if (qt * 64 + 63 >= wave_qmin) {  // some query of the tile sees some key of this wave
+            const bool need_mask = !(qt * 64 >= wave_qmax_need && qt * 64 + 63 < Tq) || (k_row0 + 15 >= Tk);
+            f32x4 pp[C::KCH][C::NB], ds[C::KCH][C::NB];
+#pragma unroll
+            for (int qc = 0; qc < C::KCH; ++qc) {
+#pragma unroll
+                for (int be = 0; be < C::NB; ++be) {
+                    f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int c = 0; c < C::NCH; ++c) {
+                        uint4 aq = make_uint4(0, 0, 0, 0), ao = make_uint4(0, 0, 0, 0);
+                        if (c * C::CK + g * C::EPC < HD) {
+                            aq = *reinterpret_cast<const uint4*>(sQ + frag_off[qc][be] + c * C::CK * (int)sizeof(T));
+                            ao = *reinterpret_cast<const uint4*>(sO + frag_off[qc][be] + c * C::CK * (int)sizeof(T));
+                        }
+                        mma16<T>(aq, kf[c], s);
+                        mma16<T>(ao, vf[c], dp);
+                    }
+                    const int ql = qc * C::CK + g * C::EPC + be * 4;  // this lane's 4 consecutive queries of the tile
+                    const f32x4 l4 = *reinterpret_cast<const f32x4*>(sL + ql);
+                    const f32x4 d4 = *reinterpret_cast<const f32x4*>(sL + 64 + ql);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        float p = __expf(s[q] - l4[q]);
+                        if (need_mask) {
+                            const int qi = qt * 64 + ql + q;
+                            if (!(qi >= q_min_lane && qi < Tq && k_idx < Tk)) p = 0.f;
+                        }
+                        pp[qc][be][q] = p;
+                        ds[qc][be][q] = p * (dp[q] - d4[q]);
+                    }
+                }
+            }
+#pragma unroll
+            for (int qc = 0; qc < C::KCH; ++qc) {
+                const uint4 pfrag = pack_frag<T>(pp[qc][0], pp[qc][C::NB - 1]);
+                const uint4 sfrag = pack_frag<T>(ds[qc][0], ds[qc][C::NB - 1]);
+#pragma unroll
+                for (int d = 0; d < C::NDB; ++d) {
+                    const uint4 ao = frag_T<T>(sO, C::PITCH, qc * C::CK, d * 16, lane);   // dO^T[d][q]
+                    mma16<T>(ao, pfrag, dv[d]);
+                    const uint4 aq = frag_T<T>(sQ, C::PITCH, qc * C::CK, d * 16, lane);   // Q^T[d][q]
+                    mma16<T>(aq, sfrag, dk[d]);
+                }
+            }
+        }
+        if (more) {
+            stQ.store(smem + (bi ^ 1) * 2 * C::TILE, tid);
+            stO.store(smem + (bi ^ 1) * 2 * C::TILE + C::TILE, tid);
+            store_vec(bi ^ 1);
+        }
+        __syncthreads();
+    }
+    if (k_idx < Tk) {
+        T* outk = static_cast<T*>(pr.dK) + ((int64_t)b * Tk + k_idx) * P.lddk + h * HD;
+        T* outv = static_cast<T*>(pr.dV) + ((int64_t)b * Tk + k_idx) * P.lddv + h * HD;
+        const float2* rope = reinterpret_cast<const float2*>(P.rope) + (int64_t)k_idx * (HD / 2);
+#pragma unroll
+        for (int d = 0; d < C::NDB; ++d) {
+            const int d0 = d * 16 + g * 4;
+            if (d0 < HD) {
+                float v[4] = {dk[d][0], dk[d][1], dk[d][2], dk[d][3]};
+                unrope(v[0], v[1], rope[d0 >> 1]);
+                unrope(v[2], v[3], rope[(d0 >> 1) + 1]);
+                store4(outk + d0, v[0], v[1], v[2], v[3]);
+                store4(outv + d0, dv[d][0], dv[d][1], dv[d][2], dv[d][3]);
+            }
+        }
+    }
+}
+
+template <typename T, int HD>
+static void launch_bwd(const SeaAttnBwdParams& P, hipStream_t s) {
+    const dim3 block(256);
+    attn_bwd_dq_kernel<T, HD><<<dim3((P.Tq + 63) / 64, P.B * P.H, P.n_problems), block, 0, s>>>(P);
+    attn_bwd_dkv_kernel<T, HD><<<dim3((P.Tk + 63) / 64, P.B * P.H, P.n_problems), block, 0, s>>>(P);
+}
+
+template <typename T>
+static int dispatch_bwd(const SeaAttnBwdParams& P, hipStream_t s) {
+    switch (P.hd) {
+        case 8: launch_bwd<T, 8>(P, s); break;
+        case 16: launch_bwd<T, 16>(P, s); break;
+        case 32: launch_bwd<T, 32>(P, s); break;
+        case 64: launch_bwd<T, 64>(P, s); break;
+        case 128: launch_bwd<T, 128>(P, s); break;
+        default: return -1;
+    }
+    return 0;
+}
+
+extern "C" int sea_attention_bwd(const SeaAttnBwdParams* params, int dtype, void* stream) {
+    SEA_REQUIRE(params != nullptr, "sea_attention_bwd: null params");
+    const SeaAttnBwdParams& P = *params;
+    SEA_REQUIRE(dtype == SEA_F32 || dtype == SEA_BF16, "sea_attention_bwd: bad dtype %d", dtype);
+    SEA_REQUIRE(P.n_problems >= 1 && P.n_problems <= SEA_MAX_ATTN_PROBLEMS, "sea_attention_bwd: n_problems=%d", P.n_problems);
+    SEA_REQUIRE(P.B >= 1 && P.H >= 1 && P.Tq >= 1 && P.Tk >= 1 && P.cap >= P.Tk && P.q_pos0 >= 0 && P.src_len >= 0 && P.rope,
+                "sea_attention_bwd: bad sizes B=%d H=%d Tq=%d Tk=%d cap=%d", P.B, P.H, P.Tq, P.Tk, P.cap);
+    SEA_REQUIRE(P.hd == 8 || P.hd == 16 || P.hd == 32 || P.hd == 64 || P.hd == 128, "sea_attention_bwd: unsupported head dim %d", P.hd);
+    const int epc = dtype == SEA_BF16 ? 8 : 4;
+    SEA_REQUIRE(P.ldo % epc == 0 && P.lddo % epc == 0 && P.lddq % 4 == 0 && P.lddk % 4 == 0 && P.lddv % 4 == 0, "sea_attention_bwd: bad strides");
+    SEA_REQUIRE((long)P.B * P.H <= 65535, "sea_attention_bwd: B*H too large for grid.y");
+    for (int i = 0; i < P.n_problems; ++i) {
+        const SeaAttnBwdProblem& q = P.p[i];
+        SEA_REQUIRE(q.Q && q.K && q.V && q.O && q.dO && q.LSE && q.delta && q.dQ && q.dK && q.dV, "sea_attention_bwd[%d]: null pointer", i);
+        SEA_REQUIRE(sea_aligned16(q.Q) && sea_aligned16(q.K) && sea_aligned16(q.V) && sea_aligned16(q.O) && sea_aligned16(q.dO) &&
+                        sea_aligned16(q.dQ) && sea_aligned16(q.dK) && sea_aligned16(q.dV), "sea_attention_bwd[%d]: pointers must be 16-byte aligned", i);
+    }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int rc = dtype == SEA_BF16 ? dispatch_bwd<__bf16>(P, s) : dispatch_bwd<float>(P, s);
+    SEA_REQUIRE(rc == 0, "sea_attention_bwd: no kernel for hd=%d", P.hd);
+    SEA_CHECK_LAUNCH("sea_attention_bwd");
+    return SEA_OK;
+}

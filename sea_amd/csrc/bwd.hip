@@ -1,0 +1,563 @@
+// Backward-pass kernels of the SEA temporal path other than attention (gfx950):
+//   sea_wgrad_grouped      dW[N,K] += dY[M,N]^T . X[M,K], db[N] += colsum(dY)       (TN GEMM, split over M, fp32 atomics)
+//   sea_transpose_weights  act-dtype W^T shadow of every weight matrix (operand of the data-gradient GEMMs)
+//   sea_rownorm_bwd        backward of sea_rownorm (AdaLN / LayerNorm / LayerNorm+GELU)
+//   sea_silu_outer_bwd     backward of sea_silu_outer
+//   sea_ib_bwd             parameter gradients of the information-bottleneck MLP
+#include "sea_common.hpp"
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+// ------------------------------------------------------------------------------------------------ transposed fragments
+// A tile stored [m][c] (contraction index m is the ROW) must feed an MFMA operand that wants, per lane, EPC consecutive
+// m for one column c0 + (lane & 15).  bf16: two ds_read_b64_tr_b16 (each delivers a 4-row x 16-column block
+// column-major: lane 4q+p of a 16-lane group supplies the address of row q, columns 4p..4p+3 and receives column
+// (lane & 15) of the 4 rows; cdna_hip_programming.md T10).  f32: four 4-byte reads.
+template <typename T>
+__device__ __forceinline__ uint4 load_frag_T(const char* tile, int pitch, int m0, int c0, int lane);
+
+template <>
+__device__ __forceinline__ uint4 load_frag_T<__bf16>(const char* tile, int pitch, int m0, int c0, int lane) {
+    const int idx = lane & 15, gg = lane >> 4, q = idx >> 2, p = idx & 3;
+    const char* base = tile + (m0 + 8 * gg + q) * pitch + (c0 + 4 * p) * 2;
+    typedef s16x4 __attribute__((address_space(3))) * lds_p;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(base));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(base + 4 * pitch));
+    uint4 out;
+    out.x = (unsigned)(unsigned short)lo[0] | ((unsigned)(unsigned short)lo[1] << 16);
+    out.y = (unsigned)(unsigned short)lo[2] | ((unsigned)(unsigned short)lo[3] << 16);
+    out.z = (unsigned)(unsigned short)hi[0] | ((unsigned)(unsigned short)hi[1] << 16);
+    out.w = (unsigned)(unsigned short)hi[2] | ((unsigned)(unsigned short)hi[3] << 16);
+    return out;
+}
+template <>
+__device__ __forceinline__ uint4 load_frag_T<float>(const char* tile, int pitch, int m0, int c0, int lane) {
+    const int idx = lane & 15, gg = lane >> 4;
+    const char* base = tile + (m0 + 4 * gg) * pitch + (c0 + idx) * 4;
+    f32x4 v = {*reinterpret_cast<const float*>(base), *reinterpret_cast<const float*>(base + pitch),
+               *reinterpret_cast<const float*>(base + 2 * pitch), *reinterpret_cast<const float*>(base + 3 * pitch)};
+    return __builtin_bit_cast(uint4, v);
+}
+
+// ------------------------------------------------------------------------------------------------ weight gradient (TN GEMM)
+#define SEA_MAX_WGRAD_GROUPS 16
+struct WgradLaunch {
+    SeaWgradGroup g[SEA_MAX_WGRAD_GROUPS];
+    int tile_start[SEA_MAX_WGRAD_GROUPS + 1];  // in (tile x split) units
+    int splits[SEA_MAX_WGRAD_GROUPS];
+    int rows_per_split[SEA_MAX_WGRAD_GROUPS];
+    int n_groups;
+};
+
+// Output tile 64 (n) x 64 (k); 4 waves as 2 x 2, each 32 x 32 = 2 x 2 MFMA tiles; the contraction runs over 64-row stages of
+// dY and X held [m][64 columns] in LDS (row pitch + 16 bytes), double-buffered through registers like the forward GEMM.
+template <typename T>
+__global__ __launch_bounds__(256) void wgrad_kernel(const WgradLaunch L) {
+    constexpr int EPC = ActTraits<T>::EPC, CK = ActTraits<T>::CK;
+    constexpr int ROWB = 64 * (int)sizeof(T);      // bytes of one tile row
+    constexpr int PITCH = ROWB + 16;
+    constexpr int CPR = ROWB / 16;                 // 16-byte chunks per row
+    constexpr int NCH = 64 * CPR / 256;            // chunks per thread per operand
+    constexpr int TILE_B = 64 * PITCH;
+    __shared__ __attribute__((aligned(16))) char smem[4 * TILE_B];  // 2 buffers x (dY tile, X tile)
+
+    int gi = 0;
+    while (gi + 1 < L.n_groups && (int)blockIdx.x >= L.tile_start[gi + 1]) ++gi;
+    const SeaWgradGroup& G = L.g[gi];
+    int t = blockIdx.x - L.tile_start[gi];
+    const int splits = L.splits[gi];
+    const int split = t % splits;
+    t /= splits;
+    const int tiles_k = (G.K + 63) / 64;
+    const int tn = t / tiles_k, tk = t - tn * tiles_k;
+    const int n0 = tn * 64, k0 = tk * 64;
+    const int m_begin = split * L.rows_per_split[gi];
+    int m_end = m_begin + L.rows_per_split[gi];
+    m_end = m_end < G.M ? m_end : G.M;
+    if (m_begin >= m_end) return;  // block-uniform
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wn = wave >> 1, wk = wave & 1;
+    const T* dY = static_cast<const T*>(G.dY);
+    const T* X = static_cast<const T*>(G.X);
+    uint4 ry[NCH], rx[NCH];
+    auto load_stage = [&](int ms) {
+#pragma unroll
+        for (int u = 0; u < NCH; ++u) {
+            const int idx = tid + u * 256;
+            const int rr = idx / CPR, cc = idx - rr * CPR;
+            const int m = ms + rr;
+            const int cn = n0 + cc * EPC, ck = k0 + cc * EPC;
+            ry[u] = (m < m_end && cn < G.N) ? *reinterpret_cast<const uint4*>(dY + (int64_t)m * G.lddy + cn) : make_uint4(0, 0, 0, 0);
+            rx[u] = (m < m_end && ck < G.K) ? *reinterpret_cast<const uint4*>(X + (int64_t)m * G.ldx + ck) : make_uint4(0, 0, 0, 0);
+        }
+    };
+    auto store_stage = [&](int buf) {
+        char* sy = smem + buf * 2 * TILE_B;
+        char* sx = sy + TILE_B;
+#pragma unroll
+        for (int u = 0; u < NCH; ++u) {
+            const int idx = tid + u * 256;
+            const int rr = idx / CPR, cc = idx - rr * CPR;
+            *reinterpret_cast<uint4*>(sy + rr * PITCH + cc * 16) = ry[u];
+            *reinterpret_cast<uint4*>(sx + rr * PITCH + cc * 16) = rx[u];
+        }
+    };
+
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float bsum = 0.f;
+    const bool do_bias = G.db != nullptr && tk == 0 && tid < 64;
+
+    const int n_stage = (m_end - m_begin + 63) / 64;
+    load_stage(m_begin);
+    store_stage(0);
+    __syncthreads();
+    for (int st = 0; st < n_stage; ++st) {
+        const char* sy = smem + (st & 1) * 2 * TILE_B;
+        const char* sx = sy + TILE_B;
+        const bool more = st + 1 < n_stage;
+        if (more) load_stage(m_begin + (st + 1) * 64);
+#pragma unroll
+        for (int mk = 0; mk < 64; mk += CK) {
+            uint4 a[2], b[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) a[i] = load_frag_T<T>(sy, PITCH, mk, wn * 32 + i * 16, lane);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) b[j] = load_frag_T<T>(sx, PITCH, mk, wk * 32 + j * 16, lane);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) mma16<T>(a[i], b[j], acc[i][j]);
+        }
+        if (do_bias) {
+            const T* col = reinterpret_cast<const T*>(sy) + tid;
+#pragma unroll 8
+            for (int rr = 0; rr < 64; ++rr) bsum += to_f32(*reinterpret_cast<const T*>(reinterpret_cast<const char*>(col) + rr * PITCH));
+        }
+        if (more) store_stage((st + 1) & 1);
+        __syncthreads();
+    }
+    // C[n][k]: lane holds column k = lane & 15, rows n = 4 (lane >> 4) + reg
+    const int r = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int k = k0 + wk * 32 + j * 16 + r;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int n = n0 + wn * 32 + i * 16 + g * 4 + q;
+                if (n < G.N && k < G.K) atomicAdd(G.dW + (int64_t)n * G.lddw + k, acc[i][j][q]);
+            }
+        }
+    if (do_bias && n0 + tid < G.N) atomicAdd(G.db + n0 + tid, bsum);
+}
+
+extern "C" int sea_wgrad_grouped(const SeaWgradGroup* groups, int n_groups, int dtype, void* stream) {
+    SEA_REQUIRE(groups && n_groups >= 1 && n_groups <= SEA_MAX_WGRAD_GROUPS, "sea_wgrad_grouped: n_groups=%d", n_groups);
+    SEA_REQUIRE(dtype == SEA_F32 || dtype == SEA_BF16, "sea_wgrad_grouped: bad dtype %d", dtype);
+    const int epc = dtype == SEA_BF16 ? 8 : 4;
+    WgradLaunch L;
+    memset(&L, 0, sizeof(L));
+    long base_tiles = 0;
+    for (int i = 0; i < n_groups; ++i) {
+        const SeaWgradGroup& G = groups[i];
+        SEA_REQUIRE(G.dY && G.X && G.dW, "sea_wgrad_grouped[%d]: null pointer", i);
+        SEA_REQUIRE(G.M >= 1 && G.N >= 8 && G.K >= 8 && G.N % 8 == 0 && G.K % 8 == 0, "sea_wgrad_grouped[%d]: bad shape M=%d N=%d K=%d", i, G.M, G.N, G.K);
+        SEA_REQUIRE(G.lddy % epc == 0 && G.ldx % epc == 0 && G.lddy >= G.N && G.ldx >= G.K && G.lddw >= G.K, "sea_wgrad_grouped[%d]: bad strides", i);
+        SEA_REQUIRE(sea_aligned16(G.dY) && sea_aligned16(G.X), "sea_wgrad_grouped[%d]: dY/X must be 16-byte aligned", i);
+        base_tiles += (long)((G.N + 63) / 64) * ((G.K + 63) / 64);
+    }
+    // split the contraction so that the launch has ~2 workgroups per CU, never below 256 rows per split
+    int total = 0;
+    for (int i = 0; i < n_groups; ++i) {
+        const SeaWgradGroup& G = groups[i];
+        long want = (512 + base_tiles - 1) / base_tiles;
+        long max_splits = (G.M + 255) / 256;
+        int splits = (int)(want < 1 ? 1 : (want > max_splits ? max_splits : want));
+        int rows = ((G.M + splits - 1) / splits + 63) / 64 * 64;
+        splits = (G.M + rows - 1) / rows;
+        L.g[i] = G;
+        L.splits[i] = splits;
+        L.rows_per_split[i] = rows;
+        L.tile_start[i] = total;
+        total += ((G.N + 63) / 64) * ((G.K + 63) / 64) * splits;
+    }
+    L.tile_start[n_groups] = total;
+    L.n_groups = n_groups;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (dtype == SEA_BF16) wgrad_kernel<__bf16><<<dim3(total), dim3(256), 0, s>>>(L);
+    else wgrad_kernel<float><<<dim3(total), dim3(256), 0, s>>>(L);
+    SEA_CHECK_LAUNCH("sea_wgrad_grouped");
+    return SEA_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ W^T shadow
+// One 32 x 32 tile per workgroup; desc (device memory) = n_desc x {src_off, dst_off, rows, cols} in elements.
+template <typename T>
+__global__ __launch_bounds__(256) void transpose_weights_kernel(const float* __restrict__ src, T* __restrict__ dst, const int64_t* __restrict__ desc,
+                                                                const int* __restrict__ tile_start, int n_desc) {
+    __shared__ float tile[32][33];
+    const int bid = blockIdx.x;
+    int lo = 0, hi = n_desc - 1;
+    while (lo < hi) {  // last matrix whose first tile is <= bid
+        const int mid = (lo + hi + 1) >> 1;
+        if (tile_start[mid] <= bid) lo = mid; else hi = mid - 1;
+    }
+    const int64_t* d = desc + 4 * lo;
+    const int64_t so = d[0], dof = d[1];
+    const int rows = (int)d[2], cols = (int)d[3];
+    const int t = bid - tile_start[lo];
+    const int tiles_c = (cols + 31) / 32;
+    const int r0 = (t / tiles_c) * 32, c0 = (t % tiles_c) * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = r0 + ty + 8 * i, c = c0 + tx;
+        tile[ty + 8 * i][tx] = (r < rows && c < cols) ? src[so + (int64_t)r * cols + c] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = c0 + ty + 8 * i, r = r0 + tx;  // dst is [cols][rows]
+        if (r < rows && c < cols) dst[dof + (int64_t)c * rows + r] = from_f32<T>(tile[tx][ty + 8 * i]);
+    }
+}
+
+extern "C" int sea_transpose_weights(const float* src, void* dst, int dst_dtype, const int64_t* desc, const int32_t* tile_start, int n_desc,
+                                     int total_tiles, void* stream) {
+    SEA_REQUIRE(src && dst && desc && tile_start && n_desc >= 1 && total_tiles >= 1, "sea_transpose_weights: bad arguments");
+    SEA_REQUIRE(dst_dtype == SEA_F32 || dst_dtype == SEA_BF16, "sea_transpose_weights: bad dtype");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (dst_dtype == SEA_BF16) transpose_weights_kernel<__bf16><<<dim3(total_tiles), dim3(256), 0, s>>>(src, static_cast<__bf16*>(dst), desc, tile_start, n_desc);
+    else transpose_weights_kernel<float><<<dim3(total_tiles), dim3(256), 0, s>>>(src, static_cast<float*>(dst), desc, tile_start, n_desc);
+    SEA_CHECK_LAUNCH("sea_transpose_weights");
+    return SEA_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ row-norm backward
+#define SEA_MAX_NORM_BWD_GROUPS 8
+struct NormBwdLaunch {
+    SeaNormBwdGroup g[SEA_MAX_NORM_BWD_GROUPS];
+    int M, d, gelu, accumulate;
+};
+
+// grid = (nblk, n_groups); each workgroup walks rows blockIdx.x*4 + wave, += 4*gridDim.x; one wave per row.
+// y = xhat*s + t, s = gamma (+1 + mod_w), t = beta (+ mod_b);  optional y = gelu(y).
+// dxhat = dy*s;  dx = rstd*(dxhat - mean(dxhat) - xhat*mean(dxhat*xhat));  dgamma += dy*xhat;  dbeta += dy;
+// dmod = [dy*xhat | dy].  Column sums are accumulated in LDS (ds_add_f32) and flushed with one global atomic per column.
+template <typename T, bool DY_ACT, bool X_ACT>
+__global__ __launch_bounds__(256) void rownorm_bwd_kernel(const NormBwdLaunch L) {
+    extern __shared__ __attribute__((aligned(16))) float cs[];  // [2][d]
+    const SeaNormBwdGroup& G = L.g[blockIdx.y];
+    const int d = L.d, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int i = threadIdx.x; i < 2 * d; i += 256) cs[i] = 0.f;
+    __syncthreads();
+    using DYT = typename std::conditional<DY_ACT, T, float>::type;
+    using XT = typename std::conditional<X_ACT, T, float>::type;
+    const float inv_d = 1.0f / (float)d;
+    for (int row = blockIdx.x * 4 + wave; row < L.M; row += 4 * gridDim.x) {
+        const DYT* dy = static_cast<const DYT*>(G.dY) + (int64_t)row * G.lddy;
+        const XT* x = static_cast<const XT*>(G.X) + (int64_t)row * G.ldx;
+        const T* mod = G.mod ? static_cast<const T*>(G.mod) + (int64_t)row * G.ldmod : nullptr;
+        T* dmod = G.dmod ? static_cast<T*>(G.dmod) + (int64_t)row * G.lddmod : nullptr;
+        const float mean = G.mean[row], rstd = G.rstd[row];
+        float c1 = 0.f, c2 = 0.f;
+        for (int i = lane * 4; i < d; i += 256) {
+            float xv[4], dv[4], s[4], tt[4] = {0.f, 0.f, 0.f, 0.f};
+            load4(x + i, xv);
+            load4(dy + i, dv);
+            load4(G.gamma + i, s);
+            if (mod) {
+                float mw[4];
+                load4(mod + i, mw);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) s[e] += 1.0f + mw[e];
+            }
+            if (L.gelu) {
+                if (G.beta) load4(G.beta + i, tt);
+                if (mod) {
+                    float mb[4];
+                    load4(mod + d + i, mb);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) tt[e] += mb[e];
+                }
+            }
+            float dyx[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float xh = (xv[e] - mean) * rstd;
+                if (L.gelu) dv[e] *= gelu_erf_grad(xh * s[e] + tt[e]);
+                const float dxh = dv[e] * s[e];
+                c1 += dxh;
+                c2 += dxh * xh;
+                dyx[e] = dv[e] * xh;
+                atomicAdd(&cs[i + e], dyx[e]);
+                atomicAdd(&cs[d + i + e], dv[e]);
+            }
+            if (dmod) {
+                store4(dmod + i, dyx[0], dyx[1], dyx[2], dyx[3]);
+                store4(dmod + d + i, dv[0], dv[1], dv[2], dv[3]);
+            }
+        }
+        c1 = wave_sum(c1) * inv_d;
+        c2 = wave_sum(c2) * inv_d;
+        float* dx32 = G.dX32 ? G.dX32 + (int64_t)row * G.lddx32 : nullptr;
+        T* dxa = G.dXact ? static_cast<T*>(G.dXact) + (int64_t)row * G.lddxact : nullptr;
+        for (int i = lane * 4; i < d; i += 256) {
+            float xv[4], dv[4], s[4], tt[4] = {0.f, 0.f, 0.f, 0.f};
+            load4(x + i, xv);
+            load4(dy + i, dv);
+            load4(G.gamma + i, s);
+            if (mod) {
+                float mw[4];
+                load4(mod + i, mw);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) s[e] += 1.0f + mw[e];
+            }
+            if (L.gelu) {
+                if (G.beta) load4(G.beta + i, tt);
+                if (mod) {
+                    float mb[4];
+                    load4(mod + d + i, mb);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) tt[e] += mb[e];
+                }
+            }
+            float o[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float xh = (xv[e] - mean) * rstd;
+                if (L.gelu) dv[e] *= gelu_erf_grad(xh * s[e] + tt[e]);
+                o[e] = rstd * (dv[e] * s[e] - c1 - xh * c2);
+            }
+            if (dx32) {
+                if (L.accumulate) {
+                    float old[4];
+                    load4(dx32 + i, old);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] += old[e];
+                }
+                store4(dx32 + i, o[0], o[1], o[2], o[3]);
+            }
+            if (dxa) store4(dxa + i, o[0], o[1], o[2], o[3]);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < d; i += 256) {
+        if (G.dgamma) atomicAdd(G.dgamma + i, cs[i]);
+        if (G.dbeta) atomicAdd(G.dbeta + i, cs[d + i]);
+    }
+}
+
+extern "C" int sea_rownorm_bwd(const SeaNormBwdGroup* groups, int n_groups, int M, int d, int dy_is_act, int x_is_act, int gelu,
+                               int accumulate, int dtype, void* stream) {
+    SEA_REQUIRE(groups && n_groups >= 1 && n_groups <= SEA_MAX_NORM_BWD_GROUPS, "sea_rownorm_bwd: n_groups=%d", n_groups);
+    SEA_REQUIRE(dtype == SEA_F32 || dtype == SEA_BF16, "sea_rownorm_bwd: bad dtype %d", dtype);
+    SEA_REQUIRE(M >= 1 && d >= 4 && d % 4 == 0 && d <= 16384, "sea_rownorm_bwd: bad M=%d d=%d", M, d);
+    NormBwdLaunch L;
+    memset(&L, 0, sizeof(L));
+    for (int i = 0; i < n_groups; ++i) {
+        const SeaNormBwdGroup& G = groups[i];
+        SEA_REQUIRE(G.dY && G.X && G.gamma && G.mean && G.rstd && (G.dX32 || G.dXact), "sea_rownorm_bwd[%d]: null pointer", i);
+        SEA_REQUIRE(G.lddy % 4 == 0 && G.ldx % 4 == 0 && G.lddy >= d && G.ldx >= d, "sea_rownorm_bwd[%d]: bad input strides", i);
+        SEA_REQUIRE((!G.mod || (G.ldmod % 4 == 0 && G.ldmod >= 2 * d)) && (!G.dmod || (G.lddmod % 4 == 0 && G.lddmod >= 2 * d)) &&
+                        (!G.dX32 || (G.lddx32 % 4 == 0 && G.lddx32 >= d)) && (!G.dXact || (G.lddxact % 4 == 0 && G.lddxact >= d)),
+                    "sea_rownorm_bwd[%d]: bad strides", i);
+        SEA_REQUIRE(sea_aligned16(G.dY) && sea_aligned16(G.X) && sea_aligned16(G.mod) && sea_aligned16(G.gamma) && sea_aligned16(G.beta) &&
+                        sea_aligned16(G.dX32) && sea_aligned16(G.dXact) && sea_aligned16(G.dmod), "sea_rownorm_bwd[%d]: pointers must be 16-byte aligned", i);
+        L.g[i] = G;
+    }
+    L.M = M; L.d = d; L.gelu = gelu; L.accumulate = accumulate;
+    int nblk = (M + 3) / 4;
+    if (nblk > 512) nblk = 512;
+    const dim3 grid(nblk, n_groups), block(256);
+    const size_t lds = (size_t)2 * d * sizeof(float);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+#define LAUNCH_NB(TT, DYA, XA)                                                                                             \
+    do {                                                                                                                   \
+        if (lds > 65536) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rownorm_bwd_kernel<TT, DYA, XA>),          \
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                  \
+        rownorm_bwd_kernel<TT, DYA, XA><<<grid, block, lds, s>>>(L);                                                       \
+    } while (0)
+    if (dtype == SEA_BF16) {
+        if (dy_is_act && x_is_act) LAUNCH_NB(__bf16, true, true);
+        else if (dy_is_act) LAUNCH_NB(__bf16, true, false);
+        else if (x_is_act) LAUNCH_NB(__bf16, false, true);
+        else LAUNCH_NB(__bf16, false, false);
+    } else {
+        LAUNCH_NB(float, false, false);
+    }
+#undef LAUNCH_NB
+    SEA_CHECK_LAUNCH("sea_rownorm_bwd");
+    return SEA_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ silu outer backward
+#define SEA_MAX_SILU_BWD_GROUPS 24
+struct SiluBwdLaunch {
+    SeaSiluBwdGroup g[SEA_MAX_SILU_BWD_GROUPS];
+    const float* c;
+    int M;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void silu_outer_bwd_kernel(const SiluBwdLaunch L) {
+    extern __shared__ __attribute__((aligned(16))) float cs[];  // [2][K2]
+    const SeaSiluBwdGroup& G = L.g[blockIdx.y];
+    const int K2 = G.K2, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int i = threadIdx.x; i < 2 * K2; i += 256) cs[i] = 0.f;
+    __syncthreads();
+    for (int row = blockIdx.x * 4 + wave; row < L.M; row += 4 * gridDim.x) {
+        const float cv = L.c[row];
+        const T* dh = static_cast<const T*>(G.dHid) + (int64_t)row * G.ld;
+        for (int i = lane * 4; i < K2; i += 256) {
+            float w[4], bb[4], dv[4];
+            load4(G.w1 + i, w);
+            load4(G.b1 + i, bb);
+            load4(dh + i, dv);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float pre = w[e] * cv + bb[e];
+                const float sg = 1.0f / (1.0f + __expf(-pre));
+                const float dpre = dv[e] * sg * (1.0f + pre * (1.0f - sg));
+                atomicAdd(&cs[i + e], dpre * cv);
+                atomicAdd(&cs[K2 + i + e], dpre);
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < K2; i += 256) {
+        atomicAdd(G.dw1 + i, cs[i]);
+        atomicAdd(G.db1 + i, cs[K2 + i]);
+    }
+}
+
+extern "C" int sea_silu_outer_bwd(const SeaSiluBwdGroup* groups, int n_groups, const float* c, int M, int dtype, void* stream) {
+    SEA_REQUIRE(groups && c && n_groups >= 1 && n_groups <= SEA_MAX_SILU_BWD_GROUPS && M >= 1, "sea_silu_outer_bwd: bad arguments");
+    SEA_REQUIRE(dtype == SEA_F32 || dtype == SEA_BF16, "sea_silu_outer_bwd: bad dtype %d", dtype);
+    SiluBwdLaunch L;
+    memset(&L, 0, sizeof(L));
+    int maxk = 0;
+    for (int i = 0; i < n_groups; ++i) {
+        const SeaSiluBwdGroup& G = groups[i];
+        SEA_REQUIRE(G.dHid && G.w1 && G.b1 && G.dw1 && G.db1 && G.K2 >= 4 && G.K2 % 4 == 0 && G.K2 <= 16384 && G.ld >= G.K2 && G.ld % 4 == 0, "sea_silu_outer_bwd[%d]: bad group", i);
+        SEA_REQUIRE(sea_aligned16(G.dHid) && sea_aligned16(G.w1) && sea_aligned16(G.b1), "sea_silu_outer_bwd[%d]: pointers must be 16-byte aligned", i);
+        L.g[i] = G;
+        maxk = G.K2 > maxk ? G.K2 : maxk;
+    }
+    L.c = c; L.M = M;
+    int nblk = (M + 3) / 4;
+    if (nblk > 256) nblk = 256;
+    const size_t lds = (size_t)2 * maxk * sizeof(float);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (dtype == SEA_BF16) {
+        if (lds > 65536) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(silu_outer_bwd_kernel<__bf16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        silu_outer_bwd_kernel<__bf16><<<dim3(nblk, n_groups), dim3(256), lds, s>>>(L);
+    } else {
+        if (lds > 65536) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(silu_outer_bwd_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        silu_outer_bwd_kernel<float><<<dim3(nblk, n_groups), dim3(256), lds, s>>>(L);
+    }
+    SEA_CHECK_LAUNCH("sea_silu_outer_bwd");
+    return SEA_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ information bottleneck backward
+// x_f += ib(c) leaves dx unchanged; this kernel produces the PARAMETER gradients of ib = W2 gelu(LN_h(w1 c + b1)) + b2 from
+// dib = sum_f dX_f.  One wave per row; LDS accumulators for db2 [E] and dW2 [E][h]; the h-wide hidden state lives in lanes 0..h-1.
+__global__ __launch_bounds__(256) void ib_bwd_kernel(const SeaIbBwdParams P) {
+    extern __shared__ __attribute__((aligned(16))) float cs[];  // [E] db2, [E*h] dW2
+    const int E = P.E, h = P.h, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float* s_b2 = cs;
+    float* s_w2 = cs + E;
+    for (int i = threadIdx.x; i < E * (h + 1); i += 256) cs[i] = 0.f;
+    __syncthreads();
+    const bool act = lane < h;
+    const float w1 = act ? P.w1[lane] : 0.f, b1 = act ? P.b1[lane] : 0.f;
+    const float lw = act ? P.lnw[lane] : 0.f, lb = act ? P.lnb[lane] : 0.f;
+    float a_w1 = 0.f, a_b1 = 0.f, a_lw = 0.f, a_lb = 0.f;  // lane k accumulates the gradients of hidden unit k over its rows
+    for (int row = blockIdx.x * 4 + wave; row < P.M; row += 4 * gridDim.x) {
+        const float cv = P.c[row];
+        const float pre = act ? w1 * cv + b1 : 0.f;
+        const float mean = wave_sum(pre) / (float)h;
+        const float cen = act ? pre - mean : 0.f;
+        const float var = wave_sum(cen * cen) / (float)h;
+        const float rstd = 1.0f / sqrtf(var + 1e-5f);
+        const float xh = cen * rstd;
+        const float u = xh * lw + lb;
+        const float hid = act ? gelu_erf(u) : 0.f;
+        float dhid = 0.f;  // lane k will hold d(hid_k)
+        for (int e0 = lane * 4; e0 < E; e0 += 256) {
+            float dib[4] = {0.f, 0.f, 0.f, 0.f};
+            for (int f = 0; f < P.n_fields; ++f) {
+                float v[4];
+                load4(P.dX[f] + (int64_t)row * P.ldx + e0, v);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) dib[e] += v[e];
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) atomicAdd(&s_b2[e0 + e], dib[e]);
+            for (int k = 0; k < h; ++k) {
+                const float hk = __shfl(hid, k);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) atomicAdd(&s_w2[(e0 + e) * h + k], dib[e] * hk);
+            }
+        }
+        // dhid_k = sum_e dib[e] W2[e][k]: every lane re-walks its columns per k (E*h is small), then a wave sum per k
+        for (int k = 0; k < h; ++k) {
+            float part = 0.f;
+            for (int e0 = lane * 4; e0 < E; e0 += 256) {
+                float dib[4] = {0.f, 0.f, 0.f, 0.f};
+                for (int f = 0; f < P.n_fields; ++f) {
+                    float v[4];
+                    load4(P.dX[f] + (int64_t)row * P.ldx + e0, v);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) dib[e] += v[e];
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) part += dib[e] * P.w2[(int64_t)(e0 + e) * h + k];
+            }
+            part = wave_sum(part);
+            if (lane == k) dhid = part;
+        }
+        const float du = act ? dhid * gelu_erf_grad(u) : 0.f;
+        a_lw += du * xh;
+        a_lb += du;
+        const float dxh = du * lw;
+        const float c1 = wave_sum(dxh) / (float)h;
+        const float c2 = wave_sum(dxh * xh) / (float)h;
+        const float dpre = act ? rstd * (dxh - c1 - xh * c2) : 0.f;
+        a_w1 += dpre * cv;
+        a_b1 += dpre;
+    }
+    if (act) {
+        atomicAdd(P.dw1 + lane, a_w1);
+        atomicAdd(P.db1 + lane, a_b1);
+        atomicAdd(P.dlnw + lane, a_lw);
+        atomicAdd(P.dlnb + lane, a_lb);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < E; i += 256) atomicAdd(P.db2 + i, s_b2[i]);
+    for (int i = threadIdx.x; i < E * h; i += 256) atomicAdd(P.dw2 + i, s_w2[i]);
+}
+
+extern "C" int sea_ib_bwd(const SeaIbBwdParams* params, void* stream) {
+    SEA_REQUIRE(params != nullptr, "sea_ib_bwd: null params");
+    const SeaIbBwdParams& P = *params;
+    SEA_REQUIRE(P.n_fields >= 1 && P.n_fields <= 8 && P.M >= 1 && P.E >= 4 && P.E % 4 == 0 && P.h >= 1 && P.h <= 64 && P.ldx >= P.E && P.ldx % 4 == 0,
+                "sea_ib_bwd: bad sizes");
+    SEA_REQUIRE(P.c && P.w1 && P.b1 && P.lnw && P.lnb && P.w2 && P.dw1 && P.db1 && P.dlnw && P.dlnb && P.dw2 && P.db2, "sea_ib_bwd: null pointer");
+    for (int f = 0; f < P.n_fields; ++f) SEA_REQUIRE(P.dX[f] && sea_aligned16(P.dX[f]), "sea_ib_bwd: dX[%d] null or misaligned", f);
+    const size_t lds = (size_t)P.E * (P.h + 1) * sizeof(float);
+    SEA_REQUIRE(lds <= 160 * 1024, "sea_ib_bwd: E*(h+1) too large for LDS");
+    if (lds > 65536) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ib_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    int nblk = (P.M + 3) / 4;
+    if (nblk > 128) nblk = 128;
+    ib_bwd_kernel<<<dim3(nblk), dim3(256), lds, static_cast<hipStream_t>(stream)>>>(P);
+    SEA_CHECK_LAUNCH("sea_ib_bwd");
+    return SEA_OK;
+}

@@ -160,3 +160,92 @@ def convert(src: torch.Tensor, dst: torch.Tensor) -> None:
     assert src.dtype == torch.float32 and src.shape == dst.shape
     N.check(N.lib().sea_convert_f32_to_act(src.data_ptr(), src.stride(0), dst.data_ptr(), dst.stride(0), src.shape[0],
                                            src.shape[1], N.dtype_code(dst.dtype), N.stream_ptr()), "sea_convert_f32_to_act")
+
+
+# ------------------------------------------------------------------------------------------------ backward wrappers
+def wgrad_grouped(groups: Sequence[Dict], dtype: torch.dtype) -> None:
+    """groups: dicts with dY act [M,N], X act [M,K], dW f32 [N,K] (accumulated), optional db f32 [N] (accumulated)."""
+    n = len(groups)
+    arr = (N.SeaWgradGroup * n)()
+    for g, d in zip(arr, groups):
+        dY, X, dW = _mat(d["dY"], "dY"), _mat(d["X"], "X"), _mat(d["dW"], "dW")
+        assert dY.dtype == dtype and X.dtype == dtype and dW.dtype == torch.float32
+        g.dY, g.X, g.dW, g.db = dY.data_ptr(), X.data_ptr(), dW.data_ptr(), N.ptr(d.get("db"))
+        g.lddy, g.ldx, g.lddw = dY.stride(0), X.stride(0), dW.stride(0)
+        g.M, g.N, g.K = dY.shape[0], dY.shape[1], X.shape[1]
+        assert X.shape[0] == g.M and dW.shape == (g.N, g.K)
+    N.check(N.lib().sea_wgrad_grouped(arr, n, N.dtype_code(dtype), N.stream_ptr()), "sea_wgrad_grouped")
+
+
+def rownorm_bwd(groups: Sequence[Dict], M: int, d: int, dy_is_act: bool, x_is_act: bool, gelu: bool, accumulate: bool,
+                dtype: torch.dtype) -> None:
+    n = len(groups)
+    arr = (N.SeaNormBwdGroup * n)()
+    for g, gd in zip(arr, groups):
+        dY, X = _mat(gd["dY"], "dY"), _mat(gd["X"], "X")
+        g.dY, g.lddy, g.X, g.ldx = dY.data_ptr(), dY.stride(0), X.data_ptr(), X.stride(0)
+        mod, dmod = gd.get("mod"), gd.get("dmod")
+        g.mod, g.ldmod = N.ptr(mod), (mod.stride(0) if mod is not None else 0)
+        g.dmod, g.lddmod = N.ptr(dmod), (dmod.stride(0) if dmod is not None else 0)
+        g.gamma, g.beta = gd["gamma"].data_ptr(), N.ptr(gd.get("beta"))
+        g.mean, g.rstd = gd["mean"].data_ptr(), gd["rstd"].data_ptr()
+        dx32, dxa = gd.get("dX32"), gd.get("dXact")
+        g.dX32, g.lddx32 = N.ptr(dx32), (dx32.stride(0) if dx32 is not None else 0)
+        g.dXact, g.lddxact = N.ptr(dxa), (dxa.stride(0) if dxa is not None else 0)
+        g.dgamma, g.dbeta = N.ptr(gd.get("dgamma")), N.ptr(gd.get("dbeta"))
+    N.check(N.lib().sea_rownorm_bwd(arr, n, M, d, int(dy_is_act), int(x_is_act), int(gelu), int(accumulate), N.dtype_code(dtype),
+                                    N.stream_ptr()), "sea_rownorm_bwd")
+
+
+def silu_outer_bwd(groups: Sequence[Dict], c: torch.Tensor, M: int, dtype: torch.dtype) -> None:
+    n = len(groups)
+    arr = (N.SeaSiluBwdGroup * n)()
+    for g, gd in zip(arr, groups):
+        dH = _mat(gd["dHid"], "dHid")
+        g.dHid, g.w1, g.b1, g.dw1, g.db1 = dH.data_ptr(), gd["w1"].data_ptr(), gd["b1"].data_ptr(), gd["dw1"].data_ptr(), gd["db1"].data_ptr()
+        g.K2, g.ld = dH.shape[1], dH.stride(0)
+    N.check(N.lib().sea_silu_outer_bwd(arr, n, c.data_ptr(), M, N.dtype_code(dtype), N.stream_ptr()), "sea_silu_outer_bwd")
+
+
+def ib_bwd(dxs: Sequence[torch.Tensor], c, w1, b1, lnw, lnb, w2, dw1, db1, dlnw, dlnb, dw2, db2) -> None:
+    P = N.SeaIbBwdParams()
+    M, E = dxs[0].shape
+    for i, x in enumerate(dxs):
+        _mat(x, "dx")
+        assert x.dtype == torch.float32 and x.stride(0) == dxs[0].stride(0)
+        P.dX[i] = x.data_ptr()
+    P.n_fields, P.ldx = len(dxs), dxs[0].stride(0)
+    P.c, P.w1, P.b1, P.lnw, P.lnb, P.w2 = (t.data_ptr() for t in (c, w1, b1, lnw, lnb, w2))
+    P.dw1, P.db1, P.dlnw, P.dlnb, P.dw2, P.db2 = (t.data_ptr() for t in (dw1, db1, dlnw, dlnb, dw2, db2))
+    P.M, P.E, P.h = M, E, w1.numel()
+    N.check(N.lib().sea_ib_bwd(C.byref(P), N.stream_ptr()), "sea_ib_bwd")
+
+
+def transpose_weights(src_flat: torch.Tensor, dst_flat: torch.Tensor, desc: torch.Tensor, tile_start: torch.Tensor) -> None:
+    """desc int64 [n,4] (src_off, dst_off, rows, cols) and tile_start int32 [n+1] live on the device."""
+    n = desc.shape[0]
+    total = int(tile_start[-1].item()) if not hasattr(tile_start, "_sea_total") else tile_start._sea_total
+    N.check(N.lib().sea_transpose_weights(src_flat.data_ptr(), dst_flat.data_ptr(), N.dtype_code(dst_flat.dtype), desc.data_ptr(),
+                                          tile_start.data_ptr(), n, total, N.stream_ptr()), "sea_transpose_weights")
+
+
+def attention_bwd(problems: Sequence[Dict], rope: torch.Tensor, B: int, H: int, hd: int, Tq: int, Tk: int, cap: int, q_pos0: int,
+                  src_len: int, q_scale: float, dtype: torch.dtype) -> None:
+    """problems: dicts with Q, K, V (row-major), O, dO [B,Tq,H*hd], LSE, delta f32 [B,H,Tq], dQ/dK/dV act [B*T, >= H*hd]."""
+    P = N.SeaAttnBwdParams()
+    P.n_problems = len(problems)
+    for i, d in enumerate(problems):
+        q = P.p[i]
+        for k in ("Q", "K", "V", "O", "dO", "dQ", "dK", "dV"):
+            N.require_gpu(d[k], k)
+            assert d[k].dtype == dtype, k
+        q.Q, q.K, q.V, q.O, q.dO = (d[k].data_ptr() for k in ("Q", "K", "V", "O", "dO"))
+        q.LSE, q.delta = d["LSE"].data_ptr(), d["delta"].data_ptr()
+        q.dQ, q.dK, q.dV = d["dQ"].data_ptr(), d["dK"].data_ptr(), d["dV"].data_ptr()
+    d0 = problems[0]
+    P.rope = rope.data_ptr()
+    P.B, P.H, P.hd, P.Tq, P.Tk, P.cap, P.q_pos0, P.src_len = B, H, hd, Tq, Tk, cap, q_pos0, src_len
+    P.ldo, P.lddo = d0["O"].stride(-2), d0["dO"].stride(-2)
+    P.lddq, P.lddk, P.lddv = d0["dQ"].stride(-2), d0["dK"].stride(-2), d0["dV"].stride(-2)
+    P.q_scale = q_scale
+    N.check(N.lib().sea_attention_bwd(C.byref(P), N.dtype_code(dtype), N.stream_ptr()), "sea_attention_bwd")
