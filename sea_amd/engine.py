@@ -81,7 +81,11 @@ class FlatParams:
                 p.data = view  # the module's parameter now aliases the flat buffer
         self.live_names = [n for _, n, _ in keyed if not is_dead(n)]
         self.flat_act = self.flat32 if act_dtype == torch.float32 else torch.empty(self.n_total, device=device, dtype=act_dtype)
+        self.flat_actT: Optional[torch.Tensor] = None   # transposed weight shadow, built on first training use
+        self._t_desc = self._t_tiles = None
+        self._t_total = 0
         self._synced_version = -1
+        self._synced_T_version = -1
         self.sync()
 
     # -- views
@@ -102,6 +106,54 @@ class FlatParams:
         o, shp = self.offsets[name]
         k = shp[0] if n is None else n
         return self.flat32[o:o + k]
+
+    # -- transposed shadow (operand of the data-gradient GEMMs: dX = dY . W needs W^T in the K-contiguous [N,K] form)
+    def enable_transposed_shadow(self) -> None:
+        if self.flat_actT is not None:
+            return
+        rows = []
+        fused_done = set()
+        for name, (o, shp) in self.offsets.items():
+            if len(shp) != 2 or shp[1] == 1 or ".ib." in name:
+                continue
+            m = _QKV.match(name)
+            if m and m.group(3) == "weight":
+                pre, which = m.group(1), m.group(2)
+                is_self = ".attn.self." in pre
+                if is_self:
+                    if which == "q":
+                        rows.append((o, o, 3 * shp[0], shp[1]))      # [q;k;v] as one [3E, E] matrix
+                    continue
+                if which == "q":
+                    rows.append((o, o, shp[0], shp[1]))
+                elif which == "k":
+                    rows.append((o, o, 2 * shp[0], shp[1]))          # [k;v] as one [2D, D] matrix
+                continue
+            rows.append((o, o, shp[0], shp[1]))
+        desc = torch.tensor(rows, dtype=torch.int64)
+        tiles = ((desc[:, 2] + 31) // 32) * ((desc[:, 3] + 31) // 32)
+        ts = torch.zeros(len(rows) + 1, dtype=torch.int32)
+        ts[1:] = torch.cumsum(tiles, 0).to(torch.int32)
+        self._t_total = int(ts[-1])
+        self._t_desc, self._t_tiles = desc.to(self.device), ts.to(self.device)
+        self.flat_actT = torch.zeros(self.n_total, device=self.device, dtype=self.act_dtype)
+        self.sync_transposed(force=True)
+
+    def sync_transposed(self, force: bool = False) -> None:
+        if self.flat_actT is None:
+            return
+        v = self.flat32._version
+        if force or v != self._synced_T_version:
+            N.check(N.lib().sea_transpose_weights(self.flat32.data_ptr(), self.flat_actT.data_ptr(), N.dtype_code(self.act_dtype),
+                                                  self._t_desc.data_ptr(), self._t_tiles.data_ptr(), self._t_desc.shape[0], self._t_total,
+                                                  N.stream_ptr()), "weight transpose")
+            self._synced_T_version = v
+
+    def actT(self, name: str, rows: Optional[int] = None) -> torch.Tensor:
+        """Activation-dtype view of W^T for the weight `name` ([rows, cols] in the model, possibly fused over adjacent tensors)."""
+        o, shp = self.offsets[name]
+        r = shp[0] if rows is None else rows
+        return self.flat_actT[o:o + r * shp[1]].view(shp[1], r)
 
     def sync(self, force: bool = False) -> None:
         """Refresh the activation-dtype shadow if any parameter view was modified in place since the last sync."""
@@ -139,6 +191,7 @@ class Plan:
         self.cap = _round_up(m.max_len, 8) if mode == "step" else _round_up(T, 8)
         self.pos0 = 0
         self.records: List[_Rec] = []
+        self._cur: List[_Rec] = self.records   # list the record builders append to (forward or backward)
         self._keep: List[object] = []
         self._x_patches: List[Tuple[object, str, int]] = []   # (struct, field, byte offset from x base)
         self._out_patches: List[Tuple[object, str, int]] = []
@@ -162,7 +215,7 @@ class Plan:
             arr = (N.SeaGemmGroup * len(chunk))()
             for g, d in zip(arr, chunk):
                 _fill_gemm(g, **d)
-            self.records.append(_Rec(L.sea_gemm_grouped, [arr, len(chunk), self.code], name, arr))
+            self._cur.append(_Rec(L.sea_gemm_grouped, [arr, len(chunk), self.code], name, arr))
             for g, d in zip(arr, chunk):
                 if d.get("R_is_x") is not None:
                     self._x_patches.append((g, "R", d["R_is_x"]))
@@ -186,7 +239,7 @@ class Plan:
                     self._x_patches.append((g, "X", gd["X_is_x"]))
                 if gd.get("Y_is_out") is not None:
                     self._out_patches.append((g, "Y32", gd["Y_is_out"]))
-            self.records.append(_Rec(L.sea_rownorm, [arr, len(chunk), self.M, d, int(x_is_act), int(gelu), 1e-5, self.code], name, arr))
+            self._cur.append(_Rec(L.sea_rownorm, [arr, len(chunk), self.M, d, int(x_is_act), int(gelu), 1e-5, self.code], name, arr))
 
     def _qkv(self, groups: List[dict], rope: torch.Tensor, hd: int, name: str) -> None:
         L = N.lib()
@@ -199,7 +252,7 @@ class Plan:
             g.M, g.N, g.K, g.col0 = self.M, W.shape[0], W.shape[1], d["col0"]
         common = N.SeaQkvCommon(rope.data_ptr(), self.H, hd, self.T, self.pos0, self.cap, float(hd) ** -0.5)
         self._pos_structs.append(common)
-        self.records.append(_Rec(L.sea_qkv_rope_grouped, [arr, len(groups), C.byref(common), self.code], name, (arr, common)))
+        self._cur.append(_Rec(L.sea_qkv_rope_grouped, [arr, len(groups), C.byref(common), self.code], name, (arr, common)))
 
     def _attn(self, problems: List[dict], hd: int, ldo: int, name: str) -> None:
         L = N.lib()
@@ -213,7 +266,7 @@ class Plan:
             P.B, P.H, P.hd, P.Tq, P.Tk, P.cap = self.B, self.H, hd, self.T, self.pos0 + self.T, self.cap
             P.q_pos0, P.src_len, P.ldo = self.pos0, self.eng.model.src_len, ldo
             self._pos_structs.append(P)
-            self.records.append(_Rec(L.sea_attention_fwd, [C.byref(P), self.code], name, P))
+            self._cur.append(_Rec(L.sea_attention_fwd, [C.byref(P), self.code], name, P))
 
     # ------------------------------------------------------------------ the plan
     def _build(self) -> None:
@@ -250,7 +303,7 @@ class Plan:
                     g.w1, g.b1, g.Hid, g.K2, g.ld = w1.data_ptr(), b1.data_ptr(), hid.data_ptr(), hid.shape[1], hid.stride(0)
                 rec = _Rec(L.sea_silu_outer, [arr, len(chunk), None, M, self.code], "adaln.silu", arr)
                 self._c_patches.append((rec.args, 2))
-                self.records.append(rec)
+                self._cur.append(rec)
             self._gemm(gemm_groups, "adaln.cond_gemm")
 
         def norm_params(pre, d):
@@ -368,7 +421,7 @@ class Plan:
         ib.b2 = P.f32_vec(pre + "ib.layers.3.bias").data_ptr()
         ib.M, ib.E, ib.h = self.M, self.E, self.eng.model.ib_hidden
         self._c_patches.append((ib, "c"))
-        self.records.append(_Rec(N.lib().sea_ib_add, [C.byref(ib)], "ib_add", ib))
+        self._cur.append(_Rec(N.lib().sea_ib_add, [C.byref(ib)], "ib_add", ib))
 
     # ------------------------------------------------------------------ binding and replay
     def bind(self, x: torch.Tensor, ib: torch.Tensor, out: torch.Tensor) -> None:
@@ -472,6 +525,10 @@ class TemporalEngine:
         self.rope_cross = torch.view_as_real(blk.cross_attn[0][0].freqs_cis.to(device)).contiguous()
         self._plans: Dict[Tuple, Plan] = {}
         self._graphs: Dict[Tuple, Tuple] = {}
+        self._train_plans: Dict[Tuple, object] = {}
+        self.grads: Optional[torch.Tensor] = None      # flat fp32 gradient buffer, same layout as params.flat32
+        self.grads_dirty = False                       # True once a backward has accumulated into it since the last zero
+        self._loss_ws: Optional[Tuple[torch.Tensor, torch.Tensor, torch.Tensor]] = None
 
     def plan(self, B: int, T: int, mode: str = "full") -> Plan:
         key = (B, T, mode)
@@ -482,6 +539,87 @@ class TemporalEngine:
             p = Plan(self, B, T, mode)
             self._plans[key] = p
         return p
+
+    # ------------------------------------------------------------------ training
+    def ensure_grads(self) -> None:
+        if self.grads is None:
+            self.grads = torch.zeros(self.params.n_total, device=self.device, dtype=torch.float32)
+
+    def grad_view(self, name: str) -> torch.Tensor:
+        o, shp = self.params.offsets[name]
+        n = 1
+        for s in shp:
+            n *= s
+        return self.grads[o:o + n].view(shp)
+
+    def grad_vec(self, name: str, n: Optional[int] = None) -> torch.Tensor:
+        o, shp = self.params.offsets[name]
+        return self.grads[o:o + (shp[0] if n is None else n)]
+
+    def grad_mat(self, name: str, rows: Optional[int] = None) -> torch.Tensor:
+        o, shp = self.params.offsets[name]
+        r = shp[0] if rows is None else rows
+        return self.grads[o:o + r * shp[1]].view(r, shp[1])
+
+    def zero_grads(self) -> None:
+        if self.grads is not None:
+            self.grads.zero_()
+        self.grads_dirty = False
+
+    def train_plan(self, B: int, T: int):
+        from .train_engine import TrainPlan
+
+        key = (B, T)
+        p = self._train_plans.get(key)
+        if p is None:
+            if T > self.model.max_len:
+                raise ValueError(f"sequence length {T} exceeds max_len {self.model.max_len}")
+            p = TrainPlan(self, B, T)
+            self._train_plans[key] = p
+        return p
+
+    def forward_train(self, x: torch.Tensor, ib: torch.Tensor):
+        """Forward that keeps the activations the backward needs.  Returns (out, plan)."""
+        B, T, F, E = x.shape
+        x, ib = x.contiguous(), ib.contiguous()
+        out = torch.empty_like(x)
+        self.params.sync()
+        self.params.sync_transposed()
+        p = self.train_plan(B, T)
+        p.bind(x, ib, out)
+        p.held = (x, ib)  # the backward list reads the inputs again: keep them alive until the next forward
+        p.run()
+        return out, p
+
+    def backward(self, plan, dout: torch.Tensor) -> None:
+        """Accumulate d loss / d parameters into self.grads from dout = d loss / d out ([B,T,F,E] fp32, contiguous)."""
+        assert dout.is_contiguous() and dout.dtype == torch.float32
+        plan.bind_dout(dout.data_ptr())
+        plan.run_backward()
+        self.grads_dirty = True
+
+    def mse_loss_and_grad(self, out: torch.Tensor, target: torch.Tensor, grad_scale: float = 1.0):
+        """loss = mean((out - target)^2) and dout = grad_scale * d loss / d out in one kernel pass."""
+        if self._loss_ws is None or self._loss_ws[0].numel() != out.numel():
+            self._loss_ws = (torch.empty_like(out), torch.zeros(1, device=self.device), torch.empty(1024, device=self.device))
+        dout, loss, partial = self._loss_ws
+        target = target.contiguous()
+        N.check(N.lib().sea_mse_fwd_bwd(out.data_ptr(), target.data_ptr(), dout.data_ptr(), loss.data_ptr(), partial.data_ptr(), 1024,
+                                        out.numel(), grad_scale, N.stream_ptr()), "sea_mse_fwd_bwd")
+        return loss, dout
+
+    def train_step(self, x: torch.Tensor, target: torch.Tensor, ib: torch.Tensor, optimizer) -> torch.Tensor:
+        """One fused train step (train/train_temporal.py:254-258): zero grads, forward, MSE + its gradient, backward, ONE gradient
+        all-reduce when torch.distributed is initialised, AdamW.  Returns the local loss as a device scalar (no host sync)."""
+        from .parallel import allreduce_flat_gradients
+
+        optimizer.zero_grad(set_to_none=False)
+        out, plan = self.forward_train(x, ib)
+        loss, dout = self.mse_loss_and_grad(out, target)
+        self.backward(plan, dout)
+        optimizer.grad_scale = allreduce_flat_gradients(self.grads, self.params.n_live)
+        optimizer.step()
+        return loss
 
     def forward(self, x: torch.Tensor, ib: torch.Tensor) -> torch.Tensor:
         """TemporalModel.forward: x [B,T,F,E] fp32, ib [B,T,1] fp32 -> [B,T,F,E] fp32."""

@@ -249,6 +249,23 @@ class TemporalModel(nn.Module):
         self._engine = None
         return super()._apply(fn, *args, **kwargs)
 
+    def _grad_anchor(self) -> torch.Tensor:
+        """A leaf that requires grad, so that autograd calls the hand-written backward of the whole-model Function."""
+        a = getattr(self, "_anchor", None)
+        if a is None or a.device != next(self.parameters()).device:
+            a = torch.zeros(1, device=next(self.parameters()).device, requires_grad=True)
+            object.__setattr__(self, "_anchor", a)
+        return a
+
+    def _live_params(self):
+        eng = self._engine
+        cache = getattr(self, "_live_cache", None)
+        if cache is None or cache[0] is not eng:
+            named = dict(self.named_parameters())
+            cache = (eng, [named[n] for n in eng.params.live_names])
+            object.__setattr__(self, "_live_cache", cache)
+        return cache[1]
+
     def engine(self, device: Optional[torch.device] = None):
         from ..engine import TemporalEngine
 

@@ -1,0 +1,49 @@
+"""Data parallelism for the temporal train step: replicated model, the trajectory batch split across ranks, ONE all-reduce per step
+over the live prefix of the flat gradient buffer (RCCL through torch.distributed backend "nccl"; gloo on CPU for tests), the 1/world
+mean folded into the AdamW kernel's grad_scale.  The reference has no distributed code: this is new functionality."""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+import torch.distributed as dist
+
+
+def shard_batch(t: torch.Tensor, rank: int, world: int) -> torch.Tensor:
+    """Rank r takes trajectories [r*B/world, (r+1)*B/world) of a global batch (B divisible by world)."""
+    B = t.shape[0]
+    if B % world != 0:
+        raise ValueError(f"global batch {B} is not divisible by world size {world}")
+    per = B // world
+    return t[rank * per:(rank + 1) * per]
+
+
+def allreduce_flat_gradients(flat_grads: torch.Tensor, n_live: int, group: Optional[dist.ProcessGroup] = None) -> float:
+    """SUM-all-reduce the live prefix of the flat gradient buffer in ONE collective; returns the grad_scale (1/world) that turns the
+    sum into the mean inside the optimizer kernel."""
+    if not dist.is_available() or not dist.is_initialized():
+        return 1.0
+    world = dist.get_world_size(group)
+    if world == 1:
+        return 1.0
+    dist.all_reduce(flat_grads[:n_live], op=dist.ReduceOp.SUM, group=group)
+    return 1.0 / world
+
+
+def broadcast_parameters(flat_params: torch.Tensor, src: int = 0, group: Optional[dist.ProcessGroup] = None) -> None:
+    """Make every rank start from rank `src`'s parameters (one broadcast of the flat buffer)."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.broadcast(flat_params, src=src, group=group)
+
+
+def parameters_in_sync(flat_params: torch.Tensor, group: Optional[dist.ProcessGroup] = None) -> bool:
+    """Debug check: the parameter buffers of all ranks are bitwise identical (compares a 64-bit checksum of the raw bits)."""
+    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return True
+    bits = flat_params.view(torch.int32).to(torch.int64)
+    idx = torch.arange(1, bits.numel() + 1, device=bits.device, dtype=torch.int64)
+    chk = torch.stack(((bits * idx).sum(), bits.sum()))
+    lo, hi = chk.clone(), chk.clone()
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=group)
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=group)
+    return bool(torch.equal(lo, hi))

@@ -1,0 +1,432 @@
+"""Training plan: forward with saved activations + hand-written backward of TemporalModel as two fixed launch lists.
+
+The reference trains with `loss.backward()` through eager autograd (train/train_temporal.py:255-257).  Here the backward is a
+second pre-built launch list over the activations the forward list saved: data gradients run through the same grouped GEMM
+kernel against the W^T shadow, parameter gradients accumulate (fp32) into ONE flat buffer laid out like the parameters, so the
+data-parallel all-reduce and the AdamW kernel each touch a single contiguous range.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Optional, Tuple
+
+import torch
+
+from . import _native as N
+from .engine import Plan, _Rec, _fill_gemm
+
+
+class TrainPlan(Plan):
+    def __init__(self, eng, B: int, T: int):
+        self.bwd: List[_Rec] = []
+        self._dout_patches: List[Tuple[object, str, int]] = []
+        eng.params.enable_transposed_shadow()
+        eng.ensure_grads()
+        super().__init__(eng, B, T, "full")
+
+    # ------------------------------------------------------------------ record builders (backward)
+    def _wgrad(self, groups: List[dict], name: str) -> None:
+        L = N.lib()
+        for s in range(0, len(groups), N.MAX_WGRAD_GROUPS):
+            chunk = groups[s:s + N.MAX_WGRAD_GROUPS]
+            arr = (N.SeaWgradGroup * len(chunk))()
+            for g, d in zip(arr, chunk):
+                dY, X, dW = d["dY"], d["X"], d["dW"]
+                g.dY, g.X, g.dW, g.db = dY.data_ptr(), X.data_ptr(), dW.data_ptr(), N.ptr(d.get("db"))
+                g.lddy, g.ldx, g.lddw = dY.stride(0), X.stride(0), dW.stride(0)
+                g.M, g.N, g.K = self.M, dW.shape[0], dW.shape[1]
+                assert dY.shape[1] == g.N and X.shape[1] == g.K, (name, dY.shape, X.shape, dW.shape)
+            self._cur.append(_Rec(L.sea_wgrad_grouped, [arr, len(chunk), self.code], name, arr))
+
+    def _norm_bwd(self, groups: List[dict], d: int, name: str, dy_is_act: bool, x_is_act: bool, gelu: bool, accumulate: bool) -> None:
+        L = N.lib()
+        for s in range(0, len(groups), N.MAX_NORM_BWD_GROUPS):
+            chunk = groups[s:s + N.MAX_NORM_BWD_GROUPS]
+            arr = (N.SeaNormBwdGroup * len(chunk))()
+            for g, gd in zip(arr, chunk):
+                dY, X = gd["dY"], gd["X"]
+                g.dY, g.lddy = dY.data_ptr(), gd.get("lddy", dY.stride(0))
+                g.X, g.ldx = X.data_ptr(), gd.get("ldx", X.stride(0))
+                mod, dmod = gd.get("mod"), gd.get("dmod")
+                g.mod, g.ldmod = N.ptr(mod), (mod.stride(0) if mod is not None else 0)
+                g.dmod, g.lddmod = N.ptr(dmod), (dmod.stride(0) if dmod is not None else 0)
+                g.gamma, g.beta = gd["gamma"].data_ptr(), N.ptr(gd.get("beta"))
+                g.mean, g.rstd = gd["mean"].data_ptr(), gd["rstd"].data_ptr()
+                dx32, dxa = gd.get("dX32"), gd.get("dXact")
+                g.dX32, g.lddx32 = N.ptr(dx32), (dx32.stride(0) if dx32 is not None else 0)
+                g.dXact, g.lddxact = N.ptr(dxa), (dxa.stride(0) if dxa is not None else 0)
+                g.dgamma, g.dbeta = N.ptr(gd.get("dgamma")), N.ptr(gd.get("dbeta"))
+                if gd.get("X_is_x") is not None:
+                    self._x_patches.append((g, "X", gd["X_is_x"]))
+                if gd.get("dY_is_dout") is not None:
+                    self._dout_patches.append((g, "dY", gd["dY_is_dout"]))
+            self._cur.append(_Rec(L.sea_rownorm_bwd, [arr, len(chunk), self.M, d, int(dy_is_act), int(x_is_act), int(gelu), int(accumulate),
+                                                      self.code], name, arr))
+
+    def _attn_bwd(self, problems: List[dict], hd: int, rope: torch.Tensor, name: str) -> None:
+        L = N.lib()
+        P = N.SeaAttnBwdParams()
+        P.n_problems = len(problems)
+        for i, d in enumerate(problems):
+            q = P.p[i]
+            q.Q, q.K, q.V, q.O, q.dO = (d[k].data_ptr() for k in ("Q", "K", "V", "O", "dO"))
+            q.LSE, q.delta = d["LSE"].data_ptr(), d["delta"].data_ptr()
+            q.dQ, q.dK, q.dV = d["dQ"].data_ptr(), d["dK"].data_ptr(), d["dV"].data_ptr()
+        d0 = problems[0]
+        P.rope = rope.data_ptr()
+        P.B, P.H, P.hd, P.Tq, P.Tk, P.cap, P.q_pos0, P.src_len = self.B, self.H, hd, self.T, self.T, self.cap, 0, self.eng.model.src_len
+        P.ldo, P.lddo = d0["O"].stride(0), d0["dO"].stride(0)
+        P.lddq, P.lddk, P.lddv = d0["dQ"].stride(0), d0["dK"].stride(0), d0["dV"].stride(0)
+        P.q_scale = float(hd) ** -0.5
+        self._cur.append(_Rec(L.sea_attention_bwd, [C.byref(P), self.code], name, P))
+
+    def _silu_bwd(self, groups: List[dict], name: str) -> None:
+        L = N.lib()
+        for s in range(0, len(groups), N.MAX_SILU_BWD_GROUPS):
+            chunk = groups[s:s + N.MAX_SILU_BWD_GROUPS]
+            arr = (N.SeaSiluBwdGroup * len(chunk))()
+            for g, d in zip(arr, chunk):
+                dH = d["dHid"]
+                g.dHid, g.w1, g.b1, g.dw1, g.db1 = dH.data_ptr(), d["w1"].data_ptr(), d["b1"].data_ptr(), d["dw1"].data_ptr(), d["db1"].data_ptr()
+                g.K2, g.ld = dH.shape[1], dH.stride(0)
+            rec = _Rec(L.sea_silu_outer_bwd, [arr, len(chunk), None, self.M, self.code], name, arr)
+            self._c_patches.append((rec.args, 2))
+            self._cur.append(rec)
+
+    def _ib_bwd(self, pre: str, dxs: List[torch.Tensor]) -> None:
+        P, G = self.eng.params, self.eng.grad_view
+        ib = N.SeaIbBwdParams()
+        for i, x in enumerate(dxs):
+            ib.dX[i] = x.data_ptr()
+        ib.n_fields, ib.ldx = len(dxs), dxs[0].stride(0)
+        names = ("ib.layers.0.weight", "ib.layers.0.bias", "ib.layers.1.weight", "ib.layers.1.bias", "ib.layers.3.weight")
+        ib.w1, ib.b1, ib.lnw, ib.lnb, ib.w2 = (P.f32(pre + n).data_ptr() for n in names)
+        ib.dw1, ib.db1, ib.dlnw, ib.dlnb, ib.dw2 = (G(pre + n).data_ptr() for n in names)
+        ib.db2 = G(pre + "ib.layers.3.bias").data_ptr()
+        ib.M, ib.E, ib.h = self.M, self.E, self.eng.model.ib_hidden
+        self._c_patches.append((ib, "c"))
+        self._cur.append(_Rec(N.lib().sea_ib_bwd, [C.byref(ib)], "bwd.ib", ib))
+
+    def _convert(self, src32: torch.Tensor, dst: torch.Tensor, name: str) -> None:
+        self._cur.append(_Rec(N.lib().sea_convert_f32_to_act, [src32.data_ptr(), src32.stride(0), dst.data_ptr(), dst.stride(0), src32.shape[0],
+                                                               src32.shape[1], self.code], name))
+
+    # ------------------------------------------------------------------ the plan
+    def _build(self) -> None:
+        eng, P, G = self.eng, self.eng.params, self.eng.grad_view
+        F, E, D, S, M, B, T, H, NL = self.F, self.E, self.D, self.S, self.M, self.B, self.T, self.H, self.L
+        L = N.lib()
+        hd_s, hd_c = E // H, D // H
+        cap, FE, f32 = self.cap, F * E, torch.float32
+        model = eng.model
+        rope_s, rope_c = eng.rope_self, eng.rope_cross
+        buf = self._buf
+
+        def Gv(name, n=None):  # flat fp32 gradient of a vector parameter (optionally fused over n elements)
+            return eng.grad_vec(name, n)
+
+        def G2(name, rows=None):
+            return eng.grad_mat(name, rows)
+
+        # ================================================================ forward
+        hid: Dict[str, torch.Tensor] = {}
+        mods: Dict[str, torch.Tensor] = {}
+        if self.adaln:
+            prefixes = []
+            for l in range(NL):
+                pre = f"blocks.{l}."
+                for i in range(F):
+                    prefixes += [(f"{pre}ln.exp.{i}.0.", E), (f"{pre}ln.exp.{i}.2.", E)]
+                if F > 1:
+                    for i in range(F):
+                        prefixes.append((f"{pre}ln_cross.{i}.", D))
+            for i in range(F):
+                prefixes.append((f"ln.{i}.", E))
+            silu_groups, gemm_groups = [], []
+            for pre, d in prefixes:
+                hid[pre], mods[pre] = buf(M, 2 * d), buf(M, 2 * d)
+                silu_groups.append((P.f32_vec(pre + "cond_mlp.0.weight", 2 * d), P.f32_vec(pre + "cond_mlp.0.bias"), hid[pre]))
+                gemm_groups.append(dict(A=hid[pre], W=P.act(pre + "cond_mlp.2.weight"), bias=P.f32_vec(pre + "cond_mlp.2.bias"), Cact=mods[pre]))
+            for s in range(0, len(silu_groups), N.MAX_SILU_GROUPS):
+                chunk = silu_groups[s:s + N.MAX_SILU_GROUPS]
+                arr = (N.SeaSiluGroup * len(chunk))()
+                for g, (w1, b1, hb) in zip(arr, chunk):
+                    g.w1, g.b1, g.Hid, g.K2, g.ld = w1.data_ptr(), b1.data_ptr(), hb.data_ptr(), hb.shape[1], hb.stride(0)
+                rec = _Rec(L.sea_silu_outer, [arr, len(chunk), None, M, self.code], "adaln.silu", arr)
+                self._c_patches.append((rec.args, 2))
+                self._cur.append(rec)
+            self._gemm(gemm_groups, "adaln.cond_gemm")
+
+        def npar(pre):
+            if self.adaln:
+                return dict(mod=mods[pre], gamma=P.f32_vec(pre + "weight"), beta=P.f32_vec(pre + "bias"))
+            return dict(gamma=P.f32_vec(pre + "weight"))
+
+        def stats():
+            return buf(M, dtype=f32), buf(M, dtype=f32)
+
+        Sv: List[dict] = []  # saved tensors per layer
+        x_prev: Optional[List[torch.Tensor]] = None
+        others_of = [[j for j in range(F) if j != i] for i in range(F)]
+        for l in range(NL):
+            pre = f"blocks.{l}."
+            sv: dict = {}
+            Sv.append(sv)
+            first = l == 0
+            sv["xr"] = [buf(M, E, dtype=f32) for _ in range(F)]
+            sv["x5"] = [buf(M, E, dtype=f32) for _ in range(F)]
+            sv["x_in"] = x_prev
+            if not model.add_info_after_cross:
+                # the info-bottleneck add precedes everything and must not touch the caller's tensor: x_in := copy + ib
+                xin = [buf(M, E, dtype=f32) for _ in range(F)]
+                for i in range(F):
+                    if first:
+                        rec = _Rec(L.sea_convert_f32_to_act, [None, FE, xin[i].data_ptr(), E, M, E, N.SEA_F32], "x.copy")
+                        self._x_patches.append((rec.args, 0, i * E * 4))
+                    else:
+                        rec = _Rec(L.sea_convert_f32_to_act, [x_prev[i].data_ptr(), E, xin[i].data_ptr(), E, M, E, N.SEA_F32], "x.copy")
+                    self._cur.append(rec)
+                self._ib(pre, xin)
+                sv["x_in"] = xin
+                first = False
+            x_in = sv["x_in"]
+            # ---- self attention
+            sv["st0"] = [stats() for _ in range(F)]
+            sv["n0"] = [buf(M, E) for _ in range(F)]
+            groups = []
+            for i in range(F):
+                g = dict(Yact=sv["n0"][i], mean=sv["st0"][i][0], rstd=sv["st0"][i][1], **npar(f"{pre}ln.exp.{i}.0."))
+                g.update(dict(X=sv["xr"][i], ldx=FE, X_is_x=i * E * 4) if first else dict(X=x_in[i]))
+                groups.append(g)
+            self._norm(groups, E, "self.adaln0")
+            sv["Q"] = [buf(B, H, T, hd_s) for _ in range(F)]
+            sv["K"] = [buf(B, H, cap, hd_s, zero=True) for _ in range(F)]
+            sv["V"] = [buf(B, H, cap, hd_s, zero=True) for _ in range(F)]
+            sv["Vt"] = [buf(B, H, hd_s, cap, zero=True) for _ in range(F)]
+            sv["att"] = [buf(M, E) for _ in range(F)]
+            sv["LSE"] = [buf(B, H, T, dtype=f32) for _ in range(F)]
+            self._qkv([dict(A=sv["n0"][i], W=P.act(f"{pre}attn.self.{i}.q.weight", 3 * E), bias=P.f32_vec(f"{pre}attn.self.{i}.q.bias", 3 * E),
+                            col0=0, Q=sv["Q"][i], K=sv["K"][i], Vt=sv["Vt"][i], V=sv["V"][i]) for i in range(F)], rope_s, hd_s, "self.qkv_rope")
+            self._attn([dict(Q=sv["Q"][i], K=sv["K"][i], Vt=sv["Vt"][i], O=sv["att"][i], LSE=sv["LSE"][i]) for i in range(F)], hd_s, E, "self.attention")
+            sv["xa1"] = [buf(M, E) for _ in range(F)]
+            groups = []
+            for i in range(F):
+                g = dict(A=sv["att"][i], W=P.act(f"{pre}attn.self.{i}.projection.weight"), C32=sv["xr"][i], Cact=sv["xa1"][i])
+                g.update(dict(R=sv["xr"][i], ldr=FE, R_is_x=i * E * 4) if first else dict(R=x_in[i]))
+                groups.append(g)
+            self._gemm(groups, "self.out_proj")
+            # ---- state exchange
+            if F > 1:
+                sv["dn_old"] = [buf(M, D, dtype=f32) for _ in range(F)]
+                sv["nd_old"] = [buf(M, D) for _ in range(F)]
+                sv["stc_old"] = [stats() for _ in range(F)]
+                sv["dn_new"] = [buf(M, D, dtype=f32) for _ in range(F)]
+                sv["nd_new"] = [buf(M, D) for _ in range(F)]
+                sv["stc_new"] = [stats() for _ in range(F)]
+                sv["xa2"] = [buf(M, E) for _ in range(F)]
+                self._gemm([dict(A=sv["xa1"][j], W=P.act(f"{pre}cross_down.{j}.weight"), bias=P.f32_vec(f"{pre}cross_down.{j}.bias"), C32=sv["dn_old"][j])
+                            for j in range(F)], "cross.down_old")
+                self._norm([dict(X=sv["dn_old"][j], Yact=sv["nd_old"][j], mean=sv["stc_old"][j][0], rstd=sv["stc_old"][j][1], **npar(f"{pre}ln_cross.{j}."))
+                            for j in range(F)], D, "cross.norm_old")
+                sv["pair"] = {}
+                sv["g"] = [buf(F - 1, M, D) for _ in range(F)]
+                for i in range(F):
+                    qkv_groups, probs, proj_groups = [], [], []
+                    for s, j in enumerate(others_of[i]):
+                        src = sv["nd_new"][j] if j < i else sv["nd_old"][j]
+                        ca = f"{pre}cross_attn.{i}.{j}."
+                        pr = dict(Q=buf(B, H, T, hd_c), K=buf(B, H, cap, hd_c, zero=True), V=buf(B, H, cap, hd_c, zero=True),
+                                  Vt=buf(B, H, hd_c, cap, zero=True), O=buf(M, D), LSE=buf(B, H, T, dtype=f32), a=buf(M, D), src=src)
+                        sv["pair"][(i, j)] = pr
+                        qkv_groups.append(dict(A=sv["nd_old"][i], W=P.act(ca + "q.weight"), bias=P.f32_vec(ca + "q.bias"), col0=0, Q=pr["Q"]))
+                        qkv_groups.append(dict(A=src, W=P.act(ca + "k.weight", 2 * D), bias=P.f32_vec(ca + "k.bias", 2 * D), col0=D,
+                                               K=pr["K"], Vt=pr["Vt"], V=pr["V"]))
+                        probs.append(dict(Q=pr["Q"], K=pr["K"], Vt=pr["Vt"], O=pr["O"], LSE=pr["LSE"]))
+                        proj_groups.append(dict(A=pr["O"], W=P.act(ca + "projection.weight"), Cact=sv["g"][i][s], Z=pr["a"], act=1))
+                    self._qkv(qkv_groups, rope_c, hd_c, f"cross{i}.qkv_rope")
+                    self._attn(probs, hd_c, D, f"cross{i}.attention")
+                    self._gemm(proj_groups, f"cross{i}.proj_gelu")
+                    self._gemm([dict(A=sv["g"][i][0], W=P.act(f"{pre}cross_up.{i}.weight"), bias=P.f32_vec(f"{pre}cross_up.{i}.bias"),
+                                     bias_scale=float(F - 1), n_seg=F - 1, a_seg_stride=M * D, R=sv["xr"][i], C32=sv["xr"][i],
+                                     Cact=(sv["xa2"][i] if i < F - 1 else None))], f"cross{i}.up_sum")
+                    if i < F - 1:
+                        self._gemm([dict(A=sv["xa2"][i], W=P.act(f"{pre}cross_down.{i}.weight"), bias=P.f32_vec(f"{pre}cross_down.{i}.bias"),
+                                         C32=sv["dn_new"][i])], f"cross{i}.down_new")
+                        self._norm([dict(X=sv["dn_new"][i], Yact=sv["nd_new"][i], mean=sv["stc_new"][i][0], rstd=sv["stc_new"][i][1],
+                                         **npar(f"{pre}ln_cross.{i}."))], D, f"cross{i}.norm_new")
+            if model.add_info_after_cross:
+                self._ib(pre, sv["xr"])
+            # ---- MLP + proj
+            sv["st2"] = [stats() for _ in range(F)]
+            sv["n2"] = [buf(M, E) for _ in range(F)]
+            sv["h"] = [buf(M, S) for _ in range(F)]
+            sv["sth"] = [stats() for _ in range(F)]
+            sv["hg"] = [buf(M, S) for _ in range(F)]
+            sv["xa4"] = [buf(M, E) for _ in range(F)]
+            self._norm([dict(X=sv["xr"][i], Yact=sv["n2"][i], mean=sv["st2"][i][0], rstd=sv["st2"][i][1], **npar(f"{pre}ln.exp.{i}.2.")) for i in range(F)],
+                       E, "mlp.adaln2")
+            self._gemm([dict(A=sv["n2"][i], W=P.act(f"{pre}mlp.{i}.layers.0.weight"), bias=P.f32_vec(f"{pre}mlp.{i}.layers.0.bias"), Cact=sv["h"][i])
+                        for i in range(F)], "mlp.fc1")
+            self._norm([dict(X=sv["h"][i], gamma=P.f32_vec(f"{pre}mlp.{i}.layers.1.weight"), beta=P.f32_vec(f"{pre}mlp.{i}.layers.1.bias"),
+                             Yact=sv["hg"][i], mean=sv["sth"][i][0], rstd=sv["sth"][i][1]) for i in range(F)], S, "mlp.ln_gelu", x_is_act=True, gelu=True)
+            self._gemm([dict(A=sv["hg"][i], W=P.act(f"{pre}mlp.{i}.layers.3.weight"), bias=P.f32_vec(f"{pre}mlp.{i}.layers.3.bias"), R=sv["xr"][i],
+                             Cact=sv["xa4"][i]) for i in range(F)], "mlp.fc2")
+            self._gemm([dict(A=sv["xa4"][i], W=P.act(f"{pre}proj.{i}.weight"), bias=P.f32_vec(f"{pre}proj.{i}.bias"), C32=sv["x5"][i])
+                        for i in range(F)], "proj")
+            x_prev = sv["x5"]
+        stf = [stats() for _ in range(F)]
+        self._norm([dict(X=x_prev[i], Y32=x_prev[i], ldy32=FE, Y_is_out=i * E * 4, mean=stf[i][0], rstd=stf[i][1], **npar(f"ln.{i}."))
+                    for i in range(F)], E, "final.norm")
+
+        # ================================================================ backward
+        self._cur = self.bwd
+        adaln = self.adaln
+        dmods: List[Tuple[str, torch.Tensor]] = []  # (prefix, dmod buffer) per USE of an AdaLN
+
+        def bpar(pre, d):
+            """norm-backward parameter/gradient pointers (+ a fresh dmod buffer for this use)"""
+            out = dict(gamma=P.f32_vec(pre + "weight"), dgamma=Gv(pre + "weight"))
+            if adaln:
+                dm = buf(M, 2 * d)
+                dmods.append((pre, dm))
+                out.update(mod=mods[pre], beta=P.f32_vec(pre + "bias"), dbeta=Gv(pre + "bias"), dmod=dm)
+            return out
+
+        dx = [buf(M, E, dtype=f32) for _ in range(F)]      # gradient of the fp32 residual stream
+        ga = [buf(M, E) for _ in range(F)]                 # act copy of the residual gradient entering a GEMM
+        gb = [buf(M, E) for _ in range(F)]
+        dS_ = [buf(M, S) for _ in range(F)]
+        dE_ = [buf(M, E) for _ in range(F)]
+        dqkv = [buf(M, 3 * E) for _ in range(F)]
+        delta_s = [buf(B, H, T, dtype=f32) for _ in range(F)]
+        # final norm
+        self._norm_bwd([dict(dY=dx[i], lddy=FE, dY_is_dout=i * E * 4, X=x_prev[i], mean=stf[i][0], rstd=stf[i][1], dX32=dx[i], dXact=ga[i],
+                             **bpar(f"ln.{i}.", E)) for i in range(F)], E, "bwd.final_norm", False, False, False, False)
+        for l in reversed(range(NL)):
+            pre = f"blocks.{l}."
+            sv = Sv[l]
+            first = l == 0 and model.add_info_after_cross
+            # ---- proj:  x5 = Wp xa4 + bp                       (ga = d x5 in act dtype)
+            self._wgrad([dict(dY=ga[i], X=sv["xa4"][i], dW=G2(f"{pre}proj.{i}.weight"), db=Gv(f"{pre}proj.{i}.bias")) for i in range(F)], "bwd.proj.wgrad")
+            self._gemm([dict(A=ga[i], W=P.actT(f"{pre}proj.{i}.weight"), C32=dx[i], Cact=gb[i]) for i in range(F)], "bwd.proj.dgrad")
+            # ---- fc2:   x4 = x3 + hg W2^T + b2                 (gb = d x4)
+            self._wgrad([dict(dY=gb[i], X=sv["hg"][i], dW=G2(f"{pre}mlp.{i}.layers.3.weight"), db=Gv(f"{pre}mlp.{i}.layers.3.bias")) for i in range(F)],
+                        "bwd.fc2.wgrad")
+            self._gemm([dict(A=gb[i], W=P.actT(f"{pre}mlp.{i}.layers.3.weight"), Cact=dS_[i]) for i in range(F)], "bwd.fc2.dgrad")
+            # ---- LayerNorm + GELU of the MLP (in place: d hg -> d h)
+            self._norm_bwd([dict(dY=dS_[i], X=sv["h"][i], gamma=P.f32_vec(f"{pre}mlp.{i}.layers.1.weight"), beta=P.f32_vec(f"{pre}mlp.{i}.layers.1.bias"),
+                                 mean=sv["sth"][i][0], rstd=sv["sth"][i][1], dXact=dS_[i], dgamma=Gv(f"{pre}mlp.{i}.layers.1.weight"),
+                                 dbeta=Gv(f"{pre}mlp.{i}.layers.1.bias")) for i in range(F)], S, "bwd.mlp.ln_gelu", True, True, True, False)
+            # ---- fc1
+            self._wgrad([dict(dY=dS_[i], X=sv["n2"][i], dW=G2(f"{pre}mlp.{i}.layers.0.weight"), db=Gv(f"{pre}mlp.{i}.layers.0.bias")) for i in range(F)],
+                        "bwd.fc1.wgrad")
+            self._gemm([dict(A=dS_[i], W=P.actT(f"{pre}mlp.{i}.layers.0.weight"), Cact=dE_[i]) for i in range(F)], "bwd.fc1.dgrad")
+            # ---- AdaLN_2: accumulates the norm branch onto the residual gradient
+            self._norm_bwd([dict(dY=dE_[i], X=sv["xr"][i], mean=sv["st2"][i][0], rstd=sv["st2"][i][1], dX32=dx[i], dXact=ga[i],
+                                 **bpar(f"{pre}ln.exp.{i}.2.", E)) for i in range(F)], E, "bwd.mlp.adaln2", True, False, False, True)
+            if model.add_info_after_cross:
+                self._ib_bwd(pre, dx)
+            # ---- state exchange (reverse Gauss-Seidel order); ga[i] = act copy of d x2_i when field i is reached
+            if F > 1:
+                dnd_old = [buf(M, D, dtype=f32) for _ in range(F)]
+                dnd_new = [buf(M, D, dtype=f32) for _ in range(F)]
+                init_old, init_new = [False] * F, [False] * F
+                ddn = buf(M, D)
+                da = [buf(M, D) for _ in range(F - 1)]
+                datt = [buf(M, D) for _ in range(F - 1)]
+                dqc = [buf(M, D) for _ in range(F - 1)]
+                dkvc = [buf(M, 2 * D) for _ in range(F - 1)]
+                delta_c = [buf(B, H, T, dtype=f32) for _ in range(F - 1)]
+                for i in reversed(range(F)):
+                    if i < F - 1:
+                        # a. nd_new[i] was the k/v source of the later fields: back through ln_cross and cross_down onto d x2_i
+                        assert init_new[i]
+                        cp = f"{pre}ln_cross.{i}."
+                        self._norm_bwd([dict(dY=dnd_new[i], X=sv["dn_new"][i], mean=sv["stc_new"][i][0], rstd=sv["stc_new"][i][1], dXact=ddn, **bpar(cp, D))],
+                                       D, f"bwd.cross{i}.norm_new", False, False, False, False)
+                        self._wgrad([dict(dY=ddn, X=sv["xa2"][i], dW=G2(f"{pre}cross_down.{i}.weight"), db=Gv(f"{pre}cross_down.{i}.bias"))], f"bwd.cross{i}.down_new.wgrad")
+                        self._gemm([dict(A=ddn, W=P.actT(f"{pre}cross_down.{i}.weight"), R=dx[i], C32=dx[i], Cact=ga[i])], f"bwd.cross{i}.down_new.dgrad")
+                    # b. cross_up (shared by the F-1 partners) with the GELU derivative fused: da_s = (d x2_i Wu) * gelu'(a_ij)
+                    others = others_of[i]
+                    self._wgrad([dict(dY=ga[i], X=sv["g"][i][s], dW=G2(f"{pre}cross_up.{i}.weight"), db=Gv(f"{pre}cross_up.{i}.bias"))
+                                 for s in range(F - 1)], f"bwd.cross{i}.up.wgrad")
+                    self._gemm([dict(A=ga[i], W=P.actT(f"{pre}cross_up.{i}.weight"), Z=sv["pair"][(i, j)]["a"], act=2, Cact=da[s])
+                                for s, j in enumerate(others)], f"bwd.cross{i}.up.dgrad")
+                    # c. projection of each pair
+                    self._wgrad([dict(dY=da[s], X=sv["pair"][(i, j)]["O"], dW=G2(f"{pre}cross_attn.{i}.{j}.projection.weight")) for s, j in enumerate(others)],
+                                f"bwd.cross{i}.proj.wgrad")
+                    self._gemm([dict(A=da[s], W=P.actT(f"{pre}cross_attn.{i}.{j}.projection.weight"), Cact=datt[s]) for s, j in enumerate(others)],
+                               f"bwd.cross{i}.proj.dgrad")
+                    # d. attention
+                    self._attn_bwd([dict(Q=sv["pair"][(i, j)]["Q"], K=sv["pair"][(i, j)]["K"], V=sv["pair"][(i, j)]["V"], O=sv["pair"][(i, j)]["O"],
+                                         dO=datt[s], LSE=sv["pair"][(i, j)]["LSE"], delta=delta_c[s], dQ=dqc[s], dK=dkvc[s][:, :D], dV=dkvc[s][:, D:])
+                                    for s, j in enumerate(others)], hd_c, rope_c, f"bwd.cross{i}.attention")
+                    # e. q / k,v projections
+                    wg = []
+                    for s, j in enumerate(others):
+                        ca = f"{pre}cross_attn.{i}.{j}."
+                        wg.append(dict(dY=dqc[s], X=sv["nd_old"][i], dW=G2(ca + "q.weight"), db=Gv(ca + "q.bias")))
+                        wg.append(dict(dY=dkvc[s], X=sv["pair"][(i, j)]["src"], dW=G2(ca + "k.weight", 2 * D), db=Gv(ca + "k.bias", 2 * D)))
+                    self._wgrad(wg, f"bwd.cross{i}.qkv.wgrad")
+                    for s, j in enumerate(others):
+                        ca = f"{pre}cross_attn.{i}.{j}."
+                        groups = []
+                        gq = dict(A=dqc[s], W=P.actT(ca + "q.weight"), C32=dnd_old[i])
+                        if init_old[i]:
+                            gq["R"] = dnd_old[i]
+                        init_old[i] = True
+                        groups.append(gq)
+                        tgt, flags = (dnd_new, init_new) if j < i else (dnd_old, init_old)
+                        gk = dict(A=dkvc[s], W=P.actT(ca + "k.weight", 2 * D), C32=tgt[j])
+                        if flags[j]:
+                            gk["R"] = tgt[j]
+                        flags[j] = True
+                        groups.append(gk)
+                        self._gemm(groups, f"bwd.cross{i}.qkv.dgrad{s}")  # sequential over s: both s accumulate into dnd_old[i]
+                # f. the pre-exchange ln_cross / cross_down of every field
+                for j in range(F):
+                    assert init_old[j]
+                ddo = [buf(M, D) for _ in range(F)]
+                self._norm_bwd([dict(dY=dnd_old[j], X=sv["dn_old"][j], mean=sv["stc_old"][j][0], rstd=sv["stc_old"][j][1], dXact=ddo[j],
+                                     **bpar(f"{pre}ln_cross.{j}.", D)) for j in range(F)], D, "bwd.cross.norm_old", False, False, False, False)
+                self._wgrad([dict(dY=ddo[j], X=sv["xa1"][j], dW=G2(f"{pre}cross_down.{j}.weight"), db=Gv(f"{pre}cross_down.{j}.bias")) for j in range(F)],
+                            "bwd.cross.down_old.wgrad")
+                self._gemm([dict(A=ddo[j], W=P.actT(f"{pre}cross_down.{j}.weight"), R=dx[j], C32=dx[j], Cact=ga[j]) for j in range(F)], "bwd.cross.down_old.dgrad")
+            # ---- self attention: x1 = x0 + att Wo^T            (ga = d x1)
+            self._wgrad([dict(dY=ga[i], X=sv["att"][i], dW=G2(f"{pre}attn.self.{i}.projection.weight")) for i in range(F)], "bwd.self.out_proj.wgrad")
+            self._gemm([dict(A=ga[i], W=P.actT(f"{pre}attn.self.{i}.projection.weight"), Cact=dE_[i]) for i in range(F)], "bwd.self.out_proj.dgrad")
+            self._attn_bwd([dict(Q=sv["Q"][i], K=sv["K"][i], V=sv["V"][i], O=sv["att"][i], dO=dE_[i], LSE=sv["LSE"][i], delta=delta_s[i],
+                                 dQ=dqkv[i][:, :E], dK=dqkv[i][:, E:2 * E], dV=dqkv[i][:, 2 * E:]) for i in range(F)], hd_s, rope_s, "bwd.self.attention")
+            self._wgrad([dict(dY=dqkv[i], X=sv["n0"][i], dW=G2(f"{pre}attn.self.{i}.q.weight", 3 * E), db=Gv(f"{pre}attn.self.{i}.q.bias", 3 * E))
+                         for i in range(F)], "bwd.self.qkv.wgrad")
+            self._gemm([dict(A=dqkv[i], W=P.actT(f"{pre}attn.self.{i}.q.weight", 3 * E), Cact=dE_[i]) for i in range(F)], "bwd.self.qkv.dgrad")
+            groups = []
+            for i in range(F):
+                g = dict(dY=dE_[i], mean=sv["st0"][i][0], rstd=sv["st0"][i][1], dX32=dx[i], dXact=ga[i], **bpar(f"{pre}ln.exp.{i}.0.", E))
+                g.update(dict(X=dx[i], ldx=FE, X_is_x=i * E * 4) if first else dict(X=sv["x_in"][i]))
+                groups.append(g)
+            self._norm_bwd(groups, E, "bwd.self.adaln0", True, False, False, True)
+            if not model.add_info_after_cross:
+                self._ib_bwd(pre, dx)
+        # ---- AdaLN condition MLPs: every USE contributes dmod; parameters are shared through the atomically accumulated gradients
+        if adaln:
+            dh = [buf(M, dm.shape[1]) for _, dm in dmods]
+            self._wgrad([dict(dY=dm, X=hid[pre], dW=G2(pre + "cond_mlp.2.weight"), db=Gv(pre + "cond_mlp.2.bias")) for pre, dm in dmods], "bwd.adaln.cond.wgrad")
+            self._gemm([dict(A=dm, W=P.actT(pre + "cond_mlp.2.weight"), Cact=dh[k]) for k, (pre, dm) in enumerate(dmods)], "bwd.adaln.cond.dgrad")
+            self._silu_bwd([dict(dHid=dh[k], w1=P.f32_vec(pre + "cond_mlp.0.weight", dm.shape[1]), b1=P.f32_vec(pre + "cond_mlp.0.bias"),
+                                 dw1=Gv(pre + "cond_mlp.0.weight", dm.shape[1]), db1=Gv(pre + "cond_mlp.0.bias")) for k, (pre, dm) in enumerate(dmods)],
+                           "bwd.adaln.silu")
+        self._cur = self.records
+        self.saved = Sv
+
+    # ------------------------------------------------------------------ replay
+    def bind_dout(self, dout_ptr: int) -> None:
+        for tgt, field, off in self._dout_patches:
+            setattr(tgt, field, dout_ptr + off)
+
+    def run_backward(self) -> None:
+        stream = N.stream_ptr()
+        for r in self.bwd:
+            rc = r.fn(*r.args, stream)
+            if rc != 0:
+                N.check(rc, r.name)
