@@ -145,7 +145,12 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-graph", action="store_true", help="replay launch by launch instead of the captured HIP graph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--mode", default="rollout", choices=["rollout", "train", "kv"],
+                    help="rollout: full-context forward step (cfg2, the default metric); train: fwd+bwd+AdamW step (cfg3/cfg4, --batch 8); "
+                         "kv: KV-cache rollout of --seq steps")
     args = ap.parse_args()
+    if args.mode != "rollout":
+        return main_other(args)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -237,6 +242,94 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline((L, E, H, max_len, sr, src, F), B, T)
+        print(json.dumps(line))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def main_other(args):
+    """--mode train: BASELINE.json configs[2]/[3] (fwd+bwd+fused AdamW, B trajectories per GPU, one RCCL all-reduce of the flat
+    gradient per step when N > 1).  --mode kv: exact KV-cache rollout (configs[4]-style long rollout).  Same JSON contract."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist_mod.init_process_group("nccl", device_id=dev)
+        dist = dist_mod
+    from sea_amd.models.temporal import TemporalModel
+    from sea_amd.utils.train_utils import initialize_optimizer, rollout
+
+    L, E, H, max_len, sr, src, F = 1, 256, 8, 2024, 8, 0, 3
+    B, T = args.batch, args.seq
+    D, S = E // 2, E * sr
+    torch.manual_seed(42)
+    model = TemporalModel(L, E, H, max_len, sr, src, F, 2, 0.0, "sea", "learnable", "mlp", "add", 1, 1, True, "adaln")
+    model.set_compute_dtype(args.dtype)
+    model = model.to(dev)
+    x = torch.randn(B, T, F, E, generator=torch.Generator().manual_seed(1234 + rank)).to(dev)
+    tgt = torch.randn(B, T, F, E, generator=torch.Generator().manual_seed(4321 + rank)).to(dev)
+    ib = torch.rand(B, T, 1, generator=torch.Generator().manual_seed(1235 + rank)).to(dev)
+    eng = model.engine(dev)
+    if args.mode == "train":
+        model.train()
+        opt = initialize_optimizer(model, {"learning_rate": 1e-4})
+        if dist is not None:
+            from sea_amd.parallel import broadcast_parameters
+
+            broadcast_parameters(eng.params.flat32)
+            eng.params.sync(force=True)
+
+        def step():
+            return eng.train_step(x, tgt, ib, opt)
+    else:
+        model.eval()
+
+        def step():
+            return rollout(model, x[:, :1].contiguous(), ib, T, mode="kv")
+    for _ in range(max(args.warmup, 1)):
+        r = step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        r = step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    assert torch.isfinite(r).all()
+    if rank == 0:
+        ms = elapsed / args.steps * 1e3
+        if args.mode == "train":
+            gflop = 3 * algorithmic_gflop(B, T, F, E, H, D, S, L)
+            line = {"metric": "train steps/sec (fwd+bwd+AdamW) on cylinder_flow-shaped fields", "value": world * args.steps / elapsed * 1.0,
+                    "unit": "rank-steps/s (each step = B trajectories x T positions, teacher-forced)", "trajectory_steps_per_s": world * B * args.steps / elapsed,
+                    "config": {"workload": f"cfg3: cylinder_flow temporal model E=256 H=8 F=3 L=1 adaln, fwd+bwd+AdamW, B={B} per GPU, T={T}",
+                               "global_batch": world * B, "seq_len": T, "parallelism": f"dp{world}: flat-gradient all-reduce (RCCL), 1 per step"},
+                    "model_algorithmic_gflop_per_step": gflop, "model_mfma_frac": gflop / (ms * 1e-3) / 1e3 / PEAK_BF16_TFLOPS}
+        else:
+            line = {"metric": "KV-cache rollout steps/sec on cylinder_flow-shaped fields", "value": world * B * T * args.steps / elapsed,
+                    "unit": "trajectory-steps/s",
+                    "config": {"workload": f"KV-cache rollout of {T} steps, B={B} per GPU, E=256 H=8 F=3 L=1 adaln", "parallelism": f"replicas x{world}"}}
+            ms = ms / T
+        line.update({"n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",
+                     "vs_baseline": None, "dtype": args.dtype, "data": "synthetic"})
         print(json.dumps(line))
     if dist is not None:
         dist.barrier()

@@ -245,7 +245,7 @@ def test_attention_backward(dtype, hd, T, src_len):
     t = 2e-5 if dtype == torch.float32 else 2e-2
     assert torch.isfinite(dQ.float()).all() and torch.isfinite(dKV.float()).all()
     def close(a, b):  # relative to the reference, with a floor for the T=1 case where dQ = dK = 0 exactly
-        return float((a.double() - b.double()).norm()) <= t * max(float(b.double().norm()), 1e-3 * float(dO.float().norm()))
+        return float((a.double() - b.double()).norm()) <= t * max(float(b.double().norm()), 0.1 * float(dO.float().norm()))
 
     assert close(dQ.float().view(B, T, H, hd), q0.grad)
     assert close(dKV[:, :E].float().reshape(B, T, H, hd), k0.grad)
