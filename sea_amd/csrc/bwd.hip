@@ -250,9 +250,17 @@ struct NormBwdLaunch {
 // y = xhat*s + t, s = gamma (+1 + mod_w), t = beta (+ mod_b);  optional y = gelu(y).
 // dxhat = dy*s;  dx = rstd*(dxhat - mean(dxhat) - xhat*mean(dxhat*xhat));  dgamma += dy*xhat;  dbeta += dy;
 // dmod = [dy*xhat | dy].  Column sums are accumulated in LDS (ds_add_f32) and flushed with one global atomic per column.
-template <typename T, bool DY_ACT, bool X_ACT>
+// KMAX > 0: d <= 256*KMAX and the column sums are accumulated in registers (lane owns columns lane*4 + 256k) and merged once at
+// the end; KMAX == 0: any d <= 16384, per-element LDS atomics (slow: 2 ds_add per element).
+template <typename T, bool DY_ACT, bool X_ACT, int KMAX>
 __global__ __launch_bounds__(256) void rownorm_bwd_kernel(const NormBwdLaunch L) {
     extern __shared__ __attribute__((aligned(16))) float cs[];  // [2][d]
+    constexpr int KA = KMAX > 0 ? KMAX : 1;
+    float accg[KA][4], accb[KA][4];
+#pragma unroll
+    for (int k = 0; k < KA; ++k)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) accg[k][e] = accb[k][e] = 0.f;
     const SeaNormBwdGroup& G = L.g[blockIdx.y];
     const int d = L.d, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int i = threadIdx.x; i < 2 * d; i += 256) cs[i] = 0.f;
@@ -267,7 +275,7 @@ __global__ __launch_bounds__(256) void rownorm_bwd_kernel(const NormBwdLaunch L)
         T* dmod = G.dmod ? static_cast<T*>(G.dmod) + (int64_t)row * G.lddmod : nullptr;
         const float mean = G.mean[row], rstd = G.rstd[row];
         float c1 = 0.f, c2 = 0.f;
-        for (int i = lane * 4; i < d; i += 256) {
+        auto pass_a = [&](int i, int k) {
             float xv[4], dv[4], s[4], tt[4] = {0.f, 0.f, 0.f, 0.f};
             load4(x + i, xv);
             load4(dy + i, dv);
@@ -296,13 +304,25 @@ __global__ __launch_bounds__(256) void rownorm_bwd_kernel(const NormBwdLaunch L)
                 c1 += dxh;
                 c2 += dxh * xh;
                 dyx[e] = dv[e] * xh;
-                atomicAdd(&cs[i + e], dyx[e]);
-                atomicAdd(&cs[d + i + e], dv[e]);
+                if constexpr (KMAX > 0) {
+                    accg[k][e] += dyx[e];
+                    accb[k][e] += dv[e];
+                } else {
+                    atomicAdd(&cs[i + e], dyx[e]);
+                    atomicAdd(&cs[d + i + e], dv[e]);
+                }
             }
             if (dmod) {
                 store4(dmod + i, dyx[0], dyx[1], dyx[2], dyx[3]);
                 store4(dmod + d + i, dv[0], dv[1], dv[2], dv[3]);
             }
+        };
+        if constexpr (KMAX > 0) {
+#pragma unroll
+            for (int k = 0; k < KMAX; ++k)
+                if (lane * 4 + 256 * k < d) pass_a(lane * 4 + 256 * k, k);
+        } else {
+            for (int i = lane * 4; i < d; i += 256) pass_a(i, 0);
         }
         c1 = wave_sum(c1) * inv_d;
         c2 = wave_sum(c2) * inv_d;
@@ -347,6 +367,19 @@ __global__ __launch_bounds__(256) void rownorm_bwd_kernel(const NormBwdLaunch L)
             if (dxa) store4(dxa + i, o[0], o[1], o[2], o[3]);
         }
     }
+    if constexpr (KMAX > 0) {
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) {
+            const int i = lane * 4 + 256 * k;
+            if (i < d) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    atomicAdd(&cs[i + e], accg[k][e]);
+                    atomicAdd(&cs[d + i + e], accb[k][e]);
+                }
+            }
+        }
+    }
     __syncthreads();
     for (int i = threadIdx.x; i < d; i += 256) {
         if (G.dgamma) atomicAdd(G.dgamma + i, cs[i]);
@@ -378,11 +411,19 @@ extern "C" int sea_rownorm_bwd(const SeaNormBwdGroup* groups, int n_groups, int 
     const dim3 grid(nblk, n_groups), block(256);
     const size_t lds = (size_t)2 * d * sizeof(float);
     hipStream_t s = static_cast<hipStream_t>(stream);
-#define LAUNCH_NB(TT, DYA, XA)                                                                                             \
+#define LAUNCH_NBK(TT, DYA, XA, KM)                                                                                        \
     do {                                                                                                                   \
-        if (lds > 65536) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rownorm_bwd_kernel<TT, DYA, XA>),          \
+        if (lds > 65536) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rownorm_bwd_kernel<TT, DYA, XA, KM>),      \
                                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                  \
-        rownorm_bwd_kernel<TT, DYA, XA><<<grid, block, lds, s>>>(L);                                                       \
+        rownorm_bwd_kernel<TT, DYA, XA, KM><<<grid, block, lds, s>>>(L);                                                   \
+    } while (0)
+#define LAUNCH_NB(TT, DYA, XA)                         \
+    do {                                               \
+        if (d <= 256) LAUNCH_NBK(TT, DYA, XA, 1);      \
+        else if (d <= 512) LAUNCH_NBK(TT, DYA, XA, 2); \
+        else if (d <= 1024) LAUNCH_NBK(TT, DYA, XA, 4);\
+        else if (d <= 2048) LAUNCH_NBK(TT, DYA, XA, 8);\
+        else LAUNCH_NBK(TT, DYA, XA, 0);               \
     } while (0)
     if (dtype == SEA_BF16) {
         if (dy_is_act && x_is_act) LAUNCH_NB(__bf16, true, true);
@@ -393,6 +434,7 @@ extern "C" int sea_rownorm_bwd(const SeaNormBwdGroup* groups, int n_groups, int 
         LAUNCH_NB(float, false, false);
     }
 #undef LAUNCH_NB
+#undef LAUNCH_NBK
     SEA_CHECK_LAUNCH("sea_rownorm_bwd");
     return SEA_OK;
 }
@@ -405,6 +447,7 @@ struct SiluBwdLaunch {
     int M;
 };
 
+// Column sums in registers: lane owns columns lane*4 + 256k (k < 8, K2 <= 2048), w1/b1 of those columns are loaded once.
 template <typename T>
 __global__ __launch_bounds__(256) void silu_outer_bwd_kernel(const SiluBwdLaunch L) {
     extern __shared__ __attribute__((aligned(16))) float cs[];  // [2][K2]
@@ -412,21 +455,46 @@ __global__ __launch_bounds__(256) void silu_outer_bwd_kernel(const SiluBwdLaunch
     const int K2 = G.K2, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int i = threadIdx.x; i < 2 * K2; i += 256) cs[i] = 0.f;
     __syncthreads();
+    constexpr int KM = 8;
+    float aw[KM][4], ab[KM][4], w[KM][4], bb[KM][4];
+#pragma unroll
+    for (int k = 0; k < KM; ++k) {
+        const int i = lane * 4 + 256 * k;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) aw[k][e] = ab[k][e] = w[k][e] = bb[k][e] = 0.f;
+        if (i < K2) {
+            load4(G.w1 + i, w[k]);
+            load4(G.b1 + i, bb[k]);
+        }
+    }
     for (int row = blockIdx.x * 4 + wave; row < L.M; row += 4 * gridDim.x) {
         const float cv = L.c[row];
         const T* dh = static_cast<const T*>(G.dHid) + (int64_t)row * G.ld;
-        for (int i = lane * 4; i < K2; i += 256) {
-            float w[4], bb[4], dv[4];
-            load4(G.w1 + i, w);
-            load4(G.b1 + i, bb);
-            load4(dh + i, dv);
+#pragma unroll
+        for (int k = 0; k < KM; ++k) {
+            const int i = lane * 4 + 256 * k;
+            if (i < K2) {
+                float dv[4];
+                load4(dh + i, dv);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float pre = w[k][e] * cv + bb[k][e];
+                    const float sg = 1.0f / (1.0f + __expf(-pre));
+                    const float dpre = dv[e] * sg * (1.0f + pre * (1.0f - sg));
+                    aw[k][e] += dpre * cv;
+                    ab[k][e] += dpre;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < KM; ++k) {
+        const int i = lane * 4 + 256 * k;
+        if (i < K2) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const float pre = w[e] * cv + bb[e];
-                const float sg = 1.0f / (1.0f + __expf(-pre));
-                const float dpre = dv[e] * sg * (1.0f + pre * (1.0f - sg));
-                atomicAdd(&cs[i + e], dpre * cv);
-                atomicAdd(&cs[K2 + i + e], dpre);
+                atomicAdd(&cs[i + e], aw[k][e]);
+                atomicAdd(&cs[K2 + i + e], ab[k][e]);
             }
         }
     }
@@ -445,7 +513,7 @@ extern "C" int sea_silu_outer_bwd(const SeaSiluBwdGroup* groups, int n_groups, c
     int maxk = 0;
     for (int i = 0; i < n_groups; ++i) {
         const SeaSiluBwdGroup& G = groups[i];
-        SEA_REQUIRE(G.dHid && G.w1 && G.b1 && G.dw1 && G.db1 && G.K2 >= 4 && G.K2 % 4 == 0 && G.K2 <= 16384 && G.ld >= G.K2 && G.ld % 4 == 0, "sea_silu_outer_bwd[%d]: bad group", i);
+        SEA_REQUIRE(G.dHid && G.w1 && G.b1 && G.dw1 && G.db1 && G.K2 >= 4 && G.K2 % 4 == 0 && G.K2 <= 2048 && G.ld >= G.K2 && G.ld % 4 == 0, "sea_silu_outer_bwd[%d]: bad group", i);
         SEA_REQUIRE(sea_aligned16(G.dHid) && sea_aligned16(G.w1) && sea_aligned16(G.b1), "sea_silu_outer_bwd[%d]: pointers must be 16-byte aligned", i);
         L.g[i] = G;
         maxk = G.K2 > maxk ? G.K2 : maxk;
@@ -545,6 +613,108 @@ __global__ __launch_bounds__(256) void ib_bwd_kernel(const SeaIbBwdParams P) {
     for (int i = threadIdx.x; i < E * h; i += 256) atomicAdd(P.dw2 + i, s_w2[i]);
 }
 
+// Fast path (h <= 8, E <= 256*KE): dib, db2 and dW2 partial sums live in registers (lane owns columns lane*4 + 256k); one pass over
+// dX per row; the partial sums are merged through LDS once per workgroup.
+template <int KE>
+__global__ __launch_bounds__(256) void ib_bwd_fast_kernel(const SeaIbBwdParams P) {
+    extern __shared__ __attribute__((aligned(16))) float cs[];  // [E] db2, [E*h] dW2
+    constexpr int HM = 8;
+    const int E = P.E, h = P.h, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float* s_b2 = cs;
+    float* s_w2 = cs + E;
+    for (int i = threadIdx.x; i < E * (h + 1); i += 256) cs[i] = 0.f;
+    __syncthreads();
+    const bool act = lane < h;
+    const float w1 = act ? P.w1[lane] : 0.f, b1 = act ? P.b1[lane] : 0.f;
+    const float lw = act ? P.lnw[lane] : 0.f, lb = act ? P.lnb[lane] : 0.f;
+    float a_w1 = 0.f, a_b1 = 0.f, a_lw = 0.f, a_lb = 0.f;
+    float ab2[KE][4], aw2[KE][4][HM];
+#pragma unroll
+    for (int k = 0; k < KE; ++k)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            ab2[k][e] = 0.f;
+#pragma unroll
+            for (int j = 0; j < HM; ++j) aw2[k][e][j] = 0.f;
+        }
+    for (int row = blockIdx.x * 4 + wave; row < P.M; row += 4 * gridDim.x) {
+        const float cv = P.c[row];
+        const float pre = act ? w1 * cv + b1 : 0.f;
+        const float mean = wave_sum(pre) / (float)h;
+        const float cen = act ? pre - mean : 0.f;
+        const float var = wave_sum(cen * cen) / (float)h;
+        const float rstd = 1.0f / sqrtf(var + 1e-5f);
+        const float xh = cen * rstd;
+        const float u = xh * lw + lb;
+        const float hid = act ? gelu_erf(u) : 0.f;
+        float hk[HM], part[HM];
+#pragma unroll
+        for (int j = 0; j < HM; ++j) {
+            hk[j] = __shfl(hid, j);
+            part[j] = 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < KE; ++k) {
+            const int e0 = lane * 4 + 256 * k;
+            if (e0 < E) {
+                float dib[4] = {0.f, 0.f, 0.f, 0.f};
+                for (int f = 0; f < P.n_fields; ++f) {
+                    float v[4];
+                    load4(P.dX[f] + (int64_t)row * P.ldx + e0, v);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) dib[e] += v[e];
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    ab2[k][e] += dib[e];
+#pragma unroll
+                    for (int j = 0; j < HM; ++j) {
+                        aw2[k][e][j] += dib[e] * hk[j];
+                        if (j < h) part[j] += dib[e] * P.w2[(int64_t)(e0 + e) * h + j];
+                    }
+                }
+            }
+        }
+        float dhid = 0.f;
+#pragma unroll
+        for (int j = 0; j < HM; ++j) {
+            const float tot = wave_sum(part[j]);
+            if (lane == j) dhid = tot;
+        }
+        const float du = act ? dhid * gelu_erf_grad(u) : 0.f;
+        a_lw += du * xh;
+        a_lb += du;
+        const float dxh = du * lw;
+        const float c1 = wave_sum(dxh) / (float)h;
+        const float c2 = wave_sum(dxh * xh) / (float)h;
+        const float dpre = act ? rstd * (dxh - c1 - xh * c2) : 0.f;
+        a_w1 += dpre * cv;
+        a_b1 += dpre;
+    }
+    if (act) {
+        atomicAdd(P.dw1 + lane, a_w1);
+        atomicAdd(P.db1 + lane, a_b1);
+        atomicAdd(P.dlnw + lane, a_lw);
+        atomicAdd(P.dlnb + lane, a_lb);
+    }
+#pragma unroll
+    for (int k = 0; k < KE; ++k) {
+        const int e0 = lane * 4 + 256 * k;
+        if (e0 < E) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                atomicAdd(&s_b2[e0 + e], ab2[k][e]);
+#pragma unroll
+                for (int j = 0; j < HM; ++j)
+                    if (j < h) atomicAdd(&s_w2[(e0 + e) * h + j], aw2[k][e][j]);
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < E; i += 256) atomicAdd(P.db2 + i, s_b2[i]);
+    for (int i = threadIdx.x; i < E * h; i += 256) atomicAdd(P.dw2 + i, s_w2[i]);
+}
+
 extern "C" int sea_ib_bwd(const SeaIbBwdParams* params, void* stream) {
     SEA_REQUIRE(params != nullptr, "sea_ib_bwd: null params");
     const SeaIbBwdParams& P = *params;
@@ -556,8 +726,11 @@ extern "C" int sea_ib_bwd(const SeaIbBwdParams* params, void* stream) {
     SEA_REQUIRE(lds <= 160 * 1024, "sea_ib_bwd: E*(h+1) too large for LDS");
     if (lds > 65536) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ib_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     int nblk = (P.M + 3) / 4;
-    if (nblk > 128) nblk = 128;
-    ib_bwd_kernel<<<dim3(nblk), dim3(256), lds, static_cast<hipStream_t>(stream)>>>(P);
+    if (nblk > 256) nblk = 256;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (P.h <= 8 && P.E <= 256) ib_bwd_fast_kernel<1><<<dim3(nblk), dim3(256), lds, s>>>(P);
+    else if (P.h <= 8 && P.E <= 1024) ib_bwd_fast_kernel<4><<<dim3(nblk), dim3(256), lds, s>>>(P);
+    else ib_bwd_kernel<<<dim3(nblk), dim3(256), lds, s>>>(P);
     SEA_CHECK_LAUNCH("sea_ib_bwd");
     return SEA_OK;
 }
