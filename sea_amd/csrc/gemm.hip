@@ -22,7 +22,7 @@ __device__ __forceinline__ int find_group(const L& launch, int bid) {
 }
 
 // ---------------------------------------------------------------------------------------------- standard epilogue
-template <typename T, int BM, int BN>
+template <typename T, int BM, int BN, bool DMA>
 __global__ __launch_bounds__(256) void gemm_grouped_kernel(const GemmLaunch L) {
     using C = GemmCfg<T, BM, BN>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -39,7 +39,8 @@ __global__ __launch_bounds__(256) void gemm_grouped_kernel(const GemmLaunch L) {
     ml.lda = G.lda; ml.ldw = G.ldw; ml.M = G.M; ml.N = G.N; ml.K = G.K; ml.n_seg = G.n_seg;
     ml.m0 = tm * BM; ml.n0 = tn * BN;
     f32x4 acc[C::MI][C::NI];
-    ml.run(smem, acc);
+    if constexpr (DMA) ml.run_dma(smem, acc);
+    else ml.run(smem, acc);
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave >> 1, wn = wave & 1, r = lane & 15, g = lane >> 4;
@@ -49,6 +50,10 @@ __global__ __launch_bounds__(256) void gemm_grouped_kernel(const GemmLaunch L) {
     T* Cact = static_cast<T*>(G.Cact);
     T* Z = static_cast<T*>(G.Z);
     const int act = G.act;
+    // The activation-dtype output is the big one (fc1: [M, 8E]); per-lane 8-byte pieces at a row stride touch a quarter of a
+    // 128-byte line per instruction, so it is staged through the (now free) LDS tile and written out as whole rows, 16 B per lane.
+    constexpr int SP = BN * (int)sizeof(T) + 16;  // staging row pitch in bytes
+    const bool staged = Cact != nullptr && (G.N % C::EPC == 0) && (G.ldcact % C::EPC == 0);
 #pragma unroll
     for (int j = 0; j < C::NI; ++j) {
         const int n = ml.n0 + wn * C::WTN + j * 16 + g * 4;  // this lane's 4 consecutive output columns
@@ -83,13 +88,26 @@ __global__ __launch_bounds__(256) void gemm_grouped_kernel(const GemmLaunch L) {
                 for (int q = 0; q < 4; ++q) v[q] += rv[q];
             }
             if (C32 != nullptr) store4(C32 + (int64_t)m * G.ldc32 + n, v[0], v[1], v[2], v[3]);
-            if (Cact != nullptr) store4(Cact + (int64_t)m * G.ldcact + n, v[0], v[1], v[2], v[3]);
+            if (staged) {
+                store4(reinterpret_cast<T*>(smem + (wm * C::WTM + i * 16 + r) * SP) + (wn * C::WTN + j * 16 + g * 4), v[0], v[1], v[2], v[3]);
+            } else if (Cact != nullptr) {
+                store4(Cact + (int64_t)m * G.ldcact + n, v[0], v[1], v[2], v[3]);
+            }
+        }
+    }
+    if (staged) {  // block-uniform
+        __syncthreads();
+        constexpr int CPRO = BN / C::EPC;  // 16-byte chunks per staged row
+        for (int idx = threadIdx.x; idx < BM * CPRO; idx += 256) {
+            const int row = idx / CPRO, cc = idx - row * CPRO;
+            const int m = ml.m0 + row, n = ml.n0 + cc * C::EPC;
+            if (m < G.M && n < G.N) *reinterpret_cast<uint4*>(Cact + (int64_t)m * G.ldcact + n) = *reinterpret_cast<const uint4*>(smem + row * SP + cc * 16);
         }
     }
 }
 
 // ---------------------------------------------------------------------------------------------- QKV + RoPE epilogue
-template <typename T, int BM, int BN>
+template <typename T, int BM, int BN, bool DMA>
 __global__ __launch_bounds__(256) void qkv_rope_kernel(const QkvLaunch L) {
     using C = GemmCfg<T, BM, BN>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -106,7 +124,8 @@ __global__ __launch_bounds__(256) void qkv_rope_kernel(const QkvLaunch L) {
     ml.lda = G.lda; ml.ldw = G.ldw; ml.M = G.M; ml.N = G.N; ml.K = G.K; ml.n_seg = 1;
     ml.m0 = tm * BM; ml.n0 = tn * BN;
     f32x4 acc[C::MI][C::NI];
-    ml.run(smem, acc);
+    if constexpr (DMA) ml.run_dma(smem, acc);
+    else ml.run(smem, acc);
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave >> 1, wn = wave & 1, r = lane & 15, g = lane >> 4;
@@ -196,6 +215,11 @@ extern "C" int sea_gemm_grouped(const SeaGemmGroup* groups, int n_groups, int dt
         t64 += (long)((G.M + 63) / 64) * ((G.N + 63) / 64);
     }
     const int tile = pick_tile(t128, t64);
+    // LDS-DMA ring: needs whole K-tiles (128 bytes of K per row per stage) and pays off only on long contractions (its 4 stages
+    // cost a workgroup per CU at 128x128; measured: K = 2048 +5 %, K = 256 -20 % against the register-staged double buffer)
+    bool dma = true;
+    for (int i = 0; i < n_groups; ++i)
+        dma = dma && (groups[i].K % (dtype == SEA_BF16 ? 64 : 32) == 0) && (long)groups[i].K * groups[i].n_seg >= 1024;
     GemmLaunch L;
     memset(&L, 0, sizeof(L));
     L.n_groups = n_groups;
@@ -207,17 +231,22 @@ extern "C" int sea_gemm_grouped(const SeaGemmGroup* groups, int n_groups, int dt
     }
     L.tile_start[n_groups] = total;
     hipStream_t s = static_cast<hipStream_t>(stream);
-#define LAUNCH_GEMM(TT, BMN)                                                                          \
-    do {                                                                                              \
-        static int once = set_lds(gemm_grouped_kernel<TT, BMN, BMN>, GemmCfg<TT, BMN, BMN>::LDS_BYTES); \
-        (void)once;                                                                                   \
-        gemm_grouped_kernel<TT, BMN, BMN><<<dim3(total), dim3(256), GemmCfg<TT, BMN, BMN>::LDS_BYTES, s>>>(L); \
+#define LAUNCH_GEMM(TT, BMN, DM)                                                                                          \
+    do {                                                                                                                  \
+        constexpr int main_ = DM ? GemmMainloop<TT, BMN, BMN>::DMA_LDS_BYTES : GemmCfg<TT, BMN, BMN>::LDS_BYTES;             \
+        constexpr int stage_ = BMN * (BMN * (int)sizeof(TT) + 16);                                                         \
+        constexpr int lds_ = main_ > stage_ ? main_ : stage_;                                                              \
+        static int once = set_lds(gemm_grouped_kernel<TT, BMN, BMN, DM>, lds_);                                            \
+        (void)once;                                                                                                       \
+        gemm_grouped_kernel<TT, BMN, BMN, DM><<<dim3(total), dim3(256), lds_, s>>>(L);                                     \
     } while (0)
-    if (dtype == SEA_BF16) {
-        if (tile == 128) LAUNCH_GEMM(__bf16, 128); else LAUNCH_GEMM(__bf16, 64);
-    } else {
-        if (tile == 128) LAUNCH_GEMM(float, 128); else LAUNCH_GEMM(float, 64);
-    }
+#define LAUNCH_GEMM_T(TT)                                                 \
+    do {                                                                  \
+        if (tile == 128) { if (dma) LAUNCH_GEMM(TT, 128, true); else LAUNCH_GEMM(TT, 128, false); } \
+        else { if (dma) LAUNCH_GEMM(TT, 64, true); else LAUNCH_GEMM(TT, 64, false); }              \
+    } while (0)
+    if (dtype == SEA_BF16) LAUNCH_GEMM_T(__bf16); else LAUNCH_GEMM_T(float);
+#undef LAUNCH_GEMM_T
 #undef LAUNCH_GEMM
     SEA_CHECK_LAUNCH("sea_gemm_grouped");
     return SEA_OK;
@@ -247,6 +276,8 @@ extern "C" int sea_qkv_rope_grouped(const SeaQkvGroup* groups, int n_groups, con
         t64 += (long)((G.M + 63) / 64) * ((G.N + 63) / 64);
     }
     const int tile = pick_tile(t128, t64);
+    bool dma = true;
+    for (int i = 0; i < n_groups; ++i) dma = dma && (groups[i].K % (dtype == SEA_BF16 ? 64 : 32) == 0) && groups[i].K >= 1024;
     QkvLaunch L;
     memset(&L, 0, sizeof(L));
     L.n_groups = n_groups;
@@ -259,17 +290,20 @@ extern "C" int sea_qkv_rope_grouped(const SeaQkvGroup* groups, int n_groups, con
     }
     L.tile_start[n_groups] = total;
     hipStream_t s = static_cast<hipStream_t>(stream);
-#define LAUNCH_QKV(TT, BMN)                                                                        \
-    do {                                                                                           \
-        static int once = set_lds(qkv_rope_kernel<TT, BMN, BMN>, GemmCfg<TT, BMN, BMN>::LDS_BYTES);  \
-        (void)once;                                                                                \
-        qkv_rope_kernel<TT, BMN, BMN><<<dim3(total), dim3(256), GemmCfg<TT, BMN, BMN>::LDS_BYTES, s>>>(L); \
+#define LAUNCH_QKV(TT, BMN, DM)                                                                                           \
+    do {                                                                                                                  \
+        constexpr int lds_ = DM ? GemmMainloop<TT, BMN, BMN>::DMA_LDS_BYTES : GemmCfg<TT, BMN, BMN>::LDS_BYTES;              \
+        static int once = set_lds(qkv_rope_kernel<TT, BMN, BMN, DM>, lds_);                                                \
+        (void)once;                                                                                                       \
+        qkv_rope_kernel<TT, BMN, BMN, DM><<<dim3(total), dim3(256), lds_, s>>>(L);                                         \
     } while (0)
-    if (dtype == SEA_BF16) {
-        if (tile == 128) LAUNCH_QKV(__bf16, 128); else LAUNCH_QKV(__bf16, 64);
-    } else {
-        if (tile == 128) LAUNCH_QKV(float, 128); else LAUNCH_QKV(float, 64);
-    }
+#define LAUNCH_QKV_T(TT)                                                  \
+    do {                                                                  \
+        if (tile == 128) { if (dma) LAUNCH_QKV(TT, 128, true); else LAUNCH_QKV(TT, 128, false); }   \
+        else { if (dma) LAUNCH_QKV(TT, 64, true); else LAUNCH_QKV(TT, 64, false); }                \
+    } while (0)
+    if (dtype == SEA_BF16) LAUNCH_QKV_T(__bf16); else LAUNCH_QKV_T(float);
+#undef LAUNCH_QKV_T
 #undef LAUNCH_QKV
     SEA_CHECK_LAUNCH("sea_qkv_rope_grouped");
     return SEA_OK;

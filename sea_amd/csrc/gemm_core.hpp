@@ -106,6 +106,78 @@ struct GemmMainloop {
         }
     }
 
+    // ------------------------------------------------------------------------------------------------------------------
+    // LDS-DMA pipeline (K % BK == 0): K-tiles go HBM -> LDS directly with global_load_lds_dwordx4 (no VGPRs, no ds_write) into a
+    // ring of NS stages; NS-1 stages are in flight while one is computed, so a K-tile's HBM/L2 latency is covered by NS-2 compute
+    // phases instead of one.  One wave-instruction writes 1 KiB = 8 tile rows x 128 B, lane-linear in LDS, so the XOR swizzle is
+    // applied to the per-lane SOURCE address (cdna_hip_programming.md rule 21): lane (row r = lane >> 3, position p = lane & 7)
+    // fetches chunk p ^ (r & 7).  The loads are issued from inline asm so that hipcc neither counts them nor drains them with a
+    // vmcnt(0) in front of every ds_read; completion is tracked by hand: counted s_waitcnt vmcnt(N), then a raw s_barrier, then
+    // the reads (one barrier per K-tile).
+    static constexpr int NS = 4;
+    static constexpr int A_DMA = BM / 32, B_DMA = BN / 32;   // wave-instructions per wave per stage
+    static constexpr int LPS = A_DMA + B_DMA;
+    static constexpr int DMA_LDS_BYTES = NS * C::BUF_BYTES;
+
+    static __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_addr) {
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(gsrc), "s"(lds_addr) : "memory");
+    }
+
+    __device__ __forceinline__ void dma_stage(int kt, unsigned lds_base, int wave, int lane) const {
+        const int kk = kt * C::BK;
+        int seg = 0, kin = kk;
+        if (n_seg > 1) {
+            seg = kk / K;
+            kin = kk - seg * K;
+        }
+        const int rl = lane >> 3;                                   // row inside the 8-row slab
+        const int chunk = (lane & 7) ^ (rl & 7);                    // swizzle on the source side
+        const T* a_base = A + seg * a_seg_stride + kin + chunk * C::EPC;
+        const T* w_base = W + kin + chunk * C::EPC;
+        const unsigned stage = lds_base + (unsigned)((kt % NS) * C::BUF_BYTES);
+#pragma unroll
+        for (int u = 0; u < A_DMA; ++u) {
+            const int r0 = (u * 4 + wave) * 8;
+            int row = m0 + r0 + rl;
+            row = row < M ? row : M - 1;
+            glds16(a_base + (int64_t)row * lda, stage + (unsigned)(r0 * C::BKB));
+        }
+#pragma unroll
+        for (int u = 0; u < B_DMA; ++u) {
+            const int r0 = (u * 4 + wave) * 8;
+            int row = n0 + r0 + rl;
+            row = row < N ? row : N - 1;
+            glds16(w_base + (int64_t)row * ldw, stage + (unsigned)(BM * C::BKB + r0 * C::BKB));
+        }
+    }
+
+    __device__ __forceinline__ void run_dma(char* smem, f32x4 (&acc)[C::MI][C::NI]) {
+        const int tid = threadIdx.x;
+        const int lane = tid & 63;
+        const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+        const int wm = wave >> 1, wn = wave & 1;
+#pragma unroll
+        for (int i = 0; i < C::MI; ++i)
+#pragma unroll
+            for (int j = 0; j < C::NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int nk = (K * n_seg) / C::BK;
+        const unsigned lds_base = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)smem);
+        for (int s = 0; s < NS - 1 && s < nk; ++s) dma_stage(s, lds_base, wave, lane);
+        for (int kt = 0; kt < nk; ++kt) {
+            // stage kt has landed once at most the loads of the stages issued after it are outstanding
+            const int newer = (nk - 1 - kt) < (NS - 2) ? (nk - 1 - kt) : (NS - 2);
+            if (newer == NS - 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * LPS) : "memory");
+            else if (newer == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();  // every wave's part of stage kt is in LDS; everyone is done reading stage kt-1
+            if (kt + NS - 1 < nk) dma_stage(kt + NS - 1, lds_base, wave, lane);  // refill the buffer stage kt-1 used
+            compute_tile(smem + (kt % NS) * C::BUF_BYTES, wm, wn, lane, acc);
+        }
+        __syncthreads();
+    }
+
     __device__ __forceinline__ void run(char* smem, f32x4 (&acc)[C::MI][C::NI]) {
         const int tid = threadIdx.x;
         const int lane = tid & 63, wave = tid >> 6;
