@@ -31,12 +31,19 @@ struct AttnCfg {
     static constexpr int LDS_BYTES = K_BYTES + V_BYTES;
 };
 
-template <typename T, int HD>
-__global__ __launch_bounds__(256) void attention_fwd_kernel(const SeaAttnParams P) {
+// SPLIT = 2: two groups of 4 waves share a query tile and take alternate key tiles (group g: tiles g, g+2, ...), each with its
+// own running max / sum / O^T; the halves are merged through LDS at the end.  This halves the serial chain of key tiles of a
+// workgroup — what bounds the launch when the grid is only a few workgroups per CU (one trajectory: 768 workgroups).
+template <typename T, int HD, int SPLIT>
+__global__ __launch_bounds__(256 * SPLIT) void attention_fwd_kernel(const SeaAttnParams P) {
     using C = AttnCfg<T, HD>;
-    __shared__ __attribute__((aligned(16))) char smem[2 * C::LDS_BYTES];  // double-buffered K and V^T tiles
+    constexpr int MERGE_BYTES = SPLIT > 1 ? 256 * (2 + 4 * C::NDB) * 4 : 0;
+    constexpr int RING_BYTES = SPLIT * 2 * C::LDS_BYTES;                   // per group: double-buffered K and V^T tiles
+    __shared__ __attribute__((aligned(16))) char smem_all[RING_BYTES > MERGE_BYTES ? RING_BYTES : MERGE_BYTES];
+    const int grp = SPLIT > 1 ? (int)(threadIdx.x >> 8) : 0;               // wave-uniform
+    char* smem = smem_all + grp * 2 * C::LDS_BYTES;
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;  // tid, wave: inside the group
     const int r = lane & 15, g = lane >> 4;
     const int n_qt = gridDim.x;
     const int qt = n_qt - 1 - (int)blockIdx.x;  // heaviest (latest) query tiles first
@@ -225,22 +232,56 @@ __global__ __launch_bounds__(256) void attention_fwd_kernel(const SeaAttnParams 
         }
     };
 
-    load_tile(0);
-    store_tile(0);
+    // group g walks tiles g, g + SPLIT, ...; every thread of the workgroup executes every barrier
+    const int n_it = (n_kt + SPLIT - 1) / SPLIT;
+    if (grp < n_kt) {
+        load_tile(grp);
+        store_tile(0);
+    }
     __syncthreads();
-    for (int kt = 0; kt < n_kt; ++kt) {
-        const char* sK = smem + (kt & 1) * C::LDS_BYTES;
+    for (int it = 0; it < n_it; ++it) {
+        const int kt = it * SPLIT + grp;
+        const char* sK = smem + (it & 1) * C::LDS_BYTES;
         const char* sV = sK + C::K_BYTES;
-        const bool more = kt + 1 < n_kt;
-        if (more) load_tile(kt + 1);
+        const bool more = kt + SPLIT < n_kt;
+        if (more) load_tile(kt + SPLIT);
         const int tile_last = kt * 64 + 63;
-        if (tile_last <= wave_first && tile_last < Tk) {
-            process(sK, sV, kt, std::false_type{});   // fully visible to every row of the wave: no masking
-        } else if (kt * 64 <= wave_last) {
-            process(sK, sV, kt, std::true_type{});    // diagonal / last tile
-        }                                             // else: nothing visible to this wave (wave-uniform)
-        if (more) store_tile((kt + 1) & 1);
+        if (kt < n_kt) {
+            if (tile_last <= wave_first && tile_last < Tk) {
+                process(sK, sV, kt, std::false_type{});   // fully visible to every row of the wave: no masking
+            } else if (kt * 64 <= wave_last) {
+                process(sK, sV, kt, std::true_type{});    // diagonal / last tile
+            }                                             // else: nothing visible to this wave (wave-uniform)
+        }
+        if (more) store_tile((it + 1) & 1);
         __syncthreads();
+    }
+
+    if constexpr (SPLIT > 1) {
+        // merge group 1 into group 0: m = max(m0, m1), l = l0 e^(m0-m) + l1 e^(m1-m), O likewise (flash-decoding combine)
+        float* mg = reinterpret_cast<float*>(smem_all);
+        constexpr int STR = 2 + 4 * C::NDB;
+        if (grp == 1) {
+            float* dst = mg + tid * STR;
+            dst[0] = m_i;
+            dst[1] = l_i;
+#pragma unroll
+            for (int d = 0; d < C::NDB; ++d)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) dst[2 + 4 * d + q] = oacc[d][q];
+        }
+        __syncthreads();
+        if (grp == 1) return;
+        const float* src = mg + tid * STR;
+        const float m1 = src[0], l1 = src[1];
+        const float m = fmaxf(m_i, m1);  // group 0 always owns tile 0, so m_i is finite
+        const float a0 = __expf(m_i - m), a1 = __expf(m1 - m);  // m1 = -inf (group 1 saw nothing) -> a1 = 0
+        l_i = l_i * a0 + l1 * a1;
+#pragma unroll
+        for (int d = 0; d < C::NDB; ++d)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) oacc[d][q] = oacc[d][q] * a0 + src[2 + 4 * d + q] * a1;
+        m_i = m;
     }
 
     // ---- finalize: this lane holds O^T[d = 16*db + 4g + reg][query q_idx]
@@ -258,18 +299,26 @@ __global__ __launch_bounds__(256) void attention_fwd_kernel(const SeaAttnParams 
     }
 }
 
-template <typename T>
-static int launch_attention(const SeaAttnParams& P, hipStream_t s) {
-    const dim3 grid((P.Tq + 63) / 64, P.B * P.H, P.n_problems), block(256);
+template <typename T, int SPLIT>
+static int launch_attention_s(const SeaAttnParams& P, hipStream_t s) {
+    const dim3 grid((P.Tq + 63) / 64, P.B * P.H, P.n_problems), block(256 * SPLIT);
     switch (P.hd) {
-        case 8: attention_fwd_kernel<T, 8><<<grid, block, 0, s>>>(P); break;
-        case 16: attention_fwd_kernel<T, 16><<<grid, block, 0, s>>>(P); break;
-        case 32: attention_fwd_kernel<T, 32><<<grid, block, 0, s>>>(P); break;
-        case 64: attention_fwd_kernel<T, 64><<<grid, block, 0, s>>>(P); break;
-        case 128: attention_fwd_kernel<T, 128><<<grid, block, 0, s>>>(P); break;
+        case 8: attention_fwd_kernel<T, 8, SPLIT><<<grid, block, 0, s>>>(P); break;
+        case 16: attention_fwd_kernel<T, 16, SPLIT><<<grid, block, 0, s>>>(P); break;
+        case 32: attention_fwd_kernel<T, 32, SPLIT><<<grid, block, 0, s>>>(P); break;
+        case 64: attention_fwd_kernel<T, 64, SPLIT><<<grid, block, 0, s>>>(P); break;
+        case 128: attention_fwd_kernel<T, 128, 1><<<grid, dim3(256), 0, s>>>(P); break;  // LDS: one group only
         default: return -1;
     }
     return 0;
+}
+
+template <typename T>
+static int launch_attention(const SeaAttnParams& P, hipStream_t s) {
+    // few workgroups per CU and a long key range: split the key tiles of a query tile over two wave groups
+    const long blocks = (long)((P.Tq + 63) / 64) * P.B * P.H * P.n_problems;
+    const bool split = blocks <= 1024 && P.Tk >= 256;
+    return split ? launch_attention_s<T, 2>(P, s) : launch_attention_s<T, 1>(P, s);
 }
 
 extern "C" int sea_attention_fwd(const SeaAttnParams* params, int dtype, void* stream) {

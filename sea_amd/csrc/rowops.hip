@@ -12,7 +12,10 @@ struct NormLaunch {
 };
 
 // One wave per row, 4 rows per workgroup, grid = (ceil(M/4), n_groups).
-template <typename T, bool X_IS_ACT>
+// KMAX > 0 (d <= 256*KMAX): the row is read from memory ONCE and kept in registers (lane owns columns lane*4 + 256k); for
+// KMAX <= 2 the gain/shift/modulation loads are issued together with it, so the whole row costs one memory round trip instead of
+// three dependent ones (these launches are latency-bound at M = 2024).  KMAX == 0: any d, three passes over the (cache-hot) row.
+template <typename T, bool X_IS_ACT, int KMAX>
 __global__ __launch_bounds__(256) void rownorm_kernel(const NormLaunch L) {
     const SeaNormGroup& G = L.g[blockIdx.y];
     const int lane = threadIdx.x & 63;
@@ -21,56 +24,118 @@ __global__ __launch_bounds__(256) void rownorm_kernel(const NormLaunch L) {
     const int d = L.d;
     using XT = typename std::conditional<X_IS_ACT, T, float>::type;
     const XT* x = static_cast<const XT*>(G.X) + (int64_t)row * G.ldx;
-
-    float sum = 0.f;
-    for (int i = lane * 4; i < d; i += 256) {
-        float v[4];
-        load4(x + i, v);
-        sum += (v[0] + v[1]) + (v[2] + v[3]);
-    }
-    const float mean = wave_sum(sum) / (float)d;
-    float sq = 0.f;
-    for (int i = lane * 4; i < d; i += 256) {
-        float v[4];
-        load4(x + i, v);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const float c = v[e] - mean;
-            sq += c * c;
-        }
-    }
-    const float var = wave_sum(sq) / (float)d;
-    const float rstd = 1.0f / sqrtf(var + L.eps);
-    if (lane == 0) {
-        if (G.mean != nullptr) G.mean[row] = mean;
-        if (G.rstd != nullptr) G.rstd[row] = rstd;
-    }
     const T* mod = G.mod != nullptr ? static_cast<const T*>(G.mod) + (int64_t)row * G.ldmod : nullptr;
     float* y32 = G.Y32 != nullptr ? G.Y32 + (int64_t)row * G.ldy32 : nullptr;
     T* yact = G.Yact != nullptr ? static_cast<T*>(G.Yact) + (int64_t)row * G.ldyact : nullptr;
-    for (int i = lane * 4; i < d; i += 256) {
-        float v[4], gm[4], bt[4] = {0.f, 0.f, 0.f, 0.f};
-        load4(x + i, v);
-        load4(G.gamma + i, gm);
-        if (G.beta != nullptr) load4(G.beta + i, bt);
-        if (mod != nullptr) {
-            float mw[4], mb[4];
-            load4(mod + i, mw);
-            load4(mod + d + i, mb);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                gm[e] += 1.0f + mw[e];
-                bt[e] += mb[e];
-            }
-        }
+    const float inv_d = 1.0f / (float)d;
+
+    auto finish = [&](int i, const float (&v)[4], float (&gm)[4], float (&bt)[4], const float (&mw)[4], const float (&mb)[4], float mean, float rstd) {
         float o[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            o[e] = (v[e] - mean) * rstd * gm[e] + bt[e];
+            const float gq = mod != nullptr ? gm[e] + 1.0f + mw[e] : gm[e];
+            const float bq = mod != nullptr ? bt[e] + mb[e] : bt[e];
+            o[e] = (v[e] - mean) * rstd * gq + bq;
             if (L.gelu) o[e] = gelu_erf(o[e]);
         }
         if (y32 != nullptr) store4(y32 + i, o[0], o[1], o[2], o[3]);
         if (yact != nullptr) store4(yact + i, o[0], o[1], o[2], o[3]);
+    };
+
+    if constexpr (KMAX > 0) {
+        constexpr bool PRE = KMAX <= 2;
+        constexpr int KP = PRE ? KMAX : 1;
+        float xv[KMAX][4], gm[KP][4], bt[KP][4], mw[KP][4], mb[KP][4];
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) {
+            const int i = lane * 4 + 256 * k;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) xv[k][e] = 0.f;
+            if (i < d) load4(x + i, xv[k]);
+            if constexpr (PRE) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) gm[k][e] = bt[k][e] = mw[k][e] = mb[k][e] = 0.f;
+                if (i < d) {
+                    load4(G.gamma + i, gm[k]);
+                    if (G.beta != nullptr) load4(G.beta + i, bt[k]);
+                    if (mod != nullptr) {
+                        load4(mod + i, mw[k]);
+                        load4(mod + d + i, mb[k]);
+                    }
+                }
+            }
+        }
+        float sum = 0.f;
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) sum += (xv[k][0] + xv[k][1]) + (xv[k][2] + xv[k][3]);  // columns >= d hold zeros
+        const float mean = wave_sum(sum) * inv_d;
+        float sq = 0.f;
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k)
+            if (lane * 4 + 256 * k < d) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float c = xv[k][e] - mean;
+                    sq += c * c;
+                }
+            }
+        const float rstd = 1.0f / sqrtf(wave_sum(sq) * inv_d + L.eps);
+        if (lane == 0) {
+            if (G.mean != nullptr) G.mean[row] = mean;
+            if (G.rstd != nullptr) G.rstd[row] = rstd;
+        }
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) {
+            const int i = lane * 4 + 256 * k;
+            if (i < d) {
+                if constexpr (PRE) {
+                    finish(i, xv[k], gm[k], bt[k], mw[k], mb[k], mean, rstd);
+                } else {
+                    float g1[4], b1[4] = {0.f, 0.f, 0.f, 0.f}, w1[4] = {0.f, 0.f, 0.f, 0.f}, m1[4] = {0.f, 0.f, 0.f, 0.f};
+                    load4(G.gamma + i, g1);
+                    if (G.beta != nullptr) load4(G.beta + i, b1);
+                    if (mod != nullptr) {
+                        load4(mod + i, w1);
+                        load4(mod + d + i, m1);
+                    }
+                    finish(i, xv[k], g1, b1, w1, m1, mean, rstd);
+                }
+            }
+        }
+    } else {
+        float sum = 0.f;
+        for (int i = lane * 4; i < d; i += 256) {
+            float v[4];
+            load4(x + i, v);
+            sum += (v[0] + v[1]) + (v[2] + v[3]);
+        }
+        const float mean = wave_sum(sum) * inv_d;
+        float sq = 0.f;
+        for (int i = lane * 4; i < d; i += 256) {
+            float v[4];
+            load4(x + i, v);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float c = v[e] - mean;
+                sq += c * c;
+            }
+        }
+        const float rstd = 1.0f / sqrtf(wave_sum(sq) * inv_d + L.eps);
+        if (lane == 0) {
+            if (G.mean != nullptr) G.mean[row] = mean;
+            if (G.rstd != nullptr) G.rstd[row] = rstd;
+        }
+        for (int i = lane * 4; i < d; i += 256) {
+            float v[4], g1[4], b1[4] = {0.f, 0.f, 0.f, 0.f}, w1[4] = {0.f, 0.f, 0.f, 0.f}, m1[4] = {0.f, 0.f, 0.f, 0.f};
+            load4(x + i, v);
+            load4(G.gamma + i, g1);
+            if (G.beta != nullptr) load4(G.beta + i, b1);
+            if (mod != nullptr) {
+                load4(mod + i, w1);
+                load4(mod + d + i, m1);
+            }
+            finish(i, v, g1, b1, w1, m1, mean, rstd);
+        }
     }
 }
 
@@ -95,13 +160,21 @@ extern "C" int sea_rownorm(const SeaNormGroup* groups, int n_groups, int M, int 
     L.M = M; L.d = d; L.gelu = gelu; L.eps = eps;
     const dim3 grid((M + 3) / 4, n_groups), block(256);
     hipStream_t s = static_cast<hipStream_t>(stream);
+#define LAUNCH_RN(TT, XA)                                                     \
+    do {                                                                       \
+        if (d <= 256) rownorm_kernel<TT, XA, 1><<<grid, block, 0, s>>>(L);     \
+        else if (d <= 512) rownorm_kernel<TT, XA, 2><<<grid, block, 0, s>>>(L);\
+        else if (d <= 1024) rownorm_kernel<TT, XA, 4><<<grid, block, 0, s>>>(L);\
+        else if (d <= 2048) rownorm_kernel<TT, XA, 8><<<grid, block, 0, s>>>(L);\
+        else rownorm_kernel<TT, XA, 0><<<grid, block, 0, s>>>(L);              \
+    } while (0)
     if (dtype == SEA_BF16) {
-        if (x_is_act) rownorm_kernel<__bf16, true><<<grid, block, 0, s>>>(L);
-        else rownorm_kernel<__bf16, false><<<grid, block, 0, s>>>(L);
+        if (x_is_act) LAUNCH_RN(__bf16, true);
+        else LAUNCH_RN(__bf16, false);
     } else {
-        // f32 activations: x is float either way
-        rownorm_kernel<float, false><<<grid, block, 0, s>>>(L);
+        LAUNCH_RN(float, false);  // f32 activations: x is float either way
     }
+#undef LAUNCH_RN
     SEA_CHECK_LAUNCH("sea_rownorm");
     return SEA_OK;
 }
