@@ -308,6 +308,12 @@ static int launch_attention_s(const SeaAttnParams& P, hipStream_t s) {
         case 32: attention_fwd_kernel<T, 32, SPLIT><<<grid, block, 0, s>>>(P); break;
         case 64: attention_fwd_kernel<T, 64, SPLIT><<<grid, block, 0, s>>>(P); break;
         case 128: attention_fwd_kernel<T, 128, 1><<<grid, dim3(256), 0, s>>>(P); break;  // LDS: one group only
+        case 256:  // the shipped multiphase dims (embed_dim 2048 / 8 heads): bf16 only, the f32 tiles would not fit the LDS ring
+            if constexpr (sizeof(T) == 2) {
+                attention_fwd_kernel<T, 256, 1><<<grid, dim3(256), 0, s>>>(P);
+                break;
+            }
+            return -1;
         default: return -1;
     }
     return 0;
@@ -328,7 +334,8 @@ extern "C" int sea_attention_fwd(const SeaAttnParams* params, int dtype, void* s
     SEA_REQUIRE(P.n_problems >= 1 && P.n_problems <= SEA_MAX_ATTN_PROBLEMS, "sea_attention_fwd: n_problems=%d", P.n_problems);
     SEA_REQUIRE(P.B >= 1 && P.H >= 1 && P.Tq >= 1 && P.Tk >= 1 && P.cap >= P.Tk && P.q_pos0 >= 0 && P.src_len >= 0,
                 "sea_attention_fwd: bad sizes B=%d H=%d Tq=%d Tk=%d cap=%d q_pos0=%d src_len=%d", P.B, P.H, P.Tq, P.Tk, P.cap, P.q_pos0, P.src_len);
-    SEA_REQUIRE(P.hd == 8 || P.hd == 16 || P.hd == 32 || P.hd == 64 || P.hd == 128, "sea_attention_fwd: unsupported head dim %d", P.hd);
+    SEA_REQUIRE(P.hd == 8 || P.hd == 16 || P.hd == 32 || P.hd == 64 || P.hd == 128 || (P.hd == 256 && dtype == SEA_BF16),
+                "sea_attention_fwd: unsupported head dim %d (8..128; 256 in bf16 only)", P.hd);
     SEA_REQUIRE(P.cap % 8 == 0, "sea_attention_fwd: cap=%d must be a multiple of 8", P.cap);
     SEA_REQUIRE(P.ldo >= P.H * P.hd && P.ldo % 4 == 0, "sea_attention_fwd: bad ldo=%d", P.ldo);
     SEA_REQUIRE((long)P.B * P.H <= 65535, "sea_attention_fwd: B*H too large for grid.y");

@@ -512,8 +512,10 @@ class TemporalEngine:
                 f"{m.exchange_mode}/{m.ib_scale_mode}/{m.ib_addition_mode}/{m.ib_mlp_layers}/{m.ib_num}")
         E, H, D = m.embed_dim, m.n_heads, m.down_dim
         for hd, what in ((E // H, "self"), (D // H, "cross")):
-            if hd not in (8, 16, 32, 64, 128) or hd * H != (E if what == "self" else D):
-                raise NotImplementedError(f"sea_amd: unsupported {what}-attention head dim {hd} (supported: 8, 16, 32, 64, 128)")
+            ok = hd in (8, 16, 32, 64, 128) or (hd == 256 and act_dtype == torch.bfloat16)
+            if not ok or hd * H != (E if what == "self" else D):
+                raise NotImplementedError(f"sea_amd: unsupported {what}-attention head dim {hd} (supported: 8, 16, 32, 64, 128; 256 with "
+                                          "compute dtype bf16, forward/rollout only)")
         if m.src_len < 0:
             raise NotImplementedError("sea_amd: src_len must be >= 0")
         if m.ib_hidden > 64:

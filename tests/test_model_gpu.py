@@ -229,3 +229,37 @@ def test_graph_replay_equals_plain_replay():
         c = eng.forward_graphed(x, ib).clone()
         d = eng.forward(x, ib)
     assert torch.equal(a, b) and torch.equal(c, d) and not torch.equal(a, c)
+
+
+def test_cfg1_shipped_cylinder_dims_rollout8():
+    """BASELINE.json configs[0]: the shipped cylinder_flow dims (embed_dim 1024, 2 field groups, head dims 128 / 64, MLP hidden 8192),
+    1 trajectory, 8-step rollout — fp32 against the reference's golden sample, recompute and KV-cache modes."""
+    from sea_amd.utils.train_utils import rollout
+
+    g = load_golden("cfg1_cylinder_rollout8")
+    cfg = cfg_from_meta(g["cfg"])
+    m = build(cfg, "fp32")
+    x, _, ib = recipe_inputs(1, 8, cfg, seed=int(g["seed"]))
+    for mode in ("recompute", "kv"):
+        pred = rollout(m, x[:, :1].cuda(), ib.cuda(), 8, mode=mode).cpu()
+        assert rel_l2(pred[:, :, :, ::37].numpy(), g["pred_sub"]) < 2e-4, mode
+        assert np.allclose(pred.pow(2).sum(dim=(0, 3)).sqrt().numpy(), g["pred_l2"], rtol=2e-4), mode
+
+
+def test_shipped_multiphase_dims_forward_bf16():
+    """configs/multiphase_flow.py dims: embed_dim 2048, 2 field groups, LN_type 'ln' -> head dims 256 / 128, MLP hidden 16384.
+    bf16 forward and a short KV rollout against the CPU oracle on the same seeded inputs (rows of 16384 exercise the generic row kernels)."""
+    from sea_amd.utils.train_utils import rollout
+
+    cfg = O.OracleConfig(1, 2048, 8, 64, 8, 0, 2, 2, True, "ln")
+    p = recipe_params(cfg)
+    x, _, ib = recipe_inputs(1, 40, cfg, seed=9)
+    with torch.no_grad():
+        ref = O.model_forward(x, ib, p, cfg)
+        ref_roll = O.rollout(x[:, :1], ib, 6, p, cfg)
+    m = build(cfg, "bf16")
+    with torch.no_grad():
+        out = m(x.cuda(), ib.cuda()).cpu()
+    assert rel_l2(out.numpy(), ref.numpy()) < BF16_TOL
+    roll = rollout(m, x[:, :1].cuda(), ib.cuda(), 6, mode="kv").cpu()
+    assert rel_l2(roll.numpy(), ref_roll.numpy()) < 2 * BF16_TOL
