@@ -64,6 +64,20 @@ int sea_device_info(int* cu_count, char* arch, int arch_len);
  * Requirements: K % 8 == 0; N % 4 == 0; lda, ldw multiples of 8; ldr, ldc32, ldcact, ldz multiples of 4; all pointers
  * 16-byte aligned.
  */
+/* Dropout (training only).  thr = round(256 p) in [0, 255], 0 = off.  Element (row, col) of random stream `stream` is KEPT iff
+ * byte (col & 3) of the 32-bit word  mix(seed, stream, row, col >> 2)  is >= thr; kept values are scaled by 256 / (256 - thr)
+ * (so the effective rate is thr/256 and the expectation is exact).  The same counter-based definition is evaluated by the
+ * forward and the backward kernels, so no mask is ever stored.  (The reference draws torch.nn.Dropout masks — models/base_blocks.py:47,
+ * 194, 286 — which cannot be reproduced bit for bit; parity is distributional, checked with sea_dropout_mask.) */
+typedef struct {
+    uint32_t seed;
+    uint32_t stream;
+    int32_t thr;
+    int32_t mode; /* GEMM epilogue: 1 = on (acc + bias) before the residual, 2 = on the act-dtype output only (backward) */
+} SeaDropout;
+/* Writes keep * scale (0 or 256/(256-thr)) for a [rows, cols] element grid of one stream: test / debugging aid. */
+int sea_dropout_mask(float* out, int64_t rows, int64_t cols, uint32_t seed, uint32_t stream, int32_t thr, void* stream_handle);
+
 #define SEA_MAX_GROUPS 16
 typedef struct {
     const void* A;      /* act [M, K], row stride lda */
@@ -78,6 +92,7 @@ typedef struct {
     int32_t M, N, K, n_seg;
     int32_t act;        /* 0 none, 1 GELU(erf) forward, 2 multiply by GELU'(Z) */
     float bias_scale;
+    SeaDropout drop;    /* element grid = (output row, output column) */
 } SeaGemmGroup;
 
 int sea_gemm_grouped(const SeaGemmGroup* groups, int n_groups, int dtype, void* stream);
@@ -138,6 +153,7 @@ typedef struct {
     SeaAttnProblem p[SEA_MAX_ATTN_PROBLEMS];
     int32_t n_problems;
     int32_t B, H, hd, Tq, Tk, cap, q_pos0, src_len, ldo;
+    SeaDropout drop;    /* on the attention probabilities; element grid = (query, key) of stream (drop.stream + problem) * B*H + b*H + h */
 } SeaAttnParams;
 
 int sea_attention_fwd(const SeaAttnParams* params, int dtype, void* stream);
@@ -198,6 +214,7 @@ typedef struct {
     const float* w2;  /* [E, h] */
     const float* b2;  /* [E] */
     int32_t M, E, h;
+    SeaDropout drop;  /* on the MLP output, an independent stream (drop.stream + field) per field; element grid = (row, column) */
 } SeaIbParams;
 
 int sea_ib_add(const SeaIbParams* params, void* stream);
@@ -306,6 +323,7 @@ typedef struct {
     int32_t B, H, hd, Tq, Tk, cap, q_pos0, src_len;
     int32_t ldo, lddo, lddq, lddk, lddv;
     float q_scale;
+    SeaDropout drop;   /* must equal the forward's */
 } SeaAttnBwdParams;
 int sea_attention_bwd(const SeaAttnBwdParams* params, int dtype, void* stream);
 
@@ -337,6 +355,7 @@ typedef struct {
     float* dw2;
     float* db2;
     int32_t M, E, h;
+    SeaDropout drop;
 } SeaIbBwdParams;
 int sea_ib_bwd(const SeaIbBwdParams* params, void* stream);
 

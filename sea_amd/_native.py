@@ -23,12 +23,16 @@ MAX_SILU_GROUPS = 24
 _vp, _i32, _i64, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 
 
+class SeaDropout(C.Structure):
+    _fields_ = [("seed", C.c_uint32), ("stream", C.c_uint32), ("thr", _i32), ("mode", _i32)]
+
+
 class SeaGemmGroup(C.Structure):
     _fields_ = [("A", _vp), ("W", _vp), ("bias", _vp), ("R", _vp), ("C32", _vp), ("Cact", _vp), ("Z", _vp),
                 ("a_seg_stride", _i64),
                 ("lda", _i32), ("ldw", _i32), ("ldr", _i32), ("ldc32", _i32), ("ldcact", _i32), ("ldz", _i32),
                 ("M", _i32), ("N", _i32), ("K", _i32), ("n_seg", _i32),
-                ("act", _i32), ("bias_scale", _f32)]
+                ("act", _i32), ("bias_scale", _f32), ("drop", SeaDropout)]
 
 
 class SeaQkvGroup(C.Structure):
@@ -47,7 +51,7 @@ class SeaAttnProblem(C.Structure):
 class SeaAttnParams(C.Structure):
     _fields_ = [("p", SeaAttnProblem * MAX_ATTN_PROBLEMS), ("n_problems", _i32),
                 ("B", _i32), ("H", _i32), ("hd", _i32), ("Tq", _i32), ("Tk", _i32), ("cap", _i32),
-                ("q_pos0", _i32), ("src_len", _i32), ("ldo", _i32)]
+                ("q_pos0", _i32), ("src_len", _i32), ("ldo", _i32), ("drop", SeaDropout)]
 
 
 class SeaNormGroup(C.Structure):
@@ -63,7 +67,7 @@ class SeaSiluGroup(C.Structure):
 class SeaIbParams(C.Structure):
     _fields_ = [("X", _vp * 8), ("n_fields", _i32), ("ldx", _i32),
                 ("c", _vp), ("w1", _vp), ("b1", _vp), ("lnw", _vp), ("lnb", _vp), ("w2", _vp), ("b2", _vp),
-                ("M", _i32), ("E", _i32), ("h", _i32)]
+                ("M", _i32), ("E", _i32), ("h", _i32), ("drop", SeaDropout)]
 
 
 class SeaWgradGroup(C.Structure):
@@ -85,7 +89,7 @@ class SeaIbBwdParams(C.Structure):
     _fields_ = [("dX", _vp * 8), ("n_fields", _i32), ("ldx", _i32),
                 ("c", _vp), ("w1", _vp), ("b1", _vp), ("lnw", _vp), ("lnb", _vp), ("w2", _vp),
                 ("dw1", _vp), ("db1", _vp), ("dlnw", _vp), ("dlnb", _vp), ("dw2", _vp), ("db2", _vp),
-                ("M", _i32), ("E", _i32), ("h", _i32)]
+                ("M", _i32), ("E", _i32), ("h", _i32), ("drop", SeaDropout)]
 
 
 class SeaAttnBwdProblem(C.Structure):
@@ -96,7 +100,7 @@ class SeaAttnBwdProblem(C.Structure):
 class SeaAttnBwdParams(C.Structure):
     _fields_ = [("p", SeaAttnBwdProblem * MAX_ATTN_PROBLEMS), ("rope", _vp), ("n_problems", _i32),
                 ("B", _i32), ("H", _i32), ("hd", _i32), ("Tq", _i32), ("Tk", _i32), ("cap", _i32), ("q_pos0", _i32), ("src_len", _i32),
-                ("ldo", _i32), ("lddo", _i32), ("lddq", _i32), ("lddk", _i32), ("lddv", _i32), ("q_scale", _f32)]
+                ("ldo", _i32), ("lddo", _i32), ("lddq", _i32), ("lddk", _i32), ("lddv", _i32), ("q_scale", _f32), ("drop", SeaDropout)]
 
 
 MAX_WGRAD_GROUPS = 16
@@ -142,6 +146,8 @@ def lib() -> C.CDLL:
     L.sea_silu_outer_bwd.argtypes = [C.POINTER(SeaSiluBwdGroup), C.c_int, _vp, C.c_int, C.c_int, _vp]
     L.sea_ib_bwd.argtypes = [C.POINTER(SeaIbBwdParams), _vp]
     L.sea_attention_bwd.argtypes = [C.POINTER(SeaAttnBwdParams), C.c_int, _vp]
+    L.sea_dropout_mask.argtypes = [_vp, _i64, _i64, C.c_uint32, C.c_uint32, _i32, _vp]
+    L.sea_dropout_mask.restype = C.c_int
     for name in ("sea_attention_bwd", "sea_wgrad_grouped", "sea_transpose_weights", "sea_rownorm_bwd", "sea_silu_outer_bwd", "sea_ib_bwd"):
         getattr(L, name).restype = C.c_int
     L.sea_mse_fwd_bwd.argtypes = [_vp, _vp, _vp, _vp, _vp, C.c_int, _i64, C.c_float, _vp]
@@ -159,14 +165,15 @@ def lib() -> C.CDLL:
 
 
 ABI_STRUCTS = (SeaGemmGroup, SeaQkvGroup, SeaQkvCommon, SeaAttnProblem, SeaAttnParams, SeaNormGroup, SeaSiluGroup,
-               SeaIbParams, SeaWgradGroup, SeaNormBwdGroup, SeaSiluBwdGroup, SeaIbBwdParams, SeaAttnBwdProblem, SeaAttnBwdParams)
+               SeaIbParams, SeaWgradGroup, SeaNormBwdGroup, SeaSiluBwdGroup, SeaIbBwdParams, SeaAttnBwdProblem, SeaAttnBwdParams,
+               SeaDropout)
 
 EXPORTED_SYMBOLS = (
     "sea_abi_version", "sea_last_error", "sea_struct_sizes", "sea_device_info", "sea_gemm_grouped", "sea_qkv_rope_grouped",
     "sea_attention_fwd", "sea_rownorm", "sea_silu_outer", "sea_ib_add", "sea_convert_f32_to_act", "sea_selftest_mfma",
     "sea_mse_fwd_bwd", "sea_relative_mse", "sea_adamw_flat",
     "sea_wgrad_grouped", "sea_transpose_weights", "sea_rownorm_bwd", "sea_silu_outer_bwd", "sea_ib_bwd",
-    "sea_attention_bwd",
+    "sea_attention_bwd", "sea_dropout_mask",
 )
 
 

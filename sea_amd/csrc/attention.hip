@@ -58,6 +58,7 @@ __global__ __launch_bounds__(256 * SPLIT) void attention_fwd_kernel(const SeaAtt
     const int q_row0 = qt * 64 + wave * 16;
     const int q_idx = q_row0 + r;
     const int q_ld = q_idx < Tq ? q_idx : Tq - 1;
+    const uint32_t drop_stream = (P.drop.stream + blockIdx.z) * (uint32_t)(P.B * P.H) + (uint32_t)bh;
 
     // Q fragments (B operand of S^T): lane holds Q[q][c*CK + g*EPC .. +EPC)
     uint4 qf[C::NCH];
@@ -212,6 +213,18 @@ __global__ __launch_bounds__(256 * SPLIT) void attention_fwd_kernel(const SeaAtt
         m_i = m_new;
 #pragma unroll
         for (int d = 0; d < C::NDB; ++d) oacc[d] *= alpha;
+        if (P.drop.thr > 0) {  // dropout on the probabilities: the row sum above stays un-dropped (softmax first, then dropout)
+            const float sc = drop_scale(P.drop.thr);
+#pragma unroll
+            for (int kc = 0; kc < C::KCH; ++kc)
+#pragma unroll
+                for (int be = 0; be < C::NB; ++be) {
+                    const int key0 = kt * 64 + kc * C::CK + g * C::EPC + be * 4;
+                    const uint32_t w = drop_word(P.drop.seed, drop_stream, (uint32_t)q_idx, (uint32_t)(key0 >> 2));
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) s[kc][be][q] *= drop_factor(w, q, P.drop.thr, sc);
+                }
+        }
         // ---- O^T += V^T . P^T
 #pragma unroll
         for (int kc = 0; kc < C::KCH; ++kc) {
@@ -337,6 +350,7 @@ extern "C" int sea_attention_fwd(const SeaAttnParams* params, int dtype, void* s
     SEA_REQUIRE(P.hd == 8 || P.hd == 16 || P.hd == 32 || P.hd == 64 || P.hd == 128 || (P.hd == 256 && dtype == SEA_BF16),
                 "sea_attention_fwd: unsupported head dim %d (8..128; 256 in bf16 only)", P.hd);
     SEA_REQUIRE(P.cap % 8 == 0, "sea_attention_fwd: cap=%d must be a multiple of 8", P.cap);
+    SEA_REQUIRE(P.drop.thr >= 0 && P.drop.thr <= 255, "sea_attention_fwd: bad dropout threshold %d", P.drop.thr);
     SEA_REQUIRE(P.ldo >= P.H * P.hd && P.ldo % 4 == 0, "sea_attention_fwd: bad ldo=%d", P.ldo);
     SEA_REQUIRE((long)P.B * P.H <= 65535, "sea_attention_fwd: B*H too large for grid.y");
     for (int i = 0; i < P.n_problems; ++i) {

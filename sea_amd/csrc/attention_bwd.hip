@@ -108,6 +108,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const SeaAttnBwdParams
     const T* Kg = static_cast<const T*>(pr.K) + (int64_t)bh * P.cap * HD;
     const T* Vg = static_cast<const T*>(pr.V) + (int64_t)bh * P.cap * HD;
     const int q_row0 = qt * 64 + wave * 16, q_idx = q_row0 + r, q_ld = q_idx < Tq ? q_idx : Tq - 1;
+    const uint32_t drop_stream = (P.drop.stream + blockIdx.z) * (uint32_t)(P.B * P.H) + (uint32_t)bh;
+    const float drop_sc = P.drop.thr > 0 ? drop_scale(P.drop.thr) : 1.f;
     const T* Og = static_cast<const T*>(pr.O) + ((int64_t)b * Tq + q_ld) * P.ldo + h * HD;
     const T* dOg = static_cast<const T*>(pr.dO) + ((int64_t)b * Tq + q_ld) * P.lddo + h * HD;
 
@@ -180,6 +182,13 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const SeaAttnBwdParams
                         mma16<T>(ak, qf[c], s);
                         mma16<T>(av, dof[c], dp);
                     }
+                    float dfac[4] = {1.f, 1.f, 1.f, 1.f};  // dropout: dP = D (dO V^T), D = keep * scale
+                    if (P.drop.thr > 0) {
+                        const int key0 = kt * 64 + kc * C::CK + g * C::EPC + be * 4;
+                        const uint32_t w = drop_word(P.drop.seed, drop_stream, (uint32_t)q_idx, (uint32_t)(key0 >> 2));
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) dfac[q] = drop_factor(w, q, P.drop.thr, drop_sc);
+                    }
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         float p = __expf(s[q] - lse);
@@ -187,7 +196,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const SeaAttnBwdParams
                             const int key = kt * 64 + kc * C::CK + g * C::EPC + be * 4 + q;
                             if (!(key <= limit && key < Tk)) p = 0.f;
                         }
-                        ds[kc][be][q] = p * (dp[q] - delta);
+                        ds[kc][be][q] = p * (dp[q] * dfac[q] - delta);
                     }
                 }
             }
@@ -241,6 +250,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const SeaAttnBwdParam
     const float* lse_g = pr.LSE + (int64_t)bh * Tq;
     const float* del_g = pr.delta + (int64_t)bh * Tq;
     const int k_row0 = kb * 64 + wave * 16, k_idx = k_row0 + r, k_ld = k_idx < Tk ? k_idx : Tk - 1;
+    const uint32_t drop_stream = (P.drop.stream + blockIdx.z) * (uint32_t)(P.B * P.H) + (uint32_t)bh;
+    const float drop_sc = P.drop.thr > 0 ? drop_scale(P.drop.thr) : 1.f;
 
     uint4 kf[C::NCH], vf[C::NCH];
 #pragma unroll
@@ -333,8 +344,13 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const SeaAttnBwdParam
                             const int qi = qt * 64 + ql + q;
                             if (!(qi >= q_min_lane && qi < Tq && k_idx < Tk)) p = 0.f;
                         }
-                        pp[qc][be][q] = p;
-                        ds[qc][be][q] = p * (dp[q] - d4[q]);
+                        float dfac = 1.f;
+                        if (P.drop.thr > 0) {
+                            const uint32_t w = drop_word(P.drop.seed, drop_stream, (uint32_t)(qt * 64 + ql + q), (uint32_t)(k_idx >> 2));
+                            dfac = drop_factor(w, k_idx & 3, P.drop.thr, drop_sc);
+                        }
+                        pp[qc][be][q] = p * dfac;                    // dV = (D P)^T dO
+                        ds[qc][be][q] = p * (dp[q] * dfac - d4[q]);  // dS = P (D dP - delta)
                     }
                 }
             }

@@ -564,6 +564,12 @@ __global__ __launch_bounds__(256) void ib_bwd_kernel(const SeaIbBwdParams P) {
             for (int f = 0; f < P.n_fields; ++f) {
                 float v[4];
                 load4(P.dX[f] + (int64_t)row * P.ldx + e0, v);
+                if (P.drop.thr > 0) {
+                    const uint32_t w = drop_word(P.drop.seed, P.drop.stream + f, (uint32_t)row, (uint32_t)(e0 >> 2));
+                    const float sc = drop_scale(P.drop.thr);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] *= drop_factor(w, e, P.drop.thr, sc);
+                }
 #pragma unroll
                 for (int e = 0; e < 4; ++e) dib[e] += v[e];
             }
@@ -583,6 +589,12 @@ __global__ __launch_bounds__(256) void ib_bwd_kernel(const SeaIbBwdParams P) {
                 for (int f = 0; f < P.n_fields; ++f) {
                     float v[4];
                     load4(P.dX[f] + (int64_t)row * P.ldx + e0, v);
+                    if (P.drop.thr > 0) {
+                        const uint32_t w = drop_word(P.drop.seed, P.drop.stream + f, (uint32_t)row, (uint32_t)(e0 >> 2));
+                        const float sc = drop_scale(P.drop.thr);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] *= drop_factor(w, e, P.drop.thr, sc);
+                    }
 #pragma unroll
                     for (int e = 0; e < 4; ++e) dib[e] += v[e];
                 }
@@ -661,6 +673,12 @@ __global__ __launch_bounds__(256) void ib_bwd_fast_kernel(const SeaIbBwdParams P
                 for (int f = 0; f < P.n_fields; ++f) {
                     float v[4];
                     load4(P.dX[f] + (int64_t)row * P.ldx + e0, v);
+                    if (P.drop.thr > 0) {
+                        const uint32_t w = drop_word(P.drop.seed, P.drop.stream + f, (uint32_t)row, (uint32_t)(e0 >> 2));
+                        const float sc = drop_scale(P.drop.thr);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] *= drop_factor(w, e, P.drop.thr, sc);
+                    }
 #pragma unroll
                     for (int e = 0; e < 4; ++e) dib[e] += v[e];
                 }

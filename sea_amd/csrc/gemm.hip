@@ -71,6 +71,17 @@ __global__ __launch_bounds__(256) void gemm_grouped_kernel(const GemmLaunch L) {
             float v[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) v[q] = acc[i][j][q] + bv[q];
+            float df[4] = {1.f, 1.f, 1.f, 1.f};
+            if (G.drop.thr > 0) {
+                const uint32_t w = drop_word(G.drop.seed, G.drop.stream, (uint32_t)m, (uint32_t)(n >> 2));
+                const float sc = drop_scale(G.drop.thr);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) df[q] = drop_factor(w, q, G.drop.thr, sc);
+                if (G.drop.mode == 1) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) v[q] *= df[q];
+                }
+            }
             if (act == 1) {
                 if (Z != nullptr) store4(Z + (int64_t)m * G.ldz + n, v[0], v[1], v[2], v[3]);
 #pragma unroll
@@ -88,6 +99,10 @@ __global__ __launch_bounds__(256) void gemm_grouped_kernel(const GemmLaunch L) {
                 for (int q = 0; q < 4; ++q) v[q] += rv[q];
             }
             if (C32 != nullptr) store4(C32 + (int64_t)m * G.ldc32 + n, v[0], v[1], v[2], v[3]);
+            if (G.drop.thr > 0 && G.drop.mode == 2) {  // backward: only the copy that feeds the dropped branch is masked
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] *= df[q];
+            }
             if (staged) {
                 store4(reinterpret_cast<T*>(smem + (wm * C::WTM + i * 16 + r) * SP) + (wn * C::WTN + j * 16 + g * 4), v[0], v[1], v[2], v[3]);
             } else if (Cact != nullptr) {
@@ -205,6 +220,7 @@ extern "C" int sea_gemm_grouped(const SeaGemmGroup* groups, int n_groups, int dt
         SEA_REQUIRE(sea_aligned16(G.A) && sea_aligned16(G.W), "sea_gemm_grouped[%d]: A/W not 16-byte aligned", i);
         SEA_REQUIRE(G.lda >= G.K && G.ldw >= G.K, "sea_gemm_grouped[%d]: leading dimension smaller than K", i);
         SEA_REQUIRE(G.C32 || G.Cact, "sea_gemm_grouped[%d]: no output", i);
+        SEA_REQUIRE(G.drop.thr >= 0 && G.drop.thr <= 255 && (G.drop.thr == 0 || G.drop.mode == 1 || G.drop.mode == 2), "sea_gemm_grouped[%d]: bad dropout", i);
         SEA_REQUIRE(G.N % 4 == 0, "sea_gemm_grouped[%d]: N=%d must be a multiple of 4", i, G.N);
         SEA_REQUIRE(G.act >= 0 && G.act <= 2 && (G.act != 2 || G.Z) && (!G.Z || (G.ldz >= G.N && G.ldz % 4 == 0)), "sea_gemm_grouped[%d]: bad act/Z", i);
         SEA_REQUIRE(sea_aligned16(G.bias) && sea_aligned16(G.R) && sea_aligned16(G.C32) && sea_aligned16(G.Cact) && sea_aligned16(G.Z),

@@ -250,9 +250,15 @@ __global__ __launch_bounds__(256) void ib_add_kernel(const SeaIbParams P) {
         }
         for (int f = 0; f < P.n_fields; ++f) {
             float* x = P.X[f] + (int64_t)row * P.ldx + e0;
-            float v[4];
+            float v[4], df[4] = {1.f, 1.f, 1.f, 1.f};
             load4(x, v);
-            store4(x, v[0] + o[0], v[1] + o[1], v[2] + o[2], v[3] + o[3]);
+            if (P.drop.thr > 0) {  // the reference evaluates the MLP (and its dropout) once per field: independent masks
+                const uint32_t w = drop_word(P.drop.seed, P.drop.stream + f, (uint32_t)row, (uint32_t)(e0 >> 2));
+                const float sc = drop_scale(P.drop.thr);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) df[e] = drop_factor(w, e, P.drop.thr, sc);
+            }
+            store4(x, v[0] + o[0] * df[0], v[1] + o[1] * df[1], v[2] + o[2] * df[2], v[3] + o[3] * df[3]);
         }
     }
 }
@@ -267,6 +273,25 @@ extern "C" int sea_ib_add(const SeaIbParams* params, void* stream) {
     for (int f = 0; f < P.n_fields; ++f) SEA_REQUIRE(P.X[f] && sea_aligned16(P.X[f]), "sea_ib_add: X[%d] null or misaligned", f);
     ib_add_kernel<<<dim3((P.M + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream)>>>(P);
     SEA_CHECK_LAUNCH("sea_ib_add");
+    return SEA_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ dropout mask (tests)
+__global__ __launch_bounds__(256) void dropout_mask_kernel(float* out, int64_t rows, int64_t cols, uint32_t seed, uint32_t stream, int thr) {
+    const int64_t total = rows * cols;
+    const float sc = thr > 0 ? drop_scale(thr) : 1.f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / cols, c = i - r * cols;
+        out[i] = thr > 0 ? drop_factor(drop_word(seed, stream, (uint32_t)r, (uint32_t)(c >> 2)), (int)(c & 3), thr, sc) : 1.f;
+    }
+}
+
+extern "C" int sea_dropout_mask(float* out, int64_t rows, int64_t cols, uint32_t seed, uint32_t stream, int32_t thr, void* stream_handle) {
+    SEA_REQUIRE(out && rows >= 1 && cols >= 1 && thr >= 0 && thr <= 255, "sea_dropout_mask: bad arguments");
+    int64_t blocks = (rows * cols + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    dropout_mask_kernel<<<dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream_handle)>>>(out, rows, cols, seed, stream, thr);
+    SEA_CHECK_LAUNCH("sea_dropout_mask");
     return SEA_OK;
 }
 

@@ -87,6 +87,22 @@ __device__ __forceinline__ float gelu_erf_grad(float x) {
 }
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
 
+// ------------------------------------------------------------------------------------------------ counter-based dropout
+__device__ __forceinline__ uint32_t fmix32(uint32_t x) {
+    x ^= x >> 16; x *= 0x85ebca6bu; x ^= x >> 13; x *= 0xc2b2ae35u; x ^= x >> 16;
+    return x;
+}
+// 4 random bytes for elements (row, 4*cb .. 4*cb+3) of a stream (include/sea_hip.h, SeaDropout)
+__device__ __forceinline__ uint32_t drop_word(uint32_t seed, uint32_t stream, uint32_t row, uint32_t cb) {
+    uint32_t x = fmix32((seed ^ (stream * 0x9E3779B1u)) + row * 0x85EBCA77u);
+    return fmix32(x ^ (cb * 0xC2B2AE3Du + 0x27D4EB2Fu));
+}
+__device__ __forceinline__ float drop_scale(int thr) { return 256.0f / (float)(256 - thr); }
+// keep-and-scale factor of element j (0..3) of a word
+__device__ __forceinline__ float drop_factor(uint32_t word, int j, int thr, float scale) {
+    return (int)((word >> (8 * j)) & 0xffu) >= thr ? scale : 0.f;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);

@@ -197,6 +197,7 @@ class Plan:
         self._out_patches: List[Tuple[object, str, int]] = []
         self._c_patches: List[Tuple[object, object]] = []      # (container, key) receiving the condition pointer
         self._pos_structs: List[object] = []                   # SeaQkvCommon / SeaAttnParams to update per step
+        self._drop_structs: List[object] = []                  # structs whose .drop.seed is re-keyed every training step
         self._bound = (None, None, None)
         self._build()
 
@@ -219,6 +220,8 @@ class Plan:
             for g, d in zip(arr, chunk):
                 if d.get("R_is_x") is not None:
                     self._x_patches.append((g, "R", d["R_is_x"]))
+                if d.get("drop") is not None:
+                    self._drop_structs.append(g)
 
     def _norm(self, groups: List[dict], d: int, name: str, x_is_act=False, gelu=False) -> None:
         L = N.lib()
@@ -254,12 +257,15 @@ class Plan:
         self._pos_structs.append(common)
         self._cur.append(_Rec(L.sea_qkv_rope_grouped, [arr, len(groups), C.byref(common), self.code], name, (arr, common)))
 
-    def _attn(self, problems: List[dict], hd: int, ldo: int, name: str) -> None:
+    def _attn(self, problems: List[dict], hd: int, ldo: int, name: str, drop=None) -> None:
         L = N.lib()
         for s in range(0, len(problems), N.MAX_ATTN_PROBLEMS):
             chunk = problems[s:s + N.MAX_ATTN_PROBLEMS]
             P = N.SeaAttnParams()
             P.n_problems = len(chunk)
+            if drop is not None:  # (thr, first stream of this launch)
+                P.drop.thr, P.drop.stream = drop[0], drop[1] + s
+                self._drop_structs.append(P)
             for i, d in enumerate(chunk):
                 P.p[i].Q, P.p[i].K, P.p[i].Vt, P.p[i].O = d["Q"].data_ptr(), d["K"].data_ptr(), d["Vt"].data_ptr(), d["O"].data_ptr()
                 P.p[i].LSE = N.ptr(d.get("LSE"))
@@ -407,9 +413,12 @@ class Plan:
         # -- final per-field norm, written straight into out[B,T,F,E]
         self._norm([dict(X=xr[i], Y32=xr[i], ldy32=FE, Y_is_out=i * E * 4, **norm_params(f"ln.{i}.", E)) for i in range(F)], E, "final.norm")
 
-    def _ib(self, pre: str, xr: List[torch.Tensor]) -> None:
+    def _ib(self, pre: str, xr: List[torch.Tensor], drop=None) -> None:
         P = self.eng.params
         ib = N.SeaIbParams()
+        if drop is not None:
+            ib.drop.thr, ib.drop.stream = drop
+            self._drop_structs.append(ib)
         for i, x in enumerate(xr):
             ib.X[i] = x.data_ptr()
         ib.n_fields, ib.ldx = len(xr), xr[0].stride(0)
@@ -445,6 +454,10 @@ class Plan:
             else:
                 setattr(tgt, field, cp)
         self._bound = key
+
+    def set_dropout_seed(self, seed: int) -> None:
+        for st in self._drop_structs:
+            st.drop.seed = seed & 0xFFFFFFFF
 
     def set_position(self, pos0: int) -> None:
         """Step mode: the T rows of this call sit at absolute positions pos0 .. pos0 + T - 1 of the K/V caches."""
@@ -484,7 +497,9 @@ class Plan:
 
 
 def _fill_gemm(g, A, W, bias=None, R=None, C32=None, Cact=None, n_seg=1, a_seg_stride=0, act=0, bias_scale=1.0, ldr=None,
-               R_is_x=None, Z=None, ldc32=None) -> None:
+               R_is_x=None, Z=None, ldc32=None, drop=None) -> None:
+    if drop is not None:  # (thr, stream, mode); the seed is patched every step
+        g.drop.thr, g.drop.stream, g.drop.mode = drop
     g.A, g.W = A.data_ptr(), W.data_ptr()
     g.Z, g.ldz = N.ptr(Z), (Z.stride(0) if Z is not None else 0)
     g.bias, g.R, g.C32, g.Cact = N.ptr(bias), N.ptr(R), N.ptr(C32), N.ptr(Cact)
@@ -530,6 +545,7 @@ class TemporalEngine:
         self._train_plans: Dict[Tuple, object] = {}
         self.grads: Optional[torch.Tensor] = None      # flat fp32 gradient buffer, same layout as params.flat32
         self.grads_dirty = False                       # True once a backward has accumulated into it since the last zero
+        self._drop_step = 0                            # dropout streams are re-keyed every training forward
         self._loss_ws: Optional[Tuple[torch.Tensor, torch.Tensor, torch.Tensor]] = None
 
     def plan(self, B: int, T: int, mode: str = "full") -> Plan:
@@ -571,12 +587,16 @@ class TemporalEngine:
     def train_plan(self, B: int, T: int):
         from .train_engine import TrainPlan
 
-        key = (B, T)
+        m = self.model
+        thr = int(round(256 * m.dropout_p)) if (m.training and m.dropout_p > 0) else 0
+        if thr > 255:
+            raise ValueError("dropout probability too close to 1")
+        key = (B, T, thr)
         p = self._train_plans.get(key)
         if p is None:
-            if T > self.model.max_len:
-                raise ValueError(f"sequence length {T} exceeds max_len {self.model.max_len}")
-            p = TrainPlan(self, B, T)
+            if T > m.max_len:
+                raise ValueError(f"sequence length {T} exceeds max_len {m.max_len}")
+            p = TrainPlan(self, B, T, drop_thr=thr)
             self._train_plans[key] = p
         return p
 
@@ -590,6 +610,9 @@ class TemporalEngine:
         p = self.train_plan(B, T)
         p.bind(x, ib, out)
         p.held = (x, ib)  # the backward list reads the inputs again: keep them alive until the next forward
+        if p.drop_thr > 0:
+            self._drop_step += 1
+            p.set_dropout_seed((torch.initial_seed() * 0x9E3779B1 + self._drop_step * 0x85EBCA77) & 0xFFFFFFFF)
         p.run()
         return out, p
 

@@ -284,11 +284,11 @@ class TemporalModel(nn.Module):
         assert x.shape[2] == self.num_variables, f"Expected {self.num_variables} variables, but got {x.shape[2]}"
         if not x.is_cuda:
             raise RuntimeError("sea_amd.TemporalModel.forward: input is on the CPU; this path has no CPU fallback")
-        if self.training and self.dropout_p > 0.0:
-            raise NotImplementedError("sea_amd: dropout > 0 in training mode is not implemented in the HIP kernels yet")
         eng = self.engine(x.device)
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
             from ..autograd import temporal_forward_with_grad
 
             return temporal_forward_with_grad(self, eng, x, x_additional_info)
+        if self.training and self.dropout_p > 0.0:
+            return eng.forward_train(x.float(), x_additional_info.float())[0]  # dropout is active in train(): counter-based masks
         return eng.forward(x.float(), x_additional_info.float())

@@ -17,12 +17,20 @@ from .engine import Plan, _Rec, _fill_gemm
 
 
 class TrainPlan(Plan):
-    def __init__(self, eng, B: int, T: int):
+    def __init__(self, eng, B: int, T: int, drop_thr: int = 0):
+        self.drop_thr = drop_thr
+        self._next_stream = 0
         self.bwd: List[_Rec] = []
         self._dout_patches: List[Tuple[object, str, int]] = []
         eng.params.enable_transposed_shadow()
         eng.ensure_grads()
         super().__init__(eng, B, T, "full")
+
+    def _streams(self, n: int) -> int:
+        """Reserve n consecutive dropout stream ids; returns the first."""
+        s = self._next_stream
+        self._next_stream += n
+        return s
 
     # ------------------------------------------------------------------ record builders (backward)
     def _wgrad(self, groups: List[dict], name: str) -> None:
@@ -63,10 +71,13 @@ class TrainPlan(Plan):
             self._cur.append(_Rec(L.sea_rownorm_bwd, [arr, len(chunk), self.M, d, int(dy_is_act), int(x_is_act), int(gelu), int(accumulate),
                                                       self.code], name, arr))
 
-    def _attn_bwd(self, problems: List[dict], hd: int, rope: torch.Tensor, name: str) -> None:
+    def _attn_bwd(self, problems: List[dict], hd: int, rope: torch.Tensor, name: str, drop=None) -> None:
         L = N.lib()
         P = N.SeaAttnBwdParams()
         P.n_problems = len(problems)
+        if drop is not None:
+            P.drop.thr, P.drop.stream = drop
+            self._drop_structs.append(P)
         for i, d in enumerate(problems):
             q = P.p[i]
             q.Q, q.K, q.V, q.O, q.dO = (d[k].data_ptr() for k in ("Q", "K", "V", "O", "dO"))
@@ -93,9 +104,12 @@ class TrainPlan(Plan):
             self._c_patches.append((rec.args, 2))
             self._cur.append(rec)
 
-    def _ib_bwd(self, pre: str, dxs: List[torch.Tensor]) -> None:
+    def _ib_bwd(self, pre: str, dxs: List[torch.Tensor], drop=None) -> None:
         P, G = self.eng.params, self.eng.grad_view
         ib = N.SeaIbBwdParams()
+        if drop is not None:
+            ib.drop.thr, ib.drop.stream = drop
+            self._drop_structs.append(ib)
         for i, x in enumerate(dxs):
             ib.dX[i] = x.data_ptr()
         ib.n_fields, ib.ldx = len(dxs), dxs[0].stride(0)
@@ -165,6 +179,7 @@ class TrainPlan(Plan):
         def stats():
             return buf(M, dtype=f32), buf(M, dtype=f32)
 
+        thr = self.drop_thr
         Sv: List[dict] = []  # saved tensors per layer
         x_prev: Optional[List[torch.Tensor]] = None
         others_of = [[j for j in range(F) if j != i] for i in range(F)]
@@ -186,7 +201,8 @@ class TrainPlan(Plan):
                     else:
                         rec = _Rec(L.sea_convert_f32_to_act, [x_prev[i].data_ptr(), E, xin[i].data_ptr(), E, M, E, N.SEA_F32], "x.copy")
                     self._cur.append(rec)
-                self._ib(pre, xin)
+                sv["ib_drop"] = (thr, self._streams(F)) if thr else None
+                self._ib(pre, xin, drop=sv["ib_drop"])
                 sv["x_in"] = xin
                 first = False
             x_in = sv["x_in"]
@@ -207,7 +223,9 @@ class TrainPlan(Plan):
             sv["LSE"] = [buf(B, H, T, dtype=f32) for _ in range(F)]
             self._qkv([dict(A=sv["n0"][i], W=P.act(f"{pre}attn.self.{i}.q.weight", 3 * E), bias=P.f32_vec(f"{pre}attn.self.{i}.q.bias", 3 * E),
                             col0=0, Q=sv["Q"][i], K=sv["K"][i], Vt=sv["Vt"][i], V=sv["V"][i]) for i in range(F)], rope_s, hd_s, "self.qkv_rope")
-            self._attn([dict(Q=sv["Q"][i], K=sv["K"][i], Vt=sv["Vt"][i], O=sv["att"][i], LSE=sv["LSE"][i]) for i in range(F)], hd_s, E, "self.attention")
+            sv["self_drop"] = (thr, self._streams(F)) if thr else None
+            self._attn([dict(Q=sv["Q"][i], K=sv["K"][i], Vt=sv["Vt"][i], O=sv["att"][i], LSE=sv["LSE"][i]) for i in range(F)], hd_s, E, "self.attention",
+                       drop=sv["self_drop"])
             sv["xa1"] = [buf(M, E) for _ in range(F)]
             groups = []
             for i in range(F):
@@ -244,7 +262,8 @@ class TrainPlan(Plan):
                         probs.append(dict(Q=pr["Q"], K=pr["K"], Vt=pr["Vt"], O=pr["O"], LSE=pr["LSE"]))
                         proj_groups.append(dict(A=pr["O"], W=P.act(ca + "projection.weight"), Cact=sv["g"][i][s], Z=pr["a"], act=1))
                     self._qkv(qkv_groups, rope_c, hd_c, f"cross{i}.qkv_rope")
-                    self._attn(probs, hd_c, D, f"cross{i}.attention")
+                    sv[("cross_drop", i)] = (thr, self._streams(F - 1)) if thr else None
+                    self._attn(probs, hd_c, D, f"cross{i}.attention", drop=sv[("cross_drop", i)])
                     self._gemm(proj_groups, f"cross{i}.proj_gelu")
                     self._gemm([dict(A=sv["g"][i][0], W=P.act(f"{pre}cross_up.{i}.weight"), bias=P.f32_vec(f"{pre}cross_up.{i}.bias"),
                                      bias_scale=float(F - 1), n_seg=F - 1, a_seg_stride=M * D, R=sv["xr"][i], C32=sv["xr"][i],
@@ -255,7 +274,8 @@ class TrainPlan(Plan):
                         self._norm([dict(X=sv["dn_new"][i], Yact=sv["nd_new"][i], mean=sv["stc_new"][i][0], rstd=sv["stc_new"][i][1],
                                          **npar(f"{pre}ln_cross.{i}."))], D, f"cross{i}.norm_new")
             if model.add_info_after_cross:
-                self._ib(pre, sv["xr"])
+                sv["ib_drop"] = (thr, self._streams(F)) if thr else None
+                self._ib(pre, sv["xr"], drop=sv["ib_drop"])
             # ---- MLP + proj
             sv["st2"] = [stats() for _ in range(F)]
             sv["n2"] = [buf(M, E) for _ in range(F)]
@@ -269,8 +289,9 @@ class TrainPlan(Plan):
                         for i in range(F)], "mlp.fc1")
             self._norm([dict(X=sv["h"][i], gamma=P.f32_vec(f"{pre}mlp.{i}.layers.1.weight"), beta=P.f32_vec(f"{pre}mlp.{i}.layers.1.bias"),
                              Yact=sv["hg"][i], mean=sv["sth"][i][0], rstd=sv["sth"][i][1]) for i in range(F)], S, "mlp.ln_gelu", x_is_act=True, gelu=True)
+            sv["mlp_drop"] = self._streams(F) if thr else None
             self._gemm([dict(A=sv["hg"][i], W=P.act(f"{pre}mlp.{i}.layers.3.weight"), bias=P.f32_vec(f"{pre}mlp.{i}.layers.3.bias"), R=sv["xr"][i],
-                             Cact=sv["xa4"][i]) for i in range(F)], "mlp.fc2")
+                             Cact=sv["xa4"][i], drop=((thr, sv["mlp_drop"] + i, 1) if thr else None)) for i in range(F)], "mlp.fc2")
             self._gemm([dict(A=sv["xa4"][i], W=P.act(f"{pre}proj.{i}.weight"), bias=P.f32_vec(f"{pre}proj.{i}.bias"), C32=sv["x5"][i])
                         for i in range(F)], "proj")
             x_prev = sv["x5"]
@@ -308,7 +329,9 @@ class TrainPlan(Plan):
             first = l == 0 and model.add_info_after_cross
             # ---- proj:  x5 = Wp xa4 + bp                       (ga = d x5 in act dtype)
             self._wgrad([dict(dY=ga[i], X=sv["xa4"][i], dW=G2(f"{pre}proj.{i}.weight"), db=Gv(f"{pre}proj.{i}.bias")) for i in range(F)], "bwd.proj.wgrad")
-            self._gemm([dict(A=ga[i], W=P.actT(f"{pre}proj.{i}.weight"), C32=dx[i], Cact=gb[i]) for i in range(F)], "bwd.proj.dgrad")
+            # (MLP-output dropout: the residual path C32 stays whole, the copy feeding fc2's backward is masked)
+            self._gemm([dict(A=ga[i], W=P.actT(f"{pre}proj.{i}.weight"), C32=dx[i], Cact=gb[i],
+                             drop=((thr, sv["mlp_drop"] + i, 2) if thr else None)) for i in range(F)], "bwd.proj.dgrad")
             # ---- fc2:   x4 = x3 + hg W2^T + b2                 (gb = d x4)
             self._wgrad([dict(dY=gb[i], X=sv["hg"][i], dW=G2(f"{pre}mlp.{i}.layers.3.weight"), db=Gv(f"{pre}mlp.{i}.layers.3.bias")) for i in range(F)],
                         "bwd.fc2.wgrad")
@@ -325,7 +348,7 @@ class TrainPlan(Plan):
             self._norm_bwd([dict(dY=dE_[i], X=sv["xr"][i], mean=sv["st2"][i][0], rstd=sv["st2"][i][1], dX32=dx[i], dXact=ga[i],
                                  **bpar(f"{pre}ln.exp.{i}.2.", E)) for i in range(F)], E, "bwd.mlp.adaln2", True, False, False, True)
             if model.add_info_after_cross:
-                self._ib_bwd(pre, dx)
+                self._ib_bwd(pre, dx, drop=sv["ib_drop"])
             # ---- state exchange (reverse Gauss-Seidel order); ga[i] = act copy of d x2_i when field i is reached
             if F > 1:
                 dnd_old = [buf(M, D, dtype=f32) for _ in range(F)]
@@ -360,7 +383,7 @@ class TrainPlan(Plan):
                     # d. attention
                     self._attn_bwd([dict(Q=sv["pair"][(i, j)]["Q"], K=sv["pair"][(i, j)]["K"], V=sv["pair"][(i, j)]["V"], O=sv["pair"][(i, j)]["O"],
                                          dO=datt[s], LSE=sv["pair"][(i, j)]["LSE"], delta=delta_c[s], dQ=dqc[s], dK=dkvc[s][:, :D], dV=dkvc[s][:, D:])
-                                    for s, j in enumerate(others)], hd_c, rope_c, f"bwd.cross{i}.attention")
+                                    for s, j in enumerate(others)], hd_c, rope_c, f"bwd.cross{i}.attention", drop=sv[("cross_drop", i)])
                     # e. q / k,v projections
                     wg = []
                     for s, j in enumerate(others):
@@ -396,7 +419,8 @@ class TrainPlan(Plan):
             self._wgrad([dict(dY=ga[i], X=sv["att"][i], dW=G2(f"{pre}attn.self.{i}.projection.weight")) for i in range(F)], "bwd.self.out_proj.wgrad")
             self._gemm([dict(A=ga[i], W=P.actT(f"{pre}attn.self.{i}.projection.weight"), Cact=dE_[i]) for i in range(F)], "bwd.self.out_proj.dgrad")
             self._attn_bwd([dict(Q=sv["Q"][i], K=sv["K"][i], V=sv["V"][i], O=sv["att"][i], dO=dE_[i], LSE=sv["LSE"][i], delta=delta_s[i],
-                                 dQ=dqkv[i][:, :E], dK=dqkv[i][:, E:2 * E], dV=dqkv[i][:, 2 * E:]) for i in range(F)], hd_s, rope_s, "bwd.self.attention")
+                                 dQ=dqkv[i][:, :E], dK=dqkv[i][:, E:2 * E], dV=dqkv[i][:, 2 * E:]) for i in range(F)], hd_s, rope_s, "bwd.self.attention",
+                           drop=sv["self_drop"])
             self._wgrad([dict(dY=dqkv[i], X=sv["n0"][i], dW=G2(f"{pre}attn.self.{i}.q.weight", 3 * E), db=Gv(f"{pre}attn.self.{i}.q.bias", 3 * E))
                          for i in range(F)], "bwd.self.qkv.wgrad")
             self._gemm([dict(A=dqkv[i], W=P.actT(f"{pre}attn.self.{i}.q.weight", 3 * E), Cact=dE_[i]) for i in range(F)], "bwd.self.qkv.dgrad")
@@ -407,7 +431,7 @@ class TrainPlan(Plan):
                 groups.append(g)
             self._norm_bwd(groups, E, "bwd.self.adaln0", True, False, False, True)
             if not model.add_info_after_cross:
-                self._ib_bwd(pre, dx)
+                self._ib_bwd(pre, dx, drop=sv["ib_drop"])
         # ---- AdaLN condition MLPs: every USE contributes dmod; parameters are shared through the atomically accumulated gradients
         if adaln:
             dh = [buf(M, dm.shape[1]) for _, dm in dmods]
