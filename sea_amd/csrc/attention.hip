@@ -46,10 +46,11 @@ __global__ __launch_bounds__(256 * SPLIT) void attention_fwd_kernel(const SeaAtt
     const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;  // tid, wave: inside the group
     const int r = lane & 15, g = lane >> 4;
     const int n_qt = gridDim.x;
-    const int qt = n_qt - 1 - (int)blockIdx.x;  // heaviest (latest) query tiles first
-    const int bh = blockIdx.y;
+    int tile_, bh, zp;
+    decode_attn_block(tile_, bh, zp);
+    const int qt = n_qt - 1 - tile_;  // heaviest (latest) query tiles first
     const int b = bh / P.H, h = bh - b * P.H;
-    const SeaAttnProblem& pr = P.p[blockIdx.z];
+    const SeaAttnProblem& pr = P.p[zp];
     const T* Qg = static_cast<const T*>(pr.Q) + (int64_t)bh * P.Tq * HD;
     const T* Kg = static_cast<const T*>(pr.K) + (int64_t)bh * P.cap * HD;
     const T* Vg = static_cast<const T*>(pr.Vt) + (int64_t)bh * HD * P.cap;
@@ -58,7 +59,7 @@ __global__ __launch_bounds__(256 * SPLIT) void attention_fwd_kernel(const SeaAtt
     const int q_row0 = qt * 64 + wave * 16;
     const int q_idx = q_row0 + r;
     const int q_ld = q_idx < Tq ? q_idx : Tq - 1;
-    const uint32_t drop_stream = (P.drop.stream + blockIdx.z) * (uint32_t)(P.B * P.H) + (uint32_t)bh;
+    const uint32_t drop_stream = (P.drop.stream + zp) * (uint32_t)(P.B * P.H) + (uint32_t)bh;
 
     // Q fragments (B operand of S^T): lane holds Q[q][c*CK + g*EPC .. +EPC)
     uint4 qf[C::NCH];

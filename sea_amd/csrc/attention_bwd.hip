@@ -100,15 +100,17 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const SeaAttnBwdParams
     using C = BwdCfg<T, HD>;
     __shared__ __attribute__((aligned(16))) char smem[4 * C::TILE];  // 2 buffers x (K tile, V tile)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, g = lane >> 4;
-    const int qt = gridDim.x - 1 - (int)blockIdx.x;
-    const int bh = blockIdx.y, b = bh / P.H, h = bh - b * P.H;
-    const SeaAttnBwdProblem& pr = P.p[blockIdx.z];
+    int tile_, bh, zp;
+    decode_attn_block(tile_, bh, zp);
+    const int qt = gridDim.x - 1 - tile_;  // heaviest query tiles first
+    const int b = bh / P.H, h = bh - b * P.H;
+    const SeaAttnBwdProblem& pr = P.p[zp];
     const int Tq = P.Tq, Tk = P.Tk;
     const T* Qg = static_cast<const T*>(pr.Q) + (int64_t)bh * Tq * HD;
     const T* Kg = static_cast<const T*>(pr.K) + (int64_t)bh * P.cap * HD;
     const T* Vg = static_cast<const T*>(pr.V) + (int64_t)bh * P.cap * HD;
     const int q_row0 = qt * 64 + wave * 16, q_idx = q_row0 + r, q_ld = q_idx < Tq ? q_idx : Tq - 1;
-    const uint32_t drop_stream = (P.drop.stream + blockIdx.z) * (uint32_t)(P.B * P.H) + (uint32_t)bh;
+    const uint32_t drop_stream = (P.drop.stream + zp) * (uint32_t)(P.B * P.H) + (uint32_t)bh;
     const float drop_sc = P.drop.thr > 0 ? drop_scale(P.drop.thr) : 1.f;
     const T* Og = static_cast<const T*>(pr.O) + ((int64_t)b * Tq + q_ld) * P.ldo + h * HD;
     const T* dOg = static_cast<const T*>(pr.dO) + ((int64_t)b * Tq + q_ld) * P.lddo + h * HD;
@@ -239,9 +241,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const SeaAttnBwdParam
     using C = BwdCfg<T, HD>;
     __shared__ __attribute__((aligned(16))) char smem[4 * C::TILE + 2 * 2 * 64 * 4];  // 2 x (Q tile, dO tile) + 2 x (lse, delta)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, g = lane >> 4;
-    const int kb = blockIdx.x;  // key tile
-    const int bh = blockIdx.y, b = bh / P.H, h = bh - b * P.H;
-    const SeaAttnBwdProblem& pr = P.p[blockIdx.z];
+    int kb, bh, zp;  // key tile: the first key tiles are seen by the most queries -> ascending order is heaviest-first
+    decode_attn_block(kb, bh, zp);
+    const int b = bh / P.H, h = bh - b * P.H;
+    const SeaAttnBwdProblem& pr = P.p[zp];
     const int Tq = P.Tq, Tk = P.Tk;
     const T* Qg = static_cast<const T*>(pr.Q) + (int64_t)bh * Tq * HD;
     const T* Kg = static_cast<const T*>(pr.K) + (int64_t)bh * P.cap * HD;
@@ -250,7 +253,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const SeaAttnBwdParam
     const float* lse_g = pr.LSE + (int64_t)bh * Tq;
     const float* del_g = pr.delta + (int64_t)bh * Tq;
     const int k_row0 = kb * 64 + wave * 16, k_idx = k_row0 + r, k_ld = k_idx < Tk ? k_idx : Tk - 1;
-    const uint32_t drop_stream = (P.drop.stream + blockIdx.z) * (uint32_t)(P.B * P.H) + (uint32_t)bh;
+    const uint32_t drop_stream = (P.drop.stream + zp) * (uint32_t)(P.B * P.H) + (uint32_t)bh;
     const float drop_sc = P.drop.thr > 0 ? drop_scale(P.drop.thr) : 1.f;
 
     uint4 kf[C::NCH], vf[C::NCH];

@@ -1,5 +1,6 @@
 // Grouped NT GEMM kernels with fused epilogues (gfx950): sea_gemm_grouped, sea_qkv_rope_grouped.
 #include "gemm_core.hpp"
+#include <stdlib.h>
 
 struct GemmLaunch {
     SeaGemmGroup g[SEA_MAX_GROUPS];
@@ -203,6 +204,8 @@ static int set_lds(K kernel, int bytes) {
 static int pick_tile(long tiles128, long tiles64) {
     // 128x128 tiles once they fill most of the 256 CUs, else 64x64 (more, smaller workgroups)
     (void)tiles64;
+    static const int forced = []() { const char* e = getenv("SEA_GEMM_TILE"); return e ? atoi(e) : 0; }();  // tuning aid
+    if (forced == 64 || forced == 128) return forced;
     return tiles128 >= 192 ? 128 : 64;
 }
 

@@ -103,6 +103,19 @@ __device__ __forceinline__ float drop_factor(uint32_t word, int j, int thr, floa
     return (int)((word >> (8 * j)) & 0xffu) >= thr ? scale : 0.f;
 }
 
+// Attention grids are (tile, batch*head, problem).  Workgroups are dealt to the CUs round-robin in linear block order; with the
+// tile index fastest, CU c receives blocks c, c + 256, ... which all have the SAME tile index (256 % 32 == 0), i.e. the same causal
+// workload: the CUs holding the last query tiles would work 32x longer than those holding the first.  Re-decode the linear id
+// with (batch*head, problem) fastest: tiles go out heaviest-first across the whole chip and every CU gets a mix of weights.
+__device__ __forceinline__ void decode_attn_block(int& tile, int& bh, int& z) {
+    const int L = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    const int nbz = gridDim.y * gridDim.z;
+    tile = L / nbz;
+    const int inner = L - tile * nbz;
+    z = inner / gridDim.y;
+    bh = inner - z * gridDim.y;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
