@@ -15,6 +15,15 @@ struct QkvLaunch {
     SeaQkvCommon c;
 };
 
+// Workgroups are dealt round-robin over the 8 XCDs (blocks b and b + 8 share an L2).  Tiles are numbered row-panel-major, so
+// consecutive tiles re-read the same A panel (and every tile of a group the same W): give each XCD a CONTIGUOUS range of tile
+// numbers so those re-reads hit its own L2 instead of crossing the fabric once per XCD (bijective form of the T1 remap,
+// cdna_hip_programming.md; only placement, never correctness).
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
 template <typename L>
 __device__ __forceinline__ int find_group(const L& launch, int bid) {
     int gi = 0;
@@ -27,9 +36,10 @@ template <typename T, int BM, int BN, bool DMA>
 __global__ __launch_bounds__(256) void gemm_grouped_kernel(const GemmLaunch L) {
     using C = GemmCfg<T, BM, BN>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int gi = find_group(L, blockIdx.x);
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int gi = find_group(L, bid);
     const SeaGemmGroup& G = L.g[gi];
-    const int t = blockIdx.x - L.tile_start[gi];
+    const int t = bid - L.tile_start[gi];
     const int tiles_n = (G.N + BN - 1) / BN;
     const int tm = t / tiles_n, tn = t - tm * tiles_n;
 
@@ -127,9 +137,10 @@ template <typename T, int BM, int BN, bool DMA>
 __global__ __launch_bounds__(256) void qkv_rope_kernel(const QkvLaunch L) {
     using C = GemmCfg<T, BM, BN>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int gi = find_group(L, blockIdx.x);
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int gi = find_group(L, bid);
     const SeaQkvGroup& G = L.g[gi];
-    const int t = blockIdx.x - L.tile_start[gi];
+    const int t = bid - L.tile_start[gi];
     const int tiles_n = (G.N + BN - 1) / BN;
     const int tm = t / tiles_n, tn = t - tm * tiles_n;
 
