@@ -295,8 +295,10 @@ typedef struct {
     float* dbeta;
     int32_t lddy, ldx, ldmod, lddx32, lddxact, lddmod;
 } SeaNormBwdGroup;
+/* ws (optional, f32, >= n_groups * min(ceil(M/4), 512) * 2 * d floats): when given, the column sums are written as per-workgroup
+ * partials and reduced by a second small launch instead of hundreds of workgroups atomically adding to the same addresses. */
 int sea_rownorm_bwd(const SeaNormBwdGroup* groups, int n_groups, int M, int d, int dy_is_act, int x_is_act, int gelu,
-                    int accumulate, int dtype, void* stream);
+                    int accumulate, int dtype, float* ws, int64_t ws_floats, void* stream);
 
 /* Backward of sea_attention_fwd + the rotary embedding of sea_qkv_rope_grouped (flash-style: P is recomputed from Q, K and the
  * forward's LSE).  For each problem, from dO (gradient of the attention output, [B, Tq, H*hd] row stride lddo):
@@ -336,7 +338,8 @@ typedef struct {
     float* db1;
     int32_t K2, ld;
 } SeaSiluBwdGroup;
-int sea_silu_outer_bwd(const SeaSiluBwdGroup* groups, int n_groups, const float* c, int M, int dtype, void* stream);
+int sea_silu_outer_bwd(const SeaSiluBwdGroup* groups, int n_groups, const float* c, int M, int dtype, float* ws, int64_t ws_floats,
+                       void* stream);  /* ws: as for sea_rownorm_bwd, >= n_groups * min(ceil(M/4), 256) * 2 * max K2 floats */
 
 /* Parameter gradients of the information-bottleneck MLP (sea_ib_add) from dib = sum_f dX_f; dX itself passes through. */
 typedef struct {

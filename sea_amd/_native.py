@@ -142,8 +142,8 @@ def lib() -> C.CDLL:
     L.sea_selftest_mfma.restype = C.c_int
     L.sea_wgrad_grouped.argtypes = [C.POINTER(SeaWgradGroup), C.c_int, C.c_int, _vp]
     L.sea_transpose_weights.argtypes = [_vp, _vp, C.c_int, _vp, _vp, C.c_int, C.c_int, _vp]
-    L.sea_rownorm_bwd.argtypes = [C.POINTER(SeaNormBwdGroup), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp]
-    L.sea_silu_outer_bwd.argtypes = [C.POINTER(SeaSiluBwdGroup), C.c_int, _vp, C.c_int, C.c_int, _vp]
+    L.sea_rownorm_bwd.argtypes = [C.POINTER(SeaNormBwdGroup), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _i64, _vp]
+    L.sea_silu_outer_bwd.argtypes = [C.POINTER(SeaSiluBwdGroup), C.c_int, _vp, C.c_int, C.c_int, _vp, _i64, _vp]
     L.sea_ib_bwd.argtypes = [C.POINTER(SeaIbBwdParams), _vp]
     L.sea_attention_bwd.argtypes = [C.POINTER(SeaAttnBwdParams), C.c_int, _vp]
     L.sea_dropout_mask.argtypes = [_vp, _i64, _i64, C.c_uint32, C.c_uint32, _i32, _vp]

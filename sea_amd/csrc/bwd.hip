@@ -5,6 +5,7 @@
 //   sea_silu_outer_bwd     backward of sea_silu_outer
 //   sea_ib_bwd             parameter gradients of the information-bottleneck MLP
 #include "sea_common.hpp"
+#include <stdlib.h>
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 
@@ -244,7 +245,33 @@ extern "C" int sea_transpose_weights(const float* src, void* dst, int dst_dtype,
 struct NormBwdLaunch {
     SeaNormBwdGroup g[SEA_MAX_NORM_BWD_GROUPS];
     int M, d, gelu, accumulate;
+    float* ws;  // optional [n_groups][gridDim.x][2][d] partial column sums (then reduced by colsum_finish_kernel)
 };
+
+// Second stage of the column sums: out[c] += sum_b ws[(g * nblk + b) * 2 * d + c].  Hundreds of workgroups adding to the same few
+// thousand addresses serialise at the memory-side atomic unit (MI355X_MICROARCH.md, Global float atomics: "every workgroup into one
+// row: 14x slower"); writing per-workgroup partials and summing them here keeps it to one add per address.
+struct ColsumFinish {
+    float* out_a[24];
+    float* out_b[24];
+    int width[24];
+    const float* ws;
+    int nblk, stride;  // stride = floats per (group, block) slab = 2 * max width
+};
+__global__ __launch_bounds__(256) void colsum_finish_kernel(const ColsumFinish F) {
+    const int g = blockIdx.y, w = F.width[g];
+    // gridDim.z slices of the workgroup partials: 16 adders per address instead of hundreds, and enough parallelism to stream the slab
+    const int per = (F.nblk + gridDim.z - 1) / gridDim.z;
+    const int b0 = blockIdx.z * per, b1 = b0 + per < F.nblk ? b0 + per : F.nblk;
+    for (int c = blockIdx.x * 256 + threadIdx.x; c < 2 * w; c += gridDim.x * 256) {
+        const float* src = F.ws + (int64_t)g * F.nblk * F.stride + c;
+        float acc = 0.f;
+#pragma unroll 8
+        for (int b = b0; b < b1; ++b) acc += src[(int64_t)b * F.stride];
+        float* dst = c < w ? F.out_a[g] : F.out_b[g];
+        if (dst != nullptr) atomicAdd(dst + (c < w ? c : c - w), acc);
+    }
+}
 
 // grid = (nblk, n_groups); each workgroup walks rows blockIdx.x*4 + wave, += 4*gridDim.x; one wave per row.
 // y = xhat*s + t, s = gamma (+1 + mod_w), t = beta (+ mod_b);  optional y = gelu(y).
@@ -275,6 +302,7 @@ __global__ __launch_bounds__(256) void rownorm_bwd_kernel(const NormBwdLaunch L)
         T* dmod = G.dmod ? static_cast<T*>(G.dmod) + (int64_t)row * G.lddmod : nullptr;
         const float mean = G.mean[row], rstd = G.rstd[row];
         float c1 = 0.f, c2 = 0.f;
+        float kdx[KA][4], kxh[KA][4];
         auto pass_a = [&](int i, int k) {
             float xv[4], dv[4], s[4], tt[4] = {0.f, 0.f, 0.f, 0.f};
             load4(x + i, xv);
@@ -307,6 +335,8 @@ __global__ __launch_bounds__(256) void rownorm_bwd_kernel(const NormBwdLaunch L)
                 if constexpr (KMAX > 0) {
                     accg[k][e] += dyx[e];
                     accb[k][e] += dv[e];
+                    kdx[k][e] = dxh;   // kept for the second pass: no second erf / second read of the row
+                    kxh[k][e] = xh;
                 } else {
                     atomicAdd(&cs[i + e], dyx[e]);
                     atomicAdd(&cs[d + i + e], dv[e]);
@@ -328,6 +358,31 @@ __global__ __launch_bounds__(256) void rownorm_bwd_kernel(const NormBwdLaunch L)
         c2 = wave_sum(c2) * inv_d;
         float* dx32 = G.dX32 ? G.dX32 + (int64_t)row * G.lddx32 : nullptr;
         T* dxa = G.dXact ? static_cast<T*>(G.dXact) + (int64_t)row * G.lddxact : nullptr;
+        auto emit = [&](int i, float (&o)[4]) {
+            if (dx32) {
+                if (L.accumulate) {
+                    float old[4];
+                    load4(dx32 + i, old);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] += old[e];
+                }
+                store4(dx32 + i, o[0], o[1], o[2], o[3]);
+            }
+            if (dxa) store4(dxa + i, o[0], o[1], o[2], o[3]);
+        };
+        if constexpr (KMAX > 0) {
+#pragma unroll
+            for (int k = 0; k < KMAX; ++k) {
+                const int i = lane * 4 + 256 * k;
+                if (i < d) {
+                    float o[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = rstd * (kdx[k][e] - c1 - kxh[k][e] * c2);
+                    emit(i, o);
+                }
+            }
+            continue;
+        }
         for (int i = lane * 4; i < d; i += 256) {
             float xv[4], dv[4], s[4], tt[4] = {0.f, 0.f, 0.f, 0.f};
             load4(x + i, xv);
@@ -355,16 +410,7 @@ __global__ __launch_bounds__(256) void rownorm_bwd_kernel(const NormBwdLaunch L)
                 if (L.gelu) dv[e] *= gelu_erf_grad(xh * s[e] + tt[e]);
                 o[e] = rstd * (dv[e] * s[e] - c1 - xh * c2);
             }
-            if (dx32) {
-                if (L.accumulate) {
-                    float old[4];
-                    load4(dx32 + i, old);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) o[e] += old[e];
-                }
-                store4(dx32 + i, o[0], o[1], o[2], o[3]);
-            }
-            if (dxa) store4(dxa + i, o[0], o[1], o[2], o[3]);
+            emit(i, o);
         }
     }
     if constexpr (KMAX > 0) {
@@ -381,14 +427,157 @@ __global__ __launch_bounds__(256) void rownorm_bwd_kernel(const NormBwdLaunch L)
         }
     }
     __syncthreads();
+    if (L.ws != nullptr) {
+        float* dst = L.ws + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 2 * d;
+        for (int i = threadIdx.x; i < 2 * d; i += 256) dst[i] = cs[i];
+        return;
+    }
     for (int i = threadIdx.x; i < d; i += 256) {
         if (G.dgamma) atomicAdd(G.dgamma + i, cs[i]);
         if (G.dbeta) atomicAdd(G.dbeta + i, cs[d + i]);
     }
 }
 
+// Wide rows (1024 < d <= 2048, the MLP hidden width at embed_dim 256): ONE WORKGROUP per row instead of one wave.  A wave per row
+// needs ~120 VGPRs of per-row state and leaves 4 waves per SIMD waiting on their own loads (measured: 51 % of wave time in
+// s_waitcnt, 36 % SIMD utilisation); with 4 waves per row each lane owns 2 chunks, the state fits 8 waves per SIMD and the row's
+// loads are spread over four times as many requesters.  Row statistics cross the 4 waves through LDS.
+template <typename T, bool DY_ACT, bool X_ACT>
+__global__ __launch_bounds__(256) void rownorm_bwd_wide_kernel(const NormBwdLaunch L) {
+    extern __shared__ __attribute__((aligned(16))) float cs[];  // [2][d] column sums + [8] row reduction scratch
+    const SeaNormBwdGroup& G = L.g[blockIdx.y];
+    const int d = L.d, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float* red = cs + 2 * d;
+    for (int i = tid; i < 2 * d; i += 256) cs[i] = 0.f;
+    using DYT = typename std::conditional<DY_ACT, T, float>::type;
+    using XT = typename std::conditional<X_ACT, T, float>::type;
+    const float inv_d = 1.0f / (float)d;
+    float accg[2][4], accb[2][4], s[2][4], tt[2][4];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int i = tid * 4 + 1024 * k;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) accg[k][e] = accb[k][e] = s[k][e] = tt[k][e] = 0.f;
+        if (i < d && G.mod == nullptr) {  // row-independent gain / shift: loaded once
+            load4(G.gamma + i, s[k]);
+            if (L.gelu && G.beta) load4(G.beta + i, tt[k]);
+        }
+    }
+    __syncthreads();
+    for (int row = blockIdx.x; row < L.M; row += gridDim.x) {
+        const DYT* dy = static_cast<const DYT*>(G.dY) + (int64_t)row * G.lddy;
+        const XT* x = static_cast<const XT*>(G.X) + (int64_t)row * G.ldx;
+        const T* mod = G.mod ? static_cast<const T*>(G.mod) + (int64_t)row * G.ldmod : nullptr;
+        T* dmod = G.dmod ? static_cast<T*>(G.dmod) + (int64_t)row * G.lddmod : nullptr;
+        const float mean = G.mean[row], rstd = G.rstd[row];
+        float xv[2][4], dv[2][4];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {  // all of the row's loads first
+            const int i = tid * 4 + 1024 * k;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) xv[k][e] = dv[k][e] = 0.f;
+            if (i < d) {
+                load4(x + i, xv[k]);
+                load4(dy + i, dv[k]);
+                if (mod) {
+                    float mw[4];
+                    load4(G.gamma + i, s[k]);
+                    load4(mod + i, mw);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) s[k][e] += 1.0f + mw[e];
+                    if (L.gelu) {
+                        float mb[4];
+                        load4(mod + d + i, mb);
+                        if (G.beta) load4(G.beta + i, tt[k]);
+                        else tt[k][0] = tt[k][1] = tt[k][2] = tt[k][3] = 0.f;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) tt[k][e] += mb[e];
+                    }
+                }
+            }
+        }
+        float c1 = 0.f, c2 = 0.f, kdx[2][4], kxh[2][4];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int i = tid * 4 + 1024 * k;
+            if (i < d) {
+                float dyx[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float xh = (xv[k][e] - mean) * rstd;
+                    if (L.gelu) dv[k][e] *= gelu_erf_grad(xh * s[k][e] + tt[k][e]);
+                    const float dxh = dv[k][e] * s[k][e];
+                    c1 += dxh;
+                    c2 += dxh * xh;
+                    dyx[e] = dv[k][e] * xh;
+                    accg[k][e] += dyx[e];
+                    accb[k][e] += dv[k][e];
+                    kdx[k][e] = dxh;
+                    kxh[k][e] = xh;
+                }
+                if (dmod) {
+                    store4(dmod + i, dyx[0], dyx[1], dyx[2], dyx[3]);
+                    store4(dmod + d + i, dv[k][0], dv[k][1], dv[k][2], dv[k][3]);
+                }
+            }
+        }
+        c1 = wave_sum(c1);
+        c2 = wave_sum(c2);
+        if (lane == 0) {
+            red[wave] = c1;
+            red[4 + wave] = c2;
+        }
+        __syncthreads();
+        c1 = (red[0] + red[1] + red[2] + red[3]) * inv_d;
+        c2 = (red[4] + red[5] + red[6] + red[7]) * inv_d;
+        __syncthreads();
+        float* dx32 = G.dX32 ? G.dX32 + (int64_t)row * G.lddx32 : nullptr;
+        T* dxa = G.dXact ? static_cast<T*>(G.dXact) + (int64_t)row * G.lddxact : nullptr;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int i = tid * 4 + 1024 * k;
+            if (i < d) {
+                float o[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = rstd * (kdx[k][e] - c1 - kxh[k][e] * c2);
+                if (dx32) {
+                    if (L.accumulate) {
+                        float old[4];
+                        load4(dx32 + i, old);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o[e] += old[e];
+                    }
+                    store4(dx32 + i, o[0], o[1], o[2], o[3]);
+                }
+                if (dxa) store4(dxa + i, o[0], o[1], o[2], o[3]);
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {  // a thread owns its columns: plain stores, no atomics needed inside the workgroup
+        const int i = tid * 4 + 1024 * k;
+        if (i < d) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                cs[i + e] = accg[k][e];
+                cs[d + i + e] = accb[k][e];
+            }
+        }
+    }
+    __syncthreads();
+    if (L.ws != nullptr) {
+        float* dst = L.ws + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 2 * d;
+        for (int i = tid; i < 2 * d; i += 256) dst[i] = cs[i];
+        return;
+    }
+    for (int i = tid; i < d; i += 256) {
+        if (G.dgamma) atomicAdd(G.dgamma + i, cs[i]);
+        if (G.dbeta) atomicAdd(G.dbeta + i, cs[d + i]);
+    }
+}
+
 extern "C" int sea_rownorm_bwd(const SeaNormBwdGroup* groups, int n_groups, int M, int d, int dy_is_act, int x_is_act, int gelu,
-                               int accumulate, int dtype, void* stream) {
+                               int accumulate, int dtype, float* ws, int64_t ws_floats, void* stream) {
     SEA_REQUIRE(groups && n_groups >= 1 && n_groups <= SEA_MAX_NORM_BWD_GROUPS, "sea_rownorm_bwd: n_groups=%d", n_groups);
     SEA_REQUIRE(dtype == SEA_F32 || dtype == SEA_BF16, "sea_rownorm_bwd: bad dtype %d", dtype);
     SEA_REQUIRE(M >= 1 && d >= 4 && d % 4 == 0 && d <= 16384, "sea_rownorm_bwd: bad M=%d d=%d", M, d);
@@ -406,10 +595,14 @@ extern "C" int sea_rownorm_bwd(const SeaNormBwdGroup* groups, int n_groups, int 
         L.g[i] = G;
     }
     L.M = M; L.d = d; L.gelu = gelu; L.accumulate = accumulate;
-    int nblk = (M + 3) / 4;
-    if (nblk > 512) nblk = 512;
+    const bool wide = d > 1024 && d <= 2048;  // one workgroup per row
+    int nblk = wide ? M : (M + 3) / 4;
+    static const int nblk_cap = []() { const char* e = getenv("SEA_NORMBWD_BLOCKS"); return e ? atoi(e) : 512; }();  // tuning aid
+    if (nblk > nblk_cap) nblk = nblk_cap;
+    const bool two_stage = ws != nullptr && ws_floats >= (int64_t)n_groups * nblk * 2 * d && nblk > 8;
+    L.ws = two_stage ? ws : nullptr;
     const dim3 grid(nblk, n_groups), block(256);
-    const size_t lds = (size_t)2 * d * sizeof(float);
+    const size_t lds = (size_t)(2 * d + 8) * sizeof(float);
     hipStream_t s = static_cast<hipStream_t>(stream);
 #define LAUNCH_NBK(TT, DYA, XA, KM)                                                                                        \
     do {                                                                                                                   \
@@ -422,7 +615,7 @@ extern "C" int sea_rownorm_bwd(const SeaNormBwdGroup* groups, int n_groups, int 
         if (d <= 256) LAUNCH_NBK(TT, DYA, XA, 1);      \
         else if (d <= 512) LAUNCH_NBK(TT, DYA, XA, 2); \
         else if (d <= 1024) LAUNCH_NBK(TT, DYA, XA, 4);\
-        else if (d <= 2048) LAUNCH_NBK(TT, DYA, XA, 8);\
+        else if (d <= 2048) rownorm_bwd_wide_kernel<TT, DYA, XA><<<grid, block, lds, s>>>(L);\
         else LAUNCH_NBK(TT, DYA, XA, 0);               \
     } while (0)
     if (dtype == SEA_BF16) {
@@ -435,6 +628,17 @@ extern "C" int sea_rownorm_bwd(const SeaNormBwdGroup* groups, int n_groups, int 
     }
 #undef LAUNCH_NB
 #undef LAUNCH_NBK
+    if (two_stage) {
+        ColsumFinish F;
+        memset(&F, 0, sizeof(F));
+        for (int i = 0; i < n_groups; ++i) {
+            F.out_a[i] = groups[i].dgamma;
+            F.out_b[i] = groups[i].dbeta;
+            F.width[i] = d;
+        }
+        F.ws = ws; F.nblk = nblk; F.stride = 2 * d;
+        colsum_finish_kernel<<<dim3((2 * d + 255) / 256, n_groups, 16), dim3(256), 0, s>>>(F);
+    }
     SEA_CHECK_LAUNCH("sea_rownorm_bwd");
     return SEA_OK;
 }
@@ -445,6 +649,8 @@ struct SiluBwdLaunch {
     SeaSiluBwdGroup g[SEA_MAX_SILU_BWD_GROUPS];
     const float* c;
     int M;
+    float* ws;   // optional [n_groups][gridDim.x][2 * maxk]
+    int maxk;
 };
 
 // Column sums in registers: lane owns columns lane*4 + 256k (k < 8, K2 <= 2048), w1/b1 of those columns are loaded once.
@@ -499,13 +705,22 @@ __global__ __launch_bounds__(256) void silu_outer_bwd_kernel(const SiluBwdLaunch
         }
     }
     __syncthreads();
+    if (L.ws != nullptr) {
+        float* dst = L.ws + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 2 * L.maxk;
+        for (int i = threadIdx.x; i < K2; i += 256) {
+            dst[i] = cs[i];
+            dst[K2 + i] = cs[K2 + i];
+        }
+        return;
+    }
     for (int i = threadIdx.x; i < K2; i += 256) {
         atomicAdd(G.dw1 + i, cs[i]);
         atomicAdd(G.db1 + i, cs[K2 + i]);
     }
 }
 
-extern "C" int sea_silu_outer_bwd(const SeaSiluBwdGroup* groups, int n_groups, const float* c, int M, int dtype, void* stream) {
+extern "C" int sea_silu_outer_bwd(const SeaSiluBwdGroup* groups, int n_groups, const float* c, int M, int dtype, float* ws, int64_t ws_floats,
+                                  void* stream) {
     SEA_REQUIRE(groups && c && n_groups >= 1 && n_groups <= SEA_MAX_SILU_BWD_GROUPS && M >= 1, "sea_silu_outer_bwd: bad arguments");
     SEA_REQUIRE(dtype == SEA_F32 || dtype == SEA_BF16, "sea_silu_outer_bwd: bad dtype %d", dtype);
     SiluBwdLaunch L;
@@ -521,6 +736,9 @@ extern "C" int sea_silu_outer_bwd(const SeaSiluBwdGroup* groups, int n_groups, c
     L.c = c; L.M = M;
     int nblk = (M + 3) / 4;
     if (nblk > 256) nblk = 256;
+    const bool two_stage = ws != nullptr && ws_floats >= (int64_t)n_groups * nblk * 2 * maxk && nblk > 8;
+    L.ws = two_stage ? ws : nullptr;
+    L.maxk = maxk;
     const size_t lds = (size_t)2 * maxk * sizeof(float);
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (dtype == SEA_BF16) {
@@ -529,6 +747,17 @@ extern "C" int sea_silu_outer_bwd(const SeaSiluBwdGroup* groups, int n_groups, c
     } else {
         if (lds > 65536) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(silu_outer_bwd_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         silu_outer_bwd_kernel<float><<<dim3(nblk, n_groups), dim3(256), lds, s>>>(L);
+    }
+    if (two_stage) {
+        ColsumFinish F;
+        memset(&F, 0, sizeof(F));
+        for (int i = 0; i < n_groups; ++i) {
+            F.out_a[i] = groups[i].dw1;
+            F.out_b[i] = groups[i].db1;
+            F.width[i] = groups[i].K2;
+        }
+        F.ws = ws; F.nblk = nblk; F.stride = 2 * maxk;
+        colsum_finish_kernel<<<dim3((2 * maxk + 255) / 256, n_groups, 16), dim3(256), 0, s>>>(F);
     }
     SEA_CHECK_LAUNCH("sea_silu_outer_bwd");
     return SEA_OK;

@@ -80,10 +80,27 @@ __device__ __forceinline__ float from_f32<float>(float v) { return v; }
 template <>
 __device__ __forceinline__ __bf16 from_f32<__bf16>(float v) { return (__bf16)v; }
 
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// erf(x / sqrt 2) and exp(-x^2 / 2) together, from ONE v_exp and one v_rcp: Abramowitz & Stegun 7.1.26
+// (erf z = 1 - (a1 t + ... + a5 t^5) e^{-z^2}, t = 1/(1 + p z), |error| <= 1.5e-7 absolute — below fp32 rounding of 1 + erf).
+// The exponential of the formula, e^{-z^2} with z = x / sqrt 2, is the Gaussian factor GELU' needs anyway.  ocml's erff costs
+// ~4x the instructions; the LayerNorm+GELU passes over [M, 8E] are VALU-bound on it.
+__device__ __forceinline__ void erf_gauss(float x, float& erf_v, float& gauss) {
+    const float z = fabsf(x) * 0.70710678118654752440f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+    gauss = __expf(-0.5f * x * x);
+    const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+    erf_v = copysignf(1.0f - poly * gauss, x);
+}
+__device__ __forceinline__ float gelu_erf(float x) {
+    float e, g;
+    erf_gauss(x, e, g);
+    return 0.5f * x * (1.0f + e);
+}
 // d/dx gelu_erf(x) = Phi(x) + x phi(x)
 __device__ __forceinline__ float gelu_erf_grad(float x) {
-    return 0.5f * (1.0f + erff(x * 0.70710678118654752440f)) + x * 0.39894228040143267794f * __expf(-0.5f * x * x);
+    float e, g;
+    erf_gauss(x, e, g);
+    return 0.5f * (1.0f + e) + x * 0.39894228040143267794f * g;
 }
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
 

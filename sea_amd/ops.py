@@ -178,7 +178,7 @@ def wgrad_grouped(groups: Sequence[Dict], dtype: torch.dtype) -> None:
 
 
 def rownorm_bwd(groups: Sequence[Dict], M: int, d: int, dy_is_act: bool, x_is_act: bool, gelu: bool, accumulate: bool,
-                dtype: torch.dtype) -> None:
+                dtype: torch.dtype, ws: Optional[torch.Tensor] = None) -> None:
     n = len(groups)
     arr = (N.SeaNormBwdGroup * n)()
     for g, gd in zip(arr, groups):
@@ -194,17 +194,18 @@ def rownorm_bwd(groups: Sequence[Dict], M: int, d: int, dy_is_act: bool, x_is_ac
         g.dXact, g.lddxact = N.ptr(dxa), (dxa.stride(0) if dxa is not None else 0)
         g.dgamma, g.dbeta = N.ptr(gd.get("dgamma")), N.ptr(gd.get("dbeta"))
     N.check(N.lib().sea_rownorm_bwd(arr, n, M, d, int(dy_is_act), int(x_is_act), int(gelu), int(accumulate), N.dtype_code(dtype),
-                                    N.stream_ptr()), "sea_rownorm_bwd")
+                                    N.ptr(ws), 0 if ws is None else ws.numel(), N.stream_ptr()), "sea_rownorm_bwd")
 
 
-def silu_outer_bwd(groups: Sequence[Dict], c: torch.Tensor, M: int, dtype: torch.dtype) -> None:
+def silu_outer_bwd(groups: Sequence[Dict], c: torch.Tensor, M: int, dtype: torch.dtype, ws: Optional[torch.Tensor] = None) -> None:
     n = len(groups)
     arr = (N.SeaSiluBwdGroup * n)()
     for g, gd in zip(arr, groups):
         dH = _mat(gd["dHid"], "dHid")
         g.dHid, g.w1, g.b1, g.dw1, g.db1 = dH.data_ptr(), gd["w1"].data_ptr(), gd["b1"].data_ptr(), gd["dw1"].data_ptr(), gd["db1"].data_ptr()
         g.K2, g.ld = dH.shape[1], dH.stride(0)
-    N.check(N.lib().sea_silu_outer_bwd(arr, n, c.data_ptr(), M, N.dtype_code(dtype), N.stream_ptr()), "sea_silu_outer_bwd")
+    N.check(N.lib().sea_silu_outer_bwd(arr, n, c.data_ptr(), M, N.dtype_code(dtype), N.ptr(ws), 0 if ws is None else ws.numel(),
+                                       N.stream_ptr()), "sea_silu_outer_bwd")
 
 
 def ib_bwd(dxs: Sequence[torch.Tensor], c, w1, b1, lnw, lnb, w2, dw1, db1, dlnw, dlnb, dw2, db2) -> None:

@@ -26,6 +26,17 @@ class TrainPlan(Plan):
         eng.ensure_grads()
         super().__init__(eng, B, T, "full")
 
+    def _colsum_ws(self, n_floats: int) -> torch.Tensor:
+        """The shared fp32 workspace of the two-stage column sums (launches on one stream never overlap), sized once for the largest
+        launch of the plan."""
+        ws = getattr(self, "_ws_colsum", None)
+        if ws is None:
+            nb512, nb256 = min((self.M + 3) // 4, 512), min((self.M + 3) // 4, 256)
+            bound = max(N.MAX_NORM_BWD_GROUPS * nb512 * 2 * self.E, self.F * nb512 * 2 * self.S, N.MAX_SILU_BWD_GROUPS * nb256 * 4 * self.E)
+            ws = self._ws_colsum = torch.empty(bound, device=self.eng.device, dtype=torch.float32)
+        assert n_floats <= ws.numel(), (n_floats, ws.numel())
+        return ws
+
     def _streams(self, n: int) -> int:
         """Reserve n consecutive dropout stream ids; returns the first."""
         s = self._next_stream
@@ -68,8 +79,9 @@ class TrainPlan(Plan):
                     self._x_patches.append((g, "X", gd["X_is_x"]))
                 if gd.get("dY_is_dout") is not None:
                     self._dout_patches.append((g, "dY", gd["dY_is_dout"]))
+            ws = self._colsum_ws(len(chunk) * min((self.M + 3) // 4, 512) * 2 * d)
             self._cur.append(_Rec(L.sea_rownorm_bwd, [arr, len(chunk), self.M, d, int(dy_is_act), int(x_is_act), int(gelu), int(accumulate),
-                                                      self.code], name, arr))
+                                                      self.code, ws.data_ptr(), ws.numel()], name, arr))
 
     def _attn_bwd(self, problems: List[dict], hd: int, rope: torch.Tensor, name: str, drop=None) -> None:
         L = N.lib()
@@ -100,7 +112,8 @@ class TrainPlan(Plan):
                 dH = d["dHid"]
                 g.dHid, g.w1, g.b1, g.dw1, g.db1 = dH.data_ptr(), d["w1"].data_ptr(), d["b1"].data_ptr(), d["dw1"].data_ptr(), d["db1"].data_ptr()
                 g.K2, g.ld = dH.shape[1], dH.stride(0)
-            rec = _Rec(L.sea_silu_outer_bwd, [arr, len(chunk), None, self.M, self.code], name, arr)
+            ws = self._colsum_ws(len(chunk) * min((self.M + 3) // 4, 256) * 2 * max(d["dHid"].shape[1] for d in chunk))
+            rec = _Rec(L.sea_silu_outer_bwd, [arr, len(chunk), None, self.M, self.code, ws.data_ptr(), ws.numel()], name, arr)
             self._c_patches.append((rec.args, 2))
             self._cur.append(rec)
 

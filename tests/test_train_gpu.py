@@ -90,7 +90,9 @@ def test_fused_train_step_equals_autograd_path():
         oa.step()
         loss_b = mb.engine().train_step(x, tgt, ib, ob)
     for (k, pa), (_, pb) in zip(ma.named_parameters(), mb.named_parameters()):
-        assert rel_l2(pb.detach().cpu().numpy(), pa.detach().cpu().numpy()) < 1e-6, k
+        # .k.bias has a mathematically zero gradient (softmax is shift-invariant per query): Adam normalises the atomics-order
+        # rounding noise to O(lr), so the two paths agree only to that noise there.
+        assert rel_l2(pb.detach().cpu().numpy(), pa.detach().cpu().numpy()) < (1e-6 if not k.endswith(".k.bias") else 1e-4), k
     assert np.isfinite(loss_b.item())
 
 
