@@ -34,7 +34,8 @@ struct AttnCfg {
 // SPLIT = 2: two groups of 4 waves share a query tile and take alternate key tiles (group g: tiles g, g+2, ...), each with its
 // own running max / sum / O^T; the halves are merged through LDS at the end.  This halves the serial chain of key tiles of a
 // workgroup — what bounds the launch when the grid is only a few workgroups per CU (one trajectory: 768 workgroups).
-template <typename T, int HD, int SPLIT>
+// DROP is a template parameter so that the inference instantiation carries none of the dropout's select/merge moves.
+template <typename T, int HD, int SPLIT, bool DROP>
 __global__ __launch_bounds__(256 * SPLIT) void attention_fwd_kernel(const SeaAttnParams P) {
     using C = AttnCfg<T, HD>;
     constexpr int MERGE_BYTES = SPLIT > 1 ? 256 * (2 + 4 * C::NDB) * 4 : 0;
@@ -193,12 +194,16 @@ __global__ __launch_bounds__(256 * SPLIT) void attention_fwd_kernel(const SeaAtt
                     }
                     mx = fmaxf(mx, s[kc][be][q]);
                 }
-        mx = fmaxf(mx, __shfl_xor(mx, 16));
-        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        mx = group_max4(mx);
         const float m_new = fmaxf(m_i, mx);
         constexpr float LOG2E = 1.4426950408889634f;
         const float alpha = __builtin_amdgcn_exp2f((m_i - m_new) * LOG2E);  // first visible tile: 2^(-inf) = 0
         const float neg_ms = -m_new * LOG2E;
+        // Row sums: in bf16 without dropout they come out of the matrix core (an all-ones A operand against the packed P^T gives
+        // sum_k P[k][query] in every row of the result) — 16 dependent v_add per tile become 2 MFMAs on the otherwise idle pipe, and the
+        // result is already summed over the 4 lane groups.  The f32 path and the dropout path (whose sum must see the un-dropped P) add
+        // on the VALU.
+        constexpr bool MFMA_SUM = sizeof(T) == 2 && !DROP;
         float psum = 0.f;
 #pragma unroll
         for (int kc = 0; kc < C::KCH; ++kc)
@@ -208,13 +213,12 @@ __global__ __launch_bounds__(256 * SPLIT) void attention_fwd_kernel(const SeaAtt
                 for (int q = 0; q < 4; ++q) {
                     const float p = __builtin_amdgcn_exp2f(fmaf(s[kc][be][q], LOG2E, neg_ms));
                     s[kc][be][q] = p;
-                    psum += p;
+                    if constexpr (!MFMA_SUM) psum += p;
                 }
-        l_i = l_i * alpha + psum;
         m_i = m_new;
 #pragma unroll
         for (int d = 0; d < C::NDB; ++d) oacc[d] *= alpha;
-        if (P.drop.thr > 0) {  // dropout on the probabilities: the row sum above stays un-dropped (softmax first, then dropout)
+        if constexpr (DROP) {  // dropout on the probabilities: the row sum above stays un-dropped (softmax first, then dropout)
             const float sc = drop_scale(P.drop.thr);
 #pragma unroll
             for (int kc = 0; kc < C::KCH; ++kc)
@@ -227,6 +231,7 @@ __global__ __launch_bounds__(256 * SPLIT) void attention_fwd_kernel(const SeaAtt
                 }
         }
         // ---- O^T += V^T . P^T
+        f32x4 lsum = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int kc = 0; kc < C::KCH; ++kc) {
             uint4 pf;
@@ -243,7 +248,10 @@ __global__ __launch_bounds__(256 * SPLIT) void attention_fwd_kernel(const SeaAtt
                 if (d * 16 + r < HD) a = *reinterpret_cast<const uint4*>(sV + v_frag_off + d * 16 * C::V_STRIDE + kc * C::CK * (int)sizeof(T));
                 mma16<T>(a, pf, oacc[d]);
             }
+            if constexpr (MFMA_SUM) mma16<T>(make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u), pf, lsum);
         }
+        if constexpr (MFMA_SUM) psum = lsum[0];
+        l_i = l_i * alpha + psum;
     };
 
     // group g walks tiles g, g + SPLIT, ...; every thread of the workgroup executes every barrier
@@ -252,6 +260,10 @@ __global__ __launch_bounds__(256 * SPLIT) void attention_fwd_kernel(const SeaAtt
         load_tile(grp);
         store_tile(0);
     }
+    // Every register loaded before the loop (the Q fragments) is complete from here on.  Without this the compiler, seeing the path
+    // that skips the conditional prologue above, keeps "Q may still be in flight" alive around the loop and waits vmcnt(0) before the
+    // first MFMA of EVERY tile — i.e. on the K/V prefetch it has just issued, serialising load latency with compute.
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), expcnt / lgkmcnt untouched
     __syncthreads();
     for (int it = 0; it < n_it; ++it) {
         const int kt = it * SPLIT + grp;
@@ -299,8 +311,11 @@ __global__ __launch_bounds__(256 * SPLIT) void attention_fwd_kernel(const SeaAtt
     }
 
     // ---- finalize: this lane holds O^T[d = 16*db + 4g + reg][query q_idx]
-    float l = l_i + __shfl_xor(l_i, 16);
-    l += __shfl_xor(l, 32);
+    float l = l_i;
+    if constexpr (!(sizeof(T) == 2 && !DROP)) {  // VALU row sums are per lane group
+        l += __shfl_xor(l, 16);
+        l += __shfl_xor(l, 32);
+    }
     const float inv = 1.0f / l;
     if (q_idx < Tq) {
         T* Og = static_cast<T*>(pr.O) + ((int64_t)b * Tq + q_idx) * P.ldo + h * HD;
@@ -313,18 +328,18 @@ __global__ __launch_bounds__(256 * SPLIT) void attention_fwd_kernel(const SeaAtt
     }
 }
 
-template <typename T, int SPLIT>
+template <typename T, int SPLIT, bool DROP>
 static int launch_attention_s(const SeaAttnParams& P, hipStream_t s) {
     const dim3 grid((P.Tq + 63) / 64, P.B * P.H, P.n_problems), block(256 * SPLIT);
     switch (P.hd) {
-        case 8: attention_fwd_kernel<T, 8, SPLIT><<<grid, block, 0, s>>>(P); break;
-        case 16: attention_fwd_kernel<T, 16, SPLIT><<<grid, block, 0, s>>>(P); break;
-        case 32: attention_fwd_kernel<T, 32, SPLIT><<<grid, block, 0, s>>>(P); break;
-        case 64: attention_fwd_kernel<T, 64, SPLIT><<<grid, block, 0, s>>>(P); break;
-        case 128: attention_fwd_kernel<T, 128, 1><<<grid, dim3(256), 0, s>>>(P); break;  // LDS: one group only
+        case 8: attention_fwd_kernel<T, 8, SPLIT, DROP><<<grid, block, 0, s>>>(P); break;
+        case 16: attention_fwd_kernel<T, 16, SPLIT, DROP><<<grid, block, 0, s>>>(P); break;
+        case 32: attention_fwd_kernel<T, 32, SPLIT, DROP><<<grid, block, 0, s>>>(P); break;
+        case 64: attention_fwd_kernel<T, 64, SPLIT, DROP><<<grid, block, 0, s>>>(P); break;
+        case 128: attention_fwd_kernel<T, 128, 1, DROP><<<grid, dim3(256), 0, s>>>(P); break;  // LDS: one group only
         case 256:  // the shipped multiphase dims (embed_dim 2048 / 8 heads): bf16 only, the f32 tiles would not fit the LDS ring
             if constexpr (sizeof(T) == 2) {
-                attention_fwd_kernel<T, 256, 1><<<grid, dim3(256), 0, s>>>(P);
+                attention_fwd_kernel<T, 256, 1, DROP><<<grid, dim3(256), 0, s>>>(P);
                 break;
             }
             return -1;
@@ -338,7 +353,8 @@ static int launch_attention(const SeaAttnParams& P, hipStream_t s) {
     // few workgroups per CU and a long key range: split the key tiles of a query tile over two wave groups
     const long blocks = (long)((P.Tq + 63) / 64) * P.B * P.H * P.n_problems;
     const bool split = blocks <= 1024 && P.Tk >= 256;
-    return split ? launch_attention_s<T, 2>(P, s) : launch_attention_s<T, 1>(P, s);
+    if (P.drop.thr > 0) return split ? launch_attention_s<T, 2, true>(P, s) : launch_attention_s<T, 1, true>(P, s);
+    return split ? launch_attention_s<T, 2, false>(P, s) : launch_attention_s<T, 1, false>(P, s);
 }
 
 extern "C" int sea_attention_fwd(const SeaAttnParams* params, int dtype, void* stream) {

@@ -133,6 +133,18 @@ __device__ __forceinline__ void decode_attn_block(int& tile, int& bh, int& z) {
     bh = inner - z * gridDim.y;
 }
 
+// max over the 4 lane groups {l, l^16, l^32, l^48} without touching the LDS crossbar: gfx950's half / row swaps
+// (v_permlane32_swap exchanges the upper half of vdst with the lower half of src, v_permlane16_swap the odd 16-lane rows of
+// vdst with the even rows of src; with vdst = src = x the two results hold both partners of every lane).
+__device__ __forceinline__ float group_max4(float x) {
+    const unsigned u = __float_as_uint(x);
+    const auto a = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    x = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+    const unsigned v = __float_as_uint(x);
+    const auto b = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+    return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
