@@ -38,10 +38,10 @@ struct AttnCfg {
 template <typename T, int HD, int SPLIT, bool DROP>
 __global__ __launch_bounds__(256 * SPLIT) void attention_fwd_kernel(const SeaAttnParams P) {
     using C = AttnCfg<T, HD>;
-    constexpr int MERGE_BYTES = SPLIT > 1 ? 256 * (2 + 4 * C::NDB) * 4 : 0;
+    constexpr int MERGE_BYTES = SPLIT > 1 ? (SPLIT - 1) * 256 * (2 + 4 * C::NDB) * 4 : 0;
     constexpr int RING_BYTES = SPLIT * 2 * C::LDS_BYTES;                   // per group: double-buffered K and V^T tiles
     __shared__ __attribute__((aligned(16))) char smem_all[RING_BYTES > MERGE_BYTES ? RING_BYTES : MERGE_BYTES];
-    const int grp = SPLIT > 1 ? (int)(threadIdx.x >> 8) : 0;               // wave-uniform
+    const int grp = SPLIT > 1 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8)) : 0;  // wave-uniform
     char* smem = smem_all + grp * 2 * C::LDS_BYTES;
 
     const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;  // tid, wave: inside the group
@@ -284,11 +284,11 @@ __global__ __launch_bounds__(256 * SPLIT) void attention_fwd_kernel(const SeaAtt
     }
 
     if constexpr (SPLIT > 1) {
-        // merge group 1 into group 0: m = max(m0, m1), l = l0 e^(m0-m) + l1 e^(m1-m), O likewise (flash-decoding combine)
+        // merge groups 1.. into group 0: m = max(m0, m1), l = l0 e^(m0-m) + l1 e^(m1-m), O likewise (flash-decoding combine)
         float* mg = reinterpret_cast<float*>(smem_all);
         constexpr int STR = 2 + 4 * C::NDB;
-        if (grp == 1) {
-            float* dst = mg + tid * STR;
+        if (grp != 0) {
+            float* dst = mg + ((grp - 1) * 256 + tid) * STR;
             dst[0] = m_i;
             dst[1] = l_i;
 #pragma unroll
@@ -297,17 +297,20 @@ __global__ __launch_bounds__(256 * SPLIT) void attention_fwd_kernel(const SeaAtt
                 for (int q = 0; q < 4; ++q) dst[2 + 4 * d + q] = oacc[d][q];
         }
         __syncthreads();
-        if (grp == 1) return;
-        const float* src = mg + tid * STR;
-        const float m1 = src[0], l1 = src[1];
-        const float m = fmaxf(m_i, m1);  // group 0 always owns tile 0, so m_i is finite
-        const float a0 = __expf(m_i - m), a1 = __expf(m1 - m);  // m1 = -inf (group 1 saw nothing) -> a1 = 0
-        l_i = l_i * a0 + l1 * a1;
+        if (grp != 0) return;
 #pragma unroll
-        for (int d = 0; d < C::NDB; ++d)
+        for (int o = 0; o < SPLIT - 1; ++o) {
+            const float* src = mg + (o * 256 + tid) * STR;
+            const float m1 = src[0], l1 = src[1];
+            const float m = fmaxf(m_i, m1);  // group 0 always owns tile 0, so m_i is finite
+            const float a0 = __expf(m_i - m), a1 = __expf(m1 - m);  // m1 = -inf (the group saw nothing) -> a1 = 0
+            l_i = l_i * a0 + l1 * a1;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) oacc[d][q] = oacc[d][q] * a0 + src[2 + 4 * d + q] * a1;
-        m_i = m;
+            for (int d = 0; d < C::NDB; ++d)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) oacc[d][q] = oacc[d][q] * a0 + src[2 + 4 * d + q] * a1;
+            m_i = m;
+        }
     }
 
     // ---- finalize: this lane holds O^T[d = 16*db + 4g + reg][query q_idx]
@@ -353,6 +356,16 @@ static int launch_attention(const SeaAttnParams& P, hipStream_t s) {
     // few workgroups per CU and a long key range: split the key tiles of a query tile over two wave groups
     const long blocks = (long)((P.Tq + 63) / 64) * P.B * P.H * P.n_problems;
     const bool split = blocks <= 1024 && P.Tk >= 256;
+    // at most two workgroups per CU: four wave groups per query tile (measured at cfg2: cross-attention 18.3 -> 17.3 us; with 768
+    // workgroups the 1024-thread workgroups no longer co-reside and it is slower, 21.7 -> 24.7 us)
+    static const int split4 = []() { const char* e = getenv("SEA_ATTN_SPLIT4"); return e ? atoi(e) : -1; }();  // tuning aid: 0 off, 1 on
+    if (split && (split4 == 1 || (split4 < 0 && blocks <= 512)) && P.hd <= 32 && P.drop.thr == 0) {
+        const dim3 grid((P.Tq + 63) / 64, P.B * P.H, P.n_problems), block(1024);
+        if (P.hd == 32) attention_fwd_kernel<T, 32, 4, false><<<grid, block, 0, s>>>(P);
+        else if (P.hd == 16) attention_fwd_kernel<T, 16, 4, false><<<grid, block, 0, s>>>(P);
+        else attention_fwd_kernel<T, 8, 4, false><<<grid, block, 0, s>>>(P);
+        return 0;
+    }
     if (P.drop.thr > 0) return split ? launch_attention_s<T, 2, true>(P, s) : launch_attention_s<T, 1, true>(P, s);
     return split ? launch_attention_s<T, 2, false>(P, s) : launch_attention_s<T, 1, false>(P, s);
 }

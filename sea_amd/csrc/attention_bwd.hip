@@ -157,6 +157,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const SeaAttnBwdParams
     stV.load(Vg, HD, 0, Tk, tid);
     stK.store(smem, tid);
     stV.store(smem + C::TILE, tid);
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): pre-loop register loads are complete, so the per-tile MFMAs do not wait on the prefetch (see attention.hip)
     __syncthreads();
     for (int kt = 0; kt < n_kt; ++kt) {
         const char* sK = smem + (kt & 1) * 2 * C::TILE;
@@ -307,6 +308,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const SeaAttnBwdParam
         stO.store(smem + C::TILE, tid);
         store_vec(0);
     }
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): pre-loop register loads are complete, so the per-tile MFMAs do not wait on the prefetch (see attention.hip)
     __syncthreads();
     for (int qt = qt0; qt < n_qt; ++qt) {
         const int bi = (qt - qt0) & 1;
