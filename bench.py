@@ -49,6 +49,15 @@ def kernel_flops(name, B, T, F, E, H, D, S):
     """Algorithmic FLOPs of ONE launch of the named plan record (per launch, all groups of the launch)."""
     M = B * T
     tri = T * (T + 1) // 2
+    per_field = 1
+    if len(name) > 3 and name[-3:-1] == ".f" and name[-1].isdigit():  # per-field launch of the lane plan ("mlp.fc1.f0")
+        name, per_field = name[:-3], F
+    if name == "adaln.cond_gemm.first":
+        return 2 * M * F * (2 * E) ** 2
+    if name == "adaln.cond_gemm.rest":
+        return 2 * M * (2 * F * (2 * E) ** 2 + F * (2 * D) ** 2)
+    if per_field > 1:
+        return kernel_flops(name, B, T, F, E, H, D, S) // per_field
     table = {
         "adaln.cond_gemm": 2 * M * ((2 * F + F) * (2 * E) ** 2 + F * (2 * D) ** 2),
         "self.qkv_rope": F * 2 * M * E * 3 * E,
@@ -61,6 +70,20 @@ def kernel_flops(name, B, T, F, E, H, D, S):
     }
     if name in table:
         return table[name]
+    # fused plan (sea_rowchain launches): the Linear layers each chain contains
+    kv_old = F * (F - 1) // 2  # pairs (iq, i), iq < i: k/v projections of the old x_i; the other half reads the new x_i
+    fused = {
+        "self.adaln0_qkv": F * 2 * M * E * 3 * E,
+        "self.proj_down_qkv": F * (2 * M * E * E + 2 * M * E * D) + F * (F - 1) * 2 * M * D * D + kv_old * 2 * M * D * 2 * D,
+        "proj_final_norm": F * 2 * M * E * E,
+        "proj_adaln0_qkv": F * (2 * M * E * E + 2 * M * E * 3 * E),
+        "mlp.fused": F * 4 * M * E * S,
+    }
+    if name in fused:
+        return fused[name]
+    if name.startswith("cross") and name.endswith("proj_up_down_kv"):
+        i = int(name[5:name.index(".")])
+        return (F - 1) * (2 * M * D * D) + 2 * M * D * E + (2 * M * E * D + (F - 1 - i) * 2 * M * D * 2 * D if i < F - 1 else 0)
     if name.startswith("cross") and name.endswith("qkv_rope"):
         return (F - 1) * 2 * M * D * 3 * D
     if name.startswith("cross") and name.endswith("attention"):

@@ -363,6 +363,95 @@ typedef struct {
 int sea_ib_bwd(const SeaIbBwdParams* params, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
+ * Row-local operator chain: everything between two attention launches of the temporal block that only mixes the
+ * columns of a row (Linear layers, residual adds, GELU, LayerNorm/AdaLN, RoPE + the attention layouts) executed by ONE
+ * launch.  A workgroup owns 32 rows of one chain ("group": one field), keeps the row tile in LDS between stages and
+ * streams the weights straight from L2 into MFMA operands; nothing but the declared outputs goes back to HBM.
+ * Replaces, fused: models/temporal.py:133-137 (self-attention projection + residual), :176-192 (cross_down, ln_cross,
+ * cross-attention q/k/v + RoPE, projection + GELU, cross_up, sum over j, residual), :111-116,140-142 (info-bottleneck
+ * add), :143-146 (AdaLN_2, proj) and :412-415 (final per-field norm); models/base_blocks.py:175-190,267-282,343-350.
+ *
+ * A stage produces v[rows, N] (fp32, in registers) and pushes it through a fixed epilogue; stages run in order:
+ *     kind 0:  v = A . W^T           A = LDS slot a_slot [rows, K] (act dtype), W act dtype [N, K] (nn.Linear layout)
+ *     kind 1:  v = X[rows, 0:N]      fp32 (x_is_act = 0) or act dtype rows loaded from global memory
+ *     kind 2:  LDS slot raw_slot <- X[rows, 0:N] (act dtype), nothing else; consecutive kind-2 stages overlap their loads
+ *     v += bias_scale * bias ;  act = 1: v = gelu_erf(v)
+ *     sum_op 1: S = v, stage ends;  3: S += v, stage ends;  2: v += S   (S: a running sum held in registers,
+ *               sum_j Up(GELU(.)) = Up(sum_j GELU(.)) — models/temporal.py:189-191)
+ *     v += R (fp32 rows);  raw_slot >= 0: LDS slot <- (act dtype) v
+ *     ib_w1 != NULL: v += W2 . gelu(LN_h(w1 c + b1)) + b2   (the info-bottleneck term of sea_ib_add, c = bind.cond[row], h <= 8)
+ *     C32 <- v ;  Cact <- (act dtype) v
+ *     qkv = 1: v goes through RoPE into the attention layouts exactly as sea_qkv_rope_grouped (columns col0 .. col0+N of
+ *              the virtual [q | k | v] row, head dim hd, tables rope), and the stage ends
+ *     norm = 1: y = LayerNorm_N(v) with gamma / beta / mod as SeaNormGroup (biased variance, eps);  norm = 2: y = gelu_erf(y) too
+ *              norm_slot >= 0: LDS slot <- (act dtype) y ;  Nact <- (act dtype) y ;  N32 <- y
+ * N and K are multiples of 64 and at most SEA_CHAIN_MAX_WIDTH (the running sum S: N <= 128); a stage must not write the slot it
+ * reads; M times any row stride stays below 2^31 elements.
+ * `ext` marks pointers that are byte OFFSETS from a per-call base instead of addresses: bit 0: X from bind.x, bit 1: R from
+ * bind.x, bit 2: N32 from bind.out — the stage array lives in device memory and stays valid across calls.
+ */
+#define SEA_CHAIN_MAX_GROUPS 8
+#define SEA_CHAIN_SLOTS 3
+#define SEA_CHAIN_MAX_WIDTH 256
+#define SEA_CHAIN_ROWS 32
+typedef struct {
+    int32_t kind, a_slot, N, K;
+    const void* W;
+    int64_t ldw;
+    const void* X;
+    int64_t ldx;
+    int32_t x_is_act, ext;
+    const float* bias;
+    float bias_scale;
+    int32_t act;
+    int32_t sum_op, raw_slot;
+    const float* R;
+    int64_t ldr;
+    const float* ib_w1;
+    const float* ib_b1;
+    const float* ib_lnw;
+    const float* ib_lnb;
+    const float* ib_w2;
+    const float* ib_b2;
+    int32_t ib_h, norm;
+    float* C32;
+    int64_t ldc32;
+    void* Cact;
+    int64_t ldcact;
+    const float* gamma;
+    const float* beta;
+    const void* mod;
+    int64_t ldmod;
+    int32_t norm_slot, qkv;
+    void* Nact;
+    int64_t ldnact;
+    float* N32;
+    int64_t ldn32;
+    int32_t col0, hd;
+    const float* rope;
+    float q_scale;
+    int32_t pad;
+    void* Qout;
+    void* Kout;
+    void* Vtout;
+} SeaChainStage;
+
+typedef struct {
+    const SeaChainStage* stages;        /* DEVICE memory: all groups' stages back to back */
+    int32_t n_groups;
+    int32_t first[SEA_CHAIN_MAX_GROUPS + 1];   /* group g runs stages first[g] .. first[g+1]-1 */
+    const float* x;                     /* per-call bases for the `ext` offsets */
+    float* out;
+    const float* cond;                  /* f32 [M] condition scalar per row (info-bottleneck term) */
+    int32_t M, T, pos0, cap, H;         /* rows; rows per trajectory, first position and KV capacity (qkv epilogue); heads */
+    float eps;
+    uint64_t* dbg;                      /* NULL, or device memory for 2 + n_stages wall_clock64() stamps of workgroup (0, 0) (development aid) */
+} SeaChainLaunch;
+
+/* `host_stages` is the host copy of launch->stages (same content), used for validation only. */
+int sea_rowchain(const SeaChainLaunch* launch, const SeaChainStage* host_stages, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
  * Self-test of the MFMA fragment maps this library relies on (16x16x32 bf16 and 16x16x4 f32, A/B/C lane maps):
  * multiplies exact small-integer matrices on the device and checks every element on the host.  Synchronous.
  * Returns 0 when both maps are as documented in cdna_hip_programming.md §3.

@@ -103,6 +103,33 @@ class SeaAttnBwdParams(C.Structure):
                 ("ldo", _i32), ("lddo", _i32), ("lddq", _i32), ("lddk", _i32), ("lddv", _i32), ("q_scale", _f32), ("drop", SeaDropout)]
 
 
+CHAIN_MAX_GROUPS = 8
+CHAIN_SLOTS = 3
+CHAIN_MAX_WIDTH = 256
+CHAIN_ROWS = 32
+
+
+class SeaChainStage(C.Structure):
+    _fields_ = [("kind", _i32), ("a_slot", _i32), ("N", _i32), ("K", _i32),
+                ("W", _vp), ("ldw", _i64), ("X", _vp), ("ldx", _i64), ("x_is_act", _i32), ("ext", _i32),
+                ("bias", _vp), ("bias_scale", _f32), ("act", _i32), ("sum_op", _i32), ("raw_slot", _i32),
+                ("R", _vp), ("ldr", _i64),
+                ("ib_w1", _vp), ("ib_b1", _vp), ("ib_lnw", _vp), ("ib_lnb", _vp), ("ib_w2", _vp), ("ib_b2", _vp),
+                ("ib_h", _i32), ("norm", _i32),
+                ("C32", _vp), ("ldc32", _i64), ("Cact", _vp), ("ldcact", _i64),
+                ("gamma", _vp), ("beta", _vp), ("mod", _vp), ("ldmod", _i64),
+                ("norm_slot", _i32), ("qkv", _i32),
+                ("Nact", _vp), ("ldnact", _i64), ("N32", _vp), ("ldn32", _i64),
+                ("col0", _i32), ("hd", _i32), ("rope", _vp), ("q_scale", _f32), ("pad", _i32),
+                ("Qout", _vp), ("Kout", _vp), ("Vtout", _vp)]
+
+
+class SeaChainLaunch(C.Structure):
+    _fields_ = [("stages", _vp), ("n_groups", _i32), ("first", _i32 * (CHAIN_MAX_GROUPS + 1)),
+                ("x", _vp), ("out", _vp), ("cond", _vp),
+                ("M", _i32), ("T", _i32), ("pos0", _i32), ("cap", _i32), ("H", _i32), ("eps", _f32), ("dbg", _vp)]
+
+
 MAX_WGRAD_GROUPS = 16
 MAX_NORM_BWD_GROUPS = 8
 MAX_SILU_BWD_GROUPS = 24
@@ -148,6 +175,8 @@ def lib() -> C.CDLL:
     L.sea_attention_bwd.argtypes = [C.POINTER(SeaAttnBwdParams), C.c_int, _vp]
     L.sea_dropout_mask.argtypes = [_vp, _i64, _i64, C.c_uint32, C.c_uint32, _i32, _vp]
     L.sea_dropout_mask.restype = C.c_int
+    L.sea_rowchain.argtypes = [C.POINTER(SeaChainLaunch), C.POINTER(SeaChainStage), C.c_int, _vp]
+    L.sea_rowchain.restype = C.c_int
     for name in ("sea_attention_bwd", "sea_wgrad_grouped", "sea_transpose_weights", "sea_rownorm_bwd", "sea_silu_outer_bwd", "sea_ib_bwd"):
         getattr(L, name).restype = C.c_int
     L.sea_mse_fwd_bwd.argtypes = [_vp, _vp, _vp, _vp, _vp, C.c_int, _i64, C.c_float, _vp]
@@ -166,14 +195,14 @@ def lib() -> C.CDLL:
 
 ABI_STRUCTS = (SeaGemmGroup, SeaQkvGroup, SeaQkvCommon, SeaAttnProblem, SeaAttnParams, SeaNormGroup, SeaSiluGroup,
                SeaIbParams, SeaWgradGroup, SeaNormBwdGroup, SeaSiluBwdGroup, SeaIbBwdParams, SeaAttnBwdProblem, SeaAttnBwdParams,
-               SeaDropout)
+               SeaDropout, SeaChainStage, SeaChainLaunch)
 
 EXPORTED_SYMBOLS = (
     "sea_abi_version", "sea_last_error", "sea_struct_sizes", "sea_device_info", "sea_gemm_grouped", "sea_qkv_rope_grouped",
     "sea_attention_fwd", "sea_rownorm", "sea_silu_outer", "sea_ib_add", "sea_convert_f32_to_act", "sea_selftest_mfma",
     "sea_mse_fwd_bwd", "sea_relative_mse", "sea_adamw_flat",
     "sea_wgrad_grouped", "sea_transpose_weights", "sea_rownorm_bwd", "sea_silu_outer_bwd", "sea_ib_bwd",
-    "sea_attention_bwd", "sea_dropout_mask",
+    "sea_attention_bwd", "sea_dropout_mask", "sea_rowchain",
 )
 
 

@@ -13,7 +13,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libsea_hip.so")
-SOURCES = ["core.hip", "gemm.hip", "attention.hip", "rowops.hip", "train.hip", "bwd.hip", "attention_bwd.hip"]
+SOURCES = ["core.hip", "gemm.hip", "attention.hip", "rowops.hip", "train.hip", "bwd.hip", "attention_bwd.hip", "rowchain.hip"]
 HEADERS = ["sea_common.hpp", "gemm_core.hpp", os.path.join("..", "..", "include", "sea_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-mcode-object-version=5", "-Wall", "-Wno-unused-function", "-Wno-unused-result"]
 

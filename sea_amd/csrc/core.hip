@@ -18,7 +18,8 @@ extern "C" int sea_struct_sizes(int* out, int cap) {
     const int sizes[] = {(int)sizeof(SeaGemmGroup), (int)sizeof(SeaQkvGroup), (int)sizeof(SeaQkvCommon), (int)sizeof(SeaAttnProblem),
                          (int)sizeof(SeaAttnParams), (int)sizeof(SeaNormGroup), (int)sizeof(SeaSiluGroup), (int)sizeof(SeaIbParams),
                          (int)sizeof(SeaWgradGroup), (int)sizeof(SeaNormBwdGroup), (int)sizeof(SeaSiluBwdGroup), (int)sizeof(SeaIbBwdParams),
-                         (int)sizeof(SeaAttnBwdProblem), (int)sizeof(SeaAttnBwdParams), (int)sizeof(SeaDropout)};
+                         (int)sizeof(SeaAttnBwdProblem), (int)sizeof(SeaAttnBwdParams), (int)sizeof(SeaDropout), (int)sizeof(SeaChainStage),
+                         (int)sizeof(SeaChainLaunch)};
     const int n = (int)(sizeof(sizes) / sizeof(sizes[0]));
     for (int i = 0; i < n && i < cap; ++i) out[i] = sizes[i];
     return n;

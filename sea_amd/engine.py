@@ -16,6 +16,8 @@ Memory layout (all in HBM, allocated through torch):
 """
 from __future__ import annotations
 
+import os
+
 import ctypes as C
 import re
 from typing import Dict, List, Optional, Tuple
@@ -23,6 +25,7 @@ from typing import Dict, List, Optional, Tuple
 import torch
 
 from . import _native as N
+from . import ops
 
 _QKV = re.compile(r"^(.*\.)(k|q|v)\.(weight|bias)$")
 _QKV_RANK = {("q", "weight"): 0, ("k", "weight"): 1, ("v", "weight"): 2, ("q", "bias"): 3, ("k", "bias"): 4, ("v", "bias"): 5}
@@ -167,11 +170,12 @@ class FlatParams:
 
 
 class _Rec:
-    """One pre-built launch: C function + argument list (the stream is appended at run time)."""
-    __slots__ = ("fn", "args", "name", "keep")
+    """One pre-built launch: C function + argument list (the stream is appended at run time).  `lane` selects the stream of a
+    concurrent replay (0 = the caller's stream); fn None marks a lane fork / join (name "fork" / "join")."""
+    __slots__ = ("fn", "args", "name", "keep", "lane")
 
-    def __init__(self, fn, args, name, keep=None):
-        self.fn, self.args, self.name, self.keep = fn, list(args), name, keep
+    def __init__(self, fn, args, name, keep=None, lane=0):
+        self.fn, self.args, self.name, self.keep, self.lane = fn, list(args), name, keep, lane
 
 
 class Plan:
@@ -199,7 +203,13 @@ class Plan:
         self._pos_structs: List[object] = []                   # SeaQkvCommon / SeaAttnParams to update per step
         self._drop_structs: List[object] = []                  # structs whose .drop.seed is re-keyed every training step
         self._bound = (None, None, None)
-        self._build()
+        self._lane = 0                    # lane the record builders tag new records with
+        self._lane_streams: Dict[int, torch.cuda.Stream] = {}
+        self.fused = self._can_fuse()
+        if self.fused:
+            self._build_fused()
+        else:
+            self._build()
 
     # ------------------------------------------------------------------ allocation helpers
     def _buf(self, *shape, dtype=None, zero=False) -> torch.Tensor:
@@ -207,6 +217,25 @@ class Plan:
         t = (torch.zeros if zero else torch.empty)(*shape, device=self.eng.device, dtype=dt)
         self._keep.append(t)
         return t
+
+    # ------------------------------------------------------------------ lanes (concurrent replay)
+    def _rec(self, fn, args, name, keep=None) -> _Rec:
+        return _Rec(fn, args, name, keep, self._lane)
+
+    def _fork(self, lane: int) -> None:
+        """Records built until the matching _join run on `lane`: in a concurrent replay that stream first waits for everything
+        the main stream has been given so far, then runs beside it."""
+        assert self._lane == 0 and lane > 0
+        self._cur.append(_Rec(None, [], "fork", None, lane))
+        self._lane = lane
+
+    def _end_lane(self) -> None:
+        self._lane = 0
+
+    def _join(self, lane: int) -> None:
+        """The main stream waits for everything given to `lane`."""
+        assert self._lane == 0
+        self._cur.append(_Rec(None, [], "join", None, lane))
 
     # ------------------------------------------------------------------ record builders
     def _gemm(self, groups: List[dict], name: str) -> None:
@@ -216,7 +245,7 @@ class Plan:
             arr = (N.SeaGemmGroup * len(chunk))()
             for g, d in zip(arr, chunk):
                 _fill_gemm(g, **d)
-            self._cur.append(_Rec(L.sea_gemm_grouped, [arr, len(chunk), self.code], name, arr))
+            self._cur.append(self._rec(L.sea_gemm_grouped, [arr, len(chunk), self.code], name, arr))
             for g, d in zip(arr, chunk):
                 if d.get("R_is_x") is not None:
                     self._x_patches.append((g, "R", d["R_is_x"]))
@@ -242,7 +271,7 @@ class Plan:
                     self._x_patches.append((g, "X", gd["X_is_x"]))
                 if gd.get("Y_is_out") is not None:
                     self._out_patches.append((g, "Y32", gd["Y_is_out"]))
-            self._cur.append(_Rec(L.sea_rownorm, [arr, len(chunk), self.M, d, int(x_is_act), int(gelu), 1e-5, self.code], name, arr))
+            self._cur.append(self._rec(L.sea_rownorm, [arr, len(chunk), self.M, d, int(x_is_act), int(gelu), 1e-5, self.code], name, arr))
 
     def _qkv(self, groups: List[dict], rope: torch.Tensor, hd: int, name: str) -> None:
         L = N.lib()
@@ -255,7 +284,7 @@ class Plan:
             g.M, g.N, g.K, g.col0 = self.M, W.shape[0], W.shape[1], d["col0"]
         common = N.SeaQkvCommon(rope.data_ptr(), self.H, hd, self.T, self.pos0, self.cap, float(hd) ** -0.5)
         self._pos_structs.append(common)
-        self._cur.append(_Rec(L.sea_qkv_rope_grouped, [arr, len(groups), C.byref(common), self.code], name, (arr, common)))
+        self._cur.append(self._rec(L.sea_qkv_rope_grouped, [arr, len(groups), C.byref(common), self.code], name, (arr, common)))
 
     def _attn(self, problems: List[dict], hd: int, ldo: int, name: str, drop=None) -> None:
         L = N.lib()
@@ -272,29 +301,28 @@ class Plan:
             P.B, P.H, P.hd, P.Tq, P.Tk, P.cap = self.B, self.H, hd, self.T, self.pos0 + self.T, self.cap
             P.q_pos0, P.src_len, P.ldo = self.pos0, self.eng.model.src_len, ldo
             self._pos_structs.append(P)
-            self._cur.append(_Rec(L.sea_attention_fwd, [C.byref(P), self.code], name, P))
+            self._cur.append(self._rec(L.sea_attention_fwd, [C.byref(P), self.code], name, P))
 
-    # ------------------------------------------------------------------ the plan
-    def _build(self) -> None:
-        eng, P = self.eng, self.eng.params
-        F, E, D, S, M, B, T, H = self.F, self.E, self.D, self.S, self.M, self.B, self.T, self.H
-        dt, L = self.dt, N.lib()
-        hd_s, hd_c = E // H, D // H
-        cap = self.cap
-        f32 = torch.float32
-
-        # ---- AdaLN condition MLPs for the WHOLE model: one silu launch + one grouped GEMM (cond_mlp.2)
+    def _cond_mods(self, split: bool = False) -> Dict[str, torch.Tensor]:
+        """AdaLN condition MLPs for the WHOLE model: silu launch + grouped GEMM (cond_mlp.2); returns prefix -> [M, 2d] (w | b).
+        `split`: the modules the first launch of the layer needs (AdaLN_0 of layer 0) go first on the main stream, all the others run
+        on lane 1 beside the self-attention and are joined by the caller (self._join(1)) before their first use."""
+        P, F, E, D, M, L = self.eng.params, self.F, self.E, self.D, self.M, N.lib()
         mods: Dict[str, torch.Tensor] = {}
-        if self.adaln:
-            inst = []
-            for l in range(self.L):
-                pre = f"blocks.{l}."
-                for i in range(F):
-                    inst += [(f"{pre}ln.exp.{i}.0.", E), (f"{pre}ln.exp.{i}.2.", E)]
-                for i in range(F):
-                    inst.append((f"{pre}ln_cross.{i}.", D))
+        if not self.adaln:
+            return mods
+        first, rest = [], []
+        for l in range(self.L):
+            pre = f"blocks.{l}."
             for i in range(F):
-                inst.append((f"ln.{i}.", E))
+                (first if l == 0 else rest).append((f"{pre}ln.exp.{i}.0.", E))
+                rest.append((f"{pre}ln.exp.{i}.2.", E))
+            for i in range(F):
+                rest.append((f"{pre}ln_cross.{i}.", D))
+        for i in range(F):
+            rest.append((f"ln.{i}.", E))
+
+        def emit(inst, tag):
             silu_groups, gemm_groups = [], []
             for pre, d in inst:
                 hid = self._buf(M, 2 * d)
@@ -307,10 +335,37 @@ class Plan:
                 arr = (N.SeaSiluGroup * len(chunk))()
                 for g, (w1, b1, hid) in zip(arr, chunk):
                     g.w1, g.b1, g.Hid, g.K2, g.ld = w1.data_ptr(), b1.data_ptr(), hid.data_ptr(), hid.shape[1], hid.stride(0)
-                rec = _Rec(L.sea_silu_outer, [arr, len(chunk), None, M, self.code], "adaln.silu", arr)
+                rec = self._rec(L.sea_silu_outer, [arr, len(chunk), None, M, self.code], "adaln.silu" + tag, arr)
                 self._c_patches.append((rec.args, 2))
                 self._cur.append(rec)
-            self._gemm(gemm_groups, "adaln.cond_gemm")
+            self._gemm(gemm_groups, "adaln.cond_gemm" + tag)
+
+        if not split:
+            emit(first + rest, "")
+            return mods
+        emit(first, ".first")
+        self._fork(1)
+        emit(rest, ".rest")
+        self._end_lane()
+        return mods
+
+    # ------------------------------------------------------------------ the plan
+    def _build(self) -> None:
+        eng, P = self.eng, self.eng.params
+        F, E, D, S, M, B, T, H = self.F, self.E, self.D, self.S, self.M, self.B, self.T, self.H
+        dt, L = self.dt, N.lib()
+        hd_s, hd_c = E // H, D // H
+        cap = self.cap
+        f32 = torch.float32
+
+        # Optional lanes (parallel graph branches) for independent work — SEA_PLAN_LANES: "cond" = the condition MLPs the first launch does
+        # not need, "all" = also every finished field's MLP beside the remaining exchange stages.  Off by default: measured at cfg2 the
+        # cross-branch dependencies of a captured HIP graph cost more than the overlap gains (0.344 ms none, 0.371 cond, 0.395 all).
+        mode = os.environ.get("SEA_PLAN_LANES", "none") if type(self) is Plan else "none"
+        lanes = mode == "all" and F >= 2 and eng.model.add_info_after_cross
+        split_cond = mode in ("cond", "all") and self.adaln
+        mods = self._cond_mods(split=split_cond)
+        cond_joined = not split_cond
 
         def norm_params(pre, d):
             if self.adaln:
@@ -338,9 +393,11 @@ class Plan:
         hg = [self._buf(M, S) for _ in range(F)]
         self.ws = dict(xr=xr, xa=xa, n_e=n_e, att_e=att_e, hbuf=hbuf, hg=hg)
 
+        xm = [self._buf(M, E) for _ in range(F)] if lanes else xa
         first = True  # the residual stream still lives in the caller's x [B,T,F,E]
         for l in range(self.L):
             pre = f"blocks.{l}."
+            last = l == self.L - 1
             if first and not eng.model.add_info_after_cross:
                 # the info-bottleneck add comes first and must not modify the caller's tensor: copy x into xr
                 for i in range(F):
@@ -373,6 +430,9 @@ class Plan:
                 groups.append(g)
             self._gemm(groups, "self.out_proj")
             first = False
+            if not cond_joined:  # everything below reads modulations computed on lane 1
+                self._join(1)
+                cond_joined = True
             # -- state exchange (Gauss-Seidel over i, models/temporal.py:187-192)
             if F > 1:
                 self._gemm([dict(A=xa[j], W=P.act(f"{pre}cross_down.{j}.weight"), bias=P.f32_vec(f"{pre}cross_down.{j}.bias"), C32=dn[j])
@@ -395,23 +455,197 @@ class Plan:
                     self._gemm([dict(A=gp[0], W=P.act(f"{pre}cross_up.{i}.weight"), bias=P.f32_vec(f"{pre}cross_up.{i}.bias"),
                                      bias_scale=float(F - 1), n_seg=F - 1, a_seg_stride=M * D, R=xr[i], C32=xr[i],
                                      Cact=(xa[i] if i < F - 1 else None))], f"cross{i}.up_sum")
+                    if lanes:
+                        # x_i is final for the exchange: its info-bottleneck add, MLP, proj (and final norm) run on their own lane beside the
+                        # remaining Gauss-Seidel stages; the last field stays on the main stream.  fc2 writes xm, not xa: the main stream
+                        # still reads xa[i] (down_new) while the lane runs.
+                        if i < F - 1:
+                            self._fork(2 + i)
+                        self._ib(pre, [xr[i]])
+                        self._mlp_proj(pre, [i], xr, xm, n_e, hbuf, hg, mods, last, tag=f".f{i}")
+                        if i < F - 1:
+                            self._end_lane()
                     if i < F - 1:
                         self._gemm([dict(A=xa[i], W=P.act(f"{pre}cross_down.{i}.weight"), bias=P.f32_vec(f"{pre}cross_down.{i}.bias"), C32=dn[i])],
                                    f"cross{i}.down_new")
                         self._norm([dict(X=dn[i], Yact=nd_new[i], **norm_params(f"{pre}ln_cross.{i}.", D))], D, f"cross{i}.norm_new")
+            if lanes:
+                for i in range(F - 1):
+                    self._join(2 + i)
+                continue
             if eng.model.add_info_after_cross:
                 self._ib(pre, xr)
-            # -- MLP: x_i += W2 gelu(LN(W1 AdaLN_2(x_i))) ; x_i = proj_i(x_i)
-            self._norm([dict(X=xr[i], Yact=n_e[i], **norm_params(f"{pre}ln.exp.{i}.2.", E)) for i in range(F)], E, "mlp.adaln2")
+            self._mlp_proj(pre, list(range(F)), xr, xa, n_e, hbuf, hg, mods, False)
+        if not lanes:
+            # -- final per-field norm, written straight into out[B,T,F,E]
+            self._norm([dict(X=xr[i], Y32=xr[i], ldy32=FE, Y_is_out=i * E * 4, **norm_params(f"ln.{i}.", E)) for i in range(F)], E, "final.norm")
+
+    def _mlp_proj(self, pre, fields, xr, xm, n_e, hbuf, hg, mods, final_norm, tag="") -> None:
+        """x_i += W2 gelu(LN(W1 AdaLN_2(x_i))) ; x_i = proj_i(x_i) for the listed fields (models/temporal.py:143-146), optionally followed
+        by the model's final per-field norm written straight into out (models/temporal.py:412-415)."""
+        P, E, S, FE = self.eng.params, self.E, self.S, self.F * self.E
+
+        def norm_params(p_, d):
+            if self.adaln:
+                return dict(mod=mods[p_], gamma=P.f32_vec(p_ + "weight"), beta=P.f32_vec(p_ + "bias"))
+            return dict(gamma=P.f32_vec(p_ + "weight"))
+
+        self._norm([dict(X=xr[i], Yact=n_e[i], **norm_params(f"{pre}ln.exp.{i}.2.", E)) for i in fields], E, "mlp.adaln2" + tag)
+        self._gemm([dict(A=n_e[i], W=P.act(f"{pre}mlp.{i}.layers.0.weight"), bias=P.f32_vec(f"{pre}mlp.{i}.layers.0.bias"), Cact=hbuf[i])
+                    for i in fields], "mlp.fc1" + tag)
+        self._norm([dict(X=hbuf[i], gamma=P.f32_vec(f"{pre}mlp.{i}.layers.1.weight"), beta=P.f32_vec(f"{pre}mlp.{i}.layers.1.bias"), Yact=hg[i])
+                    for i in fields], S, "mlp.ln_gelu" + tag, x_is_act=True, gelu=True)
+        self._gemm([dict(A=hg[i], W=P.act(f"{pre}mlp.{i}.layers.3.weight"), bias=P.f32_vec(f"{pre}mlp.{i}.layers.3.bias"), R=xr[i], Cact=xm[i])
+                    for i in fields], "mlp.fc2" + tag)
+        self._gemm([dict(A=xm[i], W=P.act(f"{pre}proj.{i}.weight"), bias=P.f32_vec(f"{pre}proj.{i}.bias"), C32=xr[i]) for i in fields], "proj" + tag)
+        if final_norm:
+            self._norm([dict(X=xr[i], Y32=xr[i], ldy32=FE, Y_is_out=i * E * 4, **norm_params(f"ln.{i}.", E)) for i in fields], E, "final.norm" + tag)
+
+    # ------------------------------------------------------------------ fused plan (row-local chains, sea_rowchain)
+    def _can_fuse(self) -> bool:
+        """The inference plan runs everything between two attention launches as one sea_rowchain launch when the widths fit its
+        LDS tiles (E, D multiples of 64 up to 256).  Opt-in with SEA_FUSED=1: measured at cfg2 (profiles/) the chains are still slower than the
+        launch-per-operator plan — every stage pays a cold ~1.5 us memory round trip for its weights with one wave per SIMD to hide it."""
+        m = self.eng.model
+        if type(self) is not Plan or os.environ.get("SEA_FUSED", "0") != "1":
+            return False
+        ok_w = lambda w: w % 64 == 0 and w <= N.CHAIN_MAX_WIDTH
+        return (ok_w(self.E) and ok_w(self.D) and 2 * self.D <= N.CHAIN_MAX_WIDTH and self.F >= 2 and m.add_info_after_cross
+                and m.ib_hidden <= 8)
+
+    def _chain(self, groups: List[List[dict]], name: str) -> None:
+        prog = ops.ChainProgram(groups, self.eng.device)
+        L = prog.launch_struct(self.M, self.T, self.pos0, self.cap, self.H)
+        self._x_patches.append((L, "x", 0))
+        self._out_patches.append((L, "out", 0))
+        self._c_patches.append((L, "cond"))
+        self._pos_structs.append(L)
+        self._cur.append(self._rec(N.lib().sea_rowchain, [C.byref(L), prog.host, self.code], name, (prog, L)))
+
+    def _build_fused(self) -> None:
+        eng, P = self.eng, self.eng.params
+        F, E, D, S, M, B, T, H = self.F, self.E, self.D, self.S, self.M, self.B, self.T, self.H
+        hd_s, hd_c = E // H, D // H
+        cap, f32 = self.cap, torch.float32
+        FE = F * E
+        mods = self._cond_mods()
+
+        def norm(pre, **kw):
+            d = dict(norm=1, gamma=P.f32_vec(pre + "weight"), **kw)
+            if self.adaln:
+                d.update(beta=P.f32_vec(pre + "bias"), mod=mods[pre])
+            return d
+
+        def qkv_stages(a_slot, K, W, bias, col0, hd, rope, **outs):
+            """[rows, n] = A . W^T + bias through RoPE into the attention layouts, in column chunks of at most 256"""
+            st, n, c = [], W.shape[0], 0
+            while c < n:
+                w = min(N.CHAIN_MAX_WIDTH, n - c)
+                st.append(dict(a_slot=a_slot, N=w, K=K, W=W[c:c + w], bias=bias[c:c + w], qkv=1, col0=col0 + c, hd=hd, rope=rope,
+                               q_scale=float(hd) ** -0.5, **outs))
+                c += w
+            return st
+
+        xr = [self._buf(M, E, dtype=f32) for _ in range(F)]     # fp32 residual stream
+        xa = [self._buf(M, E) for _ in range(F)]
+        n_e = [self._buf(M, E) for _ in range(F)]
+        att_e = [self._buf(M, E) for _ in range(F)]
+        Qs = [self._buf(B, H, T, hd_s) for _ in range(F)]
+        Ks = [[self._buf(B, H, cap, hd_s, zero=True) for _ in range(F)] for _ in range(self.L)]
+        Vs = [[self._buf(B, H, hd_s, cap, zero=True) for _ in range(F)] for _ in range(self.L)]
+        Qc = [[self._buf(B, H, T, hd_c) for _ in range(F)] for _ in range(F)]
+        Kc = [[[self._buf(B, H, cap, hd_c, zero=True) for _ in range(F)] for _ in range(F)] for _ in range(self.L)]
+        Vc = [[[self._buf(B, H, hd_c, cap, zero=True) for _ in range(F)] for _ in range(F)] for _ in range(self.L)]
+        att_c = [self._buf(M, D) for _ in range(F - 1)]
+        hbuf = [self._buf(M, S) for _ in range(F)]
+        hg = [self._buf(M, S) for _ in range(F)]
+        self.ws = dict(xr=xr, xa=xa, n_e=n_e, att_e=att_e, hbuf=hbuf, hg=hg)
+        rope_s, rope_c = eng.rope_self, eng.rope_cross
+
+        def self_qkv(l, i, a_slot):
+            pre = f"blocks.{l}."
+            return qkv_stages(a_slot, E, P.act(f"{pre}attn.self.{i}.q.weight", 3 * E), P.f32_vec(f"{pre}attn.self.{i}.q.bias", 3 * E), 0, hd_s, rope_s,
+                              Qout=Qs[i], Kout=Ks[l][i], Vtout=Vs[l][i])
+
+        def cross_kv(l, iq, j, a_slot):
+            ca = f"blocks.{l}.cross_attn.{iq}.{j}."
+            return qkv_stages(a_slot, D, P.act(ca + "k.weight", 2 * D), P.f32_vec(ca + "k.bias", 2 * D), D, hd_c, rope_c, Kout=Kc[l][iq][j], Vtout=Vc[l][iq][j])
+
+        # ---- layer 0 entry: AdaLN_0 of the caller's x, self-attention q/k/v
+        self._chain([[dict(kind=1, N=E, X_off=i * E * 4, ldx=FE, norm_slot=0, **norm(f"blocks.0.ln.exp.{i}.0."))] + self_qkv(0, i, 0) for i in range(F)],
+                    "self.adaln0_qkv")
+        for l in range(self.L):
+            pre = f"blocks.{l}."
+            self._attn([dict(Q=Qs[i], K=Ks[l][i], Vt=Vs[l][i], O=att_e[i]) for i in range(F)], hd_s, E, "self.attention")
+            # ---- x_i += proj(attn); down-projection, ln_cross; every cross-attention projection that reads the OLD x_i
+            groups = []
+            for i in range(F):
+                res = dict(R_off=i * E * 4, ldr=FE) if l == 0 else dict(R=xr[i])
+                g = [dict(kind=2, N=E, X=att_e[i], raw_slot=0),
+                     dict(a_slot=0, N=E, K=E, W=P.act(f"{pre}attn.self.{i}.projection.weight"), C32=xr[i], raw_slot=1, **res),
+                     dict(a_slot=1, N=D, K=E, W=P.act(f"{pre}cross_down.{i}.weight"), bias=P.f32_vec(f"{pre}cross_down.{i}.bias"), norm_slot=2,
+                          **norm(f"{pre}ln_cross.{i}."))]
+                for j in range(F):
+                    if j != i:
+                        ca = f"{pre}cross_attn.{i}.{j}."
+                        g += qkv_stages(2, D, P.act(ca + "q.weight"), P.f32_vec(ca + "q.bias"), 0, hd_c, rope_c, Qout=Qc[i][j])
+                for iq in range(i):  # pairs (iq, i) with iq < i read field i before its own update
+                    g += cross_kv(l, iq, i, 2)
+                groups.append(g)
+            self._chain(groups, "self.proj_down_qkv")
+            # ---- state exchange, Gauss-Seidel over i (models/temporal.py:187-192)
+            ibp = {k: P.f32_vec(f"{pre}ib.layers.{n}") for k, n in (("ib_w1", "0.weight"), ("ib_b1", "0.bias"), ("ib_lnw", "1.weight"), ("ib_lnb", "1.bias"),
+                                                                   ("ib_b2", "3.bias"))}
+            ibp["ib_w2"] = P.f32(f"{pre}ib.layers.3.weight")
+            ibp["ib_h"] = eng.model.ib_hidden
+            for i in range(F):
+                others = [j for j in range(F) if j != i]
+                self._attn([dict(Q=Qc[i][j], K=Kc[l][i][j], Vt=Vc[l][i][j], O=att_c[s]) for s, j in enumerate(others)], hd_c, D, f"cross{i}.attention")
+                g = []
+                for s, j in enumerate(others):
+                    slot = s & 1
+                    g.append(dict(kind=2, N=D, X=att_c[s], raw_slot=slot))
+                    last = s == len(others) - 1
+                    st = dict(a_slot=slot, N=D, K=D, W=P.act(f"{pre}cross_attn.{i}.{j}.projection.weight"), act=1)
+                    if len(others) == 1:
+                        st.update(raw_slot=2)
+                    elif s == 0:
+                        st.update(sum_op=1)
+                    elif last:
+                        st.update(sum_op=2, raw_slot=2)
+                    else:
+                        st.update(sum_op=3)
+                    g.append(st)
+                # x_i += cross_up(sum_j gelu(.)) ; copy for the down-projection BEFORE the info-bottleneck add ; x_i += ib ; AdaLN_2
+                g.append(dict(a_slot=2, N=E, K=D, W=P.act(f"{pre}cross_up.{i}.weight"), bias=P.f32_vec(f"{pre}cross_up.{i}.bias"), bias_scale=float(F - 1),
+                              R=xr[i], raw_slot=0, C32=xr[i], Nact=n_e[i], **ibp, **norm(f"{pre}ln.exp.{i}.2.")))
+                if i < F - 1:
+                    g.append(dict(a_slot=0, N=D, K=E, W=P.act(f"{pre}cross_down.{i}.weight"), bias=P.f32_vec(f"{pre}cross_down.{i}.bias"), norm_slot=1,
+                                  **norm(f"{pre}ln_cross.{i}.")))
+                    for iq in range(i + 1, F):  # pairs (iq, i) with iq > i read the NEW x_i
+                        g += cross_kv(l, iq, i, 1)
+                self._chain([g], f"cross{i}.proj_up_down_kv")
+            # ---- MLP: x_i += W2 gelu(LN(W1 AdaLN_2(x_i)))
             self._gemm([dict(A=n_e[i], W=P.act(f"{pre}mlp.{i}.layers.0.weight"), bias=P.f32_vec(f"{pre}mlp.{i}.layers.0.bias"), Cact=hbuf[i])
                         for i in range(F)], "mlp.fc1")
             self._norm([dict(X=hbuf[i], gamma=P.f32_vec(f"{pre}mlp.{i}.layers.1.weight"), beta=P.f32_vec(f"{pre}mlp.{i}.layers.1.bias"), Yact=hg[i])
                         for i in range(F)], S, "mlp.ln_gelu", x_is_act=True, gelu=True)
             self._gemm([dict(A=hg[i], W=P.act(f"{pre}mlp.{i}.layers.3.weight"), bias=P.f32_vec(f"{pre}mlp.{i}.layers.3.bias"), R=xr[i], Cact=xa[i])
                         for i in range(F)], "mlp.fc2")
-            self._gemm([dict(A=xa[i], W=P.act(f"{pre}proj.{i}.weight"), bias=P.f32_vec(f"{pre}proj.{i}.bias"), C32=xr[i]) for i in range(F)], "proj")
-        # -- final per-field norm, written straight into out[B,T,F,E]
-        self._norm([dict(X=xr[i], Y32=xr[i], ldy32=FE, Y_is_out=i * E * 4, **norm_params(f"ln.{i}.", E)) for i in range(F)], E, "final.norm")
+            # ---- x_i = proj_i(x_i) ; then the next layer's AdaLN_0 + q/k/v, or the final per-field norm straight into out
+            groups = []
+            for i in range(F):
+                g = [dict(kind=2, N=E, X=xa[i], raw_slot=0)]
+                st = dict(a_slot=0, N=E, K=E, W=P.act(f"{pre}proj.{i}.weight"), bias=P.f32_vec(f"{pre}proj.{i}.bias"))
+                if l == self.L - 1:
+                    st.update(N32_off=i * E * 4, ldn32=FE, **norm(f"ln.{i}."))
+                    g.append(st)
+                else:
+                    st.update(C32=xr[i], norm_slot=1, **norm(f"blocks.{l + 1}.ln.exp.{i}.0."))
+                    g.append(st)
+                    g += self_qkv(l + 1, i, 1)
+                groups.append(g)
+            self._chain(groups, "proj_final_norm" if l == self.L - 1 else "proj_adaln0_qkv")
 
     def _ib(self, pre: str, xr: List[torch.Tensor], drop=None) -> None:
         P = self.eng.params
@@ -430,7 +664,7 @@ class Plan:
         ib.b2 = P.f32_vec(pre + "ib.layers.3.bias").data_ptr()
         ib.M, ib.E, ib.h = self.M, self.E, self.eng.model.ib_hidden
         self._c_patches.append((ib, "c"))
-        self._cur.append(_Rec(N.lib().sea_ib_add, [C.byref(ib)], "ib_add", ib))
+        self._cur.append(self._rec(N.lib().sea_ib_add, [C.byref(ib)], "ib_add", ib))
 
     # ------------------------------------------------------------------ binding and replay
     def bind(self, x: torch.Tensor, ib: torch.Tensor, out: torch.Tensor) -> None:
@@ -464,28 +698,55 @@ class Plan:
         assert pos0 + self.T <= self.cap
         self.pos0 = pos0
         for s in self._pos_structs:
-            if isinstance(s, N.SeaQkvCommon):
+            if isinstance(s, (N.SeaQkvCommon, N.SeaChainLaunch)):
                 s.pos0 = pos0
             else:
                 s.q_pos0, s.Tk = pos0, pos0 + self.T
 
-    def run(self) -> None:
-        stream = N.stream_ptr()
+    def run(self, concurrent: bool = False) -> None:
+        """Replay the launch list.  Sequentially on the current stream (record order is a valid order), or — `concurrent` — with every
+        lane on its own stream, forked from / joined to the current stream by events; inside a graph capture the lanes become
+        parallel branches of the graph."""
+        main = torch.cuda.current_stream()
+        stream = main.cuda_stream
+        if not concurrent:
+            for r in self.records:
+                if r.fn is None:
+                    continue
+                rc = r.fn(*r.args, stream)
+                if rc != 0:
+                    N.check(rc, r.name)
+            return
+        open_lanes = set()
         for r in self.records:
-            rc = r.fn(*r.args, stream)
+            if r.fn is None:
+                st = self._lane_streams.get(r.lane)
+                if st is None:
+                    st = self._lane_streams[r.lane] = torch.cuda.Stream(device=self.eng.device)
+                if r.name == "fork":
+                    st.wait_stream(main)
+                    open_lanes.add(r.lane)
+                else:
+                    main.wait_stream(st)
+                    open_lanes.discard(r.lane)
+                continue
+            rc = r.fn(*r.args, stream if r.lane == 0 else self._lane_streams[r.lane].cuda_stream)
             if rc != 0:
                 N.check(rc, r.name)
+        for lane in open_lanes:  # every lane rejoins (a graph capture requires it)
+            main.wait_stream(self._lane_streams[lane])
 
     def time_records(self, iters: int = 10) -> List[Tuple[str, float]]:
         """Average device time of every launch of the plan, in milliseconds, from HIP events recorded on the launch stream
         around each launch (diagnostics / bench roofline)."""
         stream = N.stream_ptr()
-        n = len(self.records)
+        recs = [r for r in self.records if r.fn is not None]
+        n = len(recs)
         tot = [0.0] * n
         for _ in range(iters):
             evs = [torch.cuda.Event(enable_timing=True) for _ in range(n + 1)]
             evs[0].record()
-            for k, r in enumerate(self.records):
+            for k, r in enumerate(recs):
                 rc = r.fn(*r.args, stream)
                 if rc != 0:
                     N.check(rc, r.name)
@@ -493,7 +754,7 @@ class Plan:
             torch.cuda.synchronize()
             for k in range(n):
                 tot[k] += evs[k].elapsed_time(evs[k + 1])
-        return [(r.name, t / iters) for r, t in zip(self.records, tot)]
+        return [(r.name, t / iters) for r, t in zip(recs, tot)]
 
 
 def _fill_gemm(g, A, W, bias=None, R=None, C32=None, Cact=None, n_seg=1, a_seg_stride=0, act=0, bias_scale=1.0, ldr=None,
@@ -677,7 +938,7 @@ class TemporalEngine:
             torch.cuda.current_stream().wait_stream(side)
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
-                p.run()
+                p.run(concurrent=os.environ.get("SEA_LANES", "1") != "0")
             hit = (graph, out, p, x, ib)
             self._graphs[key] = hit
         hit[0].replay()
