@@ -243,10 +243,25 @@ __global__ __launch_bounds__(256) void ib_add_kernel(const SeaIbParams P) {
     for (int e0 = lane * 4; e0 < P.E; e0 += 256) {
         float o[4];
         load4(P.b2 + e0, o);
-        for (int k = 0; k < h; ++k) {
-            const float hk = __shfl(hid, k);
+        if ((h & 3) == 0) {
+            // rows of w2 are whole 16-byte chunks: request all of them before the first use (one memory round trip, not h of them)
+            for (int k0 = 0; k0 < h; k0 += 4) {
+                float w[4][4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] += P.w2[(int64_t)(e0 + e) * h + k] * hk;
+                for (int e = 0; e < 4; ++e) load4(P.w2 + (int64_t)(e0 + e) * h + k0, w[e]);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float hk = __shfl(hid, k0 + k);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] += w[e][k] * hk;
+                }
+            }
+        } else {
+            for (int k = 0; k < h; ++k) {
+                const float hk = __shfl(hid, k);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] += P.w2[(int64_t)(e0 + e) * h + k] * hk;
+            }
         }
         for (int f = 0; f < P.n_fields; ++f) {
             float* x = P.X[f] + (int64_t)row * P.ldx + e0;
@@ -269,7 +284,7 @@ extern "C" int sea_ib_add(const SeaIbParams* params, void* stream) {
     SEA_REQUIRE(P.n_fields >= 1 && P.n_fields <= 8 && P.M >= 1 && P.E >= 4 && P.E % 4 == 0 && P.h >= 1 && P.h <= 64 && P.ldx >= P.E && P.ldx % 4 == 0,
                 "sea_ib_add: bad sizes n_fields=%d M=%d E=%d h=%d ldx=%d", P.n_fields, P.M, P.E, P.h, P.ldx);
     SEA_REQUIRE(P.c && P.w1 && P.b1 && P.lnw && P.lnb && P.w2 && P.b2, "sea_ib_add: null parameter pointer");
-    SEA_REQUIRE(sea_aligned16(P.b2), "sea_ib_add: b2 must be 16-byte aligned");
+    SEA_REQUIRE(sea_aligned16(P.b2) && ((P.h & 3) != 0 || sea_aligned16(P.w2)), "sea_ib_add: b2 (and w2 when h %% 4 == 0) must be 16-byte aligned");
     for (int f = 0; f < P.n_fields; ++f) SEA_REQUIRE(P.X[f] && sea_aligned16(P.X[f]), "sea_ib_add: X[%d] null or misaligned", f);
     ib_add_kernel<<<dim3((P.M + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream)>>>(P);
     SEA_CHECK_LAUNCH("sea_ib_add");
