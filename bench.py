@@ -243,6 +243,15 @@ def main():
     dom_flops = kernel_flops(name, B, T, F, E, H, D, S)
     achieved = dom_flops / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
 
+    # HBM bytes per launch of the dominant kernel, from the committed PMC profile of this same workload (separate --pmc passes, see
+    # profiles/README.md); null when the workload or the plan differs from the profiled one
+    traffic, traffic_src = None, None
+    prof = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_forward_cfg2_pmc_traffic.json")
+    if os.path.exists(prof) and (B, T, F, E, args.dtype) == (1, 2024, 3, 256, "bf16"):
+        rec = json.load(open(prof))["launches"].get(name)
+        if rec is not None:
+            traffic, traffic_src = rec["hbm_bytes"], "profiles/r01_forward_cfg2_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, bytes per launch)"
+
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = world * B * args.steps / elapsed
@@ -258,7 +267,7 @@ def main():
             "model_algorithmic_gflop_per_step": gflop,
             "model_mfma_frac": gflop / (ms_per_step * 1e-3) / 1e3 / PEAK_BF16_TFLOPS,
             "roofline": {"kernel": name, "bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_BF16_TFLOPS, "traffic": None,
+                         "frac": achieved / PEAK_BF16_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
                          "launch_ms": dom_ms, "launch_gflop": dom_flops / 1e9, "device_ms_all_launches": total_ms,
                          "timing": "HIP events around every launch of the plan, separate instrumented pass"},
             "launch_breakdown_ms": {n: round(t, 4) for n, t in times},
