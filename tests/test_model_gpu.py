@@ -263,3 +263,29 @@ def test_shipped_multiphase_dims_forward_bf16():
     assert rel_l2(out.numpy(), ref.numpy()) < BF16_TOL
     roll = rollout(m, x[:, :1].cuda(), ib.cuda(), 6, mode="kv").cpu()
     assert rel_l2(roll.numpy(), ref_roll.numpy()) < 2 * BF16_TOL
+
+
+@pytest.mark.parametrize("env,graphed", [({"SEA_FUSED": "1"}, False), ({"SEA_PLAN_LANES": "all"}, True), ({"SEA_PLAN_LANES": "cond"}, True)])
+@pytest.mark.parametrize("dtype,tol", [("fp32", 2e-6), ("bf16", 2e-2)])
+def test_optional_plans_match_default_plan(env, graphed, dtype, tol, monkeypatch):
+    """The opt-in plans (row-local chains in one launch; parallel graph branches) compute what the default launch list computes —
+    checked on the oracle too, at widths the chain kernel supports (E=128, D=64; two layers; B=2 so rows cross a trajectory)."""
+    cfg = O.OracleConfig(2, 128, 4, 96, 8, 0, 3, 2, True, "adaln")
+    x, _, ib = recipe_inputs(2, 70, cfg, seed=5)
+    xg, ibg = x.to("cuda:0").contiguous(), ib.to("cuda:0").contiguous()
+    with torch.no_grad():
+        ref = build(cfg, dtype)(xg, ibg)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    m = build(cfg, dtype)
+    with torch.no_grad():
+        eng = m.engine()
+        out = eng.forward_graphed(xg, ibg).clone() if graphed else m(xg, ibg)
+        plan = eng.plan(2, 70, "full")
+    if "SEA_FUSED" in env:
+        assert plan.fused and any(r.name.startswith("cross0.proj_up_down_kv") for r in plan.records)
+    else:
+        assert any(r.fn is None for r in plan.records)  # fork / join markers present
+    assert rel_l2(out.cpu().numpy(), ref.cpu().numpy()) < tol
+    if dtype == "fp32":
+        assert rel_l2(out.cpu().numpy(), O.model_forward(x, ib, recipe_params(cfg), cfg).numpy()) < FP32_TOL
