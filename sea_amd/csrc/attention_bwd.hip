@@ -21,12 +21,8 @@ __device__ __forceinline__ uint4 frag_T<__bf16>(const char* tile, int pitch, int
     typedef s16x4b __attribute__((address_space(3))) * lds_p;
     const s16x4b lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(base));
     const s16x4b hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(base + 4 * pitch));
-    uint4 out;
-    out.x = (unsigned)(unsigned short)lo[0] | ((unsigned)(unsigned short)lo[1] << 16);
-    out.y = (unsigned)(unsigned short)lo[2] | ((unsigned)(unsigned short)lo[3] << 16);
-    out.z = (unsigned)(unsigned short)hi[0] | ((unsigned)(unsigned short)hi[1] << 16);
-    out.w = (unsigned)(unsigned short)hi[2] | ((unsigned)(unsigned short)hi[3] << 16);
-    return out;
+    const uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);   // already packed pairs: no repacking VALU
+    return make_uint4(l2.x, l2.y, h2.x, h2.y);
 }
 template <>
 __device__ __forceinline__ uint4 frag_T<float>(const char* tile, int pitch, int m0, int c0, int lane) {
@@ -95,7 +91,9 @@ __device__ __forceinline__ void unrope(float& e, float& o, const float2 cs) {
 }
 
 // ---------------------------------------------------------------------------------------------- dQ (+ delta)
-template <typename T, int HD>
+// DROP and (per tile) MASK are compile-time: both kernels are VALU-issue-bound (PMC: VALU busy 80-100 %), so the un-dropped,
+// off-diagonal tile — the common case — carries no select, no dropout factor and one v_fma + one v_exp per probability.
+template <typename T, int HD, bool DROP>
 __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const SeaAttnBwdParams P) {
     using C = BwdCfg<T, HD>;
     __shared__ __attribute__((aligned(16))) char smem[4 * C::TILE];  // 2 buffers x (K tile, V tile)
@@ -152,6 +150,57 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const SeaAttnBwdParams
 #pragma unroll
         for (int be = 0; be < C::NB; ++be) frag_off[kc][be] = (kc * C::CK + (r >> 2) * (4 * C::NB) + be * 4 + (r & 3)) * C::PITCH + g * 16;
 
+    constexpr float LOG2E = 1.4426950408889634f;
+    const float nlse2 = -lse * LOG2E;   // P = exp(s - lse) = 2^(s log2e - lse log2e)
+    auto tile = [&](const char* sK, const char* sV, int kt, auto mask_tag) {
+        constexpr bool MASK = decltype(mask_tag)::value;
+        f32x4 ds[C::KCH][C::NB];
+#pragma unroll
+        for (int kc = 0; kc < C::KCH; ++kc) {
+#pragma unroll
+            for (int be = 0; be < C::NB; ++be) {
+                f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int c = 0; c < C::NCH; ++c) {
+                    uint4 ak = make_uint4(0, 0, 0, 0), av = make_uint4(0, 0, 0, 0);
+                    if (c * C::CK + g * C::EPC < HD) {
+                        ak = *reinterpret_cast<const uint4*>(sK + frag_off[kc][be] + c * C::CK * (int)sizeof(T));
+                        av = *reinterpret_cast<const uint4*>(sV + frag_off[kc][be] + c * C::CK * (int)sizeof(T));
+                    }
+                    mma16<T>(ak, qf[c], s);
+                    mma16<T>(av, dof[c], dp);
+                }
+                float dfac[4] = {1.f, 1.f, 1.f, 1.f};  // dropout: dP = D (dO V^T), D = keep * scale
+                if constexpr (DROP) {
+                    const int key0 = kt * 64 + kc * C::CK + g * C::EPC + be * 4;
+                    const uint32_t w = drop_word(P.drop.seed, drop_stream, (uint32_t)q_idx, (uint32_t)(key0 >> 2));
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) dfac[q] = drop_factor(w, q, P.drop.thr, drop_sc);
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float p = __builtin_amdgcn_exp2f(fmaf(s[q], LOG2E, nlse2));
+                    if constexpr (MASK) {
+                        const int key = kt * 64 + kc * C::CK + g * C::EPC + be * 4 + q;
+                        if (!(key <= limit && key < Tk)) p = 0.f;
+                    }
+                    if constexpr (DROP) ds[kc][be][q] = p * (dp[q] * dfac[q] - delta);
+                    else ds[kc][be][q] = p * (dp[q] - delta);
+                }
+            }
+        }
+        // dQ^T[d][q] += K^T[d][key] . dS^T[key][q]
+#pragma unroll
+        for (int kc = 0; kc < C::KCH; ++kc) {
+            const uint4 bfrag = pack_frag<T>(ds[kc][0], ds[kc][C::NB - 1]);
+#pragma unroll
+            for (int d = 0; d < C::NDB; ++d) {
+                const uint4 a = frag_T<T>(sK, C::PITCH, kc * C::CK, d * 16, lane);
+                mma16<T>(a, bfrag, dq[d]);
+            }
+        }
+    };
+
     TileStager<T, HD> stK, stV;
     stK.load(Kg, HD, 0, Tk, tid);
     stV.load(Vg, HD, 0, Tk, tid);
@@ -168,51 +217,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const SeaAttnBwdParams
             stV.load(Vg, HD, (kt + 1) * 64, Tk, tid);
         }
         if (kt * 64 <= wave_last) {
-            const bool need_mask = !(kt * 64 + 63 <= wave_first && kt * 64 + 63 < Tk);
-            f32x4 ds[C::KCH][C::NB];
-#pragma unroll
-            for (int kc = 0; kc < C::KCH; ++kc) {
-#pragma unroll
-                for (int be = 0; be < C::NB; ++be) {
-                    f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                    for (int c = 0; c < C::NCH; ++c) {
-                        uint4 ak = make_uint4(0, 0, 0, 0), av = make_uint4(0, 0, 0, 0);
-                        if (c * C::CK + g * C::EPC < HD) {
-                            ak = *reinterpret_cast<const uint4*>(sK + frag_off[kc][be] + c * C::CK * (int)sizeof(T));
-                            av = *reinterpret_cast<const uint4*>(sV + frag_off[kc][be] + c * C::CK * (int)sizeof(T));
-                        }
-                        mma16<T>(ak, qf[c], s);
-                        mma16<T>(av, dof[c], dp);
-                    }
-                    float dfac[4] = {1.f, 1.f, 1.f, 1.f};  // dropout: dP = D (dO V^T), D = keep * scale
-                    if (P.drop.thr > 0) {
-                        const int key0 = kt * 64 + kc * C::CK + g * C::EPC + be * 4;
-                        const uint32_t w = drop_word(P.drop.seed, drop_stream, (uint32_t)q_idx, (uint32_t)(key0 >> 2));
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) dfac[q] = drop_factor(w, q, P.drop.thr, drop_sc);
-                    }
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        float p = __expf(s[q] - lse);
-                        if (need_mask) {
-                            const int key = kt * 64 + kc * C::CK + g * C::EPC + be * 4 + q;
-                            if (!(key <= limit && key < Tk)) p = 0.f;
-                        }
-                        ds[kc][be][q] = p * (dp[q] * dfac[q] - delta);
-                    }
-                }
-            }
-            // dQ^T[d][q] += K^T[d][key] . dS^T[key][q]
-#pragma unroll
-            for (int kc = 0; kc < C::KCH; ++kc) {
-                const uint4 bfrag = pack_frag<T>(ds[kc][0], ds[kc][C::NB - 1]);
-#pragma unroll
-                for (int d = 0; d < C::NDB; ++d) {
-                    const uint4 a = frag_T<T>(sK, C::PITCH, kc * C::CK, d * 16, lane);
-                    mma16<T>(a, bfrag, dq[d]);
-                }
-            }
+            if (kt * 64 + 63 <= wave_first && kt * 64 + 63 < Tk) tile(sK, sV, kt, std::false_type{});
+            else tile(sK, sV, kt, std::true_type{});
         }
         if (more) {
             stK.store(smem + ((kt + 1) & 1) * 2 * C::TILE, tid);
@@ -237,7 +243,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const SeaAttnBwdParams
 }
 
 // ---------------------------------------------------------------------------------------------- dK, dV
-template <typename T, int HD>
+template <typename T, int HD, bool DROP>
 __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const SeaAttnBwdParams P) {
     using C = BwdCfg<T, HD>;
     __shared__ __attribute__((aligned(16))) char smem[4 * C::TILE + 2 * 2 * 64 * 4];  // 2 x (Q tile, dO tile) + 2 x (lse, delta)
@@ -284,12 +290,67 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const SeaAttnBwdParam
 #pragma unroll
         for (int be = 0; be < C::NB; ++be) frag_off[qc][be] = (qc * C::CK + (r >> 2) * (4 * C::NB) + be * 4 + (r & 3)) * C::PITCH + g * 16;
 
+    constexpr float LOG2E = 1.4426950408889634f;
+    auto tile = [&](const char* sQ, const char* sO, const float* sL, int qt, auto mask_tag) {
+        constexpr bool MASK = decltype(mask_tag)::value;
+        f32x4 pp[C::KCH][C::NB], ds[C::KCH][C::NB];
+#pragma unroll
+        for (int qc = 0; qc < C::KCH; ++qc) {
+#pragma unroll
+            for (int be = 0; be < C::NB; ++be) {
+                f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int c = 0; c < C::NCH; ++c) {
+                    uint4 aq = make_uint4(0, 0, 0, 0), ao = make_uint4(0, 0, 0, 0);
+                    if (c * C::CK + g * C::EPC < HD) {
+                        aq = *reinterpret_cast<const uint4*>(sQ + frag_off[qc][be] + c * C::CK * (int)sizeof(T));
+                        ao = *reinterpret_cast<const uint4*>(sO + frag_off[qc][be] + c * C::CK * (int)sizeof(T));
+                    }
+                    mma16<T>(aq, kf[c], s);
+                    mma16<T>(ao, vf[c], dp);
+                }
+                const int ql = qc * C::CK + g * C::EPC + be * 4;  // this lane's 4 consecutive queries of the tile
+                const f32x4 l4 = *reinterpret_cast<const f32x4*>(sL + ql);        // -lse * log2e (scaled when staged)
+                const f32x4 d4 = *reinterpret_cast<const f32x4*>(sL + 64 + ql);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float p = __builtin_amdgcn_exp2f(fmaf(s[q], LOG2E, l4[q]));
+                    if constexpr (MASK) {
+                        const int qi = qt * 64 + ql + q;
+                        if (!(qi >= q_min_lane && qi < Tq && k_idx < Tk)) p = 0.f;
+                    }
+                    if constexpr (DROP) {
+                        const uint32_t w = drop_word(P.drop.seed, drop_stream, (uint32_t)(qt * 64 + ql + q), (uint32_t)(k_idx >> 2));
+                        const float dfac = drop_factor(w, k_idx & 3, P.drop.thr, drop_sc);
+                        pp[qc][be][q] = p * dfac;                    // dV = (D P)^T dO
+                        ds[qc][be][q] = p * (dp[q] * dfac - d4[q]);  // dS = P (D dP - delta)
+                    } else {
+                        pp[qc][be][q] = p;
+                        ds[qc][be][q] = p * (dp[q] - d4[q]);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int qc = 0; qc < C::KCH; ++qc) {
+            const uint4 pfrag = pack_frag<T>(pp[qc][0], pp[qc][C::NB - 1]);
+            const uint4 sfrag = pack_frag<T>(ds[qc][0], ds[qc][C::NB - 1]);
+#pragma unroll
+            for (int d = 0; d < C::NDB; ++d) {
+                const uint4 ao = frag_T<T>(sO, C::PITCH, qc * C::CK, d * 16, lane);   // dO^T[d][q]
+                mma16<T>(ao, pfrag, dv[d]);
+                const uint4 aq = frag_T<T>(sQ, C::PITCH, qc * C::CK, d * 16, lane);   // Q^T[d][q]
+                mma16<T>(aq, sfrag, dk[d]);
+            }
+        }
+    };
+
     TileStager<T, HD> stQ, stO;
     float r_lse = 0.f, r_del = 0.f;
     auto load_vec = [&](int qt) {
         if (tid < 64) {
             const int q = qt * 64 + tid;
-            r_lse = q < Tq ? lse_g[q] : 0.f;
+            r_lse = q < Tq ? -lse_g[q] * LOG2E : 0.f;
             r_del = q < Tq ? del_g[q] : 0.f;
         }
     };
@@ -323,54 +384,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const SeaAttnBwdParam
         }
         if (qt * 64 + 63 >= wave_qmin) {  // some query of the tile sees some key of this wave
             const bool need_mask = !(qt * 64 >= wave_qmax_need && qt * 64 + 63 < Tq) || (k_row0 + 15 >= Tk);
-            f32x4 pp[C::KCH][C::NB], ds[C::KCH][C::NB];
-#pragma unroll
-            for (int qc = 0; qc < C::KCH; ++qc) {
-#pragma unroll
-                for (int be = 0; be < C::NB; ++be) {
-                    f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                    for (int c = 0; c < C::NCH; ++c) {
-                        uint4 aq = make_uint4(0, 0, 0, 0), ao = make_uint4(0, 0, 0, 0);
-                        if (c * C::CK + g * C::EPC < HD) {
-                            aq = *reinterpret_cast<const uint4*>(sQ + frag_off[qc][be] + c * C::CK * (int)sizeof(T));
-                            ao = *reinterpret_cast<const uint4*>(sO + frag_off[qc][be] + c * C::CK * (int)sizeof(T));
-                        }
-                        mma16<T>(aq, kf[c], s);
-                        mma16<T>(ao, vf[c], dp);
-                    }
-                    const int ql = qc * C::CK + g * C::EPC + be * 4;  // this lane's 4 consecutive queries of the tile
-                    const f32x4 l4 = *reinterpret_cast<const f32x4*>(sL + ql);
-                    const f32x4 d4 = *reinterpret_cast<const f32x4*>(sL + 64 + ql);
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        float p = __expf(s[q] - l4[q]);
-                        if (need_mask) {
-                            const int qi = qt * 64 + ql + q;
-                            if (!(qi >= q_min_lane && qi < Tq && k_idx < Tk)) p = 0.f;
-                        }
-                        float dfac = 1.f;
-                        if (P.drop.thr > 0) {
-                            const uint32_t w = drop_word(P.drop.seed, drop_stream, (uint32_t)(qt * 64 + ql + q), (uint32_t)(k_idx >> 2));
-                            dfac = drop_factor(w, k_idx & 3, P.drop.thr, drop_sc);
-                        }
-                        pp[qc][be][q] = p * dfac;                    // dV = (D P)^T dO
-                        ds[qc][be][q] = p * (dp[q] * dfac - d4[q]);  // dS = P (D dP - delta)
-                    }
-                }
-            }
-#pragma unroll
-            for (int qc = 0; qc < C::KCH; ++qc) {
-                const uint4 pfrag = pack_frag<T>(pp[qc][0], pp[qc][C::NB - 1]);
-                const uint4 sfrag = pack_frag<T>(ds[qc][0], ds[qc][C::NB - 1]);
-#pragma unroll
-                for (int d = 0; d < C::NDB; ++d) {
-                    const uint4 ao = frag_T<T>(sO, C::PITCH, qc * C::CK, d * 16, lane);   // dO^T[d][q]
-                    mma16<T>(ao, pfrag, dv[d]);
-                    const uint4 aq = frag_T<T>(sQ, C::PITCH, qc * C::CK, d * 16, lane);   // Q^T[d][q]
-                    mma16<T>(aq, sfrag, dk[d]);
-                }
-            }
+            if (need_mask) tile(sQ, sO, sL, qt, std::true_type{});
+            else tile(sQ, sO, sL, qt, std::false_type{});
         }
         if (more) {
             stQ.store(smem + (bi ^ 1) * 2 * C::TILE, tid);
@@ -399,9 +414,14 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const SeaAttnBwdParam
 
 template <typename T, int HD>
 static void launch_bwd(const SeaAttnBwdParams& P, hipStream_t s) {
-    const dim3 block(256);
-    attn_bwd_dq_kernel<T, HD><<<dim3((P.Tq + 63) / 64, P.B * P.H, P.n_problems), block, 0, s>>>(P);
-    attn_bwd_dkv_kernel<T, HD><<<dim3((P.Tk + 63) / 64, P.B * P.H, P.n_problems), block, 0, s>>>(P);
+    const dim3 block(256), gq((P.Tq + 63) / 64, P.B * P.H, P.n_problems), gk((P.Tk + 63) / 64, P.B * P.H, P.n_problems);
+    if (P.drop.thr > 0) {
+        attn_bwd_dq_kernel<T, HD, true><<<gq, block, 0, s>>>(P);
+        attn_bwd_dkv_kernel<T, HD, true><<<gk, block, 0, s>>>(P);
+    } else {
+        attn_bwd_dq_kernel<T, HD, false><<<gq, block, 0, s>>>(P);
+        attn_bwd_dkv_kernel<T, HD, false><<<gk, block, 0, s>>>(P);
+    }
 }
 
 template <typename T>
