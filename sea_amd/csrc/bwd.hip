@@ -24,12 +24,8 @@ __device__ __forceinline__ uint4 load_frag_T<__bf16>(const char* tile, int pitch
     typedef s16x4 __attribute__((address_space(3))) * lds_p;
     const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(base));
     const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(base + 4 * pitch));
-    uint4 out;
-    out.x = (unsigned)(unsigned short)lo[0] | ((unsigned)(unsigned short)lo[1] << 16);
-    out.y = (unsigned)(unsigned short)lo[2] | ((unsigned)(unsigned short)lo[3] << 16);
-    out.z = (unsigned)(unsigned short)hi[0] | ((unsigned)(unsigned short)hi[1] << 16);
-    out.w = (unsigned)(unsigned short)hi[2] | ((unsigned)(unsigned short)hi[3] << 16);
-    return out;
+    const uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);   // already packed pairs
+    return make_uint4(l2.x, l2.y, h2.x, h2.y);
 }
 template <>
 __device__ __forceinline__ uint4 load_frag_T<float>(const char* tile, int pitch, int m0, int c0, int lane) {
@@ -50,17 +46,21 @@ struct WgradLaunch {
     int n_groups;
 };
 
-// Output tile 64 (n) x 64 (k); 4 waves as 2 x 2, each 32 x 32 = 2 x 2 MFMA tiles; the contraction runs over 64-row stages of
-// dY and X held [m][64 columns] in LDS (row pitch + 16 bytes), double-buffered through registers like the forward GEMM.
-template <typename T>
+// Output tile TS (n) x TS (k), TS = 64 or 128; 4 waves as 2 x 2, each TS/2 x TS/2 = MI x MI MFMA tiles; the contraction runs over
+// 64-row stages of dY and X held [m][TS columns] in LDS (row pitch + 16 bytes), double-buffered through registers like the forward
+// GEMM.  The 128 tile does 16 MFMAs per 8 transposed fragment reads (64: 4 per 4) and halves the operand re-reads; used when
+// every matrix of the launch is a multiple of 128 both ways.
+template <typename T, int TS>
 __global__ __launch_bounds__(256) void wgrad_kernel(const WgradLaunch L) {
     constexpr int EPC = ActTraits<T>::EPC, CK = ActTraits<T>::CK;
-    constexpr int ROWB = 64 * (int)sizeof(T);      // bytes of one tile row
+    constexpr int MI = TS / 32;                    // 16 x 16 MFMA tiles per wave per dimension
+    constexpr int WT = TS / 2;                     // wave tile
+    constexpr int ROWB = TS * (int)sizeof(T);      // bytes of one tile row
     constexpr int PITCH = ROWB + 16;
     constexpr int CPR = ROWB / 16;                 // 16-byte chunks per row
     constexpr int NCH = 64 * CPR / 256;            // chunks per thread per operand
     constexpr int TILE_B = 64 * PITCH;
-    __shared__ __attribute__((aligned(16))) char smem[4 * TILE_B];  // 2 buffers x (dY tile, X tile)
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // 4 * TILE_B: 2 buffers x (dY tile, X tile)
 
     int gi = 0;
     while (gi + 1 < L.n_groups && (int)blockIdx.x >= L.tile_start[gi + 1]) ++gi;
@@ -69,9 +69,9 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradLaunch L) {
     const int splits = L.splits[gi];
     const int split = t % splits;
     t /= splits;
-    const int tiles_k = (G.K + 63) / 64;
+    const int tiles_k = (G.K + TS - 1) / TS;
     const int tn = t / tiles_k, tk = t - tn * tiles_k;
-    const int n0 = tn * 64, k0 = tk * 64;
+    const int n0 = tn * TS, k0 = tk * TS;
     const int m_begin = split * L.rows_per_split[gi];
     int m_end = m_begin + L.rows_per_split[gi];
     m_end = m_end < G.M ? m_end : G.M;
@@ -105,13 +105,13 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradLaunch L) {
         }
     };
 
-    f32x4 acc[2][2];
+    f32x4 acc[MI][MI];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < MI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     float bsum = 0.f;
-    const bool do_bias = G.db != nullptr && tk == 0 && tid < 64;
+    const bool do_bias = G.db != nullptr && tk == 0 && tid < TS;
 
     const int n_stage = (m_end - m_begin + 63) / 64;
     load_stage(m_begin);
@@ -124,15 +124,15 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradLaunch L) {
         if (more) load_stage(m_begin + (st + 1) * 64);
 #pragma unroll
         for (int mk = 0; mk < 64; mk += CK) {
-            uint4 a[2], b[2];
+            uint4 a[MI], b[MI];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) a[i] = load_frag_T<T>(sy, PITCH, mk, wn * 32 + i * 16, lane);
+            for (int i = 0; i < MI; ++i) a[i] = load_frag_T<T>(sy, PITCH, mk, wn * WT + i * 16, lane);
 #pragma unroll
-            for (int j = 0; j < 2; ++j) b[j] = load_frag_T<T>(sx, PITCH, mk, wk * 32 + j * 16, lane);
+            for (int j = 0; j < MI; ++j) b[j] = load_frag_T<T>(sx, PITCH, mk, wk * WT + j * 16, lane);
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < MI; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) mma16<T>(a[i], b[j], acc[i][j]);
+                for (int j = 0; j < MI; ++j) mma16<T>(a[i], b[j], acc[i][j]);
         }
         if (do_bias) {
             const T* col = reinterpret_cast<const T*>(sy) + tid;
@@ -145,13 +145,13 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradLaunch L) {
     // C[n][k]: lane holds column k = lane & 15, rows n = 4 (lane >> 4) + reg
     const int r = lane & 15, g = lane >> 4;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int k = k0 + wk * 32 + j * 16 + r;
+        for (int j = 0; j < MI; ++j) {
+            const int k = k0 + wk * WT + j * 16 + r;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int n = n0 + wn * 32 + i * 16 + g * 4 + q;
+                const int n = n0 + wn * WT + i * 16 + g * 4 + q;
                 if (n < G.N && k < G.K) atomicAdd(G.dW + (int64_t)n * G.lddw + k, acc[i][j][q]);
             }
         }
@@ -164,15 +164,23 @@ extern "C" int sea_wgrad_grouped(const SeaWgradGroup* groups, int n_groups, int 
     const int epc = dtype == SEA_BF16 ? 8 : 4;
     WgradLaunch L;
     memset(&L, 0, sizeof(L));
-    long base_tiles = 0;
+    bool big = true;
     for (int i = 0; i < n_groups; ++i) {
         const SeaWgradGroup& G = groups[i];
         SEA_REQUIRE(G.dY && G.X && G.dW, "sea_wgrad_grouped[%d]: null pointer", i);
         SEA_REQUIRE(G.M >= 1 && G.N >= 8 && G.K >= 8 && G.N % 8 == 0 && G.K % 8 == 0, "sea_wgrad_grouped[%d]: bad shape M=%d N=%d K=%d", i, G.M, G.N, G.K);
         SEA_REQUIRE(G.lddy % epc == 0 && G.ldx % epc == 0 && G.lddy >= G.N && G.ldx >= G.K && G.lddw >= G.K, "sea_wgrad_grouped[%d]: bad strides", i);
         SEA_REQUIRE(sea_aligned16(G.dY) && sea_aligned16(G.X), "sea_wgrad_grouped[%d]: dY/X must be 16-byte aligned", i);
-        base_tiles += (long)((G.N + 63) / 64) * ((G.K + 63) / 64);
+        big = big && G.N % 128 == 0 && G.K % 128 == 0 && G.M >= 2048;
     }
+    static const int forced = []() { const char* e = getenv("SEA_WGRAD_TILE"); return e ? atoi(e) : 0; }();  // tuning aid
+    long tiles128 = 0;
+    for (int i = 0; i < n_groups; ++i) tiles128 += (long)((groups[i].N + 127) / 128) * ((groups[i].K + 127) / 128);
+    // few 128-tiles would mean many contraction splits, i.e. many atomic passes over the same outputs: measured at cfg3 the small
+    // exchange matrices (6 tiles) run 1.8x slower on the 128 tile, the MLP / condition matrices (96-192 tiles) 1.2-1.4x faster
+    const int ts = forced == 64 ? 64 : (forced == 128 ? 128 : (big && tiles128 >= 64 ? 128 : 64));
+    long base_tiles = 0;
+    for (int i = 0; i < n_groups; ++i) base_tiles += (long)((groups[i].N + ts - 1) / ts) * ((groups[i].K + ts - 1) / ts);
     // split the contraction so that the launch has ~2 workgroups per CU, never below 256 rows per split
     int total = 0;
     for (int i = 0; i < n_groups; ++i) {
@@ -186,13 +194,21 @@ extern "C" int sea_wgrad_grouped(const SeaWgradGroup* groups, int n_groups, int 
         L.splits[i] = splits;
         L.rows_per_split[i] = rows;
         L.tile_start[i] = total;
-        total += ((G.N + 63) / 64) * ((G.K + 63) / 64) * splits;
+        total += ((G.N + ts - 1) / ts) * ((G.K + ts - 1) / ts) * splits;
     }
     L.tile_start[n_groups] = total;
     L.n_groups = n_groups;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (dtype == SEA_BF16) wgrad_kernel<__bf16><<<dim3(total), dim3(256), 0, s>>>(L);
-    else wgrad_kernel<float><<<dim3(total), dim3(256), 0, s>>>(L);
+#define LAUNCH_WG(TT, TSZ)                                                                                                      \
+    do {                                                                                                                         \
+        constexpr int lds_ = 4 * 64 * (TSZ * (int)sizeof(TT) + 16);                                                              \
+        static const hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel<TT, TSZ>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_); \
+        (void)once;                                                                                                              \
+        wgrad_kernel<TT, TSZ><<<dim3(total), dim3(256), lds_, s>>>(L);                                                          \
+    } while (0)
+    if (dtype == SEA_BF16) { if (ts == 128) LAUNCH_WG(__bf16, 128); else LAUNCH_WG(__bf16, 64); }
+    else { if (ts == 128) LAUNCH_WG(float, 128); else LAUNCH_WG(float, 64); }
+#undef LAUNCH_WG
     SEA_CHECK_LAUNCH("sea_wgrad_grouped");
     return SEA_OK;
 }
