@@ -670,15 +670,14 @@ struct SiluBwdLaunch {
 };
 
 // Column sums in registers: lane owns columns lane*4 + 256k (k < 8, K2 <= 2048), w1/b1 of those columns are loaded once.
-template <typename T>
+template <typename T, int KM>
 __global__ __launch_bounds__(256) void silu_outer_bwd_kernel(const SiluBwdLaunch L) {
     extern __shared__ __attribute__((aligned(16))) float cs[];  // [2][K2]
     const SeaSiluBwdGroup& G = L.g[blockIdx.y];
     const int K2 = G.K2, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int i = threadIdx.x; i < 2 * K2; i += 256) cs[i] = 0.f;
     __syncthreads();
-    constexpr int KM = 8;
-    float aw[KM][4], ab[KM][4], w[KM][4], bb[KM][4];
+    float aw[KM][4], ab[KM][4], w[KM][4], bb[KM][4];   // KM = ceil(max K2 / 256): registers scale with the row width
 #pragma unroll
     for (int k = 0; k < KM; ++k) {
         const int i = lane * 4 + 256 * k;
@@ -689,22 +688,41 @@ __global__ __launch_bounds__(256) void silu_outer_bwd_kernel(const SiluBwdLaunch
             load4(G.b1 + i, bb[k]);
         }
     }
-    for (int row = blockIdx.x * 4 + wave; row < L.M; row += 4 * gridDim.x) {
-        const float cv = L.c[row];
-        const T* dh = static_cast<const T*>(G.dHid) + (int64_t)row * G.ld;
+    // RB rows per trip with all their loads requested first: a row is only K2 * sizeof(T) bytes (1 KB at K2 = 512), one row per trip
+    // left every wave waiting a full memory round trip per kilobyte
+    constexpr int RB = 4;
+    const int rstep = 4 * gridDim.x;
+    for (int row0 = blockIdx.x * 4 + wave; row0 < L.M; row0 += RB * rstep) {
+        float cv[RB], dv[RB][KM][4];
 #pragma unroll
-        for (int k = 0; k < KM; ++k) {
-            const int i = lane * 4 + 256 * k;
-            if (i < K2) {
-                float dv[4];
-                load4(dh + i, dv);
+        for (int u = 0; u < RB; ++u) {
+            const int row = row0 + u * rstep;
+            const int rc = row < L.M ? row : L.M - 1;
+            cv[u] = L.c[rc];
+            const T* dh = static_cast<const T*>(G.dHid) + (int64_t)rc * G.ld;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float pre = w[k][e] * cv + bb[k][e];
-                    const float sg = 1.0f / (1.0f + __expf(-pre));
-                    const float dpre = dv[e] * sg * (1.0f + pre * (1.0f - sg));
-                    aw[k][e] += dpre * cv;
-                    ab[k][e] += dpre;
+            for (int k = 0; k < KM; ++k) {
+                const int i = lane * 4 + 256 * k;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) dv[u][k][e] = 0.f;
+                if (i < K2) load4(dh + i, dv[u][k]);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < RB; ++u) {
+            const bool live = row0 + u * rstep < L.M;
+#pragma unroll
+            for (int k = 0; k < KM; ++k) {
+                const int i = lane * 4 + 256 * k;
+                if (i < K2) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float pre = w[k][e] * cv[u] + bb[k][e];
+                        const float sg = 1.0f / (1.0f + __expf(-pre));
+                        const float dpre = live ? dv[u][k][e] * sg * (1.0f + pre * (1.0f - sg)) : 0.f;
+                        aw[k][e] += dpre * cv[u];
+                        ab[k][e] += dpre;
+                    }
                 }
             }
         }
@@ -757,13 +775,21 @@ extern "C" int sea_silu_outer_bwd(const SeaSiluBwdGroup* groups, int n_groups, c
     L.maxk = maxk;
     const size_t lds = (size_t)2 * maxk * sizeof(float);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (dtype == SEA_BF16) {
-        if (lds > 65536) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(silu_outer_bwd_kernel<__bf16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        silu_outer_bwd_kernel<__bf16><<<dim3(nblk, n_groups), dim3(256), lds, s>>>(L);
-    } else {
-        if (lds > 65536) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(silu_outer_bwd_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        silu_outer_bwd_kernel<float><<<dim3(nblk, n_groups), dim3(256), lds, s>>>(L);
-    }
+#define LAUNCH_SB(TT, KMV)                                                                                                            \
+    do {                                                                                                                              \
+        if (lds > 65536) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(silu_outer_bwd_kernel<TT, KMV>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        silu_outer_bwd_kernel<TT, KMV><<<dim3(nblk, n_groups), dim3(256), lds, s>>>(L);                                                \
+    } while (0)
+#define LAUNCH_SB_T(TT)                                              \
+    do {                                                              \
+        if (maxk <= 256) LAUNCH_SB(TT, 1);                            \
+        else if (maxk <= 512) LAUNCH_SB(TT, 2);                       \
+        else if (maxk <= 1024) LAUNCH_SB(TT, 4);                      \
+        else LAUNCH_SB(TT, 8);                                        \
+    } while (0)
+    if (dtype == SEA_BF16) LAUNCH_SB_T(__bf16); else LAUNCH_SB_T(float);
+#undef LAUNCH_SB_T
+#undef LAUNCH_SB
     if (two_stage) {
         ColsumFinish F;
         memset(&F, 0, sizeof(F));
@@ -894,6 +920,16 @@ __global__ __launch_bounds__(256) void ib_bwd_fast_kernel(const SeaIbBwdParams P
 #pragma unroll
             for (int j = 0; j < HM; ++j) aw2[k][e][j] = 0.f;
         }
+    float w2r[KE][4][HM];   // the lane's rows of W2: row-invariant, loaded once
+#pragma unroll
+    for (int k = 0; k < KE; ++k)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int j = 0; j < HM; ++j) {
+                const int col = lane * 4 + 256 * k + e;
+                w2r[k][e][j] = (col < E && j < h) ? P.w2[(int64_t)col * h + j] : 0.f;
+            }
     for (int row = blockIdx.x * 4 + wave; row < P.M; row += 4 * gridDim.x) {
         const float cv = P.c[row];
         const float pre = act ? w1 * cv + b1 : 0.f;
@@ -933,7 +969,7 @@ __global__ __launch_bounds__(256) void ib_bwd_fast_kernel(const SeaIbBwdParams P
 #pragma unroll
                     for (int j = 0; j < HM; ++j) {
                         aw2[k][e][j] += dib[e] * hk[j];
-                        if (j < h) part[j] += dib[e] * P.w2[(int64_t)(e0 + e) * h + j];
+                        part[j] += dib[e] * w2r[k][e][j];
                     }
                 }
             }
