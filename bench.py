@@ -168,10 +168,12 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-graph", action="store_true", help="replay launch by launch instead of the captured HIP graph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--mode", default="rollout", choices=["rollout", "train", "kv"],
+    ap.add_argument("--mode", default="rollout", choices=["rollout", "train", "kv", "decode"],
                     help="rollout: full-context forward step (cfg2, the default metric); train: fwd+bwd+AdamW step (cfg3/cfg4, --batch 8); "
-                         "kv: KV-cache rollout of --seq steps")
+                         "kv: KV-cache rollout of --seq steps; decode: spatial decoder over a --seq-step rollout (SURVEY.md §8f rank 1)")
     args = ap.parse_args()
+    if args.mode == "decode":
+        return main_decode(args)
     if args.mode != "rollout":
         return main_other(args)
 
@@ -366,6 +368,63 @@ def main_other(args):
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def main_decode(args):
+    """--mode decode: the decode leg of full_autoregressive_evaluation (reference utils/train_utils.py:214-222) at the shipped cylinder
+    dims: 64 patches x spatial embed 16 (= temporal embed 1024), groups [[0,1],[2]], hidden 480; n_inp (mesh points per padded patch) is
+    data-dependent in the reference, 512 here.  One step = decoding a whole --seq-step rollout of --batch trajectories."""
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no GPU visible (the product path has no CPU fallback)")
+    from sea_amd.models.encoder_decoder import Decode
+    from sea_amd.utils.train_utils import decode_rollout
+
+    dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+    torch.cuda.set_device(dev)
+    groups, n_inp, hidden, D, P = [[0, 1], [2]], 512, 480, 16, 64
+    tr, T = args.batch, args.seq
+    torch.manual_seed(42)
+    dec = Decode(groups, n_inp, hidden, D).set_compute_dtype(args.dtype).to(dev).eval()
+    roll = torch.randn(tr, T, len(groups), P * D, generator=torch.Generator().manual_seed(1234)).to(dev)
+    with torch.no_grad():
+        for _ in range(max(args.warmup, 1)):
+            out = decode_rollout(dec, roll, P)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            out = decode_rollout(dec, roll, P)
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        # the dominant launch (layer2: [M, 480] x [480, 1536] + bias -> fp32) alone, HIP events on the launch stream
+        M = tr * T * P
+        dt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+        W1, W2 = dec._weights(dt)
+        hid = [torch.randn(M, hidden, device=dev).to(dt) for _ in groups]
+        o2 = torch.empty(M, 3 * n_inp, device=dev)
+        from sea_amd import ops
+        gl = [dict(A=hid[0], W=W2[0], bias=dec.decoders[0].layer2.bias.detach(), C32=o2[:, :2 * n_inp]),
+              dict(A=hid[1], W=W2[1], bias=dec.decoders[1].layer2.bias.detach(), C32=o2[:, 2 * n_inp:])]
+        ops.gemm_grouped(gl, dt)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            ops.gemm_grouped(gl, dt)
+        e1.record()
+        torch.cuda.synchronize()
+        k_ms = e0.elapsed_time(e1) / 5
+    assert torch.isfinite(out).all()
+    esz = 2 if args.dtype == "bf16" else 4
+    alg_bytes = M * hidden * esz + 3 * n_inp * hidden * esz + M * 3 * n_inp * 4   # read hidden + weights once, write the fp32 fields once
+    flops = 2 * M * hidden * 3 * n_inp
+    ms = elapsed / args.steps * 1e3
+    line = {"metric": "decoded snapshots/sec (spatial decoder over a rollout)", "value": tr * T * args.steps / elapsed, "unit": "snapshots/s",
+            "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"decode leg of the rollout evaluation: {tr} x {T} snapshots, 64 patches, spatial embed 16, hidden 480, groups [[0,1],[2]], n_inp 512"},
+            "roofline": {"kernel": "decode.layer2 (gemm_grouped)", "bound": "hbm", "achieved": alg_bytes / (k_ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
+                         "frac": alg_bytes / (k_ms * 1e-3) / 1e9 / 8000.0, "traffic": None, "launch_ms": k_ms, "launch_gflop": flops / 1e9,
+                         "mfma_tflops": flops / (k_ms * 1e-3) / 1e12}}
+    print(json.dumps(line))
 
 
 if __name__ == "__main__":

@@ -121,3 +121,17 @@ def recipe_inputs(B: int, T: int, cfg: OracleConfig, seed: int = 1234) -> Tuple[
     tgt = rng.standard_normal((B, T, cfg.num_variables, cfg.embed_dim)).astype(np.float32)
     ib = rng.random((B, T, 1)).astype(np.float32)
     return torch.from_numpy(x), torch.from_numpy(tgt), torch.from_numpy(ib)
+
+
+def decode_schema(field_groups, n_inp: int, mlp_hidden: int, embed_dim: int, pre: str = "decoders."):
+    """Parameter names / shapes / kinds of the reference's Decode module (models/encoder_decoder.py:126-136), in named_parameters order."""
+    sch = {}
+    for i, group in enumerate(field_groups):
+        sch[f"{pre}{i}.layer1.weight"] = ((mlp_hidden, embed_dim), "lin_w")
+        sch[f"{pre}{i}.layer2.weight"] = ((n_inp * len(group), mlp_hidden), "lin_w")
+        sch[f"{pre}{i}.layer2.bias"] = ((n_inp * len(group),), "lin_b")
+    return sch
+
+
+def decode_params(field_groups, n_inp: int, mlp_hidden: int, embed_dim: int, dtype=torch.float32):
+    return {k: torch.from_numpy(recipe_tensor(k, shp, kind)).to(dtype) for k, (shp, kind) in decode_schema(field_groups, n_inp, mlp_hidden, embed_dim).items()}

@@ -301,3 +301,24 @@ def train_steps(x: torch.Tensor, cond: torch.Tensor, target: torch.Tensor, p: Pa
                 vs[k] = torch.zeros_like(p[k])
             p[k], ms[k], vs[k] = adamw_update(p[k], g, ms[k], vs[k], step, lr, weight_decay=weight_decay)
     return p, losses
+
+
+# ---------------------------------------------------------------------------------------------------- spatial decoder
+def rollout_to_patches(rollout_out: torch.Tensor, n_patches: int) -> torch.Tensor:
+    """utils/train_utils.py:339-362 (inverse_transform_processed_data): [tr, T, G, P*D] -> [tr*T, P, G, D]."""
+    tr, T, G, PD = rollout_out.shape
+    D = PD // n_patches
+    return rollout_out.reshape(tr, T, G, n_patches, D).permute(0, 1, 3, 2, 4).reshape(tr * T, n_patches, G, D)
+
+
+def decode(z: torch.Tensor, p: Params, field_groups: Sequence[Sequence[int]], pre: str = "decoders.") -> torch.Tensor:
+    """models/encoder_decoder.py:126-146 (Decode.forward) with upScaleMLP of models/base_blocks.py:49-63:
+    per field group g, y = W2 gelu(W1 z[:, :, g, :]) + b2 (layer1 has no bias), reshaped to [B, P, |group|, n_inp]; groups are
+    concatenated along the field axis -> [B, P, n_fields, n_inp]."""
+    B, P_, _, _ = z.shape
+    outs = []
+    for i, group in enumerate(field_groups):
+        h = gelu_erf(linear(z[:, :, i:i + 1, :], p[f"{pre}{i}.layer1.weight"]))
+        y = linear(h, p[f"{pre}{i}.layer2.weight"], p[f"{pre}{i}.layer2.bias"])
+        outs.append(y.reshape(B, P_, len(group), -1))
+    return torch.cat(outs, dim=2)

@@ -136,3 +136,16 @@ class NoOpErrorTracker:
 def create_error_tracker(use_wandb, project_name, run_name=None, config: Dict[str, Any] = None):
     """wandb is not part of this build: always the no-op tracker (the reference falls back to it when wandb is missing)."""
     return NoOpErrorTracker()
+
+
+def inverse_transform_processed_data(transformed_data: torch.Tensor, tr: int, T: int, n_patches: int, num_field_groups: int) -> torch.Tensor:
+    """[tr, T, num_field_groups, P*D] -> [tr*T, P, num_field_groups, D] (reference utils/train_utils.py:339-362, same signature)."""
+    D = transformed_data.shape[-1] // n_patches
+    return transformed_data.reshape(tr, T, num_field_groups, n_patches, D).permute(0, 1, 3, 2, 4).reshape(tr * T, n_patches, num_field_groups, D)
+
+
+def decode_rollout(decoder, rollout_out: torch.Tensor, n_patches: int) -> torch.Tensor:
+    """The decode leg of full_autoregressive_evaluation (reference utils/train_utils.py:214-222): rollout output [tr, T, G, P*D] ->
+    decoded patches [tr*T, P, n_fields, n_inp], on the device (the reference round-trips through `processor.decode_data`)."""
+    tr, T, G, _ = rollout_out.shape
+    return decoder(inverse_transform_processed_data(rollout_out, tr, T, n_patches, G))

@@ -21,12 +21,13 @@ sys.path.insert(0, REF)
 import numpy as np
 import torch
 
-from oracle.recipe import param_schema, recipe_inputs, recipe_tensor
+from oracle.recipe import decode_schema, param_schema, recipe_inputs, recipe_tensor
 from oracle.sea_oracle import OracleConfig
 
 from models.temporal import TemporalModel  # reference
 from models import base_blocks as ref_bb  # reference
 from utils import train_utils as ref_tu  # reference
+from models.encoder_decoder import Decode as RefDecode  # reference
 
 torch.set_num_threads(8)
 
@@ -220,6 +221,28 @@ def exchange_cases():
     save("exchange", **arrs)
 
 
+def decode_cases():
+    """Decode (models/encoder_decoder.py:126-146) fed by inverse_transform_processed_data (utils/train_utils.py:339-362) on a
+    rollout-shaped tensor: cylinder-like groups [[0,1],[2]] with small dims, and a 3-group variant with ragged group sizes."""
+    for name, groups, n_inp, hidden, D, P, tr, T in (("decode_cyl_small", [[0, 1], [2]], 24, 96, 16, 9, 2, 5),
+                                                     ("decode_three_groups", [[0], [1, 2, 3], [4, 5]], 12, 64, 8, 4, 1, 7)):
+        dec = RefDecode(groups, n_inp, hidden, D, dropout=0.0).eval()
+        sch = decode_schema(groups, n_inp, hidden, D)
+        named = dict(dec.named_parameters())
+        assert list(named.keys()) == list(sch.keys()), (list(named.keys()), list(sch.keys()))
+        with torch.no_grad():
+            for k, prm in named.items():
+                shp, kind = sch[k]
+                assert tuple(prm.shape) == tuple(shp), (k, prm.shape, shp)
+                prm.copy_(torch.from_numpy(recipe_tensor(k, shp, kind)))
+        rng = np.random.Generator(np.random.PCG64(77))
+        roll = torch.from_numpy(rng.standard_normal((tr, T, len(groups), P * D)).astype(np.float32))
+        with torch.no_grad():
+            z = ref_tu.inverse_transform_processed_data(roll, tr, T, P, len(groups))
+            out = dec(z)
+        save(name, groups=np.array([len(g) for g in groups]), dims=np.array([n_inp, hidden, D, P, tr, T]), roll=n(roll), z=n(z), out=n(out))
+
+
 def big_cases():
     # cfg2 shape (BASELINE.json configs[1]): E=256, H=8, F=3, T=2024, B=1
     print("cfg2_shape")
@@ -266,6 +289,7 @@ def main():
         "rollout100_ln_f2": lambda: rollout_case("rollout100_ln_f2", OracleConfig(1, 64, 4, 128, 8, 0, 2, 2, True, "ln"), 1, 100),
         "modules": module_cases,
         "exchange": exchange_cases,
+        "decode": decode_cases,
     }
     for T in (1, 7, 16, 65):
         cases[f"model_small_adaln_f3_T{T}"] = (lambda T=T: model_case(

@@ -182,3 +182,23 @@ def test_schema_counts():
     live = O.live_param_keys({k: None for k in s}, cfg)
     n_dead = sum(int(np.prod(s[k][0])) for k in s if k not in live)
     assert n_dead == 1_057_408
+
+
+@pytest.mark.parametrize("name", ["decode_cyl_small", "decode_three_groups"])
+def test_decode_matches_reference(name):
+    """Decode + inverse_transform_processed_data against the reference's own modules."""
+    from oracle.recipe import decode_params
+
+    g = load_golden(name)
+    sizes = [int(v) for v in g["groups"]]
+    n_inp, hidden, D, P, tr, T = (int(v) for v in g["dims"])
+    groups, k = [], 0
+    for sz in sizes:
+        groups.append(list(range(k, k + sz)))
+        k += sz
+    p = decode_params(groups, n_inp, hidden, D)
+    z = O.rollout_to_patches(torch.from_numpy(g["roll"]), P)
+    assert torch.equal(z, torch.from_numpy(g["z"]))
+    out = O.decode(z, p, groups)
+    assert out.shape == g["out"].shape
+    assert rel_l2(out.numpy(), g["out"]) < 1e-6
