@@ -212,12 +212,14 @@ static int set_lds(K kernel, int bytes) {
                ? 0 : -1;
 }
 
-static int pick_tile(long tiles128, long tiles64) {
-    // 128x128 tiles once they fill most of the 256 CUs, else 64x64 (more, smaller workgroups)
-    (void)tiles64;
+static int pick_tile(long tiles128, bool dma) {
+    // 64x64 tiles until the 128x128 ones would make about four full rounds of the 256 CUs (two for the LDS-DMA main loop): below that
+    // a launch is a few tiles deep per CU and its time is one tile's latency, which the small tile halves.  Measured on the cfg2/cfg3
+    // shapes (B = 1, 2, 4, 8): condition GEMM 672 tiles 33.5 us (64) vs 37.3 (128), 1344 tiles 60.3 vs 54.9; fc1 768: 24.6 vs 30.3,
+    // 1536: 42.4 vs 40.9; fc2 (DMA) 384: 72 vs 81, 768: 157 vs 127; out_proj 762: 41.8 vs 51.6.
     static const int forced = []() { const char* e = getenv("SEA_GEMM_TILE"); return e ? atoi(e) : 0; }();  // tuning aid
     if (forced == 64 || forced == 128) return forced;
-    return tiles128 >= 192 ? 128 : 64;
+    return tiles128 >= (dma ? 512 : 1024) ? 128 : 64;
 }
 
 extern "C" int sea_gemm_grouped(const SeaGemmGroup* groups, int n_groups, int dtype, void* stream) {
@@ -244,12 +246,13 @@ extern "C" int sea_gemm_grouped(const SeaGemmGroup* groups, int n_groups, int dt
         t128 += (long)((G.M + 127) / 128) * ((G.N + 127) / 128);
         t64 += (long)((G.M + 63) / 64) * ((G.N + 63) / 64);
     }
-    const int tile = pick_tile(t128, t64);
     // LDS-DMA ring: needs whole K-tiles (128 bytes of K per row per stage) and pays off only on long contractions (its 4 stages
     // cost a workgroup per CU at 128x128; measured: K = 2048 +5 %, K = 256 -20 % against the register-staged double buffer)
     bool dma = true;
     for (int i = 0; i < n_groups; ++i)
         dma = dma && (groups[i].K % (dtype == SEA_BF16 ? 64 : 32) == 0) && (long)groups[i].K * groups[i].n_seg >= 1024;
+    (void)t64;
+    const int tile = pick_tile(t128, dma);
     GemmLaunch L;
     memset(&L, 0, sizeof(L));
     L.n_groups = n_groups;
@@ -305,9 +308,10 @@ extern "C" int sea_qkv_rope_grouped(const SeaQkvGroup* groups, int n_groups, con
         t128 += (long)((G.M + 127) / 128) * ((G.N + 127) / 128);
         t64 += (long)((G.M + 63) / 64) * ((G.N + 63) / 64);
     }
-    const int tile = pick_tile(t128, t64);
     bool dma = true;
     for (int i = 0; i < n_groups; ++i) dma = dma && (groups[i].K % (dtype == SEA_BF16 ? 64 : 32) == 0) && groups[i].K >= 1024;
+    (void)t64;
+    const int tile = pick_tile(t128, dma);
     QkvLaunch L;
     memset(&L, 0, sizeof(L));
     L.n_groups = n_groups;
