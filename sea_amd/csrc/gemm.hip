@@ -248,9 +248,10 @@ extern "C" int sea_gemm_grouped(const SeaGemmGroup* groups, int n_groups, int dt
     }
     // LDS-DMA ring: needs whole K-tiles (128 bytes of K per row per stage) and pays off only on long contractions (its 4 stages
     // cost a workgroup per CU at 128x128; measured: K = 2048 +5 %, K = 256 -20 % against the register-staged double buffer)
+    static const int dma_min_k = []() { const char* e = getenv("SEA_GEMM_DMA_MIN_K"); return e ? atoi(e) : 1024; }();  // tuning aid
     bool dma = true;
     for (int i = 0; i < n_groups; ++i)
-        dma = dma && (groups[i].K % (dtype == SEA_BF16 ? 64 : 32) == 0) && (long)groups[i].K * groups[i].n_seg >= 1024;
+        dma = dma && (groups[i].K % (dtype == SEA_BF16 ? 64 : 32) == 0) && (long)groups[i].K * groups[i].n_seg >= dma_min_k;
     (void)t64;
     const int tile = pick_tile(t128, dma);
     GemmLaunch L;
