@@ -15,7 +15,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libsea_hip.so")
 SOURCES = ["core.hip", "gemm.hip", "attention.hip", "rowops.hip", "train.hip", "bwd.hip", "attention_bwd.hip", "rowchain.hip"]
 HEADERS = ["sea_common.hpp", "gemm_core.hpp", os.path.join("..", "..", "include", "sea_hip.h")]
-FLAGS = (os.environ.get("SEA_EXTRA_FLAGS", "").split()) + ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-mcode-object-version=5", "-Wall", "-Wno-unused-function", "-Wno-unused-result"]
+FLAGS = (os.environ.get("SEA_EXTRA_FLAGS", "").split()) + ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-mcode-object-version=5", "-mllvm", "-amdgpu-mfma-vgpr-form=1", "-Wall", "-Wno-unused-function", "-Wno-unused-result"]
 
 
 def _hipcc() -> str:

@@ -431,7 +431,6 @@ __device__ __forceinline__ void chain_stage(const SeaChainStage& S, const SeaCha
 }
 
 constexpr int STAGE_WORDS = (int)(sizeof(SeaChainStage) / 4);
-constexpr int MAX_STAGES_PER_GROUP = 24;
 // A stage descriptor from the LDS copy of the table, every word made wave-uniform (SGPR) so that the stage's branches stay scalar.
 __device__ __forceinline__ void load_stage(SeaChainStage& S, const uint32_t* src) {
     uint32_t* dst = reinterpret_cast<uint32_t*>(&S);
