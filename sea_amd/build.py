@@ -15,7 +15,10 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libsea_hip.so")
 SOURCES = ["core.hip", "gemm.hip", "attention.hip", "rowops.hip", "train.hip", "bwd.hip", "attention_bwd.hip", "rowchain.hip"]
 HEADERS = ["sea_common.hpp", "gemm_core.hpp", os.path.join("..", "..", "include", "sea_hip.h")]
-FLAGS = (os.environ.get("SEA_EXTRA_FLAGS", "").split()) + ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-mcode-object-version=5", "-mllvm", "-amdgpu-mfma-vgpr-form=1", "-Wall", "-Wno-unused-function", "-Wno-unused-result"]
+# -amdgpu-mfma-vgpr-form: MFMA results land in VGPRs, so epilogues / softmax read them without v_accvgpr_read moves.
+# -ffast-math -fno-finite-math-only: reciprocal / approximate-function / reassociation freedoms for the row kernels and epilogues; infinities
+# and NaNs keep their meaning (the attention kernels mask with -inf).  Parity bars (fp32 <= 1e-4) are checked with these flags on.
+FLAGS = (os.environ.get("SEA_EXTRA_FLAGS", "").split()) + ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-mcode-object-version=5", "-mllvm", "-amdgpu-mfma-vgpr-form=1", "-ffast-math", "-fno-finite-math-only", "-Wall", "-Wno-unused-function", "-Wno-unused-result"]
 
 
 def _hipcc() -> str:
