@@ -17,8 +17,8 @@ SOURCES = ["core.hip", "gemm.hip", "attention.hip", "rowops.hip", "train.hip", "
 HEADERS = ["sea_common.hpp", "gemm_core.hpp", os.path.join("..", "..", "include", "sea_hip.h")]
 # -amdgpu-mfma-vgpr-form: MFMA results land in VGPRs, so epilogues / softmax read them without v_accvgpr_read moves.
 # -ffast-math -fno-finite-math-only: reciprocal / approximate-function / reassociation freedoms for the row kernels and epilogues; infinities
-# and NaNs keep their meaning (the attention kernels mask with -inf).  Parity bars (fp32 <= 1e-4) are checked with these flags on.
-FLAGS = (os.environ.get("SEA_EXTRA_FLAGS", "").split()) + ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-mcode-object-version=5", "-mllvm", "-amdgpu-mfma-vgpr-form=1", "-ffast-math", "-fno-finite-math-only", "-Wall", "-Wno-unused-function", "-Wno-unused-result"]
+# and NaNs keep their meaning (the attention kernels mask with -inf); f32 denormals flush to zero (no range-fixup code around v_exp / v_rcp).  Parity bars (fp32 <= 1e-4) are checked with these flags on.
+FLAGS = (os.environ.get("SEA_EXTRA_FLAGS", "").split()) + ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-mcode-object-version=5", "-mllvm", "-amdgpu-mfma-vgpr-form=1", "-ffast-math", "-fno-finite-math-only", "-fgpu-flush-denormals-to-zero", "-Wall", "-Wno-unused-function", "-Wno-unused-result"]
 
 
 def _hipcc() -> str:
