@@ -6,12 +6,14 @@ struct GemmLaunch {
     SeaGemmGroup g[SEA_MAX_GROUPS];
     int tile_start[SEA_MAX_GROUPS + 1];
     int n_groups;
+    int single_buffer;   // register-staged main loop on one LDS buffer (more workgroups per CU)
 };
 
 struct QkvLaunch {
     SeaQkvGroup g[SEA_MAX_GROUPS];
     int tile_start[SEA_MAX_GROUPS + 1];
     int n_groups;
+    int single_buffer;
     SeaQkvCommon c;
 };
 
@@ -51,6 +53,7 @@ __global__ __launch_bounds__(256) void gemm_grouped_kernel(const GemmLaunch L) {
     ml.m0 = tm * BM; ml.n0 = tn * BN;
     f32x4 acc[C::MI][C::NI];
     if constexpr (DMA) ml.run_dma(smem, acc);
+    else if (L.single_buffer) ml.run_single(smem, acc);
     else ml.run(smem, acc);
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -152,6 +155,7 @@ __global__ __launch_bounds__(256) void qkv_rope_kernel(const QkvLaunch L) {
     ml.m0 = tm * BM; ml.n0 = tn * BN;
     f32x4 acc[C::MI][C::NI];
     if constexpr (DMA) ml.run_dma(smem, acc);
+    else if (L.single_buffer) ml.run_single(smem, acc);
     else ml.run(smem, acc);
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -213,13 +217,13 @@ static int set_lds(K kernel, int bytes) {
 }
 
 static int pick_tile(long tiles128, bool dma) {
-    // 64x64 tiles until the 128x128 ones would make about four full rounds of the 256 CUs (two for the LDS-DMA main loop): below that
-    // a launch is a few tiles deep per CU and its time is one tile's latency, which the small tile halves.  Measured on the cfg2/cfg3
-    // shapes (B = 1, 2, 4, 8): condition GEMM 672 tiles 33.5 us (64) vs 37.3 (128), 1344 tiles 60.3 vs 54.9; fc1 768: 24.6 vs 30.3,
-    // 1536: 42.4 vs 40.9; fc2 (DMA) 384: 72 vs 81, 768: 157 vs 127; out_proj 762: 41.8 vs 51.6.
+    // 64x64 tiles until the launch is a couple of rounds of 128x128 tiles deep: below that its time is one tile's latency, which the small
+    // tile halves.  Measured crossovers on the cfg2/cfg3 shapes at B = 1, 2, 4, 8 (single-buffered register-staged main loop):
+    // condition GEMM 672 tiles 31.8 us (64) vs 28.0 (128); fc1 768: 22.0 vs 21.2, 6144: 135 vs 118; qkv 288: 16.7 vs 19.5, 2304: 61 vs 59;
+    // LDS-DMA main loop (fc2) 384: 70 vs 79, 768: 158 vs 127.
     static const int forced = []() { const char* e = getenv("SEA_GEMM_TILE"); return e ? atoi(e) : 0; }();  // tuning aid
     if (forced == 64 || forced == 128) return forced;
-    return tiles128 >= (dma ? 512 : 1024) ? 128 : 64;
+    return tiles128 >= (dma ? 512 : 600) ? 128 : 64;
 }
 
 extern "C" int sea_gemm_grouped(const SeaGemmGroup* groups, int n_groups, int dtype, void* stream) {
@@ -265,12 +269,15 @@ extern "C" int sea_gemm_grouped(const SeaGemmGroup* groups, int n_groups, int dt
     }
     L.tile_start[n_groups] = total;
     hipStream_t s = static_cast<hipStream_t>(stream);
+    static const int sb_env = []() { const char* e = getenv("SEA_GEMM_SINGLE"); return e ? atoi(e) : 1; }();  // tuning aid: 0 = double buffer
+    L.single_buffer = sb_env && !dma;
+    const int sb = L.single_buffer;
 #define LAUNCH_GEMM(TT, BMN, DM)                                                                                          \
     do {                                                                                                                  \
-        constexpr int main_ = DM ? GemmMainloop<TT, BMN, BMN>::DMA_LDS_BYTES : GemmCfg<TT, BMN, BMN>::LDS_BYTES;             \
+        const int main_ = DM ? GemmMainloop<TT, BMN, BMN>::DMA_LDS_BYTES : (sb ? GemmCfg<TT, BMN, BMN>::BUF_BYTES : GemmCfg<TT, BMN, BMN>::LDS_BYTES); \
         constexpr int stage_ = BMN * (BMN * (int)sizeof(TT) + 16);                                                         \
-        constexpr int lds_ = main_ > stage_ ? main_ : stage_;                                                              \
-        static int once = set_lds(gemm_grouped_kernel<TT, BMN, BMN, DM>, lds_);                                            \
+        const int lds_ = main_ > stage_ ? main_ : stage_;                                                                  \
+        static int once = set_lds(gemm_grouped_kernel<TT, BMN, BMN, DM>, DM ? GemmMainloop<TT, BMN, BMN>::DMA_LDS_BYTES : (GemmCfg<TT, BMN, BMN>::LDS_BYTES > stage_ ? GemmCfg<TT, BMN, BMN>::LDS_BYTES : stage_)); \
         (void)once;                                                                                                       \
         gemm_grouped_kernel<TT, BMN, BMN, DM><<<dim3(total), dim3(256), lds_, s>>>(L);                                     \
     } while (0)
@@ -325,10 +332,13 @@ extern "C" int sea_qkv_rope_grouped(const SeaQkvGroup* groups, int n_groups, con
     }
     L.tile_start[n_groups] = total;
     hipStream_t s = static_cast<hipStream_t>(stream);
+    static const int sbq_env = []() { const char* e = getenv("SEA_GEMM_SINGLE"); return e ? atoi(e) : 1; }();
+    L.single_buffer = sbq_env && !dma;
+    const int sbq = L.single_buffer;
 #define LAUNCH_QKV(TT, BMN, DM)                                                                                           \
     do {                                                                                                                  \
-        constexpr int lds_ = DM ? GemmMainloop<TT, BMN, BMN>::DMA_LDS_BYTES : GemmCfg<TT, BMN, BMN>::LDS_BYTES;              \
-        static int once = set_lds(qkv_rope_kernel<TT, BMN, BMN, DM>, lds_);                                                \
+        const int lds_ = DM ? GemmMainloop<TT, BMN, BMN>::DMA_LDS_BYTES : (sbq ? GemmCfg<TT, BMN, BMN>::BUF_BYTES : GemmCfg<TT, BMN, BMN>::LDS_BYTES); \
+        static int once = set_lds(qkv_rope_kernel<TT, BMN, BMN, DM>, DM ? GemmMainloop<TT, BMN, BMN>::DMA_LDS_BYTES : GemmCfg<TT, BMN, BMN>::LDS_BYTES); \
         (void)once;                                                                                                       \
         qkv_rope_kernel<TT, BMN, BMN, DM><<<dim3(total), dim3(256), lds_, s>>>(L);                                         \
     } while (0)

@@ -178,6 +178,28 @@ struct GemmMainloop {
         __syncthreads();
     }
 
+    // Single LDS buffer: half the LDS per workgroup, hence twice the resident workgroups per CU; costs a second barrier per K-tile.
+    // For short contractions a tile is mostly prologue / epilogue VALU and memory waits (PMC: 7 VALU per MFMA, MFMA pipe 17 % busy at
+    // K = 256), which other resident workgroups can fill — more of them beats a deeper pipeline inside one.
+    __device__ __forceinline__ void run_single(char* smem, f32x4 (&acc)[C::MI][C::NI]) {
+        const int tid = threadIdx.x;
+        const int lane = tid & 63, wave = tid >> 6;
+        const int wm = wave >> 1, wn = wave & 1;
+#pragma unroll
+        for (int i = 0; i < C::MI; ++i)
+#pragma unroll
+            for (int j = 0; j < C::NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int nk = (K * n_seg + C::BK - 1) / C::BK;
+        load_tile(0, tid);
+        for (int kt = 0; kt < nk; ++kt) {
+            store_tile(smem, tid);
+            __syncthreads();
+            if (kt + 1 < nk) load_tile(kt + 1, tid);
+            compute_tile(smem, wm, wn, lane, acc);
+            __syncthreads();
+        }
+    }
+
     __device__ __forceinline__ void run(char* smem, f32x4 (&acc)[C::MI][C::NI]) {
         const int tid = threadIdx.x;
         const int lane = tid & 63, wave = tid >> 6;
