@@ -256,6 +256,9 @@ extern "C" int sea_gemm_grouped(const SeaGemmGroup* groups, int n_groups, int dt
     bool dma = true;
     for (int i = 0; i < n_groups; ++i)
         dma = dma && (groups[i].K % (dtype == SEA_BF16 ? 64 : 32) == 0) && (long)groups[i].K * groups[i].n_seg >= dma_min_k;
+    // ... and only while the launch is a few tiles deep per CU (its time then is the serial chain of K-tiles of one tile, which the ring
+    // shortens: fc2 at B = 1 23 us vs 28); with many tiles per CU the single-buffered loop's occupancy wins (B = 8: 109 us vs 128)
+    dma = dma && t64 <= 1536;
     (void)t64;
     const int tile = pick_tile(t128, dma);
     GemmLaunch L;
