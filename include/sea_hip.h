@@ -452,6 +452,26 @@ typedef struct {
 int sea_rowchain(const SeaChainLaunch* launch, const SeaChainStage* host_stages, int dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
+ * Launch list: a whole plan (every launch of TemporalModel.forward, models/temporal.py:405-416, in order) replayed by ONE call, so the host
+ * side of a replay is a C loop over prepared argument structs instead of one interpreter round trip per launch (KV-cache rollout steps
+ * and plain, un-captured forwards are host-bound otherwise).  `op` selects the entry point, the other fields are its arguments:
+ *     SEA_OP_GEMM   p0 = SeaGemmGroup[n]                          SEA_OP_QKV    p0 = SeaQkvGroup[n], p1 = SeaQkvCommon
+ *     SEA_OP_ATTN   p0 = SeaAttnParams                            SEA_OP_NORM   p0 = SeaNormGroup[n], i0 = M, i1 = d, i2 = x_is_act, i3 = gelu, f0 = eps
+ *     SEA_OP_SILU   p0 = SeaSiluGroup[n], p1 = c, i0 = M          SEA_OP_IB     p0 = SeaIbParams
+ *     SEA_OP_CHAIN  p0 = SeaChainLaunch, p1 = host stage table    SEA_OP_CONVERT p0 = src, p1 = dst, l0 = lds, l1 = ldd, l2 = rows, l3 = cols
+ * Returns 0, or the failing entry's error code with sea_last_error() set (entries before it have been launched).
+ */
+enum { SEA_OP_GEMM = 1, SEA_OP_QKV = 2, SEA_OP_ATTN = 3, SEA_OP_NORM = 4, SEA_OP_SILU = 5, SEA_OP_IB = 6, SEA_OP_CHAIN = 7, SEA_OP_CONVERT = 8 };
+typedef struct {
+    int32_t op, n, dtype, i0, i1, i2, i3;
+    float f0;
+    const void* p0;
+    const void* p1;
+    int64_t l0, l1, l2, l3;
+} SeaLaunchRec;
+int sea_run_list(const SeaLaunchRec* recs, int n_recs, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
  * Self-test of the MFMA fragment maps this library relies on (16x16x32 bf16 and 16x16x4 f32, A/B/C lane maps):
  * multiplies exact small-integer matrices on the device and checks every element on the host.  Synchronous.
  * Returns 0 when both maps are as documented in cdna_hip_programming.md §3.

@@ -130,6 +130,14 @@ class SeaChainLaunch(C.Structure):
                 ("M", _i32), ("T", _i32), ("pos0", _i32), ("cap", _i32), ("H", _i32), ("eps", _f32), ("dbg", _vp)]
 
 
+
+OP_GEMM, OP_QKV, OP_ATTN, OP_NORM, OP_SILU, OP_IB, OP_CHAIN, OP_CONVERT = 1, 2, 3, 4, 5, 6, 7, 8
+
+
+class SeaLaunchRec(C.Structure):
+    _fields_ = [("op", _i32), ("n", _i32), ("dtype", _i32), ("i0", _i32), ("i1", _i32), ("i2", _i32), ("i3", _i32), ("f0", _f32),
+                ("p0", _vp), ("p1", _vp), ("l0", _i64), ("l1", _i64), ("l2", _i64), ("l3", _i64)]
+
 MAX_WGRAD_GROUPS = 16
 MAX_NORM_BWD_GROUPS = 8
 MAX_SILU_BWD_GROUPS = 24
@@ -177,6 +185,8 @@ def lib() -> C.CDLL:
     L.sea_dropout_mask.restype = C.c_int
     L.sea_rowchain.argtypes = [C.POINTER(SeaChainLaunch), C.POINTER(SeaChainStage), C.c_int, _vp]
     L.sea_rowchain.restype = C.c_int
+    L.sea_run_list.argtypes = [C.POINTER(SeaLaunchRec), C.c_int, _vp]
+    L.sea_run_list.restype = C.c_int
     for name in ("sea_attention_bwd", "sea_wgrad_grouped", "sea_transpose_weights", "sea_rownorm_bwd", "sea_silu_outer_bwd", "sea_ib_bwd"):
         getattr(L, name).restype = C.c_int
     L.sea_mse_fwd_bwd.argtypes = [_vp, _vp, _vp, _vp, _vp, C.c_int, _i64, C.c_float, _vp]
@@ -195,14 +205,14 @@ def lib() -> C.CDLL:
 
 ABI_STRUCTS = (SeaGemmGroup, SeaQkvGroup, SeaQkvCommon, SeaAttnProblem, SeaAttnParams, SeaNormGroup, SeaSiluGroup,
                SeaIbParams, SeaWgradGroup, SeaNormBwdGroup, SeaSiluBwdGroup, SeaIbBwdParams, SeaAttnBwdProblem, SeaAttnBwdParams,
-               SeaDropout, SeaChainStage, SeaChainLaunch)
+               SeaDropout, SeaChainStage, SeaChainLaunch, SeaLaunchRec)
 
 EXPORTED_SYMBOLS = (
     "sea_abi_version", "sea_last_error", "sea_struct_sizes", "sea_device_info", "sea_gemm_grouped", "sea_qkv_rope_grouped",
     "sea_attention_fwd", "sea_rownorm", "sea_silu_outer", "sea_ib_add", "sea_convert_f32_to_act", "sea_selftest_mfma",
     "sea_mse_fwd_bwd", "sea_relative_mse", "sea_adamw_flat",
     "sea_wgrad_grouped", "sea_transpose_weights", "sea_rownorm_bwd", "sea_silu_outer_bwd", "sea_ib_bwd",
-    "sea_attention_bwd", "sea_dropout_mask", "sea_rowchain",
+    "sea_attention_bwd", "sea_dropout_mask", "sea_rowchain", "sea_run_list",
 )
 
 

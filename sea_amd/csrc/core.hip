@@ -19,10 +19,31 @@ extern "C" int sea_struct_sizes(int* out, int cap) {
                          (int)sizeof(SeaAttnParams), (int)sizeof(SeaNormGroup), (int)sizeof(SeaSiluGroup), (int)sizeof(SeaIbParams),
                          (int)sizeof(SeaWgradGroup), (int)sizeof(SeaNormBwdGroup), (int)sizeof(SeaSiluBwdGroup), (int)sizeof(SeaIbBwdParams),
                          (int)sizeof(SeaAttnBwdProblem), (int)sizeof(SeaAttnBwdParams), (int)sizeof(SeaDropout), (int)sizeof(SeaChainStage),
-                         (int)sizeof(SeaChainLaunch)};
+                         (int)sizeof(SeaChainLaunch), (int)sizeof(SeaLaunchRec)};
     const int n = (int)(sizeof(sizes) / sizeof(sizes[0]));
     for (int i = 0; i < n && i < cap; ++i) out[i] = sizes[i];
     return n;
+}
+
+extern "C" int sea_run_list(const SeaLaunchRec* recs, int n_recs, void* stream) {
+    SEA_REQUIRE(recs != nullptr && n_recs >= 0, "sea_run_list: bad arguments");
+    for (int i = 0; i < n_recs; ++i) {
+        const SeaLaunchRec& R = recs[i];
+        int rc;
+        switch (R.op) {
+            case SEA_OP_GEMM: rc = sea_gemm_grouped(static_cast<const SeaGemmGroup*>(R.p0), R.n, R.dtype, stream); break;
+            case SEA_OP_QKV: rc = sea_qkv_rope_grouped(static_cast<const SeaQkvGroup*>(R.p0), R.n, static_cast<const SeaQkvCommon*>(R.p1), R.dtype, stream); break;
+            case SEA_OP_ATTN: rc = sea_attention_fwd(static_cast<const SeaAttnParams*>(R.p0), R.dtype, stream); break;
+            case SEA_OP_NORM: rc = sea_rownorm(static_cast<const SeaNormGroup*>(R.p0), R.n, R.i0, R.i1, R.i2, R.i3, R.f0, R.dtype, stream); break;
+            case SEA_OP_SILU: rc = sea_silu_outer(static_cast<const SeaSiluGroup*>(R.p0), R.n, static_cast<const float*>(R.p1), R.i0, R.dtype, stream); break;
+            case SEA_OP_IB: rc = sea_ib_add(static_cast<const SeaIbParams*>(R.p0), stream); break;
+            case SEA_OP_CHAIN: rc = sea_rowchain(static_cast<const SeaChainLaunch*>(R.p0), static_cast<const SeaChainStage*>(R.p1), R.dtype, stream); break;
+            case SEA_OP_CONVERT: rc = sea_convert_f32_to_act(static_cast<const float*>(R.p0), R.l0, const_cast<void*>(R.p1), R.l1, R.l2, R.l3, R.dtype, stream); break;
+            default: sea_set_error("sea_run_list[%d]: unknown op %d", i, R.op); return SEA_EINVAL;
+        }
+        if (rc != SEA_OK) return rc;   // sea_last_error() already names the entry point; the caller maps i back to its record
+    }
+    return SEA_OK;
 }
 
 extern "C" int sea_device_info(int* cu_count, char* arch, int arch_len) {

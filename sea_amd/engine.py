@@ -210,6 +210,8 @@ class Plan:
             self._build_fused()
         else:
             self._build()
+        self._clist = None          # (SeaLaunchRec array, [(rec index, field, args list, args index)]) for sea_run_list
+        self._compile_list()
 
     # ------------------------------------------------------------------ allocation helpers
     def _buf(self, *shape, dtype=None, zero=False) -> torch.Tensor:
@@ -688,6 +690,7 @@ class Plan:
             else:
                 setattr(tgt, field, cp)
         self._bound = key
+        self._relink()
 
     def set_dropout_seed(self, seed: int) -> None:
         for st in self._drop_structs:
@@ -703,12 +706,56 @@ class Plan:
             else:
                 s.q_pos0, s.Tk = pos0, pos0 + self.T
 
+    def _compile_list(self) -> None:
+        """Lower self.records to one SeaLaunchRec array (include/sea_hip.h): a sequential replay is then ONE native call instead of a
+        Python/ctypes round trip per launch.  Pointers into the argument structs are stable (the structs are patched in place)."""
+        L = N.lib()
+        recs = [r for r in self.records if r.fn is not None]
+        arr = (N.SeaLaunchRec * max(len(recs), 1))()
+        relink = []   # records whose pointer arguments live in the Python args list (patched by bind): copied again at bind time
+        addr = lambda o: C.addressof(o)
+        for i, r in enumerate(recs):
+            c, a = arr[i], r.args
+            if r.fn is L.sea_gemm_grouped:
+                c.op, c.p0, c.n, c.dtype = N.OP_GEMM, addr(a[0]), a[1], a[2]
+            elif r.fn is L.sea_qkv_rope_grouped:
+                c.op, c.p0, c.n, c.p1, c.dtype = N.OP_QKV, addr(a[0]), a[1], addr(r.keep[1]), a[3]
+            elif r.fn is L.sea_attention_fwd:
+                c.op, c.p0, c.dtype = N.OP_ATTN, addr(r.keep), a[1]
+            elif r.fn is L.sea_rownorm:
+                c.op, c.p0, c.n, c.i0, c.i1, c.i2, c.i3, c.f0, c.dtype = N.OP_NORM, addr(a[0]), a[1], a[2], a[3], a[4], a[5], a[6], a[7]
+            elif r.fn is L.sea_silu_outer:
+                c.op, c.p0, c.n, c.i0, c.dtype = N.OP_SILU, addr(a[0]), a[1], a[3], a[4]
+                relink.append((i, "p1", a, 2))
+            elif r.fn is L.sea_ib_add:
+                c.op, c.p0 = N.OP_IB, addr(r.keep)
+            elif r.fn is L.sea_rowchain:
+                c.op, c.p0, c.p1, c.dtype = N.OP_CHAIN, addr(r.keep[1]), addr(r.keep[0].host), a[2]
+            elif r.fn is L.sea_convert_f32_to_act:
+                c.op, c.l0, c.p1, c.l1, c.l2, c.l3, c.dtype = N.OP_CONVERT, a[1], a[2], a[3], a[4], a[5], a[6]
+                relink.append((i, "p0", a, 0))
+            else:
+                return  # a record the list runner does not know (training plans): keep the per-launch replay
+        self._clist = (arr, len(recs), relink)
+        self._relink()
+
+    def _relink(self) -> None:
+        if self._clist is not None:
+            arr, _, relink = self._clist
+            for i, field, args, k in relink:
+                setattr(arr[i], field, args[k])
+
     def run(self, concurrent: bool = False) -> None:
         """Replay the launch list.  Sequentially on the current stream (record order is a valid order), or — `concurrent` — with every
         lane on its own stream, forked from / joined to the current stream by events; inside a graph capture the lanes become
         parallel branches of the graph."""
         main = torch.cuda.current_stream()
         stream = main.cuda_stream
+        if not concurrent and self._clist is not None:
+            rc = N.lib().sea_run_list(self._clist[0], self._clist[1], stream)
+            if rc != 0:
+                N.check(rc, "plan replay (sea_run_list)")
+            return
         if not concurrent:
             for r in self.records:
                 if r.fn is None:
