@@ -81,27 +81,38 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradLaunch L) {
     const int wn = wave >> 1, wk = wave & 1;
     const T* dY = static_cast<const T*>(G.dY);
     const T* X = static_cast<const T*>(G.X);
-    uint4 ry[NCH], rx[NCH];
-    auto load_stage = [&](int ms) {
+    // Stages are requested TWO ahead into two register sets (stage s waits in set s & 1 from its request in step s - 2 to its LDS store
+    // at the end of step s - 1): a 64-row stage is only 32 MFMAs of work per wave against a ~2 us memory round trip, and at two
+    // resident workgroups per CU nothing else hides it.  Loads are unconditional (rows clamped, columns clamped, out-of-range data
+    // zeroed by a select at the store) so that the compiler can wait with vmcnt(N) for the older set alone.
+    uint4 ry[2][NCH], rx[2][NCH];
+    auto load_stage = [&](int ms, auto set_tag) {
+        constexpr int ST = decltype(set_tag)::value;
 #pragma unroll
         for (int u = 0; u < NCH; ++u) {
             const int idx = tid + u * 256;
             const int rr = idx / CPR, cc = idx - rr * CPR;
-            const int m = ms + rr;
-            const int cn = n0 + cc * EPC, ck = k0 + cc * EPC;
-            ry[u] = (m < m_end && cn < G.N) ? *reinterpret_cast<const uint4*>(dY + (int64_t)m * G.lddy + cn) : make_uint4(0, 0, 0, 0);
-            rx[u] = (m < m_end && ck < G.K) ? *reinterpret_cast<const uint4*>(X + (int64_t)m * G.ldx + ck) : make_uint4(0, 0, 0, 0);
+            int m = ms + rr;
+            m = m < m_end ? m : m_end - 1;
+            int cn = n0 + cc * EPC, ck = k0 + cc * EPC;
+            cn = cn < G.N ? cn : G.N - EPC;
+            ck = ck < G.K ? ck : G.K - EPC;
+            ry[ST][u] = *reinterpret_cast<const uint4*>(dY + (int64_t)m * G.lddy + cn);
+            rx[ST][u] = *reinterpret_cast<const uint4*>(X + (int64_t)m * G.ldx + ck);
         }
     };
-    auto store_stage = [&](int buf) {
+    auto store_stage = [&](int buf, int ms, auto set_tag) {
+        constexpr int ST = decltype(set_tag)::value;
         char* sy = smem + buf * 2 * TILE_B;
         char* sx = sy + TILE_B;
 #pragma unroll
         for (int u = 0; u < NCH; ++u) {
             const int idx = tid + u * 256;
             const int rr = idx / CPR, cc = idx - rr * CPR;
-            *reinterpret_cast<uint4*>(sy + rr * PITCH + cc * 16) = ry[u];
-            *reinterpret_cast<uint4*>(sx + rr * PITCH + cc * 16) = rx[u];
+            const bool mok = ms + rr < m_end;
+            const bool yok = mok && n0 + cc * EPC < G.N, xok = mok && k0 + cc * EPC < G.K;
+            *reinterpret_cast<uint4*>(sy + rr * PITCH + cc * 16) = yok ? ry[ST][u] : make_uint4(0, 0, 0, 0);
+            *reinterpret_cast<uint4*>(sx + rr * PITCH + cc * 16) = xok ? rx[ST][u] : make_uint4(0, 0, 0, 0);
         }
     };
 
@@ -114,34 +125,46 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradLaunch L) {
     const bool do_bias = G.db != nullptr && tk == 0 && tid < TS;
 
     const int n_stage = (m_end - m_begin + 63) / 64;
-    load_stage(m_begin);
-    store_stage(0);
-    __syncthreads();
-    for (int st = 0; st < n_stage; ++st) {
-        const char* sy = smem + (st & 1) * 2 * TILE_B;
-        const char* sx = sy + TILE_B;
-        const bool more = st + 1 < n_stage;
-        if (more) load_stage(m_begin + (st + 1) * 64);
+    using Set0 = std::integral_constant<int, 0>;
+    using Set1 = std::integral_constant<int, 1>;
+    auto step = [&](int st, auto cur_tag, auto nxt_tag) {
+        // request stage st + 2 (set st & 1, emptied at the end of step st - 1), multiply stage st, then move stage st + 1 to the other buffer
+        const int ms2 = m_begin + (st + 2) * 64;
+        load_stage(ms2 < m_end ? ms2 : m_end - 1, cur_tag);   // past the end: a harmless re-read, zeroed / never used
+        if (st >= 0) {
+            const char* sy = smem + (st & 1) * 2 * TILE_B;
+            const char* sx = sy + TILE_B;
 #pragma unroll
-        for (int mk = 0; mk < 64; mk += CK) {
-            uint4 a[MI], b[MI];
+            for (int mk = 0; mk < 64; mk += CK) {
+                uint4 a[MI], b[MI];
 #pragma unroll
-            for (int i = 0; i < MI; ++i) a[i] = load_frag_T<T>(sy, PITCH, mk, wn * WT + i * 16, lane);
+                for (int i = 0; i < MI; ++i) a[i] = load_frag_T<T>(sy, PITCH, mk, wn * WT + i * 16, lane);
 #pragma unroll
-            for (int j = 0; j < MI; ++j) b[j] = load_frag_T<T>(sx, PITCH, mk, wk * WT + j * 16, lane);
+                for (int j = 0; j < MI; ++j) b[j] = load_frag_T<T>(sx, PITCH, mk, wk * WT + j * 16, lane);
 #pragma unroll
-            for (int i = 0; i < MI; ++i)
+                for (int i = 0; i < MI; ++i)
 #pragma unroll
-                for (int j = 0; j < MI; ++j) mma16<T>(a[i], b[j], acc[i][j]);
-        }
-        if (do_bias) {
-            const T* col = reinterpret_cast<const T*>(sy) + tid;
+                    for (int j = 0; j < MI; ++j) mma16<T>(a[i], b[j], acc[i][j]);
+            }
+            if (do_bias) {
+                const T* col = reinterpret_cast<const T*>(sy) + tid;
 #pragma unroll 8
-            for (int rr = 0; rr < 64; ++rr) bsum += to_f32(*reinterpret_cast<const T*>(reinterpret_cast<const char*>(col) + rr * PITCH));
+                for (int rr = 0; rr < 64; ++rr) bsum += to_f32(*reinterpret_cast<const T*>(reinterpret_cast<const char*>(col) + rr * PITCH));
+            }
         }
-        if (more) store_stage((st + 1) & 1);
+        store_stage((st + 1) & 1, m_begin + (st + 1) * 64, nxt_tag);   // stage st + 1 (requested one step ago); st = -2 stores zeros-by-select
         __syncthreads();
+    };
+#pragma unroll
+    for (int u = 0; u < NCH; ++u) ry[0][u] = ry[1][u] = rx[0][u] = rx[1][u] = make_uint4(0, 0, 0, 0);
+    // the pipeline fills inside the loop (steps -2, -1 only request and store), whole pairs only: the loop is entered with nothing in
+    // flight and has no conditional load, the two things the compiler needs to count the loads (see attention.hip)
+    int st = -2;
+    for (; st + 1 < n_stage; st += 2) {
+        step(st, Set0{}, Set1{});
+        step(st + 1, Set1{}, Set0{});
     }
+    if (st < n_stage) step(st, Set0{}, Set1{});
     // C[n][k]: lane holds column k = lane & 15, rows n = 4 (lane >> 4) + reg
     const int r = lane & 15, g = lane >> 4;
 #pragma unroll
