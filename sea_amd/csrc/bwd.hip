@@ -711,9 +711,9 @@ __global__ __launch_bounds__(256) void silu_outer_bwd_kernel(const SiluBwdLaunch
             load4(G.b1 + i, bb[k]);
         }
     }
-    // RB rows per trip with all their loads requested first: a row is only K2 * sizeof(T) bytes (1 KB at K2 = 512), one row per trip
-    // left every wave waiting a full memory round trip per kilobyte
-    constexpr int RB = 4;
+    // RB rows per trip with their loads requested together.  Measured at cfg3 (K2 = 512): RB = 1 111 us, 2 123 us, 4 129 us — the extra
+    // registers cost more occupancy than the extra loads in flight return, so one row per trip it is.
+    constexpr int RB = 1;
     const int rstep = 4 * gridDim.x;
     for (int row0 = blockIdx.x * 4 + wave; row0 < L.M; row0 += RB * rstep) {
         float cv[RB], dv[RB][KM][4];
