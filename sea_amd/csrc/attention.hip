@@ -23,7 +23,8 @@ struct AttnCfg {
     static constexpr int NCH = (HD + CK - 1) / CK;           // head-dim chunks of the S^T contraction
     static constexpr int NDB = (HD + 15) / 16;               // 16-row d blocks of O^T
     static constexpr int K_ROW = HD * (int)sizeof(T);        // bytes per key row
-    static constexpr int K_STRIDE = K_ROW + 16;              // padded LDS stride
+    static constexpr int K_COLS = HD < CK ? CK : HD;         // LDS row holds a whole contraction chunk: columns >= HD are zeros, written once
+    static constexpr int K_STRIDE = K_COLS * (int)sizeof(T) + 16;   // padded LDS stride
     static constexpr int V_ROW = 64 * (int)sizeof(T);        // bytes per d row of the V^T tile
     static constexpr int V_STRIDE = V_ROW + 16;
     static constexpr int K_BYTES = 64 * K_STRIDE;
@@ -174,8 +175,8 @@ __global__ __launch_bounds__(256 * SPLIT) void attention_fwd_kernel(const SeaAtt
                 s[kc][be] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int c = 0; c < C::NCH; ++c) {
-                    uint4 a = make_uint4(0, 0, 0, 0);
-                    if (c * C::CK + g * C::EPC < HD) a = *reinterpret_cast<const uint4*>(sK + k_frag_off[kc][be] + c * C::CK * (int)sizeof(T));
+                    // head dims below one contraction chunk: the tile rows are zero-padded in LDS, so no lane needs a select here
+                    const uint4 a = *reinterpret_cast<const uint4*>(sK + k_frag_off[kc][be] + c * C::CK * (int)sizeof(T));
                     mma16<T>(a, qf[c], s[kc][be]);
                 }
             }
@@ -254,6 +255,14 @@ __global__ __launch_bounds__(256 * SPLIT) void attention_fwd_kernel(const SeaAtt
         l_i = l_i * alpha + psum;
     };
 
+    if constexpr (HD < C::CK) {   // zero columns HD .. CK-1 of every key row of both buffers of this group (the staging never touches them)
+        constexpr int PADB = (C::CK - HD) * (int)sizeof(T);   // multiple of 16
+        for (int i = tid; i < 2 * 64 * (PADB / 16); i += 256) {
+            const int buf = i / (64 * (PADB / 16)), rem = i - buf * 64 * (PADB / 16);
+            const int row = rem / (PADB / 16), cc = rem - row * (PADB / 16);
+            *reinterpret_cast<uint4*>(smem + buf * C::LDS_BYTES + row * C::K_STRIDE + C::K_ROW + cc * 16) = make_uint4(0, 0, 0, 0);
+        }
+    }
     // group g walks tiles g, g + SPLIT, ...; every thread of the workgroup executes every barrier
     const int n_it = (n_kt + SPLIT - 1) / SPLIT;
     if (grp < n_kt) {

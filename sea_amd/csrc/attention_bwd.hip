@@ -42,7 +42,8 @@ struct BwdCfg {
     static constexpr int NCH = (HD + CK - 1) / CK;           // head-dim chunks of a contraction over d
     static constexpr int NDB = (HD + 15) / 16;               // 16-wide d blocks
     static constexpr int ROW = HD * (int)sizeof(T);
-    static constexpr int PITCH = (NDB * 16) * (int)sizeof(T) + 16;  // rows padded to whole 16-column blocks (+16 B)
+    static constexpr int PCOLS = NDB * 16 < CK ? CK : NDB * 16;     // a row holds whole 16-column blocks and at least one contraction chunk
+    static constexpr int PITCH = PCOLS * (int)sizeof(T) + 16;       // (+16 B against bank conflicts); columns >= HD are zeros, written once
     static constexpr int TILE = 64 * PITCH;
     static constexpr int CPR = HD / EPC;                     // 16-byte chunks per row
     static constexpr int NR = (64 * CPR + 255) / 256;        // chunks per thread per tile
@@ -81,6 +82,22 @@ struct TileStager {
         }
     }
 };
+
+// zero columns HD .. PCOLS-1 of the n_tiles row-major tiles at `base` (the stagers only ever write the first HD columns)
+template <typename T, int HD>
+__device__ __forceinline__ void zero_tile_padding(char* base, int n_tiles, int tid) {
+    using C = BwdCfg<T, HD>;
+    constexpr int PADB = (C::PCOLS - HD) * (int)sizeof(T);
+    if constexpr (PADB > 0) {
+        constexpr int CH = PADB / 16;
+        static_assert(PADB % 16 == 0, "padding must be whole 16-byte chunks");
+        for (int i = tid; i < n_tiles * 64 * CH; i += 256) {
+            const int t = i / (64 * CH), rem = i - t * 64 * CH;
+            const int row = rem / CH, cc = rem - row * CH;
+            *reinterpret_cast<uint4*>(base + t * C::TILE + row * C::PITCH + HD * (int)sizeof(T) + cc * 16) = make_uint4(0, 0, 0, 0);
+        }
+    }
+}
 
 // inverse rotation of one (even, odd) pair: the forward was (e', o') = (e c - o s, e s + o c)
 __device__ __forceinline__ void unrope(float& e, float& o, const float2 cs) {
@@ -159,14 +176,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const SeaAttnBwdParams
         for (int kc = 0; kc < C::KCH; ++kc) {
 #pragma unroll
             for (int be = 0; be < C::NB; ++be) {
-                f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+                // without dropout the "- delta" of dS = P (dP - delta) rides in the MFMA's C operand: dP starts at -delta
+                f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = DROP ? f32x4{0.f, 0.f, 0.f, 0.f} : f32x4{-delta, -delta, -delta, -delta};
 #pragma unroll
                 for (int c = 0; c < C::NCH; ++c) {
-                    uint4 ak = make_uint4(0, 0, 0, 0), av = make_uint4(0, 0, 0, 0);
-                    if (c * C::CK + g * C::EPC < HD) {
-                        ak = *reinterpret_cast<const uint4*>(sK + frag_off[kc][be] + c * C::CK * (int)sizeof(T));
-                        av = *reinterpret_cast<const uint4*>(sV + frag_off[kc][be] + c * C::CK * (int)sizeof(T));
-                    }
+                    const uint4 ak = *reinterpret_cast<const uint4*>(sK + frag_off[kc][be] + c * C::CK * (int)sizeof(T));   // rows zero-padded to CK
+                    const uint4 av = *reinterpret_cast<const uint4*>(sV + frag_off[kc][be] + c * C::CK * (int)sizeof(T));
                     mma16<T>(ak, qf[c], s);
                     mma16<T>(av, dof[c], dp);
                 }
@@ -185,7 +200,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const SeaAttnBwdParams
                         if (!(key <= limit && key < Tk)) p = 0.f;
                     }
                     if constexpr (DROP) ds[kc][be][q] = p * (dp[q] * dfac[q] - delta);
-                    else ds[kc][be][q] = p * (dp[q] - delta);
+                    else ds[kc][be][q] = p * dp[q];
                 }
             }
         }
@@ -201,6 +216,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const SeaAttnBwdParams
         }
     };
 
+    zero_tile_padding<T, HD>(smem, 4, tid);
     TileStager<T, HD> stK, stV;
     stK.load(Kg, HD, 0, Tk, tid);
     stV.load(Vg, HD, 0, Tk, tid);
@@ -298,20 +314,17 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const SeaAttnBwdParam
         for (int qc = 0; qc < C::KCH; ++qc) {
 #pragma unroll
             for (int be = 0; be < C::NB; ++be) {
-                f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int c = 0; c < C::NCH; ++c) {
-                    uint4 aq = make_uint4(0, 0, 0, 0), ao = make_uint4(0, 0, 0, 0);
-                    if (c * C::CK + g * C::EPC < HD) {
-                        aq = *reinterpret_cast<const uint4*>(sQ + frag_off[qc][be] + c * C::CK * (int)sizeof(T));
-                        ao = *reinterpret_cast<const uint4*>(sO + frag_off[qc][be] + c * C::CK * (int)sizeof(T));
-                    }
-                    mma16<T>(aq, kf[c], s);
-                    mma16<T>(ao, vf[c], dp);
-                }
                 const int ql = qc * C::CK + g * C::EPC + be * 4;  // this lane's 4 consecutive queries of the tile
                 const f32x4 l4 = *reinterpret_cast<const f32x4*>(sL + ql);        // -lse * log2e (scaled when staged)
                 const f32x4 d4 = *reinterpret_cast<const f32x4*>(sL + 64 + ql);
+                f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = DROP ? f32x4{0.f, 0.f, 0.f, 0.f} : -d4;   // "- delta" in the C operand, as in the dQ kernel
+#pragma unroll
+                for (int c = 0; c < C::NCH; ++c) {
+                    const uint4 aq = *reinterpret_cast<const uint4*>(sQ + frag_off[qc][be] + c * C::CK * (int)sizeof(T));   // rows zero-padded to CK
+                    const uint4 ao = *reinterpret_cast<const uint4*>(sO + frag_off[qc][be] + c * C::CK * (int)sizeof(T));
+                    mma16<T>(aq, kf[c], s);
+                    mma16<T>(ao, vf[c], dp);
+                }
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     float p = __builtin_amdgcn_exp2f(fmaf(s[q], LOG2E, l4[q]));
@@ -326,7 +339,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const SeaAttnBwdParam
                         ds[qc][be][q] = p * (dp[q] * dfac - d4[q]);  // dS = P (D dP - delta)
                     } else {
                         pp[qc][be][q] = p;
-                        ds[qc][be][q] = p * (dp[q] - d4[q]);
+                        ds[qc][be][q] = p * dp[q];
                     }
                 }
             }
@@ -361,6 +374,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const SeaAttnBwdParam
             sl[64 + tid] = r_del;
         }
     };
+    zero_tile_padding<T, HD>(smem, 4, tid);
     if (qt0 < n_qt) {
         stQ.load(Qg, HD, qt0 * 64, Tq, tid);
         stO.load(dOg, P.lddo, qt0 * 64, Tq, tid);
