@@ -34,7 +34,8 @@ __device__ __forceinline__ int find_group(const L& launch, int bid) {
 }
 
 // ---------------------------------------------------------------------------------------------- standard epilogue
-template <typename T, int BM, int BN, bool DMA>
+// PLAIN: every group of the launch has act == 0 and no dropout (most launches): the epilogue is compiled without those options.
+template <typename T, int BM, int BN, bool DMA, bool PLAIN>
 __global__ __launch_bounds__(256) void gemm_grouped_kernel(const GemmLaunch L) {
     using C = GemmCfg<T, BM, BN>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -53,8 +54,7 @@ __global__ __launch_bounds__(256) void gemm_grouped_kernel(const GemmLaunch L) {
     ml.m0 = tm * BM; ml.n0 = tn * BN;
     f32x4 acc[C::MI][C::NI];
     if constexpr (DMA) ml.run_dma(smem, acc);
-    else if (L.single_buffer) ml.run_single(smem, acc);
-    else ml.run(smem, acc);
+    else ml.run_single(smem, acc);
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave >> 1, wn = wave & 1, r = lane & 15, g = lane >> 4;
@@ -86,7 +86,7 @@ __global__ __launch_bounds__(256) void gemm_grouped_kernel(const GemmLaunch L) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) v[q] = acc[i][j][q] + bv[q];
             float df[4] = {1.f, 1.f, 1.f, 1.f};
-            if (G.drop.thr > 0) {
+            if (!PLAIN && G.drop.thr > 0) {
                 const uint32_t w = drop_word(G.drop.seed, G.drop.stream, (uint32_t)m, (uint32_t)(n >> 2));
                 const float sc = drop_scale(G.drop.thr);
 #pragma unroll
@@ -96,7 +96,8 @@ __global__ __launch_bounds__(256) void gemm_grouped_kernel(const GemmLaunch L) {
                     for (int q = 0; q < 4; ++q) v[q] *= df[q];
                 }
             }
-            if (act == 1) {
+            if (PLAIN) {
+            } else if (act == 1) {
                 if (Z != nullptr) store4(Z + (int64_t)m * G.ldz + n, v[0], v[1], v[2], v[3]);
 #pragma unroll
                 for (int q = 0; q < 4; ++q) v[q] = gelu_erf(v[q]);
@@ -113,7 +114,7 @@ __global__ __launch_bounds__(256) void gemm_grouped_kernel(const GemmLaunch L) {
                 for (int q = 0; q < 4; ++q) v[q] += rv[q];
             }
             if (C32 != nullptr) store4(C32 + (int64_t)m * G.ldc32 + n, v[0], v[1], v[2], v[3]);
-            if (G.drop.thr > 0 && G.drop.mode == 2) {  // backward: only the copy that feeds the dropped branch is masked
+            if (!PLAIN && G.drop.thr > 0 && G.drop.mode == 2) {  // backward: only the copy that feeds the dropped branch is masked
 #pragma unroll
                 for (int q = 0; q < 4; ++q) v[q] *= df[q];
             }
@@ -155,8 +156,7 @@ __global__ __launch_bounds__(256) void qkv_rope_kernel(const QkvLaunch L) {
     ml.m0 = tm * BM; ml.n0 = tn * BN;
     f32x4 acc[C::MI][C::NI];
     if constexpr (DMA) ml.run_dma(smem, acc);
-    else if (L.single_buffer) ml.run_single(smem, acc);
-    else ml.run(smem, acc);
+    else ml.run_single(smem, acc);
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave >> 1, wn = wave & 1, r = lane & 15, g = lane >> 4;
@@ -272,17 +272,21 @@ extern "C" int sea_gemm_grouped(const SeaGemmGroup* groups, int n_groups, int dt
     }
     L.tile_start[n_groups] = total;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    static const int sb_env = []() { const char* e = getenv("SEA_GEMM_SINGLE"); return e ? atoi(e) : 1; }();  // tuning aid: 0 = double buffer
-    L.single_buffer = sb_env && !dma;
+    bool plain = true;
+    for (int i = 0; i < n_groups; ++i) plain = plain && groups[i].act == 0 && groups[i].drop.thr == 0;
+    L.single_buffer = !dma;
     const int sb = L.single_buffer;
 #define LAUNCH_GEMM(TT, BMN, DM)                                                                                          \
     do {                                                                                                                  \
         const int main_ = DM ? GemmMainloop<TT, BMN, BMN>::DMA_LDS_BYTES : (sb ? GemmCfg<TT, BMN, BMN>::BUF_BYTES : GemmCfg<TT, BMN, BMN>::LDS_BYTES); \
         constexpr int stage_ = BMN * (BMN * (int)sizeof(TT) + 16);                                                         \
         const int lds_ = main_ > stage_ ? main_ : stage_;                                                                  \
-        static int once = set_lds(gemm_grouped_kernel<TT, BMN, BMN, DM>, DM ? GemmMainloop<TT, BMN, BMN>::DMA_LDS_BYTES : (GemmCfg<TT, BMN, BMN>::LDS_BYTES > stage_ ? GemmCfg<TT, BMN, BMN>::LDS_BYTES : stage_)); \
+        static int once = set_lds(gemm_grouped_kernel<TT, BMN, BMN, DM, false>, DM ? GemmMainloop<TT, BMN, BMN>::DMA_LDS_BYTES : (GemmCfg<TT, BMN, BMN>::LDS_BYTES > stage_ ? GemmCfg<TT, BMN, BMN>::LDS_BYTES : stage_)); \
         (void)once;                                                                                                       \
-        gemm_grouped_kernel<TT, BMN, BMN, DM><<<dim3(total), dim3(256), lds_, s>>>(L);                                     \
+        static int once2 = set_lds(gemm_grouped_kernel<TT, BMN, BMN, DM, true>, DM ? GemmMainloop<TT, BMN, BMN>::DMA_LDS_BYTES : (GemmCfg<TT, BMN, BMN>::LDS_BYTES > stage_ ? GemmCfg<TT, BMN, BMN>::LDS_BYTES : stage_)); \
+        (void)once2;                                                                                                      \
+        if (plain) gemm_grouped_kernel<TT, BMN, BMN, DM, true><<<dim3(total), dim3(256), lds_, s>>>(L);                    \
+        else gemm_grouped_kernel<TT, BMN, BMN, DM, false><<<dim3(total), dim3(256), lds_, s>>>(L);                         \
     } while (0)
 #define LAUNCH_GEMM_T(TT)                                                 \
     do {                                                                  \
