@@ -167,6 +167,18 @@ __global__ __launch_bounds__(256) void qkv_rope_kernel(const QkvLaunch L) {
     T* Ko = static_cast<T*>(G.Kout);
     T* Vto = static_cast<T*>(G.Vtout);
     T* Vo = static_cast<T*>(G.Vout);
+    // per-row bookkeeping once (the integer division by T is ~20 instructions; it used to run per 4-column piece: PMC showed 19 VALU
+    // instructions per MFMA in this kernel), 32-bit element offsets (the host checks the tensors stay below 2^31 elements)
+    int rb[C::MI], rt[C::MI];
+    bool rok[C::MI];
+#pragma unroll
+    for (int i = 0; i < C::MI; ++i) {
+        const int m = ml.m0 + wm * C::WTM + i * 16 + r;
+        rok[i] = m < G.M;
+        const int mc = rok[i] ? m : G.M - 1;
+        rb[i] = mc / Tlen;
+        rt[i] = mc - rb[i] * Tlen;
+    }
 #pragma unroll
     for (int j = 0; j < C::NI; ++j) {
         const int n = ml.n0 + wn * C::WTN + j * 16 + g * 4;  // 4 consecutive columns = two (even, odd) rotation pairs
@@ -174,36 +186,33 @@ __global__ __launch_bounds__(256) void qkv_rope_kernel(const QkvLaunch L) {
         float bv[4] = {0.f, 0.f, 0.f, 0.f};
         if (G.bias != nullptr) load4(G.bias + n, bv);
         const int nn = G.col0 + n;       // column in the virtual [q | k | v] row; hd % 4 == 0 keeps the 4 columns in one head
-        const int part = nn / Ea;        // 0 q, 1 k, 2 v
+        const int part = nn >= 2 * Ea ? 2 : (nn >= Ea ? 1 : 0);   // 0 q, 1 k, 2 v
         const int hcol = nn - part * Ea;
         const int h = hcol / hd;
         const int dd = hcol - h * hd;
 #pragma unroll
         for (int i = 0; i < C::MI; ++i) {
-            const int m = ml.m0 + wm * C::WTM + i * 16 + r;
-            if (m >= G.M) continue;
-            const int b = m / Tlen;
-            const int tt = m - b * Tlen;
-            const int pos = L.c.pos0 + tt;
+            if (!rok[i]) continue;
+            const int tt = rt[i], pos = L.c.pos0 + tt;
             float v[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) v[q] = acc[i][j][q] + bv[q];
-            const int64_t bh = (int64_t)b * H + h;
+            const uint32_t bh = (uint32_t)(rb[i] * H + h);
             if (part < 2) {
                 // (xe + i xo)(c + i s): even' = xe c - xo s ; odd' = xe s + xo c   (fp32, before rounding)
-                const float2 c0 = rope[(int64_t)pos * hd2 + (dd >> 1)];
-                const float2 c1 = rope[(int64_t)pos * hd2 + (dd >> 1) + 1];
-                float o[4] = {v[0] * c0.x - v[1] * c0.y, v[0] * c0.y + v[1] * c0.x, v[2] * c1.x - v[3] * c1.y, v[2] * c1.y + v[3] * c1.x};
+                const float4 cs = *reinterpret_cast<const float4*>(rope + (uint32_t)pos * (uint32_t)hd2 + (dd >> 1));   // two (cos, sin) pairs
+                const float o[4] = {v[0] * cs.x - v[1] * cs.y, v[0] * cs.y + v[1] * cs.x, v[2] * cs.z - v[3] * cs.w, v[2] * cs.w + v[3] * cs.z};
                 if (part == 0) {
                     const float sc = L.c.q_scale;
-                    store4(Qo + (bh * Tlen + tt) * hd + dd, o[0] * sc, o[1] * sc, o[2] * sc, o[3] * sc);
+                    store4(Qo + ((bh * (uint32_t)Tlen + tt) * (uint32_t)hd + dd), o[0] * sc, o[1] * sc, o[2] * sc, o[3] * sc);
                 } else {
-                    store4(Ko + (bh * cap + pos) * hd + dd, o[0], o[1], o[2], o[3]);
+                    store4(Ko + ((bh * (uint32_t)cap + pos) * (uint32_t)hd + dd), o[0], o[1], o[2], o[3]);
                 }
             } else {
+                T* dst = Vto + ((bh * (uint32_t)hd + dd) * (uint32_t)cap + pos);
 #pragma unroll
-                for (int q = 0; q < 4; ++q) Vto[(bh * hd + dd + q) * cap + pos] = from_f32<T>(v[q]);
-                if (Vo != nullptr) store4(Vo + (bh * cap + pos) * hd + dd, v[0], v[1], v[2], v[3]);
+                for (int q = 0; q < 4; ++q) dst[(uint32_t)q * (uint32_t)cap] = from_f32<T>(v[q]);
+                if (Vo != nullptr) store4(Vo + ((bh * (uint32_t)cap + pos) * (uint32_t)hd + dd), v[0], v[1], v[2], v[3]);
             }
         }
     }
@@ -320,6 +329,8 @@ extern "C" int sea_qkv_rope_grouped(const SeaQkvGroup* groups, int n_groups, con
         SEA_REQUIRE((!hasq || G.Qout) && (!hask || G.Kout) && (!hasv || G.Vtout), "sea_qkv_rope_grouped[%d]: missing output pointer", i);
         SEA_REQUIRE(sea_aligned16(G.bias) && sea_aligned16(G.Qout) && sea_aligned16(G.Kout) && sea_aligned16(G.Vtout) && sea_aligned16(G.Vout),
                     "sea_qkv_rope_grouped[%d]: pointers must be 16-byte aligned", i);
+        SEA_REQUIRE((int64_t)(G.M / c.T + 1) * c.H * c.cap * c.hd < ((int64_t)1 << 31) && (int64_t)(c.pos0 + c.T) * (c.hd / 2) < ((int64_t)1 << 30),
+                    "sea_qkv_rope_grouped[%d]: attention tensors too large for 32-bit element offsets", i);
         t128 += (long)((G.M + 127) / 128) * ((G.N + 127) / 128);
         t64 += (long)((G.M + 63) / 64) * ((G.N + 63) / 64);
     }
