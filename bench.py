@@ -241,7 +241,28 @@ def main():
         torch.cuda.synchronize()
         times = plan.time_records(iters=max(args.steps, 5))
     total_ms = sum(t for _, t in times)
-    name, dom_ms = max(times, key=lambda nt: nt[1])
+    name, dom_ms_events = max(times, key=lambda nt: nt[1])
+    # the dominant launch alone, 20 back-to-back launches captured in one graph between two HIP events on the launch stream: the per-launch
+    # figure then carries no event / launch-gap overhead and is the one to compare with rocprofv3's average duration of that kernel
+    rec = next(r for r in plan.records if r.fn is not None and r.name == name)
+    st = torch.cuda.Stream()
+    gk = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(st):
+        with torch.cuda.graph(gk, stream=st):
+            for _ in range(20):
+                rc = rec.fn(*rec.args, st.cuda_stream)
+                assert rc == 0, name
+    gk.replay()
+    torch.cuda.synchronize()
+    best = 1e30
+    for _ in range(5):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        gk.replay()
+        e1.record()
+        torch.cuda.synchronize()
+        best = min(best, e0.elapsed_time(e1) / 20)
+    dom_ms = best
     dom_flops = kernel_flops(name, B, T, F, E, H, D, S)
     achieved = dom_flops / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
 
@@ -270,8 +291,10 @@ def main():
             "model_mfma_frac": gflop / (ms_per_step * 1e-3) / 1e3 / PEAK_BF16_TFLOPS,
             "roofline": {"kernel": name, "bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_BF16_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
-                         "launch_ms": dom_ms, "launch_gflop": dom_flops / 1e9, "device_ms_all_launches": total_ms,
-                         "timing": "HIP events around every launch of the plan, separate instrumented pass"},
+                         "launch_ms": dom_ms, "launch_ms_single_event_pair": dom_ms_events, "launch_gflop": dom_flops / 1e9,
+                         "device_ms_all_launches": total_ms,
+                         "timing": "launch_ms: HIP events around 20 back-to-back launches of the dominant record (one captured graph) / 20; "
+                                   "launch_breakdown_ms: one event pair per launch of the plan (includes ~3-6 us of event / launch gap each)"},
             "launch_breakdown_ms": {n: round(t, 4) for n, t in times},
         }
         if world == 1 and not args.no_cpu_baseline:
