@@ -400,24 +400,51 @@ def main_decode(args):
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no GPU visible (the product path has no CPU fallback)")
     from sea_amd.models.encoder_decoder import Decode
+    from sea_amd.utils.data_processors import DataPartitioner2D, MeshUnpatcher, MinMaxScaler
     from sea_amd.utils.train_utils import decode_rollout
 
     dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
     torch.cuda.set_device(dev)
-    groups, n_inp, hidden, D, P = [[0, 1], [2]], 512, 480, 16, 64
+    groups, hidden, D, P = [[0, 1], [2]], 480, 16, 64
     tr, T = args.batch, args.seq
     torch.manual_seed(42)
+    # synthetic 2-D mesh: 30000 points, denser towards x = 0.3 (a wake-like refinement), 8 x 8 cells as in the shipped config (m = n = 9)
+    gen = torch.Generator().manual_seed(7)
+    n_points = 30000
+    px = torch.rand(n_points, generator=gen); px[: n_points // 3] = 0.25 + 0.1 * torch.rand(n_points // 3, generator=gen)
+    py = torch.rand(n_points, generator=gen)
+    part = DataPartitioner2D(px, py, m=9, n=9, device=dev)
+    C_pad = part.padded_index_map.shape[1]
+    n_inp = (C_pad + 3) // 4 * 4
+    scalers = []
+    for lo, hi in ((-1.0, 3.0), (0.5, 2.0)):
+        sc = MinMaxScaler()
+        sc.min_val, sc.max_val = torch.tensor(lo), torch.tensor(hi)
+        scalers.append(sc)
+    unpatcher = MeshUnpatcher(part, groups, scalers)
     dec = Decode(groups, n_inp, hidden, D).set_compute_dtype(args.dtype).to(dev).eval()
     roll = torch.randn(tr, T, len(groups), P * D, generator=torch.Generator().manual_seed(1234)).to(dev)
     with torch.no_grad():
+        def step():
+            dec_out = decode_rollout(dec, roll, P)                                              # [tr*T, P, 3, n_inp]
+            return dec_out, unpatcher.inverse_scale_and_unpatch(dec_out[..., :C_pad], layout="BPFC")   # [tr*T, n_points, 3]
+
         for _ in range(max(args.warmup, 1)):
-            out = decode_rollout(dec, roll, P)
+            dec_out, out = step()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(args.steps):
-            out = decode_rollout(dec, roll, P)
+            dec_out, out = step()
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            unpatcher.inverse_scale_and_unpatch(dec_out[..., :C_pad], layout="BPFC")
+        e1.record()
+        torch.cuda.synchronize()
+        u_ms = e0.elapsed_time(e1) / 5
+        u_bytes = tr * T * (P * C_pad * 3 * 4 + n_points * 3 * 4) + P * C_pad * 4   # read the decoded cells + write every mesh point once
         # the dominant launch (layer2: [M, 480] x [480, 1536] + bias -> fp32) alone, HIP events on the launch stream
         M = tr * T * P
         dt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
@@ -443,7 +470,9 @@ def main_decode(args):
     line = {"metric": "decoded snapshots/sec (spatial decoder over a rollout)", "value": tr * T * args.steps / elapsed, "unit": "snapshots/s",
             "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": f"decode leg of the rollout evaluation: {tr} x {T} snapshots, 64 patches, spatial embed 16, hidden 480, groups [[0,1],[2]], n_inp 512"},
+            "config": {"workload": f"decode leg of the rollout evaluation: {tr} x {T} snapshots, 64 patches, spatial embed 16, hidden 480, groups [[0,1],[2]], "
+                                   f"mesh of {n_points} points in 8x8 cells (padded cell size {C_pad}, n_inp {n_inp}); decoder + un-patchify + inverse scaling"},
+            "unpatchify": {"ms": u_ms, "algorithmic_GB": u_bytes / 1e9, "achieved_GBps": u_bytes / (u_ms * 1e-3) / 1e9, "frac_of_hbm_peak": u_bytes / (u_ms * 1e-3) / 1e9 / 8000.0},
             "roofline": {"kernel": "decode.layer2 (gemm_grouped)", "bound": "hbm", "achieved": alg_bytes / (k_ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
                          "frac": alg_bytes / (k_ms * 1e-3) / 1e9 / 8000.0, "traffic": None, "launch_ms": k_ms, "launch_gflop": flops / 1e9,
                          "mfma_tflops": flops / (k_ms * 1e-3) / 1e12}}

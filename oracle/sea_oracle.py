@@ -322,3 +322,23 @@ def decode(z: torch.Tensor, p: Params, field_groups: Sequence[Sequence[int]], pr
         y = linear(h, p[f"{pre}{i}.layer2.weight"], p[f"{pre}{i}.layer2.bias"])
         outs.append(y.reshape(B, P_, len(group), -1))
     return torch.cat(outs, dim=2)
+
+
+def unpatchify(scaled_fields: torch.Tensor, index_map: torch.Tensor, n_points: int, field_groups: Sequence[Sequence[int]] = (),
+               scalers: Sequence[Tuple[float, float, float, float]] = ()) -> torch.Tensor:
+    """utils/data_processors.py:93-111 (DataPartitioner2D.inverse_partition) + :553-573 (inverse_scale_and_unpatch) + :258-273
+    (MinMaxScaler.inverse_transform).  scaled_fields [T, P, C, F]; index_map [P, C] with -1 padding; scalers: one
+    (range_lo, range_hi, min_val, max_val) per field group."""
+    T_, P_, C_, F_ = scaled_fields.shape
+    out = torch.empty(T_, n_points, F_, dtype=scaled_fields.dtype)
+    for p_ in range(P_):
+        idx = index_map[p_]
+        valid = idx >= 0
+        out[:, idx[valid].long(), :] = scaled_fields[:, p_, valid, :]
+    if scalers:
+        res = torch.zeros_like(out)
+        for group, (r0, r1, lo, hi) in zip(field_groups, scalers):
+            std = (out[..., list(group)] - r0) / (r1 - r0)
+            res[..., list(group)] = std * (hi - lo) + lo
+        out = res
+    return out

@@ -185,6 +185,8 @@ def lib() -> C.CDLL:
     L.sea_dropout_mask.restype = C.c_int
     L.sea_rowchain.argtypes = [C.POINTER(SeaChainLaunch), C.POINTER(SeaChainStage), C.c_int, _vp]
     L.sea_rowchain.restype = C.c_int
+    L.sea_unpatchify.argtypes = [_vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp]
+    L.sea_unpatchify.restype = C.c_int
     L.sea_run_list.argtypes = [C.POINTER(SeaLaunchRec), C.c_int, _vp]
     L.sea_run_list.restype = C.c_int
     for name in ("sea_attention_bwd", "sea_wgrad_grouped", "sea_transpose_weights", "sea_rownorm_bwd", "sea_silu_outer_bwd", "sea_ib_bwd"):
@@ -212,7 +214,7 @@ EXPORTED_SYMBOLS = (
     "sea_attention_fwd", "sea_rownorm", "sea_silu_outer", "sea_ib_add", "sea_convert_f32_to_act", "sea_selftest_mfma",
     "sea_mse_fwd_bwd", "sea_relative_mse", "sea_adamw_flat",
     "sea_wgrad_grouped", "sea_transpose_weights", "sea_rownorm_bwd", "sea_silu_outer_bwd", "sea_ib_bwd",
-    "sea_attention_bwd", "sea_dropout_mask", "sea_rowchain", "sea_run_list",
+    "sea_attention_bwd", "sea_dropout_mask", "sea_rowchain", "sea_run_list", "sea_unpatchify",
 )
 
 

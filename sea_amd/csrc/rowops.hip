@@ -338,3 +338,57 @@ extern "C" int sea_convert_f32_to_act(const float* src, int64_t lds, void* dst, 
     SEA_CHECK_LAUNCH("sea_convert_f32_to_act");
     return SEA_OK;
 }
+
+// ------------------------------------------------------------------------------------------------ un-patchify
+// One thread per (b, p, c) visits the F fields: the index-map lookup is shared by the fields and the F outputs of a mesh point are
+// contiguous ([B, n_points, F]).  Reads walk c fastest (contiguous in the decoder's [B,P,F,C] layout), writes are a scatter by design.
+__global__ __launch_bounds__(256) void unpatchify_kernel(const float* __restrict__ in, int64_t sb, int64_t sp, int64_t sf, int64_t sc,
+                                                         const int32_t* __restrict__ imap, const float* __restrict__ scale, const float* __restrict__ shift,
+                                                         float* __restrict__ out, int B, int P, int F, int C, int n_points) {
+    const int64_t total = (int64_t)B * P * C;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int c = (int)(i % C);
+        const int64_t bp = i / C;
+        const int p = (int)(bp % P);
+        const int b = (int)(bp / P);
+        const int idx = imap[(int64_t)p * C + c];
+        if (idx < 0) continue;
+        const float* src = in + b * sb + p * sp + c * sc;
+        float* dst = out + ((int64_t)b * n_points + idx) * F;
+        for (int f = 0; f < F; ++f) dst[f] = src[f * sf] * scale[f] + shift[f];
+    }
+}
+
+// Gather form: grid = (point blocks, snapshots); a workgroup's 256 points of one snapshot write 256 * F contiguous floats; the reads
+// hit the snapshot's decoded cells in L2.
+__global__ __launch_bounds__(256) void unpatchify_gather_kernel(const float* __restrict__ in, int64_t sb, int64_t sp, int64_t sf, int64_t sc,
+                                                                const int32_t* __restrict__ slot, const float* __restrict__ scale,
+                                                                const float* __restrict__ shift, float* __restrict__ out, int F, int C, int n_points) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= n_points) return;
+    const int sl = slot[n];
+    const int p = sl / C, c = sl - p * C;
+    const int b = blockIdx.y;
+    const float* src = in + b * sb + p * sp + c * sc;
+    float* dst = out + ((int64_t)b * n_points + n) * F;
+    for (int f = 0; f < F; ++f) dst[f] = src[f * sf] * scale[f] + shift[f];
+}
+
+extern "C" int sea_unpatchify(const float* in, int64_t sb, int64_t sp, int64_t sf, int64_t sc, const int32_t* index_map, const int32_t* point_slot,
+                              const float* scale, const float* shift, float* out, int B, int P, int F, int C, int n_points, void* stream) {
+    SEA_REQUIRE(in && index_map && scale && shift && out, "sea_unpatchify: null pointer");
+    SEA_REQUIRE(B >= 1 && P >= 1 && F >= 1 && C >= 1 && n_points >= 1, "sea_unpatchify: bad sizes B=%d P=%d F=%d C=%d n_points=%d", B, P, F, C, n_points);
+    if (point_slot != nullptr) {
+        SEA_REQUIRE(B <= 65535, "sea_unpatchify: B=%d too large for grid.y", B);
+        unpatchify_gather_kernel<<<dim3((n_points + 255) / 256, B, 1), dim3(256), 0, static_cast<hipStream_t>(stream)>>>(in, sb, sp, sf, sc, point_slot, scale, shift,
+                                                                                                                         out, F, C, n_points);
+        SEA_CHECK_LAUNCH("sea_unpatchify");
+        return SEA_OK;
+    }
+    const int64_t total = (int64_t)B * P * C;
+    int64_t blocks = (total + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    unpatchify_kernel<<<dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream)>>>(in, sb, sp, sf, sc, index_map, scale, shift, out, B, P, F, C, n_points);
+    SEA_CHECK_LAUNCH("sea_unpatchify");
+    return SEA_OK;
+}

@@ -327,3 +327,23 @@ def rowchain(groups: Sequence[Sequence[dict]], M: int, T: int, pos0: int, cap: i
     L = prog.launch_struct(M, T, pos0, cap, H, eps, x, out, cond)
     N.check(N.lib().sea_rowchain(C.byref(L), prog.host, N.dtype_code(dtype), N.stream_ptr()), "sea_rowchain")
     torch.cuda.current_stream().synchronize()  # the stage table is a temporary of this call
+
+
+def unpatchify(fields: torch.Tensor, layout: str, index_map: torch.Tensor, scale: torch.Tensor, shift: torch.Tensor, n_points: int,
+               point_slot: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out[b, index_map[p, c], f] = fields[b, p, f|c ...] * scale[f] + shift[f] (sea_unpatchify).  `layout` names the order of the last two
+    axes of `fields`: "BPFC" (the decoder's output) or "BPCF" (the reference's inverse_scale_and_unpatch argument)."""
+    N.require_gpu(fields, "fields")
+    assert fields.dtype == torch.float32 and fields.dim() == 4 and layout in ("BPFC", "BPCF")
+    assert index_map.dtype == torch.int32 and index_map.is_cuda and index_map.is_contiguous()
+    B, P = fields.shape[0], fields.shape[1]
+    F, Cc = (fields.shape[2], fields.shape[3]) if layout == "BPFC" else (fields.shape[3], fields.shape[2])
+    sb, sp = fields.stride(0), fields.stride(1)
+    sf, sc = (fields.stride(2), fields.stride(3)) if layout == "BPFC" else (fields.stride(3), fields.stride(2))
+    assert tuple(index_map.shape) == (P, Cc) and scale.numel() == F and shift.numel() == F
+    out = torch.empty(B, n_points, F, device=fields.device, dtype=torch.float32)
+    if point_slot is not None:
+        assert point_slot.dtype == torch.int32 and point_slot.is_cuda and point_slot.numel() == n_points
+    N.check(N.lib().sea_unpatchify(fields.data_ptr(), sb, sp, sf, sc, index_map.data_ptr(), N.ptr(point_slot), scale.data_ptr(), shift.data_ptr(),
+                                   out.data_ptr(), B, P, F, Cc, n_points, N.stream_ptr()), "sea_unpatchify")
+    return out

@@ -28,6 +28,7 @@ from models.temporal import TemporalModel  # reference
 from models import base_blocks as ref_bb  # reference
 from utils import train_utils as ref_tu  # reference
 from models.encoder_decoder import Decode as RefDecode  # reference
+from utils import data_processors as ref_dp  # reference
 
 torch.set_num_threads(8)
 
@@ -243,6 +244,36 @@ def decode_cases():
         save(name, groups=np.array([len(g) for g in groups]), dims=np.array([n_inp, hidden, D, P, tr, T]), roll=n(roll), z=n(z), out=n(out))
 
 
+def unpatch_cases():
+    """DataPartitioner2D.create_partitions / inverse_partition and MinMaxScaler.inverse_transform of the reference on a random 2-D point
+    cloud (ragged cells, one empty-ish corner), as chained by MeshProcessor.inverse_scale_and_unpatch (utils/data_processors.py:553-573)."""
+    import contextlib, io
+    rng = np.random.Generator(np.random.PCG64(31))
+    for name, npts, m, nn, T, F, groups in (("unpatch_5x5", 700, 6, 6, 3, 3, [[0, 1], [2]]), ("unpatch_3x4", 90, 4, 5, 2, 2, [[0], [1]])):
+        xy = rng.random((2, npts)).astype(np.float32)
+        xy[0, : npts // 4] *= 0.3   # uneven density -> ragged cells
+        fields = rng.standard_normal((T, npts, F)).astype(np.float32)
+        part = ref_dp.DataPartitioner2D(torch.from_numpy(xy[0]), torch.from_numpy(xy[1]), m=m, n=nn, pad_id=-1, pad_field_value=0)
+        parts, imap = part.create_partitions([torch.from_numpy(fields[:, :, i]) for i in range(F)])
+        stacked = torch.stack([p_[1] for p_ in parts], dim=1)          # [T, P, C, F]
+        index_map = torch.stack(imap, dim=0)                           # [P, C]
+        coords, recon = part.inverse_partition([(p_[0], p_[1]) for p_ in parts], time_dim=T)
+        assert torch.equal(recon, torch.from_numpy(fields))
+        # scaled variant: fields are "scaled" values; inverse transform per group with fixed min / max
+        scal, params = [], []
+        for gi, g in enumerate(groups):
+            sc = ref_dp.MinMaxScaler(feature_range=(-1, 1), name=f"g{gi}", save_dir=HERE)
+            sc.min_val, sc.max_val = torch.tensor(-2.5 - gi), torch.tensor(4.0 + 0.5 * gi)
+            scal.append(sc)
+            params.append([-1.0, 1.0, float(sc.min_val), float(sc.max_val)])
+        unscaled = torch.zeros_like(recon)
+        with contextlib.redirect_stdout(io.StringIO()):
+            for sc, g in zip(scal, groups):
+                unscaled[..., g] = sc.inverse_transform(recon[..., g])
+        save(name, xy=xy, mn=np.array([m, nn]), fields=fields, stacked=n(stacked), index_map=index_map.numpy().astype(np.int64),
+             unscaled=n(unscaled), groups=np.array([len(g) for g in groups]), scaler_params=np.array(params, dtype=np.float64))
+
+
 def big_cases():
     # cfg2 shape (BASELINE.json configs[1]): E=256, H=8, F=3, T=2024, B=1
     print("cfg2_shape")
@@ -290,6 +321,7 @@ def main():
         "modules": module_cases,
         "exchange": exchange_cases,
         "decode": decode_cases,
+        "unpatch": unpatch_cases,
     }
     for T in (1, 7, 16, 65):
         cases[f"model_small_adaln_f3_T{T}"] = (lambda T=T: model_case(

@@ -202,3 +202,19 @@ def test_decode_matches_reference(name):
     out = O.decode(z, p, groups)
     assert out.shape == g["out"].shape
     assert rel_l2(out.numpy(), g["out"]) < 1e-6
+
+
+@pytest.mark.parametrize("name", ["unpatch_5x5", "unpatch_3x4"])
+def test_unpatchify_matches_reference(name):
+    """inverse_partition + MinMaxScaler.inverse_transform against the reference's own classes."""
+    g = load_golden(name)
+    sizes = [int(v) for v in g["groups"]]
+    groups, k = [], 0
+    for sz in sizes:
+        groups.append(list(range(k, k + sz)))
+        k += sz
+    stacked, imap = torch.from_numpy(g["stacked"]), torch.from_numpy(g["index_map"])
+    n_points = g["fields"].shape[1]
+    assert torch.equal(O.unpatchify(stacked, imap, n_points), torch.from_numpy(g["fields"]))   # pure scatter: exact
+    out = O.unpatchify(stacked, imap, n_points, groups, [tuple(r) for r in g["scaler_params"]])
+    assert rel_l2(out.numpy(), g["unscaled"]) < 1e-6
