@@ -68,6 +68,56 @@ __global__ __launch_bounds__(256) void gemm_grouped_kernel(const GemmLaunch L) {
     // 128-byte line per instruction, so it is staged through the (now free) LDS tile and written out as whole rows, 16 B per lane.
     constexpr int SP = BN * (int)sizeof(T) + 16;  // staging row pitch in bytes
     const bool staged = Cact != nullptr && (G.N % C::EPC == 0) && (G.ldcact % C::EPC == 0);
+    if constexpr (PLAIN && sizeof(T) == 2) {
+        // fp32-only output (the spatial decoder's [M, n_fields * n_inp] fields: 2.5 GB per rollout): staged through LDS too, in two halves
+        // of the tile's row blocks (a half is BM/2 rows x BN floats, what the single-buffer LDS allocation holds), then written as whole
+        // rows, 16 bytes per lane — the per-lane form (16 rows x 64 B per store instruction) ran this launch at 400 TFLOP/s against
+        // 740 for the same shape with a bf16 output
+        constexpr int SP32 = BN * 4 + 16;
+        constexpr int HALF_ROWS = BM / 2;
+        if (Cact == nullptr && C32 != nullptr && G.ldc32 % 4 == 0 && HALF_ROWS * SP32 <= (BM > BN ? BM : BN) * SP + 0) {
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                if (half) __syncthreads();
+#pragma unroll
+                for (int ii = 0; ii < C::MI / 2; ++ii) {
+                    const int i = half * (C::MI / 2) + ii;
+                    const int m = ml.m0 + wm * C::WTM + i * 16 + r;
+                    const int lrow = wm * (C::WTM / 2) + ii * 16 + r;   // row inside the half: wave wm contributes WTM/2 rows per half
+#pragma unroll
+                    for (int j = 0; j < C::NI; ++j) {
+                        const int n = ml.n0 + wn * C::WTN + j * 16 + g * 4;
+                        float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+                        if (n < G.N) {
+                            if (bias != nullptr) {
+                                float bv[4];
+                                load4(bias + n, bv);
+#pragma unroll
+                                for (int q = 0; q < 4; ++q) v[q] += bv[q] * G.bias_scale;
+                            }
+                            if (R != nullptr && m < G.M) {
+                                float rv[4];
+                                load4(R + (int64_t)m * G.ldr + n, rv);
+#pragma unroll
+                                for (int q = 0; q < 4; ++q) v[q] += rv[q];
+                            }
+                        }
+                        *reinterpret_cast<float4*>(smem + lrow * SP32 + (wn * C::WTN + j * 16 + g * 4) * 4) = make_float4(v[0], v[1], v[2], v[3]);
+                    }
+                }
+                __syncthreads();
+                constexpr int CPR32 = BN / 4;   // 16-byte chunks per staged row
+                for (int idx = threadIdx.x; idx < HALF_ROWS * CPR32; idx += 256) {
+                    const int lrow = idx / CPR32, cc = idx - lrow * CPR32;
+                    // half-local row -> tile row: wave-row block wm' = lrow / (WTM/2), inside it ii*16 + r
+                    const int wmr = lrow / (C::WTM / 2), rem = lrow - wmr * (C::WTM / 2);
+                    const int m = ml.m0 + wmr * C::WTM + half * (C::WTM / 2) + rem, n = ml.n0 + cc * 4;
+                    if (m < G.M && n < G.N) *reinterpret_cast<float4*>(C32 + (int64_t)m * G.ldc32 + n) = *reinterpret_cast<const float4*>(smem + lrow * SP32 + cc * 16);
+                }
+            }
+            return;
+        }
+    }
 #pragma unroll
     for (int j = 0; j < C::NI; ++j) {
         const int n = ml.n0 + wn * C::WTN + j * 16 + g * 4;  // this lane's 4 consecutive output columns
@@ -267,7 +317,8 @@ extern "C" int sea_gemm_grouped(const SeaGemmGroup* groups, int n_groups, int dt
         dma = dma && (groups[i].K % (dtype == SEA_BF16 ? 64 : 32) == 0) && (long)groups[i].K * groups[i].n_seg >= dma_min_k;
     // ... and only while the launch is a few tiles deep per CU (its time then is the serial chain of K-tiles of one tile, which the ring
     // shortens: fc2 at B = 1 23 us vs 28); with many tiles per CU the single-buffered loop's occupancy wins (B = 8: 109 us vs 128)
-    dma = dma && t64 <= 1536;
+    static const int dma_force = []() { const char* e = getenv("SEA_GEMM_DMA_FORCE"); return e ? atoi(e) : 0; }();  // tuning aid
+    dma = dma && (t64 <= 1536 || dma_force);
     (void)t64;
     const int tile = pick_tile(t128, dma);
     GemmLaunch L;

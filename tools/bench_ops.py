@@ -49,6 +49,9 @@ if __name__ == "__main__":
     if what in ("attn", "all"):
         for (B, H, hd, T, n) in [(1, 8, 32, 2024, 3), (1, 8, 32, 2024, 1), (1, 8, 32, 1024, 3), (1, 8, 32, 512, 3), (8, 8, 32, 2024, 3), (1, 8, 16, 2024, 2), (8, 8, 16, 2024, 2), (1, 8, 32, 64, 3)]:
             attn(B, H, hd, T, n)
+    if what == "biggemm":
+        for (M, N, K, g) in [(129536, 3328, 512, 1), (129536, 3328, 448, 1), (16192, 2048, 256, 3), (16192, 512, 512, 9)]:
+            gemm(M, N, K, g)
     if what in ("gemm", "all"):
         for (M, N, K, g) in [(2024, 2048, 256, 3), (2024, 256, 2048, 3), (2024, 256, 256, 3), (2024, 768, 256, 3), (16192, 2048, 256, 3), (16192, 256, 2048, 3), (4096, 4096, 4096, 1), (2024, 512, 512, 9), (64, 256, 256, 1)]:
             gemm(M, N, K, g)
