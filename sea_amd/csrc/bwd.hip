@@ -638,6 +638,12 @@ extern "C" int sea_rownorm_bwd(const SeaNormBwdGroup* groups, int n_groups, int 
     int nblk = wide ? M : (M + 3) / 4;
     static const int nblk_cap = []() { const char* e = getenv("SEA_NORMBWD_BLOCKS"); return e ? atoi(e) : 512; }();  // tuning aid
     if (nblk > nblk_cap) nblk = nblk_cap;
+    if (wide) {
+        // all workgroups of the launch resident at once (5 per CU at the wide kernel's 90 VGPRs): a second, partial round costs more than
+        // the extra parallelism returns (measured at cfg3, 3 groups: 384 per group 171 us, 512 207 us, 448 220 us)
+        const int fit = (5 * 256 / n_groups) / 64 * 64;
+        if (fit >= 128 && nblk > fit) nblk = fit;
+    }
     const bool two_stage = ws != nullptr && ws_floats >= (int64_t)n_groups * nblk * 2 * d && nblk > 8;
     L.ws = two_stage ? ws : nullptr;
     const dim3 grid(nblk, n_groups), block(256);
