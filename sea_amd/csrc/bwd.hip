@@ -798,7 +798,11 @@ extern "C" int sea_silu_outer_bwd(const SeaSiluBwdGroup* groups, int n_groups, c
     }
     L.c = c; L.M = M;
     int nblk = (M + 3) / 4;
-    if (nblk > 256) nblk = 256;
+    // every workgroup of the launch resident at once (about 6 per CU): measured at cfg3 (12 groups) 128 per group 76 us, 160 90 us, 256 112 us
+    static const int sb_cap = []() { const char* e = getenv("SEA_SILUBWD_BLOCKS"); return e ? atoi(e) : 0; }();  // tuning aid
+    int cap = sb_cap > 0 ? sb_cap : (6 * 256 / n_groups) / 32 * 32;
+    cap = cap < 32 ? 32 : (cap > 256 ? 256 : cap);
+    if (nblk > cap) nblk = cap;
     const bool two_stage = ws != nullptr && ws_floats >= (int64_t)n_groups * nblk * 2 * maxk && nblk > 8;
     L.ws = two_stage ? ws : nullptr;
     L.maxk = maxk;
