@@ -1058,7 +1058,8 @@ extern "C" int sea_ib_bwd(const SeaIbBwdParams* params, void* stream) {
     SEA_REQUIRE(lds <= 160 * 1024, "sea_ib_bwd: E*(h+1) too large for LDS");
     if (lds > 65536) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ib_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     int nblk = (P.M + 3) / 4;
-    if (nblk > 256) nblk = 256;
+    static const int ib_cap = []() { const char* e = getenv("SEA_IBBWD_BLOCKS"); return e ? atoi(e) : 256; }();  // tuning aid
+    if (nblk > ib_cap) nblk = ib_cap;
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (P.h <= 8 && P.E <= 256) ib_bwd_fast_kernel<1><<<dim3(nblk), dim3(256), lds, s>>>(P);
     else if (P.h <= 8 && P.E <= 1024) ib_bwd_fast_kernel<4><<<dim3(nblk), dim3(256), lds, s>>>(P);
