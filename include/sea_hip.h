@@ -41,7 +41,7 @@ enum {
 int sea_abi_version(void);
 const char* sea_last_error(void);
 /* sizeof of every ABI struct in declaration order (SeaGemmGroup, SeaQkvGroup, SeaQkvCommon, SeaAttnProblem,
- * SeaAttnParams, SeaNormGroup, SeaSiluGroup, SeaIbParams, ...): lets a binding verify its layout.  Host only. */
+ * SeaAttnParams, SeaNormGroup, SeaSiluGroup, SeaIbParams, ..., SeaGemmNormGroup last): lets a binding verify its layout.  Host only. */
 int sea_struct_sizes(int* out, int cap);
 /* Number of compute units / name of device 0's architecture as HIP reports them (diagnostics for bench.py). */
 int sea_device_info(int* cu_count, char* arch, int arch_len);
@@ -182,6 +182,37 @@ typedef struct {
 
 int sea_rownorm(const SeaNormGroup* groups, int n_groups, int M, int d, int x_is_act, int gelu, float eps,
                 int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Linear layer whose output rows are normalised in the same launch (a workgroup tile spans the whole output row, N <= 256):
+ *     v    = A[M,K] . W[N,K]^T + bias (+ R)                            (as sea_gemm_grouped; C32 <- v when non-NULL)
+ *     y    = LayerNorm_N(v) with gamma / beta / mod exactly as SeaNormGroup (two-pass fp32 statistics, biased variance, eps)
+ *     Yact <- (act dtype) y ;  Y32 <- y ;  mean / rstd saved when non-NULL
+ * Replaces the pairs cross_down[i] + ln_cross[i] (models/temporal.py:177-181) and proj[i] + the model's final per-field norm
+ * (models/temporal.py:146, 412-415) — one launch and one HBM round trip of the [M, N] intermediate less than
+ * sea_gemm_grouped followed by sea_rownorm, with identical arithmetic.
+ * Requirements: N % 16 == 0, N <= 256; K % 8 == 0; lda, ldw multiples of 8; ldr, ldc32, ldy32, ldyact, ldmod multiples of 4;
+ * all pointers 16-byte aligned.
+ */
+#define SEA_MAX_GEMM_NORM_GROUPS 8
+typedef struct {
+    const void* A;      /* act [M, K], row stride lda */
+    const void* W;      /* act [N, K], row stride ldw */
+    const float* bias;  /* f32 [N] or NULL */
+    const float* R;     /* f32 [M, N] row stride ldr, or NULL */
+    float* C32;         /* f32 [M, N] pre-normalisation output, row stride ldc32, or NULL */
+    const void* mod;    /* act [M, 2N] row stride ldmod, or NULL */
+    const float* gamma; /* f32 [N] */
+    const float* beta;  /* f32 [N] or NULL */
+    float* Y32;         /* f32 [M, N] row stride ldy32, or NULL */
+    void* Yact;         /* act [M, N] row stride ldyact, or NULL */
+    float* mean;        /* f32 [M] or NULL */
+    float* rstd;        /* f32 [M] or NULL */
+    int32_t lda, ldw, ldr, ldc32, ldmod, ldy32, ldyact;
+    int32_t M, N, K;
+} SeaGemmNormGroup;
+
+int sea_gemm_rownorm(const SeaGemmNormGroup* groups, int n_groups, float eps, int dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Hidden layer of the AdaLN condition MLP for a scalar condition: Hid[m, k] = silu(w1[k] * c[m] + b1[k]).
@@ -459,9 +490,10 @@ int sea_rowchain(const SeaChainLaunch* launch, const SeaChainStage* host_stages,
  *     SEA_OP_ATTN   p0 = SeaAttnParams                            SEA_OP_NORM   p0 = SeaNormGroup[n], i0 = M, i1 = d, i2 = x_is_act, i3 = gelu, f0 = eps
  *     SEA_OP_SILU   p0 = SeaSiluGroup[n], p1 = c, i0 = M          SEA_OP_IB     p0 = SeaIbParams
  *     SEA_OP_CHAIN  p0 = SeaChainLaunch, p1 = host stage table    SEA_OP_CONVERT p0 = src, p1 = dst, l0 = lds, l1 = ldd, l2 = rows, l3 = cols
+ *     SEA_OP_GEMM_NORM p0 = SeaGemmNormGroup[n], f0 = eps
  * Returns 0, or the failing entry's error code with sea_last_error() set (entries before it have been launched).
  */
-enum { SEA_OP_GEMM = 1, SEA_OP_QKV = 2, SEA_OP_ATTN = 3, SEA_OP_NORM = 4, SEA_OP_SILU = 5, SEA_OP_IB = 6, SEA_OP_CHAIN = 7, SEA_OP_CONVERT = 8 };
+enum { SEA_OP_GEMM = 1, SEA_OP_QKV = 2, SEA_OP_ATTN = 3, SEA_OP_NORM = 4, SEA_OP_SILU = 5, SEA_OP_IB = 6, SEA_OP_CHAIN = 7, SEA_OP_CONVERT = 8, SEA_OP_GEMM_NORM = 9 };
 typedef struct {
     int32_t op, n, dtype, i0, i1, i2, i3;
     float f0;

@@ -131,12 +131,22 @@ class SeaChainLaunch(C.Structure):
 
 
 
-OP_GEMM, OP_QKV, OP_ATTN, OP_NORM, OP_SILU, OP_IB, OP_CHAIN, OP_CONVERT = 1, 2, 3, 4, 5, 6, 7, 8
+OP_GEMM, OP_QKV, OP_ATTN, OP_NORM, OP_SILU, OP_IB, OP_CHAIN, OP_CONVERT, OP_GEMM_NORM = 1, 2, 3, 4, 5, 6, 7, 8, 9
 
 
 class SeaLaunchRec(C.Structure):
     _fields_ = [("op", _i32), ("n", _i32), ("dtype", _i32), ("i0", _i32), ("i1", _i32), ("i2", _i32), ("i3", _i32), ("f0", _f32),
                 ("p0", _vp), ("p1", _vp), ("l0", _i64), ("l1", _i64), ("l2", _i64), ("l3", _i64)]
+
+MAX_GEMM_NORM_GROUPS = 8
+
+
+class SeaGemmNormGroup(C.Structure):
+    _fields_ = [("A", _vp), ("W", _vp), ("bias", _vp), ("R", _vp), ("C32", _vp), ("mod", _vp), ("gamma", _vp), ("beta", _vp),
+                ("Y32", _vp), ("Yact", _vp), ("mean", _vp), ("rstd", _vp),
+                ("lda", _i32), ("ldw", _i32), ("ldr", _i32), ("ldc32", _i32), ("ldmod", _i32), ("ldy32", _i32), ("ldyact", _i32),
+                ("M", _i32), ("N", _i32), ("K", _i32)]
+
 
 MAX_WGRAD_GROUPS = 16
 MAX_NORM_BWD_GROUPS = 8
@@ -187,6 +197,8 @@ def lib() -> C.CDLL:
     L.sea_rowchain.restype = C.c_int
     L.sea_unpatchify.argtypes = [_vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp]
     L.sea_unpatchify.restype = C.c_int
+    L.sea_gemm_rownorm.argtypes = [C.POINTER(SeaGemmNormGroup), C.c_int, C.c_float, C.c_int, _vp]
+    L.sea_gemm_rownorm.restype = C.c_int
     L.sea_run_list.argtypes = [C.POINTER(SeaLaunchRec), C.c_int, _vp]
     L.sea_run_list.restype = C.c_int
     for name in ("sea_attention_bwd", "sea_wgrad_grouped", "sea_transpose_weights", "sea_rownorm_bwd", "sea_silu_outer_bwd", "sea_ib_bwd"):
@@ -207,14 +219,14 @@ def lib() -> C.CDLL:
 
 ABI_STRUCTS = (SeaGemmGroup, SeaQkvGroup, SeaQkvCommon, SeaAttnProblem, SeaAttnParams, SeaNormGroup, SeaSiluGroup,
                SeaIbParams, SeaWgradGroup, SeaNormBwdGroup, SeaSiluBwdGroup, SeaIbBwdParams, SeaAttnBwdProblem, SeaAttnBwdParams,
-               SeaDropout, SeaChainStage, SeaChainLaunch, SeaLaunchRec)
+               SeaDropout, SeaChainStage, SeaChainLaunch, SeaLaunchRec, SeaGemmNormGroup)
 
 EXPORTED_SYMBOLS = (
     "sea_abi_version", "sea_last_error", "sea_struct_sizes", "sea_device_info", "sea_gemm_grouped", "sea_qkv_rope_grouped",
     "sea_attention_fwd", "sea_rownorm", "sea_silu_outer", "sea_ib_add", "sea_convert_f32_to_act", "sea_selftest_mfma",
     "sea_mse_fwd_bwd", "sea_relative_mse", "sea_adamw_flat",
     "sea_wgrad_grouped", "sea_transpose_weights", "sea_rownorm_bwd", "sea_silu_outer_bwd", "sea_ib_bwd",
-    "sea_attention_bwd", "sea_dropout_mask", "sea_rowchain", "sea_run_list", "sea_unpatchify",
+    "sea_attention_bwd", "sea_dropout_mask", "sea_rowchain", "sea_run_list", "sea_unpatchify", "sea_gemm_rownorm",
 )
 
 

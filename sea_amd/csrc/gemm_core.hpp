@@ -3,7 +3,7 @@
 // C[BM x BN] tile of  sum_s A_s[M,K] . W[N,K]^T  — both operands are K-contiguous ("NT" GEMM, the nn.Linear
 // layout), so A and B fragments are both 16-byte loads along K.
 //
-// Block = 256 threads = 4 waves in a 2 x 2 grid; each wave owns (BM/2) x (BN/2) as MI x NI tiles of 16 x 16.
+// Block = 256 threads = 4 waves in a WM x WN grid (2 x 2 unless stated); each wave owns (BM/WM) x (BN/WN) as MI x NI tiles of 16 x 16.
 // LDS: per K-tile every row holds 128 bytes of K (64 bf16 / 32 f32) as eight 16-byte chunks; chunk c of row r is
 // stored at chunk position c ^ (r & 7): the ds_read_b128 of a fragment (16 rows x the same chunk) then covers all
 // 16 bank slots of the 256-byte bank row (conflict-free; MI355X_MICROARCH.md §LDS, cdna_hip_programming.md T2)
@@ -18,13 +18,14 @@
 #pragma once
 #include "sea_common.hpp"
 
-template <typename T, int BM_, int BN_>
+template <typename T, int BM_, int BN_, int WM_ = 2>
 struct GemmCfg {
     static constexpr int BM = BM_, BN = BN_;
+    static constexpr int WM = WM_, WN = 4 / WM_;            // wave grid (rows x columns of waves); 4 x 1: a wave owns whole tile rows
     static constexpr int BKB = 128;                         // bytes of K per row per K-tile
     static constexpr int EPC = ActTraits<T>::EPC;           // elements per 16-byte chunk
     static constexpr int BK = BKB / (int)sizeof(T);         // K elements per K-tile
-    static constexpr int WTM = BM / 2, WTN = BN / 2;        // wave tile
+    static constexpr int WTM = BM / WM, WTN = BN / WN;      // wave tile
     static constexpr int MI = WTM / 16, NI = WTN / 16;      // 16x16 tiles per wave
     static constexpr int A_CH = BM * 8 / 256;               // 16-byte chunks staged per thread (A)
     static constexpr int B_CH = BN * 8 / 256;               // (W)
@@ -32,9 +33,9 @@ struct GemmCfg {
     static constexpr int LDS_BYTES = 2 * BUF_BYTES;
 };
 
-template <typename T, int BM, int BN>
+template <typename T, int BM, int BN, int WM = 2>
 struct GemmMainloop {
-    using C = GemmCfg<T, BM, BN>;
+    using C = GemmCfg<T, BM, BN, WM>;
 
     const T* A;
     const T* W;
@@ -157,7 +158,7 @@ struct GemmMainloop {
         const int tid = threadIdx.x;
         const int lane = tid & 63;
         const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-        const int wm = wave >> 1, wn = wave & 1;
+        const int wm = wave / C::WN, wn = wave % C::WN;
 #pragma unroll
         for (int i = 0; i < C::MI; ++i)
 #pragma unroll
@@ -184,7 +185,7 @@ struct GemmMainloop {
     __device__ __forceinline__ void run_single(char* smem, f32x4 (&acc)[C::MI][C::NI]) {
         const int tid = threadIdx.x;
         const int lane = tid & 63, wave = tid >> 6;
-        const int wm = wave >> 1, wn = wave & 1;
+        const int wm = wave / C::WN, wn = wave % C::WN;
 #pragma unroll
         for (int i = 0; i < C::MI; ++i)
 #pragma unroll
@@ -203,7 +204,7 @@ struct GemmMainloop {
     __device__ __forceinline__ void run(char* smem, f32x4 (&acc)[C::MI][C::NI]) {
         const int tid = threadIdx.x;
         const int lane = tid & 63, wave = tid >> 6;
-        const int wm = wave >> 1, wn = wave & 1;
+        const int wm = wave / C::WN, wn = wave % C::WN;
 #pragma unroll
         for (int i = 0; i < C::MI; ++i)
 #pragma unroll

@@ -275,6 +275,20 @@ class Plan:
                     self._out_patches.append((g, "Y32", gd["Y_is_out"]))
             self._cur.append(self._rec(L.sea_rownorm, [arr, len(chunk), self.M, d, int(x_is_act), int(gelu), 1e-5, self.code], name, arr))
 
+    def _gemm_norm(self, groups: List[dict], name: str) -> None:
+        """Linear + row normalisation in one launch (sea_gemm_rownorm): group dicts as _gemm (A, W, bias) plus the _norm keys
+        (mod, gamma, beta, Yact, Y32/ldy32/Y_is_out)."""
+        L = N.lib()
+        for s in range(0, len(groups), N.MAX_GEMM_NORM_GROUPS):
+            chunk = groups[s:s + N.MAX_GEMM_NORM_GROUPS]
+            arr = (N.SeaGemmNormGroup * len(chunk))()
+            for g, d in zip(arr, chunk):
+                ops.fill_gemm_norm_group(g, d["A"], d["W"], d["gamma"], bias=d.get("bias"), mod=d.get("mod"), beta=d.get("beta"),
+                                         Y32=d.get("Y32"), Yact=d.get("Yact"), ldy32=d.get("ldy32"))
+                if d.get("Y_is_out") is not None:
+                    self._out_patches.append((g, "Y32", d["Y_is_out"]))
+            self._cur.append(self._rec(L.sea_gemm_rownorm, [arr, len(chunk), 1e-5, self.code], name, arr))
+
     def _qkv(self, groups: List[dict], rope: torch.Tensor, hd: int, name: str) -> None:
         L = N.lib()
         arr = (N.SeaQkvGroup * len(groups))()
@@ -366,6 +380,9 @@ class Plan:
         mode = os.environ.get("SEA_PLAN_LANES", "none") if type(self) is Plan else "none"
         lanes = mode == "all" and F >= 2 and eng.model.add_info_after_cross
         split_cond = mode in ("cond", "all") and self.adaln
+        # Linear + the row norm that follows it in one launch (sea_gemm_rownorm) where a tile can span the whole output row: cross_down + ln_cross,
+        # the last layer's proj + the model's final norm.  SEA_FUSE_NORM=0 keeps the two-launch form (A/B measurements).
+        fuse_norm = self._fuse_norm = type(self) is Plan and os.environ.get("SEA_FUSE_NORM", "1") != "0"
         mods = self._cond_mods(split=split_cond)
         cond_joined = not split_cond
 
@@ -397,6 +414,7 @@ class Plan:
 
         xm = [self._buf(M, E) for _ in range(F)] if lanes else xa
         first = True  # the residual stream still lives in the caller's x [B,T,F,E]
+        fused_final = False
         for l in range(self.L):
             pre = f"blocks.{l}."
             last = l == self.L - 1
@@ -437,9 +455,13 @@ class Plan:
                 cond_joined = True
             # -- state exchange (Gauss-Seidel over i, models/temporal.py:187-192)
             if F > 1:
-                self._gemm([dict(A=xa[j], W=P.act(f"{pre}cross_down.{j}.weight"), bias=P.f32_vec(f"{pre}cross_down.{j}.bias"), C32=dn[j])
-                            for j in range(F)], "cross.down_old")
-                self._norm([dict(X=dn[j], Yact=nd_old[j], **norm_params(f"{pre}ln_cross.{j}.", D)) for j in range(F)], D, "cross.norm_old")
+                if fuse_norm and D <= 256 and D % 16 == 0:
+                    self._gemm_norm([dict(A=xa[j], W=P.act(f"{pre}cross_down.{j}.weight"), bias=P.f32_vec(f"{pre}cross_down.{j}.bias"), Yact=nd_old[j],
+                                          **norm_params(f"{pre}ln_cross.{j}.", D)) for j in range(F)], "cross.down_norm_old")
+                else:
+                    self._gemm([dict(A=xa[j], W=P.act(f"{pre}cross_down.{j}.weight"), bias=P.f32_vec(f"{pre}cross_down.{j}.bias"), C32=dn[j])
+                                for j in range(F)], "cross.down_old")
+                    self._norm([dict(X=dn[j], Yact=nd_old[j], **norm_params(f"{pre}ln_cross.{j}.", D)) for j in range(F)], D, "cross.norm_old")
                 for i in range(F):
                     others = [j for j in range(F) if j != i]
                     qkv_groups, probs, proj_groups = [], [], []
@@ -467,7 +489,10 @@ class Plan:
                         self._mlp_proj(pre, [i], xr, xm, n_e, hbuf, hg, mods, last, tag=f".f{i}")
                         if i < F - 1:
                             self._end_lane()
-                    if i < F - 1:
+                    if i < F - 1 and fuse_norm and D <= 256 and D % 16 == 0:
+                        self._gemm_norm([dict(A=xa[i], W=P.act(f"{pre}cross_down.{i}.weight"), bias=P.f32_vec(f"{pre}cross_down.{i}.bias"), Yact=nd_new[i],
+                                              **norm_params(f"{pre}ln_cross.{i}.", D))], f"cross{i}.down_norm_new")
+                    elif i < F - 1:
                         self._gemm([dict(A=xa[i], W=P.act(f"{pre}cross_down.{i}.weight"), bias=P.f32_vec(f"{pre}cross_down.{i}.bias"), C32=dn[i])],
                                    f"cross{i}.down_new")
                         self._norm([dict(X=dn[i], Yact=nd_new[i], **norm_params(f"{pre}ln_cross.{i}.", D))], D, f"cross{i}.norm_new")
@@ -477,12 +502,13 @@ class Plan:
                 continue
             if eng.model.add_info_after_cross:
                 self._ib(pre, xr)
-            self._mlp_proj(pre, list(range(F)), xr, xa, n_e, hbuf, hg, mods, False)
-        if not lanes:
+            fused_final = last and fuse_norm and E <= 256 and E % 16 == 0
+            self._mlp_proj(pre, list(range(F)), xr, xa, n_e, hbuf, hg, mods, False, fuse_final=fused_final)
+        if not lanes and not fused_final:
             # -- final per-field norm, written straight into out[B,T,F,E]
             self._norm([dict(X=xr[i], Y32=xr[i], ldy32=FE, Y_is_out=i * E * 4, **norm_params(f"ln.{i}.", E)) for i in range(F)], E, "final.norm")
 
-    def _mlp_proj(self, pre, fields, xr, xm, n_e, hbuf, hg, mods, final_norm, tag="") -> None:
+    def _mlp_proj(self, pre, fields, xr, xm, n_e, hbuf, hg, mods, final_norm, tag="", fuse_final=False) -> None:
         """x_i += W2 gelu(LN(W1 AdaLN_2(x_i))) ; x_i = proj_i(x_i) for the listed fields (models/temporal.py:143-146), optionally followed
         by the model's final per-field norm written straight into out (models/temporal.py:412-415)."""
         P, E, S, FE = self.eng.params, self.E, self.S, self.F * self.E
@@ -499,6 +525,10 @@ class Plan:
                     for i in fields], S, "mlp.ln_gelu" + tag, x_is_act=True, gelu=True)
         self._gemm([dict(A=hg[i], W=P.act(f"{pre}mlp.{i}.layers.3.weight"), bias=P.f32_vec(f"{pre}mlp.{i}.layers.3.bias"), R=xr[i], Cact=xm[i])
                     for i in fields], "mlp.fc2" + tag)
+        if fuse_final:  # last layer: proj_i and the model's final norm of field i in one launch, written straight into out[B,T,F,E]
+            self._gemm_norm([dict(A=xm[i], W=P.act(f"{pre}proj.{i}.weight"), bias=P.f32_vec(f"{pre}proj.{i}.bias"), Y32=xr[i], ldy32=FE, Y_is_out=i * E * 4,
+                                  **norm_params(f"ln.{i}.", E)) for i in fields], "proj_final_norm" + tag)
+            return
         self._gemm([dict(A=xm[i], W=P.act(f"{pre}proj.{i}.weight"), bias=P.f32_vec(f"{pre}proj.{i}.bias"), C32=xr[i]) for i in fields], "proj" + tag)
         if final_norm:
             self._norm([dict(X=xr[i], Y32=xr[i], ldy32=FE, Y_is_out=i * E * 4, **norm_params(f"ln.{i}.", E)) for i in fields], E, "final.norm" + tag)
@@ -722,6 +752,8 @@ class Plan:
                 c.op, c.p0, c.n, c.p1, c.dtype = N.OP_QKV, addr(a[0]), a[1], addr(r.keep[1]), a[3]
             elif r.fn is L.sea_attention_fwd:
                 c.op, c.p0, c.dtype = N.OP_ATTN, addr(r.keep), a[1]
+            elif r.fn is L.sea_gemm_rownorm:
+                c.op, c.p0, c.n, c.f0, c.dtype = N.OP_GEMM_NORM, addr(a[0]), a[1], a[2], a[3]
             elif r.fn is L.sea_rownorm:
                 c.op, c.p0, c.n, c.i0, c.i1, c.i2, c.i3, c.f0, c.dtype = N.OP_NORM, addr(a[0]), a[1], a[2], a[3], a[4], a[5], a[6], a[7]
             elif r.fn is L.sea_silu_outer:

@@ -123,6 +123,38 @@ def rownorm(groups: Sequence[Dict], M: int, d: int, x_is_act: bool, gelu: bool, 
     N.check(N.lib().sea_rownorm(arr, n, M, d, int(x_is_act), int(gelu), eps, N.dtype_code(dtype), N.stream_ptr()), "sea_rownorm")
 
 
+def fill_gemm_norm_group(g: N.SeaGemmNormGroup, A, W, gamma, bias=None, R=None, C32=None, mod=None, beta=None, Y32=None, Yact=None,
+                         mean=None, rstd=None, ldr=None, ldy32=None) -> None:
+    g.A, g.W, g.bias, g.R, g.C32 = A.data_ptr(), W.data_ptr(), N.ptr(bias), N.ptr(R), N.ptr(C32)
+    g.mod, g.gamma, g.beta = N.ptr(mod), gamma.data_ptr(), N.ptr(beta)
+    g.Y32, g.Yact, g.mean, g.rstd = N.ptr(Y32), N.ptr(Yact), N.ptr(mean), N.ptr(rstd)
+    g.lda, g.ldw = A.stride(0), W.stride(0)
+    g.ldr = (ldr if ldr is not None else R.stride(0)) if R is not None else 0
+    g.ldc32 = C32.stride(0) if C32 is not None else 0
+    g.ldmod = mod.stride(0) if mod is not None else 0
+    g.ldy32 = (ldy32 if ldy32 is not None else Y32.stride(0)) if Y32 is not None else 0
+    g.ldyact = Yact.stride(0) if Yact is not None else 0
+    g.M, g.N, g.K = A.shape[0], W.shape[0], W.shape[1]
+
+
+def gemm_rownorm(groups: Sequence[Dict], eps: float, dtype: torch.dtype) -> None:
+    """Linear + row normalisation in one launch (sea_gemm_rownorm).  groups: dicts with A [M,K] act, W [N,K] act (N <= 256, N % 16 == 0),
+    gamma f32 [N], optional bias f32 [N], R f32 [M,N], C32 f32 [M,N] (pre-norm), mod act [M,2N], beta f32 [N], Y32 / Yact, mean / rstd."""
+    n = len(groups)
+    arr = (N.SeaGemmNormGroup * n)()
+    for i, d in enumerate(groups):
+        A, W = _mat(d["A"], "A"), _mat(d["W"], "W")
+        if A.dtype != dtype or W.dtype != dtype:
+            raise ValueError(f"gemm_rownorm group {i}: A/W dtype {A.dtype}/{W.dtype} != activation dtype {dtype}")
+        if d.get("Yact") is not None and d["Yact"].dtype != dtype:
+            raise ValueError(f"gemm_rownorm group {i}: Yact dtype mismatch")
+        if d.get("mod") is not None and d["mod"].dtype != dtype:
+            raise ValueError(f"gemm_rownorm group {i}: mod dtype mismatch")
+        fill_gemm_norm_group(arr[i], A, W, d["gamma"], d.get("bias"), d.get("R"), d.get("C32"), d.get("mod"), d.get("beta"), d.get("Y32"),
+                             d.get("Yact"), d.get("mean"), d.get("rstd"))
+    N.check(N.lib().sea_gemm_rownorm(arr, n, eps, N.dtype_code(dtype), N.stream_ptr()), "sea_gemm_rownorm")
+
+
 def silu_outer(groups: Sequence[Dict], c: torch.Tensor, M: int, dtype: torch.dtype) -> None:
     """groups: dicts with w1 f32 [K2], b1 f32 [K2], Hid act [M,K2]."""
     n = len(groups)

@@ -267,6 +267,58 @@ def test_rownorm_adaln_and_ln(dtype, d):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("N_,K", [(128, 256), (256, 256), (64, 72), (48, 512)])
+def test_gemm_rownorm_matches_gemm_then_rownorm(dtype, N_, K):
+    """sea_gemm_rownorm = Linear (+ residual) followed by the AdaLN / LayerNorm row pass, in one launch: against the fp32 formula, and
+    against the two-launch form it replaces (cross_down + ln_cross, proj + final norm), ragged M, strided fp32 output."""
+    from sea_amd import ops
+
+    M = 203
+    groups, refs, keep = [], [], []
+    for gi in range(3):
+        A = rnd(M, K, dtype=dtype, seed=500 + gi)
+        W = rnd(N_, K, dtype=dtype, scale=0.2, seed=510 + gi)
+        bias = 0.3 * rnd(N_, seed=520 + gi) + 0.5
+        R = rnd(M, N_, seed=530 + gi) if gi == 1 else None
+        mod = rnd(M, 2 * N_, dtype=dtype, scale=0.5, seed=540 + gi) if gi != 2 else None
+        gamma, beta = 1 + 0.1 * rnd(N_, seed=550 + gi), (0.1 * rnd(N_, seed=560 + gi) if gi != 2 else None)
+        y = torch.empty(M, N_, device=dev(), dtype=dtype)
+        y32b = torch.zeros(M, 3 * N_, device=dev())
+        c32 = torch.empty(M, N_, device=dev())
+        mean, rstd = torch.empty(M, device=dev()), torch.empty(M, device=dev())
+        groups.append(dict(A=A, W=W, bias=bias, R=R, mod=mod, gamma=gamma, beta=beta, Yact=y, Y32=y32b[:, N_:2 * N_], C32=c32, mean=mean, rstd=rstd))
+        v = A.float() @ W.float().t() + bias + (R if R is not None else 0)
+        mu = v.mean(-1, keepdim=True)
+        var = ((v - mu) ** 2).mean(-1, keepdim=True)
+        xh = (v - mu) / torch.sqrt(var + 1e-5)
+        ref = xh * (gamma + 1 + mod[:, :N_].float()) + (beta + mod[:, N_:].float()) if mod is not None else xh * gamma
+        refs.append((v, mu[:, 0], 1 / torch.sqrt(var[:, 0] + 1e-5), ref))
+        keep.append((y, y32b, c32, mean, rstd))
+    ops.gemm_rownorm(groups, 1e-5, dtype)
+    for (v, mu, rs, ref), (y, y32b, c32, mean, rstd) in zip(refs, keep):
+        assert rel(c32, v) < 2e-5
+        assert rel(y32b[:, N_:2 * N_], ref) < 3e-5
+        assert rel(y.float(), ref) < tol(dtype, f32=3e-5)
+        assert rel(mean, mu) < 2e-5 and rel(rstd, rs) < 2e-5
+        assert float(y32b[:, :N_].abs().max()) == 0 and float(y32b[:, 2 * N_:].abs().max()) == 0
+    # the two-launch form on the same operands: identical up to the fp32 rounding of the intermediate
+    g0 = groups[0]
+    c = torch.empty(M, N_, device=dev())
+    y2 = torch.empty(M, N_, device=dev())
+    ops.gemm_grouped([dict(A=g0["A"], W=g0["W"], bias=g0["bias"], C32=c)], dtype)
+    ops.rownorm([dict(X=c, mod=g0["mod"], gamma=g0["gamma"], beta=g0["beta"], Y32=y2)], M, N_, False, False, 1e-5, dtype)
+    assert rel(keep[0][1][:, N_:2 * N_], y2) < 1e-6
+
+
+def test_gemm_rownorm_rejects_bad_shapes():
+    from sea_amd import ops
+
+    A, W = rnd(8, 64), rnd(260, 64)
+    with pytest.raises(RuntimeError, match="N a multiple of 16 up to 256"):
+        ops.gemm_rownorm([dict(A=A, W=W, gamma=rnd(260), Y32=torch.empty(8, 260, device=dev()))], 1e-5, torch.float32)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 def test_rownorm_ln_gelu_act_input(dtype):
     from sea_amd import ops
 
