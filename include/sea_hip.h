@@ -185,11 +185,13 @@ int sea_rownorm(const SeaNormGroup* groups, int n_groups, int M, int d, int x_is
 
 /* ------------------------------------------------------------------------------------------------------------
  * Linear layer whose output rows are normalised in the same launch (a workgroup tile spans the whole output row, N <= 256):
- *     v    = A[M,K] . W[N,K]^T + bias (+ R)                            (as sea_gemm_grouped; C32 <- v when non-NULL)
+ *     v    = sum_s A_s[M,K] . W[N,K]^T + bias_scale * bias (+ R)       (as sea_gemm_grouped);  Cact <- (act dtype) v when non-NULL
+ *     v    = v + ib(c)  when ib_c != NULL (info-bottleneck addend of sea_ib_add, no dropout);  C32 <- v when non-NULL
  *     y    = LayerNorm_N(v) with gamma / beta / mod exactly as SeaNormGroup (two-pass fp32 statistics, biased variance, eps)
  *     Yact <- (act dtype) y ;  Y32 <- y ;  mean / rstd saved when non-NULL
- * Replaces the pairs cross_down[i] + ln_cross[i] (models/temporal.py:177-181) and proj[i] + the model's final per-field norm
- * (models/temporal.py:146, 412-415) — one launch and one HBM round trip of the [M, N] intermediate less than
+ * Replaces the pairs cross_down[i] + ln_cross[i] (models/temporal.py:177-181), proj[i] + the model's final per-field norm
+ * (models/temporal.py:146, 412-415), and the triple cross_up[i] (+ sum over j, + residual) / _add_info / ln.exp[i][2]
+ * (models/temporal.py:178,189-191 / 140-142 / 145) — one launch and one HBM round trip of the [M, N] intermediate less than
  * sea_gemm_grouped followed by sea_rownorm, with identical arithmetic.
  * Requirements: N % 16 == 0, N <= 256; K % 8 == 0; lda, ldw multiples of 8; ldr, ldc32, ldy32, ldyact, ldmod multiples of 4;
  * all pointers 16-byte aligned.
@@ -210,6 +212,21 @@ typedef struct {
     float* rstd;        /* f32 [M] or NULL */
     int32_t lda, ldw, ldr, ldc32, ldmod, ldy32, ldyact;
     int32_t M, N, K;
+    /* extensions (all-zero = off, except n_seg >= 1 and bias_scale): */
+    int32_t n_seg;          /* sum of n_seg A operands against the same W, segment s at A + s * a_seg_stride (as SeaGemmGroup) */
+    int64_t a_seg_stride;
+    float bias_scale;
+    int32_t ldcact;
+    void* Cact;             /* act [M, N]: v BEFORE the info-bottleneck addend (the copy cross_down reads), or NULL */
+    const float* ib_c;      /* f32 [M] condition: non-NULL adds ib = W2 . gelu(LN_h(w1 c + b1)) + b2 (SeaIbParams) to v before C32 and the norm */
+    const float* ib_w1;
+    const float* ib_b1;
+    const float* ib_lnw;
+    const float* ib_lnb;
+    const float* ib_w2;     /* f32 [N, h] */
+    const float* ib_b2;     /* f32 [N] */
+    int32_t ib_h;           /* 4 or 8 */
+    int32_t pad_;
 } SeaGemmNormGroup;
 
 int sea_gemm_rownorm(const SeaGemmNormGroup* groups, int n_groups, float eps, int dtype, void* stream);

@@ -145,7 +145,10 @@ class SeaGemmNormGroup(C.Structure):
     _fields_ = [("A", _vp), ("W", _vp), ("bias", _vp), ("R", _vp), ("C32", _vp), ("mod", _vp), ("gamma", _vp), ("beta", _vp),
                 ("Y32", _vp), ("Yact", _vp), ("mean", _vp), ("rstd", _vp),
                 ("lda", _i32), ("ldw", _i32), ("ldr", _i32), ("ldc32", _i32), ("ldmod", _i32), ("ldy32", _i32), ("ldyact", _i32),
-                ("M", _i32), ("N", _i32), ("K", _i32)]
+                ("M", _i32), ("N", _i32), ("K", _i32),
+                ("n_seg", _i32), ("a_seg_stride", _i64), ("bias_scale", _f32), ("ldcact", _i32), ("Cact", _vp),
+                ("ib_c", _vp), ("ib_w1", _vp), ("ib_b1", _vp), ("ib_lnw", _vp), ("ib_lnb", _vp), ("ib_w2", _vp), ("ib_b2", _vp),
+                ("ib_h", _i32), ("pad_", _i32)]
 
 
 MAX_WGRAD_GROUPS = 16

@@ -1,11 +1,17 @@
 // Linear layer + row normalisation in one launch (gfx950): sea_gemm_rownorm.
 //
-// A workgroup tile is 64 rows x the WHOLE output row (BN = 64, 128 or 256 >= N); its 4 waves sit in a 4 x 1 grid, so a wave owns
-// 16 complete output rows: in the transposed accumulator map of gemm_core.hpp a row is then spread over the 4 lane groups of ONE
-// wave (lane & 15 = row, lane >> 4 = column quad), and the LayerNorm statistics are two cross-lane adds per pass — no LDS, no
-// second launch, and the [M, N] pre-normalisation matrix never goes to HBM unless the caller asks for it (training).
+// A workgroup tile spans the WHOLE output row (BN = 64, 128 or 256 >= N), so the LayerNorm statistics of a row are available in
+// the GEMM epilogue: no second launch, and the [M, N] pre-normalisation matrix goes to HBM only when the caller asks for it.
 // The arithmetic is the one of rownorm_kernel (rowops.hip): two-pass fp32 mean / centred biased variance, modulation
-// y = xhat * (gamma + 1 + w) + (beta + b).
+// y = xhat * (gamma + 1 + w) + (beta + b); the optional info-bottleneck addend is the one of ib_add_kernel (rowops.hip).
+//
+// Two tile shapes:
+//   * 64 rows, waves 4 x 1: a wave owns 16 complete output rows — in the transposed accumulator map of gemm_core.hpp a row is spread
+//     over the 4 lane groups of ONE wave (lane & 15 = row, lane >> 4 = column quad): statistics = two cross-lane adds per pass.
+//   * 16 rows, waves 1 x 4 (short launches): at M = 2024 the 64-row form is 32 workgroups — one workgroup's serial latency with 16
+//     column blocks per lane in the epilogue.  16-row tiles are 4x the workgroups with a quarter of the epilogue per lane, the
+//     epilogue operands requested before the main loop; the statistics cross the waves through 2 x 64 floats of LDS.  The W tile is
+//     staged per 16 rows instead of per 64 (L2 -> LDS traffic x4), which is why long launches keep the 64-row form.
 #include "gemm_core.hpp"
 #include <stdlib.h>
 
@@ -23,6 +29,177 @@ __device__ __forceinline__ float group_sum4(float x) {
     return x;
 }
 
+#define SEA_IB_FUSED_MAX_H 8
+
+// hidden activations of the info-bottleneck MLP for one row: gelu(LN_h(w1 c + b1))   (models/base_blocks.py:22-24 with dim_in = 1)
+__device__ __forceinline__ void ib_hidden(const SeaGemmNormGroup& G, int row, float (&hid)[SEA_IB_FUSED_MAX_H]) {
+    const int h = G.ib_h;
+    const float cv = G.ib_c[row];
+    float pre[SEA_IB_FUSED_MAX_H], mean = 0.f, var = 0.f;
+#pragma unroll
+    for (int k = 0; k < SEA_IB_FUSED_MAX_H; ++k) {
+        pre[k] = k < h ? G.ib_w1[k] * cv + G.ib_b1[k] : 0.f;
+        mean += pre[k];
+    }
+    mean /= (float)h;
+#pragma unroll
+    for (int k = 0; k < SEA_IB_FUSED_MAX_H; ++k) {
+        pre[k] = k < h ? pre[k] - mean : 0.f;
+        var += pre[k] * pre[k];
+    }
+    const float rstd = 1.0f / sqrtf(var / (float)h + 1e-5f);
+#pragma unroll
+    for (int k = 0; k < SEA_IB_FUSED_MAX_H; ++k) hid[k] = k < h ? gelu_erf(pre[k] * rstd * G.ib_lnw[k] + G.ib_lnb[k]) : 0.f;
+}
+
+// ib[n .. n+3] = b2 + W2[n .. n+3, :] . hid      (h % 4 == 0: rows of W2 are whole 16-byte chunks)
+__device__ __forceinline__ void ib_term(const SeaGemmNormGroup& G, int n, const float (&hid)[SEA_IB_FUSED_MAX_H], float (&o)[4]) {
+    load4(G.ib_b2 + n, o);
+    const int h = G.ib_h;
+#pragma unroll
+    for (int k0 = 0; k0 < SEA_IB_FUSED_MAX_H; k0 += 4) {
+        if (k0 < h) {
+            float w[4][4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) load4(G.ib_w2 + (int64_t)(n + e) * h + k0, w[e]);
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] += w[e][k] * hid[k0 + k];
+        }
+    }
+}
+
+// Everything after the accumulation, for a lane that owns row m and the NI column quads n = col0 + 16 j + 4 g.
+// HOIST: the operands that do not depend on the accumulators are requested by prefetch() before the main loop (latency-bound short launches).
+template <typename T, int NI, bool XWAVE, bool HOIST>
+struct NormEpilogue {
+    static constexpr int NS = HOIST ? NI : 1;   // operand slots: all column blocks when hoisted, else one, refilled per block at its use
+    float bv[NS][4], gm[NS][4], bt[NS][4], mw[NS][4], mb[NS][4], rv[NS][4], ib[NS][4];
+    float hid[SEA_IB_FUSED_MAX_H];
+
+    // operands of the value that is normalised: bias, residual, info-bottleneck addend
+    __device__ __forceinline__ void fetch_pre(const SeaGemmNormGroup& G, int js, int n, int mc) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) bv[js][q] = rv[js][q] = ib[js][q] = 0.f;
+        if (n < G.N) {   // N % 16 == 0: whole 16-column blocks are valid or not
+            if (G.bias != nullptr) {
+                load4(G.bias + n, bv[js]);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) bv[js][q] *= G.bias_scale;
+            }
+            if (G.R != nullptr) load4(G.R + (int64_t)mc * G.ldr + n, rv[js]);
+            if (G.ib_c != nullptr) ib_term(G, n, hid, ib[js]);
+        }
+    }
+    // operands of the normalisation itself: gain, shift, modulation
+    __device__ __forceinline__ void fetch_post(const SeaGemmNormGroup& G, int js, int n, int mc) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) gm[js][q] = bt[js][q] = mw[js][q] = mb[js][q] = 0.f;
+        if (n < G.N) {
+            load4(G.gamma + n, gm[js]);
+            if (G.beta != nullptr) load4(G.beta + n, bt[js]);
+            if (G.mod != nullptr) {
+                const T* mod = static_cast<const T*>(G.mod) + (int64_t)mc * G.ldmod;
+                load4(mod + n, mw[js]);
+                load4(mod + G.N + n, mb[js]);
+            }
+        }
+    }
+
+    __device__ __forceinline__ void prefetch(const SeaGemmNormGroup& G, int mc, int col0, int g) {
+#pragma unroll
+        for (int k = 0; k < SEA_IB_FUSED_MAX_H; ++k) hid[k] = 0.f;
+        if (G.ib_c != nullptr) ib_hidden(G, mc, hid);
+        if constexpr (HOIST) {
+#pragma unroll
+            for (int j = 0; j < NI; ++j) {
+                fetch_pre(G, j, col0 + j * 16 + g * 4, mc);
+                fetch_post(G, j, col0 + j * 16 + g * 4, mc);
+            }
+        }
+    }
+
+    // red: LDS scratch [2][4 waves][16 rows] (XWAVE only; the caller guarantees nobody still reads the operand tile there)
+    __device__ __forceinline__ void finish(const SeaGemmNormGroup& G, f32x4 (&acc)[NI], int m, int col0, int r, int g, int wave, float eps, float* red) {
+        const int N = G.N;
+        const bool mok = m < G.M;
+        const int mc = mok ? m : G.M - 1;
+        const float inv_n = 1.0f / (float)N;
+        if constexpr (!HOIST) prefetch(G, mc, col0, g);
+        float v[NI][4];
+        float sum = 0.f;
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            const int n = col0 + j * 16 + g * 4;
+            const int js = HOIST ? j : 0;
+            const bool nok = n < N;
+            if constexpr (!HOIST) fetch_pre(G, 0, n, mc);
+            float pre[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                pre[q] = nok ? acc[j][q] + bv[js][q] + rv[js][q] : 0.f;
+                v[j][q] = pre[q] + ib[js][q];
+            }
+            sum += (v[j][0] + v[j][1]) + (v[j][2] + v[j][3]);
+            if (mok && nok) {
+                if (G.Cact != nullptr) store4(static_cast<T*>(G.Cact) + (int64_t)m * G.ldcact + n, pre[0], pre[1], pre[2], pre[3]);
+                if (G.C32 != nullptr) store4(G.C32 + (int64_t)m * G.ldc32 + n, v[j][0], v[j][1], v[j][2], v[j][3]);
+            }
+        }
+        sum = group_sum4(sum);
+        if constexpr (XWAVE) {
+            if (g == 0) red[wave * 16 + r] = sum;
+            __syncthreads();
+            sum = (red[r] + red[16 + r]) + (red[32 + r] + red[48 + r]);
+        }
+        const float mean = sum * inv_n;
+        float sq = 0.f;
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            if (col0 + j * 16 < N) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float c = v[j][q] - mean;
+                    sq += c * c;
+                }
+            }
+        }
+        sq = group_sum4(sq);
+        if constexpr (XWAVE) {
+            if (g == 0) red[64 + wave * 16 + r] = sq;
+            __syncthreads();
+            sq = (red[64 + r] + red[80 + r]) + (red[96 + r] + red[112 + r]);
+        }
+        const float rstd = 1.0f / sqrtf(sq * inv_n + eps);
+        if (!mok) return;
+        if (g == 0 && (!XWAVE || wave == 0)) {
+            if (G.mean != nullptr) G.mean[m] = mean;
+            if (G.rstd != nullptr) G.rstd[m] = rstd;
+        }
+        float* y32 = G.Y32 != nullptr ? G.Y32 + (int64_t)m * G.ldy32 : nullptr;
+        T* yact = G.Yact != nullptr ? static_cast<T*>(G.Yact) + (int64_t)m * G.ldyact : nullptr;
+        const bool has_mod = G.mod != nullptr;
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            const int n = col0 + j * 16 + g * 4;
+            const int js = HOIST ? j : 0;
+            if (n >= N) continue;
+            if constexpr (!HOIST) fetch_post(G, 0, n, mc);
+            float o[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float gq = has_mod ? gm[js][q] + 1.0f + mw[js][q] : gm[js][q];
+                const float bq = has_mod ? bt[js][q] + mb[js][q] : bt[js][q];
+                o[q] = (v[j][q] - mean) * rstd * gq + bq;
+            }
+            if (y32 != nullptr) store4(y32 + n, o[0], o[1], o[2], o[3]);
+            if (yact != nullptr) store4(yact + n, o[0], o[1], o[2], o[3]);
+        }
+    }
+};
+
+// ---------------------------------------------------------------------------------------------- 64-row tiles
 template <typename T, int BN>
 __global__ __launch_bounds__(256) void gemm_rownorm_kernel(const GemmNormLaunch L) {
     constexpr int BM = 64;
@@ -37,92 +214,28 @@ __global__ __launch_bounds__(256) void gemm_rownorm_kernel(const GemmNormLaunch 
     GemmMainloop<T, BM, BN, 4> ml;
     ml.A = static_cast<const T*>(G.A);
     ml.W = static_cast<const T*>(G.W);
-    ml.a_seg_stride = 0;
-    ml.lda = G.lda; ml.ldw = G.ldw; ml.M = G.M; ml.N = G.N; ml.K = G.K; ml.n_seg = 1;
+    ml.a_seg_stride = G.a_seg_stride;
+    ml.lda = G.lda; ml.ldw = G.ldw; ml.M = G.M; ml.N = G.N; ml.K = G.K; ml.n_seg = G.n_seg;
     ml.m0 = tm * BM; ml.n0 = 0;
     f32x4 acc[C::MI][C::NI];
     ml.run_single(smem, acc);
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int r = lane & 15, g = lane >> 4;
-    const int m = ml.m0 + wave * 16 + r;
-    const bool mok = m < G.M;
-    const int N = G.N;
-    const float inv_n = 1.0f / (float)N;
-
-    float v[C::NI][4];
-    float sum = 0.f;
-#pragma unroll
-    for (int j = 0; j < C::NI; ++j) {
-        const int n = j * 16 + g * 4;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) v[j][q] = 0.f;
-        if (n < N) {   // N % 16 == 0: whole 16-column blocks are valid or not
-            float bv[4] = {0.f, 0.f, 0.f, 0.f};
-            if (G.bias != nullptr) load4(G.bias + n, bv);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) v[j][q] = acc[0][j][q] + bv[q];
-            if (G.R != nullptr && mok) {
-                float rv[4];
-                load4(G.R + (int64_t)m * G.ldr + n, rv);
-#pragma unroll
-                for (int q = 0; q < 4; ++q) v[j][q] += rv[q];
-            }
-            if (G.C32 != nullptr && mok) store4(G.C32 + (int64_t)m * G.ldc32 + n, v[j][0], v[j][1], v[j][2], v[j][3]);
-            sum += (v[j][0] + v[j][1]) + (v[j][2] + v[j][3]);
-        }
-    }
-    const float mean = group_sum4(sum) * inv_n;
-    float sq = 0.f;
-#pragma unroll
-    for (int j = 0; j < C::NI; ++j) {
-        if (j * 16 < N) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float c = v[j][q] - mean;
-                sq += c * c;
-            }
-        }
-    }
-    const float rstd = 1.0f / sqrtf(group_sum4(sq) * inv_n + L.eps);
-    if (!mok) return;
-    if (g == 0) {
-        if (G.mean != nullptr) G.mean[m] = mean;
-        if (G.rstd != nullptr) G.rstd[m] = rstd;
-    }
-    const T* mod = G.mod != nullptr ? static_cast<const T*>(G.mod) + (int64_t)m * G.ldmod : nullptr;
-    float* y32 = G.Y32 != nullptr ? G.Y32 + (int64_t)m * G.ldy32 : nullptr;
-    T* yact = G.Yact != nullptr ? static_cast<T*>(G.Yact) + (int64_t)m * G.ldyact : nullptr;
-#pragma unroll
-    for (int j = 0; j < C::NI; ++j) {
-        const int n = j * 16 + g * 4;
-        if (n >= N) continue;
-        float gm[4], bt[4] = {0.f, 0.f, 0.f, 0.f}, mw[4] = {0.f, 0.f, 0.f, 0.f}, mb[4] = {0.f, 0.f, 0.f, 0.f};
-        load4(G.gamma + n, gm);
-        if (G.beta != nullptr) load4(G.beta + n, bt);
-        if (mod != nullptr) {
-            load4(mod + n, mw);
-            load4(mod + N + n, mb);
-        }
-        float o[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const float gq = mod != nullptr ? gm[q] + 1.0f + mw[q] : gm[q];
-            const float bq = mod != nullptr ? bt[q] + mb[q] : bt[q];
-            o[q] = (v[j][q] - mean) * rstd * gq + bq;
-        }
-        if (y32 != nullptr) store4(y32 + n, o[0], o[1], o[2], o[3]);
-        if (yact != nullptr) store4(yact + n, o[0], o[1], o[2], o[3]);
-    }
+    NormEpilogue<T, C::NI, false, false> epi;
+    epi.finish(G, acc[0], ml.m0 + wave * 16 + (lane & 15), 0, lane & 15, lane >> 4, wave, L.eps, nullptr);
 }
 
 // ---------------------------------------------------------------------------------------------- 16-row tiles (short launches)
-// At M = 2024 the 64-row form is 32 workgroups: the launch is one workgroup's serial latency and its epilogue has 16 column blocks per
-// lane.  Here a workgroup owns 16 rows x the whole output row with its 4 waves side by side (1 x 4: wave w owns columns
-// [w BN/4, (w+1) BN/4)): 4x the workgroups, a quarter of the epilogue per lane, the modulation / gain loads issued before the
-// statistics; the row statistics cross the waves through 2 x 64 floats of LDS.  The W tile is staged per 16 rows instead of per 64
-// (L2 -> LDS traffic x4), which is why the long launches keep the 64-row form.
-template <typename T, int BN>
+// one wave-instruction of LDS-DMA: 64 lanes x 16 bytes, lane-linear at lds_addr (gemm_core.hpp, run_dma)
+__device__ __forceinline__ void glds16_gn(const void* gsrc, unsigned lds_addr) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_addr) : "memory");
+}
+
+// DMA: the whole contraction (at most 4 K-tiles) of the A rows and of W goes HBM/L2 -> LDS in ONE burst of global_load_lds (no VGPRs, no
+// ds_write, one memory round trip instead of one per K-tile), then the K-tiles are computed back to back.  LDS = nk (16 + BN) 128 B <= 136 KiB.
+template <typename T, int BN, bool DMA>
 __global__ __launch_bounds__(256) void gemm_rownorm16_kernel(const GemmNormLaunch L) {
     constexpr int BM = 16, BKB = 128;
     constexpr int EPC = ActTraits<T>::EPC, BK = BKB / (int)sizeof(T);
@@ -139,6 +252,65 @@ __global__ __launch_bounds__(256) void gemm_rownorm16_kernel(const GemmNormLaunc
     const T* A = static_cast<const T*>(G.A);
     const T* W = static_cast<const T*>(G.W);
 
+    if constexpr (DMA) {
+        const int k_total = K * G.n_seg;
+        const int nk = k_total / BK;
+        const unsigned lds_base = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)smem);
+        const int wv = __builtin_amdgcn_readfirstlane(wave);
+        const int rl = lane >> 3;
+        const int chunk = (lane & 7) ^ (rl & 7);   // swizzle on the source side: LDS position p of a row holds chunk p ^ (row & 7)
+        constexpr int SLABS = ROWS / 8, STAGE = ROWS * BKB;
+        for (int kt = 0; kt < nk; ++kt) {
+            const int kk = kt * BK;
+            int seg = 0, kin = kk;
+            if (G.n_seg > 1) {
+                seg = kk / K;
+                kin = kk - seg * K;
+            }
+            const T* a_base = A + seg * G.a_seg_stride + kin + chunk * EPC;
+            const T* w_base = W + kin + chunk * EPC;
+            for (int u = wv; u < SLABS; u += 4) {   // slab = 8 tile rows = 1 KiB; wave-uniform
+                const int row = u * 8 + rl;
+                const T* p;
+                if (u < BM / 8) {
+                    int mr = m0 + row;
+                    mr = mr < M ? mr : M - 1;
+                    p = a_base + (int64_t)mr * G.lda;
+                } else {
+                    int nr = row - BM;
+                    nr = nr < N ? nr : N - 1;
+                    p = w_base + (int64_t)nr * G.ldw;
+                }
+                glds16_gn(p, lds_base + (unsigned)(kt * STAGE + u * 8 * BKB));
+            }
+        }
+        const int m = m0 + r;
+        NormEpilogue<T, NI, true, true> epi;
+        epi.prefetch(G, m < M ? m : M - 1, wave * WTN, g);
+        f32x4 acc[NI];
+#pragma unroll
+        for (int j = 0; j < NI; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        for (int kt = 0; kt < nk; ++kt) {
+            const char* sA = smem + kt * STAGE + r * BKB;
+            const char* sB = smem + kt * STAGE + (BM + wave * WTN + r) * BKB;
+#pragma unroll
+            for (int kc = 0; kc < 2; ++kc) {
+                const int off = ((kc * 4 + g) ^ (r & 7)) << 4;
+                const uint4 af = *reinterpret_cast<const uint4*>(sA + off);
+#pragma unroll
+                for (int j = 0; j < NI; ++j) {
+                    const uint4 bf = *reinterpret_cast<const uint4*>(sB + j * 16 * BKB + off);
+                    mma16<T>(bf, af, acc[j]);
+                }
+            }
+        }
+        __syncthreads();
+        epi.finish(G, acc, m, wave * WTN, r, g, wave, L.eps, reinterpret_cast<float*>(smem));
+        return;
+    }
+
     // staging: chunk id = row * 8 + c over the ROWS = 16 + BN tile rows (A rows first), 16 bytes each
     uint4 rg[CH];
     const T* src[CH];
@@ -153,49 +325,40 @@ __global__ __launch_bounds__(256) void gemm_rownorm16_kernel(const GemmNormLaunc
             if (row < BM) {
                 int mr = m0 + row;
                 mr = mr < M ? mr : M - 1;
-                src[i] = A + (int64_t)mr * G.lda + c * EPC;
+                src[i] = A + (int64_t)mr * G.lda;
             } else {
                 int nr = row - BM;
                 nr = nr < N ? nr : N - 1;
-                src[i] = W + (int64_t)nr * G.ldw + c * EPC;
+                src[i] = W + (int64_t)nr * G.ldw;
             }
         }
     }
+    const int k_total = K * G.n_seg;
     auto load_tile = [&](int kt) {
-        const int c = tid & 7;
-        const bool kvalid = kt * BK + c * EPC < K;
+        const int kk = kt * BK + (tid & 7) * EPC;   // a 16-byte chunk never straddles two segments (K % 8 == 0)
+        const bool kvalid = kk < k_total;
+        int seg = 0, kin = kk;
+        if (G.n_seg > 1) {
+            seg = kk / K;
+            kin = kk - seg * K;
+        }
+        const int64_t a_off = seg * G.a_seg_stride + kin;
 #pragma unroll
-        for (int i = 0; i < CH; ++i)
-            rg[i] = (src[i] != nullptr && kvalid) ? *reinterpret_cast<const uint4*>(src[i] + kt * BK) : make_uint4(0, 0, 0, 0);
+        for (int i = 0; i < CH; ++i) {
+            const bool is_a = (tid + 256 * i) < BM * 8;
+            rg[i] = (src[i] != nullptr && kvalid) ? *reinterpret_cast<const uint4*>(src[i] + (is_a ? a_off : (int64_t)kin)) : make_uint4(0, 0, 0, 0);
+        }
     };
     f32x4 acc[NI];
 #pragma unroll
     for (int j = 0; j < NI; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int nk = (K + BK - 1) / BK;
+    const int nk = (k_total + BK - 1) / BK;
     load_tile(0);
 
     // epilogue operands that do not depend on the accumulators: requested now, they arrive under the main loop
     const int m = m0 + r;
-    const bool mok = m < M;
-    const int mc = mok ? m : M - 1;
-    const T* mod = G.mod != nullptr ? static_cast<const T*>(G.mod) + (int64_t)mc * G.ldmod : nullptr;
-    float bv[NI][4], gm[NI][4], bt[NI][4], mw[NI][4], mb[NI][4], rv[NI][4];
-#pragma unroll
-    for (int j = 0; j < NI; ++j) {
-        const int n = wave * WTN + j * 16 + g * 4;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) bv[j][q] = gm[j][q] = bt[j][q] = mw[j][q] = mb[j][q] = rv[j][q] = 0.f;
-        if (n < N) {
-            if (G.bias != nullptr) load4(G.bias + n, bv[j]);
-            load4(G.gamma + n, gm[j]);
-            if (G.beta != nullptr) load4(G.beta + n, bt[j]);
-            if (mod != nullptr) {
-                load4(mod + n, mw[j]);
-                load4(mod + N + n, mb[j]);
-            }
-            if (G.R != nullptr) load4(G.R + (int64_t)mc * G.ldr + n, rv[j]);
-        }
-    }
+    NormEpilogue<T, NI, true, true> epi;
+    epi.prefetch(G, m < M ? m : M - 1, wave * WTN, g);
 
     for (int kt = 0; kt < nk; ++kt) {
 #pragma unroll
@@ -217,59 +380,7 @@ __global__ __launch_bounds__(256) void gemm_rownorm16_kernel(const GemmNormLaunc
         }
         __syncthreads();
     }
-
-    float* red = reinterpret_cast<float*>(smem);   // [2][4 waves][16 rows]
-    const float inv_n = 1.0f / (float)N;
-    float v[NI][4];
-    float sum = 0.f;
-#pragma unroll
-    for (int j = 0; j < NI; ++j) {
-        const int n = wave * WTN + j * 16 + g * 4;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) v[j][q] = n < N ? acc[j][q] + bv[j][q] + rv[j][q] : 0.f;
-        sum += (v[j][0] + v[j][1]) + (v[j][2] + v[j][3]);
-        if (G.C32 != nullptr && mok && n < N) store4(G.C32 + (int64_t)m * G.ldc32 + n, v[j][0], v[j][1], v[j][2], v[j][3]);
-    }
-    sum = group_sum4(sum);
-    if (g == 0) red[wave * 16 + r] = sum;
-    __syncthreads();
-    const float mean = ((red[r] + red[16 + r]) + (red[32 + r] + red[48 + r])) * inv_n;
-    float sq = 0.f;
-#pragma unroll
-    for (int j = 0; j < NI; ++j) {
-        if (wave * WTN + j * 16 < N) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float c = v[j][q] - mean;
-                sq += c * c;
-            }
-        }
-    }
-    sq = group_sum4(sq);
-    if (g == 0) red[64 + wave * 16 + r] = sq;
-    __syncthreads();
-    const float rstd = 1.0f / sqrtf(((red[64 + r] + red[80 + r]) + (red[96 + r] + red[112 + r])) * inv_n + L.eps);
-    if (!mok) return;
-    if (g == 0 && wave == 0) {
-        if (G.mean != nullptr) G.mean[m] = mean;
-        if (G.rstd != nullptr) G.rstd[m] = rstd;
-    }
-    float* y32 = G.Y32 != nullptr ? G.Y32 + (int64_t)m * G.ldy32 : nullptr;
-    T* yact = G.Yact != nullptr ? static_cast<T*>(G.Yact) + (int64_t)m * G.ldyact : nullptr;
-#pragma unroll
-    for (int j = 0; j < NI; ++j) {
-        const int n = wave * WTN + j * 16 + g * 4;
-        if (n >= N) continue;
-        float o[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const float gq = mod != nullptr ? gm[j][q] + 1.0f + mw[j][q] : gm[j][q];
-            const float bq = mod != nullptr ? bt[j][q] + mb[j][q] : bt[j][q];
-            o[q] = (v[j][q] - mean) * rstd * gq + bq;
-        }
-        if (y32 != nullptr) store4(y32 + n, o[0], o[1], o[2], o[3]);
-        if (yact != nullptr) store4(yact + n, o[0], o[1], o[2], o[3]);
-    }
+    epi.finish(G, acc, m, wave * WTN, r, g, wave, L.eps, reinterpret_cast<float*>(smem));
 }
 
 template <typename K>
@@ -288,14 +399,19 @@ extern "C" int sea_gemm_rownorm(const SeaGemmNormGroup* groups, int n_groups, fl
     for (int i = 0; i < n_groups; ++i) {
         const SeaGemmNormGroup& G = groups[i];
         SEA_REQUIRE(G.A && G.W && G.gamma && (G.Y32 || G.Yact), "sea_gemm_rownorm[%d]: null pointer", i);
-        SEA_REQUIRE(G.M >= 1 && G.N >= 16 && G.N % 16 == 0 && G.N <= 256 && G.K >= 8 && G.K % 8 == 0, "sea_gemm_rownorm[%d]: bad shape M=%d N=%d K=%d (N a multiple of 16 up to 256)", i, G.M, G.N, G.K);
-        SEA_REQUIRE(G.lda % epc == 0 && G.ldw % epc == 0 && G.lda >= G.K && G.ldw >= G.K, "sea_gemm_rownorm[%d]: bad operand strides lda=%d ldw=%d", i, G.lda, G.ldw);
+        SEA_REQUIRE(G.M >= 1 && G.N >= 16 && G.N % 16 == 0 && G.N <= 256 && G.K >= 8 && G.K % 8 == 0 && G.n_seg >= 1,
+                    "sea_gemm_rownorm[%d]: bad shape M=%d N=%d K=%d n_seg=%d (N a multiple of 16 up to 256)", i, G.M, G.N, G.K, G.n_seg);
+        SEA_REQUIRE(G.lda % epc == 0 && G.ldw % epc == 0 && G.lda >= G.K && G.ldw >= G.K && G.a_seg_stride % epc == 0, "sea_gemm_rownorm[%d]: bad operand strides lda=%d ldw=%d", i, G.lda, G.ldw);
         SEA_REQUIRE((!G.R || (G.ldr % 4 == 0 && G.ldr >= G.N)) && (!G.C32 || (G.ldc32 % 4 == 0 && G.ldc32 >= G.N)) && (!G.Y32 || (G.ldy32 % 4 == 0 && G.ldy32 >= G.N)) &&
-                        (!G.Yact || (G.ldyact % 4 == 0 && G.ldyact >= G.N)) && (!G.mod || (G.ldmod % 4 == 0 && G.ldmod >= 2 * G.N)),
+                        (!G.Yact || (G.ldyact % 4 == 0 && G.ldyact >= G.N)) && (!G.Cact || (G.ldcact % 4 == 0 && G.ldcact >= G.N)) && (!G.mod || (G.ldmod % 4 == 0 && G.ldmod >= 2 * G.N)),
                     "sea_gemm_rownorm[%d]: bad output / modulation strides", i);
-        SEA_REQUIRE(sea_aligned16(G.A) && sea_aligned16(G.W) && sea_aligned16(G.bias) && sea_aligned16(G.R) && sea_aligned16(G.C32) && sea_aligned16(G.mod) &&
+        SEA_REQUIRE(sea_aligned16(G.A) && sea_aligned16(G.W) && sea_aligned16(G.bias) && sea_aligned16(G.R) && sea_aligned16(G.C32) && sea_aligned16(G.Cact) && sea_aligned16(G.mod) &&
                         sea_aligned16(G.gamma) && sea_aligned16(G.beta) && sea_aligned16(G.Y32) && sea_aligned16(G.Yact),
                     "sea_gemm_rownorm[%d]: pointers must be 16-byte aligned", i);
+        if (G.ib_c != nullptr)
+            SEA_REQUIRE(G.ib_w1 && G.ib_b1 && G.ib_lnw && G.ib_lnb && G.ib_w2 && G.ib_b2 && G.ib_h >= 4 && G.ib_h <= SEA_IB_FUSED_MAX_H && G.ib_h % 4 == 0 &&
+                            sea_aligned16(G.ib_w2) && sea_aligned16(G.ib_b2),
+                        "sea_gemm_rownorm[%d]: info-bottleneck addend needs all parameters, h in {4, 8}, w2 / b2 16-byte aligned (h=%d)", i, G.ib_h);
         nmax = G.N > nmax ? G.N : nmax;
         L.g[i] = G;
         L.tile_start[i] = total;
@@ -311,6 +427,19 @@ extern "C" int sea_gemm_rownorm(const SeaGemmNormGroup* groups, int n_groups, fl
             total += (groups[i].M + 15) / 16;
         }
     }
+    // whole-contraction LDS-DMA burst: every group's contraction is 1..4 whole K-tiles (128 bytes of K per row each); SEA_GEMM_NORM_DMA=0 disables
+    static const int dma_on = []() { const char* e = getenv("SEA_GEMM_NORM_DMA"); return e ? atoi(e) : 1; }();
+    int dma_nk = 0;
+    if (small && dma_on && total <= 256) {   // one workgroup per CU (its LDS is the whole contraction): only while the launch is a single round
+        const int bk = dtype == SEA_BF16 ? 64 : 32;
+        for (int i = 0; i < n_groups; ++i) {
+            const long kt = (long)groups[i].K * groups[i].n_seg;
+            const int nk = (groups[i].K % bk == 0 && kt / bk <= 4) ? (int)(kt / bk) : -1;
+            if (nk < 0) { dma_nk = -1; break; }
+            dma_nk = nk > dma_nk ? nk : dma_nk;
+        }
+        if (dma_nk < 0) dma_nk = 0;
+    }
     L.tile_start[n_groups] = total;
     L.n_groups = n_groups;
     L.eps = eps;
@@ -325,9 +454,11 @@ extern "C" int sea_gemm_rownorm(const SeaGemmNormGroup* groups, int n_groups, fl
 #define LAUNCH_GN16(TT, BNN)                                                                    \
     do {                                                                                        \
         constexpr int lds_ = (16 + BNN) * 128;                                                  \
-        static int once = set_lds_gn(gemm_rownorm16_kernel<TT, BNN>, lds_);                     \
-        (void)once;                                                                             \
-        gemm_rownorm16_kernel<TT, BNN><<<dim3(total), dim3(256), lds_, s>>>(L);                 \
+        static int once = set_lds_gn(gemm_rownorm16_kernel<TT, BNN, false>, lds_);              \
+        static int once2 = set_lds_gn(gemm_rownorm16_kernel<TT, BNN, true>, 4 * lds_);          \
+        (void)once; (void)once2;                                                                \
+        if (dma_nk > 0) gemm_rownorm16_kernel<TT, BNN, true><<<dim3(total), dim3(256), dma_nk * lds_, s>>>(L);  \
+        else gemm_rownorm16_kernel<TT, BNN, false><<<dim3(total), dim3(256), lds_, s>>>(L);      \
     } while (0)
 #define LAUNCH_GN_T(TT)                                                                          \
     do {                                                                                        \

@@ -283,10 +283,13 @@ class Plan:
             chunk = groups[s:s + N.MAX_GEMM_NORM_GROUPS]
             arr = (N.SeaGemmNormGroup * len(chunk))()
             for g, d in zip(arr, chunk):
-                ops.fill_gemm_norm_group(g, d["A"], d["W"], d["gamma"], bias=d.get("bias"), mod=d.get("mod"), beta=d.get("beta"),
-                                         Y32=d.get("Y32"), Yact=d.get("Yact"), ldy32=d.get("ldy32"))
+                ops.fill_gemm_norm_group(g, d["A"], d["W"], d["gamma"], bias=d.get("bias"), R=d.get("R"), C32=d.get("C32"), mod=d.get("mod"),
+                                         beta=d.get("beta"), Y32=d.get("Y32"), Yact=d.get("Yact"), ldy32=d.get("ldy32"), n_seg=d.get("n_seg", 1),
+                                         a_seg_stride=d.get("a_seg_stride", 0), bias_scale=d.get("bias_scale", 1.0), Cact=d.get("Cact"), ib=d.get("ib"))
                 if d.get("Y_is_out") is not None:
                     self._out_patches.append((g, "Y32", d["Y_is_out"]))
+                if d.get("ib") is not None:
+                    self._c_patches.append((g, "ib_c"))
             self._cur.append(self._rec(L.sea_gemm_rownorm, [arr, len(chunk), 1e-5, self.code], name, arr))
 
     def _qkv(self, groups: List[dict], rope: torch.Tensor, hd: int, name: str) -> None:
@@ -383,6 +386,11 @@ class Plan:
         # Linear + the row norm that follows it in one launch (sea_gemm_rownorm) where a tile can span the whole output row: cross_down + ln_cross,
         # the last layer's proj + the model's final norm.  SEA_FUSE_NORM=0 keeps the two-launch form (A/B measurements).
         fuse_norm = self._fuse_norm = type(self) is Plan and os.environ.get("SEA_FUSE_NORM", "1") != "0"
+        # ... and, opt-in (SEA_FUSE_TAIL=1), cross_up (+ sum over j, + residual) with the info-bottleneck add and AdaLN_2 that follow a field's
+        # exchange stage.  Measured at cfg2: 0.294 ms against 0.285 — ib_add and AdaLN_2 are ONE launch each for all fields, folding them into F
+        # per-field launches trades 2 launches (~13 us) for 3 x ~8 us of extra epilogue on the serial Gauss-Seidel chain.
+        fuse_tail = (fuse_norm and os.environ.get("SEA_FUSE_TAIL", "0") == "1" and F > 1 and eng.model.add_info_after_cross and not lanes
+                     and E <= 256 and E % 16 == 0 and eng.model.ib_hidden in (4, 8))
         mods = self._cond_mods(split=split_cond)
         cond_joined = not split_cond
 
@@ -476,9 +484,15 @@ class Plan:
                     self._qkv(qkv_groups, rope_c, hd_c, f"cross{i}.qkv_rope")
                     self._attn(probs, hd_c, D, f"cross{i}.attention")
                     self._gemm(proj_groups, f"cross{i}.proj_gelu")
-                    self._gemm([dict(A=gp[0], W=P.act(f"{pre}cross_up.{i}.weight"), bias=P.f32_vec(f"{pre}cross_up.{i}.bias"),
-                                     bias_scale=float(F - 1), n_seg=F - 1, a_seg_stride=M * D, R=xr[i], C32=xr[i],
-                                     Cact=(xa[i] if i < F - 1 else None))], f"cross{i}.up_sum")
+                    up = dict(A=gp[0], W=P.act(f"{pre}cross_up.{i}.weight"), bias=P.f32_vec(f"{pre}cross_up.{i}.bias"),
+                              bias_scale=float(F - 1), n_seg=F - 1, a_seg_stride=M * D, R=xr[i], C32=xr[i],
+                              Cact=(xa[i] if i < F - 1 else None))
+                    if fuse_tail:
+                        # x_i is final for the exchange: its info-bottleneck add and AdaLN_2 ride in the epilogue of the up-projection (xa[i], the
+                        # copy cross_down reads, is written before the add)
+                        self._gemm_norm([dict(ib=self._ib_params(pre), Yact=n_e[i], **up, **norm_params(f"{pre}ln.exp.{i}.2.", E))], f"cross{i}.up_sum_ib_adaln2")
+                    else:
+                        self._gemm([up], f"cross{i}.up_sum")
                     if lanes:
                         # x_i is final for the exchange: its info-bottleneck add, MLP, proj (and final norm) run on their own lane beside the
                         # remaining Gauss-Seidel stages; the last field stays on the main stream.  fc2 writes xm, not xa: the main stream
@@ -500,15 +514,17 @@ class Plan:
                 for i in range(F - 1):
                     self._join(2 + i)
                 continue
-            if eng.model.add_info_after_cross:
+            if eng.model.add_info_after_cross and not fuse_tail:
                 self._ib(pre, xr)
-            fused_final = last and fuse_norm and E <= 256 and E % 16 == 0
-            self._mlp_proj(pre, list(range(F)), xr, xa, n_e, hbuf, hg, mods, False, fuse_final=fused_final)
+            # opt-in (SEA_FUSE_FINAL=1): measured at cfg2 the fused proj + final norm is 14.5 us against 6.8 + 4.8 for the pair (N = 256 with 16-row
+            # tiles: every workgroup stages the whole 256 x 256 weight); at B = 8 (64-row tiles) the two forms tie
+            fused_final = last and fuse_norm and E <= 256 and E % 16 == 0 and os.environ.get("SEA_FUSE_FINAL", "0") == "1"
+            self._mlp_proj(pre, list(range(F)), xr, xa, n_e, hbuf, hg, mods, False, fuse_final=fused_final, skip_adaln2=fuse_tail)
         if not lanes and not fused_final:
             # -- final per-field norm, written straight into out[B,T,F,E]
             self._norm([dict(X=xr[i], Y32=xr[i], ldy32=FE, Y_is_out=i * E * 4, **norm_params(f"ln.{i}.", E)) for i in range(F)], E, "final.norm")
 
-    def _mlp_proj(self, pre, fields, xr, xm, n_e, hbuf, hg, mods, final_norm, tag="", fuse_final=False) -> None:
+    def _mlp_proj(self, pre, fields, xr, xm, n_e, hbuf, hg, mods, final_norm, tag="", fuse_final=False, skip_adaln2=False) -> None:
         """x_i += W2 gelu(LN(W1 AdaLN_2(x_i))) ; x_i = proj_i(x_i) for the listed fields (models/temporal.py:143-146), optionally followed
         by the model's final per-field norm written straight into out (models/temporal.py:412-415)."""
         P, E, S, FE = self.eng.params, self.E, self.S, self.F * self.E
@@ -518,7 +534,8 @@ class Plan:
                 return dict(mod=mods[p_], gamma=P.f32_vec(p_ + "weight"), beta=P.f32_vec(p_ + "bias"))
             return dict(gamma=P.f32_vec(p_ + "weight"))
 
-        self._norm([dict(X=xr[i], Yact=n_e[i], **norm_params(f"{pre}ln.exp.{i}.2.", E)) for i in fields], E, "mlp.adaln2" + tag)
+        if not skip_adaln2:
+            self._norm([dict(X=xr[i], Yact=n_e[i], **norm_params(f"{pre}ln.exp.{i}.2.", E)) for i in fields], E, "mlp.adaln2" + tag)
         self._gemm([dict(A=n_e[i], W=P.act(f"{pre}mlp.{i}.layers.0.weight"), bias=P.f32_vec(f"{pre}mlp.{i}.layers.0.bias"), Cact=hbuf[i])
                     for i in fields], "mlp.fc1" + tag)
         self._norm([dict(X=hbuf[i], gamma=P.f32_vec(f"{pre}mlp.{i}.layers.1.weight"), beta=P.f32_vec(f"{pre}mlp.{i}.layers.1.bias"), Yact=hg[i])
@@ -678,6 +695,12 @@ class Plan:
                     g += self_qkv(l + 1, i, 1)
                 groups.append(g)
             self._chain(groups, "proj_final_norm" if l == self.L - 1 else "proj_adaln0_qkv")
+
+    def _ib_params(self, pre: str) -> dict:
+        P = self.eng.params
+        return dict(w1=P.f32_vec(pre + "ib.layers.0.weight"), b1=P.f32_vec(pre + "ib.layers.0.bias"), lnw=P.f32_vec(pre + "ib.layers.1.weight"),
+                    lnb=P.f32_vec(pre + "ib.layers.1.bias"), w2=P.f32(pre + "ib.layers.3.weight"), b2=P.f32_vec(pre + "ib.layers.3.bias"),
+                    h=self.eng.model.ib_hidden)
 
     def _ib(self, pre: str, xr: List[torch.Tensor], drop=None) -> None:
         P = self.eng.params

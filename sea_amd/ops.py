@@ -124,7 +124,8 @@ def rownorm(groups: Sequence[Dict], M: int, d: int, x_is_act: bool, gelu: bool, 
 
 
 def fill_gemm_norm_group(g: N.SeaGemmNormGroup, A, W, gamma, bias=None, R=None, C32=None, mod=None, beta=None, Y32=None, Yact=None,
-                         mean=None, rstd=None, ldr=None, ldy32=None) -> None:
+                         mean=None, rstd=None, ldr=None, ldy32=None, n_seg=1, a_seg_stride=0, bias_scale=1.0, Cact=None, ib=None, K=None) -> None:
+    """ib: dict(c, w1, b1, lnw, lnb, w2 [N, h], b2, h) — the info-bottleneck addend (sea_hip.h, SeaGemmNormGroup)."""
     g.A, g.W, g.bias, g.R, g.C32 = A.data_ptr(), W.data_ptr(), N.ptr(bias), N.ptr(R), N.ptr(C32)
     g.mod, g.gamma, g.beta = N.ptr(mod), gamma.data_ptr(), N.ptr(beta)
     g.Y32, g.Yact, g.mean, g.rstd = N.ptr(Y32), N.ptr(Yact), N.ptr(mean), N.ptr(rstd)
@@ -134,7 +135,12 @@ def fill_gemm_norm_group(g: N.SeaGemmNormGroup, A, W, gamma, bias=None, R=None, 
     g.ldmod = mod.stride(0) if mod is not None else 0
     g.ldy32 = (ldy32 if ldy32 is not None else Y32.stride(0)) if Y32 is not None else 0
     g.ldyact = Yact.stride(0) if Yact is not None else 0
-    g.M, g.N, g.K = A.shape[0], W.shape[0], W.shape[1]
+    g.M, g.N, g.K = A.shape[0], W.shape[0], (W.shape[1] if K is None else K)
+    g.n_seg, g.a_seg_stride, g.bias_scale = n_seg, a_seg_stride, bias_scale
+    g.Cact, g.ldcact = N.ptr(Cact), (Cact.stride(0) if Cact is not None else 0)
+    if ib is not None:
+        g.ib_c, g.ib_w1, g.ib_b1, g.ib_lnw, g.ib_lnb = N.ptr(ib.get("c")), ib["w1"].data_ptr(), ib["b1"].data_ptr(), ib["lnw"].data_ptr(), ib["lnb"].data_ptr()
+        g.ib_w2, g.ib_b2, g.ib_h = ib["w2"].data_ptr(), ib["b2"].data_ptr(), ib["h"]
 
 
 def gemm_rownorm(groups: Sequence[Dict], eps: float, dtype: torch.dtype) -> None:
@@ -151,7 +157,8 @@ def gemm_rownorm(groups: Sequence[Dict], eps: float, dtype: torch.dtype) -> None
         if d.get("mod") is not None and d["mod"].dtype != dtype:
             raise ValueError(f"gemm_rownorm group {i}: mod dtype mismatch")
         fill_gemm_norm_group(arr[i], A, W, d["gamma"], d.get("bias"), d.get("R"), d.get("C32"), d.get("mod"), d.get("beta"), d.get("Y32"),
-                             d.get("Yact"), d.get("mean"), d.get("rstd"))
+                             d.get("Yact"), d.get("mean"), d.get("rstd"), n_seg=d.get("n_seg", 1), a_seg_stride=d.get("a_seg_stride", 0),
+                             bias_scale=d.get("bias_scale", 1.0), Cact=d.get("Cact"), ib=d.get("ib"))
     N.check(N.lib().sea_gemm_rownorm(arr, n, eps, N.dtype_code(dtype), N.stream_ptr()), "sea_gemm_rownorm")
 
 

@@ -265,7 +265,9 @@ def test_shipped_multiphase_dims_forward_bf16():
     assert rel_l2(roll.numpy(), ref_roll.numpy()) < 2 * BF16_TOL
 
 
-@pytest.mark.parametrize("env,graphed", [({"SEA_FUSED": "1"}, False), ({"SEA_PLAN_LANES": "all"}, True), ({"SEA_PLAN_LANES": "cond"}, True)])
+@pytest.mark.parametrize("env,graphed", [({"SEA_FUSED": "1"}, False), ({"SEA_PLAN_LANES": "all"}, True), ({"SEA_PLAN_LANES": "cond"}, True),
+                                         ({"SEA_FUSE_NORM": "0"}, False), ({"SEA_FUSE_TAIL": "1", "SEA_FUSE_FINAL": "1"}, False),
+                                         ({"SEA_FUSE_TAIL": "1", "SEA_FUSE_FINAL": "1", "SEA_GEMM_NORM_ROWS": "64"}, False)])
 @pytest.mark.parametrize("dtype,tol", [("fp32", 2e-6), ("bf16", 2e-2)])
 def test_optional_plans_match_default_plan(env, graphed, dtype, tol, monkeypatch):
     """The opt-in plans (row-local chains in one launch; parallel graph branches) compute what the default launch list computes —
@@ -282,8 +284,13 @@ def test_optional_plans_match_default_plan(env, graphed, dtype, tol, monkeypatch
         eng = m.engine()
         out = eng.forward_graphed(xg, ibg).clone() if graphed else m(xg, ibg)
         plan = eng.plan(2, 70, "full")
+    names = [r.name for r in plan.records]
     if "SEA_FUSED" in env:
         assert plan.fused and any(r.name.startswith("cross0.proj_up_down_kv") for r in plan.records)
+    elif "SEA_FUSE_NORM" in env:   # the two-launch form of Linear + row norm
+        assert "cross.norm_old" in names and "cross.down_norm_old" not in names
+    elif "SEA_FUSE_TAIL" in env:   # cross_up + info-bottleneck add + AdaLN_2 and proj + final norm in one launch each
+        assert "cross0.up_sum_ib_adaln2" in names and "proj_final_norm" in names and "ib_add" not in names and "mlp.adaln2" not in names
     else:
         assert any(r.fn is None for r in plan.records)  # fork / join markers present
     assert rel_l2(out.cpu().numpy(), ref.cpu().numpy()) < tol

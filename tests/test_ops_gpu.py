@@ -310,6 +310,40 @@ def test_gemm_rownorm_matches_gemm_then_rownorm(dtype, N_, K):
     assert rel(keep[0][1][:, N_:2 * N_], y2) < 1e-6
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M", [203, 2500])
+def test_gemm_rownorm_segments_ib_addend(dtype, M):
+    """The exchange tail of one field in one launch: x += cross_up(sum_j g_j) (segments, bias counted per segment, in-place residual),
+    the copy cross_down reads is written BEFORE the info-bottleneck addend, AdaLN_2 is taken after it.  M = 2500 runs the 64-row tiles
+    (forced through SEA_GEMM_NORM_ROWS is not needed: the launch is longer than 512 row tiles only at M > 32768, so both shapes are forced by env in
+    test_gemm_rownorm_tile_shapes_agree)."""
+    from sea_amd import ops
+
+    D, E, h, S = 128, 256, 8, 2
+    gp = rnd(S, M, D, dtype=dtype, seed=600)
+    W = rnd(E, D, dtype=dtype, scale=0.2, seed=601)
+    bias = 0.2 * rnd(E, seed=602)
+    x = rnd(M, E, seed=603)
+    x0 = x.clone()
+    mod = rnd(M, 2 * E, dtype=dtype, scale=0.5, seed=604)
+    gamma, beta = 1 + 0.1 * rnd(E, seed=605), 0.1 * rnd(E, seed=606)
+    c = torch.rand(M, device=dev())
+    w1, b1 = rnd(h, seed=607), rnd(h, seed=608)
+    lnw, lnb = 1 + 0.1 * rnd(h, seed=609), 0.1 * rnd(h, seed=610)
+    w2, b2 = rnd(E, h, scale=0.3, seed=611), 0.1 * rnd(E, seed=612)
+    xa = torch.empty(M, E, device=dev(), dtype=dtype)
+    ne = torch.empty(M, E, device=dev(), dtype=dtype)
+    ops.gemm_rownorm([dict(A=gp[0], W=W, bias=bias, bias_scale=float(S), n_seg=S, a_seg_stride=M * D, R=x, C32=x, Cact=xa, mod=mod, gamma=gamma, beta=beta,
+                           Yact=ne, ib=dict(c=c, w1=w1, b1=b1, lnw=lnw, lnb=lnb, w2=w2, b2=b2, h=h))], 1e-5, dtype)
+    pre = x0 + gp.float().sum(0) @ W.float().t() + S * bias
+    hid = gelu(torch.nn.functional.layer_norm(c[:, None] * w1 + b1, (h,), lnw, lnb, 1e-5))
+    v = pre + hid @ w2.t() + b2
+    assert rel(xa.float(), pre) < tol(dtype, f32=2e-5)
+    assert rel(x, v) < 2e-5
+    ref = torch.nn.functional.layer_norm(v, (E,), None, None, 1e-5) * (gamma + 1 + mod[:, :E].float()) + (beta + mod[:, E:].float())
+    assert rel(ne.float(), ref) < tol(dtype, f32=3e-5)
+
+
 def test_gemm_rownorm_rejects_bad_shapes():
     from sea_amd import ops
 
