@@ -79,13 +79,16 @@ def param_schema(cfg: OracleConfig) -> "OrderedDict[str, Tuple[Tuple[int, ...], 
             _linear(s, f"{b}mlp.{i}.layers.3.", E, S)
         for i in range(F):
             _linear(s, f"{b}proj.{i}.", E, E)
+        if cfg.exchange_mode == "simple":   # SimpleBlockTemporal adds no parameters (models/temporal.py:304-306)
+            continue
         for i in range(F):
             _linear(s, f"{b}cross_down.{i}.", D, E)
         for i in range(F):
             _linear(s, f"{b}cross_up.{i}.", E, D)
-        for i in range(F):
-            for j in range(F):
-                _attention(s, f"{b}cross_attn.{i}.{j}.", D)
+        if cfg.exchange_mode == "sea":      # AddBlockTemporal has no cross-attention modules (models/temporal.py:279-289)
+            for i in range(F):
+                for j in range(F):
+                    _attention(s, f"{b}cross_attn.{i}.{j}.", D)
         for i in range(F):
             _norm(s, f"{b}ln_cross.{i}.", D, cfg.LN_type)
     for i in range(F):

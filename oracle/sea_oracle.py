@@ -35,9 +35,9 @@ Params = Dict[str, torch.Tensor]
 @dataclass(frozen=True)
 class OracleConfig:
     """Constructor arguments of the reference ``TemporalModel`` that shape the
-    computation (models/temporal.py:327-344).  Only the combination both shipped
-    configs select is restated: exchange_mode='sea', ib_scale_mode='mlp',
-    ib_addition_mode='add', ib_mlp_layers=1, ib_num=1."""
+    computation (models/temporal.py:327-344).  Restated: exchange_mode in {'sea' (both
+    shipped configs), 'addition', 'simple'}, ib_scale_mode='mlp', ib_addition_mode in
+    {'add', 'none'}, ib_mlp_layers=1, ib_num=1."""
 
     num_layers: int
     embed_dim: int
@@ -49,6 +49,8 @@ class OracleConfig:
     down_proj: int = 2
     add_info_after_cross: bool = True
     LN_type: str = "adaln"
+    exchange_mode: str = "sea"
+    ib_addition_mode: str = "add"
 
     @property
     def down_dim(self) -> int:  # models/temporal.py:58-59
@@ -178,6 +180,34 @@ def sea_exchange(xs: List[torch.Tensor], cond: torch.Tensor, p: Params, pre: str
     return xs
 
 
+def add_exchange(xs: List[torch.Tensor], cond: torch.Tensor, p: Params, pre: str, cfg: OracleConfig) -> List[torch.Tensor]:
+    """AddBlockTemporal._apply_exchange (models/temporal.py:291-301): every field is down-projected and normalised FROM ITS
+    PRE-EXCHANGE VALUE (Jacobi, unlike 'sea'); x_i += cross_up_i(GELU(normalized_i + sum_{j != i} normalized_j))."""
+    F = cfg.num_variables
+    nrm = [norm(linear(xs[j], p[f"{pre}cross_down.{j}.weight"], p[f"{pre}cross_down.{j}.bias"]), cond, p, f"{pre}ln_cross.{j}.", cfg.LN_type)
+           for j in range(F)]
+    out = []
+    for i in range(F):
+        others = None
+        for j in range(F):
+            if j != i:
+                others = nrm[j] if others is None else others + nrm[j]
+        combined = nrm[i] if others is None else nrm[i] + others
+        out.append(xs[i] + linear(gelu_erf(combined), p[f"{pre}cross_up.{i}.weight"], p[f"{pre}cross_up.{i}.bias"]))
+    return out
+
+
+def exchange(xs: List[torch.Tensor], cond: torch.Tensor, p: Params, pre: str, cfg: OracleConfig) -> List[torch.Tensor]:
+    """create_block_temporal's dispatch (models/temporal.py:314-324); 'simple' = SimpleBlockTemporal (:304-306), no exchange."""
+    if cfg.exchange_mode == "sea":
+        return sea_exchange(xs, cond, p, pre, cfg)
+    if cfg.exchange_mode == "addition":
+        return add_exchange(xs, cond, p, pre, cfg)
+    if cfg.exchange_mode == "simple":
+        return list(xs)
+    raise ValueError(f"Invalid exchange_mode: {cfg.exchange_mode}")
+
+
 def info_bottleneck(cond: torch.Tensor, p: Params, pre: str) -> torch.Tensor:
     """BaseBlockTemporal._add_info with ib_scale_mode='mlp', ib_addition_mode='add'
     (models/temporal.py:111-116): MLP(1 -> scale_ratio -> E); its residual_projection is
@@ -190,14 +220,15 @@ def block_forward(xs: Sequence[torch.Tensor], cond: torch.Tensor, p: Params, pre
     F = cfg.num_variables
     assert len(xs) == F
     xs = list(xs)
-    if not cfg.add_info_after_cross:
+    add_ib = cfg.ib_addition_mode == "add"   # 'none': _add_info returns x (models/temporal.py:113-114)
+    if not cfg.add_info_after_cross and add_ib:
         ib = info_bottleneck(cond, p, pre)
         xs = [x + ib for x in xs]
     for i in range(F):
         n = norm(xs[i], cond, p, f"{pre}ln.exp.{i}.0.", cfg.LN_type)
         xs[i] = xs[i] + masked_attention(n, n, p, f"{pre}attn.self.{i}.", cfg.n_heads, cfg.src_len)
-    xs = sea_exchange(xs, cond, p, pre, cfg)
-    if cfg.add_info_after_cross:
+    xs = exchange(xs, cond, p, pre, cfg)
+    if cfg.add_info_after_cross and add_ib:
         ib = info_bottleneck(cond, p, pre)
         xs = [x + ib for x in xs]
     for i in range(F):

@@ -336,8 +336,9 @@ class Plan:
             for i in range(F):
                 (first if l == 0 else rest).append((f"{pre}ln.exp.{i}.0.", E))
                 rest.append((f"{pre}ln.exp.{i}.2.", E))
-            for i in range(F):
-                rest.append((f"{pre}ln_cross.{i}.", D))
+            if self.eng.model.exchange_mode != "simple":
+                for i in range(F):
+                    rest.append((f"{pre}ln_cross.{i}.", D))
         for i in range(F):
             rest.append((f"ln.{i}.", E))
 
@@ -380,7 +381,9 @@ class Plan:
         # Optional lanes (parallel graph branches) for independent work — SEA_PLAN_LANES: "cond" = the condition MLPs the first launch does
         # not need, "all" = also every finished field's MLP beside the remaining exchange stages.  Off by default: measured at cfg2 the
         # cross-branch dependencies of a captured HIP graph cost more than the overlap gains (0.344 ms none, 0.371 cond, 0.395 all).
-        mode = os.environ.get("SEA_PLAN_LANES", "none") if type(self) is Plan else "none"
+        xmode = eng.model.exchange_mode                                   # 'sea' | 'addition' | 'simple' (models/temporal.py:314-324)
+        has_ib = eng.model.ib_addition_mode.lower() == "add"              # 'none': _add_info returns x (models/temporal.py:113-114)
+        mode = os.environ.get("SEA_PLAN_LANES", "none") if type(self) is Plan and xmode == "sea" and has_ib else "none"
         lanes = mode == "all" and F >= 2 and eng.model.add_info_after_cross
         split_cond = mode in ("cond", "all") and self.adaln
         # Linear + the row norm that follows it in one launch (sea_gemm_rownorm) where a tile can span the whole output row: cross_down + ln_cross,
@@ -389,7 +392,7 @@ class Plan:
         # ... and, opt-in (SEA_FUSE_TAIL=1), cross_up (+ sum over j, + residual) with the info-bottleneck add and AdaLN_2 that follow a field's
         # exchange stage.  Measured at cfg2: 0.294 ms against 0.285 — ib_add and AdaLN_2 are ONE launch each for all fields, folding them into F
         # per-field launches trades 2 launches (~13 us) for 3 x ~8 us of extra epilogue on the serial Gauss-Seidel chain.
-        fuse_tail = (fuse_norm and os.environ.get("SEA_FUSE_TAIL", "0") == "1" and F > 1 and eng.model.add_info_after_cross and not lanes
+        fuse_tail = (fuse_norm and xmode == "sea" and has_ib and os.environ.get("SEA_FUSE_TAIL", "0") == "1" and F > 1 and eng.model.add_info_after_cross and not lanes
                      and E <= 256 and E % 16 == 0 and eng.model.ib_hidden in (4, 8))
         mods = self._cond_mods(split=split_cond)
         cond_joined = not split_cond
@@ -409,13 +412,14 @@ class Plan:
         Ks = [[self._buf(B, H, cap, hd_s, zero=True) for _ in range(F)] for _ in range(self.L)]
         Vs = [[self._buf(B, H, hd_s, cap, zero=True) for _ in range(F)] for _ in range(self.L)]
         dn = [self._buf(M, D, dtype=f32) for _ in range(F)]
-        nd_old = [self._buf(M, D) for _ in range(F)]
-        nd_new = [self._buf(M, D) for _ in range(F)]
-        Qc = [self._buf(B, H, T, hd_c) for _ in range(max(F - 1, 1))]
-        Kc = [[[self._buf(B, H, cap, hd_c, zero=True) for _ in range(F)] for _ in range(F)] for _ in range(self.L)]
-        Vc = [[[self._buf(B, H, hd_c, cap, zero=True) for _ in range(F)] for _ in range(F)] for _ in range(self.L)]
-        att_c = [self._buf(M, D) for _ in range(max(F - 1, 1))]
-        gp = self._buf(max(F - 1, 1), M, D)
+        if xmode == "sea":   # cross-attention workspaces
+            nd_old = [self._buf(M, D) for _ in range(F)]
+            nd_new = [self._buf(M, D) for _ in range(F)]
+            Qc = [self._buf(B, H, T, hd_c) for _ in range(max(F - 1, 1))]
+            Kc = [[[self._buf(B, H, cap, hd_c, zero=True) for _ in range(F)] for _ in range(F)] for _ in range(self.L)]
+            Vc = [[[self._buf(B, H, hd_c, cap, zero=True) for _ in range(F)] for _ in range(F)] for _ in range(self.L)]
+            att_c = [self._buf(M, D) for _ in range(max(F - 1, 1))]
+            gp = self._buf(max(F - 1, 1), M, D)
         hbuf = [self._buf(M, S) for _ in range(F)]
         hg = [self._buf(M, S) for _ in range(F)]
         self.ws = dict(xr=xr, xa=xa, n_e=n_e, att_e=att_e, hbuf=hbuf, hg=hg)
@@ -426,14 +430,14 @@ class Plan:
         for l in range(self.L):
             pre = f"blocks.{l}."
             last = l == self.L - 1
-            if first and not eng.model.add_info_after_cross:
+            if first and not eng.model.add_info_after_cross and has_ib:
                 # the info-bottleneck add comes first and must not modify the caller's tensor: copy x into xr
                 for i in range(F):
                     rec = _Rec(L.sea_convert_f32_to_act, [None, FE, xr[i].data_ptr(), E, M, E, N.SEA_F32], "x.copy")
                     self._x_patches.append((rec.args, 0, i * E * 4))
                     self.records.append(rec)
                 first = False
-            if not eng.model.add_info_after_cross:
+            if not eng.model.add_info_after_cross and has_ib:
                 self._ib(pre, xr)
             # -- self attention: x_i += proj(attn(AdaLN_0(x_i)))
             groups = []
@@ -461,8 +465,23 @@ class Plan:
             if not cond_joined:  # everything below reads modulations computed on lane 1
                 self._join(1)
                 cond_joined = True
+            if xmode == "addition":
+                # -- 'addition' exchange (models/temporal.py:291-301; Jacobi: every field read at its pre-exchange value): down-projection + norm of all
+                # fields in one launch, s = GELU(sum_j n_j) as an identity-weight GEMM over F segments, x_i += cross_up_i(s) in one grouped launch
+                ndall = self._buf(F, M, D)
+                if fuse_norm and D <= 256 and D % 16 == 0:
+                    self._gemm_norm([dict(A=xa[j], W=P.act(f"{pre}cross_down.{j}.weight"), bias=P.f32_vec(f"{pre}cross_down.{j}.bias"), Yact=ndall[j],
+                                          **norm_params(f"{pre}ln_cross.{j}.", D)) for j in range(F)], "add.down_norm")
+                else:
+                    self._gemm([dict(A=xa[j], W=P.act(f"{pre}cross_down.{j}.weight"), bias=P.f32_vec(f"{pre}cross_down.{j}.bias"), C32=dn[j])
+                                for j in range(F)], "add.down")
+                    self._norm([dict(X=dn[j], Yact=ndall[j], **norm_params(f"{pre}ln_cross.{j}.", D)) for j in range(F)], D, "add.norm")
+                sg = self._buf(M, D)
+                self._gemm([dict(A=ndall[0], W=eng.eye(D), n_seg=F, a_seg_stride=M * D, Cact=sg, act=1)], "add.sum_gelu")
+                self._gemm([dict(A=sg, W=P.act(f"{pre}cross_up.{i}.weight"), bias=P.f32_vec(f"{pre}cross_up.{i}.bias"), R=xr[i], C32=xr[i])
+                            for i in range(F)], "add.up")
             # -- state exchange (Gauss-Seidel over i, models/temporal.py:187-192)
-            if F > 1:
+            if F > 1 and xmode == "sea":
                 if fuse_norm and D <= 256 and D % 16 == 0:
                     self._gemm_norm([dict(A=xa[j], W=P.act(f"{pre}cross_down.{j}.weight"), bias=P.f32_vec(f"{pre}cross_down.{j}.bias"), Yact=nd_old[j],
                                           **norm_params(f"{pre}ln_cross.{j}.", D)) for j in range(F)], "cross.down_norm_old")
@@ -514,7 +533,7 @@ class Plan:
                 for i in range(F - 1):
                     self._join(2 + i)
                 continue
-            if eng.model.add_info_after_cross and not fuse_tail:
+            if eng.model.add_info_after_cross and has_ib and not fuse_tail:
                 self._ib(pre, xr)
             # opt-in (SEA_FUSE_FINAL=1): measured at cfg2 the fused proj + final norm is 14.5 us against 6.8 + 4.8 for the pair (N = 256 with 16-row
             # tiles: every workgroup stages the whole 256 x 256 weight); at B = 8 (64-row tiles) the two forms tie
@@ -556,7 +575,7 @@ class Plan:
         LDS tiles (E, D multiples of 64 up to 256).  Opt-in with SEA_FUSED=1: measured at cfg2 (profiles/) the chains are still slower than the
         launch-per-operator plan — every stage pays a cold ~1.5 us memory round trip for its weights with one wave per SIMD to hide it."""
         m = self.eng.model
-        if type(self) is not Plan or os.environ.get("SEA_FUSED", "0") != "1":
+        if type(self) is not Plan or os.environ.get("SEA_FUSED", "0") != "1" or m.exchange_mode != "sea" or m.ib_addition_mode.lower() != "add":
             return False
         ok_w = lambda w: w % 64 == 0 and w <= N.CHAIN_MAX_WIDTH
         return (ok_w(self.E) and ok_w(self.D) and 2 * self.D <= N.CHAIN_MAX_WIDTH and self.F >= 2 and m.add_info_after_cross
@@ -883,13 +902,15 @@ class TemporalEngine:
         if device.type != "cuda":
             raise RuntimeError("sea_amd: TemporalModel runs only on an MI355X (no CPU fallback)")
         m = model
-        if m.exchange_mode != "sea" or m.ib_scale_mode != "mlp" or m.ib_addition_mode != "add" or m.ib_mlp_layers != 1 or m.ib_num != 1:
+        if (m.exchange_mode not in ("sea", "addition", "simple") or m.ib_scale_mode != "mlp" or m.ib_addition_mode.lower() not in ("add", "none")
+                or m.ib_mlp_layers != 1 or m.ib_num != 1):
             raise NotImplementedError(
-                "sea_amd native path covers exchange_mode='sea', ib_scale_mode='mlp', ib_addition_mode='add', ib_mlp_layers=1, "
-                "ib_num=1 (the combination both shipped configs select); got "
+                "sea_amd native path covers exchange_mode in {'sea', 'addition', 'simple'}, ib_scale_mode='mlp', ib_addition_mode in {'add', 'none'}, "
+                "ib_mlp_layers=1, ib_num=1; got "
                 f"{m.exchange_mode}/{m.ib_scale_mode}/{m.ib_addition_mode}/{m.ib_mlp_layers}/{m.ib_num}")
+        self.default_variant = m.exchange_mode == "sea" and m.ib_addition_mode.lower() == "add"   # what training covers
         E, H, D = m.embed_dim, m.n_heads, m.down_dim
-        for hd, what in ((E // H, "self"), (D // H, "cross")):
+        for hd, what in ((E // H, "self"),) + (((D // H, "cross"),) if m.exchange_mode == "sea" else ()):
             ok = hd in (8, 16, 32, 64, 128) or (hd == 256 and act_dtype == torch.bfloat16)
             if not ok or hd * H != (E if what == "self" else D):
                 raise NotImplementedError(f"sea_amd: unsupported {what}-attention head dim {hd} (supported: 8, 16, 32, 64, 128; 256 with "
@@ -902,7 +923,8 @@ class TemporalEngine:
         self.params = FlatParams(model, device, act_dtype)
         blk = model.blocks[0]
         self.rope_self = torch.view_as_real(blk.attn["self"][0].freqs_cis.to(device)).contiguous()
-        self.rope_cross = torch.view_as_real(blk.cross_attn[0][0].freqs_cis.to(device)).contiguous()
+        self.rope_cross = torch.view_as_real(blk.cross_attn[0][0].freqs_cis.to(device)).contiguous() if m.exchange_mode == "sea" else None
+        self._eyes: Dict[int, torch.Tensor] = {}
         self._plans: Dict[Tuple, Plan] = {}
         self._graphs: Dict[Tuple, Tuple] = {}
         self._train_plans: Dict[Tuple, object] = {}
@@ -910,6 +932,13 @@ class TemporalEngine:
         self.grads_dirty = False                       # True once a backward has accumulated into it since the last zero
         self._drop_step = 0                            # dropout streams are re-keyed every training forward
         self._loss_ws: Optional[Tuple[torch.Tensor, torch.Tensor, torch.Tensor]] = None
+
+    def eye(self, n: int) -> torch.Tensor:
+        """Identity in the activation dtype: W of the GEMM that sums A segments and applies GELU ('addition' exchange)."""
+        e = self._eyes.get(n)
+        if e is None:
+            e = self._eyes[n] = torch.eye(n, device=self.device, dtype=self.act_dtype)
+        return e
 
     def plan(self, B: int, T: int, mode: str = "full") -> Plan:
         key = (B, T, mode)
@@ -951,6 +980,9 @@ class TemporalEngine:
         from .train_engine import TrainPlan
 
         m = self.model
+        if not self.default_variant:
+            raise NotImplementedError("sea_amd: training (backward) covers exchange_mode='sea' with ib_addition_mode='add'; the ablation variants "
+                                      f"run forward / rollout only (got {m.exchange_mode}/{m.ib_addition_mode})")
         thr = int(round(256 * m.dropout_p)) if (m.training and m.dropout_p > 0) else 0
         if thr > 255:
             raise ValueError("dropout probability too close to 1")

@@ -6,9 +6,10 @@ module is a drop-in for the temporal-rollout path.  Compute does not go through 
 TemporalModel.forward hands the whole forward to sea_amd.engine (≈30 fused HIP launches per layer over flat HBM buffers).
 
 Scope: exchange_mode='sea' with ib_scale_mode='mlp', ib_addition_mode='add' — what both shipped configs select
-(configs/cylinder_flow.py:112-128, configs/multiphase_flow.py:112-128).  The ablation variants ('pool', 'addition',
-'simple'; fourier/linear/concat/attention info-bottleneck modes) are valid arguments of the reference that this build
-does not accelerate: they raise NotImplementedError (invalid names raise ValueError as in the reference).
+(configs/cylinder_flow.py:112-128, configs/multiphase_flow.py:112-128) — forward, rollout and training; the ablation variants
+exchange_mode 'addition' / 'simple' and ib_addition_mode 'none' forward / rollout only.  'pool' and the
+fourier / linear / concat / attention info-bottleneck modes are valid arguments of the reference that this build does not
+accelerate: they raise NotImplementedError (invalid names raise ValueError as in the reference).
 """
 from __future__ import annotations
 
@@ -50,10 +51,10 @@ class BaseBlockTemporal(nn.Module):
         self.ib_num = ib_num
         self.add_info_after_cross = add_info_after_cross
         self.ib_scale_mode = self._validate_ib_mode(ib_scale_mode)
-        if self.ib_addition_mode != "add" or self.ib_scale_mode != "mlp":
+        if self.ib_addition_mode not in ("add", "none") or self.ib_scale_mode != "mlp":
             raise NotImplementedError(
                 f"sea_amd: ib_scale_mode={self.ib_scale_mode!r} / ib_addition_mode={self.ib_addition_mode!r} is an ablation variant "
-                "outside the accelerated path (supported: 'mlp' / 'add')")
+                "outside the accelerated path (supported: 'mlp' with 'add' or 'none')")
         self.internal_embed_dim = embed_dim
         self.ib_dim = embed_dim
         self.ib = MLP(self.ib_num, dropout, scale_ratio, self.ib_dim, self.ib_mlp_layers)
@@ -88,6 +89,8 @@ class BaseBlockTemporal(nn.Module):
         return mode
 
     def _add_info(self, x, add_info, var_idx):
+        if self.ib_addition_mode == "none":   # reference :113-114
+            return x
         return self.ib(add_info, residual=x)
 
     def _apply_exchange(self, x_vars, x_add):
@@ -162,11 +165,39 @@ class SEABlockTemporal(BaseBlockTemporal):
         return x_vars
 
 
+class AddBlockTemporal(BaseBlockTemporal):
+    """Ablation block (reference :279-301): x_i += cross_up_i(GELU(sum_j ln_cross_j(cross_down_j(x_j)))) with every field read at its
+    pre-exchange value.  Parameter container for the whole-model path (sea_amd.engine runs it as three grouped launches); the stand-alone
+    block forward is not provided."""
+
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.LN_type = kwargs['LN_type']
+        F, E, D = self.num_variables, self.internal_embed_dim, self.down_dim
+        self.cross_down = nn.ModuleList([nn.Linear(E, D) for _ in range(F)])
+        self.cross_up = nn.ModuleList([nn.Linear(D, E) for _ in range(F)])
+        self.ln_cross = nn.ModuleList([_make_norm(self.LN_type, D, self.ib_num) for _ in range(F)])
+
+    def _apply_exchange(self, x_vars, x_add):
+        raise NotImplementedError("sea_amd.AddBlockTemporal: call TemporalModel.forward (whole-model native path)")
+
+
+class SimpleBlockTemporal(BaseBlockTemporal):
+    """Ablation block without exchange (reference :304-306)."""
+
+    def _apply_exchange(self, x_vars, x_add):
+        return x_vars
+
+
 def create_block_temporal(exchange_mode, *args, **kwargs):
     if exchange_mode == 'sea':
         return SEABlockTemporal(*args, **kwargs)
-    if exchange_mode in ('addition', 'simple', 'pool'):
-        raise NotImplementedError(f"sea_amd: exchange_mode={exchange_mode!r} is an ablation variant outside the accelerated path")
+    if exchange_mode == 'addition':
+        return AddBlockTemporal(*args, **kwargs)
+    if exchange_mode == 'simple':
+        return SimpleBlockTemporal(*args, **kwargs)
+    if exchange_mode == 'pool':
+        raise NotImplementedError("sea_amd: exchange_mode='pool' is an ablation variant outside the accelerated path")
     raise ValueError(f"Invalid exchange_mode: {exchange_mode}")
 
 

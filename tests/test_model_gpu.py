@@ -23,7 +23,7 @@ def build(cfg, dtype="fp32"):
     from sea_amd.models.temporal import TemporalModel
 
     m = TemporalModel(cfg.num_layers, cfg.embed_dim, cfg.n_heads, cfg.max_len, cfg.scale_ratio, cfg.src_len, cfg.num_variables,
-                      cfg.down_proj, 0.0, "sea", "learnable", "mlp", "add", 1, 1, cfg.add_info_after_cross, cfg.LN_type)
+                      cfg.down_proj, 0.0, cfg.exchange_mode, "learnable", "mlp", cfg.ib_addition_mode, 1, 1, cfg.add_info_after_cross, cfg.LN_type)
     p = recipe_params(cfg)
     with torch.no_grad():
         for k, prm in m.named_parameters():
@@ -37,7 +37,32 @@ def gpu(a):
 
 
 MODEL_CASES = ["model_tiny_adaln_f3", "model_tiny_ln_f2", "model_tiny_adaln_f2_pre", "model_small_srclen2",
-               "model_small_adaln_f3_T1", "model_small_adaln_f3_T7", "model_small_adaln_f3_T16", "model_small_adaln_f3_T65"]
+               "model_small_adaln_f3_T1", "model_small_adaln_f3_T7", "model_small_adaln_f3_T16", "model_small_adaln_f3_T65",
+               # ablation variants: exchange_mode 'addition' / 'simple', ib_addition_mode 'none'
+               "model_addition_adaln_f3", "model_addition_ln_f2_pre", "model_simple_adaln_f3", "model_sea_noib_adaln_f2"]
+
+
+@pytest.mark.parametrize("xmode,ibmode", [("addition", "add"), ("simple", "add"), ("sea", "none")])
+def test_ablation_variants_rollout_bf16_and_training_refused(xmode, ibmode):
+    """The ablation variants through the same plan machinery: bf16 forward within the stated tolerance of the fp32 oracle, KV-cache rollout
+    equal to the recompute rollout, and a loud refusal of the backward (training covers 'sea' / 'add' only)."""
+    from sea_amd.utils.train_utils import rollout
+
+    cfg = O.OracleConfig(2, 128, 4, 96, 8, 0, 3, 2, True, "adaln", xmode, ibmode)
+    x, _, ib = recipe_inputs(2, 40, cfg, seed=11)
+    ref = O.model_forward(x, ib, recipe_params(cfg), cfg)
+    m = build(cfg, "bf16")
+    with torch.no_grad():
+        out = m(x.cuda(), ib.cuda())
+    assert rel_l2(out.cpu().numpy(), ref.numpy()) < BF16_TOL
+    m32 = build(cfg, "fp32")
+    a = rollout(m32, x[:, :1].cuda(), ib.cuda(), 12, mode="recompute")
+    b = rollout(m32, x[:, :1].cuda(), ib.cuda(), 12, mode="kv")
+    assert rel_l2(b.cpu().numpy(), a.cpu().numpy()) < 1e-5
+    assert rel_l2(a.cpu().numpy(), O.rollout(x[:, :1], ib, 12, recipe_params(cfg), cfg).numpy()) < FP32_TOL
+    m32.train()
+    with pytest.raises(NotImplementedError, match="training"):
+        m32(x.cuda(), ib.cuda())
 
 
 @pytest.mark.parametrize("name", MODEL_CASES)
