@@ -168,12 +168,15 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-graph", action="store_true", help="replay launch by launch instead of the captured HIP graph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--mode", default="rollout", choices=["rollout", "train", "kv", "decode"],
+    ap.add_argument("--mode", default="rollout", choices=["rollout", "train", "kv", "decode", "encode"],
                     help="rollout: full-context forward step (cfg2, the default metric); train: fwd+bwd+AdamW step (cfg3/cfg4, --batch 8); "
-                         "kv: KV-cache rollout of --seq steps; decode: spatial decoder over a --seq-step rollout (SURVEY.md §8f rank 1)")
+                         "kv: KV-cache rollout of --seq steps; decode: spatial decoder over a --seq-step rollout (SURVEY.md §8f rank 1); "
+                         "encode: spatial encoder over --seq snapshots (SURVEY.md §8f rank 2)")
     args = ap.parse_args()
     if args.mode == "decode":
         return main_decode(args)
+    if args.mode == "encode":
+        return main_encode(args)
     if args.mode != "rollout":
         return main_other(args)
 
@@ -475,6 +478,67 @@ def main_decode(args):
             "unpatchify": {"ms": u_ms, "algorithmic_GB": u_bytes / 1e9, "achieved_GBps": u_bytes / (u_ms * 1e-3) / 1e9, "frac_of_hbm_peak": u_bytes / (u_ms * 1e-3) / 1e9 / 8000.0},
             "roofline": {"kernel": "decode.layer2 (gemm_grouped)", "bound": "hbm", "achieved": alg_bytes / (k_ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
                          "frac": alg_bytes / (k_ms * 1e-3) / 1e9 / 8000.0, "traffic": None, "launch_ms": k_ms, "launch_gflop": flops / 1e9,
+                         "mfma_tflops": flops / (k_ms * 1e-3) / 1e12}}
+    print(json.dumps(line))
+
+
+def main_encode(args):
+    """--mode encode: ProcessData.process_data (reference utils/data_processors.py:335-352) at the shipped cylinder spatial dims: 64 patches,
+    groups [[0,1],[2]], spatial embed 16 (width 32, 8 heads), hidden 480, 12 EncoderBlocks; the padded cell size is data-dependent in the
+    reference, 512 mesh points here.  One step = encoding --batch x --seq snapshots that are resident in HBM as [snapshots, P, F, C] fp32."""
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no GPU visible (the product path has no CPU fallback)")
+    from sea_amd import ops
+    from sea_amd.models.encoder_decoder import PointwiseEncode
+
+    dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+    torch.cuda.set_device(dev)
+    groups, hidden, D, P, H, layers, n_inp = [[0, 1], [2]], 480, 16, 64, 8, 12, 512
+    n_snap = args.batch * args.seq
+    torch.manual_seed(42)
+    enc = PointwiseEncode(groups, n_inp, hidden, layers, D, H, 2024, 0, dropout=0.0).set_compute_dtype(args.dtype).to(dev).eval()
+    x = torch.randn(n_snap, P, 3, n_inp, generator=torch.Generator().manual_seed(1234)).to(dev)
+    with torch.no_grad():
+        for _ in range(max(args.warmup, 1)):
+            z = enc(x)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            z = enc(x)
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        # the dominant launch: the down-scale MLPs' first Linear + GELU ([M, |g| C] x [480, |g| C], both groups), HIP events on the launch stream
+        dt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+        pk = enc._packed(dt, dev)
+        Bc = min(enc.CHUNK, n_snap)
+        ws = enc._workspace(pk, Bc, P, dt, dev)
+        gl = [dict(A=A, W=g["W1"], Cact=hid, act=1) for g, A, hid in zip(pk["enc"], ws["A"], ws["hid"])]
+        ops.gemm_grouped(gl, dt)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            ops.gemm_grouped(gl, dt)
+        e1.record()
+        torch.cuda.synchronize()
+        k_ms = e0.elapsed_time(e1) / 5
+    assert torch.isfinite(z).all()
+    esz = 2 if args.dtype == "bf16" else 4
+    M = Bc * P
+    Ksum = sum(g["Kp"] for g in pk["enc"])
+    alg_bytes = M * Ksum * esz + hidden * Ksum * esz + len(groups) * M * hidden * esz    # read the cell values once + weights, write the hidden rows once
+    flops = 2 * M * hidden * Ksum
+    W = len(groups) * D
+    # algorithmic FLOPs of one snapshot: down-scale MLPs + 12 blocks (q/k/v, scores + values over P x P, projection, MLP x4)
+    per_snap = 2 * P * (hidden * 3 * n_inp + len(groups) * hidden * D) + layers * (2 * P * W * 3 * W + 4 * P * P * W + 2 * P * W * W + 2 * 2 * P * W * 4 * W)
+    ms = elapsed / args.steps * 1e3
+    line = {"metric": "encoded snapshots/sec (spatial encoder inference)", "value": n_snap * args.steps / elapsed, "unit": "snapshots/s",
+            "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"encode leg of the data preparation: {n_snap} snapshots, 64 patches x {n_inp} padded mesh points x 3 fields, spatial embed 16 "
+                                   f"(width {W}, {H} heads), hidden {hidden}, {layers} encoder blocks, chunks of {enc.CHUNK} snapshots"},
+            "model_algorithmic_gflop_per_step": per_snap * n_snap / 1e9, "input_GB": x.numel() * 4 / 1e9, "input_GBps": x.numel() * 4 / (ms * 1e-3) / 1e9,
+            "roofline": {"kernel": "encode.layer1 (gemm_grouped, GELU epilogue; one chunk)", "bound": "hbm", "achieved": alg_bytes / (k_ms * 1e-3) / 1e9, "peak": 8000.0,
+                         "unit": "GB/s", "frac": alg_bytes / (k_ms * 1e-3) / 1e9 / 8000.0, "traffic": None, "launch_ms": k_ms, "launch_gflop": flops / 1e9,
                          "mfma_tflops": flops / (k_ms * 1e-3) / 1e12}}
     print(json.dumps(line))
 

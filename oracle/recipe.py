@@ -138,3 +138,33 @@ def decode_schema(field_groups, n_inp: int, mlp_hidden: int, embed_dim: int, pre
 
 def decode_params(field_groups, n_inp: int, mlp_hidden: int, embed_dim: int, dtype=torch.float32):
     return {k: torch.from_numpy(recipe_tensor(k, shp, kind)).to(dtype) for k, (shp, kind) in decode_schema(field_groups, n_inp, mlp_hidden, embed_dim).items()}
+
+
+def encoder_schema(field_groups, n_inp: int, mlp_hidden: int, num_layers: int, embed_dim: int, pre: str = ""):
+    """Parameter names / shapes / kinds of the reference's PointwiseEncode (models/encoder_decoder.py:75-101), in named_parameters order:
+    blocks (EncoderBlock: two weight-only LayerNorms, MultiHeadAttention k/q/v + bias-free projection, MLP x4), the final nn.LayerNorm,
+    then the per-group downScaleMLPs (created after the blocks)."""
+    W = len(field_groups) * embed_dim
+    sch = OrderedDict()
+    for l in range(num_layers):
+        b = f"{pre}blocks.{l}."
+        sch[b + "ln_exp1_1.weight"] = ((W,), "norm_w")
+        sch[b + "ln_exp1_2.weight"] = ((W,), "norm_w")
+        _attention(sch, b + "attn_1.", W)
+        _linear(sch, b + "mlp_1.layers.0.", 4 * W, W)
+        sch[b + "mlp_1.layers.1.weight"] = ((4 * W,), "norm_w")
+        sch[b + "mlp_1.layers.1.bias"] = ((4 * W,), "norm_b")
+        _linear(sch, b + "mlp_1.layers.3.", W, 4 * W)
+    sch[pre + "ln.weight"] = ((W,), "norm_w")
+    sch[pre + "ln.bias"] = ((W,), "norm_b")
+    for i, group in enumerate(field_groups):
+        sch[f"{pre}encoders.{i}.layer1.weight"] = ((mlp_hidden, n_inp * len(group)), "lin_w")
+        sch[f"{pre}encoders.{i}.layer2.weight"] = ((embed_dim, mlp_hidden), "lin_w")
+        sch[f"{pre}encoders.{i}.layer2.bias"] = ((embed_dim,), "lin_b")
+    return sch
+
+
+def encoder_params(field_groups, n_inp: int, mlp_hidden: int, num_layers: int, embed_dim: int, dtype=torch.float32):
+    return {k: torch.from_numpy(recipe_tensor(k, shp, kind)).to(dtype)
+            for k, (shp, kind) in encoder_schema(field_groups, n_inp, mlp_hidden, num_layers, embed_dim).items()}
+

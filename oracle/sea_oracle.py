@@ -373,3 +373,52 @@ def unpatchify(scaled_fields: torch.Tensor, index_map: torch.Tensor, n_points: i
             res[..., list(group)] = std * (hi - lo) + lo
         out = res
     return out
+
+
+# ---------------------------------------------------------------------------------------------------- spatial encoder
+def sinusoidal_pe(length: int, d_model: int, dtype=torch.float32) -> torch.Tensor:
+    """PositionalEncoding's buffer (models/base_blocks.py:355-368), formed in fp32 as the reference does: even columns sin, odd cos."""
+    pe = torch.zeros(length, d_model)
+    position = torch.arange(0, length, dtype=torch.float).unsqueeze(1)
+    div_term = torch.exp(torch.arange(0, d_model, 2).float() * (-math.log(10000.0) / d_model))
+    pe[:, 0::2] = torch.sin(position * div_term)
+    pe[:, 1::2] = torch.cos(position * div_term[: d_model // 2])
+    return pe.to(dtype)
+
+
+def full_attention(x: torch.Tensor, p: Params, pre: str, n_heads: int) -> torch.Tensor:
+    """MultiHeadAttention.forward (models/base_blocks.py:105-121): no mask, no rotary embedding, projection without bias."""
+    B, T, C = x.shape
+    hd = C // n_heads
+    q = linear(x, p[pre + "q.weight"], p[pre + "q.bias"]).view(B, T, n_heads, hd).transpose(1, 2)
+    k = linear(x, p[pre + "k.weight"], p[pre + "k.bias"]).view(B, T, n_heads, hd).transpose(1, 2)
+    v = linear(x, p[pre + "v.weight"], p[pre + "v.bias"]).view(B, T, n_heads, hd).transpose(1, 2)
+    att = (q @ k.transpose(-2, -1)) * hd ** -0.5
+    att = att - att.max(dim=-1, keepdim=True).values
+    e = torch.exp(att)
+    att = e / e.sum(dim=-1, keepdim=True)
+    out = (att @ v).transpose(1, 2).reshape(B, T, C)
+    return linear(out, p[pre + "projection.weight"])
+
+
+def encode(x: torch.Tensor, p: Params, field_groups: Sequence[Sequence[int]], n_heads: int, num_layers: int, pre: str = "") -> torch.Tensor:
+    """PointwiseEncode.forward (models/encoder_decoder.py:103-123) in eval mode: per-group downScaleMLP (models/base_blocks.py:65-78; layer1
+    without bias, GELU, layer2), groups concatenated along the feature axis, sinusoidal positions over the P patch tokens, num_layers
+    EncoderBlocks (models/base_blocks.py:123-139: x += MHA(LN(x)); x += MLP_{x4}(LN(x)), both LayerNorms weight-only), nn.LayerNorm.
+    x: [B, P, F, C] -> [B, P, n_groups, embed_dim]."""
+    B, P, F, C = x.shape
+    zs = []
+    for i, group in enumerate(field_groups):
+        xg = x[:, :, list(group), :].reshape(B, P, -1)
+        h = gelu_erf(linear(xg, p[f"{pre}encoders.{i}.layer1.weight"]))
+        zs.append(linear(h, p[f"{pre}encoders.{i}.layer2.weight"], p[f"{pre}encoders.{i}.layer2.bias"]))
+    z = torch.cat(zs, dim=-1)
+    W = z.shape[-1]
+    z = z + sinusoidal_pe(P, W, z.dtype)[None]
+    for l in range(num_layers):
+        b = f"{pre}blocks.{l}."
+        z = z + full_attention(layer_norm(z, p[b + "ln_exp1_1.weight"], None), p, b + "attn_1.", n_heads)
+        z = z + mlp(layer_norm(z, p[b + "ln_exp1_2.weight"], None), p, b + "mlp_1.")
+    z = layer_norm(z, p[pre + "ln.weight"], p[pre + "ln.bias"])
+    return z.reshape(B, P, len(field_groups), -1)
+

@@ -235,3 +235,51 @@ class PositionalEncoding(nn.Module):
         pe[:, 0::2] = torch.sin(pos * div)
         pe[:, 1::2] = torch.cos(pos * div[: d_model // 2])
         self.register_buffer("pe", pe.unsqueeze(0))
+
+
+# ---------------------------------------------------------------------------------------------- spatial-encoder layers
+class downScaleMLP(nn.Module):  # noqa: N801  (reference name, models/base_blocks.py:65-78)
+    """Linear(d_input, hidden, bias=False) -> GELU -> Linear(hidden, d_model).  Parameter container: PointwiseEncode.forward runs all
+    groups as grouped native launches."""
+
+    def __init__(self, d_input, d_model, hidden_dim):
+        super().__init__()
+        self.d_model, self.d_input = d_model, d_input
+        self.layer1 = nn.Linear(d_input, hidden_dim, bias=False)
+        self.activation = nn.GELU()
+        self.layer2 = nn.Linear(hidden_dim, d_model)
+
+    def forward(self, x):
+        raise RuntimeError("sea_amd.downScaleMLP is a parameter container; call PointwiseEncode.forward (grouped native launch)")
+
+
+class MultiHeadAttention(nn.Module):
+    """Un-masked multi-head self-attention of the spatial encoder (reference models/base_blocks.py:91-121): k, q, v Linear with bias (in
+    that registration order), bias-free projection, no rotary embedding.  Parameter container for PointwiseEncode.forward."""
+
+    def __init__(self, n_heads, embed_dim, dropout):
+        super().__init__()
+        self.n_heads, self.head_dim, self.embed_dim = n_heads, embed_dim // n_heads, embed_dim
+        self.dropout = nn.Dropout(dropout)
+        self.k = nn.Linear(embed_dim, self.head_dim * n_heads)
+        self.q = nn.Linear(embed_dim, self.head_dim * n_heads)
+        self.v = nn.Linear(embed_dim, self.head_dim * n_heads)
+        self.projection = nn.Linear(embed_dim, embed_dim, bias=False)
+
+    def forward(self, x):
+        raise RuntimeError("sea_amd.MultiHeadAttention is a parameter container; call PointwiseEncode.forward")
+
+
+class EncoderBlock(nn.Module):
+    """x += MHA(LN(x)); x += MLP_x4(LN(x)) with weight-only LayerNorms (reference models/base_blocks.py:123-139).  Parameter container."""
+
+    def __init__(self, n_heads, max_len, embed_dim, src_len, dropout):
+        super().__init__()
+        self.ln_exp1_1 = LayerNorm(embed_dim, bias=False)
+        self.ln_exp1_2 = LayerNorm(embed_dim, bias=False)
+        self.attn_1 = MultiHeadAttention(n_heads, embed_dim, dropout)
+        self.mlp_1 = MLP(embed_dim, dropout)
+
+    def forward(self, x):
+        raise RuntimeError("sea_amd.EncoderBlock is a parameter container; call PointwiseEncode.forward")
+

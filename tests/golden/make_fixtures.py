@@ -21,13 +21,14 @@ sys.path.insert(0, REF)
 import numpy as np
 import torch
 
-from oracle.recipe import decode_schema, param_schema, recipe_inputs, recipe_tensor
+from oracle.recipe import decode_schema, encoder_schema, param_schema, recipe_inputs, recipe_tensor
 from oracle.sea_oracle import OracleConfig
 
 from models.temporal import TemporalModel  # reference
 from models import base_blocks as ref_bb  # reference
 from utils import train_utils as ref_tu  # reference
 from models.encoder_decoder import Decode as RefDecode  # reference
+from models.encoder_decoder import PointwiseEncode as RefEncode  # reference
 from utils import data_processors as ref_dp  # reference
 
 torch.set_num_threads(8)
@@ -245,6 +246,36 @@ def decode_cases():
         save(name, groups=np.array([len(g) for g in groups]), dims=np.array([n_inp, hidden, D, P, tr, T]), roll=n(roll), z=n(z), out=n(out))
 
 
+def encode_cases():
+    """PointwiseEncode (models/encoder_decoder.py:75-123) in eval mode on padded patch tensors [B, P, F, C]: a cylinder-like case whose
+    attention head dim is 4 (width 2 x 16, 8 heads — the shipped spatial dims) and a three-group case with head dim 8."""
+    for name, groups, n_inp, hidden, layers, D, H, P, B in (("encode_cyl_small", [[0, 1], [2]], 12, 48, 2, 16, 8, 9, 3),
+                                                           ("encode_three_groups", [[0], [1, 2, 3], [4, 5]], 8, 64, 3, 16, 6, 10, 2)):
+        print(name)
+        enc = RefEncode(groups, n_inp, hidden, layers, D, H, 64, 0, dropout=0.0).eval()
+        sch = encoder_schema(groups, n_inp, hidden, layers, D)
+        named = dict(enc.named_parameters())
+        assert list(named.keys()) == list(sch.keys()), (list(named.keys()), list(sch.keys()))
+        with torch.no_grad():
+            for k, prm in named.items():
+                shp, kind = sch[k]
+                assert tuple(prm.shape) == tuple(shp), (k, prm.shape, shp)
+                prm.copy_(torch.from_numpy(recipe_tensor(k, shp, kind)))
+        rng = np.random.Generator(np.random.PCG64(zlib_seed(name)))
+        Fn = sum(len(g) for g in groups)
+        x = torch.from_numpy(rng.standard_normal((B, P, Fn, n_inp)).astype(np.float32))
+        x[:, :, :, -2:] = 0.0     # padded slots of a cell (pad_field_value = 0, configs/cylinder_flow.py:23)
+        with torch.no_grad():
+            z = enc(x)
+        save(name, dims=np.array([n_inp, hidden, layers, D, H, P, B], dtype=np.int64), groups=np.array([len(g) for g in groups], dtype=np.int64),
+             x=n(x), z=n(z), pe=n(enc.spatial_pos_encoder.pe[0, :P]))
+
+
+def zlib_seed(name):
+    import zlib
+    return zlib.crc32(name.encode())
+
+
 def unpatch_cases():
     """DataPartitioner2D.create_partitions / inverse_partition and MinMaxScaler.inverse_transform of the reference on a random 2-D point
     cloud (ragged cells, one empty-ish corner), as chained by MeshProcessor.inverse_scale_and_unpatch (utils/data_processors.py:553-573)."""
@@ -322,6 +353,7 @@ def main():
         "modules": module_cases,
         "exchange": exchange_cases,
         "decode": decode_cases,
+        "encode": encode_cases,
         "unpatch": unpatch_cases,
     }
     # ablation variants of the exchange / info-bottleneck: forward only

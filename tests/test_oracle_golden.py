@@ -5,7 +5,7 @@ import pytest
 import torch
 
 from oracle import sea_oracle as O
-from oracle.recipe import param_schema, recipe_params, recipe_tensor
+from oracle.recipe import encoder_params, param_schema, recipe_params, recipe_tensor
 from tests.conftest import cfg_from_meta, load_golden, rel_l2
 
 TOL = 2e-6  # fp32 accumulation-order noise between two CPU restatements
@@ -220,3 +220,20 @@ def test_unpatchify_matches_reference(name):
     assert torch.equal(O.unpatchify(stacked, imap, n_points), torch.from_numpy(g["fields"]))   # pure scatter: exact
     out = O.unpatchify(stacked, imap, n_points, groups, [tuple(r) for r in g["scaler_params"]])
     assert rel_l2(out.numpy(), g["unscaled"]) < 1e-6
+
+
+@pytest.mark.parametrize("name", ["encode_cyl_small", "encode_three_groups"])
+def test_encode_matches_reference(name):
+    """Spatial encoder: oracle.encode against PointwiseEncode run by the reference; the sinusoidal position table too."""
+    g = load_golden(name)
+    n_inp, hidden, layers, D, H, P, B = (int(v) for v in g["dims"])
+    groups, k = [], 0
+    for sz in g["groups"]:
+        groups.append(list(range(k, k + int(sz))))
+        k += int(sz)
+    p = encoder_params(groups, n_inp, hidden, layers, D)
+    z = O.encode(T(g["x"]), p, groups, H, layers)
+    assert z.shape == g["z"].shape
+    assert rel_l2(z, g["z"]) < TOL
+    assert np.array_equal(O.sinusoidal_pe(P, len(groups) * D).numpy(), g["pe"])
+
