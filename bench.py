@@ -64,6 +64,9 @@ def kernel_flops(name, B, T, F, E, H, D, S):
         "self.attention": F * 4 * B * tri * E,
         "self.out_proj": F * 2 * M * E * E,
         "cross.down_old": F * 2 * M * E * D,
+        "cross.down_norm_old": F * 2 * M * E * D,
+        "add.down_norm": F * 2 * M * E * D,
+        "add.up": F * 2 * M * E * D,
         "mlp.fc1": F * 2 * M * E * S,
         "mlp.fc2": F * 2 * M * E * S,
         "proj": F * 2 * M * E * E,
@@ -92,8 +95,10 @@ def kernel_flops(name, B, T, F, E, H, D, S):
         return (F - 1) * 2 * M * D * D
     if name.startswith("cross") and name.endswith("up_sum"):
         return (F - 1) * 2 * M * D * E
-    if name.startswith("cross") and name.endswith("down_new"):
+    if name.startswith("cross") and (name.endswith("down_new") or name.endswith("down_norm_new")):
         return 2 * M * E * D
+    if name.startswith("cross") and name.endswith("up_sum_ib_adaln2"):
+        return (F - 1) * 2 * M * D * E
     return 0
 
 
