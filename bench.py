@@ -97,6 +97,9 @@ def kernel_flops(name, B, T, F, E, H, D, S):
         return (F - 1) * 2 * M * D * E
     if name.startswith("cross") and (name.endswith("down_new") or name.endswith("down_norm_new")):
         return 2 * M * E * D
+    if name.startswith("cross") and name.endswith(".tail"):
+        i = int(name[5:name.index(".")])
+        return (F - 1) * (2 * M * D * D + 2 * M * D * E) + (2 * M * E * D if i < F - 1 else 0)
     if name.startswith("cross") and name.endswith("up_sum_ib_adaln2"):
         return (F - 1) * 2 * M * D * E
     return 0

@@ -41,7 +41,7 @@ enum {
 int sea_abi_version(void);
 const char* sea_last_error(void);
 /* sizeof of every ABI struct in declaration order (SeaGemmGroup, SeaQkvGroup, SeaQkvCommon, SeaAttnProblem,
- * SeaAttnParams, SeaNormGroup, SeaSiluGroup, SeaIbParams, ..., SeaGemmNormGroup last): lets a binding verify its layout.  Host only. */
+ * SeaAttnParams, SeaNormGroup, SeaSiluGroup, SeaIbParams, ..., SeaGemmNormGroup, SeaExchangeTail last): lets a binding verify its layout.  Host only. */
 int sea_struct_sizes(int* out, int cap);
 /* Number of compute units / name of device 0's architecture as HIP reports them (diagnostics for bench.py). */
 int sea_device_info(int* cu_count, char* arch, int arch_len);
@@ -230,6 +230,36 @@ typedef struct {
 } SeaGemmNormGroup;
 
 int sea_gemm_rownorm(const SeaGemmNormGroup* groups, int n_groups, float eps, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Tail of one field's state-exchange stage in ONE launch (bf16 compute; a workgroup owns 16 rows through all three Linear layers):
+ *     g_s   = gelu_erf(att_s[M,D] . Wp_s[D,D]^T)                      s < n_seg      (cross_attn[i][j].projection + GELU, models/temporal.py:183,185)
+ *     x     = X + sum_s g_s . Wup[E,D]^T + bias_scale * bup            X updated in place; Xact <- (act dtype) x when non-NULL
+ *                                                                      (cross_up[i], the sum over j and the residual, models/temporal.py:185,189-191)
+ *     y     = LayerNorm_D(x . Wdown[D,E]^T + bdown) with gamma / beta / mod as SeaNormGroup;  down.Yact / down.Y32 <- y      when has_down
+ *                                                                      (cross_down[i] + ln_cross[i] of the UPDATED field: what later fields attend to)
+ * The weights of the middle layer go L2 -> LDS in one global_load_lds burst while the first layer runs from registers; the intermediates
+ * (g, the new x) never leave the CU.  Replaces three launches (sea_gemm_grouped x 2, sea_gemm_rownorm) on the serial Gauss-Seidel chain.
+ * `down`: W, ldw, bias, gamma, beta, mod, ldmod, Yact / Y32 (+ strides), mean, rstd are read; its A, M, N, K and extensions are ignored.
+ * Requirements: dtype SEA_BF16; (D, E) in {(128, 256), (64, 128)}; n_seg * D <= 256; all row strides multiples of 8 (act) / 4 (f32);
+ * pointers 16-byte aligned.  Returns SEA_EUNSUPPORTED for other shapes / dtypes (callers keep the three-launch form).
+ */
+#define SEA_XTAIL_MAX_SEG 4
+typedef struct {
+    const void* att[SEA_XTAIL_MAX_SEG];   /* act [M, D], row stride ldatt */
+    const void* Wp[SEA_XTAIL_MAX_SEG];    /* act [D, D], row stride ldwp */
+    const void* Wup;                      /* act [E, D], row stride ldwup */
+    const float* bup;                     /* f32 [E] or NULL */
+    float* X;                             /* f32 [M, E], row stride ldx: residual stream, updated in place */
+    void* Xact;                           /* act [M, E], row stride ldxact, or NULL */
+    int32_t n_seg, ldatt, ldwp, ldwup, ldx, ldxact;
+    int32_t M, D, E, has_down;
+    float bias_scale;
+    int32_t pad_;
+    SeaGemmNormGroup down;
+} SeaExchangeTail;
+
+int sea_exchange_tail(const SeaExchangeTail* params, float eps, int dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Hidden layer of the AdaLN condition MLP for a scalar condition: Hid[m, k] = silu(w1[k] * c[m] + b1[k]).
@@ -507,10 +537,10 @@ int sea_rowchain(const SeaChainLaunch* launch, const SeaChainStage* host_stages,
  *     SEA_OP_ATTN   p0 = SeaAttnParams                            SEA_OP_NORM   p0 = SeaNormGroup[n], i0 = M, i1 = d, i2 = x_is_act, i3 = gelu, f0 = eps
  *     SEA_OP_SILU   p0 = SeaSiluGroup[n], p1 = c, i0 = M          SEA_OP_IB     p0 = SeaIbParams
  *     SEA_OP_CHAIN  p0 = SeaChainLaunch, p1 = host stage table    SEA_OP_CONVERT p0 = src, p1 = dst, l0 = lds, l1 = ldd, l2 = rows, l3 = cols
- *     SEA_OP_GEMM_NORM p0 = SeaGemmNormGroup[n], f0 = eps
+ *     SEA_OP_GEMM_NORM p0 = SeaGemmNormGroup[n], f0 = eps          SEA_OP_XTAIL  p0 = SeaExchangeTail, f0 = eps
  * Returns 0, or the failing entry's error code with sea_last_error() set (entries before it have been launched).
  */
-enum { SEA_OP_GEMM = 1, SEA_OP_QKV = 2, SEA_OP_ATTN = 3, SEA_OP_NORM = 4, SEA_OP_SILU = 5, SEA_OP_IB = 6, SEA_OP_CHAIN = 7, SEA_OP_CONVERT = 8, SEA_OP_GEMM_NORM = 9 };
+enum { SEA_OP_GEMM = 1, SEA_OP_QKV = 2, SEA_OP_ATTN = 3, SEA_OP_NORM = 4, SEA_OP_SILU = 5, SEA_OP_IB = 6, SEA_OP_CHAIN = 7, SEA_OP_CONVERT = 8, SEA_OP_GEMM_NORM = 9, SEA_OP_XTAIL = 10 };
 typedef struct {
     int32_t op, n, dtype, i0, i1, i2, i3;
     float f0;

@@ -131,7 +131,7 @@ class SeaChainLaunch(C.Structure):
 
 
 
-OP_GEMM, OP_QKV, OP_ATTN, OP_NORM, OP_SILU, OP_IB, OP_CHAIN, OP_CONVERT, OP_GEMM_NORM = 1, 2, 3, 4, 5, 6, 7, 8, 9
+OP_GEMM, OP_QKV, OP_ATTN, OP_NORM, OP_SILU, OP_IB, OP_CHAIN, OP_CONVERT, OP_GEMM_NORM, OP_XTAIL = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10
 
 
 class SeaLaunchRec(C.Structure):
@@ -149,6 +149,16 @@ class SeaGemmNormGroup(C.Structure):
                 ("n_seg", _i32), ("a_seg_stride", _i64), ("bias_scale", _f32), ("ldcact", _i32), ("Cact", _vp),
                 ("ib_c", _vp), ("ib_w1", _vp), ("ib_b1", _vp), ("ib_lnw", _vp), ("ib_lnb", _vp), ("ib_w2", _vp), ("ib_b2", _vp),
                 ("ib_h", _i32), ("pad_", _i32)]
+
+
+XTAIL_MAX_SEG = 4
+
+
+class SeaExchangeTail(C.Structure):
+    _fields_ = [("att", _vp * XTAIL_MAX_SEG), ("Wp", _vp * XTAIL_MAX_SEG), ("Wup", _vp), ("bup", _vp), ("X", _vp), ("Xact", _vp),
+                ("n_seg", _i32), ("ldatt", _i32), ("ldwp", _i32), ("ldwup", _i32), ("ldx", _i32), ("ldxact", _i32),
+                ("M", _i32), ("D", _i32), ("E", _i32), ("has_down", _i32), ("bias_scale", _f32), ("pad_", _i32),
+                ("down", SeaGemmNormGroup)]
 
 
 MAX_WGRAD_GROUPS = 16
@@ -202,6 +212,8 @@ def lib() -> C.CDLL:
     L.sea_unpatchify.restype = C.c_int
     L.sea_gemm_rownorm.argtypes = [C.POINTER(SeaGemmNormGroup), C.c_int, C.c_float, C.c_int, _vp]
     L.sea_gemm_rownorm.restype = C.c_int
+    L.sea_exchange_tail.argtypes = [C.POINTER(SeaExchangeTail), C.c_float, C.c_int, _vp]
+    L.sea_exchange_tail.restype = C.c_int
     L.sea_run_list.argtypes = [C.POINTER(SeaLaunchRec), C.c_int, _vp]
     L.sea_run_list.restype = C.c_int
     for name in ("sea_attention_bwd", "sea_wgrad_grouped", "sea_transpose_weights", "sea_rownorm_bwd", "sea_silu_outer_bwd", "sea_ib_bwd"):
@@ -222,14 +234,14 @@ def lib() -> C.CDLL:
 
 ABI_STRUCTS = (SeaGemmGroup, SeaQkvGroup, SeaQkvCommon, SeaAttnProblem, SeaAttnParams, SeaNormGroup, SeaSiluGroup,
                SeaIbParams, SeaWgradGroup, SeaNormBwdGroup, SeaSiluBwdGroup, SeaIbBwdParams, SeaAttnBwdProblem, SeaAttnBwdParams,
-               SeaDropout, SeaChainStage, SeaChainLaunch, SeaLaunchRec, SeaGemmNormGroup)
+               SeaDropout, SeaChainStage, SeaChainLaunch, SeaLaunchRec, SeaGemmNormGroup, SeaExchangeTail)
 
 EXPORTED_SYMBOLS = (
     "sea_abi_version", "sea_last_error", "sea_struct_sizes", "sea_device_info", "sea_gemm_grouped", "sea_qkv_rope_grouped",
     "sea_attention_fwd", "sea_rownorm", "sea_silu_outer", "sea_ib_add", "sea_convert_f32_to_act", "sea_selftest_mfma",
     "sea_mse_fwd_bwd", "sea_relative_mse", "sea_adamw_flat",
     "sea_wgrad_grouped", "sea_transpose_weights", "sea_rownorm_bwd", "sea_silu_outer_bwd", "sea_ib_bwd",
-    "sea_attention_bwd", "sea_dropout_mask", "sea_rowchain", "sea_run_list", "sea_unpatchify", "sea_gemm_rownorm",
+    "sea_attention_bwd", "sea_dropout_mask", "sea_rowchain", "sea_run_list", "sea_unpatchify", "sea_gemm_rownorm", "sea_exchange_tail",
 )
 
 

@@ -383,6 +383,152 @@ __global__ __launch_bounds__(256) void gemm_rownorm16_kernel(const GemmNormLaunc
     epi.finish(G, acc, m, wave * WTN, r, g, wave, L.eps, reinterpret_cast<float*>(smem));
 }
 
+// ---------------------------------------------------------------------------------------------- exchange tail (three Linear layers, 16 rows)
+// One field's exchange stage after its cross-attention launch, sea_exchange_tail (include/sea_hip.h):
+//   stage 1  g_s = gelu(att_s . Wp_s^T)         both operands straight from L2 into MFMA fragments (2 x 32 KiB of weights: no LDS staging), result
+//                                               packed to bf16 into the A rows of the stage-2 K-tiles in LDS
+//   stage 2  x += sum_s g_s . Wup^T + S bup     Wup (E x S*D bf16 = 128 KiB at cfg2) arrives by ONE global_load_lds burst issued before stage 1;
+//                                               x (fp32) updated in place, its bf16 copy goes to LDS as the A tile of stage 3
+//   stage 3  y = AdaLN(x . Wdown^T + bdown)     Wdown fragments requested from L2 before stage 2 runs, rows normalised by NormEpilogue
+// A workgroup = 4 waves owns 16 rows; wave w owns the column quarter w of every stage's output.  LDS: nk (16 + E) 128 B + 16 E 2 B + 512 B.
+struct XTailLaunch {
+    SeaExchangeTail p;
+    float eps;
+};
+
+template <int D, int E>
+__global__ __launch_bounds__(256) void exchange_tail_kernel(const XTailLaunch L) {
+    using T = __bf16;
+    constexpr int BM = 16, BKB = 128, BK = 64;
+    constexpr int ROWS = BM + E, STAGE = ROWS * BKB;
+    constexpr int SMAX = 256 / D;                   // segments whose K-tiles fit 4 stages
+    constexpr int NI1 = D / 64, KS1 = D / 32;       // stage 1: 16-column blocks per wave, 32-wide contraction steps
+    constexpr int NI2 = E / 64;
+    constexpr int NI3 = D / 64, KS3 = E / 32;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const SeaExchangeTail& P = L.p;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 15, g = lane >> 4;
+    const int m0 = blockIdx.x * BM, M = P.M, S = P.n_seg;
+    const int nk = S * D / BK;
+    char* x3 = smem + nk * STAGE;                                   // bf16 [16, E] A tile of stage 3, K-tile layout with 16 rows per tile
+    float* red = reinterpret_cast<float*>(x3 + BM * E * 2);
+    const int m = m0 + r;
+    const bool mok = m < M;
+    const int mc = mok ? m : M - 1;
+
+    // ---- Wup -> LDS, all K-tiles, one burst (rows 16.. of every stage; the A rows 0..15 are written by stage 1)
+    {
+        const unsigned lds_base = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)smem);
+        const int wv = __builtin_amdgcn_readfirstlane(wave);
+        const int rl = lane >> 3;
+        const int chunk = (lane & 7) ^ (rl & 7);
+        const T* Wup = static_cast<const T*>(P.Wup);
+        for (int kt = 0; kt < nk; ++kt) {
+            const int kin = (kt * BK) % D;                          // every segment contracts against the same Wup columns
+            for (int u = wv; u < E / 8; u += 4)
+                glds16_gn(Wup + (int64_t)(u * 8 + rl) * P.ldwup + kin + chunk * 8, lds_base + (unsigned)(kt * STAGE + (BM + u * 8) * BKB));
+        }
+    }
+    // ---- stage-1 operands and the stage-2 epilogue operands: requested together
+    uint4 a1[SMAX][KS1], w1[SMAX][NI1][KS1];
+#pragma unroll
+    for (int s = 0; s < SMAX; ++s) {
+        if (s < S) {
+            const T* att = static_cast<const T*>(P.att[s]) + (int64_t)mc * P.ldatt + g * 8;
+            const T* Wp = static_cast<const T*>(P.Wp[s]) + (int64_t)(wave * (D / 4) + r) * P.ldwp + g * 8;
+#pragma unroll
+            for (int kc = 0; kc < KS1; ++kc) {
+                a1[s][kc] = *reinterpret_cast<const uint4*>(att + kc * 32);
+#pragma unroll
+                for (int jb = 0; jb < NI1; ++jb) w1[s][jb][kc] = *reinterpret_cast<const uint4*>(Wp + (int64_t)jb * 16 * P.ldwp + kc * 32);
+            }
+        }
+    }
+    float bv2[NI2][4], rv2[NI2][4];
+#pragma unroll
+    for (int j = 0; j < NI2; ++j) {
+        const int n = wave * (E / 4) + j * 16 + g * 4;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) bv2[j][q] = 0.f;
+        if (P.bup != nullptr) {
+            load4(P.bup + n, bv2[j]);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) bv2[j][q] *= P.bias_scale;
+        }
+        load4(P.X + (int64_t)mc * P.ldx + n, rv2[j]);
+    }
+    // ---- stage 1
+#pragma unroll
+    for (int s = 0; s < SMAX; ++s) {
+        if (s < S) {
+#pragma unroll
+            for (int jb = 0; jb < NI1; ++jb) {
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int kc = 0; kc < KS1; ++kc) mma16<T>(w1[s][jb][kc], a1[s][kc], acc);
+                const int kk = s * D + wave * (D / 4) + jb * 16 + g * 4;      // this lane's 4 consecutive contraction indices of stage 2, row r
+                const int kt = kk / BK, cc = kk % BK;
+                store4(reinterpret_cast<T*>(smem + kt * STAGE + r * BKB + (((cc >> 3) ^ (r & 7)) << 4) + (cc & 7) * 2),
+                       gelu_erf(acc[0]), gelu_erf(acc[1]), gelu_erf(acc[2]), gelu_erf(acc[3]));
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the LDS-DMA burst is not tracked by the compiler
+    __syncthreads();
+    // ---- stage-3 operands: requested now, they arrive under stage 2
+    uint4 wd[NI3][KS3];
+    NormEpilogue<T, NI3, true, true> epi3;
+    if (P.has_down) {
+        const T* Wd = static_cast<const T*>(P.down.W) + (int64_t)(wave * (D / 4) + r) * P.down.ldw + g * 8;
+#pragma unroll
+        for (int jb = 0; jb < NI3; ++jb)
+#pragma unroll
+            for (int kc = 0; kc < KS3; ++kc) wd[jb][kc] = *reinterpret_cast<const uint4*>(Wd + (int64_t)jb * 16 * P.down.ldw + kc * 32);
+        epi3.prefetch(P.down, mc, wave * (D / 4), g);
+    }
+    // ---- stage 2
+    f32x4 acc2[NI2];
+#pragma unroll
+    for (int j = 0; j < NI2; ++j) acc2[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int kt = 0; kt < nk; ++kt) {
+        const char* sA = smem + kt * STAGE + r * BKB;
+        const char* sB = smem + kt * STAGE + (BM + wave * (E / 4) + r) * BKB;
+#pragma unroll
+        for (int kc = 0; kc < 2; ++kc) {
+            const int off = ((kc * 4 + g) ^ (r & 7)) << 4;
+            const uint4 af = *reinterpret_cast<const uint4*>(sA + off);
+#pragma unroll
+            for (int j = 0; j < NI2; ++j) mma16<T>(*reinterpret_cast<const uint4*>(sB + j * 16 * BKB + off), af, acc2[j]);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < NI2; ++j) {
+        const int n = wave * (E / 4) + j * 16 + g * 4;
+        float v[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = acc2[j][q] + bv2[j][q] + rv2[j][q];
+        if (mok) {
+            store4(P.X + (int64_t)m * P.ldx + n, v[0], v[1], v[2], v[3]);
+            if (P.Xact != nullptr) store4(static_cast<T*>(P.Xact) + (int64_t)m * P.ldxact + n, v[0], v[1], v[2], v[3]);
+        }
+        store4(reinterpret_cast<T*>(x3 + (n / BK) * (BM * BKB) + r * BKB + ((((n % BK) >> 3) ^ (r & 7)) << 4) + (n & 7) * 2), v[0], v[1], v[2], v[3]);
+    }
+    if (!P.has_down) return;   // block-uniform
+    __syncthreads();
+    // ---- stage 3
+    f32x4 acc3[NI3];
+#pragma unroll
+    for (int jb = 0; jb < NI3; ++jb) acc3[jb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kc = 0; kc < KS3; ++kc) {
+        const uint4 af = *reinterpret_cast<const uint4*>(x3 + (kc >> 1) * (BM * BKB) + r * BKB + ((((kc & 1) * 4 + g) ^ (r & 7)) << 4));
+#pragma unroll
+        for (int jb = 0; jb < NI3; ++jb) mma16<T>(wd[jb][kc], af, acc3[jb]);
+    }
+    epi3.finish(P.down, acc3, m, wave * (D / 4), r, g, wave, L.eps, red);
+}
+
 template <typename K>
 static int set_lds_gn(K kernel, int bytes) {
     return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess ? 0 : -1;
@@ -479,3 +625,48 @@ extern "C" int sea_gemm_rownorm(const SeaGemmNormGroup* groups, int n_groups, fl
     SEA_CHECK_LAUNCH("sea_gemm_rownorm");
     return SEA_OK;
 }
+
+extern "C" int sea_exchange_tail(const SeaExchangeTail* params, float eps, int dtype, void* stream) {
+    SEA_REQUIRE(params != nullptr, "sea_exchange_tail: null params");
+    const SeaExchangeTail& P = *params;
+    const bool shape_ok = (P.D == 128 && P.E == 256) || (P.D == 64 && P.E == 128);
+    if (dtype != SEA_BF16 || !shape_ok || P.n_seg < 1 || P.n_seg > SEA_XTAIL_MAX_SEG || P.n_seg * P.D > 256) {
+        sea_set_error("sea_exchange_tail: unsupported dtype / shape (dtype=%d D=%d E=%d n_seg=%d): bf16, (D,E) in {(128,256),(64,128)}, n_seg*D <= 256", dtype, P.D, P.E, P.n_seg);
+        return SEA_EUNSUPPORTED;
+    }
+    SEA_REQUIRE(P.M >= 1 && P.Wup && P.X && sea_aligned16(P.Wup) && sea_aligned16(P.bup) && sea_aligned16(P.X) && sea_aligned16(P.Xact), "sea_exchange_tail: null / misaligned pointer");
+    SEA_REQUIRE(P.ldatt % 8 == 0 && P.ldatt >= P.D && P.ldwp % 8 == 0 && P.ldwp >= P.D && P.ldwup % 8 == 0 && P.ldwup >= P.D && P.ldx % 4 == 0 && P.ldx >= P.E &&
+                    (!P.Xact || (P.ldxact % 4 == 0 && P.ldxact >= P.E)), "sea_exchange_tail: bad strides");
+    for (int s = 0; s < P.n_seg; ++s) SEA_REQUIRE(P.att[s] && P.Wp[s] && sea_aligned16(P.att[s]) && sea_aligned16(P.Wp[s]), "sea_exchange_tail: segment %d: null / misaligned operand", s);
+    XTailLaunch L;
+    memset(&L, 0, sizeof(L));
+    L.p = P;
+    L.eps = eps;
+    if (P.has_down) {
+        const SeaGemmNormGroup& G = P.down;
+        SEA_REQUIRE(G.W && G.gamma && (G.Y32 || G.Yact) && G.ldw % 8 == 0 && G.ldw >= P.E, "sea_exchange_tail: down: null pointer or bad ldw");
+        SEA_REQUIRE((!G.Y32 || (G.ldy32 % 4 == 0 && G.ldy32 >= P.D)) && (!G.Yact || (G.ldyact % 4 == 0 && G.ldyact >= P.D)) && (!G.mod || (G.ldmod % 4 == 0 && G.ldmod >= 2 * P.D)),
+                    "sea_exchange_tail: down: bad output / modulation strides");
+        SEA_REQUIRE(sea_aligned16(G.W) && sea_aligned16(G.bias) && sea_aligned16(G.mod) && sea_aligned16(G.gamma) && sea_aligned16(G.beta) && sea_aligned16(G.Y32) && sea_aligned16(G.Yact),
+                    "sea_exchange_tail: down: pointers must be 16-byte aligned");
+        // the fields NormEpilogue reads besides the pointers checked above
+        L.p.down.M = P.M; L.p.down.N = P.D; L.p.down.K = P.E; L.p.down.n_seg = 1; L.p.down.bias_scale = 1.0f;
+        L.p.down.R = nullptr; L.p.down.C32 = nullptr; L.p.down.Cact = nullptr; L.p.down.ib_c = nullptr;
+    }
+    const int nk = P.n_seg * P.D / 64;
+    const int lds = nk * (16 + P.E) * 128 + 16 * P.E * 2 + 512;
+    const int grid = (P.M + 15) / 16;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (P.D == 128) {
+        static int once = set_lds_gn(exchange_tail_kernel<128, 256>, 4 * (16 + 256) * 128 + 16 * 256 * 2 + 512);
+        (void)once;
+        exchange_tail_kernel<128, 256><<<dim3(grid), dim3(256), lds, s>>>(L);
+    } else {
+        static int once = set_lds_gn(exchange_tail_kernel<64, 128>, 4 * (16 + 128) * 128 + 16 * 128 * 2 + 512);
+        (void)once;
+        exchange_tail_kernel<64, 128><<<dim3(grid), dim3(256), lds, s>>>(L);
+    }
+    SEA_CHECK_LAUNCH("sea_exchange_tail");
+    return SEA_OK;
+}
+

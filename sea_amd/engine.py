@@ -292,6 +292,13 @@ class Plan:
                     self._c_patches.append((g, "ib_c"))
             self._cur.append(self._rec(L.sea_gemm_rownorm, [arr, len(chunk), 1e-5, self.code], name, arr))
 
+    def _xtail(self, att, Wp, Wup, bup, bias_scale, X, down, name: str) -> None:
+        """One field's exchange tail in one launch (sea_exchange_tail): projections + GELU, up-projection of their sum + residual, and — `down` —
+        the down-projection + row norm of the updated rows."""
+        P = N.SeaExchangeTail()
+        ops.fill_exchange_tail(P, att, Wp, Wup, bup, bias_scale, X, None, down)
+        self._cur.append(self._rec(N.lib().sea_exchange_tail, [C.byref(P), 1e-5, self.code], name, P))
+
     def _qkv(self, groups: List[dict], rope: torch.Tensor, hd: int, name: str) -> None:
         L = N.lib()
         arr = (N.SeaQkvGroup * len(groups))()
@@ -402,6 +409,10 @@ class Plan:
                 return dict(mod=mods[pre], gamma=P.f32_vec(pre + "weight"), beta=P.f32_vec(pre + "bias"))
             return dict(gamma=P.f32_vec(pre + "weight"))
 
+        # the exchange tail of a field (projections + GELU, up-projection + residual, down-projection + norm) as ONE launch: bf16, the widths the
+        # kernel instantiates, short launches (SEA_FUSE_XTAIL=0 keeps the three-launch form; SEA_XTAIL_MAX_ROWS bounds M)
+        fuse_xtail = (fuse_norm and not fuse_tail and not lanes and xmode == "sea" and F > 1 and os.environ.get("SEA_FUSE_XTAIL", "1") != "0"
+                      and ops.exchange_tail_supported(dt, D, E, F - 1) and M <= int(os.environ.get("SEA_XTAIL_MAX_ROWS", "4096")))   # one workgroup per CU (136 KiB of LDS): measured faster while the launch is a single round (cfg2 0.281 -> 0.266 ms; B = 8: 1.211 -> 1.246)
         rope_s, rope_c = eng.rope_self, eng.rope_cross
         FE = F * E
         xr = [self._buf(M, E, dtype=f32) for _ in range(F)]     # fp32 residual stream
@@ -502,6 +513,16 @@ class Plan:
                         proj_groups.append(dict(A=att_c[s], W=P.act(ca + "projection.weight"), Cact=gp[s], act=1))
                     self._qkv(qkv_groups, rope_c, hd_c, f"cross{i}.qkv_rope")
                     self._attn(probs, hd_c, D, f"cross{i}.attention")
+                    if fuse_xtail:
+                        # everything between this field's cross-attention and the next field's: projections + GELU, up-projection of the sum + residual,
+                        # down-projection + ln_cross of the updated field, in one launch (a workgroup carries 16 rows through the three layers)
+                        down = None
+                        if i < F - 1:
+                            down = dict(W=P.act(f"{pre}cross_down.{i}.weight"), bias=P.f32_vec(f"{pre}cross_down.{i}.bias"), Yact=nd_new[i],
+                                        **norm_params(f"{pre}ln_cross.{i}.", D))
+                        self._xtail([att_c[s] for s in range(len(others))], [P.act(f"{pre}cross_attn.{i}.{j}.projection.weight") for j in others],
+                                    P.act(f"{pre}cross_up.{i}.weight"), P.f32_vec(f"{pre}cross_up.{i}.bias"), float(F - 1), xr[i], down, f"cross{i}.tail")
+                        continue
                     self._gemm(proj_groups, f"cross{i}.proj_gelu")
                     up = dict(A=gp[0], W=P.act(f"{pre}cross_up.{i}.weight"), bias=P.f32_vec(f"{pre}cross_up.{i}.bias"),
                               bias_scale=float(F - 1), n_seg=F - 1, a_seg_stride=M * D, R=xr[i], C32=xr[i],
@@ -794,6 +815,8 @@ class Plan:
                 c.op, c.p0, c.n, c.p1, c.dtype = N.OP_QKV, addr(a[0]), a[1], addr(r.keep[1]), a[3]
             elif r.fn is L.sea_attention_fwd:
                 c.op, c.p0, c.dtype = N.OP_ATTN, addr(r.keep), a[1]
+            elif r.fn is L.sea_exchange_tail:
+                c.op, c.p0, c.f0, c.dtype = N.OP_XTAIL, addr(r.keep), a[1], a[2]
             elif r.fn is L.sea_gemm_rownorm:
                 c.op, c.p0, c.n, c.f0, c.dtype = N.OP_GEMM_NORM, addr(a[0]), a[1], a[2], a[3]
             elif r.fn is L.sea_rownorm:

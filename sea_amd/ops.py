@@ -162,6 +162,43 @@ def gemm_rownorm(groups: Sequence[Dict], eps: float, dtype: torch.dtype) -> None
     N.check(N.lib().sea_gemm_rownorm(arr, n, eps, N.dtype_code(dtype), N.stream_ptr()), "sea_gemm_rownorm")
 
 
+def fill_exchange_tail(P: N.SeaExchangeTail, att: Sequence[torch.Tensor], Wp: Sequence[torch.Tensor], Wup, bup, bias_scale: float, X, Xact=None,
+                       down: Optional[Dict] = None) -> None:
+    """att: n_seg act [M, D] matrices, Wp: n_seg act [D, D]; Wup act [E, D]; X f32 [M, E] (in place); down: dict(W [D, E], bias, gamma, beta, mod, Yact, Y32)."""
+    for s, (a, w) in enumerate(zip(att, Wp)):
+        P.att[s], P.Wp[s] = a.data_ptr(), w.data_ptr()
+    P.n_seg, P.ldatt, P.ldwp = len(att), att[0].stride(0), Wp[0].stride(0)
+    P.Wup, P.ldwup, P.bup, P.bias_scale = Wup.data_ptr(), Wup.stride(0), N.ptr(bup), bias_scale
+    P.X, P.ldx = X.data_ptr(), X.stride(0)
+    P.Xact, P.ldxact = N.ptr(Xact), (Xact.stride(0) if Xact is not None else 0)
+    P.M, P.D, P.E = X.shape[0], Wup.shape[1], Wup.shape[0]
+    P.has_down = int(down is not None)
+    if down is not None:
+        g = P.down
+        g.W, g.ldw, g.bias = down["W"].data_ptr(), down["W"].stride(0), N.ptr(down.get("bias"))
+        g.gamma, g.beta = down["gamma"].data_ptr(), N.ptr(down.get("beta"))
+        mod, y32, yact = down.get("mod"), down.get("Y32"), down.get("Yact")
+        g.mod, g.ldmod = N.ptr(mod), (mod.stride(0) if mod is not None else 0)
+        g.Y32, g.ldy32 = N.ptr(y32), (y32.stride(0) if y32 is not None else 0)
+        g.Yact, g.ldyact = N.ptr(yact), (yact.stride(0) if yact is not None else 0)
+        g.mean, g.rstd = N.ptr(down.get("mean")), N.ptr(down.get("rstd"))
+
+
+def exchange_tail_supported(dtype: torch.dtype, D: int, E: int, n_seg: int) -> bool:
+    """Shapes sea_exchange_tail instantiates (include/sea_hip.h)."""
+    return dtype == torch.bfloat16 and (D, E) in ((128, 256), (64, 128)) and 1 <= n_seg and n_seg * D <= 256
+
+
+def exchange_tail(att, Wp, Wup, bup, bias_scale, X, Xact=None, down=None, eps: float = 1e-5, dtype: torch.dtype = torch.bfloat16) -> None:
+    """One field's exchange tail in one launch: X += sum_s gelu(att_s Wp_s^T) Wup^T + bias_scale * bup; optionally the down-projection + row norm
+    of the updated rows (sea_exchange_tail)."""
+    for t in list(att) + list(Wp) + [Wup, X]:
+        N.require_gpu(t, "exchange_tail operand")
+    P = N.SeaExchangeTail()
+    fill_exchange_tail(P, att, Wp, Wup, bup, bias_scale, X, Xact, down)
+    N.check(N.lib().sea_exchange_tail(C.byref(P), eps, N.dtype_code(dtype), N.stream_ptr()), "sea_exchange_tail")
+
+
 def silu_outer(groups: Sequence[Dict], c: torch.Tensor, M: int, dtype: torch.dtype) -> None:
     """groups: dicts with w1 f32 [K2], b1 f32 [K2], Hid act [M,K2]."""
     n = len(groups)

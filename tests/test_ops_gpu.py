@@ -344,6 +344,55 @@ def test_gemm_rownorm_segments_ib_addend(dtype, M):
     assert rel(ne.float(), ref) < tol(dtype, f32=3e-5)
 
 
+@pytest.mark.parametrize("D,E,S", [(128, 256, 2), (128, 256, 1), (64, 128, 2), (64, 128, 4)])
+@pytest.mark.parametrize("M,has_down", [(203, True), (203, False), (2024, True)])
+def test_exchange_tail_matches_three_launch_form(D, E, S, M, has_down):
+    """sea_exchange_tail (cross-attention projections + GELU, up-projection of their sum + residual, down-projection + AdaLN of the updated rows) against
+    the fp32 formula on the bf16 operands, and against the three launches it replaces (same kernels' arithmetic: agreement to bf16 rounding of g and x)."""
+    from sea_amd import ops
+
+    dt = torch.bfloat16
+    att = [rnd(M, D, dtype=dt, seed=700 + s) for s in range(S)]
+    Wp = [rnd(D, D, dtype=dt, scale=0.15, seed=710 + s) for s in range(S)]
+    Wup, bup = rnd(E, D, dtype=dt, scale=0.1, seed=720), 0.2 * rnd(E, seed=721)
+    Wd, bd = rnd(D, E, dtype=dt, scale=0.1, seed=722), 0.2 * rnd(D, seed=723)
+    x = rnd(M, E, seed=724)
+    x0 = x.clone()
+    mod = rnd(M, 2 * D, dtype=dt, scale=0.5, seed=725)
+    gamma, beta = 1 + 0.1 * rnd(D, seed=726), 0.1 * rnd(D, seed=727)
+    xa = torch.empty(M, E, device=dev(), dtype=dt)
+    nd = torch.empty(M, D, device=dev(), dtype=dt)
+    assert ops.exchange_tail_supported(dt, D, E, S)
+    ops.exchange_tail(att, Wp, Wup, bup, float(S), x, Xact=xa, down=dict(W=Wd, bias=bd, gamma=gamma, beta=beta, mod=mod, Yact=nd) if has_down else None)
+    g = [gelu(att[s].float() @ Wp[s].float().t()).to(dt).float() for s in range(S)]        # the kernel rounds g to bf16 (MFMA operand of the next layer)
+    xn = x0 + sum(g) @ Wup.float().t() + S * bup
+    assert rel(x, xn) < 2e-5
+    assert rel(xa.float(), xn) < 6e-3
+    if has_down:
+        v = xn.to(dt).float() @ Wd.float().t() + bd                                          # likewise the new x as operand of the down-projection
+        ref = torch.nn.functional.layer_norm(v, (D,), None, None, 1e-5) * (gamma + 1 + mod[:, :D].float()) + (beta + mod[:, D:].float())
+        assert rel(nd.float(), ref) < 6e-3
+    # the three-launch form on the same operands
+    gp = torch.empty(S, M, D, device=dev(), dtype=dt)
+    ops.gemm_grouped([dict(A=att[s], W=Wp[s], Cact=gp[s], act=1) for s in range(S)], dt)
+    x2, xa2 = x0.clone(), torch.empty_like(xa)
+    ops.gemm_grouped([dict(A=gp[0], W=Wup, bias=bup, bias_scale=float(S), n_seg=S, a_seg_stride=M * D, R=x2, C32=x2, Cact=xa2)], dt)
+    assert rel(x, x2) < 1e-6
+    if has_down:
+        nd2 = torch.empty_like(nd)
+        ops.gemm_rownorm([dict(A=xa2, W=Wd, bias=bd, mod=mod, gamma=gamma, beta=beta, Yact=nd2)], 1e-5, dt)
+        assert rel(nd.float(), nd2.float()) < 2e-3
+
+
+def test_exchange_tail_unsupported_shapes_are_refused():
+    from sea_amd import ops
+
+    assert not ops.exchange_tail_supported(torch.float32, 128, 256, 2) and not ops.exchange_tail_supported(torch.bfloat16, 128, 256, 3)
+    att, Wp = [rnd(8, 32, dtype=torch.bfloat16)], [rnd(32, 32, dtype=torch.bfloat16)]
+    with pytest.raises(RuntimeError, match="unsupported"):
+        ops.exchange_tail(att, Wp, rnd(64, 32, dtype=torch.bfloat16), None, 1.0, rnd(8, 64))
+
+
 def test_gemm_rownorm_rejects_bad_shapes():
     from sea_amd import ops
 
