@@ -417,20 +417,7 @@ __global__ __launch_bounds__(256) void exchange_tail_kernel(const XTailLaunch L)
     const bool mok = m < M;
     const int mc = mok ? m : M - 1;
 
-    // ---- Wup -> LDS, all K-tiles, one burst (rows 16.. of every stage; the A rows 0..15 are written by stage 1)
-    {
-        const unsigned lds_base = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)smem);
-        const int wv = __builtin_amdgcn_readfirstlane(wave);
-        const int rl = lane >> 3;
-        const int chunk = (lane & 7) ^ (rl & 7);
-        const T* Wup = static_cast<const T*>(P.Wup);
-        for (int kt = 0; kt < nk; ++kt) {
-            const int kin = (kt * BK) % D;                          // every segment contracts against the same Wup columns
-            for (int u = wv; u < E / 8; u += 4)
-                glds16_gn(Wup + (int64_t)(u * 8 + rl) * P.ldwup + kin + chunk * 8, lds_base + (unsigned)(kt * STAGE + (BM + u * 8) * BKB));
-        }
-    }
-    // ---- stage-1 operands and the stage-2 epilogue operands: requested together
+    // ---- stage-1 operands first: everything else of this kernel waits for them
     uint4 a1[SMAX][KS1], w1[SMAX][NI1][KS1];
 #pragma unroll
     for (int s = 0; s < SMAX; ++s) {
@@ -445,6 +432,20 @@ __global__ __launch_bounds__(256) void exchange_tail_kernel(const XTailLaunch L)
             }
         }
     }
+    // ---- Wup -> LDS, all K-tiles, one burst (rows 16.. of every stage; the A rows 0..15 are written by stage 1); issued after the stage-1 operand
+    // requests, which are the critical path
+    {
+        const unsigned lds_base = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)smem);
+        const int wv = __builtin_amdgcn_readfirstlane(wave);
+        const int rl = lane >> 3;
+        const int chunk = (lane & 7) ^ (rl & 7);
+        const T* Wup = static_cast<const T*>(P.Wup);
+        for (int kt = 0; kt < nk; ++kt) {
+            const int kin = (kt * BK) % D;                          // every segment contracts against the same Wup columns
+            for (int u = wv; u < E / 8; u += 4)
+                glds16_gn(Wup + (int64_t)(u * 8 + rl) * P.ldwup + kin + chunk * 8, lds_base + (unsigned)(kt * STAGE + (BM + u * 8) * BKB));
+        }
+    }
     float bv2[NI2][4], rv2[NI2][4];
 #pragma unroll
     for (int j = 0; j < NI2; ++j) {
@@ -457,6 +458,17 @@ __global__ __launch_bounds__(256) void exchange_tail_kernel(const XTailLaunch L)
             for (int q = 0; q < 4; ++q) bv2[j][q] *= P.bias_scale;
         }
         load4(P.X + (int64_t)mc * P.ldx + n, rv2[j]);
+    }
+    // ---- stage-3 operands (no dependence on stages 1-2): requested up front as well
+    uint4 wd[NI3][KS3];
+    NormEpilogue<T, NI3, true, true> epi3;
+    if (P.has_down) {
+        const T* Wd = static_cast<const T*>(P.down.W) + (int64_t)(wave * (D / 4) + r) * P.down.ldw + g * 8;
+#pragma unroll
+        for (int jb = 0; jb < NI3; ++jb)
+#pragma unroll
+            for (int kc = 0; kc < KS3; ++kc) wd[jb][kc] = *reinterpret_cast<const uint4*>(Wd + (int64_t)jb * 16 * P.down.ldw + kc * 32);
+        epi3.prefetch(P.down, mc, wave * (D / 4), g);
     }
     // ---- stage 1
 #pragma unroll
@@ -476,17 +488,6 @@ __global__ __launch_bounds__(256) void exchange_tail_kernel(const XTailLaunch L)
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the LDS-DMA burst is not tracked by the compiler
     __syncthreads();
-    // ---- stage-3 operands: requested now, they arrive under stage 2
-    uint4 wd[NI3][KS3];
-    NormEpilogue<T, NI3, true, true> epi3;
-    if (P.has_down) {
-        const T* Wd = static_cast<const T*>(P.down.W) + (int64_t)(wave * (D / 4) + r) * P.down.ldw + g * 8;
-#pragma unroll
-        for (int jb = 0; jb < NI3; ++jb)
-#pragma unroll
-            for (int kc = 0; kc < KS3; ++kc) wd[jb][kc] = *reinterpret_cast<const uint4*>(Wd + (int64_t)jb * 16 * P.down.ldw + kc * 32);
-        epi3.prefetch(P.down, mc, wave * (D / 4), g);
-    }
     // ---- stage 2
     f32x4 acc2[NI2];
 #pragma unroll

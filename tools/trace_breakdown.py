@@ -16,6 +16,8 @@ def short(n):
 def main():
     path, L = sys.argv[1], int(sys.argv[2])
     labels = json.load(open(sys.argv[3])) if len(sys.argv) > 3 else None
+    if isinstance(labels, dict):
+        labels = labels["names"]
     rows = sorted(csv.DictReader(open(path)), key=lambda r: int(r["Start_Timestamp"]))
     names = [r["Kernel_Name"] for r in rows]
     dur = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rows]
