@@ -93,6 +93,11 @@ typedef struct {
     int32_t act;        /* 0 none, 1 GELU(erf) forward, 2 multiply by GELU'(Z) */
     float bias_scale;
     SeaDropout drop;    /* element grid = (output row, output column) */
+    /* generated A operand (all groups of a launch or none): A[m, k] = silu(silu_w1[k] * silu_c[m] + silu_b1[k]) — AdaLN's cond_mlp.0 + SiLU
+     * (models/base_blocks.py:337-338, 344) evaluated inside the GEMM of cond_mlp.2; A is ignored, n_seg = 1, act = 0, K <= 1024 */
+    const float* silu_c;   /* f32 [M] or NULL */
+    const float* silu_w1;  /* f32 [K] */
+    const float* silu_b1;  /* f32 [K] */
 } SeaGemmGroup;
 
 int sea_gemm_grouped(const SeaGemmGroup* groups, int n_groups, int dtype, void* stream);

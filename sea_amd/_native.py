@@ -32,7 +32,8 @@ class SeaGemmGroup(C.Structure):
                 ("a_seg_stride", _i64),
                 ("lda", _i32), ("ldw", _i32), ("ldr", _i32), ("ldc32", _i32), ("ldcact", _i32), ("ldz", _i32),
                 ("M", _i32), ("N", _i32), ("K", _i32), ("n_seg", _i32),
-                ("act", _i32), ("bias_scale", _f32), ("drop", SeaDropout)]
+                ("act", _i32), ("bias_scale", _f32), ("drop", SeaDropout),
+                ("silu_c", _vp), ("silu_w1", _vp), ("silu_b1", _vp)]
 
 
 class SeaQkvGroup(C.Structure):

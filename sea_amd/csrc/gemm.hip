@@ -7,6 +7,7 @@ struct GemmLaunch {
     int tile_start[SEA_MAX_GROUPS + 1];
     int n_groups;
     int single_buffer;   // register-staged main loop on one LDS buffer (more workgroups per CU)
+    int silu_lds_off;    // generated-A launches: byte offset of the w1 | b1 staging area in LDS
 };
 
 struct QkvLaunch {
@@ -35,7 +36,8 @@ __device__ __forceinline__ int find_group(const L& launch, int bid) {
 
 // ---------------------------------------------------------------------------------------------- standard epilogue
 // PLAIN: every group of the launch has act == 0 and no dropout (most launches): the epilogue is compiled without those options.
-template <typename T, int BM, int BN, bool DMA, bool PLAIN>
+// SILUA: the A operand of every group is generated, A[m, k] = silu(silu_w1[k] * silu_c[m] + silu_b1[k]) (gemm_core.hpp, load_tile<true>).
+template <typename T, int BM, int BN, bool DMA, bool PLAIN, bool SILUA = false>
 __global__ __launch_bounds__(256) void gemm_grouped_kernel(const GemmLaunch L) {
     using C = GemmCfg<T, BM, BN>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -53,7 +55,19 @@ __global__ __launch_bounds__(256) void gemm_grouped_kernel(const GemmLaunch L) {
     ml.lda = G.lda; ml.ldw = G.ldw; ml.M = G.M; ml.N = G.N; ml.K = G.K; ml.n_seg = G.n_seg;
     ml.m0 = tm * BM; ml.n0 = tn * BN;
     f32x4 acc[C::MI][C::NI];
-    if constexpr (DMA) ml.run_dma(smem, acc);
+    if constexpr (SILUA) {
+        float* lw = reinterpret_cast<float*>(smem + L.silu_lds_off);
+        for (int i = threadIdx.x; i < G.K; i += 256) {
+            lw[i] = G.silu_w1[i];
+            lw[G.K + i] = G.silu_b1[i];
+        }
+        ml.silu_c = G.silu_c;
+        ml.s_w1 = lw;
+        ml.s_b1 = lw + G.K;
+        ml.init_silu(threadIdx.x);
+        __syncthreads();
+        ml.template run_single<true>(smem, acc);
+    } else if constexpr (DMA) ml.run_dma(smem, acc);
     else ml.run_single(smem, acc);
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -290,14 +304,19 @@ extern "C" int sea_gemm_grouped(const SeaGemmGroup* groups, int n_groups, int dt
     SEA_REQUIRE(dtype == SEA_F32 || dtype == SEA_BF16, "sea_gemm_grouped: bad dtype %d", dtype);
     const int epc = dtype == SEA_BF16 ? 8 : 4;
     long t128 = 0, t64 = 0;
+    int n_silu = 0;
     for (int i = 0; i < n_groups; ++i) {
         const SeaGemmGroup& G = groups[i];
-        SEA_REQUIRE(G.A && G.W, "sea_gemm_grouped[%d]: null operand", i);
+        SEA_REQUIRE((G.A || G.silu_c) && G.W, "sea_gemm_grouped[%d]: null operand", i);
+        n_silu += G.silu_c != nullptr;
+        if (G.silu_c != nullptr)
+            SEA_REQUIRE(G.silu_w1 && G.silu_b1 && sea_aligned16(G.silu_w1) && sea_aligned16(G.silu_b1) && G.n_seg == 1 && G.K <= 1024 && G.K % 8 == 0,
+                        "sea_gemm_grouped[%d]: generated A needs w1 / b1 (16-byte aligned), n_seg = 1, K <= 1024", i);
         SEA_REQUIRE(G.M >= 1 && G.N >= 1 && G.K >= 8 && G.n_seg >= 1, "sea_gemm_grouped[%d]: bad shape M=%d N=%d K=%d n_seg=%d", i, G.M, G.N, G.K, G.n_seg);
-        SEA_REQUIRE(G.K % 8 == 0 && G.lda % epc == 0 && G.ldw % epc == 0 && G.a_seg_stride % epc == 0,
+        SEA_REQUIRE(G.K % 8 == 0 && (G.silu_c || G.lda % epc == 0) && G.ldw % epc == 0 && G.a_seg_stride % epc == 0,
                     "sea_gemm_grouped[%d]: K=%d lda=%d ldw=%d must be multiples of 8/%d", i, G.K, G.lda, G.ldw, epc);
         SEA_REQUIRE(sea_aligned16(G.A) && sea_aligned16(G.W), "sea_gemm_grouped[%d]: A/W not 16-byte aligned", i);
-        SEA_REQUIRE(G.lda >= G.K && G.ldw >= G.K, "sea_gemm_grouped[%d]: leading dimension smaller than K", i);
+        SEA_REQUIRE((G.silu_c || G.lda >= G.K) && G.ldw >= G.K, "sea_gemm_grouped[%d]: leading dimension smaller than K", i);
         SEA_REQUIRE(G.C32 || G.Cact, "sea_gemm_grouped[%d]: no output", i);
         SEA_REQUIRE(G.drop.thr >= 0 && G.drop.thr <= 255 && (G.drop.thr == 0 || G.drop.mode == 1 || G.drop.mode == 2), "sea_gemm_grouped[%d]: bad dropout", i);
         SEA_REQUIRE(G.N % 4 == 0, "sea_gemm_grouped[%d]: N=%d must be a multiple of 4", i, G.N);
@@ -312,7 +331,9 @@ extern "C" int sea_gemm_grouped(const SeaGemmGroup* groups, int n_groups, int dt
     // LDS-DMA ring: needs whole K-tiles (128 bytes of K per row per stage) and pays off only on long contractions (its 4 stages
     // cost a workgroup per CU at 128x128; measured: K = 2048 +5 %, K = 256 -20 % against the register-staged double buffer)
     static const int dma_min_k = []() { const char* e = getenv("SEA_GEMM_DMA_MIN_K"); return e ? atoi(e) : 1024; }();  // tuning aid
-    bool dma = true;
+    SEA_REQUIRE(n_silu == 0 || n_silu == n_groups, "sea_gemm_grouped: generated-A groups cannot share a launch with ordinary ones");
+    const bool silu = n_silu > 0;
+    bool dma = !silu;
     for (int i = 0; i < n_groups; ++i)
         dma = dma && (groups[i].K % (dtype == SEA_BF16 ? 64 : 32) == 0) && (long)groups[i].K * groups[i].n_seg >= dma_min_k;
     // ... and only while the launch is a few tiles deep per CU (its time then is the serial chain of K-tiles of one tile, which the ring
@@ -334,6 +355,9 @@ extern "C" int sea_gemm_grouped(const SeaGemmGroup* groups, int n_groups, int dt
     hipStream_t s = static_cast<hipStream_t>(stream);
     bool plain = true;
     for (int i = 0; i < n_groups; ++i) plain = plain && groups[i].act == 0 && groups[i].drop.thr == 0;
+    SEA_REQUIRE(!silu || plain, "sea_gemm_grouped: generated-A launches take no activation / dropout epilogue");
+    int kmax = 0;
+    for (int i = 0; i < n_groups; ++i) kmax = groups[i].K > kmax ? groups[i].K : kmax;
     L.single_buffer = !dma;
     const int sb = L.single_buffer;
 #define LAUNCH_GEMM(TT, BMN, DM)                                                                                          \
@@ -348,13 +372,26 @@ extern "C" int sea_gemm_grouped(const SeaGemmGroup* groups, int n_groups, int dt
         if (plain) gemm_grouped_kernel<TT, BMN, BMN, DM, true><<<dim3(total), dim3(256), lds_, s>>>(L);                    \
         else gemm_grouped_kernel<TT, BMN, BMN, DM, false><<<dim3(total), dim3(256), lds_, s>>>(L);                         \
     } while (0)
+    // generated-A launches on the ordinary square tiles.  (64 x 256 tiles — half the recomputation of the operand, which every column tile of a
+    // row panel repeats — measured slower: 36.7 against 33.7 us at cfg2, 194 against 174 us at B = 8: two waves per SIMD instead of three.)
+#define LAUNCH_GEMM_SILU(TT, BMN)                                                                                          \
+    do {                                                                                                                  \
+        constexpr int stage_ = BMN * (BMN * (int)sizeof(TT) + 16);                                                         \
+        constexpr int main_ = GemmCfg<TT, BMN, BMN>::BUF_BYTES > stage_ ? GemmCfg<TT, BMN, BMN>::BUF_BYTES : stage_;       \
+        static int once = set_lds(gemm_grouped_kernel<TT, BMN, BMN, false, true, true>, main_ + 8 * 1024);                 \
+        (void)once;                                                                                                       \
+        L.silu_lds_off = main_;                                                                                           \
+        gemm_grouped_kernel<TT, BMN, BMN, false, true, true><<<dim3(total), dim3(256), main_ + 8 * kmax, s>>>(L);          \
+    } while (0)
 #define LAUNCH_GEMM_T(TT)                                                 \
     do {                                                                  \
-        if (tile == 128) { if (dma) LAUNCH_GEMM(TT, 128, true); else LAUNCH_GEMM(TT, 128, false); } \
+        if (silu) { if (tile == 128) LAUNCH_GEMM_SILU(TT, 128); else LAUNCH_GEMM_SILU(TT, 64); } \
+        else if (tile == 128) { if (dma) LAUNCH_GEMM(TT, 128, true); else LAUNCH_GEMM(TT, 128, false); } \
         else { if (dma) LAUNCH_GEMM(TT, 64, true); else LAUNCH_GEMM(TT, 64, false); }              \
     } while (0)
     if (dtype == SEA_BF16) LAUNCH_GEMM_T(__bf16); else LAUNCH_GEMM_T(float);
 #undef LAUNCH_GEMM_T
+#undef LAUNCH_GEMM_SILU
 #undef LAUNCH_GEMM
     SEA_CHECK_LAUNCH("sea_gemm_grouped");
     return SEA_OK;

@@ -44,6 +44,25 @@ struct GemmMainloop {
 
     uint4 ra[C::A_CH], rb[C::B_CH];
 
+    // Optional GENERATED A operand (the AdaLN condition MLP, models/base_blocks.py:337-338,344): A[m, k] = silu(w1[k] * c[m] + b1[k]) is a
+    // function of one scalar per row, so the tile is computed on the VALU (under the other waves' MFMAs) instead of being written to HBM by
+    // a launch of its own and read back: no [M, 2d] hidden matrix, one launch less.  w1 / b1 are staged in LDS once per workgroup.
+    const float* silu_c = nullptr;   // f32 [M]
+    const float* s_w1 = nullptr;     // LDS copies, f32 [K]
+    const float* s_b1 = nullptr;
+    float cvals[C::A_CH];
+
+    __device__ __forceinline__ void init_silu(int tid) {
+        const int rr = tid >> 3;
+#pragma unroll
+        for (int i = 0; i < C::A_CH; ++i) {
+            int row = m0 + rr + 32 * i;
+            row = row < M ? row : M - 1;
+            cvals[i] = silu_c[row];
+        }
+    }
+
+    template <bool SILU = false>
     __device__ __forceinline__ void load_tile(int kt, int tid) {
         const int c = tid & 7;
         const int rr = tid >> 3;
@@ -55,13 +74,31 @@ struct GemmMainloop {
             seg = kk / K;
             kin = kk - seg * K;
         }
-        const T* a_base = A + seg * a_seg_stride + kin;
         const T* w_base = W + kin;
+        if constexpr (SILU) {
+            float w[C::EPC], b[C::EPC];
 #pragma unroll
-        for (int i = 0; i < C::A_CH; ++i) {
-            int row = m0 + rr + 32 * i;
-            row = row < M ? row : M - 1;
-            ra[i] = kvalid ? *reinterpret_cast<const uint4*>(a_base + (int64_t)row * lda) : make_uint4(0, 0, 0, 0);
+            for (int e = 0; e < C::EPC; e += 4) {
+                const float4 wv = kvalid ? *reinterpret_cast<const float4*>(s_w1 + kk + e) : make_float4(0.f, 0.f, 0.f, 0.f);
+                const float4 bv = kvalid ? *reinterpret_cast<const float4*>(s_b1 + kk + e) : make_float4(0.f, 0.f, 0.f, 0.f);
+                w[e] = wv.x; w[e + 1] = wv.y; w[e + 2] = wv.z; w[e + 3] = wv.w;
+                b[e] = bv.x; b[e + 1] = bv.y; b[e + 2] = bv.z; b[e + 3] = bv.w;
+            }
+#pragma unroll
+            for (int i = 0; i < C::A_CH; ++i) {
+                T v[C::EPC];
+#pragma unroll
+                for (int e = 0; e < C::EPC; ++e) v[e] = from_f32<T>(silu_f(w[e] * cvals[i] + b[e]));
+                ra[i] = kvalid ? *reinterpret_cast<const uint4*>(v) : make_uint4(0, 0, 0, 0);
+            }
+        } else {
+            const T* a_base = A + seg * a_seg_stride + kin;
+#pragma unroll
+            for (int i = 0; i < C::A_CH; ++i) {
+                int row = m0 + rr + 32 * i;
+                row = row < M ? row : M - 1;
+                ra[i] = kvalid ? *reinterpret_cast<const uint4*>(a_base + (int64_t)row * lda) : make_uint4(0, 0, 0, 0);
+            }
         }
 #pragma unroll
         for (int i = 0; i < C::B_CH; ++i) {
@@ -182,6 +219,7 @@ struct GemmMainloop {
     // Single LDS buffer: half the LDS per workgroup, hence twice the resident workgroups per CU; costs a second barrier per K-tile.
     // For short contractions a tile is mostly prologue / epilogue VALU and memory waits (PMC: 7 VALU per MFMA, MFMA pipe 17 % busy at
     // K = 256), which other resident workgroups can fill — more of them beats a deeper pipeline inside one.
+    template <bool SILU = false>
     __device__ __forceinline__ void run_single(char* smem, f32x4 (&acc)[C::MI][C::NI]) {
         const int tid = threadIdx.x;
         const int lane = tid & 63, wave = tid >> 6;
@@ -191,11 +229,11 @@ struct GemmMainloop {
 #pragma unroll
             for (int j = 0; j < C::NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
         const int nk = (K * n_seg + C::BK - 1) / C::BK;
-        load_tile(0, tid);
+        load_tile<SILU>(0, tid);
         for (int kt = 0; kt < nk; ++kt) {
             store_tile(smem, tid);
             __syncthreads();
-            if (kt + 1 < nk) load_tile(kt + 1, tid);
+            if (kt + 1 < nk) load_tile<SILU>(kt + 1, tid);
             compute_tile(smem, wm, wn, lane, acc);
             __syncthreads();
         }

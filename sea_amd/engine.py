@@ -249,6 +249,8 @@ class Plan:
                 _fill_gemm(g, **d)
             self._cur.append(self._rec(L.sea_gemm_grouped, [arr, len(chunk), self.code], name, arr))
             for g, d in zip(arr, chunk):
+                if d.get("silu") is not None:
+                    self._c_patches.append((g, "silu_c"))
                 if d.get("R_is_x") is not None:
                     self._x_patches.append((g, "R", d["R_is_x"]))
                 if d.get("drop") is not None:
@@ -349,8 +351,23 @@ class Plan:
         for i in range(F):
             rest.append((f"ln.{i}.", E))
 
+        # cond_mlp.0 + SiLU evaluated inside the GEMM of cond_mlp.2 (generated A operand): no hidden matrix, no silu launch.  Inference plans
+        # only (the weight gradient of cond_mlp.2 reads the hidden matrix).  The operand is recomputed by every column tile of a row panel (4x at
+        # N = 512), VALU work that pays only once the hidden matrix's HBM round trip is the larger cost: measured 0.2685 against 0.2671 ms at cfg2
+        # (M = 2024: not used), 1.215 against 1.241 ms at B = 8 (used).  SEA_FUSE_SILU=1|0 forces.
+        want = os.environ.get("SEA_FUSE_SILU", "auto")
+        gen_a = (type(self) is Plan and all(2 * d <= 1024 for _, d in first + rest) and (want == "1" or (want == "auto" and M >= 8192)))
+
         def emit(inst, tag):
             silu_groups, gemm_groups = [], []
+            if gen_a:
+                for pre, d in inst:
+                    mod = self._buf(M, 2 * d)
+                    mods[pre] = mod
+                    gemm_groups.append(dict(A=None, M=M, W=P.act(pre + "cond_mlp.2.weight"), bias=P.f32_vec(pre + "cond_mlp.2.bias"), Cact=mod,
+                                            silu=(P.f32_vec(pre + "cond_mlp.0.weight", 2 * d), P.f32_vec(pre + "cond_mlp.0.bias"))))
+                self._gemm(gemm_groups, "adaln.cond_gemm" + tag)
+                return
             for pre, d in inst:
                 hid = self._buf(M, 2 * d)
                 mod = self._buf(M, 2 * d)
@@ -902,9 +919,18 @@ class Plan:
 
 
 def _fill_gemm(g, A, W, bias=None, R=None, C32=None, Cact=None, n_seg=1, a_seg_stride=0, act=0, bias_scale=1.0, ldr=None,
-               R_is_x=None, Z=None, ldc32=None, drop=None) -> None:
+               R_is_x=None, Z=None, ldc32=None, drop=None, silu=None, M=None) -> None:
     if drop is not None:  # (thr, stream, mode); the seed is patched every step
         g.drop.thr, g.drop.stream, g.drop.mode = drop
+    if silu is not None:  # generated A operand: (w1 [K] f32, b1 [K] f32); the condition pointer is patched at bind time; rows = M
+        g.A, g.W, g.lda = None, W.data_ptr(), 0
+        g.silu_w1, g.silu_b1 = silu[0].data_ptr(), silu[1].data_ptr()
+        g.Z, g.ldz, g.bias, g.R, g.C32, g.Cact = None, 0, N.ptr(bias), None, N.ptr(C32), N.ptr(Cact)
+        g.a_seg_stride, g.ldw, g.ldr = 0, W.stride(0), 0
+        g.ldc32 = C32.stride(0) if C32 is not None else 0
+        g.ldcact = Cact.stride(0) if Cact is not None else 0
+        g.M, g.N, g.K, g.n_seg, g.act, g.bias_scale = M, W.shape[0], W.shape[1], 1, 0, bias_scale
+        return
     g.A, g.W = A.data_ptr(), W.data_ptr()
     g.Z, g.ldz = N.ptr(Z), (Z.stride(0) if Z is not None else 0)
     g.bias, g.R, g.C32, g.Cact = N.ptr(bias), N.ptr(R), N.ptr(C32), N.ptr(Cact)

@@ -22,7 +22,15 @@ def _mat(t: torch.Tensor, name: str) -> torch.Tensor:
 
 
 def fill_gemm_group(g: N.SeaGemmGroup, A, W, bias=None, R=None, C32=None, Cact=None, n_seg=1, a_seg_stride=0, act=0,
-                    bias_scale=1.0, M=None, N_=None, K=None, Z=None) -> None:
+                    bias_scale=1.0, M=None, N_=None, K=None, Z=None, silu=None) -> None:
+    if silu is not None:   # generated A operand: dict(c f32 [M], w1 f32 [K], b1 f32 [K]) — A[m, k] = silu(w1[k] c[m] + b1[k])
+        g.silu_c, g.silu_w1, g.silu_b1 = silu["c"].data_ptr(), silu["w1"].data_ptr(), silu["b1"].data_ptr()
+        g.A, g.lda, g.W, g.ldw = None, 0, W.data_ptr(), W.stride(0)
+        g.bias, g.R, g.C32, g.Cact, g.Z = N.ptr(bias), None, N.ptr(C32), N.ptr(Cact), None
+        g.ldc32 = C32.stride(0) if C32 is not None else 0
+        g.ldcact = Cact.stride(0) if Cact is not None else 0
+        g.M, g.N, g.K, g.n_seg, g.act, g.bias_scale = silu["c"].numel(), W.shape[0], W.shape[1], 1, 0, bias_scale
+        return
     g.A, g.W = A.data_ptr(), W.data_ptr()
     g.bias = N.ptr(bias)
     g.R, g.C32, g.Cact = N.ptr(R), N.ptr(C32), N.ptr(Cact)
@@ -46,6 +54,12 @@ def gemm_grouped(groups: Sequence[Dict], dtype: torch.dtype) -> None:
     n = len(groups)
     arr = (N.SeaGemmGroup * n)()
     for i, d in enumerate(groups):
+        if d.get("silu") is not None:
+            W = _mat(d["W"], "W")
+            if W.dtype != dtype:
+                raise ValueError(f"gemm group {i}: W dtype {W.dtype} != activation dtype {dtype}")
+            fill_gemm_group(arr[i], None, W, d.get("bias"), None, d.get("C32"), d.get("Cact"), bias_scale=d.get("bias_scale", 1.0), silu=d["silu"])
+            continue
         A, W = _mat(d["A"], "A"), _mat(d["W"], "W")
         if A.dtype != dtype or W.dtype != dtype:
             raise ValueError(f"gemm group {i}: A/W dtype {A.dtype}/{W.dtype} != activation dtype {dtype}")

@@ -417,6 +417,36 @@ def test_rownorm_ln_gelu_act_input(dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M", [77, 2024])
+def test_cond_gemm_with_generated_operand(dtype, M):
+    """AdaLN's condition MLP in ONE launch: cond_mlp.0 + SiLU evaluated inside the GEMM of cond_mlp.2 (generated A operand), against the
+    two-launch form (sea_silu_outer, then the GEMM on its output — identical arithmetic) and the fp32 formula; groups of different widths."""
+    from sea_amd import ops
+
+    c = torch.rand(M, device=dev())
+    gen, two, refs, outs, outs2 = [], [], [], [], []
+    silu_groups = []
+    for i, K2 in enumerate((512, 256, 512, 64)):
+        w1, b1 = rnd(K2, seed=800 + i), rnd(K2, seed=810 + i)
+        W, bias = rnd(K2, K2, dtype=dtype, scale=0.1, seed=820 + i), 0.3 * rnd(K2, seed=830 + i)
+        o1, o2 = torch.empty(M, K2, device=dev(), dtype=dtype), torch.empty(M, K2, device=dev(), dtype=dtype)
+        hid = torch.empty(M, K2, device=dev(), dtype=dtype)
+        gen.append(dict(W=W, bias=bias, Cact=o1, silu=dict(c=c, w1=w1, b1=b1)))
+        silu_groups.append(dict(w1=w1, b1=b1, Hid=hid))
+        two.append(dict(A=hid, W=W, bias=bias, Cact=o2))
+        h = torch.nn.functional.silu(c[:, None] * w1 + b1).to(dtype).float()
+        refs.append(h @ W.float().t() + bias)
+        outs.append(o1)
+        outs2.append(o2)
+    ops.gemm_grouped(gen, dtype)
+    ops.silu_outer(silu_groups, c, M, dtype)
+    ops.gemm_grouped(two, dtype)
+    for o1, o2, ref in zip(outs, outs2, refs):
+        assert rel(o1.float(), ref) < tol(dtype, f32=2e-5)
+        assert torch.equal(o1, o2)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 def test_silu_outer_and_cond_gemm(dtype):
     from sea_amd import ops
 
