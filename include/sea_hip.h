@@ -570,6 +570,19 @@ int sea_unpatchify(const float* in, int64_t sb, int64_t sp, int64_t sf, int64_t 
                    const float* scale, const float* shift, float* out, int B, int P, int F, int C, int n_points, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
+ * Patchify + MinMax scaling of mesh fields (forward direction): MeshProcessor._scale_fields
+ * (utils/data_processors.py:528-536: MinMaxScaler.transform per field group, :241-247) followed by DataPartitioner2D.create_partitions /
+ * pad_partitions (:60-92) and the stack / permute the encoder's input needs (:519-525):
+ *     out[b, p, f, c] = in[b, index_map[p, c], f] * scale[f] + shift[f]     for c < C_map and index_map[p, c] >= 0
+ *                     = pad_value                                           otherwise (empty slots; the row padding C_map .. C_out - 1)
+ * `in` f32 [B, n_points, F] contiguous; index_map int32 [P, C_map] (pad_id = -1); `out` is addressed with element strides (sb, sp, sf, sc), so
+ * both the encoder's [B, P, F, C_out] layout and the reference's [T, P, C, F] are written in place.  The pad value is NOT scaled (the reference
+ * scales first and pads with pad_field_value afterwards).
+ */
+int sea_patchify(const float* in, const int32_t* index_map, const float* scale, const float* shift, float* out, int64_t sb, int64_t sp, int64_t sf,
+                 int64_t sc, int B, int P, int F, int C_map, int C_out, int n_points, float pad_value, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
  * Self-test of the MFMA fragment maps this library relies on (16x16x32 bf16 and 16x16x4 f32, A/B/C lane maps):
  * multiplies exact small-integer matrices on the device and checks every element on the host.  Synchronous.
  * Returns 0 when both maps are as documented in cdna_hip_programming.md §3.

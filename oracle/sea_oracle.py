@@ -422,3 +422,32 @@ def encode(x: torch.Tensor, p: Params, field_groups: Sequence[Sequence[int]], n_
     z = layer_norm(z, p[pre + "ln.weight"], p[pre + "ln.bias"])
     return z.reshape(B, P, len(field_groups), -1)
 
+
+# ---------------------------------------------------------------------------------------------------- patchify / dataset windows
+def patchify(fields: torch.Tensor, index_map: torch.Tensor, field_groups: Sequence[Sequence[int]] = (), scaler_params: Sequence[Sequence[float]] = (),
+             pad_value: float = 0.0) -> torch.Tensor:
+    """MeshProcessor._scale_fields (utils/data_processors.py:528-536; MinMaxScaler.transform :241-247) followed by DataPartitioner2D.create_partitions /
+    pad_partitions (:60-92) and the stack of :519-522.  fields [T, N, F]; index_map [P, C] with -1 padding; scaler_params per group
+    (range_lo, range_hi, min, max).  Returns [T, P, C, F]; padded slots hold pad_value (not scaled)."""
+    x = fields.clone()
+    for g, (r0, r1, lo, hi) in zip(field_groups, scaler_params):
+        std = (fields[..., list(g)] - lo) / (hi - lo)
+        x[..., list(g)] = std * (r1 - r0) + r0
+    idx = index_map.long()
+    out = x[:, idx.clamp_min(0).reshape(-1), :].reshape(x.shape[0], idx.shape[0], idx.shape[1], x.shape[2])
+    return torch.where((idx >= 0)[None, :, :, None], out, torch.full_like(out, pad_value))
+
+
+def dataset_window(data_list: Sequence[torch.Tensor], idx: int, src_len: int, overlap: int) -> Tuple[int, int, int]:
+    """TemporalDataset.__getitem__ without time shifting (utils/data_processors.py:420-452): (segment, first step, one-past-last step) of sample idx;
+    the target window is the same one step later."""
+    step = src_len - overlap
+    cum = 0
+    for s, d in enumerate(data_list):
+        n = d.shape[0] // step
+        if idx < cum + n:
+            a = (idx - cum) * step
+            return s, a, a + src_len
+        cum += n
+    raise IndexError("Index out of range")
+

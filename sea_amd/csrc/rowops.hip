@@ -392,3 +392,37 @@ extern "C" int sea_unpatchify(const float* in, int64_t sb, int64_t sp, int64_t s
     SEA_CHECK_LAUNCH("sea_unpatchify");
     return SEA_OK;
 }
+
+// ------------------------------------------------------------------------------------------------ patchify (forward direction of the mesh partition)
+// grid = (slot blocks, snapshots): thread = one (cell, slot) of one snapshot; the F values of its mesh point are read together (12 contiguous
+// bytes at F = 3, served from L2: a snapshot is n_points * F * 4 bytes) and written at stride sf — with the encoder's [B, P, F, C] layout the
+// writes of a wavefront are contiguous in c.  Slots >= C_map (the row padding to n_inp) and empty slots (index -1) get pad_value.
+__global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__ in, const int32_t* __restrict__ imap, const float* __restrict__ scale,
+                                                       const float* __restrict__ shift, float* __restrict__ out, int64_t sb, int64_t sp, int64_t sf, int64_t sc,
+                                                       int P, int F, int C_map, int C_out, int n_points, float pad_value) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (int64_t)P * C_out) return;
+    const int p = (int)(i / C_out), c = (int)(i - (int64_t)p * C_out);
+    const int b = blockIdx.y;
+    const int idx = c < C_map ? imap[(int64_t)p * C_map + c] : -1;
+    float* dst = out + b * sb + p * sp + c * sc;
+    if (idx < 0) {
+        for (int f = 0; f < F; ++f) dst[f * sf] = pad_value;
+        return;
+    }
+    const float* src = in + ((int64_t)b * n_points + idx) * F;
+    for (int f = 0; f < F; ++f) dst[f * sf] = src[f] * scale[f] + shift[f];
+}
+
+extern "C" int sea_patchify(const float* in, const int32_t* index_map, const float* scale, const float* shift, float* out, int64_t sb, int64_t sp, int64_t sf,
+                            int64_t sc, int B, int P, int F, int C_map, int C_out, int n_points, float pad_value, void* stream) {
+    SEA_REQUIRE(in && index_map && scale && shift && out, "sea_patchify: null pointer");
+    SEA_REQUIRE(B >= 1 && B <= 65535 && P >= 1 && F >= 1 && C_map >= 1 && C_out >= C_map && n_points >= 1, "sea_patchify: bad sizes B=%d P=%d F=%d C_map=%d C_out=%d n_points=%d",
+                B, P, F, C_map, C_out, n_points);
+    const int64_t per = (int64_t)P * C_out;
+    patchify_kernel<<<dim3((unsigned)((per + 255) / 256), B, 1), dim3(256), 0, static_cast<hipStream_t>(stream)>>>(in, index_map, scale, shift, out, sb, sp, sf, sc, P, F,
+                                                                                                                  C_map, C_out, n_points, pad_value);
+    SEA_CHECK_LAUNCH("sea_patchify");
+    return SEA_OK;
+}
+

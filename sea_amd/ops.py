@@ -437,3 +437,23 @@ def unpatchify(fields: torch.Tensor, layout: str, index_map: torch.Tensor, scale
     N.check(N.lib().sea_unpatchify(fields.data_ptr(), sb, sp, sf, sc, index_map.data_ptr(), N.ptr(point_slot), scale.data_ptr(), shift.data_ptr(),
                                    out.data_ptr(), B, P, F, Cc, n_points, N.stream_ptr()), "sea_unpatchify")
     return out
+
+
+def patchify(fields: torch.Tensor, index_map: torch.Tensor, scale: torch.Tensor, shift: torch.Tensor, layout: str = "BPFC", c_out: Optional[int] = None,
+             pad_value: float = 0.0) -> torch.Tensor:
+    """out[b, p, f, c] = fields[b, index_map[p, c], f] * scale[f] + shift[f], pad_value at empty / padded slots (sea_patchify).  fields f32
+    [B, n_points, F]; `layout` of the result: "BPFC" (the encoder's input, C padded to c_out) or "BPCF" (the reference's stacked fields)."""
+    N.require_gpu(fields, "fields")
+    assert fields.dtype == torch.float32 and fields.dim() == 3 and fields.is_contiguous() and layout in ("BPFC", "BPCF")
+    assert index_map.dtype == torch.int32 and index_map.is_cuda and index_map.is_contiguous()
+    B, n_points, F = fields.shape
+    P, C_map = index_map.shape
+    C_out = C_map if c_out is None else c_out
+    assert C_out >= C_map and scale.numel() == F and shift.numel() == F
+    out = torch.empty((B, P, F, C_out) if layout == "BPFC" else (B, P, C_out, F), device=fields.device, dtype=torch.float32)
+    sb, sp = out.stride(0), out.stride(1)
+    sf, sc = (out.stride(2), out.stride(3)) if layout == "BPFC" else (out.stride(3), out.stride(2))
+    N.check(N.lib().sea_patchify(fields.data_ptr(), index_map.data_ptr(), scale.data_ptr(), shift.data_ptr(), out.data_ptr(), sb, sp, sf, sc, B, P, F, C_map, C_out,
+                                 n_points, pad_value, N.stream_ptr()), "sea_patchify")
+    return out
+

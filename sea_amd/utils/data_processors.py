@@ -7,7 +7,7 @@ torch calls on the device (bucketize + sort), not per time step, and is plumbing
 round-trip tests with torch indexing."""
 from __future__ import annotations
 
-from typing import List, Sequence, Tuple
+from typing import List, Optional, Sequence, Tuple
 
 import torch
 
@@ -32,6 +32,14 @@ class MinMaxScaler:
             raise ValueError("The scaler has not been fitted yet. Call 'fit' with training data before using 'transform'.")
         std = (data - self.min_val) / (self.max_val - self.min_val)
         return std * (self.feature_range[1] - self.feature_range[0]) + self.feature_range[0]
+
+    def forward_affine(self) -> Tuple[float, float]:
+        """(scale, shift) of transform as x * scale + shift."""
+        if self.min_val is None:
+            raise ValueError("The scaler has not been fitted yet. Call 'fit' with training data before using 'transform'.")
+        r0, r1 = float(self.feature_range[0]), float(self.feature_range[1])
+        scale = (r1 - r0) / (float(self.max_val) - float(self.min_val))
+        return scale, r0 - float(self.min_val) * scale
 
     def inverse_affine(self) -> Tuple[float, float]:
         """(scale, shift) of inverse_transform as y * scale + shift."""
@@ -100,8 +108,63 @@ class MeshUnpatcher:
         self._scale = torch.tensor(scale, device=dev, dtype=torch.float32)
         self._shift = torch.tensor(shift, device=dev, dtype=torch.float32)
 
+    def patchify_and_scale(self, data: torch.Tensor, layout: str = "BPCF", c_out: Optional[int] = None) -> torch.Tensor:
+        """The forward leg (reference MeshProcessor.patchify_and_scale, utils/data_processors.py:484-526, with fitted scalers): data [T, N, F] ->
+        scaled, partitioned, padded fields [T, P, C, F] (layout "BPCF", the reference's) or [T, P, F, c_out] ("BPFC", what the encoder reads) in ONE
+        launch of sea_patchify; padded slots hold pad_field_value, unscaled, as in the reference."""
+        N.require_gpu(data, "data")
+        if not hasattr(self, "_fscale"):
+            F = sum(len(g) for g in self.field_groups)
+            scale, shift = [1.0] * F, [0.0] * F
+            for g, sc in zip(self.field_groups, self.scalers):
+                a, b = sc.forward_affine()
+                for f in g:
+                    scale[f], shift[f] = a, b
+            dev = self.partitioner.device
+            self._fscale = torch.tensor(scale, device=dev, dtype=torch.float32)
+            self._fshift = torch.tensor(shift, device=dev, dtype=torch.float32)
+        return ops.patchify(data.float().contiguous(), self.partitioner.padded_index_map, self._fscale, self._fshift, layout, c_out,
+                            float(self.partitioner.pad_field_value))
+
     def inverse_scale_and_unpatch(self, scaled_fields: torch.Tensor, layout: str = "BPCF") -> torch.Tensor:
         """scaled_fields [T, P, C, F] (reference layout) or, with layout="BPFC", the decoder's [T, P, F, C] output directly -> [T, N, F]."""
         N.require_gpu(scaled_fields, "scaled_fields")
         return ops.unpatchify(scaled_fields.float(), layout, self.partitioner.padded_index_map, self._scale, self._shift, self.partitioner.x_coords.numel(),
                               point_slot=self.partitioner.point_slot if self.gather else None)
+
+
+class TemporalDataset:
+    """Windows over encoded trajectories with the reference's indexing (utils/data_processors.py:388-452): sample idx of segment s covers steps
+    [k*step + shift, k*step + shift + src_len), the target is the same window one step later.  Items are VIEWS of the (device-resident) trajectory
+    tensors — no copies, no host round trip; `batch()` stacks a list of samples for the train step."""
+
+    def __init__(self, data_list, data_list_original, field_ib, src_len=64, overlap=0, device='cpu', time_shifting_flag=False):
+        self.device, self.data_list, self.data_list_original, self.field_ib = device, data_list, data_list_original, field_ib
+        self.src_len, self.overlap, self.step, self.time_shifting_flag = src_len, overlap, src_len - overlap, time_shifting_flag
+        self.segment_samples = [d.shape[0] // self.step for d in data_list]
+        self.num_samples = sum(self.segment_samples)
+
+    def __len__(self):
+        return self.num_samples
+
+    def locate(self, idx: int) -> Tuple[int, int]:
+        """(segment, sample inside the segment) of a flat index; IndexError past the end, as the reference."""
+        cum = 0
+        for s, n in enumerate(self.segment_samples):
+            if idx < cum + n:
+                return s, idx - cum
+            cum += n
+        raise IndexError("Index out of range")
+
+    def __getitem__(self, idx):
+        import numpy as np
+
+        seg, k = self.locate(idx)
+        shift = int(np.random.randint(0, self.data_list[seg].shape[0] - self.step)) if self.time_shifting_flag else 0
+        a, b = k * self.step + shift, k * self.step + shift + self.src_len
+        return self.data_list[seg][a:b], self.data_list[seg][a + 1:b + 1], self.data_list_original[seg][a + 1:b + 1], self.field_ib[seg][a:b]
+
+    def batch(self, indices: Sequence[int]):
+        items = [self[i] for i in indices]
+        return tuple(torch.stack([it[j] for it in items]) for j in range(4))
+

@@ -302,8 +302,36 @@ def unpatch_cases():
         with contextlib.redirect_stdout(io.StringIO()):
             for sc, g in zip(scal, groups):
                 unscaled[..., g] = sc.inverse_transform(recon[..., g])
+        # forward direction (MeshProcessor._scale_fields then create_partitions, utils/data_processors.py:528-536, 511-523): scale, THEN pad with 0
+        fwd = torch.zeros(T, npts, F)
+        with contextlib.redirect_stdout(io.StringIO()):
+            for sc, g in zip(scal, groups):
+                fwd[..., g] = sc.transform(torch.from_numpy(fields)[..., g])
+        parts_s, _ = part.create_partitions([fwd[:, :, i].to(torch.float32) for i in range(F)])
+        scaled_stacked = torch.stack([p_[1] for p_ in parts_s], dim=1)   # [T, P, C, F]
         save(name, xy=xy, mn=np.array([m, nn]), fields=fields, stacked=n(stacked), index_map=index_map.numpy().astype(np.int64),
-             unscaled=n(unscaled), groups=np.array([len(g) for g in groups]), scaler_params=np.array(params, dtype=np.float64))
+             unscaled=n(unscaled), groups=np.array([len(g) for g in groups]), scaler_params=np.array(params, dtype=np.float64),
+             scaled_stacked=n(scaled_stacked))
+
+
+def dataset_cases():
+    """TemporalDataset (utils/data_processors.py:388-452): window indexing over two trajectories of different lengths, with and without overlap."""
+    print("temporal_dataset")
+    rng = np.random.Generator(np.random.PCG64(41))
+    lens = (23, 17)
+    data = [torch.from_numpy(rng.standard_normal((L_, 2, 6)).astype(np.float32)) for L_ in lens]
+    orig = [torch.from_numpy(rng.standard_normal((L_, 5, 3)).astype(np.float32)) for L_ in lens]
+    ib = [torch.from_numpy(rng.random((L_, 1)).astype(np.float32)) for L_ in lens]
+    arrs = {f"data{i}": n(d) for i, d in enumerate(data)}
+    arrs.update({f"orig{i}": n(d) for i, d in enumerate(orig)})
+    arrs.update({f"ib{i}": n(d) for i, d in enumerate(ib)})
+    for tag, src_len, overlap in (("a", 5, 0), ("b", 6, 2)):
+        ds = ref_dp.TemporalDataset(data, orig, ib, src_len=src_len, overlap=overlap)
+        arrs[f"{tag}.len"] = np.array([len(ds), src_len, overlap])
+        for idx in range(len(ds)):
+            src, tgt, tgt_o, fib = ds[idx]
+            arrs[f"{tag}.{idx}.src"], arrs[f"{tag}.{idx}.tgt"], arrs[f"{tag}.{idx}.tgto"], arrs[f"{tag}.{idx}.ib"] = n(src), n(tgt), n(tgt_o), n(fib)
+    save("temporal_dataset", **arrs)
 
 
 def big_cases():
@@ -355,6 +383,7 @@ def main():
         "decode": decode_cases,
         "encode": encode_cases,
         "unpatch": unpatch_cases,
+        "dataset": dataset_cases,
     }
     # ablation variants of the exchange / info-bottleneck: forward only
     cases["model_addition_adaln_f3"] = lambda: model_case("model_addition_adaln_f3", OracleConfig(2, 64, 4, 80, 8, 0, 3, 2, True, "adaln", "addition"), 2, 33)

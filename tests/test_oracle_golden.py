@@ -237,3 +237,40 @@ def test_encode_matches_reference(name):
     assert rel_l2(z, g["z"]) < TOL
     assert np.array_equal(O.sinusoidal_pe(P, len(groups) * D).numpy(), g["pe"])
 
+
+@pytest.mark.parametrize("name", ["unpatch_5x5", "unpatch_3x4"])
+def test_patchify_matches_reference(name):
+    """Forward direction of the mesh partition: scale, then partition and pad."""
+    g = load_golden(name)
+    groups, k = [], 0
+    for sz in g["groups"]:
+        groups.append(list(range(k, k + int(sz))))
+        k += int(sz)
+    imap = T(g["index_map"])
+    assert torch.equal(O.patchify(T(g["fields"]), imap), T(g["stacked"]))
+    out = O.patchify(T(g["fields"]), imap, groups, [tuple(r) for r in g["scaler_params"]])
+    assert rel_l2(out, g["scaled_stacked"]) < 1e-6
+    pad = (imap < 0)[None, :, :, None].expand_as(out)
+    assert float(out[pad].abs().max()) == 0.0 if pad.any() else True
+
+
+def test_temporal_dataset_windows_match_reference():
+    from sea_amd.utils.data_processors import TemporalDataset
+
+    g = load_golden("temporal_dataset")
+    data, orig, ib = [T(g[f"data{i}"]) for i in range(2)], [T(g[f"orig{i}"]) for i in range(2)], [T(g[f"ib{i}"]) for i in range(2)]
+    for tag in ("a", "b"):
+        n, src_len, overlap = (int(v) for v in g[f"{tag}.len"])
+        ds = TemporalDataset(data, orig, ib, src_len=src_len, overlap=overlap)
+        assert len(ds) == n
+        for idx in range(n):
+            src, tgt, tgt_o, fib = ds[idx]
+            seg, a, b = O.dataset_window(data, idx, src_len, overlap)
+            assert torch.equal(src, data[seg][a:b]) and src.data_ptr() == data[seg][a:b].data_ptr()   # a view, not a copy
+            assert torch.equal(src, T(g[f"{tag}.{idx}.src"])) and torch.equal(tgt, T(g[f"{tag}.{idx}.tgt"]))
+            assert torch.equal(tgt_o, T(g[f"{tag}.{idx}.tgto"])) and torch.equal(fib, T(g[f"{tag}.{idx}.ib"]))
+        with pytest.raises(IndexError):
+            ds[n]
+        b4 = ds.batch([0, 1])
+        assert b4[0].shape[0] == 2 and torch.equal(b4[1][1], T(g[f"{tag}.1.tgt"]))
+

@@ -45,6 +45,18 @@ def test_partition_and_unpatch_match_reference_golden(name):
         scalers.append(sc)
     out = MeshUnpatcher(part, groups, scalers).inverse_scale_and_unpatch(stacked)
     assert rel_l2(out.cpu().numpy(), g["unscaled"]) < 1e-6
+    # forward direction (sea_patchify): plain = the torch-indexing partition bit for bit; scaled against the reference; both layouts; row padding
+    assert torch.equal(plain.patchify_and_scale(fields).cpu(), torch.from_numpy(g["stacked"]))
+    mu = MeshUnpatcher(part, groups, scalers)
+    fwd = mu.patchify_and_scale(fields)
+    assert rel_l2(fwd.cpu().numpy(), g["scaled_stacked"]) < 1e-6
+    C = stacked.shape[2]
+    enc_in = mu.patchify_and_scale(fields, layout="BPFC", c_out=C + 3)                      # the encoder's [T, P, F, n_inp] input, cells padded to n_inp
+    assert torch.equal(enc_in[..., :C].permute(0, 1, 3, 2), fwd) and float(enc_in[..., C:].abs().max()) == 0.0
+    pad = torch.from_numpy(g["index_map"] < 0)
+    assert float(fwd.cpu()[:, pad].abs().max()) == 0.0 if pad.any() else True               # padded slots hold pad_field_value, unscaled
+    back = mu.inverse_scale_and_unpatch(fwd)                                                # scale -> partition -> un-partition -> un-scale = identity
+    assert rel_l2(back.cpu().numpy(), g["fields"]) < 1e-6
 
 
 def test_decode_then_unpatch_chain_against_oracle():
