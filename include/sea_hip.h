@@ -183,6 +183,11 @@ typedef struct {
     float* mean;
     float* rstd;
     int32_t ldx, ldmod, ldy32, ldyact;
+    /* optional addend (x f32, d <= 2048): x' = x + addend is what gets normalised; Xout <- x' when non-NULL (may be X itself) — the
+     * info-bottleneck add of models/temporal.py:140-142 folded into the AdaLN_2 pass that follows it */
+    const float* addend;  /* f32 [M, d] row stride ldadd, or NULL */
+    float* Xout;          /* f32 [M, d] row stride ldxout, or NULL */
+    int32_t ldadd, ldxout;
 } SeaNormGroup;
 
 int sea_rownorm(const SeaNormGroup* groups, int n_groups, int M, int d, int x_is_act, int gelu, float eps,
@@ -279,6 +284,12 @@ typedef struct {
 } SeaSiluGroup;
 
 int sea_silu_outer(const SeaSiluGroup* groups, int n_groups, const float* c, int M, int dtype, void* stream);
+/* The same launch with up to SEA_MAX_SILU_IB extra row passes that EVALUATE the information-bottleneck MLP of a block (SeaIbParams below;
+ * both depend on the condition only): ibs[k].X[0][m, :] = W2 . gelu(LN_h(w1 c[m] + b1)) + b2 is STORED (f32 [M, E], row stride ldx;
+ * n_fields, c and drop of ibs[k] are ignored).  A later sea_rownorm adds it through SeaNormGroup.addend: no launch of its own for the add. */
+#define SEA_MAX_SILU_IB 4
+struct SeaIbParams_;
+int sea_silu_outer_ib(const SeaSiluGroup* groups, int n_groups, const float* c, int M, int dtype, const struct SeaIbParams_* ibs, int n_ib, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Information-bottleneck add: ib = W2 . gelu(LN_h(w1 * c + b1)) + b2, then X_f += ib for every field f.
@@ -286,7 +297,7 @@ int sea_silu_outer(const SeaSiluGroup* groups, int n_groups, const float* c, int
  * (models/temporal.py:111-116,140-142) = MLP(1 -> h -> E) of models/base_blocks.py:22-26 with h = scale_ratio.
  * X: n_fields f32 [M, E] matrices (row stride ldx); all parameters f32; h <= 64.
  */
-typedef struct {
+typedef struct SeaIbParams_ {
     float* X[8];
     int32_t n_fields, ldx;
     const float* c;   /* [M] */
@@ -540,7 +551,7 @@ int sea_rowchain(const SeaChainLaunch* launch, const SeaChainStage* host_stages,
  * and plain, un-captured forwards are host-bound otherwise).  `op` selects the entry point, the other fields are its arguments:
  *     SEA_OP_GEMM   p0 = SeaGemmGroup[n]                          SEA_OP_QKV    p0 = SeaQkvGroup[n], p1 = SeaQkvCommon
  *     SEA_OP_ATTN   p0 = SeaAttnParams                            SEA_OP_NORM   p0 = SeaNormGroup[n], i0 = M, i1 = d, i2 = x_is_act, i3 = gelu, f0 = eps
- *     SEA_OP_SILU   p0 = SeaSiluGroup[n], p1 = c, i0 = M          SEA_OP_IB     p0 = SeaIbParams
+ *     SEA_OP_SILU   p0 = SeaSiluGroup[n], p1 = c, i0 = M, l0 = (intptr) SeaIbParams[l1] or 0, l1 = n_ib      SEA_OP_IB     p0 = SeaIbParams
  *     SEA_OP_CHAIN  p0 = SeaChainLaunch, p1 = host stage table    SEA_OP_CONVERT p0 = src, p1 = dst, l0 = lds, l1 = ldd, l2 = rows, l3 = cols
  *     SEA_OP_GEMM_NORM p0 = SeaGemmNormGroup[n], f0 = eps          SEA_OP_XTAIL  p0 = SeaExchangeTail, f0 = eps
  * Returns 0, or the failing entry's error code with sea_last_error() set (entries before it have been launched).

@@ -58,7 +58,8 @@ class SeaAttnParams(C.Structure):
 class SeaNormGroup(C.Structure):
     _fields_ = [("X", _vp), ("mod", _vp), ("gamma", _vp), ("beta", _vp), ("Y32", _vp), ("Yact", _vp),
                 ("mean", _vp), ("rstd", _vp),
-                ("ldx", _i32), ("ldmod", _i32), ("ldy32", _i32), ("ldyact", _i32)]
+                ("ldx", _i32), ("ldmod", _i32), ("ldy32", _i32), ("ldyact", _i32),
+                ("addend", _vp), ("Xout", _vp), ("ldadd", _i32), ("ldxout", _i32)]
 
 
 class SeaSiluGroup(C.Structure):
@@ -153,6 +154,7 @@ class SeaGemmNormGroup(C.Structure):
 
 
 XTAIL_MAX_SEG = 4
+MAX_SILU_IB = 4
 
 
 class SeaExchangeTail(C.Structure):
@@ -217,6 +219,8 @@ def lib() -> C.CDLL:
     L.sea_exchange_tail.restype = C.c_int
     L.sea_patchify.argtypes = [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _vp]
     L.sea_patchify.restype = C.c_int
+    L.sea_silu_outer_ib.argtypes = [C.POINTER(SeaSiluGroup), C.c_int, _vp, C.c_int, C.c_int, _vp, C.c_int, _vp]
+    L.sea_silu_outer_ib.restype = C.c_int
     L.sea_run_list.argtypes = [C.POINTER(SeaLaunchRec), C.c_int, _vp]
     L.sea_run_list.restype = C.c_int
     for name in ("sea_attention_bwd", "sea_wgrad_grouped", "sea_transpose_weights", "sea_rownorm_bwd", "sea_silu_outer_bwd", "sea_ib_bwd"):
@@ -244,7 +248,7 @@ EXPORTED_SYMBOLS = (
     "sea_attention_fwd", "sea_rownorm", "sea_silu_outer", "sea_ib_add", "sea_convert_f32_to_act", "sea_selftest_mfma",
     "sea_mse_fwd_bwd", "sea_relative_mse", "sea_adamw_flat",
     "sea_wgrad_grouped", "sea_transpose_weights", "sea_rownorm_bwd", "sea_silu_outer_bwd", "sea_ib_bwd",
-    "sea_attention_bwd", "sea_dropout_mask", "sea_rowchain", "sea_run_list", "sea_unpatchify", "sea_gemm_rownorm", "sea_exchange_tail", "sea_patchify",
+    "sea_attention_bwd", "sea_dropout_mask", "sea_rowchain", "sea_run_list", "sea_unpatchify", "sea_gemm_rownorm", "sea_exchange_tail", "sea_patchify", "sea_silu_outer_ib",
 )
 
 

@@ -35,7 +35,8 @@ extern "C" int sea_run_list(const SeaLaunchRec* recs, int n_recs, void* stream) 
             case SEA_OP_QKV: rc = sea_qkv_rope_grouped(static_cast<const SeaQkvGroup*>(R.p0), R.n, static_cast<const SeaQkvCommon*>(R.p1), R.dtype, stream); break;
             case SEA_OP_ATTN: rc = sea_attention_fwd(static_cast<const SeaAttnParams*>(R.p0), R.dtype, stream); break;
             case SEA_OP_NORM: rc = sea_rownorm(static_cast<const SeaNormGroup*>(R.p0), R.n, R.i0, R.i1, R.i2, R.i3, R.f0, R.dtype, stream); break;
-            case SEA_OP_SILU: rc = sea_silu_outer(static_cast<const SeaSiluGroup*>(R.p0), R.n, static_cast<const float*>(R.p1), R.i0, R.dtype, stream); break;
+            case SEA_OP_SILU: rc = sea_silu_outer_ib(static_cast<const SeaSiluGroup*>(R.p0), R.n, static_cast<const float*>(R.p1), R.i0, R.dtype,
+                                                     reinterpret_cast<const SeaIbParams*>(static_cast<intptr_t>(R.l0)), (int)R.l1, stream); break;
             case SEA_OP_IB: rc = sea_ib_add(static_cast<const SeaIbParams*>(R.p0), stream); break;
             case SEA_OP_CHAIN: rc = sea_rowchain(static_cast<const SeaChainLaunch*>(R.p0), static_cast<const SeaChainStage*>(R.p1), R.dtype, stream); break;
             case SEA_OP_CONVERT: rc = sea_convert_f32_to_act(static_cast<const float*>(R.p0), R.l0, const_cast<void*>(R.p1), R.l1, R.l2, R.l3, R.dtype, stream); break;

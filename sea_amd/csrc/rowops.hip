@@ -52,6 +52,15 @@ __global__ __launch_bounds__(256) void rownorm_kernel(const NormLaunch L) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) xv[k][e] = 0.f;
             if (i < d) load4(x + i, xv[k]);
+            if constexpr (!X_IS_ACT) {
+                if (G.addend != nullptr && i < d) {   // x' = x + addend (info-bottleneck term), written back for the residual consumers
+                    float av[4];
+                    load4(G.addend + (int64_t)row * G.ldadd + i, av);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) xv[k][e] += av[e];
+                    if (G.Xout != nullptr) store4(G.Xout + (int64_t)row * G.ldxout + i, xv[k][0], xv[k][1], xv[k][2], xv[k][3]);
+                }
+            }
             if constexpr (PRE) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) gm[k][e] = bt[k][e] = mw[k][e] = mb[k][e] = 0.f;
@@ -149,6 +158,9 @@ extern "C" int sea_rownorm(const SeaNormGroup* groups, int n_groups, int M, int 
     for (int i = 0; i < n_groups; ++i) {
         const SeaNormGroup& G = groups[i];
         SEA_REQUIRE(G.X && G.gamma && (G.Y32 || G.Yact), "sea_rownorm[%d]: null pointer", i);
+        SEA_REQUIRE(!G.addend || (!x_is_act && d <= 2048 && G.ldadd % 4 == 0 && G.ldadd >= d && sea_aligned16(G.addend) && sea_aligned16(G.Xout) &&
+                                  (!G.Xout || (G.ldxout % 4 == 0 && G.ldxout >= d))), "sea_rownorm[%d]: addend needs f32 x, d <= 2048, aligned rows", i);
+        SEA_REQUIRE(G.addend || !G.Xout, "sea_rownorm[%d]: Xout without addend", i);
         SEA_REQUIRE(G.ldx % 4 == 0 && G.ldx >= d, "sea_rownorm[%d]: bad ldx=%d", i, G.ldx);
         SEA_REQUIRE(!G.mod || (G.ldmod % 4 == 0 && G.ldmod >= 2 * d), "sea_rownorm[%d]: bad ldmod=%d", i, G.ldmod);
         SEA_REQUIRE(!G.Y32 || (G.ldy32 % 4 == 0 && G.ldy32 >= d), "sea_rownorm[%d]: bad ldy32=%d", i, G.ldy32);
@@ -185,16 +197,67 @@ struct SiluLaunch {
     SeaSiluGroup g[SEA_MAX_SILU_GROUPS];
     const float* c;
     int M;
+    int n_groups;
+};
+struct SiluIbLaunch {
+    SeaIbParams ib[SEA_MAX_SILU_IB];
 };
 
+// one row of the information-bottleneck MLP, stored (the wave-per-row body of ib_add_kernel without the add)
+__device__ __forceinline__ void ib_store_row(const SeaIbParams& P, float cv, int row, int lane) {
+    const int h = P.h;
+    const bool act = lane < h;
+    const float pre = act ? P.w1[lane] * cv + P.b1[lane] : 0.f;
+    const float mean = wave_sum(pre) / (float)h;
+    const float cen = act ? pre - mean : 0.f;
+    const float var = wave_sum(cen * cen) / (float)h;
+    const float rstd = 1.0f / sqrtf(var + 1e-5f);
+    const float hid = act ? gelu_erf(cen * rstd * P.lnw[lane] + P.lnb[lane]) : 0.f;
+    for (int e0 = lane * 4; e0 < P.E; e0 += 256) {
+        float o[4];
+        load4(P.b2 + e0, o);
+        if ((h & 3) == 0) {   // rows of w2 are whole 16-byte chunks: all of them requested before the first use (one memory round trip, not h)
+            for (int k0 = 0; k0 < h; k0 += 4) {
+                float w[4][4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) load4(P.w2 + (int64_t)(e0 + e) * h + k0, w[e]);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float hk = __shfl(hid, k0 + k);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] += w[e][k] * hk;
+                }
+            }
+        } else {
+            for (int k = 0; k < h; ++k) {
+                const float hk = __shfl(hid, k);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] += P.w2[(int64_t)(e0 + e) * h + k] * hk;
+            }
+        }
+        store4(P.X[0] + (int64_t)row * P.ldx + e0, o[0], o[1], o[2], o[3]);
+    }
+}
+
 // grid = (ceil(M/4), n_groups): one wave per row, lanes stride over the K2 columns 4 at a time.
-template <typename T>
-__global__ __launch_bounds__(256) void silu_outer_kernel(const SiluLaunch L) {
-    const SeaSiluGroup& G = L.g[blockIdx.y];
+template <typename T, bool WITH_IB>
+__global__ __launch_bounds__(256) void silu_outer_kernel(const SiluLaunch L, const SiluIbLaunch I) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= L.M) return;
     const float cv = L.c[row];
+    int gy = blockIdx.y;
+    if constexpr (WITH_IB) {
+        // the info-bottleneck passes take the FIRST grid rows: they are the longer ones (a dependent LayerNorm + GELU + h-term dot per element) and
+        // dispatch is in grid order — last, they were a 2.5 us tail of the launch
+        const int n_ib = (int)gridDim.y - L.n_groups;
+        if (gy < n_ib) {   // block-uniform
+            ib_store_row(I.ib[gy], cv, row, lane);
+            return;
+        }
+        gy -= n_ib;
+    }
+    const SeaSiluGroup& G = L.g[gy];
     T* out = static_cast<T*>(G.Hid) + (int64_t)row * G.ld;
     for (int i = lane * 4; i < G.K2; i += 256) {
         float w[4], bb[4];
@@ -205,7 +268,20 @@ __global__ __launch_bounds__(256) void silu_outer_kernel(const SiluLaunch L) {
 }
 
 extern "C" int sea_silu_outer(const SeaSiluGroup* groups, int n_groups, const float* c, int M, int dtype, void* stream) {
+    return sea_silu_outer_ib(groups, n_groups, c, M, dtype, nullptr, 0, stream);
+}
+
+extern "C" int sea_silu_outer_ib(const SeaSiluGroup* groups, int n_groups, const float* c, int M, int dtype, const SeaIbParams* ibs, int n_ib, void* stream) {
     SEA_REQUIRE(groups != nullptr && c != nullptr && n_groups >= 1 && n_groups <= SEA_MAX_SILU_GROUPS && M >= 1, "sea_silu_outer: bad arguments (n_groups=%d, M=%d)", n_groups, M);
+    SEA_REQUIRE(n_ib >= 0 && n_ib <= SEA_MAX_SILU_IB && (n_ib == 0 || ibs != nullptr), "sea_silu_outer_ib: n_ib=%d out of range", n_ib);
+    SiluIbLaunch I;
+    memset(&I, 0, sizeof(I));
+    for (int k = 0; k < n_ib; ++k) {
+        const SeaIbParams& P = ibs[k];
+        SEA_REQUIRE(P.X[0] && sea_aligned16(P.X[0]) && P.E >= 4 && P.E % 4 == 0 && P.h >= 1 && P.h <= 64 && P.ldx >= P.E && P.ldx % 4 == 0 && P.w1 && P.b1 && P.lnw && P.lnb && P.w2 &&
+                        P.b2 && sea_aligned16(P.b2), "sea_silu_outer_ib: ib[%d]: bad sizes / null / misaligned pointer", k);
+        I.ib[k] = P;
+    }
     SEA_REQUIRE(dtype == SEA_F32 || dtype == SEA_BF16, "sea_silu_outer: bad dtype %d", dtype);
     SiluLaunch L;
     memset(&L, 0, sizeof(L));
@@ -215,11 +291,16 @@ extern "C" int sea_silu_outer(const SeaSiluGroup* groups, int n_groups, const fl
         SEA_REQUIRE(sea_aligned16(G.w1) && sea_aligned16(G.b1) && sea_aligned16(G.Hid), "sea_silu_outer[%d]: pointers must be 16-byte aligned", i);
         L.g[i] = G;
     }
-    L.c = c; L.M = M;
-    const dim3 grid((M + 3) / 4, n_groups), block(256);
+    L.c = c; L.M = M; L.n_groups = n_groups;
+    const dim3 grid((M + 3) / 4, n_groups + n_ib), block(256);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (dtype == SEA_BF16) silu_outer_kernel<__bf16><<<grid, block, 0, s>>>(L);
-    else silu_outer_kernel<float><<<grid, block, 0, s>>>(L);
+    if (n_ib > 0) {
+        if (dtype == SEA_BF16) silu_outer_kernel<__bf16, true><<<grid, block, 0, s>>>(L, I);
+        else silu_outer_kernel<float, true><<<grid, block, 0, s>>>(L, I);
+    } else {
+        if (dtype == SEA_BF16) silu_outer_kernel<__bf16, false><<<grid, block, 0, s>>>(L, I);
+        else silu_outer_kernel<float, false><<<grid, block, 0, s>>>(L, I);
+    }
     SEA_CHECK_LAUNCH("sea_silu_outer");
     return SEA_OK;
 }

@@ -271,6 +271,9 @@ class Plan:
                 g.Y32, g.ldy32 = N.ptr(y32), gd.get("ldy32", y32.stride(0) if y32 is not None else 0)
                 g.Yact, g.ldyact = N.ptr(yact), (yact.stride(0) if yact is not None else 0)
                 g.mean, g.rstd = N.ptr(gd.get("mean")), N.ptr(gd.get("rstd"))
+                add, xout = gd.get("addend"), gd.get("Xout")
+                g.addend, g.ldadd = N.ptr(add), (add.stride(0) if add is not None else 0)
+                g.Xout, g.ldxout = N.ptr(xout), (xout.stride(0) if xout is not None else 0)
                 if gd.get("X_is_x") is not None:
                     self._x_patches.append((g, "X", gd["X_is_x"]))
                 if gd.get("Y_is_out") is not None:
@@ -355,8 +358,8 @@ class Plan:
         # only (the weight gradient of cond_mlp.2 reads the hidden matrix).  The operand is recomputed by every column tile of a row panel (4x at
         # N = 512), VALU work that pays only once the hidden matrix's HBM round trip is the larger cost: measured 0.2685 against 0.2671 ms at cfg2
         # (M = 2024: not used), 1.215 against 1.241 ms at B = 8 (used).  SEA_FUSE_SILU=1|0 forces.
-        want = os.environ.get("SEA_FUSE_SILU", "auto")
-        gen_a = (type(self) is Plan and all(2 * d <= 1024 for _, d in first + rest) and (want == "1" or (want == "auto" and M >= 8192)))
+        gen_a = self._gen_a(first + rest)
+        ib_todo = list(getattr(self, "_ib_fold", []))   # (layer prefix, ibuf): info-bottleneck MLPs evaluated by extra row passes of the first silu launch
 
         def emit(inst, tag):
             silu_groups, gemm_groups = [], []
@@ -379,7 +382,16 @@ class Plan:
                 arr = (N.SeaSiluGroup * len(chunk))()
                 for g, (w1, b1, hid) in zip(arr, chunk):
                     g.w1, g.b1, g.Hid, g.K2, g.ld = w1.data_ptr(), b1.data_ptr(), hid.data_ptr(), hid.shape[1], hid.stride(0)
-                rec = self._rec(L.sea_silu_outer, [arr, len(chunk), None, M, self.code], "adaln.silu" + tag, arr)
+                ibs, n_ib = None, 0
+                if ib_todo:
+                    n_ib = len(ib_todo)
+                    ibs = (N.SeaIbParams * n_ib)()
+                    for ibp, (lpre, ibuf) in zip(ibs, ib_todo):
+                        q = self._ib_params(lpre)
+                        ibp.X[0], ibp.n_fields, ibp.ldx, ibp.M, ibp.E, ibp.h = ibuf.data_ptr(), 1, ibuf.stride(0), M, self.E, q["h"]
+                        ibp.w1, ibp.b1, ibp.lnw, ibp.lnb, ibp.w2, ibp.b2 = (q[k].data_ptr() for k in ("w1", "b1", "lnw", "lnb", "w2", "b2"))
+                    ib_todo.clear()
+                rec = self._rec(L.sea_silu_outer_ib, [arr, len(chunk), None, M, self.code, ibs, n_ib], "adaln.silu" + tag, (arr, ibs))
                 self._c_patches.append((rec.args, 2))
                 self._cur.append(rec)
             self._gemm(gemm_groups, "adaln.cond_gemm" + tag)
@@ -392,6 +404,11 @@ class Plan:
         emit(rest, ".rest")
         self._end_lane()
         return mods
+
+    def _gen_a(self, inst) -> bool:
+        """AdaLN condition MLPs with the generated GEMM operand (no silu launch)?  Long launches only, see _cond_mods."""
+        want = os.environ.get("SEA_FUSE_SILU", "auto")
+        return type(self) is Plan and all(2 * d <= 1024 for _, d in inst) and (want == "1" or (want == "auto" and self.M >= 8192))
 
     # ------------------------------------------------------------------ the plan
     def _build(self) -> None:
@@ -418,6 +435,14 @@ class Plan:
         # per-field launches trades 2 launches (~13 us) for 3 x ~8 us of extra epilogue on the serial Gauss-Seidel chain.
         fuse_tail = (fuse_norm and xmode == "sea" and has_ib and os.environ.get("SEA_FUSE_TAIL", "0") == "1" and F > 1 and eng.model.add_info_after_cross and not lanes
                      and E <= 256 and E % 16 == 0 and eng.model.ib_hidden in (4, 8))
+        # the info-bottleneck add without a launch of its own: its MLP depends on the condition only, so it is EVALUATED by extra row passes of the silu
+        # launch (into ibuf) and ADDED by the AdaLN_2 pass that follows it anyway (SeaNormGroup.addend).  Needs the silu launch (adaln, short launches)
+        # and the add after the exchange; SEA_FOLD_IB=0 keeps sea_ib_add.
+        fold_ib = (type(self) is Plan and has_ib and eng.model.add_info_after_cross and self.adaln and not fuse_tail and not lanes and not split_cond
+                   and self.L <= N.MAX_SILU_IB and E <= 2048 and os.environ.get("SEA_FOLD_IB", "1") != "0"
+                   and not self._gen_a([(None, E), (None, D)]))
+        ibufs = [self._buf(M, E, dtype=f32) for _ in range(self.L)] if fold_ib else None
+        self._ib_fold = [(f"blocks.{l}.", ibufs[l]) for l in range(self.L)] if fold_ib else []
         mods = self._cond_mods(split=split_cond)
         cond_joined = not split_cond
 
@@ -571,17 +596,17 @@ class Plan:
                 for i in range(F - 1):
                     self._join(2 + i)
                 continue
-            if eng.model.add_info_after_cross and has_ib and not fuse_tail:
+            if eng.model.add_info_after_cross and has_ib and not fuse_tail and not fold_ib:
                 self._ib(pre, xr)
             # opt-in (SEA_FUSE_FINAL=1): measured at cfg2 the fused proj + final norm is 14.5 us against 6.8 + 4.8 for the pair (N = 256 with 16-row
             # tiles: every workgroup stages the whole 256 x 256 weight); at B = 8 (64-row tiles) the two forms tie
             fused_final = last and fuse_norm and E <= 256 and E % 16 == 0 and os.environ.get("SEA_FUSE_FINAL", "0") == "1"
-            self._mlp_proj(pre, list(range(F)), xr, xa, n_e, hbuf, hg, mods, False, fuse_final=fused_final, skip_adaln2=fuse_tail)
+            self._mlp_proj(pre, list(range(F)), xr, xa, n_e, hbuf, hg, mods, False, fuse_final=fused_final, skip_adaln2=fuse_tail, addend=(ibufs[l] if fold_ib else None))
         if not lanes and not fused_final:
             # -- final per-field norm, written straight into out[B,T,F,E]
             self._norm([dict(X=xr[i], Y32=xr[i], ldy32=FE, Y_is_out=i * E * 4, **norm_params(f"ln.{i}.", E)) for i in range(F)], E, "final.norm")
 
-    def _mlp_proj(self, pre, fields, xr, xm, n_e, hbuf, hg, mods, final_norm, tag="", fuse_final=False, skip_adaln2=False) -> None:
+    def _mlp_proj(self, pre, fields, xr, xm, n_e, hbuf, hg, mods, final_norm, tag="", fuse_final=False, skip_adaln2=False, addend=None) -> None:
         """x_i += W2 gelu(LN(W1 AdaLN_2(x_i))) ; x_i = proj_i(x_i) for the listed fields (models/temporal.py:143-146), optionally followed
         by the model's final per-field norm written straight into out (models/temporal.py:412-415)."""
         P, E, S, FE = self.eng.params, self.E, self.S, self.F * self.E
@@ -592,7 +617,8 @@ class Plan:
             return dict(gamma=P.f32_vec(p_ + "weight"))
 
         if not skip_adaln2:
-            self._norm([dict(X=xr[i], Yact=n_e[i], **norm_params(f"{pre}ln.exp.{i}.2.", E)) for i in fields], E, "mlp.adaln2" + tag)
+            extra = (lambda i: dict(addend=addend, Xout=xr[i])) if addend is not None else (lambda i: {})   # x_i += ib rides in this pass
+            self._norm([dict(X=xr[i], Yact=n_e[i], **extra(i), **norm_params(f"{pre}ln.exp.{i}.2.", E)) for i in fields], E, ("mlp.ib_adaln2" if addend is not None else "mlp.adaln2") + tag)
         self._gemm([dict(A=n_e[i], W=P.act(f"{pre}mlp.{i}.layers.0.weight"), bias=P.f32_vec(f"{pre}mlp.{i}.layers.0.bias"), Cact=hbuf[i])
                     for i in fields], "mlp.fc1" + tag)
         self._norm([dict(X=hbuf[i], gamma=P.f32_vec(f"{pre}mlp.{i}.layers.1.weight"), beta=P.f32_vec(f"{pre}mlp.{i}.layers.1.bias"), Yact=hg[i])
@@ -838,8 +864,10 @@ class Plan:
                 c.op, c.p0, c.n, c.f0, c.dtype = N.OP_GEMM_NORM, addr(a[0]), a[1], a[2], a[3]
             elif r.fn is L.sea_rownorm:
                 c.op, c.p0, c.n, c.i0, c.i1, c.i2, c.i3, c.f0, c.dtype = N.OP_NORM, addr(a[0]), a[1], a[2], a[3], a[4], a[5], a[6], a[7]
-            elif r.fn is L.sea_silu_outer:
+            elif r.fn is L.sea_silu_outer or r.fn is L.sea_silu_outer_ib:
                 c.op, c.p0, c.n, c.i0, c.dtype = N.OP_SILU, addr(a[0]), a[1], a[3], a[4]
+                if r.fn is L.sea_silu_outer_ib and a[5] is not None:
+                    c.l0, c.l1 = addr(a[5]), a[6]
                 relink.append((i, "p1", a, 2))
             elif r.fn is L.sea_ib_add:
                 c.op, c.p0 = N.OP_IB, addr(r.keep)

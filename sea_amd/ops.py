@@ -134,6 +134,9 @@ def rownorm(groups: Sequence[Dict], M: int, d: int, x_is_act: bool, gelu: bool, 
         g.Y32, g.ldy32 = N.ptr(y32), (y32.stride(0) if y32 is not None else 0)
         g.Yact, g.ldyact = N.ptr(yact), (yact.stride(0) if yact is not None else 0)
         g.mean, g.rstd = N.ptr(gd.get("mean")), N.ptr(gd.get("rstd"))
+        add, xout = gd.get("addend"), gd.get("Xout")
+        g.addend, g.ldadd = N.ptr(add), (add.stride(0) if add is not None else 0)
+        g.Xout, g.ldxout = N.ptr(xout), (xout.stride(0) if xout is not None else 0)
     N.check(N.lib().sea_rownorm(arr, n, M, d, int(x_is_act), int(gelu), eps, N.dtype_code(dtype), N.stream_ptr()), "sea_rownorm")
 
 

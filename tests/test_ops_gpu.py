@@ -402,6 +402,47 @@ def test_gemm_rownorm_rejects_bad_shapes():
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+def test_silu_launch_evaluates_ib_and_rownorm_adds_it(dtype):
+    """The info-bottleneck add without a launch of its own: sea_silu_outer_ib stores ib(c) (two blocks' MLPs here) beside the silu rows, and
+    sea_rownorm's addend adds it, writes x + ib back and normalises that — against sea_ib_add followed by the plain row norm (bitwise) and the formula."""
+    import ctypes as C
+    from sea_amd import _native as N, ops
+
+    M, E, h, K2 = 203, 256, 8, 512
+    c = torch.rand(M, device=dev())
+    w1s, b1s, hid = rnd(K2, seed=900), rnd(K2, seed=901), torch.empty(M, K2, device=dev(), dtype=dtype)
+    arr = (N.SeaSiluGroup * 1)()
+    arr[0].w1, arr[0].b1, arr[0].Hid, arr[0].K2, arr[0].ld = w1s.data_ptr(), b1s.data_ptr(), hid.data_ptr(), K2, K2
+    ibs = (N.SeaIbParams * 2)()
+    prm, bufs = [], []
+    for k in range(2):
+        q = dict(w1=rnd(h, seed=910 + k), b1=rnd(h, seed=920 + k), lnw=1 + 0.1 * rnd(h, seed=930 + k), lnb=0.1 * rnd(h, seed=940 + k),
+                 w2=rnd(E, h, scale=0.3, seed=950 + k), b2=0.1 * rnd(E, seed=960 + k))
+        buf = torch.full((M, E), float("nan"), device=dev())
+        ibs[k].X[0], ibs[k].n_fields, ibs[k].ldx, ibs[k].M, ibs[k].E, ibs[k].h = buf.data_ptr(), 1, E, M, E, h
+        ibs[k].w1, ibs[k].b1, ibs[k].lnw, ibs[k].lnb, ibs[k].w2, ibs[k].b2 = (q[n].data_ptr() for n in ("w1", "b1", "lnw", "lnb", "w2", "b2"))
+        prm.append(q)
+        bufs.append(buf)
+    N.check(N.lib().sea_silu_outer_ib(arr, 1, c.data_ptr(), M, N.dtype_code(dtype), ibs, 2, N.stream_ptr()), "sea_silu_outer_ib")
+    assert rel(hid.float(), torch.nn.functional.silu(c[:, None] * w1s + b1s)) < tol(dtype, f32=1e-5)
+    for q, buf in zip(prm, bufs):
+        ref = gelu(torch.nn.functional.layer_norm(c[:, None] * q["w1"] + q["b1"], (h,), q["lnw"], q["lnb"], 1e-5)) @ q["w2"].t() + q["b2"]
+        assert rel(buf, ref) < 2e-5
+    # the add rides in the row norm
+    x = rnd(M, E, seed=970) * 1.3
+    mod = rnd(M, 2 * E, dtype=dtype, scale=0.5, seed=971)
+    gamma, beta = 1 + 0.1 * rnd(E, seed=972), 0.1 * rnd(E, seed=973)
+    xa, ya = x.clone(), torch.empty(M, E, device=dev(), dtype=dtype)
+    ops.rownorm([dict(X=xa, addend=bufs[0], Xout=xa, mod=mod, gamma=gamma, beta=beta, Yact=ya)], M, E, False, False, 1e-5, dtype)
+    xb, yb = x.clone(), torch.empty(M, E, device=dev(), dtype=dtype)
+    q = prm[0]
+    ops.ib_add([xb], c, q["w1"], q["b1"], q["lnw"], q["lnb"], q["w2"], q["b2"])
+    ops.rownorm([dict(X=xb, mod=mod, gamma=gamma, beta=beta, Yact=yb)], M, E, False, False, 1e-5, dtype)
+    assert rel(xa, xb) < 1e-6 and rel(ya.float(), yb.float()) < tol(dtype, f32=1e-6, bf16=4e-3)
+    assert rel(xa, x + bufs[0]) < 1e-7
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 def test_rownorm_ln_gelu_act_input(dtype):
     from sea_amd import ops
 
