@@ -385,67 +385,86 @@ __global__ __launch_bounds__(256) void gemm_rownorm16_kernel(const GemmNormLaunc
 
 // ---------------------------------------------------------------------------------------------- exchange tail (three Linear layers, 16 rows)
 // One field's exchange stage after its cross-attention launch, sea_exchange_tail (include/sea_hip.h):
-//   stage 1  g_s = gelu(att_s . Wp_s^T)         both operands straight from L2 into MFMA fragments (2 x 32 KiB of weights: no LDS staging), result
-//                                               packed to bf16 into the A rows of the stage-2 K-tiles in LDS
-//   stage 2  x += sum_s g_s . Wup^T + S bup     Wup (E x S*D bf16 = 128 KiB at cfg2) arrives by ONE global_load_lds burst issued before stage 1;
-//                                               x (fp32) updated in place, its bf16 copy goes to LDS as the A tile of stage 3
-//   stage 3  y = AdaLN(x . Wdown^T + bdown)     Wdown fragments requested from L2 before stage 2 runs, rows normalised by NormEpilogue
-// A workgroup = 4 waves owns 16 rows; wave w owns the column quarter w of every stage's output.  LDS: nk (16 + E) 128 B + 16 E 2 B + 512 B.
+//   stage 1  g = sum_s gelu(att_s . Wp_s^T)     per segment a [16 x D] x [D x D] product; the GELU outputs are summed in fp32 (cross_up is linear and
+//                                               shared by the segments: sum_s g_s Wup^T = (sum_s g_s) Wup^T) and packed to bf16 once, as the A rows of stage 2
+//   stage 2  x += g . Wup^T + S bup             x (fp32) updated in place; its bf16 copy goes to LDS as the A tile of stage 3
+//   stage 3  y = AdaLN(x . Wdown^T + bdown)     rows normalised by NormEpilogue
+// EVERY operand matrix goes L2 -> LDS by global_load_lds bursts (full 128-byte lines, no VGPRs): a probe build showed that MFMA fragments loaded
+// straight from global memory — 16 rows x 64 B per wave-instruction — cost ~4x their bytes in the CU's memory pipeline (Wdown alone +1.6 us, the
+// kernel 11.9 us against 7.7 without stage 3).  att_s, Wp_s and Wup are requested at once up front; Wdown takes over the Wp region as soon as
+// stage 1 has read it and lands under stage 2.
+// A workgroup = 4 waves owns 16 rows; wave w owns the column quarter w of every stage's output.
+// LDS: R1 = S (D/64) K-tiles of (16 + D) rows (att_s | Wp_s; later D/.. Wdown K-tiles), R2 = (D/64) K-tiles of (16 + E) rows (g | Wup), the bf16 x
+// tile [16, E], 512 B for the statistics: 152 KB at D = 128, E = 256, S = 2.
 struct XTailLaunch {
     SeaExchangeTail p;
     float eps;
 };
 
 template <int D, int E>
+struct XTailCfg {
+    static constexpr int BM = 16, BKB = 128, BK = 64;
+    static constexpr int KT1 = D / BK;                       // K-tiles of stage 1 (per segment) and of stage 2
+    static constexpr int KT3 = E / BK;                       // K-tiles of stage 3
+    static constexpr int ST1 = (BM + D) * BKB;               // stage-1 tile: att rows, then Wp rows
+    static constexpr int ST2 = (BM + E) * BKB;               // stage-2 tile: g rows, then Wup rows
+    static constexpr int ST3 = D * BKB;                      // stage-3 tile: Wdown rows (the A rows live in the x tile)
+    static constexpr int SMAX = D == 128 ? 2 : 4;
+    static __host__ __device__ constexpr int r1_bytes(int S) { return S * KT1 * ST1 > KT3 * ST3 ? S * KT1 * ST1 : KT3 * ST3; }
+    static __host__ __device__ constexpr int lds_bytes(int S) { return r1_bytes(S) + KT1 * ST2 + BM * E * 2 + 512; }
+};
+
+template <int D, int E>
 __global__ __launch_bounds__(256) void exchange_tail_kernel(const XTailLaunch L) {
     using T = __bf16;
-    constexpr int BM = 16, BKB = 128, BK = 64;
-    constexpr int ROWS = BM + E, STAGE = ROWS * BKB;
-    constexpr int SMAX = 256 / D;                   // segments whose K-tiles fit 4 stages
-    constexpr int NI1 = D / 64, KS1 = D / 32;       // stage 1: 16-column blocks per wave, 32-wide contraction steps
-    constexpr int NI2 = E / 64;
-    constexpr int NI3 = D / 64, KS3 = E / 32;
+    using C = XTailCfg<D, E>;
+    constexpr int BM = C::BM, BKB = C::BKB, BK = C::BK, KT1 = C::KT1, KT3 = C::KT3, ST1 = C::ST1, ST2 = C::ST2, ST3 = C::ST3, SMAX = C::SMAX;
+    constexpr int NI1 = D / 64, NI2 = E / 64, NI3 = D / 64;       // 16-column blocks per wave in each stage
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const SeaExchangeTail& P = L.p;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 15, g = lane >> 4;
     const int m0 = blockIdx.x * BM, M = P.M, S = P.n_seg;
-    const int nk = S * D / BK;
-    char* x3 = smem + nk * STAGE;                                   // bf16 [16, E] A tile of stage 3, K-tile layout with 16 rows per tile
+    char* R1 = smem;
+    char* R2 = smem + C::r1_bytes(S);
+    char* x3 = R2 + KT1 * ST2;
     float* red = reinterpret_cast<float*>(x3 + BM * E * 2);
     const int m = m0 + r;
     const bool mok = m < M;
     const int mc = mok ? m : M - 1;
 
-    // ---- stage-1 operands first: everything else of this kernel waits for them
-    uint4 a1[SMAX][KS1], w1[SMAX][NI1][KS1];
-#pragma unroll
-    for (int s = 0; s < SMAX; ++s) {
-        if (s < S) {
-            const T* att = static_cast<const T*>(P.att[s]) + (int64_t)mc * P.ldatt + g * 8;
-            const T* Wp = static_cast<const T*>(P.Wp[s]) + (int64_t)(wave * (D / 4) + r) * P.ldwp + g * 8;
-#pragma unroll
-            for (int kc = 0; kc < KS1; ++kc) {
-                a1[s][kc] = *reinterpret_cast<const uint4*>(att + kc * 32);
-#pragma unroll
-                for (int jb = 0; jb < NI1; ++jb) w1[s][jb][kc] = *reinterpret_cast<const uint4*>(Wp + (int64_t)jb * 16 * P.ldwp + kc * 32);
+    const unsigned lds_base = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)smem);
+    const unsigned r2_base = lds_base + (unsigned)C::r1_bytes(S);
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
+    const int rl = lane >> 3;
+    const int chunk = (lane & 7) ^ (rl & 7);   // swizzle on the source side: LDS position p of a row holds chunk p ^ (row & 7)
+    // ---- burst 1: att_s | Wp_s K-tiles (R1) and the Wup rows of the stage-2 K-tiles (R2)
+    for (int s = 0; s < S; ++s) {
+        const T* att = static_cast<const T*>(P.att[s]);
+        const T* Wp = static_cast<const T*>(P.Wp[s]);
+        for (int kt = 0; kt < KT1; ++kt) {
+            const int k0 = kt * BK + chunk * 8;
+            for (int u = wv; u < (BM + D) / 8; u += 4) {
+                const int row = u * 8 + rl;
+                const T* p;
+                if (u < BM / 8) {
+                    int mr = m0 + row;
+                    mr = mr < M ? mr : M - 1;
+                    p = att + (int64_t)mr * P.ldatt + k0;
+                } else {
+                    p = Wp + (int64_t)(row - BM) * P.ldwp + k0;
+                }
+                glds16_gn(p, lds_base + (unsigned)((s * KT1 + kt) * ST1 + u * 8 * BKB));
             }
         }
     }
-    // ---- Wup -> LDS, all K-tiles, one burst (rows 16.. of every stage; the A rows 0..15 are written by stage 1); issued after the stage-1 operand
-    // requests, which are the critical path
     {
-        const unsigned lds_base = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)smem);
-        const int wv = __builtin_amdgcn_readfirstlane(wave);
-        const int rl = lane >> 3;
-        const int chunk = (lane & 7) ^ (rl & 7);
         const T* Wup = static_cast<const T*>(P.Wup);
-        for (int kt = 0; kt < nk; ++kt) {
-            const int kin = (kt * BK) % D;                          // every segment contracts against the same Wup columns
+        for (int kt = 0; kt < KT1; ++kt)
             for (int u = wv; u < E / 8; u += 4)
-                glds16_gn(Wup + (int64_t)(u * 8 + rl) * P.ldwup + kin + chunk * 8, lds_base + (unsigned)(kt * STAGE + (BM + u * 8) * BKB));
-        }
+                glds16_gn(Wup + (int64_t)(u * 8 + rl) * P.ldwup + kt * BK + chunk * 8, r2_base + (unsigned)(kt * ST2 + (BM + u * 8) * BKB));
     }
+    // ---- epilogue operands of stages 2 and 3 (a few KB per workgroup, ordinary loads)
     float bv2[NI2][4], rv2[NI2][4];
 #pragma unroll
     for (int j = 0; j < NI2; ++j) {
@@ -459,42 +478,62 @@ __global__ __launch_bounds__(256) void exchange_tail_kernel(const XTailLaunch L)
         }
         load4(P.X + (int64_t)mc * P.ldx + n, rv2[j]);
     }
-    // ---- stage-3 operands (no dependence on stages 1-2): requested up front as well
-    uint4 wd[NI3][KS3];
     NormEpilogue<T, NI3, true, true> epi3;
-    if (P.has_down) {
-        const T* Wd = static_cast<const T*>(P.down.W) + (int64_t)(wave * (D / 4) + r) * P.down.ldw + g * 8;
+    if (P.has_down) epi3.prefetch(P.down, mc, wave * (D / 4), g);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the LDS-DMA bursts are not tracked by the compiler
+    __syncthreads();
+    // ---- stage 1: g = sum_s gelu(att_s . Wp_s^T), this wave's D/4 columns
+    float gsum[NI1][4];
 #pragma unroll
-        for (int jb = 0; jb < NI3; ++jb)
+    for (int jb = 0; jb < NI1; ++jb)
 #pragma unroll
-            for (int kc = 0; kc < KS3; ++kc) wd[jb][kc] = *reinterpret_cast<const uint4*>(Wd + (int64_t)jb * 16 * P.down.ldw + kc * 32);
-        epi3.prefetch(P.down, mc, wave * (D / 4), g);
-    }
-    // ---- stage 1
+        for (int q = 0; q < 4; ++q) gsum[jb][q] = 0.f;
 #pragma unroll
     for (int s = 0; s < SMAX; ++s) {
         if (s < S) {
+            f32x4 acc1[NI1];
 #pragma unroll
-            for (int jb = 0; jb < NI1; ++jb) {
-                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            for (int jb = 0; jb < NI1; ++jb) acc1[jb] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int kc = 0; kc < KS1; ++kc) mma16<T>(w1[s][jb][kc], a1[s][kc], acc);
-                const int kk = s * D + wave * (D / 4) + jb * 16 + g * 4;      // this lane's 4 consecutive contraction indices of stage 2, row r
-                const int kt = kk / BK, cc = kk % BK;
-                store4(reinterpret_cast<T*>(smem + kt * STAGE + r * BKB + (((cc >> 3) ^ (r & 7)) << 4) + (cc & 7) * 2),
-                       gelu_erf(acc[0]), gelu_erf(acc[1]), gelu_erf(acc[2]), gelu_erf(acc[3]));
+            for (int kt = 0; kt < KT1; ++kt) {
+                const char* sA = R1 + (s * KT1 + kt) * ST1 + r * BKB;
+                const char* sB = R1 + (s * KT1 + kt) * ST1 + (BM + wave * (D / 4) + r) * BKB;
+#pragma unroll
+                for (int kc = 0; kc < 2; ++kc) {
+                    const int off = ((kc * 4 + g) ^ (r & 7)) << 4;
+                    const uint4 af = *reinterpret_cast<const uint4*>(sA + off);
+#pragma unroll
+                    for (int jb = 0; jb < NI1; ++jb) mma16<T>(*reinterpret_cast<const uint4*>(sB + jb * 16 * BKB + off), af, acc1[jb]);
+                }
             }
+#pragma unroll
+            for (int jb = 0; jb < NI1; ++jb)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) gsum[jb][q] += gelu_erf(acc1[jb][q]);
         }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the LDS-DMA burst is not tracked by the compiler
-    __syncthreads();
+#pragma unroll
+    for (int jb = 0; jb < NI1; ++jb) {
+        const int kk = wave * (D / 4) + jb * 16 + g * 4;      // this lane's 4 consecutive contraction indices of stage 2, row r
+        const int kt = kk / BK, cc = kk % BK;
+        store4(reinterpret_cast<T*>(R2 + kt * ST2 + r * BKB + (((cc >> 3) ^ (r & 7)) << 4) + (cc & 7) * 2), gsum[jb][0], gsum[jb][1], gsum[jb][2], gsum[jb][3]);
+    }
+    __syncthreads();   // g is in place; nobody reads R1 any more
+    // ---- burst 2: Wdown K-tiles over R1, landing under stage 2
+    if (P.has_down) {
+        const T* Wd = static_cast<const T*>(P.down.W);
+        for (int kt = 0; kt < KT3; ++kt)
+            for (int u = wv; u < D / 8; u += 4)
+                glds16_gn(Wd + (int64_t)(u * 8 + rl) * P.down.ldw + kt * BK + chunk * 8, lds_base + (unsigned)(kt * ST3 + u * 8 * BKB));
+    }
     // ---- stage 2
     f32x4 acc2[NI2];
 #pragma unroll
     for (int j = 0; j < NI2; ++j) acc2[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int kt = 0; kt < nk; ++kt) {
-        const char* sA = smem + kt * STAGE + r * BKB;
-        const char* sB = smem + kt * STAGE + (BM + wave * (E / 4) + r) * BKB;
+#pragma unroll
+    for (int kt = 0; kt < KT1; ++kt) {
+        const char* sA = R2 + kt * ST2 + r * BKB;
+        const char* sB = R2 + kt * ST2 + (BM + wave * (E / 4) + r) * BKB;
 #pragma unroll
         for (int kc = 0; kc < 2; ++kc) {
             const int off = ((kc * 4 + g) ^ (r & 7)) << 4;
@@ -503,17 +542,23 @@ __global__ __launch_bounds__(256) void exchange_tail_kernel(const XTailLaunch L)
             for (int j = 0; j < NI2; ++j) mma16<T>(*reinterpret_cast<const uint4*>(sB + j * 16 * BKB + off), af, acc2[j]);
         }
     }
+    float v2[NI2][4];
 #pragma unroll
     for (int j = 0; j < NI2; ++j) {
         const int n = wave * (E / 4) + j * 16 + g * 4;
-        float v[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) v[q] = acc2[j][q] + bv2[j][q] + rv2[j][q];
-        if (mok) {
-            store4(P.X + (int64_t)m * P.ldx + n, v[0], v[1], v[2], v[3]);
-            if (P.Xact != nullptr) store4(static_cast<T*>(P.Xact) + (int64_t)m * P.ldxact + n, v[0], v[1], v[2], v[3]);
+        for (int q = 0; q < 4; ++q) v2[j][q] = acc2[j][q] + bv2[j][q] + rv2[j][q];
+        store4(reinterpret_cast<T*>(x3 + (n / BK) * (BM * BKB) + r * BKB + ((((n % BK) >> 3) ^ (r & 7)) << 4) + (n & 7) * 2), v2[j][0], v2[j][1], v2[j][2], v2[j][3]);
+    }
+    // Wdown has landed before anything else of this wave is put into the memory pipeline (stores count in vmcnt too: they are issued after the wait)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (mok) {
+#pragma unroll
+        for (int j = 0; j < NI2; ++j) {
+            const int n = wave * (E / 4) + j * 16 + g * 4;
+            store4(P.X + (int64_t)m * P.ldx + n, v2[j][0], v2[j][1], v2[j][2], v2[j][3]);
+            if (P.Xact != nullptr) store4(static_cast<T*>(P.Xact) + (int64_t)m * P.ldxact + n, v2[j][0], v2[j][1], v2[j][2], v2[j][3]);
         }
-        store4(reinterpret_cast<T*>(x3 + (n / BK) * (BM * BKB) + r * BKB + ((((n % BK) >> 3) ^ (r & 7)) << 4) + (n & 7) * 2), v[0], v[1], v[2], v[3]);
     }
     if (!P.has_down) return;   // block-uniform
     __syncthreads();
@@ -522,10 +567,16 @@ __global__ __launch_bounds__(256) void exchange_tail_kernel(const XTailLaunch L)
 #pragma unroll
     for (int jb = 0; jb < NI3; ++jb) acc3[jb] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int kc = 0; kc < KS3; ++kc) {
-        const uint4 af = *reinterpret_cast<const uint4*>(x3 + (kc >> 1) * (BM * BKB) + r * BKB + ((((kc & 1) * 4 + g) ^ (r & 7)) << 4));
+    for (int kt = 0; kt < KT3; ++kt) {
+        const char* sA = x3 + kt * (BM * BKB) + r * BKB;
+        const char* sB = R1 + kt * ST3 + (wave * (D / 4) + r) * BKB;
 #pragma unroll
-        for (int jb = 0; jb < NI3; ++jb) mma16<T>(wd[jb][kc], af, acc3[jb]);
+        for (int kc = 0; kc < 2; ++kc) {
+            const int off = ((kc * 4 + g) ^ (r & 7)) << 4;
+            const uint4 af = *reinterpret_cast<const uint4*>(sA + off);
+#pragma unroll
+            for (int jb = 0; jb < NI3; ++jb) mma16<T>(*reinterpret_cast<const uint4*>(sB + jb * 16 * BKB + off), af, acc3[jb]);
+        }
     }
     epi3.finish(P.down, acc3, m, wave * (D / 4), r, g, wave, L.eps, red);
 }
@@ -631,7 +682,7 @@ extern "C" int sea_exchange_tail(const SeaExchangeTail* params, float eps, int d
     SEA_REQUIRE(params != nullptr, "sea_exchange_tail: null params");
     const SeaExchangeTail& P = *params;
     const bool shape_ok = (P.D == 128 && P.E == 256) || (P.D == 64 && P.E == 128);
-    if (dtype != SEA_BF16 || !shape_ok || P.n_seg < 1 || P.n_seg > SEA_XTAIL_MAX_SEG || P.n_seg * P.D > 256) {
+    if (dtype != SEA_BF16 || !shape_ok || P.n_seg < 1 || P.n_seg > SEA_XTAIL_MAX_SEG || P.n_seg * P.D > 256) {   // stage-1 tiles of all segments share LDS with Wup
         sea_set_error("sea_exchange_tail: unsupported dtype / shape (dtype=%d D=%d E=%d n_seg=%d): bf16, (D,E) in {(128,256),(64,128)}, n_seg*D <= 256", dtype, P.D, P.E, P.n_seg);
         return SEA_EUNSUPPORTED;
     }
@@ -654,18 +705,16 @@ extern "C" int sea_exchange_tail(const SeaExchangeTail* params, float eps, int d
         L.p.down.M = P.M; L.p.down.N = P.D; L.p.down.K = P.E; L.p.down.n_seg = 1; L.p.down.bias_scale = 1.0f;
         L.p.down.R = nullptr; L.p.down.C32 = nullptr; L.p.down.Cact = nullptr; L.p.down.ib_c = nullptr;
     }
-    const int nk = P.n_seg * P.D / 64;
-    const int lds = nk * (16 + P.E) * 128 + 16 * P.E * 2 + 512;
     const int grid = (P.M + 15) / 16;
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (P.D == 128) {
-        static int once = set_lds_gn(exchange_tail_kernel<128, 256>, 4 * (16 + 256) * 128 + 16 * 256 * 2 + 512);
+        static int once = set_lds_gn(exchange_tail_kernel<128, 256>, XTailCfg<128, 256>::lds_bytes(2));
         (void)once;
-        exchange_tail_kernel<128, 256><<<dim3(grid), dim3(256), lds, s>>>(L);
+        exchange_tail_kernel<128, 256><<<dim3(grid), dim3(256), XTailCfg<128, 256>::lds_bytes(P.n_seg), s>>>(L);
     } else {
-        static int once = set_lds_gn(exchange_tail_kernel<64, 128>, 4 * (16 + 128) * 128 + 16 * 128 * 2 + 512);
+        static int once = set_lds_gn(exchange_tail_kernel<64, 128>, XTailCfg<64, 128>::lds_bytes(4));
         (void)once;
-        exchange_tail_kernel<64, 128><<<dim3(grid), dim3(256), lds, s>>>(L);
+        exchange_tail_kernel<64, 128><<<dim3(grid), dim3(256), XTailCfg<64, 128>::lds_bytes(P.n_seg), s>>>(L);
     }
     SEA_CHECK_LAUNCH("sea_exchange_tail");
     return SEA_OK;

@@ -454,7 +454,7 @@ class Plan:
         # the exchange tail of a field (projections + GELU, up-projection + residual, down-projection + norm) as ONE launch: bf16, the widths the
         # kernel instantiates, short launches (SEA_FUSE_XTAIL=0 keeps the three-launch form; SEA_XTAIL_MAX_ROWS bounds M)
         fuse_xtail = (fuse_norm and not fuse_tail and not lanes and xmode == "sea" and F > 1 and os.environ.get("SEA_FUSE_XTAIL", "1") != "0"
-                      and ops.exchange_tail_supported(dt, D, E, F - 1) and M <= int(os.environ.get("SEA_XTAIL_MAX_ROWS", "4096")))   # one workgroup per CU (136 KiB of LDS): measured faster while the launch is a single round (cfg2 0.281 -> 0.266 ms; B = 8: 1.211 -> 1.246)
+                      and ops.exchange_tail_supported(dt, D, E, F - 1) and M <= int(os.environ.get("SEA_XTAIL_MAX_ROWS", "1000000000")))   # measured: cfg2 0.281 -> 0.254 ms, B = 2 0.414 -> 0.404, B = 4 0.679 -> 0.675, B = 8 a tie (1.191)
         rope_s, rope_c = eng.rope_self, eng.rope_cross
         FE = F * E
         xr = [self._buf(M, E, dtype=f32) for _ in range(F)]     # fp32 residual stream

@@ -364,9 +364,10 @@ def test_exchange_tail_matches_three_launch_form(D, E, S, M, has_down):
     nd = torch.empty(M, D, device=dev(), dtype=dt)
     assert ops.exchange_tail_supported(dt, D, E, S)
     ops.exchange_tail(att, Wp, Wup, bup, float(S), x, Xact=xa, down=dict(W=Wd, bias=bd, gamma=gamma, beta=beta, mod=mod, Yact=nd) if has_down else None)
-    g = [gelu(att[s].float() @ Wp[s].float().t()).to(dt).float() for s in range(S)]        # the kernel rounds g to bf16 (MFMA operand of the next layer)
-    xn = x0 + sum(g) @ Wup.float().t() + S * bup
-    assert rel(x, xn) < 2e-5
+    # cross_up is linear and shared by the segments: the kernel sums the GELU outputs in fp32 and rounds the SUM to bf16 (MFMA operand of the next layer)
+    gs = sum(gelu(att[s].float() @ Wp[s].float().t()) for s in range(S)).to(dt).float()
+    xn = x0 + gs @ Wup.float().t() + S * bup
+    assert rel(x, xn) < 5e-5
     assert rel(xa.float(), xn) < 6e-3
     if has_down:
         v = xn.to(dt).float() @ Wd.float().t() + bd                                          # likewise the new x as operand of the down-projection
@@ -377,11 +378,11 @@ def test_exchange_tail_matches_three_launch_form(D, E, S, M, has_down):
     ops.gemm_grouped([dict(A=att[s], W=Wp[s], Cact=gp[s], act=1) for s in range(S)], dt)
     x2, xa2 = x0.clone(), torch.empty_like(xa)
     ops.gemm_grouped([dict(A=gp[0], W=Wup, bias=bup, bias_scale=float(S), n_seg=S, a_seg_stride=M * D, R=x2, C32=x2, Cact=xa2)], dt)
-    assert rel(x, x2) < 1e-6
+    assert rel(x, x2) < 5e-3      # (that form rounds every g_s to bf16 and sums inside the MFMA; the update is as large as x here)
     if has_down:
         nd2 = torch.empty_like(nd)
         ops.gemm_rownorm([dict(A=xa2, W=Wd, bias=bd, mod=mod, gamma=gamma, beta=beta, Yact=nd2)], 1e-5, dt)
-        assert rel(nd.float(), nd2.float()) < 2e-3
+        assert rel(nd.float(), nd2.float()) < 2e-2
 
 
 def test_exchange_tail_unsupported_shapes_are_refused():
