@@ -265,11 +265,17 @@ typedef struct {
     int32_t n_seg, ldatt, ldwp, ldwup, ldx, ldxact;
     int32_t M, D, E, has_down;
     float bias_scale;
-    int32_t pad_;
+    int32_t plain;                        /* 1: no first layer — x = Xin + att[0][M, E] . Wup[E, E]^T + bup (n_seg = 1, Wp ignored): an ordinary Linear + residual
+                                           * in front of the down-projection + norm, e.g. the self-attention output projection followed by
+                                           * cross_down + ln_cross of the pre-exchange fields (models/base_blocks.py:201, models/temporal.py:136, 177-181) */
+    const float* Xin;                     /* f32 [M, E], row stride ldxin: the residual is READ from here when non-NULL (X is then written only) */
+    int32_t ldxin, pad_;
     SeaGemmNormGroup down;
 } SeaExchangeTail;
 
-int sea_exchange_tail(const SeaExchangeTail* params, float eps, int dtype, void* stream);
+/* params: n_groups <= SEA_XTAIL_MAX_GROUPS problems of one shape and mode (e.g. the F fields), one grid row each */
+#define SEA_XTAIL_MAX_GROUPS 4
+int sea_exchange_tail(const SeaExchangeTail* params, int n_groups, float eps, int dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Hidden layer of the AdaLN condition MLP for a scalar condition: Hid[m, k] = silu(w1[k] * c[m] + b1[k]).
@@ -553,7 +559,7 @@ int sea_rowchain(const SeaChainLaunch* launch, const SeaChainStage* host_stages,
  *     SEA_OP_ATTN   p0 = SeaAttnParams                            SEA_OP_NORM   p0 = SeaNormGroup[n], i0 = M, i1 = d, i2 = x_is_act, i3 = gelu, f0 = eps
  *     SEA_OP_SILU   p0 = SeaSiluGroup[n], p1 = c, i0 = M, l0 = (intptr) SeaIbParams[l1] or 0, l1 = n_ib      SEA_OP_IB     p0 = SeaIbParams
  *     SEA_OP_CHAIN  p0 = SeaChainLaunch, p1 = host stage table    SEA_OP_CONVERT p0 = src, p1 = dst, l0 = lds, l1 = ldd, l2 = rows, l3 = cols
- *     SEA_OP_GEMM_NORM p0 = SeaGemmNormGroup[n], f0 = eps          SEA_OP_XTAIL  p0 = SeaExchangeTail, f0 = eps
+ *     SEA_OP_GEMM_NORM p0 = SeaGemmNormGroup[n], f0 = eps          SEA_OP_XTAIL  p0 = SeaExchangeTail[n], f0 = eps
  * Returns 0, or the failing entry's error code with sea_last_error() set (entries before it have been launched).
  */
 enum { SEA_OP_GEMM = 1, SEA_OP_QKV = 2, SEA_OP_ATTN = 3, SEA_OP_NORM = 4, SEA_OP_SILU = 5, SEA_OP_IB = 6, SEA_OP_CHAIN = 7, SEA_OP_CONVERT = 8, SEA_OP_GEMM_NORM = 9, SEA_OP_XTAIL = 10 };

@@ -154,13 +154,15 @@ class SeaGemmNormGroup(C.Structure):
 
 
 XTAIL_MAX_SEG = 4
+XTAIL_MAX_GROUPS = 4
 MAX_SILU_IB = 4
 
 
 class SeaExchangeTail(C.Structure):
     _fields_ = [("att", _vp * XTAIL_MAX_SEG), ("Wp", _vp * XTAIL_MAX_SEG), ("Wup", _vp), ("bup", _vp), ("X", _vp), ("Xact", _vp),
                 ("n_seg", _i32), ("ldatt", _i32), ("ldwp", _i32), ("ldwup", _i32), ("ldx", _i32), ("ldxact", _i32),
-                ("M", _i32), ("D", _i32), ("E", _i32), ("has_down", _i32), ("bias_scale", _f32), ("pad_", _i32),
+                ("M", _i32), ("D", _i32), ("E", _i32), ("has_down", _i32), ("bias_scale", _f32), ("plain", _i32),
+                ("Xin", _vp), ("ldxin", _i32), ("pad_", _i32),
                 ("down", SeaGemmNormGroup)]
 
 
@@ -215,7 +217,7 @@ def lib() -> C.CDLL:
     L.sea_unpatchify.restype = C.c_int
     L.sea_gemm_rownorm.argtypes = [C.POINTER(SeaGemmNormGroup), C.c_int, C.c_float, C.c_int, _vp]
     L.sea_gemm_rownorm.restype = C.c_int
-    L.sea_exchange_tail.argtypes = [C.POINTER(SeaExchangeTail), C.c_float, C.c_int, _vp]
+    L.sea_exchange_tail.argtypes = [C.POINTER(SeaExchangeTail), C.c_int, C.c_float, C.c_int, _vp]
     L.sea_exchange_tail.restype = C.c_int
     L.sea_patchify.argtypes = [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _vp]
     L.sea_patchify.restype = C.c_int

@@ -41,7 +41,7 @@ extern "C" int sea_run_list(const SeaLaunchRec* recs, int n_recs, void* stream) 
             case SEA_OP_CHAIN: rc = sea_rowchain(static_cast<const SeaChainLaunch*>(R.p0), static_cast<const SeaChainStage*>(R.p1), R.dtype, stream); break;
             case SEA_OP_CONVERT: rc = sea_convert_f32_to_act(static_cast<const float*>(R.p0), R.l0, const_cast<void*>(R.p1), R.l1, R.l2, R.l3, R.dtype, stream); break;
             case SEA_OP_GEMM_NORM: rc = sea_gemm_rownorm(static_cast<const SeaGemmNormGroup*>(R.p0), R.n, R.f0, R.dtype, stream); break;
-            case SEA_OP_XTAIL: rc = sea_exchange_tail(static_cast<const SeaExchangeTail*>(R.p0), R.f0, R.dtype, stream); break;
+            case SEA_OP_XTAIL: rc = sea_exchange_tail(static_cast<const SeaExchangeTail*>(R.p0), R.n, R.f0, R.dtype, stream); break;
             default: sea_set_error("sea_run_list[%d]: unknown op %d", i, R.op); return SEA_EINVAL;
         }
         if (rc != SEA_OK) return rc;   // sea_last_error() already names the entry point; the caller maps i back to its record

@@ -397,7 +397,7 @@ __global__ __launch_bounds__(256) void gemm_rownorm16_kernel(const GemmNormLaunc
 // LDS: R1 = S (D/64) K-tiles of (16 + D) rows (att_s | Wp_s; later D/.. Wdown K-tiles), R2 = (D/64) K-tiles of (16 + E) rows (g | Wup), the bf16 x
 // tile [16, E], 512 B for the statistics: 152 KB at D = 128, E = 256, S = 2.
 struct XTailLaunch {
-    SeaExchangeTail p;
+    SeaExchangeTail p[SEA_XTAIL_MAX_GROUPS];   // grid.y = group (field)
     float eps;
 };
 
@@ -412,34 +412,50 @@ struct XTailCfg {
     static constexpr int SMAX = D == 128 ? 2 : 4;
     static __host__ __device__ constexpr int r1_bytes(int S) { return S * KT1 * ST1 > KT3 * ST3 ? S * KT1 * ST1 : KT3 * ST3; }
     static __host__ __device__ constexpr int lds_bytes(int S) { return r1_bytes(S) + KT1 * ST2 + BM * E * 2 + 512; }
+    // PLAIN (no first layer: x = Xin + att[M, E] . Wup[E, E]^T): the E/64 K-tiles of (att | Wup) take the front of LDS, Wdown reuses it after stage 2
+    static constexpr int KT2P = E / BK;
+    static __host__ __device__ constexpr int lds_bytes_plain() { return (KT2P * ST2 > KT3 * ST3 ? KT2P * ST2 : KT3 * ST3) + BM * E * 2 + 512; }
 };
 
-template <int D, int E>
+template <int D, int E, bool PLAIN>
 __global__ __launch_bounds__(256) void exchange_tail_kernel(const XTailLaunch L) {
     using T = __bf16;
     using C = XTailCfg<D, E>;
     constexpr int BM = C::BM, BKB = C::BKB, BK = C::BK, KT1 = C::KT1, KT3 = C::KT3, ST1 = C::ST1, ST2 = C::ST2, ST3 = C::ST3, SMAX = C::SMAX;
+    constexpr int KT2 = PLAIN ? C::KT2P : KT1;                     // K-tiles of stage 2
     constexpr int NI1 = D / 64, NI2 = E / 64, NI3 = D / 64;       // 16-column blocks per wave in each stage
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const SeaExchangeTail& P = L.p;
+    const SeaExchangeTail& P = L.p[blockIdx.y];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 15, g = lane >> 4;
     const int m0 = blockIdx.x * BM, M = P.M, S = P.n_seg;
+    if (m0 >= M) return;   // block-uniform (groups of different row counts share the grid)
+    const int r1b = PLAIN ? 0 : C::r1_bytes(S);
+    const int r2b = PLAIN ? (KT2 * ST2 > KT3 * ST3 ? KT2 * ST2 : KT3 * ST3) : KT2 * ST2;
     char* R1 = smem;
-    char* R2 = smem + C::r1_bytes(S);
-    char* x3 = R2 + KT1 * ST2;
+    char* R2 = smem + r1b;
+    char* x3 = R2 + r2b;
     float* red = reinterpret_cast<float*>(x3 + BM * E * 2);
     const int m = m0 + r;
     const bool mok = m < M;
     const int mc = mok ? m : M - 1;
 
     const unsigned lds_base = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)smem);
-    const unsigned r2_base = lds_base + (unsigned)C::r1_bytes(S);
+    const unsigned r2_base = lds_base + (unsigned)r1b;
     const int wv = __builtin_amdgcn_readfirstlane(wave);
     const int rl = lane >> 3;
     const int chunk = (lane & 7) ^ (rl & 7);   // swizzle on the source side: LDS position p of a row holds chunk p ^ (row & 7)
-    // ---- burst 1: att_s | Wp_s K-tiles (R1) and the Wup rows of the stage-2 K-tiles (R2)
-    for (int s = 0; s < S; ++s) {
+    // ---- burst 1: att_s | Wp_s K-tiles (R1) and the Wup rows of the stage-2 K-tiles (R2); PLAIN: the att rows are the A rows of stage 2
+    if constexpr (PLAIN) {
+        const T* att = static_cast<const T*>(P.att[0]);
+        for (int kt = 0; kt < KT2; ++kt)
+            for (int u = wv; u < BM / 8; u += 4) {
+                int mr = m0 + u * 8 + rl;
+                mr = mr < M ? mr : M - 1;
+                glds16_gn(att + (int64_t)mr * P.ldatt + kt * BK + chunk * 8, r2_base + (unsigned)(kt * ST2 + u * 8 * BKB));
+            }
+    }
+    for (int s = 0; s < (PLAIN ? 0 : S); ++s) {
         const T* att = static_cast<const T*>(P.att[s]);
         const T* Wp = static_cast<const T*>(P.Wp[s]);
         for (int kt = 0; kt < KT1; ++kt) {
@@ -460,7 +476,7 @@ __global__ __launch_bounds__(256) void exchange_tail_kernel(const XTailLaunch L)
     }
     {
         const T* Wup = static_cast<const T*>(P.Wup);
-        for (int kt = 0; kt < KT1; ++kt)
+        for (int kt = 0; kt < KT2; ++kt)
             for (int u = wv; u < E / 8; u += 4)
                 glds16_gn(Wup + (int64_t)(u * 8 + rl) * P.ldwup + kt * BK + chunk * 8, r2_base + (unsigned)(kt * ST2 + (BM + u * 8) * BKB));
     }
@@ -476,12 +492,14 @@ __global__ __launch_bounds__(256) void exchange_tail_kernel(const XTailLaunch L)
 #pragma unroll
             for (int q = 0; q < 4; ++q) bv2[j][q] *= P.bias_scale;
         }
-        load4(P.X + (int64_t)mc * P.ldx + n, rv2[j]);
+        if (P.Xin != nullptr) load4(P.Xin + (int64_t)mc * P.ldxin + n, rv2[j]);
+        else load4(P.X + (int64_t)mc * P.ldx + n, rv2[j]);
     }
     NormEpilogue<T, NI3, true, true> epi3;
     if (P.has_down) epi3.prefetch(P.down, mc, wave * (D / 4), g);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the LDS-DMA bursts are not tracked by the compiler
     __syncthreads();
+    if constexpr (!PLAIN) {
     // ---- stage 1: g = sum_s gelu(att_s . Wp_s^T), this wave's D/4 columns
     float gsum[NI1][4];
 #pragma unroll
@@ -519,19 +537,23 @@ __global__ __launch_bounds__(256) void exchange_tail_kernel(const XTailLaunch L)
         store4(reinterpret_cast<T*>(R2 + kt * ST2 + r * BKB + (((cc >> 3) ^ (r & 7)) << 4) + (cc & 7) * 2), gsum[jb][0], gsum[jb][1], gsum[jb][2], gsum[jb][3]);
     }
     __syncthreads();   // g is in place; nobody reads R1 any more
-    // ---- burst 2: Wdown K-tiles over R1, landing under stage 2
-    if (P.has_down) {
+    }
+    auto burst_wdown = [&]() {   // Wdown K-tiles to the front of LDS (over R1; PLAIN: over the stage-2 tiles, once they have been read)
         const T* Wd = static_cast<const T*>(P.down.W);
         for (int kt = 0; kt < KT3; ++kt)
             for (int u = wv; u < D / 8; u += 4)
                 glds16_gn(Wd + (int64_t)(u * 8 + rl) * P.down.ldw + kt * BK + chunk * 8, lds_base + (unsigned)(kt * ST3 + u * 8 * BKB));
+    };
+    // ---- burst 2: landing under stage 2
+    if constexpr (!PLAIN) {
+        if (P.has_down) burst_wdown();
     }
     // ---- stage 2
     f32x4 acc2[NI2];
 #pragma unroll
     for (int j = 0; j < NI2; ++j) acc2[j] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int kt = 0; kt < KT1; ++kt) {
+    for (int kt = 0; kt < KT2; ++kt) {
         const char* sA = R2 + kt * ST2 + r * BKB;
         const char* sB = R2 + kt * ST2 + (BM + wave * (E / 4) + r) * BKB;
 #pragma unroll
@@ -549,6 +571,12 @@ __global__ __launch_bounds__(256) void exchange_tail_kernel(const XTailLaunch L)
 #pragma unroll
         for (int q = 0; q < 4; ++q) v2[j][q] = acc2[j][q] + bv2[j][q] + rv2[j][q];
         store4(reinterpret_cast<T*>(x3 + (n / BK) * (BM * BKB) + r * BKB + ((((n % BK) >> 3) ^ (r & 7)) << 4) + (n & 7) * 2), v2[j][0], v2[j][1], v2[j][2], v2[j][3]);
+    }
+    if constexpr (PLAIN) {
+        if (P.has_down) {
+            __syncthreads();   // every wave has read the stage-2 tiles: Wdown may overwrite them
+            burst_wdown();
+        }
     }
     // Wdown has landed before anything else of this wave is put into the memory pipeline (stores count in vmcnt too: they are issued after the wait)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -678,45 +706,62 @@ extern "C" int sea_gemm_rownorm(const SeaGemmNormGroup* groups, int n_groups, fl
     return SEA_OK;
 }
 
-extern "C" int sea_exchange_tail(const SeaExchangeTail* params, float eps, int dtype, void* stream) {
-    SEA_REQUIRE(params != nullptr, "sea_exchange_tail: null params");
-    const SeaExchangeTail& P = *params;
-    const bool shape_ok = (P.D == 128 && P.E == 256) || (P.D == 64 && P.E == 128);
-    if (dtype != SEA_BF16 || !shape_ok || P.n_seg < 1 || P.n_seg > SEA_XTAIL_MAX_SEG || P.n_seg * P.D > 256) {   // stage-1 tiles of all segments share LDS with Wup
-        sea_set_error("sea_exchange_tail: unsupported dtype / shape (dtype=%d D=%d E=%d n_seg=%d): bf16, (D,E) in {(128,256),(64,128)}, n_seg*D <= 256", dtype, P.D, P.E, P.n_seg);
-        return SEA_EUNSUPPORTED;
-    }
-    SEA_REQUIRE(P.M >= 1 && P.Wup && P.X && sea_aligned16(P.Wup) && sea_aligned16(P.bup) && sea_aligned16(P.X) && sea_aligned16(P.Xact), "sea_exchange_tail: null / misaligned pointer");
-    SEA_REQUIRE(P.ldatt % 8 == 0 && P.ldatt >= P.D && P.ldwp % 8 == 0 && P.ldwp >= P.D && P.ldwup % 8 == 0 && P.ldwup >= P.D && P.ldx % 4 == 0 && P.ldx >= P.E &&
-                    (!P.Xact || (P.ldxact % 4 == 0 && P.ldxact >= P.E)), "sea_exchange_tail: bad strides");
-    for (int s = 0; s < P.n_seg; ++s) SEA_REQUIRE(P.att[s] && P.Wp[s] && sea_aligned16(P.att[s]) && sea_aligned16(P.Wp[s]), "sea_exchange_tail: segment %d: null / misaligned operand", s);
+extern "C" int sea_exchange_tail(const SeaExchangeTail* params, int n_groups, float eps, int dtype, void* stream) {
+    SEA_REQUIRE(params != nullptr && n_groups >= 1 && n_groups <= SEA_XTAIL_MAX_GROUPS, "sea_exchange_tail: n_groups=%d out of range", n_groups);
     XTailLaunch L;
     memset(&L, 0, sizeof(L));
-    L.p = P;
     L.eps = eps;
-    if (P.has_down) {
-        const SeaGemmNormGroup& G = P.down;
-        SEA_REQUIRE(G.W && G.gamma && (G.Y32 || G.Yact) && G.ldw % 8 == 0 && G.ldw >= P.E, "sea_exchange_tail: down: null pointer or bad ldw");
-        SEA_REQUIRE((!G.Y32 || (G.ldy32 % 4 == 0 && G.ldy32 >= P.D)) && (!G.Yact || (G.ldyact % 4 == 0 && G.ldyact >= P.D)) && (!G.mod || (G.ldmod % 4 == 0 && G.ldmod >= 2 * P.D)),
-                    "sea_exchange_tail: down: bad output / modulation strides");
-        SEA_REQUIRE(sea_aligned16(G.W) && sea_aligned16(G.bias) && sea_aligned16(G.mod) && sea_aligned16(G.gamma) && sea_aligned16(G.beta) && sea_aligned16(G.Y32) && sea_aligned16(G.Yact),
-                    "sea_exchange_tail: down: pointers must be 16-byte aligned");
-        // the fields NormEpilogue reads besides the pointers checked above
-        L.p.down.M = P.M; L.p.down.N = P.D; L.p.down.K = P.E; L.p.down.n_seg = 1; L.p.down.bias_scale = 1.0f;
-        L.p.down.R = nullptr; L.p.down.C32 = nullptr; L.p.down.Cact = nullptr; L.p.down.ib_c = nullptr;
+    const int D = params[0].D, E = params[0].E, S0 = params[0].n_seg;
+    const bool plain = params[0].plain != 0;
+    int m_max = 0;
+    for (int gi = 0; gi < n_groups; ++gi) {
+        const SeaExchangeTail& P = params[gi];
+        const bool shape_ok = (P.D == 128 && P.E == 256) || (P.D == 64 && P.E == 128);
+        const bool seg_ok = plain ? P.n_seg == 1 : (P.n_seg >= 1 && P.n_seg <= SEA_XTAIL_MAX_SEG && P.n_seg * P.D <= 256);   // stage-1 tiles of all segments share LDS with Wup
+        if (dtype != SEA_BF16 || !shape_ok || !seg_ok) {
+            sea_set_error("sea_exchange_tail: unsupported dtype / shape (dtype=%d D=%d E=%d n_seg=%d plain=%d): bf16, (D,E) in {(128,256),(64,128)}, n_seg*D <= 256", dtype, P.D, P.E,
+                          P.n_seg, P.plain);
+            return SEA_EUNSUPPORTED;
+        }
+        SEA_REQUIRE(P.D == D && P.E == E && P.n_seg == S0 && (P.plain != 0) == plain, "sea_exchange_tail[%d]: the groups of a launch share shape and mode", gi);
+        SEA_REQUIRE(P.M >= 1 && P.Wup && P.X && sea_aligned16(P.Wup) && sea_aligned16(P.bup) && sea_aligned16(P.X) && sea_aligned16(P.Xact) && sea_aligned16(P.Xin),
+                    "sea_exchange_tail[%d]: null / misaligned pointer", gi);
+        const int katt = plain ? P.E : P.D;
+        SEA_REQUIRE(P.ldatt % 8 == 0 && P.ldatt >= katt && (plain || (P.ldwp % 8 == 0 && P.ldwp >= P.D)) && P.ldwup % 8 == 0 && P.ldwup >= katt && P.ldx % 4 == 0 && P.ldx >= P.E &&
+                        (!P.Xact || (P.ldxact % 4 == 0 && P.ldxact >= P.E)) && (!P.Xin || (P.ldxin % 4 == 0 && P.ldxin >= P.E)), "sea_exchange_tail[%d]: bad strides", gi);
+        for (int s = 0; s < P.n_seg; ++s)
+            SEA_REQUIRE(P.att[s] && sea_aligned16(P.att[s]) && (plain || (P.Wp[s] && sea_aligned16(P.Wp[s]))), "sea_exchange_tail[%d]: segment %d: null / misaligned operand", gi, s);
+        L.p[gi] = P;
+        if (P.has_down) {
+            const SeaGemmNormGroup& G = P.down;
+            SEA_REQUIRE(G.W && G.gamma && (G.Y32 || G.Yact) && G.ldw % 8 == 0 && G.ldw >= P.E, "sea_exchange_tail[%d]: down: null pointer or bad ldw", gi);
+            SEA_REQUIRE((!G.Y32 || (G.ldy32 % 4 == 0 && G.ldy32 >= P.D)) && (!G.Yact || (G.ldyact % 4 == 0 && G.ldyact >= P.D)) && (!G.mod || (G.ldmod % 4 == 0 && G.ldmod >= 2 * P.D)),
+                        "sea_exchange_tail[%d]: down: bad output / modulation strides", gi);
+            SEA_REQUIRE(sea_aligned16(G.W) && sea_aligned16(G.bias) && sea_aligned16(G.mod) && sea_aligned16(G.gamma) && sea_aligned16(G.beta) && sea_aligned16(G.Y32) && sea_aligned16(G.Yact),
+                        "sea_exchange_tail[%d]: down: pointers must be 16-byte aligned", gi);
+            // the fields NormEpilogue reads besides the pointers checked above
+            SeaGemmNormGroup& Gd = L.p[gi].down;
+            Gd.M = P.M; Gd.N = P.D; Gd.K = P.E; Gd.n_seg = 1; Gd.bias_scale = 1.0f;
+            Gd.R = nullptr; Gd.C32 = nullptr; Gd.Cact = nullptr; Gd.ib_c = nullptr;
+        }
+        m_max = P.M > m_max ? P.M : m_max;
     }
-    const int grid = (P.M + 15) / 16;
+    const dim3 grid((m_max + 15) / 16, n_groups);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (P.D == 128) {
-        static int once = set_lds_gn(exchange_tail_kernel<128, 256>, XTailCfg<128, 256>::lds_bytes(2));
-        (void)once;
-        exchange_tail_kernel<128, 256><<<dim3(grid), dim3(256), XTailCfg<128, 256>::lds_bytes(P.n_seg), s>>>(L);
-    } else {
-        static int once = set_lds_gn(exchange_tail_kernel<64, 128>, XTailCfg<64, 128>::lds_bytes(4));
-        (void)once;
-        exchange_tail_kernel<64, 128><<<dim3(grid), dim3(256), XTailCfg<64, 128>::lds_bytes(P.n_seg), s>>>(L);
-    }
+#define LAUNCH_XT(DD, EE)                                                                                                          \
+    do {                                                                                                                          \
+        if (plain) {                                                                                                              \
+            static int once = set_lds_gn(exchange_tail_kernel<DD, EE, true>, XTailCfg<DD, EE>::lds_bytes_plain());                 \
+            (void)once;                                                                                                           \
+            exchange_tail_kernel<DD, EE, true><<<grid, dim3(256), XTailCfg<DD, EE>::lds_bytes_plain(), s>>>(L);                     \
+        } else {                                                                                                                  \
+            static int once = set_lds_gn(exchange_tail_kernel<DD, EE, false>, XTailCfg<DD, EE>::lds_bytes(XTailCfg<DD, EE>::SMAX)); \
+            (void)once;                                                                                                           \
+            exchange_tail_kernel<DD, EE, false><<<grid, dim3(256), XTailCfg<DD, EE>::lds_bytes(S0), s>>>(L);                        \
+        }                                                                                                                         \
+    } while (0)
+    if (D == 128) LAUNCH_XT(128, 256); else LAUNCH_XT(64, 128);
+#undef LAUNCH_XT
     SEA_CHECK_LAUNCH("sea_exchange_tail");
     return SEA_OK;
 }
-

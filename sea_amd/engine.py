@@ -300,9 +300,19 @@ class Plan:
     def _xtail(self, att, Wp, Wup, bup, bias_scale, X, down, name: str) -> None:
         """One field's exchange tail in one launch (sea_exchange_tail): projections + GELU, up-projection of their sum + residual, and — `down` —
         the down-projection + row norm of the updated rows."""
-        P = N.SeaExchangeTail()
-        ops.fill_exchange_tail(P, att, Wp, Wup, bup, bias_scale, X, None, down)
-        self._cur.append(self._rec(N.lib().sea_exchange_tail, [C.byref(P), 1e-5, self.code], name, P))
+        P = (N.SeaExchangeTail * 1)()
+        ops.fill_exchange_tail(P[0], att, Wp, Wup, bup, bias_scale, X, None, down)
+        self._cur.append(self._rec(N.lib().sea_exchange_tail, [P, 1, 1e-5, self.code], name, P))
+
+    def _xtail_plain(self, groups: List[dict], name: str) -> None:
+        """Linear + residual followed by the down-projection + row norm of the result, several fields per launch (sea_exchange_tail, plain form):
+        dicts with att [M, E], Wup [E, E], X (written), Xin_is_x (byte offset into the caller's x: the residual of the first layer), down."""
+        P = (N.SeaExchangeTail * len(groups))()
+        for p_, d in zip(P, groups):
+            ops.fill_exchange_tail(p_, [d["att"]], None, d["Wup"], None, 1.0, d["X"], None, d["down"], None, d.get("ldxin"))
+            if d.get("Xin_is_x") is not None:
+                self._x_patches.append((p_, "Xin", d["Xin_is_x"]))
+        self._cur.append(self._rec(N.lib().sea_exchange_tail, [P, len(groups), 1e-5, self.code], name, P))
 
     def _qkv(self, groups: List[dict], rope: torch.Tensor, hd: int, name: str) -> None:
         L = N.lib()
@@ -505,15 +515,29 @@ class Plan:
             self._qkv([dict(A=n_e[i], W=P.act(f"{pre}attn.self.{i}.q.weight", 3 * E), bias=P.f32_vec(f"{pre}attn.self.{i}.q.bias", 3 * E),
                             col0=0, Q=Qs[i], K=Ks[l][i], Vt=Vs[l][i]) for i in range(F)], rope_s, hd_s, "self.qkv_rope")
             self._attn([dict(Q=Qs[i], K=Ks[l][i], Vt=Vs[l][i], O=att_e[i]) for i in range(F)], hd_s, E, "self.attention")
-            groups = []
-            for i in range(F):
-                g = dict(A=att_e[i], W=P.act(f"{pre}attn.self.{i}.projection.weight"), C32=xr[i], Cact=xa[i])
-                if first:
-                    g.update(R=xr[i], ldr=FE, R_is_x=i * E * 4)
-                else:
-                    g.update(R=xr[i])
-                groups.append(g)
-            self._gemm(groups, "self.out_proj")
+            # opt-in (SEA_FUSE_OPROJ=1): self-attention output projection + residual and the down-projection + ln_cross of the result in one launch for
+            # the F fields (sea_exchange_tail, plain form).  Measured: a tie at cfg2 (0.2574 against 0.2572 ms: 381 workgroups at one per CU are two
+            # rounds, and Wdown can only follow the 128 KiB of Wo into LDS), a loss at B = 8 (1.238 against 1.208 ms)
+            fuse_oproj = (fuse_xtail and F <= N.XTAIL_MAX_GROUPS and os.environ.get("SEA_FUSE_OPROJ", "0") == "1")
+            if fuse_oproj:
+                tg = []
+                for i in range(F):
+                    d_ = dict(att=att_e[i], Wup=P.act(f"{pre}attn.self.{i}.projection.weight"), X=xr[i],
+                              down=dict(W=P.act(f"{pre}cross_down.{i}.weight"), bias=P.f32_vec(f"{pre}cross_down.{i}.bias"), Yact=nd_old[i], **norm_params(f"{pre}ln_cross.{i}.", D)))
+                    if first:
+                        d_.update(Xin_is_x=i * E * 4, ldxin=FE)
+                    tg.append(d_)
+                self._xtail_plain(tg, "self.out_proj_down_norm")
+            else:
+                groups = []
+                for i in range(F):
+                    g = dict(A=att_e[i], W=P.act(f"{pre}attn.self.{i}.projection.weight"), C32=xr[i], Cact=xa[i])
+                    if first:
+                        g.update(R=xr[i], ldr=FE, R_is_x=i * E * 4)
+                    else:
+                        g.update(R=xr[i])
+                    groups.append(g)
+                self._gemm(groups, "self.out_proj")
             first = False
             if not cond_joined:  # everything below reads modulations computed on lane 1
                 self._join(1)
@@ -535,7 +559,9 @@ class Plan:
                             for i in range(F)], "add.up")
             # -- state exchange (Gauss-Seidel over i, models/temporal.py:187-192)
             if F > 1 and xmode == "sea":
-                if fuse_norm and D <= 256 and D % 16 == 0:
+                if fuse_oproj:
+                    pass   # nd_old written by self.out_proj_down_norm
+                elif fuse_norm and D <= 256 and D % 16 == 0:
                     self._gemm_norm([dict(A=xa[j], W=P.act(f"{pre}cross_down.{j}.weight"), bias=P.f32_vec(f"{pre}cross_down.{j}.bias"), Yact=nd_old[j],
                                           **norm_params(f"{pre}ln_cross.{j}.", D)) for j in range(F)], "cross.down_norm_old")
                 else:
@@ -859,7 +885,7 @@ class Plan:
             elif r.fn is L.sea_attention_fwd:
                 c.op, c.p0, c.dtype = N.OP_ATTN, addr(r.keep), a[1]
             elif r.fn is L.sea_exchange_tail:
-                c.op, c.p0, c.f0, c.dtype = N.OP_XTAIL, addr(r.keep), a[1], a[2]
+                c.op, c.p0, c.n, c.f0, c.dtype = N.OP_XTAIL, addr(r.keep), a[1], a[2], a[3]
             elif r.fn is L.sea_gemm_rownorm:
                 c.op, c.p0, c.n, c.f0, c.dtype = N.OP_GEMM_NORM, addr(a[0]), a[1], a[2], a[3]
             elif r.fn is L.sea_rownorm:

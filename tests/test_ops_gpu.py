@@ -385,6 +385,36 @@ def test_exchange_tail_matches_three_launch_form(D, E, S, M, has_down):
         assert rel(nd.float(), nd2.float()) < 2e-2
 
 
+@pytest.mark.parametrize("D,E", [(128, 256), (64, 128)])
+def test_exchange_tail_plain_grouped(D, E):
+    """The plain form, three fields in one launch: x = Xin + att . Wo^T (attention output projection + residual, the residual read from a strided
+    [M, F, E] tensor as in the first layer), then cross_down + AdaLN of the result — against the formula and the two launches it replaces."""
+    from sea_amd import ops
+
+    dt, M, F = torch.bfloat16, 333, 3
+    xin = rnd(M, F, E, seed=980)
+    groups, refs, keep = [], [], []
+    for i in range(F):
+        att, Wo = rnd(M, E, dtype=dt, seed=981 + i), rnd(E, E, dtype=dt, scale=0.06, seed=984 + i)
+        Wd, bd = rnd(D, E, dtype=dt, scale=0.1, seed=987 + i), 0.2 * rnd(D, seed=990 + i)
+        mod = rnd(M, 2 * D, dtype=dt, scale=0.5, seed=993 + i)
+        gamma, beta = 1 + 0.1 * rnd(D, seed=996 + i), 0.1 * rnd(D, seed=999 + i)
+        x, nd = torch.full((M, E), float("nan"), device=dev()), torch.empty(M, D, device=dev(), dtype=dt)
+        groups.append(dict(att=[att], Wup=Wo, X=x, Xin=xin[:, i], down=dict(W=Wd, bias=bd, gamma=gamma, beta=beta, mod=mod, Yact=nd)))
+        xn = xin[:, i] + att.float() @ Wo.float().t()
+        v = xn.to(dt).float() @ Wd.float().t() + bd
+        refs.append((xn, torch.nn.functional.layer_norm(v, (D,), None, None, 1e-5) * (gamma + 1 + mod[:, :D].float()) + (beta + mod[:, D:].float())))
+        keep.append((x, nd, att, Wo, Wd, bd, mod, gamma, beta))
+    ops.exchange_tail_grouped(groups)
+    for (xn, ref), (x, nd, att, Wo, Wd, bd, mod, gamma, beta), i in zip(refs, keep, range(F)):
+        assert rel(x, xn) < 2e-5
+        assert rel(nd.float(), ref) < 6e-3
+        x2, xa2, nd2 = torch.empty(M, E, device=dev()), torch.empty(M, E, device=dev(), dtype=dt), torch.empty(M, D, device=dev(), dtype=dt)
+        ops.gemm_grouped([dict(A=att, W=Wo, R=xin[:, i], C32=x2, Cact=xa2)], dt)
+        ops.gemm_rownorm([dict(A=xa2, W=Wd, bias=bd, mod=mod, gamma=gamma, beta=beta, Yact=nd2)], 1e-5, dt)
+        assert rel(x, x2) < 1e-6 and rel(nd.float(), nd2.float()) < 4e-3
+
+
 def test_exchange_tail_unsupported_shapes_are_refused():
     from sea_amd import ops
 
