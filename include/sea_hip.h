@@ -315,6 +315,10 @@ typedef struct SeaIbParams_ {
     const float* b2;  /* [E] */
     int32_t M, E, h;
     SeaDropout drop;  /* on the MLP output, an independent stream (drop.stream + field) per field; element grid = (row, column) */
+    int32_t mode;     /* which ib layer (models/temporal.py:103-109): 0 = 'mlp' (the fields above); 1 = 'linear': ib = w1[E] * c + b1[E] (nn.Linear(1, E));
+                       * 2 = 'fourier': ib = [sin(2 pi c W), cos(2 pi c W)] with w1 = W[E/2] (GaussianFourierProjection, models/base_blocks.py:143-151).
+                       * Modes 1 and 2 read only c, w1 (and b1), ignore h / lnw / lnb / w2 / b2 and take no dropout. */
+    int32_t pad_;
 } SeaIbParams;
 
 int sea_ib_add(const SeaIbParams* params, void* stream);

@@ -61,11 +61,16 @@ def param_schema(cfg: OracleConfig) -> "OrderedDict[str, Tuple[Tuple[int, ...], 
     s: "OrderedDict[str, Tuple[Tuple[int, ...], str]]" = OrderedDict()
     for layer in range(cfg.num_layers):
         b = f"blocks.{layer}."
-        _linear(s, b + "ib.residual_projection.", E, 1)
-        _linear(s, b + "ib.layers.0.", sr, 1)
-        s[b + "ib.layers.1.weight"] = ((sr,), "norm_w")
-        s[b + "ib.layers.1.bias"] = ((sr,), "norm_b")
-        _linear(s, b + "ib.layers.3.", E, sr)
+        if cfg.ib_scale_mode == "fourier":    # GaussianFourierProjection(1, E/2): a fixed random W (models/base_blocks.py:143-148)
+            s[b + "ib.W"] = ((1, E // 2), "randn")
+        elif cfg.ib_scale_mode == "linear":   # nn.Linear(1, E)
+            _linear(s, b + "ib.", E, 1)
+        else:
+            _linear(s, b + "ib.residual_projection.", E, 1)
+            _linear(s, b + "ib.layers.0.", sr, 1)
+            s[b + "ib.layers.1.weight"] = ((sr,), "norm_w")
+            s[b + "ib.layers.1.bias"] = ((sr,), "norm_b")
+            _linear(s, b + "ib.layers.3.", E, sr)
         for i in range(F):
             for n in range(3):
                 _norm(s, f"{b}ln.exp.{i}.{n}.", E, cfg.LN_type)
@@ -110,6 +115,8 @@ def recipe_tensor(key: str, shape: Tuple[int, ...], kind: str) -> np.ndarray:
         return (1.0 + 0.1 * rng.standard_normal(shape)).astype(np.float32)
     if kind == "norm_b":
         return (0.1 * rng.standard_normal(shape)).astype(np.float32)
+    if kind == "randn":
+        return rng.standard_normal(shape).astype(np.float32)
     raise ValueError(kind)
 
 

@@ -36,8 +36,8 @@ Params = Dict[str, torch.Tensor]
 class OracleConfig:
     """Constructor arguments of the reference ``TemporalModel`` that shape the
     computation (models/temporal.py:327-344).  Restated: exchange_mode in {'sea' (both
-    shipped configs), 'addition', 'simple'}, ib_scale_mode='mlp', ib_addition_mode in
-    {'add', 'none'}, ib_mlp_layers=1, ib_num=1."""
+    shipped configs), 'addition', 'simple'}, ib_scale_mode in {'mlp', 'linear', 'fourier'},
+    ib_addition_mode in {'add', 'none'}, ib_mlp_layers=1, ib_num=1."""
 
     num_layers: int
     embed_dim: int
@@ -51,6 +51,7 @@ class OracleConfig:
     LN_type: str = "adaln"
     exchange_mode: str = "sea"
     ib_addition_mode: str = "add"
+    ib_scale_mode: str = "mlp"
 
     @property
     def down_dim(self) -> int:  # models/temporal.py:58-59
@@ -208,11 +209,19 @@ def exchange(xs: List[torch.Tensor], cond: torch.Tensor, p: Params, pre: str, cf
     raise ValueError(f"Invalid exchange_mode: {cfg.exchange_mode}")
 
 
-def info_bottleneck(cond: torch.Tensor, p: Params, pre: str) -> torch.Tensor:
-    """BaseBlockTemporal._add_info with ib_scale_mode='mlp', ib_addition_mode='add'
-    (models/temporal.py:111-116): MLP(1 -> scale_ratio -> E); its residual_projection is
-    created but never used (models/base_blocks.py:15-17)."""
-    return mlp(cond, p, pre + "ib.")
+def info_bottleneck(cond: torch.Tensor, p: Params, pre: str, mode: str = "mlp") -> torch.Tensor:
+    """The ib layer of BaseBlockTemporal (models/temporal.py:103-109) as used by _add_info with
+    ib_addition_mode='add' (:111-116).  'mlp': MLP(1 -> scale_ratio -> E), whose residual_projection is
+    created but never used (models/base_blocks.py:15-17); 'linear': nn.Linear(1, E); 'fourier':
+    GaussianFourierProjection (models/base_blocks.py:143-151): x_proj = x @ W * 2 * pi in fp32, [sin, cos]."""
+    if mode == "mlp":
+        return mlp(cond, p, pre + "ib.")
+    if mode == "linear":
+        return linear(cond, p[pre + "ib.weight"], p[pre + "ib.bias"])
+    if mode == "fourier":
+        x_proj = cond @ p[pre + "ib.W"] * 2 * math.pi
+        return torch.cat([torch.sin(x_proj), torch.cos(x_proj)], dim=-1)
+    raise ValueError(f"Invalid ib_scale_mode '{mode}'")
 
 
 def block_forward(xs: Sequence[torch.Tensor], cond: torch.Tensor, p: Params, pre: str, cfg: OracleConfig) -> List[torch.Tensor]:
@@ -222,14 +231,14 @@ def block_forward(xs: Sequence[torch.Tensor], cond: torch.Tensor, p: Params, pre
     xs = list(xs)
     add_ib = cfg.ib_addition_mode == "add"   # 'none': _add_info returns x (models/temporal.py:113-114)
     if not cfg.add_info_after_cross and add_ib:
-        ib = info_bottleneck(cond, p, pre)
+        ib = info_bottleneck(cond, p, pre, cfg.ib_scale_mode)
         xs = [x + ib for x in xs]
     for i in range(F):
         n = norm(xs[i], cond, p, f"{pre}ln.exp.{i}.0.", cfg.LN_type)
         xs[i] = xs[i] + masked_attention(n, n, p, f"{pre}attn.self.{i}.", cfg.n_heads, cfg.src_len)
     xs = exchange(xs, cond, p, pre, cfg)
     if cfg.add_info_after_cross and add_ib:
-        ib = info_bottleneck(cond, p, pre)
+        ib = info_bottleneck(cond, p, pre, cfg.ib_scale_mode)
         xs = [x + ib for x in xs]
     for i in range(F):
         n = norm(xs[i], cond, p, f"{pre}ln.exp.{i}.2.", cfg.LN_type)

@@ -69,7 +69,7 @@ class SeaSiluGroup(C.Structure):
 class SeaIbParams(C.Structure):
     _fields_ = [("X", _vp * 8), ("n_fields", _i32), ("ldx", _i32),
                 ("c", _vp), ("w1", _vp), ("b1", _vp), ("lnw", _vp), ("lnb", _vp), ("w2", _vp), ("b2", _vp),
-                ("M", _i32), ("E", _i32), ("h", _i32), ("drop", SeaDropout)]
+                ("M", _i32), ("E", _i32), ("h", _i32), ("drop", SeaDropout), ("mode", _i32), ("pad_", _i32)]
 
 
 class SeaWgradGroup(C.Structure):

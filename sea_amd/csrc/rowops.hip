@@ -203,8 +203,37 @@ struct SiluIbLaunch {
     SeaIbParams ib[SEA_MAX_SILU_IB];
 };
 
+// 'linear' / 'fourier' info-bottleneck layers (SeaIbParams.mode 1 / 2): 4 consecutive output columns of one row
+__device__ __forceinline__ void ib_simple4(const SeaIbParams& P, float cv, int e0, float (&o)[4]) {
+    if (P.mode == 1) {
+        float w[4], b[4];
+        load4(P.w1 + e0, w);
+        load4(P.b1 + e0, b);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = w[e] * cv + b[e];
+    } else {
+        const int half = P.E >> 1;   // E % 8 == 0: the 4 columns are all sines or all cosines
+        const bool is_cos = e0 >= half;
+        float w[4];
+        load4(P.w1 + (is_cos ? e0 - half : e0), w);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float a = cv * w[e] * 2.0f * 3.14159274101257324f;   // ((x @ W) * 2) * pi in fp32, as the reference forms it
+            o[e] = is_cos ? cosf(a) : sinf(a);
+        }
+    }
+}
+
 // one row of the information-bottleneck MLP, stored (the wave-per-row body of ib_add_kernel without the add)
 __device__ __forceinline__ void ib_store_row(const SeaIbParams& P, float cv, int row, int lane) {
+    if (P.mode != 0) {   // block-uniform
+        for (int e0 = lane * 4; e0 < P.E; e0 += 256) {
+            float o[4];
+            ib_simple4(P, cv, e0, o);
+            store4(P.X[0] + (int64_t)row * P.ldx + e0, o[0], o[1], o[2], o[3]);
+        }
+        return;
+    }
     const int h = P.h;
     const bool act = lane < h;
     const float pre = act ? P.w1[lane] * cv + P.b1[lane] : 0.f;
@@ -278,8 +307,12 @@ extern "C" int sea_silu_outer_ib(const SeaSiluGroup* groups, int n_groups, const
     memset(&I, 0, sizeof(I));
     for (int k = 0; k < n_ib; ++k) {
         const SeaIbParams& P = ibs[k];
-        SEA_REQUIRE(P.X[0] && sea_aligned16(P.X[0]) && P.E >= 4 && P.E % 4 == 0 && P.h >= 1 && P.h <= 64 && P.ldx >= P.E && P.ldx % 4 == 0 && P.w1 && P.b1 && P.lnw && P.lnb && P.w2 &&
-                        P.b2 && sea_aligned16(P.b2), "sea_silu_outer_ib: ib[%d]: bad sizes / null / misaligned pointer", k);
+        if (P.mode == 0)
+            SEA_REQUIRE(P.X[0] && sea_aligned16(P.X[0]) && P.E >= 4 && P.E % 4 == 0 && P.h >= 1 && P.h <= 64 && P.ldx >= P.E && P.ldx % 4 == 0 && P.w1 && P.b1 && P.lnw && P.lnb &&
+                            P.w2 && P.b2 && sea_aligned16(P.b2), "sea_silu_outer_ib: ib[%d]: bad sizes / null / misaligned pointer", k);
+        else
+            SEA_REQUIRE((P.mode == 1 || P.mode == 2) && P.X[0] && sea_aligned16(P.X[0]) && P.E >= 8 && P.E % 8 == 0 && P.ldx >= P.E && P.ldx % 4 == 0 && P.w1 && sea_aligned16(P.w1) &&
+                            (P.mode == 2 || (P.b1 && sea_aligned16(P.b1))), "sea_silu_outer_ib: ib[%d]: bad sizes / null / misaligned pointer (mode %d)", k, P.mode);
         I.ib[k] = P;
     }
     SEA_REQUIRE(dtype == SEA_F32 || dtype == SEA_BF16, "sea_silu_outer: bad dtype %d", dtype);
@@ -314,6 +347,19 @@ __global__ __launch_bounds__(256) void ib_add_kernel(const SeaIbParams P) {
     if (row >= P.M) return;
     const int h = P.h;
     const float cv = P.c[row];
+    if (P.mode != 0) {   // 'linear' / 'fourier' layers: no hidden vector (block-uniform)
+        for (int e0 = lane * 4; e0 < P.E; e0 += 256) {
+            float o[4];
+            ib_simple4(P, cv, e0, o);
+            for (int f = 0; f < P.n_fields; ++f) {
+                float* x = P.X[f] + (int64_t)row * P.ldx + e0;
+                float v[4];
+                load4(x, v);
+                store4(x, v[0] + o[0], v[1] + o[1], v[2] + o[2], v[3] + o[3]);
+            }
+        }
+        return;
+    }
     const bool act = lane < h;
     const float pre = act ? P.w1[lane] * cv + P.b1[lane] : 0.f;
     const float mean = wave_sum(pre) / (float)h;
@@ -362,10 +408,17 @@ __global__ __launch_bounds__(256) void ib_add_kernel(const SeaIbParams P) {
 extern "C" int sea_ib_add(const SeaIbParams* params, void* stream) {
     SEA_REQUIRE(params != nullptr, "sea_ib_add: null params");
     const SeaIbParams& P = *params;
-    SEA_REQUIRE(P.n_fields >= 1 && P.n_fields <= 8 && P.M >= 1 && P.E >= 4 && P.E % 4 == 0 && P.h >= 1 && P.h <= 64 && P.ldx >= P.E && P.ldx % 4 == 0,
-                "sea_ib_add: bad sizes n_fields=%d M=%d E=%d h=%d ldx=%d", P.n_fields, P.M, P.E, P.h, P.ldx);
-    SEA_REQUIRE(P.c && P.w1 && P.b1 && P.lnw && P.lnb && P.w2 && P.b2, "sea_ib_add: null parameter pointer");
-    SEA_REQUIRE(sea_aligned16(P.b2) && ((P.h & 3) != 0 || sea_aligned16(P.w2)), "sea_ib_add: b2 (and w2 when h %% 4 == 0) must be 16-byte aligned");
+    SEA_REQUIRE(P.mode >= 0 && P.mode <= 2, "sea_ib_add: bad mode %d", P.mode);
+    if (P.mode == 0) {
+        SEA_REQUIRE(P.n_fields >= 1 && P.n_fields <= 8 && P.M >= 1 && P.E >= 4 && P.E % 4 == 0 && P.h >= 1 && P.h <= 64 && P.ldx >= P.E && P.ldx % 4 == 0,
+                    "sea_ib_add: bad sizes n_fields=%d M=%d E=%d h=%d ldx=%d", P.n_fields, P.M, P.E, P.h, P.ldx);
+        SEA_REQUIRE(P.c && P.w1 && P.b1 && P.lnw && P.lnb && P.w2 && P.b2, "sea_ib_add: null parameter pointer");
+        SEA_REQUIRE(sea_aligned16(P.b2) && ((P.h & 3) != 0 || sea_aligned16(P.w2)), "sea_ib_add: b2 (and w2 when h %% 4 == 0) must be 16-byte aligned");
+    } else {
+        SEA_REQUIRE(P.n_fields >= 1 && P.n_fields <= 8 && P.M >= 1 && P.E >= 8 && P.E % 8 == 0 && P.ldx >= P.E && P.ldx % 4 == 0 && P.drop.thr == 0,
+                    "sea_ib_add: bad sizes n_fields=%d M=%d E=%d ldx=%d (linear / fourier: E a multiple of 8, no dropout)", P.n_fields, P.M, P.E, P.ldx);
+        SEA_REQUIRE(P.c && P.w1 && sea_aligned16(P.w1) && (P.mode == 2 || (P.b1 && sea_aligned16(P.b1))), "sea_ib_add: null / misaligned parameter pointer");
+    }
     for (int f = 0; f < P.n_fields; ++f) SEA_REQUIRE(P.X[f] && sea_aligned16(P.X[f]), "sea_ib_add: X[%d] null or misaligned", f);
     ib_add_kernel<<<dim3((P.M + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream)>>>(P);
     SEA_CHECK_LAUNCH("sea_ib_add");

@@ -397,9 +397,8 @@ class Plan:
                     n_ib = len(ib_todo)
                     ibs = (N.SeaIbParams * n_ib)()
                     for ibp, (lpre, ibuf) in zip(ibs, ib_todo):
-                        q = self._ib_params(lpre)
-                        ibp.X[0], ibp.n_fields, ibp.ldx, ibp.M, ibp.E, ibp.h = ibuf.data_ptr(), 1, ibuf.stride(0), M, self.E, q["h"]
-                        ibp.w1, ibp.b1, ibp.lnw, ibp.lnb, ibp.w2, ibp.b2 = (q[k].data_ptr() for k in ("w1", "b1", "lnw", "lnb", "w2", "b2"))
+                        ibp.X[0], ibp.n_fields, ibp.ldx = ibuf.data_ptr(), 1, ibuf.stride(0)
+                        self._fill_ib(ibp, lpre)
                     ib_todo.clear()
                 rec = self._rec(L.sea_silu_outer_ib, [arr, len(chunk), None, M, self.code, ibs, n_ib], "adaln.silu" + tag, (arr, ibs))
                 self._c_patches.append((rec.args, 2))
@@ -443,7 +442,7 @@ class Plan:
         # ... and, opt-in (SEA_FUSE_TAIL=1), cross_up (+ sum over j, + residual) with the info-bottleneck add and AdaLN_2 that follow a field's
         # exchange stage.  Measured at cfg2: 0.294 ms against 0.285 — ib_add and AdaLN_2 are ONE launch each for all fields, folding them into F
         # per-field launches trades 2 launches (~13 us) for 3 x ~8 us of extra epilogue on the serial Gauss-Seidel chain.
-        fuse_tail = (fuse_norm and xmode == "sea" and has_ib and os.environ.get("SEA_FUSE_TAIL", "0") == "1" and F > 1 and eng.model.add_info_after_cross and not lanes
+        fuse_tail = (fuse_norm and xmode == "sea" and has_ib and eng.ib_mode == 0 and os.environ.get("SEA_FUSE_TAIL", "0") == "1" and F > 1 and eng.model.add_info_after_cross and not lanes
                      and E <= 256 and E % 16 == 0 and eng.model.ib_hidden in (4, 8))
         # the info-bottleneck add without a launch of its own: its MLP depends on the condition only, so it is EVALUATED by extra row passes of the silu
         # launch (into ibuf) and ADDED by the AdaLN_2 pass that follows it anyway (SeaNormGroup.addend).  Needs the silu launch (adaln, short launches)
@@ -665,7 +664,7 @@ class Plan:
         LDS tiles (E, D multiples of 64 up to 256).  Opt-in with SEA_FUSED=1: measured at cfg2 (profiles/) the chains are still slower than the
         launch-per-operator plan — every stage pays a cold ~1.5 us memory round trip for its weights with one wave per SIMD to hide it."""
         m = self.eng.model
-        if type(self) is not Plan or os.environ.get("SEA_FUSED", "0") != "1" or m.exchange_mode != "sea" or m.ib_addition_mode.lower() != "add":
+        if type(self) is not Plan or os.environ.get("SEA_FUSED", "0") != "1" or m.exchange_mode != "sea" or m.ib_addition_mode.lower() != "add" or self.eng.ib_mode != 0:
             return False
         ok_w = lambda w: w % 64 == 0 and w <= N.CHAIN_MAX_WIDTH
         return (ok_w(self.E) and ok_w(self.D) and 2 * self.D <= N.CHAIN_MAX_WIDTH and self.F >= 2 and m.add_info_after_cross
@@ -811,6 +810,19 @@ class Plan:
                     lnb=P.f32_vec(pre + "ib.layers.1.bias"), w2=P.f32(pre + "ib.layers.3.weight"), b2=P.f32_vec(pre + "ib.layers.3.bias"),
                     h=self.eng.model.ib_hidden)
 
+    def _fill_ib(self, ib, pre: str) -> None:
+        """The layer parameters of SeaIbParams for the block's ib_scale_mode (models/temporal.py:103-109)."""
+        P, mode = self.eng.params, self.eng.ib_mode
+        ib.mode, ib.M, ib.E = mode, self.M, self.E
+        if mode == 0:
+            q = self._ib_params(pre)
+            ib.w1, ib.b1, ib.lnw, ib.lnb, ib.w2, ib.b2 = (q[k].data_ptr() for k in ("w1", "b1", "lnw", "lnb", "w2", "b2"))
+            ib.h = q["h"]
+        elif mode == 1:   # nn.Linear(1, E): weight [E, 1], bias [E]
+            ib.w1, ib.b1, ib.h = P.f32_vec(pre + "ib.weight").data_ptr(), P.f32_vec(pre + "ib.bias").data_ptr(), 1
+        else:             # GaussianFourierProjection: W [1, E/2]
+            ib.w1, ib.h = P.f32(pre + "ib.W").data_ptr(), 1
+
     def _ib(self, pre: str, xr: List[torch.Tensor], drop=None) -> None:
         P = self.eng.params
         ib = N.SeaIbParams()
@@ -820,13 +832,7 @@ class Plan:
         for i, x in enumerate(xr):
             ib.X[i] = x.data_ptr()
         ib.n_fields, ib.ldx = len(xr), xr[0].stride(0)
-        ib.w1 = P.f32_vec(pre + "ib.layers.0.weight").data_ptr()
-        ib.b1 = P.f32_vec(pre + "ib.layers.0.bias").data_ptr()
-        ib.lnw = P.f32_vec(pre + "ib.layers.1.weight").data_ptr()
-        ib.lnb = P.f32_vec(pre + "ib.layers.1.bias").data_ptr()
-        ib.w2 = P.f32(pre + "ib.layers.3.weight").data_ptr()
-        ib.b2 = P.f32_vec(pre + "ib.layers.3.bias").data_ptr()
-        ib.M, ib.E, ib.h = self.M, self.E, self.eng.model.ib_hidden
+        self._fill_ib(ib, pre)
         self._c_patches.append((ib, "c"))
         self._cur.append(self._rec(N.lib().sea_ib_add, [C.byref(ib)], "ib_add", ib))
 
@@ -1005,13 +1011,14 @@ class TemporalEngine:
         if device.type != "cuda":
             raise RuntimeError("sea_amd: TemporalModel runs only on an MI355X (no CPU fallback)")
         m = model
-        if (m.exchange_mode not in ("sea", "addition", "simple") or m.ib_scale_mode != "mlp" or m.ib_addition_mode.lower() not in ("add", "none")
-                or m.ib_mlp_layers != 1 or m.ib_num != 1):
+        self.ib_mode = {"mlp": 0, "linear": 1, "fourier": 2}.get(m.ib_scale_mode.lower(), -1)
+        if (m.exchange_mode not in ("sea", "addition", "simple") or self.ib_mode < 0 or m.ib_addition_mode.lower() not in ("add", "none")
+                or (self.ib_mode == 0 and m.ib_mlp_layers != 1) or m.ib_num != 1 or (self.ib_mode != 0 and m.embed_dim % 8)):
             raise NotImplementedError(
-                "sea_amd native path covers exchange_mode in {'sea', 'addition', 'simple'}, ib_scale_mode='mlp', ib_addition_mode in {'add', 'none'}, "
-                "ib_mlp_layers=1, ib_num=1; got "
+                "sea_amd native path covers exchange_mode in {'sea', 'addition', 'simple'}, ib_scale_mode in {'mlp', 'linear', 'fourier'}, ib_addition_mode in "
+                "{'add', 'none'}, ib_mlp_layers=1, ib_num=1; got "
                 f"{m.exchange_mode}/{m.ib_scale_mode}/{m.ib_addition_mode}/{m.ib_mlp_layers}/{m.ib_num}")
-        self.default_variant = m.exchange_mode == "sea" and m.ib_addition_mode.lower() == "add"   # what training covers
+        self.default_variant = m.exchange_mode == "sea" and m.ib_addition_mode.lower() == "add" and self.ib_mode == 0   # what training covers
         E, H, D = m.embed_dim, m.n_heads, m.down_dim
         for hd, what in ((E // H, "self"),) + (((D // H, "cross"),) if m.exchange_mode == "sea" else ()):
             ok = hd in (8, 16, 32, 64, 128) or (hd == 256 and act_dtype == torch.bfloat16)
@@ -1020,7 +1027,7 @@ class TemporalEngine:
                                           "compute dtype bf16, forward/rollout only)")
         if m.src_len < 0:
             raise NotImplementedError("sea_amd: src_len must be >= 0")
-        if m.ib_hidden > 64:
+        if self.ib_mode == 0 and m.ib_hidden > 64:
             raise NotImplementedError("sea_amd: info-bottleneck hidden width (scale_ratio) must be <= 64")
         self.model, self.device, self.act_dtype = model, device, act_dtype
         self.params = FlatParams(model, device, act_dtype)
@@ -1084,8 +1091,8 @@ class TemporalEngine:
 
         m = self.model
         if not self.default_variant:
-            raise NotImplementedError("sea_amd: training (backward) covers exchange_mode='sea' with ib_addition_mode='add'; the ablation variants "
-                                      f"run forward / rollout only (got {m.exchange_mode}/{m.ib_addition_mode})")
+            raise NotImplementedError("sea_amd: training (backward) covers exchange_mode='sea' with ib_scale_mode='mlp', ib_addition_mode='add'; the ablation "
+                                      f"variants run forward / rollout only (got {m.exchange_mode}/{m.ib_scale_mode}/{m.ib_addition_mode})")
         thr = int(round(256 * m.dropout_p)) if (m.training and m.dropout_p > 0) else 0
         if thr > 255:
             raise ValueError("dropout probability too close to 1")

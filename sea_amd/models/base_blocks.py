@@ -237,6 +237,19 @@ class PositionalEncoding(nn.Module):
         self.register_buffer("pe", pe.unsqueeze(0))
 
 
+class GaussianFourierProjection(nn.Module):
+    """Random Fourier features of the condition (reference models/base_blocks.py:143-151): a fixed (requires_grad=False) W [input_dim, half_dim];
+    forward(x) = [sin(2 pi x W), cos(2 pi x W)].  Parameter container for the whole-model path (sea_ib_add mode 2)."""
+
+    def __init__(self, input_dim, half_dim=256, scale=1.0):
+        super().__init__()
+        self.input_dim, self.half_dim = input_dim, half_dim
+        self.W = nn.Parameter(torch.randn(input_dim, half_dim) * scale, requires_grad=False)
+
+    def forward(self, x):
+        raise RuntimeError("sea_amd.GaussianFourierProjection is a parameter container; call TemporalModel.forward")
+
+
 # ---------------------------------------------------------------------------------------------- spatial-encoder layers (SURVEY.md §8f rank 2)
 class downScaleMLP(nn.Module):  # noqa: N801  (reference name, models/base_blocks.py:65-78)
     """Linear(d_input, hidden, bias=False) -> GELU -> Linear(hidden, d_model).  Parameter container: PointwiseEncode.forward runs all

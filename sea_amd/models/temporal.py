@@ -7,8 +7,8 @@ TemporalModel.forward hands the whole forward to sea_amd.engine (≈30 fused HIP
 
 Scope: exchange_mode='sea' with ib_scale_mode='mlp', ib_addition_mode='add' — what both shipped configs select
 (configs/cylinder_flow.py:112-128, configs/multiphase_flow.py:112-128) — forward, rollout and training; the ablation variants
-exchange_mode 'addition' / 'simple' and ib_addition_mode 'none' forward / rollout only.  'pool' and the
-fourier / linear / concat / attention info-bottleneck modes are valid arguments of the reference that this build does not
+exchange_mode 'addition' / 'simple', ib_scale_mode 'fourier' (the constructor's default) / 'linear' and ib_addition_mode 'none' forward / rollout
+only.  'pool' and the concat / attention info-bottleneck additions are valid arguments of the reference that this build does not
 accelerate: they raise NotImplementedError (invalid names raise ValueError as in the reference).
 """
 from __future__ import annotations
@@ -19,7 +19,7 @@ from typing import Optional
 import torch
 import torch.nn as nn
 
-from .base_blocks import (AdaLN, LayerNorm, MLP, MaskedMultiHeadAttention, MaskedMultiHeadCrossAttention,
+from .base_blocks import (AdaLN, GaussianFourierProjection, LayerNorm, MLP, MaskedMultiHeadAttention, MaskedMultiHeadCrossAttention,
                           PositionalEncoding)
 
 _EXCHANGE_MODES = {"sea", "simple", "addition", "pool"}
@@ -51,13 +51,17 @@ class BaseBlockTemporal(nn.Module):
         self.ib_num = ib_num
         self.add_info_after_cross = add_info_after_cross
         self.ib_scale_mode = self._validate_ib_mode(ib_scale_mode)
-        if self.ib_addition_mode not in ("add", "none") or self.ib_scale_mode != "mlp":
+        if self.ib_addition_mode not in ("add", "none"):
             raise NotImplementedError(
-                f"sea_amd: ib_scale_mode={self.ib_scale_mode!r} / ib_addition_mode={self.ib_addition_mode!r} is an ablation variant "
-                "outside the accelerated path (supported: 'mlp' with 'add' or 'none')")
+                f"sea_amd: ib_addition_mode={self.ib_addition_mode!r} is an ablation variant outside the accelerated path (supported: 'add', 'none')")
         self.internal_embed_dim = embed_dim
         self.ib_dim = embed_dim
-        self.ib = MLP(self.ib_num, dropout, scale_ratio, self.ib_dim, self.ib_mlp_layers)
+        if self.ib_scale_mode == "fourier":      # reference :103-109
+            self.ib = GaussianFourierProjection(self.ib_num, int(self.ib_dim // 2))
+        elif self.ib_scale_mode == "linear":
+            self.ib = nn.Linear(self.ib_num, self.ib_dim)
+        else:
+            self.ib = MLP(self.ib_num, dropout, scale_ratio, self.ib_dim, self.ib_mlp_layers)
         self.down_ratio = down_proj
         self.down_dim = self.internal_embed_dim // self.down_ratio
         F, E = num_variables, self.internal_embed_dim
@@ -91,6 +95,8 @@ class BaseBlockTemporal(nn.Module):
     def _add_info(self, x, add_info, var_idx):
         if self.ib_addition_mode == "none":   # reference :113-114
             return x
+        if self.ib_scale_mode != "mlp":
+            raise NotImplementedError("sea_amd: the stand-alone block forward covers ib_scale_mode='mlp'; call TemporalModel.forward")
         return self.ib(add_info, residual=x)
 
     def _apply_exchange(self, x_vars, x_add):

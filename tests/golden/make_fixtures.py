@@ -36,7 +36,7 @@ torch.set_num_threads(8)
 
 def build_reference(cfg: OracleConfig, dropout=0.0):
     m = TemporalModel(cfg.num_layers, cfg.embed_dim, cfg.n_heads, cfg.max_len, cfg.scale_ratio, cfg.src_len,
-                      cfg.num_variables, cfg.down_proj, dropout, cfg.exchange_mode, "learnable", "mlp", cfg.ib_addition_mode, 1, 1,
+                      cfg.num_variables, cfg.down_proj, dropout, cfg.exchange_mode, "learnable", cfg.ib_scale_mode, cfg.ib_addition_mode, 1, 1,
                       cfg.add_info_after_cross, cfg.LN_type)
     schema = param_schema(cfg)
     named = dict(m.named_parameters())
@@ -54,7 +54,7 @@ def cfg_meta(cfg: OracleConfig):
     return np.array([cfg.num_layers, cfg.embed_dim, cfg.n_heads, cfg.max_len, cfg.scale_ratio, cfg.src_len,
                      cfg.num_variables, cfg.down_proj, int(cfg.add_info_after_cross),
                      1 if cfg.LN_type == "adaln" else 0, ("sea", "addition", "simple").index(cfg.exchange_mode),
-                     ("add", "none").index(cfg.ib_addition_mode)], dtype=np.int64)
+                     ("add", "none").index(cfg.ib_addition_mode), ("mlp", "linear", "fourier").index(cfg.ib_scale_mode)], dtype=np.int64)
 
 
 def save(name, **arrs):
@@ -389,6 +389,8 @@ def main():
     cases["model_addition_adaln_f3"] = lambda: model_case("model_addition_adaln_f3", OracleConfig(2, 64, 4, 80, 8, 0, 3, 2, True, "adaln", "addition"), 2, 33)
     cases["model_addition_ln_f2_pre"] = lambda: model_case("model_addition_ln_f2_pre", OracleConfig(1, 64, 4, 80, 8, 0, 2, 2, False, "ln", "addition"), 2, 17)
     cases["model_simple_adaln_f3"] = lambda: model_case("model_simple_adaln_f3", OracleConfig(2, 64, 4, 80, 8, 0, 3, 2, True, "adaln", "simple"), 2, 33)
+    cases["model_sea_fourier_adaln_f3"] = lambda: model_case("model_sea_fourier_adaln_f3", OracleConfig(2, 64, 4, 80, 8, 0, 3, 2, True, "adaln", "sea", "add", "fourier"), 2, 21)
+    cases["model_sea_linear_ln_f2_pre"] = lambda: model_case("model_sea_linear_ln_f2_pre", OracleConfig(1, 64, 4, 80, 8, 0, 2, 2, False, "ln", "sea", "add", "linear"), 2, 19)
     cases["model_sea_noib_adaln_f2"] = lambda: model_case("model_sea_noib_adaln_f2", OracleConfig(1, 64, 4, 80, 8, 0, 2, 2, True, "adaln", "sea", "none"), 2, 20)
     for T in (1, 7, 16, 65):
         cases[f"model_small_adaln_f3_T{T}"] = (lambda T=T: model_case(

@@ -23,7 +23,7 @@ def build(cfg, dtype="fp32"):
     from sea_amd.models.temporal import TemporalModel
 
     m = TemporalModel(cfg.num_layers, cfg.embed_dim, cfg.n_heads, cfg.max_len, cfg.scale_ratio, cfg.src_len, cfg.num_variables,
-                      cfg.down_proj, 0.0, cfg.exchange_mode, "learnable", "mlp", cfg.ib_addition_mode, 1, 1, cfg.add_info_after_cross, cfg.LN_type)
+                      cfg.down_proj, 0.0, cfg.exchange_mode, "learnable", cfg.ib_scale_mode, cfg.ib_addition_mode, 1, 1, cfg.add_info_after_cross, cfg.LN_type)
     p = recipe_params(cfg)
     with torch.no_grad():
         for k, prm in m.named_parameters():
@@ -39,16 +39,18 @@ def gpu(a):
 MODEL_CASES = ["model_tiny_adaln_f3", "model_tiny_ln_f2", "model_tiny_adaln_f2_pre", "model_small_srclen2",
                "model_small_adaln_f3_T1", "model_small_adaln_f3_T7", "model_small_adaln_f3_T16", "model_small_adaln_f3_T65",
                # ablation variants: exchange_mode 'addition' / 'simple', ib_addition_mode 'none'
-               "model_addition_adaln_f3", "model_addition_ln_f2_pre", "model_simple_adaln_f3", "model_sea_noib_adaln_f2"]
+               "model_addition_adaln_f3", "model_addition_ln_f2_pre", "model_simple_adaln_f3", "model_sea_noib_adaln_f2",
+               # ib_scale_mode 'fourier' (the constructor's default) and 'linear'
+               "model_sea_fourier_adaln_f3", "model_sea_linear_ln_f2_pre"]
 
 
-@pytest.mark.parametrize("xmode,ibmode", [("addition", "add"), ("simple", "add"), ("sea", "none")])
-def test_ablation_variants_rollout_bf16_and_training_refused(xmode, ibmode):
+@pytest.mark.parametrize("xmode,ibmode,ibscale", [("addition", "add", "mlp"), ("simple", "add", "mlp"), ("sea", "none", "mlp"), ("sea", "add", "fourier"), ("addition", "add", "linear")])
+def test_ablation_variants_rollout_bf16_and_training_refused(xmode, ibmode, ibscale):
     """The ablation variants through the same plan machinery: bf16 forward within the stated tolerance of the fp32 oracle, KV-cache rollout
     equal to the recompute rollout, and a loud refusal of the backward (training covers 'sea' / 'add' only)."""
     from sea_amd.utils.train_utils import rollout
 
-    cfg = O.OracleConfig(2, 128, 4, 96, 8, 0, 3, 2, True, "adaln", xmode, ibmode)
+    cfg = O.OracleConfig(2, 128, 4, 96, 8, 0, 3, 2, True, "adaln", xmode, ibmode, ibscale)
     x, _, ib = recipe_inputs(2, 40, cfg, seed=11)
     ref = O.model_forward(x, ib, recipe_params(cfg), cfg)
     m = build(cfg, "bf16")

@@ -10,12 +10,13 @@ from sea_amd.models.temporal import SEABlockTemporal, TemporalModel, create_bloc
 
 def make(cfg: OracleConfig, **kw):
     return TemporalModel(cfg.num_layers, cfg.embed_dim, cfg.n_heads, cfg.max_len, cfg.scale_ratio, cfg.src_len, cfg.num_variables,
-                         cfg.down_proj, 0.0, cfg.exchange_mode, "learnable", "mlp", cfg.ib_addition_mode, 1, 1, cfg.add_info_after_cross, cfg.LN_type, **kw)
+                         cfg.down_proj, 0.0, cfg.exchange_mode, "learnable", cfg.ib_scale_mode, cfg.ib_addition_mode, 1, 1, cfg.add_info_after_cross, cfg.LN_type, **kw)
 
 
 @pytest.mark.parametrize("cfg", [OracleConfig(1, 64, 4, 24, 8, 0, 3, 2, True, "adaln"), OracleConfig(2, 64, 4, 24, 8, 0, 2, 2, True, "ln"),
                                  OracleConfig(2, 64, 4, 24, 8, 0, 3, 2, True, "adaln", "addition"), OracleConfig(1, 64, 4, 24, 8, 0, 2, 2, False, "ln", "simple"),
-                                 OracleConfig(1, 64, 4, 24, 8, 0, 2, 2, True, "adaln", "sea", "none")])
+                                 OracleConfig(1, 64, 4, 24, 8, 0, 2, 2, True, "adaln", "sea", "none"),
+                                 OracleConfig(2, 64, 4, 24, 8, 0, 3, 2, True, "adaln", "sea", "add", "fourier"), OracleConfig(1, 64, 4, 24, 8, 0, 2, 2, True, "ln", "sea", "add", "linear")])
 def test_parameter_schema_matches_reference(cfg):
     """Names, order and shapes equal the reference's named_parameters() (oracle/recipe.param_schema is asserted equal to the
     reference's own by tests/golden/make_fixtures.py)."""
