@@ -44,6 +44,27 @@ MODEL_CASES = ["model_tiny_adaln_f3", "model_tiny_ln_f2", "model_tiny_adaln_f2_p
                "model_sea_fourier_adaln_f3", "model_sea_linear_ln_f2_pre"]
 
 
+@pytest.mark.parametrize("F,ln,after", [(2, "ln", True), (2, "adaln", False), (3, "ln", True)])
+def test_bf16_fused_launches_at_shipped_widths(F, ln, after):
+    """E = 256 / D = 128 (the widths sea_exchange_tail and the 16-row Linear + norm launches instantiate) with the configurations the golden
+    fixtures do not reach in bf16: F = 2 (one segment per tail), LayerNorm without modulation, the info-bottleneck add in front of the block;
+    forward against the fp32 oracle, and the KV-cache rollout (M = 2 rows per launch) against the recompute rollout."""
+    from sea_amd.utils.train_utils import rollout
+
+    cfg = O.OracleConfig(2, 256, 8, 64, 8, 0, F, 2, after, ln)
+    x, _, ib = recipe_inputs(2, 50, cfg, seed=21)
+    ref = O.model_forward(x, ib, recipe_params(cfg), cfg)
+    m = build(cfg, "bf16")
+    with torch.no_grad():
+        out = m(x.cuda(), ib.cuda())
+        names = [r.name for r in m.engine().plan(2, 50, "full").records]
+    assert "cross0.tail" in names and "cross.down_norm_old" in names
+    assert rel_l2(out.cpu().numpy(), ref.numpy()) < BF16_TOL
+    a = rollout(m, x[:, :1].cuda(), ib.cuda(), 10, mode="recompute")
+    b = rollout(m, x[:, :1].cuda(), ib.cuda(), 10, mode="kv")
+    assert rel_l2(b.cpu().numpy(), a.cpu().numpy()) < 2e-2
+
+
 @pytest.mark.parametrize("xmode,ibmode,ibscale", [("addition", "add", "mlp"), ("simple", "add", "mlp"), ("sea", "none", "mlp"), ("sea", "add", "fourier"), ("addition", "add", "linear")])
 def test_ablation_variants_rollout_bf16_and_training_refused(xmode, ibmode, ibscale):
     """The ablation variants through the same plan machinery: bf16 forward within the stated tolerance of the fp32 oracle, KV-cache rollout
