@@ -1,5 +1,6 @@
-"""Times sea_exchange_tail at the cfg2 shape (M = 2024, D = 128, E = 256, 2 segments) with its stages switched off one at a time
-(SEA_XTAIL_PROBE, read once per process): python tools/tail_probe.py [has_down]"""
+"""Times sea_exchange_tail at the cfg2 shape (M = 2024, D = 128, E = 256, 2 segments), 50 back-to-back launches in one captured graph:
+python tools/tail_probe.py [has_down].  (The probe build behind DESIGN.md §5 — stages switched off one at a time — was this script over a kernel
+with a debug switch; the switch is gone, the timing harness stays.)"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -16,7 +17,6 @@ Wup, bup, Wd, bd = rnd(E, D, scale=0.1).to(dt), rnd(E), rnd(D, E, scale=0.1).to(
 x, mod = rnd(M, E), rnd(M, 2 * D).to(dt)
 gamma, beta = rnd(D), rnd(D)
 nd = torch.empty(M, D, device=dev, dtype=dt)
-# something between launches that evicts nothing but breaks back-to-back pipelining like a plan does: a tiny dependent kernel
 down = dict(W=Wd, bias=bd, gamma=gamma, beta=beta, mod=mod, Yact=nd) if has_down else None
 graph = torch.cuda.CUDAGraph()
 side = torch.cuda.Stream()
@@ -35,4 +35,4 @@ for _ in range(10):
     graph.replay()
 e1.record()
 torch.cuda.synchronize()
-print(f"probe={os.environ.get('SEA_XTAIL_PROBE', '0')} has_down={has_down}: {e0.elapsed_time(e1) / 500 * 1e3:.2f} us per launch")
+print(f"has_down={has_down}: {e0.elapsed_time(e1) / 500 * 1e3:.2f} us per launch")
