@@ -61,6 +61,8 @@ def param_schema(cfg: OracleConfig) -> "OrderedDict[str, Tuple[Tuple[int, ...], 
     s: "OrderedDict[str, Tuple[Tuple[int, ...], str]]" = OrderedDict()
     for layer in range(cfg.num_layers):
         b = f"blocks.{layer}."
+        if cfg.exchange_mode == "pool":     # SEAPoolBlockTemporal (models/temporal.py:197-241): a module's own parameters precede its sub-modules'
+            s[b + "pool_token"] = ((1, 1, D), "randn")
         if cfg.ib_scale_mode == "fourier":    # GaussianFourierProjection(1, E/2): a fixed random W (models/base_blocks.py:143-148)
             s[b + "ib.W"] = ((1, E // 2), "randn")
         elif cfg.ib_scale_mode == "linear":   # nn.Linear(1, E)
@@ -94,8 +96,15 @@ def param_schema(cfg: OracleConfig) -> "OrderedDict[str, Tuple[Tuple[int, ...], 
             for i in range(F):
                 for j in range(F):
                     _attention(s, f"{b}cross_attn.{i}.{j}.", D)
+        elif cfg.exchange_mode == "pool":   # one cross-attention per field (field -> pool)
+            for i in range(F):
+                _attention(s, f"{b}cross_attn.{i}.", D)
         for i in range(F):
             _norm(s, f"{b}ln_cross.{i}.", D, cfg.LN_type)
+        if cfg.exchange_mode == "pool":
+            _norm(s, b + "ln_pool.", D, cfg.LN_type)
+            _linear(s, b + "pool_update.0.", 2 * D, D * F)
+            _linear(s, b + "pool_update.2.", D, 2 * D)
     for i in range(F):
         _norm(s, f"ln.{i}.", E, cfg.LN_type)
     return s

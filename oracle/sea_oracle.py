@@ -198,6 +198,26 @@ def add_exchange(xs: List[torch.Tensor], cond: torch.Tensor, p: Params, pre: str
     return out
 
 
+def pool_exchange(xs: List[torch.Tensor], cond: torch.Tensor, p: Params, pre: str, cfg: OracleConfig) -> List[torch.Tensor]:
+    """SEAPoolBlockTemporal._apply_exchange (models/temporal.py:255-277) with pool_update_method='mlp' (the only one create_block_temporal
+    can select, :314-324) in eval mode: every field is down-projected, normalised and given the sinusoidal positions of
+    PositionalEncoding (models/base_blocks.py:355-372) from its pre-exchange value; the pool token the code prepares (pool_token,
+    ln_pool) is overwritten by pool_update(cat(normalized)) (:270: Linear(F D -> 2 D), GELU, Linear(2 D -> D)); field i attends the
+    pool (masked cross-attention, q from the field), and x_i += cross_up_i(GELU(normalized_i + attention))."""
+    F = cfg.num_variables
+    T_ = xs[0].shape[1]
+    pe = sinusoidal_pe(T_, cfg.down_dim, xs[0].dtype)[None]
+    nrm = [norm(linear(xs[j], p[f"{pre}cross_down.{j}.weight"], p[f"{pre}cross_down.{j}.bias"]), cond, p, f"{pre}ln_cross.{j}.", cfg.LN_type) + pe
+           for j in range(F)]
+    cat = torch.cat(nrm, dim=-1)
+    pool = linear(gelu_erf(linear(cat, p[pre + "pool_update.0.weight"], p[pre + "pool_update.0.bias"])), p[pre + "pool_update.2.weight"], p[pre + "pool_update.2.bias"])
+    out = []
+    for i in range(F):
+        a = masked_attention(nrm[i], pool, p, f"{pre}cross_attn.{i}.", cfg.n_heads, cfg.src_len)
+        out.append(xs[i] + linear(gelu_erf(nrm[i] + a), p[f"{pre}cross_up.{i}.weight"], p[f"{pre}cross_up.{i}.bias"]))
+    return out
+
+
 def exchange(xs: List[torch.Tensor], cond: torch.Tensor, p: Params, pre: str, cfg: OracleConfig) -> List[torch.Tensor]:
     """create_block_temporal's dispatch (models/temporal.py:314-324); 'simple' = SimpleBlockTemporal (:304-306), no exchange."""
     if cfg.exchange_mode == "sea":
@@ -206,6 +226,8 @@ def exchange(xs: List[torch.Tensor], cond: torch.Tensor, p: Params, pre: str, cf
         return add_exchange(xs, cond, p, pre, cfg)
     if cfg.exchange_mode == "simple":
         return list(xs)
+    if cfg.exchange_mode == "pool":
+        return pool_exchange(xs, cond, p, pre, cfg)
     raise ValueError(f"Invalid exchange_mode: {cfg.exchange_mode}")
 
 

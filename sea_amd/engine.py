@@ -556,6 +556,42 @@ class Plan:
                 self._gemm([dict(A=ndall[0], W=eng.eye(D), n_seg=F, a_seg_stride=M * D, Cact=sg, act=1)], "add.sum_gelu")
                 self._gemm([dict(A=sg, W=P.act(f"{pre}cross_up.{i}.weight"), bias=P.f32_vec(f"{pre}cross_up.{i}.bias"), R=xr[i], C32=xr[i])
                             for i in range(F)], "add.up")
+            if xmode == "pool":
+                # -- 'pool' exchange (models/temporal.py:255-277, pool_update_method 'mlp'; Jacobi): n_j = ln_cross_j(cross_down_j(x_j)) + pe; pool =
+                # MLP(cat_j n_j); a_i = cross_attn_i(n_i, pool); x_i += cross_up_i(GELU(n_i + a_i)).  `big` holds [n_0 .. n_{F-1} | a_0 .. a_{F-1}] side by
+                # side, so that cat(n) is a view and (n_i, a_i) are two segments of one identity-weight GEMM
+                FD = F * D
+                big = self._buf(M, 2 * FD)
+                nrm = [self._buf(M, D) for _ in range(F)]
+                pe_t = self._buf(M, D, dtype=f32)
+                pe_t.copy_(blk_pe(eng, l)[:T].repeat(B, 1))
+                if fuse_norm and D <= 256 and D % 16 == 0:
+                    self._gemm_norm([dict(A=xa[j], W=P.act(f"{pre}cross_down.{j}.weight"), bias=P.f32_vec(f"{pre}cross_down.{j}.bias"), Yact=nrm[j],
+                                          **norm_params(f"{pre}ln_cross.{j}.", D)) for j in range(F)], "pool.down_norm")
+                else:
+                    self._gemm([dict(A=xa[j], W=P.act(f"{pre}cross_down.{j}.weight"), bias=P.f32_vec(f"{pre}cross_down.{j}.bias"), C32=dn[j])
+                                for j in range(F)], "pool.down")
+                    self._norm([dict(X=dn[j], Yact=nrm[j], **norm_params(f"{pre}ln_cross.{j}.", D)) for j in range(F)], D, "pool.norm")
+                self._gemm([dict(A=nrm[j], W=eng.eye(D), R=pe_t, Cact=big[:, j * D:(j + 1) * D]) for j in range(F)], "pool.pe_add")
+                hp, pool = self._buf(M, 2 * D), self._buf(M, D)
+                self._gemm([dict(A=big[:, :FD], W=P.act(f"{pre}pool_update.0.weight"), bias=P.f32_vec(f"{pre}pool_update.0.bias"), Cact=hp, act=1)], "pool.update0")
+                self._gemm([dict(A=hp, W=P.act(f"{pre}pool_update.2.weight"), bias=P.f32_vec(f"{pre}pool_update.2.bias"), Cact=pool)], "pool.update2")
+                Qp = [self._buf(B, H, T, hd_c) for _ in range(F)]
+                Kp = [self._buf(B, H, cap, hd_c, zero=True) for _ in range(F)]
+                Vp = [self._buf(B, H, hd_c, cap, zero=True) for _ in range(F)]
+                att_p = [self._buf(M, D) for _ in range(F)]
+                qg = []
+                for i in range(F):
+                    ca = f"{pre}cross_attn.{i}."
+                    qg.append(dict(A=big[:, i * D:(i + 1) * D], W=P.act(ca + "q.weight"), bias=P.f32_vec(ca + "q.bias"), col0=0, Q=Qp[i]))
+                    qg.append(dict(A=pool, W=P.act(ca + "k.weight", 2 * D), bias=P.f32_vec(ca + "k.bias", 2 * D), col0=D, K=Kp[i], Vt=Vp[i]))
+                self._qkv(qg, rope_c, hd_c, "pool.qkv_rope")
+                self._attn([dict(Q=Qp[i], K=Kp[i], Vt=Vp[i], O=att_p[i]) for i in range(F)], hd_c, D, "pool.attention")
+                self._gemm([dict(A=att_p[i], W=P.act(f"{pre}cross_attn.{i}.projection.weight"), Cact=big[:, FD + i * D:FD + (i + 1) * D]) for i in range(F)], "pool.proj")
+                sg = [self._buf(M, D) for _ in range(F)]
+                self._gemm([dict(A=big[:, i * D:(i + 1) * D], W=eng.eye(D), n_seg=2, a_seg_stride=FD, Cact=sg[i], act=1) for i in range(F)], "pool.sum_gelu")
+                self._gemm([dict(A=sg[i], W=P.act(f"{pre}cross_up.{i}.weight"), bias=P.f32_vec(f"{pre}cross_up.{i}.bias"), R=xr[i], C32=xr[i])
+                            for i in range(F)], "pool.up")
             # -- state exchange (Gauss-Seidel over i, models/temporal.py:187-192)
             if F > 1 and xmode == "sea":
                 if fuse_oproj:
@@ -1003,6 +1039,11 @@ def _fill_gemm(g, A, W, bias=None, R=None, C32=None, Cact=None, n_seg=1, a_seg_s
     g.n_seg, g.act, g.bias_scale = n_seg, act, bias_scale
 
 
+def blk_pe(eng: "TemporalEngine", layer: int) -> torch.Tensor:
+    """The block's sinusoidal table [max_len, D] (PositionalEncoding buffer `pe`, models/base_blocks.py:355-368) on the device."""
+    return eng.model.blocks[layer].pos_encoder.pe[0].to(device=eng.device, dtype=torch.float32)
+
+
 class TemporalEngine:
     """Owns the flat parameter buffers of one TemporalModel on one GPU and the plans built over them."""
 
@@ -1012,15 +1053,15 @@ class TemporalEngine:
             raise RuntimeError("sea_amd: TemporalModel runs only on an MI355X (no CPU fallback)")
         m = model
         self.ib_mode = {"mlp": 0, "linear": 1, "fourier": 2}.get(m.ib_scale_mode.lower(), -1)
-        if (m.exchange_mode not in ("sea", "addition", "simple") or self.ib_mode < 0 or m.ib_addition_mode.lower() not in ("add", "none")
+        if (m.exchange_mode not in ("sea", "addition", "simple", "pool") or self.ib_mode < 0 or m.ib_addition_mode.lower() not in ("add", "none")
                 or (self.ib_mode == 0 and m.ib_mlp_layers != 1) or m.ib_num != 1 or (self.ib_mode != 0 and m.embed_dim % 8)):
             raise NotImplementedError(
-                "sea_amd native path covers exchange_mode in {'sea', 'addition', 'simple'}, ib_scale_mode in {'mlp', 'linear', 'fourier'}, ib_addition_mode in "
+                "sea_amd native path covers exchange_mode in {'sea', 'addition', 'simple', 'pool'}, ib_scale_mode in {'mlp', 'linear', 'fourier'}, ib_addition_mode in "
                 "{'add', 'none'}, ib_mlp_layers=1, ib_num=1; got "
                 f"{m.exchange_mode}/{m.ib_scale_mode}/{m.ib_addition_mode}/{m.ib_mlp_layers}/{m.ib_num}")
         self.default_variant = m.exchange_mode == "sea" and m.ib_addition_mode.lower() == "add" and self.ib_mode == 0   # what training covers
         E, H, D = m.embed_dim, m.n_heads, m.down_dim
-        for hd, what in ((E // H, "self"),) + (((D // H, "cross"),) if m.exchange_mode == "sea" else ()):
+        for hd, what in ((E // H, "self"),) + (((D // H, "cross"),) if m.exchange_mode in ("sea", "pool") else ()):
             ok = hd in (8, 16, 32, 64, 128) or (hd == 256 and act_dtype == torch.bfloat16)
             if not ok or hd * H != (E if what == "self" else D):
                 raise NotImplementedError(f"sea_amd: unsupported {what}-attention head dim {hd} (supported: 8, 16, 32, 64, 128; 256 with "
@@ -1033,7 +1074,11 @@ class TemporalEngine:
         self.params = FlatParams(model, device, act_dtype)
         blk = model.blocks[0]
         self.rope_self = torch.view_as_real(blk.attn["self"][0].freqs_cis.to(device)).contiguous()
-        self.rope_cross = torch.view_as_real(blk.cross_attn[0][0].freqs_cis.to(device)).contiguous() if m.exchange_mode == "sea" else None
+        self.rope_cross = None
+        if m.exchange_mode == "sea":
+            self.rope_cross = torch.view_as_real(blk.cross_attn[0][0].freqs_cis.to(device)).contiguous()
+        elif m.exchange_mode == "pool":
+            self.rope_cross = torch.view_as_real(blk.cross_attn[0].freqs_cis.to(device)).contiguous()
         self._eyes: Dict[int, torch.Tensor] = {}
         self._plans: Dict[Tuple, Plan] = {}
         self._graphs: Dict[Tuple, Tuple] = {}
@@ -1051,6 +1096,9 @@ class TemporalEngine:
         return e
 
     def plan(self, B: int, T: int, mode: str = "full") -> Plan:
+        if mode == "step" and self.model.exchange_mode == "pool":
+            raise NotImplementedError("sea_amd: the KV-cache rollout does not cover exchange_mode='pool' (its sinusoidal positions are relative to the window); "
+                                      "use the recompute rollout")
         key = (B, T, mode)
         p = self._plans.get(key)
         if p is None:

@@ -7,8 +7,8 @@ TemporalModel.forward hands the whole forward to sea_amd.engine (≈30 fused HIP
 
 Scope: exchange_mode='sea' with ib_scale_mode='mlp', ib_addition_mode='add' — what both shipped configs select
 (configs/cylinder_flow.py:112-128, configs/multiphase_flow.py:112-128) — forward, rollout and training; the ablation variants
-exchange_mode 'addition' / 'simple', ib_scale_mode 'fourier' (the constructor's default) / 'linear' and ib_addition_mode 'none' forward / rollout
-only.  'pool' and the concat / attention info-bottleneck additions are valid arguments of the reference that this build does not
+exchange_mode 'addition' / 'simple' / 'pool', ib_scale_mode 'fourier' (the constructor's default) / 'linear' and ib_addition_mode 'none' forward / rollout
+only.  The concat / attention info-bottleneck additions are valid arguments of the reference that this build does not
 accelerate: they raise NotImplementedError (invalid names raise ValueError as in the reference).
 """
 from __future__ import annotations
@@ -188,6 +188,31 @@ class AddBlockTemporal(BaseBlockTemporal):
         raise NotImplementedError("sea_amd.AddBlockTemporal: call TemporalModel.forward (whole-model native path)")
 
 
+class SEAPoolBlockTemporal(BaseBlockTemporal):
+    """Ablation block with an information pool (reference :197-277, pool_update_method='mlp' — the only one create_block_temporal selects): every
+    field attends a pool token sequence computed from all (pre-exchange) fields.  Parameter container for the whole-model path; the pool token
+    and ln_pool are created, as in the reference, and never reach the output (the code overwrites the token it prepares)."""
+
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.n_heads, self.max_len, self.src_len = kwargs['n_heads'], kwargs['max_len'], kwargs['src_len']
+        self.dropout, self.LN_type = kwargs['dropout'], kwargs['LN_type']
+        self.pool_update_method = kwargs.get('pool_update_method', 'mlp')
+        if self.pool_update_method != 'mlp':
+            raise NotImplementedError("sea_amd.SEAPoolBlockTemporal: pool_update_method 'mlp' only")
+        F, E, D = self.num_variables, self.internal_embed_dim, self.down_dim
+        self.pool_token = nn.Parameter(torch.randn(1, 1, D))
+        self.cross_down = nn.ModuleList([nn.Linear(E, D) for _ in range(F)])
+        self.cross_up = nn.ModuleList([nn.Linear(D, E) for _ in range(F)])
+        self.cross_attn = nn.ModuleList([MaskedMultiHeadCrossAttention(self.n_heads, D, self.max_len, self.src_len, self.dropout) for _ in range(F)])
+        self.ln_cross = nn.ModuleList([_make_norm(self.LN_type, D, self.ib_num) for _ in range(F)])
+        self.ln_pool = _make_norm(self.LN_type, D, self.ib_num)
+        self.pool_update = nn.Sequential(nn.Linear(D * F, D * 2), nn.GELU(), nn.Linear(D * 2, D))
+
+    def _apply_exchange(self, x_vars, x_add):
+        raise NotImplementedError("sea_amd.SEAPoolBlockTemporal: call TemporalModel.forward (whole-model native path)")
+
+
 class SimpleBlockTemporal(BaseBlockTemporal):
     """Ablation block without exchange (reference :304-306)."""
 
@@ -203,7 +228,7 @@ def create_block_temporal(exchange_mode, *args, **kwargs):
     if exchange_mode == 'simple':
         return SimpleBlockTemporal(*args, **kwargs)
     if exchange_mode == 'pool':
-        raise NotImplementedError("sea_amd: exchange_mode='pool' is an ablation variant outside the accelerated path")
+        return SEAPoolBlockTemporal(*args, **kwargs)
     raise ValueError(f"Invalid exchange_mode: {exchange_mode}")
 
 

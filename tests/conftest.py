@@ -29,7 +29,7 @@ def cfg_from_meta(meta):
     return OracleConfig(num_layers=m[0], embed_dim=m[1], n_heads=m[2], max_len=m[3], scale_ratio=m[4], src_len=m[5],
                         num_variables=m[6], down_proj=m[7], add_info_after_cross=bool(m[8]),
                         LN_type="adaln" if m[9] else "ln",
-                        exchange_mode=("sea", "addition", "simple")[m[10]] if len(m) > 10 else "sea",
+                        exchange_mode=("sea", "addition", "simple", "pool")[m[10]] if len(m) > 10 else "sea",
                         ib_addition_mode=("add", "none")[m[11]] if len(m) > 11 else "add",
                         ib_scale_mode=("mlp", "linear", "fourier")[m[12]] if len(m) > 12 else "mlp")
 

@@ -53,7 +53,7 @@ def build_reference(cfg: OracleConfig, dropout=0.0):
 def cfg_meta(cfg: OracleConfig):
     return np.array([cfg.num_layers, cfg.embed_dim, cfg.n_heads, cfg.max_len, cfg.scale_ratio, cfg.src_len,
                      cfg.num_variables, cfg.down_proj, int(cfg.add_info_after_cross),
-                     1 if cfg.LN_type == "adaln" else 0, ("sea", "addition", "simple").index(cfg.exchange_mode),
+                     1 if cfg.LN_type == "adaln" else 0, ("sea", "addition", "simple", "pool").index(cfg.exchange_mode),
                      ("add", "none").index(cfg.ib_addition_mode), ("mlp", "linear", "fourier").index(cfg.ib_scale_mode)], dtype=np.int64)
 
 
@@ -389,6 +389,8 @@ def main():
     cases["model_addition_adaln_f3"] = lambda: model_case("model_addition_adaln_f3", OracleConfig(2, 64, 4, 80, 8, 0, 3, 2, True, "adaln", "addition"), 2, 33)
     cases["model_addition_ln_f2_pre"] = lambda: model_case("model_addition_ln_f2_pre", OracleConfig(1, 64, 4, 80, 8, 0, 2, 2, False, "ln", "addition"), 2, 17)
     cases["model_simple_adaln_f3"] = lambda: model_case("model_simple_adaln_f3", OracleConfig(2, 64, 4, 80, 8, 0, 3, 2, True, "adaln", "simple"), 2, 33)
+    cases["model_pool_adaln_f3"] = lambda: model_case("model_pool_adaln_f3", OracleConfig(2, 64, 4, 80, 8, 0, 3, 2, True, "adaln", "pool"), 2, 27)
+    cases["model_pool_ln_f2"] = lambda: model_case("model_pool_ln_f2", OracleConfig(1, 64, 4, 80, 8, 1, 2, 2, True, "ln", "pool"), 2, 18)
     cases["model_sea_fourier_adaln_f3"] = lambda: model_case("model_sea_fourier_adaln_f3", OracleConfig(2, 64, 4, 80, 8, 0, 3, 2, True, "adaln", "sea", "add", "fourier"), 2, 21)
     cases["model_sea_linear_ln_f2_pre"] = lambda: model_case("model_sea_linear_ln_f2_pre", OracleConfig(1, 64, 4, 80, 8, 0, 2, 2, False, "ln", "sea", "add", "linear"), 2, 19)
     cases["model_sea_noib_adaln_f2"] = lambda: model_case("model_sea_noib_adaln_f2", OracleConfig(1, 64, 4, 80, 8, 0, 2, 2, True, "adaln", "sea", "none"), 2, 20)

@@ -41,7 +41,8 @@ MODEL_CASES = ["model_tiny_adaln_f3", "model_tiny_ln_f2", "model_tiny_adaln_f2_p
                # ablation variants: exchange_mode 'addition' / 'simple', ib_addition_mode 'none'
                "model_addition_adaln_f3", "model_addition_ln_f2_pre", "model_simple_adaln_f3", "model_sea_noib_adaln_f2",
                # ib_scale_mode 'fourier' (the constructor's default) and 'linear'
-               "model_sea_fourier_adaln_f3", "model_sea_linear_ln_f2_pre"]
+               "model_sea_fourier_adaln_f3", "model_sea_linear_ln_f2_pre",
+               "model_pool_adaln_f3", "model_pool_ln_f2"]
 
 
 @pytest.mark.parametrize("F,ln,after", [(2, "ln", True), (2, "adaln", False), (3, "ln", True)])
@@ -65,7 +66,7 @@ def test_bf16_fused_launches_at_shipped_widths(F, ln, after):
     assert rel_l2(b.cpu().numpy(), a.cpu().numpy()) < 2e-2
 
 
-@pytest.mark.parametrize("xmode,ibmode,ibscale", [("addition", "add", "mlp"), ("simple", "add", "mlp"), ("sea", "none", "mlp"), ("sea", "add", "fourier"), ("addition", "add", "linear")])
+@pytest.mark.parametrize("xmode,ibmode,ibscale", [("addition", "add", "mlp"), ("simple", "add", "mlp"), ("sea", "none", "mlp"), ("sea", "add", "fourier"), ("addition", "add", "linear"), ("pool", "add", "mlp")])
 def test_ablation_variants_rollout_bf16_and_training_refused(xmode, ibmode, ibscale):
     """The ablation variants through the same plan machinery: bf16 forward within the stated tolerance of the fp32 oracle, KV-cache rollout
     equal to the recompute rollout, and a loud refusal of the backward (training covers 'sea' / 'add' only)."""
@@ -80,8 +81,12 @@ def test_ablation_variants_rollout_bf16_and_training_refused(xmode, ibmode, ibsc
     assert rel_l2(out.cpu().numpy(), ref.numpy()) < BF16_TOL
     m32 = build(cfg, "fp32")
     a = rollout(m32, x[:, :1].cuda(), ib.cuda(), 12, mode="recompute")
-    b = rollout(m32, x[:, :1].cuda(), ib.cuda(), 12, mode="kv")
-    assert rel_l2(b.cpu().numpy(), a.cpu().numpy()) < 1e-5
+    if xmode == "pool":   # its window-relative sinusoidal positions are not covered by the KV-cache step plan: refused loudly
+        with pytest.raises(NotImplementedError, match="KV-cache"):
+            rollout(m32, x[:, :1].cuda(), ib.cuda(), 12, mode="kv")
+    else:
+        b = rollout(m32, x[:, :1].cuda(), ib.cuda(), 12, mode="kv")
+        assert rel_l2(b.cpu().numpy(), a.cpu().numpy()) < 1e-5
     assert rel_l2(a.cpu().numpy(), O.rollout(x[:, :1], ib, 12, recipe_params(cfg), cfg).numpy()) < FP32_TOL
     m32.train()
     with pytest.raises(NotImplementedError, match="training"):

@@ -16,7 +16,8 @@ def make(cfg: OracleConfig, **kw):
 @pytest.mark.parametrize("cfg", [OracleConfig(1, 64, 4, 24, 8, 0, 3, 2, True, "adaln"), OracleConfig(2, 64, 4, 24, 8, 0, 2, 2, True, "ln"),
                                  OracleConfig(2, 64, 4, 24, 8, 0, 3, 2, True, "adaln", "addition"), OracleConfig(1, 64, 4, 24, 8, 0, 2, 2, False, "ln", "simple"),
                                  OracleConfig(1, 64, 4, 24, 8, 0, 2, 2, True, "adaln", "sea", "none"),
-                                 OracleConfig(2, 64, 4, 24, 8, 0, 3, 2, True, "adaln", "sea", "add", "fourier"), OracleConfig(1, 64, 4, 24, 8, 0, 2, 2, True, "ln", "sea", "add", "linear")])
+                                 OracleConfig(2, 64, 4, 24, 8, 0, 3, 2, True, "adaln", "sea", "add", "fourier"), OracleConfig(1, 64, 4, 24, 8, 0, 2, 2, True, "ln", "sea", "add", "linear"),
+                                 OracleConfig(2, 64, 4, 24, 8, 0, 3, 2, True, "adaln", "pool"), OracleConfig(1, 64, 4, 24, 8, 0, 2, 2, True, "ln", "pool")])
 def test_parameter_schema_matches_reference(cfg):
     """Names, order and shapes equal the reference's named_parameters() (oracle/recipe.param_schema is asserted equal to the
     reference's own by tests/golden/make_fixtures.py)."""
@@ -66,7 +67,7 @@ def test_error_behaviour():
     with pytest.raises(ValueError):
         TemporalModel(1, 64, 4, 24, 8, 0, 2, exchange_mode="sea", ib_scale_mode="mlp", LN_type="bogus")
     with pytest.raises(NotImplementedError):
-        TemporalModel(1, 64, 4, 24, 8, 0, 2, exchange_mode="pool", ib_scale_mode="mlp")
+        TemporalModel(1, 64, 4, 24, 8, 0, 2, exchange_mode="sea", ib_scale_mode="mlp", ib_addition_mode="concat")
     with pytest.raises(ValueError):
         create_block_temporal("nope")
     m = make(OracleConfig(1, 64, 4, 24, 8, 0, 2, 2, True, "adaln"))

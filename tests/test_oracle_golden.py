@@ -107,7 +107,9 @@ MODEL_CASES = ["model_tiny_adaln_f3", "model_tiny_ln_f2", "model_tiny_adaln_f2_p
                # ablation variants: exchange_mode 'addition' / 'simple', ib_addition_mode 'none'
                "model_addition_adaln_f3", "model_addition_ln_f2_pre", "model_simple_adaln_f3", "model_sea_noib_adaln_f2",
                # ib_scale_mode 'fourier' (the constructor's default) and 'linear'
-               "model_sea_fourier_adaln_f3", "model_sea_linear_ln_f2_pre"]
+               "model_sea_fourier_adaln_f3", "model_sea_linear_ln_f2_pre",
+               # exchange_mode 'pool' (field -> pool-token cross-attention, src_len = 1 in the second case)
+               "model_pool_adaln_f3", "model_pool_ln_f2"]
 
 
 @pytest.mark.parametrize("name", MODEL_CASES)
