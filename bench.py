@@ -276,6 +276,10 @@ def main():
     dom_ms = best
     dom_flops = kernel_flops(name, B, T, F, E, H, D, S)
     achieved = dom_flops / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
+    esz = 2 if args.dtype == "bf16" else 4
+    dom_bytes = None
+    if name == "adaln.cond_gemm":   # hidden matrices in, modulations out, weights once: 12 modules at F = 3 (9 of width 2E, 3 of width 2D)
+        dom_bytes = sum(n_mod * (2 * B * T * (2 * d) * esz + (2 * d) * (2 * d) * esz) for n_mod, d in ((3 * F, E), (F, D)))
 
     # HBM bytes per launch of the dominant kernel, from the committed PMC profile of this same workload (separate --pmc passes, see
     # profiles/README.md); null when the workload or the plan differs from the profiled one
@@ -303,6 +307,10 @@ def main():
             "roofline": {"kernel": name, "bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_BF16_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
                          "launch_ms": dom_ms, "launch_ms_single_event_pair": dom_ms_events, "launch_gflop": dom_flops / 1e9,
+                         # the same launch against the other roof (its algorithmic intensity, FLOP per algorithmic byte, sits near the machine balance
+                         # of 2500 / 8 = 312): algorithmic bytes = operands + weights + outputs once, over the same launch duration, against 8 TB/s
+                         "algorithmic_bytes": dom_bytes, "hbm_GBps": (dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_bytes and dom_ms > 0 else None),
+                         "hbm_frac": (dom_bytes / (dom_ms * 1e-3) / 1e9 / 8000.0 if dom_bytes and dom_ms > 0 else None),
                          "device_ms_all_launches": total_ms,
                          "timing": "launch_ms: HIP events around 20 back-to-back launches of the dominant record (one captured graph) / 20; "
                                    "launch_breakdown_ms: one event pair per launch of the plan (includes ~3-6 us of event / launch gap each)"},
