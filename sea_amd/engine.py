@@ -289,7 +289,8 @@ class Plan:
             arr = (N.SeaGemmNormGroup * len(chunk))()
             for g, d in zip(arr, chunk):
                 ops.fill_gemm_norm_group(g, d["A"], d["W"], d["gamma"], bias=d.get("bias"), R=d.get("R"), C32=d.get("C32"), mod=d.get("mod"),
-                                         beta=d.get("beta"), Y32=d.get("Y32"), Yact=d.get("Yact"), ldy32=d.get("ldy32"), n_seg=d.get("n_seg", 1),
+                                         beta=d.get("beta"), Y32=d.get("Y32"), Yact=d.get("Yact"), mean=d.get("mean"), rstd=d.get("rstd"),
+                                         ldy32=d.get("ldy32"), n_seg=d.get("n_seg", 1),
                                          a_seg_stride=d.get("a_seg_stride", 0), bias_scale=d.get("bias_scale", 1.0), Cact=d.get("Cact"), ib=d.get("ib"))
                 if d.get("Y_is_out") is not None:
                     self._out_patches.append((g, "Y32", d["Y_is_out"]))

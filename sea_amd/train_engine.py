@@ -7,6 +7,8 @@ data-parallel all-reduce and the AdamW kernel each touch a single contiguous ran
 """
 from __future__ import annotations
 
+import os
+
 import ctypes as C
 from typing import Dict, List, Optional, Tuple
 
@@ -255,10 +257,17 @@ class TrainPlan(Plan):
                 sv["nd_new"] = [buf(M, D) for _ in range(F)]
                 sv["stc_new"] = [stats() for _ in range(F)]
                 sv["xa2"] = [buf(M, E) for _ in range(F)]
-                self._gemm([dict(A=sv["xa1"][j], W=P.act(f"{pre}cross_down.{j}.weight"), bias=P.f32_vec(f"{pre}cross_down.{j}.bias"), C32=sv["dn_old"][j])
-                            for j in range(F)], "cross.down_old")
-                self._norm([dict(X=sv["dn_old"][j], Yact=sv["nd_old"][j], mean=sv["stc_old"][j][0], rstd=sv["stc_old"][j][1], **npar(f"{pre}ln_cross.{j}."))
-                            for j in range(F)], D, "cross.norm_old")
+                # cross_down + ln_cross in one launch (sea_gemm_rownorm); the pre-normalisation rows and the statistics are kept for the backward
+                fuse_dn = os.environ.get("SEA_FUSE_NORM", "1") != "0" and D <= 256 and D % 16 == 0
+                if fuse_dn:
+                    self._gemm_norm([dict(A=sv["xa1"][j], W=P.act(f"{pre}cross_down.{j}.weight"), bias=P.f32_vec(f"{pre}cross_down.{j}.bias"), C32=sv["dn_old"][j],
+                                          Yact=sv["nd_old"][j], mean=sv["stc_old"][j][0], rstd=sv["stc_old"][j][1], **npar(f"{pre}ln_cross.{j}."))
+                                     for j in range(F)], "cross.down_norm_old")
+                else:
+                    self._gemm([dict(A=sv["xa1"][j], W=P.act(f"{pre}cross_down.{j}.weight"), bias=P.f32_vec(f"{pre}cross_down.{j}.bias"), C32=sv["dn_old"][j])
+                                for j in range(F)], "cross.down_old")
+                    self._norm([dict(X=sv["dn_old"][j], Yact=sv["nd_old"][j], mean=sv["stc_old"][j][0], rstd=sv["stc_old"][j][1], **npar(f"{pre}ln_cross.{j}."))
+                                for j in range(F)], D, "cross.norm_old")
                 sv["pair"] = {}
                 sv["g"] = [buf(F - 1, M, D) for _ in range(F)]
                 for i in range(F):
@@ -281,7 +290,11 @@ class TrainPlan(Plan):
                     self._gemm([dict(A=sv["g"][i][0], W=P.act(f"{pre}cross_up.{i}.weight"), bias=P.f32_vec(f"{pre}cross_up.{i}.bias"),
                                      bias_scale=float(F - 1), n_seg=F - 1, a_seg_stride=M * D, R=sv["xr"][i], C32=sv["xr"][i],
                                      Cact=(sv["xa2"][i] if i < F - 1 else None))], f"cross{i}.up_sum")
-                    if i < F - 1:
+                    if i < F - 1 and fuse_dn:
+                        self._gemm_norm([dict(A=sv["xa2"][i], W=P.act(f"{pre}cross_down.{i}.weight"), bias=P.f32_vec(f"{pre}cross_down.{i}.bias"), C32=sv["dn_new"][i],
+                                              Yact=sv["nd_new"][i], mean=sv["stc_new"][i][0], rstd=sv["stc_new"][i][1], **npar(f"{pre}ln_cross.{i}."))],
+                                        f"cross{i}.down_norm_new")
+                    elif i < F - 1:
                         self._gemm([dict(A=sv["xa2"][i], W=P.act(f"{pre}cross_down.{i}.weight"), bias=P.f32_vec(f"{pre}cross_down.{i}.bias"),
                                          C32=sv["dn_new"][i])], f"cross{i}.down_new")
                         self._norm([dict(X=sv["dn_new"][i], Yact=sv["nd_new"][i], mean=sv["stc_new"][i][0], rstd=sv["stc_new"][i][1],
