@@ -121,7 +121,9 @@ struct NormEpilogue {
     }
 
     // red: LDS scratch [2][4 waves][16 rows] (XWAVE only; the caller guarantees nobody still reads the operand tile there)
-    __device__ __forceinline__ void finish(const SeaGemmNormGroup& G, f32x4 (&acc)[NI], int m, int col0, int r, int g, int wave, float eps, float* red) {
+    // lds_y (optional): the normalised rows are also written as bf16 K-tiles [N / 64][16 rows][128 B, chunk-swizzled] — the A tile of a following layer
+    __device__ __forceinline__ void finish(const SeaGemmNormGroup& G, f32x4 (&acc)[NI], int m, int col0, int r, int g, int wave, float eps, float* red,
+                                           char* lds_y = nullptr) {
         const int N = G.N;
         const bool mok = m < G.M;
         const int mc = mok ? m : G.M - 1;
@@ -172,6 +174,23 @@ struct NormEpilogue {
             sq = (red[64 + r] + red[80 + r]) + (red[96 + r] + red[112 + r]);
         }
         const float rstd = 1.0f / sqrtf(sq * inv_n + eps);
+        if (lds_y != nullptr) {   // block-uniform; rows past M hold finite garbage nobody stores
+#pragma unroll
+            for (int j = 0; j < NI; ++j) {
+                const int n = col0 + j * 16 + g * 4;
+                if (n >= N) continue;
+                if constexpr (!HOIST) fetch_post(G, 0, n, mc);
+                const int js = HOIST ? j : 0;
+                float o[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float gq = G.mod != nullptr ? gm[js][q] + 1.0f + mw[js][q] : gm[js][q];
+                    const float bq = G.mod != nullptr ? bt[js][q] + mb[js][q] : bt[js][q];
+                    o[q] = (v[j][q] - mean) * rstd * gq + bq;
+                }
+                store4(reinterpret_cast<__bf16*>(lds_y + (n >> 6) * (16 * 128) + r * 128 + ((((n & 63) >> 3) ^ (r & 7)) << 4) + (n & 7) * 2), o[0], o[1], o[2], o[3]);
+            }
+        }
         if (!mok) return;
         if (g == 0 && (!XWAVE || wave == 0)) {
             if (G.mean != nullptr) G.mean[m] = mean;
@@ -409,6 +428,7 @@ struct XTailCfg {
     static constexpr int ST1 = (BM + D) * BKB;               // stage-1 tile: att rows, then Wp rows
     static constexpr int ST2 = (BM + E) * BKB;               // stage-2 tile: g rows, then Wup rows
     static constexpr int ST3 = D * BKB;                      // stage-3 tile: Wdown rows (the A rows live in the x tile)
+    static constexpr int ST4 = 2 * D * BKB;                  // stage-4 tile: Wkv rows (k then v), KT1 tiles per projection
     static constexpr int SMAX = D == 128 ? 2 : 4;
     static __host__ __device__ constexpr int r1_bytes(int S) { return S * KT1 * ST1 > KT3 * ST3 ? S * KT1 * ST1 : KT3 * ST3; }
     static __host__ __device__ constexpr int lds_bytes(int S) { return r1_bytes(S) + KT1 * ST2 + BM * E * 2 + 512; }
@@ -590,6 +610,14 @@ __global__ __launch_bounds__(256) void exchange_tail_kernel(const XTailLaunch L)
     }
     if (!P.has_down) return;   // block-uniform
     __syncthreads();
+    const int n_kv = PLAIN ? 0 : P.n_kv;
+    auto burst_wkv = [&](int c, unsigned base) {   // Wkv[c] K-tiles (2 D rows each) to LDS at `base`
+        const T* Wk = static_cast<const T*>(P.Wkv[c]);
+        for (int kt = 0; kt < KT1; ++kt)
+            for (int u = wv; u < 2 * D / 8; u += 4)
+                glds16_gn(Wk + (int64_t)(u * 8 + rl) * P.ldwkv + kt * BK + chunk * 8, base + (unsigned)(kt * C::ST4 + u * 8 * BKB));
+    };
+    if (n_kv > 0) burst_wkv(0, r2_base);   // the stage-2 tiles have been read by every wave (barrier above): Wkv[0] lands under stage 3
     // ---- stage 3
     f32x4 acc3[NI3];
 #pragma unroll
@@ -606,7 +634,60 @@ __global__ __launch_bounds__(256) void exchange_tail_kernel(const XTailLaunch L)
             for (int jb = 0; jb < NI3; ++jb) mma16<T>(*reinterpret_cast<const uint4*>(sB + jb * 16 * BKB + off), af, acc3[jb]);
         }
     }
-    epi3.finish(P.down, acc3, m, wave * (D / 4), r, g, wave, L.eps, red);
+    epi3.finish(P.down, acc3, m, wave * (D / 4), r, g, wave, L.eps, red, n_kv > 0 ? x3 : nullptr);   // (x3: every wave is past its stage-3 reads — two barriers inside)
+    if (n_kv == 0) return;
+    // ---- stage 4: k / v projections of the normalised rows for the later fields, rotary embedding on k, attention layouts (qkv_rope_kernel's epilogue)
+    constexpr int LP4 = KT1 * (2 * D / 8) / 4;   // DMA pieces per wave per projection
+    if (n_kv > 1) burst_wkv(1, lds_base);        // stage 3 has read R1 (barriers inside finish): Wkv[1] lands under stage 4a
+    const int hd = P.hd, hd2 = hd >> 1, Hh = P.H, cap = P.cap, Tn = P.T;
+    const int bq = mc / Tn, tt = mc - bq * Tn, pos = P.pos0 + tt;
+    const float2* rope = reinterpret_cast<const float2*>(P.rope);
+    for (int c = 0; c < n_kv; ++c) {
+        if (c == 0 && n_kv > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LP4) : "memory");   // everything older than the Wkv[1] pieces
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();   // y tile and Wkv[c] are in LDS (c = 1: every wave is done with stage 4a)
+        const char* wbase = c == 0 ? R2 : R1;
+        f32x4 acc4[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc4[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kt = 0; kt < KT1; ++kt) {
+            const char* sA = x3 + kt * (BM * BKB) + r * BKB;
+            const char* sB = wbase + kt * C::ST4 + (wave * (2 * D / 4) + r) * BKB;
+#pragma unroll
+            for (int kc = 0; kc < 2; ++kc) {
+                const int off = ((kc * 4 + g) ^ (r & 7)) << 4;
+                const uint4 af = *reinterpret_cast<const uint4*>(sA + off);
+#pragma unroll
+                for (int j = 0; j < 2 * D / 64; ++j) mma16<T>(*reinterpret_cast<const uint4*>(sB + j * 16 * BKB + off), af, acc4[j]);
+            }
+        }
+        const float* bkv = P.bkv[c];
+        T* Ko = static_cast<T*>(P.Kout[c]);
+        T* Vto = static_cast<T*>(P.Vtout[c]);
+#pragma unroll
+        for (int j = 0; j < 2 * D / 64; ++j) {
+            const int nn = wave * (2 * D / 4) + j * 16 + g * 4;    // column in [k | v]: waves 0, 1 hold k, waves 2, 3 hold v
+            float bv[4], v4[4];
+            load4(bkv + nn, bv);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v4[q] = acc4[j][q] + bv[q];
+            const bool is_v = nn >= D;
+            const int hcol = is_v ? nn - D : nn;
+            const int h = hcol / hd, dd = hcol - h * hd;
+            const uint32_t bh = (uint32_t)(bq * Hh + h);
+            if (!mok) continue;
+            if (!is_v) {
+                const float4 cs = *reinterpret_cast<const float4*>(rope + (uint32_t)pos * (uint32_t)hd2 + (dd >> 1));
+                store4(Ko + ((bh * (uint32_t)cap + pos) * (uint32_t)hd + dd), v4[0] * cs.x - v4[1] * cs.y, v4[0] * cs.y + v4[1] * cs.x, v4[2] * cs.z - v4[3] * cs.w,
+                       v4[2] * cs.w + v4[3] * cs.z);
+            } else {
+                T* dst = Vto + ((bh * (uint32_t)hd + dd) * (uint32_t)cap + pos);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) dst[(uint32_t)q * (uint32_t)cap] = (T)v4[q];
+            }
+        }
+    }
 }
 
 template <typename K>
@@ -740,10 +821,19 @@ extern "C" int sea_exchange_tail(const SeaExchangeTail* params, int n_groups, fl
             SEA_REQUIRE(sea_aligned16(G.W) && sea_aligned16(G.bias) && sea_aligned16(G.mod) && sea_aligned16(G.gamma) && sea_aligned16(G.beta) && sea_aligned16(G.Y32) && sea_aligned16(G.Yact),
                         "sea_exchange_tail[%d]: down: pointers must be 16-byte aligned", gi);
             // the fields NormEpilogue reads besides the pointers checked above
+            if (P.n_kv != 0) {
+                SEA_REQUIRE(!plain && P.n_kv >= 1 && P.n_kv <= 2 && P.rope && P.H >= 1 && P.hd >= 4 && P.hd % 4 == 0 && P.H * P.hd == P.D && P.T >= 1 && P.M % P.T == 0 && P.pos0 >= 0 &&
+                                P.cap >= P.pos0 + P.T && P.ldwkv % 8 == 0 && P.ldwkv >= P.D, "sea_exchange_tail[%d]: bad K/V stage (n_kv=%d H=%d hd=%d T=%d pos0=%d cap=%d)", gi,
+                            P.n_kv, P.H, P.hd, P.T, P.pos0, P.cap);
+                for (int c = 0; c < P.n_kv; ++c)
+                    SEA_REQUIRE(P.Wkv[c] && P.bkv[c] && P.Kout[c] && P.Vtout[c] && sea_aligned16(P.Wkv[c]) && sea_aligned16(P.bkv[c]) && sea_aligned16(P.Kout[c]) &&
+                                    sea_aligned16(P.Vtout[c]), "sea_exchange_tail[%d]: K/V stage %d: null / misaligned pointer", gi, c);
+            }
             SeaGemmNormGroup& Gd = L.p[gi].down;
             Gd.M = P.M; Gd.N = P.D; Gd.K = P.E; Gd.n_seg = 1; Gd.bias_scale = 1.0f;
             Gd.R = nullptr; Gd.C32 = nullptr; Gd.Cact = nullptr; Gd.ib_c = nullptr;
         }
+        SEA_REQUIRE(P.has_down || P.n_kv == 0, "sea_exchange_tail[%d]: the K/V stage needs the down-projection stage", gi);
         m_max = P.M > m_max ? P.M : m_max;
     }
     const dim3 grid((m_max + 15) / 16, n_groups);

@@ -298,11 +298,13 @@ class Plan:
                     self._c_patches.append((g, "ib_c"))
             self._cur.append(self._rec(L.sea_gemm_rownorm, [arr, len(chunk), 1e-5, self.code], name, arr))
 
-    def _xtail(self, att, Wp, Wup, bup, bias_scale, X, down, name: str) -> None:
+    def _xtail(self, att, Wp, Wup, bup, bias_scale, X, down, name: str, kv=None) -> None:
         """One field's exchange tail in one launch (sea_exchange_tail): projections + GELU, up-projection of their sum + residual, and — `down` —
         the down-projection + row norm of the updated rows."""
         P = (N.SeaExchangeTail * 1)()
-        ops.fill_exchange_tail(P[0], att, Wp, Wup, bup, bias_scale, X, None, down)
+        ops.fill_exchange_tail(P[0], att, Wp, Wup, bup, bias_scale, X, None, down, kv=kv)
+        if kv is not None:
+            self._pos_structs.append(P[0])
         self._cur.append(self._rec(N.lib().sea_exchange_tail, [P, 1, 1e-5, self.code], name, P))
 
     def _xtail_plain(self, groups: List[dict], name: str) -> None:
@@ -604,6 +606,24 @@ class Plan:
                     self._gemm([dict(A=xa[j], W=P.act(f"{pre}cross_down.{j}.weight"), bias=P.f32_vec(f"{pre}cross_down.{j}.bias"), C32=dn[j])
                                 for j in range(F)], "cross.down_old")
                     self._norm([dict(X=dn[j], Yact=nd_old[j], **norm_params(f"{pre}ln_cross.{j}.", D)) for j in range(F)], D, "cross.norm_old")
+                # opt-in (SEA_FUSE_KV=1): the K/V projections of an updated field for the fields after it ride in that field's tail (stage 4 of
+                # sea_exchange_tail: at most two), and every projection that reads pre-exchange rows (all Q, the K/V of later fields) goes into ONE launch up
+                # front — two launches less on the serial chain.  Measured a tie at cfg2 (0.2565 against 0.2562 ms: a projection in the tail costs 3.3 us —
+                # its weights can only follow Wup / Wdown into LDS, and the V^T scatter is 2-byte stores — against the 8.9 us launch it replaces minus the
+                # larger up-front launch), 1.240 against 1.231 ms at B = 8, 0.1420 against 0.1433 ms per KV-cache step
+                fuse_kv = fuse_xtail and F - 1 <= 2 and F * (F - 1) * 3 // 2 <= N.MAX_GROUPS and os.environ.get("SEA_FUSE_KV", "0") == "1"
+                if fuse_kv:
+                    Qall = [[self._buf(B, H, T, hd_c) if j != i else None for j in range(F)] for i in range(F)]
+                    hoist = []
+                    for i in range(F):
+                        for j in range(F):
+                            if j == i:
+                                continue
+                            ca = f"{pre}cross_attn.{i}.{j}."
+                            hoist.append(dict(A=nd_old[i], W=P.act(ca + "q.weight"), bias=P.f32_vec(ca + "q.bias"), col0=0, Q=Qall[i][j]))
+                            if j > i:
+                                hoist.append(dict(A=nd_old[j], W=P.act(ca + "k.weight", 2 * D), bias=P.f32_vec(ca + "k.bias", 2 * D), col0=D, K=Kc[l][i][j], Vt=Vc[l][i][j]))
+                    self._qkv(hoist, rope_c, hd_c, "cross.qkv_rope_old")
                 for i in range(F):
                     others = [j for j in range(F) if j != i]
                     qkv_groups, probs, proj_groups = [], [], []
@@ -613,9 +633,10 @@ class Plan:
                         qkv_groups.append(dict(A=nd_old[i], W=P.act(ca + "q.weight"), bias=P.f32_vec(ca + "q.bias"), col0=0, Q=Qc[s]))
                         qkv_groups.append(dict(A=src, W=P.act(ca + "k.weight", 2 * D), bias=P.f32_vec(ca + "k.bias", 2 * D), col0=D,
                                                K=Kc[l][i][j], Vt=Vc[l][i][j]))
-                        probs.append(dict(Q=Qc[s], K=Kc[l][i][j], Vt=Vc[l][i][j], O=att_c[s]))
+                        probs.append(dict(Q=(Qall[i][j] if fuse_kv else Qc[s]), K=Kc[l][i][j], Vt=Vc[l][i][j], O=att_c[s]))
                         proj_groups.append(dict(A=att_c[s], W=P.act(ca + "projection.weight"), Cact=gp[s], act=1))
-                    self._qkv(qkv_groups, rope_c, hd_c, f"cross{i}.qkv_rope")
+                    if not fuse_kv:
+                        self._qkv(qkv_groups, rope_c, hd_c, f"cross{i}.qkv_rope")
                     self._attn(probs, hd_c, D, f"cross{i}.attention")
                     if fuse_xtail:
                         # everything between this field's cross-attention and the next field's: projections + GELU, up-projection of the sum + residual,
@@ -624,8 +645,13 @@ class Plan:
                         if i < F - 1:
                             down = dict(W=P.act(f"{pre}cross_down.{i}.weight"), bias=P.f32_vec(f"{pre}cross_down.{i}.bias"), Yact=nd_new[i],
                                         **norm_params(f"{pre}ln_cross.{i}.", D))
+                        kv = None
+                        if fuse_kv and i < F - 1:   # the fields after this one attend to its updated, normalised rows
+                            kv = dict(proj=[dict(W=P.act(f"{pre}cross_attn.{iq}.{i}.k.weight", 2 * D), bias=P.f32_vec(f"{pre}cross_attn.{iq}.{i}.k.bias", 2 * D),
+                                                 K=Kc[l][iq][i], Vt=Vc[l][iq][i]) for iq in range(i + 1, F)],
+                                      rope=rope_c, H=H, hd=hd_c, T=T, pos0=self.pos0, cap=cap)
                         self._xtail([att_c[s] for s in range(len(others))], [P.act(f"{pre}cross_attn.{i}.{j}.projection.weight") for j in others],
-                                    P.act(f"{pre}cross_up.{i}.weight"), P.f32_vec(f"{pre}cross_up.{i}.bias"), float(F - 1), xr[i], down, f"cross{i}.tail")
+                                    P.act(f"{pre}cross_up.{i}.weight"), P.f32_vec(f"{pre}cross_up.{i}.bias"), float(F - 1), xr[i], down, f"cross{i}.tail", kv=kv)
                         continue
                     self._gemm(proj_groups, f"cross{i}.proj_gelu")
                     up = dict(A=gp[0], W=P.act(f"{pre}cross_up.{i}.weight"), bias=P.f32_vec(f"{pre}cross_up.{i}.bias"),
@@ -906,7 +932,7 @@ class Plan:
         assert pos0 + self.T <= self.cap
         self.pos0 = pos0
         for s in self._pos_structs:
-            if isinstance(s, (N.SeaQkvCommon, N.SeaChainLaunch)):
+            if isinstance(s, (N.SeaQkvCommon, N.SeaChainLaunch, N.SeaExchangeTail)):
                 s.pos0 = pos0
             else:
                 s.q_pos0, s.Tk = pos0, pos0 + self.T

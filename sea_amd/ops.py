@@ -180,7 +180,7 @@ def gemm_rownorm(groups: Sequence[Dict], eps: float, dtype: torch.dtype) -> None
 
 
 def fill_exchange_tail(P: N.SeaExchangeTail, att: Sequence[torch.Tensor], Wp: Optional[Sequence[torch.Tensor]], Wup, bup, bias_scale: float, X, Xact=None,
-                       down: Optional[Dict] = None, Xin=None, ldxin: Optional[int] = None) -> None:
+                       down: Optional[Dict] = None, Xin=None, ldxin: Optional[int] = None, kv: Optional[Dict] = None) -> None:
     """att: n_seg act [M, D] matrices, Wp: n_seg act [D, D]; Wup act [E, D]; X f32 [M, E] (in place); down: dict(W [D, E], bias, gamma, beta, mod, Yact, Y32).
     Wp None = the plain form: x = Xin + att[0][M, E] . Wup[E, E]^T + bup (no first layer)."""
     plain = Wp is None
@@ -196,6 +196,13 @@ def fill_exchange_tail(P: N.SeaExchangeTail, att: Sequence[torch.Tensor], Wp: Op
     P.M, P.E = X.shape[0], Wup.shape[0]
     P.D = down["W"].shape[0] if plain and down is not None else (P.E // 2 if plain else Wup.shape[1])
     P.has_down = int(down is not None)
+    P.n_kv = 0
+    if kv is not None:   # dict(proj=[dict(W [2D, D], bias [2D], K, Vt), ...] (1 or 2), rope, H, hd, T, pos0, cap): K/V projections of the normalised rows
+        P.n_kv = len(kv["proj"])
+        for c, d in enumerate(kv["proj"]):
+            P.Wkv[c], P.bkv[c], P.Kout[c], P.Vtout[c] = d["W"].data_ptr(), d["bias"].data_ptr(), d["K"].data_ptr(), d["Vt"].data_ptr()
+        P.ldwkv = kv["proj"][0]["W"].stride(0)
+        P.rope, P.H, P.hd, P.T, P.pos0, P.cap = kv["rope"].data_ptr(), kv["H"], kv["hd"], kv["T"], kv["pos0"], kv["cap"]
     if down is not None:
         g = P.down
         g.W, g.ldw, g.bias = down["W"].data_ptr(), down["W"].stride(0), N.ptr(down.get("bias"))
@@ -212,13 +219,13 @@ def exchange_tail_supported(dtype: torch.dtype, D: int, E: int, n_seg: int) -> b
     return dtype == torch.bfloat16 and (D, E) in ((128, 256), (64, 128)) and 1 <= n_seg and n_seg * D <= 256
 
 
-def exchange_tail(att, Wp, Wup, bup, bias_scale, X, Xact=None, down=None, eps: float = 1e-5, dtype: torch.dtype = torch.bfloat16, Xin=None) -> None:
+def exchange_tail(att, Wp, Wup, bup, bias_scale, X, Xact=None, down=None, eps: float = 1e-5, dtype: torch.dtype = torch.bfloat16, Xin=None, kv=None) -> None:
     """One field's exchange tail in one launch: X += sum_s gelu(att_s Wp_s^T) Wup^T + bias_scale * bup; optionally the down-projection + row norm
     of the updated rows (sea_exchange_tail).  Wp None: the plain form X = (Xin or X) + att[0] Wup^T + bup."""
     for t in list(att) + list(Wp or []) + [Wup, X]:
         N.require_gpu(t, "exchange_tail operand")
     P = (N.SeaExchangeTail * 1)()
-    fill_exchange_tail(P[0], att, Wp, Wup, bup, bias_scale, X, Xact, down, Xin)
+    fill_exchange_tail(P[0], att, Wp, Wup, bup, bias_scale, X, Xact, down, Xin, kv=kv)
     N.check(N.lib().sea_exchange_tail(P, 1, eps, N.dtype_code(dtype), N.stream_ptr()), "sea_exchange_tail")
 
 
