@@ -68,6 +68,7 @@ def kernel_flops(name, B, T, F, E, H, D, S):
         "add.down_norm": F * 2 * M * E * D,
         "add.up": F * 2 * M * E * D,
         "mlp.fc1": F * 2 * M * E * S,
+        "mlp.fc1_ln_gelu": F * 2 * M * E * S,
         "mlp.fc2": F * 2 * M * E * S,
         "proj": F * 2 * M * E * E,
     }

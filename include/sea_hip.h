@@ -41,7 +41,7 @@ enum {
 int sea_abi_version(void);
 const char* sea_last_error(void);
 /* sizeof of every ABI struct in declaration order (SeaGemmGroup, SeaQkvGroup, SeaQkvCommon, SeaAttnProblem,
- * SeaAttnParams, SeaNormGroup, SeaSiluGroup, SeaIbParams, ..., SeaGemmNormGroup, SeaExchangeTail last): lets a binding verify its layout.  Host only. */
+ * SeaAttnParams, SeaNormGroup, SeaSiluGroup, SeaIbParams, ..., SeaGemmNormGroup, SeaExchangeTail, SeaMlpGroup last): lets a binding verify its layout.  Host only. */
 int sea_struct_sizes(int* out, int cap);
 /* Number of compute units / name of device 0's architecture as HIP reports them (diagnostics for bench.py). */
 int sea_device_info(int* cu_count, char* arch, int arch_len);
@@ -285,6 +285,26 @@ typedef struct {
 /* params: n_groups <= SEA_XTAIL_MAX_GROUPS problems of one shape and mode (e.g. the F fields), one grid row each */
 #define SEA_XTAIL_MAX_GROUPS 4
 int sea_exchange_tail(const SeaExchangeTail* params, int n_groups, float eps, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * First half of the field MLP in one launch (bf16):  Hg = gelu_erf(LayerNorm_S(A[M,E] . W1[S,E]^T + b1) * lnw + lnb)
+ * Replaces models/base_blocks.py:22-24 (Linear(E, S), nn.LayerNorm(S), GELU) = sea_gemm_grouped + sea_rownorm(gelu): a workgroup owns 32 complete
+ * rows of the hidden matrix, the pre-activation matrix never reaches HBM.  (E, S) in {(256, 2048), (128, 1024)}; row strides multiples of 8;
+ * pointers 16-byte aligned.  Returns SEA_EUNSUPPORTED for other shapes / dtypes (callers keep the two-launch form).
+ */
+#define SEA_MAX_MLP_GROUPS 8
+typedef struct {
+    const void* A;      /* act [M, E], row stride lda */
+    const void* W1;     /* act [S, E], row stride ldw */
+    const float* b1;    /* f32 [S] */
+    const float* lnw;   /* f32 [S] */
+    const float* lnb;   /* f32 [S] */
+    void* Hg;           /* act [M, S], row stride ldh */
+    int32_t lda, ldw, ldh;
+    int32_t M, E, S;
+} SeaMlpGroup;
+
+int sea_mlp_fc1_ln_gelu(const SeaMlpGroup* groups, int n_groups, float eps, int dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Hidden layer of the AdaLN condition MLP for a scalar condition: Hid[m, k] = silu(w1[k] * c[m] + b1[k]).
@@ -573,9 +593,10 @@ int sea_rowchain(const SeaChainLaunch* launch, const SeaChainStage* host_stages,
  *     SEA_OP_SILU   p0 = SeaSiluGroup[n], p1 = c, i0 = M, l0 = (intptr) SeaIbParams[l1] or 0, l1 = n_ib      SEA_OP_IB     p0 = SeaIbParams
  *     SEA_OP_CHAIN  p0 = SeaChainLaunch, p1 = host stage table    SEA_OP_CONVERT p0 = src, p1 = dst, l0 = lds, l1 = ldd, l2 = rows, l3 = cols
  *     SEA_OP_GEMM_NORM p0 = SeaGemmNormGroup[n], f0 = eps          SEA_OP_XTAIL  p0 = SeaExchangeTail[n], f0 = eps
+ *     SEA_OP_MLP1   p0 = SeaMlpGroup[n], f0 = eps
  * Returns 0, or the failing entry's error code with sea_last_error() set (entries before it have been launched).
  */
-enum { SEA_OP_GEMM = 1, SEA_OP_QKV = 2, SEA_OP_ATTN = 3, SEA_OP_NORM = 4, SEA_OP_SILU = 5, SEA_OP_IB = 6, SEA_OP_CHAIN = 7, SEA_OP_CONVERT = 8, SEA_OP_GEMM_NORM = 9, SEA_OP_XTAIL = 10 };
+enum { SEA_OP_GEMM = 1, SEA_OP_QKV = 2, SEA_OP_ATTN = 3, SEA_OP_NORM = 4, SEA_OP_SILU = 5, SEA_OP_IB = 6, SEA_OP_CHAIN = 7, SEA_OP_CONVERT = 8, SEA_OP_GEMM_NORM = 9, SEA_OP_XTAIL = 10, SEA_OP_MLP1 = 11 };
 typedef struct {
     int32_t op, n, dtype, i0, i1, i2, i3;
     float f0;

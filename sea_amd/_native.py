@@ -133,7 +133,7 @@ class SeaChainLaunch(C.Structure):
 
 
 
-OP_GEMM, OP_QKV, OP_ATTN, OP_NORM, OP_SILU, OP_IB, OP_CHAIN, OP_CONVERT, OP_GEMM_NORM, OP_XTAIL = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10
+OP_GEMM, OP_QKV, OP_ATTN, OP_NORM, OP_SILU, OP_IB, OP_CHAIN, OP_CONVERT, OP_GEMM_NORM, OP_XTAIL, OP_MLP1 = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11
 
 
 class SeaLaunchRec(C.Structure):
@@ -166,6 +166,14 @@ class SeaExchangeTail(C.Structure):
                 ("Wkv", _vp * 2), ("bkv", _vp * 2), ("Kout", _vp * 2), ("Vtout", _vp * 2), ("rope", _vp),
                 ("ldwkv", _i32), ("H", _i32), ("hd", _i32), ("T", _i32), ("pos0", _i32), ("cap", _i32),
                 ("down", SeaGemmNormGroup)]
+
+
+MAX_MLP_GROUPS = 8
+
+
+class SeaMlpGroup(C.Structure):
+    _fields_ = [("A", _vp), ("W1", _vp), ("b1", _vp), ("lnw", _vp), ("lnb", _vp), ("Hg", _vp),
+                ("lda", _i32), ("ldw", _i32), ("ldh", _i32), ("M", _i32), ("E", _i32), ("S", _i32)]
 
 
 MAX_WGRAD_GROUPS = 16
@@ -225,6 +233,8 @@ def lib() -> C.CDLL:
     L.sea_patchify.restype = C.c_int
     L.sea_silu_outer_ib.argtypes = [C.POINTER(SeaSiluGroup), C.c_int, _vp, C.c_int, C.c_int, _vp, C.c_int, _vp]
     L.sea_silu_outer_ib.restype = C.c_int
+    L.sea_mlp_fc1_ln_gelu.argtypes = [C.POINTER(SeaMlpGroup), C.c_int, C.c_float, C.c_int, _vp]
+    L.sea_mlp_fc1_ln_gelu.restype = C.c_int
     L.sea_run_list.argtypes = [C.POINTER(SeaLaunchRec), C.c_int, _vp]
     L.sea_run_list.restype = C.c_int
     for name in ("sea_attention_bwd", "sea_wgrad_grouped", "sea_transpose_weights", "sea_rownorm_bwd", "sea_silu_outer_bwd", "sea_ib_bwd"):
@@ -245,14 +255,14 @@ def lib() -> C.CDLL:
 
 ABI_STRUCTS = (SeaGemmGroup, SeaQkvGroup, SeaQkvCommon, SeaAttnProblem, SeaAttnParams, SeaNormGroup, SeaSiluGroup,
                SeaIbParams, SeaWgradGroup, SeaNormBwdGroup, SeaSiluBwdGroup, SeaIbBwdParams, SeaAttnBwdProblem, SeaAttnBwdParams,
-               SeaDropout, SeaChainStage, SeaChainLaunch, SeaLaunchRec, SeaGemmNormGroup, SeaExchangeTail)
+               SeaDropout, SeaChainStage, SeaChainLaunch, SeaLaunchRec, SeaGemmNormGroup, SeaExchangeTail, SeaMlpGroup)
 
 EXPORTED_SYMBOLS = (
     "sea_abi_version", "sea_last_error", "sea_struct_sizes", "sea_device_info", "sea_gemm_grouped", "sea_qkv_rope_grouped",
     "sea_attention_fwd", "sea_rownorm", "sea_silu_outer", "sea_ib_add", "sea_convert_f32_to_act", "sea_selftest_mfma",
     "sea_mse_fwd_bwd", "sea_relative_mse", "sea_adamw_flat",
     "sea_wgrad_grouped", "sea_transpose_weights", "sea_rownorm_bwd", "sea_silu_outer_bwd", "sea_ib_bwd",
-    "sea_attention_bwd", "sea_dropout_mask", "sea_rowchain", "sea_run_list", "sea_unpatchify", "sea_gemm_rownorm", "sea_exchange_tail", "sea_patchify", "sea_silu_outer_ib",
+    "sea_attention_bwd", "sea_dropout_mask", "sea_rowchain", "sea_run_list", "sea_unpatchify", "sea_gemm_rownorm", "sea_exchange_tail", "sea_patchify", "sea_silu_outer_ib", "sea_mlp_fc1_ln_gelu",
 )
 
 

@@ -1,0 +1,230 @@
+// First half of the field MLP in one launch (gfx950, bf16): sea_mlp_fc1_ln_gelu.
+//
+//     Hg = gelu_erf(LayerNorm_S(A[M, E] . W1[S, E]^T + b1) * lnw + lnb)          (models/base_blocks.py:22-24: Linear, nn.LayerNorm(S), GELU)
+//
+// A workgroup (8 waves) owns 32 COMPLETE rows of the [M, S] hidden matrix, so the LayerNorm statistics and the activation are an epilogue: the
+// pre-activation matrix (25 MB at cfg2) is never written, the LayerNorm + GELU pass over it (a launch of its own, 17.9 us at cfg2) disappears.
+// The price is that every workgroup streams the whole W1 (S x E bf16 = 1 MiB) from L2: W1 goes L2 -> LDS by global_load_lds in stages of 64 rows
+// x the full contraction (32 KiB), a ring of 4 stages (3 in flight), one barrier per stage; the 32 A rows (16 KiB) stay resident.  Per stage 4 of
+// the 8 waves compute (a 16-row block each, two row blocks: 16 MFMAs), even stages the lower four waves, odd stages the upper four, so that
+// every wave ends with S / 128 column blocks x 2 row blocks of accumulators (128 VGPRs at S = 2048).  The activations leave through LDS as
+// whole rows (the ring is free by then).
+#include "gemm_core.hpp"
+#include <stdlib.h>
+
+struct MlpLaunch {
+    SeaMlpGroup g[SEA_MAX_MLP_GROUPS];
+    int tile_start[SEA_MAX_MLP_GROUPS + 1];
+    int n_groups;
+    float eps;
+};
+
+__device__ __forceinline__ void glds16_mlp(const void* gsrc, unsigned lds_addr) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_addr) : "memory");
+}
+
+// KT = E / 64 K-tiles; NSB = S / 128 column blocks per wave
+template <int KT, int NSB>
+__global__ __launch_bounds__(512) void mlp_fc1_ln_gelu_kernel(const MlpLaunch L) {
+    using T = __bf16;
+    constexpr int BM = 32, BKB = 128, BK = 64, NS = 4, NW = 8;
+    constexpr int S = NSB * 128, NSTAGE = S / 64;
+    constexpr int A_BYTES = KT * BM * BKB;                 // resident A rows, K-tile major
+    constexpr int STAGE = KT * 64 * BKB;                   // 64 W rows x the whole contraction
+    constexpr int LPS = KT * 8 / NW;                       // DMA pieces per wave per stage (KT = 4: 4, KT = 2: 2)
+    constexpr int SP = S * 2 + 16;                         // staging pitch of an output row
+    static_assert(NS * STAGE >= 0 && BM * SP <= A_BYTES + NS * STAGE, "the output tile is staged over the operand memory");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int gi = 0;
+    while (gi + 1 < L.n_groups && (int)blockIdx.x >= L.tile_start[gi + 1]) ++gi;
+    const SeaMlpGroup& G = L.g[gi];
+    const int m0 = (blockIdx.x - L.tile_start[gi]) * BM, M = G.M;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 15, g = lane >> 4;
+    const int half = wave >> 2, wq = wave & 3;             // which stages this wave computes, and its 16-row block inside a stage
+    const T* A = static_cast<const T*>(G.A);
+    const T* W = static_cast<const T*>(G.W1);
+    const unsigned lds_base = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)smem);
+    const int rl = lane >> 3;
+    const int chunk = (lane & 7) ^ (rl & 7);               // swizzle on the source side
+    // ---- A rows: KT x 4 pieces of 8 rows, resident for the whole kernel
+    for (int p = wave; p < KT * (BM / 8); p += NW) {
+        const int kt = p / (BM / 8), u = p - kt * (BM / 8);
+        int row = m0 + u * 8 + rl;
+        row = row < M ? row : M - 1;
+        glds16_mlp(A + (int64_t)row * G.lda + kt * BK + chunk * 8, lds_base + (unsigned)(kt * BM * BKB + u * 8 * BKB));
+    }
+    constexpr int A_PIECES = (KT * (BM / 8) + NW - 1) / NW;   // per wave, upper bound (waves past the count issue none: wave-uniform)
+    auto dma_stage = [&](int s) {
+        const unsigned base = lds_base + (unsigned)(A_BYTES + (s % NS) * STAGE);
+#pragma unroll
+        for (int i = 0; i < LPS; ++i) {
+            const int p = i * NW + wave;                      // piece: K-tile kt, 8 rows u
+            const int kt = p >> 3, u = p & 7;
+            glds16_mlp(W + (int64_t)(s * 64 + u * 8 + rl) * G.ldw + kt * BK + chunk * 8, base + (unsigned)(kt * 64 * BKB + u * 8 * BKB));
+        }
+    };
+    for (int s = 0; s < NS - 1; ++s) dma_stage(s);
+    (void)A_PIECES;
+
+    f32x4 acc[NSB][2];
+#pragma unroll
+    for (int i = 0; i < NSB; ++i) {
+        acc[i][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+        acc[i][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int s = 0; s < NSTAGE; ++s) {
+        // stage s (and the A rows, older) have landed once at most the pieces of the stages issued after it are outstanding
+        if (s + 2 < NSTAGE) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPS) : "memory");
+        else if (s + 1 < NSTAGE) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (s + NS - 1 < NSTAGE) dma_stage(s + NS - 1);
+        if ((s & 1) == half) {   // wave-uniform
+            const char* sW = smem + A_BYTES + (s % NS) * STAGE + (wq * 16 + r) * BKB;
+            const char* sA = smem + r * BKB;
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+                for (int kc = 0; kc < 2; ++kc) {
+                    const int off = ((kc * 4 + g) ^ (r & 7)) << 4;
+                    const uint4 wf = *reinterpret_cast<const uint4*>(sW + kt * 64 * BKB + off);
+                    const uint4 a0 = *reinterpret_cast<const uint4*>(sA + kt * BM * BKB + off);
+                    const uint4 a1 = *reinterpret_cast<const uint4*>(sA + kt * BM * BKB + 16 * BKB + off);
+                    mma16<T>(wf, a0, acc[s >> 1][0]);
+                    mma16<T>(wf, a1, acc[s >> 1][1]);
+                }
+        }
+    }
+    __syncthreads();   // operand memory is free: statistics scratch and the output tile go over it
+
+    // ---- epilogue: + b1, LayerNorm over the S columns of a row (two-pass, fp32), * lnw + lnb, GELU, bf16
+    // this lane: rows m0 + mb*16 + r, columns n(i) = (2 i + half) * 64 + wq * 16 + 4 g + q
+    float* red = reinterpret_cast<float*>(smem);   // [2 passes][8 waves][32 rows]
+    const float inv_s = 1.0f / (float)S;
+    float sum[2] = {0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < NSB; ++i) {
+        const int n = (2 * i + half) * 64 + wq * 16 + g * 4;
+        float bv[4];
+        load4(G.b1 + n, bv);
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[i][mb][q] += bv[q];
+            sum[mb] += (acc[i][mb][0] + acc[i][mb][1]) + (acc[i][mb][2] + acc[i][mb][3]);
+        }
+    }
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb) {
+        sum[mb] += __shfl_xor(sum[mb], 16);
+        sum[mb] += __shfl_xor(sum[mb], 32);
+        if (g == 0) red[wave * 32 + mb * 16 + r] = sum[mb];
+    }
+    __syncthreads();
+    float mean[2], sq[2] = {0.f, 0.f};
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb) {
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) t += red[w * 32 + mb * 16 + r];
+        mean[mb] = t * inv_s;
+    }
+#pragma unroll
+    for (int i = 0; i < NSB; ++i)
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float c = acc[i][mb][q] - mean[mb];
+                sq[mb] += c * c;
+            }
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb) {
+        sq[mb] += __shfl_xor(sq[mb], 16);
+        sq[mb] += __shfl_xor(sq[mb], 32);
+        if (g == 0) red[256 + wave * 32 + mb * 16 + r] = sq[mb];
+    }
+    __syncthreads();
+    float rstd[2];
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb) {
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) t += red[256 + w * 32 + mb * 16 + r];
+        rstd[mb] = 1.0f / sqrtf(t * inv_s + L.eps);
+    }
+    __syncthreads();   // everyone has read the statistics: the output tile may overwrite them
+#pragma unroll
+    for (int i = 0; i < NSB; ++i) {
+        const int n = (2 * i + half) * 64 + wq * 16 + g * 4;
+        float gm[4], bt[4];
+        load4(G.lnw + n, gm);
+        load4(G.lnb + n, bt);
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb) {
+            float o[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) o[q] = gelu_erf((acc[i][mb][q] - mean[mb]) * rstd[mb] * gm[q] + bt[q]);
+            store4(reinterpret_cast<T*>(smem + (mb * 16 + r) * SP) + n, o[0], o[1], o[2], o[3]);
+        }
+    }
+    __syncthreads();
+    T* Hg = static_cast<T*>(G.Hg);
+    constexpr int CPR = S / 8;   // 16-byte chunks per row
+    for (int idx = tid; idx < BM * CPR; idx += 512) {
+        const int row = idx / CPR, cc = idx - row * CPR;
+        const int m = m0 + row;
+        if (m < M) *reinterpret_cast<uint4*>(Hg + (int64_t)m * G.ldh + cc * 8) = *reinterpret_cast<const uint4*>(smem + row * SP + cc * 16);
+    }
+}
+
+template <typename K>
+static int set_lds_mlp(K kernel, int bytes) {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess ? 0 : -1;
+}
+
+extern "C" int sea_mlp_fc1_ln_gelu(const SeaMlpGroup* groups, int n_groups, float eps, int dtype, void* stream) {
+    SEA_REQUIRE(groups != nullptr && n_groups >= 1 && n_groups <= SEA_MAX_MLP_GROUPS, "sea_mlp_fc1_ln_gelu: n_groups=%d out of range", n_groups);
+    const int E = groups[0].E, S = groups[0].S;
+    const bool shape_ok = (E == 256 && S == 2048) || (E == 128 && S == 1024);
+    if (dtype != SEA_BF16 || !shape_ok) {
+        sea_set_error("sea_mlp_fc1_ln_gelu: unsupported dtype / shape (dtype=%d E=%d S=%d): bf16, (E, S) in {(256, 2048), (128, 1024)}", dtype, E, S);
+        return SEA_EUNSUPPORTED;
+    }
+    MlpLaunch L;
+    memset(&L, 0, sizeof(L));
+    int total = 0;
+    for (int i = 0; i < n_groups; ++i) {
+        const SeaMlpGroup& G = groups[i];
+        SEA_REQUIRE(G.E == E && G.S == S && G.M >= 1, "sea_mlp_fc1_ln_gelu[%d]: the groups of a launch share E and S", i);
+        SEA_REQUIRE(G.A && G.W1 && G.b1 && G.lnw && G.lnb && G.Hg, "sea_mlp_fc1_ln_gelu[%d]: null pointer", i);
+        SEA_REQUIRE(G.lda % 8 == 0 && G.lda >= E && G.ldw % 8 == 0 && G.ldw >= E && G.ldh % 8 == 0 && G.ldh >= S, "sea_mlp_fc1_ln_gelu[%d]: bad strides", i);
+        SEA_REQUIRE(sea_aligned16(G.A) && sea_aligned16(G.W1) && sea_aligned16(G.b1) && sea_aligned16(G.lnw) && sea_aligned16(G.lnb) && sea_aligned16(G.Hg),
+                    "sea_mlp_fc1_ln_gelu[%d]: pointers must be 16-byte aligned", i);
+        L.g[i] = G;
+        L.tile_start[i] = total;
+        total += (G.M + 31) / 32;
+    }
+    L.tile_start[n_groups] = total;
+    L.n_groups = n_groups;
+    L.eps = eps;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (E == 256) {
+        constexpr int lds = 4 * 32 * 128 + 4 * (4 * 64 * 128);   // 16 KiB + 128 KiB
+        static int once = set_lds_mlp(mlp_fc1_ln_gelu_kernel<4, 16>, lds);
+        (void)once;
+        mlp_fc1_ln_gelu_kernel<4, 16><<<dim3(total), dim3(512), lds, s>>>(L);
+    } else {
+        constexpr int lds0 = 2 * 32 * 128 + 4 * (2 * 64 * 128);  // 8 KiB + 64 KiB = 73728 >= 32 * (1024 * 2 + 16) = 66048
+        static int once = set_lds_mlp(mlp_fc1_ln_gelu_kernel<2, 8>, lds0);
+        (void)once;
+        mlp_fc1_ln_gelu_kernel<2, 8><<<dim3(total), dim3(512), lds0, s>>>(L);
+    }
+    SEA_CHECK_LAUNCH("sea_mlp_fc1_ln_gelu");
+    return SEA_OK;
+}

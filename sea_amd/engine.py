@@ -707,10 +707,18 @@ class Plan:
         if not skip_adaln2:
             extra = (lambda i: dict(addend=addend, Xout=xr[i])) if addend is not None else (lambda i: {})   # x_i += ib rides in this pass
             self._norm([dict(X=xr[i], Yact=n_e[i], **extra(i), **norm_params(f"{pre}ln.exp.{i}.2.", E)) for i in fields], E, ("mlp.ib_adaln2" if addend is not None else "mlp.adaln2") + tag)
-        self._gemm([dict(A=n_e[i], W=P.act(f"{pre}mlp.{i}.layers.0.weight"), bias=P.f32_vec(f"{pre}mlp.{i}.layers.0.bias"), Cact=hbuf[i])
-                    for i in fields], "mlp.fc1" + tag)
-        self._norm([dict(X=hbuf[i], gamma=P.f32_vec(f"{pre}mlp.{i}.layers.1.weight"), beta=P.f32_vec(f"{pre}mlp.{i}.layers.1.bias"), Yact=hg[i])
-                    for i in fields], S, "mlp.ln_gelu" + tag, x_is_act=True, gelu=True)
+        # Linear + nn.LayerNorm + GELU in one launch where the kernel is instantiated (bf16; SEA_FUSE_MLP1=0 keeps the two launches)
+        if (type(self) is Plan and os.environ.get("SEA_FUSE_MLP1", "1") != "0" and ops.mlp_fc1_supported(self.dt, E, S) and len(fields) <= N.MAX_MLP_GROUPS):
+            arr = (N.SeaMlpGroup * len(fields))()
+            for g_, i in zip(arr, fields):
+                ops.fill_mlp_group(g_, n_e[i], P.act(f"{pre}mlp.{i}.layers.0.weight"), P.f32_vec(f"{pre}mlp.{i}.layers.0.bias"),
+                                   P.f32_vec(f"{pre}mlp.{i}.layers.1.weight"), P.f32_vec(f"{pre}mlp.{i}.layers.1.bias"), hg[i])
+            self._cur.append(self._rec(N.lib().sea_mlp_fc1_ln_gelu, [arr, len(fields), 1e-5, self.code], "mlp.fc1_ln_gelu" + tag, arr))
+        else:
+            self._gemm([dict(A=n_e[i], W=P.act(f"{pre}mlp.{i}.layers.0.weight"), bias=P.f32_vec(f"{pre}mlp.{i}.layers.0.bias"), Cact=hbuf[i])
+                        for i in fields], "mlp.fc1" + tag)
+            self._norm([dict(X=hbuf[i], gamma=P.f32_vec(f"{pre}mlp.{i}.layers.1.weight"), beta=P.f32_vec(f"{pre}mlp.{i}.layers.1.bias"), Yact=hg[i])
+                        for i in fields], S, "mlp.ln_gelu" + tag, x_is_act=True, gelu=True)
         self._gemm([dict(A=hg[i], W=P.act(f"{pre}mlp.{i}.layers.3.weight"), bias=P.f32_vec(f"{pre}mlp.{i}.layers.3.bias"), R=xr[i], Cact=xm[i])
                     for i in fields], "mlp.fc2" + tag)
         if fuse_final:  # last layer: proj_i and the model's final norm of field i in one launch, written straight into out[B,T,F,E]
@@ -953,6 +961,8 @@ class Plan:
                 c.op, c.p0, c.n, c.p1, c.dtype = N.OP_QKV, addr(a[0]), a[1], addr(r.keep[1]), a[3]
             elif r.fn is L.sea_attention_fwd:
                 c.op, c.p0, c.dtype = N.OP_ATTN, addr(r.keep), a[1]
+            elif r.fn is L.sea_mlp_fc1_ln_gelu:
+                c.op, c.p0, c.n, c.f0, c.dtype = N.OP_MLP1, addr(a[0]), a[1], a[2], a[3]
             elif r.fn is L.sea_exchange_tail:
                 c.op, c.p0, c.n, c.f0, c.dtype = N.OP_XTAIL, addr(r.keep), a[1], a[2], a[3]
             elif r.fn is L.sea_gemm_rownorm:

@@ -481,3 +481,24 @@ def patchify(fields: torch.Tensor, index_map: torch.Tensor, scale: torch.Tensor,
                                  n_points, pad_value, N.stream_ptr()), "sea_patchify")
     return out
 
+
+def mlp_fc1_supported(dtype: torch.dtype, E: int, S: int) -> bool:
+    """Shapes sea_mlp_fc1_ln_gelu instantiates (include/sea_hip.h)."""
+    return dtype == torch.bfloat16 and (E, S) in ((256, 2048), (128, 1024))
+
+
+def fill_mlp_group(g: N.SeaMlpGroup, A, W1, b1, lnw, lnb, Hg) -> None:
+    g.A, g.W1, g.b1, g.lnw, g.lnb, g.Hg = A.data_ptr(), W1.data_ptr(), b1.data_ptr(), lnw.data_ptr(), lnb.data_ptr(), Hg.data_ptr()
+    g.lda, g.ldw, g.ldh = A.stride(0), W1.stride(0), Hg.stride(0)
+    g.M, g.E, g.S = A.shape[0], W1.shape[1], W1.shape[0]
+
+
+def mlp_fc1_ln_gelu(groups: Sequence[Dict], eps: float = 1e-5, dtype: torch.dtype = torch.bfloat16) -> None:
+    """Hg = gelu(LayerNorm(A W1^T + b1) * lnw + lnb) in one launch (sea_mlp_fc1_ln_gelu): dicts with A [M,E], W1 [S,E], b1, lnw, lnb f32 [S], Hg [M,S]."""
+    arr = (N.SeaMlpGroup * len(groups))()
+    for g, d in zip(arr, groups):
+        for k in ("A", "W1", "Hg"):
+            _mat(d[k], k)
+        fill_mlp_group(g, d["A"], d["W1"], d["b1"], d["lnw"], d["lnb"], d["Hg"])
+    N.check(N.lib().sea_mlp_fc1_ln_gelu(arr, len(groups), eps, N.dtype_code(dtype), N.stream_ptr()), "sea_mlp_fc1_ln_gelu")
+

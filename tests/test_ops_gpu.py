@@ -509,6 +509,34 @@ def test_silu_launch_evaluates_ib_and_rownorm_adds_it(dtype):
     assert rel(xa, x + bufs[0]) < 1e-7
 
 
+@pytest.mark.parametrize("E,S", [(256, 2048), (128, 1024)])
+@pytest.mark.parametrize("M", [77, 2024])
+def test_mlp_fc1_ln_gelu_matches_two_launch_form(E, S, M):
+    """sea_mlp_fc1_ln_gelu (Linear + nn.LayerNorm + GELU with 32 complete hidden rows per workgroup) against the fp32 formula on the bf16 operands and
+    against the two launches it replaces (sea_gemm_grouped, sea_rownorm with the GELU epilogue — which round the pre-activation to bf16 in between)."""
+    from sea_amd import ops
+
+    dt = torch.bfloat16
+    groups, refs, keep = [], [], []
+    for i in range(3):
+        A = rnd(M, E, dtype=dt, seed=1300 + i)
+        W1, b1 = rnd(S, E, dtype=dt, scale=0.08, seed=1310 + i), 0.3 * rnd(S, seed=1320 + i)
+        lnw, lnb = 1 + 0.1 * rnd(S, seed=1330 + i), 0.1 * rnd(S, seed=1340 + i)
+        Hg = torch.full((M, S), float("nan"), device=dev(), dtype=dt)
+        groups.append(dict(A=A, W1=W1, b1=b1, lnw=lnw, lnb=lnb, Hg=Hg))
+        refs.append(gelu(torch.nn.functional.layer_norm(A.float() @ W1.float().t() + b1, (S,), lnw, lnb, 1e-5)))
+        keep.append(Hg)
+    assert ops.mlp_fc1_supported(dt, E, S)
+    ops.mlp_fc1_ln_gelu(groups)
+    for ref, Hg, d in zip(refs, keep, groups):
+        assert rel(Hg.float(), ref) < 6e-3
+        h = torch.empty(M, S, device=dev(), dtype=dt)
+        hg2 = torch.empty(M, S, device=dev(), dtype=dt)
+        ops.gemm_grouped([dict(A=d["A"], W=d["W1"], bias=d["b1"], Cact=h)], dt)
+        ops.rownorm([dict(X=h, gamma=d["lnw"], beta=d["lnb"], Yact=hg2)], M, S, True, True, 1e-5, dt)
+        assert rel(Hg.float(), hg2.float()) < 8e-3
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_rownorm_ln_gelu_act_input(dtype):
     from sea_amd import ops
