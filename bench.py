@@ -281,6 +281,10 @@ def main():
     dom_bytes = None
     if name == "adaln.cond_gemm":   # hidden matrices in, modulations out, weights once: 12 modules at F = 3 (9 of width 2E, 3 of width 2D)
         dom_bytes = sum(n_mod * (2 * B * T * (2 * d) * esz + (2 * d) * (2 * d) * esz) for n_mod, d in ((3 * F, E), (F, D)))
+    elif name == "mlp.fc1_ln_gelu":  # per field: normalised rows in, W1 and the three vectors once, activated hidden rows out (the pre-activation never leaves the CU)
+        dom_bytes = F * (B * T * E * esz + S * E * esz + 3 * S * 4 + B * T * S * esz)
+    elif name == "mlp.fc2":          # activated hidden rows and the residual in, W2 once, rows out
+        dom_bytes = F * (B * T * S * esz + S * E * esz + B * T * E * 4 + B * T * E * esz)
 
     # HBM bytes per launch of the dominant kernel, from the committed PMC profile of this same workload (separate --pmc passes, see
     # profiles/README.md); null when the workload or the plan differs from the profiled one

@@ -17,6 +17,7 @@ struct MlpLaunch {
     int tile_start[SEA_MAX_MLP_GROUPS + 1];
     int n_groups;
     float eps;
+    int per_xcd;   // > 0: workgroup b takes tile (b % 8) * per_xcd + b / 8, so that the tiles of one field (one W1) sit on as few XCDs (L2s) as possible
 };
 
 __device__ __forceinline__ void glds16_mlp(const void* gsrc, unsigned lds_addr) {
@@ -37,10 +38,13 @@ __global__ __launch_bounds__(512) void mlp_fc1_ln_gelu_kernel(const MlpLaunch L)
     constexpr int SP = S * 2 + 16;                         // staging pitch of an output row
     static_assert(NS * STAGE >= 0 && BM * SP <= A_BYTES + NS * STAGE, "the output tile is staged over the operand memory");
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    // workgroups go to the XCDs round-robin: consecutive tiles (the same field, the same W1) are given to the same XCD
+    const int tile = L.per_xcd > 0 ? (int)(blockIdx.x & 7) * L.per_xcd + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    if (tile >= L.tile_start[L.n_groups]) return;
     int gi = 0;
-    while (gi + 1 < L.n_groups && (int)blockIdx.x >= L.tile_start[gi + 1]) ++gi;
+    while (gi + 1 < L.n_groups && tile >= L.tile_start[gi + 1]) ++gi;
     const SeaMlpGroup& G = L.g[gi];
-    const int m0 = (blockIdx.x - L.tile_start[gi]) * BM, M = G.M;
+    const int m0 = (tile - L.tile_start[gi]) * BM, M = G.M;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 15, g = lane >> 4;
@@ -71,6 +75,7 @@ __global__ __launch_bounds__(512) void mlp_fc1_ln_gelu_kernel(const MlpLaunch L)
     (void)A_PIECES;
 
     f32x4 acc[NSB][2];
+    uint4 areg[KT][2][2];
 #pragma unroll
     for (int i = 0; i < NSB; ++i) {
         acc[i][0] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -84,19 +89,27 @@ __global__ __launch_bounds__(512) void mlp_fc1_ln_gelu_kernel(const MlpLaunch L)
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         if (s + NS - 1 < NSTAGE) dma_stage(s + NS - 1);
+        if (s == 0) {            // the A rows have landed: this lane's fragments of all 32 rows stay in registers for the whole contraction
+            const char* sA = smem + r * BKB;   // (read from LDS per stage they were two of every three fragment loads of the main loop)
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+                for (int kc = 0; kc < 2; ++kc) {
+                    const int off = ((kc * 4 + g) ^ (r & 7)) << 4;
+                    areg[kt][kc][0] = *reinterpret_cast<const uint4*>(sA + kt * BM * BKB + off);
+                    areg[kt][kc][1] = *reinterpret_cast<const uint4*>(sA + kt * BM * BKB + 16 * BKB + off);
+                }
+        }
         if ((s & 1) == half) {   // wave-uniform
             const char* sW = smem + A_BYTES + (s % NS) * STAGE + (wq * 16 + r) * BKB;
-            const char* sA = smem + r * BKB;
 #pragma unroll
             for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
                 for (int kc = 0; kc < 2; ++kc) {
                     const int off = ((kc * 4 + g) ^ (r & 7)) << 4;
                     const uint4 wf = *reinterpret_cast<const uint4*>(sW + kt * 64 * BKB + off);
-                    const uint4 a0 = *reinterpret_cast<const uint4*>(sA + kt * BM * BKB + off);
-                    const uint4 a1 = *reinterpret_cast<const uint4*>(sA + kt * BM * BKB + 16 * BKB + off);
-                    mma16<T>(wf, a0, acc[s >> 1][0]);
-                    mma16<T>(wf, a1, acc[s >> 1][1]);
+                    mma16<T>(wf, areg[kt][kc][0], acc[s >> 1][0]);
+                    mma16<T>(wf, areg[kt][kc][1], acc[s >> 1][1]);
                 }
         }
     }
@@ -226,6 +239,11 @@ extern "C" int sea_mlp_fc1_ln_gelu(const SeaMlpGroup* groups, int n_groups, floa
     L.n_groups = n_groups;
     L.eps = eps;
     hipStream_t s = static_cast<hipStream_t>(stream);
+    static const bool xcd_map = [] { const char* e = getenv("SEA_MLP_XCD"); return !(e && e[0] == '0'); }();
+    if (xcd_map && total >= 16) {
+        L.per_xcd = (total + 7) / 8;
+        total = 8 * L.per_xcd;
+    }
     if (E == 256) {
         constexpr int lds = 4 * 32 * 128 + 4 * (4 * 64 * 128);   // 16 KiB + 128 KiB
         static int once = set_lds_mlp(mlp_fc1_ln_gelu_kernel<4, 16>, lds);

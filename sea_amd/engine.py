@@ -707,8 +707,11 @@ class Plan:
         if not skip_adaln2:
             extra = (lambda i: dict(addend=addend, Xout=xr[i])) if addend is not None else (lambda i: {})   # x_i += ib rides in this pass
             self._norm([dict(X=xr[i], Yact=n_e[i], **extra(i), **norm_params(f"{pre}ln.exp.{i}.2.", E)) for i in fields], E, ("mlp.ib_adaln2" if addend is not None else "mlp.adaln2") + tag)
-        # Linear + nn.LayerNorm + GELU in one launch where the kernel is instantiated (bf16; SEA_FUSE_MLP1=0 keeps the two launches)
-        if (type(self) is Plan and os.environ.get("SEA_FUSE_MLP1", "1") != "0" and ops.mlp_fc1_supported(self.dt, E, S) and len(fields) <= N.MAX_MLP_GROUPS):
+        # Linear + nn.LayerNorm + GELU in one launch where the kernel is instantiated (bf16; SEA_FUSE_MLP1=0 keeps the two launches, =1 forces
+        # the one launch).  Every workgroup of that kernel streams the whole of W1, so it needs enough 32-row tiles to pay: with the few rows
+        # of a KV-cache step the two launches are faster (0.143 vs 0.163 ms per step at cfg2), hence the row threshold.
+        want = os.environ.get("SEA_FUSE_MLP1", "auto")
+        if (type(self) is Plan and want != "0" and (want == "1" or self.M >= 1024) and ops.mlp_fc1_supported(self.dt, E, S) and len(fields) <= N.MAX_MLP_GROUPS):
             arr = (N.SeaMlpGroup * len(fields))()
             for g_, i in zip(arr, fields):
                 ops.fill_mlp_group(g_, n_e[i], P.act(f"{pre}mlp.{i}.layers.0.weight"), P.f32_vec(f"{pre}mlp.{i}.layers.0.bias"),

@@ -319,7 +319,7 @@ def test_shipped_multiphase_dims_forward_bf16():
 
 
 @pytest.mark.parametrize("env,graphed", [({"SEA_FUSED": "1"}, False), ({"SEA_PLAN_LANES": "all"}, True), ({"SEA_PLAN_LANES": "cond"}, True),
-                                         ({"SEA_FUSE_NORM": "0"}, False), ({"SEA_FUSE_XTAIL": "0"}, False), ({"SEA_FUSE_SILU": "1"}, False), ({"SEA_FOLD_IB": "0"}, False), ({"SEA_FUSE_MLP1": "0"}, False), ({"SEA_FUSE_OPROJ": "1"}, False), ({"SEA_FUSE_KV": "1"}, False), ({"SEA_FUSE_TAIL": "1", "SEA_FUSE_FINAL": "1"}, False),
+                                         ({"SEA_FUSE_NORM": "0"}, False), ({"SEA_FUSE_XTAIL": "0"}, False), ({"SEA_FUSE_SILU": "1"}, False), ({"SEA_FOLD_IB": "0"}, False), ({"SEA_FUSE_MLP1": "1"}, False), ({"SEA_FUSE_OPROJ": "1"}, False), ({"SEA_FUSE_KV": "1"}, False), ({"SEA_FUSE_TAIL": "1", "SEA_FUSE_FINAL": "1"}, False),
                                          ({"SEA_FUSE_TAIL": "1", "SEA_FUSE_FINAL": "1", "SEA_GEMM_NORM_ROWS": "64"}, False)])
 @pytest.mark.parametrize("dtype,tol", [("fp32", 2e-6), ("bf16", 2e-2)])
 def test_optional_plans_match_default_plan(env, graphed, dtype, tol, monkeypatch):
@@ -344,8 +344,12 @@ def test_optional_plans_match_default_plan(env, graphed, dtype, tol, monkeypatch
         assert (dtype == "bf16") == ("cross.qkv_rope_old" in names) and (dtype == "fp32") == ("cross1.qkv_rope" in names)
     elif "SEA_FUSE_OPROJ" in env:  # self-attention output projection with cross_down + ln_cross in one launch (opt-in)
         assert (dtype == "fp32") == ("self.out_proj" in names) and (dtype == "bf16") == ("self.out_proj_down_norm" in names)
-    elif "SEA_FUSE_MLP1" in env:   # fc1 and LayerNorm + GELU as two launches
-        assert "mlp.fc1" in names and "mlp.ln_gelu" in names
+    elif "SEA_FUSE_MLP1" in env:   # Linear + nn.LayerNorm + GELU in one launch, forced (default from 1024 rows up: a KV-cache step keeps two launches)
+        assert (dtype == "bf16") == ("mlp.fc1_ln_gelu" in names) and (dtype == "fp32") == ("mlp.fc1" in names)
+        monkeypatch.delenv("SEA_FUSE_MLP1")
+        e2 = build(cfg, dtype).engine()
+        assert "mlp.fc1" in [r.name for r in e2.plan(2, 70, "full").records]
+        assert ("mlp.fc1_ln_gelu" in [r.name for r in e2.plan(16, 70, "full").records]) == (dtype == "bf16")
     elif "SEA_FOLD_IB" in env:     # the info-bottleneck add as its own launch (default: evaluated in the silu launch, added by the AdaLN_2 pass)
         assert "ib_add" in names and "mlp.adaln2" in names and "mlp.ib_adaln2" not in names
     elif "SEA_FUSE_SILU" in env:   # AdaLN condition MLPs with the generated operand (default only for long launches)
