@@ -36,7 +36,9 @@ __global__ __launch_bounds__(512) void mlp_fc1_ln_gelu_kernel(const MlpLaunch L)
     constexpr int STAGE = KT * 64 * BKB;                   // 64 W rows x the whole contraction
     constexpr int LPS = KT * 8 / NW;                       // DMA pieces per wave per stage (KT = 4: 4, KT = 2: 2)
     constexpr int SP = S * 2 + 16;                         // staging pitch of an output row
-    static_assert(NS * STAGE >= 0 && BM * SP <= A_BYTES + NS * STAGE, "the output tile is staged over the operand memory");
+    constexpr int PRM_OFF = A_BYTES + NS * STAGE;          // lnw | lnb (2 S floats) behind the ring: DMA'd at the start, read by the epilogue
+    constexpr int B1_OFF = 0, RED_OFF = S * 4;             // b1 and the statistics scratch go where the A rows were (they live in registers after stage 0)
+    static_assert(BM * SP <= PRM_OFF && RED_OFF + 2 * NW * BM * 4 <= A_BYTES, "the output tile is staged over the operand memory");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // workgroups go to the XCDs round-robin: consecutive tiles (the same field, the same W1) are given to the same XCD
     const int tile = L.per_xcd > 0 ? (int)(blockIdx.x & 7) * L.per_xcd + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
@@ -54,7 +56,13 @@ __global__ __launch_bounds__(512) void mlp_fc1_ln_gelu_kernel(const MlpLaunch L)
     const unsigned lds_base = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)smem);
     const int rl = lane >> 3;
     const int chunk = (lane & 7) ^ (rl & 7);               // swizzle on the source side
-    // ---- A rows: KT x 4 pieces of 8 rows, resident for the whole kernel
+    // ---- gains / shifts of the LayerNorm: 1 KiB pieces straight into LDS, oldest in the queue (the epilogue finds them there)
+    for (int p = wave; p < 2 * (S / 256); p += NW) {
+        const float* src = p < S / 256 ? G.lnw : G.lnb;
+        const int q = p < S / 256 ? p : p - S / 256;
+        glds16_mlp(src + q * 256 + lane * 4, lds_base + (unsigned)(PRM_OFF + p * 1024));
+    }
+    // ---- A rows: KT x 4 pieces of 8 rows
     for (int p = wave; p < KT * (BM / 8); p += NW) {
         const int kt = p / (BM / 8), u = p - kt * (BM / 8);
         int row = m0 + u * 8 + rl;
@@ -99,7 +107,10 @@ __global__ __launch_bounds__(512) void mlp_fc1_ln_gelu_kernel(const MlpLaunch L)
                     areg[kt][kc][0] = *reinterpret_cast<const uint4*>(sA + kt * BM * BKB + off);
                     areg[kt][kc][1] = *reinterpret_cast<const uint4*>(sA + kt * BM * BKB + 16 * BKB + off);
                 }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the reads are complete before the next barrier releases the b1 DMA over these rows
         }
+        if (s == 1)              // every wave has its A fragments (barrier above): b1 goes where the A rows were
+            for (int p = wave; p < S / 256; p += NW) glds16_mlp(G.b1 + p * 256 + lane * 4, lds_base + (unsigned)(B1_OFF + p * 1024));
         if ((s & 1) == half) {   // wave-uniform
             const char* sW = smem + A_BYTES + (s % NS) * STAGE + (wq * 16 + r) * BKB;
 #pragma unroll
@@ -113,27 +124,22 @@ __global__ __launch_bounds__(512) void mlp_fc1_ln_gelu_kernel(const MlpLaunch L)
                 }
         }
     }
-    __syncthreads();   // operand memory is free: statistics scratch and the output tile go over it
-
     // ---- epilogue: + b1, LayerNorm over the S columns of a row (two-pass, fp32), * lnw + lnb, GELU, bf16
     // this lane: rows m0 + mb*16 + r, columns n(i) = (2 i + half) * 64 + wq * 16 + 4 g + q
-    float* red = reinterpret_cast<float*>(smem);   // [2 passes][8 waves][32 rows]
-    // b1 | lnw | lnb (3 S floats) are staged in LDS with one coalesced pass: the per-lane form is 3 x 16 dependent 16-byte global loads in a
-    // 235-VGPR kernel (probe: the epilogue without GELU cost 12.5 us of the launch's 36.6)
-    float* prm = reinterpret_cast<float*>(smem + 4096);
-    for (int idx = tid; idx < 3 * S / 4; idx += 512) {
-        const int which = idx / (S / 4), c4 = idx - which * (S / 4);
-        const float* src = which == 0 ? G.b1 : (which == 1 ? G.lnw : G.lnb);
-        *reinterpret_cast<float4*>(prm + which * S + c4 * 4) = *reinterpret_cast<const float4*>(src + c4 * 4);
-    }
-    __syncthreads();
+    // b1 | lnw | lnb are in LDS already (DMA'd under the main loop; the last stage's vmcnt(0) + barrier made them visible): the per-lane form
+    // is 3 x 16 dependent 16-byte global loads, and a staging pass here put a cold L2 round trip in front of the statistics (probe build:
+    // 4.9 us between the last MFMA and the GELU, for 0.3 us of arithmetic).  Nothing below touches the ring until the output tile is written.
+    float* red = reinterpret_cast<float*>(smem + RED_OFF);   // [2 passes][8 waves][32 rows]
+    const float* pb1 = reinterpret_cast<const float*>(smem + B1_OFF);
+    const float* pgm = reinterpret_cast<const float*>(smem + PRM_OFF);
+    const float* pbt = pgm + S;
     const float inv_s = 1.0f / (float)S;
     float sum[2] = {0.f, 0.f};
 #pragma unroll
     for (int i = 0; i < NSB; ++i) {
         const int n = (2 * i + half) * 64 + wq * 16 + g * 4;
         float bv[4];
-        load4(prm + n, bv);
+        load4(pb1 + n, bv);
 #pragma unroll
         for (int mb = 0; mb < 2; ++mb) {
 #pragma unroll
@@ -180,31 +186,38 @@ __global__ __launch_bounds__(512) void mlp_fc1_ln_gelu_kernel(const MlpLaunch L)
         for (int w = 0; w < NW; ++w) t += red[256 + w * 32 + mb * 16 + r];
         rstd[mb] = 1.0f / sqrtf(t * inv_s + L.eps);
     }
-#pragma unroll
-    for (int i = 0; i < NSB; ++i) {   // activations in place of the accumulators (the gains / shifts are still in LDS)
-        const int n = (2 * i + half) * 64 + wq * 16 + g * 4;
-        float gm[4], bt[4];
-        load4(prm + S + n, gm);
-        load4(prm + 2 * S + n, bt);
-#pragma unroll
-        for (int mb = 0; mb < 2; ++mb)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) acc[i][mb][q] = gelu_erf((acc[i][mb][q] - mean[mb]) * rstd[mb] * gm[q] + bt[q]);
-    }
-    __syncthreads();   // everyone has read the statistics and the parameters: the output tile may overwrite them
-#pragma unroll
-    for (int i = 0; i < NSB; ++i) {
-        const int n = (2 * i + half) * 64 + wq * 16 + g * 4;
-#pragma unroll
-        for (int mb = 0; mb < 2; ++mb) store4(reinterpret_cast<T*>(smem + (mb * 16 + r) * SP) + n, acc[i][mb][0], acc[i][mb][1], acc[i][mb][2], acc[i][mb][3]);
-    }
-    __syncthreads();
+    __syncthreads();   // every wave is past the main loop and has read the statistics: the output tile may go over the A region and the ring
+    // The tile leaves in NCK column chunks: a chunk is activated (VALU), staged in LDS, and its whole-row stores are issued while the next chunk
+    // is being activated — the stores of a workgroup are 128 KiB, and every workgroup of the launch reaches this point at the same time
+    // (probe build: GELU 7 us, stores 4.9 us when they followed each other).
+    constexpr int NCK = 4, IPC = NSB / NCK, CW = S / NCK;   // chunks, column blocks per chunk, columns per chunk
     T* Hg = static_cast<T*>(G.Hg);
-    constexpr int CPR = S / 8;   // 16-byte chunks per row
-    for (int idx = tid; idx < BM * CPR; idx += 512) {
-        const int row = idx / CPR, cc = idx - row * CPR;
-        const int m = m0 + row;
-        if (m < M) *reinterpret_cast<uint4*>(Hg + (int64_t)m * G.ldh + cc * 8) = *reinterpret_cast<const uint4*>(smem + row * SP + cc * 16);
+#pragma unroll
+    for (int c = 0; c < NCK; ++c) {
+#pragma unroll
+        for (int ii = 0; ii < IPC; ++ii) {
+            const int i = c * IPC + ii;
+            const int n = (2 * i + half) * 64 + wq * 16 + g * 4;
+            float gm[4], bt[4];
+            load4(pgm + n, gm);
+            load4(pbt + n, bt);
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb) {
+                float y[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) y[q] = gelu_erf((acc[i][mb][q] - mean[mb]) * rstd[mb] * gm[q] + bt[q]);
+                store4(reinterpret_cast<T*>(smem + (mb * 16 + r) * SP) + n, y[0], y[1], y[2], y[3]);
+            }
+        }
+        __syncthreads();
+        constexpr int CPR = CW / 8;   // 16-byte pieces per row of the chunk
+#pragma unroll
+        for (int k = 0; k < BM * CPR / 512; ++k) {
+            const int idx = tid + k * 512;
+            const int row = idx / CPR, cc = idx - row * CPR;
+            const int m = m0 + row;
+            if (m < M) *reinterpret_cast<uint4*>(Hg + (int64_t)m * G.ldh + c * CW + cc * 8) = *reinterpret_cast<const uint4*>(smem + row * SP + c * CW * 2 + cc * 16);
+        }
     }
 }
 
@@ -240,17 +253,17 @@ extern "C" int sea_mlp_fc1_ln_gelu(const SeaMlpGroup* groups, int n_groups, floa
     L.eps = eps;
     hipStream_t s = static_cast<hipStream_t>(stream);
     static const bool xcd_map = [] { const char* e = getenv("SEA_MLP_XCD"); return !(e && e[0] == '0'); }();
-    if (xcd_map && total >= 16) {
+    if (xcd_map && total > 256) {   // one round of workgroups: the plain order measured 0.6 us faster (cfg2, 190 tiles); several rounds: XCD-local wins (B=8)
         L.per_xcd = (total + 7) / 8;
         total = 8 * L.per_xcd;
     }
     if (E == 256) {
-        constexpr int lds = 4 * 32 * 128 + 4 * (4 * 64 * 128);   // 16 KiB + 128 KiB
+        constexpr int lds = 4 * 32 * 128 + 4 * (4 * 64 * 128) + 2 * 2048 * 4;   // A 16 KiB + ring 128 KiB + lnw | lnb 16 KiB = all 160 KiB of the CU
         static int once = set_lds_mlp(mlp_fc1_ln_gelu_kernel<4, 16>, lds);
         (void)once;
         mlp_fc1_ln_gelu_kernel<4, 16><<<dim3(total), dim3(512), lds, s>>>(L);
     } else {
-        constexpr int lds0 = 2 * 32 * 128 + 4 * (2 * 64 * 128);  // 8 KiB + 64 KiB = 73728 >= 32 * (1024 * 2 + 16) = 66048
+        constexpr int lds0 = 2 * 32 * 128 + 4 * (2 * 64 * 128) + 2 * 1024 * 4;  // 8 KiB + 64 KiB (>= the output tile, 32 * (1024 * 2 + 16) = 66048) + lnw | lnb 8 KiB
         static int once = set_lds_mlp(mlp_fc1_ln_gelu_kernel<2, 8>, lds0);
         (void)once;
         mlp_fc1_ln_gelu_kernel<2, 8><<<dim3(total), dim3(512), lds0, s>>>(L);
