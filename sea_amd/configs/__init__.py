@@ -1,0 +1,1 @@
+"""Model / dataset configurations named after the reference configs (cylinder_flow, multiphase_flow)."""

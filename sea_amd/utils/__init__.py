@@ -1,0 +1,1 @@
+"""Rollout helpers, scalers and dataset windows around the HIP engine."""
