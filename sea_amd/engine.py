@@ -432,11 +432,13 @@ class Plan:
         f32 = torch.float32
 
         # Optional lanes (parallel graph branches) for independent work — SEA_PLAN_LANES: "cond" = the condition MLPs the first launch does
-        # not need, "all" = also every finished field's MLP beside the remaining exchange stages.  Off by default: measured at cfg2 the
-        # cross-branch dependencies of a captured HIP graph cost more than the overlap gains (0.344 ms none, 0.371 cond, 0.395 all).
+        # not need, "all" = also every finished field's MLP beside the remaining exchange stages.  At one trajectory the
+        # cross-branch dependencies of a captured HIP graph cost more than the overlap gains; from 8192 rows up the condition lane pays (1 %).
         xmode = eng.model.exchange_mode                                   # 'sea' | 'addition' | 'simple' (models/temporal.py:314-324)
         has_ib = eng.model.ib_addition_mode.lower() == "add"              # 'none': _add_info returns x (models/temporal.py:113-114)
-        mode = os.environ.get("SEA_PLAN_LANES", "none") if type(self) is Plan and xmode == "sea" and has_ib else "none"
+        mode = os.environ.get("SEA_PLAN_LANES", "auto") if type(self) is Plan and xmode == "sea" and has_ib else "none"
+        if mode == "auto":   # with the current 21-launch plan: cfg2 0.252 ms none / 0.284 cond / 0.358 all; B=8 1.166 none / 1.154 cond / 1.245 all
+            mode = "cond" if self.M >= 8192 else "none"
         lanes = mode == "all" and F >= 2 and eng.model.add_info_after_cross
         split_cond = mode in ("cond", "all") and self.adaln
         # Linear + the row norm that follows it in one launch (sea_gemm_rownorm) where a tile can span the whole output row: cross_down + ln_cross,
