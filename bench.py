@@ -60,6 +60,7 @@ def kernel_flops(name, B, T, F, E, H, D, S):
         return kernel_flops(name, B, T, F, E, H, D, S) // per_field
     table = {
         "adaln.cond_gemm": 2 * M * ((2 * F + F) * (2 * E) ** 2 + F * (2 * D) ** 2),
+        "adaln.cond_mlp": 2 * M * ((2 * F + F) * (2 * E) ** 2 + F * (2 * D) ** 2),   # cond_mlp.2 of the 12 modules (the silu rows are not counted)
         "self.qkv_rope": F * 2 * M * E * 3 * E,
         "self.attention": F * 4 * B * tri * E,
         "self.out_proj": F * 2 * M * E * E,
@@ -281,6 +282,8 @@ def main():
     dom_bytes = None
     if name == "adaln.cond_gemm":   # hidden matrices in, modulations out, weights once: 12 modules at F = 3 (9 of width 2E, 3 of width 2D)
         dom_bytes = sum(n_mod * (2 * B * T * (2 * d) * esz + (2 * d) * (2 * d) * esz) for n_mod, d in ((3 * F, E), (F, D)))
+    elif name == "adaln.cond_mlp":   # the condition once, weights once, modulations out: no hidden matrix
+        dom_bytes = sum(n_mod * (B * T * (2 * d) * esz + (2 * d) * (2 * d) * esz + 3 * (2 * d) * 4) for n_mod, d in ((3 * F, E), (F, D))) + B * T * 4
     elif name == "mlp.fc1_ln_gelu":  # per field: normalised rows in, W1 and the three vectors once, activated hidden rows out (the pre-activation never leaves the CU)
         dom_bytes = F * (B * T * E * esz + S * E * esz + 3 * S * 4 + B * T * S * esz)
     elif name == "mlp.fc2":          # activated hidden rows and the residual in, W2 once, rows out

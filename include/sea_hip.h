@@ -41,7 +41,7 @@ enum {
 int sea_abi_version(void);
 const char* sea_last_error(void);
 /* sizeof of every ABI struct in declaration order (SeaGemmGroup, SeaQkvGroup, SeaQkvCommon, SeaAttnProblem,
- * SeaAttnParams, SeaNormGroup, SeaSiluGroup, SeaIbParams, ..., SeaGemmNormGroup, SeaExchangeTail, SeaMlpGroup last): lets a binding verify its layout.  Host only. */
+ * SeaAttnParams, SeaNormGroup, SeaSiluGroup, SeaIbParams, ..., SeaGemmNormGroup, SeaExchangeTail, SeaMlpGroup, SeaCondGroup last): lets a binding verify its layout.  Host only. */
 int sea_struct_sizes(int* out, int cap);
 /* Number of compute units / name of device 0's architecture as HIP reports them (diagnostics for bench.py). */
 int sea_device_info(int* cu_count, char* arch, int arch_len);
@@ -305,6 +305,29 @@ typedef struct {
 } SeaMlpGroup;
 
 int sea_mlp_fc1_ln_gelu(const SeaMlpGroup* groups, int n_groups, float eps, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * AdaLN condition MLP of a scalar condition in ONE launch, for every module of the model:
+ *     Out_g[m, :] = W2_g . silu(w1_g * c[m] + b1_g) + b2_g            (g < n_groups; W2_g in nn.Linear layout [K, K])
+ * Replaces cond_mlp = Sequential(Linear(1, 2d), SiLU, Linear(2d, 2d)) of AdaptiveLayerNorm (models/base_blocks.py:337-345) for all the
+ * AdaLN modules of TemporalModel at once — sea_silu_outer + the cond_mlp.2 group of sea_gemm_grouped without the hidden matrix between
+ * them: a workgroup owns 32 complete rows of one module, generates their hidden rows into LDS once and streams W2 through an LDS ring.
+ * The `n_ib` information-bottleneck layers are evaluated by extra workgroups of the same launch exactly as sea_silu_outer_ib does.
+ * bf16 only, K = 128, 256 or 512 (d = 64 / 128 / 256), ldw % 8 == 0, ldo % 8 == 0, pointers 16-byte aligned; SEA_EUNSUPPORTED otherwise (callers keep
+ * the two launches).  c: f32 [M].
+ */
+#define SEA_MAX_COND_GROUPS 24
+typedef struct {
+    const float* w1;    /* f32 [K]: cond_mlp.0.weight[:, 0] */
+    const float* b1;    /* f32 [K]: cond_mlp.0.bias */
+    const void* W2;     /* act [K, K], row stride ldw: cond_mlp.2.weight */
+    const float* b2;    /* f32 [K]: cond_mlp.2.bias */
+    void* Out;          /* act [M, K], row stride ldo: (scale | shift) rows */
+    int32_t K, ldw, ldo, pad_;
+} SeaCondGroup;
+
+struct SeaIbParams_;
+int sea_cond_mlp(const SeaCondGroup* groups, int n_groups, const float* c, int M, int dtype, const struct SeaIbParams_* ibs, int n_ib, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Hidden layer of the AdaLN condition MLP for a scalar condition: Hid[m, k] = silu(w1[k] * c[m] + b1[k]).
@@ -593,10 +616,10 @@ int sea_rowchain(const SeaChainLaunch* launch, const SeaChainStage* host_stages,
  *     SEA_OP_SILU   p0 = SeaSiluGroup[n], p1 = c, i0 = M, l0 = (intptr) SeaIbParams[l1] or 0, l1 = n_ib      SEA_OP_IB     p0 = SeaIbParams
  *     SEA_OP_CHAIN  p0 = SeaChainLaunch, p1 = host stage table    SEA_OP_CONVERT p0 = src, p1 = dst, l0 = lds, l1 = ldd, l2 = rows, l3 = cols
  *     SEA_OP_GEMM_NORM p0 = SeaGemmNormGroup[n], f0 = eps          SEA_OP_XTAIL  p0 = SeaExchangeTail[n], f0 = eps
- *     SEA_OP_MLP1   p0 = SeaMlpGroup[n], f0 = eps
+ *     SEA_OP_MLP1   p0 = SeaMlpGroup[n], f0 = eps                 SEA_OP_COND   p0 = SeaCondGroup[n], p1 = c, i0 = M, l0 = (intptr) SeaIbParams[l1] or 0, l1 = n_ib
  * Returns 0, or the failing entry's error code with sea_last_error() set (entries before it have been launched).
  */
-enum { SEA_OP_GEMM = 1, SEA_OP_QKV = 2, SEA_OP_ATTN = 3, SEA_OP_NORM = 4, SEA_OP_SILU = 5, SEA_OP_IB = 6, SEA_OP_CHAIN = 7, SEA_OP_CONVERT = 8, SEA_OP_GEMM_NORM = 9, SEA_OP_XTAIL = 10, SEA_OP_MLP1 = 11 };
+enum { SEA_OP_GEMM = 1, SEA_OP_QKV = 2, SEA_OP_ATTN = 3, SEA_OP_NORM = 4, SEA_OP_SILU = 5, SEA_OP_IB = 6, SEA_OP_CHAIN = 7, SEA_OP_CONVERT = 8, SEA_OP_GEMM_NORM = 9, SEA_OP_XTAIL = 10, SEA_OP_MLP1 = 11, SEA_OP_COND = 12 };
 typedef struct {
     int32_t op, n, dtype, i0, i1, i2, i3;
     float f0;

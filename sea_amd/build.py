@@ -13,7 +13,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libsea_hip.so")
-SOURCES = ["core.hip", "gemm.hip", "gemm_norm.hip", "mlp_fused.hip", "attention.hip", "rowops.hip", "train.hip", "bwd.hip", "attention_bwd.hip", "rowchain.hip"]
+SOURCES = ["core.hip", "gemm.hip", "gemm_norm.hip", "mlp_fused.hip", "cond_mlp.hip", "attention.hip", "rowops.hip", "train.hip", "bwd.hip", "attention_bwd.hip", "rowchain.hip"]
 HEADERS = ["sea_common.hpp", "gemm_core.hpp", os.path.join("..", "..", "include", "sea_hip.h")]
 # -amdgpu-mfma-vgpr-form: MFMA results land in VGPRs, so epilogues / softmax read them without v_accvgpr_read moves.
 # -ffast-math -fno-finite-math-only: reciprocal / approximate-function / reassociation freedoms for the row kernels and epilogues; infinities

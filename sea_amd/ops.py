@@ -502,3 +502,26 @@ def mlp_fc1_ln_gelu(groups: Sequence[Dict], eps: float = 1e-5, dtype: torch.dtyp
         fill_mlp_group(g, d["A"], d["W1"], d["b1"], d["lnw"], d["lnb"], d["Hg"])
     N.check(N.lib().sea_mlp_fc1_ln_gelu(arr, len(groups), eps, N.dtype_code(dtype), N.stream_ptr()), "sea_mlp_fc1_ln_gelu")
 
+
+
+def cond_mlp_supported(dtype: torch.dtype, widths: Sequence[int]) -> bool:
+    """Shapes sea_cond_mlp instantiates: bf16, module width K = 2d in {128, 256, 512}."""
+    return dtype == torch.bfloat16 and all(k in (128, 256, 512) for k in widths)
+
+
+def fill_cond_group(g, w1: torch.Tensor, b1: torch.Tensor, W2: torch.Tensor, b2: torch.Tensor, Out: torch.Tensor) -> None:
+    g.w1, g.b1, g.W2, g.b2, g.Out = w1.data_ptr(), b1.data_ptr(), W2.data_ptr(), b2.data_ptr(), Out.data_ptr()
+    g.K, g.ldw, g.ldo = W2.shape[0], W2.stride(0), Out.stride(0)
+
+
+def cond_mlp(groups: Sequence[Dict], c: torch.Tensor, dtype: torch.dtype = torch.bfloat16) -> None:
+    """Out = W2 silu(w1 c + b1) + b2 for every AdaLN condition MLP in one launch (sea_cond_mlp): dicts with w1, b1 f32 [K], W2 [K,K], b2 f32 [K], Out [M,K];
+    c f32 [M]."""
+    assert c.dtype == torch.float32 and c.is_contiguous()
+    arr = (N.SeaCondGroup * len(groups))()
+    for g, d in zip(arr, groups):
+        _mat(d["W2"], "W2")
+        _mat(d["Out"], "Out")
+        assert d["W2"].shape[0] == d["W2"].shape[1] == d["Out"].shape[1] and d["Out"].shape[0] == c.shape[0]
+        fill_cond_group(g, d["w1"], d["b1"], d["W2"], d["b2"], d["Out"])
+    N.check(N.lib().sea_cond_mlp(arr, len(groups), c.data_ptr(), c.shape[0], N.dtype_code(dtype), None, 0, N.stream_ptr()), "sea_cond_mlp")

@@ -319,7 +319,7 @@ def test_shipped_multiphase_dims_forward_bf16():
 
 
 @pytest.mark.parametrize("env,graphed", [({"SEA_FUSED": "1"}, False), ({"SEA_PLAN_LANES": "all"}, True), ({"SEA_PLAN_LANES": "cond"}, True),
-                                         ({"SEA_FUSE_NORM": "0"}, False), ({"SEA_FUSE_XTAIL": "0"}, False), ({"SEA_FUSE_SILU": "1"}, False), ({"SEA_FOLD_IB": "0"}, False), ({"SEA_FUSE_MLP1": "1"}, False), ({"SEA_FUSE_OPROJ": "1"}, False), ({"SEA_FUSE_KV": "1"}, False), ({"SEA_FUSE_TAIL": "1", "SEA_FUSE_FINAL": "1"}, False),
+                                         ({"SEA_FUSE_NORM": "0"}, False), ({"SEA_FUSE_XTAIL": "0"}, False), ({"SEA_FUSE_SILU": "1"}, False), ({"SEA_FOLD_IB": "0"}, False), ({"SEA_FUSE_MLP1": "1"}, False), ({"SEA_FUSE_COND": "1"}, False), ({"SEA_FUSE_OPROJ": "1"}, False), ({"SEA_FUSE_KV": "1"}, False), ({"SEA_FUSE_TAIL": "1", "SEA_FUSE_FINAL": "1"}, False),
                                          ({"SEA_FUSE_TAIL": "1", "SEA_FUSE_FINAL": "1", "SEA_GEMM_NORM_ROWS": "64"}, False)])
 @pytest.mark.parametrize("dtype,tol", [("fp32", 2e-6), ("bf16", 2e-2)])
 def test_optional_plans_match_default_plan(env, graphed, dtype, tol, monkeypatch):
@@ -350,6 +350,8 @@ def test_optional_plans_match_default_plan(env, graphed, dtype, tol, monkeypatch
         e2 = build(cfg, dtype).engine()
         assert "mlp.fc1" in [r.name for r in e2.plan(2, 70, "full").records]
         assert ("mlp.fc1_ln_gelu" in [r.name for r in e2.plan(16, 70, "full").records]) == (dtype == "bf16")
+    elif "SEA_FUSE_COND" in env:   # the condition MLPs of every module in one sea_cond_mlp launch (bf16; opt-in) instead of the silu launch + grouped GEMM
+        assert (dtype == "bf16") == ("adaln.cond_mlp" in names) and (dtype == "fp32") == ("adaln.cond_gemm" in names)
     elif "SEA_FOLD_IB" in env:     # the info-bottleneck add as its own launch (default: evaluated in the silu launch, added by the AdaLN_2 pass)
         assert "ib_add" in names and "mlp.adaln2" in names and "mlp.ib_adaln2" not in names
     elif "SEA_FUSE_SILU" in env:   # AdaLN condition MLPs with the generated operand (default only for long launches)
