@@ -222,10 +222,13 @@ __global__ __launch_bounds__(256) void qkv_rope_kernel(const QkvLaunch L) {
     if constexpr (DMA) ml.run_dma(smem, acc);
     else ml.run_single(smem, acc);
 
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int wm = wave >> 1, wn = wave & 1, r = lane & 15, g = lane >> 4;
     const int H = L.c.H, hd = L.c.hd, Tlen = L.c.T, cap = L.c.cap;
     const int Ea = H * hd, hd2 = hd >> 1;
+    // a 16-column MFMA block lies inside one head of one of q / k / v when hd and the group's column offset are multiples of 16: part, head and
+    // the q / k / v branch are then WAVE-uniform (scalar branches, one integer division per block instead of one per lane)
+    const bool blk_uniform = (hd & 15) == 0 && (G.col0 & 15) == 0;
     const float2* rope = reinterpret_cast<const float2*>(L.c.rope);
     T* Qo = static_cast<T*>(G.Qout);
     T* Ko = static_cast<T*>(G.Kout);
@@ -250,10 +253,26 @@ __global__ __launch_bounds__(256) void qkv_rope_kernel(const QkvLaunch L) {
         float bv[4] = {0.f, 0.f, 0.f, 0.f};
         if (G.bias != nullptr) load4(G.bias + n, bv);
         const int nn = G.col0 + n;       // column in the virtual [q | k | v] row; hd % 4 == 0 keeps the 4 columns in one head
-        const int part = nn >= 2 * Ea ? 2 : (nn >= Ea ? 1 : 0);   // 0 q, 1 k, 2 v
-        const int hcol = nn - part * Ea;
-        const int h = hcol / hd;
-        const int dd = hcol - h * hd;
+        int part, h, dd;
+        if (blk_uniform) {   // block-uniform
+            const int nb = __builtin_amdgcn_readfirstlane(nn - g * 4);   // first column of the 16-column block (the same in every lane)
+            part = nb >= 2 * Ea ? 2 : (nb >= Ea ? 1 : 0);                // 0 q, 1 k, 2 v
+            const int hb = nb - part * Ea;
+            h = hb / hd;
+            dd = hb - h * hd + g * 4;
+        } else {
+            part = nn >= 2 * Ea ? 2 : (nn >= Ea ? 1 : 0);
+            const int hcol = nn - part * Ea;
+            h = hcol / hd;
+            dd = hcol - h * hd;
+        }
+        // the (cos, sin) pairs of every row block of this column block, requested together ahead of their use
+        float4 csr[C::MI];
+#pragma unroll
+        for (int i = 0; i < C::MI; ++i) {
+            csr[i] = make_float4(1.f, 0.f, 1.f, 0.f);
+            if (part < 2) csr[i] = *reinterpret_cast<const float4*>(rope + (uint32_t)(L.c.pos0 + rt[i]) * (uint32_t)hd2 + (dd >> 1));   // rt is clamped: always in range
+        }
 #pragma unroll
         for (int i = 0; i < C::MI; ++i) {
             if (!rok[i]) continue;
@@ -264,7 +283,7 @@ __global__ __launch_bounds__(256) void qkv_rope_kernel(const QkvLaunch L) {
             const uint32_t bh = (uint32_t)(rb[i] * H + h);
             if (part < 2) {
                 // (xe + i xo)(c + i s): even' = xe c - xo s ; odd' = xe s + xo c   (fp32, before rounding)
-                const float4 cs = *reinterpret_cast<const float4*>(rope + (uint32_t)pos * (uint32_t)hd2 + (dd >> 1));   // two (cos, sin) pairs
+                const float4 cs = csr[i];   // two (cos, sin) pairs
                 const float o[4] = {v[0] * cs.x - v[1] * cs.y, v[0] * cs.y + v[1] * cs.x, v[2] * cs.z - v[3] * cs.w, v[2] * cs.w + v[3] * cs.z};
                 if (part == 0) {
                     const float sc = L.c.q_scale;

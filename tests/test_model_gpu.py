@@ -171,6 +171,32 @@ def test_causality_and_prefix_consistency():
     assert rel_l2(c.cpu().numpy(), a[:, :50].cpu().numpy()) < 1e-5
 
 
+def test_cfg2_full_size_causality_and_prefix_bf16():
+    """The same size-independent properties at BASELINE.json configs[1] (E=256, H=8, F=3, T=2024, B=1) in bf16, i.e. through the plan bench.py
+    times (fused launches, graph replay included): a perturbation at step 1500 leaves every earlier output bit-identical and changes later ones;
+    the forward of the 1000-step prefix equals the prefix of the forward within the bf16 tolerance; the graph replay equals the plain replay bitwise, and so do 25 further replays."""
+    g = load_golden("cfg2_shape")
+    cfg = cfg_from_meta(g["cfg"])
+    m = build(cfg, "bf16")
+    x, _, ib = recipe_inputs(1, 2024, cfg, seed=int(g["seed"]))
+    x, ib = x.cuda().contiguous(), ib.cuda().contiguous()
+    with torch.no_grad():
+        a = m(x, ib).clone()
+        names = [r.name for r in m.engine().plan(1, 2024, "full").records]
+        assert "mlp.fc1_ln_gelu" in names and "cross0.tail" in names and "cross.down_norm_old" in names   # the plan of the bench line
+        x2 = x.clone()
+        x2[:, 1500] += 1.0
+        b = m(x2, ib).clone()
+        c = m(x[:, :1000].contiguous(), ib[:, :1000].contiguous()).clone()
+        gr = m.engine().forward_graphed(x, ib).clone()
+    assert torch.equal(a[:, :1500], b[:, :1500]) and not torch.equal(a[:, 1500:], b[:, 1500:])
+    assert rel_l2(c.cpu().numpy(), a[:, :1000].cpu().numpy()) < BF16_TOL
+    assert torch.equal(gr, a)
+    with torch.no_grad():   # run-to-run determinism of the whole plan (this caught a packed-fp32 code path of the QKV + RoPE launch that was not, sea_amd/build.py)
+        for _ in range(25):
+            assert torch.equal(m(x, ib), a)
+
+
 @pytest.mark.parametrize("name", ["rollout8_adaln_f3", "rollout100_ln_f2", "rollout100_ln_f2_e256"])
 def test_rollout_recompute_matches_reference_golden(name):
     from sea_amd.utils.train_utils import relativeMSE, rollout
