@@ -197,6 +197,30 @@ def test_cfg2_full_size_causality_and_prefix_bf16():
             assert torch.equal(m(x, ib), a)
 
 
+@pytest.mark.parametrize("cfg_args,dtype,B,T", [((1, 64, 4, 96, 8, 0, 3, 2, True, "adaln"), "fp32", 2, 90),
+                                                ((2, 128, 4, 160, 8, 0, 3, 2, True, "adaln"), "bf16", 3, 150),
+                                                ((2, 256, 8, 640, 8, 0, 2, 2, False, "ln"), "bf16", 1, 600),
+                                                ((1, 256, 8, 640, 8, 0, 3, 2, True, "adaln"), "fp32", 1, 600),
+                                                ((1, 2048, 8, 64, 8, 0, 2, 2, True, "ln"), "bf16", 1, 40)])
+def test_forward_and_kv_rollout_replays_are_bit_identical(cfg_args, dtype, B, T):
+    """No launch of the inference plans may depend on timing: 20 replays of the forward and a second KV-cache rollout reproduce the first bit for bit
+    (other instantiations than cfg2's: fp32, E = 64 / 128 / 2048, LayerNorm without modulation, two layers, F = 2)."""
+    from sea_amd.utils.train_utils import rollout
+
+    cfg = O.OracleConfig(*cfg_args)
+    m = build(cfg, dtype)
+    x, _, ib = recipe_inputs(B, T, cfg, seed=77)
+    x, ib = x.cuda().contiguous(), ib.cuda().contiguous()
+    with torch.no_grad():
+        a = m(x, ib).clone()
+        for _ in range(20):
+            assert torch.equal(m(x, ib), a)
+        n = min(T, 48)
+        r1 = rollout(m, x[:, :1].contiguous(), ib, n, mode="kv").clone()
+        r2 = rollout(m, x[:, :1].contiguous(), ib, n, mode="kv")
+    assert torch.equal(r1, r2)
+
+
 @pytest.mark.parametrize("name", ["rollout8_adaln_f3", "rollout100_ln_f2", "rollout100_ln_f2_e256"])
 def test_rollout_recompute_matches_reference_golden(name):
     from sea_amd.utils.train_utils import relativeMSE, rollout
