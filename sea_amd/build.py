@@ -25,7 +25,10 @@ FLAGS = (os.environ.get("SEA_EXTRA_FLAGS", "").split()) + ["--offload-arch=gfx95
 # rotation of qkv_rope_kernel<bf16, 64, 64> gave, in about one launch of ten, a wrong value in ONE output column (head column 14 or 30: lanes
 # 48-63, third element of the 4-column piece) of one 16-row block, on identical inputs (tools/determinism_one.py: 0 of 400 replays differ without
 # the packed forms, 34 of 200 with them; the 128x128 instantiation was not affected).  Not understood further; the scalar forms cost nothing measurable.
-FILE_FLAGS = {"gemm.hip": ["-fno-slp-vectorize"]}
+# attention_bwd.hip holds the inverse rotation (unrope) and is built the same way as a precaution (training step 4.13 ms either way); a blanket
+# -fno-slp-vectorize costs 4 % of the cfg2 step (GELU / softmax epilogues), so the other files keep the packed forms and are covered by the
+# replay-determinism tests (tests/test_model_gpu.py).
+FILE_FLAGS = {"gemm.hip": ["-fno-slp-vectorize"], "attention_bwd.hip": ["-fno-slp-vectorize"]}
 
 
 def _hipcc() -> str:
