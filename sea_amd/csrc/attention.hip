@@ -340,6 +340,168 @@ __global__ __launch_bounds__(256 * SPLIT) void attention_fwd_kernel(const SeaAtt
     }
 }
 
+template <typename T>
+__device__ __forceinline__ void unpack16(const uint4& r, float (&o)[ActTraits<T>::EPC]);
+template <>
+__device__ __forceinline__ void unpack16<float>(const uint4& r, float (&o)[4]) {
+    o[0] = __builtin_bit_cast(float, r.x); o[1] = __builtin_bit_cast(float, r.y); o[2] = __builtin_bit_cast(float, r.z); o[3] = __builtin_bit_cast(float, r.w);
+}
+template <>
+__device__ __forceinline__ void unpack16<__bf16>(const uint4& r, float (&o)[8]) {   // bf16 -> f32 is a shift
+    o[0] = __builtin_bit_cast(float, r.x << 16); o[1] = __builtin_bit_cast(float, r.x & 0xffff0000u);
+    o[2] = __builtin_bit_cast(float, r.y << 16); o[3] = __builtin_bit_cast(float, r.y & 0xffff0000u);
+    o[4] = __builtin_bit_cast(float, r.z << 16); o[5] = __builtin_bit_cast(float, r.z & 0xffff0000u);
+    o[6] = __builtin_bit_cast(float, r.w << 16); o[7] = __builtin_bit_cast(float, r.w & 0xffff0000u);
+}
+
+// ---------------------------------------------------------------------------------------------- one query row per (trajectory, head)
+// The KV-cache rollout step (Tq = 1): the tiled kernel above spends a 16-query MFMA tile and a serial walk over all key tiles of one workgroup
+// on a single query.  Here a workgroup of 8 waves owns one (problem, trajectory, head):
+//   phase 1  every thread scores keys tid, tid + 512, ... (q . K[key] in fp32, q pre-scaled), workgroup max and sum, probabilities to LDS;
+//   phase 2  wave w owns head columns d = w, w + 8, ...; a lane walks 8-key vectors of row d of V^T (16-byte loads, consecutive lanes consecutive
+//            vectors) against the probabilities in LDS, then a wave reduction per column.
+// Same visibility rule as above (keys j <= q_pos0 + src_len, j < Tk); probabilities stay fp32 (the tiled kernel rounds them to the MFMA dtype).
+template <typename T, int HD>
+__global__ __launch_bounds__(512) void attention_row_kernel(const SeaAttnParams P) {
+    constexpr int EPC = ActTraits<T>::EPC;                 // elements per 16 bytes
+    constexpr int NW = 8, KPT = 16;                        // keys per thread in phase 1: up to 512 * 16 = 8192 keys
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* red = reinterpret_cast<float*>(smem);           // [2][NW] workgroup max / sum
+    float* prob = red + 2 * NW + 16;                       // [round_up(nk, 8) + 8]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int bh = blockIdx.x, zp = blockIdx.y;
+    const int b = bh / P.H, h = bh - b * P.H;
+    const SeaAttnProblem& pr = P.p[zp];
+    const T* Qg = static_cast<const T*>(pr.Q) + (int64_t)bh * HD;           // Tq = 1
+    const T* Kg = static_cast<const T*>(pr.K) + (int64_t)bh * P.cap * HD;
+    const T* Vg = static_cast<const T*>(pr.Vt) + (int64_t)bh * HD * P.cap;
+    const int vis = P.q_pos0 + P.src_len + 1;
+    const int nk = vis < P.Tk ? vis : P.Tk;                                  // visible keys 0 .. nk-1 (>= 1: key 0 is always visible)
+    float q[HD];
+#pragma unroll
+    for (int c = 0; c < HD / 4; ++c) load4(Qg + c * 4, *reinterpret_cast<float(*)[4]>(q + c * 4));
+    // ---- phase 1: the rows of G keys are requested together (one memory round trip per group; all of a 2048-key cache is one group in bf16)
+    constexpr int CPK = HD * (int)sizeof(T) / 16;          // 16-byte chunks per key row (hd = 8 bf16: one row is exactly 16 bytes)
+    constexpr int G = CPK >= 16 ? 1 : (16 / CPK > 4 ? 4 : 16 / CPK);
+    float sc[KPT];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int j0 = 0; j0 < KPT; j0 += G) {
+        if (j0 * 512 >= nk) break;                         // block-uniform
+        uint4 raw[G][CPK];
+#pragma unroll
+        for (int jj = 0; jj < G; ++jj) {
+            const int key = tid + (j0 + jj) * 512;
+            const uint4* kr = reinterpret_cast<const uint4*>(Kg + (int64_t)(key < nk ? key : nk - 1) * HD);
+#pragma unroll
+            for (int c = 0; c < CPK; ++c) raw[jj][c] = kr[c];
+        }
+#pragma unroll
+        for (int jj = 0; jj < G; ++jj) {
+            const int key = tid + (j0 + jj) * 512;
+            float acc = 0.f;
+#pragma unroll
+            for (int c = 0; c < CPK; ++c) {
+                float kv[EPC];
+                unpack16<T>(raw[jj][c], kv);
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) acc += q[c * EPC + e] * kv[e];
+            }
+            sc[j0 + jj] = key < nk ? acc : -INFINITY;
+            mx = fmaxf(mx, sc[j0 + jj]);
+        }
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    if (lane == 0) red[wave] = mx;
+    __syncthreads();
+    float m = red[0];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) m = fmaxf(m, red[w]);
+    constexpr float LOG2E = 1.4426950408889634f;
+    float ls = 0.f;
+#pragma unroll
+    for (int j = 0; j < KPT; ++j) {
+        const int key = tid + j * 512;
+        if (j * 512 >= nk) break;                          // block-uniform: sc[j] is not set beyond
+        if (key < nk) {
+            const float pv = __builtin_amdgcn_exp2f((sc[j] - m) * LOG2E);
+            prob[key] = pv;
+            ls += pv;
+        }
+    }
+    const int nk8 = (nk + 7) & ~7;
+    if (tid < nk8 - nk) prob[nk + tid] = 0.f;              // the tail of the last 8-key vector
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) ls += __shfl_xor(ls, o);
+    if (lane == 0) red[NW + wave] = ls;
+    __syncthreads();
+    float l = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) l += red[NW + w];
+    const float inv = 1.0f / l;
+    // ---- phase 2
+    const int nvec = nk8 >> 3;
+    T* Og = static_cast<T*>(pr.O) + (int64_t)b * P.ldo + h * HD;              // Tq = 1: row b
+    constexpr int DPW = HD / NW > 0 ? HD / NW : 1;                            // head columns per wave (hd = 8: waves 0..7 take one each)
+    constexpr int VPC = 8 * (int)sizeof(T) / 16;                              // 16-byte chunks per 8-key vector of a V^T row
+    float acc[DPW];
+#pragma unroll
+    for (int i = 0; i < DPW; ++i) acc[i] = 0.f;
+    if (wave * DPW < HD) {
+#pragma unroll 4
+        for (int v = lane; v < nvec; v += 64) {
+            uint4 raw[DPW][VPC];
+#pragma unroll
+            for (int i = 0; i < DPW; ++i) {
+                const uint4* vr = reinterpret_cast<const uint4*>(Vg + (int64_t)(wave * DPW + i) * P.cap + v * 8);
+#pragma unroll
+                for (int c = 0; c < VPC; ++c) raw[i][c] = vr[c];
+            }
+            float pv[8];
+            load4(prob + v * 8, *reinterpret_cast<float(*)[4]>(pv));
+            load4(prob + v * 8 + 4, *reinterpret_cast<float(*)[4]>(pv + 4));
+            const bool tail = v * 8 + 8 > nk;   // last vector: V^T beyond the visible keys is not data (0 * garbage must stay 0)
+#pragma unroll
+            for (int i = 0; i < DPW; ++i) {
+                float vv[8];
+#pragma unroll
+                for (int c = 0; c < VPC; ++c) unpack16<T>(raw[i][c], *reinterpret_cast<float(*)[EPC]>(vv + c * EPC));
+                if (tail) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) vv[e] = v * 8 + e < nk ? vv[e] : 0.f;
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[i] += pv[e] * vv[e];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < DPW; ++i) {
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) acc[i] += __shfl_xor(acc[i], o);
+            if (lane == 0) Og[wave * DPW + i] = from_f32<T>(acc[i] * inv);
+        }
+    }
+    (void)EPC;
+}
+
+template <typename T>
+static bool launch_attention_row(const SeaAttnParams& P, hipStream_t s) {
+    static const int on = []() { const char* e = getenv("SEA_ATTN_ROW"); return e ? atoi(e) : 1; }();  // tuning aid: 0 keeps the tiled kernel
+    if (!on || P.Tq != 1 || P.drop.thr != 0 || P.Tk > 8192 || (P.hd != 8 && P.hd != 16 && P.hd != 32 && P.hd != 64)) return false;
+    for (int i = 0; i < P.n_problems; ++i)
+        if (P.p[i].LSE != nullptr) return false;
+    const dim3 grid(P.B * P.H, P.n_problems), block(512);
+    const int lds = (2 * 8 + 16 + ((P.Tk + 7) & ~7) + 8) * 4;
+    switch (P.hd) {
+        case 8: attention_row_kernel<T, 8><<<grid, block, lds, s>>>(P); break;
+        case 16: attention_row_kernel<T, 16><<<grid, block, lds, s>>>(P); break;
+        case 32: attention_row_kernel<T, 32><<<grid, block, lds, s>>>(P); break;
+        default: attention_row_kernel<T, 64><<<grid, block, lds, s>>>(P); break;
+    }
+    return true;
+}
+
 template <typename T, int SPLIT, bool DROP>
 static int launch_attention_s(const SeaAttnParams& P, hipStream_t s) {
     const dim3 grid((P.Tq + 63) / 64, P.B * P.H, P.n_problems), block(256 * SPLIT);
@@ -363,6 +525,7 @@ static int launch_attention_s(const SeaAttnParams& P, hipStream_t s) {
 template <typename T>
 static int launch_attention(const SeaAttnParams& P, hipStream_t s) {
     // few workgroups per CU and a long key range: split the key tiles of a query tile over two wave groups
+    if (launch_attention_row<T>(P, s)) return 0;
     const long blocks = (long)((P.Tq + 63) / 64) * P.B * P.H * P.n_problems;
     const bool split = blocks <= 1024 && P.Tk >= 256;
     // at most two workgroups per CU: four wave groups per query tile (measured at cfg2: cross-attention 18.3 -> 17.3 us; with 768

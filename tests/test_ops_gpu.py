@@ -223,6 +223,32 @@ def test_attention_decode_and_multiproblem(dtype):
         assert float(Obig[..., : H * hd].abs().max()) == 0
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("hd", [8, 16, 32, 64])
+@pytest.mark.parametrize("q_pos0,src_len,Tk", [(0, 0, 1), (6, 0, 7), (510, 0, 511), (511, 0, 512), (2023, 0, 2024), (100, 3, 104), (100, 3, 90), (5000, 0, 5001)])
+def test_attention_single_query_row_kernel(dtype, hd, q_pos0, src_len, Tk):
+    """The KV-cache step (Tq = 1, no LSE): the one-row kernel (a workgroup per (trajectory, head), fp32 probabilities) against the formula; cache
+    padding and everything past the visible keys poisoned with NaN; keys limited by the causal rule or by Tk, whichever is smaller."""
+    from sea_amd import ops
+
+    B, H = 2, 4
+    cap = (max(Tk, q_pos0 + src_len + 1) + 15) // 8 * 8
+    Q = rnd(B, H, 1, hd, dtype=dtype, scale=hd ** -0.25, seed=260)
+    K = rnd(B, H, cap, hd, dtype=dtype, scale=hd ** -0.25, seed=261)
+    Vt = rnd(B, H, hd, cap, dtype=dtype, seed=262)
+    nk = min(Tk, q_pos0 + src_len + 1)
+    K[:, :, nk:] = float("nan")
+    Vt[:, :, :, nk:] = float("nan")
+    O = torch.full((B, 1, H * hd), float("nan"), device=dev(), dtype=dtype)
+    ops.attention_fwd([dict(Q=Q, K=K, Vt=Vt, O=O)], B, H, hd, 1, Tk, cap, q_pos0, src_len, dtype)
+    Kc, Vc = K.clone(), Vt.clone()
+    Kc[:, :, nk:] = 0
+    Vc[:, :, :, nk:] = 0
+    Oref, _ = attention_ref(Q, Kc, Vc, q_pos0, src_len, Tk)
+    assert torch.isfinite(O.float()).all()
+    assert rel(O.float(), Oref) < tol(dtype, f32=2e-5, bf16=8e-3)
+
+
 def test_attention_softmax_rescale_branch():
     """Force the running max to jump late in the key sequence (cdna guide rule 26): one key far above the others."""
     from sea_amd import ops
