@@ -200,6 +200,86 @@ __global__ __launch_bounds__(256) void gemm_grouped_kernel(const GemmLaunch L) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------- a few rows (KV-cache rollout steps)
+// M <= 16 rows: the tiled kernels above give such a launch to N / 64 workgroups that each walk the whole contraction K-tile by K-tile (fc2 of the
+// cfg2 step: 12 workgroups x 32 dependent K-tiles = 13 us for 3 rows).  Here a workgroup of 4 waves owns 16 output columns of one group, wave w
+// the quarter w of the contraction: EVERY fragment of its quarter — 16 W rows and the (up to 16) A rows, 16 bytes per lane — is requested before
+// the first MFMA (one memory round trip), the four partial 16 x 16 tiles meet in LDS, wave 0 runs the epilogue.  bf16, K % 128 == 0, K <= 2048.
+struct SkinnyLaunch {
+    SeaGemmGroup g[SEA_MAX_GROUPS];
+    int blk_start[SEA_MAX_GROUPS + 1];
+    int n_groups;
+};
+
+__device__ __forceinline__ int find_group_blk(const SkinnyLaunch& launch, int bid) {
+    int gi = 0;
+    while (gi + 1 < launch.n_groups && bid >= launch.blk_start[gi + 1]) ++gi;
+    return gi;
+}
+
+template <int KSTEPS>   // 32-wide contraction steps per wave = K / 128
+__device__ __forceinline__ void skinny_quarter(const __bf16* Arow, const __bf16* Wrow, int k0, f32x4& acc) {
+    uint4 wf[KSTEPS], af[KSTEPS];
+#pragma unroll
+    for (int i = 0; i < KSTEPS; ++i) {
+        wf[i] = *reinterpret_cast<const uint4*>(Wrow + k0 + i * 32);
+        af[i] = *reinterpret_cast<const uint4*>(Arow + k0 + i * 32);
+    }
+#pragma unroll
+    for (int i = 0; i < KSTEPS; ++i) mma16<__bf16>(wf[i], af[i], acc);
+}
+
+__global__ __launch_bounds__(256) void gemm_skinny_kernel(const SkinnyLaunch L) {
+    __shared__ __attribute__((aligned(16))) float red[3][64][4];
+    const int gi = find_group_blk(L, (int)blockIdx.x);
+    const SeaGemmGroup& G = L.g[gi];
+    const int n0 = ((int)blockIdx.x - L.blk_start[gi]) * 16;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int r = lane & 15, g = lane >> 4;
+    const int m = r < G.M ? r : G.M - 1;                  // rows beyond M repeat the last row; their results are never stored
+    const int n = n0 + r < G.N ? n0 + r : G.N - 1;
+    const int kq = G.K >> 2;                              // this wave's quarter of the contraction
+    const __bf16* Arow = static_cast<const __bf16*>(G.A) + (int64_t)m * G.lda + g * 8;
+    const __bf16* Wrow = static_cast<const __bf16*>(G.W) + (int64_t)n * G.ldw + g * 8;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const int k0 = wave * kq;
+    switch (kq >> 5) {   // block-uniform
+        case 2: skinny_quarter<2>(Arow, Wrow, k0, acc); break;
+        case 4: skinny_quarter<4>(Arow, Wrow, k0, acc); break;
+        case 8: skinny_quarter<8>(Arow, Wrow, k0, acc); break;
+        case 16: skinny_quarter<16>(Arow, Wrow, k0, acc); break;
+        default:
+            for (int i = 0; i < (kq >> 5); ++i)
+                mma16<__bf16>(*reinterpret_cast<const uint4*>(Wrow + k0 + i * 32), *reinterpret_cast<const uint4*>(Arow + k0 + i * 32), acc);
+    }
+    if (wave > 0) *reinterpret_cast<float4*>(red[wave - 1][lane]) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    __syncthreads();
+    if (wave > 0) return;
+#pragma unroll
+    for (int w = 0; w < 3; ++w) {
+        const float4 p = *reinterpret_cast<const float4*>(red[w][lane]);
+        acc[0] += p.x; acc[1] += p.y; acc[2] += p.z; acc[3] += p.w;
+    }
+    // this lane: output row r, columns n0 + 4 g .. + 3
+    const int nc = n0 + g * 4;
+    if (r >= G.M || nc >= G.N) return;
+    float v[4] = {acc[0], acc[1], acc[2], acc[3]};
+    if (G.bias != nullptr) {
+        float bv[4];
+        load4(G.bias + nc, bv);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] += bv[q] * G.bias_scale;
+    }
+    if (G.R != nullptr) {
+        float rv[4];
+        load4(G.R + (int64_t)r * G.ldr + nc, rv);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] += rv[q];
+    }
+    if (G.C32 != nullptr) store4(G.C32 + (int64_t)r * G.ldc32 + nc, v[0], v[1], v[2], v[3]);
+    if (G.Cact != nullptr) store4(static_cast<__bf16*>(G.Cact) + (int64_t)r * G.ldcact + nc, v[0], v[1], v[2], v[3]);
+}
+
 // ---------------------------------------------------------------------------------------------- QKV + RoPE epilogue
 template <typename T, int BM, int BN, bool DMA>
 __global__ __launch_bounds__(256) void qkv_rope_kernel(const QkvLaunch L) {
@@ -346,6 +426,28 @@ extern "C" int sea_gemm_grouped(const SeaGemmGroup* groups, int n_groups, int dt
         SEA_REQUIRE((!G.R || G.ldr >= G.N) && (!G.C32 || G.ldc32 >= G.N) && (!G.Cact || G.ldcact >= G.N), "sea_gemm_grouped[%d]: output stride < N", i);
         t128 += (long)((G.M + 127) / 128) * ((G.N + 127) / 128);
         t64 += (long)((G.M + 63) / 64) * ((G.N + 63) / 64);
+    }
+    // a few rows (a KV-cache rollout step): one workgroup per 16 output columns, the contraction split over its four waves
+    static const int skinny_env = []() { const char* e = getenv("SEA_GEMM_SKINNY"); return e ? atoi(e) : 1; }();  // tuning aid: 0 keeps the tiled kernels
+    bool skinny = skinny_env != 0 && dtype == SEA_BF16 && n_silu == 0;
+    for (int i = 0; i < n_groups && skinny; ++i) {
+        const SeaGemmGroup& G = groups[i];
+        skinny = G.M <= 16 && G.n_seg == 1 && G.K % 128 == 0 && G.K <= 2048 && G.act == 0 && G.drop.thr == 0 && G.N % 4 == 0;
+    }
+    if (skinny) {
+        SkinnyLaunch S;
+        memset(&S, 0, sizeof(S));
+        int blocks = 0;
+        for (int i = 0; i < n_groups; ++i) {
+            S.g[i] = groups[i];
+            S.blk_start[i] = blocks;
+            blocks += (groups[i].N + 15) / 16;
+        }
+        S.blk_start[n_groups] = blocks;
+        S.n_groups = n_groups;
+        gemm_skinny_kernel<<<dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream)>>>(S);
+        SEA_CHECK_LAUNCH("sea_gemm_grouped");
+        return SEA_OK;
     }
     // LDS-DMA ring: needs whole K-tiles (128 bytes of K per row per stage) and pays off only on long contractions (its 4 stages
     // cost a workgroup per CU at 128x128; measured: K = 2048 +5 %, K = 256 -20 % against the register-staged double buffer)

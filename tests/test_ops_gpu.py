@@ -80,6 +80,31 @@ def test_gemm_grouped_gelu_multiseg(dtype):
     assert rel(x, ref) < tol(dtype, bf16=1e-5)
 
 
+@pytest.mark.parametrize("M", [1, 3, 16])
+@pytest.mark.parametrize("K,N_", [(128, 256), (256, 2048), (512, 512), (2048, 256), (256, 100), (384, 48)])
+def test_gemm_few_rows_kernel(M, K, N_):
+    """M <= 16 rows in bf16 (the GEMMs of a KV-cache rollout step) run the one-workgroup-per-16-columns kernel with the contraction split over
+    its waves: bias (scaled), in-place fp32 residual, fp32 and bf16 outputs, strided A, three groups of different widths in one launch."""
+    from sea_amd import ops
+
+    dt = torch.bfloat16
+    groups, refs = [], []
+    for i, (k, n) in enumerate(((K, N_), (K, 64), (256, N_))):
+        Abig = rnd(M, 2 * k, dtype=dt, seed=1500 + i)
+        A = Abig[:, k:]
+        W = rnd(n, k, dtype=dt, scale=k ** -0.5, seed=1510 + i)
+        b = rnd(n, seed=1520 + i)
+        x = rnd(M, n, seed=1530 + i)
+        x0 = x.clone()
+        act = torch.full((M, n), float("nan"), device=dev(), dtype=dt)
+        groups.append(dict(A=A, W=W, bias=b, R=x, C32=x, Cact=act, bias_scale=2.0))
+        refs.append(x0 + A.float() @ W.float().t() + 2.0 * b)
+    ops.gemm_grouped(groups, dt)
+    for g_, ref in zip(groups, refs):
+        assert rel(g_["C32"], ref) < 2e-5
+        assert rel(g_["Cact"].float(), ref) < 4e-3
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_gemm_strided_a(dtype):
     from sea_amd import ops
