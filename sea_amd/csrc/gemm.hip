@@ -381,6 +381,85 @@ __global__ __launch_bounds__(256) void qkv_rope_kernel(const QkvLaunch L) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------- QKV + RoPE for a few rows
+// The same split of the contraction over four waves as gemm_skinny_kernel, with the epilogue of qkv_rope_kernel (bias, rotary embedding on q / k,
+// q scale, attention layouts) on the one 16-column block of the workgroup.  M <= 16 rows, bf16, K % 128 == 0, K <= 2048, head dim and the group's
+// column offset multiples of 16 (a block lies inside one head of one of q / k / v).
+struct QkvSkinnyLaunch {
+    SeaQkvGroup g[SEA_MAX_GROUPS];
+    int blk_start[SEA_MAX_GROUPS + 1];
+    int n_groups;
+    SeaQkvCommon c;
+};
+
+__global__ __launch_bounds__(256) void qkv_skinny_kernel(const QkvSkinnyLaunch L) {
+    using T = __bf16;
+    __shared__ __attribute__((aligned(16))) float red[3][64][4];
+    int gi = 0;
+    while (gi + 1 < L.n_groups && (int)blockIdx.x >= L.blk_start[gi + 1]) ++gi;
+    const SeaQkvGroup& G = L.g[gi];
+    const int n0 = ((int)blockIdx.x - L.blk_start[gi]) * 16;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int r = lane & 15, g = lane >> 4;
+    const int m = r < G.M ? r : G.M - 1;
+    const int nr = n0 + r < G.N ? n0 + r : G.N - 1;
+    const int kq = G.K >> 2;
+    const T* Arow = static_cast<const T*>(G.A) + (int64_t)m * G.lda + g * 8;
+    const T* Wrow = static_cast<const T*>(G.W) + (int64_t)nr * G.ldw + g * 8;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const int k0 = wave * kq;
+    switch (kq >> 5) {   // block-uniform
+        case 2: skinny_quarter<2>(Arow, Wrow, k0, acc); break;
+        case 4: skinny_quarter<4>(Arow, Wrow, k0, acc); break;
+        case 8: skinny_quarter<8>(Arow, Wrow, k0, acc); break;
+        case 16: skinny_quarter<16>(Arow, Wrow, k0, acc); break;
+        default:
+            for (int i = 0; i < (kq >> 5); ++i)
+                mma16<T>(*reinterpret_cast<const uint4*>(Wrow + k0 + i * 32), *reinterpret_cast<const uint4*>(Arow + k0 + i * 32), acc);
+    }
+    if (wave > 0) *reinterpret_cast<float4*>(red[wave - 1][lane]) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    __syncthreads();
+    if (wave > 0) return;
+#pragma unroll
+    for (int w = 0; w < 3; ++w) {
+        const float4 p = *reinterpret_cast<const float4*>(red[w][lane]);
+        acc[0] += p.x; acc[1] += p.y; acc[2] += p.z; acc[3] += p.w;
+    }
+    const int n = n0 + g * 4;                             // this lane: row r, columns n .. n + 3 of the group
+    if (r >= G.M || n >= G.N) return;
+    const int H = L.c.H, hd = L.c.hd, Tlen = L.c.T, cap = L.c.cap;
+    const int Ea = H * hd, hd2 = hd >> 1;
+    float v[4] = {acc[0], acc[1], acc[2], acc[3]};
+    if (G.bias != nullptr) {
+        float bv[4];
+        load4(G.bias + n, bv);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] += bv[q];
+    }
+    const int nb = G.col0 + n0;                           // first column of the block in the virtual [q | k | v] row (block-uniform)
+    const int part = nb >= 2 * Ea ? 2 : (nb >= Ea ? 1 : 0);
+    const int hb = nb - part * Ea;
+    const int h = hb / hd;
+    const int dd = hb - h * hd + g * 4;
+    const int bidx = r / Tlen, tt = r - bidx * Tlen, pos = L.c.pos0 + tt;
+    const uint32_t bh = (uint32_t)(bidx * H + h);
+    if (part < 2) {
+        const float4 cs = *reinterpret_cast<const float4*>(reinterpret_cast<const float2*>(L.c.rope) + (uint32_t)pos * (uint32_t)hd2 + (dd >> 1));
+        const float o[4] = {v[0] * cs.x - v[1] * cs.y, v[0] * cs.y + v[1] * cs.x, v[2] * cs.z - v[3] * cs.w, v[2] * cs.w + v[3] * cs.z};
+        if (part == 0) {
+            const float sc = L.c.q_scale;
+            store4(static_cast<T*>(G.Qout) + ((bh * (uint32_t)Tlen + tt) * (uint32_t)hd + dd), o[0] * sc, o[1] * sc, o[2] * sc, o[3] * sc);
+        } else {
+            store4(static_cast<T*>(G.Kout) + ((bh * (uint32_t)cap + pos) * (uint32_t)hd + dd), o[0], o[1], o[2], o[3]);
+        }
+    } else {
+        T* dst = static_cast<T*>(G.Vtout) + ((bh * (uint32_t)hd + dd) * (uint32_t)cap + pos);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) dst[(uint32_t)q * (uint32_t)cap] = from_f32<T>(v[q]);
+        if (G.Vout != nullptr) store4(static_cast<T*>(G.Vout) + ((bh * (uint32_t)cap + pos) * (uint32_t)hd + dd), v[0], v[1], v[2], v[3]);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------- host side
 template <typename K>
 static int set_lds(K kernel, int bytes) {
@@ -542,6 +621,26 @@ extern "C" int sea_qkv_rope_grouped(const SeaQkvGroup* groups, int n_groups, con
                     "sea_qkv_rope_grouped[%d]: attention tensors too large for 32-bit element offsets", i);
         t128 += (long)((G.M + 127) / 128) * ((G.N + 127) / 128);
         t64 += (long)((G.M + 63) / 64) * ((G.N + 63) / 64);
+    }
+    // a few rows (a KV-cache rollout step): one workgroup per 16-column block, the contraction split over its four waves
+    static const int skinny_env = []() { const char* e = getenv("SEA_GEMM_SKINNY"); return e ? atoi(e) : 1; }();
+    bool skinny = skinny_env != 0 && dtype == SEA_BF16 && c.hd % 16 == 0;
+    for (int i = 0; i < n_groups && skinny; ++i) skinny = groups[i].M <= 16 && groups[i].K % 128 == 0 && groups[i].K <= 2048 && groups[i].col0 % 16 == 0 && groups[i].N % 16 == 0;
+    if (skinny) {
+        QkvSkinnyLaunch S;
+        memset(&S, 0, sizeof(S));
+        int blocks = 0;
+        for (int i = 0; i < n_groups; ++i) {
+            S.g[i] = groups[i];
+            S.blk_start[i] = blocks;
+            blocks += groups[i].N / 16;
+        }
+        S.blk_start[n_groups] = blocks;
+        S.n_groups = n_groups;
+        S.c = c;
+        qkv_skinny_kernel<<<dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream)>>>(S);
+        SEA_CHECK_LAUNCH("sea_qkv_rope_grouped");
+        return SEA_OK;
     }
     bool dma = true;
     for (int i = 0; i < n_groups; ++i) dma = dma && (groups[i].K % (dtype == SEA_BF16 ? 64 : 32) == 0) && groups[i].K >= 1024;

@@ -131,7 +131,8 @@ def rope_table(hd, n):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("B,T,H,hd,pos0,cap", [(2, 100, 8, 32, 0, 104), (1, 2024, 8, 32, 0, 2024), (3, 1, 4, 16, 5, 16), (2, 9, 4, 8, 0, 16)])
+@pytest.mark.parametrize("B,T,H,hd,pos0,cap", [(2, 100, 8, 32, 0, 104), (1, 2024, 8, 32, 0, 2024), (3, 1, 4, 16, 5, 16), (2, 9, 4, 8, 0, 16),
+                                                (3, 1, 8, 32, 5, 16), (1, 1, 8, 16, 100, 104), (2, 4, 8, 32, 7, 16), (16, 1, 8, 32, 2023, 2024)])   # the last four: the few-row kernel in bf16
 def test_qkv_rope_self(dtype, B, T, H, hd, pos0, cap):
     from sea_amd import ops
 
@@ -160,10 +161,11 @@ def test_qkv_rope_self(dtype, B, T, H, hd, pos0, cap):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-def test_qkv_rope_cross_groups(dtype):
+@pytest.mark.parametrize("B,T", [(2, 50), (3, 1), (2, 5)])
+def test_qkv_rope_cross_groups(dtype, B, T):
     from sea_amd import ops
 
-    B, T, H, hd = 2, 50, 8, 16
+    H, hd = 8, 16
     D = H * hd
     M = B * T
     xi, xj = rnd(M, D, dtype=dtype, seed=50), rnd(M, D, dtype=dtype, seed=51)
