@@ -1,29 +1,34 @@
 """Benchmark of the SEA temporal-rollout hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W
-    (N > 1: launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`, one rank per GPU)
+    python bench.py --gpus N --steps K --warmup W          (N > 1: the parent starts N rank processes itself, one per GPU, before any GPU call;
+                                                            under `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N` it is a rank)
 
-Workload (BASELINE.json configs[1], "cfg2"): TemporalModel(1 layer, embed_dim 256, 8 heads, max_len 2024, scale_ratio 8,
-3 field groups, AdaLN, SEA exchange), synthetic cylinder_flow-shaped encoded fields x ~ N(0,1) [B, 2024, 3, 256] with one
-scalar condition per step, random-init weights (reference init N(0,0.02), seed 42), bf16 compute.
-One STEP = one full-context forward of the model over the 2024-step window = one iteration of the reference's rollout loop
-(utils/train_utils.py:203-207) at prefix length 2024 in its own recompute mode; it advances every trajectory of the batch by
-one time step.  value = trajectory-steps per second over all GPUs (weak scaling: B trajectories per GPU, no collective —
-rollout shards by trajectory).  The K timed steps replay the step's captured HIP graph.
+Model (BASELINE.json configs[1..3], "cfg2" / "cfg3" / "cfg4"): TemporalModel(1 layer, embed_dim 256, 8 heads, max_len 2024, scale_ratio 8, 3 field
+groups, AdaLN, SEA exchange), synthetic cylinder_flow-shaped encoded fields x ~ N(0,1) [B, 2024, 3, 256] with one scalar condition per step,
+random-init weights (reference init N(0, 0.02), seed 42), bf16 compute.
 
-Extra objects in the JSON line:
-  roofline     — the dominant kernel of the step (largest share of device time): algorithmic FLOPs of one launch divided
-                 by its average launch duration, measured here with HIP events on the launch stream around every launch of
-                 the plan (a separate instrumented pass of the same K steps), against the dense bf16 MFMA peak (2.5 PFLOP/s,
-                 MI355X_MICROARCH.md).  traffic: HBM bytes per launch from rocprofv3 PMC passes when profiles/ holds them, else null.
-  cpu_baseline — the CPU oracle (oracle/sea_oracle.py, a restatement of the reference pinned by its golden vectors) timed on
-                 this host's cores on the same workload (bounded sample: 1 warm-up + 3 forwards), rank 0, N = 1 only.
+ONE JSON line.  Its legs (all measured inside the driver-timed run):
+  rollout  cfg2: one STEP = one full-context forward over the 2024-step window = one iteration of the reference's rollout loop
+           (utils/train_utils.py:203-207) at prefix length 2024 in its own recompute mode; B = 1 trajectory per GPU; the K timed steps replay
+           the step's captured HIP graph.  N = 1: this is the headline (`value` = trajectory-steps/s).
+  train    cfg3 / cfg4: fwd + MSE + bwd + fused AdamW (train/train_temporal.py:254-258), B = 8 trajectories per GPU, T = 2024; N > 1: replicated
+           model, the batch split by rank, ONE all-reduce of the flat fp32 gradient per step (RCCL), the 1/world mean folded into AdamW.
+           N > 1: this is the headline (`value` = trajectory-steps/s over all GPUs), with the all-reduce timed on its own and a single-GPU
+           step of the same processes beside it.
+  kv       exact KV-cache rollouts: 2024 steps of the cfg2 model, and a cfg5-shaped one (multiphase structure: F = 2, LayerNorm, 100 steps).
+  cpu_baseline (N = 1, rank 0): the CPU oracle (oracle/sea_oracle.py, pinned by the reference's golden vectors) on this host's cores: forward,
+           forward + backward + AdamW (1 warm-up + 1 pass), 8- and 100-step recompute rollouts.
+  roofline the dominant launch of the headline leg: algorithmic FLOPs (and bytes) of ONE launch, derived from the launch's own argument
+           structs, over its duration measured with HIP events on the launch stream (20 back-to-back launches in one captured graph); the
+           MFMA roof is the headline (`frac`), the HBM-side figures are beside it (`hbm_frac`).
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -33,6 +38,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA, MI355X (MI355X_MICROARCH.md "Chip-level parameters")
+PEAK_HBM_GBPS = 8000.0
+CFG = dict(L=1, E=256, H=8, max_len=2024, sr=8, src=0, F=3)
 
 
 def algorithmic_gflop(B, T, F, E, H, D, S, L, adaln=True):
@@ -45,66 +52,50 @@ def algorithmic_gflop(B, T, F, E, H, D, S, L, adaln=True):
     return (L * per_layer + F * A(E)) / 1e9
 
 
-def kernel_flops(name, B, T, F, E, H, D, S):
-    """Algorithmic FLOPs of ONE launch of the named plan record (per launch, all groups of the launch)."""
-    M = B * T
-    tri = T * (T + 1) // 2
-    per_field = 1
-    if len(name) > 3 and name[-3:-1] == ".f" and name[-1].isdigit():  # per-field launch of the lane plan ("mlp.fc1.f0")
-        name, per_field = name[:-3], F
-    if name == "adaln.cond_gemm.first":
-        return 2 * M * F * (2 * E) ** 2
-    if name == "adaln.cond_gemm.rest":
-        return 2 * M * (2 * F * (2 * E) ** 2 + F * (2 * D) ** 2)
-    if per_field > 1:
-        return kernel_flops(name, B, T, F, E, H, D, S) // per_field
-    table = {
-        "adaln.cond_gemm": 2 * M * ((2 * F + F) * (2 * E) ** 2 + F * (2 * D) ** 2),
-        "adaln.cond_mlp": 2 * M * ((2 * F + F) * (2 * E) ** 2 + F * (2 * D) ** 2),   # cond_mlp.2 of the 12 modules (the silu rows are not counted)
-        "self.qkv_rope": F * 2 * M * E * 3 * E,
-        "self.attention": F * 4 * B * tri * E,
-        "self.out_proj": F * 2 * M * E * E,
-        "cross.down_old": F * 2 * M * E * D,
-        "cross.down_norm_old": F * 2 * M * E * D,
-        "add.down_norm": F * 2 * M * E * D,
-        "add.up": F * 2 * M * E * D,
-        "mlp.fc1": F * 2 * M * E * S,
-        "mlp.fc1_ln_gelu": F * 2 * M * E * S,
-        "mlp.fc2": F * 2 * M * E * S,
-        "proj": F * 2 * M * E * E,
-    }
-    if name in table:
-        return table[name]
-    # fused plan (sea_rowchain launches): the Linear layers each chain contains
-    kv_old = F * (F - 1) // 2  # pairs (iq, i), iq < i: k/v projections of the old x_i; the other half reads the new x_i
-    fused = {
-        "self.adaln0_qkv": F * 2 * M * E * 3 * E,
-        "self.proj_down_qkv": F * (2 * M * E * E + 2 * M * E * D) + F * (F - 1) * 2 * M * D * D + kv_old * 2 * M * D * 2 * D,
-        "proj_final_norm": F * 2 * M * E * E,
-        "proj_adaln0_qkv": F * (2 * M * E * E + 2 * M * E * 3 * E),
-        "mlp.fused": F * 4 * M * E * S,
-    }
-    if name in fused:
-        return fused[name]
-    if name.startswith("cross") and name.endswith("proj_up_down_kv"):
-        i = int(name[5:name.index(".")])
-        return (F - 1) * (2 * M * D * D) + 2 * M * D * E + (2 * M * E * D + (F - 1 - i) * 2 * M * D * 2 * D if i < F - 1 else 0)
-    if name.startswith("cross") and name.endswith("qkv_rope"):
-        return (F - 1) * 2 * M * D * 3 * D
-    if name.startswith("cross") and name.endswith("attention"):
-        return (F - 1) * 4 * B * tri * D
-    if name.startswith("cross") and name.endswith("proj_gelu"):
-        return (F - 1) * 2 * M * D * D
-    if name.startswith("cross") and name.endswith("up_sum"):
-        return (F - 1) * 2 * M * D * E
-    if name.startswith("cross") and (name.endswith("down_new") or name.endswith("down_norm_new")):
-        return 2 * M * E * D
-    if name.startswith("cross") and name.endswith(".tail"):
-        i = int(name[5:name.index(".")])
-        return (F - 1) * (2 * M * D * D + 2 * M * D * E) + (2 * M * E * D if i < F - 1 else 0)
-    if name.startswith("cross") and name.endswith("up_sum_ib_adaln2"):
-        return (F - 1) * 2 * M * D * E
-    return 0
+def record_work(rec, esz):
+    """(algorithmic FLOPs, algorithmic HBM bytes) of ONE launch of a plan record, from the launch's own argument structs: matrix products count
+    2mnk (causal attention over the visible pairs only), operands / weights / outputs are counted once."""
+    from sea_amd import _native as N
+
+    L = N.lib()
+    fl = by = 0
+    a = rec.args
+    if rec.fn is L.sea_gemm_grouped:
+        for g in a[0][:a[1]]:
+            fl += 2 * g.M * g.N * g.K * g.n_seg
+            by += (0 if g.silu_c else g.M * g.K * g.n_seg * esz) + g.N * g.K * esz + (g.M * g.N * 4 if g.C32 else 0) + (g.M * g.N * esz if g.Cact else 0) \
+                + (g.M * g.N * 4 if g.R else 0) + (g.M * g.N * esz if g.Z else 0)
+    elif rec.fn is L.sea_qkv_rope_grouped:
+        for g in a[0][:a[1]]:
+            fl += 2 * g.M * g.N * g.K
+            by += g.M * g.K * esz + g.N * g.K * esz + g.M * g.N * esz
+    elif rec.fn is L.sea_gemm_rownorm:
+        for g in a[0][:a[1]]:
+            fl += 2 * g.M * g.N * g.K * g.n_seg
+            by += g.M * g.K * g.n_seg * esz + g.N * g.K * esz + (g.M * g.N * esz if g.Yact else 0) + (g.M * g.N * 4 if g.Y32 else 0) + (g.M * 2 * g.N * esz if g.mod else 0)
+    elif rec.fn is L.sea_mlp_fc1_ln_gelu:
+        for g in a[0][:a[1]]:
+            fl += 2 * g.M * g.E * g.S
+            by += g.M * g.E * esz + g.S * g.E * esz + 3 * g.S * 4 + g.M * g.S * esz
+    elif rec.fn is L.sea_exchange_tail:
+        for g in rec.keep[:a[1]]:
+            fl += g.n_seg * 2 * g.M * g.D * g.D * (0 if g.plain else 1) + 2 * g.M * g.D * g.E + (2 * g.M * g.E * g.D if g.has_down else 0)
+            by += g.n_seg * (g.M * g.D * esz + g.D * g.D * esz) + g.D * g.E * esz + 2 * g.M * g.E * 4 + (g.E * g.D * esz + g.M * g.D * esz if g.has_down else 0)
+    elif rec.fn is L.sea_attention_fwd:
+        P = rec.keep
+        tri = P.Tq * (P.Tq + 1) // 2 + P.Tq * (P.Tk - P.Tq)
+        fl = P.n_problems * 4 * P.B * P.H * tri * P.hd
+        by = P.n_problems * P.B * P.H * (2 * P.Tq + 2 * P.Tk) * P.hd * esz
+    elif rec.fn is L.sea_attention_bwd:
+        P = rec.keep
+        tri = P.Tq * (P.Tq + 1) // 2
+        fl = P.n_problems * 10 * P.B * P.H * tri * P.hd          # S, dP, dV, dK, dQ: five products where the forward has two
+        by = P.n_problems * P.B * P.H * 8 * P.Tq * P.hd * esz
+    elif rec.fn is L.sea_wgrad_grouped:
+        for g in a[0][:a[1]]:
+            fl += 2 * g.M * g.N * g.K
+            by += g.M * (g.N + g.K) * esz + g.N * g.K * 4
+    return fl, by
 
 
 def log(msg):
@@ -135,66 +126,296 @@ def host_cores() -> int:
     return min(n, 64)
 
 
-def cpu_baseline(cfg_args, B, T):
-    """Oracle forward on the host cores (bounded: 1 warm-up + 3 timed forwards at the bench shape)."""
-    from oracle import sea_oracle as O
-
-    L, E, H, max_len, sr, src, F = cfg_args
-    cfg = O.OracleConfig(L, E, H, max_len, sr, src, F, 2, True, "adaln")
+# ------------------------------------------------------------------------------------------------------------------ CPU baseline
+def _oracle_params(cfg):
     from oracle.recipe import param_schema
 
     g = torch.Generator().manual_seed(42)
     p = {}
     for k, (shp, kind) in param_schema(cfg).items():
-        if kind == "lin_w":
-            p[k] = torch.randn(shp, generator=g) * 0.02
-        elif kind == "norm_w":
-            p[k] = torch.ones(shp)
-        else:
-            p[k] = torch.zeros(shp)
-    x = torch.randn(B, T, F, E, generator=torch.Generator().manual_seed(1234))
+        p[k] = torch.randn(shp, generator=g) * 0.02 if kind == "lin_w" else (torch.ones(shp) if kind == "norm_w" else torch.zeros(shp))
+    return p
+
+
+def cpu_baseline(B, T):
+    """The CPU oracle on the host cores, bounded (about 30 s): forward (1 warm-up + 3 passes), forward + backward + AdamW (1 warm-up + 1 pass,
+    train/train_temporal.py:254-258), and the reference's recompute rollouts of 8 and 100 steps (utils/train_utils.py:202-209), B = 1, fp32."""
+    from oracle import sea_oracle as O
+
+    c = CFG
+    cfg = O.OracleConfig(c["L"], c["E"], c["H"], c["max_len"], c["sr"], c["src"], c["F"], 2, True, "adaln")
+    p = _oracle_params(cfg)
+    x = torch.randn(B, T, c["F"], c["E"], generator=torch.Generator().manual_seed(1234))
+    tgt = torch.randn(B, T, c["F"], c["E"], generator=torch.Generator().manual_seed(4321))
     ib = torch.rand(B, T, 1, generator=torch.Generator().manual_seed(1235))
     cores = host_cores()
     torch.set_num_threads(cores)
-    log(f"cpu_baseline: oracle forward on {cores} host threads ...")
+    log(f"cpu_baseline: oracle on {cores} host threads: forward ...")
     with torch.no_grad():
         O.model_forward(x, ib, p, cfg)
         n = 3
         t0 = time.perf_counter()
         for _ in range(n):
             O.model_forward(x, ib, p, cfg)
-        dt = (time.perf_counter() - t0) / n
-    return {"value": B / dt, "unit": "trajectory-steps/s", "cores": cores, "kind": "port",
-            "sample": f"oracle fp32 forward, B={B}, T={T}, 1 warm-up + {n} timed passes, {dt:.3f} s/pass, torch CPU threads={cores}"}
+        fwd = (time.perf_counter() - t0) / n
+    log("cpu_baseline: forward + backward + AdamW ...")
+    O.train_steps(x, ib, tgt, p, cfg, 1, lr=1e-4)
+    t0 = time.perf_counter()
+    O.train_steps(x, ib, tgt, p, cfg, 1, lr=1e-4)
+    trn = time.perf_counter() - t0
+    log("cpu_baseline: recompute rollouts (8 and 100 steps) ...")
+    roll = {}
+    with torch.no_grad():
+        O.rollout(x[:, :1], ib, 8, p, cfg)
+        for n_steps in (8, 100):
+            t0 = time.perf_counter()
+            O.rollout(x[:, :1], ib, n_steps, p, cfg)
+            roll[n_steps] = n_steps * B / (time.perf_counter() - t0)
+    return {"value": B / fwd, "unit": "trajectory-steps/s", "cores": cores, "kind": "port",
+            "sample": f"oracle fp32 at the bench shape (B={B}, T={T}): forward 1 warm-up + {n} passes, {fwd:.3f} s/pass; forward+backward+AdamW 1 warm-up + 1 pass; "
+                      f"recompute rollouts of 8 and 100 steps; torch CPU threads={cores}",
+            "forward_s_per_pass": fwd, "train_step_s": trn, "train_trajectory_steps_per_s": B / trn,
+            "rollout8_steps_per_s": roll[8], "rollout100_steps_per_s": roll[100]}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--batch", type=int, default=1, help="trajectories per GPU")
-    ap.add_argument("--seq", type=int, default=2024)
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
-    ap.add_argument("--no-graph", action="store_true", help="replay launch by launch instead of the captured HIP graph")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--mode", default="rollout", choices=["rollout", "train", "kv", "decode", "encode"],
-                    help="rollout: full-context forward step (cfg2, the default metric); train: fwd+bwd+AdamW step (cfg3/cfg4, --batch 8); "
-                         "kv: KV-cache rollout of --seq steps; decode: spatial decoder over a --seq-step rollout (SURVEY.md §8f rank 1); "
-                         "encode: spatial encoder over --seq snapshots (SURVEY.md §8f rank 2)")
-    args = ap.parse_args()
-    if args.mode == "decode":
-        return main_decode(args)
-    if args.mode == "encode":
-        return main_encode(args)
-    if args.mode != "rollout":
-        return main_other(args)
+# ------------------------------------------------------------------------------------------------------------------ helpers
+def _sync_barrier(dist):
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
 
+
+def _timed(step, n_steps, warmup, dist, dev):
+    """W untimed steps, then exactly n_steps between barrier + synchronize on both sides; the MAX over ranks in seconds."""
+    for _ in range(max(warmup, 1)):
+        r = step()
+    _sync_barrier(dist)
+    t0 = time.perf_counter()
+    for _ in range(n_steps):
+        r = step()
+    _sync_barrier(dist)
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    return elapsed, r
+
+
+def _launch_time_ms(rec, reps=20):
+    """Average duration of one launch of a record: `reps` back-to-back launches captured in one graph between two HIP events recorded on the
+    launch stream (no per-launch event or dispatch gap)."""
+    st = torch.cuda.Stream()
+    gk = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(st):
+        with torch.cuda.graph(gk, stream=st):
+            for _ in range(reps):
+                rc = rec.fn(*rec.args, st.cuda_stream)
+                assert rc == 0, rec.name
+    gk.replay()
+    torch.cuda.synchronize()
+    best = 1e30
+    for _ in range(5):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        gk.replay()
+        e1.record()
+        torch.cuda.synchronize()
+        best = min(best, e0.elapsed_time(e1) / reps)
+    return best
+
+
+def _time_list(recs, iters):
+    """[(record, ms)] per record: one HIP event pair per launch on the launch stream (includes a few us of event / dispatch gap each)."""
+    from sea_amd import _native as N
+
+    stream = N.stream_ptr()
+    recs = [r for r in recs if r.fn is not None]
+    tot = [0.0] * len(recs)
+    for _ in range(iters):
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(len(recs) + 1)]
+        evs[0].record()
+        for k, r in enumerate(recs):
+            rc = r.fn(*r.args, stream)
+            assert rc == 0, r.name
+            evs[k + 1].record()
+        torch.cuda.synchronize()
+        for k in range(len(recs)):
+            tot[k] += evs[k].elapsed_time(evs[k + 1])
+    return [(r, t / iters) for r, t in zip(recs, tot)]
+
+
+def _roofline(recs_times, esz, traffic_file=None):
+    """Roofline object of the dominant launch (largest share of device time) of a timed record list."""
+    rec, dom_ms_events = max(recs_times, key=lambda rt: rt[1])
+    dom_ms = _launch_time_ms(rec)
+    fl, by = record_work(rec, esz)
+    tflops = fl / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
+    gbps = by / (dom_ms * 1e-3) / 1e9 if by and dom_ms > 0 else None
+    traffic = traffic_src = None
+    if traffic_file and os.path.exists(traffic_file):
+        e = json.load(open(traffic_file))["launches"].get(rec.name)
+        if e is not None:
+            traffic, traffic_src = e["hbm_bytes"], os.path.relpath(traffic_file, ROOT) + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, bytes per launch)"
+    return {"kernel": rec.name, "bound": "mfma", "achieved": tflops, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": tflops / PEAK_BF16_TFLOPS,
+            "traffic": traffic, "traffic_source": traffic_src,
+            "hbm_GBps": gbps, "hbm_frac": gbps / PEAK_HBM_GBPS if gbps else None, "algorithmic_bytes": by, "flop_per_algorithmic_byte": fl / by if by else None,
+            "machine_balance_flop_per_byte": PEAK_BF16_TFLOPS * 1e12 / (PEAK_HBM_GBPS * 1e9),
+            "launch_ms": dom_ms, "launch_ms_single_event_pair": dom_ms_events, "launch_gflop": fl / 1e9,
+            "device_ms_all_launches": sum(t for _, t in recs_times),
+            "timing": "launch_ms: HIP events on the launch stream around 20 back-to-back launches of the dominant record (one captured graph) / 20"}
+
+
+def build_model(dev, dtype, F=3, ln="adaln", max_len=2024):
+    from sea_amd.models.temporal import TemporalModel
+
+    c = CFG
+    torch.manual_seed(42)
+    m = TemporalModel(c["L"], c["E"], c["H"], max_len, c["sr"], c["src"], F, 2, 0.0, "sea", "learnable", "mlp", "add", 1, 1, True, ln)
+    m.set_compute_dtype(dtype)
+    return m.to(dev)
+
+
+def inputs(B, T, F, E, rank, dev):
+    x = torch.randn(B, T, F, E, generator=torch.Generator().manual_seed(1234 + rank)).to(dev)
+    tgt = torch.randn(B, T, F, E, generator=torch.Generator().manual_seed(4321 + rank)).to(dev)
+    ib = torch.rand(B, T, 1, generator=torch.Generator().manual_seed(1235 + rank)).to(dev)
+    return x, tgt, ib
+
+
+# ------------------------------------------------------------------------------------------------------------------ legs
+def leg_rollout(args, dist, dev, rank, world, steps, warmup, B):
+    c = CFG
+    F, E, H, L, T = c["F"], c["E"], c["H"], c["L"], args.seq
+    D, S = E // 2, E * c["sr"]
+    model = build_model(dev, args.dtype).eval()
+    x, _, ib = inputs(B, T, F, E, rank, dev)
+    eng = model.engine(dev)
+    step = (lambda: eng.forward(x, ib)) if args.no_graph else (lambda: eng.forward_graphed(x, ib))
+    log(f"rollout leg: cfg2 forward, B={B} per GPU, {'plain' if args.no_graph else 'hip-graph'} replay, {steps} timed steps")
+    with torch.no_grad():
+        elapsed, out = _timed(step, steps, warmup, dist, dev)
+        assert torch.isfinite(out).all()
+        plan = eng.plan(B, T, "full")
+        plan.bind(x, ib, torch.empty_like(x))
+        plan.run()
+        torch.cuda.synchronize()
+        times = _time_list(plan.records, iters=10)
+        esz = 2 if args.dtype == "bf16" else 4
+        pmc = os.path.join(ROOT, "profiles", "r02_forward_cfg2_pmc_traffic.json") if (B, T, args.dtype) == (1, 2024, "bf16") else None
+        roof = _roofline(times, esz, pmc)
+    ms = elapsed / steps * 1e3
+    gflop = algorithmic_gflop(B, T, F, E, H, D, S, L)
+    return {"value": world * B * steps / elapsed, "unit": "trajectory-steps/s", "ms_per_step": ms, "steps": steps,
+            "workload": f"cfg2: cylinder_flow temporal model E={E} H={H} F={F} L={L} adaln, forward-only rollout step at T={T} (recompute mode), B={B} per GPU",
+            "replay": "plain" if args.no_graph else "hip-graph", "model_algorithmic_gflop_per_step": gflop,
+            "model_mfma_frac": gflop / (ms * 1e-3) / 1e3 / PEAK_BF16_TFLOPS, "n_launches": len(times),
+            "roofline": roof, "launch_breakdown_ms": {r.name: round(t, 4) for r, t in times}}
+
+
+def leg_train(args, dist, dev, rank, world, steps, warmup, B):
+    from sea_amd.utils.train_utils import initialize_optimizer
+
+    c = CFG
+    F, E, H, L, T = c["F"], c["E"], c["H"], c["L"], args.seq
+    D, S = E // 2, E * c["sr"]
+    model = build_model(dev, args.dtype).train()
+    x, tgt, ib = inputs(B, T, F, E, rank, dev)
+    eng = model.engine(dev)
+    opt = initialize_optimizer(model, {"learning_rate": 1e-4})
+    single_ms = None
+    if dist is not None:
+        # the same step without the collective, on every rank at once: the single-GPU figure the data-parallel one is compared with
+        for _ in range(3):
+            eng.train_step(x, tgt, ib, opt, allreduce=False)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(10):
+            eng.train_step(x, tgt, ib, opt, allreduce=False)
+        torch.cuda.synchronize()
+        single_ms = (time.perf_counter() - t0) / 10 * 1e3
+        from sea_amd.parallel import broadcast_parameters
+
+        broadcast_parameters(eng.params.flat32)      # the ranks drifted apart in those local steps: start the timed run in sync
+        eng.params.sync(force=True)
+        eng.params.sync_transposed(force=True)
+    log(f"train leg: cfg3/cfg4 fwd+bwd+AdamW, B={B} per GPU, world {world}, {steps} timed steps")
+    elapsed, loss = _timed(lambda: eng.train_step(x, tgt, ib, opt), steps, warmup, dist, dev)
+    assert torch.isfinite(loss).all()
+    ms = elapsed / steps * 1e3
+    gflop = 3 * algorithmic_gflop(B, T, F, E, H, D, S, L)
+    out = {"value": world * B * steps / elapsed, "unit": "trajectory-steps/s", "train_steps_per_s": steps / elapsed, "ms_per_step": ms, "steps": steps,
+           "workload": f"cfg{'3' if world == 1 else '4'}: cylinder_flow temporal model E={E} H={H} F={F} L={L} adaln, fwd+bwd+AdamW (teacher-forced, T={T}), B={B} per GPU, "
+                       f"global batch {world * B}",
+           "parallelism": f"dp{world}: replicated model, batch split by rank, one flat-gradient all-reduce per step (RCCL), 1/world folded into AdamW",
+           "world_size": world, "model_algorithmic_gflop_per_step": gflop, "model_mfma_frac": gflop / (ms * 1e-3) / 1e3 / PEAK_BF16_TFLOPS}
+    if dist is not None:
+        from sea_amd.parallel import parameters_in_sync
+
+        g = eng.grads[:eng.params.n_live]
+        _sync_barrier(dist)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            dist.all_reduce(g, op=dist.ReduceOp.SUM)
+        e1.record()
+        torch.cuda.synchronize()
+        ar_ms = e0.elapsed_time(e1) / 10
+        out.update({"allreduce_ms": ar_ms, "allreduce_bytes": g.numel() * g.element_size(), "allreduce_dtype": str(g.dtype).replace("torch.", ""),
+                    "allreduce_busbw_GBps": g.numel() * g.element_size() * 2 * (world - 1) / world / (ar_ms * 1e-3) / 1e9,
+                    "backend": "nccl (RCCL)", "single_gpu_ms_per_step": single_ms, "dp_efficiency_vs_single_gpu_step": single_ms / ms,
+                    "parameters_in_sync_after_run": parameters_in_sync(eng.params.flat32)})
+    # per-launch breakdown of forward + backward, rank-local
+    plan = eng.train_plan(B, T)
+    esz = 2 if args.dtype == "bf16" else 4
+    times = _time_list(list(plan.records) + list(plan.bwd), iters=3)
+    out["roofline"] = _roofline(times, esz)
+    out["n_launches"] = len(times)
+    out["top_launches_ms"] = {r.name: round(t, 4) for r, t in sorted(times, key=lambda rt: -rt[1])[:12]}
+    return out
+
+
+def leg_kv(args, dev, rank):
+    from sea_amd.utils.train_utils import rollout
+
+    c = CFG
+    out = {}
+    for key, F, ln, n_steps, reps in (("cfg2_2024_steps", 3, "adaln", args.seq, 3), ("cfg5_shape_100_steps_F2_ln", 2, "ln", 100, 20)):
+        model = build_model(dev, args.dtype, F=F, ln=ln).eval()
+        x, _, ib = inputs(1, max(n_steps, 1), F, c["E"], rank, dev)
+        x0 = x[:, :1].contiguous()
+        for _ in range(2):
+            r = rollout(model, x0, ib, n_steps, mode="kv")
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            r = rollout(model, x0, ib, n_steps, mode="kv")
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / reps
+        assert torch.isfinite(r).all()
+        out[key] = {"steps_per_s": n_steps / dt, "ms_per_step": dt / n_steps * 1e3, "rollout_ms": dt * 1e3,
+                    "workload": f"exact KV-cache rollout of {n_steps} steps, B=1, E={c['E']} H={c['H']} F={F} L=1 {ln}"}
+        if n_steps <= 100:   # the reference-equivalent recompute rollout of the same length beside it
+            for _ in range(2):
+                rollout(model, x0, ib, n_steps, mode="recompute")
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(3):
+                rollout(model, x0, ib, n_steps, mode="recompute")
+            torch.cuda.synchronize()
+            out[key]["recompute_steps_per_s"] = n_steps / ((time.perf_counter() - t0) / 3)
+        del model
+    return out
+
+
+# ------------------------------------------------------------------------------------------------------------------ rank body
+def run_rank(args):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus} (WORLD_SIZE={world})")
+    if args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no GPU visible (the product path has no CPU fallback)")
     torch.cuda.set_device(local_rank)
@@ -206,225 +427,101 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist_mod.init_process_group("nccl", device_id=dev)
         dist = dist_mod
-
-    from sea_amd.models.temporal import TemporalModel
-
-    L, E, H, max_len, sr, src, F = 1, 256, 8, 2024, 8, 0, 3
-    B, T = args.batch, args.seq
-    D, S = E // 2, E * sr
-    torch.manual_seed(42)
-    model = TemporalModel(L, E, H, max_len, sr, src, F, 2, 0.0, "sea", "learnable", "mlp", "add", 1, 1, True, "adaln")
-    model.set_compute_dtype(args.dtype)
-    model = model.to(dev).eval()
-    x = torch.randn(B, T, F, E, generator=torch.Generator().manual_seed(1234 + rank)).to(dev)
-    ib = torch.rand(B, T, 1, generator=torch.Generator().manual_seed(1235 + rank)).to(dev)
-    eng = model.engine(dev)
-
-    def step():
-        return eng.forward(x, ib) if args.no_graph else eng.forward_graphed(x, ib)
-
-    log(f"model built on {dev}; warm-up ({args.warmup} steps, {'plain' if args.no_graph else 'hip-graph'} replay)")
-    with torch.no_grad():
-        for _ in range(max(args.warmup, 1)):
-            out = step()
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            out = step()
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-        elapsed = time.perf_counter() - t0
-    if dist is not None:
-        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
-    assert torch.isfinite(out).all()
-
-    log(f"timed {args.steps} steps in {elapsed:.4f} s; per-launch event timing ...")
-    # ---- per-launch device times (HIP events on the launch stream), same number of steps
-    with torch.no_grad():
-        plan = eng.plan(B, T, "full")
-        plan.bind(x, ib, torch.empty_like(x))
-        plan.run()
-        torch.cuda.synchronize()
-        times = plan.time_records(iters=max(args.steps, 5))
-    total_ms = sum(t for _, t in times)
-    name, dom_ms_events = max(times, key=lambda nt: nt[1])
-    # the dominant launch alone, 20 back-to-back launches captured in one graph between two HIP events on the launch stream: the per-launch
-    # figure then carries no event / launch-gap overhead and is the one to compare with rocprofv3's average duration of that kernel
-    rec = next(r for r in plan.records if r.fn is not None and r.name == name)
-    st = torch.cuda.Stream()
-    gk = torch.cuda.CUDAGraph()
-    with torch.cuda.stream(st):
-        with torch.cuda.graph(gk, stream=st):
-            for _ in range(20):
-                rc = rec.fn(*rec.args, st.cuda_stream)
-                assert rc == 0, name
-    gk.replay()
-    torch.cuda.synchronize()
-    best = 1e30
-    for _ in range(5):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        gk.replay()
-        e1.record()
-        torch.cuda.synchronize()
-        best = min(best, e0.elapsed_time(e1) / 20)
-    dom_ms = best
-    dom_flops = kernel_flops(name, B, T, F, E, H, D, S)
-    achieved = dom_flops / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
-    esz = 2 if args.dtype == "bf16" else 4
-    dom_bytes = None
-    if name == "adaln.cond_gemm":   # hidden matrices in, modulations out, weights once: 12 modules at F = 3 (9 of width 2E, 3 of width 2D)
-        dom_bytes = sum(n_mod * (2 * B * T * (2 * d) * esz + (2 * d) * (2 * d) * esz) for n_mod, d in ((3 * F, E), (F, D)))
-    elif name == "adaln.cond_mlp":   # the condition once, weights once, modulations out: no hidden matrix
-        dom_bytes = sum(n_mod * (B * T * (2 * d) * esz + (2 * d) * (2 * d) * esz + 3 * (2 * d) * 4) for n_mod, d in ((3 * F, E), (F, D))) + B * T * 4
-    elif name == "mlp.fc1_ln_gelu":  # per field: normalised rows in, W1 and the three vectors once, activated hidden rows out (the pre-activation never leaves the CU)
-        dom_bytes = F * (B * T * E * esz + S * E * esz + 3 * S * 4 + B * T * S * esz)
-    elif name == "mlp.fc2":          # activated hidden rows and the residual in, W2 once, rows out
-        dom_bytes = F * (B * T * S * esz + S * E * esz + B * T * E * 4 + B * T * E * esz)
-
-    # HBM bytes per launch of the dominant kernel, from the committed PMC profile of this same workload (separate --pmc passes, see
-    # profiles/README.md); null when the workload or the plan differs from the profiled one
-    traffic, traffic_src = None, None
-    prof = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_forward_cfg2_pmc_traffic.json")
-    if os.path.exists(prof) and (B, T, F, E, args.dtype) == (1, 2024, 3, 256, "bf16"):
-        rec = json.load(open(prof))["launches"].get(name)
-        if rec is not None:
-            traffic, traffic_src = rec["hbm_bytes"], "profiles/r01_forward_cfg2_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, bytes per launch)"
-
-    # Which roof bounds the dominant launch: its algorithmic intensity (FLOP per algorithmic byte: operands + weights + outputs once) against the
-    # machine balance 2500 TFLOP/s / 8 TB/s = 312 FLOP/B.  Below it the HBM roof is the bound and `achieved` is algorithmic bytes over the launch
-    # duration; the MFMA-side figures stay in the object either way.
-    hbm_GBps = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_bytes and dom_ms > 0 else None
-    intensity = dom_flops / dom_bytes if dom_bytes else None
-    hbm_bound = intensity is not None and intensity < PEAK_BF16_TFLOPS * 1e12 / 8000e9
-    roofline = {"kernel": name, "bound": "hbm" if hbm_bound else "mfma",
-                "achieved": hbm_GBps if hbm_bound else achieved, "peak": 8000.0 if hbm_bound else PEAK_BF16_TFLOPS, "unit": "GB/s" if hbm_bound else "TFLOP/s",
-                "frac": (hbm_GBps / 8000.0) if hbm_bound else achieved / PEAK_BF16_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
-                "flop_per_algorithmic_byte": intensity, "algorithmic_bytes": dom_bytes,
-                "hbm_GBps": hbm_GBps, "hbm_frac": hbm_GBps / 8000.0 if hbm_GBps else None,
-                "mfma_TFLOPs": achieved, "mfma_frac": achieved / PEAK_BF16_TFLOPS,
-                "launch_ms": dom_ms, "launch_ms_single_event_pair": dom_ms_events, "launch_gflop": dom_flops / 1e9,
-                "device_ms_all_launches": total_ms,
-                "timing": "launch_ms: HIP events around 20 back-to-back launches of the dominant record (one captured graph) / 20; "
-                          "launch_breakdown_ms: one event pair per launch of the plan (includes ~3-6 us of event / launch gap each)"}
+    legs = {"all": ("rollout", "train", "kv"), "rollout": ("rollout",), "train": ("train",), "kv": ("kv",)}[args.mode]
+    headline = "train" if (world > 1 and "train" in legs) else legs[0]
+    res = {}
+    if "rollout" in legs:
+        res["rollout"] = leg_rollout(args, dist, dev, rank, world, args.steps if headline == "rollout" else max(args.steps // 4, 20), args.warmup, args.batch or 1)
+        torch.cuda.empty_cache()
+    if "train" in legs:
+        res["train"] = leg_train(args, dist, dev, rank, world, args.steps if headline == "train" else max(min(args.steps // 8, 50), 10), min(args.warmup, 5),
+                                 args.batch or 8)
+        torch.cuda.empty_cache()
+    if "kv" in legs and (world == 1 or headline == "kv"):
+        res["kv"] = leg_kv(args, dev, rank)
     if rank == 0:
-        ms_per_step = elapsed / args.steps * 1e3
-        value = world * B * args.steps / elapsed
-        gflop = algorithmic_gflop(B, T, F, E, H, D, S, L)
+        h = res[headline]
+        hk = h["cfg2_2024_steps"] if headline == "kv" else h
         line = {
-            "metric": "rollout steps/sec (full-context forward, recompute mode) on cylinder_flow-shaped fields",
-            "value": value, "unit": "trajectory-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": "cfg2: cylinder_flow temporal model E=256 H=8 F=3 L=1 adaln, forward-only rollout step at T=2024",
-                       "trajectories_per_gpu": B, "seq_len": T, "fields": F, "embed_dim": E, "replay": "plain" if args.no_graph else "hip-graph",
-                       "parallelism": f"replicas x{world} (rollout shards by trajectory, no collective)"},
-            "model_algorithmic_gflop_per_step": gflop,
-            "model_mfma_frac": gflop / (ms_per_step * 1e-3) / 1e3 / PEAK_BF16_TFLOPS,
-            "roofline": roofline,
-            "launch_breakdown_ms": {n: round(t, 4) for n, t in times},
+            "metric": {"rollout": "rollout steps/sec (full-context forward, recompute mode) on cylinder_flow-shaped fields",
+                       "train": "train steps/sec (fwd+bwd+AdamW, data-parallel) on cylinder_flow-shaped fields, in trajectory-steps/s",
+                       "kv": "KV-cache rollout steps/sec on cylinder_flow-shaped fields"}[headline],
+            "value": hk["steps_per_s"] * world if headline == "kv" else h["value"], "unit": "trajectory-steps/s", "n_gpus": world,
+            "steps": h.get("steps", args.steps), "warmup": args.warmup, "ms_per_step": hk["ms_per_step"],
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": hk["workload"], "headline_leg": headline, "seq_len": args.seq, "fields": CFG["F"], "embed_dim": CFG["E"],
+                       "parallelism": h.get("parallelism", f"replicas x{world} (rollout shards by trajectory, no collective)")},
+            "roofline": h.get("roofline"),
         }
-        if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline((L, E, H, max_len, sr, src, F), B, T)
-        print(json.dumps(line))
+        for k in ("rollout", "train", "kv"):
+            if k in res:
+                line[k] = res[k]
+        if world == 1 and not args.no_cpu_baseline and args.mode in ("all", "rollout"):
+            line["cpu_baseline"] = cpu_baseline(1, args.seq)
+        print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
 
 
-def main_other(args):
-    """--mode train: BASELINE.json configs[2]/[3] (fwd+bwd+fused AdamW, B trajectories per GPU, one RCCL all-reduce of the flat
-    gradient per step when N > 1).  --mode kv: exact KV-cache rollout (configs[4]-style long rollout).  Same JSON contract."""
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist_mod
+# ------------------------------------------------------------------------------------------------------------------ launcher
+def launch_ranks(args) -> int:
+    """`python bench.py --gpus N`, N > 1, outside torch.distributed.run: start N fresh rank processes (this process has made no GPU call), pass
+    rank 0's JSON line through, fail if any rank fails."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0, _ = procs[0].communicate()
+    rcs = [procs[0].returncode]
+    deadline = time.time() + 120
+    for p in procs[1:]:
+        try:
+            rcs.append(p.wait(timeout=max(1.0, deadline - time.time())))
+        except subprocess.TimeoutExpired:
+            p.kill()
+            rcs.append(-9)
+    if any(rcs):
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+        print(f"[bench] rank exit codes {rcs}", file=sys.stderr)
+        return 1
+    lines = [ln for ln in out0.decode().splitlines() if ln.startswith("{")]
+    if not lines:
+        print("[bench] rank 0 printed no JSON line", file=sys.stderr)
+        return 1
+    print(lines[-1], flush=True)
+    return 0
 
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist_mod.init_process_group("nccl", device_id=dev)
-        dist = dist_mod
-    from sea_amd.models.temporal import TemporalModel
-    from sea_amd.utils.train_utils import initialize_optimizer, rollout
 
-    L, E, H, max_len, sr, src, F = 1, 256, 8, 2024, 8, 0, 3
-    B, T = args.batch, args.seq
-    D, S = E // 2, E * sr
-    torch.manual_seed(42)
-    model = TemporalModel(L, E, H, max_len, sr, src, F, 2, 0.0, "sea", "learnable", "mlp", "add", 1, 1, True, "adaln")
-    model.set_compute_dtype(args.dtype)
-    model = model.to(dev)
-    x = torch.randn(B, T, F, E, generator=torch.Generator().manual_seed(1234 + rank)).to(dev)
-    tgt = torch.randn(B, T, F, E, generator=torch.Generator().manual_seed(4321 + rank)).to(dev)
-    ib = torch.rand(B, T, 1, generator=torch.Generator().manual_seed(1235 + rank)).to(dev)
-    eng = model.engine(dev)
-    if args.mode == "train":
-        model.train()
-        opt = initialize_optimizer(model, {"learning_rate": 1e-4})
-        if dist is not None:
-            from sea_amd.parallel import broadcast_parameters
-
-            broadcast_parameters(eng.params.flat32)
-            eng.params.sync(force=True)
-
-        def step():
-            return eng.train_step(x, tgt, ib, opt)
-    else:
-        model.eval()
-
-        def step():
-            return rollout(model, x[:, :1].contiguous(), ib, T, mode="kv")
-    for _ in range(max(args.warmup, 1)):
-        r = step()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        r = step()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
-    assert torch.isfinite(r).all()
-    if rank == 0:
-        ms = elapsed / args.steps * 1e3
-        if args.mode == "train":
-            gflop = 3 * algorithmic_gflop(B, T, F, E, H, D, S, L)
-            line = {"metric": "train steps/sec (fwd+bwd+AdamW) on cylinder_flow-shaped fields", "value": world * args.steps / elapsed * 1.0,
-                    "unit": "rank-steps/s (each step = B trajectories x T positions, teacher-forced)", "trajectory_steps_per_s": world * B * args.steps / elapsed,
-                    "config": {"workload": f"cfg3: cylinder_flow temporal model E=256 H=8 F=3 L=1 adaln, fwd+bwd+AdamW, B={B} per GPU, T={T}",
-                               "global_batch": world * B, "seq_len": T, "parallelism": f"dp{world}: flat-gradient all-reduce (RCCL), 1 per step"},
-                    "model_algorithmic_gflop_per_step": gflop, "model_mfma_frac": gflop / (ms * 1e-3) / 1e3 / PEAK_BF16_TFLOPS}
-        else:
-            line = {"metric": "KV-cache rollout steps/sec on cylinder_flow-shaped fields", "value": world * B * T * args.steps / elapsed,
-                    "unit": "trajectory-steps/s",
-                    "config": {"workload": f"KV-cache rollout of {T} steps, B={B} per GPU, E=256 H=8 F=3 L=1 adaln", "parallelism": f"replicas x{world}"}}
-            ms = ms / T
-        line.update({"n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",
-                     "vs_baseline": None, "dtype": args.dtype, "data": "synthetic"})
-        print(json.dumps(line))
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200, help="timed steps of the headline leg (the other legs run a fixed fraction)")
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=0, help="trajectories per GPU (default: 1 for the rollout leg, 8 for the train leg)")
+    ap.add_argument("--seq", type=int, default=2024)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-graph", action="store_true", help="replay launch by launch instead of the captured HIP graph")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--mode", default="all", choices=["all", "rollout", "train", "kv", "decode", "encode"],
+                    help="all: every leg in one line (default); rollout / train / kv: one leg; decode / encode: the spatial decoder / encoder legs "
+                         "(SURVEY.md §8f ranks 1 and 2)")
+    args = ap.parse_args()
+    if args.mode == "decode":
+        return main_decode(args)
+    if args.mode == "encode":
+        return main_encode(args)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args))
+    run_rank(args)
 
 
 def main_decode(args):

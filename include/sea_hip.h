@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define SEA_ABI_VERSION 1
+#define SEA_ABI_VERSION 2
 
 enum { SEA_F32 = 0, SEA_BF16 = 1 };
 
@@ -41,7 +41,7 @@ enum {
 int sea_abi_version(void);
 const char* sea_last_error(void);
 /* sizeof of every ABI struct in declaration order (SeaGemmGroup, SeaQkvGroup, SeaQkvCommon, SeaAttnProblem,
- * SeaAttnParams, SeaNormGroup, SeaSiluGroup, SeaIbParams, ..., SeaGemmNormGroup, SeaExchangeTail, SeaMlpGroup, SeaCondGroup last): lets a binding verify its layout.  Host only. */
+ * SeaAttnParams, SeaNormGroup, SeaSiluGroup, SeaIbParams, ..., SeaLaunchRec, SeaGemmNormGroup, SeaExchangeTail, SeaMlpGroup last): lets a binding verify its layout.  Host only. */
 int sea_struct_sizes(int* out, int cap);
 /* Number of compute units / name of device 0's architecture as HIP reports them (diagnostics for bench.py). */
 int sea_device_info(int* cu_count, char* arch, int arch_len);
@@ -307,29 +307,6 @@ typedef struct {
 int sea_mlp_fc1_ln_gelu(const SeaMlpGroup* groups, int n_groups, float eps, int dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
- * AdaLN condition MLP of a scalar condition in ONE launch, for every module of the model:
- *     Out_g[m, :] = W2_g . silu(w1_g * c[m] + b1_g) + b2_g            (g < n_groups; W2_g in nn.Linear layout [K, K])
- * Replaces cond_mlp = Sequential(Linear(1, 2d), SiLU, Linear(2d, 2d)) of AdaptiveLayerNorm (models/base_blocks.py:337-345) for all the
- * AdaLN modules of TemporalModel at once — sea_silu_outer + the cond_mlp.2 group of sea_gemm_grouped without the hidden matrix between
- * them: a workgroup owns 32 complete rows of one module, generates their hidden rows into LDS once and streams W2 through an LDS ring.
- * The `n_ib` information-bottleneck layers are evaluated by extra workgroups of the same launch exactly as sea_silu_outer_ib does.
- * bf16 only, K = 128, 256 or 512 (d = 64 / 128 / 256), ldw % 8 == 0, ldo % 8 == 0, pointers 16-byte aligned; SEA_EUNSUPPORTED otherwise (callers keep
- * the two launches).  c: f32 [M].
- */
-#define SEA_MAX_COND_GROUPS 24
-typedef struct {
-    const float* w1;    /* f32 [K]: cond_mlp.0.weight[:, 0] */
-    const float* b1;    /* f32 [K]: cond_mlp.0.bias */
-    const void* W2;     /* act [K, K], row stride ldw: cond_mlp.2.weight */
-    const float* b2;    /* f32 [K]: cond_mlp.2.bias */
-    void* Out;          /* act [M, K], row stride ldo: (scale | shift) rows */
-    int32_t K, ldw, ldo, pad_;
-} SeaCondGroup;
-
-struct SeaIbParams_;
-int sea_cond_mlp(const SeaCondGroup* groups, int n_groups, const float* c, int M, int dtype, const struct SeaIbParams_* ibs, int n_ib, void* stream);
-
-/* ------------------------------------------------------------------------------------------------------------
  * Hidden layer of the AdaLN condition MLP for a scalar condition: Hid[m, k] = silu(w1[k] * c[m] + b1[k]).
  * Replaces cond_mlp.0 (Linear(1, 2d)) + nn.SiLU (models/base_blocks.py:337-338, 344); cond_mlp.2 is a
  * sea_gemm_grouped group.  c: f32 [M]; w1, b1: f32 [K2]; Hid: act [M, K2] row stride ld.
@@ -519,107 +496,18 @@ typedef struct {
 int sea_ib_bwd(const SeaIbBwdParams* params, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
- * Row-local operator chain: everything between two attention launches of the temporal block that only mixes the
- * columns of a row (Linear layers, residual adds, GELU, LayerNorm/AdaLN, RoPE + the attention layouts) executed by ONE
- * launch.  A workgroup owns 32 rows of one chain ("group": one field), keeps the row tile in LDS between stages and
- * streams the weights straight from L2 into MFMA operands; nothing but the declared outputs goes back to HBM.
- * Replaces, fused: models/temporal.py:133-137 (self-attention projection + residual), :176-192 (cross_down, ln_cross,
- * cross-attention q/k/v + RoPE, projection + GELU, cross_up, sum over j, residual), :111-116,140-142 (info-bottleneck
- * add), :143-146 (AdaLN_2, proj) and :412-415 (final per-field norm); models/base_blocks.py:175-190,267-282,343-350.
- *
- * A stage produces v[rows, N] (fp32, in registers) and pushes it through a fixed epilogue; stages run in order:
- *     kind 0:  v = A . W^T           A = LDS slot a_slot [rows, K] (act dtype), W act dtype [N, K] (nn.Linear layout)
- *     kind 1:  v = X[rows, 0:N]      fp32 (x_is_act = 0) or act dtype rows loaded from global memory
- *     kind 2:  LDS slot raw_slot <- X[rows, 0:N] (act dtype), nothing else; consecutive kind-2 stages overlap their loads
- *     v += bias_scale * bias ;  act = 1: v = gelu_erf(v)
- *     sum_op 1: S = v, stage ends;  3: S += v, stage ends;  2: v += S   (S: a running sum held in registers,
- *               sum_j Up(GELU(.)) = Up(sum_j GELU(.)) — models/temporal.py:189-191)
- *     v += R (fp32 rows);  raw_slot >= 0: LDS slot <- (act dtype) v
- *     ib_w1 != NULL: v += W2 . gelu(LN_h(w1 c + b1)) + b2   (the info-bottleneck term of sea_ib_add, c = bind.cond[row], h <= 8)
- *     C32 <- v ;  Cact <- (act dtype) v
- *     qkv = 1: v goes through RoPE into the attention layouts exactly as sea_qkv_rope_grouped (columns col0 .. col0+N of
- *              the virtual [q | k | v] row, head dim hd, tables rope), and the stage ends
- *     norm = 1: y = LayerNorm_N(v) with gamma / beta / mod as SeaNormGroup (biased variance, eps);  norm = 2: y = gelu_erf(y) too
- *              norm_slot >= 0: LDS slot <- (act dtype) y ;  Nact <- (act dtype) y ;  N32 <- y
- * N and K are multiples of 64 and at most SEA_CHAIN_MAX_WIDTH (the running sum S: N <= 128); a stage must not write the slot it
- * reads; M times any row stride stays below 2^31 elements.
- * `ext` marks pointers that are byte OFFSETS from a per-call base instead of addresses: bit 0: X from bind.x, bit 1: R from
- * bind.x, bit 2: N32 from bind.out — the stage array lives in device memory and stays valid across calls.
- */
-#define SEA_CHAIN_MAX_GROUPS 8
-#define SEA_CHAIN_SLOTS 3
-#define SEA_CHAIN_MAX_WIDTH 256
-#define SEA_CHAIN_ROWS 32
-typedef struct {
-    int32_t kind, a_slot, N, K;
-    const void* W;
-    int64_t ldw;
-    const void* X;
-    int64_t ldx;
-    int32_t x_is_act, ext;
-    const float* bias;
-    float bias_scale;
-    int32_t act;
-    int32_t sum_op, raw_slot;
-    const float* R;
-    int64_t ldr;
-    const float* ib_w1;
-    const float* ib_b1;
-    const float* ib_lnw;
-    const float* ib_lnb;
-    const float* ib_w2;
-    const float* ib_b2;
-    int32_t ib_h, norm;
-    float* C32;
-    int64_t ldc32;
-    void* Cact;
-    int64_t ldcact;
-    const float* gamma;
-    const float* beta;
-    const void* mod;
-    int64_t ldmod;
-    int32_t norm_slot, qkv;
-    void* Nact;
-    int64_t ldnact;
-    float* N32;
-    int64_t ldn32;
-    int32_t col0, hd;
-    const float* rope;
-    float q_scale;
-    int32_t pad;
-    void* Qout;
-    void* Kout;
-    void* Vtout;
-} SeaChainStage;
-
-typedef struct {
-    const SeaChainStage* stages;        /* DEVICE memory: all groups' stages back to back */
-    int32_t n_groups;
-    int32_t first[SEA_CHAIN_MAX_GROUPS + 1];   /* group g runs stages first[g] .. first[g+1]-1 */
-    const float* x;                     /* per-call bases for the `ext` offsets */
-    float* out;
-    const float* cond;                  /* f32 [M] condition scalar per row (info-bottleneck term) */
-    int32_t M, T, pos0, cap, H;         /* rows; rows per trajectory, first position and KV capacity (qkv epilogue); heads */
-    float eps;
-    uint64_t* dbg;                      /* NULL, or device memory for 2 + n_stages wall_clock64() stamps of workgroup (0, 0) (development aid) */
-} SeaChainLaunch;
-
-/* `host_stages` is the host copy of launch->stages (same content), used for validation only. */
-int sea_rowchain(const SeaChainLaunch* launch, const SeaChainStage* host_stages, int dtype, void* stream);
-
-/* ------------------------------------------------------------------------------------------------------------
  * Launch list: a whole plan (every launch of TemporalModel.forward, models/temporal.py:405-416, in order) replayed by ONE call, so the host
  * side of a replay is a C loop over prepared argument structs instead of one interpreter round trip per launch (KV-cache rollout steps
  * and plain, un-captured forwards are host-bound otherwise).  `op` selects the entry point, the other fields are its arguments:
  *     SEA_OP_GEMM   p0 = SeaGemmGroup[n]                          SEA_OP_QKV    p0 = SeaQkvGroup[n], p1 = SeaQkvCommon
  *     SEA_OP_ATTN   p0 = SeaAttnParams                            SEA_OP_NORM   p0 = SeaNormGroup[n], i0 = M, i1 = d, i2 = x_is_act, i3 = gelu, f0 = eps
  *     SEA_OP_SILU   p0 = SeaSiluGroup[n], p1 = c, i0 = M, l0 = (intptr) SeaIbParams[l1] or 0, l1 = n_ib      SEA_OP_IB     p0 = SeaIbParams
- *     SEA_OP_CHAIN  p0 = SeaChainLaunch, p1 = host stage table    SEA_OP_CONVERT p0 = src, p1 = dst, l0 = lds, l1 = ldd, l2 = rows, l3 = cols
+ *     SEA_OP_CONVERT p0 = src, p1 = dst, l0 = lds, l1 = ldd, l2 = rows, l3 = cols
  *     SEA_OP_GEMM_NORM p0 = SeaGemmNormGroup[n], f0 = eps          SEA_OP_XTAIL  p0 = SeaExchangeTail[n], f0 = eps
- *     SEA_OP_MLP1   p0 = SeaMlpGroup[n], f0 = eps                 SEA_OP_COND   p0 = SeaCondGroup[n], p1 = c, i0 = M, l0 = (intptr) SeaIbParams[l1] or 0, l1 = n_ib
+ *     SEA_OP_MLP1   p0 = SeaMlpGroup[n], f0 = eps
  * Returns 0, or the failing entry's error code with sea_last_error() set (entries before it have been launched).
  */
-enum { SEA_OP_GEMM = 1, SEA_OP_QKV = 2, SEA_OP_ATTN = 3, SEA_OP_NORM = 4, SEA_OP_SILU = 5, SEA_OP_IB = 6, SEA_OP_CHAIN = 7, SEA_OP_CONVERT = 8, SEA_OP_GEMM_NORM = 9, SEA_OP_XTAIL = 10, SEA_OP_MLP1 = 11, SEA_OP_COND = 12 };
+enum { SEA_OP_GEMM = 1, SEA_OP_QKV = 2, SEA_OP_ATTN = 3, SEA_OP_NORM = 4, SEA_OP_SILU = 5, SEA_OP_IB = 6, SEA_OP_CONVERT = 8, SEA_OP_GEMM_NORM = 9, SEA_OP_XTAIL = 10, SEA_OP_MLP1 = 11 };   /* 7 and 12 were round-1 entry points (sea_rowchain, sea_cond_mlp), removed in ABI v2 */
 typedef struct {
     int32_t op, n, dtype, i0, i1, i2, i3;
     float f0;

@@ -15,6 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libsea_hip.so")
 
 SEA_F32, SEA_BF16 = 0, 1
+ABI_VERSION = 2   # include/sea_hip.h SEA_ABI_VERSION
 MAX_GROUPS = 16
 MAX_ATTN_PROBLEMS = 8
 MAX_NORM_GROUPS = 16
@@ -105,35 +106,7 @@ class SeaAttnBwdParams(C.Structure):
                 ("ldo", _i32), ("lddo", _i32), ("lddq", _i32), ("lddk", _i32), ("lddv", _i32), ("q_scale", _f32), ("drop", SeaDropout)]
 
 
-CHAIN_MAX_GROUPS = 8
-CHAIN_SLOTS = 3
-CHAIN_MAX_WIDTH = 256
-CHAIN_ROWS = 32
-
-
-class SeaChainStage(C.Structure):
-    _fields_ = [("kind", _i32), ("a_slot", _i32), ("N", _i32), ("K", _i32),
-                ("W", _vp), ("ldw", _i64), ("X", _vp), ("ldx", _i64), ("x_is_act", _i32), ("ext", _i32),
-                ("bias", _vp), ("bias_scale", _f32), ("act", _i32), ("sum_op", _i32), ("raw_slot", _i32),
-                ("R", _vp), ("ldr", _i64),
-                ("ib_w1", _vp), ("ib_b1", _vp), ("ib_lnw", _vp), ("ib_lnb", _vp), ("ib_w2", _vp), ("ib_b2", _vp),
-                ("ib_h", _i32), ("norm", _i32),
-                ("C32", _vp), ("ldc32", _i64), ("Cact", _vp), ("ldcact", _i64),
-                ("gamma", _vp), ("beta", _vp), ("mod", _vp), ("ldmod", _i64),
-                ("norm_slot", _i32), ("qkv", _i32),
-                ("Nact", _vp), ("ldnact", _i64), ("N32", _vp), ("ldn32", _i64),
-                ("col0", _i32), ("hd", _i32), ("rope", _vp), ("q_scale", _f32), ("pad", _i32),
-                ("Qout", _vp), ("Kout", _vp), ("Vtout", _vp)]
-
-
-class SeaChainLaunch(C.Structure):
-    _fields_ = [("stages", _vp), ("n_groups", _i32), ("first", _i32 * (CHAIN_MAX_GROUPS + 1)),
-                ("x", _vp), ("out", _vp), ("cond", _vp),
-                ("M", _i32), ("T", _i32), ("pos0", _i32), ("cap", _i32), ("H", _i32), ("eps", _f32), ("dbg", _vp)]
-
-
-
-OP_GEMM, OP_QKV, OP_ATTN, OP_NORM, OP_SILU, OP_IB, OP_CHAIN, OP_CONVERT, OP_GEMM_NORM, OP_XTAIL, OP_MLP1, OP_COND = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12
+OP_GEMM, OP_QKV, OP_ATTN, OP_NORM, OP_SILU, OP_IB, OP_CONVERT, OP_GEMM_NORM, OP_XTAIL, OP_MLP1 = 1, 2, 3, 4, 5, 6, 8, 9, 10, 11
 
 
 class SeaLaunchRec(C.Structure):
@@ -174,13 +147,6 @@ MAX_MLP_GROUPS = 8
 class SeaMlpGroup(C.Structure):
     _fields_ = [("A", _vp), ("W1", _vp), ("b1", _vp), ("lnw", _vp), ("lnb", _vp), ("Hg", _vp),
                 ("lda", _i32), ("ldw", _i32), ("ldh", _i32), ("M", _i32), ("E", _i32), ("S", _i32)]
-
-
-MAX_COND_GROUPS = 24
-
-
-class SeaCondGroup(C.Structure):
-    _fields_ = [("w1", _vp), ("b1", _vp), ("W2", _vp), ("b2", _vp), ("Out", _vp), ("K", _i32), ("ldw", _i32), ("ldo", _i32), ("pad_", _i32)]
 
 
 MAX_WGRAD_GROUPS = 16
@@ -228,8 +194,6 @@ def lib() -> C.CDLL:
     L.sea_attention_bwd.argtypes = [C.POINTER(SeaAttnBwdParams), C.c_int, _vp]
     L.sea_dropout_mask.argtypes = [_vp, _i64, _i64, C.c_uint32, C.c_uint32, _i32, _vp]
     L.sea_dropout_mask.restype = C.c_int
-    L.sea_rowchain.argtypes = [C.POINTER(SeaChainLaunch), C.POINTER(SeaChainStage), C.c_int, _vp]
-    L.sea_rowchain.restype = C.c_int
     L.sea_unpatchify.argtypes = [_vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp]
     L.sea_unpatchify.restype = C.c_int
     L.sea_gemm_rownorm.argtypes = [C.POINTER(SeaGemmNormGroup), C.c_int, C.c_float, C.c_int, _vp]
@@ -242,8 +206,6 @@ def lib() -> C.CDLL:
     L.sea_silu_outer_ib.restype = C.c_int
     L.sea_mlp_fc1_ln_gelu.argtypes = [C.POINTER(SeaMlpGroup), C.c_int, C.c_float, C.c_int, _vp]
     L.sea_mlp_fc1_ln_gelu.restype = C.c_int
-    L.sea_cond_mlp.argtypes = [C.POINTER(SeaCondGroup), C.c_int, _vp, C.c_int, C.c_int, _vp, C.c_int, _vp]
-    L.sea_cond_mlp.restype = C.c_int
     L.sea_run_list.argtypes = [C.POINTER(SeaLaunchRec), C.c_int, _vp]
     L.sea_run_list.restype = C.c_int
     for name in ("sea_attention_bwd", "sea_wgrad_grouped", "sea_transpose_weights", "sea_rownorm_bwd", "sea_silu_outer_bwd", "sea_ib_bwd"):
@@ -256,22 +218,22 @@ def lib() -> C.CDLL:
                  "sea_ib_add", "sea_convert_f32_to_act", "sea_device_info", "sea_mse_fwd_bwd", "sea_relative_mse",
                  "sea_adamw_flat"):
         getattr(L, name).restype = C.c_int
-    if L.sea_abi_version() != 1:
-        raise NativeLibraryError(f"{LIB_PATH}: ABI version {L.sea_abi_version()} != 1; rebuild")
+    if L.sea_abi_version() != ABI_VERSION:
+        raise NativeLibraryError(f"{LIB_PATH}: ABI version {L.sea_abi_version()} != {ABI_VERSION}; rebuild (python -m sea_amd.build --force)")
     _lib = L
     return L
 
 
 ABI_STRUCTS = (SeaGemmGroup, SeaQkvGroup, SeaQkvCommon, SeaAttnProblem, SeaAttnParams, SeaNormGroup, SeaSiluGroup,
                SeaIbParams, SeaWgradGroup, SeaNormBwdGroup, SeaSiluBwdGroup, SeaIbBwdParams, SeaAttnBwdProblem, SeaAttnBwdParams,
-               SeaDropout, SeaChainStage, SeaChainLaunch, SeaLaunchRec, SeaGemmNormGroup, SeaExchangeTail, SeaMlpGroup, SeaCondGroup)
+               SeaDropout, SeaLaunchRec, SeaGemmNormGroup, SeaExchangeTail, SeaMlpGroup)
 
 EXPORTED_SYMBOLS = (
     "sea_abi_version", "sea_last_error", "sea_struct_sizes", "sea_device_info", "sea_gemm_grouped", "sea_qkv_rope_grouped",
     "sea_attention_fwd", "sea_rownorm", "sea_silu_outer", "sea_ib_add", "sea_convert_f32_to_act", "sea_selftest_mfma",
     "sea_mse_fwd_bwd", "sea_relative_mse", "sea_adamw_flat",
     "sea_wgrad_grouped", "sea_transpose_weights", "sea_rownorm_bwd", "sea_silu_outer_bwd", "sea_ib_bwd",
-    "sea_attention_bwd", "sea_dropout_mask", "sea_rowchain", "sea_run_list", "sea_unpatchify", "sea_gemm_rownorm", "sea_exchange_tail", "sea_patchify", "sea_silu_outer_ib", "sea_mlp_fc1_ln_gelu", "sea_cond_mlp",
+    "sea_attention_bwd", "sea_dropout_mask", "sea_run_list", "sea_unpatchify", "sea_gemm_rownorm", "sea_exchange_tail", "sea_patchify", "sea_silu_outer_ib", "sea_mlp_fc1_ln_gelu",
 )
 
 

@@ -12,11 +12,16 @@ class _TemporalFn(torch.autograd.Function):
     def forward(ctx, anchor, x, ib, model, eng):
         out, plan = eng.forward_train(x, ib)
         ctx.plan, ctx.eng, ctx.model = plan, eng, model
+        ctx.generation = plan.generation   # the saved activations live in the plan's workspace: a later forward of the same shape replaces them
         return out
 
     @staticmethod
     def backward(ctx, dout):
         eng, model = ctx.eng, ctx.model
+        if ctx.plan.generation != ctx.generation:
+            raise RuntimeError("sea_amd: backward() of a TemporalModel forward whose saved activations were overwritten by a later grad-enabled forward of the "
+                               "same shape (one activation set per (batch, length) is kept): run backward() before the next forward, or run the other "
+                               "forward under torch.no_grad()")
         live = model._live_params()
         # torch semantics: gradients accumulate until zero_grad().  A step that starts from p.grad is None starts from zero.
         if eng.grads_dirty and live and live[0].grad is None:

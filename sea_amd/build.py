@@ -12,8 +12,9 @@ from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
+BUILD = os.path.join(CSRC, "build")          # objects + compiler temporaries (git-ignored; only the .so has to travel to the GPU box)
 LIB = os.path.join(CSRC, "libsea_hip.so")
-SOURCES = ["core.hip", "gemm.hip", "gemm_norm.hip", "mlp_fused.hip", "cond_mlp.hip", "attention.hip", "rowops.hip", "train.hip", "bwd.hip", "attention_bwd.hip", "rowchain.hip"]
+SOURCES = ["core.hip", "gemm.hip", "gemm_norm.hip", "mlp_fused.hip", "attention.hip", "rowops.hip", "train.hip", "bwd.hip", "attention_bwd.hip"]
 HEADERS = ["sea_common.hpp", "gemm_core.hpp", os.path.join("..", "..", "include", "sea_hip.h")]
 # -amdgpu-mfma-vgpr-form: MFMA results land in VGPRs, so epilogues / softmax read them without v_accvgpr_read moves.
 # -ffast-math -fno-finite-math-only: reciprocal / approximate-function / reassociation freedoms for the row kernels and epilogues; infinities
@@ -21,14 +22,31 @@ HEADERS = ["sea_common.hpp", "gemm_core.hpp", os.path.join("..", "..", "include"
 FLAGS = (os.environ.get("SEA_EXTRA_FLAGS", "").split()) + ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-mcode-object-version=5", "-mllvm", "-amdgpu-mfma-vgpr-form=1", "-ffast-math", "-fno-finite-math-only", "-fgpu-flush-denormals-to-zero", "-Wall", "-Wno-unused-function", "-Wno-unused-result"]
 
 
-# Per-file flags.  gemm.hip: no SLP vectorisation — the packed fp32 instructions (v_pk_mul_f32 / v_pk_fma_f32 with op_sel) it formed from the RoPE
-# rotation of qkv_rope_kernel<bf16, 64, 64> gave, in about one launch of ten, a wrong value in ONE output column (head column 14 or 30: lanes
-# 48-63, third element of the 4-column piece) of one 16-row block, on identical inputs (tools/determinism_one.py: 0 of 400 replays differ without
-# the packed forms, 34 of 200 with them; the 128x128 instantiation was not affected).  Not understood further; the scalar forms cost nothing measurable.
-# attention_bwd.hip holds the inverse rotation (unrope) and is built the same way as a precaution (training step 4.13 ms either way); a blanket
-# -fno-slp-vectorize costs 4 % of the cfg2 step (GELU / softmax epilogues), so the other files keep the packed forms and are covered by the
-# replay-determinism tests (tests/test_model_gpu.py).
-FILE_FLAGS = {"gemm.hip": ["-fno-slp-vectorize"], "attention_bwd.hip": ["-fno-slp-vectorize"]}
+# Per-file flags: none.  (Round 1 built gemm.hip and attention_bwd.hip with -fno-slp-vectorize to mask wrong values of
+# qkv_rope_kernel<bf16, 64, 64>; the cause is now known — see lint_isa below — and is excluded for EVERY file by the lint instead.)
+FILE_FLAGS: dict = {}
+
+# gfx950 erratum found in round 2 (DESIGN.md section 5, tools/isa_variants.py, tools/pk_opsel_bench.hip): a packed fp32 VOP3P instruction
+# (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32) whose LOW result half selects the HIGH dword of its src1 pair (op_sel:[x,1] / op_sel:[x,1,y])
+# returns a wrong low result in lanes 48-63 — about 2..8 of 10^4 executions — whenever another wave of the CU is issuing MFMAs at that
+# moment; never when no MFMA runs beside it; independent of the registers, of wait states around it, of negation modifiers, of the MFMA
+# result form.  High-half selects of src0 / src2 and low-half selects for the high result are not affected.  hipcc (ROCm 7.2) forms such
+# instructions when its SLP vectoriser packs scalar fp32 code with a lane swap (the RoPE rotation, sums of squares, horizontal adds), so
+# every device assembly listing of the build is checked and the build FAILS if one is present: the source is then rewritten with the
+# scalar-lane helpers of sea_common.hpp (fma1 / mul1 / add1), which the vectoriser cannot pack.
+_PK_SRC1_HI = __import__("re").compile(r"^\s*v_pk_(?:fma|mul|add)_f32\b.*\bop_sel:\[[01],1[,\]]")
+
+
+def lint_isa(asm_path: str) -> list:
+    """[(kernel symbol, line number, instruction)] of every packed fp32 instruction with the forbidden src1 select in a device .s file."""
+    bad, kernel = [], "?"
+    with open(asm_path) as f:
+        for no, line in enumerate(f, 1):
+            if line[:1].isalpha() or line[:1] == "_":   # "symbol:   ; @symbol" opens a function
+                kernel = line.split(":")[0]
+            elif _PK_SRC1_HI.match(line):
+                bad.append((kernel, no, line.strip()))
+    return bad
 
 
 def _hipcc() -> str:
@@ -36,6 +54,10 @@ def _hipcc() -> str:
         if cand and (os.path.isabs(cand) and os.path.exists(cand) or not os.path.isabs(cand)):
             return cand
     raise RuntimeError("hipcc not found")
+
+
+def _asm_of(obj: str) -> str:
+    return obj[:-2] + "-hip-amdgcn-amd-amdhsa-gfx950.s"
 
 
 def _stale(target: str, deps) -> bool:
@@ -51,12 +73,14 @@ def build(force: bool = False, verbose: bool = True) -> str:
     hdrs = [os.path.join(CSRC, h) for h in HEADERS]
     objs = []
     jobs = []
+    os.makedirs(BUILD, exist_ok=True)
     for s in srcs:
         src = os.path.join(CSRC, s)
-        obj = os.path.join(CSRC, s.replace(".hip", ".o"))
+        obj = os.path.join(BUILD, s.replace(".hip", ".o"))
         objs.append(obj)
-        if force or _stale(obj, [src] + hdrs):
-            jobs.append([hipcc] + FLAGS + FILE_FLAGS.get(s, []) + ["-c", src, "-o", obj])
+        if force or _stale(obj, [src] + hdrs) or not os.path.exists(_asm_of(obj)):
+            # -save-temps=obj: the device assembly listing lands next to the object (one compile), for lint_isa
+            jobs.append([hipcc] + FLAGS + FILE_FLAGS.get(s, []) + ["-save-temps=obj", "-c", src, "-o", obj])
 
     def run(cmd):
         if verbose:
@@ -71,6 +95,16 @@ def build(force: bool = False, verbose: bool = True) -> str:
                     print(out)
                 if rc != 0:
                     raise RuntimeError("hipcc failed:\n" + out)
+    findings = []
+    for obj in objs:
+        for kernel, no, ins in lint_isa(_asm_of(obj)):
+            findings.append(f"{os.path.basename(_asm_of(obj))}:{no}: {kernel}: {ins}")
+    if findings:
+        for obj in objs:   # a later build must not link these objects
+            if lint_isa(_asm_of(obj)):
+                os.remove(obj)
+        raise RuntimeError("sea_amd.build: packed fp32 instructions with the low half reading the high dword of src1 (gfx950 erratum, see build.py):\n  "
+                           + "\n  ".join(findings[:40]) + (f"\n  ... {len(findings) - 40} more" if len(findings) > 40 else ""))
     if force or jobs or _stale(LIB, objs):
         rc, out = run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)
         if rc != 0:

@@ -100,12 +100,7 @@ __device__ __forceinline__ void zero_tile_padding(char* base, int n_tiles, int t
 }
 
 // inverse rotation of one (even, odd) pair: the forward was (e', o') = (e c - o s, e s + o c)
-__device__ __forceinline__ void unrope(float& e, float& o, const float2 cs) {
-    const float ne = e * cs.x + o * cs.y;
-    const float no = o * cs.x - e * cs.y;
-    e = ne;
-    o = no;
-}
+__device__ __forceinline__ void unrope(float& e, float& o, const float2 cs) { unrope_pair(e, o, cs.x, cs.y); }   // scalar-lane ops, see sea_common.hpp
 
 // ---------------------------------------------------------------------------------------------- dQ (+ delta)
 // DROP and (per tile) MASK are compile-time: both kernels are VALU-issue-bound (PMC: VALU busy 80-100 %), so the un-dropped,

@@ -18,8 +18,8 @@ extern "C" int sea_struct_sizes(int* out, int cap) {
     const int sizes[] = {(int)sizeof(SeaGemmGroup), (int)sizeof(SeaQkvGroup), (int)sizeof(SeaQkvCommon), (int)sizeof(SeaAttnProblem),
                          (int)sizeof(SeaAttnParams), (int)sizeof(SeaNormGroup), (int)sizeof(SeaSiluGroup), (int)sizeof(SeaIbParams),
                          (int)sizeof(SeaWgradGroup), (int)sizeof(SeaNormBwdGroup), (int)sizeof(SeaSiluBwdGroup), (int)sizeof(SeaIbBwdParams),
-                         (int)sizeof(SeaAttnBwdProblem), (int)sizeof(SeaAttnBwdParams), (int)sizeof(SeaDropout), (int)sizeof(SeaChainStage),
-                         (int)sizeof(SeaChainLaunch), (int)sizeof(SeaLaunchRec), (int)sizeof(SeaGemmNormGroup), (int)sizeof(SeaExchangeTail), (int)sizeof(SeaMlpGroup), (int)sizeof(SeaCondGroup)};
+                         (int)sizeof(SeaAttnBwdProblem), (int)sizeof(SeaAttnBwdParams), (int)sizeof(SeaDropout), (int)sizeof(SeaLaunchRec),
+                         (int)sizeof(SeaGemmNormGroup), (int)sizeof(SeaExchangeTail), (int)sizeof(SeaMlpGroup)};
     const int n = (int)(sizeof(sizes) / sizeof(sizes[0]));
     for (int i = 0; i < n && i < cap; ++i) out[i] = sizes[i];
     return n;
@@ -38,13 +38,10 @@ extern "C" int sea_run_list(const SeaLaunchRec* recs, int n_recs, void* stream) 
             case SEA_OP_SILU: rc = sea_silu_outer_ib(static_cast<const SeaSiluGroup*>(R.p0), R.n, static_cast<const float*>(R.p1), R.i0, R.dtype,
                                                      reinterpret_cast<const SeaIbParams*>(static_cast<intptr_t>(R.l0)), (int)R.l1, stream); break;
             case SEA_OP_IB: rc = sea_ib_add(static_cast<const SeaIbParams*>(R.p0), stream); break;
-            case SEA_OP_CHAIN: rc = sea_rowchain(static_cast<const SeaChainLaunch*>(R.p0), static_cast<const SeaChainStage*>(R.p1), R.dtype, stream); break;
             case SEA_OP_CONVERT: rc = sea_convert_f32_to_act(static_cast<const float*>(R.p0), R.l0, const_cast<void*>(R.p1), R.l1, R.l2, R.l3, R.dtype, stream); break;
             case SEA_OP_GEMM_NORM: rc = sea_gemm_rownorm(static_cast<const SeaGemmNormGroup*>(R.p0), R.n, R.f0, R.dtype, stream); break;
             case SEA_OP_XTAIL: rc = sea_exchange_tail(static_cast<const SeaExchangeTail*>(R.p0), R.n, R.f0, R.dtype, stream); break;
             case SEA_OP_MLP1: rc = sea_mlp_fc1_ln_gelu(static_cast<const SeaMlpGroup*>(R.p0), R.n, R.f0, R.dtype, stream); break;
-            case SEA_OP_COND: rc = sea_cond_mlp(static_cast<const SeaCondGroup*>(R.p0), R.n, static_cast<const float*>(R.p1), R.i0, R.dtype,
-                                                reinterpret_cast<const SeaIbParams*>(static_cast<intptr_t>(R.l0)), (int)R.l1, stream); break;
             default: sea_set_error("sea_run_list[%d]: unknown op %d", i, R.op); return SEA_EINVAL;
         }
         if (rc != SEA_OK) return rc;   // sea_last_error() already names the entry point; the caller maps i back to its record

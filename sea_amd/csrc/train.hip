@@ -64,7 +64,7 @@ __global__ __launch_bounds__(256) void relative_mse_kernel(const float* __restri
     if (row >= rows) return;
     const float* pr = p + row * d;
     const float* tr = t + row * d;
-    float num = 0.f, den = 0.f;
+    float num4[4] = {0.f, 0.f, 0.f, 0.f}, den4[4] = {0.f, 0.f, 0.f, 0.f};   // scalar-lane FMAs: see sea_common.hpp (packed horizontal adds trip the build's ISA check)
     for (int i = lane * 4; i < d; i += 256) {
         float a[4], b[4];
         load4(pr + i, a);
@@ -72,12 +72,12 @@ __global__ __launch_bounds__(256) void relative_mse_kernel(const float* __restri
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const float df = a[e] - b[e];
-            num += df * df;
-            den += b[e] * b[e];
+            num4[e] = fma1(df, df, num4[e]);
+            den4[e] = fma1(b[e], b[e], den4[e]);
         }
     }
-    num = wave_sum(num);
-    den = wave_sum(den);
+    const float num = wave_sum(add1(add1(num4[0], num4[1]), add1(num4[2], num4[3])));
+    const float den = wave_sum(add1(add1(den4[0], den4[1]), add1(den4[2], den4[3])));
     if (lane == 0) y[row] = num / (den + 1e-8f);
 }
 

@@ -205,11 +205,7 @@ class Plan:
         self._bound = (None, None, None)
         self._lane = 0                    # lane the record builders tag new records with
         self._lane_streams: Dict[int, torch.cuda.Stream] = {}
-        self.fused = self._can_fuse()
-        if self.fused:
-            self._build_fused()
-        else:
-            self._build()
+        self._build()
         self._clist = None          # (SeaLaunchRec array, [(rec index, field, args list, args index)]) for sea_run_list
         self._compile_list()
 
@@ -383,31 +379,6 @@ class Plan:
                     gemm_groups.append(dict(A=None, M=M, W=P.act(pre + "cond_mlp.2.weight"), bias=P.f32_vec(pre + "cond_mlp.2.bias"), Cact=mod,
                                             silu=(P.f32_vec(pre + "cond_mlp.0.weight", 2 * d), P.f32_vec(pre + "cond_mlp.0.bias"))))
                 self._gemm(gemm_groups, "adaln.cond_gemm" + tag)
-                return
-            # cond_mlp.0 + SiLU + cond_mlp.2 of every module in ONE launch with 32 complete rows per workgroup (sea_cond_mlp: the hidden rows are
-            # generated into LDS, W2 streams through a ring; bf16, widths 128 / 256 / 512).  Opt-in (SEA_FUSE_COND=1): measured at cfg2 the launch
-            # takes 39.9 us against 11.1 + 22.8 for the silu launch + grouped GEMM (0.2612 against 0.2553 ms per step) — 768 workgroups of 160 KiB
-            # are three rounds, each paying its prologue and 512 KiB of W2, where the 128 x 128 tiles of the GEMM stream less than half of that —
-            # and ties on the KV-cache step (0.1438 against 0.1441 ms).
-            if (type(self) is Plan and os.environ.get("SEA_FUSE_COND", "0") == "1" and len(inst) <= N.MAX_COND_GROUPS
-                    and ops.cond_mlp_supported(self.dt, [2 * d for _, d in inst])):
-                arr = (N.SeaCondGroup * len(inst))()
-                for g_, (pre, d) in zip(arr, inst):
-                    mod = self._buf(M, 2 * d)
-                    mods[pre] = mod
-                    ops.fill_cond_group(g_, P.f32_vec(pre + "cond_mlp.0.weight", 2 * d), P.f32_vec(pre + "cond_mlp.0.bias"), P.act(pre + "cond_mlp.2.weight"),
-                                        P.f32_vec(pre + "cond_mlp.2.bias"), mod)
-                ibs, n_ib = None, 0
-                if ib_todo:
-                    n_ib = len(ib_todo)
-                    ibs = (N.SeaIbParams * n_ib)()
-                    for ibp, (lpre, ibuf) in zip(ibs, ib_todo):
-                        ibp.X[0], ibp.n_fields, ibp.ldx = ibuf.data_ptr(), 1, ibuf.stride(0)
-                        self._fill_ib(ibp, lpre)
-                    ib_todo.clear()
-                rec = self._rec(L.sea_cond_mlp, [arr, len(inst), None, M, self.code, ibs, n_ib], "adaln.cond_mlp" + tag, (arr, ibs))
-                self._c_patches.append((rec.args, 2))
-                self._cur.append(rec)
                 return
             for pre, d in inst:
                 hid = self._buf(M, 2 * d)
@@ -759,152 +730,6 @@ class Plan:
         if final_norm:
             self._norm([dict(X=xr[i], Y32=xr[i], ldy32=FE, Y_is_out=i * E * 4, **norm_params(f"ln.{i}.", E)) for i in fields], E, "final.norm" + tag)
 
-    # ------------------------------------------------------------------ fused plan (row-local chains, sea_rowchain)
-    def _can_fuse(self) -> bool:
-        """The inference plan runs everything between two attention launches as one sea_rowchain launch when the widths fit its
-        LDS tiles (E, D multiples of 64 up to 256).  Opt-in with SEA_FUSED=1: measured at cfg2 (profiles/) the chains are still slower than the
-        launch-per-operator plan — every stage pays a cold ~1.5 us memory round trip for its weights with one wave per SIMD to hide it."""
-        m = self.eng.model
-        if type(self) is not Plan or os.environ.get("SEA_FUSED", "0") != "1" or m.exchange_mode != "sea" or m.ib_addition_mode.lower() != "add" or self.eng.ib_mode != 0:
-            return False
-        ok_w = lambda w: w % 64 == 0 and w <= N.CHAIN_MAX_WIDTH
-        return (ok_w(self.E) and ok_w(self.D) and 2 * self.D <= N.CHAIN_MAX_WIDTH and self.F >= 2 and m.add_info_after_cross
-                and m.ib_hidden <= 8)
-
-    def _chain(self, groups: List[List[dict]], name: str) -> None:
-        prog = ops.ChainProgram(groups, self.eng.device)
-        L = prog.launch_struct(self.M, self.T, self.pos0, self.cap, self.H)
-        self._x_patches.append((L, "x", 0))
-        self._out_patches.append((L, "out", 0))
-        self._c_patches.append((L, "cond"))
-        self._pos_structs.append(L)
-        self._cur.append(self._rec(N.lib().sea_rowchain, [C.byref(L), prog.host, self.code], name, (prog, L)))
-
-    def _build_fused(self) -> None:
-        eng, P = self.eng, self.eng.params
-        F, E, D, S, M, B, T, H = self.F, self.E, self.D, self.S, self.M, self.B, self.T, self.H
-        hd_s, hd_c = E // H, D // H
-        cap, f32 = self.cap, torch.float32
-        FE = F * E
-        mods = self._cond_mods()
-
-        def norm(pre, **kw):
-            d = dict(norm=1, gamma=P.f32_vec(pre + "weight"), **kw)
-            if self.adaln:
-                d.update(beta=P.f32_vec(pre + "bias"), mod=mods[pre])
-            return d
-
-        def qkv_stages(a_slot, K, W, bias, col0, hd, rope, **outs):
-            """[rows, n] = A . W^T + bias through RoPE into the attention layouts, in column chunks of at most 256"""
-            st, n, c = [], W.shape[0], 0
-            while c < n:
-                w = min(N.CHAIN_MAX_WIDTH, n - c)
-                st.append(dict(a_slot=a_slot, N=w, K=K, W=W[c:c + w], bias=bias[c:c + w], qkv=1, col0=col0 + c, hd=hd, rope=rope,
-                               q_scale=float(hd) ** -0.5, **outs))
-                c += w
-            return st
-
-        xr = [self._buf(M, E, dtype=f32) for _ in range(F)]     # fp32 residual stream
-        xa = [self._buf(M, E) for _ in range(F)]
-        n_e = [self._buf(M, E) for _ in range(F)]
-        att_e = [self._buf(M, E) for _ in range(F)]
-        Qs = [self._buf(B, H, T, hd_s) for _ in range(F)]
-        Ks = [[self._buf(B, H, cap, hd_s, zero=True) for _ in range(F)] for _ in range(self.L)]
-        Vs = [[self._buf(B, H, hd_s, cap, zero=True) for _ in range(F)] for _ in range(self.L)]
-        Qc = [[self._buf(B, H, T, hd_c) for _ in range(F)] for _ in range(F)]
-        Kc = [[[self._buf(B, H, cap, hd_c, zero=True) for _ in range(F)] for _ in range(F)] for _ in range(self.L)]
-        Vc = [[[self._buf(B, H, hd_c, cap, zero=True) for _ in range(F)] for _ in range(F)] for _ in range(self.L)]
-        att_c = [self._buf(M, D) for _ in range(F - 1)]
-        hbuf = [self._buf(M, S) for _ in range(F)]
-        hg = [self._buf(M, S) for _ in range(F)]
-        self.ws = dict(xr=xr, xa=xa, n_e=n_e, att_e=att_e, hbuf=hbuf, hg=hg)
-        rope_s, rope_c = eng.rope_self, eng.rope_cross
-
-        def self_qkv(l, i, a_slot):
-            pre = f"blocks.{l}."
-            return qkv_stages(a_slot, E, P.act(f"{pre}attn.self.{i}.q.weight", 3 * E), P.f32_vec(f"{pre}attn.self.{i}.q.bias", 3 * E), 0, hd_s, rope_s,
-                              Qout=Qs[i], Kout=Ks[l][i], Vtout=Vs[l][i])
-
-        def cross_kv(l, iq, j, a_slot):
-            ca = f"blocks.{l}.cross_attn.{iq}.{j}."
-            return qkv_stages(a_slot, D, P.act(ca + "k.weight", 2 * D), P.f32_vec(ca + "k.bias", 2 * D), D, hd_c, rope_c, Kout=Kc[l][iq][j], Vtout=Vc[l][iq][j])
-
-        # ---- layer 0 entry: AdaLN_0 of the caller's x, self-attention q/k/v
-        self._chain([[dict(kind=1, N=E, X_off=i * E * 4, ldx=FE, norm_slot=0, **norm(f"blocks.0.ln.exp.{i}.0."))] + self_qkv(0, i, 0) for i in range(F)],
-                    "self.adaln0_qkv")
-        for l in range(self.L):
-            pre = f"blocks.{l}."
-            self._attn([dict(Q=Qs[i], K=Ks[l][i], Vt=Vs[l][i], O=att_e[i]) for i in range(F)], hd_s, E, "self.attention")
-            # ---- x_i += proj(attn); down-projection, ln_cross; every cross-attention projection that reads the OLD x_i
-            groups = []
-            for i in range(F):
-                res = dict(R_off=i * E * 4, ldr=FE) if l == 0 else dict(R=xr[i])
-                g = [dict(kind=2, N=E, X=att_e[i], raw_slot=0),
-                     dict(a_slot=0, N=E, K=E, W=P.act(f"{pre}attn.self.{i}.projection.weight"), C32=xr[i], raw_slot=1, **res),
-                     dict(a_slot=1, N=D, K=E, W=P.act(f"{pre}cross_down.{i}.weight"), bias=P.f32_vec(f"{pre}cross_down.{i}.bias"), norm_slot=2,
-                          **norm(f"{pre}ln_cross.{i}."))]
-                for j in range(F):
-                    if j != i:
-                        ca = f"{pre}cross_attn.{i}.{j}."
-                        g += qkv_stages(2, D, P.act(ca + "q.weight"), P.f32_vec(ca + "q.bias"), 0, hd_c, rope_c, Qout=Qc[i][j])
-                for iq in range(i):  # pairs (iq, i) with iq < i read field i before its own update
-                    g += cross_kv(l, iq, i, 2)
-                groups.append(g)
-            self._chain(groups, "self.proj_down_qkv")
-            # ---- state exchange, Gauss-Seidel over i (models/temporal.py:187-192)
-            ibp = {k: P.f32_vec(f"{pre}ib.layers.{n}") for k, n in (("ib_w1", "0.weight"), ("ib_b1", "0.bias"), ("ib_lnw", "1.weight"), ("ib_lnb", "1.bias"),
-                                                                   ("ib_b2", "3.bias"))}
-            ibp["ib_w2"] = P.f32(f"{pre}ib.layers.3.weight")
-            ibp["ib_h"] = eng.model.ib_hidden
-            for i in range(F):
-                others = [j for j in range(F) if j != i]
-                self._attn([dict(Q=Qc[i][j], K=Kc[l][i][j], Vt=Vc[l][i][j], O=att_c[s]) for s, j in enumerate(others)], hd_c, D, f"cross{i}.attention")
-                g = []
-                for s, j in enumerate(others):
-                    slot = s & 1
-                    g.append(dict(kind=2, N=D, X=att_c[s], raw_slot=slot))
-                    last = s == len(others) - 1
-                    st = dict(a_slot=slot, N=D, K=D, W=P.act(f"{pre}cross_attn.{i}.{j}.projection.weight"), act=1)
-                    if len(others) == 1:
-                        st.update(raw_slot=2)
-                    elif s == 0:
-                        st.update(sum_op=1)
-                    elif last:
-                        st.update(sum_op=2, raw_slot=2)
-                    else:
-                        st.update(sum_op=3)
-                    g.append(st)
-                # x_i += cross_up(sum_j gelu(.)) ; copy for the down-projection BEFORE the info-bottleneck add ; x_i += ib ; AdaLN_2
-                g.append(dict(a_slot=2, N=E, K=D, W=P.act(f"{pre}cross_up.{i}.weight"), bias=P.f32_vec(f"{pre}cross_up.{i}.bias"), bias_scale=float(F - 1),
-                              R=xr[i], raw_slot=0, C32=xr[i], Nact=n_e[i], **ibp, **norm(f"{pre}ln.exp.{i}.2.")))
-                if i < F - 1:
-                    g.append(dict(a_slot=0, N=D, K=E, W=P.act(f"{pre}cross_down.{i}.weight"), bias=P.f32_vec(f"{pre}cross_down.{i}.bias"), norm_slot=1,
-                                  **norm(f"{pre}ln_cross.{i}.")))
-                    for iq in range(i + 1, F):  # pairs (iq, i) with iq > i read the NEW x_i
-                        g += cross_kv(l, iq, i, 1)
-                self._chain([g], f"cross{i}.proj_up_down_kv")
-            # ---- MLP: x_i += W2 gelu(LN(W1 AdaLN_2(x_i)))
-            self._gemm([dict(A=n_e[i], W=P.act(f"{pre}mlp.{i}.layers.0.weight"), bias=P.f32_vec(f"{pre}mlp.{i}.layers.0.bias"), Cact=hbuf[i])
-                        for i in range(F)], "mlp.fc1")
-            self._norm([dict(X=hbuf[i], gamma=P.f32_vec(f"{pre}mlp.{i}.layers.1.weight"), beta=P.f32_vec(f"{pre}mlp.{i}.layers.1.bias"), Yact=hg[i])
-                        for i in range(F)], S, "mlp.ln_gelu", x_is_act=True, gelu=True)
-            self._gemm([dict(A=hg[i], W=P.act(f"{pre}mlp.{i}.layers.3.weight"), bias=P.f32_vec(f"{pre}mlp.{i}.layers.3.bias"), R=xr[i], Cact=xa[i])
-                        for i in range(F)], "mlp.fc2")
-            # ---- x_i = proj_i(x_i) ; then the next layer's AdaLN_0 + q/k/v, or the final per-field norm straight into out
-            groups = []
-            for i in range(F):
-                g = [dict(kind=2, N=E, X=xa[i], raw_slot=0)]
-                st = dict(a_slot=0, N=E, K=E, W=P.act(f"{pre}proj.{i}.weight"), bias=P.f32_vec(f"{pre}proj.{i}.bias"))
-                if l == self.L - 1:
-                    st.update(N32_off=i * E * 4, ldn32=FE, **norm(f"ln.{i}."))
-                    g.append(st)
-                else:
-                    st.update(C32=xr[i], norm_slot=1, **norm(f"blocks.{l + 1}.ln.exp.{i}.0."))
-                    g.append(st)
-                    g += self_qkv(l + 1, i, 1)
-                groups.append(g)
-            self._chain(groups, "proj_final_norm" if l == self.L - 1 else "proj_adaln0_qkv")
-
     def _ib_params(self, pre: str) -> dict:
         P = self.eng.params
         return dict(w1=P.f32_vec(pre + "ib.layers.0.weight"), b1=P.f32_vec(pre + "ib.layers.0.bias"), lnw=P.f32_vec(pre + "ib.layers.1.weight"),
@@ -970,7 +795,7 @@ class Plan:
         assert pos0 + self.T <= self.cap
         self.pos0 = pos0
         for s in self._pos_structs:
-            if isinstance(s, (N.SeaQkvCommon, N.SeaChainLaunch, N.SeaExchangeTail)):
+            if isinstance(s, (N.SeaQkvCommon, N.SeaExchangeTail)):
                 s.pos0 = pos0
             else:
                 s.q_pos0, s.Tk = pos0, pos0 + self.T
@@ -1004,15 +829,8 @@ class Plan:
                 if r.fn is L.sea_silu_outer_ib and a[5] is not None:
                     c.l0, c.l1 = addr(a[5]), a[6]
                 relink.append((i, "p1", a, 2))
-            elif r.fn is L.sea_cond_mlp:
-                c.op, c.p0, c.n, c.i0, c.dtype = N.OP_COND, addr(a[0]), a[1], a[3], a[4]
-                if a[5] is not None:
-                    c.l0, c.l1 = addr(a[5]), a[6]
-                relink.append((i, "p1", a, 2))
             elif r.fn is L.sea_ib_add:
                 c.op, c.p0 = N.OP_IB, addr(r.keep)
-            elif r.fn is L.sea_rowchain:
-                c.op, c.p0, c.p1, c.dtype = N.OP_CHAIN, addr(r.keep[1]), addr(r.keep[0].host), a[2]
             elif r.fn is L.sea_convert_f32_to_act:
                 c.op, c.l0, c.p1, c.l1, c.l2, c.l3, c.dtype = N.OP_CONVERT, a[1], a[2], a[3], a[4], a[5], a[6]
                 relink.append((i, "p0", a, 0))
@@ -1235,6 +1053,7 @@ class TemporalEngine:
         p = self.train_plan(B, T)
         p.bind(x, ib, out)
         p.held = (x, ib)  # the backward list reads the inputs again: keep them alive until the next forward
+        p.generation = getattr(p, "generation", 0) + 1   # identifies the activation set now in the plan's workspace (autograd.py checks it)
         if p.drop_thr > 0:
             self._drop_step += 1
             p.set_dropout_seed((torch.initial_seed() * 0x9E3779B1 + self._drop_step * 0x85EBCA77) & 0xFFFFFFFF)
@@ -1258,16 +1077,17 @@ class TemporalEngine:
                                         out.numel(), grad_scale, N.stream_ptr()), "sea_mse_fwd_bwd")
         return loss, dout
 
-    def train_step(self, x: torch.Tensor, target: torch.Tensor, ib: torch.Tensor, optimizer) -> torch.Tensor:
+    def train_step(self, x: torch.Tensor, target: torch.Tensor, ib: torch.Tensor, optimizer, allreduce: bool = True) -> torch.Tensor:
         """One fused train step (train/train_temporal.py:254-258): zero grads, forward, MSE + its gradient, backward, ONE gradient
-        all-reduce when torch.distributed is initialised, AdamW.  Returns the local loss as a device scalar (no host sync)."""
+        all-reduce when torch.distributed is initialised (`allreduce=False`: a rank-local step, e.g. to time the step without the collective),
+        AdamW.  Returns the local loss as a device scalar (no host sync)."""
         from .parallel import allreduce_flat_gradients
 
         optimizer.zero_grad(set_to_none=False)
         out, plan = self.forward_train(x, ib)
         loss, dout = self.mse_loss_and_grad(out, target)
         self.backward(plan, dout)
-        optimizer.grad_scale = allreduce_flat_gradients(self.grads, self.params.n_live)
+        optimizer.grad_scale = allreduce_flat_gradients(self.grads, self.params.n_live) if allreduce else 1.0
         optimizer.step()
         return loss
 
@@ -1317,6 +1137,10 @@ class TemporalEngine:
         assert one == 1 and ib.shape[0] == B and ib.shape[1] >= n_steps
         if n_steps > self.model.max_len:
             raise ValueError(f"rollout of {n_steps} steps exceeds max_len {self.model.max_len}")
+        if self.model.src_len > 0:
+            # the reference masks with tril(diagonal=src_len) (models/base_blocks.py:173, 265): in its recompute loop the rows already produced re-attend
+            # to the src_len rows appended after them, so their K/V and everything downstream change from step to step — a cache is not exact
+            raise NotImplementedError("sea_amd: the KV-cache rollout is exact only for src_len == 0; use the recompute rollout (rollout(..., mode='recompute'))")
         self.params.sync()
         traj = torch.empty(n_steps + 1, B, F, E, device=self.device, dtype=torch.float32)
         traj[0].copy_(x0[:, 0])

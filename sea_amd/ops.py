@@ -366,83 +366,6 @@ def attention_bwd(problems: Sequence[Dict], rope: torch.Tensor, B: int, H: int, 
     N.check(N.lib().sea_attention_bwd(C.byref(P), N.dtype_code(dtype), N.stream_ptr()), "sea_attention_bwd")
 
 
-# ---------------------------------------------------------------------------------------------------- row-local chains
-_CHAIN_PTRS = ("W", "X", "bias", "R", "ib_w1", "ib_b1", "ib_lnw", "ib_lnb", "ib_w2", "ib_b2", "C32", "Cact", "gamma", "beta", "mod",
-               "Nact", "N32", "rope", "Qout", "Kout", "Vtout")
-_CHAIN_LD = {"W": "ldw", "X": "ldx", "R": "ldr", "C32": "ldc32", "Cact": "ldcact", "mod": "ldmod", "Nact": "ldnact", "N32": "ldn32"}
-
-
-def fill_chain_stage(st: "N.SeaChainStage", d: dict) -> None:
-    """Fill one SeaChainStage from a dict of tensors / scalars (keys = field names; tensors give pointer and row stride).
-    `X_off` / `R_off` / `N32_off` (byte offsets) select the per-call bases bind.x / bind.x / bind.out instead of an address."""
-    st.kind = int(d.get("kind", 0))
-    st.a_slot = int(d.get("a_slot", 0))
-    st.N, st.K = int(d["N"]), int(d.get("K", 0))
-    st.raw_slot, st.norm_slot = int(d.get("raw_slot", -1)), int(d.get("norm_slot", -1))
-    st.bias_scale = float(d.get("bias_scale", 1.0))
-    for k in ("x_is_act", "act", "sum_op", "ib_h", "norm", "qkv", "col0", "hd"):
-        setattr(st, k, int(d.get(k, 0)))
-    st.q_scale = float(d.get("q_scale", 1.0))
-    for k in _CHAIN_PTRS:
-        t = d.get(k)
-        setattr(st, k, None if t is None else t.data_ptr())
-        if t is not None and k in _CHAIN_LD:
-            setattr(st, _CHAIN_LD[k], int(d.get(_CHAIN_LD[k], t.stride(0))))
-    ext = 0
-    for bit, key, field, ld in ((1, "X_off", "X", "ldx"), (2, "R_off", "R", "ldr"), (4, "N32_off", "N32", "ldn32")):
-        if d.get(key) is not None:
-            ext |= bit
-            setattr(st, field, int(d[key]))
-            setattr(st, ld, int(d[ld]))
-    st.ext = ext
-
-
-class ChainProgram:
-    """Stage table of one sea_rowchain launch: host mirror (validation) + device copy (what the kernel reads)."""
-
-    def __init__(self, groups: Sequence[Sequence[dict]], device):
-        n = sum(len(g) for g in groups)
-        assert 1 <= len(groups) <= N.CHAIN_MAX_GROUPS
-        self.host = (N.SeaChainStage * n)()
-        self.first = [0]
-        self.keep = []
-        i = 0
-        for g in groups:
-            for d in g:
-                fill_chain_stage(self.host[i], d)
-                self.keep.append([v for v in d.values() if isinstance(v, torch.Tensor)])
-                i += 1
-            self.first.append(i)
-        raw = bytes(memoryview(self.host).cast("B"))
-        self.dev = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(device)
-        self.n_groups = len(groups)
-
-    def launch_struct(self, M, T, pos0, cap, H, eps=1e-5, x=None, out=None, cond=None) -> "N.SeaChainLaunch":
-        L = N.SeaChainLaunch()
-        L.stages, L.n_groups = self.dev.data_ptr(), self.n_groups
-        for i, f in enumerate(self.first):
-            L.first[i] = f
-        L.x, L.out, L.cond = N.ptr(x), N.ptr(out), N.ptr(cond)
-        L.M, L.T, L.pos0, L.cap, L.H, L.eps = M, T, pos0, cap, H, eps
-        return L
-
-
-def rowchain(groups: Sequence[Sequence[dict]], M: int, T: int, pos0: int, cap: int, H: int, dtype, eps: float = 1e-5,
-             x=None, out=None, cond=None) -> None:
-    """Row-local operator chains (sea_rowchain): `groups[g]` is the stage list of chain g, see include/sea_hip.h."""
-    dev = None
-    for g in groups:
-        for d in g:
-            for v in d.values():
-                if isinstance(v, torch.Tensor):
-                    N.require_gpu(v, "rowchain operand")
-                    dev = v.device
-    prog = ChainProgram(groups, dev)
-    L = prog.launch_struct(M, T, pos0, cap, H, eps, x, out, cond)
-    N.check(N.lib().sea_rowchain(C.byref(L), prog.host, N.dtype_code(dtype), N.stream_ptr()), "sea_rowchain")
-    torch.cuda.current_stream().synchronize()  # the stage table is a temporary of this call
-
-
 def unpatchify(fields: torch.Tensor, layout: str, index_map: torch.Tensor, scale: torch.Tensor, shift: torch.Tensor, n_points: int,
                point_slot: Optional[torch.Tensor] = None) -> torch.Tensor:
     """out[b, index_map[p, c], f] = fields[b, p, f|c ...] * scale[f] + shift[f] (sea_unpatchify).  `layout` names the order of the last two
@@ -501,27 +424,3 @@ def mlp_fc1_ln_gelu(groups: Sequence[Dict], eps: float = 1e-5, dtype: torch.dtyp
             _mat(d[k], k)
         fill_mlp_group(g, d["A"], d["W1"], d["b1"], d["lnw"], d["lnb"], d["Hg"])
     N.check(N.lib().sea_mlp_fc1_ln_gelu(arr, len(groups), eps, N.dtype_code(dtype), N.stream_ptr()), "sea_mlp_fc1_ln_gelu")
-
-
-
-def cond_mlp_supported(dtype: torch.dtype, widths: Sequence[int]) -> bool:
-    """Shapes sea_cond_mlp instantiates: bf16, module width K = 2d in {128, 256, 512}."""
-    return dtype == torch.bfloat16 and all(k in (128, 256, 512) for k in widths)
-
-
-def fill_cond_group(g, w1: torch.Tensor, b1: torch.Tensor, W2: torch.Tensor, b2: torch.Tensor, Out: torch.Tensor) -> None:
-    g.w1, g.b1, g.W2, g.b2, g.Out = w1.data_ptr(), b1.data_ptr(), W2.data_ptr(), b2.data_ptr(), Out.data_ptr()
-    g.K, g.ldw, g.ldo = W2.shape[0], W2.stride(0), Out.stride(0)
-
-
-def cond_mlp(groups: Sequence[Dict], c: torch.Tensor, dtype: torch.dtype = torch.bfloat16) -> None:
-    """Out = W2 silu(w1 c + b1) + b2 for every AdaLN condition MLP in one launch (sea_cond_mlp): dicts with w1, b1 f32 [K], W2 [K,K], b2 f32 [K], Out [M,K];
-    c f32 [M]."""
-    assert c.dtype == torch.float32 and c.is_contiguous()
-    arr = (N.SeaCondGroup * len(groups))()
-    for g, d in zip(arr, groups):
-        _mat(d["W2"], "W2")
-        _mat(d["Out"], "Out")
-        assert d["W2"].shape[0] == d["W2"].shape[1] == d["Out"].shape[1] and d["Out"].shape[0] == c.shape[0]
-        fill_cond_group(g, d["w1"], d["b1"], d["W2"], d["b2"], d["Out"])
-    N.check(N.lib().sea_cond_mlp(arr, len(groups), c.data_ptr(), c.shape[0], N.dtype_code(dtype), None, 0, N.stream_ptr()), "sea_cond_mlp")

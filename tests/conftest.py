@@ -38,3 +38,8 @@ def rel_l2(a, b):
     a = np.asarray(a, dtype=np.float64)
     b = np.asarray(b, dtype=np.float64)
     return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
+
+
+def grad_sub_stride(numel, cap=384):
+    """Stride of the committed sub-sample of a flattened cfg3-shaped gradient (tests/golden/make_fixtures.py::sub_stride)."""
+    return max(1, numel // cap) | 1

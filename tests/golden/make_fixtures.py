@@ -365,6 +365,45 @@ def big_cases():
          pred_l2=n(pred.pow(2).sum(dim=(0, 3)).sqrt()))
 
 
+def sub_stride(numel, cap=384):
+    """Stride of the committed sub-sample of a flattened gradient: at most `cap` elements, never a multiple of a power-of-two row length
+    (odd), so the samples walk across rows and columns."""
+    st = max(1, numel // cap)
+    return st | 1
+
+
+def cfg3_train_case():
+    """cfg3-shaped training step of the reference (BASELINE.json configs[2] at one trajectory: E=256, H=8, F=3, T=2024, B=1 — every multi-tile
+    path of the backward is exercised at this size): train/train_temporal.py:254-258 once, fp32.  Stored: loss, eval- and train-mode output
+    sub-samples, and for every parameter with a gradient its L2 norm, its sum and a strided sub-sample (sub_stride)."""
+    print("cfg3_train")
+    cfg = OracleConfig(1, 256, 8, 2024, 8, 0, 3, 2, True, "adaln")
+    m = build_reference(cfg)
+    x, tgt, ib = recipe_inputs(1, 2024, cfg, seed=2024)
+    m.train()
+    loss_fn = torch.nn.MSELoss()
+    opt = ref_tu.initialize_optimizer(m, {"learning_rate": 1e-4})
+    opt.zero_grad()
+    o = m(x, ib)
+    loss = loss_fn(o, tgt)
+    loss.backward()
+    arrs = dict(cfg=cfg_meta(cfg), seed=np.array(2024), loss=np.array(loss.item(), dtype=np.float64), out_sub=n(o[:, ::97, :, ::13]),
+                dead_keys=np.array([k for k, p in m.named_parameters() if p.grad is None]))
+    keys = [k for k, p in m.named_parameters() if p.grad is not None]
+    arrs["grad_keys"] = np.array(keys)
+    arrs["grad_l2"] = np.array([float(m.get_parameter(k).grad.double().pow(2).sum().sqrt()) for k in keys], dtype=np.float64)
+    arrs["grad_sum"] = np.array([float(m.get_parameter(k).grad.double().sum()) for k in keys], dtype=np.float64)
+    for k in keys:
+        g = m.get_parameter(k).grad.reshape(-1)
+        arrs["gsub:" + k] = n(g[:: sub_stride(g.numel())])
+    opt.step()
+    # parameters after the AdamW step, same sub-sampling (lr 1e-4: the update is +-lr per element at step 1, so this pins signs)
+    for k in keys:
+        q = m.get_parameter(k).detach().reshape(-1)
+        arrs["p1sub:" + k] = n(q[:: sub_stride(q.numel())])
+    save("cfg3_train", **arrs)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default=None)
@@ -402,6 +441,8 @@ def main():
             fn()
     if args.big and args.only is None or args.only == "big":
         big_cases()
+    if args.big and args.only is None or args.only == "cfg3_train":
+        cfg3_train_case()
 
 
 if __name__ == "__main__":

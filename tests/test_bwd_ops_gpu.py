@@ -202,10 +202,20 @@ def _rope(x, table):  # x [B,T,H,hd]
 @pytest.mark.parametrize("hd", [8, 16, 32, 64, 128])
 @pytest.mark.parametrize("T,src_len", [(1, 0), (50, 0), (130, 0), (200, 3)])
 def test_attention_backward(dtype, hd, T, src_len):
+    _attention_backward_case(dtype, hd, T, src_len, B=2, H=3)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("hd", [16, 32])
+def test_attention_backward_full_length(dtype, hd):
+    """T = 2024 (cfg3's sequence length: 32 key tiles per query tile, the multi-tile dK/dV walk) at the two head dims of the cfg2 / cfg3 model."""
+    _attention_backward_case(dtype, hd, 2024, 0, B=1, H=2)
+
+
+def _attention_backward_case(dtype, hd, T, src_len, B, H):
     """dQ/dK/dV of the q/k/v projection outputs (RoPE and scale undone) against autograd through rope -> scale -> masked softmax."""
     from sea_amd import ops
 
-    B, H = 2, 3
     E = H * hd
     cap = (T + 7) // 8 * 8
     scale = hd ** -0.5

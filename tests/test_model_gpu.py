@@ -81,9 +81,11 @@ def test_ablation_variants_rollout_bf16_and_training_refused(xmode, ibmode, ibsc
     assert rel_l2(out.cpu().numpy(), ref.numpy()) < BF16_TOL
     m32 = build(cfg, "fp32")
     a = rollout(m32, x[:, :1].cuda(), ib.cuda(), 12, mode="recompute")
-    if xmode == "pool":   # its window-relative sinusoidal positions are not covered by the KV-cache step plan: refused loudly
+    if xmode == "pool":   # its window-relative sinusoidal positions are not covered by the KV-cache step plan: the engine refuses loudly, the
+        # rollout front end (what the evaluation loops call) falls back to the recompute loop
         with pytest.raises(NotImplementedError, match="KV-cache"):
-            rollout(m32, x[:, :1].cuda(), ib.cuda(), 12, mode="kv")
+            m32.engine().rollout_kv(x[:, :1].cuda(), ib.cuda(), 12)
+        assert torch.equal(rollout(m32, x[:, :1].cuda(), ib.cuda(), 12, mode="kv"), a)
     else:
         b = rollout(m32, x[:, :1].cuda(), ib.cuda(), 12, mode="kv")
         assert rel_l2(b.cpu().numpy(), a.cpu().numpy()) < 1e-5
@@ -91,6 +93,46 @@ def test_ablation_variants_rollout_bf16_and_training_refused(xmode, ibmode, ibsc
     m32.train()
     with pytest.raises(NotImplementedError, match="training"):
         m32(x.cuda(), ib.cuda())
+
+
+def test_kv_rollout_with_src_len_is_refused_and_falls_back_to_recompute():
+    """src_len > 0: the reference's recompute loop lets rows already produced attend to the src_len rows appended after them (mask
+    tril(diagonal=src_len), models/base_blocks.py:173), so a K/V cache is not exact: the engine refuses, rollout() recomputes, and that
+    recompute rollout matches the CPU oracle's restatement of the reference loop."""
+    from sea_amd.utils.train_utils import rollout
+
+    g = load_golden("model_small_srclen2")
+    cfg = cfg_from_meta(g["cfg"])
+    assert cfg.src_len == 2
+    m = build(cfg, "fp32")
+    x, ib = gpu(g["x"]), gpu(g["ib"])
+    with pytest.raises(NotImplementedError, match="src_len"):
+        m.engine().rollout_kv(x[:, :1].contiguous(), ib, 6)
+    a = rollout(m, x[:, :1].contiguous(), ib, 6, mode="kv")
+    b = rollout(m, x[:, :1].contiguous(), ib, 6, mode="recompute")
+    assert torch.equal(a, b)
+    ref = O.rollout(torch.from_numpy(g["x"])[:, :1], torch.from_numpy(g["ib"]), 6, recipe_params(cfg), cfg)
+    assert rel_l2(a.cpu().numpy(), ref.numpy()) < FP32_TOL
+
+
+def test_backward_after_second_forward_of_same_shape_raises():
+    """One activation set per (batch, length) lives in the training plan's workspace: a backward whose activations were replaced by a later
+    grad-enabled forward must fail loudly instead of returning wrong gradients (torch itself would handle the pattern)."""
+    from sea_amd.utils.train_utils import SeaMSELoss
+
+    g = load_golden("model_tiny_adaln_f3")
+    cfg = cfg_from_meta(g["cfg"])
+    m = build(cfg, "fp32").train()
+    x, tgt, ib = gpu(g["x"]), gpu(g["tgt"]), gpu(g["ib"])
+    out1 = m(x, ib)
+    out2 = m(x * 0.5, ib)
+    with pytest.raises(RuntimeError, match="overwritten"):
+        SeaMSELoss()(out1, tgt).backward()
+    SeaMSELoss()(out2, tgt).backward()          # the latest forward's backward is fine
+    out3 = m(x, ib)
+    with torch.no_grad():
+        m(x * 0.5, ib)                          # an eval-style forward between forward and backward does not touch the training plan
+    SeaMSELoss()(out3, tgt).backward()
 
 
 @pytest.mark.parametrize("name", MODEL_CASES)
@@ -368,13 +410,13 @@ def test_shipped_multiphase_dims_forward_bf16():
     assert rel_l2(roll.numpy(), ref_roll.numpy()) < 2 * BF16_TOL
 
 
-@pytest.mark.parametrize("env,graphed", [({"SEA_FUSED": "1"}, False), ({"SEA_PLAN_LANES": "all"}, True), ({"SEA_PLAN_LANES": "cond"}, True),
-                                         ({"SEA_FUSE_NORM": "0"}, False), ({"SEA_FUSE_XTAIL": "0"}, False), ({"SEA_FUSE_SILU": "1"}, False), ({"SEA_FOLD_IB": "0"}, False), ({"SEA_FUSE_MLP1": "1"}, False), ({"SEA_FUSE_COND": "1"}, False), ({"SEA_FUSE_OPROJ": "1"}, False), ({"SEA_FUSE_KV": "1"}, False), ({"SEA_FUSE_TAIL": "1", "SEA_FUSE_FINAL": "1"}, False),
+@pytest.mark.parametrize("env,graphed", [({"SEA_PLAN_LANES": "all"}, True), ({"SEA_PLAN_LANES": "cond"}, True),
+                                         ({"SEA_FUSE_NORM": "0"}, False), ({"SEA_FUSE_XTAIL": "0"}, False), ({"SEA_FUSE_SILU": "1"}, False), ({"SEA_FOLD_IB": "0"}, False), ({"SEA_FUSE_MLP1": "1"}, False), ({"SEA_FUSE_OPROJ": "1"}, False), ({"SEA_FUSE_KV": "1"}, False), ({"SEA_FUSE_TAIL": "1", "SEA_FUSE_FINAL": "1"}, False),
                                          ({"SEA_FUSE_TAIL": "1", "SEA_FUSE_FINAL": "1", "SEA_GEMM_NORM_ROWS": "64"}, False)])
 @pytest.mark.parametrize("dtype,tol", [("fp32", 2e-6), ("bf16", 2e-2)])
 def test_optional_plans_match_default_plan(env, graphed, dtype, tol, monkeypatch):
-    """The opt-in plans (row-local chains in one launch; parallel graph branches) compute what the default launch list computes —
-    checked on the oracle too, at widths the chain kernel supports (E=128, D=64; two layers; B=2 so rows cross a trajectory)."""
+    """The opt-in plans (fusion switches; parallel graph branches) compute what the default launch list computes — checked on the oracle too
+    (E=128, D=64; two layers; B=2 so rows cross a trajectory)."""
     cfg = O.OracleConfig(2, 128, 4, 96, 8, 0, 3, 2, True, "adaln")
     x, _, ib = recipe_inputs(2, 70, cfg, seed=5)
     xg, ibg = x.to("cuda:0").contiguous(), ib.to("cuda:0").contiguous()
@@ -388,9 +430,7 @@ def test_optional_plans_match_default_plan(env, graphed, dtype, tol, monkeypatch
         out = eng.forward_graphed(xg, ibg).clone() if graphed else m(xg, ibg)
         plan = eng.plan(2, 70, "full")
     names = [r.name for r in plan.records]
-    if "SEA_FUSED" in env:
-        assert plan.fused and any(r.name.startswith("cross0.proj_up_down_kv") for r in plan.records)
-    elif "SEA_FUSE_KV" in env:     # one hoisted QKV+RoPE launch + the K/V stage of the tails instead of per-field launches (bf16; opt-in)
+    if "SEA_FUSE_KV" in env:     # one hoisted QKV+RoPE launch + the K/V stage of the tails instead of per-field launches (bf16; opt-in)
         assert (dtype == "bf16") == ("cross.qkv_rope_old" in names) and (dtype == "fp32") == ("cross1.qkv_rope" in names)
     elif "SEA_FUSE_OPROJ" in env:  # self-attention output projection with cross_down + ln_cross in one launch (opt-in)
         assert (dtype == "fp32") == ("self.out_proj" in names) and (dtype == "bf16") == ("self.out_proj_down_norm" in names)
@@ -400,8 +440,6 @@ def test_optional_plans_match_default_plan(env, graphed, dtype, tol, monkeypatch
         e2 = build(cfg, dtype).engine()
         assert "mlp.fc1" in [r.name for r in e2.plan(2, 70, "full").records]
         assert ("mlp.fc1_ln_gelu" in [r.name for r in e2.plan(16, 70, "full").records]) == (dtype == "bf16")
-    elif "SEA_FUSE_COND" in env:   # the condition MLPs of every module in one sea_cond_mlp launch (bf16; opt-in) instead of the silu launch + grouped GEMM
-        assert (dtype == "bf16") == ("adaln.cond_mlp" in names) and (dtype == "fp32") == ("adaln.cond_gemm" in names)
     elif "SEA_FOLD_IB" in env:     # the info-bottleneck add as its own launch (default: evaluated in the silu launch, added by the AdaLN_2 pass)
         assert "ib_add" in names and "mlp.adaln2" in names and "mlp.ib_adaln2" not in names
     elif "SEA_FUSE_SILU" in env:   # AdaLN condition MLPs with the generated operand (default only for long launches)

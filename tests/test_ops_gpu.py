@@ -590,60 +590,6 @@ def test_mlp_fc1_ln_gelu_matches_two_launch_form(E, S, M):
         assert rel(Hg.float(), hg2.float()) < 8e-3
 
 
-@pytest.mark.parametrize("M", [3, 77, 2024])
-def test_cond_mlp_matches_two_launch_form(M):
-    """sea_cond_mlp (cond_mlp.0 + SiLU + cond_mlp.2 of every AdaLN module in one launch, hidden rows generated in LDS) against the fp32 formula on the
-    bf16-rounded hidden rows and against the two launches it replaces (sea_silu_outer, sea_gemm_grouped); widths 512, 256 and 128 mixed in one launch,
-    plus two information-bottleneck layers evaluated by the same launch."""
-    import ctypes as C
-    from sea_amd import _native as N, ops
-
-    dt = torch.bfloat16
-    c = torch.rand(M, device=dev())
-    groups, refs = [], []
-    for i, K in enumerate((512, 256, 128, 512, 256)):
-        w1, b1 = rnd(K, seed=1400 + i), rnd(K, seed=1410 + i)
-        W2, b2 = rnd(K, K, dtype=dt, scale=0.06, seed=1420 + i), 0.3 * rnd(K, seed=1430 + i)
-        Out = torch.full((M, K), float("nan"), device=dev(), dtype=dt)
-        groups.append(dict(w1=w1, b1=b1, W2=W2, b2=b2, Out=Out))
-        hid = torch.nn.functional.silu(c[:, None] * w1 + b1).to(dt).float()
-        refs.append(hid @ W2.float().t() + b2)
-    assert ops.cond_mlp_supported(dt, [512, 256])
-    arr = (N.SeaCondGroup * len(groups))()
-    for g, d in zip(arr, groups):
-        ops.fill_cond_group(g, d["w1"], d["b1"], d["W2"], d["b2"], d["Out"])
-    E, h = 256, 8
-    ibs = (N.SeaIbParams * 2)()
-    prm, bufs = [], []
-    for k in range(2):
-        q = dict(w1=rnd(h, seed=1440 + k), b1=rnd(h, seed=1450 + k), lnw=1 + 0.1 * rnd(h, seed=1460 + k), lnb=0.1 * rnd(h, seed=1470 + k),
-                 w2=rnd(E, h, scale=0.3, seed=1480 + k), b2=0.1 * rnd(E, seed=1490 + k))
-        buf = torch.full((M, E), float("nan"), device=dev())
-        ibs[k].X[0], ibs[k].n_fields, ibs[k].ldx, ibs[k].M, ibs[k].E, ibs[k].h = buf.data_ptr(), 1, E, M, E, h
-        ibs[k].w1, ibs[k].b1, ibs[k].lnw, ibs[k].lnb, ibs[k].w2, ibs[k].b2 = (q[n].data_ptr() for n in ("w1", "b1", "lnw", "lnb", "w2", "b2"))
-        prm.append(q)
-        bufs.append(buf)
-    N.check(N.lib().sea_cond_mlp(arr, len(groups), c.data_ptr(), M, N.dtype_code(dt), ibs, 2, N.stream_ptr()), "sea_cond_mlp")
-    for d, ref in zip(groups, refs):
-        assert rel(d["Out"].float(), ref) < 4e-3
-        K = d["W2"].shape[0]
-        hid = torch.empty(M, K, device=dev(), dtype=dt)
-        out2 = torch.empty(M, K, device=dev(), dtype=dt)
-        ops.silu_outer([dict(w1=d["w1"], b1=d["b1"], Hid=hid)], c, M, dt)
-        ops.gemm_grouped([dict(A=hid, W=d["W2"], bias=d["b2"], Cact=out2)], dt)
-        assert rel(d["Out"].float(), out2.float()) < 4e-3
-    for q, buf in zip(prm, bufs):
-        ref = gelu(torch.nn.functional.layer_norm(c[:, None] * q["w1"] + q["b1"], (h,), q["lnw"], q["lnb"], 1e-5)) @ q["w2"].t() + q["b2"]
-        assert rel(buf, ref) < 2e-5
-    # the plain wrapper (no information-bottleneck layers), and a refusal of other widths
-    for d in groups:
-        d["Out"].fill_(float("nan"))
-    ops.cond_mlp(groups, c)
-    for d, ref in zip(groups, refs):
-        assert rel(d["Out"].float(), ref) < 4e-3
-    assert not ops.cond_mlp_supported(dt, [64]) and not ops.cond_mlp_supported(torch.float32, [512])
-
-
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_rownorm_ln_gelu_act_input(dtype):
     from sea_amd import ops

@@ -180,6 +180,28 @@ def test_cfg2_shape_forward():
     assert np.allclose(out.pow(2).sum(dim=(0, 1, 3)).sqrt().numpy(), g["out_l2"], rtol=1e-5)
 
 
+def test_cfg3_train_step_matches_reference():
+    """BASELINE.json configs[2] shape at one trajectory (E=256, H=8, F=3, T=2024): loss, the set of gradient-less parameters, and every live
+    parameter's gradient (L2 norm, sum, strided sub-sample) of the oracle's autograd against the reference's (train/train_temporal.py:254-258)."""
+    from oracle.recipe import recipe_inputs
+    from tests.conftest import grad_sub_stride
+
+    g = load_golden("cfg3_train")
+    cfg = cfg_from_meta(g["cfg"])
+    p = recipe_params(cfg)
+    x, tgt, ib = recipe_inputs(1, 2024, cfg, seed=int(g["seed"]))
+    out, loss, grads = O.loss_and_grads(x, ib, tgt, p, cfg)
+    assert abs(float(loss) - float(g["loss"])) < 1e-6 * float(g["loss"])
+    assert rel_l2(out[:, ::97, :, ::13], g["out_sub"]) < 5e-6
+    keys = [str(k) for k in g["grad_keys"]]
+    assert sorted(grads.keys()) == sorted(keys)
+    assert sorted(k for k in p if k not in grads) == sorted(str(k) for k in g["dead_keys"])
+    for k, l2 in zip(keys, g["grad_l2"]):
+        gr = grads[k].reshape(-1)
+        assert abs(float(gr.double().norm()) - l2) < 2e-5 * l2, k
+        assert rel_l2(gr[:: grad_sub_stride(gr.numel())], g["gsub:" + k]) < 5e-5, k
+
+
 def test_schema_counts():
     cfg = O.OracleConfig(1, 256, 8, 2024, 8, 0, 3, 2, True, "adaln")
     s = param_schema(cfg)

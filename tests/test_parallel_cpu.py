@@ -69,3 +69,20 @@ def test_single_process_is_identity():
     assert parameters_in_sync(g)
     with pytest.raises(ValueError):
         shard_batch(torch.zeros(7, 2), 0, 2)
+
+
+def test_bench_parent_launches_ranks_and_fails_cleanly_without_gpus():
+    """`python bench.py --gpus 2` as a plain command: the parent starts the rank processes itself (no torch.distributed.run needed) and, in this
+    GPU-less container, reports their failure with a non-zero exit code instead of hanging or raising a traceback of its own."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--mode", "train", "--steps", "1", "--warmup", "1"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible: this checks the no-GPU failure path only")
+    assert r.returncode == 1
+    assert "rank exit codes" in r.stderr and "needs an MI355X" in r.stderr
+    assert "{" not in r.stdout
