@@ -102,6 +102,28 @@ __device__ __forceinline__ float gelu_erf_grad(float x) {
     erf_gauss(x, e, g);
     return 0.5f * (1.0f + e) + x * 0.39894228040143267794f * g;
 }
+// GELU for results that are rounded to bf16 at once: x Phi(x) with Phi(x) - 1/2 = x P(x^2) on |x| <= 4 (degree-7 polynomial in x^2, Chebyshev fit of
+// erf(x / sqrt 2) / (2 x)), the argument clamped to [-4, 4] (1 - Phi(4) = 3e-5).  |error| <= 1.8e-4 for |x| <= 4 and <= 7e-5 |x| beyond — below the bf16
+// rounding of the result (2^-9 relative) over the range LayerNorm outputs live in — for 11 plain fp32 instructions and no v_exp / v_rcp (quarter rate),
+// against ~22 + 2 transcendental for the A&S form above.  The fp32 path (parity bar 1e-4) never uses it.
+__device__ __forceinline__ float gelu_erf_bf16(float x) {
+    const float xc = __builtin_amdgcn_fmed3f(x, -4.0f, 4.0f);
+    const float u = xc * xc;
+    float p = -1.903182723e-09f;
+    p = fmaf(p, u, 1.410586208e-07f);
+    p = fmaf(p, u, -4.565313247e-06f);
+    p = fmaf(p, u, 8.634554251e-05f);
+    p = fmaf(p, u, -1.085383119e-03f);
+    p = fmaf(p, u, 9.789848700e-03f);
+    p = fmaf(p, u, -6.636063010e-02f);
+    p = fmaf(p, u, 3.989269733e-01f);
+    return x * fmaf(xc, p, 0.5f);
+}
+template <typename T>
+__device__ __forceinline__ float gelu_for(float x) {   // the GELU whose result is stored as T
+    if constexpr (sizeof(T) == 2) return gelu_erf_bf16(x);
+    else return gelu_erf(x);
+}
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
 
 // ------------------------------------------------------------------------------------------------ scalar-lane fp32 arithmetic
