@@ -46,8 +46,9 @@ class Decode(nn.Module):
         self.decoders = nn.ModuleList([upScaleMLP(d_model=embed_dim, d_output=n_inp * len(g), hidden_dim=MLP_hidden) for g in self.field_groups])
         self.compute_dtype = "fp32"
         self._shadow = None  # (key, [W1 act], [W2 act])
-        if embed_dim % 8 or MLP_hidden % 8 or n_inp % 4:
-            raise NotImplementedError("sea_amd.Decode: embed_dim and MLP_hidden must be multiples of 8, n_inp a multiple of 4 (16-byte operand rows)")
+        if embed_dim % 8 or MLP_hidden % 8:
+            raise NotImplementedError("sea_amd.Decode: embed_dim and MLP_hidden must be multiples of 8 (16-byte operand rows)")
+        self._n_inp_p = (n_inp + 3) // 4 * 4   # a field's output columns are padded to 16 bytes inside (n_inp is the padded cell size: data-dependent in the reference)
 
     def set_compute_dtype(self, dtype) -> "Decode":
         name = {torch.float32: "fp32", torch.bfloat16: "bf16"}.get(dtype, dtype)
@@ -58,12 +59,22 @@ class Decode(nn.Module):
 
     def _weights(self, dt: torch.dtype):
         """Activation-dtype copies of the Linear weights, refreshed when a parameter was written (version counter) or moved."""
-        ps = [d.layer1.weight for d in self.decoders] + [d.layer2.weight for d in self.decoders]
+        ps = [d.layer1.weight for d in self.decoders] + [d.layer2.weight for d in self.decoders] + [d.layer2.bias for d in self.decoders]
         key = (dt, tuple((p.data_ptr(), p._version) for p in ps))
         if self._shadow is None or self._shadow[0] != key:
             with torch.no_grad():
                 conv = lambda p: p.detach().contiguous() if dt == torch.float32 else p.detach().to(dt).contiguous()
-                self._shadow = (key, [conv(d.layer1.weight) for d in self.decoders], [conv(d.layer2.weight) for d in self.decoders])
+                C, Cp = self.n_inp, self._n_inp_p
+
+                def pad_out(t, grp):   # layer2 rows / bias entries of field f at [f C, (f + 1) C) -> [f Cp, f Cp + C); the pad rows are zero
+                    if Cp == C:
+                        return t.detach()
+                    out = torch.zeros((len(grp), Cp) + tuple(t.shape[1:]), device=t.device, dtype=t.dtype)
+                    out[:, :C] = t.detach().view((len(grp), C) + tuple(t.shape[1:]))
+                    return out.view((len(grp) * Cp,) + tuple(t.shape[1:]))
+
+                self._shadow = (key, [conv(d.layer1.weight) for d in self.decoders], [conv(pad_out(d.layer2.weight, g)) for d, g in zip(self.decoders, self.field_groups)],
+                                [pad_out(d.layer2.bias, g).float().contiguous() for d, g in zip(self.decoders, self.field_groups)])
         return self._shadow[1], self._shadow[2]
 
     def forward(self, z: torch.Tensor) -> torch.Tensor:
@@ -80,16 +91,18 @@ class Decode(nn.Module):
             ops.convert(zf, za)
         W1, W2 = self._weights(dt)
         n_fields = sum(len(g) for g in self.field_groups)
-        out = torch.empty(M, n_fields * self.n_inp, device=z.device, dtype=torch.float32)
+        Cp = self._n_inp_p
+        out = torch.empty(M, n_fields * Cp, device=z.device, dtype=torch.float32)
         hid: List[torch.Tensor] = [torch.empty(M, self.MLP_hidden, device=z.device, dtype=dt) for _ in range(G)]
         ops.gemm_grouped([dict(A=za[:, g * D:(g + 1) * D], W=W1[g], Cact=hid[g], act=1) for g in range(G)], dt)
         groups, off = [], 0
         for g, grp in enumerate(self.field_groups):
-            w = len(grp) * self.n_inp
-            groups.append(dict(A=hid[g], W=W2[g], bias=self.decoders[g].layer2.bias.detach(), C32=out[:, off:off + w]))
+            w = len(grp) * Cp
+            groups.append(dict(A=hid[g], W=W2[g], bias=self._shadow[3][g], C32=out[:, off:off + w]))
             off += w
         ops.gemm_grouped(groups, dt)
-        return out.view(B, P, n_fields, self.n_inp)
+        out = out.view(B, P, n_fields, Cp)
+        return out if Cp == self.n_inp else out[..., :self.n_inp]   # a strided view: sea_unpatchify reads it in place
 
 
 def _round_up(x: int, m: int) -> int:
@@ -123,9 +136,10 @@ class PointwiseEncode(nn.Module):
         for g in self.field_groups:
             if g != list(range(g[0], g[0] + len(g))):
                 raise NotImplementedError("sea_amd.PointwiseEncode: a field group must be a run of consecutive field indices (column slice of the [M, F*C] input)")
-        if W % n_heads or (W // n_heads) % 4 or W % 8 or MLP_hidden % 8 or embed_dim % 4 or n_inp % 4:
+        if W % n_heads or (W // n_heads) % 4 or W % 8 or MLP_hidden % 8 or embed_dim % 4:
             raise NotImplementedError("sea_amd.PointwiseEncode: need n_groups*embed_dim a multiple of 8 and of n_heads, head dim and embed_dim multiples of 4, "
-                                      "MLP_hidden a multiple of 8, n_inp a multiple of 4")
+                                      "MLP_hidden a multiple of 8")
+        self._n_inp_p = (n_inp + 3) // 4 * 4   # a field's cell columns are padded to 16 bytes inside (zero weight columns: exact)
         if (W // n_heads) > 128:
             raise NotImplementedError("sea_amd.PointwiseEncode: head dim above 128")
 
@@ -160,12 +174,13 @@ class PointwiseEncode(nn.Module):
         with torch.no_grad():
             conv = lambda t: t.detach().to(device=dev, dtype=dt).contiguous()  # noqa: E731
             enc = []
+            C, Cp = self.n_inp, self._n_inp_p
             for g, m in zip(self.field_groups, self.encoders):
-                K = len(g) * self.n_inp
+                K = len(g) * Cp
                 Kp = _round_up(K, 8)
                 w1 = torch.zeros(self.MLP_hidden, Kp, device=dev, dtype=dt)
-                w1[:, :K] = m.layer1.weight.detach().to(dt)
-                enc.append(dict(K=K, Kp=Kp, col0=g[0] * self.n_inp, W1=w1, W2=conv(m.layer2.weight), b2=m.layer2.bias.detach().to(dev, f32).contiguous()))
+                w1[:, :K].view(self.MLP_hidden, len(g), Cp)[:, :, :C] = m.layer1.weight.detach().to(dt).view(self.MLP_hidden, len(g), C)
+                enc.append(dict(K=K, Kp=Kp, col0=g[0] * Cp, W1=w1, W2=conv(m.layer2.weight), b2=m.layer2.bias.detach().to(dev, f32).contiguous()))
 
             def pad_rows(w):   # [H*hd, ...] -> [H*hdp, ...], head h at rows h*hdp .. h*hdp + hd - 1
                 out = torch.zeros((H, hdp) + tuple(w.shape[1:]), device=dev, dtype=w.dtype)
@@ -214,7 +229,10 @@ class PointwiseEncode(nn.Module):
         dev = x.device
         pk = self._packed(dt, dev)
         W, G, H, hdp = self.num_groups * self.embed_dim, self.num_groups, self.n_heads, pk["hdp"]
-        xf = x.detach().to(torch.float32).contiguous().view(B * P, F * C)
+        xf = x.detach().to(torch.float32)
+        if self._n_inp_p != C:   # pad each field's cell columns to 16 bytes (one copy; sea_patchify can write this layout directly: c_out)
+            xf = torch.nn.functional.pad(xf, (0, self._n_inp_p - C))
+        xf = xf.contiguous().view(B * P, F * self._n_inp_p)
         out = torch.empty(B * P, W, device=dev, dtype=torch.float32)
         x_is_act = dt != torch.float32
         for b0 in range(0, B, self.CHUNK):

@@ -44,6 +44,8 @@ def train(config: Dict[str, Any], error_tracker):
         optimizer, scheduler = optimizer
     start = time.time()
     best_val = float('inf')
+    best_rollout = float('inf')
+    processor, mesh_processor = config.get('processor'), config.get('mesh_processor')   # the reference builds both in get_datasets (:225-230)
     error_tracker.log_model(model, loss_fn, optimizer)
     full_eval_interval = config.get('full_eval_interval', 50)
     for epoch in range(1, config['epoch_num'] + 1):
@@ -72,8 +74,17 @@ def train(config: Dict[str, Any], error_tracker):
             val_loss = val_sum.item() / max(n_val, 1)
             val_metrics = {"Loss": val_loss}
             if epoch % full_eval_interval == 0:
-                res = full_autoregressive_evaluation(model, validationLoader, loss_fn, device, None, None, config, epoch, plot_traj=False)
+                res = full_autoregressive_evaluation(model, validationLoader, loss_fn, device, processor, mesh_processor, config, epoch, plot_traj=False)
                 val_metrics["Full_Encoded_Rel_MSE"] = res['encoded_rel_mse']
+                if processor is not None and mesh_processor is not None:
+                    val_metrics["Full_Decoded_Rel_MSE"] = res['decoded_rel_mse']
+                # the reference keeps a second checkpoint on the best rollout error (:305-318), the decoded one when it can be computed
+                score = res['decoded_rel_mse'] if res['decoded_rel_mse'] == res['decoded_rel_mse'] else res['encoded_rel_mse']
+                if score < best_rollout and config.get('save_dir'):
+                    best_rollout = score
+                    path = f"{config['save_dir']}/temporal_Checkpoint_{config.get('case_name', 'case')}_{config.get('run_name', 'run')}.pt"
+                    torch.save({k: v.detach().cpu() for k, v in model.state_dict().items()}, path)
+                    print("--- New Best Rollout Checkpoint Saved ---")
             error_tracker.record_error("val", epoch, val_metrics)
             print(f"\nEpoch: {epoch}/{config['epoch_num']}  Train Loss: {train_loss:.8f}  " + "  ".join(f"{k}: {v:.8f}" for k, v in val_metrics.items()))
             if val_loss < best_val:

@@ -133,6 +133,114 @@ class MeshUnpatcher:
                               point_slot=self.partitioner.point_slot if self.gather else None)
 
 
+class MeshProcessor:
+    """MeshProcessor(config, coordinates) of the reference (utils/data_processors.py:454-573) on the device: `patchify_and_scale` (scale, partition into
+    the (m-1) x (n-1) cells, pad) and `inverse_scale_and_unpatch` (scatter back, inverse scaling), ONE launch each (sea_patchify / sea_unpatchify).
+    config keys as the reference: 'dimension' ('2D'; the 3-D partitioner is out of scope), 'field_groups', 'scale_feature_range' (None in both shipped
+    configs; a (lo, hi) pair builds one MinMaxScaler per field group — the reference's own constructor call at :481 passes a dict and cannot run),
+    'm', 'n', 'pad_id', 'pad_field_value'.  coordinates: [2, N]."""
+
+    def __init__(self, config, coordinates, device="cuda"):
+        self.config = config
+        self.dimension = config.get('dimension', '3D')
+        if 'field_groups' not in config:
+            raise ValueError("'field_groups' must be specified in the config dictionary")
+        if self.dimension != '2D':
+            raise NotImplementedError("sea_amd.MeshProcessor: only the 2-D partitioner is built (both shipped configs are 2-D)")
+        self.field_groups = [list(g) for g in config['field_groups']]
+        self.scale_feature_range = config.get('scale_feature_range')
+        self.coordinates = coordinates
+        self.device = torch.device(device)
+        self.scalers = [MinMaxScaler(tuple(self.scale_feature_range), name=f"{config.get('csv_scale_name', 'scaler')}-group{i}")
+                        for i in range(len(self.field_groups))] if self.scale_feature_range is not None else []
+        self.partitioner: Optional[DataPartitioner2D] = None
+        self._unpatcher: Optional[MeshUnpatcher] = None
+
+    def patchify_and_scale(self, data: torch.Tensor, train_indices=None):
+        """data [T, N, F] -> (stacked_coords [1, P, C, 2], fields [T, P, C, F]); the scalers are fitted on `data` when train_indices is given
+        (reference :484-526: it fits on everything it is handed, whatever the indices say)."""
+        data = data.to(self.device).float()
+        if self.scalers:
+            if train_indices is None and any(sc.min_val is None for sc in self.scalers):
+                raise ValueError("No saved scaler values found and train_indices is None.")
+            if train_indices is not None:
+                for sc, g in zip(self.scalers, self.field_groups):
+                    sc.fit(data[:, :, g])
+        self.partitioner = DataPartitioner2D(self.coordinates[0], self.coordinates[1], m=self.config['m'], n=self.config['n'], pad_id=self.config.get('pad_id', -1),
+                                             pad_field_value=self.config.get('pad_field_value', 0), device=self.device)
+        self._unpatcher = MeshUnpatcher(self.partitioner, self.field_groups, self.scalers)
+        fields = self._unpatcher.patchify_and_scale(data, layout="BPCF")
+        idx = self.partitioner.padded_index_map.long()
+        coords = self.partitioner.full_coords[idx.clamp_min(0)] * (idx >= 0)[..., None]
+        self.stacked_coords = coords[None]
+        return self.stacked_coords, fields
+
+    def inverse_scale_and_unpatch(self, scaled_fields: torch.Tensor, layout: str = "BPCF") -> torch.Tensor:
+        """[T, P, C, F] (the reference's argument; layout="BPFC" reads the decoder's [T, P, F, C] output in place) -> [T, N, F]."""
+        if self._unpatcher is None:
+            raise ValueError("call patchify_and_scale first (it builds the partition)")
+        return self._unpatcher.inverse_scale_and_unpatch(scaled_fields.to(self.device), layout=layout)
+
+
+class ProcessData:
+    """ProcessData(n_inp, config) of the reference (utils/data_processors.py:291-373): the frozen spatial autoencoder around the temporal model —
+    `initialize_and_process_data` / `process_data` encode padded patches [B, P, F, C] -> [B, P, G, D], `decode_data` decodes [B, P, G, D] ->
+    [B, P, n_fields, n_inp].  The model is built and loaded ONCE (the reference rebuilds it and re-reads the checkpoint on every call) and stays on the
+    device; inputs and outputs stay there too."""
+
+    def __init__(self, n_inp, config, device=None):
+        self.config, self.n_inp = config, n_inp
+        self.model_path = config['encoder_decoder_path']
+        self.batch_size = config.get('spatial_batch_size', 1000)
+        self.device = torch.device(device if device is not None else config.get('device', 'cuda'))
+        self.embed_dim = config['embed_dim_spatial']
+        if config['dimension'] == '3D':
+            self.P = (config['m'] - 1) * (config['n'] - 1) * (config['k'] - 1)
+        else:
+            self.P = (config['m'] - 1) * (config['n'] - 1)
+        self.model_spatial = None
+
+    def initialize_spatial_model(self):
+        from ..models.encoder_decoder import SpatialModel
+
+        c = self.config
+        m = SpatialModel(field_groups=c['field_groups'], n_inp=self.n_inp, MLP_hidden=c['MLP_hidden_spatial'], num_layers=c['num_layers_spatial'],
+                         embed_dim=c['embed_dim_spatial'], n_heads=c['n_heads_spatial'], max_len=c['block_size_spatial'], src_len=c['src_len_spatial'],
+                         variational=c['variational_spatial'], dropout=c['dropout_spatial'])
+        if 'dtype_spatial' in c:
+            m.set_compute_dtype(c['dtype_spatial'])
+        return m.to(self.device)
+
+    def load_model(self):
+        sd = self.model_path if isinstance(self.model_path, dict) else torch.load(self.model_path, map_location='cpu')
+        self.model_spatial.load_state_dict({k.replace("module.", ""): v for k, v in sd.items()})
+        self.model_spatial.eval()
+
+    def _model(self):
+        if self.model_spatial is None:
+            self.model_spatial = self.initialize_spatial_model()
+            self.load_model()
+        return self.model_spatial
+
+    def initialize_and_process_data(self, data):
+        if isinstance(data, torch.Tensor):
+            data = [data[i:i + self.batch_size] for i in range(0, data.shape[0], self.batch_size)]
+        return self.process_data(data)
+
+    def process_data(self, dataloader):
+        m = self._model()
+        out = []
+        with torch.no_grad():
+            for data in dataloader:
+                data = m.generate_padding_mask(data.to(self.device).float().clone())
+                out.append(m.encode(data))
+        return torch.cat(out, dim=0)
+
+    def decode_data(self, data):
+        with torch.no_grad():
+            return self._model().decode(data.to(self.device))
+
+
 class TemporalDataset:
     """Windows over encoded trajectories with the reference's indexing (utils/data_processors.py:388-452): sample idx of segment s covers steps
     [k*step + shift, k*step + shift + src_len), the target is the same window one step later.  Items are VIEWS of the (device-resident) trajectory

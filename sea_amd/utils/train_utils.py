@@ -8,6 +8,7 @@ reference-equivalent recompute mode and an exact KV-cache mode.
 """
 from __future__ import annotations
 
+import os
 from typing import Any, Dict
 
 import torch
@@ -94,30 +95,64 @@ def autoregressive_validation(model, validationLoader, loss_fn, device):
     with torch.no_grad():
         data, target, _, ib = next(iter(validationLoader))
         data, target, ib = data[0:1].to(device), target[0:1].to(device), ib[0:1].to(device)
-        pred = rollout(model, data[:, 0:1].contiguous(), ib, target.shape[1], mode=getattr(model, "rollout_mode", "kv"))
+        pred = rollout(model, data[:, 0:1].contiguous(), ib, target.shape[1], mode=_rollout_mode(model))
         v_loss = loss_fn(pred, target)
         v_rel_mse = relativeMSE_with_time(pred, target, dim=3).mean()
     return v_loss.item(), v_rel_mse.item()
 
 
 def full_autoregressive_evaluation(model, dataLoader, loss_fn, device, processor, mesh_processor, config, epoch, plot_traj=True):
-    """Encoded-space half of the reference's evaluation (:186-212): rollout every batch and average relativeMSE.  The decoded
-    metric needs the spatial autoencoder and mesh un-patching (out of scope): `decoded_rel_mse` is NaN unless a
-    `processor` with a `decode_rollout(pred, target_original)` method is supplied."""
+    """The reference's evaluation (:186-312) on the device: roll every batch out from its first step, relativeMSE in the encoded space; then —
+    when `processor` (ProcessData: the frozen spatial decoder) and `mesh_processor` (MeshProcessor) are given — decode the rollout
+    (inverse_transform_processed_data -> processor.decode_data), undo the SEA_isolate / SEA_mixed layout switch, un-patchify + inverse-scale
+    (mesh_processor.inverse_scale_and_unpatch) and take relativeMSE_with_time over the mesh points per step and field.  The per-step table goes to
+    `{save_dir}/rollout_error_{case_name}_{run_name}.csv` as in the reference; its contour plots are not produced.  Returns the reference's dict
+    {'encoded_rel_mse', 'decoded_rel_mse'} (None for an empty loader); decoded_rel_mse is NaN without the two processors."""
     model.eval()
     enc_sum, dec_sum, n_batches = 0.0, 0.0, 0
+    decode = processor is not None and mesh_processor is not None
     with torch.no_grad():
         for data, target, original_data, ib in dataLoader:
             data, target, ib = data.to(device), target.to(device), ib.to(device)
-            pred = rollout(model, data[:, 0:1].contiguous(), ib, target.shape[1], mode=getattr(model, "rollout_mode", "kv"))
+            pred = rollout(model, data[:, 0:1].contiguous(), ib, target.shape[1], mode=_rollout_mode(model, config))
             enc_sum += relativeMSE(pred, target).mean().item()
-            if processor is not None and hasattr(processor, "decode_rollout"):
-                dec_sum += float(processor.decode_rollout(pred, original_data))
+            if decode:
+                tr, T = pred.shape[0], pred.shape[1]
+                if config['dimension'] == '3D':
+                    n_patches = (config['m'] - 1) * (config['n'] - 1) * (config['k'] - 1)
+                else:
+                    n_patches = (config['m'] - 1) * (config['n'] - 1)
+                dec = processor.decode_data(inverse_transform_processed_data(pred, tr, T, n_patches, len(config['field_groups'])))   # [tr*T, P, F, C]
+                if config.get('SEA_mixed'):
+                    B_, P_, F_, C_ = dec.shape
+                    fields = mesh_processor.inverse_scale_and_unpatch(dec.reshape(B_, P_, C_, F_))
+                elif config.get('SEA_isolate'):
+                    fields = mesh_processor.inverse_scale_and_unpatch(dec, layout="BPFC")     # the permute(0, 1, 3, 2) of :225 is read in place
+                else:
+                    assert False, "Invalid SEA data configuration"
+                fields = fields.reshape(tr, T, fields.shape[1], fields.shape[2])
+                per_step = relativeMSE_with_time(fields, original_data.to(device).float(), dim=2).mean(dim=0)       # [T, F]
+                dec_sum += per_step.mean().item()
+                if config.get('save_dir') and os.path.isdir(config['save_dir']):
+                    import csv
+
+                    with open(f"{config['save_dir']}/rollout_error_{config.get('case_name', 'case')}_{config.get('run_name', 'run')}.csv", 'w', newline='') as f:
+                        w = csv.writer(f)
+                        w.writerow(['Time Step'] + [f'Field {i + 1}' for i in range(per_step.shape[1])])
+                        for i, row in enumerate(per_step.cpu().numpy()):
+                            w.writerow([i + 1] + list(row))
             else:
                 dec_sum = float("nan")
             n_batches += 1
-    n_batches = max(n_batches, 1)
+    if n_batches == 0:
+        return None
     return {"encoded_rel_mse": enc_sum / n_batches, "decoded_rel_mse": dec_sum / n_batches}
+
+
+def _rollout_mode(model, config=None) -> str:
+    if config is not None and config.get('rollout_mode'):
+        return config['rollout_mode']
+    return getattr(model, "rollout_mode", "kv")
 
 
 # ------------------------------------------------------------------------------------------------ error trackers (duck type, :50-110)
@@ -138,6 +173,12 @@ class NoOpErrorTracker:
 def create_error_tracker(use_wandb, project_name, run_name=None, config: Dict[str, Any] = None):
     """wandb is not part of this build: always the no-op tracker (the reference falls back to it when wandb is missing)."""
     return NoOpErrorTracker()
+
+
+def transform_processed_data(processed_data: torch.Tensor, tr: int, T: int, n_patches: int, num_field_groups: int) -> torch.Tensor:
+    """[tr*T, P, num_field_groups, D] -> [tr, T, num_field_groups, P*D] (reference utils/train_utils.py:315-337, same signature)."""
+    D = processed_data.shape[-1]
+    return processed_data.reshape(tr, T, n_patches, num_field_groups, D).permute(0, 1, 3, 2, 4).reshape(tr, T, num_field_groups, -1)
 
 
 def inverse_transform_processed_data(transformed_data: torch.Tensor, tr: int, T: int, n_patches: int, num_field_groups: int) -> torch.Tensor:

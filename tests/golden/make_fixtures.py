@@ -404,6 +404,87 @@ def cfg3_train_case():
     save("cfg3_train", **arrs)
 
 
+def eval_case():
+    """The `temporal test` evaluation of the reference on a synthetic mesh (main.py:101-123 -> utils/train_utils.py:186-312), end to end with the
+    reference's OWN classes: MeshProcessor.patchify_and_scale -> ProcessData (frozen SpatialModel, recipe weights, loaded from a checkpoint file
+    as the reference does) -> transform_processed_data -> TemporalDataset / DataLoader -> full_autoregressive_evaluation (rollout, decode,
+    un-patchify, per-field relative MSE) and autoregressive_validation.  Stored: the raw mesh + fields + conditions (inputs), the dims, and the
+    reference's metrics and intermediate tensors."""
+    import contextlib, io, tempfile
+    import matplotlib
+    matplotlib.use("Agg")
+    from models.encoder_decoder import SpatialModel as RefSpatial
+    from torch.utils.data import DataLoader
+
+    print("eval_synth")
+    tmp = tempfile.mkdtemp(prefix="sea_eval_")
+    groups, D, hidden, layers, Hs = [[0, 1], [2]], 8, 32, 2, 2
+    m_ = n_ = 5
+    P = (m_ - 1) * (n_ - 1)
+    tr, T, npts, F = 2, 7, 420, 3
+    rng = np.random.Generator(np.random.PCG64(2025))
+    xy = rng.random((2, npts)).astype(np.float32)
+    xy[0, : npts // 3] = 0.2 + 0.15 * xy[0, : npts // 3]          # a denser band: ragged cells
+    tt = np.arange(T + 1, dtype=np.float32)[None, :, None]
+    ph = rng.random((tr, 1, 1)).astype(np.float32) * 6.28
+    fields = np.stack([np.sin(3 * xy[0][None, None, :] + 0.3 * tt + ph), np.cos(2 * xy[1][None, None, :] - 0.2 * tt + ph) * xy[0][None, None, :],
+                       0.5 * np.sin(4 * xy[0][None, None, :] * xy[1][None, None, :] + 0.1 * tt) + 0.1 * ph], axis=-1).astype(np.float32)   # [tr, T+1, N, F]
+    cond = (0.2 + 0.6 * rng.random((tr, 1, 1)).astype(np.float32)) * np.ones((tr, T + 1, 1), dtype=np.float32)
+    E = P * D
+    config = dict(device="cpu", save_dir=tmp, dimension="2D", field_groups=groups, scale_feature_range=None, csv_scale_name="scaler", m=m_, n=n_, k=None,
+                  pad_id=-1, pad_field_value=0, MLP_hidden_spatial=hidden, num_layers_spatial=layers, embed_dim_spatial=D, n_heads_spatial=Hs,
+                  block_size_spatial=64, dropout_spatial=0.0, variational_spatial=False, src_len_spatial=0,
+                  encoder_decoder_path=os.path.join(tmp, "encoder_decoder.pt"), spatial_batch_size=1000, perform_initial_test=False,
+                  random_seed=42, SEA_isolate=True, SEA_mixed=False, case_name="synth", run_name="fixture")
+    coords = torch.from_numpy(xy)
+    data = torch.from_numpy(fields)
+    with contextlib.redirect_stdout(io.StringIO()):
+        mp_ = ref_dp.MeshProcessor(config, coords)
+        stacked_coords, scaled = mp_.patchify_and_scale(data.reshape(tr * (T + 1), npts, F), train_indices=np.arange(1))
+    n_inp = scaled.shape[2]
+    config["n_inp"] = n_inp
+    _, imap = mp_.partitioner.create_partitions([data[0, :1, :, i].to(torch.float32) for i in range(F)])
+    index_map = torch.stack(imap, dim=0).numpy().astype(np.int64)                   # [P, C], pad_id = -1
+    scaled_p = scaled.permute(0, 1, 3, 2)                        # SEA_isolate (train/train_temporal.py:152-153)
+    # the frozen spatial autoencoder: recipe weights under the reference's own state_dict keys, saved the way the reference expects to load them
+    sp = RefSpatial(groups, n_inp, hidden, layers, D, Hs, 64, 0, variational=False, dropout=0.0)
+    sch = OrderedDictMerge(encoder_schema(groups, n_inp, hidden, layers, D, pre="encode."), decode_schema(groups, n_inp, hidden, D, pre="decode.decoders."))
+    named = dict(sp.named_parameters())
+    assert sorted(named.keys()) == sorted(sch.keys()), (sorted(set(named) ^ set(sch)))
+    with torch.no_grad():
+        for k, prm in named.items():
+            shp, kind = sch[k]
+            prm.copy_(torch.from_numpy(recipe_tensor(k, shp, kind)))
+    torch.save(sp.state_dict(), config["encoder_decoder_path"])
+    with contextlib.redirect_stdout(io.StringIO()):
+        proc = ref_dp.ProcessData(n_inp, config)
+        z = proc.initialize_and_process_data(scaled_p.clone())                     # [tr*(T+1), P, G, D]
+    enc = ref_tu.transform_processed_data(z, tr, T + 1, P, len(groups))       # [tr, T+1, G, P*D]
+    ds = ref_dp.TemporalDataset([enc[i] for i in range(tr)], [data[i] for i in range(tr)], [torch.from_numpy(cond[i]) for i in range(tr)], src_len=T, overlap=0)
+    loader = DataLoader(ds, batch_size=tr, shuffle=False)
+    cfg = OracleConfig(1, E, 4, 32, 8, 0, len(groups), 2, True, "adaln")
+    model = build_reference(cfg)
+    with contextlib.redirect_stdout(io.StringIO()):
+        res = ref_tu.full_autoregressive_evaluation(model, loader, torch.nn.MSELoss(), torch.device("cpu"), proc, mp_, config, 0, plot_traj=False)
+        v_loss, v_rel = ref_tu.autoregressive_validation(model, loader, torch.nn.MSELoss(), torch.device("cpu"))
+    import csv
+    with open(os.path.join(tmp, "rollout_error_synth_fixture.csv")) as f:
+        rows = [r for r in csv.reader(f)][1:]
+    per_step = np.array([[float(v) for v in r[1:]] for r in rows], dtype=np.float64)     # [T, F] decoded rel-MSE of the LAST batch (there is one)
+    save("eval_synth", xy=xy, fields=fields, cond=cond, dims=np.array([m_, n_, D, hidden, layers, Hs, n_inp, tr, T], dtype=np.int64),
+         groups=np.array([len(g) for g in groups]), cfg=cfg_meta(cfg), scaled=n(scaled), index_map=index_map, z=n(z), enc=n(enc),
+         encoded_rel_mse=np.array(res["encoded_rel_mse"]), decoded_rel_mse=np.array(res["decoded_rel_mse"]), decoded_per_step=per_step,
+         val_loss=np.array(v_loss), val_rel_mse_time=np.array(v_rel))
+    import shutil
+    shutil.rmtree(tmp, ignore_errors=True)
+
+
+def OrderedDictMerge(a, b):
+    out = dict(a)
+    out.update(b)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default=None)
@@ -443,6 +524,8 @@ def main():
         big_cases()
     if args.big and args.only is None or args.only == "cfg3_train":
         cfg3_train_case()
+    if args.only is None or args.only == "eval_synth":
+        eval_case()
 
 
 if __name__ == "__main__":

@@ -74,7 +74,17 @@ def test_decode_rejects_cpu_and_bad_dims():
     from sea_amd.models.encoder_decoder import Decode
 
     with pytest.raises(NotImplementedError):
-        Decode([[0]], 10, 64, 16)  # n_inp not a multiple of 4
+        Decode([[0]], 12, 60, 16)  # MLP_hidden not a multiple of 8
+    # any padded cell size works (it is data-dependent in the reference): 10 columns per field, padded to 12 inside, sliced on the way out
+    groups = [[0, 1], [2]]
+    m10 = Decode(groups, 10, 64, 16).to("cuda:0").eval()
+    z = torch.randn(2, 5, 2, 16)
+    from oracle import sea_oracle as O
+    p = {k: v.detach().cpu() for k, v in m10.state_dict().items()}
+    with torch.no_grad():
+        out = m10(z.cuda())
+    assert out.shape == (2, 5, 3, 10)
+    assert rel_l2(out.cpu().numpy(), O.decode(z, p, groups).numpy()) < 1e-4
     m = Decode([[0]], 12, 64, 16)
     with pytest.raises(RuntimeError):
         m(torch.zeros(1, 4, 1, 16))  # CPU tensor: no fallback

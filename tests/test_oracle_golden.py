@@ -202,6 +202,43 @@ def test_cfg3_train_step_matches_reference():
         assert rel_l2(gr[:: grad_sub_stride(gr.numel())], g["gsub:" + k]) < 5e-5, k
 
 
+def test_temporal_test_evaluation_chain_matches_reference():
+    """The whole `temporal test` chain of the reference on a synthetic mesh (tests/golden/eval_synth.npz: its own MeshProcessor, ProcessData,
+    TemporalDataset and full_autoregressive_evaluation) restated with the oracle's functions: patchify -> encode -> rollout -> decode -> un-patchify ->
+    per-step, per-field relative MSE."""
+    from oracle.recipe import decode_schema, encoder_schema
+
+    g = load_golden("eval_synth")
+    m_, n_, D, hidden, layers, Hs, n_inp, tr, T = (int(v) for v in g["dims"])
+    groups, f0 = [], 0
+    for n_f in g["groups"]:
+        groups.append(list(range(f0, f0 + int(n_f))))
+        f0 += int(n_f)
+    P = (m_ - 1) * (n_ - 1)
+    fields, imap = T_(g["fields"]), T_(g["index_map"])
+    npts, F = fields.shape[2], fields.shape[3]
+    scaled = O.patchify(fields.reshape(tr * (T + 1), npts, F), imap)                 # [B, P, C, F]
+    assert torch.equal(scaled, T_(g["scaled"]))
+    ep = {k: T_(recipe_tensor("encode." + k, shp, kind)) for k, (shp, kind) in encoder_schema(groups, n_inp, hidden, layers, D).items()}
+    dp = {k: T_(recipe_tensor("decode." + k, shp, kind)) for k, (shp, kind) in decode_schema(groups, n_inp, hidden, D).items()}
+    z = O.encode(scaled.permute(0, 1, 3, 2), ep, groups, Hs, layers)
+    assert rel_l2(z, g["z"]) < 1e-5
+    enc = z.reshape(tr, T + 1, P, len(groups), D).permute(0, 1, 3, 2, 4).reshape(tr, T + 1, len(groups), P * D)
+    cfg = cfg_from_meta(g["cfg"])
+    pred = O.rollout(enc[:, :1], T_(g["cond"])[:, :T], T, recipe_params(cfg), cfg)
+    enc_rel = O.relative_mse(pred, enc[:, 1:]).mean()
+    assert abs(float(enc_rel) - float(g["encoded_rel_mse"])) < 1e-4 * float(g["encoded_rel_mse"])
+    dec = O.decode(O.rollout_to_patches(pred, P), dp, groups)                         # [tr*T, P, F, C]
+    rec = O.unpatchify(dec.permute(0, 1, 3, 2), imap, npts).reshape(tr, T, npts, F)
+    per_step = O.relative_mse(rec, fields[:, 1:], dim=2).mean(dim=0)
+    assert rel_l2(per_step, g["decoded_per_step"]) < 1e-4
+    assert abs(float(per_step.mean()) - float(g["decoded_rel_mse"])) < 1e-4 * float(g["decoded_rel_mse"])
+
+
+def T_(a):
+    return torch.from_numpy(np.asarray(a))
+
+
 def test_schema_counts():
     cfg = O.OracleConfig(1, 256, 8, 2024, 8, 0, 3, 2, True, "adaln")
     s = param_schema(cfg)
