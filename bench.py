@@ -77,10 +77,6 @@ def record_work(rec, esz):
         for g in a[0][:a[1]]:
             fl += 2 * g.M * g.E * g.S
             by += g.M * g.E * esz + g.S * g.E * esz + 3 * g.S * 4 + g.M * g.S * esz
-    elif rec.fn is L.sea_mlp_fc2_ln_gelu:
-        for g in a[0][:a[1]]:
-            fl += 2 * g.M * g.E * g.S
-            by += g.M * g.S * esz + g.S * g.E * esz + 2 * g.S * 4 + g.M * g.E * (esz + 4)
     elif rec.fn is L.sea_exchange_tail:
         for g in rec.keep[:a[1]]:
             fl += g.n_seg * 2 * g.M * g.D * g.D * (0 if g.plain else 1) + 2 * g.M * g.D * g.E + (2 * g.M * g.E * g.D if g.has_down else 0)

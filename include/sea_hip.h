@@ -41,7 +41,7 @@ enum {
 int sea_abi_version(void);
 const char* sea_last_error(void);
 /* sizeof of every ABI struct in declaration order (SeaGemmGroup, SeaQkvGroup, SeaQkvCommon, SeaAttnProblem,
- * SeaAttnParams, SeaNormGroup, SeaSiluGroup, SeaIbParams, ..., SeaLaunchRec, SeaGemmNormGroup, SeaExchangeTail, SeaMlpGroup, SeaMlp2Group last): lets a binding verify its layout.  Host only. */
+ * SeaAttnParams, SeaNormGroup, SeaSiluGroup, SeaIbParams, ..., SeaLaunchRec, SeaGemmNormGroup, SeaExchangeTail, SeaMlpGroup last): lets a binding verify its layout.  Host only. */
 int sea_struct_sizes(int* out, int cap);
 /* Number of compute units / name of device 0's architecture as HIP reports them (diagnostics for bench.py). */
 int sea_device_info(int* cu_count, char* arch, int arch_len);
@@ -98,10 +98,6 @@ typedef struct {
     const float* silu_c;   /* f32 [M] or NULL */
     const float* silu_w1;  /* f32 [K] */
     const float* silu_b1;  /* f32 [K] */
-    /* optional row statistics of the output (act = 0, N % 32 == 0): stats[m][b] = (mean, sum of squared deviations from it) of the fp32 values
-     * acc + bias in columns 32 b .. 32 b + 31 of row m — the per-block partials a consumer combines into LayerNorm statistics of the whole row
-     * (sea_mlp_fc2_ln_gelu) without another pass over the matrix.  f32 [M][N / 32][2], contiguous. */
-    float* stats;
 } SeaGemmGroup;
 
 int sea_gemm_grouped(const SeaGemmGroup* groups, int n_groups, int dtype, void* stream);
@@ -310,33 +306,6 @@ typedef struct {
 
 int sea_mlp_fc1_ln_gelu(const SeaMlpGroup* groups, int n_groups, float eps, int dtype, void* stream);
 
-/* ------------------------------------------------------------------------------------------------------------
- * Second half of the field MLP with the LayerNorm + GELU of the first half applied on the way in (bf16):
- *     Out = R + b2 + gelu_erf(LayerNorm_S(H) * lnw + lnb) . W2[E, S]^T
- * Replaces models/base_blocks.py:23-26 (nn.LayerNorm(S), GELU, Linear(S, E)) and the residual add of models/temporal.py:145 =
- * sea_rownorm(gelu) + sea_gemm_grouped: H is the PRE-activation matrix sea_gemm_grouped wrote (with `stats`, the per-32-column partial
- * statistics of its fp32 values); a workgroup owns 64 rows x ALL E output columns, so every hidden element is normalised and activated exactly
- * once, while its K-tile waits in LDS for the MFMAs — the activated matrix never exists in HBM.
- * ksplit = 2 splits the contraction over two workgroups per row tile (short launches: twice the workgroups, half of W2 each): segment 0 of
- * Out holds R + b2 + the first half's sum, segment 1 the second half's — a consumer GEMM adds them with n_seg = 2 (the following Linear, proj, is
- * linear in its input).  (E, S) in {(256, 2048), (128, 1024)}; bf16; SEA_EUNSUPPORTED otherwise.
- */
-typedef struct {
-    const void* H;        /* act [M, S], row stride ldh: pre-activations (bias included) */
-    const float* stats;   /* f32 [M][S / 32][2]: (mean, M2) per 32-column block, see SeaGemmGroup.stats */
-    const float* lnw;     /* f32 [S] */
-    const float* lnb;     /* f32 [S] */
-    const void* W2;       /* act [E, S], row stride ldw */
-    const float* b2;      /* f32 [E] */
-    const float* R;       /* f32 [M, E], row stride ldr, or NULL */
-    void* Out;            /* act [ksplit][M, E]: row stride ldo, segment stride out_seg_stride elements */
-    float* C32;           /* f32 [M, E] row stride ldc32, or NULL (ksplit = 1 only) */
-    int64_t out_seg_stride;
-    int32_t ldh, ldw, ldr, ldo, ldc32;
-    int32_t M, E, S;
-} SeaMlp2Group;
-
-int sea_mlp_fc2_ln_gelu(const SeaMlp2Group* groups, int n_groups, int ksplit, float eps, int dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Hidden layer of the AdaLN condition MLP for a scalar condition: Hid[m, k] = silu(w1[k] * c[m] + b1[k]).
@@ -536,10 +505,10 @@ int sea_ib_bwd(const SeaIbBwdParams* params, void* stream);
  *     SEA_OP_SILU   p0 = SeaSiluGroup[n], p1 = c, i0 = M, l0 = (intptr) SeaIbParams[l1] or 0, l1 = n_ib      SEA_OP_IB     p0 = SeaIbParams
  *     SEA_OP_CONVERT p0 = src, p1 = dst, l0 = lds, l1 = ldd, l2 = rows, l3 = cols
  *     SEA_OP_GEMM_NORM p0 = SeaGemmNormGroup[n], f0 = eps          SEA_OP_XTAIL  p0 = SeaExchangeTail[n], f0 = eps
- *     SEA_OP_MLP1   p0 = SeaMlpGroup[n], f0 = eps                 SEA_OP_MLP2   p0 = SeaMlp2Group[n], i0 = ksplit, f0 = eps
+ *     SEA_OP_MLP1   p0 = SeaMlpGroup[n], f0 = eps
  * Returns 0, or the failing entry's error code with sea_last_error() set (entries before it have been launched).
  */
-enum { SEA_OP_GEMM = 1, SEA_OP_QKV = 2, SEA_OP_ATTN = 3, SEA_OP_NORM = 4, SEA_OP_SILU = 5, SEA_OP_IB = 6, SEA_OP_CONVERT = 8, SEA_OP_GEMM_NORM = 9, SEA_OP_XTAIL = 10, SEA_OP_MLP1 = 11, SEA_OP_MLP2 = 13 };   /* 7 and 12 were round-1 entry points (sea_rowchain, sea_cond_mlp), removed in ABI v2 */
+enum { SEA_OP_GEMM = 1, SEA_OP_QKV = 2, SEA_OP_ATTN = 3, SEA_OP_NORM = 4, SEA_OP_SILU = 5, SEA_OP_IB = 6, SEA_OP_CONVERT = 8, SEA_OP_GEMM_NORM = 9, SEA_OP_XTAIL = 10, SEA_OP_MLP1 = 11 };   /* 7 and 12 were round-1 entry points (sea_rowchain, sea_cond_mlp), removed in ABI v2 */
 typedef struct {
     int32_t op, n, dtype, i0, i1, i2, i3;
     float f0;

@@ -34,7 +34,7 @@ class SeaGemmGroup(C.Structure):
                 ("lda", _i32), ("ldw", _i32), ("ldr", _i32), ("ldc32", _i32), ("ldcact", _i32), ("ldz", _i32),
                 ("M", _i32), ("N", _i32), ("K", _i32), ("n_seg", _i32),
                 ("act", _i32), ("bias_scale", _f32), ("drop", SeaDropout),
-                ("silu_c", _vp), ("silu_w1", _vp), ("silu_b1", _vp), ("stats", _vp)]
+                ("silu_c", _vp), ("silu_w1", _vp), ("silu_b1", _vp)]
 
 
 class SeaQkvGroup(C.Structure):
@@ -106,7 +106,7 @@ class SeaAttnBwdParams(C.Structure):
                 ("ldo", _i32), ("lddo", _i32), ("lddq", _i32), ("lddk", _i32), ("lddv", _i32), ("q_scale", _f32), ("drop", SeaDropout)]
 
 
-OP_GEMM, OP_QKV, OP_ATTN, OP_NORM, OP_SILU, OP_IB, OP_CONVERT, OP_GEMM_NORM, OP_XTAIL, OP_MLP1, OP_MLP2 = 1, 2, 3, 4, 5, 6, 8, 9, 10, 11, 13
+OP_GEMM, OP_QKV, OP_ATTN, OP_NORM, OP_SILU, OP_IB, OP_CONVERT, OP_GEMM_NORM, OP_XTAIL, OP_MLP1 = 1, 2, 3, 4, 5, 6, 8, 9, 10, 11
 
 
 class SeaLaunchRec(C.Structure):
@@ -147,12 +147,6 @@ MAX_MLP_GROUPS = 8
 class SeaMlpGroup(C.Structure):
     _fields_ = [("A", _vp), ("W1", _vp), ("b1", _vp), ("lnw", _vp), ("lnb", _vp), ("Hg", _vp),
                 ("lda", _i32), ("ldw", _i32), ("ldh", _i32), ("M", _i32), ("E", _i32), ("S", _i32)]
-
-
-class SeaMlp2Group(C.Structure):
-    _fields_ = [("H", _vp), ("stats", _vp), ("lnw", _vp), ("lnb", _vp), ("W2", _vp), ("b2", _vp), ("R", _vp), ("Out", _vp), ("C32", _vp),
-                ("out_seg_stride", _i64), ("ldh", _i32), ("ldw", _i32), ("ldr", _i32), ("ldo", _i32), ("ldc32", _i32),
-                ("M", _i32), ("E", _i32), ("S", _i32)]
 
 
 MAX_WGRAD_GROUPS = 16
@@ -212,8 +206,6 @@ def lib() -> C.CDLL:
     L.sea_silu_outer_ib.restype = C.c_int
     L.sea_mlp_fc1_ln_gelu.argtypes = [C.POINTER(SeaMlpGroup), C.c_int, C.c_float, C.c_int, _vp]
     L.sea_mlp_fc1_ln_gelu.restype = C.c_int
-    L.sea_mlp_fc2_ln_gelu.argtypes = [C.POINTER(SeaMlp2Group), C.c_int, C.c_int, C.c_float, C.c_int, _vp]
-    L.sea_mlp_fc2_ln_gelu.restype = C.c_int
     L.sea_run_list.argtypes = [C.POINTER(SeaLaunchRec), C.c_int, _vp]
     L.sea_run_list.restype = C.c_int
     for name in ("sea_attention_bwd", "sea_wgrad_grouped", "sea_transpose_weights", "sea_rownorm_bwd", "sea_silu_outer_bwd", "sea_ib_bwd"):
@@ -234,14 +226,14 @@ def lib() -> C.CDLL:
 
 ABI_STRUCTS = (SeaGemmGroup, SeaQkvGroup, SeaQkvCommon, SeaAttnProblem, SeaAttnParams, SeaNormGroup, SeaSiluGroup,
                SeaIbParams, SeaWgradGroup, SeaNormBwdGroup, SeaSiluBwdGroup, SeaIbBwdParams, SeaAttnBwdProblem, SeaAttnBwdParams,
-               SeaDropout, SeaLaunchRec, SeaGemmNormGroup, SeaExchangeTail, SeaMlpGroup, SeaMlp2Group)
+               SeaDropout, SeaLaunchRec, SeaGemmNormGroup, SeaExchangeTail, SeaMlpGroup)
 
 EXPORTED_SYMBOLS = (
     "sea_abi_version", "sea_last_error", "sea_struct_sizes", "sea_device_info", "sea_gemm_grouped", "sea_qkv_rope_grouped",
     "sea_attention_fwd", "sea_rownorm", "sea_silu_outer", "sea_ib_add", "sea_convert_f32_to_act", "sea_selftest_mfma",
     "sea_mse_fwd_bwd", "sea_relative_mse", "sea_adamw_flat",
     "sea_wgrad_grouped", "sea_transpose_weights", "sea_rownorm_bwd", "sea_silu_outer_bwd", "sea_ib_bwd",
-    "sea_attention_bwd", "sea_dropout_mask", "sea_run_list", "sea_unpatchify", "sea_gemm_rownorm", "sea_exchange_tail", "sea_patchify", "sea_silu_outer_ib", "sea_mlp_fc1_ln_gelu", "sea_mlp_fc2_ln_gelu",
+    "sea_attention_bwd", "sea_dropout_mask", "sea_run_list", "sea_unpatchify", "sea_gemm_rownorm", "sea_exchange_tail", "sea_patchify", "sea_silu_outer_ib", "sea_mlp_fc1_ln_gelu",
 )
 
 

@@ -95,6 +95,10 @@ def build(force: bool = False, verbose: bool = True) -> str:
                     print(out)
                 if rc != 0:
                     raise RuntimeError("hipcc failed:\n" + out)
+    for f in os.listdir(BUILD):   # -save-temps leaves preprocessed sources, bitcode and host listings (tens of MB): only objects and device listings are kept
+        stem = f.split("-hip-")[0].split(".")[0]
+        if (not (f.endswith(".o") and "-hip-" not in f) and not f.endswith("-hip-amdgcn-amd-amdhsa-gfx950.s")) or stem + ".hip" not in srcs:
+            os.remove(os.path.join(BUILD, f))
     findings = []
     for obj in objs:
         for kernel, no, ins in lint_isa(_asm_of(obj)):

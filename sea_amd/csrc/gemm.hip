@@ -89,7 +89,7 @@ __global__ __launch_bounds__(256) void gemm_grouped_kernel(const GemmLaunch L) {
         // 740 for the same shape with a bf16 output
         constexpr int SP32 = BN * 4 + 16;
         constexpr int HALF_ROWS = BM / 2;
-        if (Cact == nullptr && C32 != nullptr && G.stats == nullptr && G.ldc32 % 4 == 0 && HALF_ROWS * SP32 <= (BM > BN ? BM : BN) * SP + 0) {
+        if (Cact == nullptr && C32 != nullptr && G.ldc32 % 4 == 0 && HALF_ROWS * SP32 <= (BM > BN ? BM : BN) * SP + 0) {
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
                 if (half) __syncthreads();
@@ -130,51 +130,6 @@ __global__ __launch_bounds__(256) void gemm_grouped_kernel(const GemmLaunch L) {
                 }
             }
             return;
-        }
-    }
-    if (G.stats != nullptr) {   // block-uniform.  Row statistics per 32-column block (two 16-column MFMA tiles of this wave): mean and centred sum of
-        // squares of the fp32 values acc + bias — what a consumer merges into the LayerNorm statistics of the whole row (sea_mlp_fc2_ln_gelu)
-        const int nblk = G.N >> 5;
-#pragma unroll
-        for (int jp = 0; jp < C::NI / 2; ++jp) {
-            const int nb = ml.n0 + wn * C::WTN + jp * 32;
-            float bq[2][4];
-#pragma unroll
-            for (int jj = 0; jj < 2; ++jj) {
-                const int n = nb + jj * 16 + g * 4;
-                bq[jj][0] = bq[jj][1] = bq[jj][2] = bq[jj][3] = 0.f;
-                if (bias != nullptr && n < G.N) {
-                    load4(bias + n, bq[jj]);
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) bq[jj][q] *= G.bias_scale;
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < C::MI; ++i) {
-                const int m = ml.m0 + wm * C::WTM + i * 16 + r;
-                float v8[8], s = 0.f;
-#pragma unroll
-                for (int jj = 0; jj < 2; ++jj)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        v8[jj * 4 + q] = acc[i][jp * 2 + jj][q] + bq[jj][q];
-                        s += v8[jj * 4 + q];
-                    }
-                s += __shfl_xor(s, 16);
-                s += __shfl_xor(s, 32);
-                const float mean = s * (1.0f / 32.0f);
-                float m2a = 0.f, m2b = 0.f;   // scalar-lane FMAs (sea_common.hpp): a packed sum of squares trips the build's ISA check
-#pragma unroll
-                for (int e = 0; e < 8; e += 2) {
-                    const float c0 = v8[e] - mean, c1 = v8[e + 1] - mean;
-                    m2a = fma1(c0, c0, m2a);
-                    m2b = fma1(c1, c1, m2b);
-                }
-                float m2 = add1(m2a, m2b);
-                m2 += __shfl_xor(m2, 16);
-                m2 += __shfl_xor(m2, 32);
-                if (g == 0 && m < G.M && nb < G.N) *reinterpret_cast<float2*>(G.stats + ((int64_t)m * nblk + (nb >> 5)) * 2) = make_float2(mean, m2);
-            }
         }
     }
 #pragma unroll
@@ -547,8 +502,6 @@ extern "C" int sea_gemm_grouped(const SeaGemmGroup* groups, int n_groups, int dt
         SEA_REQUIRE(G.C32 || G.Cact, "sea_gemm_grouped[%d]: no output", i);
         SEA_REQUIRE(G.drop.thr >= 0 && G.drop.thr <= 255 && (G.drop.thr == 0 || G.drop.mode == 1 || G.drop.mode == 2), "sea_gemm_grouped[%d]: bad dropout", i);
         SEA_REQUIRE(G.N % 4 == 0, "sea_gemm_grouped[%d]: N=%d must be a multiple of 4", i, G.N);
-        SEA_REQUIRE(!G.stats || (G.N % 32 == 0 && G.act == 0 && G.drop.thr == 0 && !G.silu_c && sea_aligned16(G.stats)),
-                    "sea_gemm_grouped[%d]: row statistics need N %% 32 == 0, no activation / dropout / generated operand", i);
         SEA_REQUIRE(G.act >= 0 && G.act <= 2 && (G.act != 2 || G.Z) && (!G.Z || (G.ldz >= G.N && G.ldz % 4 == 0)), "sea_gemm_grouped[%d]: bad act/Z", i);
         SEA_REQUIRE(sea_aligned16(G.bias) && sea_aligned16(G.R) && sea_aligned16(G.C32) && sea_aligned16(G.Cact) && sea_aligned16(G.Z),
                     "sea_gemm_grouped[%d]: bias/R/C32/Cact/Z must be 16-byte aligned", i);
@@ -562,7 +515,7 @@ extern "C" int sea_gemm_grouped(const SeaGemmGroup* groups, int n_groups, int dt
     bool skinny = skinny_env != 0 && dtype == SEA_BF16 && n_silu == 0;
     for (int i = 0; i < n_groups && skinny; ++i) {
         const SeaGemmGroup& G = groups[i];
-        skinny = G.M <= 16 && G.n_seg == 1 && G.K % 128 == 0 && G.K <= 2048 && G.act == 0 && G.drop.thr == 0 && G.N % 4 == 0 && !G.stats;
+        skinny = G.M <= 16 && G.n_seg == 1 && G.K % 128 == 0 && G.K <= 2048 && G.act == 0 && G.drop.thr == 0 && G.N % 4 == 0;
     }
     if (skinny) {
         SkinnyLaunch S;

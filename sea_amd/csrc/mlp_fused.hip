@@ -271,265 +271,3 @@ extern "C" int sea_mlp_fc1_ln_gelu(const SeaMlpGroup* groups, int n_groups, floa
     SEA_CHECK_LAUNCH("sea_mlp_fc1_ln_gelu");
     return SEA_OK;
 }
-
-// =====================================================================================================================================
-// Second half of the field MLP with the first half's LayerNorm + GELU applied on the way in: sea_mlp_fc2_ln_gelu (bf16).
-//
-//     Out = R + b2 + gelu_erf(LayerNorm_S(H) * lnw + lnb) . W2[E, S]^T        (models/base_blocks.py:23-26, models/temporal.py:145)
-//
-// H is the pre-activation matrix the ordinary tiled GEMM of the first Linear wrote, together with per-32-column partial statistics of its
-// fp32 values (SeaGemmGroup.stats).  A workgroup (4 waves) owns 64 rows x ALL E output columns (wave w: columns w E/4 ..), so every hidden
-// element is normalised and activated exactly once, in the K-tile that needs it:
-//   * W2 K-tiles (E rows x 128 B) and raw H K-tiles (64 rows x 128 B) go L2 -> LDS by global_load_lds through rings of 3 and 4 stages (the raw
-//     tile three iterations ahead of its use: it comes from HBM, W2 from L2); completion is counted by hand (vmcnt), one barrier per K-tile;
-//   * iteration kt runs the MFMAs of K-tile kt (A tile kt: activated in the iteration before) and, beside them (two waves per SIMD), LayerNorm +
-//     GELU of the raw K-tile kt + 1 into the other A buffer;
-//   * lnw / lnb of the workgroup's K range sit in LDS (DMA'd first), the row statistics are merged once per workgroup from the partials
-//     (Chan's pairwise combination of (n, mean, M2): no cancellation whatever the row mean).
-// ksplit = 2: two workgroups per row tile take half of the contraction each and write their sums to two segments (the first one carries
-// R + b2); the Linear that follows (proj) is linear in its input and adds the segments with its n_seg = 2 operand — no atomics, no extra pass.
-struct Mlp2Launch {
-    SeaMlp2Group g[SEA_MAX_MLP_GROUPS];
-    int tile_start[SEA_MAX_MLP_GROUPS + 1];
-    int n_groups, ksplit, per_xcd;
-    float eps;
-    int probe;   // development aid (SEA_MLP2_PROBE): bit 0 no GELU, bit 1 no MFMAs, bit 2 no activation pass at all, bit 3 no W2 DMA after the prologue
-};
-
-template <int BN>   // = E: 256 or 128
-__global__ __launch_bounds__(512) void mlp_fc2_ln_gelu_kernel(const Mlp2Launch L) {
-    using T = __bf16;
-    constexpr int BM = 64, BKB = 128, BK = 64, NW = 8, NSW = 3, NSH = 4;
-    constexpr int W_STAGE = BN * BKB, H_STAGE = BM * BKB, A_TILE = BM * BKB;
-    // mean | rstd (64 + 64 floats) are staged in A buffer 1: read once below, before the barrier at the top of iteration 0, after which that buffer is first written
-    constexpr int W_OFF = 0, H_OFF = NSW * W_STAGE, A_OFF = H_OFF + NSH * H_STAGE, P_OFF = A_OFF + A_TILE, GB_OFF = A_OFF + 2 * A_TILE;   // GB: lnw | lnb of the K range
-    constexpr int WTN = BN / 4, NI = WTN / 16, MI = 2;         // wave grid 2 x 4: a wave owns 32 rows x BN / 4 columns
-    constexpr int LPS_W = BN / 8 / NW, LPS_H = BM / 8 / NW, LPS = LPS_W + LPS_H;   // DMA pieces (1 KiB = 8 rows x 128 B) per wave per K-tile
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tile = L.per_xcd > 0 ? (int)(blockIdx.x & 7) * L.per_xcd + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
-    if (tile >= L.tile_start[L.n_groups]) return;
-    int gi = 0;
-    while (gi + 1 < L.n_groups && tile >= L.tile_start[gi + 1]) ++gi;
-    const SeaMlp2Group& G = L.g[gi];
-    const int t_in = tile - L.tile_start[gi];
-    const int row_tiles = (G.M + BM - 1) / BM;
-    const int kp = t_in / row_tiles;                      // which part of the contraction (0 .. ksplit - 1)
-    const int m0 = (t_in - kp * row_tiles) * BM, M = G.M, S = G.S;
-    const int kspan = S / L.ksplit, k_begin = kp * kspan, nk = kspan / BK;   // >= 8
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int r = lane & 15, g = lane >> 4;
-    const int wr = wave >> 2, wc = wave & 3;
-    const unsigned lds_base = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)smem);
-
-    // ---- lnw | lnb of this workgroup's K range: 1 KiB pieces by LDS DMA (drained by the one vmcnt(0) below, before the main loop)
-    const int gb_pieces = kspan / 256;                     // per vector
-    for (int p = wave; p < 2 * gb_pieces; p += NW) {
-        const float* src = p < gb_pieces ? G.lnw : G.lnb;
-        const int q = p < gb_pieces ? p : p - gb_pieces;
-        glds16_mlp(src + k_begin + q * 256 + lane * 4, lds_base + (unsigned)(GB_OFF + p * 1024));
-    }
-    // ---- operand streams: W2 K-tiles (BN rows x 128 B) through a ring of NSW = 3 stages, raw H K-tiles (64 rows x 128 B) through a ring of NSH = 4, both
-    // by LDS DMA (1 KiB pieces, swizzle on the source side, gemm_core.hpp); iteration j requests [H(j + 4), W2(j + 2)]: the raw tile three iterations
-    // before its LayerNorm + GELU pass, the W2 tile two iterations before its MFMAs.  Completion is counted by hand (in-order vmcnt).
-    const int rl = lane >> 3;
-    const int chunk = (lane & 7) ^ (rl & 7);
-    const T* H = static_cast<const T*>(G.H);
-    const T* W = static_cast<const T*>(G.W2);
-    auto dma_h = [&](int kt) __attribute__((always_inline)) {
-        const unsigned base = lds_base + (unsigned)(H_OFF + (kt % NSH) * H_STAGE);
-#pragma unroll
-        for (int i = 0; i < LPS_H; ++i) {
-            const int u = i * NW + wave;
-            int row = m0 + u * 8 + rl;
-            row = row < M ? row : M - 1;
-            glds16_mlp(H + (int64_t)row * G.ldh + k_begin + kt * BK + chunk * 8, base + (unsigned)(u * 8 * BKB));
-        }
-    };
-    auto dma_w = [&](int kt) __attribute__((always_inline)) {
-        const unsigned base = lds_base + (unsigned)(W_OFF + (kt % NSW) * W_STAGE);
-#pragma unroll
-        for (int i = 0; i < LPS_W; ++i) {
-            const int u = i * NW + wave;
-            glds16_mlp(W + (int64_t)(u * 8 + rl) * G.ldw + k_begin + kt * BK + chunk * 8, base + (unsigned)(u * 8 * BKB));
-        }
-    };
-    dma_h(0);
-    dma_h(1);
-    dma_h(2);     // [H(2), W2(0)]: the group of "iteration -2"
-    dma_w(0);
-    // this thread activates the 16-byte chunk at LDS position ac of row ar of every raw K-tile
-    const int ac = tid & 7, ar = tid >> 3;
-    const int akc = ac ^ (ar & 7);                         // the K chunk that sits at position ac of row ar
-
-    // ---- row statistics: merge the S / 32 partials (mean_b, M2_b over 32 columns) of each of the 64 rows; 8 threads per row, then three shuffles
-    {
-        const int nblk = S >> 5, per = nblk >> 3;
-        const int part = tid & 7;
-        int row = m0 + ar;
-        row = row < M ? row : M - 1;
-        const float2* st = reinterpret_cast<const float2*>(G.stats) + (int64_t)row * nblk + part * per;
-        float n_a = 0.f, mean_a = 0.f, m2_a = 0.f;
-        for (int b = 0; b < per; ++b) {
-            const float2 pb = st[b];
-            const float n_ab = n_a + 32.f, d = pb.x - mean_a;
-            mean_a += d * (32.f / n_ab);
-            m2_a += pb.y + d * d * (n_a * 32.f / n_ab);
-            n_a = n_ab;
-        }
-#pragma unroll
-        for (int o = 1; o <= 4; o <<= 1) {   // equal counts on both sides
-            const float mean_b = __shfl_xor(mean_a, o), m2_b = __shfl_xor(m2_a, o);
-            const float d = mean_b - mean_a;
-            mean_a += 0.5f * d;
-            m2_a += m2_b + d * d * (0.5f * n_a);
-            n_a *= 2.f;
-        }
-        if (part == 0) {
-            float* pm = reinterpret_cast<float*>(smem + P_OFF);
-            pm[ar] = mean_a;
-            pm[BM + ar] = 1.0f / sqrtf(m2_a / (float)S + L.eps);
-        }
-    }
-    __syncthreads();   // the statistics are in LDS (the compiler drained its own loads, issued after the DMAs above: those have landed too)
-    float ra, rb;                                          // y = h * ra + rb  ==  (h - mean) * rstd
-    {
-        const float* pm = reinterpret_cast<const float*>(smem + P_OFF);
-        ra = pm[BM + ar];
-        rb = -pm[ar] * ra;
-    }
-    auto activate = [&](int kt) __attribute__((always_inline)) {   // raw K-tile kt -> LayerNorm + GELU -> A buffer kt & 1
-        const char* hraw = smem + H_OFF + (kt % NSH) * H_STAGE;
-        char* abuf = smem + A_OFF + (kt & 1) * A_TILE;
-        const float* gm = reinterpret_cast<const float*>(smem + GB_OFF) + kt * BK + akc * 8;
-        const float* bt = gm + kspan;
-        float gmv[8], btv[8];
-        load4(gm, *reinterpret_cast<float(*)[4]>(&gmv[0]));
-        load4(gm + 4, *reinterpret_cast<float(*)[4]>(&gmv[4]));
-        load4(bt, *reinterpret_cast<float(*)[4]>(&btv[0]));
-        load4(bt + 4, *reinterpret_cast<float(*)[4]>(&btv[4]));
-        const bf16x8 hv = *reinterpret_cast<const bf16x8*>(hraw + ar * BKB + ac * 16);
-        bf16x8 yv;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const float xn = fmaf((float)hv[e], ra, rb);
-            const float un = fmaf(xn, gmv[e], btv[e]);
-            yv[e] = (__bf16)((L.probe & 1) ? un : ((L.probe & 64) ? gelu_erf(un) : gelu_erf_bf16(un)));
-        }
-        *reinterpret_cast<bf16x8*>(abuf + ar * BKB + ac * 16) = yv;
-    };
-
-    f32x4 acc[MI][NI];
-#pragma unroll
-    for (int i = 0; i < MI; ++i)
-#pragma unroll
-        for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    // Iteration kt (-1 only activates K-tile 0): at the top, raw tile kt + 1 and W2 tile kt must have landed; the group requested last,
-    // [H(kt + 3), W2(kt + 1)] = LPS pieces per wave, may still be in flight.  One barrier per K-tile: MFMAs of K-tile kt, and beside them (two waves
-    // per SIMD) LayerNorm + GELU of raw tile kt + 1 into the other A buffer.
-    for (int kt = -1; kt < nk; ++kt) {
-        if (kt + 3 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();   // every wave's pieces are in LDS; A buffer (kt & 1) is complete; nobody still reads what the requests below overwrite
-        if (kt + 4 < nk) dma_h(kt + 4);
-        if (kt + 2 < nk && !(L.probe & 8)) dma_w(kt + 2);
-        // the two waves of a SIMD (w and w + 4) take the two halves of the iteration in opposite order, so that one's MFMAs run beside the other's VALU work
-        const bool do_act = kt + 1 < nk && !(L.probe & 4);
-        if (wr == 1 && do_act && !(L.probe & 32)) activate(kt + 1);
-        if (kt >= 0 && !(L.probe & 2)) {
-            const char* sA = smem + A_OFF + (kt & 1) * A_TILE + (wr * 32 + r) * BKB;
-            const char* sW = smem + W_OFF + (kt % NSW) * W_STAGE + (wc * WTN + r) * BKB;
-#pragma unroll
-            for (int kc = 0; kc < 2; ++kc) {
-                const int off = ((kc * 4 + g) ^ (r & 7)) << 4;
-                uint4 af[MI], wf[NI];
-#pragma unroll
-                for (int i = 0; i < MI; ++i) af[i] = *reinterpret_cast<const uint4*>(sA + i * 16 * BKB + off);
-#pragma unroll
-                for (int j = 0; j < NI; ++j) wf[j] = *reinterpret_cast<const uint4*>(sW + j * 16 * BKB + off);
-#pragma unroll
-                for (int i = 0; i < MI; ++i)
-#pragma unroll
-                    for (int j = 0; j < NI; ++j) mma16<T>(wf[j], af[i], acc[i][j]);   // transposed tile: lane = output row, 4 consecutive columns
-            }
-        }
-        if ((wr == 0 || (L.probe & 32)) && do_act) activate(kt + 1);
-    }
-    // ---- epilogue: this lane holds rows m0 + 32 wr + 16 i + r, columns wc WTN + 16 j + 4 g .. + 3
-    T* Out = static_cast<T*>(G.Out) + (int64_t)kp * G.out_seg_stride;
-    const bool first = kp == 0;
-#pragma unroll
-    for (int j = 0; j < NI; ++j) {
-        const int n = wc * WTN + j * 16 + g * 4;
-        float bv[4] = {0.f, 0.f, 0.f, 0.f};
-        if (first) load4(G.b2 + n, bv);
-#pragma unroll
-        for (int i = 0; i < MI; ++i) {
-            const int m = m0 + wr * 32 + i * 16 + r;
-            if (m >= M) continue;
-            float v[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) v[q] = acc[i][j][q] + bv[q];
-            if (first && G.R != nullptr) {
-                float rv[4];
-                load4(G.R + (int64_t)m * G.ldr + n, rv);
-#pragma unroll
-                for (int q = 0; q < 4; ++q) v[q] += rv[q];
-            }
-            if (G.C32 != nullptr) store4(G.C32 + (int64_t)m * G.ldc32 + n, v[0], v[1], v[2], v[3]);
-            store4(Out + (int64_t)m * G.ldo + n, v[0], v[1], v[2], v[3]);
-        }
-    }
-}
-
-extern "C" int sea_mlp_fc2_ln_gelu(const SeaMlp2Group* groups, int n_groups, int ksplit, float eps, int dtype, void* stream) {
-    SEA_REQUIRE(groups != nullptr && n_groups >= 1 && n_groups <= SEA_MAX_MLP_GROUPS, "sea_mlp_fc2_ln_gelu: n_groups=%d out of range", n_groups);
-    SEA_REQUIRE(ksplit == 1 || ksplit == 2, "sea_mlp_fc2_ln_gelu: ksplit=%d (1 or 2)", ksplit);
-    const int E = groups[0].E, S = groups[0].S;
-    const bool shape_ok = (E == 256 && S == 2048) || (E == 128 && S == 1024);
-    if (dtype != SEA_BF16 || !shape_ok) {
-        sea_set_error("sea_mlp_fc2_ln_gelu: unsupported dtype / shape (dtype=%d E=%d S=%d): bf16, (E, S) in {(256, 2048), (128, 1024)}", dtype, E, S);
-        return SEA_EUNSUPPORTED;
-    }
-    Mlp2Launch L;
-    memset(&L, 0, sizeof(L));
-    int total = 0;
-    for (int i = 0; i < n_groups; ++i) {
-        const SeaMlp2Group& G = groups[i];
-        SEA_REQUIRE(G.E == E && G.S == S && G.M >= 1, "sea_mlp_fc2_ln_gelu[%d]: the groups of a launch share E and S", i);
-        SEA_REQUIRE(G.H && G.stats && G.lnw && G.lnb && G.W2 && G.b2 && G.Out, "sea_mlp_fc2_ln_gelu[%d]: null pointer", i);
-        SEA_REQUIRE(G.ldh % 8 == 0 && G.ldh >= S && G.ldw % 8 == 0 && G.ldw >= S && G.ldo % 4 == 0 && G.ldo >= E && (!G.R || (G.ldr % 4 == 0 && G.ldr >= E)) &&
-                        (!G.C32 || (G.ldc32 % 4 == 0 && G.ldc32 >= E)),
-                    "sea_mlp_fc2_ln_gelu[%d]: bad strides", i);
-        SEA_REQUIRE(sea_aligned16(G.H) && sea_aligned16(G.stats) && sea_aligned16(G.lnw) && sea_aligned16(G.lnb) && sea_aligned16(G.W2) && sea_aligned16(G.b2) &&
-                        sea_aligned16(G.R) && sea_aligned16(G.Out) && sea_aligned16(G.C32) && G.out_seg_stride % 8 == 0,
-                    "sea_mlp_fc2_ln_gelu[%d]: pointers must be 16-byte aligned", i);
-        SEA_REQUIRE(ksplit == 1 || !G.C32, "sea_mlp_fc2_ln_gelu[%d]: the fp32 output needs ksplit = 1", i);
-        L.g[i] = G;
-        L.tile_start[i] = total;
-        total += ((G.M + 63) / 64) * ksplit;
-    }
-    L.tile_start[n_groups] = total;
-    L.n_groups = n_groups;
-    L.ksplit = ksplit;
-    L.eps = eps;
-    { const char* e = getenv("SEA_MLP2_PROBE"); L.probe = e ? atoi(e) : 0; }
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    // consecutive tiles (one field, one part of W2) on one XCD: its L2 fetches that part of W2 once
-    L.per_xcd = (total + 7) / 8;
-    const int grid = 8 * L.per_xcd;
-    if (E == 256) {
-        constexpr int lds = 3 * 256 * 128 + 4 * 64 * 128 + 2 * 64 * 128 + 2 * 2048 * 4;   // W2 ring 96 + raw H ring 32 + A tiles 16 + lnw | lnb 16 KiB = all 160 KiB of the CU
-        static int once = set_lds_mlp(mlp_fc2_ln_gelu_kernel<256>, lds);
-        (void)once;
-        mlp_fc2_ln_gelu_kernel<256><<<dim3(grid), dim3(512), lds, s>>>(L);
-    } else {
-        constexpr int lds = 3 * 128 * 128 + 4 * 64 * 128 + 2 * 64 * 128 + 2 * 1024 * 4;
-        static int once = set_lds_mlp(mlp_fc2_ln_gelu_kernel<128>, lds);
-        (void)once;
-        mlp_fc2_ln_gelu_kernel<128><<<dim3(grid), dim3(512), lds, s>>>(L);
-    }
-    SEA_CHECK_LAUNCH("sea_mlp_fc2_ln_gelu");
-    return SEA_OK;
-}

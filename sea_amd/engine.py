@@ -708,34 +708,6 @@ class Plan:
         # Linear + nn.LayerNorm + GELU in one launch where the kernel is instantiated (bf16; SEA_FUSE_MLP1=0 keeps the two launches, =1 forces
         # the one launch).  Every workgroup of that kernel streams the whole of W1, so it needs enough 32-row tiles to pay: with the few rows
         # of a KV-cache step the two launches are faster (0.143 vs 0.163 ms per step at cfg2), hence the row threshold.
-        # The two-pass form (opt-in, SEA_MLP2=1; bf16): fc1 on the ordinary tiles writes the pre-activations and per-32-column row statistics from its
-        # epilogue; LayerNorm + GELU happen in fc2's operand path, where a workgroup owns 64 rows x all E output columns so every hidden element is
-        # activated once; short launches split fc2's contraction over two workgroups per row tile and hand proj both partial sums as two operand
-        # segments (proj is linear in its input).  Measured (tools/mlp2_probe.py, cfg2 shape): 19.5 + 30.9 us against 26.6 + 18.4 us for the one-launch
-        # first half + plain fc2; B = 8: 120 + 155 against 144 + 76 us — the activation pass (VALU), the 96 KiB of fragment reads per K-tile (LDS) and
-        # the operand streams do not overlap inside one 8-wave workgroup per CU, see DESIGN.md section 5.
-        want2 = os.environ.get("SEA_MLP2", "auto")
-        if (type(self) is Plan and want2 == "1" and ops.mlp_fc2_supported(self.dt, E, S) and len(fields) <= N.MAX_MLP_GROUPS):
-            M = self.M
-            row_tiles = (M + 63) // 64
-            ksplit = 2 if len(fields) * row_tiles <= 128 else 1
-            stats = {i: self._buf(M, S // 32, 2, dtype=torch.float32) for i in fields}
-            seg = {i: self._buf(ksplit, M, E) for i in fields}
-            self._gemm([dict(A=n_e[i], W=P.act(f"{pre}mlp.{i}.layers.0.weight"), bias=P.f32_vec(f"{pre}mlp.{i}.layers.0.bias"), Cact=hbuf[i], stats=stats[i])
-                        for i in fields], "mlp.fc1_stats" + tag)
-            arr = (N.SeaMlp2Group * len(fields))()
-            for g_, i in zip(arr, fields):
-                ops.fill_mlp2_group(g_, hbuf[i], stats[i], P.f32_vec(f"{pre}mlp.{i}.layers.1.weight"), P.f32_vec(f"{pre}mlp.{i}.layers.1.bias"),
-                                    P.act(f"{pre}mlp.{i}.layers.3.weight"), P.f32_vec(f"{pre}mlp.{i}.layers.3.bias"), xr[i], seg[i])
-            self._cur.append(self._rec(N.lib().sea_mlp_fc2_ln_gelu, [arr, len(fields), ksplit, 1e-5, self.code], "mlp.ln_gelu_fc2" + tag, arr))
-            pj = lambda i: dict(A=seg[i], n_seg=ksplit, a_seg_stride=M * E, W=P.act(f"{pre}proj.{i}.weight"), bias=P.f32_vec(f"{pre}proj.{i}.bias"))  # noqa: E731
-            if fuse_final:
-                self._gemm_norm([dict(Y32=xr[i], ldy32=FE, Y_is_out=i * E * 4, **pj(i), **norm_params(f"ln.{i}.", E)) for i in fields], "proj_final_norm" + tag)
-                return
-            self._gemm([dict(C32=xr[i], **pj(i)) for i in fields], "proj" + tag)
-            if final_norm:
-                self._norm([dict(X=xr[i], Y32=xr[i], ldy32=FE, Y_is_out=i * E * 4, **norm_params(f"ln.{i}.", E)) for i in fields], E, "final.norm" + tag)
-            return
         want = os.environ.get("SEA_FUSE_MLP1", "auto")
         if (type(self) is Plan and want != "0" and (want == "1" or self.M >= 1024) and ops.mlp_fc1_supported(self.dt, E, S) and len(fields) <= N.MAX_MLP_GROUPS):
             arr = (N.SeaMlpGroup * len(fields))()
@@ -846,8 +818,6 @@ class Plan:
                 c.op, c.p0, c.dtype = N.OP_ATTN, addr(r.keep), a[1]
             elif r.fn is L.sea_mlp_fc1_ln_gelu:
                 c.op, c.p0, c.n, c.f0, c.dtype = N.OP_MLP1, addr(a[0]), a[1], a[2], a[3]
-            elif r.fn is L.sea_mlp_fc2_ln_gelu:
-                c.op, c.p0, c.n, c.i0, c.f0, c.dtype = N.OP_MLP2, addr(a[0]), a[1], a[2], a[3], a[4]
             elif r.fn is L.sea_exchange_tail:
                 c.op, c.p0, c.n, c.f0, c.dtype = N.OP_XTAIL, addr(r.keep), a[1], a[2], a[3]
             elif r.fn is L.sea_gemm_rownorm:
@@ -935,7 +905,7 @@ class Plan:
 
 
 def _fill_gemm(g, A, W, bias=None, R=None, C32=None, Cact=None, n_seg=1, a_seg_stride=0, act=0, bias_scale=1.0, ldr=None,
-               R_is_x=None, Z=None, ldc32=None, drop=None, silu=None, M=None, stats=None) -> None:
+               R_is_x=None, Z=None, ldc32=None, drop=None, silu=None, M=None) -> None:
     if drop is not None:  # (thr, stream, mode); the seed is patched every step
         g.drop.thr, g.drop.stream, g.drop.mode = drop
     if silu is not None:  # generated A operand: (w1 [K] f32, b1 [K] f32); the condition pointer is patched at bind time; rows = M
@@ -957,7 +927,6 @@ def _fill_gemm(g, A, W, bias=None, R=None, C32=None, Cact=None, n_seg=1, a_seg_s
     g.ldcact = Cact.stride(0) if Cact is not None else 0
     g.M, g.N, g.K = A.shape[-2], W.shape[0], W.shape[1]
     g.n_seg, g.act, g.bias_scale = n_seg, act, bias_scale
-    g.stats = N.ptr(stats)
 
 
 def blk_pe(eng: "TemporalEngine", layer: int) -> torch.Tensor:

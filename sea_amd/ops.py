@@ -22,7 +22,7 @@ def _mat(t: torch.Tensor, name: str) -> torch.Tensor:
 
 
 def fill_gemm_group(g: N.SeaGemmGroup, A, W, bias=None, R=None, C32=None, Cact=None, n_seg=1, a_seg_stride=0, act=0,
-                    bias_scale=1.0, M=None, N_=None, K=None, Z=None, silu=None, stats=None) -> None:
+                    bias_scale=1.0, M=None, N_=None, K=None, Z=None, silu=None) -> None:
     if silu is not None:   # generated A operand: dict(c f32 [M], w1 f32 [K], b1 f32 [K]) — A[m, k] = silu(w1[k] c[m] + b1[k])
         g.silu_c, g.silu_w1, g.silu_b1 = silu["c"].data_ptr(), silu["w1"].data_ptr(), silu["b1"].data_ptr()
         g.A, g.lda, g.W, g.ldw = None, 0, W.data_ptr(), W.stride(0)
@@ -46,7 +46,6 @@ def fill_gemm_group(g: N.SeaGemmGroup, A, W, bias=None, R=None, C32=None, Cact=N
     g.n_seg = n_seg
     g.act = act
     g.bias_scale = bias_scale
-    g.stats = N.ptr(stats)   # f32 [M, N / 32, 2] contiguous: per-32-column (mean, M2) of the fp32 output rows
 
 
 def gemm_grouped(groups: Sequence[Dict], dtype: torch.dtype) -> None:
@@ -70,7 +69,7 @@ def gemm_grouped(groups: Sequence[Dict], dtype: torch.dtype) -> None:
         if d.get("Cact") is not None and d["Cact"].dtype != dtype:
             raise ValueError(f"gemm group {i}: Cact dtype mismatch")
         fill_gemm_group(arr[i], A, W, d.get("bias"), d.get("R"), d.get("C32"), d.get("Cact"), d.get("n_seg", 1),
-                        d.get("a_seg_stride", 0), d.get("act", 0), d.get("bias_scale", 1.0), K=d.get("K"), Z=d.get("Z"), stats=d.get("stats"))
+                        d.get("a_seg_stride", 0), d.get("act", 0), d.get("bias_scale", 1.0), K=d.get("K"), Z=d.get("Z"))
     N.check(N.lib().sea_gemm_grouped(arr, n, N.dtype_code(dtype), N.stream_ptr()), "sea_gemm_grouped")
 
 
@@ -425,30 +424,3 @@ def mlp_fc1_ln_gelu(groups: Sequence[Dict], eps: float = 1e-5, dtype: torch.dtyp
             _mat(d[k], k)
         fill_mlp_group(g, d["A"], d["W1"], d["b1"], d["lnw"], d["lnb"], d["Hg"])
     N.check(N.lib().sea_mlp_fc1_ln_gelu(arr, len(groups), eps, N.dtype_code(dtype), N.stream_ptr()), "sea_mlp_fc1_ln_gelu")
-
-
-def mlp_fc2_supported(dtype: torch.dtype, E: int, S: int) -> bool:
-    """Shapes sea_mlp_fc2_ln_gelu instantiates: bf16, (E, S) in {(256, 2048), (128, 1024)}."""
-    return dtype == torch.bfloat16 and (E, S) in ((256, 2048), (128, 1024))
-
-
-def fill_mlp2_group(g: N.SeaMlp2Group, H, stats, lnw, lnb, W2, b2, R, Out, C32=None) -> None:
-    """Out: act [ksplit, M, E] (or [M, E] for ksplit = 1)."""
-    g.H, g.stats, g.lnw, g.lnb, g.W2, g.b2 = H.data_ptr(), stats.data_ptr(), lnw.data_ptr(), lnb.data_ptr(), W2.data_ptr(), b2.data_ptr()
-    g.R, g.Out, g.C32 = N.ptr(R), Out.data_ptr(), N.ptr(C32)
-    g.out_seg_stride = Out.stride(0) if Out.dim() == 3 else 0
-    g.ldh, g.ldw, g.ldo = H.stride(0), W2.stride(0), Out.stride(-2)
-    g.ldr = R.stride(0) if R is not None else 0
-    g.ldc32 = C32.stride(0) if C32 is not None else 0
-    g.M, g.E, g.S = H.shape[0], W2.shape[0], W2.shape[1]
-
-
-def mlp_fc2_ln_gelu(groups: Sequence[Dict], ksplit: int = 1, eps: float = 1e-5, dtype: torch.dtype = torch.bfloat16) -> None:
-    """Out = R + b2 + gelu(LayerNorm(H) * lnw + lnb) W2^T (sea_mlp_fc2_ln_gelu): dicts with H [M,S] (pre-activations), stats f32 [M,S/32,2] (written by
-    gemm_grouped(..., stats=...)), lnw, lnb f32 [S], W2 [E,S], b2 f32 [E], optional R f32 [M,E], Out act [ksplit,M,E] or [M,E], optional C32."""
-    arr = (N.SeaMlp2Group * len(groups))()
-    for g, d in zip(arr, groups):
-        for k in ("H", "W2"):
-            _mat(d[k], k)
-        fill_mlp2_group(g, d["H"], d["stats"], d["lnw"], d["lnb"], d["W2"], d["b2"], d.get("R"), d["Out"], d.get("C32"))
-    N.check(N.lib().sea_mlp_fc2_ln_gelu(arr, len(groups), ksplit, eps, N.dtype_code(dtype), N.stream_ptr()), "sea_mlp_fc2_ln_gelu")
