@@ -493,6 +493,9 @@ typedef struct {
     float* db2;
     int32_t M, E, h;
     SeaDropout drop;
+    int32_t mode;   /* 0: the MLP form above; 1: ib = nn.Linear(1, E) (ib_scale_mode 'linear', models/temporal.py:106-107): dw1 [E] += sum_m c[m] sum_f dX_f[m, :],
+                     * db1 [E] += sum_m sum_f dX_f[m, :]; the other pointers are ignored */
+    int32_t pad_;
 } SeaIbBwdParams;
 int sea_ib_bwd(const SeaIbBwdParams* params, void* stream);
 

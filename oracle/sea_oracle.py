@@ -311,6 +311,10 @@ def live_param_keys(p: Params, cfg: OracleConfig) -> List[str]:
         pre = f"blocks.{layer}."
         dead_marks.append(pre + "ln.cross.")
         dead_marks.append(pre + "ib.residual_projection.")
+        if getattr(cfg, "ib_addition_mode", "add") == "none":      # the layer is evaluated but its output dropped (models/temporal.py:112-114)
+            dead_marks.append(pre + "ib.")
+        elif getattr(cfg, "ib_scale_mode", "mlp") == "fourier":    # fixed random features (models/base_blocks.py:147: requires_grad=False)
+            dead_marks.append(pre + "ib.W")
         for i in range(cfg.num_variables):
             dead_marks.append(f"{pre}ln.exp.{i}.1.")
             dead_marks.append(f"{pre}cross_attn.{i}.{i}.")

@@ -92,7 +92,7 @@ class SeaIbBwdParams(C.Structure):
     _fields_ = [("dX", _vp * 8), ("n_fields", _i32), ("ldx", _i32),
                 ("c", _vp), ("w1", _vp), ("b1", _vp), ("lnw", _vp), ("lnb", _vp), ("w2", _vp),
                 ("dw1", _vp), ("db1", _vp), ("dlnw", _vp), ("dlnb", _vp), ("dw2", _vp), ("db2", _vp),
-                ("M", _i32), ("E", _i32), ("h", _i32), ("drop", SeaDropout)]
+                ("M", _i32), ("E", _i32), ("h", _i32), ("drop", SeaDropout), ("mode", _i32), ("pad_", _i32)]
 
 
 class SeaAttnBwdProblem(C.Structure):

@@ -1047,9 +1047,44 @@ __global__ __launch_bounds__(256) void ib_bwd_fast_kernel(const SeaIbBwdParams P
     for (int i = threadIdx.x; i < E * h; i += 256) atomicAdd(P.dw2 + i, s_w2[i]);
 }
 
+// ib = nn.Linear(1, E): dw[e] += sum_m c[m] g[m, e], db[e] += sum_m g[m, e] with g = sum over the fields of dX_f.  grid = (E / 64 column blocks, row chunks);
+// lane = column, the four waves of a workgroup take rows w, w + 4, ... of the chunk, partial sums meet in LDS, one atomic per column per workgroup.
+__global__ __launch_bounds__(256) void ib_linear_bwd_kernel(const SeaIbBwdParams P) {
+    __shared__ float red[2][4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int col = blockIdx.x * 64 + lane;
+    const int rows_per = (P.M + gridDim.y - 1) / gridDim.y;
+    const int r0 = blockIdx.y * rows_per, r1 = min(P.M, r0 + rows_per);
+    float aw = 0.f, ab = 0.f;
+    if (col < P.E) {
+        for (int m = r0 + wave; m < r1; m += 4) {
+            float gsum = 0.f;
+            for (int f = 0; f < P.n_fields; ++f) gsum += P.dX[f][(int64_t)m * P.ldx + col];
+            aw = fmaf(P.c[m], gsum, aw);
+            ab += gsum;
+        }
+    }
+    red[0][wave][lane] = aw;
+    red[1][wave][lane] = ab;
+    __syncthreads();
+    if (wave == 0 && col < P.E) {
+        atomicAdd(P.dw1 + col, (red[0][0][lane] + red[0][1][lane]) + (red[0][2][lane] + red[0][3][lane]));
+        atomicAdd(P.db1 + col, (red[1][0][lane] + red[1][1][lane]) + (red[1][2][lane] + red[1][3][lane]));
+    }
+}
+
 extern "C" int sea_ib_bwd(const SeaIbBwdParams* params, void* stream) {
     SEA_REQUIRE(params != nullptr, "sea_ib_bwd: null params");
     const SeaIbBwdParams& P = *params;
+    if (P.mode == 1) {
+        SEA_REQUIRE(P.n_fields >= 1 && P.n_fields <= 8 && P.M >= 1 && P.E >= 1 && P.ldx >= P.E && P.c && P.dw1 && P.db1, "sea_ib_bwd (linear): bad arguments");
+        for (int f = 0; f < P.n_fields; ++f) SEA_REQUIRE(P.dX[f] != nullptr, "sea_ib_bwd (linear): dX[%d] null", f);
+        const int chunks = P.M >= 4096 ? 64 : (P.M + 63) / 64;
+        ib_linear_bwd_kernel<<<dim3((P.E + 63) / 64, chunks), dim3(256), 0, static_cast<hipStream_t>(stream)>>>(P);
+        SEA_CHECK_LAUNCH("sea_ib_bwd");
+        return SEA_OK;
+    }
+    SEA_REQUIRE(P.mode == 0, "sea_ib_bwd: mode %d", P.mode);
     SEA_REQUIRE(P.n_fields >= 1 && P.n_fields <= 8 && P.M >= 1 && P.E >= 4 && P.E % 4 == 0 && P.h >= 1 && P.h <= 64 && P.ldx >= P.E && P.ldx % 4 == 0,
                 "sea_ib_bwd: bad sizes");
     SEA_REQUIRE(P.c && P.w1 && P.b1 && P.lnw && P.lnb && P.w2 && P.dw1 && P.db1 && P.dlnw && P.dlnb && P.dw2 && P.db2, "sea_ib_bwd: null pointer");

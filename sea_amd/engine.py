@@ -35,13 +35,21 @@ def _round_up(x: int, m: int) -> int:
     return (x + m - 1) // m * m
 
 
-def dead_prefixes(num_layers: int, F: int) -> List[str]:
-    """Parameter-name prefixes that never receive a gradient on this path."""
+def dead_prefixes(model) -> List[str]:
+    """Parameter-name prefixes that never receive a gradient on this path: the unused middle AdaLN of every field, `ln.cross`, the
+    diagonal cross-attention modules, the info-bottleneck's residual projection — and, per variant, the whole info-bottleneck layer when its output is
+    not added (ib_addition_mode 'none': the reference still evaluates it, models/temporal.py:112-114) and the fixed random matrix of the Fourier form
+    (models/base_blocks.py:147: requires_grad=False)."""
     out = []
-    for layer in range(num_layers):
+    ib_none = model.ib_addition_mode.lower() == "none"
+    for layer in range(model.num_layers):
         pre = f"blocks.{layer}."
         out += [pre + "ln.cross.", pre + "ib.residual_projection."]
-        for i in range(F):
+        if ib_none:
+            out.append(pre + "ib.")
+        elif model.ib_scale_mode.lower() == "fourier":
+            out.append(pre + "ib.W")
+        for i in range(model.num_variables):
             out += [f"{pre}ln.exp.{i}.1.", f"{pre}cross_attn.{i}.{i}."]
     return out
 
@@ -60,7 +68,7 @@ class FlatParams:
                 keyed.append(((base, _QKV_RANK[(m.group(2), m.group(3))]), name, p))
             else:
                 keyed.append(((idx, 0), name, p))
-        dead = dead_prefixes(model.num_layers, model.num_variables)
+        dead = dead_prefixes(model)
         is_dead = lambda n: any(n.startswith(d) for d in dead)  # noqa: E731
         keyed.sort(key=lambda t: (is_dead(t[1]), t[0]))
         self.offsets: Dict[str, Tuple[int, Tuple[int, ...]]] = {}
@@ -949,7 +957,7 @@ class TemporalEngine:
                 "sea_amd native path covers exchange_mode in {'sea', 'addition', 'simple', 'pool'}, ib_scale_mode in {'mlp', 'linear', 'fourier'}, ib_addition_mode in "
                 "{'add', 'none'}, ib_mlp_layers=1, ib_num=1; got "
                 f"{m.exchange_mode}/{m.ib_scale_mode}/{m.ib_addition_mode}/{m.ib_mlp_layers}/{m.ib_num}")
-        self.default_variant = m.exchange_mode == "sea" and m.ib_addition_mode.lower() == "add" and self.ib_mode == 0   # what training covers
+        self.trainable_variant = m.exchange_mode in ("sea", "addition", "simple")   # what the hand-written backward covers ('pool': forward / rollout only)
         E, H, D = m.embed_dim, m.n_heads, m.down_dim
         for hd, what in ((E // H, "self"),) + (((D // H, "cross"),) if m.exchange_mode in ("sea", "pool") else ()):
             ok = hd in (8, 16, 32, 64, 128) or (hd == 256 and act_dtype == torch.bfloat16)
@@ -1028,9 +1036,9 @@ class TemporalEngine:
         from .train_engine import TrainPlan
 
         m = self.model
-        if not self.default_variant:
-            raise NotImplementedError("sea_amd: training (backward) covers exchange_mode='sea' with ib_scale_mode='mlp', ib_addition_mode='add'; the ablation "
-                                      f"variants run forward / rollout only (got {m.exchange_mode}/{m.ib_scale_mode}/{m.ib_addition_mode})")
+        if not self.trainable_variant:
+            raise NotImplementedError("sea_amd: training (backward) covers exchange_mode in {'sea', 'addition', 'simple'} with every ib_scale_mode / ib_addition_mode "
+                                      f"the forward covers; exchange_mode='pool' runs forward / rollout only (got {m.exchange_mode})")
         thr = int(round(256 * m.dropout_p)) if (m.training and m.dropout_p > 0) else 0
         if thr > 255:
             raise ValueError("dropout probability too close to 1")

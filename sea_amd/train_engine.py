@@ -120,19 +120,25 @@ class TrainPlan(Plan):
             self._cur.append(rec)
 
     def _ib_bwd(self, pre: str, dxs: List[torch.Tensor], drop=None) -> None:
-        P, G = self.eng.params, self.eng.grad_view
+        P, G, mode = self.eng.params, self.eng.grad_view, self.eng.ib_mode
+        if mode == 2:      # GaussianFourierProjection: its matrix is fixed (requires_grad=False in the reference): nothing to accumulate
+            return
         ib = N.SeaIbBwdParams()
-        if drop is not None:
-            ib.drop.thr, ib.drop.stream = drop
-            self._drop_structs.append(ib)
         for i, x in enumerate(dxs):
             ib.dX[i] = x.data_ptr()
         ib.n_fields, ib.ldx = len(dxs), dxs[0].stride(0)
-        names = ("ib.layers.0.weight", "ib.layers.0.bias", "ib.layers.1.weight", "ib.layers.1.bias", "ib.layers.3.weight")
-        ib.w1, ib.b1, ib.lnw, ib.lnb, ib.w2 = (P.f32(pre + n).data_ptr() for n in names)
-        ib.dw1, ib.db1, ib.dlnw, ib.dlnb, ib.dw2 = (G(pre + n).data_ptr() for n in names)
-        ib.db2 = G(pre + "ib.layers.3.bias").data_ptr()
-        ib.M, ib.E, ib.h = self.M, self.E, self.eng.model.ib_hidden
+        ib.M, ib.E, ib.mode = self.M, self.E, mode
+        if mode == 1:      # nn.Linear(1, E): weight [E, 1], bias [E]
+            ib.dw1, ib.db1 = G(pre + "ib.weight").data_ptr(), G(pre + "ib.bias").data_ptr()
+        else:
+            if drop is not None:
+                ib.drop.thr, ib.drop.stream = drop
+                self._drop_structs.append(ib)
+            names = ("ib.layers.0.weight", "ib.layers.0.bias", "ib.layers.1.weight", "ib.layers.1.bias", "ib.layers.3.weight")
+            ib.w1, ib.b1, ib.lnw, ib.lnb, ib.w2 = (P.f32(pre + n).data_ptr() for n in names)
+            ib.dw1, ib.db1, ib.dlnw, ib.dlnb, ib.dw2 = (G(pre + n).data_ptr() for n in names)
+            ib.db2 = G(pre + "ib.layers.3.bias").data_ptr()
+            ib.h = self.eng.model.ib_hidden
         self._c_patches.append((ib, "c"))
         self._cur.append(_Rec(N.lib().sea_ib_bwd, [C.byref(ib)], "bwd.ib", ib))
 
@@ -150,6 +156,12 @@ class TrainPlan(Plan):
         model = eng.model
         rope_s, rope_c = eng.rope_self, eng.rope_cross
         buf = self._buf
+        # variants of the block (reference models/temporal.py:285-312, 103-116): exchange 'sea' (Gauss-Seidel cross-attention) | 'addition' (Jacobi sum of the
+        # normalised down-projections) | 'simple' (none); info-bottleneck layer 'mlp' | 'linear' | 'fourier' (fixed random features: no parameter gradient),
+        # added ('add') or not ('none': the layer then has no gradient at all)
+        xmode = model.exchange_mode
+        has_ib = model.ib_addition_mode.lower() == "add"
+        ib_mode = eng.ib_mode
 
         def Gv(name, n=None):  # flat fp32 gradient of a vector parameter (optionally fused over n elements)
             return eng.grad_vec(name, n)
@@ -166,7 +178,7 @@ class TrainPlan(Plan):
                 pre = f"blocks.{l}."
                 for i in range(F):
                     prefixes += [(f"{pre}ln.exp.{i}.0.", E), (f"{pre}ln.exp.{i}.2.", E)]
-                if F > 1:
+                if F > 1 and xmode in ("sea", "addition"):
                     for i in range(F):
                         prefixes.append((f"{pre}ln_cross.{i}.", D))
             for i in range(F):
@@ -206,7 +218,7 @@ class TrainPlan(Plan):
             sv["xr"] = [buf(M, E, dtype=f32) for _ in range(F)]
             sv["x5"] = [buf(M, E, dtype=f32) for _ in range(F)]
             sv["x_in"] = x_prev
-            if not model.add_info_after_cross:
+            if not model.add_info_after_cross and has_ib:
                 # the info-bottleneck add precedes everything and must not touch the caller's tensor: x_in := copy + ib
                 xin = [buf(M, E, dtype=f32) for _ in range(F)]
                 for i in range(F):
@@ -249,7 +261,24 @@ class TrainPlan(Plan):
                 groups.append(g)
             self._gemm(groups, "self.out_proj")
             # ---- state exchange
-            if F > 1:
+            if F > 1 and xmode == "addition":
+                # Jacobi: every field is read at its pre-exchange value; s = sum_j n_j is the same for every field (models/temporal.py:297-301)
+                sv["dn"] = [buf(M, D, dtype=f32) for _ in range(F)]
+                sv["nd"] = buf(F, M, D)
+                sv["stc"] = [stats() for _ in range(F)]
+                sv["s_pre"], sv["sg"] = buf(M, D), buf(M, D)
+                if os.environ.get("SEA_FUSE_NORM", "1") != "0" and D <= 256 and D % 16 == 0:
+                    self._gemm_norm([dict(A=sv["xa1"][j], W=P.act(f"{pre}cross_down.{j}.weight"), bias=P.f32_vec(f"{pre}cross_down.{j}.bias"), C32=sv["dn"][j],
+                                          Yact=sv["nd"][j], mean=sv["stc"][j][0], rstd=sv["stc"][j][1], **npar(f"{pre}ln_cross.{j}.")) for j in range(F)], "add.down_norm")
+                else:
+                    self._gemm([dict(A=sv["xa1"][j], W=P.act(f"{pre}cross_down.{j}.weight"), bias=P.f32_vec(f"{pre}cross_down.{j}.bias"), C32=sv["dn"][j])
+                                for j in range(F)], "add.down")
+                    self._norm([dict(X=sv["dn"][j], Yact=sv["nd"][j], mean=sv["stc"][j][0], rstd=sv["stc"][j][1], **npar(f"{pre}ln_cross.{j}.")) for j in range(F)],
+                               D, "add.norm")
+                self._gemm([dict(A=sv["nd"][0], W=eng.eye(D), n_seg=F, a_seg_stride=M * D, Cact=sv["sg"], Z=sv["s_pre"], act=1)], "add.sum_gelu")
+                self._gemm([dict(A=sv["sg"], W=P.act(f"{pre}cross_up.{i}.weight"), bias=P.f32_vec(f"{pre}cross_up.{i}.bias"), R=sv["xr"][i], C32=sv["xr"][i])
+                            for i in range(F)], "add.up")
+            if F > 1 and xmode == "sea":
                 sv["dn_old"] = [buf(M, D, dtype=f32) for _ in range(F)]
                 sv["nd_old"] = [buf(M, D) for _ in range(F)]
                 sv["stc_old"] = [stats() for _ in range(F)]
@@ -299,7 +328,7 @@ class TrainPlan(Plan):
                                          C32=sv["dn_new"][i])], f"cross{i}.down_new")
                         self._norm([dict(X=sv["dn_new"][i], Yact=sv["nd_new"][i], mean=sv["stc_new"][i][0], rstd=sv["stc_new"][i][1],
                                          **npar(f"{pre}ln_cross.{i}."))], D, f"cross{i}.norm_new")
-            if model.add_info_after_cross:
+            if model.add_info_after_cross and has_ib:
                 sv["ib_drop"] = (thr, self._streams(F)) if thr else None
                 self._ib(pre, sv["xr"], drop=sv["ib_drop"])
             # ---- MLP + proj
@@ -352,7 +381,7 @@ class TrainPlan(Plan):
         for l in reversed(range(NL)):
             pre = f"blocks.{l}."
             sv = Sv[l]
-            first = l == 0 and model.add_info_after_cross
+            first = l == 0 and (model.add_info_after_cross or not has_ib)
             # ---- proj:  x5 = Wp xa4 + bp                       (ga = d x5 in act dtype)
             self._wgrad([dict(dY=ga[i], X=sv["xa4"][i], dW=G2(f"{pre}proj.{i}.weight"), db=Gv(f"{pre}proj.{i}.bias")) for i in range(F)], "bwd.proj.wgrad")
             # (MLP-output dropout: the residual path C32 stays whole, the copy feeding fc2's backward is masked)
@@ -373,10 +402,22 @@ class TrainPlan(Plan):
             # ---- AdaLN_2: accumulates the norm branch onto the residual gradient
             self._norm_bwd([dict(dY=dE_[i], X=sv["xr"][i], mean=sv["st2"][i][0], rstd=sv["st2"][i][1], dX32=dx[i], dXact=ga[i],
                                  **bpar(f"{pre}ln.exp.{i}.2.", E)) for i in range(F)], E, "bwd.mlp.adaln2", True, False, False, True)
-            if model.add_info_after_cross:
+            if model.add_info_after_cross and has_ib:
                 self._ib_bwd(pre, dx, drop=sv["ib_drop"])
+            if F > 1 and xmode == "addition":
+                # x2_i = x1_i + Wu_i g + bu_i, g = gelu(s), s = sum_j n_j, n_j = ln_cross_j(Wd_j x1_j + bd_j): ga[i] = act copy of d x2_i
+                self._wgrad([dict(dY=ga[i], X=sv["sg"], dW=G2(f"{pre}cross_up.{i}.weight"), db=Gv(f"{pre}cross_up.{i}.bias")) for i in range(F)], "bwd.add.up.wgrad")
+                dgp = buf(F, M, D)
+                self._gemm([dict(A=ga[i], W=P.actT(f"{pre}cross_up.{i}.weight"), Cact=dgp[i]) for i in range(F)], "bwd.add.up.dgrad")
+                ds = buf(M, D)      # d s = (sum_i d g_i) * gelu'(s): the sum over the fields as operand segments of an identity GEMM, the derivative as its epilogue
+                self._gemm([dict(A=dgp[0], W=eng.eye(D), n_seg=F, a_seg_stride=M * D, Z=sv["s_pre"], act=2, Cact=ds)], "bwd.add.sum_gelu")
+                ddn = [buf(M, D) for _ in range(F)]
+                self._norm_bwd([dict(dY=ds, X=sv["dn"][j], mean=sv["stc"][j][0], rstd=sv["stc"][j][1], dXact=ddn[j], **bpar(f"{pre}ln_cross.{j}.", D)) for j in range(F)],
+                               D, "bwd.add.norm", True, False, False, False)
+                self._wgrad([dict(dY=ddn[j], X=sv["xa1"][j], dW=G2(f"{pre}cross_down.{j}.weight"), db=Gv(f"{pre}cross_down.{j}.bias")) for j in range(F)], "bwd.add.down.wgrad")
+                self._gemm([dict(A=ddn[j], W=P.actT(f"{pre}cross_down.{j}.weight"), R=dx[j], C32=dx[j], Cact=ga[j]) for j in range(F)], "bwd.add.down.dgrad")
             # ---- state exchange (reverse Gauss-Seidel order); ga[i] = act copy of d x2_i when field i is reached
-            if F > 1:
+            if F > 1 and xmode == "sea":
                 dnd_old = [buf(M, D, dtype=f32) for _ in range(F)]
                 dnd_new = [buf(M, D, dtype=f32) for _ in range(F)]
                 init_old, init_new = [False] * F, [False] * F
@@ -456,7 +497,7 @@ class TrainPlan(Plan):
                 g.update(dict(X=dx[i], ldx=FE, X_is_x=i * E * 4) if first else dict(X=sv["x_in"][i]))
                 groups.append(g)
             self._norm_bwd(groups, E, "bwd.self.adaln0", True, False, False, True)
-            if not model.add_info_after_cross:
+            if not model.add_info_after_cross and has_ib:
                 self._ib_bwd(pre, dx, drop=sv["ib_drop"])
         # ---- AdaLN condition MLPs: every USE contributes dmod; parameters are shared through the atomically accumulated gradients
         if adaln:

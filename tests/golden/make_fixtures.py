@@ -94,6 +94,8 @@ def model_case(name, cfg, B, T, train=False, lr=1e-3, seed=1234):
                         arrs["grad:" + k] = n(p.grad)
             opt.step()
             losses.append(loss.item())
+            if train == "grads":   # gradients, loss and the set of gradient-less parameters only (the ablation variants: small fixtures)
+                break
             if step in (1, 3):
                 for k, p in m.named_parameters():
                     if p.grad is not None:
@@ -514,6 +516,12 @@ def main():
     cases["model_sea_fourier_adaln_f3"] = lambda: model_case("model_sea_fourier_adaln_f3", OracleConfig(2, 64, 4, 80, 8, 0, 3, 2, True, "adaln", "sea", "add", "fourier"), 2, 21)
     cases["model_sea_linear_ln_f2_pre"] = lambda: model_case("model_sea_linear_ln_f2_pre", OracleConfig(1, 64, 4, 80, 8, 0, 2, 2, False, "ln", "sea", "add", "linear"), 2, 19)
     cases["model_sea_noib_adaln_f2"] = lambda: model_case("model_sea_noib_adaln_f2", OracleConfig(1, 64, 4, 80, 8, 0, 2, 2, True, "adaln", "sea", "none"), 2, 20)
+    # ... and their training step (gradients of every parameter + the set of gradient-less ones), small dims
+    cases["train_addition_adaln_f3"] = lambda: model_case("train_addition_adaln_f3", OracleConfig(2, 32, 2, 24, 8, 0, 3, 2, True, "adaln", "addition"), 2, 12, train="grads")
+    cases["train_simple_ln_f2"] = lambda: model_case("train_simple_ln_f2", OracleConfig(1, 32, 2, 24, 8, 0, 2, 2, True, "ln", "simple"), 2, 12, train="grads")
+    cases["train_sea_noib_adaln_f2"] = lambda: model_case("train_sea_noib_adaln_f2", OracleConfig(1, 32, 2, 24, 8, 0, 2, 2, True, "adaln", "sea", "none"), 2, 12, train="grads")
+    cases["train_sea_linear_ln_f2_pre"] = lambda: model_case("train_sea_linear_ln_f2_pre", OracleConfig(1, 32, 2, 24, 8, 0, 2, 2, False, "ln", "sea", "add", "linear"), 2, 12, train="grads")
+    cases["train_addition_fourier_adaln_f3"] = lambda: model_case("train_addition_fourier_adaln_f3", OracleConfig(1, 32, 2, 24, 8, 0, 3, 2, True, "adaln", "addition", "add", "fourier"), 2, 12, train="grads")
     for T in (1, 7, 16, 65):
         cases[f"model_small_adaln_f3_T{T}"] = (lambda T=T: model_case(
             f"model_small_adaln_f3_T{T}", OracleConfig(1, 64, 4, 80, 8, 0, 3, 2, True, "adaln"), 2, T))

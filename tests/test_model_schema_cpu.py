@@ -87,7 +87,7 @@ def test_flat_layout_offsets():
 
     cfg = OracleConfig(1, 64, 4, 24, 8, 0, 3, 2, True, "adaln")
     m = make(cfg)
-    dead = dead_prefixes(1, 3)
+    dead = dead_prefixes(m)
     names = [k for k, _ in m.named_parameters()]
     n_dead = sum(any(k.startswith(d) for d in dead) for k in names)
     from oracle.sea_oracle import live_param_keys

@@ -12,9 +12,12 @@ from tests.test_model_gpu import build, gpu
 pytestmark = pytest.mark.gpu
 
 TRAIN_CASES = ["model_tiny_adaln_f3", "model_tiny_ln_f2", "model_tiny_adaln_f2_pre"]
+# the ablation variants of the block (reference models/temporal.py:285-312, 103-116): 'addition' / 'simple' exchange, the info-bottleneck
+# layer not added ('none'), as nn.Linear ('linear') or as fixed Fourier features ('fourier')
+VARIANT_TRAIN_CASES = ["train_addition_adaln_f3", "train_simple_ln_f2", "train_sea_noib_adaln_f2", "train_sea_linear_ln_f2_pre", "train_addition_fourier_adaln_f3"]
 
 
-@pytest.mark.parametrize("name", TRAIN_CASES)
+@pytest.mark.parametrize("name", TRAIN_CASES + VARIANT_TRAIN_CASES)
 def test_gradients_match_reference_golden_fp32(name):
     """The reference's own train-step sequence (zero_grad, forward, MSELoss, backward) through the drop-in surface."""
     from sea_amd.utils.train_utils import SeaMSELoss
