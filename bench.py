@@ -537,7 +537,7 @@ def main_decode(args):
     dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
     torch.cuda.set_device(dev)
     groups, hidden, D, P = [[0, 1], [2]], 480, 16, 64
-    tr, T = args.batch, args.seq
+    tr, T = args.batch or 1, args.seq
     torch.manual_seed(42)
     # synthetic 2-D mesh: 30000 points, denser towards x = 0.3 (a wake-like refinement), 8 x 8 cells as in the shipped config (m = n = 9)
     gen = torch.Generator().manual_seed(7)
@@ -622,7 +622,7 @@ def main_encode(args):
     dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
     torch.cuda.set_device(dev)
     groups, hidden, D, P, H, layers, n_inp = [[0, 1], [2]], 480, 16, 64, 8, 12, 512
-    n_snap = args.batch * args.seq
+    n_snap = (args.batch or 1) * args.seq
     torch.manual_seed(42)
     enc = PointwiseEncode(groups, n_inp, hidden, layers, D, H, 2024, 0, dropout=0.0).set_compute_dtype(args.dtype).to(dev).eval()
     x = torch.randn(n_snap, P, 3, n_inp, generator=torch.Generator().manual_seed(1234)).to(dev)

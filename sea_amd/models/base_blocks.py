@@ -42,10 +42,22 @@ def _as_act(t: torch.Tensor) -> torch.Tensor:
     return out
 
 
-def _no_dropout(module: nn.Module, p: float) -> None:
-    if module.training and p > 0.0:
-        raise NotImplementedError(
-            "sea_amd: dropout > 0 in training mode is not implemented in the HIP kernels yet; use dropout=0.0 or eval()")
+_DROP_CALLS = [0]
+
+
+def _dropout_key(module: nn.Module, p: float):
+    """(seed, stream, thr) of this call's counter-based dropout masks, or None in eval mode / for p = 0: keep iff a hash byte of (seed, stream, row, column)
+    >= thr = round(256 p), kept values scaled by 256 / (256 - thr) (include/sea_hip.h, SeaDropout) — where the reference applies nn.Dropout.  Its torch RNG
+    stream cannot be reproduced; every call draws fresh masks from torch.initial_seed() and a call counter."""
+    if not module.training or p <= 0.0:
+        return None
+    thr = int(round(256 * p))
+    if thr <= 0:
+        return None
+    if thr > 255:
+        raise ValueError("dropout probability too close to 1")
+    _DROP_CALLS[0] += 1
+    return (torch.initial_seed() * 0x9E3779B1 + _DROP_CALLS[0] * 0x85EBCA77) & 0xFFFFFFFF, (id(module) >> 4) & 0xFFFF, thr
 
 
 def precompute_freqs_cis(dim: int, end: int, theta: float = 10000.0) -> torch.Tensor:
@@ -121,7 +133,7 @@ class MLP(nn.Module):
     def forward(self, x, residual=None):
         """`residual` (fp32, same shape as the output) is an extension over the reference signature: when given, the second
         GEMM's epilogue returns residual + MLP(x)."""
-        _no_dropout(self, self._p)
+        dk = _dropout_key(self, self._p)
         dt = _act_dtype()
         fc1, ln, _, fc2 = self.layers
         lead = x.shape[:-1]
@@ -132,7 +144,7 @@ class MLP(nn.Module):
                 y = torch.zeros(c.numel(), fc2.out_features, device=x.device, dtype=torch.float32)
             else:
                 y = residual.reshape(c.numel(), fc2.out_features).clone()  # the kernel accumulates in place
-            ops.ib_add([y], c, fc1.weight.reshape(-1), fc1.bias, ln.weight, ln.bias, fc2.weight, fc2.bias)
+            ops.ib_add([y], c, fc1.weight.reshape(-1), fc1.bias, ln.weight, ln.bias, fc2.weight, fc2.bias, drop=dk)
             return y.view(*lead, fc2.out_features)
         a = _as_act(x)
         M = a.shape[0]
@@ -142,7 +154,8 @@ class MLP(nn.Module):
         ops.rownorm([dict(X=h, gamma=ln.weight, beta=ln.bias, Yact=hg)], M, h.shape[1], dt != torch.float32, True, ln.eps, dt)
         y = torch.empty(M, fc2.out_features, device=x.device, dtype=torch.float32)
         R = None if residual is None else residual.reshape(M, fc2.out_features).contiguous()
-        ops.gemm_grouped([dict(A=hg, W=_as_act(fc2.weight), bias=fc2.bias, R=R, C32=y)], dt)
+        # nn.Dropout on the MLP output (reference :47), before the residual: mode 1 of the GEMM epilogue
+        ops.gemm_grouped([dict(A=hg, W=_as_act(fc2.weight), bias=fc2.bias, R=R, C32=y, drop=None if dk is None else (dk[0], dk[1], dk[2], 1))], dt)
         return y.view(*lead, fc2.out_features)
 
 
@@ -182,7 +195,7 @@ class _MaskedAttentionBase(nn.Module):
         state_dict.pop(prefix + "tril", None)
 
     def _attend(self, x_q: torch.Tensor, x_kv: torch.Tensor, residual: Optional[torch.Tensor] = None, gelu_out: bool = False) -> torch.Tensor:
-        _no_dropout(self, self._p)
+        dk = _dropout_key(self, self._p)   # nn.Dropout on the attention probabilities (reference :194, :286)
         dt = _act_dtype()
         B, T, Cdim = x_q.shape
         H, hd = self.n_heads, self.head_dim
@@ -201,7 +214,7 @@ class _MaskedAttentionBase(nn.Module):
         ops.qkv_rope_grouped([dict(A=aq, W=Wq, bias=self.q.bias, col0=0, Q=Q), dict(A=akv, W=Wkv, bias=bkv, col0=Cdim, K=K, Vt=Vt)],
                              rope, H, hd, T, 0, cap, float(hd) ** -0.5, dt)
         O = torch.empty(B, T, Cdim, device=dev, dtype=dt)
-        ops.attention_fwd([dict(Q=Q, K=K, Vt=Vt, O=O)], B, H, hd, T, T, cap, 0, self.src_len, dt)
+        ops.attention_fwd([dict(Q=Q, K=K, Vt=Vt, O=O)], B, H, hd, T, T, cap, 0, self.src_len, dt, drop=dk)
         y = torch.empty(B * T, Cdim, device=dev, dtype=torch.float32)
         R = None if residual is None else residual.reshape(B * T, Cdim).contiguous()
         ops.gemm_grouped([dict(A=O.view(B * T, Cdim), W=_as_act(self.projection.weight), R=R, C32=y, act=int(gelu_out))], dt)

@@ -22,7 +22,7 @@ def _mat(t: torch.Tensor, name: str) -> torch.Tensor:
 
 
 def fill_gemm_group(g: N.SeaGemmGroup, A, W, bias=None, R=None, C32=None, Cact=None, n_seg=1, a_seg_stride=0, act=0,
-                    bias_scale=1.0, M=None, N_=None, K=None, Z=None, silu=None) -> None:
+                    bias_scale=1.0, M=None, N_=None, K=None, Z=None, silu=None, drop=None) -> None:
     if silu is not None:   # generated A operand: dict(c f32 [M], w1 f32 [K], b1 f32 [K]) — A[m, k] = silu(w1[k] c[m] + b1[k])
         g.silu_c, g.silu_w1, g.silu_b1 = silu["c"].data_ptr(), silu["w1"].data_ptr(), silu["b1"].data_ptr()
         g.A, g.lda, g.W, g.ldw = None, 0, W.data_ptr(), W.stride(0)
@@ -46,6 +46,8 @@ def fill_gemm_group(g: N.SeaGemmGroup, A, W, bias=None, R=None, C32=None, Cact=N
     g.n_seg = n_seg
     g.act = act
     g.bias_scale = bias_scale
+    if drop is not None:   # (seed, stream, thr, mode): counter-based dropout of the epilogue (include/sea_hip.h, SeaDropout)
+        g.drop.seed, g.drop.stream, g.drop.thr, g.drop.mode = drop
 
 
 def gemm_grouped(groups: Sequence[Dict], dtype: torch.dtype) -> None:
@@ -69,7 +71,7 @@ def gemm_grouped(groups: Sequence[Dict], dtype: torch.dtype) -> None:
         if d.get("Cact") is not None and d["Cact"].dtype != dtype:
             raise ValueError(f"gemm group {i}: Cact dtype mismatch")
         fill_gemm_group(arr[i], A, W, d.get("bias"), d.get("R"), d.get("C32"), d.get("Cact"), d.get("n_seg", 1),
-                        d.get("a_seg_stride", 0), d.get("act", 0), d.get("bias_scale", 1.0), K=d.get("K"), Z=d.get("Z"))
+                        d.get("a_seg_stride", 0), d.get("act", 0), d.get("bias_scale", 1.0), K=d.get("K"), Z=d.get("Z"), drop=d.get("drop"))
     N.check(N.lib().sea_gemm_grouped(arr, n, N.dtype_code(dtype), N.stream_ptr()), "sea_gemm_grouped")
 
 
@@ -96,7 +98,7 @@ def qkv_rope_grouped(groups: Sequence[Dict], rope: torch.Tensor, H: int, hd: int
 
 
 def attention_fwd(problems: Sequence[Dict], B: int, H: int, hd: int, Tq: int, Tk: int, cap: int, q_pos0: int,
-                  src_len: int, dtype: torch.dtype) -> None:
+                  src_len: int, dtype: torch.dtype, drop=None) -> None:
     """problems: dicts with Q [B,H,Tq,hd], K [B,H,cap,hd], Vt [B,H,hd,cap], O [B,Tq,H*hd] (row stride = O.stride(1)),
     optional LSE f32 [B,H,Tq]."""
     P = N.SeaAttnParams()
@@ -114,6 +116,8 @@ def attention_fwd(problems: Sequence[Dict], B: int, H: int, hd: int, Tq: int, Tk
         P.p[i].Q, P.p[i].K, P.p[i].Vt, P.p[i].O = d["Q"].data_ptr(), d["K"].data_ptr(), d["Vt"].data_ptr(), O.data_ptr()
         P.p[i].LSE = N.ptr(d.get("LSE"))
     P.B, P.H, P.hd, P.Tq, P.Tk, P.cap, P.q_pos0, P.src_len, P.ldo = B, H, hd, Tq, Tk, cap, q_pos0, src_len, ldo
+    if drop is not None:   # (seed, first stream, thr): dropout of the attention probabilities, problem i on stream + i
+        P.drop.seed, P.drop.stream, P.drop.thr = drop
     N.check(N.lib().sea_attention_fwd(C.byref(P), N.dtype_code(dtype), N.stream_ptr()), "sea_attention_fwd")
 
 
@@ -250,9 +254,12 @@ def silu_outer(groups: Sequence[Dict], c: torch.Tensor, M: int, dtype: torch.dty
     N.check(N.lib().sea_silu_outer(arr, n, c.data_ptr(), M, N.dtype_code(dtype), N.stream_ptr()), "sea_silu_outer")
 
 
-def ib_add(xs: Sequence[torch.Tensor], c: torch.Tensor, w1, b1, lnw, lnb, w2, b2) -> None:
-    """xs: f32 [M,E] matrices (equal row stride) updated in place: x += W2 gelu(LN(w1 c + b1)) + b2."""
+def ib_add(xs: Sequence[torch.Tensor], c: torch.Tensor, w1, b1, lnw, lnb, w2, b2, drop=None) -> None:
+    """xs: f32 [M,E] matrices (equal row stride) updated in place: x += W2 gelu(LN(w1 c + b1)) + b2; drop = (seed, first stream, thr): dropout of the MLP output,
+    field i on stream + i."""
     P = N.SeaIbParams()
+    if drop is not None:
+        P.drop.seed, P.drop.stream, P.drop.thr = drop
     M, E = xs[0].shape
     for i, x in enumerate(xs):
         _mat(x, "x")

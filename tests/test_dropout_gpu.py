@@ -208,3 +208,39 @@ def test_model_training_with_dropout_is_consistent():
     lm, _, _ = loss_at(-eps, direction)
     numeric = (lp - lm) / (2 * eps)
     assert abs(analytic - numeric) < 3e-2 * max(abs(numeric), 1e-3), (analytic, numeric)
+
+
+def test_standalone_module_forwards_with_dropout():
+    """The stand-alone module mirrors in train() with dropout > 0 (cylinder ships 0.1): the MLP output is zeroed with probability thr / 256 and the kept
+    values are the eval-mode values scaled by 256 / (256 - thr) — exactly, element by element (nn.Dropout's keep / scale semantics); the attention
+    modules drop probabilities (fresh masks per call, mean over calls -> the eval output); eval() is untouched."""
+    from sea_amd.models.base_blocks import MLP, MaskedMultiHeadAttention, MaskedMultiHeadCrossAttention
+
+    torch.manual_seed(11)
+    p = 0.25
+    thr = round(256 * p)
+    mlp = MLP(64, p, 8).to(dev())
+    x = rnd(3, 40, 64, seed=5)
+    mlp.eval()
+    with torch.no_grad():
+        y_eval = mlp(x)
+        mlp.train()
+        y1, y2 = mlp(x), mlp(x)
+    zero = y1 == 0
+    assert abs(float(zero.float().mean()) - thr / 256) < 0.03
+    assert rel(y1[~zero], y_eval[~zero] * (256.0 / (256 - thr))) < 1e-5
+    assert not torch.equal(y1, y2)                      # fresh masks per call
+    att = MaskedMultiHeadAttention(4, 64, 48, 0, p).to(dev())
+    cross = MaskedMultiHeadCrossAttention(4, 64, 48, 0, p).to(dev())
+    for mod, args in ((att, (x,)), (cross, (x, rnd(3, 40, 64, seed=6)))):
+        mod.eval()
+        with torch.no_grad():
+            ref = mod(*args)
+            mod.train()
+            outs = [mod(*args) for _ in range(48)]
+        assert all(torch.isfinite(o).all() for o in outs) and not torch.equal(outs[0], outs[1])
+        mean = torch.stack(outs).mean(0)
+        assert rel(mean[:, 8:], ref[:, 8:]) < 0.12     # unbiased (rows with several keys; 48 draws)
+        mod.eval()
+        with torch.no_grad():
+            assert torch.equal(mod(*args), ref)

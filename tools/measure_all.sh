@@ -1,19 +1,18 @@
 #!/bin/bash
 # Round measurement set (run on the MI355X box from the repository root): bench lines, rocprofv3 kernel stats / traces, PMC passes.
+#   tools/measure_all.sh [tag]      -> gpurun_out/<tag>/   (default tag: final)
 set -o pipefail
-O=gpurun_out/final
+O=gpurun_out/${1:-final}
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 python bench.py > $O/bench_n1.json 2> $O/bench_n1.err || exit 1
-python bench.py --batch 8 --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_b8.json 2>/dev/null || exit 1
-python bench.py --mode train --batch 8 --steps 20 --warmup 5 > $O/bench_train.json 2>/dev/null || exit 1
-python bench.py --mode kv --steps 20 --warmup 3 > $O/bench_kv.json 2>/dev/null || exit 1
+python bench.py --mode rollout --batch 8 --steps 50 --warmup 5 --no-cpu-baseline > $O/bench_rollout_b8.json 2>/dev/null || exit 1
 python bench.py --mode decode --steps 10 --warmup 3 > $O/bench_decode.json 2>/dev/null || exit 1
 python bench.py --mode encode --steps 10 --warmup 3 > $O/bench_encode.json 2>/dev/null || exit 1
 echo "bench lines done"
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_fwd -o run -- python3 bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-graph > $O/prof_fwd.json 2> $O/prof_fwd.err || exit 1
-rocprofv3 --kernel-trace --output-format csv -d $O/prof_graph -o run -- python3 bench.py --steps 40 --warmup 5 --no-cpu-baseline > $O/prof_graph.json 2> $O/prof_graph.err || exit 1
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_train -o run -- python3 bench.py --mode train --batch 8 --steps 10 --warmup 3 > $O/prof_train.json 2> $O/prof_train.err || exit 1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_fwd -o run -- python3 bench.py --mode rollout --steps 50 --warmup 10 --no-cpu-baseline --no-graph > $O/prof_fwd.json 2> $O/prof_fwd.err || exit 1
+rocprofv3 --kernel-trace --output-format csv -d $O/prof_graph -o run -- python3 bench.py --mode rollout --steps 40 --warmup 5 --no-cpu-baseline > $O/prof_graph.json 2> $O/prof_graph.err || exit 1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_train -o run -- python3 bench.py --mode train --steps 10 --warmup 3 > $O/prof_train.json 2> $O/prof_train.err || exit 1
 echo "traces done"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_f -o run -- python3 tools/pmc_forward.py > $O/pmc_f.log 2>&1 || exit 1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_w -o run -- python3 tools/pmc_forward.py > $O/pmc_w.log 2>&1 || exit 1
