@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define SEA_ABI_VERSION 2
+#define SEA_ABI_VERSION 3
 
 enum { SEA_F32 = 0, SEA_BF16 = 1 };
 
@@ -41,7 +41,7 @@ enum {
 int sea_abi_version(void);
 const char* sea_last_error(void);
 /* sizeof of every ABI struct in declaration order (SeaGemmGroup, SeaQkvGroup, SeaQkvCommon, SeaAttnProblem,
- * SeaAttnParams, SeaNormGroup, SeaSiluGroup, SeaIbParams, ..., SeaLaunchRec, SeaGemmNormGroup, SeaExchangeTail, SeaMlpGroup last): lets a binding verify its layout.  Host only. */
+ * SeaAttnParams, SeaNormGroup, SeaSiluGroup, SeaIbParams, ..., SeaLaunchRec, SeaGemmNormGroup, SeaExchangeTail, SeaMlpGroup, SeaKvNorm, SeaKvField, SeaKvPair, SeaKvLayer, SeaKvGlobal last): lets a binding verify its layout.  Host only. */
 int sea_struct_sizes(int* out, int cap);
 /* Number of compute units / name of device 0's architecture as HIP reports them (diagnostics for bench.py). */
 int sea_device_info(int* cu_count, char* arch, int arch_len);
@@ -547,6 +547,67 @@ int sea_unpatchify(const float* in, int64_t sb, int64_t sp, int64_t sf, int64_t 
  */
 int sea_patchify(const float* in, const int32_t* index_map, const float* scale, const float* shift, float* out, int64_t sb, int64_t sp, int64_t sf,
                  int64_t sc, int B, int P, int F, int C_map, int C_out, int n_points, float pad_value, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Exact KV-cache rollout, the whole step loop in one call (utils/train_utils.py:202-209 around models/temporal.py:120-200, 398-417; one row per
+ * call instead of the growing prefix).  Step k (position pos0 + k) reads traj[pos0 + k] ([B, F, E] f32), appends this position's keys / values to the
+ * caches, attends over positions <= pos0 + k and writes traj[pos0 + k + 1].  Seven launches per layer and step (sea_amd/csrc/kvstep.hip): every
+ * Linear is a GEMV of fp32 activation vectors against act-dtype weights; the q/k/v projections of a head ride in its attention workgroup; the
+ * Gauss-Seidel tails of all fields are one launch whose workgroups hand the updated field over through tagged 8-byte granules.
+ * Supported: exchange_mode 'sea' (exchange = 1, F >= 2) or 'simple' (exchange = 0), LN_type adaln / ln, any info-bottleneck mode (the caller
+ * evaluates the term for all steps), src_len = 0, E <= 512, head dims 8 / 16 / 32 / 64, widths whose 16-byte chunk count is a power of two <= 64
+ * or 128 / 256 / 512.
+ * What depends on the condition only is evaluated by the CALLER for all steps before the call: SeaKvNorm.mod = act [n_rows, 2 d] (row (pos) * B + b:
+ * AdaLN's cond_mlp output, models/base_blocks.py:337-344; NULL for LN_type 'ln'), SeaKvLayer.ib = f32 [n_rows, E] (the info-bottleneck term,
+ * models/temporal.py:103-114; NULL for ib_addition_mode 'none').
+ * Caches are act [B, H, cap, hd] for keys AND values (row-major values: an append is one row).  Workspaces are f32, sized in elements:
+ * att_e, xr, xq, x3, xl[0], xl[1]: B F E; hbuf: B F S; nd_old: B F D; oc, qc: F (F-1) B D; ml: F (F-1) B H 2; handoff: B F D 8-byte words, zeroed once
+ * by the caller; err: one int32, zeroed by the caller — non-zero after the call's work has completed means a hand-off wait gave up (results invalid).
+ * tag0: the caller's running launch counter (each (step, layer) consumes one value; values must not repeat while `handoff` lives; 0 is never used).
+ */
+#define SEA_KV_MAX_FIELDS 4
+typedef struct {
+    const float* gamma;   /* f32 [d] */
+    const float* beta;    /* f32 [d] or NULL */
+    const void* mod;      /* act [n_rows, ldmod] (scale | shift) or NULL */
+    int32_t ldmod, pad_;
+} SeaKvNorm;
+typedef struct {
+    SeaKvNorm ln0, ln_cross, ln2;                  /* ln.exp.i.0, ln_cross.i, ln.exp.i.2 */
+    const void* Wqkv; const float* bqkv;           /* act [3E, E] (q | k | v), f32 [3E] */
+    const void* Wo;                                /* act [E, E], no bias */
+    const void* Wdown; const float* bdown;         /* act [D, E] */
+    const void* Wup; const float* bup;             /* act [E, D] */
+    const void* W1; const float* b1;               /* act [S, E] */
+    const float* lnw; const float* lnb;            /* f32 [S]: nn.LayerNorm(S) */
+    const void* W2; const float* b2;               /* act [E, S] */
+    const void* Wproj; const float* bproj;         /* act [E, E] */
+    void* Ks; void* Vs;                            /* act [B, H, cap, E / H] */
+} SeaKvField;
+typedef struct {
+    const void* Wq; const float* bq;               /* act [D, D] */
+    const void* Wkv; const float* bkv;             /* act [2D, D] (k | v) */
+    const void* Wp;                                /* act [D, D], no bias */
+    void* Kc; void* Vc;                            /* act [B, H, cap, D / H] */
+} SeaKvPair;
+typedef struct {
+    SeaKvField f[SEA_KV_MAX_FIELDS];
+    SeaKvPair p[SEA_KV_MAX_FIELDS][SEA_KV_MAX_FIELDS];   /* p[i][j]: field i attends to field j (j != i) */
+    const float* ib;
+} SeaKvLayer;
+typedef struct {
+    int32_t F, E, D, S, H, B, L, cap, exchange, ib_after_cross;
+    SeaKvNorm final_ln[SEA_KV_MAX_FIELDS];
+    const float* rope_self;    /* f32 [max_len, E / H / 2, 2] (cos, sin) */
+    const float* rope_cross;   /* f32 [max_len, D / H / 2, 2] */
+    float* traj;               /* f32 [n_positions + 1, B, F, E] */
+    float* xl[2];
+    float* att_e; float* xr; float* xq; float* x3; float* hbuf; float* nd_old; float* oc; float* qc; float* ml;
+    unsigned long long* handoff;
+    int32_t* err;
+} SeaKvGlobal;
+
+int sea_kv_rollout(const SeaKvGlobal* G, const SeaKvLayer* layers, int pos0, int n_steps, uint32_t tag0, int dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Self-test of the MFMA fragment maps this library relies on (16x16x32 bf16 and 16x16x4 f32, A/B/C lane maps):

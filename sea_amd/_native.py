@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libsea_hip.so")
 
 SEA_F32, SEA_BF16 = 0, 1
-ABI_VERSION = 2   # include/sea_hip.h SEA_ABI_VERSION
+ABI_VERSION = 3   # include/sea_hip.h SEA_ABI_VERSION
 MAX_GROUPS = 16
 MAX_ATTN_PROBLEMS = 8
 MAX_NORM_GROUPS = 16
@@ -149,6 +149,36 @@ class SeaMlpGroup(C.Structure):
                 ("lda", _i32), ("ldw", _i32), ("ldh", _i32), ("M", _i32), ("E", _i32), ("S", _i32)]
 
 
+KV_MAX_FIELDS = 4
+
+
+class SeaKvNorm(C.Structure):
+    _fields_ = [("gamma", _vp), ("beta", _vp), ("mod", _vp), ("ldmod", _i32), ("pad_", _i32)]
+
+
+class SeaKvField(C.Structure):
+    _fields_ = [("ln0", SeaKvNorm), ("ln_cross", SeaKvNorm), ("ln2", SeaKvNorm),
+                ("Wqkv", _vp), ("bqkv", _vp), ("Wo", _vp), ("Wdown", _vp), ("bdown", _vp), ("Wup", _vp), ("bup", _vp),
+                ("W1", _vp), ("b1", _vp), ("lnw", _vp), ("lnb", _vp), ("W2", _vp), ("b2", _vp), ("Wproj", _vp), ("bproj", _vp),
+                ("Ks", _vp), ("Vs", _vp)]
+
+
+class SeaKvPair(C.Structure):
+    _fields_ = [("Wq", _vp), ("bq", _vp), ("Wkv", _vp), ("bkv", _vp), ("Wp", _vp), ("Kc", _vp), ("Vc", _vp)]
+
+
+class SeaKvLayer(C.Structure):
+    _fields_ = [("f", SeaKvField * KV_MAX_FIELDS), ("p", (SeaKvPair * KV_MAX_FIELDS) * KV_MAX_FIELDS), ("ib", _vp)]
+
+
+class SeaKvGlobal(C.Structure):
+    _fields_ = [("F", _i32), ("E", _i32), ("D", _i32), ("S", _i32), ("H", _i32), ("B", _i32), ("L", _i32), ("cap", _i32),
+                ("exchange", _i32), ("ib_after_cross", _i32), ("final_ln", SeaKvNorm * KV_MAX_FIELDS),
+                ("rope_self", _vp), ("rope_cross", _vp), ("traj", _vp), ("xl", _vp * 2),
+                ("att_e", _vp), ("xr", _vp), ("xq", _vp), ("x3", _vp), ("hbuf", _vp), ("nd_old", _vp), ("oc", _vp), ("qc", _vp), ("ml", _vp),
+                ("handoff", _vp), ("err", _vp)]
+
+
 MAX_WGRAD_GROUPS = 16
 MAX_NORM_BWD_GROUPS = 8
 MAX_SILU_BWD_GROUPS = 24
@@ -208,6 +238,8 @@ def lib() -> C.CDLL:
     L.sea_mlp_fc1_ln_gelu.restype = C.c_int
     L.sea_run_list.argtypes = [C.POINTER(SeaLaunchRec), C.c_int, _vp]
     L.sea_run_list.restype = C.c_int
+    L.sea_kv_rollout.argtypes = [C.POINTER(SeaKvGlobal), C.POINTER(SeaKvLayer), C.c_int, C.c_int, C.c_uint32, C.c_int, _vp]
+    L.sea_kv_rollout.restype = C.c_int
     for name in ("sea_attention_bwd", "sea_wgrad_grouped", "sea_transpose_weights", "sea_rownorm_bwd", "sea_silu_outer_bwd", "sea_ib_bwd"):
         getattr(L, name).restype = C.c_int
     L.sea_mse_fwd_bwd.argtypes = [_vp, _vp, _vp, _vp, _vp, C.c_int, _i64, C.c_float, _vp]
@@ -226,14 +258,14 @@ def lib() -> C.CDLL:
 
 ABI_STRUCTS = (SeaGemmGroup, SeaQkvGroup, SeaQkvCommon, SeaAttnProblem, SeaAttnParams, SeaNormGroup, SeaSiluGroup,
                SeaIbParams, SeaWgradGroup, SeaNormBwdGroup, SeaSiluBwdGroup, SeaIbBwdParams, SeaAttnBwdProblem, SeaAttnBwdParams,
-               SeaDropout, SeaLaunchRec, SeaGemmNormGroup, SeaExchangeTail, SeaMlpGroup)
+               SeaDropout, SeaLaunchRec, SeaGemmNormGroup, SeaExchangeTail, SeaMlpGroup, SeaKvNorm, SeaKvField, SeaKvPair, SeaKvLayer, SeaKvGlobal)
 
 EXPORTED_SYMBOLS = (
     "sea_abi_version", "sea_last_error", "sea_struct_sizes", "sea_device_info", "sea_gemm_grouped", "sea_qkv_rope_grouped",
     "sea_attention_fwd", "sea_rownorm", "sea_silu_outer", "sea_ib_add", "sea_convert_f32_to_act", "sea_selftest_mfma",
     "sea_mse_fwd_bwd", "sea_relative_mse", "sea_adamw_flat",
     "sea_wgrad_grouped", "sea_transpose_weights", "sea_rownorm_bwd", "sea_silu_outer_bwd", "sea_ib_bwd",
-    "sea_attention_bwd", "sea_dropout_mask", "sea_run_list", "sea_unpatchify", "sea_gemm_rownorm", "sea_exchange_tail", "sea_patchify", "sea_silu_outer_ib", "sea_mlp_fc1_ln_gelu",
+    "sea_attention_bwd", "sea_dropout_mask", "sea_run_list", "sea_unpatchify", "sea_gemm_rownorm", "sea_exchange_tail", "sea_patchify", "sea_silu_outer_ib", "sea_mlp_fc1_ln_gelu", "sea_kv_rollout",
 )
 
 

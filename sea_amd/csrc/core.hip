@@ -19,7 +19,8 @@ extern "C" int sea_struct_sizes(int* out, int cap) {
                          (int)sizeof(SeaAttnParams), (int)sizeof(SeaNormGroup), (int)sizeof(SeaSiluGroup), (int)sizeof(SeaIbParams),
                          (int)sizeof(SeaWgradGroup), (int)sizeof(SeaNormBwdGroup), (int)sizeof(SeaSiluBwdGroup), (int)sizeof(SeaIbBwdParams),
                          (int)sizeof(SeaAttnBwdProblem), (int)sizeof(SeaAttnBwdParams), (int)sizeof(SeaDropout), (int)sizeof(SeaLaunchRec),
-                         (int)sizeof(SeaGemmNormGroup), (int)sizeof(SeaExchangeTail), (int)sizeof(SeaMlpGroup)};
+                         (int)sizeof(SeaGemmNormGroup), (int)sizeof(SeaExchangeTail), (int)sizeof(SeaMlpGroup), (int)sizeof(SeaKvNorm), (int)sizeof(SeaKvField),
+                         (int)sizeof(SeaKvPair), (int)sizeof(SeaKvLayer), (int)sizeof(SeaKvGlobal)};
     const int n = (int)(sizeof(sizes) / sizeof(sizes[0]));
     for (int i = 0; i < n && i < cap; ++i) out[i] = sizes[i];
     return n;

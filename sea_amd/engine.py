@@ -981,6 +981,7 @@ class TemporalEngine:
         self._plans: Dict[Tuple, Plan] = {}
         self._graphs: Dict[Tuple, Tuple] = {}
         self._train_plans: Dict[Tuple, object] = {}
+        self._kv_fast: Dict[int, object] = {}          # B -> kv_engine.KvFast
         self.grads: Optional[torch.Tensor] = None      # flat fp32 gradient buffer, same layout as params.flat32
         self.grads_dirty = False                       # True once a backward has accumulated into it since the last zero
         self._drop_step = 0                            # dropout streams are re-keyed every training forward
@@ -1149,6 +1150,13 @@ class TemporalEngine:
             # the reference masks with tril(diagonal=src_len) (models/base_blocks.py:173, 265): in its recompute loop the rows already produced re-attend
             # to the src_len rows appended after them, so their K/V and everything downstream change from step to step — a cache is not exact
             raise NotImplementedError("sea_amd: the KV-cache rollout is exact only for src_len == 0; use the recompute rollout (rollout(..., mode='recompute'))")
+        from . import kv_engine
+        if kv_engine.supported(self, B):
+            # small models: seven launches per layer and step, condition-only work batched over all steps up front (sea_kv_rollout)
+            kf = self._kv_fast.get(B)
+            if kf is None:
+                kf = self._kv_fast[B] = kv_engine.KvFast(self, B)
+            return kf.rollout(x0, ib, n_steps)
         self.params.sync()
         traj = torch.empty(n_steps + 1, B, F, E, device=self.device, dtype=torch.float32)
         traj[0].copy_(x0[:, 0])
