@@ -16,6 +16,7 @@
 // Reference: the loop of utils/train_utils.py:202-209 around models/temporal.py:120-200, 398-417 (one row per call instead of the whole prefix).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "../../include/sea_hip.h"
@@ -43,10 +44,65 @@ __device__ __forceinline__ void unpack_w<__bf16>(const uint4& r, float (&o)[8]) 
 __device__ __forceinline__ float round_to(float v, float) { return v; }
 __device__ __forceinline__ float round_to(float v, __bf16) { return (float)(__bf16)v; }
 
+// ------------------------------------------------------------------------------------------------ reductions without the LDS crossbar
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+// a[u] <- sum of a[u] over the TL consecutive lanes of this lane's team (TL a power of two <= 64); every lane of the team gets the sum.
+// quad_perm swaps, then half-row / row mirrors (the groups below are already uniform), then gfx950's row / half swaps.
+template <int N>
+__device__ __forceinline__ void team_reduce(float (&a)[N], int TL) {
+    if (TL >= 2) {
+#pragma unroll
+        for (int u = 0; u < N; ++u) a[u] += dpp_f<0xB1>(a[u]);
+    }
+    if (TL >= 4) {
+#pragma unroll
+        for (int u = 0; u < N; ++u) a[u] += dpp_f<0x4E>(a[u]);
+    }
+    if (TL >= 8) {
+#pragma unroll
+        for (int u = 0; u < N; ++u) a[u] += dpp_f<0x141>(a[u]);
+    }
+    if (TL >= 16) {
+#pragma unroll
+        for (int u = 0; u < N; ++u) a[u] += dpp_f<0x140>(a[u]);
+    }
+    if (TL >= 32) {
+#pragma unroll
+        for (int u = 0; u < N; ++u) {
+            const unsigned x = __float_as_uint(a[u]);
+            const auto r = __builtin_amdgcn_permlane16_swap(x, x, false, false);
+            a[u] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+        }
+    }
+    if (TL >= 64) {
+#pragma unroll
+        for (int u = 0; u < N; ++u) {
+            const unsigned x = __float_as_uint(a[u]);
+            const auto r = __builtin_amdgcn_permlane32_swap(x, x, false, false);
+            a[u] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+        }
+    }
+}
+__device__ __forceinline__ float wave_sum_fast(float v) {
+    float a[1] = {v};
+    team_reduce<1>(a, 64);
+    return a[0];
+}
+__device__ __forceinline__ float wave_max_fast(float v) {
+    v = fmaxf(v, dpp_f<0xB1>(v));
+    v = fmaxf(v, dpp_f<0x4E>(v));
+    v = fmaxf(v, dpp_f<0x141>(v));
+    v = fmaxf(v, dpp_f<0x140>(v));
+    return group_max4(v);
+}
+
 // ------------------------------------------------------------------------------------------------ workgroup reductions
 // red: LDS, >= 32 floats.  Every thread of the workgroup calls; contains two barriers.
 __device__ __forceinline__ float wg_sum(float v, float* red, int tid, int nthreads) {
-    v = wave_sum(v);
+    v = wave_sum_fast(v);
     __syncthreads();                     // red may still be read from a previous call
     if ((tid & 63) == 0) red[tid >> 6] = v;
     __syncthreads();
@@ -55,8 +111,7 @@ __device__ __forceinline__ float wg_sum(float v, float* red, int tid, int nthrea
     return s;
 }
 __device__ __forceinline__ float wg_max(float v, float* red, int tid, int nthreads) {
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    v = wave_max_fast(v);
     __syncthreads();
     if ((tid & 63) == 0) red[tid >> 6] = v;
     __syncthreads();
@@ -68,8 +123,31 @@ __device__ __forceinline__ float wg_max(float v, float* red, int tid, int nthrea
 // ------------------------------------------------------------------------------------------------ row norm (models/base_blocks.py:320-352)
 // ys = (xs - mean) * rstd * gq + bq over d elements (both in LDS, may alias), two-pass statistics like rownorm_kernel; gq = gamma + 1 + mod[0:d],
 // bq = beta + mod[d:2d] with a modulation row, else gamma / beta (beta may be null).  Optional GELU (the MLP's LayerNorm + GELU).
-template <typename T>
-__device__ __forceinline__ void wg_norm(const float* xs, float* ys, int d, const SeaKvNorm& nm, int64_t modrow, bool gelu, float* red, int tid, int nthreads) {
+// NormRegs: this thread's gain / shift of up to NPT elements (i = tid + k nthreads), requested at kernel entry so that they are not a round trip
+// of their own behind the statistics.
+template <int NPT>
+struct NormRegs {
+    float gq[NPT], bq[NPT];
+};
+template <typename T, int NPT>
+__device__ __forceinline__ void norm_issue(NormRegs<NPT>& R, int d, const SeaKvNorm& nm, int64_t modrow, int tid, int nthreads) {
+    const T* mod = nm.mod != nullptr ? static_cast<const T*>(nm.mod) + modrow * nm.ldmod : nullptr;
+#pragma unroll
+    for (int k = 0; k < NPT; ++k) {
+        const int i = tid + k * nthreads;
+        R.gq[k] = R.bq[k] = 0.f;
+        if (i < d) {
+            R.gq[k] = nm.gamma[i];
+            if (nm.beta != nullptr) R.bq[k] = nm.beta[i];
+            if (mod != nullptr) {
+                R.gq[k] += 1.0f + to_f32(mod[i]);
+                R.bq[k] += to_f32(mod[d + i]);
+            }
+        }
+    }
+}
+template <int NPT>
+__device__ __forceinline__ void wg_norm_r(const float* xs, float* ys, int d, const NormRegs<NPT>& R, bool gelu, float* red, int tid, int nthreads) {
     float s = 0.f;
     for (int i = tid; i < d; i += nthreads) s += xs[i];
     const float mean = wg_sum(s, red, tid, nthreads) / (float)d;
@@ -79,73 +157,118 @@ __device__ __forceinline__ void wg_norm(const float* xs, float* ys, int d, const
         q = fma1(c, c, q);
     }
     const float rstd = 1.0f / sqrtf(wg_sum(q, red, tid, nthreads) / (float)d + KV_EPS);
-    const T* mod = nm.mod != nullptr ? static_cast<const T*>(nm.mod) + modrow * nm.ldmod : nullptr;
-    for (int i = tid; i < d; i += nthreads) {
-        float gq = nm.gamma[i], bq = nm.beta != nullptr ? nm.beta[i] : 0.f;
-        if (mod != nullptr) {
-            gq += 1.0f + to_f32(mod[i]);
-            bq += to_f32(mod[d + i]);
+#pragma unroll
+    for (int k = 0; k < NPT; ++k) {
+        const int i = tid + k * nthreads;
+        if (i < d) {
+            float o = (xs[i] - mean) * rstd * R.gq[k] + R.bq[k];
+            if (gelu) o = gelu_erf(o);
+            ys[i] = o;
         }
-        float o = (xs[i] - mean) * rstd * gq + bq;
-        if (gelu) o = gelu_erf(o);
-        ys[i] = o;
     }
     __syncthreads();
 }
 
 // ------------------------------------------------------------------------------------------------ GEMV
 // ys[r] = sum_k W[rowmap(r), k] * xs[k], r < nrows; xs, ys in LDS (fp32).  A team of TL lanes owns a row: lane tl of the team holds the 16-byte
-// chunks tl, tl + TL, ... of it (CPL per lane; CPL == 1: K / EPC <= 64 chunks, several teams per wave); 8 (or CPL) loads per lane are in flight.
-// The caller puts a barrier between this and the first read of ys.
-template <typename T, int CPL, typename RowMap>
-__device__ __forceinline__ void wg_gemv_c(const T* __restrict__ W, int ldw, int K, int nrows, const float* xs, float* ys, RowMap rowmap, int tid, int nthreads) {
+// chunks tl, tl + TL, ... of it (CPL per lane; CPL == 1: K / EPC <= 64 chunks, several teams per wave).  The workgroup covers rpp rows per
+// "block"; gemv_issue requests the weights of NB blocks into registers (no dependence on the input vector: issued at kernel entry, or one
+// stage ahead), gemv_apply consumes them.  The caller puts a barrier between gemv_apply and the first read of ys.
+struct Geo {
+    int TL, tpw, team, tl, rpp, wave;
+};
+template <int CPL>
+__device__ __forceinline__ Geo team_geo(int kc, int tid, int nthreads) {
+    Geo g;
+    const int lane = tid & 63;
+    g.wave = tid >> 6;
+    g.TL = CPL == 1 ? kc : 64;                   // power of two <= 64
+    const int l2 = 31 - __builtin_clz((unsigned)g.TL);
+    g.tpw = 64 >> l2;
+    g.team = lane >> l2;
+    g.tl = lane & (g.TL - 1);
+    g.rpp = (nthreads >> 6) * g.tpw;
+    return g;
+}
+template <int CPL, int NB>
+struct WRegs {
+    uint4 w[NB][CPL];
+};
+template <typename T, int CPL, int NB, typename RowMap>
+__device__ __forceinline__ void gemv_issue(WRegs<CPL, NB>& R, const T* __restrict__ W, int ldw, int K, int nrows, int blk0, RowMap rowmap, int tid, int nthreads) {
     constexpr int EPC = ActTraits<T>::EPC;
-    constexpr int RB = CPL >= 8 ? 1 : 8 / CPL;
-    const int lane = tid & 63, wave = tid >> 6, nw = nthreads >> 6;
-    const int kc = K / EPC;
-    const int TL = CPL == 1 ? kc : 64;            // power of two <= 64
-    const int tpw = 64 / TL;
-    const int team = lane / TL, tl = lane - team * TL;
+    const Geo g = team_geo<CPL>(K / EPC, tid, nthreads);
+#pragma unroll
+    for (int u = 0; u < NB; ++u) {   // no branch per block (blocks beyond the rows re-read the last row: a cache hit; a branch here costs the allocator every register)
+        int row = (blk0 + u) * g.rpp + g.wave * g.tpw + g.team;
+        row = row < nrows ? row : nrows - 1;
+        const T* wr = W + (int64_t)rowmap(row) * ldw;
+#pragma unroll
+        for (int t = 0; t < CPL; ++t) R.w[u][t] = *reinterpret_cast<const uint4*>(wr + (g.tl + t * g.TL) * EPC);
+    }
+}
+template <typename T, int CPL, int NB>
+__device__ __forceinline__ void gemv_apply(const WRegs<CPL, NB>& R, int K, int nrows, int blk0, const float* xs, float* ys, int tid, int nthreads) {
+    constexpr int EPC = ActTraits<T>::EPC;
+    const Geo g = team_geo<CPL>(K / EPC, tid, nthreads);
     float xv[CPL][EPC];
 #pragma unroll
     for (int t = 0; t < CPL; ++t)
 #pragma unroll
-        for (int e = 0; e < EPC; ++e) xv[t][e] = xs[(tl + t * TL) * EPC + e];
-    const int rpp = nw * tpw;                     // rows per pass of the workgroup
-    for (int r0 = 0; r0 < nrows; r0 += rpp * RB) {
-        uint4 w[RB][CPL];
+        for (int e = 0; e < EPC; ++e) xv[t][e] = xs[(g.tl + t * g.TL) * EPC + e];
+    float acc[NB];
 #pragma unroll
-        for (int u = 0; u < RB; ++u) {
-            int row = r0 + u * rpp + wave * tpw + team;
-            row = row < nrows ? row : nrows - 1;
-            const T* wr = W + (int64_t)rowmap(row) * ldw;
+    for (int u = 0; u < NB; ++u) {
+        float a0 = 0.f, a1 = 0.f;
 #pragma unroll
-            for (int t = 0; t < CPL; ++t) w[u][t] = *reinterpret_cast<const uint4*>(wr + (tl + t * TL) * EPC);
-        }
+        for (int t = 0; t < CPL; ++t) {
+            float wv[EPC];
+            unpack_w<T>(R.w[u][t], wv);
 #pragma unroll
-        for (int u = 0; u < RB; ++u) {
-            const int row = r0 + u * rpp + wave * tpw + team;
-            float acc = 0.f;
-#pragma unroll
-            for (int t = 0; t < CPL; ++t) {
-                float wv[EPC];
-                unpack_w<T>(w[u][t], wv);
-#pragma unroll
-                for (int e = 0; e < EPC; ++e) acc = fma1(wv[e], xv[t][e], acc);
+            for (int e = 0; e < EPC; e += 2) {   // (fma1: plain fmaf pairs become v_pk_fma_f32 op_sel:[0,1,0], the form the build's lint refuses)
+                a0 = fma1(wv[e], xv[t][e], a0);
+                a1 = fma1(wv[e + 1], xv[t][e + 1], a1);
             }
-            for (int o = TL >> 1; o >= 1; o >>= 1) acc += __shfl_xor(acc, o);
-            if (tl == 0 && row < nrows) ys[row] = acc;
         }
+        acc[u] = a0 + a1;
+    }
+    team_reduce<NB>(acc, g.TL);
+#pragma unroll
+    for (int u = 0; u < NB; ++u) {
+        const int row = (blk0 + u) * g.rpp + g.wave * g.tpw + g.team;
+        if (g.tl == 0 && row < nrows) ys[row] = acc[u];
     }
 }
-
+// blocks blk0, blk0 + 1, ... until the rows are covered: 8 loads per lane in flight
+template <typename T, int CPL, typename RowMap>
+__device__ __forceinline__ void gemv_stream(const T* __restrict__ W, int ldw, int K, int nrows, int blk0, const float* xs, float* ys, RowMap rowmap, int tid, int nthreads) {
+    constexpr int NB = CPL >= 8 ? 1 : 8 / CPL;
+    const Geo g = team_geo<CPL>(K / ActTraits<T>::EPC, tid, nthreads);
+    for (int b = blk0; b * g.rpp < nrows; b += NB) {
+        WRegs<CPL, NB> R;
+        gemv_issue<T, CPL, NB>(R, W, ldw, K, nrows, b, rowmap, tid, nthreads);
+        gemv_apply<T, CPL, NB>(R, K, nrows, b, xs, ys, tid, nthreads);
+    }
+}
 template <typename T, typename RowMap>
 __device__ __forceinline__ void wg_gemv(const T* __restrict__ W, int ldw, int K, int nrows, const float* xs, float* ys, RowMap rowmap, int tid, int nthreads) {
     const int kc = K / ActTraits<T>::EPC;
-    if (kc <= 64) wg_gemv_c<T, 1>(W, ldw, K, nrows, xs, ys, rowmap, tid, nthreads);
-    else if (kc == 128) wg_gemv_c<T, 2>(W, ldw, K, nrows, xs, ys, rowmap, tid, nthreads);
-    else if (kc == 256) wg_gemv_c<T, 4>(W, ldw, K, nrows, xs, ys, rowmap, tid, nthreads);
-    else wg_gemv_c<T, 8>(W, ldw, K, nrows, xs, ys, rowmap, tid, nthreads);   // kc == 512 (the host checks)
+    if (kc <= 64) gemv_stream<T, 1>(W, ldw, K, nrows, 0, xs, ys, rowmap, tid, nthreads);
+    else if (kc == 128) gemv_stream<T, 2>(W, ldw, K, nrows, 0, xs, ys, rowmap, tid, nthreads);
+    else if (kc == 256) gemv_stream<T, 4>(W, ldw, K, nrows, 0, xs, ys, rowmap, tid, nthreads);
+    else gemv_stream<T, 8>(W, ldw, K, nrows, 0, xs, ys, rowmap, tid, nthreads);   // kc == 512 (the host checks)
+}
+// A Linear layer in the two forms of the kernels below.  PRE (the host has checked that the contraction is at most 64 chunks and that NB blocks cover
+// the rows): the weights are requested early (`pre_issue` at kernel entry) and consumed when the input vector is in LDS (`pre_finish`).  Otherwise
+// `pre_issue` does nothing and `pre_finish` streams.
+template <bool PRE, typename T, int NB, typename RowMap>
+__device__ __forceinline__ void pre_issue(WRegs<1, NB>& R, const T* __restrict__ W, int ldw, int K, int nrows, RowMap rowmap, int tid, int nthreads) {
+    if constexpr (PRE) gemv_issue<T, 1, NB>(R, W, ldw, K, nrows, 0, rowmap, tid, nthreads);
+}
+template <bool PRE, typename T, int NB, typename RowMap>
+__device__ __forceinline__ void pre_finish(const WRegs<1, NB>& R, const T* __restrict__ W, int ldw, int K, int nrows, const float* xs, float* ys, RowMap rowmap, int tid, int nthreads) {
+    if constexpr (PRE) gemv_apply<T, 1, NB>(R, K, nrows, 0, xs, ys, tid, nthreads);
+    else wg_gemv<T>(W, ldw, K, nrows, xs, ys, rowmap, tid, nthreads);
 }
 
 struct IdentityRow {
@@ -156,51 +279,100 @@ struct IdentityRow {
 // Workgroup-wide softmax(q . K^T) V over keys 0 .. nk_cached-1 of the cache (K, V: [cap, HD] rows of T) plus — has_cur — one more key held in
 // LDS (kcur / vcur, fp32).  Returns through LDS: oacc[HD] = sum_k exp(s_k - m) v_k, and (m, l) to every thread.  prob: LDS [>= nk_cached + 1].
 // q (LDS) is pre-scaled.  nk_cached + has_cur may be 0: m = -inf, l = 0, oacc = 0.
+// PRE (cap <= KPT * 512 positions): the key rows do not depend on this step's query — k_prefetch requests every key row of a thread (scores: thread t
+// owns keys t, t + nthreads, ...) at kernel entry; the value chunks (thread (slot, chunk) owns keys slot, slot + nthreads / CPK, ...) are requested
+// as soon as the scores have freed those registers and land under the two softmax reductions.  Otherwise both stream.
 template <typename T, int HD>
-__device__ __forceinline__ void wg_attend(const T* __restrict__ Kg, const T* __restrict__ Vg, int nk_cached, bool has_cur, const float* q_l, const float* kcur, const float* vcur,
-                                          float* prob, float* part /* [nw][HD] */, float* oacc, float* red, float& m_out, float& l_out, int tid, int nthreads) {
-    constexpr int EPC = ActTraits<T>::EPC;
-    constexpr int CPK = HD / EPC;                 // 16-byte chunks per key row
-    constexpr float LOG2E = 1.4426950408889634f;
-    float q[HD];
+struct KRegs {
+    static constexpr int EPC = ActTraits<T>::EPC;
+    static constexpr int CPK = HD / EPC;
+    static constexpr int KPT = 4, VPT = 4 * CPK;
+    uint4 k[KPT][CPK];
+};
+template <bool PRE, typename T, int HD>
+__device__ __forceinline__ void k_prefetch(KRegs<T, HD>& R, const T* __restrict__ Kg, int nk_cached, int tid, int nthreads) {
+    if constexpr (PRE) {
+        constexpr int CPK = KRegs<T, HD>::CPK;
 #pragma unroll
-    for (int c = 0; c < HD; ++c) q[c] = q_l[c];
-    const int nk = nk_cached + (has_cur ? 1 : 0);
-    // ---- scores: thread t owns keys t, t + nthreads, ...; the rows of KB keys requested together (8 loads in flight per lane)
-    constexpr int KB = CPK >= 8 ? 1 : (CPK >= 4 ? 2 : 4);
-    float mx = -INFINITY;
-    for (int k0 = 0; k0 < nk_cached; k0 += nthreads * KB) {
-        uint4 raw[KB][CPK];
-#pragma unroll
-        for (int j = 0; j < KB; ++j) {
-            const int key = k0 + j * nthreads + tid;
-            const uint4* kr = reinterpret_cast<const uint4*>(Kg + (int64_t)(key < nk_cached ? key : nk_cached - 1) * HD);
-#pragma unroll
-            for (int c = 0; c < CPK; ++c) raw[j][c] = kr[c];
-        }
-#pragma unroll
-        for (int j = 0; j < KB; ++j) {
-            const int key = k0 + j * nthreads + tid;
-            float acc = 0.f;
-#pragma unroll
-            for (int c = 0; c < CPK; ++c) {
-                float kv[EPC];
-                unpack_w<T>(raw[j][c], kv);
-#pragma unroll
-                for (int e = 0; e < EPC; ++e) acc = fma1(q[c * EPC + e], kv[e], acc);
-            }
+        for (int j = 0; j < KRegs<T, HD>::KPT; ++j) {
+            const int key = j * nthreads + tid;
             if (key < nk_cached) {
-                prob[key] = acc;
-                mx = fmaxf(mx, acc);
+                const uint4* kr = reinterpret_cast<const uint4*>(Kg + (int64_t)key * HD);
+#pragma unroll
+                for (int c = 0; c < CPK; ++c) R.k[j][c] = kr[c];
             }
         }
     }
-    if (has_cur && tid == 0) {
-        float acc = 0.f;
+}
+template <bool PRE, typename T, int HD>
+__device__ __forceinline__ void wg_attend(const KRegs<T, HD>& R, const T* __restrict__ Kg, const T* __restrict__ Vg, int nk_cached, bool has_cur, const float* q_l, const float* kcur,
+                                          const float* vcur, float* prob, float* part /* [nw][HD] */, float* oacc, float* red, float& m_out, float& l_out, int tid, int nthreads) {
+    constexpr int EPC = ActTraits<T>::EPC;
+    constexpr int CPK = HD / EPC;                 // 16-byte chunks per key row
+    constexpr int KPT = KRegs<T, HD>::KPT, VPT = KRegs<T, HD>::VPT;
+    constexpr float LOG2E = 1.4426950408889634f;
+    const int nk = nk_cached + (has_cur ? 1 : 0);
+    float mx = -INFINITY;
+    {
+        float q[HD];
 #pragma unroll
-        for (int c = 0; c < HD; ++c) acc = fma1(q[c], kcur[c], acc);
-        prob[nk_cached] = acc;
-        mx = fmaxf(mx, acc);
+        for (int c = 0; c < HD; ++c) q[c] = q_l[c];
+        auto score = [&](const uint4 (&raw)[CPK], int key) __attribute__((always_inline)) {
+            float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+            for (int c = 0; c < CPK; ++c) {
+                float kv[EPC];
+                unpack_w<T>(raw[c], kv);
+#pragma unroll
+                for (int e = 0; e < EPC; e += 2) {
+                    a0 = fma1(q[c * EPC + e], kv[e], a0);
+                    a1 = fma1(q[c * EPC + e + 1], kv[e + 1], a1);
+                }
+            }
+            const float acc = a0 + a1;
+            prob[key] = acc;
+            mx = fmaxf(mx, acc);
+        };
+        if constexpr (PRE) {
+#pragma unroll
+            for (int j = 0; j < KPT; ++j) {
+                const int key = j * nthreads + tid;
+                if (key < nk_cached) score(R.k[j], key);
+            }
+        } else {
+            constexpr int KB = CPK >= 8 ? 1 : (CPK >= 4 ? 2 : 4);   // 8 loads in flight per lane
+            for (int k0 = 0; k0 < nk_cached; k0 += nthreads * KB) {
+                uint4 raw[KB][CPK];
+#pragma unroll
+                for (int j = 0; j < KB; ++j) {
+                    const int key = k0 + j * nthreads + tid;
+                    const uint4* kr = reinterpret_cast<const uint4*>(Kg + (int64_t)(key < nk_cached ? key : nk_cached - 1) * HD);
+#pragma unroll
+                    for (int c = 0; c < CPK; ++c) raw[j][c] = kr[c];
+                }
+#pragma unroll
+                for (int j = 0; j < KB; ++j) {
+                    const int key = k0 + j * nthreads + tid;
+                    if (key < nk_cached) score(raw[j], key);
+                }
+            }
+        }
+        if (has_cur && tid == 0) {
+            float acc = 0.f;
+#pragma unroll
+            for (int c = 0; c < HD; ++c) acc = fma1(q[c], kcur[c], acc);
+            prob[nk_cached] = acc;
+            mx = fmaxf(mx, acc);
+        }
+    }
+    const int ch = tid % CPK, slot = tid / CPK, nslot = nthreads / CPK;
+    uint4 vr[VPT];
+    if constexpr (PRE) {
+#pragma unroll
+        for (int j = 0; j < VPT; ++j) {
+            const int key = j * nslot + slot;
+            if (key < nk_cached) vr[j] = *reinterpret_cast<const uint4*>(Vg + (int64_t)key * HD + ch * EPC);
+        }
     }
     const float m = wg_max(mx, red, tid, nthreads);   // barriers inside: prob is complete
     float ls = 0.f;
@@ -210,26 +382,34 @@ __device__ __forceinline__ void wg_attend(const T* __restrict__ Kg, const T* __r
         ls += pv;
     }
     const float l = wg_sum(ls, red, tid, nthreads);   // barriers inside: prob holds the probabilities
-    // ---- o = sum_k p_k v_k: thread (slot, chunk) walks keys slot, slot + nthreads / CPK, ... of its 16-byte column chunk
-    const int ch = tid % CPK, slot = tid / CPK, nslot = nthreads / CPK;
+    // ---- o = sum_k p_k v_k
     float acc[EPC];
 #pragma unroll
     for (int e = 0; e < EPC; ++e) acc[e] = 0.f;
-    for (int k0 = 0; k0 < nk_cached; k0 += nslot * 4) {
-        uint4 raw[4];
-        float pv[4];
+    auto pv_add = [&](const uint4& raw, float pv) __attribute__((always_inline)) {
+        float vv[EPC];
+        unpack_w<T>(raw, vv);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int key = k0 + j * nslot + slot;
-            raw[j] = *reinterpret_cast<const uint4*>(Vg + (int64_t)(key < nk_cached ? key : nk_cached - 1) * HD + ch * EPC);
-            pv[j] = key < nk_cached ? prob[key] : 0.f;
+        for (int e = 0; e < EPC; ++e) acc[e] = fma1(pv, vv[e], acc[e]);
+    };
+    if constexpr (PRE) {
+#pragma unroll
+        for (int j = 0; j < VPT; ++j) {
+            const int key = j * nslot + slot;
+            if (key < nk_cached) pv_add(vr[j], prob[key]);
         }
+    } else {
+        for (int k0 = 0; k0 < nk_cached; k0 += nslot * 4) {
+            uint4 raw[4];
+            float pv[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            float vv[EPC];
-            unpack_w<T>(raw[j], vv);
+            for (int j = 0; j < 4; ++j) {
+                const int key = k0 + j * nslot + slot;
+                raw[j] = *reinterpret_cast<const uint4*>(Vg + (int64_t)(key < nk_cached ? key : nk_cached - 1) * HD + ch * EPC);
+                pv[j] = key < nk_cached ? prob[key] : 0.f;
+            }
 #pragma unroll
-            for (int e = 0; e < EPC; ++e) acc[e] = fma1(pv[j], vv[e], acc[e]);
+            for (int j = 0; j < 4; ++j) pv_add(raw[j], pv[j]);
         }
     }
     if (has_cur && slot == 0) {
@@ -239,8 +419,10 @@ __device__ __forceinline__ void wg_attend(const T* __restrict__ Kg, const T* __r
     }
     // lanes of a wave with the same chunk: lane % CPK (CPK divides 64)
 #pragma unroll
-    for (int e = 0; e < EPC; ++e)
+    for (int e = 0; e < EPC; ++e) {
+#pragma unroll
         for (int o = 32; o >= CPK; o >>= 1) acc[e] += __shfl_xor(acc[e], o);
+    }
     const int lane = tid & 63, wave = tid >> 6, nw = nthreads >> 6;
     if (lane < CPK) {
 #pragma unroll
@@ -258,23 +440,44 @@ __device__ __forceinline__ void wg_attend(const T* __restrict__ Kg, const T* __r
 }
 
 // bias + rotary embedding (interleaved pairs, models/base_blocks.py:81-88) + q scale on a projected head held in LDS: qkv = [q | k | v] (HD each).
-// k and v are rounded to the cache dtype (later steps read them back from the cache) and appended at `pos`.
-template <typename T, int HD>
-__device__ __forceinline__ void head_finish(float* qkv, const float* bq, const float* bk, const float* bv, const float* rope, int pos, bool with_kv, T* Krow, T* Vrow, int tid) {
+// k and v are rounded to the cache dtype (later steps read them back from the cache) and appended at `pos`.  Thread roles: tid < HD/2 rotates a
+// q pair, HD/2 <= tid < HD a k pair, 64 <= tid < 64 + HD adds a v bias; head_issue requests each role's bias / (cos, sin) at kernel entry.
+struct HeadRegs {
+    float b0, b1;
+    float2 cs;
+};
+template <int HD>
+__device__ __forceinline__ void head_issue(HeadRegs& R, const float* bq, const float* bk, const float* bv, const float* rope, int pos, bool with_kv, int tid) {
     constexpr int HD2 = HD / 2;
     const float2* cs = reinterpret_cast<const float2*>(rope) + (int64_t)pos * HD2;
+    R.b0 = R.b1 = 0.f;
+    R.cs = make_float2(1.f, 0.f);
+    if (tid < HD2) {
+        R.cs = cs[tid];
+        R.b0 = bq[2 * tid];
+        R.b1 = bq[2 * tid + 1];
+    } else if (with_kv && tid < 2 * HD2) {
+        const int t = tid - HD2;
+        R.cs = cs[t];
+        R.b0 = bk[2 * t];
+        R.b1 = bk[2 * t + 1];
+    } else if (with_kv && tid >= 64 && tid < 64 + HD) {
+        R.b0 = bv[tid - 64];
+    }
+}
+template <typename T, int HD>
+__device__ __forceinline__ void head_finish(const HeadRegs& R, float* qkv, bool with_kv, T* Krow, T* Vrow, int tid) {
+    constexpr int HD2 = HD / 2;
     const float scale = 1.0f / sqrtf((float)HD);
     if (tid < HD2) {
-        const float2 c = cs[tid];
         float oe, oo;
-        rope_pair(qkv[2 * tid] + bq[2 * tid], qkv[2 * tid + 1] + bq[2 * tid + 1], c.x, c.y, oe, oo);
+        rope_pair(qkv[2 * tid] + R.b0, qkv[2 * tid + 1] + R.b1, R.cs.x, R.cs.y, oe, oo);
         qkv[2 * tid] = oe * scale;
         qkv[2 * tid + 1] = oo * scale;
     } else if (with_kv && tid < 2 * HD2) {
         const int t = tid - HD2;
-        const float2 c = cs[t];
         float oe, oo;
-        rope_pair(qkv[HD + 2 * t] + bk[2 * t], qkv[HD + 2 * t + 1] + bk[2 * t + 1], c.x, c.y, oe, oo);
+        rope_pair(qkv[HD + 2 * t] + R.b0, qkv[HD + 2 * t + 1] + R.b1, R.cs.x, R.cs.y, oe, oo);
         oe = round_to(oe, T());
         oo = round_to(oo, T());
         qkv[HD + 2 * t] = oe;
@@ -283,7 +486,7 @@ __device__ __forceinline__ void head_finish(float* qkv, const float* bq, const f
         Krow[2 * t + 1] = from_f32<T>(oo);
     } else if (with_kv && tid >= 64 && tid < 64 + HD) {
         const int t = tid - 64;
-        const float v = round_to(qkv[2 * HD + t] + bv[t], T());
+        const float v = round_to(qkv[2 * HD + t] + R.b0, T());
         qkv[2 * HD + t] = v;
         Vrow[t] = from_f32<T>(v);
     }
@@ -303,13 +506,17 @@ struct KvArgs {
 
 __device__ __forceinline__ int pair_index(int i, int j, int F) { return i * (F - 1) + (j < i ? j : j - 1); }
 
+// Every kernel below opens by REQUESTING whatever does not depend on the activations — weights of its Linear layers (registers), gains, shifts,
+// modulation rows, biases, cache rows — so that the launch is one memory round trip deep instead of one per stage.  E, D <= 512: a 512-thread
+// workgroup holds one element of a row per thread.
+
 // ------------------------------------------------------------------------------------------------ A: self attention (models/temporal.py:127-136 up to the projection)
 // grid F * B * H, block 512.  LDS: xs[E] ns[E] qkv[3 HD] oacc[HD] red[32] part[8 HD] prob[cap + 8]
-template <typename T, int HD>
+template <bool PRE, typename T, int HD>
 __global__ __launch_bounds__(512) void kv_self_kernel(const KvArgs A) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int E = A.G.E, H = A.G.H, B = A.G.B, F = A.G.F, cap = A.G.cap, pos = A.pos;
-    const int tid = threadIdx.x, nth = blockDim.x;
+    const int tid = threadIdx.x, nth = 512;
     const int h = blockIdx.x % H, ib_ = blockIdx.x / H, b = ib_ % B, i = ib_ / B;
     float* xs = sm;
     float* ns = xs + E;
@@ -320,70 +527,89 @@ __global__ __launch_bounds__(512) void kv_self_kernel(const KvArgs A) {
     float* prob = part + 8 * HD;
     const SeaKvField& Fd = A.L.f[i];
     const int64_t crow = (int64_t)pos * B + b;
-    const float* x = A.xin + ((int64_t)b * F + i) * E;
-    const float* ibp = (A.L.ib != nullptr && !A.G.ib_after_cross) ? A.L.ib + crow * E : nullptr;
-    for (int e = tid; e < E; e += nth) xs[e] = x[e] + (ibp != nullptr ? ibp[e] : 0.f);
-    __syncthreads();
-    wg_norm<T>(xs, ns, E, Fd.ln0, crow, false, red, tid, nth);
-    const int hh = h;
-    auto rowmap = [=](int r) { return (r / HD) * E + hh * HD + (r % HD); };
-    wg_gemv<T>(static_cast<const T*>(Fd.Wqkv), E, E, 3 * HD, ns, qkv, rowmap, tid, nth);
-    __syncthreads();
     const int64_t bh = (int64_t)b * H + h;
     T* Kc = static_cast<T*>(Fd.Ks) + bh * cap * HD;
     T* Vc = static_cast<T*>(Fd.Vs) + bh * cap * HD;
-    head_finish<T, HD>(qkv, Fd.bqkv + h * HD, Fd.bqkv + E + h * HD, Fd.bqkv + 2 * E + h * HD, A.G.rope_self, pos, true, Kc + (int64_t)pos * HD, Vc + (int64_t)pos * HD, tid);
+    const int hh = h;
+    auto rowmap = [=](int r) { return (r / HD) * E + hh * HD + (r % HD); };
+    WRegs<1, 8> rw;
+    pre_issue<PRE, T, 8>(rw, static_cast<const T*>(Fd.Wqkv), E, E, 3 * HD, rowmap, tid, nth);
+    const float* x = A.xin + ((int64_t)b * F + i) * E;
+    const float* ibp = (A.L.ib != nullptr && !A.G.ib_after_cross) ? A.L.ib + crow * E : nullptr;
+    if (tid < E) xs[tid] = x[tid] + (ibp != nullptr ? ibp[tid] : 0.f);
+    NormRegs<1> nr;
+    norm_issue<T, 1>(nr, E, Fd.ln0, crow, tid, nth);
+    HeadRegs hr;
+    head_issue<HD>(hr, Fd.bqkv + h * HD, Fd.bqkv + E + h * HD, Fd.bqkv + 2 * E + h * HD, A.G.rope_self, pos, true, tid);
+    KRegs<T, HD> kr;
+    k_prefetch<PRE, T, HD>(kr, Kc, pos, tid, nth);
+    __syncthreads();
+    wg_norm_r<1>(xs, ns, E, nr, false, red, tid, nth);
+    pre_finish<PRE, T, 8>(rw, static_cast<const T*>(Fd.Wqkv), E, E, 3 * HD, ns, qkv, rowmap, tid, nth);
+    __syncthreads();
+    head_finish<T, HD>(hr, qkv, true, Kc + (int64_t)pos * HD, Vc + (int64_t)pos * HD, tid);
     float m, l;
-    wg_attend<T, HD>(Kc, Vc, pos, true, qkv, qkv + HD, qkv + 2 * HD, prob, part, oacc, red, m, l, tid, nth);
+    wg_attend<PRE, T, HD>(kr, Kc, Vc, pos, true, qkv, qkv + HD, qkv + 2 * HD, prob, part, oacc, red, m, l, tid, nth);
     if (tid < HD) A.G.att_e[((int64_t)b * F + i) * E + h * HD + tid] = oacc[tid] / l;
 }
 
 // ------------------------------------------------------------------------------------------------ B: out-projection + residual, down-projection + ln_cross (models/temporal.py:136, 177-178)
 // grid F * B, block 512.  LDS: att[E] xs[E] y[E] red[32]
-template <typename T>
+template <bool PRE, typename T>
 __global__ __launch_bounds__(512) void kv_oproj_kernel(const KvArgs A) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int E = A.G.E, D = A.G.D, B = A.G.B, F = A.G.F;
-    const int tid = threadIdx.x, nth = blockDim.x;
+    const int tid = threadIdx.x, nth = 512;
     const int b = blockIdx.x % B, i = blockIdx.x / B;
     float* att = sm;
     float* xs = att + E;
     float* y = xs + E;
     float* red = y + E;
     const SeaKvField& Fd = A.L.f[i];
+    const bool ex = A.G.exchange != 0;
     const int64_t crow = (int64_t)A.pos * B + b, ro = ((int64_t)b * F + i);
+    WRegs<1, 16> rwo;
+    WRegs<1, 8> rwd;
+    pre_issue<PRE, T, 16>(rwo, static_cast<const T*>(Fd.Wo), E, E, E, IdentityRow(), tid, nth);
+    if (ex) pre_issue<PRE, T, 8>(rwd, static_cast<const T*>(Fd.Wdown), E, E, D, IdentityRow(), tid, nth);
     const float* ibp = (A.L.ib != nullptr && !A.G.ib_after_cross) ? A.L.ib + crow * E : nullptr;
-    for (int e = tid; e < E; e += nth) {
-        att[e] = A.G.att_e[ro * E + e];
-        xs[e] = A.xin[ro * E + e] + (ibp != nullptr ? ibp[e] : 0.f);
+    if (tid < E) {
+        att[tid] = A.G.att_e[ro * E + tid];
+        xs[tid] = A.xin[ro * E + tid] + (ibp != nullptr ? ibp[tid] : 0.f);
+    }
+    NormRegs<1> nr;
+    float bd = 0.f;
+    if (ex) {
+        norm_issue<T, 1>(nr, D, Fd.ln_cross, crow, tid, nth);
+        if (tid < D) bd = Fd.bdown[tid];
     }
     __syncthreads();
-    wg_gemv<T>(static_cast<const T*>(Fd.Wo), E, E, E, att, y, IdentityRow(), tid, nth);
+    pre_finish<PRE, T, 16>(rwo, static_cast<const T*>(Fd.Wo), E, E, E, att, y, IdentityRow(), tid, nth);
     __syncthreads();
-    for (int e = tid; e < E; e += nth) {
-        const float v = xs[e] + y[e];
-        xs[e] = v;
-        A.G.xr[ro * E + e] = v;
+    if (tid < E) {
+        const float v = xs[tid] + y[tid];
+        xs[tid] = v;
+        A.G.xr[ro * E + tid] = v;
     }
     __syncthreads();
-    if (!A.G.exchange) return;
-    wg_gemv<T>(static_cast<const T*>(Fd.Wdown), E, E, D, xs, y, IdentityRow(), tid, nth);
+    if (!ex) return;
+    pre_finish<PRE, T, 8>(rwd, static_cast<const T*>(Fd.Wdown), E, E, D, xs, y, IdentityRow(), tid, nth);
     __syncthreads();
-    for (int e = tid; e < D; e += nth) y[e] += Fd.bdown[e];
+    if (tid < D) y[tid] += bd;
     __syncthreads();
-    wg_norm<T>(y, y, D, Fd.ln_cross, crow, false, red, tid, nth);
-    for (int e = tid; e < D; e += nth) A.G.nd_old[ro * D + e] = y[e];
+    wg_norm_r<1>(y, y, D, nr, false, red, tid, nth);
+    if (tid < D) A.G.nd_old[ro * D + tid] = y[tid];
 }
 
 // ------------------------------------------------------------------------------------------------ C: cross attention of every pair (models/temporal.py:181-186; base_blocks.py:232-293)
 // grid F (F-1) * B * H, block 512.  Pair (i, j): query from nd_old_i; source j > i: key / value of this position from nd_old_j, appended, the head's
 // output is final; source j < i (updated earlier in this sweep): only the cached keys here — (o, m, l) and q go to the tail, which merges this
 // position's key.  LDS: ni[D] nj[D] qkv[3 HD] oacc[HD] red[32] part[8 HD] prob[cap + 8]
-template <typename T, int HD>
+template <bool PRE, typename T, int HD>
 __global__ __launch_bounds__(512) void kv_cross_kernel(const KvArgs A) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int D = A.G.D, H = A.G.H, B = A.G.B, F = A.G.F, cap = A.G.cap, pos = A.pos;
-    const int tid = threadIdx.x, nth = blockDim.x;
+    const int tid = threadIdx.x, nth = 512;
     const int h = blockIdx.x % H, pb = blockIdx.x / H, b = pb % B, p = pb / B;
     const int i = p / (F - 1), s = p % (F - 1), j = s < i ? s : s + 1;
     const bool old_src = j > i;
@@ -395,25 +621,31 @@ __global__ __launch_bounds__(512) void kv_cross_kernel(const KvArgs A) {
     float* part = red + 32;
     float* prob = part + 8 * HD;
     const SeaKvPair& P = A.L.p[i][j];
-    for (int e = tid; e < D; e += nth) {
-        ni[e] = A.G.nd_old[((int64_t)b * F + i) * D + e];
-        nj[e] = A.G.nd_old[((int64_t)b * F + j) * D + e];
-    }
-    __syncthreads();
-    const int hh = h;
-    auto qmap = [=](int r) { return hh * HD + r; };
-    wg_gemv<T>(static_cast<const T*>(P.Wq), D, D, HD, ni, qkv, qmap, tid, nth);
-    if (old_src) {
-        auto kvmap = [=](int r) { return (r / HD) * D + hh * HD + (r % HD); };
-        wg_gemv<T>(static_cast<const T*>(P.Wkv), D, D, 2 * HD, nj, qkv + HD, kvmap, tid, nth);
-    }
-    __syncthreads();
     const int64_t bh = (int64_t)b * H + h;
     T* Kc = static_cast<T*>(P.Kc) + bh * cap * HD;
     T* Vc = static_cast<T*>(P.Vc) + bh * cap * HD;
-    head_finish<T, HD>(qkv, P.bq + h * HD, P.bkv + h * HD, P.bkv + D + h * HD, A.G.rope_cross, pos, old_src, Kc + (int64_t)pos * HD, Vc + (int64_t)pos * HD, tid);
+    const int hh = h;
+    auto qmap = [=](int r) { return hh * HD + r; };
+    auto kvmap = [=](int r) { return (r / HD) * D + hh * HD + (r % HD); };
+    WRegs<1, 2> rq;
+    WRegs<1, 4> rkv;
+    pre_issue<PRE, T, 2>(rq, static_cast<const T*>(P.Wq), D, D, HD, qmap, tid, nth);
+    if (old_src) pre_issue<PRE, T, 4>(rkv, static_cast<const T*>(P.Wkv), D, D, 2 * HD, kvmap, tid, nth);
+    if (tid < D) {
+        ni[tid] = A.G.nd_old[((int64_t)b * F + i) * D + tid];
+        nj[tid] = A.G.nd_old[((int64_t)b * F + j) * D + tid];
+    }
+    HeadRegs hr;
+    head_issue<HD>(hr, P.bq + h * HD, P.bkv + h * HD, P.bkv + D + h * HD, A.G.rope_cross, pos, old_src, tid);
+    KRegs<T, HD> kr;
+    k_prefetch<PRE, T, HD>(kr, Kc, pos, tid, nth);
+    __syncthreads();
+    pre_finish<PRE, T, 2>(rq, static_cast<const T*>(P.Wq), D, D, HD, ni, qkv, qmap, tid, nth);
+    if (old_src) pre_finish<PRE, T, 4>(rkv, static_cast<const T*>(P.Wkv), D, D, 2 * HD, nj, qkv + HD, kvmap, tid, nth);
+    __syncthreads();
+    head_finish<T, HD>(hr, qkv, old_src, Kc + (int64_t)pos * HD, Vc + (int64_t)pos * HD, tid);
     float m, l;
-    wg_attend<T, HD>(Kc, Vc, pos, old_src, qkv, qkv + HD, qkv + 2 * HD, prob, part, oacc, red, m, l, tid, nth);
+    wg_attend<PRE, T, HD>(kr, Kc, Vc, pos, old_src, qkv, qkv + HD, qkv + 2 * HD, prob, part, oacc, red, m, l, tid, nth);
     const int64_t po = ((int64_t)p * B + b) * D + h * HD;
     if (tid < HD) {
         A.G.oc[po + tid] = old_src ? oacc[tid] / l : oacc[tid];
@@ -429,13 +661,15 @@ __global__ __launch_bounds__(512) void kv_cross_kernel(const KvArgs A) {
 // ------------------------------------------------------------------------------------------------ T: the Gauss-Seidel tails (models/temporal.py:187-192)
 // grid F * B (field-major: workgroup (i, b) only ever waits for workgroups with a smaller index), block 512.
 // LDS: nj[D] kv[2 D] o[D] g[D] gs[D] xs[E] y[E] red[32]
-template <typename T>
-__global__ __launch_bounds__(512) void kv_tail_kernel(const KvArgs A) {
-    extern __shared__ __attribute__((aligned(16))) float sm[];
-    const int E = A.G.E, D = A.G.D, H = A.G.H, B = A.G.B, F = A.G.F, cap = A.G.cap, pos = A.pos;
+// The body is specialised on (number of fields, this field): which pairs wait, which weights are requested when and how many register blocks are
+// alive is then static — with run-time control flow around the register blocks the allocator spills.
+template <bool PRE, typename T, int NF, int I>
+__device__ __forceinline__ void tail_body(const KvArgs& A, float* sm, int b) {
+    constexpr bool HAS_DOWN = I < NF - 1;
+    constexpr int NNEW = I;                          // sources updated before this field in the sweep: j = 0 .. I - 1
+    const int E = A.G.E, D = A.G.D, H = A.G.H, B = A.G.B, cap = A.G.cap, pos = A.pos;
     const int hd = D / H, hd2 = hd >> 1;
-    const int tid = threadIdx.x, nth = blockDim.x;
-    const int b = blockIdx.x % B, i = blockIdx.x / B;
+    const int tid = threadIdx.x, nth = 512;
     float* nj = sm;
     float* kv = nj + D;
     float* o = kv + 2 * D;
@@ -444,173 +678,264 @@ __global__ __launch_bounds__(512) void kv_tail_kernel(const KvArgs A) {
     float* xs = gs + D;
     float* y = xs + E;
     float* red = y + E;
-    const SeaKvField& Fd = A.L.f[i];
-    const int64_t crow = (int64_t)pos * B + b, ro = (int64_t)b * F + i;
-    for (int e = tid; e < D; e += nth) gs[e] = 0.f;
-    for (int e = tid; e < E; e += nth) xs[e] = A.G.xr[ro * E + e];
-    // old-source pairs first: nothing to wait for
-    for (int pass = 0; pass < 2; ++pass) {
-        for (int j = 0; j < F; ++j) {
-            if (j == i || (pass == 0) != (j > i)) continue;   // block-uniform
-            const int p = pair_index(i, j, F);
-            const SeaKvPair& P = A.L.p[i][j];
-            const int64_t po = ((int64_t)p * B + b) * D;
-            __syncthreads();
-            if (j > i) {
-                for (int e = tid; e < D; e += nth) o[e] = A.G.oc[po + e];
-            } else {
-                // the source field's rows of THIS sweep: granules {value, tag} published by workgroup (j, b)
-                const unsigned long long* hg = A.G.handoff + ((int64_t)b * F + j) * D;
-                for (int e = tid; e < D; e += nth) {
-                    float v = 0.f;
-                    int it = 0;
-                    for (; it < KV_SPIN_LIMIT; ++it) {
-                        const unsigned long long pk = __hip_atomic_load(hg + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        if ((uint32_t)(pk >> 32) == A.tag) {
-                            v = __builtin_bit_cast(float, (uint32_t)pk);
-                            break;
-                        }
-                        __builtin_amdgcn_s_sleep(4);
-                    }
-                    if (it == KV_SPIN_LIMIT) __hip_atomic_store(A.G.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    nj[e] = v;
+    const SeaKvField& Fd = A.L.f[I];
+    const int64_t crow = (int64_t)pos * B + b, ro = (int64_t)b * NF + I;
+    // ---- requested before the first wait: the projections of every pair, the k / v weights of the first two updated sources
+    WRegs<1, 4> rp[NF - 1];
+    WRegs<1, 8> rkv[NNEW > 2 ? 2 : (NNEW > 0 ? NNEW : 1)];
+    WRegs<1, 8> rup, rdn;
+    if constexpr (NNEW >= 1) pre_issue<PRE, T, 8>(rkv[0], static_cast<const T*>(A.L.p[I][0].Wkv), D, D, 2 * D, IdentityRow(), tid, nth);
+    if constexpr (NNEW >= 2) pre_issue<PRE, T, 8>(rkv[1], static_cast<const T*>(A.L.p[I][1].Wkv), D, D, 2 * D, IdentityRow(), tid, nth);
+#pragma unroll
+    for (int s = 0; s < NF - 1; ++s) pre_issue<PRE, T, 4>(rp[s], static_cast<const T*>(A.L.p[I][s < I ? s : s + 1].Wp), D, D, D, IdentityRow(), tid, nth);
+    if constexpr (NNEW == 0) {   // the first field waits for nobody: everything at entry
+        pre_issue<PRE, T, 8>(rup, static_cast<const T*>(Fd.Wup), D, D, E, IdentityRow(), tid, nth);
+        if constexpr (HAS_DOWN) pre_issue<PRE, T, 8>(rdn, static_cast<const T*>(Fd.Wdown), E, E, D, IdentityRow(), tid, nth);
+    }
+    NormRegs<1> nr;
+    float bd = 0.f, bu = 0.f;
+    if constexpr (HAS_DOWN) {
+        norm_issue<T, 1>(nr, D, Fd.ln_cross, crow, tid, nth);
+        if (tid < D) bd = Fd.bdown[tid];
+    }
+    if (tid < E) {
+        bu = Fd.bup[tid];
+        xs[tid] = A.G.xr[ro * E + tid];
+    }
+    float gsum = 0.f;                                // element tid of sum_j gelu(proj_j(o_j))
+    // ---- sources not yet updated in this sweep (j > I): their heads' outputs are final
+#pragma unroll
+    for (int s = I; s < NF - 1; ++s) {
+        const int p = I * (NF - 1) + s;
+        const int64_t po = ((int64_t)p * B + b) * D;
+        __syncthreads();
+        if (tid < D) o[tid] = A.G.oc[po + tid];
+        __syncthreads();
+        pre_finish<PRE, T, 4>(rp[s], static_cast<const T*>(A.L.p[I][s + 1].Wp), D, D, D, o, g, IdentityRow(), tid, nth);
+        __syncthreads();
+        if (tid < D) gsum += gelu_erf(g[tid]);
+    }
+    if constexpr (NNEW > 0) pre_issue<PRE, T, 8>(rup, static_cast<const T*>(Fd.Wup), D, D, E, IdentityRow(), tid, nth);
+    // ---- sources updated earlier in this sweep (j < I): granules {value, tag} published by workgroup (j, b)
+#pragma unroll
+    for (int j = 0; j < NNEW; ++j) {
+        const int p = I * (NF - 1) + j;
+        const SeaKvPair& P = A.L.p[I][j];
+        const int64_t po = ((int64_t)p * B + b) * D;
+        const unsigned long long* hg = A.G.handoff + ((int64_t)b * NF + j) * D;
+        __syncthreads();
+        if (tid < D) {
+            float v = 0.f;
+            int it = 0;
+            for (; it < KV_SPIN_LIMIT; ++it) {
+                const unsigned long long pk = __hip_atomic_load(hg + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((uint32_t)(pk >> 32) == A.tag) {
+                    v = __builtin_bit_cast(float, (uint32_t)pk);
+                    break;
                 }
-                __syncthreads();
-                wg_gemv<T>(static_cast<const T*>(P.Wkv), D, D, 2 * D, nj, kv, IdentityRow(), tid, nth);
-                __syncthreads();
-                // bias, rotary embedding of k, append, merge this key into the head's (o, m, l)
-                if (tid < D / 2) {
-                    const int hh = tid / hd2, t = tid - hh * hd2;
-                    const float2 c = reinterpret_cast<const float2*>(A.G.rope_cross)[(int64_t)pos * hd2 + t];
-                    const int c0 = hh * hd + 2 * t;
-                    float oe, oo;
-                    rope_pair(kv[c0] + P.bkv[c0], kv[c0 + 1] + P.bkv[c0 + 1], c.x, c.y, oe, oo);
-                    oe = round_to(oe, T());
-                    oo = round_to(oo, T());
-                    kv[c0] = oe;
-                    kv[c0 + 1] = oo;
-                    T* Kr = static_cast<T*>(P.Kc) + (((int64_t)b * H + hh) * cap + pos) * hd;
-                    Kr[2 * t] = from_f32<T>(oe);
-                    Kr[2 * t + 1] = from_f32<T>(oo);
-                }
-                for (int e = tid; e < D; e += nth) {
-                    const float v = round_to(kv[D + e] + P.bkv[D + e], T());
-                    kv[D + e] = v;
-                    const int hh = e / hd;
-                    static_cast<T*>(P.Vc)[(((int64_t)b * H + hh) * cap + pos) * hd + (e - hh * hd)] = from_f32<T>(v);
-                }
-                __syncthreads();
-                for (int e = tid; e < D; e += nth) {
-                    const int hh = e / hd;
-                    float sc = 0.f;
-                    for (int c = 0; c < hd; ++c) sc = fma1(A.G.qc[po + hh * hd + c], kv[hh * hd + c], sc);
-                    const float* ml = A.G.ml + (((int64_t)p * B + b) * H + hh) * 2;
-                    const float m0 = ml[0], l0 = ml[1];
-                    const float m1 = fmaxf(m0, sc);
-                    const float w0 = l0 > 0.f ? __expf(m0 - m1) : 0.f, w1 = __expf(sc - m1);
-                    o[e] = (A.G.oc[po + e] * w0 + kv[D + e] * w1) / (l0 * w0 + w1);
-                }
+                __builtin_amdgcn_s_sleep(1);
             }
-            __syncthreads();
-            wg_gemv<T>(static_cast<const T*>(P.Wp), D, D, D, o, g, IdentityRow(), tid, nth);
-            __syncthreads();
-            for (int e = tid; e < D; e += nth) gs[e] += gelu_erf(g[e]);
+            if (it == KV_SPIN_LIMIT) __hip_atomic_store(A.G.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            nj[tid] = v;
         }
+        // what the merge needs besides k / v: requested while the k / v projection runs
+        float qv = 0.f, ov = 0.f, m0 = 0.f, l0 = 0.f, bk0 = 0.f, bk1 = 0.f, bvv = 0.f;
+        float2 cs = make_float2(1.f, 0.f);
+        if (tid < D) {
+            const int hh = tid / hd;
+            qv = A.G.qc[po + tid];
+            ov = A.G.oc[po + tid];
+            const float* ml = A.G.ml + (((int64_t)p * B + b) * H + hh) * 2;
+            m0 = ml[0];
+            l0 = ml[1];
+            bvv = P.bkv[D + tid];
+        }
+        if (tid < D / 2) {
+            const int hh = tid / hd2, t = tid - hh * hd2;
+            cs = reinterpret_cast<const float2*>(A.G.rope_cross)[(int64_t)pos * hd2 + t];
+            bk0 = P.bkv[hh * hd + 2 * t];
+            bk1 = P.bkv[hh * hd + 2 * t + 1];
+        }
+        __syncthreads();
+        if constexpr (PRE) {
+            if (j < 2) gemv_apply<T, 1, 8>(rkv[j < 2 ? j : 0], D, 2 * D, 0, nj, kv, tid, nth);
+            else wg_gemv<T>(static_cast<const T*>(P.Wkv), D, D, 2 * D, nj, kv, IdentityRow(), tid, nth);   // (a fourth field's third source)
+        } else {
+            wg_gemv<T>(static_cast<const T*>(P.Wkv), D, D, 2 * D, nj, kv, IdentityRow(), tid, nth);
+        }
+        __syncthreads();
+        // bias, rotary embedding of k, append, merge this key into the head's (o, m, l)
+        if (tid < D / 2) {
+            const int hh = tid / hd2, t = tid - hh * hd2;
+            const int c0 = hh * hd + 2 * t;
+            float oe, oo;
+            rope_pair(kv[c0] + bk0, kv[c0 + 1] + bk1, cs.x, cs.y, oe, oo);
+            oe = round_to(oe, T());
+            oo = round_to(oo, T());
+            kv[c0] = oe;
+            kv[c0 + 1] = oo;
+            T* Kr = static_cast<T*>(P.Kc) + (((int64_t)b * H + hh) * cap + pos) * hd;
+            Kr[2 * t] = from_f32<T>(oe);
+            Kr[2 * t + 1] = from_f32<T>(oo);
+        }
+        float vv = 0.f;
+        if (tid < D) {
+            vv = round_to(kv[D + tid] + bvv, T());
+            const int hh = tid / hd;
+            static_cast<T*>(P.Vc)[(((int64_t)b * H + hh) * cap + pos) * hd + (tid - hh * hd)] = from_f32<T>(vv);
+        }
+        __syncthreads();
+        // score of this position's key: sum over the head's hd consecutive lanes (hd a power of two <= 64: heads do not straddle waves)
+        float sc[1] = {tid < D ? qv * kv[tid] : 0.f};
+        team_reduce<1>(sc, hd);
+        if (tid < D) {
+            const float m1 = fmaxf(m0, sc[0]);
+            const float w0 = l0 > 0.f ? __expf(m0 - m1) : 0.f, w1 = __expf(sc[0] - m1);
+            o[tid] = (ov * w0 + vv * w1) / (l0 * w0 + w1);
+        }
+        __syncthreads();
+        pre_finish<PRE, T, 4>(rp[j], static_cast<const T*>(P.Wp), D, D, D, o, g, IdentityRow(), tid, nth);
+        __syncthreads();
+        if (tid < D) gsum += gelu_erf(g[tid]);
+    }
+    if (tid < D) gs[tid] = gsum;
+    if constexpr (NNEW > 0 && HAS_DOWN) pre_issue<PRE, T, 8>(rdn, static_cast<const T*>(Fd.Wdown), E, E, D, IdentityRow(), tid, nth);
+    __syncthreads();
+    pre_finish<PRE, T, 8>(rup, static_cast<const T*>(Fd.Wup), D, D, E, gs, y, IdentityRow(), tid, nth);
+    __syncthreads();
+    if (tid < E) {
+        const float v = xs[tid] + y[tid] + (float)(NF - 1) * bu;
+        xs[tid] = v;
+        A.G.xr[ro * E + tid] = v;
     }
     __syncthreads();
-    wg_gemv<T>(static_cast<const T*>(Fd.Wup), D, D, E, gs, y, IdentityRow(), tid, nth);
-    __syncthreads();
-    const float bs = (float)(F - 1);
-    for (int e = tid; e < E; e += nth) {
-        const float v = xs[e] + y[e] + bs * Fd.bup[e];
-        xs[e] = v;
-        A.G.xr[ro * E + e] = v;
+    if constexpr (HAS_DOWN) {
+        pre_finish<PRE, T, 8>(rdn, static_cast<const T*>(Fd.Wdown), E, E, D, xs, y, IdentityRow(), tid, nth);
+        __syncthreads();
+        if (tid < D) y[tid] += bd;
+        __syncthreads();
+        wg_norm_r<1>(y, y, D, nr, false, red, tid, nth);
+        unsigned long long* hgo = A.G.handoff + ((int64_t)b * NF + I) * D;
+        if (tid < D)
+            __hip_atomic_store(hgo + tid, ((unsigned long long)A.tag << 32) | (unsigned long long)__builtin_bit_cast(uint32_t, y[tid]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    __syncthreads();
-    if (i == F - 1) return;
-    wg_gemv<T>(static_cast<const T*>(Fd.Wdown), E, E, D, xs, y, IdentityRow(), tid, nth);
-    __syncthreads();
-    for (int e = tid; e < D; e += nth) y[e] += Fd.bdown[e];
-    __syncthreads();
-    wg_norm<T>(y, y, D, Fd.ln_cross, crow, false, red, tid, nth);
-    unsigned long long* hg = A.G.handoff + ((int64_t)b * F + i) * D;
-    for (int e = tid; e < D; e += nth)
-        __hip_atomic_store(hg + e, ((unsigned long long)A.tag << 32) | (unsigned long long)__builtin_bit_cast(uint32_t, y[e]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+template <bool PRE, typename T>
+__global__ __launch_bounds__(512) void kv_tail_kernel(const KvArgs A) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int B = A.G.B;
+    const int b = blockIdx.x % B, i = blockIdx.x / B;
+    switch (A.G.F * 4 + i) {   // block-uniform
+        case 2 * 4 + 0: tail_body<PRE, T, 2, 0>(A, sm, b); break;
+        case 2 * 4 + 1: tail_body<PRE, T, 2, 1>(A, sm, b); break;
+        case 3 * 4 + 0: tail_body<PRE, T, 3, 0>(A, sm, b); break;
+        case 3 * 4 + 1: tail_body<PRE, T, 3, 1>(A, sm, b); break;
+        case 3 * 4 + 2: tail_body<PRE, T, 3, 2>(A, sm, b); break;
+        case 4 * 4 + 0: tail_body<PRE, T, 4, 0>(A, sm, b); break;
+        case 4 * 4 + 1: tail_body<PRE, T, 4, 1>(A, sm, b); break;
+        case 4 * 4 + 2: tail_body<PRE, T, 4, 2>(A, sm, b); break;
+        default: tail_body<PRE, T, 4, 3>(A, sm, b); break;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ D: info-bottleneck add + AdaLN_2 + fc1 (models/temporal.py:139-145; base_blocks.py:22)
-// grid (F * B, S / rows_per_wg), block 256.  LDS: xs[E] ns[E] hs[rows] red[32]
-template <typename T>
-__global__ __launch_bounds__(256) void kv_fc1_kernel(const KvArgs A, int rows_per_wg) {
+// grid (F * B, S / 32), block 256: 32 rows of W1 per workgroup.  LDS: xs[E] ns[E] hs[32] red[32]
+template <bool PRE, typename T>
+__global__ __launch_bounds__(256) void kv_fc1_kernel(const KvArgs A) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
+    constexpr int ROWS = 32;
     const int E = A.G.E, S = A.G.S, B = A.G.B, F = A.G.F;
-    const int tid = threadIdx.x, nth = blockDim.x;
-    const int b = blockIdx.x % B, i = blockIdx.x / B, r0 = blockIdx.y * rows_per_wg;
+    const int tid = threadIdx.x, nth = 256;
+    const int b = blockIdx.x % B, i = blockIdx.x / B, r0 = blockIdx.y * ROWS;
     float* xs = sm;
     float* ns = xs + E;
     float* hs = ns + E;
-    float* red = hs + rows_per_wg;
+    float* red = hs + ROWS;
     const SeaKvField& Fd = A.L.f[i];
     const int64_t crow = (int64_t)A.pos * B + b, ro = (int64_t)b * F + i;
+    const int nr_ = r0 + ROWS <= S ? ROWS : S - r0;
+    const T* W = static_cast<const T*>(Fd.W1) + (int64_t)r0 * E;
+    WRegs<1, 4> rw;
+    pre_issue<PRE, T, 4>(rw, W, E, E, nr_, IdentityRow(), tid, nth);
     const float* ibp = (A.L.ib != nullptr && A.G.ib_after_cross) ? A.L.ib + crow * E : nullptr;
     for (int e = tid; e < E; e += nth) {
         const float v = A.G.xr[ro * E + e] + (ibp != nullptr ? ibp[e] : 0.f);
         xs[e] = v;
         if (blockIdx.y == 0) A.G.xq[ro * E + e] = v;
     }
+    NormRegs<2> nrg;
+    norm_issue<T, 2>(nrg, E, Fd.ln2, crow, tid, nth);
+    const float b1v = tid < nr_ ? Fd.b1[r0 + tid] : 0.f;
     __syncthreads();
-    wg_norm<T>(xs, ns, E, Fd.ln2, crow, false, red, tid, nth);
-    const int nr = r0 + rows_per_wg <= S ? rows_per_wg : S - r0;
-    wg_gemv<T>(static_cast<const T*>(Fd.W1) + (int64_t)r0 * E, E, E, nr, ns, hs, IdentityRow(), tid, nth);
+    wg_norm_r<2>(xs, ns, E, nrg, false, red, tid, nth);
+    pre_finish<PRE, T, 4>(rw, W, E, E, nr_, ns, hs, IdentityRow(), tid, nth);
     __syncthreads();
-    for (int e = tid; e < nr; e += nth) A.G.hbuf[ro * S + r0 + e] = hs[e] + Fd.b1[r0 + e];
+    if (tid < nr_) A.G.hbuf[ro * S + r0 + tid] = hs[tid] + b1v;
 }
 
 // ------------------------------------------------------------------------------------------------ E: nn.LayerNorm(S) + GELU + fc2 + residual (base_blocks.py:23-25; temporal.py:145)
-// grid (F * B, E / rows_per_wg), block 256.  LDS: hs[S] ys[rows] red[32]
+// grid (F * B, E / 4), block 256: 4 rows of W2 per workgroup (a wave per row).  LDS: hs[S] ys[4] red[32]
 template <typename T>
-__global__ __launch_bounds__(256) void kv_fc2_kernel(const KvArgs A, int rows_per_wg) {
+__global__ __launch_bounds__(256) void kv_fc2_kernel(const KvArgs A) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
+    constexpr int ROWS = 4, EPC = ActTraits<T>::EPC;
     const int E = A.G.E, S = A.G.S, B = A.G.B, F = A.G.F;
-    const int tid = threadIdx.x, nth = blockDim.x;
-    const int b = blockIdx.x % B, i = blockIdx.x / B, r0 = blockIdx.y * rows_per_wg;
+    const int tid = threadIdx.x, nth = 256;
+    const int b = blockIdx.x % B, i = blockIdx.x / B, r0 = blockIdx.y * ROWS;
     float* hs = sm;
     float* ys = hs + S;
-    float* red = ys + rows_per_wg;
+    float* red = ys + ROWS;
     const SeaKvField& Fd = A.L.f[i];
     const int64_t ro = (int64_t)b * F + i;
+    const int nr_ = r0 + ROWS <= E ? ROWS : E - r0;
+    const T* W = static_cast<const T*>(Fd.W2) + (int64_t)r0 * S;
+    const int kc = S / EPC;
+    WRegs<4, 1> r4;
+    WRegs<2, 1> r2;
+    if (kc == 256) gemv_issue<T, 4, 1>(r4, W, S, S, nr_, 0, IdentityRow(), tid, nth);
+    else if (kc == 128) gemv_issue<T, 2, 1>(r2, W, S, S, nr_, 0, IdentityRow(), tid, nth);
     for (int e = tid * 4; e < S; e += nth * 4) *reinterpret_cast<float4*>(hs + e) = *reinterpret_cast<const float4*>(A.G.hbuf + ro * S + e);
-    __syncthreads();
     SeaKvNorm nm;
     nm.gamma = Fd.lnw; nm.beta = Fd.lnb; nm.mod = nullptr; nm.ldmod = 0; nm.pad_ = 0;
-    wg_norm<T>(hs, hs, S, nm, 0, true, red, tid, nth);
-    const int nr = r0 + rows_per_wg <= E ? rows_per_wg : E - r0;
-    wg_gemv<T>(static_cast<const T*>(Fd.W2) + (int64_t)r0 * S, S, S, nr, hs, ys, IdentityRow(), tid, nth);
+    NormRegs<16> nrg;
+    norm_issue<T, 16>(nrg, S, nm, 0, tid, nth);
+    const float b2v = tid < nr_ ? Fd.b2[r0 + tid] + A.G.xq[ro * E + r0 + tid] : 0.f;
     __syncthreads();
-    for (int e = tid; e < nr; e += nth) A.G.x3[ro * E + r0 + e] = ys[e] + Fd.b2[r0 + e] + A.G.xq[ro * E + r0 + e];
+    wg_norm_r<16>(hs, hs, S, nrg, true, red, tid, nth);
+    if (kc == 256) gemv_apply<T, 4, 1>(r4, S, nr_, 0, hs, ys, tid, nth);
+    else if (kc == 128) gemv_apply<T, 2, 1>(r2, S, nr_, 0, hs, ys, tid, nth);
+    else wg_gemv<T>(W, S, S, nr_, hs, ys, IdentityRow(), tid, nth);
+    __syncthreads();
+    if (tid < nr_) A.G.x3[ro * E + r0 + tid] = ys[tid] + b2v;
 }
 
 // ------------------------------------------------------------------------------------------------ Fin: proj (+ the model's final norm after the last layer) (temporal.py:146, 412-415)
 // grid F * B, block 512.  LDS: xs[E] y[E] red[32]
-template <typename T>
+template <bool PRE, typename T>
 __global__ __launch_bounds__(512) void kv_proj_kernel(const KvArgs A) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int E = A.G.E, B = A.G.B, F = A.G.F;
-    const int tid = threadIdx.x, nth = blockDim.x;
+    const int tid = threadIdx.x, nth = 512;
     const int b = blockIdx.x % B, i = blockIdx.x / B;
     float* xs = sm;
     float* y = xs + E;
     float* red = y + E;
     const SeaKvField& Fd = A.L.f[i];
     const int64_t crow = (int64_t)A.pos * B + b, ro = (int64_t)b * F + i;
-    for (int e = tid; e < E; e += nth) xs[e] = A.G.x3[ro * E + e];
+    WRegs<1, 16> rw;
+    pre_issue<PRE, T, 16>(rw, static_cast<const T*>(Fd.Wproj), E, E, E, IdentityRow(), tid, nth);
+    if (tid < E) xs[tid] = A.G.x3[ro * E + tid];
+    NormRegs<1> nr;
+    if (A.last_layer) norm_issue<T, 1>(nr, E, A.G.final_ln[i], crow, tid, nth);
+    const float bp = tid < E ? Fd.bproj[tid] : 0.f;
     __syncthreads();
-    wg_gemv<T>(static_cast<const T*>(Fd.Wproj), E, E, E, xs, y, IdentityRow(), tid, nth);
+    pre_finish<PRE, T, 16>(rw, static_cast<const T*>(Fd.Wproj), E, E, E, xs, y, IdentityRow(), tid, nth);
     __syncthreads();
-    for (int e = tid; e < E; e += nth) y[e] += Fd.bproj[e];
+    if (tid < E) y[tid] += bp;
     __syncthreads();
-    if (A.last_layer) wg_norm<T>(y, y, E, A.G.final_ln[i], crow, false, red, tid, nth);
-    for (int e = tid; e < E; e += nth) A.xout[ro * E + e] = y[e];
+    if (A.last_layer) wg_norm_r<1>(y, y, E, nr, false, red, tid, nth);
+    if (tid < E) A.xout[ro * E + tid] = y[tid];
 }
 
 static bool pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
@@ -620,24 +945,38 @@ static bool kdim_ok(int K, int epc) {
     return (kc <= 64 && pow2(kc) && kc >= 2) || kc == 128 || kc == 256 || kc == 512;
 }
 
-template <typename T>
+static int ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+// PRE: every Linear layer of the 512-thread kernels is at most 64 chunks wide and fits the register blocks the kernels request at entry, the cache
+// fits the four key rows a thread prefetches.  SEA_KV_PRE=0 keeps the streaming form.
+static bool pre_ok(const SeaKvGlobal& G, int epc) {
+    static const int env = []() { const char* e = getenv("SEA_KV_PRE"); return e ? atoi(e) : 1; }();   // tuning aid
+    if (!env) return false;
+    const int kcE = G.E / epc, kcD = G.exchange ? G.D / epc : 1;
+    if (kcE > 64 || kcD > 64 || G.cap > 2048) return false;
+    const int rppE = 8 * (64 / kcE), rppE4 = 4 * (64 / kcE), rppD = 8 * (64 / kcD);
+    const int hd_s = G.E / G.H;
+    bool ok = ceil_div(3 * hd_s, rppE) <= 8 && ceil_div(G.E, rppE) <= 16 && ceil_div(32, rppE4) <= 4;
+    if (G.exchange) {
+        const int hd_c = G.D / G.H;
+        ok = ok && ceil_div(G.D, rppE) <= 8 && ceil_div(2 * hd_c, rppD) <= 4 && ceil_div(hd_c, rppD) <= 2 && ceil_div(2 * G.D, rppD) <= 8 && ceil_div(G.D, rppD) <= 4 &&
+             ceil_div(G.E, rppD) <= 8;
+    }
+    return ok;
+}
+
+template <bool PRE, typename T>
 static int run_steps(const SeaKvGlobal& G, const SeaKvLayer* layers, int pos0, int n_steps, uint32_t tag0, hipStream_t s) {
     const int F = G.F, E = G.E, D = G.D, S = G.S, H = G.H, B = G.B, Ln = G.L, cap = G.cap;
     const int hd_s = E / H, hd_c = G.exchange ? D / H : 0;
     const int lds_attn_s = (2 * E + 3 * hd_s + hd_s + 32 + 8 * hd_s + cap + 8) * 4;
     const int lds_attn_c = G.exchange ? (2 * D + 3 * hd_c + hd_c + 32 + 8 * hd_c + cap + 8) * 4 : 0;
     const int lds_b = (3 * E + 32) * 4, lds_t = (6 * D + 2 * E + 32) * 4, lds_p = (2 * E + 32) * 4;
-    const int r1 = 32, r2 = S >= 2048 ? 4 : 8;
+    const int r1 = 32, r2 = 4;
     const int lds_d = (2 * E + r1 + 32) * 4, lds_e = (S + r2 + 32) * 4;
     const int64_t slab = (int64_t)B * F * E;
-#define KV_SELF(HDV)                                                                                   \
-    do {                                                                                               \
-        kv_self_kernel<T, HDV><<<dim3(F * B * H), dim3(512), lds_attn_s, s>>>(A);                      \
-    } while (0)
-#define KV_CROSS(HDV)                                                                                  \
-    do {                                                                                               \
-        kv_cross_kernel<T, HDV><<<dim3(F * (F - 1) * B * H), dim3(512), lds_attn_c, s>>>(A);           \
-    } while (0)
+#define KV_SELF(HDV) kv_self_kernel<PRE, T, HDV><<<dim3(F * B * H), dim3(512), lds_attn_s, s>>>(A)
+#define KV_CROSS(HDV) kv_cross_kernel<PRE, T, HDV><<<dim3(F * (F - 1) * B * H), dim3(512), lds_attn_c, s>>>(A)
     for (int k = 0; k < n_steps; ++k) {
         const int pos = pos0 + k;
         for (int l = 0; l < Ln; ++l) {
@@ -654,21 +993,25 @@ static int run_steps(const SeaKvGlobal& G, const SeaKvLayer* layers, int pos0, i
                 case 8: KV_SELF(8); break;
                 case 16: KV_SELF(16); break;
                 case 32: KV_SELF(32); break;
-                default: KV_SELF(64); break;
+                default:
+                    if constexpr (!PRE) KV_SELF(64);   // (PRE never holds at head dim 64: its 192 projection rows exceed the register blocks)
+                    break;
             }
-            kv_oproj_kernel<T><<<dim3(F * B), dim3(512), lds_b, s>>>(A);
+            kv_oproj_kernel<PRE, T><<<dim3(F * B), dim3(512), lds_b, s>>>(A);
             if (G.exchange) {
                 switch (hd_c) {
                     case 8: KV_CROSS(8); break;
                     case 16: KV_CROSS(16); break;
                     case 32: KV_CROSS(32); break;
-                    default: KV_CROSS(64); break;
+                    default:
+                        if constexpr (!PRE) KV_CROSS(64);
+                        break;
                 }
-                kv_tail_kernel<T><<<dim3(F * B), dim3(512), lds_t, s>>>(A);
+                kv_tail_kernel<PRE, T><<<dim3(F * B), dim3(512), lds_t, s>>>(A);
             }
-            kv_fc1_kernel<T><<<dim3(F * B, (S + r1 - 1) / r1), dim3(256), lds_d, s>>>(A, r1);
-            kv_fc2_kernel<T><<<dim3(F * B, (E + r2 - 1) / r2), dim3(256), lds_e, s>>>(A, r2);
-            kv_proj_kernel<T><<<dim3(F * B), dim3(512), lds_p, s>>>(A);
+            kv_fc1_kernel<PRE, T><<<dim3(F * B, (S + r1 - 1) / r1), dim3(256), lds_d, s>>>(A);
+            kv_fc2_kernel<T><<<dim3(F * B, (E + r2 - 1) / r2), dim3(256), lds_e, s>>>(A);
+            kv_proj_kernel<PRE, T><<<dim3(F * B), dim3(512), lds_p, s>>>(A);
         }
     }
 #undef KV_SELF
@@ -685,7 +1028,7 @@ extern "C" int sea_kv_rollout(const SeaKvGlobal* G, const SeaKvLayer* layers, in
     const int F = G->F, E = G->E, D = G->D, S = G->S, H = G->H, B = G->B;
     SEA_REQUIRE(F >= 1 && F <= SEA_KV_MAX_FIELDS && B >= 1 && B <= 64 && H >= 1 && G->L >= 1 && G->cap >= pos0 + n_steps && G->cap <= 8192,
                 "sea_kv_rollout: bad sizes (F=%d B=%d H=%d L=%d cap=%d pos0=%d n_steps=%d)", F, B, H, G->L, G->cap, pos0, n_steps);
-    SEA_REQUIRE(E % H == 0 && E <= 512 && kdim_ok(E, epc) && S <= 8192 && kdim_ok(S, epc) && S % 4 == 0, "sea_kv_rollout: unsupported widths E=%d S=%d", E, S);
+    SEA_REQUIRE(E % H == 0 && E <= 512 && kdim_ok(E, epc) && S <= 4096 && kdim_ok(S, epc) && S % 4 == 0, "sea_kv_rollout: unsupported widths E=%d S=%d", E, S);
     const int hd_s = E / H;
     SEA_REQUIRE(hd_s == 8 || hd_s == 16 || hd_s == 32 || hd_s == 64, "sea_kv_rollout: self head dim %d (8 / 16 / 32 / 64)", hd_s);
     if (G->exchange) {
@@ -696,8 +1039,14 @@ extern "C" int sea_kv_rollout(const SeaKvGlobal* G, const SeaKvLayer* layers, in
     }
     SEA_REQUIRE(G->traj && G->att_e && G->xr && G->xq && G->x3 && G->hbuf && G->err && G->rope_self && (G->L == 1 || (G->xl[0] && G->xl[1])), "sea_kv_rollout: null workspace");
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (dtype == SEA_BF16) run_steps<__bf16>(*G, layers, pos0, n_steps, tag0, s);
-    else run_steps<float>(*G, layers, pos0, n_steps, tag0, s);
+    const bool pre = pre_ok(*G, epc) && E / H <= 32 && (!G->exchange || D / H <= 32);
+    if (dtype == SEA_BF16) {
+        if (pre) run_steps<true, __bf16>(*G, layers, pos0, n_steps, tag0, s);
+        else run_steps<false, __bf16>(*G, layers, pos0, n_steps, tag0, s);
+    } else {
+        if (pre) run_steps<true, float>(*G, layers, pos0, n_steps, tag0, s);
+        else run_steps<false, float>(*G, layers, pos0, n_steps, tag0, s);
+    }
     SEA_CHECK_LAUNCH("sea_kv_rollout");
     return SEA_OK;
 }

@@ -54,7 +54,7 @@ def supported(eng, B: int) -> bool:
         return False
     F, E, D, S, H = m.num_variables, m.embed_dim, m.down_dim, m.mlp_hidden, m.n_heads
     epc = 8 if eng.act_dtype == torch.bfloat16 else 4
-    if not (1 <= F <= N.KV_MAX_FIELDS and 1 <= B <= 64 and E <= 512 and S <= 8192 and S % 4 == 0 and _chunks_ok(E, epc) and _chunks_ok(S, epc)):
+    if not (1 <= F <= N.KV_MAX_FIELDS and 1 <= B <= 64 and E <= 512 and S <= 4096 and S % 4 == 0 and _chunks_ok(E, epc) and _chunks_ok(S, epc)):
         return False
     if E % H or E // H not in (8, 16, 32, 64):
         return False
