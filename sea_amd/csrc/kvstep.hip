@@ -146,8 +146,8 @@ __device__ __forceinline__ void norm_issue(NormRegs<NPT>& R, int d, const SeaKvN
         }
     }
 }
-template <int NPT>
-__device__ __forceinline__ void wg_norm_r(const float* xs, float* ys, int d, const NormRegs<NPT>& R, bool gelu, float* red, int tid, int nthreads) {
+template <int NPT, typename T>
+__device__ __forceinline__ void wg_norm_r(const float* xs, float* ys, T* yT, int d, const NormRegs<NPT>& R, bool gelu, float* red, int tid, int nthreads) {
     float s = 0.f;
     for (int i = tid; i < d; i += nthreads) s += xs[i];
     const float mean = wg_sum(s, red, tid, nthreads) / (float)d;
@@ -164,6 +164,7 @@ __device__ __forceinline__ void wg_norm_r(const float* xs, float* ys, int d, con
             float o = (xs[i] - mean) * rstd * R.gq[k] + R.bq[k];
             if (gelu) o = gelu_erf(o);
             ys[i] = o;
+            if (yT != nullptr) yT[i] = from_f32<T>(o);   // the matrix-core operand copy
         }
     }
     __syncthreads();
@@ -258,17 +259,63 @@ __device__ __forceinline__ void wg_gemv(const T* __restrict__ W, int ldw, int K,
     else if (kc == 256) gemv_stream<T, 4>(W, ldw, K, nrows, 0, xs, ys, rowmap, tid, nthreads);
     else gemv_stream<T, 8>(W, ldw, K, nrows, 0, xs, ys, rowmap, tid, nthreads);   // kc == 512 (the host checks)
 }
-// A Linear layer in the two forms of the kernels below.  PRE (the host has checked that the contraction is at most 64 chunks and that NB blocks cover
-// the rows): the weights are requested early (`pre_issue` at kernel entry) and consumed when the input vector is in LDS (`pre_finish`).  Otherwise
-// `pre_issue` does nothing and `pre_finish` streams.
-template <bool PRE, typename T, int NB, typename RowMap>
-__device__ __forceinline__ void pre_issue(WRegs<1, NB>& R, const T* __restrict__ W, int ldw, int K, int nrows, RowMap rowmap, int tid, int nthreads) {
-    if constexpr (PRE) gemv_issue<T, 1, NB>(R, W, ldw, K, nrows, 0, rowmap, tid, nthreads);
+// A Linear layer on the matrix cores, for the kernels whose widths are template constants (KDIM = the contraction length; 0 = run-time widths,
+// the streaming VALU form above).  A wave owns 16-row tiles t = wave, wave + nwaves, ... (NT of them); the weight fragments of a tile are the A
+// operand (lane (r, g): row 16 t + r, 16-byte chunk 4 kk + g), the input vector — kept in LDS in the weights' dtype — is the B operand with every
+// column the same, so C[row 4 g + q][any column] = y[16 t + 4 g + q]: lanes with r = 0 store.  `pre_issue` requests all fragments (kernel entry),
+// `pre_finish` multiplies once the vector is in LDS.
+template <int KS, int NT>
+struct MRegs {
+    uint4 w[NT][KS];
+};
+template <typename T, int KDIM>
+struct MCfg {
+    static constexpr int KS = KDIM > 0 ? KDIM / ActTraits<T>::CK : 1;   // mma16 steps per tile
+};
+template <int KDIM, typename T, int NT, typename RowMap>
+__device__ __forceinline__ void pre_issue(MRegs<MCfg<T, KDIM>::KS, NT>& R, const T* __restrict__ W, int ldw, int nrows, RowMap rowmap, int tid, int nthreads) {
+    if constexpr (KDIM > 0) {
+        constexpr int EPC = ActTraits<T>::EPC, KS = MCfg<T, KDIM>::KS;
+        const int lane = tid & 63, wave = tid >> 6, nw = nthreads >> 6, r = lane & 15, g = lane >> 4;
+#pragma unroll
+        for (int u = 0; u < NT; ++u) {
+            int row = (u * nw + wave) * 16 + r;
+            row = row < nrows ? row : nrows - 1;
+            const T* wr = W + (int64_t)rowmap(row) * ldw + g * EPC;
+#pragma unroll
+            for (int kk = 0; kk < KS; ++kk) R.w[u][kk] = *reinterpret_cast<const uint4*>(wr + kk * 4 * EPC);
+        }
+    }
 }
-template <bool PRE, typename T, int NB, typename RowMap>
-__device__ __forceinline__ void pre_finish(const WRegs<1, NB>& R, const T* __restrict__ W, int ldw, int K, int nrows, const float* xs, float* ys, RowMap rowmap, int tid, int nthreads) {
-    if constexpr (PRE) gemv_apply<T, 1, NB>(R, K, nrows, 0, xs, ys, tid, nthreads);
-    else wg_gemv<T>(W, ldw, K, nrows, xs, ys, rowmap, tid, nthreads);
+template <int KDIM, typename T, int NT, typename RowMap>
+__device__ __forceinline__ void pre_finish(const MRegs<MCfg<T, KDIM>::KS, NT>& R, const T* __restrict__ W, int ldw, int K, int nrows, const float* xs, const T* xT, float* ys,
+                                           RowMap rowmap, int tid, int nthreads) {
+    if constexpr (KDIM > 0) {
+        constexpr int EPC = ActTraits<T>::EPC, KS = MCfg<T, KDIM>::KS;
+        const int lane = tid & 63, wave = tid >> 6, nw = nthreads >> 6, r = lane & 15, g = lane >> 4;
+        uint4 xf[KS];
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk) xf[kk] = *reinterpret_cast<const uint4*>(xT + (kk * 4 + g) * EPC);
+#pragma unroll
+        for (int u = 0; u < NT; ++u) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kk = 0; kk < KS; ++kk) mma16<T>(R.w[u][kk], xf[kk], acc);
+            const int row0 = (u * nw + wave) * 16 + g * 4;
+            if (r == 0) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (row0 + q < nrows) ys[row0 + q] = acc[q];
+            }
+        }
+    } else {
+        wg_gemv<T>(W, ldw, K, nrows, xs, ys, rowmap, tid, nthreads);
+    }
+}
+// fp32 vector in LDS -> the same vector in the weights' dtype (the B operand above); the caller's next barrier publishes it
+template <typename T>
+__device__ __forceinline__ void to_operand(const float* xs, T* xT, int n, int tid, int nthreads) {
+    for (int i = tid; i < n; i += nthreads) xT[i] = from_f32<T>(xs[i]);
 }
 
 struct IdentityRow {
@@ -504,23 +551,27 @@ struct KvArgs {
     float* xout;         // [B, F, E] output rows of this layer
 };
 
-__device__ __forceinline__ int pair_index(int i, int j, int F) { return i * (F - 1) + (j < i ? j : j - 1); }
-
 // Every kernel below opens by REQUESTING whatever does not depend on the activations — weights of its Linear layers (registers), gains, shifts,
 // modulation rows, biases, cache rows — so that the launch is one memory round trip deep instead of one per stage.  E, D <= 512: a 512-thread
 // workgroup holds one element of a row per thread.
+// KE / KD > 0: E and D are these template constants and the Linear layers run on the matrix cores (pre_issue / pre_finish); KE = 0: run-time
+// widths, streaming VALU GEMVs.
+constexpr int tiles_per_wave(int rows, int nwaves) { return rows <= 0 ? 1 : (rows + 16 * nwaves - 1) / (16 * nwaves); }
 
 // ------------------------------------------------------------------------------------------------ A: self attention (models/temporal.py:127-136 up to the projection)
-// grid F * B * H, block 512.  LDS: xs[E] ns[E] qkv[3 HD] oacc[HD] red[32] part[8 HD] prob[cap + 8]
-template <bool PRE, typename T, int HD>
+// grid F * B * H, block 512.  LDS: xs[E] ns[E] nsT[E] qkv[3 HD] oacc[HD] red[32] part[8 HD] prob[cap + 8]
+template <int KE, typename T, int HD>
 __global__ __launch_bounds__(512) void kv_self_kernel(const KvArgs A) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    const int E = A.G.E, H = A.G.H, B = A.G.B, F = A.G.F, cap = A.G.cap, pos = A.pos;
+    constexpr bool PRE = KE > 0;
+    const int E = PRE ? KE : A.G.E;
+    const int H = A.G.H, B = A.G.B, F = A.G.F, cap = A.G.cap, pos = A.pos;
     const int tid = threadIdx.x, nth = 512;
     const int h = blockIdx.x % H, ib_ = blockIdx.x / H, b = ib_ % B, i = ib_ / B;
     float* xs = sm;
     float* ns = xs + E;
-    float* qkv = ns + E;
+    T* nsT = reinterpret_cast<T*>(ns + E);
+    float* qkv = ns + 2 * E;
     float* oacc = qkv + 3 * HD;
     float* red = oacc + HD;
     float* part = red + 32;
@@ -532,8 +583,8 @@ __global__ __launch_bounds__(512) void kv_self_kernel(const KvArgs A) {
     T* Vc = static_cast<T*>(Fd.Vs) + bh * cap * HD;
     const int hh = h;
     auto rowmap = [=](int r) { return (r / HD) * E + hh * HD + (r % HD); };
-    WRegs<1, 8> rw;
-    pre_issue<PRE, T, 8>(rw, static_cast<const T*>(Fd.Wqkv), E, E, 3 * HD, rowmap, tid, nth);
+    MRegs<MCfg<T, KE>::KS, 1> rw;
+    pre_issue<KE, T, 1>(rw, static_cast<const T*>(Fd.Wqkv), E, 3 * HD, rowmap, tid, nth);
     const float* x = A.xin + ((int64_t)b * F + i) * E;
     const float* ibp = (A.L.ib != nullptr && !A.G.ib_after_cross) ? A.L.ib + crow * E : nullptr;
     if (tid < E) xs[tid] = x[tid] + (ibp != nullptr ? ibp[tid] : 0.f);
@@ -544,8 +595,8 @@ __global__ __launch_bounds__(512) void kv_self_kernel(const KvArgs A) {
     KRegs<T, HD> kr;
     k_prefetch<PRE, T, HD>(kr, Kc, pos, tid, nth);
     __syncthreads();
-    wg_norm_r<1>(xs, ns, E, nr, false, red, tid, nth);
-    pre_finish<PRE, T, 8>(rw, static_cast<const T*>(Fd.Wqkv), E, E, 3 * HD, ns, qkv, rowmap, tid, nth);
+    wg_norm_r<1, T>(xs, ns, PRE ? nsT : nullptr, E, nr, false, red, tid, nth);
+    pre_finish<KE, T, 1>(rw, static_cast<const T*>(Fd.Wqkv), E, E, 3 * HD, ns, nsT, qkv, rowmap, tid, nth);
     __syncthreads();
     head_finish<T, HD>(hr, qkv, true, Kc + (int64_t)pos * HD, Vc + (int64_t)pos * HD, tid);
     float m, l;
@@ -554,27 +605,33 @@ __global__ __launch_bounds__(512) void kv_self_kernel(const KvArgs A) {
 }
 
 // ------------------------------------------------------------------------------------------------ B: out-projection + residual, down-projection + ln_cross (models/temporal.py:136, 177-178)
-// grid F * B, block 512.  LDS: att[E] xs[E] y[E] red[32]
-template <bool PRE, typename T>
+// grid F * B, block 512.  LDS: att[E] xs[E] y[E] attT[E] xsT[E] red[32]
+template <int KE, int KD, typename T>
 __global__ __launch_bounds__(512) void kv_oproj_kernel(const KvArgs A) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    const int E = A.G.E, D = A.G.D, B = A.G.B, F = A.G.F;
+    constexpr bool PRE = KE > 0;
+    const int E = PRE ? KE : A.G.E, D = PRE ? KD : A.G.D;
+    const int B = A.G.B, F = A.G.F;
     const int tid = threadIdx.x, nth = 512;
     const int b = blockIdx.x % B, i = blockIdx.x / B;
     float* att = sm;
     float* xs = att + E;
     float* y = xs + E;
-    float* red = y + E;
+    T* attT = reinterpret_cast<T*>(y + E);
+    T* xsT = reinterpret_cast<T*>(y + 2 * E);
+    float* red = y + 3 * E;
     const SeaKvField& Fd = A.L.f[i];
     const bool ex = A.G.exchange != 0;
     const int64_t crow = (int64_t)A.pos * B + b, ro = ((int64_t)b * F + i);
-    WRegs<1, 16> rwo;
-    WRegs<1, 8> rwd;
-    pre_issue<PRE, T, 16>(rwo, static_cast<const T*>(Fd.Wo), E, E, E, IdentityRow(), tid, nth);
-    if (ex) pre_issue<PRE, T, 8>(rwd, static_cast<const T*>(Fd.Wdown), E, E, D, IdentityRow(), tid, nth);
+    MRegs<MCfg<T, KE>::KS, tiles_per_wave(KE, 8)> rwo;
+    MRegs<MCfg<T, KE>::KS, tiles_per_wave(KD, 8)> rwd;
+    pre_issue<KE, T, tiles_per_wave(KE, 8)>(rwo, static_cast<const T*>(Fd.Wo), E, E, IdentityRow(), tid, nth);
+    if (ex) pre_issue<KE, T, tiles_per_wave(KD, 8)>(rwd, static_cast<const T*>(Fd.Wdown), E, D, IdentityRow(), tid, nth);
     const float* ibp = (A.L.ib != nullptr && !A.G.ib_after_cross) ? A.L.ib + crow * E : nullptr;
     if (tid < E) {
-        att[tid] = A.G.att_e[ro * E + tid];
+        const float av = A.G.att_e[ro * E + tid];
+        att[tid] = av;
+        if constexpr (PRE) attT[tid] = from_f32<T>(av);
         xs[tid] = A.xin[ro * E + tid] + (ibp != nullptr ? ibp[tid] : 0.f);
     }
     NormRegs<1> nr;
@@ -584,38 +641,43 @@ __global__ __launch_bounds__(512) void kv_oproj_kernel(const KvArgs A) {
         if (tid < D) bd = Fd.bdown[tid];
     }
     __syncthreads();
-    pre_finish<PRE, T, 16>(rwo, static_cast<const T*>(Fd.Wo), E, E, E, att, y, IdentityRow(), tid, nth);
+    pre_finish<KE, T, tiles_per_wave(KE, 8)>(rwo, static_cast<const T*>(Fd.Wo), E, E, E, att, attT, y, IdentityRow(), tid, nth);
     __syncthreads();
     if (tid < E) {
         const float v = xs[tid] + y[tid];
         xs[tid] = v;
+        if constexpr (PRE) xsT[tid] = from_f32<T>(v);
         A.G.xr[ro * E + tid] = v;
     }
     __syncthreads();
     if (!ex) return;
-    pre_finish<PRE, T, 8>(rwd, static_cast<const T*>(Fd.Wdown), E, E, D, xs, y, IdentityRow(), tid, nth);
+    pre_finish<KE, T, tiles_per_wave(KD, 8)>(rwd, static_cast<const T*>(Fd.Wdown), E, E, D, xs, xsT, y, IdentityRow(), tid, nth);
     __syncthreads();
     if (tid < D) y[tid] += bd;
     __syncthreads();
-    wg_norm_r<1>(y, y, D, nr, false, red, tid, nth);
+    wg_norm_r<1, T>(y, y, nullptr, D, nr, false, red, tid, nth);
     if (tid < D) A.G.nd_old[ro * D + tid] = y[tid];
 }
 
 // ------------------------------------------------------------------------------------------------ C: cross attention of every pair (models/temporal.py:181-186; base_blocks.py:232-293)
 // grid F (F-1) * B * H, block 512.  Pair (i, j): query from nd_old_i; source j > i: key / value of this position from nd_old_j, appended, the head's
 // output is final; source j < i (updated earlier in this sweep): only the cached keys here — (o, m, l) and q go to the tail, which merges this
-// position's key.  LDS: ni[D] nj[D] qkv[3 HD] oacc[HD] red[32] part[8 HD] prob[cap + 8]
-template <bool PRE, typename T, int HD>
+// position's key.  LDS: ni[D] nj[D] niT[D] njT[D] qkv[3 HD] oacc[HD] red[32] part[8 HD] prob[cap + 8]
+template <int KD, typename T, int HD>
 __global__ __launch_bounds__(512) void kv_cross_kernel(const KvArgs A) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    const int D = A.G.D, H = A.G.H, B = A.G.B, F = A.G.F, cap = A.G.cap, pos = A.pos;
+    constexpr bool PRE = KD > 0;
+    const int D = PRE ? KD : A.G.D;
+    const int H = A.G.H, B = A.G.B, F = A.G.F, cap = A.G.cap, pos = A.pos;
     const int tid = threadIdx.x, nth = 512;
     const int h = blockIdx.x % H, pb = blockIdx.x / H, b = pb % B, p = pb / B;
     const int i = p / (F - 1), s = p % (F - 1), j = s < i ? s : s + 1;
     const bool old_src = j > i;
     float* ni = sm;
     float* nj = ni + D;
-    float* qkv = nj + D;
+    T* niT = reinterpret_cast<T*>(nj + D);
+    T* njT = reinterpret_cast<T*>(nj + 2 * D);
+    float* qkv = nj + 3 * D;
     float* oacc = qkv + 3 * HD;
     float* red = oacc + HD;
     float* part = red + 32;
@@ -627,21 +689,25 @@ __global__ __launch_bounds__(512) void kv_cross_kernel(const KvArgs A) {
     const int hh = h;
     auto qmap = [=](int r) { return hh * HD + r; };
     auto kvmap = [=](int r) { return (r / HD) * D + hh * HD + (r % HD); };
-    WRegs<1, 2> rq;
-    WRegs<1, 4> rkv;
-    pre_issue<PRE, T, 2>(rq, static_cast<const T*>(P.Wq), D, D, HD, qmap, tid, nth);
-    if (old_src) pre_issue<PRE, T, 4>(rkv, static_cast<const T*>(P.Wkv), D, D, 2 * HD, kvmap, tid, nth);
+    MRegs<MCfg<T, KD>::KS, 1> rq, rkv;
+    pre_issue<KD, T, 1>(rq, static_cast<const T*>(P.Wq), D, HD, qmap, tid, nth);
+    if (old_src) pre_issue<KD, T, 1>(rkv, static_cast<const T*>(P.Wkv), D, 2 * HD, kvmap, tid, nth);
     if (tid < D) {
-        ni[tid] = A.G.nd_old[((int64_t)b * F + i) * D + tid];
-        nj[tid] = A.G.nd_old[((int64_t)b * F + j) * D + tid];
+        const float a = A.G.nd_old[((int64_t)b * F + i) * D + tid], c = A.G.nd_old[((int64_t)b * F + j) * D + tid];
+        ni[tid] = a;
+        nj[tid] = c;
+        if constexpr (PRE) {
+            niT[tid] = from_f32<T>(a);
+            njT[tid] = from_f32<T>(c);
+        }
     }
     HeadRegs hr;
     head_issue<HD>(hr, P.bq + h * HD, P.bkv + h * HD, P.bkv + D + h * HD, A.G.rope_cross, pos, old_src, tid);
     KRegs<T, HD> kr;
     k_prefetch<PRE, T, HD>(kr, Kc, pos, tid, nth);
     __syncthreads();
-    pre_finish<PRE, T, 2>(rq, static_cast<const T*>(P.Wq), D, D, HD, ni, qkv, qmap, tid, nth);
-    if (old_src) pre_finish<PRE, T, 4>(rkv, static_cast<const T*>(P.Wkv), D, D, 2 * HD, nj, qkv + HD, kvmap, tid, nth);
+    pre_finish<KD, T, 1>(rq, static_cast<const T*>(P.Wq), D, D, HD, ni, niT, qkv, qmap, tid, nth);
+    if (old_src) pre_finish<KD, T, 1>(rkv, static_cast<const T*>(P.Wkv), D, D, 2 * HD, nj, njT, qkv + HD, kvmap, tid, nth);
     __syncthreads();
     head_finish<T, HD>(hr, qkv, old_src, Kc + (int64_t)pos * HD, Vc + (int64_t)pos * HD, tid);
     float m, l;
@@ -660,14 +726,17 @@ __global__ __launch_bounds__(512) void kv_cross_kernel(const KvArgs A) {
 
 // ------------------------------------------------------------------------------------------------ T: the Gauss-Seidel tails (models/temporal.py:187-192)
 // grid F * B (field-major: workgroup (i, b) only ever waits for workgroups with a smaller index), block 512.
-// LDS: nj[D] kv[2 D] o[D] g[D] gs[D] xs[E] y[E] red[32]
+// LDS: nj[D] kv[2 D] o[D] g[D] gs[D] njT[D] oT[D] gsT[D] xs[E] y[E] xsT[E] red[32]
 // The body is specialised on (number of fields, this field): which pairs wait, which weights are requested when and how many register blocks are
 // alive is then static — with run-time control flow around the register blocks the allocator spills.
-template <bool PRE, typename T, int NF, int I>
+template <int KE, int KD, typename T, int NF, int I>
 __device__ __forceinline__ void tail_body(const KvArgs& A, float* sm, int b) {
+    constexpr bool PRE = KE > 0;
     constexpr bool HAS_DOWN = I < NF - 1;
     constexpr int NNEW = I;                          // sources updated before this field in the sweep: j = 0 .. I - 1
-    const int E = A.G.E, D = A.G.D, H = A.G.H, B = A.G.B, cap = A.G.cap, pos = A.pos;
+    constexpr int NT_2D = tiles_per_wave(2 * KD, 8), NT_D = tiles_per_wave(KD, 8), NT_E = tiles_per_wave(KE, 8);
+    const int E = PRE ? KE : A.G.E, D = PRE ? KD : A.G.D;
+    const int H = A.G.H, B = A.G.B, cap = A.G.cap, pos = A.pos;
     const int hd = D / H, hd2 = hd >> 1;
     const int tid = threadIdx.x, nth = 512;
     float* nj = sm;
@@ -675,22 +744,27 @@ __device__ __forceinline__ void tail_body(const KvArgs& A, float* sm, int b) {
     float* o = kv + 2 * D;
     float* g = o + D;
     float* gs = g + D;
-    float* xs = gs + D;
+    T* njT = reinterpret_cast<T*>(gs + D);
+    T* oT = reinterpret_cast<T*>(gs + 2 * D);
+    T* gsT = reinterpret_cast<T*>(gs + 3 * D);
+    float* xs = gs + 4 * D;
     float* y = xs + E;
-    float* red = y + E;
+    T* xsT = reinterpret_cast<T*>(y + E);
+    float* red = y + 2 * E;
     const SeaKvField& Fd = A.L.f[I];
     const int64_t crow = (int64_t)pos * B + b, ro = (int64_t)b * NF + I;
     // ---- requested before the first wait: the projections of every pair, the k / v weights of the first two updated sources
-    WRegs<1, 4> rp[NF - 1];
-    WRegs<1, 8> rkv[NNEW > 2 ? 2 : (NNEW > 0 ? NNEW : 1)];
-    WRegs<1, 8> rup, rdn;
-    if constexpr (NNEW >= 1) pre_issue<PRE, T, 8>(rkv[0], static_cast<const T*>(A.L.p[I][0].Wkv), D, D, 2 * D, IdentityRow(), tid, nth);
-    if constexpr (NNEW >= 2) pre_issue<PRE, T, 8>(rkv[1], static_cast<const T*>(A.L.p[I][1].Wkv), D, D, 2 * D, IdentityRow(), tid, nth);
+    MRegs<MCfg<T, KD>::KS, NT_D> rp[NF - 1];
+    MRegs<MCfg<T, KD>::KS, NT_2D> rkv[NNEW > 2 ? 2 : (NNEW > 0 ? NNEW : 1)];
+    MRegs<MCfg<T, KD>::KS, NT_E> rup;
+    MRegs<MCfg<T, KE>::KS, NT_D> rdn;
+    if constexpr (NNEW >= 1) pre_issue<KD, T, NT_2D>(rkv[0], static_cast<const T*>(A.L.p[I][0].Wkv), D, 2 * D, IdentityRow(), tid, nth);
+    if constexpr (NNEW >= 2) pre_issue<KD, T, NT_2D>(rkv[1], static_cast<const T*>(A.L.p[I][1].Wkv), D, 2 * D, IdentityRow(), tid, nth);
 #pragma unroll
-    for (int s = 0; s < NF - 1; ++s) pre_issue<PRE, T, 4>(rp[s], static_cast<const T*>(A.L.p[I][s < I ? s : s + 1].Wp), D, D, D, IdentityRow(), tid, nth);
+    for (int s = 0; s < NF - 1; ++s) pre_issue<KD, T, NT_D>(rp[s], static_cast<const T*>(A.L.p[I][s < I ? s : s + 1].Wp), D, D, IdentityRow(), tid, nth);
     if constexpr (NNEW == 0) {   // the first field waits for nobody: everything at entry
-        pre_issue<PRE, T, 8>(rup, static_cast<const T*>(Fd.Wup), D, D, E, IdentityRow(), tid, nth);
-        if constexpr (HAS_DOWN) pre_issue<PRE, T, 8>(rdn, static_cast<const T*>(Fd.Wdown), E, E, D, IdentityRow(), tid, nth);
+        pre_issue<KD, T, NT_E>(rup, static_cast<const T*>(Fd.Wup), D, E, IdentityRow(), tid, nth);
+        if constexpr (HAS_DOWN) pre_issue<KE, T, NT_D>(rdn, static_cast<const T*>(Fd.Wdown), E, D, IdentityRow(), tid, nth);
     }
     NormRegs<1> nr;
     float bd = 0.f, bu = 0.f;
@@ -709,13 +783,17 @@ __device__ __forceinline__ void tail_body(const KvArgs& A, float* sm, int b) {
         const int p = I * (NF - 1) + s;
         const int64_t po = ((int64_t)p * B + b) * D;
         __syncthreads();
-        if (tid < D) o[tid] = A.G.oc[po + tid];
+        if (tid < D) {
+            const float v = A.G.oc[po + tid];
+            o[tid] = v;
+            if constexpr (PRE) oT[tid] = from_f32<T>(v);
+        }
         __syncthreads();
-        pre_finish<PRE, T, 4>(rp[s], static_cast<const T*>(A.L.p[I][s + 1].Wp), D, D, D, o, g, IdentityRow(), tid, nth);
+        pre_finish<KD, T, NT_D>(rp[s], static_cast<const T*>(A.L.p[I][s + 1].Wp), D, D, D, o, oT, g, IdentityRow(), tid, nth);
         __syncthreads();
         if (tid < D) gsum += gelu_erf(g[tid]);
     }
-    if constexpr (NNEW > 0) pre_issue<PRE, T, 8>(rup, static_cast<const T*>(Fd.Wup), D, D, E, IdentityRow(), tid, nth);
+    if constexpr (NNEW > 0) pre_issue<KD, T, NT_E>(rup, static_cast<const T*>(Fd.Wup), D, E, IdentityRow(), tid, nth);
     // ---- sources updated earlier in this sweep (j < I): granules {value, tag} published by workgroup (j, b)
 #pragma unroll
     for (int j = 0; j < NNEW; ++j) {
@@ -737,6 +815,7 @@ __device__ __forceinline__ void tail_body(const KvArgs& A, float* sm, int b) {
             }
             if (it == KV_SPIN_LIMIT) __hip_atomic_store(A.G.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             nj[tid] = v;
+            if constexpr (PRE) njT[tid] = from_f32<T>(v);
         }
         // what the merge needs besides k / v: requested while the k / v projection runs
         float qv = 0.f, ov = 0.f, m0 = 0.f, l0 = 0.f, bk0 = 0.f, bk1 = 0.f, bvv = 0.f;
@@ -758,7 +837,7 @@ __device__ __forceinline__ void tail_body(const KvArgs& A, float* sm, int b) {
         }
         __syncthreads();
         if constexpr (PRE) {
-            if (j < 2) gemv_apply<T, 1, 8>(rkv[j < 2 ? j : 0], D, 2 * D, 0, nj, kv, tid, nth);
+            if (j < 2) pre_finish<KD, T, NT_2D>(rkv[j < 2 ? j : 0], static_cast<const T*>(P.Wkv), D, D, 2 * D, nj, njT, kv, IdentityRow(), tid, nth);
             else wg_gemv<T>(static_cast<const T*>(P.Wkv), D, D, 2 * D, nj, kv, IdentityRow(), tid, nth);   // (a fourth field's third source)
         } else {
             wg_gemv<T>(static_cast<const T*>(P.Wkv), D, D, 2 * D, nj, kv, IdentityRow(), tid, nth);
@@ -791,73 +870,82 @@ __device__ __forceinline__ void tail_body(const KvArgs& A, float* sm, int b) {
         if (tid < D) {
             const float m1 = fmaxf(m0, sc[0]);
             const float w0 = l0 > 0.f ? __expf(m0 - m1) : 0.f, w1 = __expf(sc[0] - m1);
-            o[tid] = (ov * w0 + vv * w1) / (l0 * w0 + w1);
+            const float ov2 = (ov * w0 + vv * w1) / (l0 * w0 + w1);
+            o[tid] = ov2;
+            if constexpr (PRE) oT[tid] = from_f32<T>(ov2);
         }
         __syncthreads();
-        pre_finish<PRE, T, 4>(rp[j], static_cast<const T*>(P.Wp), D, D, D, o, g, IdentityRow(), tid, nth);
+        pre_finish<KD, T, NT_D>(rp[j], static_cast<const T*>(P.Wp), D, D, D, o, oT, g, IdentityRow(), tid, nth);
         __syncthreads();
         if (tid < D) gsum += gelu_erf(g[tid]);
     }
-    if (tid < D) gs[tid] = gsum;
-    if constexpr (NNEW > 0 && HAS_DOWN) pre_issue<PRE, T, 8>(rdn, static_cast<const T*>(Fd.Wdown), E, E, D, IdentityRow(), tid, nth);
+    if (tid < D) {
+        gs[tid] = gsum;
+        if constexpr (PRE) gsT[tid] = from_f32<T>(gsum);
+    }
+    if constexpr (NNEW > 0 && HAS_DOWN) pre_issue<KE, T, NT_D>(rdn, static_cast<const T*>(Fd.Wdown), E, D, IdentityRow(), tid, nth);
     __syncthreads();
-    pre_finish<PRE, T, 8>(rup, static_cast<const T*>(Fd.Wup), D, D, E, gs, y, IdentityRow(), tid, nth);
+    pre_finish<KD, T, NT_E>(rup, static_cast<const T*>(Fd.Wup), D, D, E, gs, gsT, y, IdentityRow(), tid, nth);
     __syncthreads();
     if (tid < E) {
         const float v = xs[tid] + y[tid] + (float)(NF - 1) * bu;
         xs[tid] = v;
+        if constexpr (PRE) xsT[tid] = from_f32<T>(v);
         A.G.xr[ro * E + tid] = v;
     }
     __syncthreads();
     if constexpr (HAS_DOWN) {
-        pre_finish<PRE, T, 8>(rdn, static_cast<const T*>(Fd.Wdown), E, E, D, xs, y, IdentityRow(), tid, nth);
+        pre_finish<KE, T, NT_D>(rdn, static_cast<const T*>(Fd.Wdown), E, E, D, xs, xsT, y, IdentityRow(), tid, nth);
         __syncthreads();
         if (tid < D) y[tid] += bd;
         __syncthreads();
-        wg_norm_r<1>(y, y, D, nr, false, red, tid, nth);
+        wg_norm_r<1, T>(y, y, nullptr, D, nr, false, red, tid, nth);
         unsigned long long* hgo = A.G.handoff + ((int64_t)b * NF + I) * D;
         if (tid < D)
             __hip_atomic_store(hgo + tid, ((unsigned long long)A.tag << 32) | (unsigned long long)__builtin_bit_cast(uint32_t, y[tid]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
-template <bool PRE, typename T>
+template <int KE, int KD, typename T>
 __global__ __launch_bounds__(512) void kv_tail_kernel(const KvArgs A) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int B = A.G.B;
     const int b = blockIdx.x % B, i = blockIdx.x / B;
     switch (A.G.F * 4 + i) {   // block-uniform
-        case 2 * 4 + 0: tail_body<PRE, T, 2, 0>(A, sm, b); break;
-        case 2 * 4 + 1: tail_body<PRE, T, 2, 1>(A, sm, b); break;
-        case 3 * 4 + 0: tail_body<PRE, T, 3, 0>(A, sm, b); break;
-        case 3 * 4 + 1: tail_body<PRE, T, 3, 1>(A, sm, b); break;
-        case 3 * 4 + 2: tail_body<PRE, T, 3, 2>(A, sm, b); break;
-        case 4 * 4 + 0: tail_body<PRE, T, 4, 0>(A, sm, b); break;
-        case 4 * 4 + 1: tail_body<PRE, T, 4, 1>(A, sm, b); break;
-        case 4 * 4 + 2: tail_body<PRE, T, 4, 2>(A, sm, b); break;
-        default: tail_body<PRE, T, 4, 3>(A, sm, b); break;
+        case 2 * 4 + 0: tail_body<KE, KD, T, 2, 0>(A, sm, b); break;
+        case 2 * 4 + 1: tail_body<KE, KD, T, 2, 1>(A, sm, b); break;
+        case 3 * 4 + 0: tail_body<KE, KD, T, 3, 0>(A, sm, b); break;
+        case 3 * 4 + 1: tail_body<KE, KD, T, 3, 1>(A, sm, b); break;
+        case 3 * 4 + 2: tail_body<KE, KD, T, 3, 2>(A, sm, b); break;
+        case 4 * 4 + 0: tail_body<KE, KD, T, 4, 0>(A, sm, b); break;
+        case 4 * 4 + 1: tail_body<KE, KD, T, 4, 1>(A, sm, b); break;
+        case 4 * 4 + 2: tail_body<KE, KD, T, 4, 2>(A, sm, b); break;
+        default: tail_body<KE, KD, T, 4, 3>(A, sm, b); break;
     }
 }
 
 // ------------------------------------------------------------------------------------------------ D: info-bottleneck add + AdaLN_2 + fc1 (models/temporal.py:139-145; base_blocks.py:22)
-// grid (F * B, S / 32), block 256: 32 rows of W1 per workgroup.  LDS: xs[E] ns[E] hs[32] red[32]
-template <bool PRE, typename T>
+// grid (F * B, S / 32), block 256: 32 rows of W1 per workgroup.  LDS: xs[E] ns[E] nsT[E] hs[32] red[32]
+template <int KE, typename T>
 __global__ __launch_bounds__(256) void kv_fc1_kernel(const KvArgs A) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     constexpr int ROWS = 32;
-    const int E = A.G.E, S = A.G.S, B = A.G.B, F = A.G.F;
+    constexpr bool PRE = KE > 0;
+    const int E = PRE ? KE : A.G.E;
+    const int S = A.G.S, B = A.G.B, F = A.G.F;
     const int tid = threadIdx.x, nth = 256;
     const int b = blockIdx.x % B, i = blockIdx.x / B, r0 = blockIdx.y * ROWS;
     float* xs = sm;
     float* ns = xs + E;
-    float* hs = ns + E;
+    T* nsT = reinterpret_cast<T*>(ns + E);
+    float* hs = ns + 2 * E;
     float* red = hs + ROWS;
     const SeaKvField& Fd = A.L.f[i];
     const int64_t crow = (int64_t)A.pos * B + b, ro = (int64_t)b * F + i;
     const int nr_ = r0 + ROWS <= S ? ROWS : S - r0;
     const T* W = static_cast<const T*>(Fd.W1) + (int64_t)r0 * E;
-    WRegs<1, 4> rw;
-    pre_issue<PRE, T, 4>(rw, W, E, E, nr_, IdentityRow(), tid, nth);
+    MRegs<MCfg<T, KE>::KS, 1> rw;
+    pre_issue<KE, T, 1>(rw, W, E, nr_, IdentityRow(), tid, nth);
     const float* ibp = (A.L.ib != nullptr && A.G.ib_after_cross) ? A.L.ib + crow * E : nullptr;
     for (int e = tid; e < E; e += nth) {
         const float v = A.G.xr[ro * E + e] + (ibp != nullptr ? ibp[e] : 0.f);
@@ -868,8 +956,8 @@ __global__ __launch_bounds__(256) void kv_fc1_kernel(const KvArgs A) {
     norm_issue<T, 2>(nrg, E, Fd.ln2, crow, tid, nth);
     const float b1v = tid < nr_ ? Fd.b1[r0 + tid] : 0.f;
     __syncthreads();
-    wg_norm_r<2>(xs, ns, E, nrg, false, red, tid, nth);
-    pre_finish<PRE, T, 4>(rw, W, E, E, nr_, ns, hs, IdentityRow(), tid, nth);
+    wg_norm_r<2, T>(xs, ns, PRE ? nsT : nullptr, E, nrg, false, red, tid, nth);
+    pre_finish<KE, T, 1>(rw, W, E, E, nr_, ns, nsT, hs, IdentityRow(), tid, nth);
     __syncthreads();
     if (tid < nr_) A.G.hbuf[ro * S + r0 + tid] = hs[tid] + b1v;
 }
@@ -902,7 +990,7 @@ __global__ __launch_bounds__(256) void kv_fc2_kernel(const KvArgs A) {
     norm_issue<T, 16>(nrg, S, nm, 0, tid, nth);
     const float b2v = tid < nr_ ? Fd.b2[r0 + tid] + A.G.xq[ro * E + r0 + tid] : 0.f;
     __syncthreads();
-    wg_norm_r<16>(hs, hs, S, nrg, true, red, tid, nth);
+    wg_norm_r<16, T>(hs, hs, nullptr, S, nrg, true, red, tid, nth);
     if (kc == 256) gemv_apply<T, 4, 1>(r4, S, nr_, 0, hs, ys, tid, nth);
     else if (kc == 128) gemv_apply<T, 2, 1>(r2, S, nr_, 0, hs, ys, tid, nth);
     else wg_gemv<T>(W, S, S, nr_, hs, ys, IdentityRow(), tid, nth);
@@ -911,30 +999,37 @@ __global__ __launch_bounds__(256) void kv_fc2_kernel(const KvArgs A) {
 }
 
 // ------------------------------------------------------------------------------------------------ Fin: proj (+ the model's final norm after the last layer) (temporal.py:146, 412-415)
-// grid F * B, block 512.  LDS: xs[E] y[E] red[32]
-template <bool PRE, typename T>
+// grid F * B, block 512.  LDS: xs[E] y[E] xsT[E] red[32]
+template <int KE, typename T>
 __global__ __launch_bounds__(512) void kv_proj_kernel(const KvArgs A) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    const int E = A.G.E, B = A.G.B, F = A.G.F;
+    constexpr bool PRE = KE > 0;
+    const int E = PRE ? KE : A.G.E;
+    const int B = A.G.B, F = A.G.F;
     const int tid = threadIdx.x, nth = 512;
     const int b = blockIdx.x % B, i = blockIdx.x / B;
     float* xs = sm;
     float* y = xs + E;
-    float* red = y + E;
+    T* xsT = reinterpret_cast<T*>(y + E);
+    float* red = y + 2 * E;
     const SeaKvField& Fd = A.L.f[i];
     const int64_t crow = (int64_t)A.pos * B + b, ro = (int64_t)b * F + i;
-    WRegs<1, 16> rw;
-    pre_issue<PRE, T, 16>(rw, static_cast<const T*>(Fd.Wproj), E, E, E, IdentityRow(), tid, nth);
-    if (tid < E) xs[tid] = A.G.x3[ro * E + tid];
+    MRegs<MCfg<T, KE>::KS, tiles_per_wave(KE, 8)> rw;
+    pre_issue<KE, T, tiles_per_wave(KE, 8)>(rw, static_cast<const T*>(Fd.Wproj), E, E, IdentityRow(), tid, nth);
+    if (tid < E) {
+        const float v = A.G.x3[ro * E + tid];
+        xs[tid] = v;
+        if constexpr (PRE) xsT[tid] = from_f32<T>(v);
+    }
     NormRegs<1> nr;
     if (A.last_layer) norm_issue<T, 1>(nr, E, A.G.final_ln[i], crow, tid, nth);
     const float bp = tid < E ? Fd.bproj[tid] : 0.f;
     __syncthreads();
-    pre_finish<PRE, T, 16>(rw, static_cast<const T*>(Fd.Wproj), E, E, E, xs, y, IdentityRow(), tid, nth);
+    pre_finish<KE, T, tiles_per_wave(KE, 8)>(rw, static_cast<const T*>(Fd.Wproj), E, E, E, xs, xsT, y, IdentityRow(), tid, nth);
     __syncthreads();
     if (tid < E) y[tid] += bp;
     __syncthreads();
-    if (A.last_layer) wg_norm_r<1>(y, y, E, nr, false, red, tid, nth);
+    if (A.last_layer) wg_norm_r<1, T>(y, y, nullptr, E, nr, false, red, tid, nth);
     if (tid < E) A.xout[ro * E + tid] = y[tid];
 }
 
@@ -945,38 +1040,28 @@ static bool kdim_ok(int K, int epc) {
     return (kc <= 64 && pow2(kc) && kc >= 2) || kc == 128 || kc == 256 || kc == 512;
 }
 
-static int ceil_div(int a, int b) { return (a + b - 1) / b; }
-
-// PRE: every Linear layer of the 512-thread kernels is at most 64 chunks wide and fits the register blocks the kernels request at entry, the cache
-// fits the four key rows a thread prefetches.  SEA_KV_PRE=0 keeps the streaming form.
-static bool pre_ok(const SeaKvGlobal& G, int epc) {
-    static const int env = []() { const char* e = getenv("SEA_KV_PRE"); return e ? atoi(e) : 1; }();   // tuning aid
-    if (!env) return false;
-    const int kcE = G.E / epc, kcD = G.exchange ? G.D / epc : 1;
-    if (kcE > 64 || kcD > 64 || G.cap > 2048) return false;
-    const int rppE = 8 * (64 / kcE), rppE4 = 4 * (64 / kcE), rppD = 8 * (64 / kcD);
-    const int hd_s = G.E / G.H;
-    bool ok = ceil_div(3 * hd_s, rppE) <= 8 && ceil_div(G.E, rppE) <= 16 && ceil_div(32, rppE4) <= 4;
-    if (G.exchange) {
-        const int hd_c = G.D / G.H;
-        ok = ok && ceil_div(G.D, rppE) <= 8 && ceil_div(2 * hd_c, rppD) <= 4 && ceil_div(hd_c, rppD) <= 2 && ceil_div(2 * G.D, rppD) <= 8 && ceil_div(G.D, rppD) <= 4 &&
-             ceil_div(G.E, rppD) <= 8;
-    }
-    return ok;
+// Widths with matrix-core kernels: E in {64, 128, 256} with D = E / 2 (or no exchange), heads of at most 32 columns, a cache of at most 2048
+// positions (the key rows a thread prefetches).  SEA_KV_PRE=0 keeps the run-time-width kernels (tuning aid).
+static int pre_width(const SeaKvGlobal& G) {
+    static const int env = []() { const char* e = getenv("SEA_KV_PRE"); return e ? atoi(e) : 1; }();
+    if (!env || G.cap > 2048 || (G.E != 64 && G.E != 128 && G.E != 256) || G.E / G.H > 32) return 0;
+    if (G.exchange && (G.D * 2 != G.E || G.D / G.H > 32)) return 0;
+    return G.E;
 }
 
-template <bool PRE, typename T>
+template <int KE, typename T>
 static int run_steps(const SeaKvGlobal& G, const SeaKvLayer* layers, int pos0, int n_steps, uint32_t tag0, hipStream_t s) {
+    constexpr int KD = KE / 2;
     const int F = G.F, E = G.E, D = G.D, S = G.S, H = G.H, B = G.B, Ln = G.L, cap = G.cap;
     const int hd_s = E / H, hd_c = G.exchange ? D / H : 0;
-    const int lds_attn_s = (2 * E + 3 * hd_s + hd_s + 32 + 8 * hd_s + cap + 8) * 4;
-    const int lds_attn_c = G.exchange ? (2 * D + 3 * hd_c + hd_c + 32 + 8 * hd_c + cap + 8) * 4 : 0;
-    const int lds_b = (3 * E + 32) * 4, lds_t = (6 * D + 2 * E + 32) * 4, lds_p = (2 * E + 32) * 4;
+    const int lds_attn_s = (3 * E + 3 * hd_s + hd_s + 32 + 8 * hd_s + cap + 8) * 4;
+    const int lds_attn_c = G.exchange ? (4 * D + 3 * hd_c + hd_c + 32 + 8 * hd_c + cap + 8) * 4 : 0;
+    const int lds_b = (5 * E + 32) * 4, lds_t = (9 * D + 3 * E + 32) * 4, lds_p = (3 * E + 32) * 4;
     const int r1 = 32, r2 = 4;
-    const int lds_d = (2 * E + r1 + 32) * 4, lds_e = (S + r2 + 32) * 4;
+    const int lds_d = (3 * E + r1 + 32) * 4, lds_e = (S + r2 + 32) * 4;
     const int64_t slab = (int64_t)B * F * E;
-#define KV_SELF(HDV) kv_self_kernel<PRE, T, HDV><<<dim3(F * B * H), dim3(512), lds_attn_s, s>>>(A)
-#define KV_CROSS(HDV) kv_cross_kernel<PRE, T, HDV><<<dim3(F * (F - 1) * B * H), dim3(512), lds_attn_c, s>>>(A)
+#define KV_SELF(HDV) kv_self_kernel<KE, T, HDV><<<dim3(F * B * H), dim3(512), lds_attn_s, s>>>(A)
+#define KV_CROSS(HDV) kv_cross_kernel<KD, T, HDV><<<dim3(F * (F - 1) * B * H), dim3(512), lds_attn_c, s>>>(A)
     for (int k = 0; k < n_steps; ++k) {
         const int pos = pos0 + k;
         for (int l = 0; l < Ln; ++l) {
@@ -994,29 +1079,39 @@ static int run_steps(const SeaKvGlobal& G, const SeaKvLayer* layers, int pos0, i
                 case 16: KV_SELF(16); break;
                 case 32: KV_SELF(32); break;
                 default:
-                    if constexpr (!PRE) KV_SELF(64);   // (PRE never holds at head dim 64: its 192 projection rows exceed the register blocks)
+                    if constexpr (KE == 0) KV_SELF(64);   // (the matrix-core kernels stop at head dim 32)
                     break;
             }
-            kv_oproj_kernel<PRE, T><<<dim3(F * B), dim3(512), lds_b, s>>>(A);
+            kv_oproj_kernel<KE, KD, T><<<dim3(F * B), dim3(512), lds_b, s>>>(A);
             if (G.exchange) {
                 switch (hd_c) {
                     case 8: KV_CROSS(8); break;
                     case 16: KV_CROSS(16); break;
                     case 32: KV_CROSS(32); break;
                     default:
-                        if constexpr (!PRE) KV_CROSS(64);
+                        if constexpr (KE == 0) KV_CROSS(64);
                         break;
                 }
-                kv_tail_kernel<PRE, T><<<dim3(F * B), dim3(512), lds_t, s>>>(A);
+                kv_tail_kernel<KE, KD, T><<<dim3(F * B), dim3(512), lds_t, s>>>(A);
             }
-            kv_fc1_kernel<PRE, T><<<dim3(F * B, (S + r1 - 1) / r1), dim3(256), lds_d, s>>>(A);
+            kv_fc1_kernel<KE, T><<<dim3(F * B, (S + r1 - 1) / r1), dim3(256), lds_d, s>>>(A);
             kv_fc2_kernel<T><<<dim3(F * B, (E + r2 - 1) / r2), dim3(256), lds_e, s>>>(A);
-            kv_proj_kernel<PRE, T><<<dim3(F * B), dim3(512), lds_p, s>>>(A);
+            kv_proj_kernel<KE, T><<<dim3(F * B), dim3(512), lds_p, s>>>(A);
         }
     }
 #undef KV_SELF
 #undef KV_CROSS
     return 0;
+}
+
+template <typename T>
+static int run_steps_t(const SeaKvGlobal& G, const SeaKvLayer* layers, int pos0, int n_steps, uint32_t tag0, hipStream_t s) {
+    switch (pre_width(G)) {
+        case 64: return run_steps<64, T>(G, layers, pos0, n_steps, tag0, s);
+        case 128: return run_steps<128, T>(G, layers, pos0, n_steps, tag0, s);
+        case 256: return run_steps<256, T>(G, layers, pos0, n_steps, tag0, s);
+        default: return run_steps<0, T>(G, layers, pos0, n_steps, tag0, s);
+    }
 }
 
 }  // namespace
@@ -1039,14 +1134,8 @@ extern "C" int sea_kv_rollout(const SeaKvGlobal* G, const SeaKvLayer* layers, in
     }
     SEA_REQUIRE(G->traj && G->att_e && G->xr && G->xq && G->x3 && G->hbuf && G->err && G->rope_self && (G->L == 1 || (G->xl[0] && G->xl[1])), "sea_kv_rollout: null workspace");
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const bool pre = pre_ok(*G, epc) && E / H <= 32 && (!G->exchange || D / H <= 32);
-    if (dtype == SEA_BF16) {
-        if (pre) run_steps<true, __bf16>(*G, layers, pos0, n_steps, tag0, s);
-        else run_steps<false, __bf16>(*G, layers, pos0, n_steps, tag0, s);
-    } else {
-        if (pre) run_steps<true, float>(*G, layers, pos0, n_steps, tag0, s);
-        else run_steps<false, float>(*G, layers, pos0, n_steps, tag0, s);
-    }
+    if (dtype == SEA_BF16) run_steps_t<__bf16>(*G, layers, pos0, n_steps, tag0, s);
+    else run_steps_t<float>(*G, layers, pos0, n_steps, tag0, s);
     SEA_CHECK_LAUNCH("sea_kv_rollout");
     return SEA_OK;
 }
