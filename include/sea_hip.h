@@ -265,20 +265,6 @@ typedef struct {
     int32_t n_seg, ldatt, ldwp, ldwup, ldx, ldxact;
     int32_t M, D, E, has_down;
     float bias_scale;
-    int32_t plain;                        /* 1: no first layer — x = Xin + att[0][M, E] . Wup[E, E]^T + bup (n_seg = 1, Wp ignored): an ordinary Linear + residual
-                                           * in front of the down-projection + norm, e.g. the self-attention output projection followed by
-                                           * cross_down + ln_cross of the pre-exchange fields (models/base_blocks.py:201, models/temporal.py:136, 177-181) */
-    const float* Xin;                     /* f32 [M, E], row stride ldxin: the residual is READ from here when non-NULL (X is then written only) */
-    int32_t ldxin, n_kv;
-    /* n_kv in {1, 2} (needs has_down, plain = 0): a fourth layer — the K / V projections of the NORMALISED rows y for the later fields that attend to this
-     * one (cross_attn[iq][i].k / .v, models/base_blocks.py:271-280), with bias, rotary embedding on k and the attention layouts of
-     * sea_qkv_rope_grouped: Kout[c] act [B, H, cap, hd] at row pos0 + t, Vtout[c] act [B, H, hd, cap] at column pos0 + t; row m = b * T + t; D = H * hd */
-    const void* Wkv[2];                   /* act [2 D, D]: k rows then v rows, row stride ldwkv */
-    const float* bkv[2];                  /* f32 [2 D] */
-    void* Kout[2];
-    void* Vtout[2];
-    const float* rope;                    /* f32 [>= pos0 + T, hd / 2, 2] (cos, sin) */
-    int32_t ldwkv, H, hd, T, pos0, cap;
     SeaGemmNormGroup down;
 } SeaExchangeTail;
 

@@ -134,10 +134,7 @@ MAX_SILU_IB = 4
 class SeaExchangeTail(C.Structure):
     _fields_ = [("att", _vp * XTAIL_MAX_SEG), ("Wp", _vp * XTAIL_MAX_SEG), ("Wup", _vp), ("bup", _vp), ("X", _vp), ("Xact", _vp),
                 ("n_seg", _i32), ("ldatt", _i32), ("ldwp", _i32), ("ldwup", _i32), ("ldx", _i32), ("ldxact", _i32),
-                ("M", _i32), ("D", _i32), ("E", _i32), ("has_down", _i32), ("bias_scale", _f32), ("plain", _i32),
-                ("Xin", _vp), ("ldxin", _i32), ("n_kv", _i32),
-                ("Wkv", _vp * 2), ("bkv", _vp * 2), ("Kout", _vp * 2), ("Vtout", _vp * 2), ("rope", _vp),
-                ("ldwkv", _i32), ("H", _i32), ("hd", _i32), ("T", _i32), ("pos0", _i32), ("cap", _i32),
+                ("M", _i32), ("D", _i32), ("E", _i32), ("has_down", _i32), ("bias_scale", _f32),
                 ("down", SeaGemmNormGroup)]
 
 

@@ -429,21 +429,17 @@ struct XTailCfg {
     static constexpr int ST1 = (BM + D) * BKB;               // stage-1 tile: att rows, then Wp rows
     static constexpr int ST2 = (BM + E) * BKB;               // stage-2 tile: g rows, then Wup rows
     static constexpr int ST3 = D * BKB;                      // stage-3 tile: Wdown rows (the A rows live in the x tile)
-    static constexpr int ST4 = 2 * D * BKB;                  // stage-4 tile: Wkv rows (k then v), KT1 tiles per projection
     static constexpr int SMAX = D == 128 ? 2 : 4;
     static __host__ __device__ constexpr int r1_bytes(int S) { return S * KT1 * ST1 > KT3 * ST3 ? S * KT1 * ST1 : KT3 * ST3; }
     static __host__ __device__ constexpr int lds_bytes(int S) { return r1_bytes(S) + KT1 * ST2 + BM * E * 2 + 512; }
-    // PLAIN (no first layer: x = Xin + att[M, E] . Wup[E, E]^T): the E/64 K-tiles of (att | Wup) take the front of LDS, Wdown reuses it after stage 2
-    static constexpr int KT2P = E / BK;
-    static __host__ __device__ constexpr int lds_bytes_plain() { return (KT2P * ST2 > KT3 * ST3 ? KT2P * ST2 : KT3 * ST3) + BM * E * 2 + 512; }
 };
 
-template <int D, int E, bool PLAIN>
+template <int D, int E>
 __global__ __launch_bounds__(256) void exchange_tail_kernel(const XTailLaunch L) {
     using T = __bf16;
     using C = XTailCfg<D, E>;
     constexpr int BM = C::BM, BKB = C::BKB, BK = C::BK, KT1 = C::KT1, KT3 = C::KT3, ST1 = C::ST1, ST2 = C::ST2, ST3 = C::ST3, SMAX = C::SMAX;
-    constexpr int KT2 = PLAIN ? C::KT2P : KT1;                     // K-tiles of stage 2
+    constexpr int KT2 = KT1;                                       // K-tiles of stage 2
     constexpr int NI1 = D / 64, NI2 = E / 64, NI3 = D / 64;       // 16-column blocks per wave in each stage
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const SeaExchangeTail& P = L.p[blockIdx.y];
@@ -451,8 +447,8 @@ __global__ __launch_bounds__(256) void exchange_tail_kernel(const XTailLaunch L)
     const int r = lane & 15, g = lane >> 4;
     const int m0 = blockIdx.x * BM, M = P.M, S = P.n_seg;
     if (m0 >= M) return;   // block-uniform (groups of different row counts share the grid)
-    const int r1b = PLAIN ? 0 : C::r1_bytes(S);
-    const int r2b = PLAIN ? (KT2 * ST2 > KT3 * ST3 ? KT2 * ST2 : KT3 * ST3) : KT2 * ST2;
+    const int r1b = C::r1_bytes(S);
+    const int r2b = KT2 * ST2;
     char* R1 = smem;
     char* R2 = smem + r1b;
     char* x3 = R2 + r2b;
@@ -466,17 +462,8 @@ __global__ __launch_bounds__(256) void exchange_tail_kernel(const XTailLaunch L)
     const int wv = __builtin_amdgcn_readfirstlane(wave);
     const int rl = lane >> 3;
     const int chunk = (lane & 7) ^ (rl & 7);   // swizzle on the source side: LDS position p of a row holds chunk p ^ (row & 7)
-    // ---- burst 1: att_s | Wp_s K-tiles (R1) and the Wup rows of the stage-2 K-tiles (R2); PLAIN: the att rows are the A rows of stage 2
-    if constexpr (PLAIN) {
-        const T* att = static_cast<const T*>(P.att[0]);
-        for (int kt = 0; kt < KT2; ++kt)
-            for (int u = wv; u < BM / 8; u += 4) {
-                int mr = m0 + u * 8 + rl;
-                mr = mr < M ? mr : M - 1;
-                glds16_gn(att + (int64_t)mr * P.ldatt + kt * BK + chunk * 8, r2_base + (unsigned)(kt * ST2 + u * 8 * BKB));
-            }
-    }
-    for (int s = 0; s < (PLAIN ? 0 : S); ++s) {
+    // ---- burst 1: att_s | Wp_s K-tiles (R1) and the Wup rows of the stage-2 K-tiles (R2)
+    for (int s = 0; s < S; ++s) {
         const T* att = static_cast<const T*>(P.att[s]);
         const T* Wp = static_cast<const T*>(P.Wp[s]);
         for (int kt = 0; kt < KT1; ++kt) {
@@ -513,14 +500,13 @@ __global__ __launch_bounds__(256) void exchange_tail_kernel(const XTailLaunch L)
 #pragma unroll
             for (int q = 0; q < 4; ++q) bv2[j][q] *= P.bias_scale;
         }
-        if (P.Xin != nullptr) load4(P.Xin + (int64_t)mc * P.ldxin + n, rv2[j]);
-        else load4(P.X + (int64_t)mc * P.ldx + n, rv2[j]);
+        load4(P.X + (int64_t)mc * P.ldx + n, rv2[j]);
     }
     NormEpilogue<T, NI3, true, true> epi3;
     if (P.has_down) epi3.prefetch(P.down, mc, wave * (D / 4), g);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the LDS-DMA bursts are not tracked by the compiler
     __syncthreads();
-    if constexpr (!PLAIN) {
+    {
     // ---- stage 1: g = sum_s gelu(att_s . Wp_s^T), this wave's D/4 columns
     float gsum[NI1][4];
 #pragma unroll
@@ -559,16 +545,14 @@ __global__ __launch_bounds__(256) void exchange_tail_kernel(const XTailLaunch L)
     }
     __syncthreads();   // g is in place; nobody reads R1 any more
     }
-    auto burst_wdown = [&]() {   // Wdown K-tiles to the front of LDS (over R1; PLAIN: over the stage-2 tiles, once they have been read)
+    auto burst_wdown = [&]() {   // Wdown K-tiles to the front of LDS (over R1)
         const T* Wd = static_cast<const T*>(P.down.W);
         for (int kt = 0; kt < KT3; ++kt)
             for (int u = wv; u < D / 8; u += 4)
                 glds16_gn(Wd + (int64_t)(u * 8 + rl) * P.down.ldw + kt * BK + chunk * 8, lds_base + (unsigned)(kt * ST3 + u * 8 * BKB));
     };
     // ---- burst 2: landing under stage 2
-    if constexpr (!PLAIN) {
-        if (P.has_down) burst_wdown();
-    }
+    if (P.has_down) burst_wdown();
     // ---- stage 2
     f32x4 acc2[NI2];
 #pragma unroll
@@ -593,12 +577,6 @@ __global__ __launch_bounds__(256) void exchange_tail_kernel(const XTailLaunch L)
         for (int q = 0; q < 4; ++q) v2[j][q] = acc2[j][q] + bv2[j][q] + rv2[j][q];
         store4(reinterpret_cast<T*>(x3 + (n / BK) * (BM * BKB) + r * BKB + ((((n % BK) >> 3) ^ (r & 7)) << 4) + (n & 7) * 2), v2[j][0], v2[j][1], v2[j][2], v2[j][3]);
     }
-    if constexpr (PLAIN) {
-        if (P.has_down) {
-            __syncthreads();   // every wave has read the stage-2 tiles: Wdown may overwrite them
-            burst_wdown();
-        }
-    }
     // Wdown has landed before anything else of this wave is put into the memory pipeline (stores count in vmcnt too: they are issued after the wait)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (mok) {
@@ -611,14 +589,6 @@ __global__ __launch_bounds__(256) void exchange_tail_kernel(const XTailLaunch L)
     }
     if (!P.has_down) return;   // block-uniform
     __syncthreads();
-    const int n_kv = PLAIN ? 0 : P.n_kv;
-    auto burst_wkv = [&](int c, unsigned base) {   // Wkv[c] K-tiles (2 D rows each) to LDS at `base`
-        const T* Wk = static_cast<const T*>(P.Wkv[c]);
-        for (int kt = 0; kt < KT1; ++kt)
-            for (int u = wv; u < 2 * D / 8; u += 4)
-                glds16_gn(Wk + (int64_t)(u * 8 + rl) * P.ldwkv + kt * BK + chunk * 8, base + (unsigned)(kt * C::ST4 + u * 8 * BKB));
-    };
-    if (n_kv > 0) burst_wkv(0, r2_base);   // the stage-2 tiles have been read by every wave (barrier above): Wkv[0] lands under stage 3
     // ---- stage 3
     f32x4 acc3[NI3];
 #pragma unroll
@@ -635,62 +605,7 @@ __global__ __launch_bounds__(256) void exchange_tail_kernel(const XTailLaunch L)
             for (int jb = 0; jb < NI3; ++jb) mma16<T>(*reinterpret_cast<const uint4*>(sB + jb * 16 * BKB + off), af, acc3[jb]);
         }
     }
-    epi3.finish(P.down, acc3, m, wave * (D / 4), r, g, wave, L.eps, red, n_kv > 0 ? x3 : nullptr);   // (x3: every wave is past its stage-3 reads — two barriers inside)
-    if (n_kv == 0) return;
-    // ---- stage 4: k / v projections of the normalised rows for the later fields, rotary embedding on k, attention layouts (qkv_rope_kernel's epilogue)
-    constexpr int LP4 = KT1 * (2 * D / 8) / 4;   // DMA pieces per wave per projection
-    if (n_kv > 1) burst_wkv(1, lds_base);        // stage 3 has read R1 (barriers inside finish): Wkv[1] lands under stage 4a
-    const int hd = P.hd, hd2 = hd >> 1, Hh = P.H, cap = P.cap, Tn = P.T;
-    const int bq = mc / Tn, tt = mc - bq * Tn, pos = P.pos0 + tt;
-    const float2* rope = reinterpret_cast<const float2*>(P.rope);
-    for (int c = 0; c < n_kv; ++c) {
-        if (c == 0 && n_kv > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LP4) : "memory");   // everything older than the Wkv[1] pieces
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();   // y tile and Wkv[c] are in LDS (c = 1: every wave is done with stage 4a)
-        const char* wbase = c == 0 ? R2 : R1;
-        f32x4 acc4[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc4[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int kt = 0; kt < KT1; ++kt) {
-            const char* sA = x3 + kt * (BM * BKB) + r * BKB;
-            const char* sB = wbase + kt * C::ST4 + (wave * (2 * D / 4) + r) * BKB;
-#pragma unroll
-            for (int kc = 0; kc < 2; ++kc) {
-                const int off = ((kc * 4 + g) ^ (r & 7)) << 4;
-                const uint4 af = *reinterpret_cast<const uint4*>(sA + off);
-#pragma unroll
-                for (int j = 0; j < 2 * D / 64; ++j) mma16<T>(*reinterpret_cast<const uint4*>(sB + j * 16 * BKB + off), af, acc4[j]);
-            }
-        }
-        const float* bkv = P.bkv[c];
-        T* Ko = static_cast<T*>(P.Kout[c]);
-        T* Vto = static_cast<T*>(P.Vtout[c]);
-#pragma unroll
-        for (int j = 0; j < 2 * D / 64; ++j) {
-            const int nn = wave * (2 * D / 4) + j * 16 + g * 4;    // column in [k | v]: waves 0, 1 hold k, waves 2, 3 hold v
-            float bv[4], v4[4];
-            load4(bkv + nn, bv);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) v4[q] = acc4[j][q] + bv[q];
-            const bool is_v = nn >= D;
-            const int hcol = is_v ? nn - D : nn;
-            const int h = hcol / hd, dd = hcol - h * hd;
-            const uint32_t bh = (uint32_t)(bq * Hh + h);
-            if (!mok) continue;
-            if (!is_v) {
-                const float4 cs = *reinterpret_cast<const float4*>(rope + (uint32_t)pos * (uint32_t)hd2 + (dd >> 1));
-                float o4[4];
-                rope_pair(v4[0], v4[1], cs.x, cs.y, o4[0], o4[1]);
-                rope_pair(v4[2], v4[3], cs.z, cs.w, o4[2], o4[3]);
-                store4(Ko + ((bh * (uint32_t)cap + pos) * (uint32_t)hd + dd), o4[0], o4[1], o4[2], o4[3]);
-            } else {
-                T* dst = Vto + ((bh * (uint32_t)hd + dd) * (uint32_t)cap + pos);
-#pragma unroll
-                for (int q = 0; q < 4; ++q) dst[(uint32_t)q * (uint32_t)cap] = (T)v4[q];
-            }
-        }
-    }
+    epi3.finish(P.down, acc3, m, wave * (D / 4), r, g, wave, L.eps, red, nullptr);
 }
 
 template <typename K>
@@ -796,25 +711,21 @@ extern "C" int sea_exchange_tail(const SeaExchangeTail* params, int n_groups, fl
     memset(&L, 0, sizeof(L));
     L.eps = eps;
     const int D = params[0].D, E = params[0].E, S0 = params[0].n_seg;
-    const bool plain = params[0].plain != 0;
     int m_max = 0;
     for (int gi = 0; gi < n_groups; ++gi) {
         const SeaExchangeTail& P = params[gi];
         const bool shape_ok = (P.D == 128 && P.E == 256) || (P.D == 64 && P.E == 128);
-        const bool seg_ok = plain ? P.n_seg == 1 : (P.n_seg >= 1 && P.n_seg <= SEA_XTAIL_MAX_SEG && P.n_seg * P.D <= 256);   // stage-1 tiles of all segments share LDS with Wup
+        const bool seg_ok = P.n_seg >= 1 && P.n_seg <= SEA_XTAIL_MAX_SEG && P.n_seg * P.D <= 256;   // stage-1 tiles of all segments share LDS with Wup
         if (dtype != SEA_BF16 || !shape_ok || !seg_ok) {
-            sea_set_error("sea_exchange_tail: unsupported dtype / shape (dtype=%d D=%d E=%d n_seg=%d plain=%d): bf16, (D,E) in {(128,256),(64,128)}, n_seg*D <= 256", dtype, P.D, P.E,
-                          P.n_seg, P.plain);
+            sea_set_error("sea_exchange_tail: unsupported dtype / shape (dtype=%d D=%d E=%d n_seg=%d): bf16, (D,E) in {(128,256),(64,128)}, n_seg*D <= 256", dtype, P.D, P.E, P.n_seg);
             return SEA_EUNSUPPORTED;
         }
-        SEA_REQUIRE(P.D == D && P.E == E && P.n_seg == S0 && (P.plain != 0) == plain, "sea_exchange_tail[%d]: the groups of a launch share shape and mode", gi);
-        SEA_REQUIRE(P.M >= 1 && P.Wup && P.X && sea_aligned16(P.Wup) && sea_aligned16(P.bup) && sea_aligned16(P.X) && sea_aligned16(P.Xact) && sea_aligned16(P.Xin),
-                    "sea_exchange_tail[%d]: null / misaligned pointer", gi);
-        const int katt = plain ? P.E : P.D;
-        SEA_REQUIRE(P.ldatt % 8 == 0 && P.ldatt >= katt && (plain || (P.ldwp % 8 == 0 && P.ldwp >= P.D)) && P.ldwup % 8 == 0 && P.ldwup >= katt && P.ldx % 4 == 0 && P.ldx >= P.E &&
-                        (!P.Xact || (P.ldxact % 4 == 0 && P.ldxact >= P.E)) && (!P.Xin || (P.ldxin % 4 == 0 && P.ldxin >= P.E)), "sea_exchange_tail[%d]: bad strides", gi);
+        SEA_REQUIRE(P.D == D && P.E == E && P.n_seg == S0, "sea_exchange_tail[%d]: the groups of a launch share their shape", gi);
+        SEA_REQUIRE(P.M >= 1 && P.Wup && P.X && sea_aligned16(P.Wup) && sea_aligned16(P.bup) && sea_aligned16(P.X) && sea_aligned16(P.Xact), "sea_exchange_tail[%d]: null / misaligned pointer", gi);
+        SEA_REQUIRE(P.ldatt % 8 == 0 && P.ldatt >= P.D && P.ldwp % 8 == 0 && P.ldwp >= P.D && P.ldwup % 8 == 0 && P.ldwup >= P.D && P.ldx % 4 == 0 && P.ldx >= P.E &&
+                        (!P.Xact || (P.ldxact % 4 == 0 && P.ldxact >= P.E)), "sea_exchange_tail[%d]: bad strides", gi);
         for (int s = 0; s < P.n_seg; ++s)
-            SEA_REQUIRE(P.att[s] && sea_aligned16(P.att[s]) && (plain || (P.Wp[s] && sea_aligned16(P.Wp[s]))), "sea_exchange_tail[%d]: segment %d: null / misaligned operand", gi, s);
+            SEA_REQUIRE(P.att[s] && sea_aligned16(P.att[s]) && P.Wp[s] && sea_aligned16(P.Wp[s]), "sea_exchange_tail[%d]: segment %d: null / misaligned operand", gi, s);
         L.p[gi] = P;
         if (P.has_down) {
             const SeaGemmNormGroup& G = P.down;
@@ -824,34 +735,19 @@ extern "C" int sea_exchange_tail(const SeaExchangeTail* params, int n_groups, fl
             SEA_REQUIRE(sea_aligned16(G.W) && sea_aligned16(G.bias) && sea_aligned16(G.mod) && sea_aligned16(G.gamma) && sea_aligned16(G.beta) && sea_aligned16(G.Y32) && sea_aligned16(G.Yact),
                         "sea_exchange_tail[%d]: down: pointers must be 16-byte aligned", gi);
             // the fields NormEpilogue reads besides the pointers checked above
-            if (P.n_kv != 0) {
-                SEA_REQUIRE(!plain && P.n_kv >= 1 && P.n_kv <= 2 && P.rope && P.H >= 1 && P.hd >= 4 && P.hd % 4 == 0 && P.H * P.hd == P.D && P.T >= 1 && P.M % P.T == 0 && P.pos0 >= 0 &&
-                                P.cap >= P.pos0 + P.T && P.ldwkv % 8 == 0 && P.ldwkv >= P.D, "sea_exchange_tail[%d]: bad K/V stage (n_kv=%d H=%d hd=%d T=%d pos0=%d cap=%d)", gi,
-                            P.n_kv, P.H, P.hd, P.T, P.pos0, P.cap);
-                for (int c = 0; c < P.n_kv; ++c)
-                    SEA_REQUIRE(P.Wkv[c] && P.bkv[c] && P.Kout[c] && P.Vtout[c] && sea_aligned16(P.Wkv[c]) && sea_aligned16(P.bkv[c]) && sea_aligned16(P.Kout[c]) &&
-                                    sea_aligned16(P.Vtout[c]), "sea_exchange_tail[%d]: K/V stage %d: null / misaligned pointer", gi, c);
-            }
             SeaGemmNormGroup& Gd = L.p[gi].down;
             Gd.M = P.M; Gd.N = P.D; Gd.K = P.E; Gd.n_seg = 1; Gd.bias_scale = 1.0f;
             Gd.R = nullptr; Gd.C32 = nullptr; Gd.Cact = nullptr; Gd.ib_c = nullptr;
         }
-        SEA_REQUIRE(P.has_down || P.n_kv == 0, "sea_exchange_tail[%d]: the K/V stage needs the down-projection stage", gi);
         m_max = P.M > m_max ? P.M : m_max;
     }
     const dim3 grid((m_max + 15) / 16, n_groups);
     hipStream_t s = static_cast<hipStream_t>(stream);
-#define LAUNCH_XT(DD, EE)                                                                                                          \
-    do {                                                                                                                          \
-        if (plain) {                                                                                                              \
-            static int once = set_lds_gn(exchange_tail_kernel<DD, EE, true>, XTailCfg<DD, EE>::lds_bytes_plain());                 \
-            (void)once;                                                                                                           \
-            exchange_tail_kernel<DD, EE, true><<<grid, dim3(256), XTailCfg<DD, EE>::lds_bytes_plain(), s>>>(L);                     \
-        } else {                                                                                                                  \
-            static int once = set_lds_gn(exchange_tail_kernel<DD, EE, false>, XTailCfg<DD, EE>::lds_bytes(XTailCfg<DD, EE>::SMAX)); \
-            (void)once;                                                                                                           \
-            exchange_tail_kernel<DD, EE, false><<<grid, dim3(256), XTailCfg<DD, EE>::lds_bytes(S0), s>>>(L);                        \
-        }                                                                                                                         \
+#define LAUNCH_XT(DD, EE)                                                                                            \
+    do {                                                                                                            \
+        static int once = set_lds_gn(exchange_tail_kernel<DD, EE>, XTailCfg<DD, EE>::lds_bytes(XTailCfg<DD, EE>::SMAX)); \
+        (void)once;                                                                                                 \
+        exchange_tail_kernel<DD, EE><<<grid, dim3(256), XTailCfg<DD, EE>::lds_bytes(S0), s>>>(L);                     \
     } while (0)
     if (D == 128) LAUNCH_XT(128, 256); else LAUNCH_XT(64, 128);
 #undef LAUNCH_XT

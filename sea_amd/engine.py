@@ -302,24 +302,12 @@ class Plan:
                     self._c_patches.append((g, "ib_c"))
             self._cur.append(self._rec(L.sea_gemm_rownorm, [arr, len(chunk), 1e-5, self.code], name, arr))
 
-    def _xtail(self, att, Wp, Wup, bup, bias_scale, X, down, name: str, kv=None) -> None:
+    def _xtail(self, att, Wp, Wup, bup, bias_scale, X, down, name: str) -> None:
         """One field's exchange tail in one launch (sea_exchange_tail): projections + GELU, up-projection of their sum + residual, and — `down` —
         the down-projection + row norm of the updated rows."""
         P = (N.SeaExchangeTail * 1)()
-        ops.fill_exchange_tail(P[0], att, Wp, Wup, bup, bias_scale, X, None, down, kv=kv)
-        if kv is not None:
-            self._pos_structs.append(P[0])
+        ops.fill_exchange_tail(P[0], att, Wp, Wup, bup, bias_scale, X, None, down)
         self._cur.append(self._rec(N.lib().sea_exchange_tail, [P, 1, 1e-5, self.code], name, P))
-
-    def _xtail_plain(self, groups: List[dict], name: str) -> None:
-        """Linear + residual followed by the down-projection + row norm of the result, several fields per launch (sea_exchange_tail, plain form):
-        dicts with att [M, E], Wup [E, E], X (written), Xin_is_x (byte offset into the caller's x: the residual of the first layer), down."""
-        P = (N.SeaExchangeTail * len(groups))()
-        for p_, d in zip(P, groups):
-            ops.fill_exchange_tail(p_, [d["att"]], None, d["Wup"], None, 1.0, d["X"], None, d["down"], None, d.get("ldxin"))
-            if d.get("Xin_is_x") is not None:
-                self._x_patches.append((p_, "Xin", d["Xin_is_x"]))
-        self._cur.append(self._rec(N.lib().sea_exchange_tail, [P, len(groups), 1e-5, self.code], name, P))
 
     def _qkv(self, groups: List[dict], rope: torch.Tensor, hd: int, name: str) -> None:
         L = N.lib()
@@ -448,15 +436,10 @@ class Plan:
         # Linear + the row norm that follows it in one launch (sea_gemm_rownorm) where a tile can span the whole output row: cross_down + ln_cross,
         # the last layer's proj + the model's final norm.  SEA_FUSE_NORM=0 keeps the two-launch form (A/B measurements).
         fuse_norm = self._fuse_norm = type(self) is Plan and os.environ.get("SEA_FUSE_NORM", "1") != "0"
-        # ... and, opt-in (SEA_FUSE_TAIL=1), cross_up (+ sum over j, + residual) with the info-bottleneck add and AdaLN_2 that follow a field's
-        # exchange stage.  Measured at cfg2: 0.294 ms against 0.285 — ib_add and AdaLN_2 are ONE launch each for all fields, folding them into F
-        # per-field launches trades 2 launches (~13 us) for 3 x ~8 us of extra epilogue on the serial Gauss-Seidel chain.
-        fuse_tail = (fuse_norm and xmode == "sea" and has_ib and eng.ib_mode == 0 and os.environ.get("SEA_FUSE_TAIL", "0") == "1" and F > 1 and eng.model.add_info_after_cross and not lanes
-                     and E <= 256 and E % 16 == 0 and eng.model.ib_hidden in (4, 8))
         # the info-bottleneck add without a launch of its own: its MLP depends on the condition only, so it is EVALUATED by extra row passes of the silu
         # launch (into ibuf) and ADDED by the AdaLN_2 pass that follows it anyway (SeaNormGroup.addend).  Needs the silu launch (adaln, short launches)
         # and the add after the exchange; SEA_FOLD_IB=0 keeps sea_ib_add.
-        fold_ib = (type(self) is Plan and has_ib and eng.model.add_info_after_cross and self.adaln and not fuse_tail and not lanes and not split_cond
+        fold_ib = (type(self) is Plan and has_ib and eng.model.add_info_after_cross and self.adaln and not lanes and not split_cond
                    and self.L <= N.MAX_SILU_IB and E <= 2048 and os.environ.get("SEA_FOLD_IB", "1") != "0"
                    and not self._gen_a([(None, E), (None, D)]))
         ibufs = [self._buf(M, E, dtype=f32) for _ in range(self.L)] if fold_ib else None
@@ -471,7 +454,7 @@ class Plan:
 
         # the exchange tail of a field (projections + GELU, up-projection + residual, down-projection + norm) as ONE launch: bf16, the widths the
         # kernel instantiates, short launches (SEA_FUSE_XTAIL=0 keeps the three-launch form; SEA_XTAIL_MAX_ROWS bounds M)
-        fuse_xtail = (fuse_norm and not fuse_tail and not lanes and xmode == "sea" and F > 1 and os.environ.get("SEA_FUSE_XTAIL", "1") != "0"
+        fuse_xtail = (fuse_norm and not lanes and xmode == "sea" and F > 1 and os.environ.get("SEA_FUSE_XTAIL", "1") != "0"
                       and ops.exchange_tail_supported(dt, D, E, F - 1) and M <= int(os.environ.get("SEA_XTAIL_MAX_ROWS", "1000000000")))   # measured: cfg2 0.281 -> 0.254 ms, B = 2 0.414 -> 0.404, B = 4 0.679 -> 0.675, B = 8 a tie (1.191)
         rope_s, rope_c = eng.rope_self, eng.rope_cross
         FE = F * E
@@ -497,7 +480,6 @@ class Plan:
 
         xm = [self._buf(M, E) for _ in range(F)] if lanes else xa
         first = True  # the residual stream still lives in the caller's x [B,T,F,E]
-        fused_final = False
         for l in range(self.L):
             pre = f"blocks.{l}."
             last = l == self.L - 1
@@ -523,29 +505,15 @@ class Plan:
             self._qkv([dict(A=n_e[i], W=P.act(f"{pre}attn.self.{i}.q.weight", 3 * E), bias=P.f32_vec(f"{pre}attn.self.{i}.q.bias", 3 * E),
                             col0=0, Q=Qs[i], K=Ks[l][i], Vt=Vs[l][i]) for i in range(F)], rope_s, hd_s, "self.qkv_rope")
             self._attn([dict(Q=Qs[i], K=Ks[l][i], Vt=Vs[l][i], O=att_e[i]) for i in range(F)], hd_s, E, "self.attention")
-            # opt-in (SEA_FUSE_OPROJ=1): self-attention output projection + residual and the down-projection + ln_cross of the result in one launch for
-            # the F fields (sea_exchange_tail, plain form).  Measured: a tie at cfg2 (0.2574 against 0.2572 ms: 381 workgroups at one per CU are two
-            # rounds, and Wdown can only follow the 128 KiB of Wo into LDS), a loss at B = 8 (1.238 against 1.208 ms)
-            fuse_oproj = (fuse_xtail and F <= N.XTAIL_MAX_GROUPS and os.environ.get("SEA_FUSE_OPROJ", "0") == "1")
-            if fuse_oproj:
-                tg = []
-                for i in range(F):
-                    d_ = dict(att=att_e[i], Wup=P.act(f"{pre}attn.self.{i}.projection.weight"), X=xr[i],
-                              down=dict(W=P.act(f"{pre}cross_down.{i}.weight"), bias=P.f32_vec(f"{pre}cross_down.{i}.bias"), Yact=nd_old[i], **norm_params(f"{pre}ln_cross.{i}.", D)))
-                    if first:
-                        d_.update(Xin_is_x=i * E * 4, ldxin=FE)
-                    tg.append(d_)
-                self._xtail_plain(tg, "self.out_proj_down_norm")
-            else:
-                groups = []
-                for i in range(F):
-                    g = dict(A=att_e[i], W=P.act(f"{pre}attn.self.{i}.projection.weight"), C32=xr[i], Cact=xa[i])
-                    if first:
-                        g.update(R=xr[i], ldr=FE, R_is_x=i * E * 4)
-                    else:
-                        g.update(R=xr[i])
-                    groups.append(g)
-                self._gemm(groups, "self.out_proj")
+            groups = []
+            for i in range(F):
+                g = dict(A=att_e[i], W=P.act(f"{pre}attn.self.{i}.projection.weight"), C32=xr[i], Cact=xa[i])
+                if first:
+                    g.update(R=xr[i], ldr=FE, R_is_x=i * E * 4)
+                else:
+                    g.update(R=xr[i])
+                groups.append(g)
+            self._gemm(groups, "self.out_proj")
             first = False
             if not cond_joined:  # everything below reads modulations computed on lane 1
                 self._join(1)
@@ -603,33 +571,13 @@ class Plan:
                             for i in range(F)], "pool.up")
             # -- state exchange (Gauss-Seidel over i, models/temporal.py:187-192)
             if F > 1 and xmode == "sea":
-                if fuse_oproj:
-                    pass   # nd_old written by self.out_proj_down_norm
-                elif fuse_norm and D <= 256 and D % 16 == 0:
+                if fuse_norm and D <= 256 and D % 16 == 0:
                     self._gemm_norm([dict(A=xa[j], W=P.act(f"{pre}cross_down.{j}.weight"), bias=P.f32_vec(f"{pre}cross_down.{j}.bias"), Yact=nd_old[j],
                                           **norm_params(f"{pre}ln_cross.{j}.", D)) for j in range(F)], "cross.down_norm_old")
                 else:
                     self._gemm([dict(A=xa[j], W=P.act(f"{pre}cross_down.{j}.weight"), bias=P.f32_vec(f"{pre}cross_down.{j}.bias"), C32=dn[j])
                                 for j in range(F)], "cross.down_old")
                     self._norm([dict(X=dn[j], Yact=nd_old[j], **norm_params(f"{pre}ln_cross.{j}.", D)) for j in range(F)], D, "cross.norm_old")
-                # opt-in (SEA_FUSE_KV=1): the K/V projections of an updated field for the fields after it ride in that field's tail (stage 4 of
-                # sea_exchange_tail: at most two), and every projection that reads pre-exchange rows (all Q, the K/V of later fields) goes into ONE launch up
-                # front — two launches less on the serial chain.  Measured a tie at cfg2 (0.2565 against 0.2562 ms: a projection in the tail costs 3.3 us —
-                # its weights can only follow Wup / Wdown into LDS, and the V^T scatter is 2-byte stores — against the 8.9 us launch it replaces minus the
-                # larger up-front launch), 1.240 against 1.231 ms at B = 8, 0.1420 against 0.1433 ms per KV-cache step
-                fuse_kv = fuse_xtail and F - 1 <= 2 and F * (F - 1) * 3 // 2 <= N.MAX_GROUPS and os.environ.get("SEA_FUSE_KV", "0") == "1"
-                if fuse_kv:
-                    Qall = [[self._buf(B, H, T, hd_c) if j != i else None for j in range(F)] for i in range(F)]
-                    hoist = []
-                    for i in range(F):
-                        for j in range(F):
-                            if j == i:
-                                continue
-                            ca = f"{pre}cross_attn.{i}.{j}."
-                            hoist.append(dict(A=nd_old[i], W=P.act(ca + "q.weight"), bias=P.f32_vec(ca + "q.bias"), col0=0, Q=Qall[i][j]))
-                            if j > i:
-                                hoist.append(dict(A=nd_old[j], W=P.act(ca + "k.weight", 2 * D), bias=P.f32_vec(ca + "k.bias", 2 * D), col0=D, K=Kc[l][i][j], Vt=Vc[l][i][j]))
-                    self._qkv(hoist, rope_c, hd_c, "cross.qkv_rope_old")
                 for i in range(F):
                     others = [j for j in range(F) if j != i]
                     qkv_groups, probs, proj_groups = [], [], []
@@ -639,10 +587,9 @@ class Plan:
                         qkv_groups.append(dict(A=nd_old[i], W=P.act(ca + "q.weight"), bias=P.f32_vec(ca + "q.bias"), col0=0, Q=Qc[s]))
                         qkv_groups.append(dict(A=src, W=P.act(ca + "k.weight", 2 * D), bias=P.f32_vec(ca + "k.bias", 2 * D), col0=D,
                                                K=Kc[l][i][j], Vt=Vc[l][i][j]))
-                        probs.append(dict(Q=(Qall[i][j] if fuse_kv else Qc[s]), K=Kc[l][i][j], Vt=Vc[l][i][j], O=att_c[s]))
+                        probs.append(dict(Q=Qc[s], K=Kc[l][i][j], Vt=Vc[l][i][j], O=att_c[s]))
                         proj_groups.append(dict(A=att_c[s], W=P.act(ca + "projection.weight"), Cact=gp[s], act=1))
-                    if not fuse_kv:
-                        self._qkv(qkv_groups, rope_c, hd_c, f"cross{i}.qkv_rope")
+                    self._qkv(qkv_groups, rope_c, hd_c, f"cross{i}.qkv_rope")
                     self._attn(probs, hd_c, D, f"cross{i}.attention")
                     if fuse_xtail:
                         # everything between this field's cross-attention and the next field's: projections + GELU, up-projection of the sum + residual,
@@ -651,24 +598,14 @@ class Plan:
                         if i < F - 1:
                             down = dict(W=P.act(f"{pre}cross_down.{i}.weight"), bias=P.f32_vec(f"{pre}cross_down.{i}.bias"), Yact=nd_new[i],
                                         **norm_params(f"{pre}ln_cross.{i}.", D))
-                        kv = None
-                        if fuse_kv and i < F - 1:   # the fields after this one attend to its updated, normalised rows
-                            kv = dict(proj=[dict(W=P.act(f"{pre}cross_attn.{iq}.{i}.k.weight", 2 * D), bias=P.f32_vec(f"{pre}cross_attn.{iq}.{i}.k.bias", 2 * D),
-                                                 K=Kc[l][iq][i], Vt=Vc[l][iq][i]) for iq in range(i + 1, F)],
-                                      rope=rope_c, H=H, hd=hd_c, T=T, pos0=self.pos0, cap=cap)
                         self._xtail([att_c[s] for s in range(len(others))], [P.act(f"{pre}cross_attn.{i}.{j}.projection.weight") for j in others],
-                                    P.act(f"{pre}cross_up.{i}.weight"), P.f32_vec(f"{pre}cross_up.{i}.bias"), float(F - 1), xr[i], down, f"cross{i}.tail", kv=kv)
+                                    P.act(f"{pre}cross_up.{i}.weight"), P.f32_vec(f"{pre}cross_up.{i}.bias"), float(F - 1), xr[i], down, f"cross{i}.tail")
                         continue
                     self._gemm(proj_groups, f"cross{i}.proj_gelu")
                     up = dict(A=gp[0], W=P.act(f"{pre}cross_up.{i}.weight"), bias=P.f32_vec(f"{pre}cross_up.{i}.bias"),
                               bias_scale=float(F - 1), n_seg=F - 1, a_seg_stride=M * D, R=xr[i], C32=xr[i],
                               Cact=(xa[i] if i < F - 1 else None))
-                    if fuse_tail:
-                        # x_i is final for the exchange: its info-bottleneck add and AdaLN_2 ride in the epilogue of the up-projection (xa[i], the
-                        # copy cross_down reads, is written before the add)
-                        self._gemm_norm([dict(ib=self._ib_params(pre), Yact=n_e[i], **up, **norm_params(f"{pre}ln.exp.{i}.2.", E))], f"cross{i}.up_sum_ib_adaln2")
-                    else:
-                        self._gemm([up], f"cross{i}.up_sum")
+                    self._gemm([up], f"cross{i}.up_sum")
                     if lanes:
                         # x_i is final for the exchange: its info-bottleneck add, MLP, proj (and final norm) run on their own lane beside the
                         # remaining Gauss-Seidel stages; the last field stays on the main stream.  fc2 writes xm, not xa: the main stream
@@ -690,17 +627,14 @@ class Plan:
                 for i in range(F - 1):
                     self._join(2 + i)
                 continue
-            if eng.model.add_info_after_cross and has_ib and not fuse_tail and not fold_ib:
+            if eng.model.add_info_after_cross and has_ib and not fold_ib:
                 self._ib(pre, xr)
-            # opt-in (SEA_FUSE_FINAL=1): measured at cfg2 the fused proj + final norm is 14.5 us against 6.8 + 4.8 for the pair (N = 256 with 16-row
-            # tiles: every workgroup stages the whole 256 x 256 weight); at B = 8 (64-row tiles) the two forms tie
-            fused_final = last and fuse_norm and E <= 256 and E % 16 == 0 and os.environ.get("SEA_FUSE_FINAL", "0") == "1"
-            self._mlp_proj(pre, list(range(F)), xr, xa, n_e, hbuf, hg, mods, False, fuse_final=fused_final, skip_adaln2=fuse_tail, addend=(ibufs[l] if fold_ib else None))
-        if not lanes and not fused_final:
+            self._mlp_proj(pre, list(range(F)), xr, xa, n_e, hbuf, hg, mods, False, addend=(ibufs[l] if fold_ib else None))
+        if not lanes:
             # -- final per-field norm, written straight into out[B,T,F,E]
             self._norm([dict(X=xr[i], Y32=xr[i], ldy32=FE, Y_is_out=i * E * 4, **norm_params(f"ln.{i}.", E)) for i in range(F)], E, "final.norm")
 
-    def _mlp_proj(self, pre, fields, xr, xm, n_e, hbuf, hg, mods, final_norm, tag="", fuse_final=False, skip_adaln2=False, addend=None) -> None:
+    def _mlp_proj(self, pre, fields, xr, xm, n_e, hbuf, hg, mods, final_norm, tag="", addend=None) -> None:
         """x_i += W2 gelu(LN(W1 AdaLN_2(x_i))) ; x_i = proj_i(x_i) for the listed fields (models/temporal.py:143-146), optionally followed
         by the model's final per-field norm written straight into out (models/temporal.py:412-415)."""
         P, E, S, FE = self.eng.params, self.E, self.S, self.F * self.E
@@ -710,9 +644,8 @@ class Plan:
                 return dict(mod=mods[p_], gamma=P.f32_vec(p_ + "weight"), beta=P.f32_vec(p_ + "bias"))
             return dict(gamma=P.f32_vec(p_ + "weight"))
 
-        if not skip_adaln2:
-            extra = (lambda i: dict(addend=addend, Xout=xr[i])) if addend is not None else (lambda i: {})   # x_i += ib rides in this pass
-            self._norm([dict(X=xr[i], Yact=n_e[i], **extra(i), **norm_params(f"{pre}ln.exp.{i}.2.", E)) for i in fields], E, ("mlp.ib_adaln2" if addend is not None else "mlp.adaln2") + tag)
+        extra = (lambda i: dict(addend=addend, Xout=xr[i])) if addend is not None else (lambda i: {})   # x_i += ib rides in this pass
+        self._norm([dict(X=xr[i], Yact=n_e[i], **extra(i), **norm_params(f"{pre}ln.exp.{i}.2.", E)) for i in fields], E, ("mlp.ib_adaln2" if addend is not None else "mlp.adaln2") + tag)
         # Linear + nn.LayerNorm + GELU in one launch where the kernel is instantiated (bf16; SEA_FUSE_MLP1=0 keeps the two launches, =1 forces
         # the one launch).  Every workgroup of that kernel streams the whole of W1, so it needs enough 32-row tiles to pay: with the few rows
         # of a KV-cache step the two launches are faster (0.143 vs 0.163 ms per step at cfg2), hence the row threshold.
@@ -730,10 +663,6 @@ class Plan:
                         for i in fields], S, "mlp.ln_gelu" + tag, x_is_act=True, gelu=True)
         self._gemm([dict(A=hg[i], W=P.act(f"{pre}mlp.{i}.layers.3.weight"), bias=P.f32_vec(f"{pre}mlp.{i}.layers.3.bias"), R=xr[i], Cact=xm[i])
                     for i in fields], "mlp.fc2" + tag)
-        if fuse_final:  # last layer: proj_i and the model's final norm of field i in one launch, written straight into out[B,T,F,E]
-            self._gemm_norm([dict(A=xm[i], W=P.act(f"{pre}proj.{i}.weight"), bias=P.f32_vec(f"{pre}proj.{i}.bias"), Y32=xr[i], ldy32=FE, Y_is_out=i * E * 4,
-                                  **norm_params(f"ln.{i}.", E)) for i in fields], "proj_final_norm" + tag)
-            return
         self._gemm([dict(A=xm[i], W=P.act(f"{pre}proj.{i}.weight"), bias=P.f32_vec(f"{pre}proj.{i}.bias"), C32=xr[i]) for i in fields], "proj" + tag)
         if final_norm:
             self._norm([dict(X=xr[i], Y32=xr[i], ldy32=FE, Y_is_out=i * E * 4, **norm_params(f"ln.{i}.", E)) for i in fields], E, "final.norm" + tag)
@@ -803,7 +732,7 @@ class Plan:
         assert pos0 + self.T <= self.cap
         self.pos0 = pos0
         for s in self._pos_structs:
-            if isinstance(s, (N.SeaQkvCommon, N.SeaExchangeTail)):
+            if isinstance(s, N.SeaQkvCommon):
                 s.pos0 = pos0
             else:
                 s.q_pos0, s.Tk = pos0, pos0 + self.T
@@ -1069,11 +998,12 @@ class TemporalEngine:
         p.run()
         return out, p
 
-    def backward(self, plan, dout: torch.Tensor) -> None:
-        """Accumulate d loss / d parameters into self.grads from dout = d loss / d out ([B,T,F,E] fp32, contiguous)."""
+    def backward(self, plan, dout: torch.Tensor, on_bucket=None) -> None:
+        """Accumulate d loss / d parameters into self.grads from dout = d loss / d out ([B,T,F,E] fp32, contiguous).  `on_bucket(lo, hi)`: called
+        as soon as self.grads[lo:hi] is final (TrainPlan.grad_buckets), while later launches are still being issued."""
         assert dout.is_contiguous() and dout.dtype == torch.float32
         plan.bind_dout(dout.data_ptr())
-        plan.run_backward()
+        plan.run_backward(on_bucket)
         self.grads_dirty = True
 
     def mse_loss_and_grad(self, out: torch.Tensor, target: torch.Tensor, grad_scale: float = 1.0):
@@ -1087,16 +1017,18 @@ class TemporalEngine:
         return loss, dout
 
     def train_step(self, x: torch.Tensor, target: torch.Tensor, ib: torch.Tensor, optimizer, allreduce: bool = True) -> torch.Tensor:
-        """One fused train step (train/train_temporal.py:254-258): zero grads, forward, MSE + its gradient, backward, ONE gradient
-        all-reduce when torch.distributed is initialised (`allreduce=False`: a rank-local step, e.g. to time the step without the collective),
+        """One fused train step (train/train_temporal.py:254-258): zero grads, forward, MSE + its gradient, backward, the gradient
+        all-reduce when torch.distributed is initialised (the MLP slice as soon as it is final, the rest after the backward: sea_amd/parallel.py) (`allreduce=False`: a rank-local step, e.g. to time the step without the collective),
         AdamW.  Returns the local loss as a device scalar (no host sync)."""
-        from .parallel import allreduce_flat_gradients
+        from .parallel import OverlappedGradientReduce
 
         optimizer.zero_grad(set_to_none=False)
         out, plan = self.forward_train(x, ib)
         loss, dout = self.mse_loss_and_grad(out, target)
-        self.backward(plan, dout)
-        optimizer.grad_scale = allreduce_flat_gradients(self.grads, self.params.n_live) if allreduce else 1.0
+        red = OverlappedGradientReduce(self.grads, self.params.n_live) if allreduce else None
+        self.backward(plan, dout, red.on_bucket if (red is not None and red.active) else None)
+        optimizer.grad_scale = red.finish() if red is not None else 1.0
+        self.last_allreduce_calls = red.calls if red is not None else 0
         optimizer.step()
         return loss
 

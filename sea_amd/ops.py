@@ -183,30 +183,18 @@ def gemm_rownorm(groups: Sequence[Dict], eps: float, dtype: torch.dtype) -> None
     N.check(N.lib().sea_gemm_rownorm(arr, n, eps, N.dtype_code(dtype), N.stream_ptr()), "sea_gemm_rownorm")
 
 
-def fill_exchange_tail(P: N.SeaExchangeTail, att: Sequence[torch.Tensor], Wp: Optional[Sequence[torch.Tensor]], Wup, bup, bias_scale: float, X, Xact=None,
-                       down: Optional[Dict] = None, Xin=None, ldxin: Optional[int] = None, kv: Optional[Dict] = None) -> None:
-    """att: n_seg act [M, D] matrices, Wp: n_seg act [D, D]; Wup act [E, D]; X f32 [M, E] (in place); down: dict(W [D, E], bias, gamma, beta, mod, Yact, Y32).
-    Wp None = the plain form: x = Xin + att[0][M, E] . Wup[E, E]^T + bup (no first layer)."""
-    plain = Wp is None
+def fill_exchange_tail(P: N.SeaExchangeTail, att: Sequence[torch.Tensor], Wp: Sequence[torch.Tensor], Wup, bup, bias_scale: float, X, Xact=None,
+                       down: Optional[Dict] = None) -> None:
+    """att: n_seg act [M, D] matrices, Wp: n_seg act [D, D]; Wup act [E, D]; X f32 [M, E] (in place); down: dict(W [D, E], bias, gamma, beta, mod, Yact, Y32)."""
     for s, a in enumerate(att):
         P.att[s] = a.data_ptr()
-        if not plain:
-            P.Wp[s] = Wp[s].data_ptr()
-    P.n_seg, P.ldatt, P.ldwp, P.plain = len(att), att[0].stride(0), (0 if plain else Wp[0].stride(0)), int(plain)
-    P.Xin, P.ldxin = N.ptr(Xin), ((ldxin if ldxin is not None else Xin.stride(0)) if Xin is not None else (ldxin or 0))
+        P.Wp[s] = Wp[s].data_ptr()
+    P.n_seg, P.ldatt, P.ldwp = len(att), att[0].stride(0), Wp[0].stride(0)
     P.Wup, P.ldwup, P.bup, P.bias_scale = Wup.data_ptr(), Wup.stride(0), N.ptr(bup), bias_scale
     P.X, P.ldx = X.data_ptr(), X.stride(0)
     P.Xact, P.ldxact = N.ptr(Xact), (Xact.stride(0) if Xact is not None else 0)
-    P.M, P.E = X.shape[0], Wup.shape[0]
-    P.D = down["W"].shape[0] if plain and down is not None else (P.E // 2 if plain else Wup.shape[1])
+    P.M, P.E, P.D = X.shape[0], Wup.shape[0], Wup.shape[1]
     P.has_down = int(down is not None)
-    P.n_kv = 0
-    if kv is not None:   # dict(proj=[dict(W [2D, D], bias [2D], K, Vt), ...] (1 or 2), rope, H, hd, T, pos0, cap): K/V projections of the normalised rows
-        P.n_kv = len(kv["proj"])
-        for c, d in enumerate(kv["proj"]):
-            P.Wkv[c], P.bkv[c], P.Kout[c], P.Vtout[c] = d["W"].data_ptr(), d["bias"].data_ptr(), d["K"].data_ptr(), d["Vt"].data_ptr()
-        P.ldwkv = kv["proj"][0]["W"].stride(0)
-        P.rope, P.H, P.hd, P.T, P.pos0, P.cap = kv["rope"].data_ptr(), kv["H"], kv["hd"], kv["T"], kv["pos0"], kv["cap"]
     if down is not None:
         g = P.down
         g.W, g.ldw, g.bias = down["W"].data_ptr(), down["W"].stride(0), N.ptr(down.get("bias"))
@@ -223,21 +211,21 @@ def exchange_tail_supported(dtype: torch.dtype, D: int, E: int, n_seg: int) -> b
     return dtype == torch.bfloat16 and (D, E) in ((128, 256), (64, 128)) and 1 <= n_seg and n_seg * D <= 256
 
 
-def exchange_tail(att, Wp, Wup, bup, bias_scale, X, Xact=None, down=None, eps: float = 1e-5, dtype: torch.dtype = torch.bfloat16, Xin=None, kv=None) -> None:
+def exchange_tail(att, Wp, Wup, bup, bias_scale, X, Xact=None, down=None, eps: float = 1e-5, dtype: torch.dtype = torch.bfloat16) -> None:
     """One field's exchange tail in one launch: X += sum_s gelu(att_s Wp_s^T) Wup^T + bias_scale * bup; optionally the down-projection + row norm
-    of the updated rows (sea_exchange_tail).  Wp None: the plain form X = (Xin or X) + att[0] Wup^T + bup."""
-    for t in list(att) + list(Wp or []) + [Wup, X]:
+    of the updated rows (sea_exchange_tail)."""
+    for t in list(att) + list(Wp) + [Wup, X]:
         N.require_gpu(t, "exchange_tail operand")
     P = (N.SeaExchangeTail * 1)()
-    fill_exchange_tail(P[0], att, Wp, Wup, bup, bias_scale, X, Xact, down, Xin, kv=kv)
+    fill_exchange_tail(P[0], att, Wp, Wup, bup, bias_scale, X, Xact, down)
     N.check(N.lib().sea_exchange_tail(P, 1, eps, N.dtype_code(dtype), N.stream_ptr()), "sea_exchange_tail")
 
 
 def exchange_tail_grouped(groups: Sequence[Dict], eps: float = 1e-5, dtype: torch.dtype = torch.bfloat16) -> None:
-    """Several problems of one shape and mode in one launch (grid row per group): dicts with the arguments of exchange_tail."""
+    """Several problems of one shape in one launch (grid row per group): dicts with the arguments of exchange_tail."""
     P = (N.SeaExchangeTail * len(groups))()
     for p_, d in zip(P, groups):
-        fill_exchange_tail(p_, d["att"], d.get("Wp"), d["Wup"], d.get("bup"), d.get("bias_scale", 1.0), d["X"], d.get("Xact"), d.get("down"), d.get("Xin"))
+        fill_exchange_tail(p_, d["att"], d["Wp"], d["Wup"], d.get("bup"), d.get("bias_scale", 1.0), d["X"], d.get("Xact"), d.get("down"))
     N.check(N.lib().sea_exchange_tail(P, len(groups), eps, N.dtype_code(dtype), N.stream_ptr()), "sea_exchange_tail")
 
 

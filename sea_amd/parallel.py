@@ -1,9 +1,11 @@
-"""Data parallelism for the temporal train step: replicated model, the trajectory batch split across ranks, ONE all-reduce per step
-over the live prefix of the flat gradient buffer (RCCL through torch.distributed backend "nccl"; gloo on CPU for tests), the 1/world
-mean folded into the AdamW kernel's grad_scale.  The reference has no distributed code: this is new functionality."""
+"""Data parallelism for the temporal train step: replicated model, the trajectory batch split across ranks, the live prefix of the flat
+gradient buffer SUM-all-reduced once per step (RCCL through torch.distributed backend "nccl"; gloo for tests) — as ONE collective
+(allreduce_flat_gradients), or, from the fused train step, with the slices that are final early in the backward reduced under the rest of it
+(OverlappedGradientReduce) — and the 1/world mean folded into the AdamW kernel's grad_scale.  The reference has no distributed code: this is new functionality."""
 from __future__ import annotations
 
-from typing import Optional
+import os
+from typing import List, Optional, Tuple
 
 import torch
 import torch.distributed as dist
@@ -28,6 +30,39 @@ def allreduce_flat_gradients(flat_grads: torch.Tensor, n_live: int, group: Optio
         return 1.0
     dist.all_reduce(flat_grads[:n_live], op=dist.ReduceOp.SUM, group=group)
     return 1.0 / world
+
+
+class OverlappedGradientReduce:
+    """The same SUM all-reduce of grads[:n_live], started early where it can be: `on_bucket(lo, hi)` (called by the backward replay as soon as
+    grads[lo:hi] is final) enqueues an asynchronous all-reduce of that slice — RCCL runs it on its own stream behind everything issued so far, beside
+    the backward launches that follow — and `finish()` reduces what no bucket covered, waits for the early collectives and returns grad_scale.
+    Every element is reduced exactly once by every rank in the same order: ranks stay bit-identical.  SEA_DP_OVERLAP=0 keeps the single collective."""
+
+    def __init__(self, flat_grads: torch.Tensor, n_live: int, group: Optional[dist.ProcessGroup] = None):
+        self.grads, self.n_live, self.group = flat_grads, n_live, group
+        self.world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+        self.active = self.world > 1 and os.environ.get("SEA_DP_OVERLAP", "1") != "0"
+        self.works: List = []
+        self.done: List[Tuple[int, int]] = []
+        self.calls = 0
+
+    def on_bucket(self, lo: int, hi: int) -> None:
+        self.works.append(dist.all_reduce(self.grads[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        self.done.append((lo, hi))
+        self.calls += 1
+
+    def finish(self) -> float:
+        if self.world == 1:
+            return 1.0
+        pos = 0
+        for lo, hi in sorted(self.done) + [(self.n_live, self.n_live)]:
+            if lo > pos:
+                dist.all_reduce(self.grads[pos:lo], op=dist.ReduceOp.SUM, group=self.group)
+                self.calls += 1
+            pos = max(pos, hi)
+        for w in self.works:
+            w.wait()
+        return 1.0 / self.world
 
 
 def broadcast_parameters(flat_params: torch.Tensor, src: int = 0, group: Optional[dist.ProcessGroup] = None) -> None:

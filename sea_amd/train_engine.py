@@ -23,6 +23,7 @@ class TrainPlan(Plan):
         self.drop_thr = drop_thr
         self._next_stream = 0
         self.bwd: List[_Rec] = []
+        self._buckets = None
         self._dout_patches: List[Tuple[object, str, int]] = []
         eng.params.enable_transposed_shadow()
         eng.ensure_grads()
@@ -515,9 +516,36 @@ class TrainPlan(Plan):
         for tgt, field, off in self._dout_patches:
             setattr(tgt, field, dout_ptr + off)
 
-    def run_backward(self) -> None:
+    def grad_buckets(self):
+        """[(number of backward records after which the slice is final, flat start, flat end)] in backward order: the field MLPs + proj of a layer
+        (fc1 / LayerNorm / fc2 / proj: 45 % of the parameters at cfg3) are contiguous in the flat gradient buffer and complete right after that
+        layer's `bwd.fc1.wgrad`, long before the exchange / attention / condition-MLP gradients: a data-parallel step can start reducing them while the
+        rest of the backward runs (sea_amd/parallel.py)."""
+        if self._buckets is None:
+            P = self.eng.params
+            out = []
+            idxs = [k for k, r in enumerate(self.bwd) if r.name == "bwd.fc1.wgrad"]
+            for k, idx in enumerate(idxs):
+                l = self.L - 1 - k
+                names = [n for n in P.offsets if n.startswith(f"blocks.{l}.mlp.") or n.startswith(f"blocks.{l}.proj.")]
+                if not names:
+                    continue
+                size = lambda n: int(torch.Size(P.offsets[n][1]).numel())
+                lo = min(P.offsets[n][0] for n in names)
+                hi = max(P.offsets[n][0] + size(n) for n in names)
+                inside = {n for n, (o, _) in P.offsets.items() if lo <= o < hi}
+                if inside == set(names) and hi <= P.n_live:   # contiguous and live: otherwise this layer goes with the rest
+                    out.append((idx + 1, lo, hi))
+            self._buckets = out
+        return self._buckets
+
+    def run_backward(self, on_bucket=None) -> None:
+        """Replay the backward launch list; `on_bucket(lo, hi)` is called as soon as grads[lo:hi] is final (grad_buckets)."""
         stream = N.stream_ptr()
-        for r in self.bwd:
+        marks = {n: (lo, hi) for n, lo, hi in self.grad_buckets()} if on_bucket is not None else {}
+        for k, r in enumerate(self.bwd):
             rc = r.fn(*r.args, stream)
             if rc != 0:
                 N.check(rc, r.name)
+            if k + 1 in marks:
+                on_bucket(*marks[k + 1])

@@ -438,72 +438,6 @@ def test_exchange_tail_matches_three_launch_form(D, E, S, M, has_down):
         assert rel(nd.float(), nd2.float()) < 2e-2
 
 
-@pytest.mark.parametrize("D,E,H,n_kv", [(128, 256, 8, 2), (128, 256, 8, 1), (64, 128, 4, 2)])
-def test_exchange_tail_kv_stage(D, E, H, n_kv):
-    """The fourth layer of the tail: K / V projections of the normalised rows for later fields, written with rotary embedding in the attention layouts —
-    against sea_qkv_rope_grouped fed with the tail's own normalised rows (same arithmetic on the same bf16 operand), at a position offset and with two
-    trajectories (row -> (b, t) mapping)."""
-    from sea_amd import ops
-
-    dt, B, T, pos0 = torch.bfloat16, 2, 100, 3
-    M, S, hd = B * T, 2, D // H
-    cap = ((pos0 + T + 7) // 8) * 8
-    att = [rnd(M, D, dtype=dt, seed=1200 + s) for s in range(S)]
-    Wp = [rnd(D, D, dtype=dt, scale=0.15, seed=1210 + s) for s in range(S)]
-    Wup, bup = rnd(E, D, dtype=dt, scale=0.1, seed=1220), 0.2 * rnd(E, seed=1221)
-    Wd, bd = rnd(D, E, dtype=dt, scale=0.1, seed=1222), 0.2 * rnd(D, seed=1223)
-    x = rnd(M, E, seed=1224)
-    mod = rnd(M, 2 * D, dtype=dt, scale=0.5, seed=1225)
-    gamma, beta = 1 + 0.1 * rnd(D, seed=1226), 0.1 * rnd(D, seed=1227)
-    nd = torch.empty(M, D, device=dev(), dtype=dt)
-    ang = torch.outer(torch.arange(cap, dtype=torch.float32), 1.0 / (10000 ** (torch.arange(0, hd, 2).float() / hd)))
-    rope = torch.stack((torch.cos(ang), torch.sin(ang)), dim=-1).to(dev()).contiguous()
-    proj, refs = [], []
-    for c in range(n_kv):
-        Wkv, bkv = rnd(2 * D, D, dtype=dt, scale=0.2, seed=1230 + c), 0.3 * rnd(2 * D, seed=1240 + c)
-        K = torch.zeros(B, H, cap, hd, device=dev(), dtype=dt)
-        Vt = torch.zeros(B, H, hd, cap, device=dev(), dtype=dt)
-        proj.append(dict(W=Wkv, bias=bkv, K=K, Vt=Vt))
-    ops.exchange_tail(att, Wp, Wup, bup, float(S), x, down=dict(W=Wd, bias=bd, gamma=gamma, beta=beta, mod=mod, Yact=nd),
-                      kv=dict(proj=proj, rope=rope, H=H, hd=hd, T=T, pos0=pos0, cap=cap))
-    for c, d in enumerate(proj):
-        K2 = torch.zeros_like(d["K"])
-        Vt2 = torch.zeros_like(d["Vt"])
-        ops.qkv_rope_grouped([dict(A=nd, W=d["W"], bias=d["bias"], col0=D, K=K2, Vt=Vt2)], rope, H, hd, T, pos0, cap, hd ** -0.5, dt)
-        assert rel(d["K"].float(), K2.float()) < 1e-6 and rel(d["Vt"].float(), Vt2.float()) < 1e-6
-        assert float(d["K"][:, :, :pos0].abs().max()) == 0 and float(d["Vt"][:, :, :, pos0 + T:].abs().max()) == 0
-
-
-@pytest.mark.parametrize("D,E", [(128, 256), (64, 128)])
-def test_exchange_tail_plain_grouped(D, E):
-    """The plain form, three fields in one launch: x = Xin + att . Wo^T (attention output projection + residual, the residual read from a strided
-    [M, F, E] tensor as in the first layer), then cross_down + AdaLN of the result — against the formula and the two launches it replaces."""
-    from sea_amd import ops
-
-    dt, M, F = torch.bfloat16, 333, 3
-    xin = rnd(M, F, E, seed=980)
-    groups, refs, keep = [], [], []
-    for i in range(F):
-        att, Wo = rnd(M, E, dtype=dt, seed=981 + i), rnd(E, E, dtype=dt, scale=0.06, seed=984 + i)
-        Wd, bd = rnd(D, E, dtype=dt, scale=0.1, seed=987 + i), 0.2 * rnd(D, seed=990 + i)
-        mod = rnd(M, 2 * D, dtype=dt, scale=0.5, seed=993 + i)
-        gamma, beta = 1 + 0.1 * rnd(D, seed=996 + i), 0.1 * rnd(D, seed=999 + i)
-        x, nd = torch.full((M, E), float("nan"), device=dev()), torch.empty(M, D, device=dev(), dtype=dt)
-        groups.append(dict(att=[att], Wup=Wo, X=x, Xin=xin[:, i], down=dict(W=Wd, bias=bd, gamma=gamma, beta=beta, mod=mod, Yact=nd)))
-        xn = xin[:, i] + att.float() @ Wo.float().t()
-        v = xn.to(dt).float() @ Wd.float().t() + bd
-        refs.append((xn, torch.nn.functional.layer_norm(v, (D,), None, None, 1e-5) * (gamma + 1 + mod[:, :D].float()) + (beta + mod[:, D:].float())))
-        keep.append((x, nd, att, Wo, Wd, bd, mod, gamma, beta))
-    ops.exchange_tail_grouped(groups)
-    for (xn, ref), (x, nd, att, Wo, Wd, bd, mod, gamma, beta), i in zip(refs, keep, range(F)):
-        assert rel(x, xn) < 2e-5
-        assert rel(nd.float(), ref) < 6e-3
-        x2, xa2, nd2 = torch.empty(M, E, device=dev()), torch.empty(M, E, device=dev(), dtype=dt), torch.empty(M, D, device=dev(), dtype=dt)
-        ops.gemm_grouped([dict(A=att, W=Wo, R=xin[:, i], C32=x2, Cact=xa2)], dt)
-        ops.gemm_rownorm([dict(A=xa2, W=Wd, bias=bd, mod=mod, gamma=gamma, beta=beta, Yact=nd2)], 1e-5, dt)
-        assert rel(x, x2) < 1e-6 and rel(nd.float(), nd2.float()) < 4e-3
-
-
 def test_exchange_tail_unsupported_shapes_are_refused():
     from sea_amd import ops
 

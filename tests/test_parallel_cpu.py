@@ -46,6 +46,17 @@ def _worker(rank, world, port, ret):
         assert torch.all(flat[n_live:] == 123.0)
         w[:n_live] -= 0.1 * flat[:n_live] * scale     # every rank applies the same update
         assert parameters_in_sync(w)
+        # the same reduction in slices: two buckets announced early (out of order, as a backward would), the three remainders by finish()
+        from sea_amd.parallel import OverlappedGradientReduce
+
+        flat2 = local_grad.clone()
+        flat2[n_live:] = 123.0
+        red = OverlappedGradientReduce(flat2, n_live)
+        assert red.active
+        red.on_bucket(400, 650)
+        red.on_bucket(100, 180)
+        assert red.finish() == 1.0 / world and red.calls == 5
+        assert torch.equal(flat2, flat)              # every element reduced exactly once, the dead tail untouched
         ret[rank] = "ok"
     except Exception as e:  # pragma: no cover
         ret[rank] = repr(e)

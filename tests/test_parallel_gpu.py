@@ -1,7 +1,8 @@
 """Data-parallel train step on the device (SURVEY.md §8(e) "Verification"): engine.train_step at world size N against the single-process step on
 the global batch — gradients after the all-reduce equal the global-batch gradients (<= 1e-6, fp32), parameters stay bit-identical across ranks.
 The ranks of this test share the box's one GPU and reduce through gloo (two RCCL ranks cannot share a device); on a multi-GPU node the same body
-runs one rank per GPU over RCCL when SEA_TEST_DP_BACKEND=nccl."""
+runs one rank per GPU over RCCL when SEA_TEST_DP_BACKEND=nccl.  The step reduces the gradient buffer in slices (sea_amd/parallel.py:
+OverlappedGradientReduce): the equality with the single-process gradients covers every slice boundary."""
 import os
 import socket
 
@@ -53,6 +54,8 @@ def _run_steps(x, tgt, ib, world, rank):
         if step == 0:
             grads1 = (eng.grads[:eng.params.n_live] * opt.grad_scale).cpu()   # the mean gradient AdamW consumed
         assert parameters_in_sync(eng.params.flat32)
+        if world > 1:   # the MLP + proj slice went early (under the rest of the backward), the two remainders after it: three collectives, every element once
+            assert eng.last_allreduce_calls == 3, eng.last_allreduce_calls
     return grads1, eng.params.flat32[:eng.params.n_live].cpu()
 
 
