@@ -441,6 +441,12 @@ static int dispatch_bwd(const SeaAttnBwdParams& P, hipStream_t s) {
         case 32: launch_bwd<T, 32>(P, s); break;
         case 64: launch_bwd<T, 64>(P, s); break;
         case 128: launch_bwd<T, 128>(P, s); break;
+        case 256:   // the shipped multiphase dims (embed_dim 2048 / 8 heads): bf16 only — four [64, 256] f32 tiles do not fit the 160 KB of LDS
+            if constexpr (sizeof(T) == 2) {
+                launch_bwd<T, 256>(P, s);
+                break;
+            }
+            return -1;
         default: return -1;
     }
     return 0;
@@ -453,7 +459,8 @@ extern "C" int sea_attention_bwd(const SeaAttnBwdParams* params, int dtype, void
     SEA_REQUIRE(P.n_problems >= 1 && P.n_problems <= SEA_MAX_ATTN_PROBLEMS, "sea_attention_bwd: n_problems=%d", P.n_problems);
     SEA_REQUIRE(P.B >= 1 && P.H >= 1 && P.Tq >= 1 && P.Tk >= 1 && P.cap >= P.Tk && P.q_pos0 >= 0 && P.src_len >= 0 && P.rope,
                 "sea_attention_bwd: bad sizes B=%d H=%d Tq=%d Tk=%d cap=%d", P.B, P.H, P.Tq, P.Tk, P.cap);
-    SEA_REQUIRE(P.hd == 8 || P.hd == 16 || P.hd == 32 || P.hd == 64 || P.hd == 128, "sea_attention_bwd: unsupported head dim %d", P.hd);
+    SEA_REQUIRE(P.hd == 8 || P.hd == 16 || P.hd == 32 || P.hd == 64 || P.hd == 128 || (P.hd == 256 && dtype == SEA_BF16),
+                "sea_attention_bwd: unsupported head dim %d (8 .. 128; 256 with bf16)", P.hd);
     const int epc = dtype == SEA_BF16 ? 8 : 4;
     SEA_REQUIRE(P.ldo % epc == 0 && P.lddo % epc == 0 && P.lddq % 4 == 0 && P.lddk % 4 == 0 && P.lddv % 4 == 0, "sea_attention_bwd: bad strides");
     SEA_REQUIRE((long)P.B * P.H <= 65535, "sea_attention_bwd: B*H too large for grid.y");

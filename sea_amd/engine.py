@@ -892,7 +892,7 @@ class TemporalEngine:
             ok = hd in (8, 16, 32, 64, 128) or (hd == 256 and act_dtype == torch.bfloat16)
             if not ok or hd * H != (E if what == "self" else D):
                 raise NotImplementedError(f"sea_amd: unsupported {what}-attention head dim {hd} (supported: 8, 16, 32, 64, 128; 256 with "
-                                          "compute dtype bf16, forward/rollout only)")
+                                          "compute dtype bf16)")
         if m.src_len < 0:
             raise NotImplementedError("sea_amd: src_len must be >= 0")
         if self.ib_mode == 0 and m.ib_hidden > 64:
