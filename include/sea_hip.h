@@ -591,9 +591,13 @@ typedef struct {
     float* att_e; float* xr; float* xq; float* x3; float* hbuf; float* nd_old; float* oc; float* qc; float* ml;
     unsigned long long* handoff;
     int32_t* err;
+    int64_t handoff_words;     /* size of `handoff` in 8-byte words: >= B F D; with >= sea_kv_arena_words() words, B = 1 and L = 1 the whole rollout runs as ONE
+                                * persistent launch (every workgroup keeps the weights of its role in registers across steps) */
 } SeaKvGlobal;
 
 int sea_kv_rollout(const SeaKvGlobal* G, const SeaKvLayer* layers, int pos0, int n_steps, uint32_t tag0, int dtype, void* stream);
+/* Words of `handoff` the persistent form of sea_kv_rollout needs for these sizes (host only). */
+int64_t sea_kv_arena_words(const SeaKvGlobal* G);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Self-test of the MFMA fragment maps this library relies on (16x16x32 bf16 and 16x16x4 f32, A/B/C lane maps):

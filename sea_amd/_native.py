@@ -173,7 +173,7 @@ class SeaKvGlobal(C.Structure):
                 ("exchange", _i32), ("ib_after_cross", _i32), ("final_ln", SeaKvNorm * KV_MAX_FIELDS),
                 ("rope_self", _vp), ("rope_cross", _vp), ("traj", _vp), ("xl", _vp * 2),
                 ("att_e", _vp), ("xr", _vp), ("xq", _vp), ("x3", _vp), ("hbuf", _vp), ("nd_old", _vp), ("oc", _vp), ("qc", _vp), ("ml", _vp),
-                ("handoff", _vp), ("err", _vp)]
+                ("handoff", _vp), ("err", _vp), ("handoff_words", _i64)]
 
 
 MAX_WGRAD_GROUPS = 16
@@ -237,6 +237,8 @@ def lib() -> C.CDLL:
     L.sea_run_list.restype = C.c_int
     L.sea_kv_rollout.argtypes = [C.POINTER(SeaKvGlobal), C.POINTER(SeaKvLayer), C.c_int, C.c_int, C.c_uint32, C.c_int, _vp]
     L.sea_kv_rollout.restype = C.c_int
+    L.sea_kv_arena_words.argtypes = [C.POINTER(SeaKvGlobal)]
+    L.sea_kv_arena_words.restype = C.c_int64
     for name in ("sea_attention_bwd", "sea_wgrad_grouped", "sea_transpose_weights", "sea_rownorm_bwd", "sea_silu_outer_bwd", "sea_ib_bwd"):
         getattr(L, name).restype = C.c_int
     L.sea_mse_fwd_bwd.argtypes = [_vp, _vp, _vp, _vp, _vp, C.c_int, _i64, C.c_float, _vp]
@@ -262,7 +264,7 @@ EXPORTED_SYMBOLS = (
     "sea_attention_fwd", "sea_rownorm", "sea_silu_outer", "sea_ib_add", "sea_convert_f32_to_act", "sea_selftest_mfma",
     "sea_mse_fwd_bwd", "sea_relative_mse", "sea_adamw_flat",
     "sea_wgrad_grouped", "sea_transpose_weights", "sea_rownorm_bwd", "sea_silu_outer_bwd", "sea_ib_bwd",
-    "sea_attention_bwd", "sea_dropout_mask", "sea_run_list", "sea_unpatchify", "sea_gemm_rownorm", "sea_exchange_tail", "sea_patchify", "sea_silu_outer_ib", "sea_mlp_fc1_ln_gelu", "sea_kv_rollout",
+    "sea_attention_bwd", "sea_dropout_mask", "sea_run_list", "sea_unpatchify", "sea_gemm_rownorm", "sea_exchange_tail", "sea_patchify", "sea_silu_outer_ib", "sea_mlp_fc1_ln_gelu", "sea_kv_rollout", "sea_kv_arena_words",
 )
 
 

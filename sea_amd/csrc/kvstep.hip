@@ -318,6 +318,34 @@ __device__ __forceinline__ void to_operand(const float* xs, T* xT, int n, int ti
     for (int i = tid; i < n; i += nthreads) xT[i] = from_f32<T>(xs[i]);
 }
 
+// 16-byte load of cache rows.  COH (the persistent kernel, where a row written by another workgroup in an earlier step must be seen): a buffer load
+// with sc1 — past this CU's L1, served coherently — matching sc1 (write-through) stores on the producer side; otherwise a plain load.
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+template <bool COH>
+__device__ __forceinline__ uint4 ld16(const void* base, int64_t byte_off) {
+    if constexpr (COH) {
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0x7fffffff, 0x00020000);
+        const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)byte_off, 0, 16);
+        return make_uint4(v.x, v.y, v.z, v.w);
+    } else {
+        return *reinterpret_cast<const uint4*>(static_cast<const char*>(base) + byte_off);
+    }
+}
+// two adjacent cache elements as ONE store (COH: sc1, 4 or 8 bytes: the hand-off forms validated for this part are >= 4-byte stores)
+template <bool COH>
+__device__ __forceinline__ void store_pair(__bf16* p, float a, float b) {
+    const uint32_t lo = (uint32_t)__builtin_bit_cast(unsigned short, (__bf16)a), hi = (uint32_t)__builtin_bit_cast(unsigned short, (__bf16)b);
+    const uint32_t pk = lo | (hi << 16);
+    if constexpr (COH) __hip_atomic_store(reinterpret_cast<uint32_t*>(p), pk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else *reinterpret_cast<uint32_t*>(p) = pk;
+}
+template <bool COH>
+__device__ __forceinline__ void store_pair(float* p, float a, float b) {
+    const unsigned long long pk = (unsigned long long)__builtin_bit_cast(uint32_t, a) | ((unsigned long long)__builtin_bit_cast(uint32_t, b) << 32);
+    if constexpr (COH) __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), pk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else *reinterpret_cast<unsigned long long*>(p) = pk;
+}
+
 struct IdentityRow {
     __device__ __forceinline__ int operator()(int r) const { return r; }
 };
@@ -336,7 +364,7 @@ struct KRegs {
     static constexpr int KPT = 4, VPT = 4 * CPK;
     uint4 k[KPT][CPK];
 };
-template <bool PRE, typename T, int HD>
+template <bool PRE, bool COH, typename T, int HD>
 __device__ __forceinline__ void k_prefetch(KRegs<T, HD>& R, const T* __restrict__ Kg, int nk_cached, int tid, int nthreads) {
     if constexpr (PRE) {
         constexpr int CPK = KRegs<T, HD>::CPK;
@@ -344,14 +372,26 @@ __device__ __forceinline__ void k_prefetch(KRegs<T, HD>& R, const T* __restrict_
         for (int j = 0; j < KRegs<T, HD>::KPT; ++j) {
             const int key = j * nthreads + tid;
             if (key < nk_cached) {
-                const uint4* kr = reinterpret_cast<const uint4*>(Kg + (int64_t)key * HD);
 #pragma unroll
-                for (int c = 0; c < CPK; ++c) R.k[j][c] = kr[c];
+                for (int c = 0; c < CPK; ++c) R.k[j][c] = ld16<COH>(Kg, ((int64_t)key * HD) * (int64_t)sizeof(T) + c * 16);
             }
         }
     }
 }
-template <bool PRE, typename T, int HD>
+// the row of ONE key (the last cached one) into its owner's register slot: for caches whose newest row is written by another workgroup late in the
+// previous step, everything but that row is requested early and this one once the step's hand-off says it is there
+template <bool COH, typename T, int HD>
+__device__ __forceinline__ void k_prefetch_one(KRegs<T, HD>& R, const T* __restrict__ Kg, int key, int tid, int nthreads) {
+    constexpr int CPK = KRegs<T, HD>::CPK;
+#pragma unroll
+    for (int j = 0; j < KRegs<T, HD>::KPT; ++j) {
+        if (key >= 0 && j * nthreads + tid == key) {
+#pragma unroll
+            for (int c = 0; c < CPK; ++c) R.k[j][c] = ld16<COH>(Kg, ((int64_t)key * HD) * (int64_t)sizeof(T) + c * 16);
+        }
+    }
+}
+template <bool PRE, bool COH, typename T, int HD>
 __device__ __forceinline__ void wg_attend(const KRegs<T, HD>& R, const T* __restrict__ Kg, const T* __restrict__ Vg, int nk_cached, bool has_cur, const float* q_l, const float* kcur,
                                           const float* vcur, float* prob, float* part /* [nw][HD] */, float* oacc, float* red, float& m_out, float& l_out, int tid, int nthreads) {
     constexpr int EPC = ActTraits<T>::EPC;
@@ -418,7 +458,7 @@ __device__ __forceinline__ void wg_attend(const KRegs<T, HD>& R, const T* __rest
 #pragma unroll
         for (int j = 0; j < VPT; ++j) {
             const int key = j * nslot + slot;
-            if (key < nk_cached) vr[j] = *reinterpret_cast<const uint4*>(Vg + (int64_t)key * HD + ch * EPC);
+            if (key < nk_cached) vr[j] = ld16<COH>(Vg, ((int64_t)key * HD + ch * EPC) * (int64_t)sizeof(T));
         }
     }
     const float m = wg_max(mx, red, tid, nthreads);   // barriers inside: prob is complete
@@ -512,7 +552,7 @@ __device__ __forceinline__ void head_issue(HeadRegs& R, const float* bq, const f
         R.b0 = bv[tid - 64];
     }
 }
-template <typename T, int HD>
+template <bool COH, typename T, int HD>
 __device__ __forceinline__ void head_finish(const HeadRegs& R, float* qkv, bool with_kv, T* Krow, T* Vrow, int tid) {
     constexpr int HD2 = HD / 2;
     const float scale = 1.0f / sqrtf((float)HD);
@@ -529,15 +569,17 @@ __device__ __forceinline__ void head_finish(const HeadRegs& R, float* qkv, bool 
         oo = round_to(oo, T());
         qkv[HD + 2 * t] = oe;
         qkv[HD + 2 * t + 1] = oo;
-        Krow[2 * t] = from_f32<T>(oe);
-        Krow[2 * t + 1] = from_f32<T>(oo);
+        store_pair<COH>(Krow + 2 * t, oe, oo);
     } else if (with_kv && tid >= 64 && tid < 64 + HD) {
         const int t = tid - 64;
         const float v = round_to(qkv[2 * HD + t] + R.b0, T());
         qkv[2 * HD + t] = v;
-        Vrow[t] = from_f32<T>(v);
+        if constexpr (!COH) Vrow[t] = from_f32<T>(v);
     }
     __syncthreads();
+    if constexpr (COH) {   // the value row as pairs (>= 4-byte stores); every element of it was rounded above
+        if (with_kv && tid < HD2) store_pair<true>(Vrow + 2 * tid, qkv[2 * HD + 2 * tid], qkv[2 * HD + 2 * tid + 1]);
+    }
 }
 
 struct KvArgs {
@@ -593,14 +635,14 @@ __global__ __launch_bounds__(512) void kv_self_kernel(const KvArgs A) {
     HeadRegs hr;
     head_issue<HD>(hr, Fd.bqkv + h * HD, Fd.bqkv + E + h * HD, Fd.bqkv + 2 * E + h * HD, A.G.rope_self, pos, true, tid);
     KRegs<T, HD> kr;
-    k_prefetch<PRE, T, HD>(kr, Kc, pos, tid, nth);
+    k_prefetch<PRE, false, T, HD>(kr, Kc, pos, tid, nth);
     __syncthreads();
     wg_norm_r<1, T>(xs, ns, PRE ? nsT : nullptr, E, nr, false, red, tid, nth);
     pre_finish<KE, T, 1>(rw, static_cast<const T*>(Fd.Wqkv), E, E, 3 * HD, ns, nsT, qkv, rowmap, tid, nth);
     __syncthreads();
-    head_finish<T, HD>(hr, qkv, true, Kc + (int64_t)pos * HD, Vc + (int64_t)pos * HD, tid);
+    head_finish<false, T, HD>(hr, qkv, true, Kc + (int64_t)pos * HD, Vc + (int64_t)pos * HD, tid);
     float m, l;
-    wg_attend<PRE, T, HD>(kr, Kc, Vc, pos, true, qkv, qkv + HD, qkv + 2 * HD, prob, part, oacc, red, m, l, tid, nth);
+    wg_attend<PRE, false, T, HD>(kr, Kc, Vc, pos, true, qkv, qkv + HD, qkv + 2 * HD, prob, part, oacc, red, m, l, tid, nth);
     if (tid < HD) A.G.att_e[((int64_t)b * F + i) * E + h * HD + tid] = oacc[tid] / l;
 }
 
@@ -704,14 +746,14 @@ __global__ __launch_bounds__(512) void kv_cross_kernel(const KvArgs A) {
     HeadRegs hr;
     head_issue<HD>(hr, P.bq + h * HD, P.bkv + h * HD, P.bkv + D + h * HD, A.G.rope_cross, pos, old_src, tid);
     KRegs<T, HD> kr;
-    k_prefetch<PRE, T, HD>(kr, Kc, pos, tid, nth);
+    k_prefetch<PRE, false, T, HD>(kr, Kc, pos, tid, nth);
     __syncthreads();
     pre_finish<KD, T, 1>(rq, static_cast<const T*>(P.Wq), D, D, HD, ni, niT, qkv, qmap, tid, nth);
     if (old_src) pre_finish<KD, T, 1>(rkv, static_cast<const T*>(P.Wkv), D, D, 2 * HD, nj, njT, qkv + HD, kvmap, tid, nth);
     __syncthreads();
-    head_finish<T, HD>(hr, qkv, old_src, Kc + (int64_t)pos * HD, Vc + (int64_t)pos * HD, tid);
+    head_finish<false, T, HD>(hr, qkv, old_src, Kc + (int64_t)pos * HD, Vc + (int64_t)pos * HD, tid);
     float m, l;
-    wg_attend<PRE, T, HD>(kr, Kc, Vc, pos, old_src, qkv, qkv + HD, qkv + 2 * HD, prob, part, oacc, red, m, l, tid, nth);
+    wg_attend<PRE, false, T, HD>(kr, Kc, Vc, pos, old_src, qkv, qkv + HD, qkv + 2 * HD, prob, part, oacc, red, m, l, tid, nth);
     const int64_t po = ((int64_t)p * B + b) * D + h * HD;
     if (tid < HD) {
         A.G.oc[po + tid] = old_src ? oacc[tid] / l : oacc[tid];
@@ -1033,6 +1075,514 @@ __global__ __launch_bounds__(512) void kv_proj_kernel(const KvArgs A) {
     if (tid < E) A.xout[ro * E + tid] = y[tid];
 }
 
+// ================================================================================================ the whole rollout as ONE launch
+// Persistent form of the seven phases for B = 1, one layer, fixed widths (KE / KD): every workgroup has ONE role for the whole rollout and keeps the
+// weights of that role in registers across steps (requested once, before the step loop) — no weight streaming and no launch boundary per step.
+// What a phase hands to the next travels as tagged 8-byte granules {value, step tag} (one agent-scope store each; the consumer polls the words it
+// needs — first one sentinel word from one lane with s_sleep, then all of them); every buffer is single: the consumer of step s has read it before
+// the data dependencies let its producer reach step s + 1.  Cache rows are written with sc1 (write-through) stores and read with sc1 loads: the key /
+// value row the tail of field i appends for a source j < i is read by another workgroup from the next step on.  Every spin is bounded and reports
+// through the error word; a role never waits for a role with a larger block index within a step chain that it feeds, and all roles fit the chip at
+// once (<= 256 workgroups of 512 threads, checked by the host), so the grid drains whatever happens.
+// Roles by block index: self (F H) | oproj (F) | cross (F (F-1) H) | tail (F) | proj (F) | fc (F n_fcf: fc1 rows, then fc2 rows of the same field).
+struct KvPersist {
+    SeaKvLayer L;
+    SeaKvGlobal G;
+    int32_t pos0, n_steps;
+    uint32_t tag0;
+    int32_t n_fcf;                 // fc workgroups per field
+    int32_t r1, r2;                // fc1 / fc2 rows per fc workgroup
+    unsigned long long* gx;        // [F, E]   next step's input rows (proj -> self, oproj)
+    unsigned long long* gatt;      // [F, E]   self-attention outputs (self -> oproj)
+    unsigned long long* gxr;       // [F, E]   x after the out-projection (oproj -> tail)
+    unsigned long long* gnd;       // [F, D]   ln_cross(cross_down(x)) of the pre-exchange rows (oproj -> cross)
+    unsigned long long* goc;       // [P, D]   cross-attention outputs / unnormalised partials (cross -> tail)
+    unsigned long long* gqc;       // [P, D]   queries of the pairs whose source is updated in this sweep
+    unsigned long long* gml;       // [P, H, 2]
+    unsigned long long* gnew;      // [F, D]   the updated field's normalised down-projection (tail -> later tails)
+    unsigned long long* gxr2;      // [F, E]   x after the exchange (tail -> fc)
+    unsigned long long* gh;        // [F, S]   fc1 rows (fc -> fc)
+    unsigned long long* gx3;       // [F, E]   x after fc2 (fc -> proj)
+};
+
+__device__ __forceinline__ void gr_put(unsigned long long* g, float v, uint32_t tag) {
+    __hip_atomic_store(g, ((unsigned long long)tag << 32) | (unsigned long long)__builtin_bit_cast(uint32_t, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float gr_get(const unsigned long long* g, uint32_t tag, int32_t* err) {
+    for (int it = 0; it < KV_SPIN_LIMIT; ++it) {
+        const unsigned long long pk = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((uint32_t)(pk >> 32) == tag) return __builtin_bit_cast(float, (uint32_t)pk);
+        __builtin_amdgcn_s_sleep(1);
+    }
+    __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return 0.f;
+}
+// One lane waits (politely) until the first word of a vector carries the tag — the producers are then in this phase — before the whole workgroup
+// starts polling its own words: hundreds of spinning lanes would otherwise sit on the fabric for most of every step.
+__device__ __forceinline__ void gr_wait_first(const unsigned long long* g, uint32_t tag, int tid) {
+    if (tid == 0) {
+        for (int it = 0; it < KV_SPIN_LIMIT; ++it) {
+            const unsigned long long pk = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((uint32_t)(pk >> 32) == tag) break;
+            __builtin_amdgcn_s_sleep(8);
+        }
+    }
+    __syncthreads();
+}
+
+template <int KE, typename T, int HD>
+__device__ __attribute__((noinline)) void role_self(const KvPersist& A, float* sm, int i, int h) {
+    constexpr int E = KE;
+    const int H = A.G.H, F = A.G.F, cap = A.G.cap;
+    const int tid = threadIdx.x, nth = 512;
+    float* xs = sm;
+    float* ns = xs + E;
+    T* nsT = reinterpret_cast<T*>(ns + E);
+    float* qkv = ns + 2 * E;
+    float* oacc = qkv + 3 * HD;
+    float* red = oacc + HD;
+    float* part = red + 32;
+    float* prob = part + 8 * HD;
+    const SeaKvField& Fd = A.L.f[i];
+    T* Kc = static_cast<T*>(Fd.Ks) + (int64_t)h * cap * HD;
+    T* Vc = static_cast<T*>(Fd.Vs) + (int64_t)h * cap * HD;
+    const int hh = h;
+    auto rowmap = [=](int r) { return (r / HD) * E + hh * HD + (r % HD); };
+    MRegs<MCfg<T, KE>::KS, 1> rw;
+    pre_issue<KE, T, 1>(rw, static_cast<const T*>(Fd.Wqkv), E, 3 * HD, rowmap, tid, nth);
+    for (int s = 0; s < A.n_steps; ++s) {
+        const int pos = A.pos0 + s;
+        const uint32_t tag = A.tag0 + (uint32_t)s;
+        const int64_t crow = pos;
+        NormRegs<1> nr;
+        norm_issue<T, 1>(nr, E, Fd.ln0, crow, tid, nth);
+        HeadRegs hr;
+        head_issue<HD>(hr, Fd.bqkv + h * HD, Fd.bqkv + E + h * HD, Fd.bqkv + 2 * E + h * HD, A.G.rope_self, pos, true, tid);
+        KRegs<T, HD> kr;
+        k_prefetch<true, true, T, HD>(kr, Kc, pos, tid, nth);
+        const float* ibp = (A.L.ib != nullptr && !A.G.ib_after_cross) ? A.L.ib + crow * E : nullptr;
+        if (s > 0) gr_wait_first(A.gx + i * E, tag - 1, tid);
+        if (tid < E) {
+            const float xv = s == 0 ? A.G.traj[((int64_t)pos * F + i) * E + tid] : gr_get(A.gx + i * E + tid, tag - 1, A.G.err);
+            xs[tid] = xv + (ibp != nullptr ? ibp[tid] : 0.f);
+        }
+        __syncthreads();
+        wg_norm_r<1, T>(xs, ns, nsT, E, nr, false, red, tid, nth);
+        pre_finish<KE, T, 1>(rw, static_cast<const T*>(Fd.Wqkv), E, E, 3 * HD, ns, nsT, qkv, rowmap, tid, nth);
+        __syncthreads();
+        head_finish<true, T, HD>(hr, qkv, true, Kc + (int64_t)pos * HD, Vc + (int64_t)pos * HD, tid);
+        float m, l;
+        wg_attend<true, true, T, HD>(kr, Kc, Vc, pos, true, qkv, qkv + HD, qkv + 2 * HD, prob, part, oacc, red, m, l, tid, nth);
+        if (tid < HD) gr_put(A.gatt + i * E + h * HD + tid, oacc[tid] / l, tag);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this step's cache row has left the CU before the next step's loads are issued
+        __syncthreads();
+    }
+}
+
+template <int KE, int KD, typename T>
+__device__ __attribute__((noinline)) void role_oproj(const KvPersist& A, float* sm, int i) {
+    constexpr int E = KE, D = KD;
+    const int F = A.G.F;
+    const int tid = threadIdx.x, nth = 512;
+    float* att = sm;
+    float* xs = att + E;
+    float* y = xs + E;
+    T* attT = reinterpret_cast<T*>(y + E);
+    T* xsT = reinterpret_cast<T*>(y + 2 * E);
+    float* red = y + 3 * E;
+    const SeaKvField& Fd = A.L.f[i];
+    const bool ex = A.G.exchange != 0;
+    MRegs<MCfg<T, KE>::KS, tiles_per_wave(KE, 8)> rwo;
+    MRegs<MCfg<T, KE>::KS, tiles_per_wave(KD, 8)> rwd;
+    pre_issue<KE, T, tiles_per_wave(KE, 8)>(rwo, static_cast<const T*>(Fd.Wo), E, E, IdentityRow(), tid, nth);
+    if (ex) pre_issue<KE, T, tiles_per_wave(KD, 8)>(rwd, static_cast<const T*>(Fd.Wdown), E, D, IdentityRow(), tid, nth);
+    const float bd = (ex && tid < D) ? Fd.bdown[tid] : 0.f;
+    for (int s = 0; s < A.n_steps; ++s) {
+        const int pos = A.pos0 + s;
+        const uint32_t tag = A.tag0 + (uint32_t)s;
+        const int64_t crow = pos;
+        NormRegs<1> nr;
+        if (ex) norm_issue<T, 1>(nr, D, Fd.ln_cross, crow, tid, nth);
+        const float* ibp = (A.L.ib != nullptr && !A.G.ib_after_cross) ? A.L.ib + crow * E : nullptr;
+        float xv = 0.f;
+        if (tid < E) xv = (s == 0 ? A.G.traj[((int64_t)pos * F + i) * E + tid] : gr_get(A.gx + i * E + tid, tag - 1, A.G.err)) + (ibp != nullptr ? ibp[tid] : 0.f);
+        gr_wait_first(A.gatt + i * E, tag, tid);
+        if (tid < E) {
+            const float av = gr_get(A.gatt + i * E + tid, tag, A.G.err);
+            att[tid] = av;
+            attT[tid] = from_f32<T>(av);
+            xs[tid] = xv;
+        }
+        __syncthreads();
+        pre_finish<KE, T, tiles_per_wave(KE, 8)>(rwo, static_cast<const T*>(Fd.Wo), E, E, E, att, attT, y, IdentityRow(), tid, nth);
+        __syncthreads();
+        if (tid < E) {
+            const float v = xs[tid] + y[tid];
+            xs[tid] = v;
+            xsT[tid] = from_f32<T>(v);
+            gr_put(A.gxr + i * E + tid, v, tag);
+        }
+        __syncthreads();
+        if (ex) {
+            pre_finish<KE, T, tiles_per_wave(KD, 8)>(rwd, static_cast<const T*>(Fd.Wdown), E, E, D, xs, xsT, y, IdentityRow(), tid, nth);
+            __syncthreads();
+            if (tid < D) y[tid] += bd;
+            __syncthreads();
+            wg_norm_r<1, T>(y, y, nullptr, D, nr, false, red, tid, nth);
+            if (tid < D) gr_put(A.gnd + i * D + tid, y[tid], tag);
+        }
+        __syncthreads();
+    }
+}
+
+template <int KD, typename T, int HD>
+__device__ __attribute__((noinline)) void role_cross(const KvPersist& A, float* sm, int p, int h) {
+    constexpr int D = KD;
+    const int H = A.G.H, F = A.G.F, cap = A.G.cap;
+    const int tid = threadIdx.x, nth = 512;
+    const int i = p / (F - 1), sx = p % (F - 1), j = sx < i ? sx : sx + 1;
+    const bool old_src = j > i;
+    float* ni = sm;
+    float* nj = ni + D;
+    T* niT = reinterpret_cast<T*>(nj + D);
+    T* njT = reinterpret_cast<T*>(nj + 2 * D);
+    float* qkv = nj + 3 * D;
+    float* oacc = qkv + 3 * HD;
+    float* red = oacc + HD;
+    float* part = red + 32;
+    float* prob = part + 8 * HD;
+    const SeaKvPair& P = A.L.p[i][j];
+    T* Kc = static_cast<T*>(P.Kc) + (int64_t)h * cap * HD;
+    T* Vc = static_cast<T*>(P.Vc) + (int64_t)h * cap * HD;
+    const int hh = h;
+    auto qmap = [=](int r) { return hh * HD + r; };
+    auto kvmap = [=](int r) { return (r / HD) * D + hh * HD + (r % HD); };
+    MRegs<MCfg<T, KD>::KS, 1> rq, rkv;
+    pre_issue<KD, T, 1>(rq, static_cast<const T*>(P.Wq), D, HD, qmap, tid, nth);
+    if (old_src) pre_issue<KD, T, 1>(rkv, static_cast<const T*>(P.Wkv), D, 2 * HD, kvmap, tid, nth);
+    for (int s = 0; s < A.n_steps; ++s) {
+        const int pos = A.pos0 + s;
+        const uint32_t tag = A.tag0 + (uint32_t)s;
+        HeadRegs hr;
+        head_issue<HD>(hr, P.bq + h * HD, P.bkv + h * HD, P.bkv + D + h * HD, A.G.rope_cross, pos, old_src, tid);
+        // cached rows: this workgroup's own (source not yet updated in the sweep) are all there; a row appended by the TAIL of field i at the previous step
+        // is there once this step's hand-off chain has reached this workgroup — everything but that row is requested now, that row after the wait
+        KRegs<T, HD> kr;
+        k_prefetch<true, true, T, HD>(kr, Kc, old_src ? pos : pos - 1, tid, nth);
+        gr_wait_first(A.gnd + (i > j ? i : j) * D, tag, tid);
+        if (tid < D) {
+            const float a = gr_get(A.gnd + i * D + tid, tag, A.G.err), c = gr_get(A.gnd + j * D + tid, tag, A.G.err);
+            ni[tid] = a;
+            nj[tid] = c;
+            niT[tid] = from_f32<T>(a);
+            njT[tid] = from_f32<T>(c);
+        }
+        if (!old_src) k_prefetch_one<true, T, HD>(kr, Kc, pos - 1, tid, nth);
+        __syncthreads();
+        pre_finish<KD, T, 1>(rq, static_cast<const T*>(P.Wq), D, D, HD, ni, niT, qkv, qmap, tid, nth);
+        if (old_src) pre_finish<KD, T, 1>(rkv, static_cast<const T*>(P.Wkv), D, D, 2 * HD, nj, njT, qkv + HD, kvmap, tid, nth);
+        __syncthreads();
+        head_finish<true, T, HD>(hr, qkv, old_src, Kc + (int64_t)pos * HD, Vc + (int64_t)pos * HD, tid);
+        float m, l;
+        wg_attend<true, true, T, HD>(kr, Kc, Vc, pos, old_src, qkv, qkv + HD, qkv + 2 * HD, prob, part, oacc, red, m, l, tid, nth);
+        const int po = p * D + h * HD;
+        if (tid < HD) {
+            if (!old_src) gr_put(A.gqc + po + tid, qkv[tid], tag);
+            gr_put(A.goc + po + tid, old_src ? oacc[tid] / l : oacc[tid], tag);
+        }
+        if (!old_src && tid < 2) gr_put(A.gml + (p * H + h) * 2 + tid, tid == 0 ? m : l, tag);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+}
+
+template <int KE, int KD, typename T, int NF, int I>
+__device__ __attribute__((noinline)) void role_tail(const KvPersist& A, float* sm) {
+    constexpr bool HAS_DOWN = I < NF - 1;
+    constexpr int NNEW = I;
+    constexpr int NT_2D = tiles_per_wave(2 * KD, 8), NT_D = tiles_per_wave(KD, 8), NT_E = tiles_per_wave(KE, 8);
+    constexpr int E = KE, D = KD;
+    const int H = A.G.H, cap = A.G.cap;
+    const int hd = D / H, hd2 = hd >> 1;
+    const int tid = threadIdx.x, nth = 512;
+    float* nj = sm;
+    float* kv = nj + D;
+    float* o = kv + 2 * D;
+    float* g = o + D;
+    float* gs = g + D;
+    T* njT = reinterpret_cast<T*>(gs + D);
+    T* oT = reinterpret_cast<T*>(gs + 2 * D);
+    T* gsT = reinterpret_cast<T*>(gs + 3 * D);
+    float* xs = gs + 4 * D;
+    float* y = xs + E;
+    T* xsT = reinterpret_cast<T*>(y + E);
+    float* red = y + 2 * E;
+    const SeaKvField& Fd = A.L.f[I];
+    // resident for the whole rollout: projections of every pair, k / v weights of up to two updated sources, up- and down-projection
+    MRegs<MCfg<T, KD>::KS, NT_D> rp[NF - 1];
+    MRegs<MCfg<T, KD>::KS, NT_2D> rkv[NNEW > 2 ? 2 : (NNEW > 0 ? NNEW : 1)];
+    MRegs<MCfg<T, KD>::KS, NT_E> rup;
+    MRegs<MCfg<T, KE>::KS, NT_D> rdn;
+    if constexpr (NNEW >= 1) pre_issue<KD, T, NT_2D>(rkv[0], static_cast<const T*>(A.L.p[I][0].Wkv), D, 2 * D, IdentityRow(), tid, nth);
+    if constexpr (NNEW >= 2) pre_issue<KD, T, NT_2D>(rkv[1], static_cast<const T*>(A.L.p[I][1].Wkv), D, 2 * D, IdentityRow(), tid, nth);
+#pragma unroll
+    for (int s = 0; s < NF - 1; ++s) pre_issue<KD, T, NT_D>(rp[s], static_cast<const T*>(A.L.p[I][s < I ? s : s + 1].Wp), D, D, IdentityRow(), tid, nth);
+    pre_issue<KD, T, NT_E>(rup, static_cast<const T*>(Fd.Wup), D, E, IdentityRow(), tid, nth);
+    if constexpr (HAS_DOWN) pre_issue<KE, T, NT_D>(rdn, static_cast<const T*>(Fd.Wdown), E, D, IdentityRow(), tid, nth);
+    const float bd = (HAS_DOWN && tid < D) ? Fd.bdown[tid] : 0.f;
+    const float bu = tid < E ? Fd.bup[tid] : 0.f;
+    for (int st = 0; st < A.n_steps; ++st) {
+        const int pos = A.pos0 + st;
+        const uint32_t tag = A.tag0 + (uint32_t)st;
+        const int64_t crow = pos;
+        NormRegs<1> nr;
+        if constexpr (HAS_DOWN) norm_issue<T, 1>(nr, D, Fd.ln_cross, crow, tid, nth);
+        float gsum = 0.f;
+        // ---- sources not yet updated in this sweep (j > I): their heads' outputs are final
+#pragma unroll
+        for (int s = I; s < NF - 1; ++s) {
+            const int p = I * (NF - 1) + s;
+            gr_wait_first(A.goc + p * D + D - 1, tag, tid);
+            if (tid < D) {
+                const float v = gr_get(A.goc + p * D + tid, tag, A.G.err);
+                o[tid] = v;
+                oT[tid] = from_f32<T>(v);
+            }
+            __syncthreads();
+            pre_finish<KD, T, NT_D>(rp[s], static_cast<const T*>(A.L.p[I][s + 1].Wp), D, D, D, o, oT, g, IdentityRow(), tid, nth);
+            __syncthreads();
+            if (tid < D) gsum += gelu_erf(g[tid]);
+        }
+        // ---- sources updated earlier in this sweep (j < I)
+#pragma unroll
+        for (int j = 0; j < NNEW; ++j) {
+            const int p = I * (NF - 1) + j;
+            const SeaKvPair& P = A.L.p[I][j];
+            float qv = 0.f, ov = 0.f, m0 = 0.f, l0 = 0.f, bk0 = 0.f, bk1 = 0.f, bv0 = 0.f, bv1 = 0.f;
+            float2 cs = make_float2(1.f, 0.f);
+            if (tid < D / 2) {
+                const int hh = tid / hd2, t = tid - hh * hd2;
+                cs = reinterpret_cast<const float2*>(A.G.rope_cross)[(int64_t)pos * hd2 + t];
+                bk0 = P.bkv[hh * hd + 2 * t];
+                bk1 = P.bkv[hh * hd + 2 * t + 1];
+                bv0 = P.bkv[D + 2 * tid];
+                bv1 = P.bkv[D + 2 * tid + 1];
+            }
+            gr_wait_first(A.gnew + j * D, tag, tid);
+            if (tid < D) {
+                const float v = gr_get(A.gnew + j * D + tid, tag, A.G.err);
+                nj[tid] = v;
+                njT[tid] = from_f32<T>(v);
+                const int hh = tid / hd;
+                qv = gr_get(A.gqc + p * D + tid, tag, A.G.err);
+                ov = gr_get(A.goc + p * D + tid, tag, A.G.err);
+                m0 = gr_get(A.gml + (p * H + hh) * 2, tag, A.G.err);
+                l0 = gr_get(A.gml + (p * H + hh) * 2 + 1, tag, A.G.err);
+            }
+            __syncthreads();
+            if (j < 2) pre_finish<KD, T, NT_2D>(rkv[j < 2 ? j : 0], static_cast<const T*>(P.Wkv), D, D, 2 * D, nj, njT, kv, IdentityRow(), tid, nth);
+            else wg_gemv<T>(static_cast<const T*>(P.Wkv), D, D, 2 * D, nj, kv, IdentityRow(), tid, nth);
+            __syncthreads();
+            // bias, rotary embedding of k, append (pairs: >= 4-byte write-through stores), merge this key into the head's (o, m, l)
+            if (tid < D / 2) {
+                const int hh = tid / hd2, t = tid - hh * hd2;
+                const int c0 = hh * hd + 2 * t;
+                float oe, oo;
+                rope_pair(kv[c0] + bk0, kv[c0 + 1] + bk1, cs.x, cs.y, oe, oo);
+                oe = round_to(oe, T());
+                oo = round_to(oo, T());
+                kv[c0] = oe;
+                kv[c0 + 1] = oo;
+                store_pair<true>(static_cast<T*>(P.Kc) + ((int64_t)hh * cap + pos) * hd + 2 * t, oe, oo);
+                const float v0 = round_to(kv[D + 2 * tid] + bv0, T()), v1 = round_to(kv[D + 2 * tid + 1] + bv1, T());
+                kv[D + 2 * tid] = v0;
+                kv[D + 2 * tid + 1] = v1;
+                const int hv = (2 * tid) / hd;
+                store_pair<true>(static_cast<T*>(P.Vc) + ((int64_t)hv * cap + pos) * hd + (2 * tid - hv * hd), v0, v1);
+            }
+            __syncthreads();
+            float sc[1] = {tid < D ? qv * kv[tid] : 0.f};
+            team_reduce<1>(sc, hd);
+            if (tid < D) {
+                const float m1 = fmaxf(m0, sc[0]);
+                const float w0 = l0 > 0.f ? __expf(m0 - m1) : 0.f, w1 = __expf(sc[0] - m1);
+                const float ov2 = (ov * w0 + kv[D + tid] * w1) / (l0 * w0 + w1);
+                o[tid] = ov2;
+                oT[tid] = from_f32<T>(ov2);
+            }
+            __syncthreads();
+            pre_finish<KD, T, NT_D>(rp[j], static_cast<const T*>(P.Wp), D, D, D, o, oT, g, IdentityRow(), tid, nth);
+            __syncthreads();
+            if (tid < D) gsum += gelu_erf(g[tid]);
+        }
+        if (tid < D) {
+            gs[tid] = gsum;
+            gsT[tid] = from_f32<T>(gsum);
+        }
+        if (tid < E) xs[tid] = gr_get(A.gxr + I * E + tid, tag, A.G.err);   // (published before the cross phase: no wait to speak of)
+        __syncthreads();
+        pre_finish<KD, T, NT_E>(rup, static_cast<const T*>(Fd.Wup), D, D, E, gs, gsT, y, IdentityRow(), tid, nth);
+        __syncthreads();
+        float xnew = 0.f;
+        if (tid < E) {
+            xnew = xs[tid] + y[tid] + (float)(NF - 1) * bu;
+            xs[tid] = xnew;
+            xsT[tid] = from_f32<T>(xnew);
+        }
+        __syncthreads();
+        if constexpr (HAS_DOWN) {
+            pre_finish<KE, T, NT_D>(rdn, static_cast<const T*>(Fd.Wdown), E, E, D, xs, xsT, y, IdentityRow(), tid, nth);
+            __syncthreads();
+            if (tid < D) y[tid] += bd;
+            __syncthreads();
+            wg_norm_r<1, T>(y, y, nullptr, D, nr, false, red, tid, nth);
+            if (tid < D) gr_put(A.gnew + I * D + tid, y[tid], tag);
+        }
+        // the rows appended above must have left this CU before anything downstream of x can lead to their being read (next step's cross attention)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid < E) gr_put(A.gxr2 + I * E + tid, xnew, tag);
+        __syncthreads();
+    }
+}
+
+template <int KE, int KD, typename T>
+__device__ __forceinline__ void role_tail_dispatch(const KvPersist& A, float* sm, int i) {
+    switch (A.G.F * 4 + i) {   // block-uniform
+        case 2 * 4 + 0: role_tail<KE, KD, T, 2, 0>(A, sm); break;
+        case 2 * 4 + 1: role_tail<KE, KD, T, 2, 1>(A, sm); break;
+        case 3 * 4 + 0: role_tail<KE, KD, T, 3, 0>(A, sm); break;
+        case 3 * 4 + 1: role_tail<KE, KD, T, 3, 1>(A, sm); break;
+        case 3 * 4 + 2: role_tail<KE, KD, T, 3, 2>(A, sm); break;
+        case 4 * 4 + 0: role_tail<KE, KD, T, 4, 0>(A, sm); break;
+        case 4 * 4 + 1: role_tail<KE, KD, T, 4, 1>(A, sm); break;
+        case 4 * 4 + 2: role_tail<KE, KD, T, 4, 2>(A, sm); break;
+        default: role_tail<KE, KD, T, 4, 3>(A, sm); break;
+    }
+}
+
+// fc1 rows [k r1, (k+1) r1) and fc2 rows [k r2, (k+1) r2) of field i.  LDS: xs[E] ns[E] nsT[E] hs[S] ys[128] red[32]
+template <int KE, typename T>
+__device__ __attribute__((noinline)) void role_fc(const KvPersist& A, float* sm, int i, int k) {
+    constexpr int E = KE, EPC = ActTraits<T>::EPC;
+    const int S = A.G.S, exch = A.G.exchange;
+    const int tid = threadIdx.x, nth = 512;
+    float* xs = sm;
+    float* ns = xs + E;
+    T* nsT = reinterpret_cast<T*>(ns + E);
+    float* hs = ns + 2 * E;
+    float* ys = hs + S;
+    float* red = ys + 128;
+    const SeaKvField& Fd = A.L.f[i];
+    const int r1 = A.r1, r2 = A.r2;
+    const int a0 = k * r1, n1 = a0 >= S ? 0 : (a0 + r1 <= S ? r1 : S - a0);          // fc1 rows of this workgroup (a multiple of 16 except at the end)
+    const int c0 = k * r2, n2 = c0 >= E ? 0 : (c0 + r2 <= E ? r2 : E - c0);          // fc2 rows (<= 8)
+    const T* W1 = static_cast<const T*>(Fd.W1) + (int64_t)(n1 > 0 ? a0 : 0) * E;
+    const T* W2 = static_cast<const T*>(Fd.W2) + (int64_t)(n2 > 0 ? c0 : 0) * S;
+    MRegs<MCfg<T, KE>::KS, 1> rw1;                      // up to 8 tiles of 16 rows: r1 <= 128
+    pre_issue<KE, T, 1>(rw1, W1, E, n1 > 0 ? n1 : 1, IdentityRow(), tid, nth);
+    const int kc = S / EPC;
+    WRegs<4, 1> w4;                                      // fc2: a wave per row, 8 rows per pass
+    WRegs<2, 1> w2;
+    if (kc == 256) gemv_issue<T, 4, 1>(w4, W2, S, S, n2 > 0 ? n2 : 1, 0, IdentityRow(), tid, nth);
+    else if (kc == 128) gemv_issue<T, 2, 1>(w2, W2, S, S, n2 > 0 ? n2 : 1, 0, IdentityRow(), tid, nth);
+    SeaKvNorm nm;
+    nm.gamma = Fd.lnw; nm.beta = Fd.lnb; nm.mod = nullptr; nm.ldmod = 0; nm.pad_ = 0;
+    NormRegs<8> nrs;                                     // S <= 4096
+    norm_issue<T, 8>(nrs, S, nm, 0, tid, nth);
+    const float b1v = tid < n1 ? Fd.b1[a0 + tid] : 0.f;
+    const float b2v = tid < n2 ? Fd.b2[c0 + tid] : 0.f;
+    const unsigned long long* gin = exch ? A.gxr2 : A.gxr;   // no exchange: the out-projection's rows go straight to the MLP
+    for (int s = 0; s < A.n_steps; ++s) {
+        const int pos = A.pos0 + s;
+        const uint32_t tag = A.tag0 + (uint32_t)s;
+        const int64_t crow = pos;
+        NormRegs<1> nr;
+        norm_issue<T, 1>(nr, E, Fd.ln2, crow, tid, nth);
+        const float* ibp = (A.L.ib != nullptr && A.G.ib_after_cross) ? A.L.ib + crow * E : nullptr;
+        const float ibv = (ibp != nullptr && tid < E) ? ibp[tid] : 0.f;
+        gr_wait_first(gin + i * E, tag, tid);
+        if (tid < E) xs[tid] = gr_get(gin + i * E + tid, tag, A.G.err) + ibv;
+        __syncthreads();
+        const float xq = (tid < n2) ? xs[c0 + tid] : 0.f;                 // the residual of this workgroup's fc2 rows
+        wg_norm_r<1, T>(xs, ns, nsT, E, nr, false, red, tid, nth);
+        if (n1 > 0) pre_finish<KE, T, 1>(rw1, W1, E, E, n1, ns, nsT, ys, IdentityRow(), tid, nth);
+        __syncthreads();
+        if (tid < n1) gr_put(A.gh + (int64_t)i * S + a0 + tid, ys[tid] + b1v, tag);
+        // ---- all rows of the field's hidden vector (every fc workgroup of the field contributes r1 of them)
+        gr_wait_first(A.gh + (int64_t)i * S + S - 1, tag, tid);
+        for (int e = tid; e < S; e += nth) hs[e] = gr_get(A.gh + (int64_t)i * S + e, tag, A.G.err);
+        __syncthreads();
+        wg_norm_r<8, T>(hs, hs, nullptr, S, nrs, true, red, tid, nth);
+        if (n2 > 0) {
+            if (kc == 256) gemv_apply<T, 4, 1>(w4, S, n2, 0, hs, ys, tid, nth);
+            else if (kc == 128) gemv_apply<T, 2, 1>(w2, S, n2, 0, hs, ys, tid, nth);
+            else wg_gemv<T>(W2, S, S, n2, hs, ys, IdentityRow(), tid, nth);
+        }
+        __syncthreads();
+        if (tid < n2) gr_put(A.gx3 + i * E + c0 + tid, ys[tid] + b2v + xq, tag);
+        __syncthreads();
+    }
+}
+
+template <int KE, typename T>
+__device__ __attribute__((noinline)) void role_proj(const KvPersist& A, float* sm, int i) {
+    constexpr int E = KE;
+    const int F = A.G.F;
+    const int tid = threadIdx.x, nth = 512;
+    float* xs = sm;
+    float* y = xs + E;
+    T* xsT = reinterpret_cast<T*>(y + E);
+    float* red = y + 2 * E;
+    const SeaKvField& Fd = A.L.f[i];
+    MRegs<MCfg<T, KE>::KS, tiles_per_wave(KE, 8)> rw;
+    pre_issue<KE, T, tiles_per_wave(KE, 8)>(rw, static_cast<const T*>(Fd.Wproj), E, E, IdentityRow(), tid, nth);
+    const float bp = tid < E ? Fd.bproj[tid] : 0.f;
+    for (int s = 0; s < A.n_steps; ++s) {
+        const int pos = A.pos0 + s;
+        const uint32_t tag = A.tag0 + (uint32_t)s;
+        NormRegs<1> nr;
+        norm_issue<T, 1>(nr, E, A.G.final_ln[i], (int64_t)pos, tid, nth);
+        gr_wait_first(A.gx3 + i * E + E - 1, tag, tid);
+        if (tid < E) {
+            const float v = gr_get(A.gx3 + i * E + tid, tag, A.G.err);
+            xs[tid] = v;
+            xsT[tid] = from_f32<T>(v);
+        }
+        __syncthreads();
+        pre_finish<KE, T, tiles_per_wave(KE, 8)>(rw, static_cast<const T*>(Fd.Wproj), E, E, E, xs, xsT, y, IdentityRow(), tid, nth);
+        __syncthreads();
+        if (tid < E) y[tid] += bp;
+        __syncthreads();
+        wg_norm_r<1, T>(y, y, nullptr, E, nr, false, red, tid, nth);
+        if (tid < E) {
+            A.G.traj[((int64_t)(pos + 1) * F + i) * E + tid] = y[tid];
+            gr_put(A.gx + i * E + tid, y[tid], tag);
+        }
+        __syncthreads();
+    }
+}
+
+template <int KE, typename T, int HDS, int HDC>
+__global__ __launch_bounds__(512) void kv_persistent_kernel(const KvPersist A) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    constexpr int KD = KE / 2;
+    const int F = A.G.F, H = A.G.H, ex = A.G.exchange;
+    int w = blockIdx.x;
+    const int n_self = F * H, n_cross = ex ? F * (F - 1) * H : 0, n_tail = ex ? F : 0;
+    if (w < n_self) { role_self<KE, T, HDS>(A, sm, w / H, w % H); return; }
+    w -= n_self;
+    if (w < F) { role_oproj<KE, KD, T>(A, sm, w); return; }
+    w -= F;
+    if (w < n_cross) { role_cross<KD, T, HDC>(A, sm, w / H, w % H); return; }
+    w -= n_cross;
+    if (w < n_tail) { role_tail_dispatch<KE, KD, T>(A, sm, w); return; }
+    w -= n_tail;
+    if (w < F) { role_proj<KE, T>(A, sm, w); return; }
+    w -= F;
+    if (w < F * A.n_fcf) role_fc<KE, T>(A, sm, w / A.n_fcf, w % A.n_fcf);
+}
+
 static bool pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 static bool kdim_ok(int K, int epc) {
     if (K % epc) return false;
@@ -1043,7 +1593,8 @@ static bool kdim_ok(int K, int epc) {
 // Widths with matrix-core kernels: E in {64, 128, 256} with D = E / 2 (or no exchange), heads of at most 32 columns, a cache of at most 2048
 // positions (the key rows a thread prefetches).  SEA_KV_PRE=0 keeps the run-time-width kernels (tuning aid).
 static int pre_width(const SeaKvGlobal& G) {
-    static const int env = []() { const char* e = getenv("SEA_KV_PRE"); return e ? atoi(e) : 1; }();
+    const char* ev = getenv("SEA_KV_PRE");
+    const int env = ev ? atoi(ev) : 1;
     if (!env || G.cap > 2048 || (G.E != 64 && G.E != 128 && G.E != 256) || G.E / G.H > 32) return 0;
     if (G.exchange && (G.D * 2 != G.E || G.D / G.H > 32)) return 0;
     return G.E;
@@ -1104,17 +1655,76 @@ static int run_steps(const SeaKvGlobal& G, const SeaKvLayer* layers, int pos0, i
     return 0;
 }
 
+// Words of the granule arena the persistent form needs (SeaKvGlobal.handoff; the first F * D words are the tails' hand-off of the seven-launch form).
+static int64_t persist_words(const SeaKvGlobal& G) {
+    const int64_t F = G.F, E = G.E, D = G.D, S = G.S, H = G.H, P = F * (F - 1);
+    return F * D * 2 + F * E * 5 + P * D * 2 + P * H * 2 + F * S;
+}
+
+// The persistent form applies to: one trajectory, one layer, the fixed-width kernels (pre_width) with cross heads of 8 or 16 columns, F >= 1, and a
+// role count that fits the chip (one 512-thread workgroup per CU is always resident).  SEA_KV_PERSIST=0 keeps the seven launches per step.
+template <int KE, typename T>
+static bool run_persistent(const SeaKvGlobal& G, const SeaKvLayer* layers, int pos0, int n_steps, uint32_t tag0, hipStream_t s) {
+    const char* ev = getenv("SEA_KV_PERSIST");   // read per call: tests compare the two forms in one process
+    const int env = ev ? atoi(ev) : 1;
+    if constexpr (KE == 0) return false;
+    else {
+        if (!env || G.B != 1 || G.L != 1 || n_steps < 1 || G.handoff_words < persist_words(G) || G.S > 4096) return false;
+        const int F = G.F, E = G.E, D = G.D, S = G.S, H = G.H, ex = G.exchange;
+        const int hd_s = E / H;
+        if (hd_s != 16 && hd_s != 32) return false;
+        static const int cus = []() { int n = 0; return hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, 0) == hipSuccess ? n : 0; }();
+        const int fixed = F * H + F + (ex ? F * (F - 1) * H + F : 0) + F;
+        const int room = (cus - fixed) / F;
+        if (room < 1) return false;
+        int r1 = ((S + room - 1) / room + 15) / 16 * 16;
+        const int n_fcf = (S + r1 - 1) / r1;
+        const int r2 = (E + n_fcf - 1) / n_fcf;
+        if (r1 > 128 || r2 > 8 || fixed + F * n_fcf > cus) return false;
+        KvPersist A;
+        A.L = layers[0];
+        A.G = G;
+        A.pos0 = pos0; A.n_steps = n_steps; A.tag0 = tag0; A.n_fcf = n_fcf; A.r1 = r1; A.r2 = r2;
+        const int64_t P = (int64_t)F * (F - 1);
+        unsigned long long* g = G.handoff;
+        A.gnew = g; g += F * D;
+        A.gnd = g; g += F * D;
+        A.gx = g; g += F * E;
+        A.gatt = g; g += F * E;
+        A.gxr = g; g += F * E;
+        A.gxr2 = g; g += F * E;
+        A.gx3 = g; g += F * E;
+        A.goc = g; g += P * D;
+        A.gqc = g; g += P * D;
+        A.gml = g; g += P * H * 2;
+        A.gh = g;
+        const int hd_c = hd_s / 2, cap = G.cap;
+        int lds = (3 * E + 4 * hd_s + 32 + 8 * hd_s + cap + 8);
+        const int lds_c = (4 * D + 4 * hd_c + 32 + 8 * hd_c + cap + 8), lds_t = 9 * D + 3 * E + 32, lds_f = 3 * E + S + 128 + 32, lds_b = 5 * E + 32;
+        lds = lds > lds_c ? lds : lds_c;
+        lds = lds > lds_t ? lds : lds_t;
+        lds = lds > lds_f ? lds : lds_f;
+        lds = lds > lds_b ? lds : lds_b;
+        const dim3 grid(fixed + F * n_fcf), block(512);
+        if (hd_s == 32) kv_persistent_kernel<KE, T, 32, 16><<<grid, block, lds * 4, s>>>(A);
+        else kv_persistent_kernel<KE, T, 16, 8><<<grid, block, lds * 4, s>>>(A);
+        return true;
+    }
+}
+
 template <typename T>
 static int run_steps_t(const SeaKvGlobal& G, const SeaKvLayer* layers, int pos0, int n_steps, uint32_t tag0, hipStream_t s) {
     switch (pre_width(G)) {
-        case 64: return run_steps<64, T>(G, layers, pos0, n_steps, tag0, s);
-        case 128: return run_steps<128, T>(G, layers, pos0, n_steps, tag0, s);
-        case 256: return run_steps<256, T>(G, layers, pos0, n_steps, tag0, s);
+        case 64: return run_persistent<64, T>(G, layers, pos0, n_steps, tag0, s) ? 0 : run_steps<64, T>(G, layers, pos0, n_steps, tag0, s);
+        case 128: return run_persistent<128, T>(G, layers, pos0, n_steps, tag0, s) ? 0 : run_steps<128, T>(G, layers, pos0, n_steps, tag0, s);
+        case 256: return run_persistent<256, T>(G, layers, pos0, n_steps, tag0, s) ? 0 : run_steps<256, T>(G, layers, pos0, n_steps, tag0, s);
         default: return run_steps<0, T>(G, layers, pos0, n_steps, tag0, s);
     }
 }
 
 }  // namespace
+
+extern "C" int64_t sea_kv_arena_words(const SeaKvGlobal* G) { return G != nullptr ? persist_words(*G) : 0; }
 
 extern "C" int sea_kv_rollout(const SeaKvGlobal* G, const SeaKvLayer* layers, int pos0, int n_steps, uint32_t tag0, int dtype, void* stream) {
     SEA_REQUIRE(G != nullptr && layers != nullptr && n_steps >= 0 && pos0 >= 0, "sea_kv_rollout: bad arguments");
@@ -1130,7 +1740,7 @@ extern "C" int sea_kv_rollout(const SeaKvGlobal* G, const SeaKvLayer* layers, in
         SEA_REQUIRE(F >= 2 && D % H == 0 && D <= 512 && kdim_ok(D, epc), "sea_kv_rollout: unsupported exchange width D=%d (F=%d)", D, F);
         const int hd_c = D / H;
         SEA_REQUIRE(hd_c == 8 || hd_c == 16 || hd_c == 32 || hd_c == 64, "sea_kv_rollout: cross head dim %d (8 / 16 / 32 / 64)", hd_c);
-        SEA_REQUIRE(G->nd_old && G->oc && G->qc && G->ml && G->handoff && G->rope_cross, "sea_kv_rollout: null exchange workspace");
+        SEA_REQUIRE(G->nd_old && G->oc && G->qc && G->ml && G->handoff && G->handoff_words >= (int64_t)B * F * D && G->rope_cross, "sea_kv_rollout: null / short exchange workspace");
     }
     SEA_REQUIRE(G->traj && G->att_e && G->xr && G->xq && G->x3 && G->hbuf && G->err && G->rope_self && (G->L == 1 || (G->xl[0] && G->xl[1])), "sea_kv_rollout: null workspace");
     hipStream_t s = static_cast<hipStream_t>(stream);

@@ -99,7 +99,9 @@ class KvFast:
             G.nd_old = buf(B, F, D).data_ptr()
             G.oc, G.qc = buf(npair, B, D).data_ptr(), buf(npair, B, D).data_ptr()
             G.ml = buf(npair, B, H, 2).data_ptr()
-            G.handoff = buf(B, F, D, dtype=torch.int64, zero=True).data_ptr()
+        # granule words: the tails' hand-off of the seven-launch form, or — one trajectory, one layer — the whole arena of the persistent form
+        words = max(int(N.lib().sea_kv_arena_words(C.byref(G))), B * F * max(D, 1), 1)
+        G.handoff, G.handoff_words = buf(words, dtype=torch.int64, zero=True).data_ptr(), words
         self.err = buf(1, dtype=torch.int32, zero=True)
         G.err = self.err.data_ptr()
         self.layers = (N.SeaKvLayer * L)()

@@ -85,9 +85,13 @@ def test_fast_kv_rows_of_a_batch_are_independent(monkeypatch):
     x, _, ib = recipe_inputs(4, 24, cfg, seed=9)
     x0, ibg = x[:, :1].cuda().contiguous(), ib.cuda().contiguous()
     full = _kv(m, x0, ibg, 24, monkeypatch, True)
+    monkeypatch.setenv("SEA_KV_PERSIST", "0")   # the same launches at both batch sizes (one trajectory alone would otherwise take the persistent form)
     for b in (0, 3):
         one = _kv(m, x0[b:b + 1].contiguous(), ibg[b:b + 1].contiguous(), 24, monkeypatch, True)
         assert torch.equal(one[0], full[b])
+    monkeypatch.setenv("SEA_KV_PERSIST", "1")
+    one = _kv(m, x0[1:2].contiguous(), ibg[1:2].contiguous(), 24, monkeypatch, True)
+    assert rel_l2(one[0].cpu().numpy(), full[1].cpu().numpy()) < 1e-5
 
 
 def test_fast_kv_full_length_cfg2(monkeypatch):
@@ -107,6 +111,40 @@ def test_fast_kv_full_length_cfg2(monkeypatch):
     b = _kv(mb, x0, ibg, 2024, monkeypatch, True)
     assert torch.equal(a, b) and bool(torch.isfinite(a).all())
     print(f"bf16 fast vs fp32 fast over 2024 steps: rel-L2 {rel_l2(a.cpu().numpy(), fast.cpu().numpy()):.3e}")
+
+
+PERSIST_CASES = [
+    # one trajectory, one layer, fixed widths: the whole rollout is ONE launch (every workgroup one role, weights resident in registers)
+    ((1, 256, 8, 160, 8, 0, 3, 2, True, "adaln"), 130),
+    ((1, 128, 8, 96, 8, 0, 2, 2, False, "ln"), 60),                                      # two fields, ib before the block, head dims 16 / 8
+    ((1, 128, 4, 64, 8, 0, 4, 2, True, "adaln", "sea", "none", "mlp"), 40),              # four fields (a third updated source streams its k / v weights)
+    ((1, 64, 4, 64, 4, 0, 3, 2, True, "ln", "simple", "add", "fourier"), 30),            # no exchange: four roles only
+    ((1, 256, 8, 64, 4, 0, 1, 2, True, "adaln", "sea", "add", "linear"), 40),            # one field (n / 2 > 16 rows: the batched condition pass of the
+                                                                                         # shorter rollout runs the same GEMM kernel, so the prefix is bit-identical)
+]
+
+
+@pytest.mark.parametrize("dtype,tol_oracle,tol_paths", [("fp32", 1e-4, 1e-5), ("bf16", 3e-2, 2e-2)])
+@pytest.mark.parametrize("cfg_args,n", PERSIST_CASES)
+def test_persistent_kv_rollout(cfg_args, n, dtype, tol_oracle, tol_paths, monkeypatch):
+    """The persistent form against the oracle, against the seven-launch form (SEA_KV_PERSIST=0) and against itself (a second rollout reuses the caches
+    and the granule arena with fresh tags; a shorter one is its prefix)."""
+    cfg = O.OracleConfig(*cfg_args)
+    m = build(cfg, dtype)
+    x, _, ib = recipe_inputs(1, n, cfg, seed=8)
+    x0, ibg = x[:, :1].cuda().contiguous(), ib.cuda().contiguous()
+    monkeypatch.setenv("SEA_KV_PERSIST", "1")
+    a = _kv(m, x0, ibg, n, monkeypatch, True)
+    ref = O.rollout(x[:, :1], ib, n, recipe_params(cfg), cfg)
+    k = min(n, 8)
+    assert rel_l2(a.cpu().numpy()[:, :k], ref.numpy()[:, :k]) < tol_oracle
+    if dtype == "fp32":
+        assert rel_l2(a.cpu().numpy(), ref.numpy()) < tol_oracle
+    assert torch.equal(_kv(m, x0, ibg, n, monkeypatch, True), a)
+    assert torch.equal(_kv(m, x0, ibg, n // 2, monkeypatch, True), a[:, :n // 2])
+    monkeypatch.setenv("SEA_KV_PERSIST", "0")
+    b = _kv(m, x0, ibg, n, monkeypatch, True)
+    assert rel_l2(a.cpu().numpy(), b.cpu().numpy()) < tol_paths
 
 
 def test_models_outside_the_limits_keep_the_generic_plan(monkeypatch):
