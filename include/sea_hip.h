@@ -598,6 +598,9 @@ typedef struct {
 int sea_kv_rollout(const SeaKvGlobal* G, const SeaKvLayer* layers, int pos0, int n_steps, uint32_t tag0, int dtype, void* stream);
 /* Words of `handoff` the persistent form of sea_kv_rollout needs for these sizes (host only). */
 int64_t sea_kv_arena_words(const SeaKvGlobal* G);
+/* Tuning aid: register a device buffer of n_steps * 64 8-byte words that the persistent form fills with 100 MHz clock stamps of its hand-offs
+ * (tools/kv_persist_timeline.py); NULL switches it off. */
+void sea_kv_debug_stamps(unsigned long long* buf);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Self-test of the MFMA fragment maps this library relies on (16x16x32 bf16 and 16x16x4 f32, A/B/C lane maps):

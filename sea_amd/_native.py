@@ -239,6 +239,8 @@ def lib() -> C.CDLL:
     L.sea_kv_rollout.restype = C.c_int
     L.sea_kv_arena_words.argtypes = [C.POINTER(SeaKvGlobal)]
     L.sea_kv_arena_words.restype = C.c_int64
+    L.sea_kv_debug_stamps.argtypes = [_vp]
+    L.sea_kv_debug_stamps.restype = None
     for name in ("sea_attention_bwd", "sea_wgrad_grouped", "sea_transpose_weights", "sea_rownorm_bwd", "sea_silu_outer_bwd", "sea_ib_bwd"):
         getattr(L, name).restype = C.c_int
     L.sea_mse_fwd_bwd.argtypes = [_vp, _vp, _vp, _vp, _vp, C.c_int, _i64, C.c_float, _vp]
@@ -264,7 +266,7 @@ EXPORTED_SYMBOLS = (
     "sea_attention_fwd", "sea_rownorm", "sea_silu_outer", "sea_ib_add", "sea_convert_f32_to_act", "sea_selftest_mfma",
     "sea_mse_fwd_bwd", "sea_relative_mse", "sea_adamw_flat",
     "sea_wgrad_grouped", "sea_transpose_weights", "sea_rownorm_bwd", "sea_silu_outer_bwd", "sea_ib_bwd",
-    "sea_attention_bwd", "sea_dropout_mask", "sea_run_list", "sea_unpatchify", "sea_gemm_rownorm", "sea_exchange_tail", "sea_patchify", "sea_silu_outer_ib", "sea_mlp_fc1_ln_gelu", "sea_kv_rollout", "sea_kv_arena_words",
+    "sea_attention_bwd", "sea_dropout_mask", "sea_run_list", "sea_unpatchify", "sea_gemm_rownorm", "sea_exchange_tail", "sea_patchify", "sea_silu_outer_ib", "sea_mlp_fc1_ln_gelu", "sea_kv_rollout", "sea_kv_arena_words", "sea_kv_debug_stamps",
 )
 
 

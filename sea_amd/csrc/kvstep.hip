@@ -1103,8 +1103,13 @@ struct KvPersist {
     unsigned long long* gxr2;      // [F, E]   x after the exchange (tail -> fc)
     unsigned long long* gh;        // [F, S]   fc1 rows (fc -> fc)
     unsigned long long* gx3;       // [F, E]   x after fc2 (fc -> proj)
+    unsigned long long* stamps;    // tuning aid (sea_kv_debug_stamps): [n_steps, 16 roles, 4] values of the 100 MHz device clock, or NULL
 };
 
+// event k (< 4) of role slot `slot` (< 16) at step s: the device-wide 100 MHz clock (tuning aid, off unless a buffer was registered)
+__device__ __forceinline__ void stamp(const KvPersist& A, int s, int slot, int k) {
+    if (A.stamps != nullptr && threadIdx.x == 0) A.stamps[((int64_t)s * 16 + slot) * 4 + k] = wall_clock64();
+}
 __device__ __forceinline__ void gr_put(unsigned long long* g, float v, uint32_t tag) {
     __hip_atomic_store(g, ((unsigned long long)tag << 32) | (unsigned long long)__builtin_bit_cast(uint32_t, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -1117,6 +1122,21 @@ __device__ __forceinline__ float gr_get(const unsigned long long* g, uint32_t ta
     __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return 0.f;
 }
+// two words with both loads in flight at once (one round trip when both are there)
+__device__ __forceinline__ void gr_get2(const unsigned long long* g0, const unsigned long long* g1, uint32_t tag, int32_t* err, float& v0, float& v1) {
+    for (int it = 0; it < KV_SPIN_LIMIT; ++it) {
+        const unsigned long long p0 = __hip_atomic_load(g0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long p1 = __hip_atomic_load(g1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((uint32_t)(p0 >> 32) == tag && (uint32_t)(p1 >> 32) == tag) {
+            v0 = __builtin_bit_cast(float, (uint32_t)p0);
+            v1 = __builtin_bit_cast(float, (uint32_t)p1);
+            return;
+        }
+        __builtin_amdgcn_s_sleep(1);
+    }
+    __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    v0 = v1 = 0.f;
+}
 // One lane waits (politely) until the first word of a vector carries the tag — the producers are then in this phase — before the whole workgroup
 // starts polling its own words: hundreds of spinning lanes would otherwise sit on the fabric for most of every step.
 __device__ __forceinline__ void gr_wait_first(const unsigned long long* g, uint32_t tag, int tid) {
@@ -1124,7 +1144,7 @@ __device__ __forceinline__ void gr_wait_first(const unsigned long long* g, uint3
         for (int it = 0; it < KV_SPIN_LIMIT; ++it) {
             const unsigned long long pk = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if ((uint32_t)(pk >> 32) == tag) break;
-            __builtin_amdgcn_s_sleep(8);
+            __builtin_amdgcn_s_sleep(1);
         }
     }
     __syncthreads();
@@ -1161,19 +1181,21 @@ __device__ __attribute__((noinline)) void role_self(const KvPersist& A, float* s
         KRegs<T, HD> kr;
         k_prefetch<true, true, T, HD>(kr, Kc, pos, tid, nth);
         const float* ibp = (A.L.ib != nullptr && !A.G.ib_after_cross) ? A.L.ib + crow * E : nullptr;
-        if (s > 0) gr_wait_first(A.gx + i * E, tag - 1, tid);
         if (tid < E) {
             const float xv = s == 0 ? A.G.traj[((int64_t)pos * F + i) * E + tid] : gr_get(A.gx + i * E + tid, tag - 1, A.G.err);
             xs[tid] = xv + (ibp != nullptr ? ibp[tid] : 0.f);
         }
         __syncthreads();
+        if (h == 0 && i == 0) stamp(A, s, 0, 0);
         wg_norm_r<1, T>(xs, ns, nsT, E, nr, false, red, tid, nth);
         pre_finish<KE, T, 1>(rw, static_cast<const T*>(Fd.Wqkv), E, E, 3 * HD, ns, nsT, qkv, rowmap, tid, nth);
         __syncthreads();
         head_finish<true, T, HD>(hr, qkv, true, Kc + (int64_t)pos * HD, Vc + (int64_t)pos * HD, tid);
+        if (h == 0 && i == 0) stamp(A, s, 0, 1);
         float m, l;
         wg_attend<true, true, T, HD>(kr, Kc, Vc, pos, true, qkv, qkv + HD, qkv + 2 * HD, prob, part, oacc, red, m, l, tid, nth);
         if (tid < HD) gr_put(A.gatt + i * E + h * HD + tid, oacc[tid] / l, tag);
+        if (h == 0 && i == 0) stamp(A, s, 0, 2);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this step's cache row has left the CU before the next step's loads are issued
         __syncthreads();
     }
@@ -1206,7 +1228,6 @@ __device__ __attribute__((noinline)) void role_oproj(const KvPersist& A, float* 
         const float* ibp = (A.L.ib != nullptr && !A.G.ib_after_cross) ? A.L.ib + crow * E : nullptr;
         float xv = 0.f;
         if (tid < E) xv = (s == 0 ? A.G.traj[((int64_t)pos * F + i) * E + tid] : gr_get(A.gx + i * E + tid, tag - 1, A.G.err)) + (ibp != nullptr ? ibp[tid] : 0.f);
-        gr_wait_first(A.gatt + i * E, tag, tid);
         if (tid < E) {
             const float av = gr_get(A.gatt + i * E + tid, tag, A.G.err);
             att[tid] = av;
@@ -1214,6 +1235,7 @@ __device__ __attribute__((noinline)) void role_oproj(const KvPersist& A, float* 
             xs[tid] = xv;
         }
         __syncthreads();
+        if (i == 0) stamp(A, s, 1, 0);
         pre_finish<KE, T, tiles_per_wave(KE, 8)>(rwo, static_cast<const T*>(Fd.Wo), E, E, E, att, attT, y, IdentityRow(), tid, nth);
         __syncthreads();
         if (tid < E) {
@@ -1231,6 +1253,7 @@ __device__ __attribute__((noinline)) void role_oproj(const KvPersist& A, float* 
             wg_norm_r<1, T>(y, y, nullptr, D, nr, false, red, tid, nth);
             if (tid < D) gr_put(A.gnd + i * D + tid, y[tid], tag);
         }
+        if (i == 0) stamp(A, s, 1, 1);
         __syncthreads();
     }
 }
@@ -1271,7 +1294,8 @@ __device__ __attribute__((noinline)) void role_cross(const KvPersist& A, float* 
         k_prefetch<true, true, T, HD>(kr, Kc, old_src ? pos : pos - 1, tid, nth);
         gr_wait_first(A.gnd + (i > j ? i : j) * D, tag, tid);
         if (tid < D) {
-            const float a = gr_get(A.gnd + i * D + tid, tag, A.G.err), c = gr_get(A.gnd + j * D + tid, tag, A.G.err);
+            float a, c;
+            gr_get2(A.gnd + i * D + tid, A.gnd + j * D + tid, tag, A.G.err, a, c);
             ni[tid] = a;
             nj[tid] = c;
             niT[tid] = from_f32<T>(a);
@@ -1279,6 +1303,7 @@ __device__ __attribute__((noinline)) void role_cross(const KvPersist& A, float* 
         }
         if (!old_src) k_prefetch_one<true, T, HD>(kr, Kc, pos - 1, tid, nth);
         __syncthreads();
+        if (h == 0 && (p == 0 || p == F * (F - 1) - 1)) stamp(A, s, p == 0 ? 2 : 3, 0);
         pre_finish<KD, T, 1>(rq, static_cast<const T*>(P.Wq), D, D, HD, ni, niT, qkv, qmap, tid, nth);
         if (old_src) pre_finish<KD, T, 1>(rkv, static_cast<const T*>(P.Wkv), D, D, 2 * HD, nj, njT, qkv + HD, kvmap, tid, nth);
         __syncthreads();
@@ -1291,6 +1316,7 @@ __device__ __attribute__((noinline)) void role_cross(const KvPersist& A, float* 
             gr_put(A.goc + po + tid, old_src ? oacc[tid] / l : oacc[tid], tag);
         }
         if (!old_src && tid < 2) gr_put(A.gml + (p * H + h) * 2 + tid, tid == 0 ? m : l, tag);
+        if (h == 0 && (p == 0 || p == F * (F - 1) - 1)) stamp(A, s, p == 0 ? 2 : 3, 1);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
@@ -1338,11 +1364,12 @@ __device__ __attribute__((noinline)) void role_tail(const KvPersist& A, float* s
         NormRegs<1> nr;
         if constexpr (HAS_DOWN) norm_issue<T, 1>(nr, D, Fd.ln_cross, crow, tid, nth);
         float gsum = 0.f;
+        if (tid < E) xs[tid] = gr_get(A.gxr + I * E + tid, tag, A.G.err);   // (published before the cross phase)
         // ---- sources not yet updated in this sweep (j > I): their heads' outputs are final
 #pragma unroll
         for (int s = I; s < NF - 1; ++s) {
             const int p = I * (NF - 1) + s;
-            gr_wait_first(A.goc + p * D + D - 1, tag, tid);
+            if (s == I) stamp(A, st, 4 + I, 0);
             if (tid < D) {
                 const float v = gr_get(A.goc + p * D + tid, tag, A.G.err);
                 o[tid] = v;
@@ -1353,12 +1380,24 @@ __device__ __attribute__((noinline)) void role_tail(const KvPersist& A, float* s
             __syncthreads();
             if (tid < D) gsum += gelu_erf(g[tid]);
         }
-        // ---- sources updated earlier in this sweep (j < I)
+        // ---- sources updated earlier in this sweep (j < I): what the cross-attention launch left for them (partials, queries) is there long before the
+        // updated rows are — gathered now, off the chain
+        float qvs[NNEW > 0 ? NNEW : 1], ovs[NNEW > 0 ? NNEW : 1], m0s[NNEW > 0 ? NNEW : 1], l0s[NNEW > 0 ? NNEW : 1];
+#pragma unroll
+        for (int j = 0; j < NNEW; ++j) {
+            qvs[j] = ovs[j] = m0s[j] = l0s[j] = 0.f;
+            if (tid < D) {
+                const int p = I * (NF - 1) + j, hh = tid / hd;
+                gr_get2(A.gqc + p * D + tid, A.goc + p * D + tid, tag, A.G.err, qvs[j], ovs[j]);
+                gr_get2(A.gml + (p * H + hh) * 2, A.gml + (p * H + hh) * 2 + 1, tag, A.G.err, m0s[j], l0s[j]);
+            }
+        }
 #pragma unroll
         for (int j = 0; j < NNEW; ++j) {
             const int p = I * (NF - 1) + j;
             const SeaKvPair& P = A.L.p[I][j];
-            float qv = 0.f, ov = 0.f, m0 = 0.f, l0 = 0.f, bk0 = 0.f, bk1 = 0.f, bv0 = 0.f, bv1 = 0.f;
+            const float qv = qvs[j], ov = ovs[j], m0 = m0s[j], l0 = l0s[j];
+            float bk0 = 0.f, bk1 = 0.f, bv0 = 0.f, bv1 = 0.f;
             float2 cs = make_float2(1.f, 0.f);
             if (tid < D / 2) {
                 const int hh = tid / hd2, t = tid - hh * hd2;
@@ -1368,18 +1407,13 @@ __device__ __attribute__((noinline)) void role_tail(const KvPersist& A, float* s
                 bv0 = P.bkv[D + 2 * tid];
                 bv1 = P.bkv[D + 2 * tid + 1];
             }
-            gr_wait_first(A.gnew + j * D, tag, tid);
             if (tid < D) {
                 const float v = gr_get(A.gnew + j * D + tid, tag, A.G.err);
                 nj[tid] = v;
                 njT[tid] = from_f32<T>(v);
-                const int hh = tid / hd;
-                qv = gr_get(A.gqc + p * D + tid, tag, A.G.err);
-                ov = gr_get(A.goc + p * D + tid, tag, A.G.err);
-                m0 = gr_get(A.gml + (p * H + hh) * 2, tag, A.G.err);
-                l0 = gr_get(A.gml + (p * H + hh) * 2 + 1, tag, A.G.err);
             }
             __syncthreads();
+            if (j == NNEW - 1) stamp(A, st, 4 + I, 1);
             if (j < 2) pre_finish<KD, T, NT_2D>(rkv[j < 2 ? j : 0], static_cast<const T*>(P.Wkv), D, D, 2 * D, nj, njT, kv, IdentityRow(), tid, nth);
             else wg_gemv<T>(static_cast<const T*>(P.Wkv), D, D, 2 * D, nj, kv, IdentityRow(), tid, nth);
             __syncthreads();
@@ -1419,7 +1453,6 @@ __device__ __attribute__((noinline)) void role_tail(const KvPersist& A, float* s
             gs[tid] = gsum;
             gsT[tid] = from_f32<T>(gsum);
         }
-        if (tid < E) xs[tid] = gr_get(A.gxr + I * E + tid, tag, A.G.err);   // (published before the cross phase: no wait to speak of)
         __syncthreads();
         pre_finish<KD, T, NT_E>(rup, static_cast<const T*>(Fd.Wup), D, D, E, gs, gsT, y, IdentityRow(), tid, nth);
         __syncthreads();
@@ -1437,11 +1470,13 @@ __device__ __attribute__((noinline)) void role_tail(const KvPersist& A, float* s
             __syncthreads();
             wg_norm_r<1, T>(y, y, nullptr, D, nr, false, red, tid, nth);
             if (tid < D) gr_put(A.gnew + I * D + tid, y[tid], tag);
+            stamp(A, st, 4 + I, 2);
         }
         // the rows appended above must have left this CU before anything downstream of x can lead to their being read (next step's cross attention)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (tid < E) gr_put(A.gxr2 + I * E + tid, xnew, tag);
+        stamp(A, st, 4 + I, 3);
         __syncthreads();
     }
 }
@@ -1504,15 +1539,18 @@ __device__ __attribute__((noinline)) void role_fc(const KvPersist& A, float* sm,
         gr_wait_first(gin + i * E, tag, tid);
         if (tid < E) xs[tid] = gr_get(gin + i * E + tid, tag, A.G.err) + ibv;
         __syncthreads();
+        if (k == 0 && (i == 0 || i == A.G.F - 1)) stamp(A, s, i == 0 ? 8 : 9, 0);
         const float xq = (tid < n2) ? xs[c0 + tid] : 0.f;                 // the residual of this workgroup's fc2 rows
         wg_norm_r<1, T>(xs, ns, nsT, E, nr, false, red, tid, nth);
         if (n1 > 0) pre_finish<KE, T, 1>(rw1, W1, E, E, n1, ns, nsT, ys, IdentityRow(), tid, nth);
         __syncthreads();
         if (tid < n1) gr_put(A.gh + (int64_t)i * S + a0 + tid, ys[tid] + b1v, tag);
+        if (k == 0 && (i == 0 || i == A.G.F - 1)) stamp(A, s, i == 0 ? 8 : 9, 1);
         // ---- all rows of the field's hidden vector (every fc workgroup of the field contributes r1 of them)
         gr_wait_first(A.gh + (int64_t)i * S + S - 1, tag, tid);
         for (int e = tid; e < S; e += nth) hs[e] = gr_get(A.gh + (int64_t)i * S + e, tag, A.G.err);
         __syncthreads();
+        if (k == 0 && (i == 0 || i == A.G.F - 1)) stamp(A, s, i == 0 ? 8 : 9, 2);
         wg_norm_r<8, T>(hs, hs, nullptr, S, nrs, true, red, tid, nth);
         if (n2 > 0) {
             if (kc == 256) gemv_apply<T, 4, 1>(w4, S, n2, 0, hs, ys, tid, nth);
@@ -1521,6 +1559,7 @@ __device__ __attribute__((noinline)) void role_fc(const KvPersist& A, float* sm,
         }
         __syncthreads();
         if (tid < n2) gr_put(A.gx3 + i * E + c0 + tid, ys[tid] + b2v + xq, tag);
+        if (k == 0 && (i == 0 || i == A.G.F - 1)) stamp(A, s, i == 0 ? 8 : 9, 3);
         __syncthreads();
     }
 }
@@ -1543,13 +1582,13 @@ __device__ __attribute__((noinline)) void role_proj(const KvPersist& A, float* s
         const uint32_t tag = A.tag0 + (uint32_t)s;
         NormRegs<1> nr;
         norm_issue<T, 1>(nr, E, A.G.final_ln[i], (int64_t)pos, tid, nth);
-        gr_wait_first(A.gx3 + i * E + E - 1, tag, tid);
         if (tid < E) {
             const float v = gr_get(A.gx3 + i * E + tid, tag, A.G.err);
             xs[tid] = v;
             xsT[tid] = from_f32<T>(v);
         }
         __syncthreads();
+        if (i == 0 || i == F - 1) stamp(A, s, i == 0 ? 10 : 11, 0);
         pre_finish<KE, T, tiles_per_wave(KE, 8)>(rw, static_cast<const T*>(Fd.Wproj), E, E, E, xs, xsT, y, IdentityRow(), tid, nth);
         __syncthreads();
         if (tid < E) y[tid] += bp;
@@ -1559,6 +1598,7 @@ __device__ __attribute__((noinline)) void role_proj(const KvPersist& A, float* s
             A.G.traj[((int64_t)(pos + 1) * F + i) * E + tid] = y[tid];
             gr_put(A.gx + i * E + tid, y[tid], tag);
         }
+        if (i == 0 || i == F - 1) stamp(A, s, i == 0 ? 10 : 11, 1);
         __syncthreads();
     }
 }
@@ -1655,6 +1695,8 @@ static int run_steps(const SeaKvGlobal& G, const SeaKvLayer* layers, int pos0, i
     return 0;
 }
 
+static unsigned long long* g_kv_stamps = nullptr;   // sea_kv_debug_stamps
+
 // Words of the granule arena the persistent form needs (SeaKvGlobal.handoff; the first F * D words are the tails' hand-off of the seven-launch form).
 static int64_t persist_words(const SeaKvGlobal& G) {
     const int64_t F = G.F, E = G.E, D = G.D, S = G.S, H = G.H, P = F * (F - 1);
@@ -1698,6 +1740,7 @@ static bool run_persistent(const SeaKvGlobal& G, const SeaKvLayer* layers, int p
         A.gqc = g; g += P * D;
         A.gml = g; g += P * H * 2;
         A.gh = g;
+        A.stamps = g_kv_stamps;
         const int hd_c = hd_s / 2, cap = G.cap;
         int lds = (3 * E + 4 * hd_s + 32 + 8 * hd_s + cap + 8);
         const int lds_c = (4 * D + 4 * hd_c + 32 + 8 * hd_c + cap + 8), lds_t = 9 * D + 3 * E + 32, lds_f = 3 * E + S + 128 + 32, lds_b = 5 * E + 32;
@@ -1723,6 +1766,9 @@ static int run_steps_t(const SeaKvGlobal& G, const SeaKvLayer* layers, int pos0,
 }
 
 }  // namespace
+
+// Tuning aid: a device buffer of n_steps * 64 8-byte words receives time stamps of the persistent form's hand-offs (NULL: off).  Not part of the ABI proper.
+extern "C" void sea_kv_debug_stamps(unsigned long long* buf) { g_kv_stamps = buf; }
 
 extern "C" int64_t sea_kv_arena_words(const SeaKvGlobal* G) { return G != nullptr ? persist_words(*G) : 0; }
 
