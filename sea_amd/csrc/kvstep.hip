@@ -1113,17 +1113,34 @@ __device__ __forceinline__ void stamp(const KvPersist& A, int s, int slot, int k
 __device__ __forceinline__ void gr_put(unsigned long long* g, float v, uint32_t tag) {
     __hip_atomic_store(g, ((unsigned long long)tag << 32) | (unsigned long long)__builtin_bit_cast(uint32_t, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ __forceinline__ float gr_get(const unsigned long long* g, uint32_t tag, int32_t* err) {
+// A wait that gives up sets the error word; every other wait looks at that word every 256 polls and, once it is set, stops waiting for good
+// (`dead`): a rollout whose workgroups are not all on the chip drains in seconds instead of n_steps x the spin limit.
+struct ErrCtx {
+    int32_t* err;
+    int dead;
+};
+__device__ __forceinline__ bool gr_give_up(ErrCtx& ec, int it) {
+    if ((it & 255) == 255 && __hip_atomic_load(ec.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) ec.dead = 1;
+    if (it == KV_SPIN_LIMIT - 1) {
+        __hip_atomic_store(ec.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ec.dead = 1;
+    }
+    return ec.dead != 0;
+}
+__device__ __forceinline__ float gr_get(const unsigned long long* g, uint32_t tag, ErrCtx& ec) {
+    if (ec.dead) return 0.f;
     for (int it = 0; it < KV_SPIN_LIMIT; ++it) {
         const unsigned long long pk = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if ((uint32_t)(pk >> 32) == tag) return __builtin_bit_cast(float, (uint32_t)pk);
+        if (gr_give_up(ec, it)) break;
         __builtin_amdgcn_s_sleep(1);
     }
-    __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return 0.f;
 }
 // two words with both loads in flight at once (one round trip when both are there)
-__device__ __forceinline__ void gr_get2(const unsigned long long* g0, const unsigned long long* g1, uint32_t tag, int32_t* err, float& v0, float& v1) {
+__device__ __forceinline__ void gr_get2(const unsigned long long* g0, const unsigned long long* g1, uint32_t tag, ErrCtx& ec, float& v0, float& v1) {
+    v0 = v1 = 0.f;
+    if (ec.dead) return;
     for (int it = 0; it < KV_SPIN_LIMIT; ++it) {
         const unsigned long long p0 = __hip_atomic_load(g0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const unsigned long long p1 = __hip_atomic_load(g1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1132,18 +1149,18 @@ __device__ __forceinline__ void gr_get2(const unsigned long long* g0, const unsi
             v1 = __builtin_bit_cast(float, (uint32_t)p1);
             return;
         }
+        if (gr_give_up(ec, it)) break;
         __builtin_amdgcn_s_sleep(1);
     }
-    __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    v0 = v1 = 0.f;
 }
 // One lane waits (politely) until the first word of a vector carries the tag — the producers are then in this phase — before the whole workgroup
 // starts polling its own words: hundreds of spinning lanes would otherwise sit on the fabric for most of every step.
-__device__ __forceinline__ void gr_wait_first(const unsigned long long* g, uint32_t tag, int tid) {
-    if (tid == 0) {
+__device__ __forceinline__ void gr_wait_first(const unsigned long long* g, uint32_t tag, ErrCtx& ec, int tid) {
+    if (tid == 0 && !ec.dead) {
         for (int it = 0; it < KV_SPIN_LIMIT; ++it) {
             const unsigned long long pk = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if ((uint32_t)(pk >> 32) == tag) break;
+            if (gr_give_up(ec, it)) break;
             __builtin_amdgcn_s_sleep(1);
         }
     }
@@ -1155,6 +1172,7 @@ __device__ __attribute__((noinline)) void role_self(const KvPersist& A, float* s
     constexpr int E = KE;
     const int H = A.G.H, F = A.G.F, cap = A.G.cap;
     const int tid = threadIdx.x, nth = 512;
+    ErrCtx ec{A.G.err, 0};
     float* xs = sm;
     float* ns = xs + E;
     T* nsT = reinterpret_cast<T*>(ns + E);
@@ -1182,7 +1200,7 @@ __device__ __attribute__((noinline)) void role_self(const KvPersist& A, float* s
         k_prefetch<true, true, T, HD>(kr, Kc, pos, tid, nth);
         const float* ibp = (A.L.ib != nullptr && !A.G.ib_after_cross) ? A.L.ib + crow * E : nullptr;
         if (tid < E) {
-            const float xv = s == 0 ? A.G.traj[((int64_t)pos * F + i) * E + tid] : gr_get(A.gx + i * E + tid, tag - 1, A.G.err);
+            const float xv = s == 0 ? A.G.traj[((int64_t)pos * F + i) * E + tid] : gr_get(A.gx + i * E + tid, tag - 1, ec);
             xs[tid] = xv + (ibp != nullptr ? ibp[tid] : 0.f);
         }
         __syncthreads();
@@ -1206,6 +1224,7 @@ __device__ __attribute__((noinline)) void role_oproj(const KvPersist& A, float* 
     constexpr int E = KE, D = KD;
     const int F = A.G.F;
     const int tid = threadIdx.x, nth = 512;
+    ErrCtx ec{A.G.err, 0};
     float* att = sm;
     float* xs = att + E;
     float* y = xs + E;
@@ -1227,9 +1246,9 @@ __device__ __attribute__((noinline)) void role_oproj(const KvPersist& A, float* 
         if (ex) norm_issue<T, 1>(nr, D, Fd.ln_cross, crow, tid, nth);
         const float* ibp = (A.L.ib != nullptr && !A.G.ib_after_cross) ? A.L.ib + crow * E : nullptr;
         float xv = 0.f;
-        if (tid < E) xv = (s == 0 ? A.G.traj[((int64_t)pos * F + i) * E + tid] : gr_get(A.gx + i * E + tid, tag - 1, A.G.err)) + (ibp != nullptr ? ibp[tid] : 0.f);
+        if (tid < E) xv = (s == 0 ? A.G.traj[((int64_t)pos * F + i) * E + tid] : gr_get(A.gx + i * E + tid, tag - 1, ec)) + (ibp != nullptr ? ibp[tid] : 0.f);
         if (tid < E) {
-            const float av = gr_get(A.gatt + i * E + tid, tag, A.G.err);
+            const float av = gr_get(A.gatt + i * E + tid, tag, ec);
             att[tid] = av;
             attT[tid] = from_f32<T>(av);
             xs[tid] = xv;
@@ -1263,6 +1282,7 @@ __device__ __attribute__((noinline)) void role_cross(const KvPersist& A, float* 
     constexpr int D = KD;
     const int H = A.G.H, F = A.G.F, cap = A.G.cap;
     const int tid = threadIdx.x, nth = 512;
+    ErrCtx ec{A.G.err, 0};
     const int i = p / (F - 1), sx = p % (F - 1), j = sx < i ? sx : sx + 1;
     const bool old_src = j > i;
     float* ni = sm;
@@ -1292,10 +1312,10 @@ __device__ __attribute__((noinline)) void role_cross(const KvPersist& A, float* 
         // is there once this step's hand-off chain has reached this workgroup — everything but that row is requested now, that row after the wait
         KRegs<T, HD> kr;
         k_prefetch<true, true, T, HD>(kr, Kc, old_src ? pos : pos - 1, tid, nth);
-        gr_wait_first(A.gnd + (i > j ? i : j) * D, tag, tid);
+        gr_wait_first(A.gnd + (i > j ? i : j) * D, tag, ec, tid);
         if (tid < D) {
             float a, c;
-            gr_get2(A.gnd + i * D + tid, A.gnd + j * D + tid, tag, A.G.err, a, c);
+            gr_get2(A.gnd + i * D + tid, A.gnd + j * D + tid, tag, ec, a, c);
             ni[tid] = a;
             nj[tid] = c;
             niT[tid] = from_f32<T>(a);
@@ -1331,6 +1351,7 @@ __device__ __attribute__((noinline)) void role_tail(const KvPersist& A, float* s
     const int H = A.G.H, cap = A.G.cap;
     const int hd = D / H, hd2 = hd >> 1;
     const int tid = threadIdx.x, nth = 512;
+    ErrCtx ec{A.G.err, 0};
     float* nj = sm;
     float* kv = nj + D;
     float* o = kv + 2 * D;
@@ -1364,14 +1385,14 @@ __device__ __attribute__((noinline)) void role_tail(const KvPersist& A, float* s
         NormRegs<1> nr;
         if constexpr (HAS_DOWN) norm_issue<T, 1>(nr, D, Fd.ln_cross, crow, tid, nth);
         float gsum = 0.f;
-        if (tid < E) xs[tid] = gr_get(A.gxr + I * E + tid, tag, A.G.err);   // (published before the cross phase)
+        if (tid < E) xs[tid] = gr_get(A.gxr + I * E + tid, tag, ec);   // (published before the cross phase)
         // ---- sources not yet updated in this sweep (j > I): their heads' outputs are final
 #pragma unroll
         for (int s = I; s < NF - 1; ++s) {
             const int p = I * (NF - 1) + s;
             if (s == I) stamp(A, st, 4 + I, 0);
             if (tid < D) {
-                const float v = gr_get(A.goc + p * D + tid, tag, A.G.err);
+                const float v = gr_get(A.goc + p * D + tid, tag, ec);
                 o[tid] = v;
                 oT[tid] = from_f32<T>(v);
             }
@@ -1388,8 +1409,8 @@ __device__ __attribute__((noinline)) void role_tail(const KvPersist& A, float* s
             qvs[j] = ovs[j] = m0s[j] = l0s[j] = 0.f;
             if (tid < D) {
                 const int p = I * (NF - 1) + j, hh = tid / hd;
-                gr_get2(A.gqc + p * D + tid, A.goc + p * D + tid, tag, A.G.err, qvs[j], ovs[j]);
-                gr_get2(A.gml + (p * H + hh) * 2, A.gml + (p * H + hh) * 2 + 1, tag, A.G.err, m0s[j], l0s[j]);
+                gr_get2(A.gqc + p * D + tid, A.goc + p * D + tid, tag, ec, qvs[j], ovs[j]);
+                gr_get2(A.gml + (p * H + hh) * 2, A.gml + (p * H + hh) * 2 + 1, tag, ec, m0s[j], l0s[j]);
             }
         }
 #pragma unroll
@@ -1408,7 +1429,7 @@ __device__ __attribute__((noinline)) void role_tail(const KvPersist& A, float* s
                 bv1 = P.bkv[D + 2 * tid + 1];
             }
             if (tid < D) {
-                const float v = gr_get(A.gnew + j * D + tid, tag, A.G.err);
+                const float v = gr_get(A.gnew + j * D + tid, tag, ec);
                 nj[tid] = v;
                 njT[tid] = from_f32<T>(v);
             }
@@ -1502,6 +1523,7 @@ __device__ __attribute__((noinline)) void role_fc(const KvPersist& A, float* sm,
     constexpr int E = KE, EPC = ActTraits<T>::EPC;
     const int S = A.G.S, exch = A.G.exchange;
     const int tid = threadIdx.x, nth = 512;
+    ErrCtx ec{A.G.err, 0};
     float* xs = sm;
     float* ns = xs + E;
     T* nsT = reinterpret_cast<T*>(ns + E);
@@ -1536,8 +1558,8 @@ __device__ __attribute__((noinline)) void role_fc(const KvPersist& A, float* sm,
         norm_issue<T, 1>(nr, E, Fd.ln2, crow, tid, nth);
         const float* ibp = (A.L.ib != nullptr && A.G.ib_after_cross) ? A.L.ib + crow * E : nullptr;
         const float ibv = (ibp != nullptr && tid < E) ? ibp[tid] : 0.f;
-        gr_wait_first(gin + i * E, tag, tid);
-        if (tid < E) xs[tid] = gr_get(gin + i * E + tid, tag, A.G.err) + ibv;
+        gr_wait_first(gin + i * E, tag, ec, tid);
+        if (tid < E) xs[tid] = gr_get(gin + i * E + tid, tag, ec) + ibv;
         __syncthreads();
         if (k == 0 && (i == 0 || i == A.G.F - 1)) stamp(A, s, i == 0 ? 8 : 9, 0);
         const float xq = (tid < n2) ? xs[c0 + tid] : 0.f;                 // the residual of this workgroup's fc2 rows
@@ -1547,8 +1569,8 @@ __device__ __attribute__((noinline)) void role_fc(const KvPersist& A, float* sm,
         if (tid < n1) gr_put(A.gh + (int64_t)i * S + a0 + tid, ys[tid] + b1v, tag);
         if (k == 0 && (i == 0 || i == A.G.F - 1)) stamp(A, s, i == 0 ? 8 : 9, 1);
         // ---- all rows of the field's hidden vector (every fc workgroup of the field contributes r1 of them)
-        gr_wait_first(A.gh + (int64_t)i * S + S - 1, tag, tid);
-        for (int e = tid; e < S; e += nth) hs[e] = gr_get(A.gh + (int64_t)i * S + e, tag, A.G.err);
+        gr_wait_first(A.gh + (int64_t)i * S + S - 1, tag, ec, tid);
+        for (int e = tid; e < S; e += nth) hs[e] = gr_get(A.gh + (int64_t)i * S + e, tag, ec);
         __syncthreads();
         if (k == 0 && (i == 0 || i == A.G.F - 1)) stamp(A, s, i == 0 ? 8 : 9, 2);
         wg_norm_r<8, T>(hs, hs, nullptr, S, nrs, true, red, tid, nth);
@@ -1569,6 +1591,7 @@ __device__ __attribute__((noinline)) void role_proj(const KvPersist& A, float* s
     constexpr int E = KE;
     const int F = A.G.F;
     const int tid = threadIdx.x, nth = 512;
+    ErrCtx ec{A.G.err, 0};
     float* xs = sm;
     float* y = xs + E;
     T* xsT = reinterpret_cast<T*>(y + E);
@@ -1583,7 +1606,7 @@ __device__ __attribute__((noinline)) void role_proj(const KvPersist& A, float* s
         NormRegs<1> nr;
         norm_issue<T, 1>(nr, E, A.G.final_ln[i], (int64_t)pos, tid, nth);
         if (tid < E) {
-            const float v = gr_get(A.gx3 + i * E + tid, tag, A.G.err);
+            const float v = gr_get(A.gx3 + i * E + tid, tag, ec);
             xs[tid] = v;
             xsT[tid] = from_f32<T>(v);
         }

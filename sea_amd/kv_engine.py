@@ -170,11 +170,19 @@ class KvFast:
         for l in range(self.L):
             self.layers[l].ib = cp.ibufs[l].data_ptr() if (cp is not None and self.has_ib) else None
         self.G.traj = traj.data_ptr()
-        rc = N.lib().sea_kv_rollout(C.byref(self.G), self.layers, 0, n_steps, self._tag, N.dtype_code(eng.act_dtype), N.stream_ptr())
-        N.check(rc, "sea_kv_rollout")
-        self._tag = (self._tag + n_steps * self.L) & 0xFFFFFFFF or 1
-        out = traj[1:].permute(1, 0, 2, 3).contiguous()
-        if int(self.err.item()) != 0:   # (synchronises)
+        for attempt in (0, 1):
+            rc = N.lib().sea_kv_rollout(C.byref(self.G), self.layers, 0, n_steps, self._tag, N.dtype_code(eng.act_dtype), N.stream_ptr())
+            N.check(rc, "sea_kv_rollout")
+            self._tag = (self._tag + n_steps * self.L) & 0xFFFFFFFF or 1
+            out = traj[1:].permute(1, 0, 2, 3).contiguous()
+            if int(self.err.item()) == 0:   # (synchronises)
+                return out
+            # A hand-off wait gave up: the persistent form needs all its workgroups on the chip at once, which another process on the same GPU can
+            # deny.  Nothing is lost but time — every spin is bounded, the trajectory is recomputed from position 0 — so fall back once, for good, to
+            # the seven launches per step (their only hand-off is between workgroups of one 3-workgroup launch).
             self.err.zero_()
+            if attempt == 0 and self.G.handoff_words > B * F * max(self.D, 1):
+                self.G.handoff_words = B * F * max(self.D, 1)
+                continue
             raise RuntimeError("sea_kv_rollout: a hand-off wait inside the exchange tails gave up (results invalid)")
         return out
