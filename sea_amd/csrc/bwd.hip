@@ -366,7 +366,7 @@ __global__ __launch_bounds__(256) void rownorm_bwd_kernel(const NormBwdLaunch L)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const float xh = (xv[e] - mean) * rstd;
-                if (L.gelu) dv[e] *= gelu_erf_grad(xh * s[e] + tt[e]);
+                if (L.gelu) dv[e] *= gelu_grad_for<T>(xh * s[e] + tt[e]);
                 const float dxh = dv[e] * s[e];
                 c1 += dxh;
                 c2 += dxh * xh;
@@ -446,7 +446,7 @@ __global__ __launch_bounds__(256) void rownorm_bwd_kernel(const NormBwdLaunch L)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const float xh = (xv[e] - mean) * rstd;
-                if (L.gelu) dv[e] *= gelu_erf_grad(xh * s[e] + tt[e]);
+                if (L.gelu) dv[e] *= gelu_grad_for<T>(xh * s[e] + tt[e]);
                 o[e] = rstd * (dv[e] * s[e] - c1 - xh * c2);
             }
             emit(i, o);
@@ -544,7 +544,7 @@ __global__ __launch_bounds__(256) void rownorm_bwd_wide_kernel(const NormBwdLaun
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const float xh = (xv[k][e] - mean) * rstd;
-                    if (L.gelu) dv[k][e] *= gelu_erf_grad(xh * s[k][e] + tt[k][e]);
+                    if (L.gelu) dv[k][e] *= gelu_grad_for<T>(xh * s[k][e] + tt[k][e]);
                     const float dxh = dv[k][e] * s[k][e];
                     c1 += dxh;
                     c2 += dxh * xh;

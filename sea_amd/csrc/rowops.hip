@@ -37,7 +37,7 @@ __global__ __launch_bounds__(256) void rownorm_kernel(const NormLaunch L) {
             const float gq = mod != nullptr ? gm[e] + 1.0f + mw[e] : gm[e];
             const float bq = mod != nullptr ? bt[e] + mb[e] : bt[e];
             o[e] = (v[e] - mean) * rstd * gq + bq;
-            if (L.gelu) o[e] = gelu_erf(o[e]);
+            if (L.gelu) o[e] = y32 != nullptr ? gelu_erf(o[e]) : gelu_for<T>(o[e]);   // (an output that only exists in bf16 takes the polynomial form)
         }
         if (y32 != nullptr) store4(y32 + i, o[0], o[1], o[2], o[3]);
         if (yact != nullptr) store4(yact + i, o[0], o[1], o[2], o[3]);
