@@ -76,10 +76,11 @@ def record_work(rec, esz):
     elif rec.fn is L.sea_mlp_fc1_ln_gelu:
         for g in a[0][:a[1]]:
             fl += 2 * g.M * g.E * g.S
-            by += g.M * g.E * esz + g.S * g.E * esz + 3 * g.S * 4 + g.M * g.S * esz
+            rows_in = g.M * g.E * esz if not g.X32 else g.M * g.E * 4 * (1 + (1 if g.addend else 0) + (1 if g.Xout else 0)) + (g.M * 2 * g.E * esz if g.mod else 0)
+            by += rows_in + g.S * g.E * esz + 3 * g.S * 4 + g.M * g.S * esz
     elif rec.fn is L.sea_exchange_tail:
         for g in rec.keep[:a[1]]:
-            fl += g.n_seg * 2 * g.M * g.D * g.D * (0 if g.plain else 1) + 2 * g.M * g.D * g.E + (2 * g.M * g.E * g.D if g.has_down else 0)
+            fl += g.n_seg * 2 * g.M * g.D * g.D + 2 * g.M * g.D * g.E + (2 * g.M * g.E * g.D if g.has_down else 0)
             by += g.n_seg * (g.M * g.D * esz + g.D * g.D * esz) + g.D * g.E * esz + 2 * g.M * g.E * 4 + (g.E * g.D * esz + g.M * g.D * esz if g.has_down else 0)
     elif rec.fn is L.sea_attention_fwd:
         P = rec.keep

@@ -288,6 +288,19 @@ typedef struct {
     void* Hg;           /* act [M, S], row stride ldh */
     int32_t lda, ldw, ldh;
     int32_t M, E, S;
+    /* Optional prologue (X32 != NULL; A is then ignored): the operand rows are produced inside the launch from the fp32 residual stream —
+     *     x = X32 (+ addend);  Xout <- x when non-NULL (may be X32);  A row = (x - mean) * rstd * (gamma [+ 1 + mod[0:E]]) + (beta [+ mod[E:2E]])
+     * i.e. the info-bottleneck add and AdaLN_2 / LayerNorm in front of the MLP (models/temporal.py:139-145; SeaNormGroup's semantics, two-pass fp32
+     * statistics): one launch less on the chain, the normalised rows never reach HBM. */
+    const float* X32;    /* f32 [M, E], row stride ldx32 */
+    const float* addend; /* f32 [M, E], row stride ldadd, or NULL */
+    float* Xout;         /* f32 [M, E], row stride ldxout, or NULL */
+    const void* mod;     /* act [M, 2E] (scale | shift), row stride ldmod, or NULL */
+    const float* gamma;  /* f32 [E] */
+    const float* beta;   /* f32 [E] or NULL */
+    int32_t ldx32, ldadd, ldxout, ldmod;
+    float norm_eps;
+    int32_t pad_;
 } SeaMlpGroup;
 
 int sea_mlp_fc1_ln_gelu(const SeaMlpGroup* groups, int n_groups, float eps, int dtype, void* stream);

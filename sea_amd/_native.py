@@ -143,7 +143,9 @@ MAX_MLP_GROUPS = 8
 
 class SeaMlpGroup(C.Structure):
     _fields_ = [("A", _vp), ("W1", _vp), ("b1", _vp), ("lnw", _vp), ("lnb", _vp), ("Hg", _vp),
-                ("lda", _i32), ("ldw", _i32), ("ldh", _i32), ("M", _i32), ("E", _i32), ("S", _i32)]
+                ("lda", _i32), ("ldw", _i32), ("ldh", _i32), ("M", _i32), ("E", _i32), ("S", _i32),
+                ("X32", _vp), ("addend", _vp), ("Xout", _vp), ("mod", _vp), ("gamma", _vp), ("beta", _vp),
+                ("ldx32", _i32), ("ldadd", _i32), ("ldxout", _i32), ("ldmod", _i32), ("norm_eps", _f32), ("pad_", _i32)]
 
 
 KV_MAX_FIELDS = 4

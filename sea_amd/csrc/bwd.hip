@@ -205,10 +205,11 @@ extern "C" int sea_wgrad_grouped(const SeaWgradGroup* groups, int n_groups, int 
     long base_tiles = 0;
     for (int i = 0; i < n_groups; ++i) base_tiles += (long)((groups[i].N + ts - 1) / ts) * ((groups[i].K + ts - 1) / ts);
     // split the contraction so that the launch has ~2 workgroups per CU, never below 256 rows per split
+    static const int wg_target = []() { const char* e = getenv("SEA_WGRAD_TARGET"); return e ? atoi(e) : 512; }();  // tuning aid
     int total = 0;
     for (int i = 0; i < n_groups; ++i) {
         const SeaWgradGroup& G = groups[i];
-        long want = (512 + base_tiles - 1) / base_tiles;
+        long want = (wg_target + base_tiles - 1) / base_tiles;
         long max_splits = (G.M + 255) / 256;
         int splits = (int)(want < 1 ? 1 : (want > max_splits ? max_splits : want));
         int rows = ((G.M + splits - 1) / splits + 63) / 64 * 64;

@@ -56,6 +56,84 @@ __global__ __launch_bounds__(512) void mlp_fc1_ln_gelu_kernel(const MlpLaunch L)
     const unsigned lds_base = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)smem);
     const int rl = lane >> 3;
     const int chunk = (lane & 7) ^ (rl & 7);               // swizzle on the source side
+    // ---- optional prologue: the operand rows are the normalised rows of the fp32 residual stream (x + addend, AdaLN / LayerNorm), written straight into
+    // the A region in the K-tile-major, swizzled layout the LDS-DMA of ready-made rows would have produced.  16 lanes own a row (16 columns each), the
+    // statistics are two-pass like sea_rownorm's.  It runs BEFORE any LDS-DMA is issued (the compiler's wait for these loads is a vmcnt(0): behind the
+    // weight stream it would wait for that too; measured the other way round: 32.1 us per launch against 31.2).
+    if (G.X32 != nullptr) {
+        constexpr int E = KT * 64, CPT = E / 16;              // columns per lane
+        const int prow = tid >> 4, pl = tid & 15;              // 512 threads = 32 rows x 16 lanes
+        int row = m0 + prow;
+        const bool rok = row < M;
+        row = rok ? row : M - 1;
+        const int c0 = pl * CPT;
+        float xv[CPT];
+#pragma unroll
+        for (int c = 0; c < CPT; c += 4) load4(G.X32 + (int64_t)row * G.ldx32 + c0 + c, *reinterpret_cast<float(*)[4]>(xv + c));
+        if (G.addend != nullptr) {
+#pragma unroll
+            for (int c = 0; c < CPT; c += 4) {
+                float av[4];
+                load4(G.addend + (int64_t)row * G.ldadd + c0 + c, av);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) xv[c + e] += av[e];
+            }
+        }
+        float gq[CPT], bq[CPT];
+#pragma unroll
+        for (int c = 0; c < CPT; c += 4) {
+            load4(G.gamma + c0 + c, *reinterpret_cast<float(*)[4]>(gq + c));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) bq[c + e] = 0.f;
+            if (G.beta != nullptr) load4(G.beta + c0 + c, *reinterpret_cast<float(*)[4]>(bq + c));
+            if (G.mod != nullptr) {
+                float mw[4], mb[4];
+                const T* mod = static_cast<const T*>(G.mod) + (int64_t)row * G.ldmod;
+                load4(mod + c0 + c, mw);
+                load4(mod + E + c0 + c, mb);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    gq[c + e] += 1.0f + mw[e];
+                    bq[c + e] += mb[e];
+                }
+            }
+        }
+        if (G.Xout != nullptr && rok) {
+#pragma unroll
+            for (int c = 0; c < CPT; c += 4) store4(G.Xout + (int64_t)row * G.ldxout + c0 + c, xv[c], xv[c + 1], xv[c + 2], xv[c + 3]);
+        }
+        float s4[4] = {0.f, 0.f, 0.f, 0.f};   // (add1 / fma1: the vectoriser's packed horizontal adds are the form the build's lint refuses beside MFMAs)
+#pragma unroll
+        for (int c = 0; c < CPT; c += 4)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) s4[e] = add1(s4[e], xv[c + e]);
+        float sm_ = add1(add1(s4[0], s4[1]), add1(s4[2], s4[3]));
+#pragma unroll
+        for (int o = 8; o >= 1; o >>= 1) sm_ += __shfl_xor(sm_, o);
+        const float mean = sm_ * (1.0f / (float)E);
+        float q4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < CPT; c += 4)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float d_ = xv[c + e] - mean;
+                q4[e] = fma1(d_, d_, q4[e]);
+            }
+        float sq = add1(add1(q4[0], q4[1]), add1(q4[2], q4[3]));
+#pragma unroll
+        for (int o = 8; o >= 1; o >>= 1) sq += __shfl_xor(sq, o);
+        const float rstd = 1.0f / sqrtf(sq * (1.0f / (float)E) + G.norm_eps);
+        // column c0 + c of row prow -> K-tile (c0 + c) / 64, 16-byte chunk ((c0 + c) % 64) / 8 at position chunk ^ (row & 7)
+#pragma unroll
+        for (int c = 0; c < CPT; c += 8) {
+            const int col = c0 + c, kt = col >> 6, ck = (col & 63) >> 3;
+            bf16x8 pv;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) pv[e] = (__bf16)((xv[c + e] - mean) * rstd * gq[c + e] + bq[c + e]);
+            *reinterpret_cast<bf16x8*>(smem + kt * BM * BKB + prow * BKB + ((ck ^ (prow & 7)) << 4)) = pv;
+        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // (the Xout stores too: nothing of this wave is in the memory pipeline when the DMAs start)
+    }
     // ---- gains / shifts of the LayerNorm: 1 KiB pieces straight into LDS, oldest in the queue (the epilogue finds them there)
     for (int p = wave; p < 2 * (S / 256); p += NW) {
         const float* src = p < S / 256 ? G.lnw : G.lnb;
@@ -63,7 +141,7 @@ __global__ __launch_bounds__(512) void mlp_fc1_ln_gelu_kernel(const MlpLaunch L)
         glds16_mlp(src + q * 256 + lane * 4, lds_base + (unsigned)(PRM_OFF + p * 1024));
     }
     // ---- A rows: KT x 4 pieces of 8 rows
-    for (int p = wave; p < KT * (BM / 8); p += NW) {
+    for (int p = wave; G.X32 == nullptr && p < KT * (BM / 8); p += NW) {
         const int kt = p / (BM / 8), u = p - kt * (BM / 8);
         int row = m0 + u * 8 + rl;
         row = row < M ? row : M - 1;
@@ -240,8 +318,13 @@ extern "C" int sea_mlp_fc1_ln_gelu(const SeaMlpGroup* groups, int n_groups, floa
     for (int i = 0; i < n_groups; ++i) {
         const SeaMlpGroup& G = groups[i];
         SEA_REQUIRE(G.E == E && G.S == S && G.M >= 1, "sea_mlp_fc1_ln_gelu[%d]: the groups of a launch share E and S", i);
-        SEA_REQUIRE(G.A && G.W1 && G.b1 && G.lnw && G.lnb && G.Hg, "sea_mlp_fc1_ln_gelu[%d]: null pointer", i);
-        SEA_REQUIRE(G.lda % 8 == 0 && G.lda >= E && G.ldw % 8 == 0 && G.ldw >= E && G.ldh % 8 == 0 && G.ldh >= S, "sea_mlp_fc1_ln_gelu[%d]: bad strides", i);
+        SEA_REQUIRE((G.A || G.X32) && G.W1 && G.b1 && G.lnw && G.lnb && G.Hg, "sea_mlp_fc1_ln_gelu[%d]: null pointer", i);
+        SEA_REQUIRE((G.X32 || (G.lda % 8 == 0 && G.lda >= E)) && G.ldw % 8 == 0 && G.ldw >= E && G.ldh % 8 == 0 && G.ldh >= S, "sea_mlp_fc1_ln_gelu[%d]: bad strides", i);
+        if (G.X32 != nullptr)
+            SEA_REQUIRE(G.gamma && G.ldx32 % 4 == 0 && G.ldx32 >= E && (!G.addend || (G.ldadd % 4 == 0 && G.ldadd >= E)) && (!G.Xout || (G.ldxout % 4 == 0 && G.ldxout >= E)) &&
+                            (!G.mod || (G.ldmod % 8 == 0 && G.ldmod >= 2 * E)) && sea_aligned16(G.X32) && sea_aligned16(G.addend) && sea_aligned16(G.Xout) && sea_aligned16(G.mod) &&
+                            sea_aligned16(G.gamma) && sea_aligned16(G.beta) && G.norm_eps > 0.f,
+                        "sea_mlp_fc1_ln_gelu[%d]: norm prologue: null / misaligned pointer or bad stride", i);
         SEA_REQUIRE(sea_aligned16(G.A) && sea_aligned16(G.W1) && sea_aligned16(G.b1) && sea_aligned16(G.lnw) && sea_aligned16(G.lnb) && sea_aligned16(G.Hg),
                     "sea_mlp_fc1_ln_gelu[%d]: pointers must be 16-byte aligned", i);
         L.g[i] = G;

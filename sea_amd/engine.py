@@ -644,18 +644,27 @@ class Plan:
                 return dict(mod=mods[p_], gamma=P.f32_vec(p_ + "weight"), beta=P.f32_vec(p_ + "bias"))
             return dict(gamma=P.f32_vec(p_ + "weight"))
 
-        extra = (lambda i: dict(addend=addend, Xout=xr[i])) if addend is not None else (lambda i: {})   # x_i += ib rides in this pass
-        self._norm([dict(X=xr[i], Yact=n_e[i], **extra(i), **norm_params(f"{pre}ln.exp.{i}.2.", E)) for i in fields], E, ("mlp.ib_adaln2" if addend is not None else "mlp.adaln2") + tag)
         # Linear + nn.LayerNorm + GELU in one launch where the kernel is instantiated (bf16; SEA_FUSE_MLP1=0 keeps the two launches, =1 forces
         # the one launch).  Every workgroup of that kernel streams the whole of W1, so it needs enough 32-row tiles to pay: with the few rows
         # of a KV-cache step the two launches are faster (0.143 vs 0.163 ms per step at cfg2), hence the row threshold.
         want = os.environ.get("SEA_FUSE_MLP1", "auto")
-        if (type(self) is Plan and want != "0" and (want == "1" or self.M >= 1024) and ops.mlp_fc1_supported(self.dt, E, S) and len(fields) <= N.MAX_MLP_GROUPS):
+        fused = (type(self) is Plan and want != "0" and (want == "1" or self.M >= 1024) and ops.mlp_fc1_supported(self.dt, E, S) and len(fields) <= N.MAX_MLP_GROUPS)
+        # ... and the row pass in front of it (info-bottleneck add + AdaLN_2 / LayerNorm) as that launch's prologue: a workgroup owns its 32 rows from the
+        # fp32 residual stream to the activated hidden rows.  Measured (graph replay): cfg2 0.2472 -> 0.2440 ms (the launch itself 27.4 -> 31.2-32.2 us: its
+        # loads sit in front of the weight stream; the row pass it replaces is 7.8 us), B = 8 1.127 -> 1.138 ms (142 -> 171 us per launch against a 32 us row
+        # pass that runs at HBM speed) — used for short launches only.  SEA_FUSE_MLPNORM=0 / 1 forces.
+        wn = os.environ.get("SEA_FUSE_MLPNORM", "auto")
+        norm_in = fused and (wn == "1" or (wn == "auto" and self.M <= 4096))
+        extra = (lambda i: dict(addend=addend, Xout=xr[i])) if addend is not None else (lambda i: {})   # x_i += ib rides in this pass
+        if not norm_in:
+            self._norm([dict(X=xr[i], Yact=n_e[i], **extra(i), **norm_params(f"{pre}ln.exp.{i}.2.", E)) for i in fields], E, ("mlp.ib_adaln2" if addend is not None else "mlp.adaln2") + tag)
+        if fused:
             arr = (N.SeaMlpGroup * len(fields))()
             for g_, i in zip(arr, fields):
-                ops.fill_mlp_group(g_, n_e[i], P.act(f"{pre}mlp.{i}.layers.0.weight"), P.f32_vec(f"{pre}mlp.{i}.layers.0.bias"),
-                                   P.f32_vec(f"{pre}mlp.{i}.layers.1.weight"), P.f32_vec(f"{pre}mlp.{i}.layers.1.bias"), hg[i])
-            self._cur.append(self._rec(N.lib().sea_mlp_fc1_ln_gelu, [arr, len(fields), 1e-5, self.code], "mlp.fc1_ln_gelu" + tag, arr))
+                nrm = dict(X32=xr[i], **extra(i), **norm_params(f"{pre}ln.exp.{i}.2.", E)) if norm_in else None
+                ops.fill_mlp_group(g_, None if norm_in else n_e[i], P.act(f"{pre}mlp.{i}.layers.0.weight"), P.f32_vec(f"{pre}mlp.{i}.layers.0.bias"),
+                                   P.f32_vec(f"{pre}mlp.{i}.layers.1.weight"), P.f32_vec(f"{pre}mlp.{i}.layers.1.bias"), hg[i], nrm)
+            self._cur.append(self._rec(N.lib().sea_mlp_fc1_ln_gelu, [arr, len(fields), 1e-5, self.code], "mlp.fc1_ln_gelu" + tag, arr))   # (with or without the norm prologue: one name for the profiles)
         else:
             self._gemm([dict(A=n_e[i], W=P.act(f"{pre}mlp.{i}.layers.0.weight"), bias=P.f32_vec(f"{pre}mlp.{i}.layers.0.bias"), Cact=hbuf[i])
                         for i in fields], "mlp.fc1" + tag)

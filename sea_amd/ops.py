@@ -405,17 +405,32 @@ def mlp_fc1_supported(dtype: torch.dtype, E: int, S: int) -> bool:
     return dtype == torch.bfloat16 and (E, S) in ((256, 2048), (128, 1024))
 
 
-def fill_mlp_group(g: N.SeaMlpGroup, A, W1, b1, lnw, lnb, Hg) -> None:
-    g.A, g.W1, g.b1, g.lnw, g.lnb, g.Hg = A.data_ptr(), W1.data_ptr(), b1.data_ptr(), lnw.data_ptr(), lnb.data_ptr(), Hg.data_ptr()
-    g.lda, g.ldw, g.ldh = A.stride(0), W1.stride(0), Hg.stride(0)
-    g.M, g.E, g.S = A.shape[0], W1.shape[1], W1.shape[0]
+def fill_mlp_group(g: N.SeaMlpGroup, A, W1, b1, lnw, lnb, Hg, norm: Optional[Dict] = None) -> None:
+    """norm (optional): dict(X32 f32 [M,E], gamma, beta=None, mod=None, addend=None, Xout=None, eps=1e-5) — the operand rows are normalised inside
+    the launch from the fp32 residual stream (A is then None)."""
+    g.W1, g.b1, g.lnw, g.lnb, g.Hg = W1.data_ptr(), b1.data_ptr(), lnw.data_ptr(), lnb.data_ptr(), Hg.data_ptr()
+    g.ldw, g.ldh = W1.stride(0), Hg.stride(0)
+    g.E, g.S = W1.shape[1], W1.shape[0]
+    if norm is None:
+        g.A, g.lda, g.M = A.data_ptr(), A.stride(0), A.shape[0]
+        g.X32 = None
+        return
+    X = norm["X32"]
+    g.A, g.lda, g.M = None, 0, X.shape[0]
+    g.X32, g.ldx32 = X.data_ptr(), X.stride(0)
+    add, xout, mod = norm.get("addend"), norm.get("Xout"), norm.get("mod")
+    g.addend, g.ldadd = N.ptr(add), (add.stride(0) if add is not None else 0)
+    g.Xout, g.ldxout = N.ptr(xout), (xout.stride(0) if xout is not None else 0)
+    g.mod, g.ldmod = N.ptr(mod), (mod.stride(0) if mod is not None else 0)
+    g.gamma, g.beta = norm["gamma"].data_ptr(), N.ptr(norm.get("beta"))
+    g.norm_eps = norm.get("eps", 1e-5)
 
 
 def mlp_fc1_ln_gelu(groups: Sequence[Dict], eps: float = 1e-5, dtype: torch.dtype = torch.bfloat16) -> None:
     """Hg = gelu(LayerNorm(A W1^T + b1) * lnw + lnb) in one launch (sea_mlp_fc1_ln_gelu): dicts with A [M,E], W1 [S,E], b1, lnw, lnb f32 [S], Hg [M,S]."""
     arr = (N.SeaMlpGroup * len(groups))()
     for g, d in zip(arr, groups):
-        for k in ("A", "W1", "Hg"):
+        for k in ("W1", "Hg") + (("A",) if d.get("norm") is None else ()):
             _mat(d[k], k)
-        fill_mlp_group(g, d["A"], d["W1"], d["b1"], d["lnw"], d["lnb"], d["Hg"])
+        fill_mlp_group(g, d.get("A"), d["W1"], d["b1"], d["lnw"], d["lnb"], d["Hg"], d.get("norm"))
     N.check(N.lib().sea_mlp_fc1_ln_gelu(arr, len(groups), eps, N.dtype_code(dtype), N.stream_ptr()), "sea_mlp_fc1_ln_gelu")

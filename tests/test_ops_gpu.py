@@ -524,6 +524,42 @@ def test_mlp_fc1_ln_gelu_matches_two_launch_form(E, S, M):
         assert rel(Hg.float(), hg2.float()) < 8e-3
 
 
+@pytest.mark.parametrize("E,S", [(256, 2048), (128, 1024)])
+@pytest.mark.parametrize("M,adaln,with_add", [(77, True, True), (2024, True, True), (333, False, False), (64, True, False)])
+def test_mlp_fc1_ln_gelu_norm_prologue(E, S, M, adaln, with_add):
+    """The operand rows produced inside the launch (x + addend, AdaLN_2 / LayerNorm of the fp32 residual stream) against the row pass + the launch on its
+    ready-made rows: x + addend written back exactly, hidden rows within the bf16 rounding of the normalised rows (statistics are summed in another order)."""
+    from sea_amd import ops
+
+    dt = torch.bfloat16
+    groups, groups2, keep = [], [], []
+    for i in range(3):
+        x = rnd(M, E, seed=1400 + i) * 1.7 + 0.3
+        add = 0.2 * rnd(M, E, seed=1410 + i) if with_add else None
+        mod = (0.3 * rnd(M, 2 * E, seed=1420 + i)).to(dt) if adaln else None
+        gamma, beta = 1 + 0.1 * rnd(E, seed=1430 + i), (0.1 * rnd(E, seed=1440 + i) if adaln else None)
+        W1, b1 = rnd(S, E, dtype=dt, scale=0.08, seed=1450 + i), 0.3 * rnd(S, seed=1460 + i)
+        lnw, lnb = 1 + 0.1 * rnd(S, seed=1470 + i), 0.1 * rnd(S, seed=1480 + i)
+        Hg = torch.full((M, S), float("nan"), device=dev(), dtype=dt)
+        x_in = x.clone()
+        groups.append(dict(W1=W1, b1=b1, lnw=lnw, lnb=lnb, Hg=Hg,
+                           norm=dict(X32=x_in, addend=add, Xout=(x_in if with_add else None), mod=mod, gamma=gamma, beta=beta)))
+        # the two-launch form on the same inputs
+        x2, n2, Hg2 = x.clone(), torch.empty(M, E, device=dev(), dtype=dt), torch.empty(M, S, device=dev(), dtype=dt)
+        nd = dict(X=x2, Yact=n2, gamma=gamma, beta=beta, mod=mod)
+        if with_add:
+            nd.update(addend=add, Xout=x2)
+        ops.rownorm([nd], M, E, False, False, 1e-5, dt)
+        groups2.append(dict(A=n2, W1=W1, b1=b1, lnw=lnw, lnb=lnb, Hg=Hg2))
+        keep.append((x_in, x2, Hg, Hg2))
+    ops.mlp_fc1_ln_gelu(groups)
+    ops.mlp_fc1_ln_gelu(groups2)
+    for x_in, x2, Hg, Hg2 in keep:
+        assert torch.equal(x_in, x2)
+        assert bool(torch.isfinite(Hg.float()).all())
+        assert rel(Hg.float(), Hg2.float()) < 8e-3
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_rownorm_ln_gelu_act_input(dtype):
     from sea_amd import ops
