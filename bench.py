@@ -293,8 +293,12 @@ def leg_rollout(args, dist, dev, rank, world, steps, warmup, B):
     model = build_model(dev, args.dtype).eval()
     x, _, ib = inputs(B, T, F, E, rank, dev)
     eng = model.engine(dev)
-    step = (lambda: eng.forward(x, ib)) if args.no_graph else (lambda: eng.forward_graphed(x, ib))
-    log(f"rollout leg: cfg2 forward, B={B} per GPU, {'plain' if args.no_graph else 'hip-graph'} replay, {steps} timed steps")
+    # Default: the plan's launch list replayed by ONE native call per step (sea_run_list: the host stays ~3 steps ahead of the device).  Measured on one
+    # box, same build: 0.2360 / 0.2371 ms per step against 0.2420 / 0.2424 as a captured HIP graph — a graph launch costs ~10 us of device idle time per replay
+    # (rocprofv3: the gap in front of the first kernel of every replay), more than the launch boundaries it saves.  --graph times the graph replay.
+    use_graph = args.graph and not args.no_graph
+    step = (lambda: eng.forward_graphed(x, ib)) if use_graph else (lambda: eng.forward(x, ib))
+    log(f"rollout leg: cfg2 forward, B={B} per GPU, {'hip-graph' if use_graph else 'plain'} replay, {steps} timed steps")
     with torch.no_grad():
         elapsed, out = _timed(step, steps, warmup, dist, dev)
         assert torch.isfinite(out).all()
@@ -310,7 +314,7 @@ def leg_rollout(args, dist, dev, rank, world, steps, warmup, B):
     gflop = algorithmic_gflop(B, T, F, E, H, D, S, L)
     return {"value": world * B * steps / elapsed, "unit": "trajectory-steps/s", "ms_per_step": ms, "steps": steps,
             "workload": f"cfg2: cylinder_flow temporal model E={E} H={H} F={F} L={L} adaln, forward-only rollout step at T={T} (recompute mode), B={B} per GPU",
-            "replay": "plain" if args.no_graph else "hip-graph", "model_algorithmic_gflop_per_step": gflop,
+            "replay": "hip-graph" if use_graph else "plain (one native call per step: sea_run_list)", "model_algorithmic_gflop_per_step": gflop,
             "model_mfma_frac": gflop / (ms * 1e-3) / 1e3 / PEAK_BF16_TFLOPS, "n_launches": len(times),
             "roofline": roof, "launch_breakdown_ms": {r.name: round(t, 4) for r, t in times}}
 
@@ -510,7 +514,8 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="trajectories per GPU (default: 1 for the rollout leg, 8 for the train leg)")
     ap.add_argument("--seq", type=int, default=2024)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
-    ap.add_argument("--no-graph", action="store_true", help="replay launch by launch instead of the captured HIP graph")
+    ap.add_argument("--graph", action="store_true", help="rollout leg: replay the captured HIP graph instead of the plan's launch list (default: the launch list)")
+    ap.add_argument("--no-graph", action="store_true", help="(the default now; kept for the measurement scripts)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--mode", default="all", choices=["all", "rollout", "train", "kv", "decode", "encode"],
                     help="all: every leg in one line (default); rollout / train / kv: one leg; decode / encode: the spatial decoder / encoder legs "
