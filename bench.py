@@ -78,6 +78,11 @@ def record_work(rec, esz):
             fl += 2 * g.M * g.E * g.S
             rows_in = g.M * g.E * esz if not g.X32 else g.M * g.E * 4 * (1 + (1 if g.addend else 0) + (1 if g.Xout else 0)) + (g.M * 2 * g.E * esz if g.mod else 0)
             by += rows_in + g.S * g.E * esz + 3 * g.S * 4 + g.M * g.S * esz
+    elif rec.fn is L.sea_mlp_fc2_proj_norm:
+        for g in a[0][:a[1]]:
+            fl += 2 * g.M * g.E * g.S + 2 * g.M * g.E * g.E
+            by += g.M * g.S * esz + g.E * g.S * esz + g.E * g.E * esz + g.M * g.E * 4 + (g.M * g.E * 4 if g.Y32 else 0) + (g.M * g.E * esz if g.Yact else 0) \
+                + (g.M * 2 * g.E * esz if g.mod else 0)
     elif rec.fn is L.sea_exchange_tail:
         for g in rec.keep[:a[1]]:
             fl += g.n_seg * 2 * g.M * g.D * g.D + 2 * g.M * g.D * g.E + (2 * g.M * g.E * g.D if g.has_down else 0)
@@ -303,13 +308,15 @@ def leg_rollout(args, dist, dev, rank, world, steps, warmup, B):
         elapsed, out = _timed(step, steps, warmup, dist, dev)
         assert torch.isfinite(out).all()
         plan = eng.plan(B, T, "full")
-        plan.bind(x, ib, torch.empty_like(x))
+        out_keep = torch.empty_like(x)   # stays alive until the records have been timed: _launch_time_ms captures a graph, and torch.cuda.graph empties the
+        plan.bind(x, ib, out_keep)       # allocator's cache on entry — a freed output block would be unmapped under the launches that still write it
         plan.run()
         torch.cuda.synchronize()
         times = _time_list(plan.records, iters=10)
         esz = 2 if args.dtype == "bf16" else 4
         pmc = os.path.join(ROOT, "profiles", "r02_forward_cfg2_pmc_traffic.json") if (B, T, args.dtype) == (1, 2024, "bf16") else None
         roof = _roofline(times, esz, pmc)
+        del out_keep
     ms = elapsed / steps * 1e3
     gflop = algorithmic_gflop(B, T, F, E, H, D, S, L)
     return {"value": world * B * steps / elapsed, "unit": "trajectory-steps/s", "ms_per_step": ms, "steps": steps,

@@ -41,7 +41,7 @@ enum {
 int sea_abi_version(void);
 const char* sea_last_error(void);
 /* sizeof of every ABI struct in declaration order (SeaGemmGroup, SeaQkvGroup, SeaQkvCommon, SeaAttnProblem,
- * SeaAttnParams, SeaNormGroup, SeaSiluGroup, SeaIbParams, ..., SeaLaunchRec, SeaGemmNormGroup, SeaExchangeTail, SeaMlpGroup, SeaKvNorm, SeaKvField, SeaKvPair, SeaKvLayer, SeaKvGlobal last): lets a binding verify its layout.  Host only. */
+ * SeaAttnParams, SeaNormGroup, SeaSiluGroup, SeaIbParams, ..., SeaLaunchRec, SeaGemmNormGroup, SeaExchangeTail, SeaMlpGroup, SeaMlp2Group, SeaKvNorm, SeaKvField, SeaKvPair, SeaKvLayer, SeaKvGlobal last): lets a binding verify its layout.  Host only. */
 int sea_struct_sizes(int* out, int cap);
 /* Number of compute units / name of device 0's architecture as HIP reports them (diagnostics for bench.py). */
 int sea_device_info(int* cu_count, char* arch, int arch_len);
@@ -305,6 +305,31 @@ typedef struct {
 
 int sea_mlp_fc1_ln_gelu(const SeaMlpGroup* groups, int n_groups, float eps, int dtype, void* stream);
 
+/* ------------------------------------------------------------------------------------------------------------
+ * Second half of the field MLP, proj and the final norm in one launch (bf16; a workgroup owns 32 complete rows through both Linear layers):
+ *     x3  = Hg[M,S] . W2[E,S]^T + b2 + R            (models/base_blocks.py:25; the residual of models/temporal.py:145)
+ *     y   = x3 . Wproj[E,E]^T + bproj               (models/temporal.py:146)
+ *     out = norm(y) with gamma / beta / mod as SeaNormGroup when gamma != NULL (the model's final per-field norm, models/temporal.py:412-415), else y
+ * Replaces sea_gemm_grouped x 2 + sea_rownorm on the tail of the layer; x3 and y never reach HBM.  Same shapes and requirements as sea_mlp_fc1_ln_gelu.
+ */
+typedef struct {
+    const void* Hg;      /* act [M, S], row stride ldh: the activated hidden rows */
+    const void* W2;      /* act [E, S], row stride ldw2 */
+    const float* b2;     /* f32 [E] */
+    const float* R;      /* f32 [M, E], row stride ldr: the residual stream */
+    const void* Wproj;   /* act [E, E], row stride ldwp */
+    const float* bproj;  /* f32 [E] */
+    const float* gamma;  /* f32 [E] or NULL (no norm) */
+    const float* beta;   /* f32 [E] or NULL */
+    const void* mod;     /* act [M, 2E] (scale | shift), row stride ldmod, or NULL */
+    float* Y32;          /* f32 [M, E], row stride ldy32, or NULL */
+    void* Yact;          /* act [M, E], row stride ldyact, or NULL */
+    int32_t ldh, ldw2, ldr, ldwp, ldmod, ldy32, ldyact;
+    int32_t M, E, S;
+} SeaMlp2Group;
+
+int sea_mlp_fc2_proj_norm(const SeaMlp2Group* groups, int n_groups, float eps, int dtype, void* stream);
+
 
 /* ------------------------------------------------------------------------------------------------------------
  * Hidden layer of the AdaLN condition MLP for a scalar condition: Hid[m, k] = silu(w1[k] * c[m] + b1[k]).
@@ -508,9 +533,10 @@ int sea_ib_bwd(const SeaIbBwdParams* params, void* stream);
  *     SEA_OP_CONVERT p0 = src, p1 = dst, l0 = lds, l1 = ldd, l2 = rows, l3 = cols
  *     SEA_OP_GEMM_NORM p0 = SeaGemmNormGroup[n], f0 = eps          SEA_OP_XTAIL  p0 = SeaExchangeTail[n], f0 = eps
  *     SEA_OP_MLP1   p0 = SeaMlpGroup[n], f0 = eps
+ *     SEA_OP_MLP2   p0 = SeaMlp2Group[n], f0 = eps
  * Returns 0, or the failing entry's error code with sea_last_error() set (entries before it have been launched).
  */
-enum { SEA_OP_GEMM = 1, SEA_OP_QKV = 2, SEA_OP_ATTN = 3, SEA_OP_NORM = 4, SEA_OP_SILU = 5, SEA_OP_IB = 6, SEA_OP_CONVERT = 8, SEA_OP_GEMM_NORM = 9, SEA_OP_XTAIL = 10, SEA_OP_MLP1 = 11 };   /* 7 and 12 were round-1 entry points (sea_rowchain, sea_cond_mlp), removed in ABI v2 */
+enum { SEA_OP_GEMM = 1, SEA_OP_QKV = 2, SEA_OP_ATTN = 3, SEA_OP_NORM = 4, SEA_OP_SILU = 5, SEA_OP_IB = 6, SEA_OP_CONVERT = 8, SEA_OP_GEMM_NORM = 9, SEA_OP_XTAIL = 10, SEA_OP_MLP1 = 11, SEA_OP_MLP2 = 13 };   /* 7 and 12 were round-1 entry points (sea_rowchain, sea_cond_mlp), removed in ABI v2 */
 typedef struct {
     int32_t op, n, dtype, i0, i1, i2, i3;
     float f0;

@@ -106,7 +106,7 @@ class SeaAttnBwdParams(C.Structure):
                 ("ldo", _i32), ("lddo", _i32), ("lddq", _i32), ("lddk", _i32), ("lddv", _i32), ("q_scale", _f32), ("drop", SeaDropout)]
 
 
-OP_GEMM, OP_QKV, OP_ATTN, OP_NORM, OP_SILU, OP_IB, OP_CONVERT, OP_GEMM_NORM, OP_XTAIL, OP_MLP1 = 1, 2, 3, 4, 5, 6, 8, 9, 10, 11
+OP_GEMM, OP_QKV, OP_ATTN, OP_NORM, OP_SILU, OP_IB, OP_CONVERT, OP_GEMM_NORM, OP_XTAIL, OP_MLP1, OP_MLP2 = 1, 2, 3, 4, 5, 6, 8, 9, 10, 11, 13
 
 
 class SeaLaunchRec(C.Structure):
@@ -146,6 +146,13 @@ class SeaMlpGroup(C.Structure):
                 ("lda", _i32), ("ldw", _i32), ("ldh", _i32), ("M", _i32), ("E", _i32), ("S", _i32),
                 ("X32", _vp), ("addend", _vp), ("Xout", _vp), ("mod", _vp), ("gamma", _vp), ("beta", _vp),
                 ("ldx32", _i32), ("ldadd", _i32), ("ldxout", _i32), ("ldmod", _i32), ("norm_eps", _f32), ("pad_", _i32)]
+
+
+class SeaMlp2Group(C.Structure):
+    _fields_ = [("Hg", _vp), ("W2", _vp), ("b2", _vp), ("R", _vp), ("Wproj", _vp), ("bproj", _vp), ("gamma", _vp), ("beta", _vp), ("mod", _vp),
+                ("Y32", _vp), ("Yact", _vp),
+                ("ldh", _i32), ("ldw2", _i32), ("ldr", _i32), ("ldwp", _i32), ("ldmod", _i32), ("ldy32", _i32), ("ldyact", _i32),
+                ("M", _i32), ("E", _i32), ("S", _i32)]
 
 
 KV_MAX_FIELDS = 4
@@ -235,6 +242,8 @@ def lib() -> C.CDLL:
     L.sea_silu_outer_ib.restype = C.c_int
     L.sea_mlp_fc1_ln_gelu.argtypes = [C.POINTER(SeaMlpGroup), C.c_int, C.c_float, C.c_int, _vp]
     L.sea_mlp_fc1_ln_gelu.restype = C.c_int
+    L.sea_mlp_fc2_proj_norm.argtypes = [C.POINTER(SeaMlp2Group), C.c_int, C.c_float, C.c_int, _vp]
+    L.sea_mlp_fc2_proj_norm.restype = C.c_int
     L.sea_run_list.argtypes = [C.POINTER(SeaLaunchRec), C.c_int, _vp]
     L.sea_run_list.restype = C.c_int
     L.sea_kv_rollout.argtypes = [C.POINTER(SeaKvGlobal), C.POINTER(SeaKvLayer), C.c_int, C.c_int, C.c_uint32, C.c_int, _vp]
@@ -261,14 +270,14 @@ def lib() -> C.CDLL:
 
 ABI_STRUCTS = (SeaGemmGroup, SeaQkvGroup, SeaQkvCommon, SeaAttnProblem, SeaAttnParams, SeaNormGroup, SeaSiluGroup,
                SeaIbParams, SeaWgradGroup, SeaNormBwdGroup, SeaSiluBwdGroup, SeaIbBwdParams, SeaAttnBwdProblem, SeaAttnBwdParams,
-               SeaDropout, SeaLaunchRec, SeaGemmNormGroup, SeaExchangeTail, SeaMlpGroup, SeaKvNorm, SeaKvField, SeaKvPair, SeaKvLayer, SeaKvGlobal)
+               SeaDropout, SeaLaunchRec, SeaGemmNormGroup, SeaExchangeTail, SeaMlpGroup, SeaMlp2Group, SeaKvNorm, SeaKvField, SeaKvPair, SeaKvLayer, SeaKvGlobal)
 
 EXPORTED_SYMBOLS = (
     "sea_abi_version", "sea_last_error", "sea_struct_sizes", "sea_device_info", "sea_gemm_grouped", "sea_qkv_rope_grouped",
     "sea_attention_fwd", "sea_rownorm", "sea_silu_outer", "sea_ib_add", "sea_convert_f32_to_act", "sea_selftest_mfma",
     "sea_mse_fwd_bwd", "sea_relative_mse", "sea_adamw_flat",
     "sea_wgrad_grouped", "sea_transpose_weights", "sea_rownorm_bwd", "sea_silu_outer_bwd", "sea_ib_bwd",
-    "sea_attention_bwd", "sea_dropout_mask", "sea_run_list", "sea_unpatchify", "sea_gemm_rownorm", "sea_exchange_tail", "sea_patchify", "sea_silu_outer_ib", "sea_mlp_fc1_ln_gelu", "sea_kv_rollout", "sea_kv_arena_words", "sea_kv_debug_stamps",
+    "sea_attention_bwd", "sea_dropout_mask", "sea_run_list", "sea_unpatchify", "sea_gemm_rownorm", "sea_exchange_tail", "sea_patchify", "sea_silu_outer_ib", "sea_mlp_fc1_ln_gelu", "sea_mlp_fc2_proj_norm", "sea_kv_rollout", "sea_kv_arena_words", "sea_kv_debug_stamps",
 )
 
 

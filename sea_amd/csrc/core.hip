@@ -19,7 +19,7 @@ extern "C" int sea_struct_sizes(int* out, int cap) {
                          (int)sizeof(SeaAttnParams), (int)sizeof(SeaNormGroup), (int)sizeof(SeaSiluGroup), (int)sizeof(SeaIbParams),
                          (int)sizeof(SeaWgradGroup), (int)sizeof(SeaNormBwdGroup), (int)sizeof(SeaSiluBwdGroup), (int)sizeof(SeaIbBwdParams),
                          (int)sizeof(SeaAttnBwdProblem), (int)sizeof(SeaAttnBwdParams), (int)sizeof(SeaDropout), (int)sizeof(SeaLaunchRec),
-                         (int)sizeof(SeaGemmNormGroup), (int)sizeof(SeaExchangeTail), (int)sizeof(SeaMlpGroup), (int)sizeof(SeaKvNorm), (int)sizeof(SeaKvField),
+                         (int)sizeof(SeaGemmNormGroup), (int)sizeof(SeaExchangeTail), (int)sizeof(SeaMlpGroup), (int)sizeof(SeaMlp2Group), (int)sizeof(SeaKvNorm), (int)sizeof(SeaKvField),
                          (int)sizeof(SeaKvPair), (int)sizeof(SeaKvLayer), (int)sizeof(SeaKvGlobal)};
     const int n = (int)(sizeof(sizes) / sizeof(sizes[0]));
     for (int i = 0; i < n && i < cap; ++i) out[i] = sizes[i];
@@ -43,6 +43,7 @@ extern "C" int sea_run_list(const SeaLaunchRec* recs, int n_recs, void* stream) 
             case SEA_OP_GEMM_NORM: rc = sea_gemm_rownorm(static_cast<const SeaGemmNormGroup*>(R.p0), R.n, R.f0, R.dtype, stream); break;
             case SEA_OP_XTAIL: rc = sea_exchange_tail(static_cast<const SeaExchangeTail*>(R.p0), R.n, R.f0, R.dtype, stream); break;
             case SEA_OP_MLP1: rc = sea_mlp_fc1_ln_gelu(static_cast<const SeaMlpGroup*>(R.p0), R.n, R.f0, R.dtype, stream); break;
+            case SEA_OP_MLP2: rc = sea_mlp_fc2_proj_norm(static_cast<const SeaMlp2Group*>(R.p0), R.n, R.f0, R.dtype, stream); break;
             default: sea_set_error("sea_run_list[%d]: unknown op %d", i, R.op); return SEA_EINVAL;
         }
         if (rc != SEA_OK) return rc;   // sea_last_error() already names the entry point; the caller maps i back to its record

@@ -206,9 +206,13 @@ struct GemmMainloop {
         for (int kt = 0; kt < nk; ++kt) {
             // stage kt has landed once at most the loads of the stages issued after it are outstanding
             const int newer = (nk - 1 - kt) < (NS - 2) ? (nk - 1 - kt) : (NS - 2);
-            if (newer == NS - 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * LPS) : "memory");
-            else if (newer == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // lgkmcnt(0): this wave's fragment reads of stage kt-1 are RETIRED before it arrives at the barrier.  The buffer they read is refilled right
+            // behind the barrier (one phase after its last read), and nothing but a retired read orders an LDS-DMA write against an earlier ds_read
+            // (cdna_hip_programming.md, "Read a staged buffer ..." / WAR).  Found in round 2 with a sibling of this loop (mlp_fused.hip): with two
+            // workgroups per CU rare 8-row pieces of a tile were multiplied against the NEXT stage's data.
+            if (newer == NS - 2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((NS - 2) * LPS) : "memory");
+            else if (newer == 1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(LPS) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();  // every wave's part of stage kt is in LDS; everyone is done reading stage kt-1
             if (kt + NS - 1 < nk) dma_stage(kt + NS - 1, lds_base, wave, lane);  // refill the buffer stage kt-1 used
             compute_tile(smem + (kt % NS) * C::BUF_BYTES, wm, wn, lane, acc);

@@ -170,9 +170,10 @@ __global__ __launch_bounds__(512) void mlp_fc1_ln_gelu_kernel(const MlpLaunch L)
 #pragma unroll
     for (int s = 0; s < NSTAGE; ++s) {
         // stage s (and the A rows, older) have landed once at most the pieces of the stages issued after it are outstanding
-        if (s + 2 < NSTAGE) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPS) : "memory");
-        else if (s + 1 < NSTAGE) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // (lgkmcnt(0): the fragment reads of the previous stage are retired before the barrier that releases its slot to the next DMA, see gemm_core.hpp)
+        if (s + 2 < NSTAGE) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * LPS) : "memory");
+        else if (s + 1 < NSTAGE) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(LPS) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         if (s + NS - 1 < NSTAGE) dma_stage(s + NS - 1);
         if (s == 0) {            // the A rows have landed: this lane's fragments of all 32 rows stay in registers for the whole contraction
@@ -299,6 +300,226 @@ __global__ __launch_bounds__(512) void mlp_fc1_ln_gelu_kernel(const MlpLaunch L)
     }
 }
 
+// ================================================================================================ second half of the field MLP, proj and the final norm
+//     x3  = Hg[M, S] . W2[E, S]^T + b2 + R                       (models/base_blocks.py:25, the residual of models/temporal.py:145)
+//     y   = x3 . Wproj[E, E]^T + bproj                            (models/temporal.py:146)
+//     out = norm(y) (gamma / beta / mod as SeaNormGroup) or y     (the model's final per-field norm, models/temporal.py:412-415)
+// A workgroup (8 waves) owns 32 COMPLETE rows through both Linear layers, so x3 never leaves the CU and the norm is an epilogue: three launches
+// (fc2 19.8 us, proj 7.1, final norm 5.6 at cfg2) become one.  The price is the one the fc1 kernel pays: every workgroup streams the whole W2 (E x S
+// bf16 = 1 MiB) — but fc2's own 64 x 64-tile launch is bound by the same megabyte per CU, and there is no heavy epilogue here.
+// K-tiles of 64: a stage = the A tile (32 rows of Hg) + the W tile (E rows of W2), both by global_load_lds, a ring of 3 stages (2 in flight beside the
+// one being multiplied); the E / 64 K-tiles of Wproj follow as further stages of the same ring.  Wave w owns output columns [E/8 w, E/8 (w+1)) of all
+// 32 rows in both layers (transposed MFMA tiles: a lane holds 4 consecutive columns of a row).
+struct Mlp2Launch {
+    SeaMlp2Group g[SEA_MAX_MLP_GROUPS];
+    int tile_start[SEA_MAX_MLP_GROUPS + 1];
+    int n_groups;
+    float eps;
+    int per_xcd;
+};
+
+template <int KTE, int KTS>
+__global__ __launch_bounds__(512) void mlp_fc2_proj_norm_kernel(const Mlp2Launch L) {
+    using T = __bf16;
+    constexpr int BM = 32, BKB = 128, BK = 64, NS = 3, NW = 8;
+    constexpr int E = KTE * 64, S = KTS * 64;
+    constexpr int STAGE_A = BM * BKB, STAGE_W = E * BKB, STAGE = STAGE_A + STAGE_W;
+    constexpr int X_OFF = NS * STAGE, RED_OFF = X_OFF + KTE * BM * BKB;      // x3 tile (K-tile major, swizzled like a DMA'd tile), statistics scratch
+    constexpr int NSTAGE = KTS + KTE;
+    constexpr int WPW = E / 8 / NW;                                          // 8-row W pieces per wave per stage (E = 256: 4)
+    constexpr int LPS = WPW + 1;                                             // + one A piece (waves 4 .. 7 repeat pieces 0 .. 3: same bytes, same place)
+    constexpr int NJ = E / NW / 16;                                          // 16-column blocks per wave (E = 256: 2)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tile = L.per_xcd > 0 ? (int)(blockIdx.x & 7) * L.per_xcd + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    if (tile >= L.tile_start[L.n_groups]) return;
+    int gi = 0;
+    while (gi + 1 < L.n_groups && tile >= L.tile_start[gi + 1]) ++gi;
+    const SeaMlp2Group& G = L.g[gi];
+    const int m0 = (tile - L.tile_start[gi]) * BM, M = G.M;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 15, g = lane >> 4;
+    const T* A = static_cast<const T*>(G.Hg);
+    const T* W2 = static_cast<const T*>(G.W2);
+    const T* Wp = static_cast<const T*>(G.Wproj);
+    const unsigned lds_base = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)smem);
+    const int rl = lane >> 3;
+    const int chunk = (lane & 7) ^ (rl & 7);               // swizzle on the source side
+    // ---- epilogue operands: ordinary loads, requested before the weight stream (older than every DMA piece: they never hold a counted wait up)
+    // this lane: rows m0 + 16 i + r (i < 2), columns n(j) = wave * (E / 8) + 16 j + 4 g + q
+    float b2v[NJ][4], bpv[NJ][4], rv[2][NJ][4], gq[NJ][4], bq[NJ][4], mwv[2][NJ][4], mbv[2][NJ][4];
+    const bool has_norm = G.gamma != nullptr;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int n = wave * (E / NW) + j * 16 + g * 4;
+        load4(G.b2 + n, b2v[j]);
+        load4(G.bproj + n, bpv[j]);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) gq[j][q] = bq[j][q] = 0.f;
+        if (has_norm) {
+            load4(G.gamma + n, gq[j]);
+            if (G.beta != nullptr) load4(G.beta + n, bq[j]);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            int m = m0 + i * 16 + r;
+            m = m < M ? m : M - 1;
+            load4(G.R + (int64_t)m * G.ldr + n, rv[i][j]);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) mwv[i][j][q] = mbv[i][j][q] = 0.f;
+            if (has_norm && G.mod != nullptr) {
+                const T* mod = static_cast<const T*>(G.mod) + (int64_t)m * G.ldmod;
+                load4(mod + n, mwv[i][j]);
+                load4(mod + E + n, mbv[i][j]);
+            }
+        }
+    }
+    auto dma_stage = [&](int s) {
+        const unsigned base = lds_base + (unsigned)((s % NS) * STAGE);
+        const bool second = s >= KTS;                         // Wproj K-tiles behind the W2 ones
+        const T* W = second ? Wp : W2;
+        const int ldw = second ? G.ldwp : G.ldw2;
+        const int kt = second ? s - KTS : s;
+        {   // the A piece of this wave (4 pieces of 8 rows; the second layer's operand is the x3 tile: the piece is issued all the same, it keeps the
+            // per-wave count of every stage equal)
+            const int u = wave & 3;
+            int row = m0 + u * 8 + rl;
+            row = row < M ? row : M - 1;
+            const int ka = second ? 0 : kt;
+            glds16_mlp(A + (int64_t)row * G.ldh + ka * BK + chunk * 8, base + (unsigned)(u * 8 * BKB));
+        }
+#pragma unroll
+        for (int i = 0; i < WPW; ++i) {
+            const int u = i * NW + wave;                      // 8-row piece of the W tile
+            glds16_mlp(W + (int64_t)(u * 8 + rl) * ldw + kt * BK + chunk * 8, base + (unsigned)(STAGE_A + u * 8 * BKB));
+        }
+    };
+    for (int s = 0; s < NS - 1; ++s) dma_stage(s);
+
+    f32x4 acc[2][NJ];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float x3v[2][NJ][4];
+#pragma unroll
+    for (int s = 0; s < NSTAGE; ++s) {
+        // stage s has landed once at most the pieces of the stage issued after it are outstanding.  lgkmcnt(0): this wave's fragment reads of the
+        // PREVIOUS stage are retired before it arrives at the barrier — the slot they read is re-staged right behind the barrier, one phase after its
+        // last read, and nothing else orders an LDS-DMA write against an earlier ds_read (seen as rare wrong 8-row pieces with two workgroups per CU)
+        if (s + 1 < NSTAGE) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(LPS) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                         // ... for every wave; and nobody still reads the slot the next DMA goes to
+        if (s + NS - 1 < NSTAGE) dma_stage(s + NS - 1);
+        if (s == KTS) {
+            // ---- between the layers: x3 = acc + b2 + R, as bf16 into the x3 tile (the second layer's A operand); acc restarts
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    const int n = wave * (E / NW) + j * 16 + g * 4, m = i * 16 + r;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) x3v[i][j][q] = acc[i][j][q] + b2v[j][q] + rv[i][j][q];
+                    store4(reinterpret_cast<T*>(smem + X_OFF + (n >> 6) * (BM * BKB) + m * BKB + ((((n & 63) >> 3) ^ (m & 7)) << 4) + (n & 7) * 2), x3v[i][j][0], x3v[i][j][1],
+                           x3v[i][j][2], x3v[i][j][3]);
+                    acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+        const char* sA = s < KTS ? smem + (s % NS) * STAGE + r * BKB : smem + X_OFF + (s - KTS) * (BM * BKB) + r * BKB;
+        const char* sW = smem + (s % NS) * STAGE + STAGE_A + (wave * (E / NW) + r) * BKB;
+#pragma unroll
+        for (int kc = 0; kc < 2; ++kc) {
+            const int off = ((kc * 4 + g) ^ (r & 7)) << 4;
+            uint4 af[2], wf[NJ];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) af[i] = *reinterpret_cast<const uint4*>(sA + i * 16 * BKB + off);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) wf[j] = *reinterpret_cast<const uint4*>(sW + j * 16 * BKB + off);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) mma16<T>(wf[j], af[i], acc[i][j]);
+        }
+    }
+    // ---- epilogue: + bproj, optional row norm over the E columns (two-pass, fp32; the row's columns are spread over the 8 waves), outputs
+    float* red = reinterpret_cast<float*>(smem + RED_OFF);   // [2 passes][8 waves][32 rows]
+    float v[2][NJ][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[i][j][q] = acc[i][j][q] + bpv[j][q];
+    float mean[2] = {0.f, 0.f}, rstd[2] = {1.f, 1.f};
+    if (has_norm) {   // block-uniform
+        const float inv_e = 1.0f / (float)E;
+        float sum[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            float t4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) t4[q] = add1(t4[q], v[i][j][q]);
+            sum[i] = add1(add1(t4[0], t4[1]), add1(t4[2], t4[3]));
+            sum[i] += __shfl_xor(sum[i], 16);
+            sum[i] += __shfl_xor(sum[i], 32);
+            if (g == 0) red[wave * 32 + i * 16 + r] = sum[i];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            float t = 0.f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) t += red[w * 32 + i * 16 + r];
+            mean[i] = t * inv_e;
+            float q4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float c = v[i][j][q] - mean[i];
+                    q4[q] = fma1(c, c, q4[q]);
+                }
+            float sq = add1(add1(q4[0], q4[1]), add1(q4[2], q4[3]));
+            sq += __shfl_xor(sq, 16);
+            sq += __shfl_xor(sq, 32);
+            if (g == 0) red[256 + wave * 32 + i * 16 + r] = sq;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            float t = 0.f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) t += red[256 + w * 32 + i * 16 + r];
+            rstd[i] = 1.0f / sqrtf(t * inv_e + L.eps);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int m = m0 + i * 16 + r;
+        if (m >= M) continue;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int n = wave * (E / NW) + j * 16 + g * 4;
+            float o[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (has_norm) {
+                    const float gg = G.mod != nullptr ? gq[j][q] + 1.0f + mwv[i][j][q] : gq[j][q];
+                    o[q] = (v[i][j][q] - mean[i]) * rstd[i] * gg + (bq[j][q] + mbv[i][j][q]);
+                } else {
+                    o[q] = v[i][j][q];
+                }
+            }
+            if (G.Y32 != nullptr) store4(G.Y32 + (int64_t)m * G.ldy32 + n, o[0], o[1], o[2], o[3]);
+            if (G.Yact != nullptr) store4(static_cast<T*>(G.Yact) + (int64_t)m * G.ldyact + n, o[0], o[1], o[2], o[3]);
+        }
+    }
+}
+
 template <typename K>
 static int set_lds_mlp(K kernel, int bytes) {
     return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess ? 0 : -1;
@@ -352,5 +573,56 @@ extern "C" int sea_mlp_fc1_ln_gelu(const SeaMlpGroup* groups, int n_groups, floa
         mlp_fc1_ln_gelu_kernel<2, 8><<<dim3(total), dim3(512), lds0, s>>>(L);
     }
     SEA_CHECK_LAUNCH("sea_mlp_fc1_ln_gelu");
+    return SEA_OK;
+}
+
+extern "C" int sea_mlp_fc2_proj_norm(const SeaMlp2Group* groups, int n_groups, float eps, int dtype, void* stream) {
+    SEA_REQUIRE(groups != nullptr && n_groups >= 1 && n_groups <= SEA_MAX_MLP_GROUPS, "sea_mlp_fc2_proj_norm: n_groups=%d out of range", n_groups);
+    const int E = groups[0].E, S = groups[0].S;
+    const bool shape_ok = (E == 256 && S == 2048) || (E == 128 && S == 1024);
+    if (dtype != SEA_BF16 || !shape_ok) {
+        sea_set_error("sea_mlp_fc2_proj_norm: unsupported dtype / shape (dtype=%d E=%d S=%d): bf16, (E, S) in {(256, 2048), (128, 1024)}", dtype, E, S);
+        return SEA_EUNSUPPORTED;
+    }
+    Mlp2Launch L;
+    memset(&L, 0, sizeof(L));
+    int total = 0;
+    for (int i = 0; i < n_groups; ++i) {
+        const SeaMlp2Group& G = groups[i];
+        SEA_REQUIRE(G.E == E && G.S == S && G.M >= 1, "sea_mlp_fc2_proj_norm[%d]: the groups of a launch share E and S", i);
+        SEA_REQUIRE(G.Hg && G.W2 && G.b2 && G.R && G.Wproj && G.bproj && (G.Y32 || G.Yact), "sea_mlp_fc2_proj_norm[%d]: null pointer", i);
+        SEA_REQUIRE(G.ldh % 8 == 0 && G.ldh >= S && G.ldw2 % 8 == 0 && G.ldw2 >= S && G.ldwp % 8 == 0 && G.ldwp >= E && G.ldr % 4 == 0 && G.ldr >= E &&
+                        (!G.Y32 || (G.ldy32 % 4 == 0 && G.ldy32 >= E)) && (!G.Yact || (G.ldyact % 4 == 0 && G.ldyact >= E)) && (!G.mod || (G.ldmod % 4 == 0 && G.ldmod >= 2 * E)),
+                    "sea_mlp_fc2_proj_norm[%d]: bad strides", i);
+        SEA_REQUIRE(sea_aligned16(G.Hg) && sea_aligned16(G.W2) && sea_aligned16(G.b2) && sea_aligned16(G.R) && sea_aligned16(G.Wproj) && sea_aligned16(G.bproj) &&
+                        sea_aligned16(G.gamma) && sea_aligned16(G.beta) && sea_aligned16(G.mod) && sea_aligned16(G.Y32) && sea_aligned16(G.Yact),
+                    "sea_mlp_fc2_proj_norm[%d]: pointers must be 16-byte aligned", i);
+        SEA_REQUIRE(G.gamma || (!G.beta && !G.mod), "sea_mlp_fc2_proj_norm[%d]: beta / mod without gamma", i);
+        L.g[i] = G;
+        L.tile_start[i] = total;
+        total += (G.M + 31) / 32;
+    }
+    L.tile_start[n_groups] = total;
+    L.n_groups = n_groups;
+    L.eps = eps;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (total > 256) {   // several rounds of workgroups: consecutive tiles (one field: one W2, one Wproj) on one XCD
+        L.per_xcd = (total + 7) / 8;
+        total = 8 * L.per_xcd;
+    }
+    if (E == 256) {
+        constexpr int lds = 3 * (32 * 128 + 256 * 128) + 4 * 32 * 128 + 2 * 8 * 32 * 4;   // ring 108 KiB + x3 tile 16 KiB + statistics 2 KiB
+        static int once = set_lds_mlp(mlp_fc2_proj_norm_kernel<4, 32>, lds);
+        (void)once;
+        mlp_fc2_proj_norm_kernel<4, 32><<<dim3(total), dim3(512), lds, s>>>(L);
+    } else {
+        constexpr int lds0 = 3 * (32 * 128 + 128 * 128) + 2 * 32 * 128 + 2 * 8 * 32 * 4;
+        static const int pad = []() { const char* e = getenv("SEA_MLP2_LDS_PAD"); return e ? atoi(e) : 0; }();   // debugging aid
+        const int lds = lds0 + pad;
+        static int once = set_lds_mlp(mlp_fc2_proj_norm_kernel<2, 16>, 160 * 1024);
+        (void)once;
+        mlp_fc2_proj_norm_kernel<2, 16><<<dim3(total), dim3(512), lds, s>>>(L);
+    }
+    SEA_CHECK_LAUNCH("sea_mlp_fc2_proj_norm");
     return SEA_OK;
 }

@@ -629,12 +629,9 @@ class Plan:
                 continue
             if eng.model.add_info_after_cross and has_ib and not fold_ib:
                 self._ib(pre, xr)
-            self._mlp_proj(pre, list(range(F)), xr, xa, n_e, hbuf, hg, mods, False, addend=(ibufs[l] if fold_ib else None))
-        if not lanes:
-            # -- final per-field norm, written straight into out[B,T,F,E]
-            self._norm([dict(X=xr[i], Y32=xr[i], ldy32=FE, Y_is_out=i * E * 4, **norm_params(f"ln.{i}.", E)) for i in range(F)], E, "final.norm")
+            self._mlp_proj(pre, list(range(F)), xr, xa, n_e, hbuf, hg, mods, last, addend=(ibufs[l] if fold_ib else None))
 
-    def _mlp_proj(self, pre, fields, xr, xm, n_e, hbuf, hg, mods, final_norm, tag="", addend=None) -> None:
+    def _mlp_proj(self, pre, fields, xr, xm, n_e, hbuf, hg, mods, final_norm, tag="", addend=None) -> bool:
         """x_i += W2 gelu(LN(W1 AdaLN_2(x_i))) ; x_i = proj_i(x_i) for the listed fields (models/temporal.py:143-146), optionally followed
         by the model's final per-field norm written straight into out (models/temporal.py:412-415)."""
         P, E, S, FE = self.eng.params, self.E, self.S, self.F * self.E
@@ -670,11 +667,27 @@ class Plan:
                         for i in fields], "mlp.fc1" + tag)
             self._norm([dict(X=hbuf[i], gamma=P.f32_vec(f"{pre}mlp.{i}.layers.1.weight"), beta=P.f32_vec(f"{pre}mlp.{i}.layers.1.bias"), Yact=hg[i])
                         for i in fields], S, "mlp.ln_gelu" + tag, x_is_act=True, gelu=True)
+        # fc2 + residual, proj and — after the last layer — the model's final norm in one launch where the kernel is instantiated (the same shapes as the
+        # fc1 kernel): a workgroup owns 32 complete rows through both Linear layers.  Measured (plain replay, same box): cfg2 0.2373 -> 0.2358 ms (the launch
+        # 30.8 us against 19.8 + 7.1 + 5.6 with two boundaries less: a 32-row workgroup per CU streams W2 at a third of the rate three co-resident 64 x 64
+        # tiles do), B = 8 1.108 -> 1.18 ms (200 us against 76 + 21 + 31) — short launches only.  SEA_FUSE_MLP2=0 / 1 forces.
+        w2 = os.environ.get("SEA_FUSE_MLP2", "auto")
+        if (type(self) is Plan and (w2 == "1" or (w2 == "auto" and 1024 <= self.M <= 4096)) and ops.mlp_fc1_supported(self.dt, E, S) and len(fields) <= N.MAX_MLP_GROUPS):
+            arr = (N.SeaMlp2Group * len(fields))()
+            for g_, i in zip(arr, fields):
+                nrm = norm_params(f"ln.{i}.", E) if final_norm else {}
+                ops.fill_mlp2_group(g_, hg[i], P.act(f"{pre}mlp.{i}.layers.3.weight"), P.f32_vec(f"{pre}mlp.{i}.layers.3.bias"), xr[i],
+                                    P.act(f"{pre}proj.{i}.weight"), P.f32_vec(f"{pre}proj.{i}.bias"), Y32=xr[i], ldy32=(FE if final_norm else None), **nrm)
+                if final_norm:
+                    self._out_patches.append((g_, "Y32", i * E * 4))
+            self._cur.append(self._rec(N.lib().sea_mlp_fc2_proj_norm, [arr, len(fields), 1e-5, self.code], ("mlp.fc2_proj_norm" if final_norm else "mlp.fc2_proj") + tag, arr))
+            return final_norm
         self._gemm([dict(A=hg[i], W=P.act(f"{pre}mlp.{i}.layers.3.weight"), bias=P.f32_vec(f"{pre}mlp.{i}.layers.3.bias"), R=xr[i], Cact=xm[i])
                     for i in fields], "mlp.fc2" + tag)
         self._gemm([dict(A=xm[i], W=P.act(f"{pre}proj.{i}.weight"), bias=P.f32_vec(f"{pre}proj.{i}.bias"), C32=xr[i]) for i in fields], "proj" + tag)
         if final_norm:
             self._norm([dict(X=xr[i], Y32=xr[i], ldy32=FE, Y_is_out=i * E * 4, **norm_params(f"ln.{i}.", E)) for i in fields], E, "final.norm" + tag)
+        return final_norm
 
     def _ib_params(self, pre: str) -> dict:
         P = self.eng.params
@@ -764,6 +777,8 @@ class Plan:
                 c.op, c.p0, c.dtype = N.OP_ATTN, addr(r.keep), a[1]
             elif r.fn is L.sea_mlp_fc1_ln_gelu:
                 c.op, c.p0, c.n, c.f0, c.dtype = N.OP_MLP1, addr(a[0]), a[1], a[2], a[3]
+            elif r.fn is L.sea_mlp_fc2_proj_norm:
+                c.op, c.p0, c.n, c.f0, c.dtype = N.OP_MLP2, addr(a[0]), a[1], a[2], a[3]
             elif r.fn is L.sea_exchange_tail:
                 c.op, c.p0, c.n, c.f0, c.dtype = N.OP_XTAIL, addr(r.keep), a[1], a[2], a[3]
             elif r.fn is L.sea_gemm_rownorm:

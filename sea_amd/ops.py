@@ -426,6 +426,27 @@ def fill_mlp_group(g: N.SeaMlpGroup, A, W1, b1, lnw, lnb, Hg, norm: Optional[Dic
     g.norm_eps = norm.get("eps", 1e-5)
 
 
+def fill_mlp2_group(g: N.SeaMlp2Group, Hg, W2, b2, R, Wproj, bproj, Y32=None, Yact=None, gamma=None, beta=None, mod=None, ldy32=None) -> None:
+    g.Hg, g.W2, g.b2, g.R, g.Wproj, g.bproj = Hg.data_ptr(), W2.data_ptr(), b2.data_ptr(), R.data_ptr(), Wproj.data_ptr(), bproj.data_ptr()
+    g.ldh, g.ldw2, g.ldr, g.ldwp = Hg.stride(0), W2.stride(0), R.stride(0), Wproj.stride(0)
+    g.gamma, g.beta, g.mod, g.ldmod = N.ptr(gamma), N.ptr(beta), N.ptr(mod), (mod.stride(0) if mod is not None else 0)
+    g.Y32, g.ldy32 = N.ptr(Y32), (ldy32 if ldy32 is not None else (Y32.stride(0) if Y32 is not None else 0))
+    g.Yact, g.ldyact = N.ptr(Yact), (Yact.stride(0) if Yact is not None else 0)
+    g.M, g.E, g.S = Hg.shape[0], W2.shape[0], W2.shape[1]
+
+
+def mlp_fc2_proj_norm(groups: Sequence[Dict], eps: float = 1e-5, dtype: torch.dtype = torch.bfloat16) -> None:
+    """out = norm(proj(Hg W2^T + b2 + R)) in one launch (sea_mlp_fc2_proj_norm): dicts with Hg [M,S], W2 [E,S], b2, R f32 [M,E], Wproj [E,E], bproj,
+    Y32 and / or Yact, optional gamma / beta / mod (no gamma: no norm)."""
+    arr = (N.SeaMlp2Group * len(groups))()
+    for g, d in zip(arr, groups):
+        for k in ("Hg", "W2", "Wproj", "R"):
+            _mat(d[k], k)
+        fill_mlp2_group(g, d["Hg"], d["W2"], d["b2"], d["R"], d["Wproj"], d["bproj"], d.get("Y32"), d.get("Yact"), d.get("gamma"), d.get("beta"), d.get("mod"),
+                        d.get("ldy32"))
+    N.check(N.lib().sea_mlp_fc2_proj_norm(arr, len(groups), eps, N.dtype_code(dtype), N.stream_ptr()), "sea_mlp_fc2_proj_norm")
+
+
 def mlp_fc1_ln_gelu(groups: Sequence[Dict], eps: float = 1e-5, dtype: torch.dtype = torch.bfloat16) -> None:
     """Hg = gelu(LayerNorm(A W1^T + b1) * lnw + lnb) in one launch (sea_mlp_fc1_ln_gelu): dicts with A [M,E], W1 [S,E], b1, lnw, lnb f32 [S], Hg [M,S]."""
     arr = (N.SeaMlpGroup * len(groups))()

@@ -560,6 +560,52 @@ def test_mlp_fc1_ln_gelu_norm_prologue(E, S, M, adaln, with_add):
         assert rel(Hg.float(), Hg2.float()) < 8e-3
 
 
+@pytest.mark.parametrize("E,S", [(256, 2048), (128, 1024)])
+@pytest.mark.parametrize("M,norm", [(77, "adaln"), (2024, "adaln"), (333, "ln"), (64, None), (9000, "adaln")])
+def test_mlp_fc2_proj_norm_matches_three_launch_form(E, S, M, norm):
+    """sea_mlp_fc2_proj_norm (fc2 + residual, proj, the final norm: 32 complete rows per workgroup through both layers) against the fp32 formula on the
+    bf16 operands and against the three launches it replaces (which round x3 to bf16 between the layers, as this kernel does)."""
+    from sea_amd import ops
+
+    dt = torch.bfloat16
+    groups, refs, keep = [], [], []
+    for i in range(3):
+        Hg = rnd(M, S, dtype=dt, seed=1500 + i)
+        W2, b2 = rnd(E, S, dtype=dt, scale=0.03, seed=1510 + i), 0.2 * rnd(E, seed=1520 + i)
+        R = rnd(M, E, seed=1530 + i)
+        Wp, bp = rnd(E, E, dtype=dt, scale=0.08, seed=1540 + i), 0.2 * rnd(E, seed=1550 + i)
+        gamma = 1 + 0.1 * rnd(E, seed=1560 + i) if norm else None
+        beta = 0.1 * rnd(E, seed=1570 + i) if norm == "adaln" else None
+        mod = (0.3 * rnd(M, 2 * E, seed=1580 + i)).to(dt) if norm == "adaln" else None
+        out = torch.full((M, 3 * E), float("nan"), device=dev())                 # the caller's [M, F, E] output, this field's column range
+        y32 = out[:, i * E:(i + 1) * E]
+        groups.append(dict(Hg=Hg, W2=W2, b2=b2, R=R, Wproj=Wp, bproj=bp, Y32=y32, gamma=gamma, beta=beta, mod=mod))
+        x3 = (Hg.float() @ W2.float().t() + b2 + R).to(dt).float()
+        y = x3 @ Wp.float().t() + bp
+        if norm:
+            mu, var = y.mean(1, keepdim=True), y.var(1, unbiased=False, keepdim=True)
+            yh = (y - mu) / torch.sqrt(var + 1e-5)
+            if norm == "adaln":
+                y = yh * (gamma + 1 + mod[:, :E].float()) + beta + mod[:, E:].float()
+            else:
+                y = yh * gamma
+        refs.append(y)
+        keep.append(y32)
+    ops.mlp_fc2_proj_norm(groups)
+    for ref, y32, d in zip(refs, keep, groups):
+        assert bool(torch.isfinite(y32).all())
+        assert rel(y32, ref) < 6e-3
+        # the three launches
+        xm = torch.empty(M, E, device=dev(), dtype=dt)
+        y2 = torch.empty(M, E, device=dev())
+        ops.gemm_grouped([dict(A=d["Hg"], W=d["W2"], bias=d["b2"], R=d["R"], Cact=xm)], dt)
+        ops.gemm_grouped([dict(A=xm, W=d["Wproj"], bias=d["bproj"], C32=y2)], dt)
+        if norm:
+            nd = dict(X=y2, Y32=y2, gamma=d["gamma"], beta=d["beta"], mod=d["mod"])
+            ops.rownorm([nd], M, E, False, False, 1e-5, dt)
+        assert rel(y32, y2) < 2e-3
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_rownorm_ln_gelu_act_input(dtype):
     from sea_amd import ops
