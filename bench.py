@@ -210,22 +210,36 @@ def _timed(step, n_steps, warmup, dist, dev):
 
 
 def _launch_time_ms(rec, reps=20):
-    """Average duration of one launch of a record: `reps` back-to-back launches captured in one graph between two HIP events recorded on the
-    launch stream (no per-launch event or dispatch gap)."""
-    st = torch.cuda.Stream()
-    gk = torch.cuda.CUDAGraph()
-    with torch.cuda.stream(st):
-        with torch.cuda.graph(gk, stream=st):
+    """Average duration of one launch of a record: `reps` back-to-back launches between two HIP events recorded on the launch stream — captured in one
+    graph (no dispatch gap between them: the figure rocprofv3's per-kernel average agrees with) when no process group is alive; with one alive the
+    launches are enqueued directly (its watchdog thread's event queries would break a global-mode capture), which adds ~1 us of launch boundary each."""
+    from sea_amd import _native as N
+
+    use_graph = not (torch.distributed.is_available() and torch.distributed.is_initialized())
+    if use_graph:
+        st = torch.cuda.Stream()
+        gk = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(st):
+            with torch.cuda.graph(gk, stream=st):
+                for _ in range(reps):
+                    rc = rec.fn(*rec.args, st.cuda_stream)
+                    assert rc == 0, rec.name
+        burst = gk.replay
+    else:
+        stream = N.stream_ptr()
+
+        def burst():
             for _ in range(reps):
-                rc = rec.fn(*rec.args, st.cuda_stream)
+                rc = rec.fn(*rec.args, stream)
                 assert rc == 0, rec.name
-    gk.replay()
+
+    burst()
     torch.cuda.synchronize()
     best = 1e30
     for _ in range(5):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        gk.replay()
+        burst()
         e1.record()
         torch.cuda.synchronize()
         best = min(best, e0.elapsed_time(e1) / reps)
@@ -270,7 +284,7 @@ def _roofline(recs_times, esz, traffic_file=None):
             "machine_balance_flop_per_byte": PEAK_BF16_TFLOPS * 1e12 / (PEAK_HBM_GBPS * 1e9),
             "launch_ms": dom_ms, "launch_ms_single_event_pair": dom_ms_events, "launch_gflop": fl / 1e9,
             "device_ms_all_launches": sum(t for _, t in recs_times),
-            "timing": "launch_ms: HIP events on the launch stream around 20 back-to-back launches of the dominant record (one captured graph) / 20"}
+            "timing": "launch_ms: HIP events on the launch stream around 20 back-to-back launches of the dominant record (one captured graph at N = 1) / 20, best of 5"}
 
 
 def build_model(dev, dtype, F=3, ln="adaln", max_len=2024):
@@ -308,8 +322,8 @@ def leg_rollout(args, dist, dev, rank, world, steps, warmup, B):
         elapsed, out = _timed(step, steps, warmup, dist, dev)
         assert torch.isfinite(out).all()
         plan = eng.plan(B, T, "full")
-        out_keep = torch.empty_like(x)   # stays alive until the records have been timed: _launch_time_ms captures a graph, and torch.cuda.graph empties the
-        plan.bind(x, ib, out_keep)       # allocator's cache on entry — a freed output block would be unmapped under the launches that still write it
+        out_keep = torch.empty_like(x)   # stays alive until the records have been timed (a freed output block can be unmapped — e.g. by the cache flush a graph
+        plan.bind(x, ib, out_keep)       # capture starts with — under launches that still write it: seen as a memory fault when the final-norm launch was timed)
         plan.run()
         torch.cuda.synchronize()
         times = _time_list(plan.records, iters=10)

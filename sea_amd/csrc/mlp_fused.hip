@@ -56,10 +56,35 @@ __global__ __launch_bounds__(512) void mlp_fc1_ln_gelu_kernel(const MlpLaunch L)
     const unsigned lds_base = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)smem);
     const int rl = lane >> 3;
     const int chunk = (lane & 7) ^ (rl & 7);               // swizzle on the source side
+    // ---- gains / shifts of the LayerNorm: 1 KiB pieces straight into LDS, oldest in the queue (the epilogue finds them there)
+    for (int p = wave; p < 2 * (S / 256); p += NW) {
+        const float* src = p < S / 256 ? G.lnw : G.lnb;
+        const int q = p < S / 256 ? p : p - S / 256;
+        glds16_mlp(src + q * 256 + lane * 4, lds_base + (unsigned)(PRM_OFF + p * 1024));
+    }
+    // ---- A rows: KT x 4 pieces of 8 rows
+    for (int p = wave; G.X32 == nullptr && p < KT * (BM / 8); p += NW) {
+        const int kt = p / (BM / 8), u = p - kt * (BM / 8);
+        int row = m0 + u * 8 + rl;
+        row = row < M ? row : M - 1;
+        glds16_mlp(A + (int64_t)row * G.lda + kt * BK + chunk * 8, lds_base + (unsigned)(kt * BM * BKB + u * 8 * BKB));
+    }
+    constexpr int A_PIECES = (KT * (BM / 8) + NW - 1) / NW;   // per wave, upper bound (waves past the count issue none: wave-uniform)
+    auto dma_stage = [&](int s) {
+        const unsigned base = lds_base + (unsigned)(A_BYTES + (s % NS) * STAGE);
+#pragma unroll
+        for (int i = 0; i < LPS; ++i) {
+            const int p = i * NW + wave;                      // piece: K-tile kt, 8 rows u
+            const int kt = p >> 3, u = p & 7;
+            glds16_mlp(W + (int64_t)(s * 64 + u * 8 + rl) * G.ldw + kt * BK + chunk * 8, base + (unsigned)(kt * 64 * BKB + u * 8 * BKB));
+        }
+    };
+    dma_stage(0);
+    (void)A_PIECES;
     // ---- optional prologue: the operand rows are the normalised rows of the fp32 residual stream (x + addend, AdaLN / LayerNorm), written straight into
     // the A region in the K-tile-major, swizzled layout the LDS-DMA of ready-made rows would have produced.  16 lanes own a row (16 columns each), the
-    // statistics are two-pass like sea_rownorm's.  It runs BEFORE any LDS-DMA is issued (the compiler's wait for these loads is a vmcnt(0): behind the
-    // weight stream it would wait for that too; measured the other way round: 32.1 us per launch against 31.2).
+    // statistics are two-pass like sea_rownorm's.  Only the first weight stage is requested in front of it: the compiler's wait for these loads is a
+    // vmcnt(0), which behind the whole ring fill would wait for all of that (measured: 32.1 us per launch against 31.2 with nothing in front).
     if (G.X32 != nullptr) {
         constexpr int E = KT * 64, CPT = E / 16;              // columns per lane
         const int prow = tid >> 4, pl = tid & 15;              // 512 threads = 32 rows x 16 lanes
@@ -134,31 +159,7 @@ __global__ __launch_bounds__(512) void mlp_fc1_ln_gelu_kernel(const MlpLaunch L)
         }
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // (the Xout stores too: nothing of this wave is in the memory pipeline when the DMAs start)
     }
-    // ---- gains / shifts of the LayerNorm: 1 KiB pieces straight into LDS, oldest in the queue (the epilogue finds them there)
-    for (int p = wave; p < 2 * (S / 256); p += NW) {
-        const float* src = p < S / 256 ? G.lnw : G.lnb;
-        const int q = p < S / 256 ? p : p - S / 256;
-        glds16_mlp(src + q * 256 + lane * 4, lds_base + (unsigned)(PRM_OFF + p * 1024));
-    }
-    // ---- A rows: KT x 4 pieces of 8 rows
-    for (int p = wave; G.X32 == nullptr && p < KT * (BM / 8); p += NW) {
-        const int kt = p / (BM / 8), u = p - kt * (BM / 8);
-        int row = m0 + u * 8 + rl;
-        row = row < M ? row : M - 1;
-        glds16_mlp(A + (int64_t)row * G.lda + kt * BK + chunk * 8, lds_base + (unsigned)(kt * BM * BKB + u * 8 * BKB));
-    }
-    constexpr int A_PIECES = (KT * (BM / 8) + NW - 1) / NW;   // per wave, upper bound (waves past the count issue none: wave-uniform)
-    auto dma_stage = [&](int s) {
-        const unsigned base = lds_base + (unsigned)(A_BYTES + (s % NS) * STAGE);
-#pragma unroll
-        for (int i = 0; i < LPS; ++i) {
-            const int p = i * NW + wave;                      // piece: K-tile kt, 8 rows u
-            const int kt = p >> 3, u = p & 7;
-            glds16_mlp(W + (int64_t)(s * 64 + u * 8 + rl) * G.ldw + kt * BK + chunk * 8, base + (unsigned)(kt * 64 * BKB + u * 8 * BKB));
-        }
-    };
-    for (int s = 0; s < NS - 1; ++s) dma_stage(s);
-    (void)A_PIECES;
+    for (int s = 1; s < NS - 1; ++s) dma_stage(s);
 
     f32x4 acc[NSB][2];
     uint4 areg[KT][2][2];
