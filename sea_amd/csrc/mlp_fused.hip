@@ -617,10 +617,8 @@ extern "C" int sea_mlp_fc2_proj_norm(const SeaMlp2Group* groups, int n_groups, f
         (void)once;
         mlp_fc2_proj_norm_kernel<4, 32><<<dim3(total), dim3(512), lds, s>>>(L);
     } else {
-        constexpr int lds0 = 3 * (32 * 128 + 128 * 128) + 2 * 32 * 128 + 2 * 8 * 32 * 4;
-        static const int pad = []() { const char* e = getenv("SEA_MLP2_LDS_PAD"); return e ? atoi(e) : 0; }();   // debugging aid
-        const int lds = lds0 + pad;
-        static int once = set_lds_mlp(mlp_fc2_proj_norm_kernel<2, 16>, 160 * 1024);
+        constexpr int lds = 3 * (32 * 128 + 128 * 128) + 2 * 32 * 128 + 2 * 8 * 32 * 4;    // ring 60 KiB + x3 tile 8 KiB + statistics 2 KiB
+        static int once = set_lds_mlp(mlp_fc2_proj_norm_kernel<2, 16>, lds);
         (void)once;
         mlp_fc2_proj_norm_kernel<2, 16><<<dim3(total), dim3(512), lds, s>>>(L);
     }
