@@ -40,10 +40,14 @@ template <typename T, int HD, int SPLIT, bool DROP>
 __global__ __launch_bounds__(256 * SPLIT) void attention_fwd_kernel(const SeaAttnParams P) {
     using C = AttnCfg<T, HD>;
     constexpr int MERGE_BYTES = SPLIT > 1 ? (SPLIT - 1) * 256 * (2 + 4 * C::NDB) * 4 : 0;
-    constexpr int RING_BYTES = SPLIT * 2 * C::LDS_BYTES;                   // per group: double-buffered K and V^T tiles
+    // per group: double-buffered K and V^T tiles; ONE buffer where two do not fit the 160 KiB (f32 at head dim 256: 133 KiB per tile pair) — the
+    // next tile still travels in registers under the MFMAs, its LDS write waits for a second barrier per tile
+    constexpr int NBUF = 2 * C::LDS_BYTES <= 160 * 1024 ? 2 : 1;
+    static_assert(NBUF == 2 || (SPLIT == 1 && HD >= C::CK), "single-buffer form: one wave group, no zero-padded key rows");
+    constexpr int RING_BYTES = SPLIT * NBUF * C::LDS_BYTES;
     __shared__ __attribute__((aligned(16))) char smem_all[RING_BYTES > MERGE_BYTES ? RING_BYTES : MERGE_BYTES];
     const int grp = SPLIT > 1 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8)) : 0;  // wave-uniform
-    char* smem = smem_all + grp * 2 * C::LDS_BYTES;
+    char* smem = smem_all + grp * NBUF * C::LDS_BYTES;
 
     const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;  // tid, wave: inside the group
     const int r = lane & 15, g = lane >> 4;
@@ -276,7 +280,7 @@ __global__ __launch_bounds__(256 * SPLIT) void attention_fwd_kernel(const SeaAtt
     __syncthreads();
     for (int it = 0; it < n_it; ++it) {
         const int kt = it * SPLIT + grp;
-        const char* sK = smem + (it & 1) * C::LDS_BYTES;
+        const char* sK = smem + (NBUF == 2 ? (it & 1) : 0) * C::LDS_BYTES;
         const char* sV = sK + C::K_BYTES;
         const bool more = kt + SPLIT < n_kt;
         if (more) load_tile(kt + SPLIT);
@@ -288,7 +292,8 @@ __global__ __launch_bounds__(256 * SPLIT) void attention_fwd_kernel(const SeaAtt
                 process(sK, sV, kt, std::true_type{});    // diagonal / last tile
             }                                             // else: nothing visible to this wave (wave-uniform)
         }
-        if (more) store_tile((it + 1) & 1);
+        if constexpr (NBUF == 1) __syncthreads();   // every wave is done reading the only buffer
+        if (more) store_tile(NBUF == 2 ? (it + 1) & 1 : 0);
         __syncthreads();
     }
 
@@ -511,12 +516,7 @@ static int launch_attention_s(const SeaAttnParams& P, hipStream_t s) {
         case 32: attention_fwd_kernel<T, 32, SPLIT, DROP><<<grid, block, 0, s>>>(P); break;
         case 64: attention_fwd_kernel<T, 64, SPLIT, DROP><<<grid, block, 0, s>>>(P); break;
         case 128: attention_fwd_kernel<T, 128, 1, DROP><<<grid, dim3(256), 0, s>>>(P); break;  // LDS: one group only
-        case 256:  // the shipped multiphase dims (embed_dim 2048 / 8 heads): bf16 only, the f32 tiles would not fit the LDS ring
-            if constexpr (sizeof(T) == 2) {
-                attention_fwd_kernel<T, 256, 1, DROP><<<grid, dim3(256), 0, s>>>(P);
-                break;
-            }
-            return -1;
+        case 256: attention_fwd_kernel<T, 256, 1, DROP><<<grid, dim3(256), 0, s>>>(P); break;  // the shipped multiphase dims (embed_dim 2048 / 8 heads); f32: single LDS buffer
         default: return -1;
     }
     return 0;
@@ -549,8 +549,7 @@ extern "C" int sea_attention_fwd(const SeaAttnParams* params, int dtype, void* s
     SEA_REQUIRE(P.n_problems >= 1 && P.n_problems <= SEA_MAX_ATTN_PROBLEMS, "sea_attention_fwd: n_problems=%d", P.n_problems);
     SEA_REQUIRE(P.B >= 1 && P.H >= 1 && P.Tq >= 1 && P.Tk >= 1 && P.cap >= P.Tk && P.q_pos0 >= 0 && P.src_len >= 0,
                 "sea_attention_fwd: bad sizes B=%d H=%d Tq=%d Tk=%d cap=%d q_pos0=%d src_len=%d", P.B, P.H, P.Tq, P.Tk, P.cap, P.q_pos0, P.src_len);
-    SEA_REQUIRE(P.hd == 8 || P.hd == 16 || P.hd == 32 || P.hd == 64 || P.hd == 128 || (P.hd == 256 && dtype == SEA_BF16),
-                "sea_attention_fwd: unsupported head dim %d (8..128; 256 in bf16 only)", P.hd);
+    SEA_REQUIRE(P.hd == 8 || P.hd == 16 || P.hd == 32 || P.hd == 64 || P.hd == 128 || P.hd == 256, "sea_attention_fwd: unsupported head dim %d (8..256, powers of two)", P.hd);
     SEA_REQUIRE(P.cap % 8 == 0, "sea_attention_fwd: cap=%d must be a multiple of 8", P.cap);
     SEA_REQUIRE(P.drop.thr >= 0 && P.drop.thr <= 255, "sea_attention_fwd: bad dropout threshold %d", P.drop.thr);
     SEA_REQUIRE(P.ldo >= P.H * P.hd && P.ldo % 4 == 0, "sea_attention_fwd: bad ldo=%d", P.ldo);

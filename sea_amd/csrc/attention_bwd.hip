@@ -47,6 +47,9 @@ struct BwdCfg {
     static constexpr int TILE = 64 * PITCH;
     static constexpr int CPR = HD / EPC;                     // 16-byte chunks per row
     static constexpr int NR = (64 * CPR + 255) / 256;        // chunks per thread per tile
+    // the two streamed tiles are double-buffered; ONE buffer pair where four tiles do not fit the 160 KiB (f32 at head dim 256: 65 KiB per tile) — the
+    // next pair still travels in registers under the MFMAs, its LDS write waits for a second barrier per tile
+    static constexpr int NBUF = 4 * TILE + 1024 <= 160 * 1024 ? 2 : 1;
 };
 
 template <typename T>
@@ -108,7 +111,7 @@ __device__ __forceinline__ void unrope(float& e, float& o, const float2 cs) { un
 template <typename T, int HD, bool DROP>
 __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const SeaAttnBwdParams P) {
     using C = BwdCfg<T, HD>;
-    __shared__ __attribute__((aligned(16))) char smem[4 * C::TILE];  // 2 buffers x (K tile, V tile)
+    __shared__ __attribute__((aligned(16))) char smem[C::NBUF * 2 * C::TILE];  // NBUF buffers x (K tile, V tile)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, g = lane >> 4;
     int tile_, bh, zp;
     decode_attn_block(tile_, bh, zp);
@@ -211,7 +214,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const SeaAttnBwdParams
         }
     };
 
-    zero_tile_padding<T, HD>(smem, 4, tid);
+    zero_tile_padding<T, HD>(smem, 2 * C::NBUF, tid);
     TileStager<T, HD> stK, stV;
     stK.load(Kg, HD, 0, Tk, tid);
     stV.load(Vg, HD, 0, Tk, tid);
@@ -220,7 +223,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const SeaAttnBwdParams
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): pre-loop register loads are complete, so the per-tile MFMAs do not wait on the prefetch (see attention.hip)
     __syncthreads();
     for (int kt = 0; kt < n_kt; ++kt) {
-        const char* sK = smem + (kt & 1) * 2 * C::TILE;
+        const char* sK = smem + (C::NBUF == 2 ? (kt & 1) : 0) * 2 * C::TILE;
         const char* sV = sK + C::TILE;
         const bool more = kt + 1 < n_kt;
         if (more) {
@@ -231,9 +234,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const SeaAttnBwdParams
             if (kt * 64 + 63 <= wave_first && kt * 64 + 63 < Tk) tile(sK, sV, kt, std::false_type{});
             else tile(sK, sV, kt, std::true_type{});
         }
+        if constexpr (C::NBUF == 1) __syncthreads();   // every wave is done reading the only buffer pair
         if (more) {
-            stK.store(smem + ((kt + 1) & 1) * 2 * C::TILE, tid);
-            stV.store(smem + ((kt + 1) & 1) * 2 * C::TILE + C::TILE, tid);
+            char* nxt = smem + (C::NBUF == 2 ? ((kt + 1) & 1) : 0) * 2 * C::TILE;
+            stK.store(nxt, tid);
+            stV.store(nxt + C::TILE, tid);
         }
         __syncthreads();
     }
@@ -257,7 +262,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const SeaAttnBwdParams
 template <typename T, int HD, bool DROP>
 __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const SeaAttnBwdParams P) {
     using C = BwdCfg<T, HD>;
-    __shared__ __attribute__((aligned(16))) char smem[4 * C::TILE + 2 * 2 * 64 * 4];  // 2 x (Q tile, dO tile) + 2 x (lse, delta)
+    constexpr int VEC_OFF = C::NBUF * 2 * C::TILE;
+    __shared__ __attribute__((aligned(16))) char smem[VEC_OFF + 2 * 2 * 64 * 4];  // NBUF x (Q tile, dO tile) + 2 x (lse, delta)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, g = lane >> 4;
     int kb, bh, zp;  // key tile: the first key tiles are seen by the most queries -> ascending order is heaviest-first
     decode_attn_block(kb, bh, zp);
@@ -363,13 +369,13 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const SeaAttnBwdParam
         }
     };
     auto store_vec = [&](int buf) {
-        float* sl = reinterpret_cast<float*>(smem + 4 * C::TILE) + buf * 128;
+        float* sl = reinterpret_cast<float*>(smem + VEC_OFF) + buf * 128;
         if (tid < 64) {
             sl[tid] = r_lse;
             sl[64 + tid] = r_del;
         }
     };
-    zero_tile_padding<T, HD>(smem, 4, tid);
+    zero_tile_padding<T, HD>(smem, 2 * C::NBUF, tid);
     if (qt0 < n_qt) {
         stQ.load(Qg, HD, qt0 * 64, Tq, tid);
         stO.load(dOg, P.lddo, qt0 * 64, Tq, tid);
@@ -382,11 +388,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const SeaAttnBwdParam
     __syncthreads();
     for (int qt = qt0; qt < n_qt; ++qt) {
         const int bi = (qt - qt0) & 1;
-        const char* sQ = smem + bi * 2 * C::TILE;
+        const char* sQ = smem + (C::NBUF == 2 ? bi : 0) * 2 * C::TILE;
         const char* sO = sQ + C::TILE;
-        const float* sL = reinterpret_cast<const float*>(smem + 4 * C::TILE) + bi * 128;
+        const float* sL = reinterpret_cast<const float*>(smem + VEC_OFF) + bi * 128;
         const bool more = qt + 1 < n_qt;
-        if (more) {
+        if (more && C::NBUF == 2) {
             stQ.load(Qg, HD, (qt + 1) * 64, Tq, tid);
             stO.load(dOg, P.lddo, (qt + 1) * 64, Tq, tid);
             load_vec(qt + 1);
@@ -396,9 +402,20 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const SeaAttnBwdParam
             if (need_mask) tile(sQ, sO, sL, qt, std::true_type{});
             else tile(sQ, sO, sL, qt, std::false_type{});
         }
+        if constexpr (C::NBUF == 1) {
+            __syncthreads();   // every wave is done reading the only buffer pair
+            // (this form also loads the next pair only now: with dK, dV and the K / V fragments of a 256-wide f32 head in registers there is no room
+            // for two tiles in flight — it is the parity path of the shipped multiphase width, not a fast one)
+            if (more) {
+                stQ.load(Qg, HD, (qt + 1) * 64, Tq, tid);
+                stO.load(dOg, P.lddo, (qt + 1) * 64, Tq, tid);
+                load_vec(qt + 1);
+            }
+        }
         if (more) {
-            stQ.store(smem + (bi ^ 1) * 2 * C::TILE, tid);
-            stO.store(smem + (bi ^ 1) * 2 * C::TILE + C::TILE, tid);
+            char* nxt = smem + (C::NBUF == 2 ? (bi ^ 1) : 0) * 2 * C::TILE;
+            stQ.store(nxt, tid);
+            stO.store(nxt + C::TILE, tid);
             store_vec(bi ^ 1);
         }
         __syncthreads();
@@ -441,12 +458,7 @@ static int dispatch_bwd(const SeaAttnBwdParams& P, hipStream_t s) {
         case 32: launch_bwd<T, 32>(P, s); break;
         case 64: launch_bwd<T, 64>(P, s); break;
         case 128: launch_bwd<T, 128>(P, s); break;
-        case 256:   // the shipped multiphase dims (embed_dim 2048 / 8 heads): bf16 only — four [64, 256] f32 tiles do not fit the 160 KB of LDS
-            if constexpr (sizeof(T) == 2) {
-                launch_bwd<T, 256>(P, s);
-                break;
-            }
-            return -1;
+        case 256: launch_bwd<T, 256>(P, s); break;   // the shipped multiphase dims (embed_dim 2048 / 8 heads); f32: one LDS buffer pair (BwdCfg::NBUF)
         default: return -1;
     }
     return 0;
@@ -459,8 +471,7 @@ extern "C" int sea_attention_bwd(const SeaAttnBwdParams* params, int dtype, void
     SEA_REQUIRE(P.n_problems >= 1 && P.n_problems <= SEA_MAX_ATTN_PROBLEMS, "sea_attention_bwd: n_problems=%d", P.n_problems);
     SEA_REQUIRE(P.B >= 1 && P.H >= 1 && P.Tq >= 1 && P.Tk >= 1 && P.cap >= P.Tk && P.q_pos0 >= 0 && P.src_len >= 0 && P.rope,
                 "sea_attention_bwd: bad sizes B=%d H=%d Tq=%d Tk=%d cap=%d", P.B, P.H, P.Tq, P.Tk, P.cap);
-    SEA_REQUIRE(P.hd == 8 || P.hd == 16 || P.hd == 32 || P.hd == 64 || P.hd == 128 || (P.hd == 256 && dtype == SEA_BF16),
-                "sea_attention_bwd: unsupported head dim %d (8 .. 128; 256 with bf16)", P.hd);
+    SEA_REQUIRE(P.hd == 8 || P.hd == 16 || P.hd == 32 || P.hd == 64 || P.hd == 128 || P.hd == 256, "sea_attention_bwd: unsupported head dim %d (8 .. 256, powers of two)", P.hd);
     const int epc = dtype == SEA_BF16 ? 8 : 4;
     SEA_REQUIRE(P.ldo % epc == 0 && P.lddo % epc == 0 && P.lddq % 4 == 0 && P.lddk % 4 == 0 && P.lddv % 4 == 0, "sea_attention_bwd: bad strides");
     SEA_REQUIRE((long)P.B * P.H <= 65535, "sea_attention_bwd: B*H too large for grid.y");

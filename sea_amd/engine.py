@@ -913,10 +913,8 @@ class TemporalEngine:
         self.trainable_variant = m.exchange_mode in ("sea", "addition", "simple")   # what the hand-written backward covers ('pool': forward / rollout only)
         E, H, D = m.embed_dim, m.n_heads, m.down_dim
         for hd, what in ((E // H, "self"),) + (((D // H, "cross"),) if m.exchange_mode in ("sea", "pool") else ()):
-            ok = hd in (8, 16, 32, 64, 128) or (hd == 256 and act_dtype == torch.bfloat16)
-            if not ok or hd * H != (E if what == "self" else D):
-                raise NotImplementedError(f"sea_amd: unsupported {what}-attention head dim {hd} (supported: 8, 16, 32, 64, 128; 256 with "
-                                          "compute dtype bf16)")
+            if hd not in (8, 16, 32, 64, 128, 256) or hd * H != (E if what == "self" else D):
+                raise NotImplementedError(f"sea_amd: unsupported {what}-attention head dim {hd} (supported: 8, 16, 32, 64, 128, 256)")
         if m.src_len < 0:
             raise NotImplementedError("sea_amd: src_len must be >= 0")
         if self.ib_mode == 0 and m.ib_hidden > 64:

@@ -128,21 +128,22 @@ def test_gradients_match_oracle_larger_shape(dtype, tol):
     assert worst < 10 * tol, (worst_k, worst)
 
 
-def test_gradients_at_multiphase_width_head_dim_256():
+@pytest.mark.parametrize("dtype,tol", [("bf16", 6e-2), ("fp32", 1e-4)])
+def test_gradients_at_multiphase_width_head_dim_256(dtype, tol):
     """embed_dim 2048, 8 heads (the shipped multiphase_flow dims: self-attention head dim 256, cross 128, MLP hidden 16384), LayerNorm without
-    modulation, two fields: forward + backward in bf16 against the CPU oracle's fp32 autograd (T = 40: one key tile, every width-dependent path of
-    the row passes and GEMMs).  bf16 <= 6e-2 over all parameters together, each within 10x of that."""
+    modulation, two fields: forward + backward against the CPU oracle's fp32 autograd (T = 40: one key tile, every width-dependent path of
+    the row passes and GEMMs).  bf16 <= 6e-2 / fp32 <= 1e-4 over all parameters together, each within 10x of that."""
     cfg = O.OracleConfig(1, 2048, 8, 48, 8, 0, 2, 2, True, "ln")
     p = recipe_params(cfg)
     x, tgt, ib = recipe_inputs(1, 40, cfg, seed=5)
     _, loss_ref, grads_ref = O.loss_and_grads(x, ib, tgt, p, cfg)
-    m = build(cfg, "bf16").train()
+    m = build(cfg, dtype).train()
     eng = m.engine()
     out, plan = eng.forward_train(x.cuda(), ib.cuda())
     loss, dout = eng.mse_loss_and_grad(out, tgt.cuda())
     eng.zero_grads()
     eng.backward(plan, dout)
-    assert abs(loss.item() - float(loss_ref)) < 6e-2 * float(loss_ref)
+    assert abs(loss.item() - float(loss_ref)) < tol * float(loss_ref)
     num = den = 0.0
     worst, worst_k = 0.0, None
     for k, gr in grads_ref.items():
@@ -152,9 +153,9 @@ def test_gradients_at_multiphase_width_head_dim_256():
         e = rel_l2(mine.numpy(), gr.numpy())
         if e > worst:
             worst, worst_k = e, k
-    print(f"multiphase width bf16 gradients: overall rel-L2 {(num / den) ** 0.5:.3e}, worst {worst_k} {worst:.3e}")
-    assert (num / den) ** 0.5 < 6e-2
-    assert worst < 0.6, (worst_k, worst)
+    print(f"multiphase width {dtype} gradients: overall rel-L2 {(num / den) ** 0.5:.3e}, worst {worst_k} {worst:.3e}")
+    assert (num / den) ** 0.5 < tol
+    assert worst < 10 * tol, (worst_k, worst)
     assert sorted(eng.params.live_names) == sorted(grads_ref.keys())
 
 
