@@ -305,7 +305,7 @@ def rollout(x0: torch.Tensor, cond: torch.Tensor, n_steps: int, p: Params, cfg: 
 
 def live_param_keys(p: Params, cfg: OracleConfig) -> List[str]:
     """Parameters that receive a gradient on this path: everything except
-    ln.exp.{i}.1, ln.cross, the diagonal cross_attn.{i}.{i}, ib.residual_projection."""
+    ln.exp.{i}.1, ln.cross, the diagonal cross_attn.{i}.{i}, ib.residual_projection (and, per variant, the unused info-bottleneck layer / the pool token)."""
     dead_marks = []
     for layer in range(cfg.num_layers):
         pre = f"blocks.{layer}."
@@ -318,6 +318,8 @@ def live_param_keys(p: Params, cfg: OracleConfig) -> List[str]:
         for i in range(cfg.num_variables):
             dead_marks.append(f"{pre}ln.exp.{i}.1.")
             dead_marks.append(f"{pre}cross_attn.{i}.{i}.")
+        if getattr(cfg, "exchange_mode", "sea") == "pool":         # the 'mlp' pool update ignores its token argument (models/temporal.py:244-249)
+            dead_marks += [pre + "pool_token", pre + "ln_pool."]
     return [k for k in p if not any(k.startswith(d) for d in dead_marks)]
 
 

@@ -51,6 +51,8 @@ def dead_prefixes(model) -> List[str]:
             out.append(pre + "ib.W")
         for i in range(model.num_variables):
             out += [f"{pre}ln.exp.{i}.1.", f"{pre}cross_attn.{i}.{i}."]
+        if model.exchange_mode == "pool":   # the 'mlp' pool update ignores its token argument (models/temporal.py:244-249): the token and its norm are never used
+            out += [pre + "pool_token", pre + "ln_pool."]
     return out
 
 
@@ -910,7 +912,6 @@ class TemporalEngine:
                 "sea_amd native path covers exchange_mode in {'sea', 'addition', 'simple', 'pool'}, ib_scale_mode in {'mlp', 'linear', 'fourier'}, ib_addition_mode in "
                 "{'add', 'none'}, ib_mlp_layers=1, ib_num=1; got "
                 f"{m.exchange_mode}/{m.ib_scale_mode}/{m.ib_addition_mode}/{m.ib_mlp_layers}/{m.ib_num}")
-        self.trainable_variant = m.exchange_mode in ("sea", "addition", "simple")   # what the hand-written backward covers ('pool': forward / rollout only)
         E, H, D = m.embed_dim, m.n_heads, m.down_dim
         for hd, what in ((E // H, "self"),) + (((D // H, "cross"),) if m.exchange_mode in ("sea", "pool") else ()):
             if hd not in (8, 16, 32, 64, 128, 256) or hd * H != (E if what == "self" else D):
@@ -988,10 +989,10 @@ class TemporalEngine:
         from .train_engine import TrainPlan
 
         m = self.model
-        if not self.trainable_variant:
-            raise NotImplementedError("sea_amd: training (backward) covers exchange_mode in {'sea', 'addition', 'simple'} with every ib_scale_mode / ib_addition_mode "
-                                      f"the forward covers; exchange_mode='pool' runs forward / rollout only (got {m.exchange_mode})")
         thr = int(round(256 * m.dropout_p)) if (m.training and m.dropout_p > 0) else 0
+        if thr > 0 and m.exchange_mode == "pool":
+            raise NotImplementedError("sea_amd: exchange_mode='pool' trains with dropout = 0 only (the reference also drops the position-encoded rows, "
+                                      "models/base_blocks.py:371-372: no counter-based mask is defined for that site)")
         if thr > 255:
             raise ValueError("dropout probability too close to 1")
         key = (B, T, thr)

@@ -15,7 +15,7 @@ from typing import Dict, List, Optional, Tuple
 import torch
 
 from . import _native as N
-from .engine import Plan, _Rec, _fill_gemm
+from .engine import Plan, _Rec, _fill_gemm, blk_pe
 
 
 class TrainPlan(Plan):
@@ -179,7 +179,7 @@ class TrainPlan(Plan):
                 pre = f"blocks.{l}."
                 for i in range(F):
                     prefixes += [(f"{pre}ln.exp.{i}.0.", E), (f"{pre}ln.exp.{i}.2.", E)]
-                if F > 1 and xmode in ("sea", "addition"):
+                if (F > 1 and xmode in ("sea", "addition")) or xmode == "pool":
                     for i in range(F):
                         prefixes.append((f"{pre}ln_cross.{i}.", D))
             for i in range(F):
@@ -279,6 +279,47 @@ class TrainPlan(Plan):
                 self._gemm([dict(A=sv["nd"][0], W=eng.eye(D), n_seg=F, a_seg_stride=M * D, Cact=sv["sg"], Z=sv["s_pre"], act=1)], "add.sum_gelu")
                 self._gemm([dict(A=sv["sg"], W=P.act(f"{pre}cross_up.{i}.weight"), bias=P.f32_vec(f"{pre}cross_up.{i}.bias"), R=sv["xr"][i], C32=sv["xr"][i])
                             for i in range(F)], "add.up")
+            if xmode == "pool":
+                # 'pool' exchange (models/temporal.py:255-283, pool_update_method 'mlp'; Jacobi; runs for F = 1 too): n_j = ln_cross_j(cross_down_j(x_j)) + pe,
+                # pool = W2 gelu(W0 cat_j n_j + b0) + b2, a_i = cross_attn_i(n_i, pool), x_i += cross_up_i(gelu(n_i + a_i)).  `big` = [n_0 .. n_{F-1} | a_0 .. a_{F-1}]
+                # as in the inference plan (engine.py); everything a gradient needs is kept.  (pool_token / ln_pool never reach the output: dead parameters.)
+                FD = F * D
+                sv["dn"] = [buf(M, D, dtype=f32) for _ in range(F)]
+                sv["stc"] = [stats() for _ in range(F)]
+                nrm = [buf(M, D) for _ in range(F)]
+                big = sv["big"] = buf(M, 2 * FD)
+                pe_t = buf(M, D, dtype=f32)
+                pe_t.copy_(blk_pe(eng, l)[:T].repeat(B, 1))
+                if os.environ.get("SEA_FUSE_NORM", "1") != "0" and D <= 256 and D % 16 == 0:
+                    self._gemm_norm([dict(A=sv["xa1"][j], W=P.act(f"{pre}cross_down.{j}.weight"), bias=P.f32_vec(f"{pre}cross_down.{j}.bias"), C32=sv["dn"][j],
+                                          Yact=nrm[j], mean=sv["stc"][j][0], rstd=sv["stc"][j][1], **npar(f"{pre}ln_cross.{j}.")) for j in range(F)], "pool.down_norm")
+                else:
+                    self._gemm([dict(A=sv["xa1"][j], W=P.act(f"{pre}cross_down.{j}.weight"), bias=P.f32_vec(f"{pre}cross_down.{j}.bias"), C32=sv["dn"][j])
+                                for j in range(F)], "pool.down")
+                    self._norm([dict(X=sv["dn"][j], Yact=nrm[j], mean=sv["stc"][j][0], rstd=sv["stc"][j][1], **npar(f"{pre}ln_cross.{j}.")) for j in range(F)],
+                               D, "pool.norm")
+                self._gemm([dict(A=nrm[j], W=eng.eye(D), R=pe_t, Cact=big[:, j * D:(j + 1) * D]) for j in range(F)], "pool.pe_add")
+                sv["hp_pre"], sv["hp"], sv["pool"] = buf(M, 2 * D), buf(M, 2 * D), buf(M, D)
+                self._gemm([dict(A=big[:, :FD], W=P.act(f"{pre}pool_update.0.weight"), bias=P.f32_vec(f"{pre}pool_update.0.bias"), Cact=sv["hp"], Z=sv["hp_pre"],
+                                 act=1)], "pool.update0")
+                self._gemm([dict(A=sv["hp"], W=P.act(f"{pre}pool_update.2.weight"), bias=P.f32_vec(f"{pre}pool_update.2.bias"), Cact=sv["pool"])], "pool.update2")
+                sv["pq"] = [dict(Q=buf(B, H, T, hd_c), K=buf(B, H, cap, hd_c, zero=True), V=buf(B, H, cap, hd_c, zero=True), Vt=buf(B, H, hd_c, cap, zero=True),
+                                 O=buf(M, D), LSE=buf(B, H, T, dtype=f32)) for _ in range(F)]
+                qg = []
+                for i in range(F):
+                    ca, pr = f"{pre}cross_attn.{i}.", sv["pq"][i]
+                    qg.append(dict(A=big[:, i * D:(i + 1) * D], W=P.act(ca + "q.weight"), bias=P.f32_vec(ca + "q.bias"), col0=0, Q=pr["Q"]))
+                    qg.append(dict(A=sv["pool"], W=P.act(ca + "k.weight", 2 * D), bias=P.f32_vec(ca + "k.bias", 2 * D), col0=D, K=pr["K"], Vt=pr["Vt"], V=pr["V"]))
+                self._qkv(qg, rope_c, hd_c, "pool.qkv_rope")
+                sv["pool_drop"] = (thr, self._streams(F)) if thr else None
+                self._attn([dict(Q=pr["Q"], K=pr["K"], Vt=pr["Vt"], O=pr["O"], LSE=pr["LSE"]) for pr in sv["pq"]], hd_c, D, "pool.attention", drop=sv["pool_drop"])
+                self._gemm([dict(A=sv["pq"][i]["O"], W=P.act(f"{pre}cross_attn.{i}.projection.weight"), Cact=big[:, FD + i * D:FD + (i + 1) * D]) for i in range(F)],
+                           "pool.proj")
+                sv["ps_pre"], sv["psg"] = [buf(M, D) for _ in range(F)], [buf(M, D) for _ in range(F)]
+                self._gemm([dict(A=big[:, i * D:(i + 1) * D], W=eng.eye(D), n_seg=2, a_seg_stride=FD, Cact=sv["psg"][i], Z=sv["ps_pre"][i], act=1) for i in range(F)],
+                           "pool.sum_gelu")
+                self._gemm([dict(A=sv["psg"][i], W=P.act(f"{pre}cross_up.{i}.weight"), bias=P.f32_vec(f"{pre}cross_up.{i}.bias"), R=sv["xr"][i], C32=sv["xr"][i])
+                            for i in range(F)], "pool.up")
             if F > 1 and xmode == "sea":
                 sv["dn_old"] = [buf(M, D, dtype=f32) for _ in range(F)]
                 sv["nd_old"] = [buf(M, D) for _ in range(F)]
@@ -417,6 +458,48 @@ class TrainPlan(Plan):
                                D, "bwd.add.norm", True, False, False, False)
                 self._wgrad([dict(dY=ddn[j], X=sv["xa1"][j], dW=G2(f"{pre}cross_down.{j}.weight"), db=Gv(f"{pre}cross_down.{j}.bias")) for j in range(F)], "bwd.add.down.wgrad")
                 self._gemm([dict(A=ddn[j], W=P.actT(f"{pre}cross_down.{j}.weight"), R=dx[j], C32=dx[j], Cact=ga[j]) for j in range(F)], "bwd.add.down.dgrad")
+            if xmode == "pool":
+                # x2_i = x1_i + Wu_i gelu(s_i) + bu_i, s_i = n_i + a_i: ga[i] = act copy of d x2_i; dnd[j] collects d n_j (from s_j, from q_j and through the pool)
+                FD, big = F * D, sv["big"]
+                self._wgrad([dict(dY=ga[i], X=sv["psg"][i], dW=G2(f"{pre}cross_up.{i}.weight"), db=Gv(f"{pre}cross_up.{i}.bias")) for i in range(F)], "bwd.pool.up.wgrad")
+                ds = [buf(M, D) for _ in range(F)]
+                dnd = [buf(M, D, dtype=f32) for _ in range(F)]
+                self._gemm([dict(A=ga[i], W=P.actT(f"{pre}cross_up.{i}.weight"), Z=sv["ps_pre"][i], act=2, Cact=ds[i], C32=dnd[i]) for i in range(F)], "bwd.pool.up.dgrad")
+                self._wgrad([dict(dY=ds[i], X=sv["pq"][i]["O"], dW=G2(f"{pre}cross_attn.{i}.projection.weight")) for i in range(F)], "bwd.pool.proj.wgrad")
+                datt = [buf(M, D) for _ in range(F)]
+                self._gemm([dict(A=ds[i], W=P.actT(f"{pre}cross_attn.{i}.projection.weight"), Cact=datt[i]) for i in range(F)], "bwd.pool.proj.dgrad")
+                dqp, dkvp = [buf(M, D) for _ in range(F)], [buf(M, 2 * D) for _ in range(F)]
+                delta_p = [buf(B, H, T, dtype=f32) for _ in range(F)]
+                self._attn_bwd([dict(Q=sv["pq"][i]["Q"], K=sv["pq"][i]["K"], V=sv["pq"][i]["V"], O=sv["pq"][i]["O"], dO=datt[i], LSE=sv["pq"][i]["LSE"],
+                                     delta=delta_p[i], dQ=dqp[i], dK=dkvp[i][:, :D], dV=dkvp[i][:, D:]) for i in range(F)], hd_c, rope_c, "bwd.pool.attention",
+                               drop=sv["pool_drop"])
+                wg = []
+                for i in range(F):
+                    ca = f"{pre}cross_attn.{i}."
+                    wg.append(dict(dY=dqp[i], X=big[:, i * D:(i + 1) * D], dW=G2(ca + "q.weight"), db=Gv(ca + "q.bias")))
+                    wg.append(dict(dY=dkvp[i], X=sv["pool"], dW=G2(ca + "k.weight", 2 * D), db=Gv(ca + "k.bias", 2 * D)))
+                self._wgrad(wg, "bwd.pool.qkv.wgrad")
+                self._gemm([dict(A=dqp[i], W=P.actT(f"{pre}cross_attn.{i}.q.weight"), R=dnd[i], C32=dnd[i]) for i in range(F)], "bwd.pool.q.dgrad")
+                dpool32, dpool = buf(M, D, dtype=f32), buf(M, D)
+                for i in range(F):   # sequential: every field's keys / values came from the same pool rows
+                    g = dict(A=dkvp[i], W=P.actT(f"{pre}cross_attn.{i}.k.weight", 2 * D), C32=dpool32)
+                    if i > 0:
+                        g["R"] = dpool32
+                    if i == F - 1:
+                        g["Cact"] = dpool
+                    self._gemm([g], f"bwd.pool.kv.dgrad{i}")
+                self._wgrad([dict(dY=dpool, X=sv["hp"], dW=G2(f"{pre}pool_update.2.weight"), db=Gv(f"{pre}pool_update.2.bias"))], "bwd.pool.update2.wgrad")
+                dhp = buf(M, 2 * D)
+                self._gemm([dict(A=dpool, W=P.actT(f"{pre}pool_update.2.weight"), Z=sv["hp_pre"], act=2, Cact=dhp)], "bwd.pool.update2.dgrad")
+                self._wgrad([dict(dY=dhp, X=big[:, :FD], dW=G2(f"{pre}pool_update.0.weight"), db=Gv(f"{pre}pool_update.0.bias"))], "bwd.pool.update0.wgrad")
+                w0t = P.actT(f"{pre}pool_update.0.weight")          # [F D, 2 D]: rows j D .. (j+1) D map d hp onto d n_j
+                self._gemm([dict(A=dhp, W=w0t[j * D:(j + 1) * D], R=dnd[j], C32=dnd[j]) for j in range(F)], "bwd.pool.update0.dgrad")
+                ddn = [buf(M, D) for _ in range(F)]
+                self._norm_bwd([dict(dY=dnd[j], X=sv["dn"][j], mean=sv["stc"][j][0], rstd=sv["stc"][j][1], dXact=ddn[j], **bpar(f"{pre}ln_cross.{j}.", D))
+                                for j in range(F)], D, "bwd.pool.norm", False, False, False, False)
+                self._wgrad([dict(dY=ddn[j], X=sv["xa1"][j], dW=G2(f"{pre}cross_down.{j}.weight"), db=Gv(f"{pre}cross_down.{j}.bias")) for j in range(F)],
+                            "bwd.pool.down.wgrad")
+                self._gemm([dict(A=ddn[j], W=P.actT(f"{pre}cross_down.{j}.weight"), R=dx[j], C32=dx[j], Cact=ga[j]) for j in range(F)], "bwd.pool.down.dgrad")
             # ---- state exchange (reverse Gauss-Seidel order); ga[i] = act copy of d x2_i when field i is reached
             if F > 1 and xmode == "sea":
                 dnd_old = [buf(M, D, dtype=f32) for _ in range(F)]

@@ -522,6 +522,8 @@ def main():
     cases["train_sea_noib_adaln_f2"] = lambda: model_case("train_sea_noib_adaln_f2", OracleConfig(1, 32, 2, 24, 8, 0, 2, 2, True, "adaln", "sea", "none"), 2, 12, train="grads")
     cases["train_sea_linear_ln_f2_pre"] = lambda: model_case("train_sea_linear_ln_f2_pre", OracleConfig(1, 32, 2, 24, 8, 0, 2, 2, False, "ln", "sea", "add", "linear"), 2, 12, train="grads")
     cases["train_addition_fourier_adaln_f3"] = lambda: model_case("train_addition_fourier_adaln_f3", OracleConfig(1, 32, 2, 24, 8, 0, 3, 2, True, "adaln", "addition", "add", "fourier"), 2, 12, train="grads")
+    cases["train_pool_adaln_f3"] = lambda: model_case("train_pool_adaln_f3", OracleConfig(2, 32, 2, 24, 8, 0, 3, 2, True, "adaln", "pool"), 2, 12, train="grads")
+    cases["train_pool_ln_f1"] = lambda: model_case("train_pool_ln_f1", OracleConfig(1, 32, 2, 24, 8, 0, 1, 2, False, "ln", "pool"), 2, 12, train="grads")
     for T in (1, 7, 16, 65):
         cases[f"model_small_adaln_f3_T{T}"] = (lambda T=T: model_case(
             f"model_small_adaln_f3_T{T}", OracleConfig(1, 64, 4, 80, 8, 0, 3, 2, True, "adaln"), 2, T))

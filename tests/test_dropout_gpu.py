@@ -244,3 +244,19 @@ def test_standalone_module_forwards_with_dropout():
         mod.eval()
         with torch.no_grad():
             assert torch.equal(mod(*args), ref)
+
+
+def test_pool_exchange_training_with_dropout_is_refused():
+    """exchange_mode='pool' also drops its position-encoded rows in the reference (PositionalEncoding, models/base_blocks.py:370-372): no mask is
+    defined for that site here, so a training forward with dropout > 0 fails loudly; eval() (rollouts) and dropout 0 run."""
+    from sea_amd.models.temporal import TemporalModel
+
+    m = TemporalModel(1, 64, 4, 48, 8, 0, 2, 2, 0.1, "pool", "learnable", "mlp", "add", 1, 1, True, "ln").to("cuda:0")
+    cfg = O.OracleConfig(1, 64, 4, 48, 8, 0, 2, 2, True, "ln", "pool")
+    x, _, ib = (t.cuda() for t in recipe_inputs(2, 20, cfg, seed=4))
+    m.eval()
+    with torch.no_grad():
+        assert torch.isfinite(m(x, ib)).all()
+    m.train()
+    with pytest.raises(NotImplementedError, match="dropout"):
+        m(x, ib)

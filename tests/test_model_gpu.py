@@ -69,7 +69,7 @@ def test_bf16_fused_launches_at_shipped_widths(F, ln, after):
 @pytest.mark.parametrize("xmode,ibmode,ibscale", [("addition", "add", "mlp"), ("simple", "add", "mlp"), ("sea", "none", "mlp"), ("sea", "add", "fourier"), ("addition", "add", "linear"), ("pool", "add", "mlp")])
 def test_ablation_variants_rollout_bf16_and_training(xmode, ibmode, ibscale):
     """The ablation variants through the same plan machinery: bf16 forward within the stated tolerance of the fp32 oracle, KV-cache rollout
-    equal to the recompute rollout, and the hand-written backward against the oracle's autograd ('pool': refused loudly)."""
+    equal to the recompute rollout, and the hand-written backward against the oracle's autograd."""
     from sea_amd.utils.train_utils import rollout
 
     cfg = O.OracleConfig(2, 128, 4, 96, 8, 0, 3, 2, True, "adaln", xmode, ibmode, ibscale)
@@ -91,20 +91,17 @@ def test_ablation_variants_rollout_bf16_and_training(xmode, ibmode, ibscale):
         assert rel_l2(b.cpu().numpy(), a.cpu().numpy()) < 1e-5
     assert rel_l2(a.cpu().numpy(), O.rollout(x[:, :1], ib, 12, recipe_params(cfg), cfg).numpy()) < FP32_TOL
     m32.train()
-    if xmode == "pool":   # the one variant whose backward is not built: refused loudly
-        with pytest.raises(NotImplementedError, match="training"):
-            m32(x.cuda(), ib.cuda())
-    else:                 # gradients against the CPU oracle's autograd (the reference-generated goldens are in tests/test_train_gpu.py)
-        _, loss_ref, grads_ref = O.loss_and_grads(x, ib, x * 0.5, recipe_params(cfg), cfg)
-        eng = m32.engine()
-        out, plan = eng.forward_train(x.cuda(), ib.cuda())
-        loss, dout = eng.mse_loss_and_grad(out, (x * 0.5).cuda())
-        eng.zero_grads()
-        eng.backward(plan, dout)
-        assert abs(loss.item() - float(loss_ref)) < 1e-4 * float(loss_ref)
-        for k, gr in grads_ref.items():
-            assert rel_l2(eng.grad_view(k).cpu().numpy(), gr.numpy()) < 2e-4, k
-        assert sorted(eng.params.live_names) == sorted(grads_ref.keys())
+    # gradients against the CPU oracle's autograd (the reference-generated goldens are in tests/test_train_gpu.py)
+    _, loss_ref, grads_ref = O.loss_and_grads(x, ib, x * 0.5, recipe_params(cfg), cfg)
+    eng = m32.engine()
+    out, plan = eng.forward_train(x.cuda(), ib.cuda())
+    loss, dout = eng.mse_loss_and_grad(out, (x * 0.5).cuda())
+    eng.zero_grads()
+    eng.backward(plan, dout)
+    assert abs(loss.item() - float(loss_ref)) < 1e-4 * float(loss_ref)
+    for k, gr in grads_ref.items():
+        assert rel_l2(eng.grad_view(k).cpu().numpy(), gr.numpy()) < 2e-4, k
+    assert sorted(eng.params.live_names) == sorted(grads_ref.keys())
 
 
 def test_kv_rollout_with_src_len_is_refused_and_falls_back_to_recompute():

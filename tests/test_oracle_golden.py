@@ -149,6 +149,24 @@ def test_model_grads_and_adamw(name):
         assert torch.equal(p3[k], p[k])
 
 
+@pytest.mark.parametrize("name", ["train_addition_adaln_f3", "train_simple_ln_f2", "train_sea_noib_adaln_f2", "train_sea_linear_ln_f2_pre",
+                                  "train_addition_fourier_adaln_f3", "train_pool_adaln_f3", "train_pool_ln_f1"])
+def test_variant_model_grads(name):
+    """The ablation variants' train step (reference models/temporal.py:197-312, 103-116): output, loss, every gradient and the set of gradient-less
+    parameters of the oracle against what the reference produced."""
+    g = load_golden(name)
+    cfg = cfg_from_meta(g["cfg"])
+    p = recipe_params(cfg)
+    out, loss, grads = O.loss_and_grads(T(g["x"]), T(g["ib"]), T(g["tgt"]), p, cfg)
+    assert rel_l2(out, g["out_train"]) < TOL
+    assert abs(float(loss) - float(g["losses"][0])) < 1e-6 * abs(float(g["losses"][0]))
+    dead = set(str(k) for k in g["dead_keys"])
+    assert set(p.keys()) - set(O.live_param_keys(p, cfg)) == dead
+    assert set(grads.keys()) == set(p.keys()) - dead
+    worst = max(rel_l2(grads[k], g["grad:" + k]) for k in grads)
+    assert worst < 2e-5, worst
+
+
 @pytest.mark.parametrize("name", ["rollout8_adaln_f3", "rollout100_ln_f2", "rollout100_ln_f2_e256"])
 def test_rollout(name):
     g = load_golden(name)

@@ -13,8 +13,9 @@ pytestmark = pytest.mark.gpu
 
 TRAIN_CASES = ["model_tiny_adaln_f3", "model_tiny_ln_f2", "model_tiny_adaln_f2_pre"]
 # the ablation variants of the block (reference models/temporal.py:285-312, 103-116): 'addition' / 'simple' exchange, the info-bottleneck
-# layer not added ('none'), as nn.Linear ('linear') or as fixed Fourier features ('fourier')
-VARIANT_TRAIN_CASES = ["train_addition_adaln_f3", "train_simple_ln_f2", "train_sea_noib_adaln_f2", "train_sea_linear_ln_f2_pre", "train_addition_fourier_adaln_f3"]
+# layer not added ('none'), as nn.Linear ('linear') or as fixed Fourier features ('fourier'), the 'pool' exchange (a pooled token per row; also with one field)
+VARIANT_TRAIN_CASES = ["train_addition_adaln_f3", "train_simple_ln_f2", "train_sea_noib_adaln_f2", "train_sea_linear_ln_f2_pre", "train_addition_fourier_adaln_f3",
+                       "train_pool_adaln_f3", "train_pool_ln_f1"]
 
 
 @pytest.mark.parametrize("name", TRAIN_CASES + VARIANT_TRAIN_CASES)
