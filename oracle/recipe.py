@@ -63,6 +63,9 @@ def param_schema(cfg: OracleConfig) -> "OrderedDict[str, Tuple[Tuple[int, ...], 
         b = f"blocks.{layer}."
         if cfg.exchange_mode == "pool":     # SEAPoolBlockTemporal (models/temporal.py:197-241): a module's own parameters precede its sub-modules'
             s[b + "pool_token"] = ((1, 1, D), "randn")
+        if cfg.ib_addition_mode == "attention":   # cross_attn_ib is registered before the info-bottleneck layer (models/temporal.py:49-57)
+            for i in range(F):
+                _attention(s, f"{b}cross_attn_ib.{i}.", E)
         if cfg.ib_scale_mode == "fourier":    # GaussianFourierProjection(1, E/2): a fixed random W (models/base_blocks.py:143-148)
             s[b + "ib.W"] = ((1, E // 2), "randn")
         elif cfg.ib_scale_mode == "linear":   # nn.Linear(1, E)

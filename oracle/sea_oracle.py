@@ -37,7 +37,7 @@ class OracleConfig:
     """Constructor arguments of the reference ``TemporalModel`` that shape the
     computation (models/temporal.py:327-344).  Restated: exchange_mode in {'sea' (both
     shipped configs), 'addition', 'simple'}, ib_scale_mode in {'mlp', 'linear', 'fourier'},
-    ib_addition_mode in {'add', 'none'}, ib_mlp_layers=1, ib_num=1."""
+    ib_addition_mode in {'add', 'attention', 'none'}, ib_mlp_layers=1, ib_num=1."""
 
     num_layers: int
     embed_dim: int
@@ -246,22 +246,49 @@ def info_bottleneck(cond: torch.Tensor, p: Params, pre: str, mode: str = "mlp") 
     raise ValueError(f"Invalid ib_scale_mode '{mode}'")
 
 
+def plain_cross_attention(x_q: torch.Tensor, x_kv: torch.Tensor, p: Params, pre: str, n_heads: int) -> torch.Tensor:
+    """MultiHeadCrossAttention.forward (models/base_blocks.py:222-243): q from x_q, k / v from x_kv, no rotary embedding, NO mask (the module's
+    `tril` buffer is never read), softmax over all source rows, projection without bias."""
+    B, T, C = x_q.shape
+    Ts = x_kv.shape[1]
+    hd = C // n_heads
+    q = linear(x_q, p[pre + "q.weight"], p[pre + "q.bias"]).view(B, T, n_heads, hd).transpose(1, 2)
+    k = linear(x_kv, p[pre + "k.weight"], p[pre + "k.bias"]).view(B, Ts, n_heads, hd).transpose(1, 2)
+    v = linear(x_kv, p[pre + "v.weight"], p[pre + "v.bias"]).view(B, Ts, n_heads, hd).transpose(1, 2)
+    att = (q @ k.transpose(-2, -1)) * hd ** -0.5
+    att = att - att.max(dim=-1, keepdim=True).values
+    e = torch.exp(att)
+    att = e / e.sum(dim=-1, keepdim=True)
+    out = (att @ v).transpose(1, 2).reshape(B, T, C)
+    return linear(out, p[pre + "projection.weight"])
+
+
+def add_info(xs: List[torch.Tensor], cond: torch.Tensor, p: Params, pre: str, cfg: OracleConfig) -> List[torch.Tensor]:
+    """BaseBlockTemporal._add_info over the fields (models/temporal.py:111-120): 'none' returns x, 'add' adds the info-bottleneck rows, 'attention' adds
+    cross_attn_ib[i](x_i, ib rows) — every row attends to the info-bottleneck rows of ALL positions of its trajectory."""
+    if cfg.ib_addition_mode == "none":
+        return xs
+    ib = info_bottleneck(cond, p, pre, cfg.ib_scale_mode)
+    if cfg.ib_addition_mode == "add":
+        return [x + ib for x in xs]
+    if cfg.ib_addition_mode == "attention":
+        return [x + plain_cross_attention(x, ib, p, f"{pre}cross_attn_ib.{i}.", cfg.n_heads) for i, x in enumerate(xs)]
+    raise ValueError(f"ib_addition_mode {cfg.ib_addition_mode!r} is not restated")
+
+
 def block_forward(xs: Sequence[torch.Tensor], cond: torch.Tensor, p: Params, pre: str, cfg: OracleConfig) -> List[torch.Tensor]:
     """BaseBlockTemporal.forward (models/temporal.py:126-148)."""
     F = cfg.num_variables
     assert len(xs) == F
     xs = list(xs)
-    add_ib = cfg.ib_addition_mode == "add"   # 'none': _add_info returns x (models/temporal.py:113-114)
-    if not cfg.add_info_after_cross and add_ib:
-        ib = info_bottleneck(cond, p, pre, cfg.ib_scale_mode)
-        xs = [x + ib for x in xs]
+    if not cfg.add_info_after_cross:
+        xs = add_info(xs, cond, p, pre, cfg)
     for i in range(F):
         n = norm(xs[i], cond, p, f"{pre}ln.exp.{i}.0.", cfg.LN_type)
         xs[i] = xs[i] + masked_attention(n, n, p, f"{pre}attn.self.{i}.", cfg.n_heads, cfg.src_len)
     xs = exchange(xs, cond, p, pre, cfg)
-    if cfg.add_info_after_cross and add_ib:
-        ib = info_bottleneck(cond, p, pre, cfg.ib_scale_mode)
-        xs = [x + ib for x in xs]
+    if cfg.add_info_after_cross:
+        xs = add_info(xs, cond, p, pre, cfg)
     for i in range(F):
         n = norm(xs[i], cond, p, f"{pre}ln.exp.{i}.2.", cfg.LN_type)
         xs[i] = xs[i] + mlp(n, p, f"{pre}mlp.{i}.")

@@ -324,7 +324,7 @@ class Plan:
         self._pos_structs.append(common)
         self._cur.append(self._rec(L.sea_qkv_rope_grouped, [arr, len(groups), C.byref(common), self.code], name, (arr, common)))
 
-    def _attn(self, problems: List[dict], hd: int, ldo: int, name: str, drop=None) -> None:
+    def _attn(self, problems: List[dict], hd: int, ldo: int, name: str, drop=None, src_len: Optional[int] = None) -> None:
         L = N.lib()
         for s in range(0, len(problems), N.MAX_ATTN_PROBLEMS):
             chunk = problems[s:s + N.MAX_ATTN_PROBLEMS]
@@ -337,7 +337,7 @@ class Plan:
                 P.p[i].Q, P.p[i].K, P.p[i].Vt, P.p[i].O = d["Q"].data_ptr(), d["K"].data_ptr(), d["Vt"].data_ptr(), d["O"].data_ptr()
                 P.p[i].LSE = N.ptr(d.get("LSE"))
             P.B, P.H, P.hd, P.Tq, P.Tk, P.cap = self.B, self.H, hd, self.T, self.pos0 + self.T, self.cap
-            P.q_pos0, P.src_len, P.ldo = self.pos0, self.eng.model.src_len, ldo
+            P.q_pos0, P.src_len, P.ldo = self.pos0, (self.eng.model.src_len if src_len is None else src_len), ldo
             self._pos_structs.append(P)
             self._cur.append(self._rec(L.sea_attention_fwd, [C.byref(P), self.code], name, P))
 
@@ -430,6 +430,7 @@ class Plan:
         # cross-branch dependencies of a captured HIP graph cost more than the overlap gains; from 8192 rows up the condition lane pays (1 %).
         xmode = eng.model.exchange_mode                                   # 'sea' | 'addition' | 'simple' (models/temporal.py:314-324)
         has_ib = eng.model.ib_addition_mode.lower() == "add"              # 'none': _add_info returns x (models/temporal.py:113-114)
+        ib_attn = eng.model.ib_addition_mode.lower() == "attention"       # x_i += cross_attn_ib_i(x_i, ib rows) (models/temporal.py:117-118)
         mode = os.environ.get("SEA_PLAN_LANES", "auto") if type(self) is Plan and xmode == "sea" and has_ib else "none"
         if mode == "auto":   # with the current 21-launch plan: cfg2 0.252 ms none / 0.284 cond / 0.358 all; B=8 1.166 none / 1.154 cond / 1.245 all
             mode = "cond" if self.M >= 8192 else "none"
@@ -485,7 +486,7 @@ class Plan:
         for l in range(self.L):
             pre = f"blocks.{l}."
             last = l == self.L - 1
-            if first and not eng.model.add_info_after_cross and has_ib:
+            if first and not eng.model.add_info_after_cross and (has_ib or ib_attn):
                 # the info-bottleneck add comes first and must not modify the caller's tensor: copy x into xr
                 for i in range(F):
                     rec = _Rec(L.sea_convert_f32_to_act, [None, FE, xr[i].data_ptr(), E, M, E, N.SEA_F32], "x.copy")
@@ -494,6 +495,8 @@ class Plan:
                 first = False
             if not eng.model.add_info_after_cross and has_ib:
                 self._ib(pre, xr)
+            if not eng.model.add_info_after_cross and ib_attn:
+                self._ib_attn(pre, xr)
             # -- self attention: x_i += proj(attn(AdaLN_0(x_i)))
             groups = []
             for i in range(F):
@@ -631,6 +634,8 @@ class Plan:
                 continue
             if eng.model.add_info_after_cross and has_ib and not fold_ib:
                 self._ib(pre, xr)
+            if eng.model.add_info_after_cross and ib_attn:
+                self._ib_attn(pre, xr)
             self._mlp_proj(pre, list(range(F)), xr, xa, n_e, hbuf, hg, mods, last, addend=(ibufs[l] if fold_ib else None))
 
     def _mlp_proj(self, pre, fields, xr, xm, n_e, hbuf, hg, mods, final_norm, tag="", addend=None) -> bool:
@@ -722,6 +727,48 @@ class Plan:
         self._fill_ib(ib, pre)
         self._c_patches.append((ib, "c"))
         self._cur.append(self._rec(N.lib().sea_ib_add, [C.byref(ib)], "ib_add", ib))
+
+    def _ib_rows(self, pre: str, drop=None):
+        """The info-bottleneck rows ib(cond) [M, E] as a buffer of their own (fp32, and in the activation dtype): a copy of zeros, the usual ib add on top."""
+        L, M, E, f32 = N.lib(), self.M, self.E, torch.float32
+        zeros, ib32 = self._buf(M, E, dtype=f32, zero=True), self._buf(M, E, dtype=f32)
+        self._cur.append(self._rec(L.sea_convert_f32_to_act, [zeros.data_ptr(), E, ib32.data_ptr(), E, M, E, N.SEA_F32], "ib.rows.zero", zeros))
+        self._ib(pre, [ib32], drop=drop)
+        if self.dt == f32:
+            return ib32, ib32
+        ibact = self._buf(M, E)
+        self._cur.append(self._rec(L.sea_convert_f32_to_act, [ib32.data_ptr(), E, ibact.data_ptr(), E, M, E, self.code], "ib.rows.act"))
+        return ib32, ibact
+
+    def _act_copy(self, x32: torch.Tensor, name: str, keep: bool = False) -> torch.Tensor:
+        """Activation-dtype copy of an fp32 [M, E] (possibly strided) matrix — the operand of a GEMM that reads the residual stream directly.  `keep`: a
+        real copy in fp32 too (training: the rows are updated in place afterwards and the weight gradient needs them as they were)."""
+        if self.dt == torch.float32 and not keep:
+            return x32
+        y = self._buf(self.M, x32.shape[1])
+        self._cur.append(self._rec(N.lib().sea_convert_f32_to_act, [x32.data_ptr(), x32.stride(0), y.data_ptr(), y.stride(0), self.M, x32.shape[1], self.code], name))
+        return y
+
+    def _ib_attn(self, pre: str, xr: List[torch.Tensor]) -> None:
+        """ib_addition_mode 'attention' (models/temporal.py:117-118; MultiHeadCrossAttention, models/base_blocks.py:205-243): x_i += proj_i(softmax(q_i(x_i)
+        k_i(ib)^T / sqrt(hd)) v_i(ib)) — no mask, no rotary embedding: the usual QKV / attention launches with a zero-angle rotation table and a visibility
+        window (src_len) as long as the sequence."""
+        eng, P, B, H, T, E, M, cap = self.eng, self.eng.params, self.B, self.H, self.T, self.E, self.M, self.cap
+        F, hd = len(xr), E // H
+        _, ibact = self._ib_rows(pre)
+        xq = [self._act_copy(xr[i], "ib.attn.x_act") for i in range(F)]
+        Q = [self._buf(B, H, T, hd) for _ in range(F)]
+        K = [self._buf(B, H, cap, hd, zero=True) for _ in range(F)]
+        Vt = [self._buf(B, H, hd, cap, zero=True) for _ in range(F)]
+        att = [self._buf(M, E) for _ in range(F)]
+        qg = []
+        for i in range(F):
+            ca = f"{pre}cross_attn_ib.{i}."
+            qg.append(dict(A=xq[i], W=P.act(ca + "q.weight"), bias=P.f32_vec(ca + "q.bias"), col0=0, Q=Q[i]))
+            qg.append(dict(A=ibact, W=P.act(ca + "k.weight", 2 * E), bias=P.f32_vec(ca + "k.bias", 2 * E), col0=E, K=K[i], Vt=Vt[i]))
+        self._qkv(qg, eng.rope_identity(hd), hd, "ib.attn.qkv")
+        self._attn([dict(Q=Q[i], K=K[i], Vt=Vt[i], O=att[i]) for i in range(F)], hd, E, "ib.attn.attention", src_len=self.cap)
+        self._gemm([dict(A=att[i], W=P.act(f"{pre}cross_attn_ib.{i}.projection.weight"), R=xr[i], C32=xr[i]) for i in range(F)], "ib.attn.proj")
 
     # ------------------------------------------------------------------ binding and replay
     def bind(self, x: torch.Tensor, ib: torch.Tensor, out: torch.Tensor) -> None:
@@ -906,11 +953,11 @@ class TemporalEngine:
             raise RuntimeError("sea_amd: TemporalModel runs only on an MI355X (no CPU fallback)")
         m = model
         self.ib_mode = {"mlp": 0, "linear": 1, "fourier": 2}.get(m.ib_scale_mode.lower(), -1)
-        if (m.exchange_mode not in ("sea", "addition", "simple", "pool") or self.ib_mode < 0 or m.ib_addition_mode.lower() not in ("add", "none")
+        if (m.exchange_mode not in ("sea", "addition", "simple", "pool") or self.ib_mode < 0 or m.ib_addition_mode.lower() not in ("add", "none", "attention")
                 or (self.ib_mode == 0 and m.ib_mlp_layers != 1) or m.ib_num != 1 or (self.ib_mode != 0 and m.embed_dim % 8)):
             raise NotImplementedError(
                 "sea_amd native path covers exchange_mode in {'sea', 'addition', 'simple', 'pool'}, ib_scale_mode in {'mlp', 'linear', 'fourier'}, ib_addition_mode in "
-                "{'add', 'none'}, ib_mlp_layers=1, ib_num=1; got "
+                "{'add', 'attention', 'none'}, ib_mlp_layers=1, ib_num=1; got "
                 f"{m.exchange_mode}/{m.ib_scale_mode}/{m.ib_addition_mode}/{m.ib_mlp_layers}/{m.ib_num}")
         E, H, D = m.embed_dim, m.n_heads, m.down_dim
         for hd, what in ((E // H, "self"),) + (((D // H, "cross"),) if m.exchange_mode in ("sea", "pool") else ()):
@@ -946,10 +993,22 @@ class TemporalEngine:
             e = self._eyes[n] = torch.eye(n, device=self.device, dtype=self.act_dtype)
         return e
 
+    def rope_identity(self, hd: int) -> torch.Tensor:
+        """A rotation table of zero angles for the un-rotated attention of ib_addition_mode 'attention' (models/base_blocks.py:222-243)."""
+        t = self._eyes.get(("rope", hd))
+        if t is None:
+            t = torch.zeros(_round_up(self.model.max_len, 8), hd // 2, 2, device=self.device, dtype=torch.float32)
+            t[..., 0] = 1.0
+            self._eyes[("rope", hd)] = t
+        return t
+
     def plan(self, B: int, T: int, mode: str = "full") -> Plan:
         if mode == "step" and self.model.exchange_mode == "pool":
             raise NotImplementedError("sea_amd: the KV-cache rollout does not cover exchange_mode='pool' (its sinusoidal positions are relative to the window); "
                                       "use the recompute rollout")
+        if mode == "step" and self.model.ib_addition_mode.lower() == "attention":
+            raise NotImplementedError("sea_amd: the KV-cache rollout does not cover ib_addition_mode='attention' (every row attends to the info-bottleneck rows "
+                                      "of ALL positions of the window, later ones included: rows already produced change as the window grows); use the recompute rollout")
         key = (B, T, mode)
         p = self._plans.get(key)
         if p is None:
@@ -990,6 +1049,9 @@ class TemporalEngine:
 
         m = self.model
         thr = int(round(256 * m.dropout_p)) if (m.training and m.dropout_p > 0) else 0
+        if thr > 0 and m.ib_addition_mode.lower() == "attention":
+            raise NotImplementedError("sea_amd: ib_addition_mode='attention' trains with dropout = 0 only (the reference evaluates the info-bottleneck layer, and its "
+                                      "dropout, once per field: one set of rows is shared here)")
         if thr > 0 and m.exchange_mode == "pool":
             raise NotImplementedError("sea_amd: exchange_mode='pool' trains with dropout = 0 only (the reference also drops the position-encoded rows, "
                                       "models/base_blocks.py:371-372: no counter-based mask is defined for that site)")

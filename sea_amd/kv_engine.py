@@ -50,7 +50,7 @@ def supported(eng, B: int) -> bool:
     m = eng.model
     if os.environ.get("SEA_KV_FAST", "1") == "0":
         return False
-    if m.exchange_mode not in ("sea", "simple") or m.src_len != 0:
+    if m.exchange_mode not in ("sea", "simple") or m.src_len != 0 or m.ib_addition_mode.lower() == "attention":
         return False
     F, E, D, S, H = m.num_variables, m.embed_dim, m.down_dim, m.mlp_hidden, m.n_heads
     epc = 8 if eng.act_dtype == torch.bfloat16 else 4

@@ -235,6 +235,57 @@ class MaskedMultiHeadCrossAttention(_MaskedAttentionBase):
         return self._attend(x_1, x_2)
 
 
+class MultiHeadCrossAttention(nn.Module):
+    """Un-masked cross-attention without rotary embedding: q from x_1, k and v from x_2 (reference models/base_blocks.py:205-243; the block's
+    ib_addition_mode 'attention' attends from the field rows to the info-bottleneck rows of every position with it, models/temporal.py:49-53,117-118).
+    Same parameters as the masked modules (k, q, v with bias, bias-free projection) and the same dense `tril` buffer in the checkpoint schema
+    (never used by the forward, synthesised on save / dropped on load like theirs)."""
+
+    def __init__(self, n_heads, embed_dim, max_len, src_len, dropout):
+        super().__init__()
+        self.n_heads, self.max_len, self.src_len = n_heads, max_len, src_len
+        self.head_dim = embed_dim // n_heads
+        self.dropout = nn.Dropout(dropout)
+        self._p = dropout
+        self.embed_dim = embed_dim
+        self.k = nn.Linear(embed_dim, self.head_dim * n_heads)
+        self.q = nn.Linear(embed_dim, self.head_dim * n_heads)
+        self.v = nn.Linear(embed_dim, self.head_dim * n_heads)
+        self.projection = nn.Linear(embed_dim, embed_dim, bias=False)
+        self._register_state_dict_hook(_MaskedAttentionBase._emit_tril)
+        self._register_load_state_dict_pre_hook(_MaskedAttentionBase._drop_tril)
+
+    def forward(self, x_1, x_2):
+        if self.training and self._p > 0:
+            raise NotImplementedError("sea_amd.MultiHeadCrossAttention: dropout > 0 in train() is not covered")
+        dt = _act_dtype()
+        B, T, Cdim = x_1.shape
+        Ts = x_2.shape[1]
+        H, hd = self.n_heads, self.head_dim
+        cap = (Ts + 7) // 8 * 8
+        dev = x_1.device
+        Wkv = _as_act(torch.cat((self.k.weight, self.v.weight), dim=0))
+        bkv = torch.cat((self.k.bias, self.v.bias))
+        Q = torch.empty(B, H, T, hd, device=dev, dtype=dt)
+        K = torch.zeros(B, H, cap, hd, device=dev, dtype=dt)
+        Vt = torch.zeros(B, H, hd, cap, device=dev, dtype=dt)
+        ident = identity_rope(hd, max(T, Ts), dev)
+        ops.qkv_rope_grouped([dict(A=_as_act(x_1), W=_as_act(self.q.weight), bias=self.q.bias, col0=0, Q=Q)], ident, H, hd, T, 0, cap, float(hd) ** -0.5, dt)
+        ops.qkv_rope_grouped([dict(A=_as_act(x_2), W=Wkv, bias=bkv, col0=Cdim, K=K, Vt=Vt)], ident, H, hd, Ts, 0, cap, float(hd) ** -0.5, dt)
+        O = torch.empty(B, T, Cdim, device=dev, dtype=dt)
+        ops.attention_fwd([dict(Q=Q, K=K, Vt=Vt, O=O)], B, H, hd, T, Ts, cap, 0, Ts, dt)   # src_len >= Ts: every key is visible to every query
+        y = torch.empty(B * T, Cdim, device=dev, dtype=torch.float32)
+        ops.gemm_grouped([dict(A=O.view(B * T, Cdim), W=_as_act(self.projection.weight), C32=y)], dt)
+        return y.view(B, T, Cdim)
+
+
+def identity_rope(hd: int, length: int, device) -> torch.Tensor:
+    """A rotation table of zero angles ([length, hd/2, (cos, sin)] = (1, 0)): the QKV kernel's RoPE epilogue as a no-op for the un-rotated attention modules."""
+    t = torch.zeros(length, hd // 2, 2, device=device, dtype=torch.float32)
+    t[..., 0] = 1.0
+    return t
+
+
 class PositionalEncoding(nn.Module):
     """Sinusoidal table kept only because its buffer `pe` [1, 5000, d] is in the checkpoint schema (reference :355-372);
     with RoPE in the attention modules the temporal path never adds it."""

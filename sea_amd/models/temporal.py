@@ -7,9 +7,9 @@ TemporalModel.forward hands the whole forward to sea_amd.engine (≈30 fused HIP
 
 Scope: exchange_mode='sea' with ib_scale_mode='mlp', ib_addition_mode='add' — what both shipped configs select
 (configs/cylinder_flow.py:112-128, configs/multiphase_flow.py:112-128) — forward, rollout and training; the ablation variants
-exchange_mode 'addition' / 'simple' / 'pool', ib_scale_mode 'fourier' (the constructor's default) / 'linear' and ib_addition_mode 'none' forward / rollout
-only.  The concat / attention info-bottleneck additions are valid arguments of the reference that this build does not
-accelerate: they raise NotImplementedError (invalid names raise ValueError as in the reference).
+exchange_mode 'addition' / 'simple' / 'pool', ib_scale_mode 'fourier' (the constructor's default) / 'linear' and ib_addition_mode 'none' / 'attention' through the
+same plans, forward, rollout and training.  The 'concat' info-bottleneck addition is a valid argument of the reference that this build
+does not accelerate: it raises NotImplementedError (invalid names raise ValueError as in the reference).
 """
 from __future__ import annotations
 
@@ -19,7 +19,7 @@ from typing import Optional
 import torch
 import torch.nn as nn
 
-from .base_blocks import (AdaLN, GaussianFourierProjection, LayerNorm, MLP, MaskedMultiHeadAttention, MaskedMultiHeadCrossAttention,
+from .base_blocks import (AdaLN, GaussianFourierProjection, LayerNorm, MLP, MaskedMultiHeadAttention, MaskedMultiHeadCrossAttention, MultiHeadCrossAttention,
                           PositionalEncoding)
 
 _EXCHANGE_MODES = {"sea", "simple", "addition", "pool"}
@@ -50,11 +50,14 @@ class BaseBlockTemporal(nn.Module):
         self.ib_addition_mode = self._validate_ib_addition_mode(ib_addition_mode)
         self.ib_num = ib_num
         self.add_info_after_cross = add_info_after_cross
-        self.ib_scale_mode = self._validate_ib_mode(ib_scale_mode)
-        if self.ib_addition_mode not in ("add", "none"):
+        if self.ib_addition_mode == "concat":
             raise NotImplementedError(
-                f"sea_amd: ib_addition_mode={self.ib_addition_mode!r} is an ablation variant outside the accelerated path (supported: 'add', 'none')")
+                "sea_amd: ib_addition_mode='concat' (blocks widened by 64 info-bottleneck columns) is an ablation variant outside the accelerated path "
+                "(supported: 'add', 'attention', 'none')")
         self.internal_embed_dim = embed_dim
+        if self.ib_addition_mode == "attention":   # reference :49-53 (registered before the info-bottleneck layer: the checkpoint's key order)
+            self.cross_attn_ib = nn.ModuleList([MultiHeadCrossAttention(n_heads, self.internal_embed_dim, max_len, src_len, dropout) for _ in range(num_variables)])
+        self.ib_scale_mode = self._validate_ib_mode(ib_scale_mode)
         self.ib_dim = embed_dim
         if self.ib_scale_mode == "fourier":      # reference :103-109
             self.ib = GaussianFourierProjection(self.ib_num, int(self.ib_dim // 2))
@@ -97,6 +100,8 @@ class BaseBlockTemporal(nn.Module):
             return x
         if self.ib_scale_mode != "mlp":
             raise NotImplementedError("sea_amd: the stand-alone block forward covers ib_scale_mode='mlp'; call TemporalModel.forward")
+        if self.ib_addition_mode == "attention":   # reference :117-118
+            return x + self.cross_attn_ib[var_idx](x, self.ib(add_info))
         return self.ib(add_info, residual=x)
 
     def _apply_exchange(self, x_vars, x_add):

@@ -86,7 +86,7 @@ class TrainPlan(Plan):
             self._cur.append(_Rec(L.sea_rownorm_bwd, [arr, len(chunk), self.M, d, int(dy_is_act), int(x_is_act), int(gelu), int(accumulate),
                                                       self.code, ws.data_ptr(), ws.numel()], name, arr))
 
-    def _attn_bwd(self, problems: List[dict], hd: int, rope: torch.Tensor, name: str, drop=None) -> None:
+    def _attn_bwd(self, problems: List[dict], hd: int, rope: torch.Tensor, name: str, drop=None, src_len: Optional[int] = None) -> None:
         L = N.lib()
         P = N.SeaAttnBwdParams()
         P.n_problems = len(problems)
@@ -100,7 +100,7 @@ class TrainPlan(Plan):
             q.dQ, q.dK, q.dV = d["dQ"].data_ptr(), d["dK"].data_ptr(), d["dV"].data_ptr()
         d0 = problems[0]
         P.rope = rope.data_ptr()
-        P.B, P.H, P.hd, P.Tq, P.Tk, P.cap, P.q_pos0, P.src_len = self.B, self.H, hd, self.T, self.T, self.cap, 0, self.eng.model.src_len
+        P.B, P.H, P.hd, P.Tq, P.Tk, P.cap, P.q_pos0, P.src_len = self.B, self.H, hd, self.T, self.T, self.cap, 0, (self.eng.model.src_len if src_len is None else src_len)
         P.ldo, P.lddo = d0["O"].stride(0), d0["dO"].stride(0)
         P.lddq, P.lddk, P.lddv = d0["dQ"].stride(0), d0["dK"].stride(0), d0["dV"].stride(0)
         P.q_scale = float(hd) ** -0.5
@@ -119,6 +119,53 @@ class TrainPlan(Plan):
             rec = _Rec(L.sea_silu_outer_bwd, [arr, len(chunk), None, self.M, self.code, ws.data_ptr(), ws.numel()], name, arr)
             self._c_patches.append((rec.args, 2))
             self._cur.append(rec)
+
+    def _ib_attn_fwd(self, pre: str, xs: List[torch.Tensor], sv: dict) -> None:
+        """ib_addition_mode 'attention' with everything the backward needs kept (the inference form: engine.Plan._ib_attn): xs[i] += proj_i(attention(q_i(xs[i]),
+        k_i / v_i(ib rows))), un-masked and un-rotated (models/temporal.py:117-118, models/base_blocks.py:205-243)."""
+        eng, P, B, H, T, E, M, cap = self.eng, self.eng.params, self.B, self.H, self.T, self.E, self.M, self.cap
+        F, hd, buf, f32 = len(xs), self.E // self.H, self._buf, torch.float32
+        _, sv["ia_ib"] = self._ib_rows(pre)
+        sv["ia_xq"] = [self._act_copy(xs[i], "ib.attn.x_act", keep=True) for i in range(F)]
+        sv["ia"] = [dict(Q=buf(B, H, T, hd), K=buf(B, H, cap, hd, zero=True), V=buf(B, H, cap, hd, zero=True), Vt=buf(B, H, hd, cap, zero=True), O=buf(M, E),
+                         LSE=buf(B, H, T, dtype=f32)) for _ in range(F)]
+        qg = []
+        for i in range(F):
+            ca, pr = f"{pre}cross_attn_ib.{i}.", sv["ia"][i]
+            qg.append(dict(A=sv["ia_xq"][i], W=P.act(ca + "q.weight"), bias=P.f32_vec(ca + "q.bias"), col0=0, Q=pr["Q"]))
+            qg.append(dict(A=sv["ia_ib"], W=P.act(ca + "k.weight", 2 * E), bias=P.f32_vec(ca + "k.bias", 2 * E), col0=E, K=pr["K"], Vt=pr["Vt"], V=pr["V"]))
+        self._qkv(qg, eng.rope_identity(hd), hd, "ib.attn.qkv")
+        self._attn([dict(Q=pr["Q"], K=pr["K"], Vt=pr["Vt"], O=pr["O"], LSE=pr["LSE"]) for pr in sv["ia"]], hd, E, "ib.attn.attention", src_len=cap)
+        self._gemm([dict(A=sv["ia"][i]["O"], W=P.act(f"{pre}cross_attn_ib.{i}.projection.weight"), R=xs[i], C32=xs[i]) for i in range(F)], "ib.attn.proj")
+
+    def _ib_attn_bwd(self, pre: str, sv: dict, dx: List[torch.Tensor], ga: List[torch.Tensor]) -> None:
+        """Backward of _ib_attn_fwd: dx[i] (fp32) is the gradient of the rows it produced and ga[i] their activation-dtype copy; on return both hold the
+        gradient of its INPUT rows (the residual passes through, the query path is added), and the info-bottleneck layer has received the sum of the fields'
+        key / value paths."""
+        eng, P, G2, Gv = self.eng, self.eng.params, self.eng.grad_mat, self.eng.grad_vec
+        B, H, T, E, M, F = self.B, self.H, self.T, self.E, self.M, len(dx)
+        hd, buf, f32 = E // H, self._buf, torch.float32
+        self._wgrad([dict(dY=ga[i], X=sv["ia"][i]["O"], dW=G2(f"{pre}cross_attn_ib.{i}.projection.weight")) for i in range(F)], "bwd.ib.attn.proj.wgrad")
+        datt = [buf(M, E) for _ in range(F)]
+        self._gemm([dict(A=ga[i], W=P.actT(f"{pre}cross_attn_ib.{i}.projection.weight"), Cact=datt[i]) for i in range(F)], "bwd.ib.attn.proj.dgrad")
+        dq, dkv = [buf(M, E) for _ in range(F)], [buf(M, 2 * E) for _ in range(F)]
+        delta = [buf(B, H, T, dtype=f32) for _ in range(F)]
+        self._attn_bwd([dict(Q=pr["Q"], K=pr["K"], V=pr["V"], O=pr["O"], dO=datt[i], LSE=pr["LSE"], delta=delta[i], dQ=dq[i], dK=dkv[i][:, :E], dV=dkv[i][:, E:])
+                        for i, pr in enumerate(sv["ia"])], hd, eng.rope_identity(hd), "bwd.ib.attn.attention", src_len=self.cap)
+        wg = []
+        for i in range(F):
+            ca = f"{pre}cross_attn_ib.{i}."
+            wg.append(dict(dY=dq[i], X=sv["ia_xq"][i], dW=G2(ca + "q.weight"), db=Gv(ca + "q.bias")))
+            wg.append(dict(dY=dkv[i], X=sv["ia_ib"], dW=G2(ca + "k.weight", 2 * E), db=Gv(ca + "k.bias", 2 * E)))
+        self._wgrad(wg, "bwd.ib.attn.qkv.wgrad")
+        self._gemm([dict(A=dq[i], W=P.actT(f"{pre}cross_attn_ib.{i}.q.weight"), R=dx[i], C32=dx[i], Cact=ga[i]) for i in range(F)], "bwd.ib.attn.q.dgrad")
+        dib = buf(M, E, dtype=f32)
+        for i in range(F):   # sequential: every field's keys / values came from the same info-bottleneck rows
+            g = dict(A=dkv[i], W=P.actT(f"{pre}cross_attn_ib.{i}.k.weight", 2 * E), C32=dib)
+            if i > 0:
+                g["R"] = dib
+            self._gemm([g], f"bwd.ib.attn.kv.dgrad{i}")
+        self._ib_bwd(pre, [dib])
 
     def _ib_bwd(self, pre: str, dxs: List[torch.Tensor], drop=None) -> None:
         P, G, mode = self.eng.params, self.eng.grad_view, self.eng.ib_mode
@@ -162,6 +209,7 @@ class TrainPlan(Plan):
         # added ('add') or not ('none': the layer then has no gradient at all)
         xmode = model.exchange_mode
         has_ib = model.ib_addition_mode.lower() == "add"
+        ib_attn = model.ib_addition_mode.lower() == "attention"   # x_i += cross_attn_ib_i(x_i, ib rows) (models/temporal.py:117-118)
         ib_mode = eng.ib_mode
 
         def Gv(name, n=None):  # flat fp32 gradient of a vector parameter (optionally fused over n elements)
@@ -219,7 +267,7 @@ class TrainPlan(Plan):
             sv["xr"] = [buf(M, E, dtype=f32) for _ in range(F)]
             sv["x5"] = [buf(M, E, dtype=f32) for _ in range(F)]
             sv["x_in"] = x_prev
-            if not model.add_info_after_cross and has_ib:
+            if not model.add_info_after_cross and (has_ib or ib_attn):
                 # the info-bottleneck add precedes everything and must not touch the caller's tensor: x_in := copy + ib
                 xin = [buf(M, E, dtype=f32) for _ in range(F)]
                 for i in range(F):
@@ -229,8 +277,11 @@ class TrainPlan(Plan):
                     else:
                         rec = _Rec(L.sea_convert_f32_to_act, [x_prev[i].data_ptr(), E, xin[i].data_ptr(), E, M, E, N.SEA_F32], "x.copy")
                     self._cur.append(rec)
-                sv["ib_drop"] = (thr, self._streams(F)) if thr else None
-                self._ib(pre, xin, drop=sv["ib_drop"])
+                if ib_attn:
+                    self._ib_attn_fwd(pre, xin, sv)
+                else:
+                    sv["ib_drop"] = (thr, self._streams(F)) if thr else None
+                    self._ib(pre, xin, drop=sv["ib_drop"])
                 sv["x_in"] = xin
                 first = False
             x_in = sv["x_in"]
@@ -373,6 +424,8 @@ class TrainPlan(Plan):
             if model.add_info_after_cross and has_ib:
                 sv["ib_drop"] = (thr, self._streams(F)) if thr else None
                 self._ib(pre, sv["xr"], drop=sv["ib_drop"])
+            if model.add_info_after_cross and ib_attn:
+                self._ib_attn_fwd(pre, sv["xr"], sv)
             # ---- MLP + proj
             sv["st2"] = [stats() for _ in range(F)]
             sv["n2"] = [buf(M, E) for _ in range(F)]
@@ -423,7 +476,7 @@ class TrainPlan(Plan):
         for l in reversed(range(NL)):
             pre = f"blocks.{l}."
             sv = Sv[l]
-            first = l == 0 and (model.add_info_after_cross or not has_ib)
+            first = l == 0 and (model.add_info_after_cross or not (has_ib or ib_attn))
             # ---- proj:  x5 = Wp xa4 + bp                       (ga = d x5 in act dtype)
             self._wgrad([dict(dY=ga[i], X=sv["xa4"][i], dW=G2(f"{pre}proj.{i}.weight"), db=Gv(f"{pre}proj.{i}.bias")) for i in range(F)], "bwd.proj.wgrad")
             # (MLP-output dropout: the residual path C32 stays whole, the copy feeding fc2's backward is masked)
@@ -446,6 +499,8 @@ class TrainPlan(Plan):
                                  **bpar(f"{pre}ln.exp.{i}.2.", E)) for i in range(F)], E, "bwd.mlp.adaln2", True, False, False, True)
             if model.add_info_after_cross and has_ib:
                 self._ib_bwd(pre, dx, drop=sv["ib_drop"])
+            if model.add_info_after_cross and ib_attn:
+                self._ib_attn_bwd(pre, sv, dx, ga)
             if F > 1 and xmode == "addition":
                 # x2_i = x1_i + Wu_i g + bu_i, g = gelu(s), s = sum_j n_j, n_j = ln_cross_j(Wd_j x1_j + bd_j): ga[i] = act copy of d x2_i
                 self._wgrad([dict(dY=ga[i], X=sv["sg"], dW=G2(f"{pre}cross_up.{i}.weight"), db=Gv(f"{pre}cross_up.{i}.bias")) for i in range(F)], "bwd.add.up.wgrad")
@@ -583,6 +638,8 @@ class TrainPlan(Plan):
             self._norm_bwd(groups, E, "bwd.self.adaln0", True, False, False, True)
             if not model.add_info_after_cross and has_ib:
                 self._ib_bwd(pre, dx, drop=sv["ib_drop"])
+            if not model.add_info_after_cross and ib_attn:
+                self._ib_attn_bwd(pre, sv, dx, ga)
         # ---- AdaLN condition MLPs: every USE contributes dmod; parameters are shared through the atomically accumulated gradients
         if adaln:
             dh = [buf(M, dm.shape[1]) for _, dm in dmods]

@@ -72,8 +72,9 @@ def rollout(model, x0: torch.Tensor, ib: torch.Tensor, n_steps: int, mode: str =
                         prefix-consistent), O(N) token-forwards.
     """
     assert mode in ("recompute", "kv")
-    if mode == "kv" and (getattr(model, "src_len", 0) > 0 or getattr(model, "exchange_mode", "sea") == "pool"):
-        mode = "recompute"   # a cache is exact only for strictly causal attention (src_len == 0) and absolute positions (not 'pool'): see rollout_kv
+    if mode == "kv" and (getattr(model, "src_len", 0) > 0 or getattr(model, "exchange_mode", "sea") == "pool"
+                         or str(getattr(model, "ib_addition_mode", "add")).lower() == "attention"):
+        mode = "recompute"   # a cache is exact only for strictly causal attention (src_len == 0, no un-masked info-bottleneck attention) and absolute positions (not 'pool'): see rollout_kv
     was_training = model.training
     model.eval()
     try:

@@ -54,7 +54,7 @@ def cfg_meta(cfg: OracleConfig):
     return np.array([cfg.num_layers, cfg.embed_dim, cfg.n_heads, cfg.max_len, cfg.scale_ratio, cfg.src_len,
                      cfg.num_variables, cfg.down_proj, int(cfg.add_info_after_cross),
                      1 if cfg.LN_type == "adaln" else 0, ("sea", "addition", "simple", "pool").index(cfg.exchange_mode),
-                     ("add", "none").index(cfg.ib_addition_mode), ("mlp", "linear", "fourier").index(cfg.ib_scale_mode)], dtype=np.int64)
+                     ("add", "none", "attention").index(cfg.ib_addition_mode), ("mlp", "linear", "fourier").index(cfg.ib_scale_mode)], dtype=np.int64)
 
 
 def save(name, **arrs):
@@ -524,6 +524,11 @@ def main():
     cases["train_addition_fourier_adaln_f3"] = lambda: model_case("train_addition_fourier_adaln_f3", OracleConfig(1, 32, 2, 24, 8, 0, 3, 2, True, "adaln", "addition", "add", "fourier"), 2, 12, train="grads")
     cases["train_pool_adaln_f3"] = lambda: model_case("train_pool_adaln_f3", OracleConfig(2, 32, 2, 24, 8, 0, 3, 2, True, "adaln", "pool"), 2, 12, train="grads")
     cases["train_pool_ln_f1"] = lambda: model_case("train_pool_ln_f1", OracleConfig(1, 32, 2, 24, 8, 0, 1, 2, False, "ln", "pool"), 2, 12, train="grads")
+    # ib_addition_mode 'attention' (models/temporal.py:49-53,117-118): forward at two shapes (after / before the exchange), the train step of each
+    cases["model_ibattn_adaln_f3"] = lambda: model_case("model_ibattn_adaln_f3", OracleConfig(2, 64, 4, 80, 8, 0, 3, 2, True, "adaln", "sea", "attention"), 2, 27)
+    cases["model_ibattn_ln_f2_pre"] = lambda: model_case("model_ibattn_ln_f2_pre", OracleConfig(1, 64, 4, 80, 8, 0, 2, 2, False, "ln", "addition", "attention", "linear"), 2, 70)
+    cases["train_ibattn_adaln_f3"] = lambda: model_case("train_ibattn_adaln_f3", OracleConfig(2, 32, 2, 24, 8, 0, 3, 2, True, "adaln", "sea", "attention"), 2, 12, train="grads")
+    cases["train_ibattn_ln_f2_pre"] = lambda: model_case("train_ibattn_ln_f2_pre", OracleConfig(1, 32, 2, 24, 8, 0, 2, 2, False, "ln", "simple", "attention", "fourier"), 2, 12, train="grads")
     for T in (1, 7, 16, 65):
         cases[f"model_small_adaln_f3_T{T}"] = (lambda T=T: model_case(
             f"model_small_adaln_f3_T{T}", OracleConfig(1, 64, 4, 80, 8, 0, 3, 2, True, "adaln"), 2, T))

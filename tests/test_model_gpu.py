@@ -11,7 +11,7 @@ import torch
 
 from oracle import sea_oracle as O
 from oracle.recipe import recipe_inputs, recipe_params
-from tests.conftest import cfg_from_meta, load_golden, rel_l2
+from tests.conftest import cfg_from_meta, grad_err, load_golden, rel_l2
 
 pytestmark = pytest.mark.gpu
 
@@ -42,7 +42,9 @@ MODEL_CASES = ["model_tiny_adaln_f3", "model_tiny_ln_f2", "model_tiny_adaln_f2_p
                "model_addition_adaln_f3", "model_addition_ln_f2_pre", "model_simple_adaln_f3", "model_sea_noib_adaln_f2",
                # ib_scale_mode 'fourier' (the constructor's default) and 'linear'
                "model_sea_fourier_adaln_f3", "model_sea_linear_ln_f2_pre",
-               "model_pool_adaln_f3", "model_pool_ln_f2"]
+               "model_pool_adaln_f3", "model_pool_ln_f2",
+               # ib_addition_mode 'attention': un-masked cross-attention from the field rows to the info-bottleneck rows (after / before the exchange)
+               "model_ibattn_adaln_f3", "model_ibattn_ln_f2_pre"]
 
 
 @pytest.mark.parametrize("F,ln,after", [(2, "ln", True), (2, "adaln", False), (3, "ln", True)])
@@ -66,7 +68,8 @@ def test_bf16_fused_launches_at_shipped_widths(F, ln, after):
     assert rel_l2(b.cpu().numpy(), a.cpu().numpy()) < 2e-2
 
 
-@pytest.mark.parametrize("xmode,ibmode,ibscale", [("addition", "add", "mlp"), ("simple", "add", "mlp"), ("sea", "none", "mlp"), ("sea", "add", "fourier"), ("addition", "add", "linear"), ("pool", "add", "mlp")])
+@pytest.mark.parametrize("xmode,ibmode,ibscale", [("addition", "add", "mlp"), ("simple", "add", "mlp"), ("sea", "none", "mlp"), ("sea", "add", "fourier"), ("addition", "add", "linear"), ("pool", "add", "mlp"),
+                                                  ("sea", "attention", "mlp")])
 def test_ablation_variants_rollout_bf16_and_training(xmode, ibmode, ibscale):
     """The ablation variants through the same plan machinery: bf16 forward within the stated tolerance of the fp32 oracle, KV-cache rollout
     equal to the recompute rollout, and the hand-written backward against the oracle's autograd."""
@@ -81,8 +84,9 @@ def test_ablation_variants_rollout_bf16_and_training(xmode, ibmode, ibscale):
     assert rel_l2(out.cpu().numpy(), ref.numpy()) < BF16_TOL
     m32 = build(cfg, "fp32")
     a = rollout(m32, x[:, :1].cuda(), ib.cuda(), 12, mode="recompute")
-    if xmode == "pool":   # its window-relative sinusoidal positions are not covered by the KV-cache step plan: the engine refuses loudly, the
-        # rollout front end (what the evaluation loops call) falls back to the recompute loop
+    if xmode == "pool" or ibmode == "attention":
+        # 'pool': window-relative sinusoidal positions; ib 'attention': rows attend to the info-bottleneck rows of LATER positions of the window — neither is
+        # a cache-able recurrence: the engine refuses loudly, the rollout front end (what the evaluation loops call) falls back to the recompute loop
         with pytest.raises(NotImplementedError, match="KV-cache"):
             m32.engine().rollout_kv(x[:, :1].cuda(), ib.cuda(), 12)
         assert torch.equal(rollout(m32, x[:, :1].cuda(), ib.cuda(), 12, mode="kv"), a)
@@ -100,7 +104,7 @@ def test_ablation_variants_rollout_bf16_and_training(xmode, ibmode, ibscale):
     eng.backward(plan, dout)
     assert abs(loss.item() - float(loss_ref)) < 1e-4 * float(loss_ref)
     for k, gr in grads_ref.items():
-        assert rel_l2(eng.grad_view(k).cpu().numpy(), gr.numpy()) < 2e-4, k
+        assert grad_err(eng.grad_view(k).cpu().numpy(), gr.numpy()) < 2e-4, k
     assert sorted(eng.params.live_names) == sorted(grads_ref.keys())
 
 

@@ -17,7 +17,9 @@ def make(cfg: OracleConfig, **kw):
                                  OracleConfig(2, 64, 4, 24, 8, 0, 3, 2, True, "adaln", "addition"), OracleConfig(1, 64, 4, 24, 8, 0, 2, 2, False, "ln", "simple"),
                                  OracleConfig(1, 64, 4, 24, 8, 0, 2, 2, True, "adaln", "sea", "none"),
                                  OracleConfig(2, 64, 4, 24, 8, 0, 3, 2, True, "adaln", "sea", "add", "fourier"), OracleConfig(1, 64, 4, 24, 8, 0, 2, 2, True, "ln", "sea", "add", "linear"),
-                                 OracleConfig(2, 64, 4, 24, 8, 0, 3, 2, True, "adaln", "pool"), OracleConfig(1, 64, 4, 24, 8, 0, 2, 2, True, "ln", "pool")])
+                                 OracleConfig(2, 64, 4, 24, 8, 0, 3, 2, True, "adaln", "pool"), OracleConfig(1, 64, 4, 24, 8, 0, 2, 2, True, "ln", "pool"),
+                                 OracleConfig(2, 64, 4, 24, 8, 0, 3, 2, True, "adaln", "sea", "attention"),
+                                 OracleConfig(1, 64, 4, 24, 8, 0, 2, 2, False, "ln", "simple", "attention", "fourier")])
 def test_parameter_schema_matches_reference(cfg):
     """Names, order and shapes equal the reference's named_parameters() (oracle/recipe.param_schema is asserted equal to the
     reference's own by tests/golden/make_fixtures.py)."""

@@ -6,7 +6,7 @@ import torch
 
 from oracle import sea_oracle as O
 from oracle.recipe import encoder_params, param_schema, recipe_params, recipe_tensor
-from tests.conftest import cfg_from_meta, load_golden, rel_l2
+from tests.conftest import cfg_from_meta, grad_err, load_golden, rel_l2
 
 TOL = 2e-6  # fp32 accumulation-order noise between two CPU restatements
 
@@ -109,7 +109,9 @@ MODEL_CASES = ["model_tiny_adaln_f3", "model_tiny_ln_f2", "model_tiny_adaln_f2_p
                # ib_scale_mode 'fourier' (the constructor's default) and 'linear'
                "model_sea_fourier_adaln_f3", "model_sea_linear_ln_f2_pre",
                # exchange_mode 'pool' (field -> pool-token cross-attention, src_len = 1 in the second case)
-               "model_pool_adaln_f3", "model_pool_ln_f2"]
+               "model_pool_adaln_f3", "model_pool_ln_f2",
+               # ib_addition_mode 'attention' (un-masked cross-attention from the field rows to the info-bottleneck rows), after and before the exchange
+               "model_ibattn_adaln_f3", "model_ibattn_ln_f2_pre"]
 
 
 @pytest.mark.parametrize("name", MODEL_CASES)
@@ -150,7 +152,7 @@ def test_model_grads_and_adamw(name):
 
 
 @pytest.mark.parametrize("name", ["train_addition_adaln_f3", "train_simple_ln_f2", "train_sea_noib_adaln_f2", "train_sea_linear_ln_f2_pre",
-                                  "train_addition_fourier_adaln_f3", "train_pool_adaln_f3", "train_pool_ln_f1"])
+                                  "train_addition_fourier_adaln_f3", "train_pool_adaln_f3", "train_pool_ln_f1", "train_ibattn_adaln_f3", "train_ibattn_ln_f2_pre"])
 def test_variant_model_grads(name):
     """The ablation variants' train step (reference models/temporal.py:197-312, 103-116): output, loss, every gradient and the set of gradient-less
     parameters of the oracle against what the reference produced."""
@@ -163,7 +165,7 @@ def test_variant_model_grads(name):
     dead = set(str(k) for k in g["dead_keys"])
     assert set(p.keys()) - set(O.live_param_keys(p, cfg)) == dead
     assert set(grads.keys()) == set(p.keys()) - dead
-    worst = max(rel_l2(grads[k], g["grad:" + k]) for k in grads)
+    worst = max(grad_err(grads[k], g["grad:" + k]) for k in grads)
     assert worst < 2e-5, worst
 
 

@@ -6,16 +6,16 @@ import torch
 
 from oracle import sea_oracle as O
 from oracle.recipe import recipe_inputs, recipe_params
-from tests.conftest import cfg_from_meta, load_golden, rel_l2
+from tests.conftest import cfg_from_meta, grad_err, load_golden, rel_l2
 from tests.test_model_gpu import build, gpu
 
 pytestmark = pytest.mark.gpu
 
 TRAIN_CASES = ["model_tiny_adaln_f3", "model_tiny_ln_f2", "model_tiny_adaln_f2_pre"]
 # the ablation variants of the block (reference models/temporal.py:285-312, 103-116): 'addition' / 'simple' exchange, the info-bottleneck
-# layer not added ('none'), as nn.Linear ('linear') or as fixed Fourier features ('fourier'), the 'pool' exchange (a pooled token per row; also with one field)
+# layer not added ('none'), as nn.Linear ('linear') or as fixed Fourier features ('fourier'), the 'pool' exchange (a pooled token per row; also with one field), the info-bottleneck rows attended to instead of added ('attention')
 VARIANT_TRAIN_CASES = ["train_addition_adaln_f3", "train_simple_ln_f2", "train_sea_noib_adaln_f2", "train_sea_linear_ln_f2_pre", "train_addition_fourier_adaln_f3",
-                       "train_pool_adaln_f3", "train_pool_ln_f1"]
+                       "train_pool_adaln_f3", "train_pool_ln_f1", "train_ibattn_adaln_f3", "train_ibattn_ln_f2_pre"]
 
 
 @pytest.mark.parametrize("name", TRAIN_CASES + VARIANT_TRAIN_CASES)
@@ -39,7 +39,7 @@ def test_gradients_match_reference_golden_fp32(name):
             assert p.grad is None, k  # exactly the reference's set of gradient-less parameters
             continue
         assert p.grad is not None, k
-        e = rel_l2(p.grad.cpu().numpy(), g["grad:" + k])
+        e = grad_err(p.grad.cpu().numpy(), g["grad:" + k])
         if e > worst:
             worst, worst_k = e, k
     assert worst < 1e-4, (worst_k, worst)
