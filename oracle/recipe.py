@@ -55,7 +55,9 @@ def _attention(s, pre: str, d: int):
 
 
 def param_schema(cfg: OracleConfig) -> "OrderedDict[str, Tuple[Tuple[int, ...], str]]":
-    E, D, F = cfg.embed_dim, cfg.down_dim, cfg.num_variables
+    Eo, D, F = cfg.embed_dim, cfg.down_dim, cfg.num_variables
+    E = cfg.internal_embed_dim                         # the block's row width ('concat': embed_dim + 64, models/temporal.py:48)
+    Eib = 64 if cfg.ib_addition_mode == "concat" else Eo   # the info-bottleneck layer's output width (models/temporal.py:100-101)
     S = max(1, int(E * cfg.scale_ratio))
     sr = max(1, int(1 * cfg.scale_ratio))  # ib MLP hidden: dim_in = ib_num = 1
     s: "OrderedDict[str, Tuple[Tuple[int, ...], str]]" = OrderedDict()
@@ -67,15 +69,15 @@ def param_schema(cfg: OracleConfig) -> "OrderedDict[str, Tuple[Tuple[int, ...], 
             for i in range(F):
                 _attention(s, f"{b}cross_attn_ib.{i}.", E)
         if cfg.ib_scale_mode == "fourier":    # GaussianFourierProjection(1, E/2): a fixed random W (models/base_blocks.py:143-148)
-            s[b + "ib.W"] = ((1, E // 2), "randn")
+            s[b + "ib.W"] = ((1, Eib // 2), "randn")
         elif cfg.ib_scale_mode == "linear":   # nn.Linear(1, E)
-            _linear(s, b + "ib.", E, 1)
+            _linear(s, b + "ib.", Eib, 1)
         else:
-            _linear(s, b + "ib.residual_projection.", E, 1)
+            _linear(s, b + "ib.residual_projection.", Eib, 1)
             _linear(s, b + "ib.layers.0.", sr, 1)
             s[b + "ib.layers.1.weight"] = ((sr,), "norm_w")
             s[b + "ib.layers.1.bias"] = ((sr,), "norm_b")
-            _linear(s, b + "ib.layers.3.", E, sr)
+            _linear(s, b + "ib.layers.3.", Eib, sr)
         for i in range(F):
             for n in range(3):
                 _norm(s, f"{b}ln.exp.{i}.{n}.", E, cfg.LN_type)
@@ -88,7 +90,7 @@ def param_schema(cfg: OracleConfig) -> "OrderedDict[str, Tuple[Tuple[int, ...], 
             s[f"{b}mlp.{i}.layers.1.bias"] = ((S,), "norm_b")
             _linear(s, f"{b}mlp.{i}.layers.3.", E, S)
         for i in range(F):
-            _linear(s, f"{b}proj.{i}.", E, E)
+            _linear(s, f"{b}proj.{i}.", Eo, E)
         if cfg.exchange_mode == "simple":   # SimpleBlockTemporal adds no parameters (models/temporal.py:304-306)
             continue
         for i in range(F):
@@ -109,7 +111,7 @@ def param_schema(cfg: OracleConfig) -> "OrderedDict[str, Tuple[Tuple[int, ...], 
             _linear(s, b + "pool_update.0.", 2 * D, D * F)
             _linear(s, b + "pool_update.2.", D, 2 * D)
     for i in range(F):
-        _norm(s, f"ln.{i}.", E, cfg.LN_type)
+        _norm(s, f"ln.{i}.", Eo, cfg.LN_type)
     return s
 
 

@@ -37,7 +37,7 @@ class OracleConfig:
     """Constructor arguments of the reference ``TemporalModel`` that shape the
     computation (models/temporal.py:327-344).  Restated: exchange_mode in {'sea' (both
     shipped configs), 'addition', 'simple'}, ib_scale_mode in {'mlp', 'linear', 'fourier'},
-    ib_addition_mode in {'add', 'attention', 'none'}, ib_mlp_layers=1, ib_num=1."""
+    ib_addition_mode in {'add', 'attention', 'concat', 'none'}, ib_mlp_layers=1, ib_num=1."""
 
     num_layers: int
     embed_dim: int
@@ -54,8 +54,12 @@ class OracleConfig:
     ib_scale_mode: str = "mlp"
 
     @property
+    def internal_embed_dim(self) -> int:  # models/temporal.py:40,48: 'concat' widens the block's rows by ib_dim_concat = 64 columns
+        return self.embed_dim + 64 if self.ib_addition_mode == "concat" else self.embed_dim
+
+    @property
     def down_dim(self) -> int:  # models/temporal.py:58-59
-        return self.embed_dim // self.down_proj
+        return self.internal_embed_dim // self.down_proj
 
 
 # --------------------------------------------------------------------------- primitives
@@ -273,6 +277,8 @@ def add_info(xs: List[torch.Tensor], cond: torch.Tensor, p: Params, pre: str, cf
         return [x + ib for x in xs]
     if cfg.ib_addition_mode == "attention":
         return [x + plain_cross_attention(x, ib, p, f"{pre}cross_attn_ib.{i}.", cfg.n_heads) for i, x in enumerate(xs)]
+    if cfg.ib_addition_mode == "concat":   # :115-116 (the layer's width is ib_dim_concat, :100-101)
+        return [torch.cat([x, ib], dim=-1) for x in xs]
     raise ValueError(f"ib_addition_mode {cfg.ib_addition_mode!r} is not restated")
 
 

@@ -195,7 +195,12 @@ class Plan:
         assert mode in ("full", "step")
         self.eng, self.B, self.T, self.mode = eng, B, T, mode
         m = eng.model
-        self.F, self.E, self.H, self.L = m.num_variables, m.embed_dim, m.n_heads, m.num_layers
+        self.F, self.H, self.L = m.num_variables, m.n_heads, m.num_layers
+        # E: the row width INSIDE a block; Eo: the width of the model's input / output rows and of every block's proj output.  They differ only with
+        # ib_addition_mode 'concat' (models/temporal.py:48: rows widened by ib_dim_concat = 64 info-bottleneck columns, `ib_dim` wide layer)
+        self.Eo, self.E = m.embed_dim, m.internal_embed_dim
+        self.concat = m.ib_addition_mode.lower() == "concat"
+        self.ib_dim = self.E - self.Eo if self.concat else self.E
         self.D = m.down_dim
         self.S = m.mlp_hidden
         self.M = B * T
@@ -215,6 +220,7 @@ class Plan:
         self._bound = (None, None, None)
         self._lane = 0                    # lane the record builders tag new records with
         self._lane_streams: Dict[int, torch.cuda.Stream] = {}
+        self._zero_ib: Optional[torch.Tensor] = None   # 'concat': the zeros the info-bottleneck columns are reset to
         self._build()
         self._clist = None          # (SeaLaunchRec array, [(rec index, field, args list, args index)]) for sea_run_list
         self._compile_list()
@@ -359,7 +365,7 @@ class Plan:
                 for i in range(F):
                     rest.append((f"{pre}ln_cross.{i}.", D))
         for i in range(F):
-            rest.append((f"ln.{i}.", E))
+            rest.append((f"ln.{i}.", self.Eo))
 
         # cond_mlp.0 + SiLU evaluated inside the GEMM of cond_mlp.2 (generated A operand): no hidden matrix, no silu launch.  Inference plans
         # only (the weight gradient of cond_mlp.2 reads the hidden matrix).  The operand is recomputed by every column tile of a row panel (4x at
@@ -460,7 +466,8 @@ class Plan:
         fuse_xtail = (fuse_norm and not lanes and xmode == "sea" and F > 1 and os.environ.get("SEA_FUSE_XTAIL", "1") != "0"
                       and ops.exchange_tail_supported(dt, D, E, F - 1) and M <= int(os.environ.get("SEA_XTAIL_MAX_ROWS", "1000000000")))   # measured: cfg2 0.281 -> 0.254 ms, B = 2 0.414 -> 0.404, B = 4 0.679 -> 0.675, B = 8 a tie (1.191)
         rope_s, rope_c = eng.rope_self, eng.rope_cross
-        FE = F * E
+        Eo, concat = self.Eo, self.concat
+        FE = F * Eo                                             # row stride of the caller's [B, T, F, Eo] tensors
         xr = [self._buf(M, E, dtype=f32) for _ in range(F)]     # fp32 residual stream
         xa = [self._buf(M, E) for _ in range(F)]                # act-dtype copy (GEMM A operand)
         n_e = [self._buf(M, E) for _ in range(F)]               # normalised rows, dim E
@@ -486,13 +493,22 @@ class Plan:
         for l in range(self.L):
             pre = f"blocks.{l}."
             last = l == self.L - 1
-            if first and not eng.model.add_info_after_cross and (has_ib or ib_attn):
+            if first and not eng.model.add_info_after_cross and (has_ib or ib_attn or concat):
                 # the info-bottleneck add comes first and must not modify the caller's tensor: copy x into xr
                 for i in range(F):
-                    rec = _Rec(L.sea_convert_f32_to_act, [None, FE, xr[i].data_ptr(), E, M, E, N.SEA_F32], "x.copy")
-                    self._x_patches.append((rec.args, 0, i * E * 4))
+                    rec = _Rec(L.sea_convert_f32_to_act, [None, FE, xr[i].data_ptr(), E, M, Eo, N.SEA_F32], "x.copy")
+                    self._x_patches.append((rec.args, 0, i * Eo * 4))
                     self.records.append(rec)
                 first = False
+            if concat:
+                # x_i := [x_i | ib rows] (models/temporal.py:115-116): columns Eo .. E-1 of the residual rows are zeroed, then the usual info-bottleneck add
+                # runs on them (columns 0 .. Eo-1 hold the caller's rows / the previous block's proj output)
+                if self._zero_ib is None:
+                    self._zero_ib = self._buf(M, self.ib_dim, dtype=f32, zero=True)
+                for i in range(F):
+                    self._cur.append(self._rec(L.sea_convert_f32_to_act, [self._zero_ib.data_ptr(), self.ib_dim, xr[i][:, Eo:].data_ptr(), E, M, self.ib_dim, N.SEA_F32],
+                                               "ib.concat.zero"))
+                self._ib(pre, [xr[i][:, Eo:] for i in range(F)])
             if not eng.model.add_info_after_cross and has_ib:
                 self._ib(pre, xr)
             if not eng.model.add_info_after_cross and ib_attn:
@@ -502,7 +518,7 @@ class Plan:
             for i in range(F):
                 g = dict(Yact=n_e[i], **norm_params(f"{pre}ln.exp.{i}.0.", E))
                 if first:
-                    g.update(X=xr[i], ldx=FE, X_is_x=i * E * 4)
+                    g.update(X=xr[i], ldx=FE, X_is_x=i * Eo * 4)
                 else:
                     g.update(X=xr[i])
                 groups.append(g)
@@ -514,7 +530,7 @@ class Plan:
             for i in range(F):
                 g = dict(A=att_e[i], W=P.act(f"{pre}attn.self.{i}.projection.weight"), C32=xr[i], Cact=xa[i])
                 if first:
-                    g.update(R=xr[i], ldr=FE, R_is_x=i * E * 4)
+                    g.update(R=xr[i], ldr=FE, R_is_x=i * Eo * 4)
                 else:
                     g.update(R=xr[i])
                 groups.append(g)
@@ -641,7 +657,8 @@ class Plan:
     def _mlp_proj(self, pre, fields, xr, xm, n_e, hbuf, hg, mods, final_norm, tag="", addend=None) -> bool:
         """x_i += W2 gelu(LN(W1 AdaLN_2(x_i))) ; x_i = proj_i(x_i) for the listed fields (models/temporal.py:143-146), optionally followed
         by the model's final per-field norm written straight into out (models/temporal.py:412-415)."""
-        P, E, S, FE = self.eng.params, self.E, self.S, self.F * self.E
+        P, E, S, Eo, FE = self.eng.params, self.E, self.S, self.Eo, self.F * self.Eo
+        xo = xr if Eo == E else [t[:, :Eo] for t in xr]   # the proj output / the next block's input rows ('concat': the first Eo columns of the widened rows)
 
         def norm_params(p_, d):
             if self.adaln:
@@ -679,7 +696,7 @@ class Plan:
         # 30.8 us against 19.8 + 7.1 + 5.6 with two boundaries less: a 32-row workgroup per CU streams W2 at a third of the rate three co-resident 64 x 64
         # tiles do), B = 8 1.108 -> 1.18 ms (200 us against 76 + 21 + 31) — short launches only.  SEA_FUSE_MLP2=0 / 1 forces.
         w2 = os.environ.get("SEA_FUSE_MLP2", "auto")
-        if (type(self) is Plan and (w2 == "1" or (w2 == "auto" and 1024 <= self.M <= 4096)) and ops.mlp_fc1_supported(self.dt, E, S) and len(fields) <= N.MAX_MLP_GROUPS):
+        if (type(self) is Plan and (w2 == "1" or (w2 == "auto" and 1024 <= self.M <= 4096)) and ops.mlp_fc1_supported(self.dt, E, S) and Eo == E and len(fields) <= N.MAX_MLP_GROUPS):
             arr = (N.SeaMlp2Group * len(fields))()
             for g_, i in zip(arr, fields):
                 nrm = norm_params(f"ln.{i}.", E) if final_norm else {}
@@ -691,9 +708,9 @@ class Plan:
             return final_norm
         self._gemm([dict(A=hg[i], W=P.act(f"{pre}mlp.{i}.layers.3.weight"), bias=P.f32_vec(f"{pre}mlp.{i}.layers.3.bias"), R=xr[i], Cact=xm[i])
                     for i in fields], "mlp.fc2" + tag)
-        self._gemm([dict(A=xm[i], W=P.act(f"{pre}proj.{i}.weight"), bias=P.f32_vec(f"{pre}proj.{i}.bias"), C32=xr[i]) for i in fields], "proj" + tag)
+        self._gemm([dict(A=xm[i], W=P.act(f"{pre}proj.{i}.weight"), bias=P.f32_vec(f"{pre}proj.{i}.bias"), C32=xo[i]) for i in fields], "proj" + tag)
         if final_norm:
-            self._norm([dict(X=xr[i], Y32=xr[i], ldy32=FE, Y_is_out=i * E * 4, **norm_params(f"ln.{i}.", E)) for i in fields], E, "final.norm" + tag)
+            self._norm([dict(X=xo[i], Y32=xo[i], ldy32=FE, Y_is_out=i * Eo * 4, **norm_params(f"ln.{i}.", Eo)) for i in fields], Eo, "final.norm" + tag)
         return final_norm
 
     def _ib_params(self, pre: str) -> dict:
@@ -705,7 +722,7 @@ class Plan:
     def _fill_ib(self, ib, pre: str) -> None:
         """The layer parameters of SeaIbParams for the block's ib_scale_mode (models/temporal.py:103-109)."""
         P, mode = self.eng.params, self.eng.ib_mode
-        ib.mode, ib.M, ib.E = mode, self.M, self.E
+        ib.mode, ib.M, ib.E = mode, self.M, self.ib_dim
         if mode == 0:
             q = self._ib_params(pre)
             ib.w1, ib.b1, ib.lnw, ib.lnb, ib.w2, ib.b2 = (q[k].data_ptr() for k in ("w1", "b1", "lnw", "lnb", "w2", "b2"))
@@ -953,13 +970,16 @@ class TemporalEngine:
             raise RuntimeError("sea_amd: TemporalModel runs only on an MI355X (no CPU fallback)")
         m = model
         self.ib_mode = {"mlp": 0, "linear": 1, "fourier": 2}.get(m.ib_scale_mode.lower(), -1)
-        if (m.exchange_mode not in ("sea", "addition", "simple", "pool") or self.ib_mode < 0 or m.ib_addition_mode.lower() not in ("add", "none", "attention")
-                or (self.ib_mode == 0 and m.ib_mlp_layers != 1) or m.ib_num != 1 or (self.ib_mode != 0 and m.embed_dim % 8)):
+        if (m.exchange_mode not in ("sea", "addition", "simple", "pool") or self.ib_mode < 0 or m.ib_addition_mode.lower() not in ("add", "none", "attention", "concat")
+                or (self.ib_mode == 0 and m.ib_mlp_layers != 1) or m.ib_num != 1 or (self.ib_mode != 0 and m.embed_dim % 8 and m.ib_addition_mode.lower() != "concat")):
             raise NotImplementedError(
                 "sea_amd native path covers exchange_mode in {'sea', 'addition', 'simple', 'pool'}, ib_scale_mode in {'mlp', 'linear', 'fourier'}, ib_addition_mode in "
-                "{'add', 'attention', 'none'}, ib_mlp_layers=1, ib_num=1; got "
+                "{'add', 'attention', 'concat', 'none'}, ib_mlp_layers=1, ib_num=1; got "
                 f"{m.exchange_mode}/{m.ib_scale_mode}/{m.ib_addition_mode}/{m.ib_mlp_layers}/{m.ib_num}")
-        E, H, D = m.embed_dim, m.n_heads, m.down_dim
+        if m.ib_addition_mode.lower() == "concat" and m.add_info_after_cross:
+            raise NotImplementedError("sea_amd: ib_addition_mode='concat' needs add_info_after_cross=False (with the info-bottleneck step after the exchange the "
+                                      "reference's own forward fails: its attention modules are built for rows that are already widened, models/temporal.py:48,74-76,126-139)")
+        E, H, D = m.internal_embed_dim, m.n_heads, m.down_dim
         for hd, what in ((E // H, "self"),) + (((D // H, "cross"),) if m.exchange_mode in ("sea", "pool") else ()):
             if hd not in (8, 16, 32, 64, 128, 256) or hd * H != (E if what == "self" else D):
                 raise NotImplementedError(f"sea_amd: unsupported {what}-attention head dim {hd} (supported: 8, 16, 32, 64, 128, 256)")

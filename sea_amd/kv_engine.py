@@ -50,8 +50,8 @@ def supported(eng, B: int) -> bool:
     m = eng.model
     if os.environ.get("SEA_KV_FAST", "1") == "0":
         return False
-    if m.exchange_mode not in ("sea", "simple") or m.src_len != 0 or m.ib_addition_mode.lower() == "attention":
-        return False
+    if m.exchange_mode not in ("sea", "simple") or m.src_len != 0 or m.ib_addition_mode.lower() in ("attention", "concat"):
+        return False   # ('concat': rows of two widths; the generic step plan covers it)
     F, E, D, S, H = m.num_variables, m.embed_dim, m.down_dim, m.mlp_hidden, m.n_heads
     epc = 8 if eng.act_dtype == torch.bfloat16 else 4
     if not (1 <= F <= N.KV_MAX_FIELDS and 1 <= B <= 64 and E <= 512 and S <= 4096 and S % 4 == 0 and _chunks_ok(E, epc) and _chunks_ok(S, epc)):

@@ -8,8 +8,8 @@ TemporalModel.forward hands the whole forward to sea_amd.engine (≈30 fused HIP
 Scope: exchange_mode='sea' with ib_scale_mode='mlp', ib_addition_mode='add' — what both shipped configs select
 (configs/cylinder_flow.py:112-128, configs/multiphase_flow.py:112-128) — forward, rollout and training; the ablation variants
 exchange_mode 'addition' / 'simple' / 'pool', ib_scale_mode 'fourier' (the constructor's default) / 'linear' and ib_addition_mode 'none' / 'attention' through the
-same plans, forward, rollout and training.  The 'concat' info-bottleneck addition is a valid argument of the reference that this build
-does not accelerate: it raises NotImplementedError (invalid names raise ValueError as in the reference).
+same plans, forward, rollout and training, and ib_addition_mode 'concat' (blocks widened by 64 info-bottleneck columns; like the reference
+it only runs with add_info_after_cross=False).  Invalid names raise ValueError as in the reference.
 """
 from __future__ import annotations
 
@@ -50,15 +50,12 @@ class BaseBlockTemporal(nn.Module):
         self.ib_addition_mode = self._validate_ib_addition_mode(ib_addition_mode)
         self.ib_num = ib_num
         self.add_info_after_cross = add_info_after_cross
-        if self.ib_addition_mode == "concat":
-            raise NotImplementedError(
-                "sea_amd: ib_addition_mode='concat' (blocks widened by 64 info-bottleneck columns) is an ablation variant outside the accelerated path "
-                "(supported: 'add', 'attention', 'none')")
-        self.internal_embed_dim = embed_dim
+        # 'concat' (reference :48): the block works on rows widened by ib_dim_concat info-bottleneck columns; proj maps them back to embed_dim
+        self.internal_embed_dim = embed_dim + self.ib_dim_concat if self.ib_addition_mode == "concat" else embed_dim
         if self.ib_addition_mode == "attention":   # reference :49-53 (registered before the info-bottleneck layer: the checkpoint's key order)
             self.cross_attn_ib = nn.ModuleList([MultiHeadCrossAttention(n_heads, self.internal_embed_dim, max_len, src_len, dropout) for _ in range(num_variables)])
         self.ib_scale_mode = self._validate_ib_mode(ib_scale_mode)
-        self.ib_dim = embed_dim
+        self.ib_dim = self.ib_dim_concat if self.ib_addition_mode == "concat" else embed_dim   # reference :100-101
         if self.ib_scale_mode == "fourier":      # reference :103-109
             self.ib = GaussianFourierProjection(self.ib_num, int(self.ib_dim // 2))
         elif self.ib_scale_mode == "linear":
@@ -102,6 +99,8 @@ class BaseBlockTemporal(nn.Module):
             raise NotImplementedError("sea_amd: the stand-alone block forward covers ib_scale_mode='mlp'; call TemporalModel.forward")
         if self.ib_addition_mode == "attention":   # reference :117-118
             return x + self.cross_attn_ib[var_idx](x, self.ib(add_info))
+        if self.ib_addition_mode == "concat":      # reference :115-116
+            return torch.cat([x, self.ib(add_info)], dim=-1)
         return self.ib(add_info, residual=x)
 
     def _apply_exchange(self, x_vars, x_add):
@@ -263,8 +262,11 @@ class TemporalModel(nn.Module):
         self.num_layers, self.embed_dim, self.n_heads, self.max_len = num_layers, embed_dim, n_heads, max_len
         self.src_len, self.down_proj, self.dropout_p = src_len, down_proj, dropout
         self.ib_mlp_layers, self.add_info_after_cross = ib_mlp_layers, add_info_after_cross
-        self.down_dim = embed_dim // down_proj
-        self.mlp_hidden = max(1, int(embed_dim * scale_ratio))
+        # block-internal width: 'concat' widens the rows of every block by 64 info-bottleneck columns (models/temporal.py:40,48); down_dim / the MLP
+        # hidden width follow it (:58-59, base_blocks.py:13)
+        self.internal_embed_dim = embed_dim + 64 if str(ib_addition_mode).lower() == "concat" else embed_dim
+        self.down_dim = self.internal_embed_dim // down_proj
+        self.mlp_hidden = max(1, int(self.internal_embed_dim * scale_ratio))
         self.ib_hidden = max(1, int(1 * scale_ratio))  # blocks always see ib_num=1
         self.blocks = nn.ModuleList([
             create_block_temporal(

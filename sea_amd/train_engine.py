@@ -175,7 +175,7 @@ class TrainPlan(Plan):
         for i, x in enumerate(dxs):
             ib.dX[i] = x.data_ptr()
         ib.n_fields, ib.ldx = len(dxs), dxs[0].stride(0)
-        ib.M, ib.E, ib.mode = self.M, self.E, mode
+        ib.M, ib.E, ib.mode = self.M, self.ib_dim, mode
         if mode == 1:      # nn.Linear(1, E): weight [E, 1], bias [E]
             ib.dw1, ib.db1 = G(pre + "ib.weight").data_ptr(), G(pre + "ib.bias").data_ptr()
         else:
@@ -200,7 +200,8 @@ class TrainPlan(Plan):
         F, E, D, S, M, B, T, H, NL = self.F, self.E, self.D, self.S, self.M, self.B, self.T, self.H, self.L
         L = N.lib()
         hd_s, hd_c = E // H, D // H
-        cap, FE, f32 = self.cap, F * E, torch.float32
+        Eo, concat = self.Eo, self.concat          # E: the row width inside a block; Eo: model input / output and proj output rows ('concat': E = Eo + 64)
+        cap, FE, f32 = self.cap, F * Eo, torch.float32
         model = eng.model
         rope_s, rope_c = eng.rope_self, eng.rope_cross
         buf = self._buf
@@ -227,11 +228,11 @@ class TrainPlan(Plan):
                 pre = f"blocks.{l}."
                 for i in range(F):
                     prefixes += [(f"{pre}ln.exp.{i}.0.", E), (f"{pre}ln.exp.{i}.2.", E)]
-                if (F > 1 and xmode in ("sea", "addition")) or xmode == "pool":
+                if (F > 1 and xmode == "sea") or xmode in ("addition", "pool"):   # ('addition' / 'pool' exchange a single field with itself too)
                     for i in range(F):
                         prefixes.append((f"{pre}ln_cross.{i}.", D))
             for i in range(F):
-                prefixes.append((f"ln.{i}.", E))
+                prefixes.append((f"ln.{i}.", Eo))
             silu_groups, gemm_groups = [], []
             for pre, d in prefixes:
                 hid[pre], mods[pre] = buf(M, 2 * d), buf(M, 2 * d)
@@ -265,19 +266,28 @@ class TrainPlan(Plan):
             Sv.append(sv)
             first = l == 0
             sv["xr"] = [buf(M, E, dtype=f32) for _ in range(F)]
-            sv["x5"] = [buf(M, E, dtype=f32) for _ in range(F)]
+            sv["x5"] = [buf(M, Eo, dtype=f32) for _ in range(F)]
             sv["x_in"] = x_prev
-            if not model.add_info_after_cross and (has_ib or ib_attn):
+            if not model.add_info_after_cross and (has_ib or ib_attn or concat):
                 # the info-bottleneck add precedes everything and must not touch the caller's tensor: x_in := copy + ib
                 xin = [buf(M, E, dtype=f32) for _ in range(F)]
                 for i in range(F):
                     if first:
-                        rec = _Rec(L.sea_convert_f32_to_act, [None, FE, xin[i].data_ptr(), E, M, E, N.SEA_F32], "x.copy")
-                        self._x_patches.append((rec.args, 0, i * E * 4))
+                        rec = _Rec(L.sea_convert_f32_to_act, [None, FE, xin[i].data_ptr(), E, M, Eo, N.SEA_F32], "x.copy")
+                        self._x_patches.append((rec.args, 0, i * Eo * 4))
                     else:
-                        rec = _Rec(L.sea_convert_f32_to_act, [x_prev[i].data_ptr(), E, xin[i].data_ptr(), E, M, E, N.SEA_F32], "x.copy")
+                        rec = _Rec(L.sea_convert_f32_to_act, [x_prev[i].data_ptr(), Eo, xin[i].data_ptr(), E, M, Eo, N.SEA_F32], "x.copy")
                     self._cur.append(rec)
-                if ib_attn:
+                if concat:
+                    # x_in := [x | ib rows] (models/temporal.py:115-116): the info-bottleneck columns are reset, then the usual add runs on them
+                    if self._zero_ib is None:
+                        self._zero_ib = buf(M, self.ib_dim, dtype=f32, zero=True)
+                    for i in range(F):
+                        self._cur.append(_Rec(L.sea_convert_f32_to_act, [self._zero_ib.data_ptr(), self.ib_dim, xin[i][:, Eo:].data_ptr(), E, M, self.ib_dim, N.SEA_F32],
+                                              "ib.concat.zero"))
+                    sv["ib_drop"] = (thr, self._streams(F)) if thr else None
+                    self._ib(pre, [t[:, Eo:] for t in xin], drop=sv["ib_drop"])
+                elif ib_attn:
                     self._ib_attn_fwd(pre, xin, sv)
                 else:
                     sv["ib_drop"] = (thr, self._streams(F)) if thr else None
@@ -291,7 +301,7 @@ class TrainPlan(Plan):
             groups = []
             for i in range(F):
                 g = dict(Yact=sv["n0"][i], mean=sv["st0"][i][0], rstd=sv["st0"][i][1], **npar(f"{pre}ln.exp.{i}.0."))
-                g.update(dict(X=sv["xr"][i], ldx=FE, X_is_x=i * E * 4) if first else dict(X=x_in[i]))
+                g.update(dict(X=sv["xr"][i], ldx=FE, X_is_x=i * Eo * 4) if first else dict(X=x_in[i]))
                 groups.append(g)
             self._norm(groups, E, "self.adaln0")
             sv["Q"] = [buf(B, H, T, hd_s) for _ in range(F)]
@@ -309,11 +319,11 @@ class TrainPlan(Plan):
             groups = []
             for i in range(F):
                 g = dict(A=sv["att"][i], W=P.act(f"{pre}attn.self.{i}.projection.weight"), C32=sv["xr"][i], Cact=sv["xa1"][i])
-                g.update(dict(R=sv["xr"][i], ldr=FE, R_is_x=i * E * 4) if first else dict(R=x_in[i]))
+                g.update(dict(R=sv["xr"][i], ldr=FE, R_is_x=i * Eo * 4) if first else dict(R=x_in[i]))
                 groups.append(g)
             self._gemm(groups, "self.out_proj")
             # ---- state exchange
-            if F > 1 and xmode == "addition":
+            if xmode == "addition":
                 # Jacobi: every field is read at its pre-exchange value; s = sum_j n_j is the same for every field (models/temporal.py:297-301)
                 sv["dn"] = [buf(M, D, dtype=f32) for _ in range(F)]
                 sv["nd"] = buf(F, M, D)
@@ -446,8 +456,8 @@ class TrainPlan(Plan):
                         for i in range(F)], "proj")
             x_prev = sv["x5"]
         stf = [stats() for _ in range(F)]
-        self._norm([dict(X=x_prev[i], Y32=x_prev[i], ldy32=FE, Y_is_out=i * E * 4, mean=stf[i][0], rstd=stf[i][1], **npar(f"ln.{i}."))
-                    for i in range(F)], E, "final.norm")
+        self._norm([dict(X=x_prev[i], Y32=x_prev[i], ldy32=FE, Y_is_out=i * Eo * 4, mean=stf[i][0], rstd=stf[i][1], **npar(f"ln.{i}."))
+                    for i in range(F)], Eo, "final.norm")
 
         # ================================================================ backward
         self._cur = self.bwd
@@ -470,17 +480,20 @@ class TrainPlan(Plan):
         dE_ = [buf(M, E) for _ in range(F)]
         dqkv = [buf(M, 3 * E) for _ in range(F)]
         delta_s = [buf(B, H, T, dtype=f32) for _ in range(F)]
+        # the gradient of a block's OUTPUT rows (Eo wide: the proj output) lives in the first Eo columns of the E-wide residual-gradient buffers
+        dxo = dx if Eo == E else [t[:, :Eo] for t in dx]
+        gao = ga if Eo == E else [t[:, :Eo] for t in ga]
         # final norm
-        self._norm_bwd([dict(dY=dx[i], lddy=FE, dY_is_dout=i * E * 4, X=x_prev[i], mean=stf[i][0], rstd=stf[i][1], dX32=dx[i], dXact=ga[i],
-                             **bpar(f"ln.{i}.", E)) for i in range(F)], E, "bwd.final_norm", False, False, False, False)
+        self._norm_bwd([dict(dY=dxo[i], lddy=FE, dY_is_dout=i * Eo * 4, X=x_prev[i], mean=stf[i][0], rstd=stf[i][1], dX32=dxo[i], dXact=gao[i],
+                             **bpar(f"ln.{i}.", Eo)) for i in range(F)], Eo, "bwd.final_norm", False, False, False, False)
         for l in reversed(range(NL)):
             pre = f"blocks.{l}."
             sv = Sv[l]
-            first = l == 0 and (model.add_info_after_cross or not (has_ib or ib_attn))
-            # ---- proj:  x5 = Wp xa4 + bp                       (ga = d x5 in act dtype)
-            self._wgrad([dict(dY=ga[i], X=sv["xa4"][i], dW=G2(f"{pre}proj.{i}.weight"), db=Gv(f"{pre}proj.{i}.bias")) for i in range(F)], "bwd.proj.wgrad")
+            first = l == 0 and (model.add_info_after_cross or not (has_ib or ib_attn or concat))
+            # ---- proj:  x5 = Wp xa4 + bp                       (gao = d x5 in act dtype)
+            self._wgrad([dict(dY=gao[i], X=sv["xa4"][i], dW=G2(f"{pre}proj.{i}.weight"), db=Gv(f"{pre}proj.{i}.bias")) for i in range(F)], "bwd.proj.wgrad")
             # (MLP-output dropout: the residual path C32 stays whole, the copy feeding fc2's backward is masked)
-            self._gemm([dict(A=ga[i], W=P.actT(f"{pre}proj.{i}.weight"), C32=dx[i], Cact=gb[i],
+            self._gemm([dict(A=gao[i], W=P.actT(f"{pre}proj.{i}.weight"), C32=dx[i], Cact=gb[i],
                              drop=((thr, sv["mlp_drop"] + i, 2) if thr else None)) for i in range(F)], "bwd.proj.dgrad")
             # ---- fc2:   x4 = x3 + hg W2^T + b2                 (gb = d x4)
             self._wgrad([dict(dY=gb[i], X=sv["hg"][i], dW=G2(f"{pre}mlp.{i}.layers.3.weight"), db=Gv(f"{pre}mlp.{i}.layers.3.bias")) for i in range(F)],
@@ -501,7 +514,7 @@ class TrainPlan(Plan):
                 self._ib_bwd(pre, dx, drop=sv["ib_drop"])
             if model.add_info_after_cross and ib_attn:
                 self._ib_attn_bwd(pre, sv, dx, ga)
-            if F > 1 and xmode == "addition":
+            if xmode == "addition":
                 # x2_i = x1_i + Wu_i g + bu_i, g = gelu(s), s = sum_j n_j, n_j = ln_cross_j(Wd_j x1_j + bd_j): ga[i] = act copy of d x2_i
                 self._wgrad([dict(dY=ga[i], X=sv["sg"], dW=G2(f"{pre}cross_up.{i}.weight"), db=Gv(f"{pre}cross_up.{i}.bias")) for i in range(F)], "bwd.add.up.wgrad")
                 dgp = buf(F, M, D)
@@ -640,6 +653,8 @@ class TrainPlan(Plan):
                 self._ib_bwd(pre, dx, drop=sv["ib_drop"])
             if not model.add_info_after_cross and ib_attn:
                 self._ib_attn_bwd(pre, sv, dx, ga)
+            if concat:   # the info-bottleneck columns of the widened rows; columns 0 .. Eo-1 of dx / ga are the gradient of the previous block's output
+                self._ib_bwd(pre, [t[:, Eo:] for t in dx], drop=sv["ib_drop"])
         # ---- AdaLN condition MLPs: every USE contributes dmod; parameters are shared through the atomically accumulated gradients
         if adaln:
             dh = [buf(M, dm.shape[1]) for _, dm in dmods]

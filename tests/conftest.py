@@ -30,7 +30,7 @@ def cfg_from_meta(meta):
                         num_variables=m[6], down_proj=m[7], add_info_after_cross=bool(m[8]),
                         LN_type="adaln" if m[9] else "ln",
                         exchange_mode=("sea", "addition", "simple", "pool")[m[10]] if len(m) > 10 else "sea",
-                        ib_addition_mode=("add", "none", "attention")[m[11]] if len(m) > 11 else "add",
+                        ib_addition_mode=("add", "none", "attention", "concat")[m[11]] if len(m) > 11 else "add",
                         ib_scale_mode=("mlp", "linear", "fourier")[m[12]] if len(m) > 12 else "mlp")
 
 

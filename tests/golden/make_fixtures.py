@@ -54,7 +54,7 @@ def cfg_meta(cfg: OracleConfig):
     return np.array([cfg.num_layers, cfg.embed_dim, cfg.n_heads, cfg.max_len, cfg.scale_ratio, cfg.src_len,
                      cfg.num_variables, cfg.down_proj, int(cfg.add_info_after_cross),
                      1 if cfg.LN_type == "adaln" else 0, ("sea", "addition", "simple", "pool").index(cfg.exchange_mode),
-                     ("add", "none", "attention").index(cfg.ib_addition_mode), ("mlp", "linear", "fourier").index(cfg.ib_scale_mode)], dtype=np.int64)
+                     ("add", "none", "attention", "concat").index(cfg.ib_addition_mode), ("mlp", "linear", "fourier").index(cfg.ib_scale_mode)], dtype=np.int64)
 
 
 def save(name, **arrs):
@@ -529,6 +529,13 @@ def main():
     cases["model_ibattn_ln_f2_pre"] = lambda: model_case("model_ibattn_ln_f2_pre", OracleConfig(1, 64, 4, 80, 8, 0, 2, 2, False, "ln", "addition", "attention", "linear"), 2, 70)
     cases["train_ibattn_adaln_f3"] = lambda: model_case("train_ibattn_adaln_f3", OracleConfig(2, 32, 2, 24, 8, 0, 3, 2, True, "adaln", "sea", "attention"), 2, 12, train="grads")
     cases["train_ibattn_ln_f2_pre"] = lambda: model_case("train_ibattn_ln_f2_pre", OracleConfig(1, 32, 2, 24, 8, 0, 2, 2, False, "ln", "simple", "attention", "fourier"), 2, 12, train="grads")
+    # ib_addition_mode 'concat' (models/temporal.py:48,115-116: blocks widened by 64 info-bottleneck columns; the reference only runs it with the
+    # info-bottleneck step BEFORE the block, add_info_after_cross=False): embed_dim 64 -> rows of 128 (head dims 32 / 16)
+    cases["model_ibconcat_adaln_f3"] = lambda: model_case("model_ibconcat_adaln_f3", OracleConfig(2, 64, 4, 80, 8, 0, 3, 2, False, "adaln", "sea", "concat"), 2, 27)
+    cases["model_ibconcat_ln_f2"] = lambda: model_case("model_ibconcat_ln_f2", OracleConfig(1, 64, 4, 80, 8, 0, 2, 2, False, "ln", "addition", "concat", "linear"), 2, 70)
+    # (training: small hidden widths — scale_ratio 4 — keep the per-parameter gradients of these 128-wide models under 2 MB per file)
+    cases["train_ibconcat_ln_f2"] = lambda: model_case("train_ibconcat_ln_f2", OracleConfig(1, 64, 4, 24, 4, 0, 2, 2, False, "ln", "sea", "concat"), 2, 12, train="grads")
+    cases["train_ibconcat_adaln_f1"] = lambda: model_case("train_ibconcat_adaln_f1", OracleConfig(1, 64, 4, 24, 4, 0, 1, 2, False, "adaln", "addition", "concat", "fourier"), 2, 12, train="grads")
     for T in (1, 7, 16, 65):
         cases[f"model_small_adaln_f3_T{T}"] = (lambda T=T: model_case(
             f"model_small_adaln_f3_T{T}", OracleConfig(1, 64, 4, 80, 8, 0, 3, 2, True, "adaln"), 2, T))

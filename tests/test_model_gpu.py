@@ -44,7 +44,9 @@ MODEL_CASES = ["model_tiny_adaln_f3", "model_tiny_ln_f2", "model_tiny_adaln_f2_p
                "model_sea_fourier_adaln_f3", "model_sea_linear_ln_f2_pre",
                "model_pool_adaln_f3", "model_pool_ln_f2",
                # ib_addition_mode 'attention': un-masked cross-attention from the field rows to the info-bottleneck rows (after / before the exchange)
-               "model_ibattn_adaln_f3", "model_ibattn_ln_f2_pre"]
+               "model_ibattn_adaln_f3", "model_ibattn_ln_f2_pre",
+               # ib_addition_mode 'concat': every block works on rows widened by 64 info-bottleneck columns (embed_dim 64 -> 128)
+               "model_ibconcat_adaln_f3", "model_ibconcat_ln_f2"]
 
 
 @pytest.mark.parametrize("F,ln,after", [(2, "ln", True), (2, "adaln", False), (3, "ln", True)])
@@ -106,6 +108,35 @@ def test_ablation_variants_rollout_bf16_and_training(xmode, ibmode, ibscale):
     for k, gr in grads_ref.items():
         assert grad_err(eng.grad_view(k).cpu().numpy(), gr.numpy()) < 2e-4, k
     assert sorted(eng.params.live_names) == sorted(grads_ref.keys())
+
+
+def test_ib_concat_rollouts_bf16_and_constructor_rules():
+    """ib_addition_mode 'concat' (models/temporal.py:48,115-116): embed_dim 192 -> block rows of 256 (head dims 32 / 16, the widths of the fused bf16 launches).
+    KV-cache rollout (generic step plan: the concatenation is per position, so the cache is exact) against the recompute rollout and the oracle; bf16 forward
+    within the stated tolerance; add_info_after_cross=True is refused (the reference's own forward fails there)."""
+    from sea_amd.models.temporal import TemporalModel
+    from sea_amd.utils.train_utils import rollout
+
+    cfg = O.OracleConfig(2, 192, 8, 96, 8, 0, 3, 2, False, "adaln", "sea", "concat")
+    x, _, ib = recipe_inputs(2, 40, cfg, seed=12)
+    p = recipe_params(cfg)
+    ref = O.model_forward(x, ib, p, cfg)
+    m = build(cfg, "bf16")
+    with torch.no_grad():
+        out = m(x.cuda(), ib.cuda())
+    assert out.shape == (2, 40, 3, 192)
+    assert rel_l2(out.cpu().numpy(), ref.numpy()) < BF16_TOL
+    m32 = build(cfg, "fp32")
+    with torch.no_grad():
+        assert rel_l2(m32(x.cuda(), ib.cuda()).cpu().numpy(), ref.numpy()) < FP32_TOL
+    a = rollout(m32, x[:, :1].cuda(), ib.cuda(), 12, mode="recompute")
+    b = rollout(m32, x[:, :1].cuda(), ib.cuda(), 12, mode="kv")
+    assert len(m32.engine()._kv_fast) == 0          # rows of two widths: the generic step plan, not sea_kv_rollout
+    assert rel_l2(b.cpu().numpy(), a.cpu().numpy()) < 1e-5
+    assert rel_l2(a.cpu().numpy(), O.rollout(x[:, :1], ib, 12, p, cfg).numpy()) < FP32_TOL
+    bad = TemporalModel(1, 64, 4, 32, 8, 0, 2, 2, 0.0, "sea", "learnable", "mlp", "concat", 1, 1, True, "ln").to("cuda:0")
+    with pytest.raises(NotImplementedError, match="add_info_after_cross"):
+        bad(x[:, :8, :2, :64].contiguous().cuda(), ib[:, :8].cuda())
 
 
 def test_kv_rollout_with_src_len_is_refused_and_falls_back_to_recompute():

@@ -19,7 +19,9 @@ def make(cfg: OracleConfig, **kw):
                                  OracleConfig(2, 64, 4, 24, 8, 0, 3, 2, True, "adaln", "sea", "add", "fourier"), OracleConfig(1, 64, 4, 24, 8, 0, 2, 2, True, "ln", "sea", "add", "linear"),
                                  OracleConfig(2, 64, 4, 24, 8, 0, 3, 2, True, "adaln", "pool"), OracleConfig(1, 64, 4, 24, 8, 0, 2, 2, True, "ln", "pool"),
                                  OracleConfig(2, 64, 4, 24, 8, 0, 3, 2, True, "adaln", "sea", "attention"),
-                                 OracleConfig(1, 64, 4, 24, 8, 0, 2, 2, False, "ln", "simple", "attention", "fourier")])
+                                 OracleConfig(1, 64, 4, 24, 8, 0, 2, 2, False, "ln", "simple", "attention", "fourier"),
+                                 OracleConfig(2, 64, 4, 24, 8, 0, 3, 2, False, "adaln", "sea", "concat"),
+                                 OracleConfig(1, 64, 4, 24, 8, 0, 2, 2, False, "ln", "addition", "concat", "linear")])
 def test_parameter_schema_matches_reference(cfg):
     """Names, order and shapes equal the reference's named_parameters() (oracle/recipe.param_schema is asserted equal to the
     reference's own by tests/golden/make_fixtures.py)."""
@@ -68,8 +70,10 @@ def test_error_behaviour():
         TemporalModel(1, 64, 4, 24, 8, 0, 2, exchange_mode="sea", ib_scale_mode="mlp", pos_encoding_mode="bogus")
     with pytest.raises(ValueError):
         TemporalModel(1, 64, 4, 24, 8, 0, 2, exchange_mode="sea", ib_scale_mode="mlp", LN_type="bogus")
-    with pytest.raises(NotImplementedError):
-        TemporalModel(1, 64, 4, 24, 8, 0, 2, exchange_mode="sea", ib_scale_mode="mlp", ib_addition_mode="concat")
+    with pytest.raises(ValueError):
+        TemporalModel(1, 64, 4, 24, 8, 0, 2, exchange_mode="sea", ib_scale_mode="mlp", ib_addition_mode="bogus")
+    wide = TemporalModel(1, 64, 4, 24, 8, 0, 2, exchange_mode="sea", ib_scale_mode="mlp", ib_addition_mode="concat")   # rows of 64 + 64 inside the block
+    assert wide.blocks[0].internal_embed_dim == 128 and wide.blocks[0].proj[0].weight.shape == (64, 128) and wide.blocks[0].ib.layers[-1].out_features == 64
     with pytest.raises(ValueError):
         create_block_temporal("nope")
     m = make(OracleConfig(1, 64, 4, 24, 8, 0, 2, 2, True, "adaln"))

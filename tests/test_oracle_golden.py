@@ -111,7 +111,9 @@ MODEL_CASES = ["model_tiny_adaln_f3", "model_tiny_ln_f2", "model_tiny_adaln_f2_p
                # exchange_mode 'pool' (field -> pool-token cross-attention, src_len = 1 in the second case)
                "model_pool_adaln_f3", "model_pool_ln_f2",
                # ib_addition_mode 'attention' (un-masked cross-attention from the field rows to the info-bottleneck rows), after and before the exchange
-               "model_ibattn_adaln_f3", "model_ibattn_ln_f2_pre"]
+               "model_ibattn_adaln_f3", "model_ibattn_ln_f2_pre",
+               # ib_addition_mode 'concat' (rows widened by 64 info-bottleneck columns inside every block)
+               "model_ibconcat_adaln_f3", "model_ibconcat_ln_f2"]
 
 
 @pytest.mark.parametrize("name", MODEL_CASES)
@@ -152,7 +154,7 @@ def test_model_grads_and_adamw(name):
 
 
 @pytest.mark.parametrize("name", ["train_addition_adaln_f3", "train_simple_ln_f2", "train_sea_noib_adaln_f2", "train_sea_linear_ln_f2_pre",
-                                  "train_addition_fourier_adaln_f3", "train_pool_adaln_f3", "train_pool_ln_f1", "train_ibattn_adaln_f3", "train_ibattn_ln_f2_pre"])
+                                  "train_addition_fourier_adaln_f3", "train_pool_adaln_f3", "train_pool_ln_f1", "train_ibattn_adaln_f3", "train_ibattn_ln_f2_pre", "train_ibconcat_ln_f2", "train_ibconcat_adaln_f1"])
 def test_variant_model_grads(name):
     """The ablation variants' train step (reference models/temporal.py:197-312, 103-116): output, loss, every gradient and the set of gradient-less
     parameters of the oracle against what the reference produced."""

@@ -13,9 +13,10 @@ pytestmark = pytest.mark.gpu
 
 TRAIN_CASES = ["model_tiny_adaln_f3", "model_tiny_ln_f2", "model_tiny_adaln_f2_pre"]
 # the ablation variants of the block (reference models/temporal.py:285-312, 103-116): 'addition' / 'simple' exchange, the info-bottleneck
-# layer not added ('none'), as nn.Linear ('linear') or as fixed Fourier features ('fourier'), the 'pool' exchange (a pooled token per row; also with one field), the info-bottleneck rows attended to instead of added ('attention')
+# layer not added ('none'), as nn.Linear ('linear') or as fixed Fourier features ('fourier'), the 'pool' exchange (a pooled token per row; also with one field), the info-bottleneck rows attended to instead of added ('attention') or concatenated to the block's rows ('concat'; the second case also has ONE field in 'addition' mode)
 VARIANT_TRAIN_CASES = ["train_addition_adaln_f3", "train_simple_ln_f2", "train_sea_noib_adaln_f2", "train_sea_linear_ln_f2_pre", "train_addition_fourier_adaln_f3",
-                       "train_pool_adaln_f3", "train_pool_ln_f1", "train_ibattn_adaln_f3", "train_ibattn_ln_f2_pre"]
+                       "train_pool_adaln_f3", "train_pool_ln_f1", "train_ibattn_adaln_f3", "train_ibattn_ln_f2_pre",
+                       "train_ibconcat_ln_f2", "train_ibconcat_adaln_f1"]
 
 
 @pytest.mark.parametrize("name", TRAIN_CASES + VARIANT_TRAIN_CASES)
