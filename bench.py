@@ -15,7 +15,8 @@ ONE JSON line.  Its legs (all measured inside the driver-timed run):
            model, the batch split by rank, ONE all-reduce of the flat fp32 gradient per step (RCCL), the 1/world mean folded into AdamW.
            N > 1: this is the headline (`value` = trajectory-steps/s over all GPUs), with the all-reduce timed on its own and a single-GPU
            step of the same processes beside it.
-  kv       exact KV-cache rollouts: 2024 steps of the cfg2 model, and a cfg5-shaped one (multiphase structure: F = 2, LayerNorm, 100 steps).
+  kv       exact KV-cache rollouts: 2024 steps of the cfg2 model, a cfg5-shaped one (multiphase structure: F = 2, LayerNorm, 100 steps), and 100 steps at
+           the two SHIPPED widths (configs/cylinder_flow.py: embed_dim 1024; configs/multiphase_flow.py: embed_dim 2048 — BASELINE.json configs[0] / [4]).
   cpu_baseline (N = 1, rank 0): the CPU oracle (oracle/sea_oracle.py, pinned by the reference's golden vectors) on this host's cores: forward,
            forward + backward + AdamW (1 warm-up + 1 pass), 8- and 100-step recompute rollouts.
   roofline the dominant launch of the headline leg: algorithmic FLOPs (and bytes) of ONE launch, derived from the launch's own argument
@@ -431,6 +432,34 @@ def leg_kv(args, dev, rank):
                 rollout(model, x0, ib, n_steps, mode="recompute")
             torch.cuda.synchronize()
             out[key]["recompute_steps_per_s"] = n_steps / ((time.perf_counter() - t0) / 3)
+        del model
+    # the SHIPPED widths (BASELINE.json configs[0] / configs[4]: configs/cylinder_flow.py embed_dim 1024 adaln, configs/multiphase_flow.py embed_dim 2048 ln; both 2
+    # field groups, 8 heads, 1 layer, block 2024): 100-step exact KV-cache rollouts (generic step plan: these widths are outside sea_kv_rollout's register-
+    # resident kernels) with the reference-equivalent recompute rollout beside them
+    from sea_amd.models.temporal import TemporalModel
+
+    for key, E, ln in (("cfg1_cylinder_dims_100_steps", 1024, "adaln"), ("cfg5_multiphase_dims_100_steps", 2048, "ln")):
+        torch.manual_seed(42)
+        model = TemporalModel(1, E, 8, 2024, 8, 0, 2, 2, 0.0, "sea", "learnable", "mlp", "add", 1, 1, True, ln)
+        model.set_compute_dtype(args.dtype)
+        model = model.to(dev).eval()
+        x0 = torch.randn(1, 1, 2, E, generator=torch.Generator().manual_seed(77)).to(dev)
+        ib = torch.rand(1, 100, 1, generator=torch.Generator().manual_seed(78)).to(dev)
+        res = {}
+        for mode, reps in (("kv", 10), ("recompute", 3)):
+            for _ in range(2):
+                r = rollout(model, x0, ib, 100, mode=mode)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                r = rollout(model, x0, ib, 100, mode=mode)
+            torch.cuda.synchronize()
+            res[mode] = (time.perf_counter() - t0) / reps
+            assert torch.isfinite(r).all()
+        nbytes = sum(p.numel() for p in model.parameters()) * (2 if args.dtype == "bf16" else 4)
+        out[key] = {"steps_per_s": 100 / res["kv"], "ms_per_step": res["kv"] / 100 * 1e3, "recompute_steps_per_s": 100 / res["recompute"],
+                    "parameter_MB": nbytes / 1e6, "weight_read_GBps": nbytes * 100 / res["kv"] / 1e9,
+                    "workload": f"exact KV-cache rollout of 100 steps, B=1, E={E} H=8 F=2 L=1 {ln} (shipped width; every step streams the {nbytes / 1e6:.0f} MB of weights once)"}
         del model
     return out
 

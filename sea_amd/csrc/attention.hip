@@ -490,15 +490,138 @@ __global__ __launch_bounds__(512) void attention_row_kernel(const SeaAttnParams 
     (void)EPC;
 }
 
+// The same for WIDE heads (128 / 256: the shipped widths, embed_dim 1024 / 2048 over 8 heads), where a thread cannot hold the query and a key row:
+// HD / 32 adjacent lanes share a key (32 columns each, the partial dot products meet by lane shuffles), the raw scores go to LDS and are turned into
+// probabilities by a second pass (no per-thread score array: any number of keys), and phase 2 walks a wave's HD / 8 value rows 8 at a time.
+template <typename T, int HD>
+__global__ __launch_bounds__(512) void attention_row_wide_kernel(const SeaAttnParams P) {
+    constexpr int EPC = ActTraits<T>::EPC;
+    constexpr int NW = 8, LPK = HD / 32, KPP = 512 / LPK, CPS = 32 / EPC;   // lanes per key, keys per pass, 16-byte chunks per 32-column slice
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* red = reinterpret_cast<float*>(smem);           // [2][NW] workgroup max / sum
+    float* prob = red + 2 * NW + 16;                       // [round_up(nk, 8) + 8]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int bh = blockIdx.x, zp = blockIdx.y;
+    const int b = bh / P.H, h = bh - b * P.H;
+    const SeaAttnProblem& pr = P.p[zp];
+    const T* Qg = static_cast<const T*>(pr.Q) + (int64_t)bh * HD;           // Tq = 1
+    const T* Kg = static_cast<const T*>(pr.K) + (int64_t)bh * P.cap * HD;
+    const T* Vg = static_cast<const T*>(pr.Vt) + (int64_t)bh * HD * P.cap;
+    const int vis = P.q_pos0 + P.src_len + 1;
+    const int nk = vis < P.Tk ? vis : P.Tk;
+    const int part = tid % LPK, k_first = tid / LPK;
+    float q[32];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) load4(Qg + part * 32 + c * 4, *reinterpret_cast<float(*)[4]>(q + c * 4));
+    // ---- phase 1a: raw scores to LDS, the running maximum in registers
+    float mx = -INFINITY;
+    for (int key = k_first; key < nk; key += 2 * KPP) {   // two keys per iteration: both rows are requested before either is used
+        uint4 raw[2][CPS];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int kk = key + u * KPP;
+            const uint4* kr = reinterpret_cast<const uint4*>(Kg + (int64_t)(kk < nk ? kk : nk - 1) * HD + part * 32);
+#pragma unroll
+            for (int c = 0; c < CPS; ++c) raw[u][c] = kr[c];
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int kk = key + u * KPP;
+            float acc = 0.f;
+#pragma unroll
+            for (int c = 0; c < CPS; ++c) {
+                float kv[EPC];
+                unpack16<T>(raw[u][c], kv);
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) acc += q[c * EPC + e] * kv[e];
+            }
+#pragma unroll
+            for (int o = 1; o < LPK; o <<= 1) acc += __shfl_xor(acc, o);
+            if (kk < nk) {
+                if (part == 0) prob[kk] = acc;
+                mx = fmaxf(mx, acc);
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    if (lane == 0) red[wave] = mx;
+    __syncthreads();
+    float m = red[0];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) m = fmaxf(m, red[w]);
+    // ---- phase 1b: probabilities in place
+    constexpr float LOG2E = 1.4426950408889634f;
+    float ls = 0.f;
+    for (int key = tid; key < nk; key += 512) {
+        const float pv = __builtin_amdgcn_exp2f((prob[key] - m) * LOG2E);
+        prob[key] = pv;
+        ls += pv;
+    }
+    const int nk8 = (nk + 7) & ~7;
+    if (tid < nk8 - nk) prob[nk + tid] = 0.f;              // the tail of the last 8-key vector
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) ls += __shfl_xor(ls, o);
+    if (lane == 0) red[NW + wave] = ls;
+    __syncthreads();
+    float l = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) l += red[NW + w];
+    const float inv = 1.0f / l;
+    // ---- phase 2: wave w owns value rows d = w * DPW .. + DPW - 1, eight at a time
+    const int nvec = nk8 >> 3;
+    T* Og = static_cast<T*>(pr.O) + (int64_t)b * P.ldo + h * HD;
+    constexpr int DPW = HD / NW, DCH = 8;
+    constexpr int VPC = 8 * (int)sizeof(T) / 16;
+    for (int dc = 0; dc < DPW; dc += DCH) {
+        float acc[DCH];
+#pragma unroll
+        for (int i = 0; i < DCH; ++i) acc[i] = 0.f;
+        for (int v = lane; v < nvec; v += 64) {
+            uint4 raw[DCH][VPC];
+#pragma unroll
+            for (int i = 0; i < DCH; ++i) {
+                const uint4* vr = reinterpret_cast<const uint4*>(Vg + (int64_t)(wave * DPW + dc + i) * P.cap + v * 8);
+#pragma unroll
+                for (int c = 0; c < VPC; ++c) raw[i][c] = vr[c];
+            }
+            float pv[8];
+            load4(prob + v * 8, *reinterpret_cast<float(*)[4]>(pv));
+            load4(prob + v * 8 + 4, *reinterpret_cast<float(*)[4]>(pv + 4));
+            const bool tail = v * 8 + 8 > nk;
+#pragma unroll
+            for (int i = 0; i < DCH; ++i) {
+                float vv[8];
+#pragma unroll
+                for (int c = 0; c < VPC; ++c) unpack16<T>(raw[i][c], *reinterpret_cast<float(*)[EPC]>(vv + c * EPC));
+                if (tail) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) vv[e] = v * 8 + e < nk ? vv[e] : 0.f;
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[i] += pv[e] * vv[e];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < DCH; ++i) {
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) acc[i] += __shfl_xor(acc[i], o);
+            if (lane == 0) Og[wave * DPW + dc + i] = from_f32<T>(acc[i] * inv);
+        }
+    }
+}
+
 template <typename T>
 static bool launch_attention_row(const SeaAttnParams& P, hipStream_t s) {
     static const int on = []() { const char* e = getenv("SEA_ATTN_ROW"); return e ? atoi(e) : 1; }();  // tuning aid: 0 keeps the tiled kernel
-    if (!on || P.Tq != 1 || P.drop.thr != 0 || P.Tk > 8192 || (P.hd != 8 && P.hd != 16 && P.hd != 32 && P.hd != 64)) return false;
+    if (!on || P.Tq != 1 || P.drop.thr != 0 || P.Tk > 8192 || (P.hd != 8 && P.hd != 16 && P.hd != 32 && P.hd != 64 && P.hd != 128 && P.hd != 256)) return false;
     for (int i = 0; i < P.n_problems; ++i)
         if (P.p[i].LSE != nullptr) return false;
     const dim3 grid(P.B * P.H, P.n_problems), block(512);
     const int lds = (2 * 8 + 16 + ((P.Tk + 7) & ~7) + 8) * 4;
     switch (P.hd) {
+        case 128: attention_row_wide_kernel<T, 128><<<grid, block, lds, s>>>(P); return true;
+        case 256: attention_row_wide_kernel<T, 256><<<grid, block, lds, s>>>(P); return true;
         case 8: attention_row_kernel<T, 8><<<grid, block, lds, s>>>(P); break;
         case 16: attention_row_kernel<T, 16><<<grid, block, lds, s>>>(P); break;
         case 32: attention_row_kernel<T, 32><<<grid, block, lds, s>>>(P); break;

@@ -217,6 +217,32 @@ __device__ __forceinline__ int find_group_blk(const SkinnyLaunch& launch, int bi
     return gi;
 }
 
+// epilogue of the few-row kernels — this lane: output row r, columns n0 + 4 g .. + 3; bias, GELU (act 1, pre-activation kept in Z), residual, fp32 / bf16 outputs
+__device__ __forceinline__ void skinny_epilogue(const SeaGemmGroup& G, const f32x4& acc, int r, int g, int n0) {
+    const int nc = n0 + g * 4;
+    if (r >= G.M || nc >= G.N) return;
+    float v[4] = {acc[0], acc[1], acc[2], acc[3]};
+    if (G.bias != nullptr) {
+        float bv[4];
+        load4(G.bias + nc, bv);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] += bv[q] * G.bias_scale;
+    }
+    if (G.act == 1) {
+        if (G.Z != nullptr) store4(static_cast<__bf16*>(G.Z) + (int64_t)r * G.ldz + nc, v[0], v[1], v[2], v[3]);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = gelu_erf(v[q]);
+    }
+    if (G.R != nullptr) {
+        float rv[4];
+        load4(G.R + (int64_t)r * G.ldr + nc, rv);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] += rv[q];
+    }
+    if (G.C32 != nullptr) store4(G.C32 + (int64_t)r * G.ldc32 + nc, v[0], v[1], v[2], v[3]);
+    if (G.Cact != nullptr) store4(static_cast<__bf16*>(G.Cact) + (int64_t)r * G.ldcact + nc, v[0], v[1], v[2], v[3]);
+}
+
 template <int KSTEPS>   // 32-wide contraction steps per wave = K / 128
 __device__ __forceinline__ void skinny_quarter(const __bf16* Arow, const __bf16* Wrow, int k0, f32x4& acc) {
     uint4 wf[KSTEPS], af[KSTEPS];
@@ -260,24 +286,66 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const SkinnyLaunch L) 
         const float4 p = *reinterpret_cast<const float4*>(red[w][lane]);
         acc[0] += p.x; acc[1] += p.y; acc[2] += p.z; acc[3] += p.w;
     }
-    // this lane: output row r, columns n0 + 4 g .. + 3
-    const int nc = n0 + g * 4;
-    if (r >= G.M || nc >= G.N) return;
-    float v[4] = {acc[0], acc[1], acc[2], acc[3]};
-    if (G.bias != nullptr) {
-        float bv[4];
-        load4(G.bias + nc, bv);
+    skinny_epilogue(G, acc, r, g, n0);
+}
+
+// The same for LONG contractions (fc2 of the shipped widths: K = 8192 / 16384 for one row per field; the tiled kernels give such a launch to N / 128
+// workgroups that each walk 4 MB of weights K-tile by K-tile: 81 us at the multiphase width).  Eight waves per 16 output columns, wave w the eighth w of the
+// contraction in rounds of 8 steps, the next round's fragments requested before the current round's MFMAs (two register sets): 128 KiB of weights in flight per
+// workgroup, one workgroup per 16 columns -> every CU streams its own 16 weight rows end to end.  K % 2048 == 0 (whole rounds).
+__global__ __launch_bounds__(512) void gemm_skinny_long_kernel(const SkinnyLaunch L) {
+    constexpr int NWV = 8, RS = 8;
+    __shared__ __attribute__((aligned(16))) float red[NWV - 1][64][4];
+    const int gi = find_group_blk(L, (int)blockIdx.x);
+    const SeaGemmGroup& G = L.g[gi];
+    const int n0 = ((int)blockIdx.x - L.blk_start[gi]) * 16;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int r = lane & 15, g = lane >> 4;
+    const int m = r < G.M ? r : G.M - 1;
+    const int n = n0 + r < G.N ? n0 + r : G.N - 1;
+    const int kw = G.K / NWV;                             // this wave's share of the contraction
+    const __bf16* Arow = static_cast<const __bf16*>(G.A) + (int64_t)m * G.lda + g * 8 + wave * kw;
+    const __bf16* Wrow = static_cast<const __bf16*>(G.W) + (int64_t)n * G.ldw + g * 8 + wave * kw;
+    const int rounds = kw / (32 * RS);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    uint4 w0[RS], a0[RS], w1[RS], a1[RS];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) v[q] += bv[q] * G.bias_scale;
+    for (int i = 0; i < RS; ++i) {
+        w0[i] = *reinterpret_cast<const uint4*>(Wrow + i * 32);
+        a0[i] = *reinterpret_cast<const uint4*>(Arow + i * 32);
     }
-    if (G.R != nullptr) {
-        float rv[4];
-        load4(G.R + (int64_t)r * G.ldr + nc, rv);
+    for (int rd = 0; rd < rounds; rd += 2) {
+        const bool more1 = rd + 1 < rounds, more2 = rd + 2 < rounds;
+        if (more1) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) v[q] += rv[q];
+            for (int i = 0; i < RS; ++i) {
+                w1[i] = *reinterpret_cast<const uint4*>(Wrow + (rd + 1) * 32 * RS + i * 32);
+                a1[i] = *reinterpret_cast<const uint4*>(Arow + (rd + 1) * 32 * RS + i * 32);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < RS; ++i) mma16<__bf16>(w0[i], a0[i], acc);
+        if (more2) {
+#pragma unroll
+            for (int i = 0; i < RS; ++i) {
+                w0[i] = *reinterpret_cast<const uint4*>(Wrow + (rd + 2) * 32 * RS + i * 32);
+                a0[i] = *reinterpret_cast<const uint4*>(Arow + (rd + 2) * 32 * RS + i * 32);
+            }
+        }
+        if (more1) {
+#pragma unroll
+            for (int i = 0; i < RS; ++i) mma16<__bf16>(w1[i], a1[i], acc);
+        }
     }
-    if (G.C32 != nullptr) store4(G.C32 + (int64_t)r * G.ldc32 + nc, v[0], v[1], v[2], v[3]);
-    if (G.Cact != nullptr) store4(static_cast<__bf16*>(G.Cact) + (int64_t)r * G.ldcact + nc, v[0], v[1], v[2], v[3]);
+    if (wave > 0) *reinterpret_cast<float4*>(red[wave - 1][lane]) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    __syncthreads();
+    if (wave > 0) return;
+#pragma unroll
+    for (int w = 0; w < NWV - 1; ++w) {
+        const float4 p = *reinterpret_cast<const float4*>(red[w][lane]);
+        acc[0] += p.x; acc[1] += p.y; acc[2] += p.z; acc[3] += p.w;
+    }
+    skinny_epilogue(G, acc, r, g, n0);
 }
 
 // ---------------------------------------------------------------------------------------------- QKV + RoPE epilogue
@@ -515,8 +583,11 @@ extern "C" int sea_gemm_grouped(const SeaGemmGroup* groups, int n_groups, int dt
     bool skinny = skinny_env != 0 && dtype == SEA_BF16 && n_silu == 0;
     for (int i = 0; i < n_groups && skinny; ++i) {
         const SeaGemmGroup& G = groups[i];
-        skinny = G.M <= 16 && G.n_seg == 1 && G.K % 128 == 0 && G.K <= 2048 && G.act == 0 && G.drop.thr == 0 && G.N % 4 == 0;
+        skinny = G.M <= 16 && G.n_seg == 1 && G.K % 128 == 0 && (G.K <= 2048 || (G.K % 2048 == 0 && G.K <= 32768)) && G.act <= 1 && G.drop.thr == 0 && G.N % 4 == 0;
     }
+    bool long_k = false;   // one kernel per launch: the long-contraction form as soon as one group needs it (every group must then have whole rounds)
+    for (int i = 0; i < n_groups && skinny; ++i) long_k = long_k || groups[i].K > 2048;
+    for (int i = 0; i < n_groups && skinny && long_k; ++i) skinny = groups[i].K % 2048 == 0;
     if (skinny) {
         SkinnyLaunch S;
         memset(&S, 0, sizeof(S));
@@ -528,7 +599,8 @@ extern "C" int sea_gemm_grouped(const SeaGemmGroup* groups, int n_groups, int dt
         }
         S.blk_start[n_groups] = blocks;
         S.n_groups = n_groups;
-        gemm_skinny_kernel<<<dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream)>>>(S);
+        if (long_k) gemm_skinny_long_kernel<<<dim3(blocks), dim3(512), 0, static_cast<hipStream_t>(stream)>>>(S);
+        else gemm_skinny_kernel<<<dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream)>>>(S);
         SEA_CHECK_LAUNCH("sea_gemm_grouped");
         return SEA_OK;
     }

@@ -149,6 +149,96 @@ __global__ __launch_bounds__(256) void rownorm_kernel(const NormLaunch L) {
     }
 }
 
+// A FEW LONG rows (the KV-cache step of the shipped widths: one row of 8192 / 16384 hidden values per field): a wave per row walks such a row in three
+// dependent passes of d / 256 iterations (78 us for 2 rows of 16384 at the multiphase width).  Here a workgroup of 1024 threads owns a row: every thread
+// keeps its d / 4096 pieces of 4 columns in registers (one memory round trip), the two statistics cross the 16 waves through LDS.  d <= 32768.
+template <typename T, bool X_IS_ACT>
+__global__ __launch_bounds__(1024) void rownorm_fewrows_kernel(const NormLaunch L) {
+    constexpr int KM = 8, NT = 1024;
+    __shared__ float red[2][NT / 64];
+    const SeaNormGroup& G = L.g[blockIdx.y];
+    const int row = (int)blockIdx.x, tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int d = L.d;
+    using XT = typename std::conditional<X_IS_ACT, T, float>::type;
+    const XT* x = static_cast<const XT*>(G.X) + (int64_t)row * G.ldx;
+    const T* mod = G.mod != nullptr ? static_cast<const T*>(G.mod) + (int64_t)row * G.ldmod : nullptr;
+    float* y32 = G.Y32 != nullptr ? G.Y32 + (int64_t)row * G.ldy32 : nullptr;
+    T* yact = G.Yact != nullptr ? static_cast<T*>(G.Yact) + (int64_t)row * G.ldyact : nullptr;
+    const float inv_d = 1.0f / (float)d;
+    float xv[KM][4];
+#pragma unroll
+    for (int k = 0; k < KM; ++k) {
+        const int i = tid * 4 + NT * 4 * k;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) xv[k][e] = 0.f;
+        if (i < d) {
+            load4(x + i, xv[k]);
+            if constexpr (!X_IS_ACT) {
+                if (G.addend != nullptr) {
+                    float av[4];
+                    load4(G.addend + (int64_t)row * G.ldadd + i, av);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) xv[k][e] += av[e];
+                    if (G.Xout != nullptr) store4(G.Xout + (int64_t)row * G.ldxout + i, xv[k][0], xv[k][1], xv[k][2], xv[k][3]);
+                }
+            }
+        }
+    }
+    float sum = 0.f;
+#pragma unroll
+    for (int k = 0; k < KM; ++k) sum += (xv[k][0] + xv[k][1]) + (xv[k][2] + xv[k][3]);   // columns >= d hold zeros
+    sum = wave_sum(sum);
+    if (lane == 0) red[0][wave] = sum;
+    __syncthreads();
+    float tot = 0.f;
+#pragma unroll
+    for (int w = 0; w < NT / 64; ++w) tot += red[0][w];
+    const float mean = tot * inv_d;
+    float sq = 0.f;
+#pragma unroll
+    for (int k = 0; k < KM; ++k)
+        if (tid * 4 + NT * 4 * k < d) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float c = xv[k][e] - mean;
+                sq += c * c;
+            }
+        }
+    sq = wave_sum(sq);
+    if (lane == 0) red[1][wave] = sq;
+    __syncthreads();
+    tot = 0.f;
+#pragma unroll
+    for (int w = 0; w < NT / 64; ++w) tot += red[1][w];
+    const float rstd = 1.0f / sqrtf(tot * inv_d + L.eps);
+    if (tid == 0) {
+        if (G.mean != nullptr) G.mean[row] = mean;
+        if (G.rstd != nullptr) G.rstd[row] = rstd;
+    }
+#pragma unroll
+    for (int k = 0; k < KM; ++k) {
+        const int i = tid * 4 + NT * 4 * k;
+        if (i < d) {
+            float g1[4], b1[4] = {0.f, 0.f, 0.f, 0.f}, w1[4] = {0.f, 0.f, 0.f, 0.f}, m1[4] = {0.f, 0.f, 0.f, 0.f}, o[4];
+            load4(G.gamma + i, g1);
+            if (G.beta != nullptr) load4(G.beta + i, b1);
+            if (mod != nullptr) {
+                load4(mod + i, w1);
+                load4(mod + d + i, m1);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float gq = mod != nullptr ? g1[e] + 1.0f + w1[e] : g1[e];
+                const float bq = mod != nullptr ? b1[e] + m1[e] : b1[e];
+                o[e] = (xv[k][e] - mean) * rstd * gq + bq;
+                if (L.gelu) o[e] = y32 != nullptr ? gelu_erf(o[e]) : gelu_for<T>(o[e]);
+            }
+            if (y32 != nullptr) store4(y32 + i, o[0], o[1], o[2], o[3]);
+            if (yact != nullptr) store4(yact + i, o[0], o[1], o[2], o[3]);
+        }
+    }
+}
+
 extern "C" int sea_rownorm(const SeaNormGroup* groups, int n_groups, int M, int d, int x_is_act, int gelu, float eps,
                            int dtype, void* stream) {
     SEA_REQUIRE(groups != nullptr && n_groups >= 1 && n_groups <= SEA_MAX_NORM_GROUPS, "sea_rownorm: n_groups=%d", n_groups);
@@ -173,6 +263,17 @@ extern "C" int sea_rownorm(const SeaNormGroup* groups, int n_groups, int M, int 
     L.M = M; L.d = d; L.gelu = gelu; L.eps = eps;
     const dim3 grid((M + 3) / 4, n_groups), block(256);
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if (M <= 32 && d > 2048 && d <= 32768) {   // a few long rows: a workgroup per row
+        const dim3 gridw(M, n_groups), blockw(1024);
+        if (dtype == SEA_BF16) {
+            if (x_is_act) rownorm_fewrows_kernel<__bf16, true><<<gridw, blockw, 0, s>>>(L);
+            else rownorm_fewrows_kernel<__bf16, false><<<gridw, blockw, 0, s>>>(L);
+        } else {
+            rownorm_fewrows_kernel<float, false><<<gridw, blockw, 0, s>>>(L);
+        }
+        SEA_CHECK_LAUNCH("sea_rownorm");
+        return SEA_OK;
+    }
 #define LAUNCH_RN(TT, XA)                                                     \
     do {                                                                       \
         if (d <= 256) rownorm_kernel<TT, XA, 1><<<grid, block, 0, s>>>(L);     \
@@ -277,14 +378,18 @@ extern "C" int sea_silu_outer_ib(const SeaSiluGroup* groups, int n_groups, const
 // ------------------------------------------------------------------------------------------------ information bottleneck add
 // One wave per row.  Lanes 0..h-1 compute the hidden vector gelu(LN_h(w1 c + b1)) (h <= 64), the wave shares it by
 // __shfl, then every lane produces 4 consecutive output columns at a time and adds them to all fields.
+// SPLIT (a few rows, e.g. a KV-cache step): the four waves of a workgroup share ONE row (wave w the columns 256 w + 1024 k ..), so a wide row is four short
+// chains instead of one long one (22 us for one row of 2048 at the multiphase width).
+template <bool SPLIT>
 __global__ __launch_bounds__(256) void ib_add_kernel(const SeaIbParams P) {
     const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int row = SPLIT ? (int)blockIdx.x : (int)(blockIdx.x * 4 + (threadIdx.x >> 6));
     if (row >= P.M) return;
+    const int e_first = SPLIT ? (int)(threadIdx.x >> 6) * 256 + lane * 4 : lane * 4, e_step = SPLIT ? 1024 : 256;
     const int h = P.h;
     const float cv = P.c[row];
     if (P.mode != 0) {   // 'linear' / 'fourier' layers: no hidden vector (block-uniform)
-        for (int e0 = lane * 4; e0 < P.E; e0 += 256) {
+        for (int e0 = e_first; e0 < P.E; e0 += e_step) {
             float o[4];
             ib_simple4(P, cv, e0, o);
             for (int f = 0; f < P.n_fields; ++f) {
@@ -303,7 +408,7 @@ __global__ __launch_bounds__(256) void ib_add_kernel(const SeaIbParams P) {
     const float var = wave_sum(cen * cen) / (float)h;
     const float rstd = 1.0f / sqrtf(var + 1e-5f);
     const float hid = act ? gelu_erf(cen * rstd * P.lnw[lane] + P.lnb[lane]) : 0.f;
-    for (int e0 = lane * 4; e0 < P.E; e0 += 256) {
+    for (int e0 = e_first; e0 < P.E; e0 += e_step) {
         float o[4];
         load4(P.b2 + e0, o);
         if ((h & 3) == 0) {
@@ -356,7 +461,8 @@ extern "C" int sea_ib_add(const SeaIbParams* params, void* stream) {
         SEA_REQUIRE(P.c && P.w1 && sea_aligned16(P.w1) && (P.mode == 2 || (P.b1 && sea_aligned16(P.b1))), "sea_ib_add: null / misaligned parameter pointer");
     }
     for (int f = 0; f < P.n_fields; ++f) SEA_REQUIRE(P.X[f] && sea_aligned16(P.X[f]), "sea_ib_add: X[%d] null or misaligned", f);
-    ib_add_kernel<<<dim3((P.M + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream)>>>(P);
+    if (P.M <= 16 && P.E > 256) ib_add_kernel<true><<<dim3(P.M), dim3(256), 0, static_cast<hipStream_t>(stream)>>>(P);
+    else ib_add_kernel<false><<<dim3((P.M + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream)>>>(P);
     SEA_CHECK_LAUNCH("sea_ib_add");
     return SEA_OK;
 }

@@ -105,6 +105,62 @@ def test_gemm_few_rows_kernel(M, K, N_):
         assert rel(g_["Cact"].float(), ref) < 4e-3
 
 
+@pytest.mark.parametrize("M", [1, 2, 16])
+@pytest.mark.parametrize("K,N_", [(8192, 1024), (16384, 2048), (2048, 16384), (4096, 100)])
+def test_gemm_few_rows_long_contraction_and_gelu(M, K, N_):
+    """The few-row kernels at the SHIPPED widths (fc2 / fc1 of a KV-cache step at embed_dim 1024 / 2048: contractions of 8192 / 16384 over eight waves in
+    rounds) and with the GELU epilogue (act 1: the pre-activation kept in Z) the cross-attention projection of a step uses."""
+    from sea_amd import ops
+
+    dt = torch.bfloat16
+    A = rnd(M, K, dtype=dt, seed=1600)
+    W = rnd(N_, K, dtype=dt, scale=K ** -0.5, seed=1601)
+    b = rnd(N_, seed=1602)
+    x = rnd(M, N_, seed=1603)
+    x0 = x.clone()
+    act = torch.full((M, N_), float("nan"), device=dev(), dtype=dt)
+    ops.gemm_grouped([dict(A=A, W=W, bias=b, R=x, C32=x, Cact=act)], dt)
+    ref = x0 + A.float() @ W.float().t() + b
+    assert rel(x, ref) < 3e-5 and rel(act.float(), ref) < 4e-3
+    # GELU epilogue, two groups of different contraction lengths in one launch (both whole rounds when one is long)
+    z = torch.full((M, N_), float("nan"), device=dev(), dtype=dt)
+    g = torch.full((M, N_), float("nan"), device=dev(), dtype=dt)
+    K2 = 2048
+    A2, W2 = rnd(M, K2, dtype=dt, seed=1604), rnd(64, K2, dtype=dt, scale=K2 ** -0.5, seed=1605)
+    g2 = torch.empty(M, 64, device=dev())
+    ops.gemm_grouped([dict(A=A, W=W, bias=b, Cact=g, Z=z, act=1), dict(A=A2, W=W2, C32=g2, act=1)], dt)
+    pre = A.float() @ W.float().t() + b
+    assert rel(z.float(), pre) < 4e-3
+    assert rel(g.float(), torch.nn.functional.gelu(pre)) < 6e-3
+    assert rel(g2, torch.nn.functional.gelu(A2.float() @ W2.float().t())) < 3e-5
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,d", [(1, 8192), (2, 16384), (5, 4096), (3, 2052)])
+def test_rownorm_few_long_rows(dtype, M, d):
+    """A few long rows (the MLP's LayerNorm + GELU of a KV-cache step at the shipped widths): a workgroup per row.  LayerNorm + GELU of act rows, and the
+    modulated form on fp32 rows with both outputs and the statistics."""
+    from sea_amd import ops
+
+    x = rnd(M, d, dtype=dtype, seed=1700)
+    lnw, lnb = 1 + 0.1 * rnd(d, seed=1701), 0.1 * rnd(d, seed=1702)
+    y = torch.full((M, d), float("nan"), device=dev(), dtype=dtype)
+    ops.rownorm([dict(X=x, gamma=lnw, beta=lnb, Yact=y)], M, d, True, True, 1e-5, dtype)
+    xf = x.float()
+    mu, var = xf.mean(1, keepdim=True), xf.var(1, unbiased=False, keepdim=True)
+    ref = torch.nn.functional.gelu((xf - mu) / torch.sqrt(var + 1e-5) * lnw + lnb)
+    assert rel(y.float(), ref) < tol(dtype, f32=1e-5, bf16=6e-3)
+    x32 = rnd(M, d, seed=1703)
+    mod = (0.3 * rnd(M, 2 * d, seed=1704)).to(dtype)
+    y32, ya = torch.empty(M, d, device=dev()), torch.empty(M, d, device=dev(), dtype=dtype)
+    mean, rstd = torch.empty(M, device=dev()), torch.empty(M, device=dev())
+    ops.rownorm([dict(X=x32, mod=mod, gamma=lnw, beta=lnb, Y32=y32, Yact=ya, mean=mean, rstd=rstd)], M, d, False, False, 1e-5, dtype)
+    mu, var = x32.mean(1, keepdim=True), x32.var(1, unbiased=False, keepdim=True)
+    ref = (x32 - mu) / torch.sqrt(var + 1e-5) * (lnw + 1 + mod[:, :d].float()) + lnb + mod[:, d:].float()
+    assert rel(y32, ref) < 1e-5 and rel(ya.float(), ref) < tol(dtype, f32=1e-5, bf16=6e-3)
+    assert rel(mean, mu[:, 0]) < 1e-4 and rel(rstd, 1 / torch.sqrt(var[:, 0] + 1e-5)) < 1e-5
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_gemm_strided_a(dtype):
     from sea_amd import ops
@@ -252,11 +308,12 @@ def test_attention_decode_and_multiproblem(dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("hd", [8, 16, 32, 64])
+@pytest.mark.parametrize("hd", [8, 16, 32, 64, 128, 256])
 @pytest.mark.parametrize("q_pos0,src_len,Tk", [(0, 0, 1), (6, 0, 7), (510, 0, 511), (511, 0, 512), (2023, 0, 2024), (100, 3, 104), (100, 3, 90), (5000, 0, 5001)])
 def test_attention_single_query_row_kernel(dtype, hd, q_pos0, src_len, Tk):
-    """The KV-cache step (Tq = 1, no LSE): the one-row kernel (a workgroup per (trajectory, head), fp32 probabilities) against the formula; cache
-    padding and everything past the visible keys poisoned with NaN; keys limited by the causal rule or by Tk, whichever is smaller."""
+    """The KV-cache step (Tq = 1, no LSE): the one-row kernels (a workgroup per (trajectory, head), fp32 probabilities; head dims 128 / 256 — the shipped
+    widths — with several lanes per key) against the formula; cache padding and everything past the visible keys poisoned with NaN; keys limited by the
+    causal rule or by Tk, whichever is smaller."""
     from sea_amd import ops
 
     B, H = 2, 4
