@@ -405,6 +405,33 @@ def test_rollout_kv_bf16_error_is_reported_and_bounded():
     assert e8 < 3e-2 and e100 < 1e-1
 
 
+def test_cfg5_shipped_multiphase_dims_rollout100():
+    """BASELINE.json configs[4] at its own size: the shipped multiphase_flow dims (embed_dim 2048, 2 field groups, 'ln', head dims 256 / 128, MLP hidden 16384),
+    a 100-step autoregressive rollout.  fp32 KV-cache rollout (few-row kernels at every width of a step: contractions up to 16384, rows of 16384, one-row
+    attention at head dims 256 / 128) against the CPU oracle's restatement of the reference's recompute loop at north_star's 1e-4, and against the device's own
+    recompute rollout; bf16 within the stated 100-step tolerance (1e-1; the measured value is printed)."""
+    from sea_amd.utils.train_utils import rollout
+
+    cfg = O.OracleConfig(1, 2048, 8, 104, 8, 0, 2, 2, True, "ln")
+    p = recipe_params(cfg)
+    x, _, ib = recipe_inputs(1, 100, cfg, seed=21)
+    with torch.no_grad():
+        ref = O.rollout(x[:, :1], ib, 100, p, cfg).numpy()
+    x0, ibg = x[:, :1].cuda().contiguous(), ib.cuda().contiguous()
+    m32 = build(cfg, "fp32")
+    kv = rollout(m32, x0, ibg, 100, mode="kv").cpu().numpy()
+    rc = rollout(m32, x0, ibg, 100, mode="recompute").cpu().numpy()
+    e_kv, e_rc = rel_l2(kv, ref), rel_l2(rc, ref)
+    print(f"multiphase dims, 100 steps, fp32 vs oracle: KV {e_kv:.3e}, recompute {e_rc:.3e}")
+    assert e_kv < FP32_TOL and e_rc < FP32_TOL
+    del m32
+    mb = build(cfg, "bf16")
+    kb = rollout(mb, x0, ibg, 100, mode="kv").cpu().numpy()
+    e8, e100 = rel_l2(kb[:, :8], ref[:, :8]), rel_l2(kb, ref)
+    print(f"multiphase dims, bf16 KV rollout rel-L2: 8 steps {e8:.3e}, 100 steps {e100:.3e}")
+    assert e8 < 3e-2 and e100 < 1e-1
+
+
 def test_graph_replay_equals_plain_replay():
     cfg = O.OracleConfig(1, 64, 4, 96, 8, 0, 3, 2, True, "adaln")
     m = build(cfg, "bf16")
