@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define SEA_ABI_VERSION 3
+#define SEA_ABI_VERSION 4
 
 enum { SEA_F32 = 0, SEA_BF16 = 1 };
 
@@ -41,7 +41,7 @@ enum {
 int sea_abi_version(void);
 const char* sea_last_error(void);
 /* sizeof of every ABI struct in declaration order (SeaGemmGroup, SeaQkvGroup, SeaQkvCommon, SeaAttnProblem,
- * SeaAttnParams, SeaNormGroup, SeaSiluGroup, SeaIbParams, ..., SeaLaunchRec, SeaGemmNormGroup, SeaExchangeTail, SeaMlpGroup, SeaMlp2Group, SeaKvNorm, SeaKvField, SeaKvPair, SeaKvLayer, SeaKvGlobal last): lets a binding verify its layout.  Host only. */
+ * SeaAttnParams, SeaNormGroup, SeaSiluGroup, SeaIbParams, ..., SeaLaunchRec, SeaGemmNormGroup, SeaExchangeTail, SeaMlpGroup, SeaMlp2Group, SeaKvNorm, SeaKvField, SeaKvPair, SeaKvLayer, SeaKvGlobal, SeaStepPatch last): lets a binding verify its layout.  Host only. */
 int sea_struct_sizes(int* out, int cap);
 /* Number of compute units / name of device 0's architecture as HIP reports them (diagnostics for bench.py). */
 int sea_device_info(int* cu_count, char* arch, int arch_len);
@@ -545,6 +545,18 @@ typedef struct {
     int64_t l0, l1, l2, l3;
 } SeaLaunchRec;
 int sea_run_list(const SeaLaunchRec* recs, int n_recs, void* stream);
+
+/* The same list replayed for n_steps consecutive steps of a KV-cache rollout (the loop of utils/train_utils.py:202-209) without returning to the caller's
+ * language between steps: before step s (s = step0 .. step0 + n_steps - 1) every patch writes  base + s * stride  into the HOST argument struct it points
+ * into — the position of a SeaQkvCommon / SeaAttnParams (kind 0: int32), the row pointers of the step's input / condition / output (kind 1: 64-bit) —, then
+ * the list is launched (kernel arguments are copied at launch, so the structs may change under launches still in flight). */
+typedef struct {
+    void* addr;          /* host address of the field (inside a struct a SeaLaunchRec points to, or inside a SeaLaunchRec of `recs`) */
+    int32_t kind;        /* 0: int32 field, 1: 64-bit field (a device pointer) */
+    int32_t pad_;
+    int64_t base, stride;
+} SeaStepPatch;
+int sea_run_list_steps(const SeaLaunchRec* recs, int n_recs, const SeaStepPatch* patches, int n_patches, int step0, int n_steps, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Un-patchify + inverse MinMax scaling of decoded fields: the scatter of DataPartitioner2D.inverse_partition

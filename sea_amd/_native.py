@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libsea_hip.so")
 
 SEA_F32, SEA_BF16 = 0, 1
-ABI_VERSION = 3   # include/sea_hip.h SEA_ABI_VERSION
+ABI_VERSION = 4   # include/sea_hip.h SEA_ABI_VERSION
 MAX_GROUPS = 16
 MAX_ATTN_PROBLEMS = 8
 MAX_NORM_GROUPS = 16
@@ -155,6 +155,10 @@ class SeaMlp2Group(C.Structure):
                 ("M", _i32), ("E", _i32), ("S", _i32)]
 
 
+class SeaStepPatch(C.Structure):
+    _fields_ = [("addr", _vp), ("kind", _i32), ("pad_", _i32), ("base", C.c_int64), ("stride", C.c_int64)]
+
+
 KV_MAX_FIELDS = 4
 
 
@@ -246,6 +250,8 @@ def lib() -> C.CDLL:
     L.sea_mlp_fc2_proj_norm.restype = C.c_int
     L.sea_run_list.argtypes = [C.POINTER(SeaLaunchRec), C.c_int, _vp]
     L.sea_run_list.restype = C.c_int
+    L.sea_run_list_steps.argtypes = [C.POINTER(SeaLaunchRec), C.c_int, C.POINTER(SeaStepPatch), C.c_int, C.c_int, C.c_int, _vp]
+    L.sea_run_list_steps.restype = C.c_int
     L.sea_kv_rollout.argtypes = [C.POINTER(SeaKvGlobal), C.POINTER(SeaKvLayer), C.c_int, C.c_int, C.c_uint32, C.c_int, _vp]
     L.sea_kv_rollout.restype = C.c_int
     L.sea_kv_arena_words.argtypes = [C.POINTER(SeaKvGlobal)]
@@ -270,14 +276,14 @@ def lib() -> C.CDLL:
 
 ABI_STRUCTS = (SeaGemmGroup, SeaQkvGroup, SeaQkvCommon, SeaAttnProblem, SeaAttnParams, SeaNormGroup, SeaSiluGroup,
                SeaIbParams, SeaWgradGroup, SeaNormBwdGroup, SeaSiluBwdGroup, SeaIbBwdParams, SeaAttnBwdProblem, SeaAttnBwdParams,
-               SeaDropout, SeaLaunchRec, SeaGemmNormGroup, SeaExchangeTail, SeaMlpGroup, SeaMlp2Group, SeaKvNorm, SeaKvField, SeaKvPair, SeaKvLayer, SeaKvGlobal)
+               SeaDropout, SeaLaunchRec, SeaGemmNormGroup, SeaExchangeTail, SeaMlpGroup, SeaMlp2Group, SeaKvNorm, SeaKvField, SeaKvPair, SeaKvLayer, SeaKvGlobal, SeaStepPatch)
 
 EXPORTED_SYMBOLS = (
     "sea_abi_version", "sea_last_error", "sea_struct_sizes", "sea_device_info", "sea_gemm_grouped", "sea_qkv_rope_grouped",
     "sea_attention_fwd", "sea_rownorm", "sea_silu_outer", "sea_ib_add", "sea_convert_f32_to_act", "sea_selftest_mfma",
     "sea_mse_fwd_bwd", "sea_relative_mse", "sea_adamw_flat",
     "sea_wgrad_grouped", "sea_transpose_weights", "sea_rownorm_bwd", "sea_silu_outer_bwd", "sea_ib_bwd",
-    "sea_attention_bwd", "sea_dropout_mask", "sea_run_list", "sea_unpatchify", "sea_gemm_rownorm", "sea_exchange_tail", "sea_patchify", "sea_silu_outer_ib", "sea_mlp_fc1_ln_gelu", "sea_mlp_fc2_proj_norm", "sea_kv_rollout", "sea_kv_arena_words", "sea_kv_debug_stamps",
+    "sea_attention_bwd", "sea_dropout_mask", "sea_run_list", "sea_run_list_steps", "sea_unpatchify", "sea_gemm_rownorm", "sea_exchange_tail", "sea_patchify", "sea_silu_outer_ib", "sea_mlp_fc1_ln_gelu", "sea_mlp_fc2_proj_norm", "sea_kv_rollout", "sea_kv_arena_words", "sea_kv_debug_stamps",
 )
 
 

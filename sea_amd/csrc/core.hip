@@ -20,7 +20,7 @@ extern "C" int sea_struct_sizes(int* out, int cap) {
                          (int)sizeof(SeaWgradGroup), (int)sizeof(SeaNormBwdGroup), (int)sizeof(SeaSiluBwdGroup), (int)sizeof(SeaIbBwdParams),
                          (int)sizeof(SeaAttnBwdProblem), (int)sizeof(SeaAttnBwdParams), (int)sizeof(SeaDropout), (int)sizeof(SeaLaunchRec),
                          (int)sizeof(SeaGemmNormGroup), (int)sizeof(SeaExchangeTail), (int)sizeof(SeaMlpGroup), (int)sizeof(SeaMlp2Group), (int)sizeof(SeaKvNorm), (int)sizeof(SeaKvField),
-                         (int)sizeof(SeaKvPair), (int)sizeof(SeaKvLayer), (int)sizeof(SeaKvGlobal)};
+                         (int)sizeof(SeaKvPair), (int)sizeof(SeaKvLayer), (int)sizeof(SeaKvGlobal), (int)sizeof(SeaStepPatch)};
     const int n = (int)(sizeof(sizes) / sizeof(sizes[0]));
     for (int i = 0; i < n && i < cap; ++i) out[i] = sizes[i];
     return n;
@@ -47,6 +47,23 @@ extern "C" int sea_run_list(const SeaLaunchRec* recs, int n_recs, void* stream) 
             default: sea_set_error("sea_run_list[%d]: unknown op %d", i, R.op); return SEA_EINVAL;
         }
         if (rc != SEA_OK) return rc;   // sea_last_error() already names the entry point; the caller maps i back to its record
+    }
+    return SEA_OK;
+}
+
+extern "C" int sea_run_list_steps(const SeaLaunchRec* recs, int n_recs, const SeaStepPatch* patches, int n_patches, int step0, int n_steps, void* stream) {
+    SEA_REQUIRE(recs != nullptr && n_recs >= 0 && n_patches >= 0 && (n_patches == 0 || patches != nullptr) && step0 >= 0 && n_steps >= 0, "sea_run_list_steps: bad arguments");
+    for (int i = 0; i < n_patches; ++i)
+        SEA_REQUIRE(patches[i].addr != nullptr && (patches[i].kind == 0 || patches[i].kind == 1), "sea_run_list_steps: patch %d: null address or bad kind %d", i, patches[i].kind);
+    for (int s = step0; s < step0 + n_steps; ++s) {
+        for (int i = 0; i < n_patches; ++i) {
+            const SeaStepPatch& P = patches[i];
+            const int64_t v = P.base + (int64_t)s * P.stride;
+            if (P.kind == 0) *static_cast<int32_t*>(P.addr) = (int32_t)v;
+            else *static_cast<int64_t*>(P.addr) = v;
+        }
+        const int rc = sea_run_list(recs, n_recs, stream);
+        if (rc != SEA_OK) return rc;
     }
     return SEA_OK;
 }

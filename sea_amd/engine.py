@@ -825,6 +825,53 @@ class Plan:
             else:
                 s.q_pos0, s.Tk = pos0, pos0 + self.T
 
+    def step_patch_table(self, x_base: int, x_stride: int, c_base: int, c_stride: int, out_base: int, out_stride: int):
+        """The per-step edits of a KV-cache rollout (set_position + bind_ptrs) as a SeaStepPatch array for sea_run_list_steps: step s reads its rows at
+        x_base + s * x_stride, its condition values at c_base + s * c_stride, writes its rows at out_base + s * out_stride and sits at position s of the
+        caches.  None when the plan has no native launch list."""
+        if self._clist is None:
+            return None
+        arr, _, relink = self._clist
+        rows = []   # (address, kind, base, stride)
+
+        def field_addr(tgt, field):
+            if isinstance(tgt, list):   # a pointer argument kept in a record's Python args list: its native copy is a field of the SeaLaunchRec
+                for i, rf, args, k in relink:
+                    if args is tgt and k == field:
+                        return C.addressof(arr[i]) + getattr(N.SeaLaunchRec, rf).offset
+                raise KeyError("patched argument without a native copy")
+            return C.addressof(tgt) + getattr(type(tgt), field).offset
+
+        for st in self._pos_structs:
+            if isinstance(st, N.SeaQkvCommon):
+                rows.append((field_addr(st, "pos0"), 0, 0, 1))
+            else:
+                rows.append((field_addr(st, "q_pos0"), 0, 0, 1))
+                rows.append((field_addr(st, "Tk"), 0, self.T, 1))
+        for tgt, field, off in self._x_patches:
+            rows.append((field_addr(tgt, field), 1, x_base + off, x_stride))
+        for tgt, field, off in self._out_patches:
+            rows.append((field_addr(tgt, field), 1, out_base + off, out_stride))
+        for tgt, field in self._c_patches:
+            rows.append((field_addr(tgt, field), 1, c_base, c_stride))
+        tab = (N.SeaStepPatch * max(len(rows), 1))()
+        for t, (a_, k_, b_, s_) in zip(tab, rows):
+            t.addr, t.kind, t.base, t.stride = a_, k_, b_, s_
+        return tab, len(rows)
+
+    def run_steps(self, n_steps: int, x_base: int, x_stride: int, c_base: int, c_stride: int, out_base: int, out_stride: int) -> bool:
+        """n_steps consecutive KV-cache steps from position 0 in ONE native call (sea_run_list_steps); False when the plan has no native list."""
+        pt = self.step_patch_table(x_base, x_stride, c_base, c_stride, out_base, out_stride)
+        if pt is None:
+            return False
+        assert n_steps <= self.cap
+        rc = N.lib().sea_run_list_steps(self._clist[0], self._clist[1], pt[0], pt[1], 0, n_steps, N.stream_ptr())
+        self._bound = (None, None, None)   # the structs now hold the last step's pointers / position
+        self.pos0 = n_steps - 1 if n_steps > 0 else self.pos0
+        if rc != 0:
+            N.check(rc, "KV-cache rollout (sea_run_list_steps)")
+        return True
+
     def _compile_list(self) -> None:
         """Lower self.records to one SeaLaunchRec array (include/sea_hip.h): a sequential replay is then ONE native call instead of a
         Python/ctypes round trip per launch.  Pointers into the argument structs are stable (the structs are patched in place)."""
@@ -1201,8 +1248,10 @@ class TemporalEngine:
         p = self.plan(B, 1, "step")
         slab = B * F * E * 4
         base, cbase = traj.data_ptr(), cond.data_ptr()
-        for s in range(n_steps):
-            p.set_position(s)
-            p.bind_ptrs(base + s * slab, cbase + s * B * 4, base + (s + 1) * slab)
-            p.run()
+        # the step loop in native code (the plan's launch list + a table of the per-step edits); SEA_KV_NATIVE_LOOP=0: one Python round trip per step
+        if os.environ.get("SEA_KV_NATIVE_LOOP", "1") == "0" or not p.run_steps(n_steps, base, slab, cbase, B * 4, base + slab, slab):
+            for s in range(n_steps):
+                p.set_position(s)
+                p.bind_ptrs(base + s * slab, cbase + s * B * 4, base + (s + 1) * slab)
+                p.run()
         return traj[1:].permute(1, 0, 2, 3).contiguous()

@@ -39,7 +39,9 @@ def main():
         import bench
         eng = m.engine()
         p = eng.plan(1, 1, "step")
+        xs, cs, ys = torch.randn(1, 2, E, device=dev), torch.rand(1, device=dev), torch.empty(1, 2, E, device=dev)
         p.set_position(50)
+        p.bind_ptrs(xs.data_ptr(), cs.data_ptr(), ys.data_ptr())
         times = bench._time_list(list(p.records), iters=5)
         tot = sum(t for _, t in times)
         nbytes = sum(prm.numel() for prm in m.parameters()) * 2
