@@ -56,6 +56,28 @@ def dead_prefixes(model) -> List[str]:
     return out
 
 
+def grad_phase(model, name: str) -> int:
+    """When a parameter's gradient is FINAL in the hand-written backward, as an ordinal (lower = earlier): per layer, last layer first —
+    0: the field MLP + proj; 1: everything between them and the self-attention (exchange, ln_cross, the norm in front of the MLP, the info-bottleneck step
+    behind the exchange; with the last layer: the model's final norms); 2: self-attention, the norm in front of it, an info-bottleneck step in front of
+    the block.  The flat buffers are laid out in this order, so that what a data-parallel step can reduce early is ONE contiguous slice per phase
+    (train_engine.TrainPlan.grad_buckets)."""
+    L = model.num_layers
+    m = re.match(r"^blocks\.(\d+)\.(.*)$", name)
+    if not m:
+        return 1   # ln.{i}.*: with the last layer's middle phase
+    l, rest = int(m.group(1)), m.group(2)
+    if rest.startswith("mlp.") or rest.startswith("proj."):
+        sub = 0
+    elif rest.startswith("attn.self.") or re.match(r"^ln\.exp\.\d+\.0\.", rest):
+        sub = 2
+    elif (rest.startswith("ib.") or rest.startswith("cross_attn_ib.")) and not model.add_info_after_cross:
+        sub = 2
+    else:
+        sub = 1
+    return (L - 1 - l) * 3 + sub
+
+
 class FlatParams:
     """One contiguous fp32 buffer holding every parameter of the model (+ the activation-dtype shadow)."""
 
@@ -72,7 +94,7 @@ class FlatParams:
                 keyed.append(((idx, 0), name, p))
         dead = dead_prefixes(model)
         is_dead = lambda n: any(n.startswith(d) for d in dead)  # noqa: E731
-        keyed.sort(key=lambda t: (is_dead(t[1]), t[0]))
+        keyed.sort(key=lambda t: (is_dead(t[1]), grad_phase(model, t[1]), t[0]))
         self.offsets: Dict[str, Tuple[int, Tuple[int, ...]]] = {}
         off = 0
         self.n_live = 0
@@ -93,6 +115,7 @@ class FlatParams:
                 view.copy_(p.detach().to(device=device, dtype=torch.float32))
                 p.data = view  # the module's parameter now aliases the flat buffer
         self.live_names = [n for _, n, _ in keyed if not is_dead(n)]
+        self.phase_of = {n: grad_phase(model, n) for _, n, _ in keyed if not is_dead(n)}
         self.flat_act = self.flat32 if act_dtype == torch.float32 else torch.empty(self.n_total, device=device, dtype=act_dtype)
         self.flat_actT: Optional[torch.Tensor] = None   # transposed weight shadow, built on first training use
         self._t_desc = self._t_tiles = None

@@ -463,6 +463,24 @@ class TrainPlan(Plan):
         self._cur = self.bwd
         adaln = self.adaln
         dmods: List[Tuple[str, torch.Tensor]] = []  # (prefix, dmod buffer) per USE of an AdaLN
+        self._phase_marks: List[Tuple[int, int]] = []   # (number of backward records, gradient phase final after them): engine.grad_phase
+        # data-parallel runs: the condition MLPs' backward is emitted per phase (the modules whose modulation gradients are complete), so that the slice of
+        # a phase can be all-reduced while the later phases run; a single process keeps the one grouped launch set at the end
+        import torch.distributed as _dist
+        dp = _dist.is_available() and _dist.is_initialized() and _dist.get_world_size() > 1 and os.environ.get("SEA_DP_OVERLAP", "1") != "0"
+        split_cond = adaln and dp
+
+        def cond_backward(tag=""):
+            """cond_mlp backward of every AdaLN use collected in `dmods` so far (shared parameters accumulate through the weight-gradient kernel)."""
+            if not dmods:
+                return
+            dh = [buf(M, dm.shape[1]) for _, dm in dmods]
+            self._wgrad([dict(dY=dm, X=hid[pre_], dW=G2(pre_ + "cond_mlp.2.weight"), db=Gv(pre_ + "cond_mlp.2.bias")) for pre_, dm in dmods], "bwd.adaln.cond.wgrad" + tag)
+            self._gemm([dict(A=dm, W=P.actT(pre_ + "cond_mlp.2.weight"), Cact=dh[k]) for k, (pre_, dm) in enumerate(dmods)], "bwd.adaln.cond.dgrad" + tag)
+            self._silu_bwd([dict(dHid=dh[k], w1=P.f32_vec(pre_ + "cond_mlp.0.weight", dm.shape[1]), b1=P.f32_vec(pre_ + "cond_mlp.0.bias"),
+                                 dw1=Gv(pre_ + "cond_mlp.0.weight", dm.shape[1]), db1=Gv(pre_ + "cond_mlp.0.bias")) for k, (pre_, dm) in enumerate(dmods)],
+                           "bwd.adaln.silu" + tag)
+            dmods.clear()
 
         def bpar(pre, d):
             """norm-backward parameter/gradient pointers (+ a fresh dmod buffer for this use)"""
@@ -506,6 +524,7 @@ class TrainPlan(Plan):
             # ---- fc1
             self._wgrad([dict(dY=dS_[i], X=sv["n2"][i], dW=G2(f"{pre}mlp.{i}.layers.0.weight"), db=Gv(f"{pre}mlp.{i}.layers.0.bias")) for i in range(F)],
                         "bwd.fc1.wgrad")
+            self._phase_marks.append((len(self.bwd), (NL - 1 - l) * 3))            # the field MLPs + proj of this layer are final
             self._gemm([dict(A=dS_[i], W=P.actT(f"{pre}mlp.{i}.layers.0.weight"), Cact=dE_[i]) for i in range(F)], "bwd.fc1.dgrad")
             # ---- AdaLN_2: accumulates the norm branch onto the residual gradient
             self._norm_bwd([dict(dY=dE_[i], X=sv["xr"][i], mean=sv["st2"][i][0], rstd=sv["st2"][i][1], dX32=dx[i], dXact=ga[i],
@@ -634,6 +653,10 @@ class TrainPlan(Plan):
                 self._wgrad([dict(dY=ddo[j], X=sv["xa1"][j], dW=G2(f"{pre}cross_down.{j}.weight"), db=Gv(f"{pre}cross_down.{j}.bias")) for j in range(F)],
                             "bwd.cross.down_old.wgrad")
                 self._gemm([dict(A=ddo[j], W=P.actT(f"{pre}cross_down.{j}.weight"), R=dx[j], C32=dx[j], Cact=ga[j]) for j in range(F)], "bwd.cross.down_old.dgrad")
+            if split_cond:
+                cond_backward(f".l{l}a")   # the modules used so far: (final norms,) the norm in front of the MLP, ln_cross
+            if dp:
+                self._phase_marks.append((len(self.bwd), (NL - 1 - l) * 3 + 1))    # exchange, ln_cross, norm 2, info-bottleneck step behind the exchange(, final norms)
             # ---- self attention: x1 = x0 + att Wo^T            (ga = d x1)
             self._wgrad([dict(dY=ga[i], X=sv["att"][i], dW=G2(f"{pre}attn.self.{i}.projection.weight")) for i in range(F)], "bwd.self.out_proj.wgrad")
             self._gemm([dict(A=ga[i], W=P.actT(f"{pre}attn.self.{i}.projection.weight"), Cact=dE_[i]) for i in range(F)], "bwd.self.out_proj.dgrad")
@@ -655,14 +678,14 @@ class TrainPlan(Plan):
                 self._ib_attn_bwd(pre, sv, dx, ga)
             if concat:   # the info-bottleneck columns of the widened rows; columns 0 .. Eo-1 of dx / ga are the gradient of the previous block's output
                 self._ib_bwd(pre, [t[:, Eo:] for t in dx], drop=sv["ib_drop"])
-        # ---- AdaLN condition MLPs: every USE contributes dmod; parameters are shared through the atomically accumulated gradients
+            if split_cond:
+                cond_backward(f".l{l}b")   # the norm in front of the self-attention
+            if dp and l > 0:
+                self._phase_marks.append((len(self.bwd), (NL - 1 - l) * 3 + 2))
+        # ---- AdaLN condition MLPs: every USE contributes dmod; parameters are shared through the atomically accumulated gradients (data-parallel runs
+        # have emitted them per phase above: nothing is left here)
         if adaln:
-            dh = [buf(M, dm.shape[1]) for _, dm in dmods]
-            self._wgrad([dict(dY=dm, X=hid[pre], dW=G2(pre + "cond_mlp.2.weight"), db=Gv(pre + "cond_mlp.2.bias")) for pre, dm in dmods], "bwd.adaln.cond.wgrad")
-            self._gemm([dict(A=dm, W=P.actT(pre + "cond_mlp.2.weight"), Cact=dh[k]) for k, (pre, dm) in enumerate(dmods)], "bwd.adaln.cond.dgrad")
-            self._silu_bwd([dict(dHid=dh[k], w1=P.f32_vec(pre + "cond_mlp.0.weight", dm.shape[1]), b1=P.f32_vec(pre + "cond_mlp.0.bias"),
-                                 dw1=Gv(pre + "cond_mlp.0.weight", dm.shape[1]), db1=Gv(pre + "cond_mlp.0.bias")) for k, (pre, dm) in enumerate(dmods)],
-                           "bwd.adaln.silu")
+            cond_backward()
         self._cur = self.records
         self.saved = Sv
 
@@ -672,25 +695,25 @@ class TrainPlan(Plan):
             setattr(tgt, field, dout_ptr + off)
 
     def grad_buckets(self):
-        """[(number of backward records after which the slice is final, flat start, flat end)] in backward order: the field MLPs + proj of a layer
-        (fc1 / LayerNorm / fc2 / proj: 45 % of the parameters at cfg3) are contiguous in the flat gradient buffer and complete right after that
-        layer's `bwd.fc1.wgrad`, long before the exchange / attention / condition-MLP gradients: a data-parallel step can start reducing them while the
-        rest of the backward runs (sea_amd/parallel.py)."""
+        """[(number of backward records after which the slice is final, flat start, flat end)] in backward order.  The flat buffers are laid out by gradient
+        phase (engine.grad_phase): the field MLPs + proj of a layer (45 % of the parameters at cfg3) are one contiguous slice, complete right after that
+        layer's `bwd.fc1.wgrad`; in a data-parallel run the exchange / norm-2 / ln_cross / final-norm slice (with its condition MLPs, whose backward is then
+        emitted per phase) is complete before the self-attention backward starts.  A data-parallel step reduces each slice while the rest of the backward
+        runs (sea_amd/parallel.py); what the last phase holds goes after the backward."""
         if self._buckets is None:
             P = self.eng.params
+            size = lambda n: int(torch.Size(P.offsets[n][1]).numel())
+            last_phase = max(P.phase_of.values()) if P.phase_of else 0
             out = []
-            idxs = [k for k, r in enumerate(self.bwd) if r.name == "bwd.fc1.wgrad"]
-            for k, idx in enumerate(idxs):
-                l = self.L - 1 - k
-                names = [n for n in P.offsets if n.startswith(f"blocks.{l}.mlp.") or n.startswith(f"blocks.{l}.proj.")]
-                if not names:
+            for idx, ph in self._phase_marks:
+                names = [n for n, q in P.phase_of.items() if q == ph]
+                if not names or ph == last_phase:
                     continue
-                size = lambda n: int(torch.Size(P.offsets[n][1]).numel())
                 lo = min(P.offsets[n][0] for n in names)
                 hi = max(P.offsets[n][0] + size(n) for n in names)
                 inside = {n for n, (o, _) in P.offsets.items() if lo <= o < hi}
-                if inside == set(names) and hi <= P.n_live:   # contiguous and live: otherwise this layer goes with the rest
-                    out.append((idx + 1, lo, hi))
+                assert inside == set(names) and hi <= P.n_live, ("gradient phase is not one contiguous live slice", ph)
+                out.append((idx, lo, hi))
             self._buckets = out
         return self._buckets
 

@@ -2,7 +2,8 @@
 the global batch — gradients after the all-reduce equal the global-batch gradients (<= 1e-6, fp32), parameters stay bit-identical across ranks.
 The ranks of this test share the box's one GPU and reduce through gloo (two RCCL ranks cannot share a device); on a multi-GPU node the same body
 runs one rank per GPU over RCCL when SEA_TEST_DP_BACKEND=nccl.  The step reduces the gradient buffer in slices (sea_amd/parallel.py:
-OverlappedGradientReduce): the equality with the single-process gradients covers every slice boundary."""
+OverlappedGradientReduce; the flat layout is ordered by the phase of the backward that completes a gradient, engine.grad_phase): the equality with the
+single-process gradients covers every slice boundary."""
 import os
 import socket
 
@@ -54,8 +55,13 @@ def _run_steps(x, tgt, ib, world, rank):
         if step == 0:
             grads1 = (eng.grads[:eng.params.n_live] * opt.grad_scale).cpu()   # the mean gradient AdamW consumed
         assert parameters_in_sync(eng.params.flat32)
-        if world > 1:   # the MLP + proj slice went early (under the rest of the backward), the two remainders after it: three collectives, every element once
+        if world > 1:
+            # three collectives, every element once: the MLP + proj slice and the exchange / norm / condition-MLP slice go early (each as soon as the backward
+            # has finished it, under the launches that follow), the self-attention slice after the backward — most of the buffer is on its way before then
             assert eng.last_allreduce_calls == 3, eng.last_allreduce_calls
+            bk = eng.train_plan(xs.shape[0], xs.shape[1]).grad_buckets()
+            assert len(bk) == 2 and bk[0][1] == 0 and bk[0][2] == bk[1][1] and bk[0][0] < bk[1][0]
+            assert bk[1][2] / eng.params.n_live > 0.7, bk
     return grads1, eng.params.flat32[:eng.params.n_live].cpu()
 
 
