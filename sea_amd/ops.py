@@ -7,7 +7,7 @@ operator tests; sea_amd/engine.py pre-builds the same structs once per plan for 
 from __future__ import annotations
 
 import ctypes as C
-from typing import Dict, List, Optional, Sequence
+from typing import Dict, Optional, Sequence
 
 import torch
 

@@ -15,7 +15,7 @@ from typing import Dict, List, Optional, Tuple
 import torch
 
 from . import _native as N
-from .engine import Plan, _Rec, _fill_gemm, blk_pe
+from .engine import Plan, _Rec, blk_pe
 
 
 class TrainPlan(Plan):

@@ -7,7 +7,7 @@ torch calls on the device (bucketize + sort), not per time step, and is plumbing
 round-trip tests with torch indexing."""
 from __future__ import annotations
 
-from typing import List, Optional, Sequence, Tuple
+from typing import Optional, Sequence, Tuple
 
 import torch
 
