@@ -317,8 +317,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const SeaAttnBwdParam
             for (int be = 0; be < C::NB; ++be) {
                 const int ql = qc * C::CK + g * C::EPC + be * 4;  // this lane's 4 consecutive queries of the tile
                 const f32x4 l4 = *reinterpret_cast<const f32x4*>(sL + ql);        // -lse * log2e (scaled when staged)
-                const f32x4 d4 = *reinterpret_cast<const f32x4*>(sL + 64 + ql);
-                f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = DROP ? f32x4{0.f, 0.f, 0.f, 0.f} : -d4;   // "- delta" in the C operand, as in the dQ kernel
+                const f32x4 nd4 = *reinterpret_cast<const f32x4*>(sL + 64 + ql);      // -delta (negated when staged: no negation per score block here)
+                f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = DROP ? f32x4{0.f, 0.f, 0.f, 0.f} : nd4;   // "- delta" in the C operand, as in the dQ kernel
 #pragma unroll
                 for (int c = 0; c < C::NCH; ++c) {
                     const uint4 aq = *reinterpret_cast<const uint4*>(sQ + frag_off[qc][be] + c * C::CK * (int)sizeof(T));   // rows zero-padded to CK
@@ -337,7 +337,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const SeaAttnBwdParam
                         const uint32_t w = drop_word(P.drop.seed, drop_stream, (uint32_t)(qt * 64 + ql + q), (uint32_t)(k_idx >> 2));
                         const float dfac = drop_factor(w, k_idx & 3, P.drop.thr, drop_sc);
                         pp[qc][be][q] = p * dfac;                    // dV = (D P)^T dO
-                        ds[qc][be][q] = p * (dp[q] * dfac - d4[q]);  // dS = P (D dP - delta)
+                        ds[qc][be][q] = p * (dp[q] * dfac + nd4[q]);  // dS = P (D dP - delta)
                     } else {
                         pp[qc][be][q] = p;
                         ds[qc][be][q] = p * dp[q];
@@ -372,7 +372,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const SeaAttnBwdParam
         float* sl = reinterpret_cast<float*>(smem + VEC_OFF) + buf * 128;
         if (tid < 64) {
             sl[tid] = r_lse;
-            sl[64 + tid] = r_del;
+            sl[64 + tid] = -r_del;
         }
     };
     zero_tile_padding<T, HD>(smem, 2 * C::NBUF, tid);
