@@ -1,0 +1,35 @@
+"""Does a padded row stride of the weights help the 32-row MLP kernels?  (W2's rows are 4 KiB apart: a K-tile of a stage is 256 pieces of 128 B at a 4 KiB stride.)
+Development aid: python tools/stride_probe.py"""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+from sea_amd import ops
+from tools.bench_ops import timeit
+
+dev = torch.device("cuda:0")
+bf = torch.bfloat16
+
+
+def main():
+    M, E, S, F = 2024, 256, 2048, 3
+    for pad2, pad1, padp in ((0, 0, 0), (64, 0, 0), (64, 64, 64), (8, 8, 8), (256, 0, 0)):
+        g2, g1 = [], []
+        for i in range(F):
+            Hg = torch.randn(M, S, device=dev).to(bf)
+            W2 = torch.randn(E, S + pad2, device=dev).to(bf)[:, :S]
+            Wp = torch.randn(E, E + padp, device=dev).to(bf)[:, :E]
+            g2.append(dict(Hg=Hg, W2=W2, b2=torch.zeros(E, device=dev), R=torch.randn(M, E, device=dev), Wproj=Wp, bproj=torch.zeros(E, device=dev),
+                           Y32=torch.empty(M, E, device=dev), gamma=torch.ones(E, device=dev)))
+            A = torch.randn(M, E, device=dev).to(bf)
+            W1 = torch.randn(S, E + pad1, device=dev).to(bf)[:, :E]
+            g1.append(dict(A=A, W1=W1, b1=torch.zeros(S, device=dev), lnw=torch.ones(S, device=dev), lnb=torch.zeros(S, device=dev), Hg=torch.empty(M, S, device=dev, dtype=bf)))
+        t2 = timeit(lambda: ops.mlp_fc2_proj_norm(g2))
+        t1 = timeit(lambda: ops.mlp_fc1_ln_gelu(g1))
+        print(f"row padding W2 +{pad2}, W1 +{pad1}, Wproj +{padp} elements: fc2_proj_norm {t2:6.1f} us   fc1_ln_gelu {t1:6.1f} us", flush=True)
+
+
+if __name__ == "__main__":
+    main()
