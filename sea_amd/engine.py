@@ -507,8 +507,11 @@ class Plan:
             Vc = [[[self._buf(B, H, hd_c, cap, zero=True) for _ in range(F)] for _ in range(F)] for _ in range(self.L)]
             att_c = [self._buf(M, D) for _ in range(max(F - 1, 1))]
             gp = self._buf(max(F - 1, 1), M, D)
-        hbuf = [self._buf(M, S) for _ in range(F)]
-        hg = [self._buf(M, S) for _ in range(F)]
+        # hidden rows of the MLP: S is a power of two (4 KiB rows at cfg2) — a 32-row workgroup's stores, and the next launch's 32-row operand tiles, would sit
+        # at one 4 KiB stride and crowd a few memory channels; 128 B of padding per row spreads them (fc1 + LN + GELU 27.0 -> 25.4 us stand-alone)
+        pad = 64 if (type(self) is Plan and S % 1024 == 0) else 0
+        hbuf = [self._buf(M, S + pad)[:, :S] for _ in range(F)]
+        hg = [self._buf(M, S + pad)[:, :S] for _ in range(F)]
         self.ws = dict(xr=xr, xa=xa, n_e=n_e, att_e=att_e, hbuf=hbuf, hg=hg)
 
         xm = [self._buf(M, E) for _ in range(F)] if lanes else xa

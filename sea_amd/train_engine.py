@@ -439,9 +439,10 @@ class TrainPlan(Plan):
             # ---- MLP + proj
             sv["st2"] = [stats() for _ in range(F)]
             sv["n2"] = [buf(M, E) for _ in range(F)]
-            sv["h"] = [buf(M, S) for _ in range(F)]
+            spad = 64 if S % 1024 == 0 else 0   # hidden rows at a power-of-two stride crowd a few memory channels (engine.Plan._build): 128 B of padding per row
+            sv["h"] = [buf(M, S + spad)[:, :S] for _ in range(F)]
             sv["sth"] = [stats() for _ in range(F)]
-            sv["hg"] = [buf(M, S) for _ in range(F)]
+            sv["hg"] = [buf(M, S + spad)[:, :S] for _ in range(F)]
             sv["xa4"] = [buf(M, E) for _ in range(F)]
             self._norm([dict(X=sv["xr"][i], Yact=sv["n2"][i], mean=sv["st2"][i][0], rstd=sv["st2"][i][1], **npar(f"{pre}ln.exp.{i}.2.")) for i in range(F)],
                        E, "mlp.adaln2")
@@ -494,7 +495,7 @@ class TrainPlan(Plan):
         dx = [buf(M, E, dtype=f32) for _ in range(F)]      # gradient of the fp32 residual stream
         ga = [buf(M, E) for _ in range(F)]                 # act copy of the residual gradient entering a GEMM
         gb = [buf(M, E) for _ in range(F)]
-        dS_ = [buf(M, S) for _ in range(F)]
+        dS_ = [buf(M, S + (64 if S % 1024 == 0 else 0))[:, :S] for _ in range(F)]
         dE_ = [buf(M, E) for _ in range(F)]
         dqkv = [buf(M, 3 * E) for _ in range(F)]
         delta_s = [buf(B, H, T, dtype=f32) for _ in range(F)]
