@@ -32,5 +32,22 @@ def main():
         print(f"row padding W2 +{pad2}, W1 +{pad1}, Wproj +{padp}, Hg +{padh} elements: fc2_proj_norm {t2:6.1f} us   fc1_ln_gelu {t1:6.1f} us", flush=True)
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and len(sys.argv) == 1:
     main()
+
+
+def cond_probe():
+    """The AdaLN condition GEMM (12 modules, A = silu rows [M, 512] / [M, 256]) with padded operand / output rows."""
+    M = 2024
+    for pa, pc in ((0, 0), (64, 0), (0, 64), (64, 64)):
+        gs = []
+        for n, k in [(512, 512)] * 9 + [(256, 256)] * 3:
+            A = torch.randn(M, k + pa, device=dev).to(bf)[:, :k]
+            W = torch.randn(n, k, device=dev).to(bf)
+            gs.append(dict(A=A, W=W, Cact=torch.empty(M, n + pc, device=dev, dtype=bf)[:, :n]))
+        us = timeit(lambda: ops.gemm_grouped(gs, bf))
+        print(f"cond GEMM: A rows +{pa}, output rows +{pc} elements: {us:6.1f} us", flush=True)
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "cond":
+    cond_probe()
