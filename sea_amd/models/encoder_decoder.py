@@ -108,6 +108,43 @@ class Decode(nn.Module):
         return out if Cp == self.n_inp else out[..., :self.n_inp]   # a strided view: sea_unpatchify reads it in place
 
 
+    def forward_prefix(self, z: torch.Tensor, buckets) -> torch.Tensor:
+        """The decoder for a consumer that only reads the first cells of a patch (MeshUnpatcher.decode_and_unpatch: a patch holds as many mesh points as its
+        cell has, the rest of its n_inp columns is padding nobody reads — 71 % of the columns on the bench's wake-refined mesh).  z [B, P, n_groups,
+        embed_dim] with the patches in the CALLER's order; buckets: [(p_lo, p_hi, n_cols)] covering 0 .. P — for the patches p_lo .. p_hi-1 only the first
+        n_cols columns of every field are computed.  Rows are patch-major inside (a bucket is one contiguous row range: one GEMM group per (bucket, field)
+        with the first n_cols rows of the field's second-layer weights).  Returns [B, P, n_fields, n_inp] as a strided view; columns >= n_cols of a
+        bucket's patches are UNDEFINED."""
+        N.require_gpu(z, "Decode input")
+        B, P, G, D = z.shape
+        assert G == self.num_groups and D == self.embed_dim, (z.shape, self.num_groups, self.embed_dim)
+        dt = torch.float32 if self.compute_dtype == "fp32" else torch.bfloat16
+        M = B * P
+        zf = z.detach().to(torch.float32).permute(1, 0, 2, 3).contiguous().view(M, G * D)      # patch-major rows
+        za = zf if dt == torch.float32 else torch.empty(M, G * D, device=z.device, dtype=dt)
+        if dt != torch.float32:
+            ops.convert(zf, za)
+        W1, W2 = self._weights(dt)
+        bias = self._shadow[3]
+        n_fields = sum(len(g) for g in self.field_groups)
+        Cp = self._n_inp_p
+        out = torch.empty(M, n_fields * Cp, device=z.device, dtype=torch.float32)
+        hid: List[torch.Tensor] = [torch.empty(M, self.MLP_hidden, device=z.device, dtype=dt) for _ in range(G)]
+        ops.gemm_grouped([dict(A=za[:, g * D:(g + 1) * D], W=W1[g], Cact=hid[g], act=1) for g in range(G)], dt)
+        groups = []
+        for p_lo, p_hi, n_cols in buckets:
+            nn = min(_round_up(max(int(n_cols), 1), 32), Cp)
+            r0, r1 = p_lo * B, p_hi * B
+            f = 0
+            for g, grp in enumerate(self.field_groups):
+                for j in range(len(grp)):
+                    groups.append(dict(A=hid[g][r0:r1], W=W2[g][j * Cp:j * Cp + nn], bias=bias[g][j * Cp:j * Cp + nn], C32=out[r0:r1, f * Cp:f * Cp + nn]))
+                    f += 1
+        for s0 in range(0, len(groups), N.MAX_GROUPS):
+            ops.gemm_grouped(groups[s0:s0 + N.MAX_GROUPS], dt)
+        return out.view(P, B, n_fields, Cp).permute(1, 0, 2, 3)[..., :self.n_inp]
+
+
 def _round_up(x: int, m: int) -> int:
     return (x + m - 1) // m * m
 

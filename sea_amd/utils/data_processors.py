@@ -133,6 +133,57 @@ class MeshUnpatcher:
                               point_slot=self.partitioner.point_slot if self.gather else None)
 
 
+    # ------------------------------------------------------------------ decoder + un-patchify without the padding
+    def _prefix_plan(self, max_buckets: int):
+        """Patches sorted by how many mesh points their cell holds, cut into <= max_buckets runs that minimise sum(run length x longest cell of the run) —
+        the columns the decoder has to produce; the index map and the point -> slot table in that patch order."""
+        key = max_buckets
+        plan = getattr(self, "_pplan", None)
+        if plan is None or plan[0] != key:
+            part = self.partitioner
+            idx = part.padded_index_map
+            P, C = idx.shape
+            counts = (idx != part.pad_id).sum(dim=1).cpu().tolist()       # a cell's valid slots are a prefix of its row (DataPartitioner2D pads at the end)
+            order = sorted(range(P), key=lambda q: -counts[q])
+            cs = [counts[q] for q in order]                                # non-increasing
+            K = max(1, min(max_buckets, P))
+            INF = float("inf")
+            cost = [[INF] * (P + 1) for _ in range(K + 1)]                 # cost[k][i]: the first i patches in k runs
+            back = [[0] * (P + 1) for _ in range(K + 1)]
+            cost[0][0] = 0
+            for k in range(1, K + 1):
+                for i in range(1, P + 1):
+                    for j in range(k - 1, i):                             # the last run is j .. i-1: its longest cell is cs[j]
+                        c = cost[k - 1][j] + (i - j) * cs[j]
+                        if c < cost[k][i]:
+                            cost[k][i], back[k][i] = c, j
+            k_best = min(range(1, K + 1), key=lambda k: cost[k][P])
+            cuts, i = [], P
+            for k in range(k_best, 0, -1):
+                j = back[k][i]
+                cuts.append((j, i, cs[j]))
+                i = j
+            buckets = cuts[::-1]
+            order_t = torch.tensor(order, device=idx.device, dtype=torch.long)
+            rank = torch.empty(P, dtype=torch.long, device=idx.device)
+            rank[order_t] = torch.arange(P, device=idx.device)
+            ps = part.point_slot.long()
+            slot_sorted = (rank[ps // C] * C + ps % C).to(torch.int32).contiguous()
+            plan = self._pplan = (key, order_t, buckets, idx[order_t].contiguous(), slot_sorted)
+        return plan[1:]
+
+    def decode_and_unpatch(self, decoder, z: torch.Tensor) -> torch.Tensor:
+        """decoder(z) followed by inverse_scale_and_unpatch(..., layout="BPFC") — z [T, P, n_groups, embed_dim] -> [T, N, F] — with the decoder run only over
+        the columns the un-patchify reads: a patch's first `count(cell)` columns per field (Decode.forward_prefix; the rest of a padded cell is never
+        produced, so the result equals the two-call chain bit for bit where it is defined — everywhere)."""
+        N.require_gpu(z, "z")
+        n_fields = sum(len(g) for g in self.field_groups)
+        order, buckets, idx_sorted, slot_sorted = self._prefix_plan(max(1, N.MAX_GROUPS // n_fields))
+        cells = decoder.forward_prefix(z[:, order], buckets)
+        C = idx_sorted.shape[1]
+        return ops.unpatchify(cells[..., :C], "BPFC", idx_sorted, self._scale, self._shift, self.partitioner.x_coords.numel(), point_slot=slot_sorted)
+
+
 class MeshProcessor:
     """MeshProcessor(config, coordinates) of the reference (utils/data_processors.py:454-573) on the device: `patchify_and_scale` (scale, partition into
     the (m-1) x (n-1) cells, pad) and `inverse_scale_and_unpatch` (scatter back, inverse scaling), ONE launch each (sea_patchify / sea_unpatchify).
@@ -180,6 +231,13 @@ class MeshProcessor:
         if self._unpatcher is None:
             raise ValueError("call patchify_and_scale first (it builds the partition)")
         return self._unpatcher.inverse_scale_and_unpatch(scaled_fields.to(self.device), layout=layout)
+
+    def decode_and_unpatch(self, decoder, z: torch.Tensor) -> torch.Tensor:
+        """decoder(z) + inverse_scale_and_unpatch(..., layout="BPFC") in one go, the decoder run only over a cell's mesh points (MeshUnpatcher.decode_and_unpatch):
+        z [T, P, n_groups, embed_dim] -> [T, N, F]."""
+        if self._unpatcher is None:
+            raise ValueError("call patchify_and_scale first (it builds the partition)")
+        return self._unpatcher.decode_and_unpatch(decoder, z.to(self.device))
 
 
 class ProcessData:
@@ -239,6 +297,10 @@ class ProcessData:
     def decode_data(self, data):
         with torch.no_grad():
             return self._model().decode(data.to(self.device))
+
+    def decoder(self):
+        """The frozen spatial decoder module (sea_amd.Decode) — for MeshProcessor.decode_and_unpatch."""
+        return self._model().decode
 
 
 class TemporalDataset:

@@ -123,8 +123,12 @@ def full_autoregressive_evaluation(model, dataLoader, loss_fn, device, processor
                     n_patches = (config['m'] - 1) * (config['n'] - 1) * (config['k'] - 1)
                 else:
                     n_patches = (config['m'] - 1) * (config['n'] - 1)
-                dec = processor.decode_data(inverse_transform_processed_data(pred, tr, T, n_patches, len(config['field_groups'])))   # [tr*T, P, F, C]
-                if config.get('SEA_mixed'):
+                z = inverse_transform_processed_data(pred, tr, T, n_patches, len(config['field_groups']))
+                fused = config.get('SEA_isolate') and not config.get('SEA_mixed') and hasattr(processor, 'decoder') and hasattr(mesh_processor, 'decode_and_unpatch')
+                dec = None if fused else processor.decode_data(z)   # [tr*T, P, F, C]
+                if fused:   # the decoder over a cell's mesh points only, then the scatter: the same fields as the two calls below, without the padding
+                    fields = mesh_processor.decode_and_unpatch(processor.decoder(), z)
+                elif config.get('SEA_mixed'):
                     B_, P_, F_, C_ = dec.shape
                     fields = mesh_processor.inverse_scale_and_unpatch(dec.reshape(B_, P_, C_, F_))
                 elif config.get('SEA_isolate'):

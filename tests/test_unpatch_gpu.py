@@ -92,3 +92,15 @@ def test_decode_then_unpatch_chain_against_oracle():
     ref = O.unpatchify(ref_dec, part.padded_index_map.cpu().long(), npts, groups, [(-1.0, 1.0, -1.0, 3.0), (-1.0, 1.0, 0.5, 2.0)])
     assert out.shape == (tr * T, npts, 3)
     assert rel_l2(out.cpu().numpy(), ref.numpy()) < 1e-5
+    # the same fields with the decoder run only over the columns the un-patchify reads (patches sorted by cell size, a few buckets): bit for bit
+    from sea_amd.utils.train_utils import inverse_transform_processed_data
+
+    mu = MeshUnpatcher(part, groups, scalers)
+    with torch.no_grad():
+        z = inverse_transform_processed_data(roll.cuda(), tr, T, P, len(groups))
+        fused = mu.decode_and_unpatch(dec, z)
+    assert torch.equal(fused, out)
+    order, buckets, _, _ = mu._prefix_plan(5)
+    counts = (part.padded_index_map != part.pad_id).sum(dim=1)[order].cpu().tolist()
+    assert buckets[0][0] == 0 and buckets[-1][1] == P and all(a[1] == b[0] for a, b in zip(buckets, buckets[1:]))
+    assert all(max(counts[lo:hi]) == n for lo, hi, n in buckets) and len(buckets) <= 5
