@@ -15,7 +15,9 @@ import torch.multiprocessing as mp
 
 pytestmark = pytest.mark.gpu
 
-CFG = (1, 64, 4, 48, 8, 0, 3, 2, True, "adaln")
+CFGS = {"cfg3_like": (1, 64, 4, 48, 8, 0, 3, 2, True, "adaln"),                 # one layer, AdaLN, info-bottleneck step behind the exchange (the benchmark's structure)
+        "two_layers_ln_pre": (2, 64, 4, 48, 8, 0, 2, 2, False, "ln")}             # two layers, plain LayerNorm, info-bottleneck step in front of the block
+CFG = CFGS["cfg3_like"]
 B_GLOBAL, T, STEPS, LR = 4, 40, 3, 1e-3
 
 
@@ -27,25 +29,25 @@ def _free_port():
     return p
 
 
-def _model(dtype="fp32"):
+def _model(dtype="fp32", cfg="cfg3_like"):
     from oracle import sea_oracle as O
     from tests.test_model_gpu import build
 
-    return build(O.OracleConfig(*CFG), dtype).train()
+    return build(O.OracleConfig(*CFGS[cfg]), dtype).train()
 
 
-def _data():
+def _data(cfg="cfg3_like"):
     from oracle import sea_oracle as O
     from oracle.recipe import recipe_inputs
 
-    return recipe_inputs(B_GLOBAL, T, O.OracleConfig(*CFG), seed=31)
+    return recipe_inputs(B_GLOBAL, T, O.OracleConfig(*CFGS[cfg]), seed=31)
 
 
-def _run_steps(x, tgt, ib, world, rank):
+def _run_steps(x, tgt, ib, world, rank, cfg="cfg3_like"):
     from sea_amd.parallel import parameters_in_sync, shard_batch
     from sea_amd.utils.train_utils import initialize_optimizer
 
-    m = _model()
+    m = _model(cfg=cfg)
     eng = m.engine()
     opt = initialize_optimizer(m, {"learning_rate": LR})
     xs, ts, cs = (shard_batch(t, rank, world).cuda().contiguous() for t in (x, tgt, ib))
@@ -58,21 +60,24 @@ def _run_steps(x, tgt, ib, world, rank):
         if world > 1:
             # three collectives, every element once: the MLP + proj slice and the exchange / norm / condition-MLP slice go early (each as soon as the backward
             # has finished it, under the launches that follow), the self-attention slice after the backward — most of the buffer is on its way before then
-            assert eng.last_allreduce_calls == 3, eng.last_allreduce_calls
             bk = eng.train_plan(xs.shape[0], xs.shape[1]).grad_buckets()
-            assert len(bk) == 2 and bk[0][1] == 0 and bk[0][2] == bk[1][1] and bk[0][0] < bk[1][0]
-            assert bk[1][2] / eng.params.n_live > 0.7, bk
+            assert eng.last_allreduce_calls == len(bk) + 1, (eng.last_allreduce_calls, bk)
+            assert bk[0][1] == 0 and all(a[2] == b[1] and a[0] < b[0] for a, b in zip(bk, bk[1:]))     # contiguous slices, in the order the backward finishes them
+            if cfg == "cfg3_like":
+                assert len(bk) == 2 and bk[1][2] / eng.params.n_live > 0.7, bk
+            else:
+                assert len(bk) == 5, bk    # two layers: (MLP, middle, self-attention) of the last layer, (MLP, middle) of the first
     return grads1, eng.params.flat32[:eng.params.n_live].cpu()
 
 
-def _worker(rank, world, port, backend, ret):
+def _worker(rank, world, port, backend, ret, cfg):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     torch.cuda.set_device(rank if backend == "nccl" else 0)
     dist.init_process_group(backend, rank=rank, world_size=world)
     try:
-        x, tgt, ib = _data()
-        g, p = _run_steps(x, tgt, ib, world, rank)
+        x, tgt, ib = _data(cfg)
+        g, p = _run_steps(x, tgt, ib, world, rank, cfg)
         ret[rank] = (g.numpy(), p.numpy())
     except Exception as e:  # pragma: no cover
         ret[rank] = repr(e)
@@ -80,20 +85,20 @@ def _worker(rank, world, port, backend, ret):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [1, 2])
-def test_train_step_world_n_equals_single_process_global_batch(world):
+@pytest.mark.parametrize("world,cfg", [(1, "cfg3_like"), (2, "cfg3_like"), (2, "two_layers_ln_pre")])
+def test_train_step_world_n_equals_single_process_global_batch(world, cfg):
     backend = os.environ.get("SEA_TEST_DP_BACKEND", "gloo")
     if backend == "nccl" and torch.cuda.device_count() < world:
         pytest.skip("needs one GPU per rank")
-    x, tgt, ib = _data()
-    g_ref, p_ref = _run_steps(x, tgt, ib, 1, 0)       # single process, the global batch
+    x, tgt, ib = _data(cfg)
+    g_ref, p_ref = _run_steps(x, tgt, ib, 1, 0, cfg)  # single process, the global batch
     if world == 1:
-        g2, p2 = _run_steps(x, tgt, ib, 1, 0)         # the body at N = 1: run-to-run agreement (fp32 atomics order)
+        g2, p2 = _run_steps(x, tgt, ib, 1, 0, cfg)    # the body at N = 1: run-to-run agreement (fp32 atomics order)
         assert np.linalg.norm(g2.numpy() - g_ref.numpy()) <= 1e-6 * np.linalg.norm(g_ref.numpy())
         return
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(_worker, args=(world, _free_port(), backend, ret), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), backend, ret, cfg), nprocs=world, join=True)
     got = dict(ret)
     assert all(not isinstance(v, str) for v in got.values()), got
     for r in range(world):
