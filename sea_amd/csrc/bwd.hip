@@ -44,75 +44,135 @@ struct WgradLaunch {
     int splits[SEA_MAX_WGRAD_GROUPS];
     int rows_per_split[SEA_MAX_WGRAD_GROUPS];
     int n_groups;
+    int xcd;   // 1: XCD-contiguous work order (see the kernel)
 };
 
-// Output tile TS (n) x TS (k), TS = 64 or 128; 4 waves as 2 x 2, each TS/2 x TS/2 = MI x MI MFMA tiles; the contraction runs over
-// 64-row stages of dY and X held [m][TS columns] in LDS (row pitch + 16 bytes), double-buffered through registers like the forward
-// GEMM.  The 128 tile does 16 MFMAs per 8 transposed fragment reads (64: 4 per 4) and halves the operand re-reads; used when
-// every matrix of the launch is a multiple of 128 both ways.
-template <typename T, int TS>
-__global__ __launch_bounds__(256) void wgrad_kernel(const WgradLaunch L) {
-    constexpr int EPC = ActTraits<T>::EPC, CK = ActTraits<T>::CK;
-    constexpr int MI = TS / 32;                    // 16 x 16 MFMA tiles per wave per dimension
-    constexpr int WT = TS / 2;                     // wave tile
-    constexpr int ROWB = TS * (int)sizeof(T);      // bytes of one tile row
-    constexpr int PITCH = ROWB + 16;
-    constexpr int CPR = ROWB / 16;                 // 16-byte chunks per row
-    constexpr int NCH = 64 * CPR / 256;            // chunks per thread per operand
-    constexpr int TILE_B = 64 * PITCH;
-    extern __shared__ __attribute__((aligned(16))) char smem[];  // 4 * TILE_B: 2 buffers x (dY tile, X tile)
+// Output tile TN (n) x TK (k) per workgroup, one WT x WT tile (WT / 16 squared MFMA tiles) per wave: 64 x 64 (4 waves of 32 x 32) or 128 x 128
+// (4 waves of 64 x 64).  The contraction runs over 64-row stages of dY and X held
+// [m][columns] in LDS (padded row pitch), double-buffered through registers like the forward GEMM.
+// LDS row padding: the transposed bf16 fragment read takes, per 16-lane group, 32 bytes of each of 4 consecutive rows — a pitch of 8 dwords mod 64
+// banks puts those on 32 distinct banks; the f32 read takes 64 bytes of each of two rows 4 apart per LDS cycle: 4 dwords mod 32 per row.  (Shifting
+// every 8-row block by another 128 bytes, so that the two 16-lane groups of an LDS cycle never meet, changed neither SQ_LDS_BANK_CONFLICT — what it
+// counts here are the extra array cycles of the 16-byte stores — nor the time.)
+template <typename T>
+constexpr int WGRAD_PAD = sizeof(T) == 2 ? 32 : 16;
 
+template <typename T, int TN, int TK, int WT>
+__global__ __launch_bounds__((TN / WT) * (TK / WT) * 64) void wgrad_kernel(const WgradLaunch L) {
+    constexpr int EPC = ActTraits<T>::EPC, CK = ActTraits<T>::CK;
+    constexpr int WK = TK / WT, NT = (TN / WT) * WK * 64;   // waves along k, threads
+    constexpr int MI = WT / 16;                    // 16 x 16 MFMA tiles per wave per dimension
+    constexpr int PAD = WGRAD_PAD<T>;
+    constexpr int PITCH_Y = TN * (int)sizeof(T) + PAD, PITCH_X = TK * (int)sizeof(T) + PAD;
+    constexpr int CPR_Y = TN * (int)sizeof(T) / 16, CPR_X = TK * (int)sizeof(T) / 16;   // 16-byte chunks per tile row
+    constexpr int NCH_Y = 64 * CPR_Y / NT, NCH_X = 64 * CPR_X / NT;                     // chunks per thread per operand
+    static_assert(NCH_Y * NT == 64 * CPR_Y && NCH_X * NT == 64 * CPR_X, "whole chunks per thread");
+    constexpr int TILE_Y = 64 * PITCH_Y, TILE_X = 64 * PITCH_X;
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // 2 buffers x (dY tile, X tile)
+
+    // Work items are numbered (group, split, tn, tk) with tk fastest: neighbours share the dY column block (same tn, same rows), the next ones the
+    // X block.  Each XCD takes a contiguous range of them (xcd_remap), so that what neighbours share is fetched into ONE L2 once instead of into
+    // several: in the plain order (split fastest, dealt round-robin) no two workgroups of an XCD shared anything.
+    const int bid = L.xcd ? xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x;
     int gi = 0;
-    while (gi + 1 < L.n_groups && (int)blockIdx.x >= L.tile_start[gi + 1]) ++gi;
+    while (gi + 1 < L.n_groups && bid >= L.tile_start[gi + 1]) ++gi;
     const SeaWgradGroup& G = L.g[gi];
-    int t = blockIdx.x - L.tile_start[gi];
+    int t = bid - L.tile_start[gi];
     const int splits = L.splits[gi];
-    const int split = t % splits;
-    t /= splits;
-    const int tiles_k = (G.K + TS - 1) / TS;
-    const int tn = t / tiles_k, tk = t - tn * tiles_k;
-    const int n0 = tn * TS, k0 = tk * TS;
+    const int tiles_k = (G.K + TK - 1) / TK, tiles_n = (G.N + TN - 1) / TN;
+    int split, tn, tk;
+    if (L.xcd) {
+        tk = t % tiles_k;
+        t /= tiles_k;
+        tn = t % tiles_n;
+        split = t / tiles_n;
+    } else {
+        split = t % splits;
+        t /= splits;
+        tn = t / tiles_k;
+        tk = t - tn * tiles_k;
+    }
+    const int n0 = tn * TN, k0 = tk * TK;
     const int m_begin = split * L.rows_per_split[gi];
     int m_end = m_begin + L.rows_per_split[gi];
     m_end = m_end < G.M ? m_end : G.M;
     if (m_begin >= m_end) return;  // block-uniform
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wn = wave >> 1, wk = wave & 1;
+    const int wn = wave / WK, wk = wave - wn * WK;
     const T* dY = static_cast<const T*>(G.dY);
     const T* X = static_cast<const T*>(G.X);
     // Stages are requested TWO ahead into two register sets (stage s waits in set s & 1 from its request in step s - 2 to its LDS store
     // at the end of step s - 1): a 64-row stage is only 32 MFMAs of work per wave against a ~2 us memory round trip, and at two
-    // resident workgroups per CU nothing else hides it.  Loads are unconditional (rows clamped, columns clamped, out-of-range data
-    // zeroed by a select at the store) so that the compiler can wait with vmcnt(N) for the older set alone.
-    uint4 ry[2][NCH], rx[2][NCH];
+    // waves per SIMD nothing else hides it.  Every path issues the same loads in the same order (rows clamped, columns clamped, out-of-range data
+    // zeroed by a select at the store) so that the compiler can wait with vmcnt(N) for the older set alone.  A stage that lies wholly inside the
+    // rows of the split, in a tile that lies wholly inside the matrix (block-uniform: every stage but the last of almost every workgroup), takes the
+    // plain path: one scalar row base + a per-thread 32-bit offset per chunk, no clamps, no selects — the two waves of a SIMD share its VALU
+    // issue with the MFMAs, and the clamped form spent as many issue cycles on addresses and selects as on the matrix core.
+    uint4 ry[2][NCH_Y], rx[2][NCH_X];
+    const bool full_tile = n0 + TN <= G.N && k0 + TK <= G.K;
+    // chunk u of a thread lies u * (NT / CPR) rows below its chunk 0: one per-thread offset per operand, the rest is scalar
+    constexpr int RSTEP_Y = NT / CPR_Y, RSTEP_X = NT / CPR_X;
+    static_assert(RSTEP_Y * CPR_Y == NT && RSTEP_X * CPR_X == NT, "a chunk column per thread");
+    const uint32_t offy0 = (uint32_t)((tid / CPR_Y) * G.lddy + n0 + (tid % CPR_Y) * EPC);
+    const uint32_t offx0 = (uint32_t)((tid / CPR_X) * G.ldx + k0 + (tid % CPR_X) * EPC);
     auto load_stage = [&](int ms, auto set_tag) {
         constexpr int ST = decltype(set_tag)::value;
+        if (full_tile && ms + 64 <= m_end) {
+            const T* by = dY + (int64_t)ms * G.lddy;
+            const T* bx = X + (int64_t)ms * G.ldx;
 #pragma unroll
-        for (int u = 0; u < NCH; ++u) {
-            const int idx = tid + u * 256;
-            const int rr = idx / CPR, cc = idx - rr * CPR;
+            for (int u = 0; u < NCH_Y; ++u) ry[ST][u] = *reinterpret_cast<const uint4*>(by + (int64_t)(u * RSTEP_Y) * G.lddy + offy0);
+#pragma unroll
+            for (int u = 0; u < NCH_X; ++u) rx[ST][u] = *reinterpret_cast<const uint4*>(bx + (int64_t)(u * RSTEP_X) * G.ldx + offx0);
+            return;
+        }
+#pragma unroll
+        for (int u = 0; u < NCH_Y; ++u) {
+            const int idx = tid + u * NT;
+            const int rr = idx / CPR_Y, cc = idx - rr * CPR_Y;
             int m = ms + rr;
             m = m < m_end ? m : m_end - 1;
-            int cn = n0 + cc * EPC, ck = k0 + cc * EPC;
+            int cn = n0 + cc * EPC;
             cn = cn < G.N ? cn : G.N - EPC;
-            ck = ck < G.K ? ck : G.K - EPC;
             ry[ST][u] = *reinterpret_cast<const uint4*>(dY + (int64_t)m * G.lddy + cn);
+        }
+#pragma unroll
+        for (int u = 0; u < NCH_X; ++u) {
+            const int idx = tid + u * NT;
+            const int rr = idx / CPR_X, cc = idx - rr * CPR_X;
+            int m = ms + rr;
+            m = m < m_end ? m : m_end - 1;
+            int ck = k0 + cc * EPC;
+            ck = ck < G.K ? ck : G.K - EPC;
             rx[ST][u] = *reinterpret_cast<const uint4*>(X + (int64_t)m * G.ldx + ck);
         }
     };
+    const int soffy0 = (tid / CPR_Y) * PITCH_Y + (tid % CPR_Y) * 16;            // LDS byte offsets of chunk 0; chunk u: + u * RSTEP rows
+    const int soffx0 = TILE_Y + (tid / CPR_X) * PITCH_X + (tid % CPR_X) * 16;
     auto store_stage = [&](int buf, int ms, auto set_tag) {
         constexpr int ST = decltype(set_tag)::value;
-        char* sy = smem + buf * 2 * TILE_B;
-        char* sx = sy + TILE_B;
+        char* sy = smem + buf * (TILE_Y + TILE_X);
+        if (full_tile && ms + 64 <= m_end) {
 #pragma unroll
-        for (int u = 0; u < NCH; ++u) {
-            const int idx = tid + u * 256;
-            const int rr = idx / CPR, cc = idx - rr * CPR;
-            const bool mok = ms + rr < m_end;
-            const bool yok = mok && n0 + cc * EPC < G.N, xok = mok && k0 + cc * EPC < G.K;
-            *reinterpret_cast<uint4*>(sy + rr * PITCH + cc * 16) = yok ? ry[ST][u] : make_uint4(0, 0, 0, 0);
-            *reinterpret_cast<uint4*>(sx + rr * PITCH + cc * 16) = xok ? rx[ST][u] : make_uint4(0, 0, 0, 0);
+            for (int u = 0; u < NCH_Y; ++u) *reinterpret_cast<uint4*>(sy + soffy0 + u * RSTEP_Y * PITCH_Y) = ry[ST][u];
+#pragma unroll
+            for (int u = 0; u < NCH_X; ++u) *reinterpret_cast<uint4*>(sy + soffx0 + u * RSTEP_X * PITCH_X) = rx[ST][u];
+            return;
+        }
+#pragma unroll
+        for (int u = 0; u < NCH_Y; ++u) {
+            const int idx = tid + u * NT;
+            const int rr = idx / CPR_Y, cc = idx - rr * CPR_Y;
+            const bool yok = ms + rr < m_end && n0 + cc * EPC < G.N;
+            *reinterpret_cast<uint4*>(sy + soffy0 + u * RSTEP_Y * PITCH_Y) = yok ? ry[ST][u] : make_uint4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int u = 0; u < NCH_X; ++u) {
+            const int idx = tid + u * NT;
+            const int rr = idx / CPR_X, cc = idx - rr * CPR_X;
+            const bool xok = ms + rr < m_end && k0 + cc * EPC < G.K;
+            *reinterpret_cast<uint4*>(sy + soffx0 + u * RSTEP_X * PITCH_X) = xok ? rx[ST][u] : make_uint4(0, 0, 0, 0);
         }
     };
 
@@ -121,8 +181,14 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradLaunch L) {
     for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < MI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float bsum = 0.f;
-    const bool do_bias = G.db != nullptr && tk == 0 && tid < TS;
+    // db[n] = column sums of dY: on the matrix core too — the wave's dY fragments against an all-ones operand give, in every column of the result, the
+    // sum over the contraction rows (wave-uniform: the k-first tile's k-first waves; 64 two-byte LDS reads and a dependent add chain per thread before)
+    f32x4 bacc[MI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i) bacc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const bool do_bias = G.db != nullptr && tk == 0 && wk == 0;
+    const uint32_t one_bits = sizeof(T) == 2 ? 0x3f803f80u : 0x3f800000u;
+    const uint4 ones = make_uint4(one_bits, one_bits, one_bits, one_bits);
 
     const int n_stage = (m_end - m_begin + 63) / 64;
     using Set0 = std::integral_constant<int, 0>;
@@ -132,31 +198,32 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradLaunch L) {
         const int ms2 = m_begin + (st + 2) * 64;
         load_stage(ms2 < m_end ? ms2 : m_end - 1, cur_tag);   // past the end: a harmless re-read, zeroed / never used
         if (st >= 0) {
-            const char* sy = smem + (st & 1) * 2 * TILE_B;
-            const char* sx = sy + TILE_B;
+            const char* sy = smem + (st & 1) * (TILE_Y + TILE_X);
+            const char* sx = sy + TILE_Y;
 #pragma unroll
             for (int mk = 0; mk < 64; mk += CK) {
                 uint4 a[MI], b[MI];
 #pragma unroll
-                for (int i = 0; i < MI; ++i) a[i] = load_frag_T<T>(sy, PITCH, mk, wn * WT + i * 16, lane);
+                for (int i = 0; i < MI; ++i) a[i] = load_frag_T<T>(sy, PITCH_Y, mk, wn * WT + i * 16, lane);
 #pragma unroll
-                for (int j = 0; j < MI; ++j) b[j] = load_frag_T<T>(sx, PITCH, mk, wk * WT + j * 16, lane);
+                for (int j = 0; j < MI; ++j) b[j] = load_frag_T<T>(sx, PITCH_X, mk, wk * WT + j * 16, lane);
 #pragma unroll
                 for (int i = 0; i < MI; ++i)
 #pragma unroll
                     for (int j = 0; j < MI; ++j) mma16<T>(a[i], b[j], acc[i][j]);
-            }
-            if (do_bias) {
-                const T* col = reinterpret_cast<const T*>(sy) + tid;
-#pragma unroll 8
-                for (int rr = 0; rr < 64; ++rr) bsum += to_f32(*reinterpret_cast<const T*>(reinterpret_cast<const char*>(col) + rr * PITCH));
+                if (do_bias) {
+#pragma unroll
+                    for (int i = 0; i < MI; ++i) mma16<T>(a[i], ones, bacc[i]);
+                }
             }
         }
-        store_stage((st + 1) & 1, m_begin + (st + 1) * 64, nxt_tag);   // stage st + 1 (requested one step ago); st = -2 stores zeros-by-select
+        store_stage((st + 1) & 1, m_begin + (st + 1) * 64, nxt_tag);   // stage st + 1 (requested one step ago); st = -2 stores the zeroed registers
         __syncthreads();
     };
 #pragma unroll
-    for (int u = 0; u < NCH; ++u) ry[0][u] = ry[1][u] = rx[0][u] = rx[1][u] = make_uint4(0, 0, 0, 0);
+    for (int u = 0; u < NCH_Y; ++u) ry[0][u] = ry[1][u] = make_uint4(0, 0, 0, 0);
+#pragma unroll
+    for (int u = 0; u < NCH_X; ++u) rx[0][u] = rx[1][u] = make_uint4(0, 0, 0, 0);
     // the pipeline fills inside the loop (steps -2, -1 only request and store), whole pairs only: the loop is entered with nothing in
     // flight and has no conditional load, the two things the compiler needs to count the loads (see attention.hip)
     int st = -2;
@@ -178,7 +245,15 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradLaunch L) {
                 if (n < G.N && k < G.K) atomicAdd(G.dW + (int64_t)n * G.lddw + k, acc[i][j][q]);
             }
         }
-    if (do_bias && n0 + tid < G.N) atomicAdd(G.db + n0 + tid, bsum);
+    if (do_bias && r == 0) {   // every column of bacc holds the same sums
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int n = n0 + wn * WT + i * 16 + g * 4 + q;
+                if (n < G.N) atomicAdd(G.db + n, bacc[i][q]);
+            }
+    }
 }
 
 extern "C" int sea_wgrad_grouped(const SeaWgradGroup* groups, int n_groups, int dtype, void* stream) {
@@ -200,16 +275,37 @@ extern "C" int sea_wgrad_grouped(const SeaWgradGroup* groups, int n_groups, int 
     long tiles128 = 0;
     for (int i = 0; i < n_groups; ++i) tiles128 += (long)((groups[i].N + 127) / 128) * ((groups[i].K + 127) / 128);
     // few 128-tiles would mean many contraction splits, i.e. many atomic passes over the same outputs: measured at cfg3 the small
-    // exchange matrices (6 tiles) run 1.8x slower on the 128 tile, the MLP / condition matrices (96-192 tiles) 1.2-1.4x faster
-    const int ts = forced == 64 ? 64 : (forced == 128 ? 128 : (big && tiles128 >= 64 ? 128 : 64));
+    // exchange matrices (6 tiles) run 1.8x slower on the 128 tile, the MLP / condition matrices (96-192 tiles) 1.2-1.4x faster.
+    // (256 x 128 / 128 x 256 tiles with 8 waves, the wide side along the smaller matrix dimension so that the larger operand is read by half as many
+    // workgroups, were measured too: cond 152 against 181 us before the main loop was reworked, 131 against 132 after — not kept.)
+    const int tn = forced == 64 ? 64 : (forced == 128 ? 128 : (big && tiles128 >= 64 ? 128 : 64)), tk = tn;
     long base_tiles = 0;
-    for (int i = 0; i < n_groups; ++i) base_tiles += (long)((groups[i].N + ts - 1) / ts) * ((groups[i].K + ts - 1) / ts);
-    // split the contraction so that the launch has ~2 workgroups per CU, never below 256 rows per split
-    static const int wg_target = []() { const char* e = getenv("SEA_WGRAD_TARGET"); return e ? atoi(e) : 512; }();  // tuning aid
+    for (int i = 0; i < n_groups; ++i) base_tiles += (long)((groups[i].N + tn - 1) / tn) * ((groups[i].K + tk - 1) / tk);
+    // Split the contraction so that the launch fills the chip's resident-workgroup slots (2 per CU with the 128 tile's 72 KiB of LDS)
+    // in WHOLE rounds, never below 256 rows per split: the launch lasts rounds x stages-per-split, so 576 workgroups on 512
+    // slots (what "about 512" gave the MLP matrices at cfg3: 96 tiles x 6 splits) take two rounds of 42 stages where 480 take one of 51.  The
+    // split count minimises rounds x (stages + 2) — the 2 prices a workgroup's fill and its atomic pass over the tile.
+    static const int wg_target = []() { const char* e = getenv("SEA_WGRAD_TARGET"); return e ? atoi(e) : 0; }();  // tuning aid: "about this many workgroups"
+    const long slots = 512;   // the 64 tile could sit four to a CU, but its launches are small matrices whose extra splits cost more in atomic passes than they fill (measured)
+    int m_max = 1;
+    for (int i = 0; i < n_groups; ++i) m_max = groups[i].M > m_max ? groups[i].M : m_max;
+    long best_splits = 1;
+    if (wg_target > 0) {
+        best_splits = (wg_target + base_tiles - 1) / base_tiles;
+    } else {
+        long best_cost = -1;
+        const long s_max = (m_max + 255) / 256;
+        for (long sp = 1; sp <= s_max && sp <= 64; ++sp) {
+            const long rounds = (base_tiles * sp + slots - 1) / slots;
+            const long stages = ((m_max + sp - 1) / sp + 63) / 64;
+            const long cost = rounds * (stages + 2);
+            if (best_cost < 0 || cost < best_cost) best_cost = cost, best_splits = sp;
+        }
+    }
     int total = 0;
     for (int i = 0; i < n_groups; ++i) {
         const SeaWgradGroup& G = groups[i];
-        long want = (wg_target + base_tiles - 1) / base_tiles;
+        long want = best_splits;
         long max_splits = (G.M + 255) / 256;
         int splits = (int)(want < 1 ? 1 : (want > max_splits ? max_splits : want));
         int rows = ((G.M + splits - 1) / splits + 63) / 64 * 64;
@@ -218,20 +314,22 @@ extern "C" int sea_wgrad_grouped(const SeaWgradGroup* groups, int n_groups, int 
         L.splits[i] = splits;
         L.rows_per_split[i] = rows;
         L.tile_start[i] = total;
-        total += ((G.N + ts - 1) / ts) * ((G.K + ts - 1) / ts) * splits;
+        total += ((G.N + tn - 1) / tn) * ((G.K + tk - 1) / tk) * splits;
     }
     L.tile_start[n_groups] = total;
     L.n_groups = n_groups;
+    static const bool xcd_order = [] { const char* e = getenv("SEA_WGRAD_XCD"); return !(e && e[0] == '0'); }();  // tuning aid
+    L.xcd = xcd_order ? 1 : 0;
     hipStream_t s = static_cast<hipStream_t>(stream);
-#define LAUNCH_WG(TT, TSZ)                                                                                                      \
+#define LAUNCH_WG(TT, TN_, TK_, WT_)                                                                                             \
     do {                                                                                                                         \
-        constexpr int lds_ = 4 * 64 * (TSZ * (int)sizeof(TT) + 16);                                                              \
-        static const hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel<TT, TSZ>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_); \
+        constexpr int lds_ = 2 * 64 * ((TN_ + TK_) * (int)sizeof(TT) + 2 * WGRAD_PAD<TT>);                                                      \
+        static const hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel<TT, TN_, TK_, WT_>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_); \
         (void)once;                                                                                                              \
-        wgrad_kernel<TT, TSZ><<<dim3(total), dim3(256), lds_, s>>>(L);                                                          \
+        wgrad_kernel<TT, TN_, TK_, WT_><<<dim3(total), dim3((TN_ / WT_) * (TK_ / WT_) * 64), lds_, s>>>(L);                      \
     } while (0)
-    if (dtype == SEA_BF16) { if (ts == 128) LAUNCH_WG(__bf16, 128); else LAUNCH_WG(__bf16, 64); }
-    else { if (ts == 128) LAUNCH_WG(float, 128); else LAUNCH_WG(float, 64); }
+    if (dtype == SEA_BF16) { if (tn == 128) LAUNCH_WG(__bf16, 128, 128, 64); else LAUNCH_WG(__bf16, 64, 64, 32); }
+    else { if (tn == 128) LAUNCH_WG(float, 128, 128, 64); else LAUNCH_WG(float, 64, 64, 32); }
 #undef LAUNCH_WG
     SEA_CHECK_LAUNCH("sea_wgrad_grouped");
     return SEA_OK;

@@ -18,15 +18,6 @@ struct QkvLaunch {
     SeaQkvCommon c;
 };
 
-// Workgroups are dealt round-robin over the 8 XCDs (blocks b and b + 8 share an L2).  Tiles are numbered row-panel-major, so
-// consecutive tiles re-read the same A panel (and every tile of a group the same W): give each XCD a CONTIGUOUS range of tile
-// numbers so those re-reads hit its own L2 instead of crossing the fabric once per XCD (bijective form of the T1 remap,
-// cdna_hip_programming.md; only placement, never correctness).
-__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
-    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
-    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-}
-
 template <typename L>
 __device__ __forceinline__ int find_group(const L& launch, int bid) {
     int gi = 0;

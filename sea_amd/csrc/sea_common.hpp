@@ -254,3 +254,11 @@ __device__ __forceinline__ void load4(const __bf16* src, float (&o)[4]) {
     bf16x4 v = *reinterpret_cast<const bf16x4*>(src);
     o[0] = (float)v[0]; o[1] = (float)v[1]; o[2] = (float)v[2]; o[3] = (float)v[3];
 }
+
+// Workgroups are dealt round-robin over the 8 XCDs (blocks b and b + 8 share an L2).  Kernels that number their tiles so that consecutive
+// tiles re-read the same operand panel give each XCD a CONTIGUOUS range of tile numbers, so that those re-reads hit its own L2 instead of
+// crossing the fabric once per XCD (bijective form of the T1 remap, cdna_hip_programming.md; only placement, never correctness).
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}

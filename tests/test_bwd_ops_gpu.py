@@ -49,6 +49,27 @@ def test_wgrad(dtype, M, N_, K):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("shapes", [[(2048, 256)] * 3, [(256, 2048)] * 3, [(512, 512)] * 5 + [(256, 256)] * 2, [(768, 256)] * 3 + [(1024, 512)]])
+def test_wgrad_cfg3_launch_shapes(dtype, shapes):
+    """The grouped launches of the cfg3 backward (MLP, condition, QKV matrices: the 128 tile, XCD-contiguous work order, whole-round splits) at a ragged row
+    count: the plain path of interior stages and the clamped path of the last one.  Strided operands, bias sums on the matrix core, accumulation into existing content."""
+    from sea_amd import ops
+
+    M = 2048 + 333
+    gs, refs = [], []
+    for i, (n, k) in enumerate(shapes):
+        dY = rnd(M, n + 64, dtype=dtype, seed=100 + i)[:, :n]
+        X = rnd(M, k + 64, dtype=dtype, seed=200 + i)[:, 64:]
+        dW, db = rnd(n, k, seed=300 + i), rnd(n, seed=400 + i)
+        refs.append((dW + dY.float().t() @ X.float(), db + dY.float().sum(0)))
+        gs.append(dict(dY=dY, X=X, dW=dW, db=db))
+    ops.wgrad_grouped(gs, dtype)
+    for g, (rw, rb) in zip(gs, refs):
+        assert rel(g["dW"], rw) < 2e-5
+        assert rel(g["db"], rb) < 2e-5
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 def test_wgrad_grouped_shared_output(dtype):
     """Several groups accumulating into the same dW (the multi-segment cross_up case)."""
     from sea_amd import ops
