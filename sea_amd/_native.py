@@ -189,7 +189,7 @@ class SeaKvGlobal(C.Structure):
                 ("handoff", _vp), ("err", _vp), ("handoff_words", _i64)]
 
 
-MAX_WGRAD_GROUPS = 16
+MAX_WGRAD_GROUPS = 32
 MAX_NORM_BWD_GROUPS = 8
 MAX_SILU_BWD_GROUPS = 24
 

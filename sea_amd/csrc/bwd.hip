@@ -37,7 +37,7 @@ __device__ __forceinline__ uint4 load_frag_T<float>(const char* tile, int pitch,
 }
 
 // ------------------------------------------------------------------------------------------------ weight gradient (TN GEMM)
-#define SEA_MAX_WGRAD_GROUPS 16
+#define SEA_MAX_WGRAD_GROUPS 32
 struct WgradLaunch {
     SeaWgradGroup g[SEA_MAX_WGRAD_GROUPS];
     int tile_start[SEA_MAX_WGRAD_GROUPS + 1];  // in (tile x split) units
@@ -286,7 +286,9 @@ extern "C" int sea_wgrad_grouped(const SeaWgradGroup* groups, int n_groups, int 
     // slots (what "about 512" gave the MLP matrices at cfg3: 96 tiles x 6 splits) take two rounds of 42 stages where 480 take one of 51.  The
     // split count minimises rounds x (stages + 2) — the 2 prices a workgroup's fill and its atomic pass over the tile.
     static const int wg_target = []() { const char* e = getenv("SEA_WGRAD_TARGET"); return e ? atoi(e) : 0; }();  // tuning aid: "about this many workgroups"
-    const long slots = 512;   // the 64 tile could sit four to a CU, but its launches are small matrices whose extra splits cost more in atomic passes than they fill (measured)
+    // the 64 tile sits four to a CU (40 KiB of LDS); launches of a few small matrices keep to 512 — their extra splits cost more in atomic passes over
+    // the same few tiles than they fill (measured) —, a launch of many (the exchange's gradients in one launch: 184 tiles) fills all 1024
+    const long slots = tn == 64 && base_tiles >= 64 ? 1024 : 512;
     int m_max = 1;
     for (int i = 0; i < n_groups; ++i) m_max = groups[i].M > m_max ? groups[i].M : m_max;
     long best_splits = 1;

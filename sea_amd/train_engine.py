@@ -593,30 +593,34 @@ class TrainPlan(Plan):
                 dnd_old = [buf(M, D, dtype=f32) for _ in range(F)]
                 dnd_new = [buf(M, D, dtype=f32) for _ in range(F)]
                 init_old, init_new = [False] * F, [False] * F
-                ddn = buf(M, D)
-                da = [buf(M, D) for _ in range(F - 1)]
+                # Weight gradients are leaves of the backward graph: nothing waits for them.  The exchange's are small matrices ([D or E] x [D or E]
+                # outputs over M rows: 1-3 GFLOP each, 16-24 us per launch of two or three of them, most of it launch, pipeline fill and the atomic pass)
+                # and there are 5 launches of them per field — they are collected in `xw` and run as ONE grouped launch behind the loop (cfg3: 17 launches
+                # of ~19 us -> one; their dY operands therefore get a buffer per field instead of one reused by every field).
+                xw: List[dict] = []
+                ddn_f = [buf(M, D) for _ in range(F)]
+                da_f = [[buf(M, D) for _ in range(F - 1)] for _ in range(F)]
                 datt = [buf(M, D) for _ in range(F - 1)]
-                dqc = [buf(M, D) for _ in range(F - 1)]
-                dkvc = [buf(M, 2 * D) for _ in range(F - 1)]
+                dqc_f = [[buf(M, D) for _ in range(F - 1)] for _ in range(F)]
+                dkvc_f = [[buf(M, 2 * D) for _ in range(F - 1)] for _ in range(F)]
                 delta_c = [buf(B, H, T, dtype=f32) for _ in range(F - 1)]
                 for i in reversed(range(F)):
+                    ddn, da, dqc, dkvc = ddn_f[i], da_f[i], dqc_f[i], dkvc_f[i]
                     if i < F - 1:
                         # a. nd_new[i] was the k/v source of the later fields: back through ln_cross and cross_down onto d x2_i
                         assert init_new[i]
                         cp = f"{pre}ln_cross.{i}."
                         self._norm_bwd([dict(dY=dnd_new[i], X=sv["dn_new"][i], mean=sv["stc_new"][i][0], rstd=sv["stc_new"][i][1], dXact=ddn, **bpar(cp, D))],
                                        D, f"bwd.cross{i}.norm_new", False, False, False, False)
-                        self._wgrad([dict(dY=ddn, X=sv["xa2"][i], dW=G2(f"{pre}cross_down.{i}.weight"), db=Gv(f"{pre}cross_down.{i}.bias"))], f"bwd.cross{i}.down_new.wgrad")
+                        xw.append(dict(dY=ddn, X=sv["xa2"][i], dW=G2(f"{pre}cross_down.{i}.weight"), db=Gv(f"{pre}cross_down.{i}.bias")))
                         self._gemm([dict(A=ddn, W=P.actT(f"{pre}cross_down.{i}.weight"), R=dx[i], C32=dx[i], Cact=ga[i])], f"bwd.cross{i}.down_new.dgrad")
                     # b. cross_up (shared by the F-1 partners) with the GELU derivative fused: da_s = (d x2_i Wu) * gelu'(a_ij)
                     others = others_of[i]
-                    self._wgrad([dict(dY=ga[i], X=sv["g"][i][s], dW=G2(f"{pre}cross_up.{i}.weight"), db=Gv(f"{pre}cross_up.{i}.bias"))
-                                 for s in range(F - 1)], f"bwd.cross{i}.up.wgrad")
+                    xw += [dict(dY=ga[i], X=sv["g"][i][s], dW=G2(f"{pre}cross_up.{i}.weight"), db=Gv(f"{pre}cross_up.{i}.bias")) for s in range(F - 1)]   # ga[i] is next written in f.
                     self._gemm([dict(A=ga[i], W=P.actT(f"{pre}cross_up.{i}.weight"), Z=sv["pair"][(i, j)]["a"], act=2, Cact=da[s])
                                 for s, j in enumerate(others)], f"bwd.cross{i}.up.dgrad")
                     # c. projection of each pair
-                    self._wgrad([dict(dY=da[s], X=sv["pair"][(i, j)]["O"], dW=G2(f"{pre}cross_attn.{i}.{j}.projection.weight")) for s, j in enumerate(others)],
-                                f"bwd.cross{i}.proj.wgrad")
+                    xw += [dict(dY=da[s], X=sv["pair"][(i, j)]["O"], dW=G2(f"{pre}cross_attn.{i}.{j}.projection.weight")) for s, j in enumerate(others)]
                     self._gemm([dict(A=da[s], W=P.actT(f"{pre}cross_attn.{i}.{j}.projection.weight"), Cact=datt[s]) for s, j in enumerate(others)],
                                f"bwd.cross{i}.proj.dgrad")
                     # d. attention
@@ -624,12 +628,10 @@ class TrainPlan(Plan):
                                          dO=datt[s], LSE=sv["pair"][(i, j)]["LSE"], delta=delta_c[s], dQ=dqc[s], dK=dkvc[s][:, :D], dV=dkvc[s][:, D:])
                                     for s, j in enumerate(others)], hd_c, rope_c, f"bwd.cross{i}.attention", drop=sv[("cross_drop", i)])
                     # e. q / k,v projections
-                    wg = []
                     for s, j in enumerate(others):
                         ca = f"{pre}cross_attn.{i}.{j}."
-                        wg.append(dict(dY=dqc[s], X=sv["nd_old"][i], dW=G2(ca + "q.weight"), db=Gv(ca + "q.bias")))
-                        wg.append(dict(dY=dkvc[s], X=sv["pair"][(i, j)]["src"], dW=G2(ca + "k.weight", 2 * D), db=Gv(ca + "k.bias", 2 * D)))
-                    self._wgrad(wg, f"bwd.cross{i}.qkv.wgrad")
+                        xw.append(dict(dY=dqc[s], X=sv["nd_old"][i], dW=G2(ca + "q.weight"), db=Gv(ca + "q.bias")))
+                        xw.append(dict(dY=dkvc[s], X=sv["pair"][(i, j)]["src"], dW=G2(ca + "k.weight", 2 * D), db=Gv(ca + "k.bias", 2 * D)))
                     for s, j in enumerate(others):
                         ca = f"{pre}cross_attn.{i}.{j}."
                         groups = []
@@ -651,8 +653,8 @@ class TrainPlan(Plan):
                 ddo = [buf(M, D) for _ in range(F)]
                 self._norm_bwd([dict(dY=dnd_old[j], X=sv["dn_old"][j], mean=sv["stc_old"][j][0], rstd=sv["stc_old"][j][1], dXact=ddo[j],
                                      **bpar(f"{pre}ln_cross.{j}.", D)) for j in range(F)], D, "bwd.cross.norm_old", False, False, False, False)
-                self._wgrad([dict(dY=ddo[j], X=sv["xa1"][j], dW=G2(f"{pre}cross_down.{j}.weight"), db=Gv(f"{pre}cross_down.{j}.bias")) for j in range(F)],
-                            "bwd.cross.down_old.wgrad")
+                xw += [dict(dY=ddo[j], X=sv["xa1"][j], dW=G2(f"{pre}cross_down.{j}.weight"), db=Gv(f"{pre}cross_down.{j}.bias")) for j in range(F)]
+                self._wgrad(xw, "bwd.cross.wgrad")   # before the data gradient below overwrites ga
                 self._gemm([dict(A=ddo[j], W=P.actT(f"{pre}cross_down.{j}.weight"), R=dx[j], C32=dx[j], Cact=ga[j]) for j in range(F)], "bwd.cross.down_old.dgrad")
             if split_cond:
                 cond_backward(f".l{l}a")   # the modules used so far: (final norms,) the norm in front of the MLP, ln_cross
