@@ -152,9 +152,11 @@ __global__ __launch_bounds__(256) void rownorm_kernel(const NormLaunch L) {
 // A FEW LONG rows (the KV-cache step of the shipped widths: one row of 8192 / 16384 hidden values per field): a wave per row walks such a row in three
 // dependent passes of d / 256 iterations (78 us for 2 rows of 16384 at the multiphase width).  Here a workgroup of 1024 threads owns a row: every thread
 // keeps its d / 4096 pieces of 4 columns in registers (one memory round trip), the two statistics cross the 16 waves through LDS.  d <= 32768.
-template <typename T, bool X_IS_ACT>
+// KM = 1 (d <= 4096: a KV-cache step's rows at the shipped widths): the gains, shifts and modulations of the thread's one piece are requested WITH the row, so the launch is
+// one memory round trip, not two (the wave-per-row kernel below takes 8 us for 2 rows of 2048, three dependent passes of 8 pieces).
+template <typename T, bool X_IS_ACT, int KM>
 __global__ __launch_bounds__(1024) void rownorm_fewrows_kernel(const NormLaunch L) {
-    constexpr int KM = 8, NT = 1024;
+    constexpr int NT = 1024;
     __shared__ float red[2][NT / 64];
     const SeaNormGroup& G = L.g[blockIdx.y];
     const int row = (int)blockIdx.x, tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -166,6 +168,18 @@ __global__ __launch_bounds__(1024) void rownorm_fewrows_kernel(const NormLaunch 
     T* yact = G.Yact != nullptr ? static_cast<T*>(G.Yact) + (int64_t)row * G.ldyact : nullptr;
     const float inv_d = 1.0f / (float)d;
     float xv[KM][4];
+    float pg[4] = {0.f, 0.f, 0.f, 0.f}, pb[4] = {0.f, 0.f, 0.f, 0.f}, pw[4] = {0.f, 0.f, 0.f, 0.f}, pm[4] = {0.f, 0.f, 0.f, 0.f};   // KM == 1: requested up front
+    if constexpr (KM == 1) {
+        const int i = tid * 4;
+        if (i < d) {
+            load4(G.gamma + i, pg);
+            if (G.beta != nullptr) load4(G.beta + i, pb);
+            if (mod != nullptr) {
+                load4(mod + i, pw);
+                load4(mod + d + i, pm);
+            }
+        }
+    }
 #pragma unroll
     for (int k = 0; k < KM; ++k) {
         const int i = tid * 4 + NT * 4 * k;
@@ -220,11 +234,16 @@ __global__ __launch_bounds__(1024) void rownorm_fewrows_kernel(const NormLaunch 
         const int i = tid * 4 + NT * 4 * k;
         if (i < d) {
             float g1[4], b1[4] = {0.f, 0.f, 0.f, 0.f}, w1[4] = {0.f, 0.f, 0.f, 0.f}, m1[4] = {0.f, 0.f, 0.f, 0.f}, o[4];
-            load4(G.gamma + i, g1);
-            if (G.beta != nullptr) load4(G.beta + i, b1);
-            if (mod != nullptr) {
-                load4(mod + i, w1);
-                load4(mod + d + i, m1);
+            if constexpr (KM == 1) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) g1[e] = pg[e], b1[e] = pb[e], w1[e] = pw[e], m1[e] = pm[e];
+            } else {
+                load4(G.gamma + i, g1);
+                if (G.beta != nullptr) load4(G.beta + i, b1);
+                if (mod != nullptr) {
+                    load4(mod + i, w1);
+                    load4(mod + d + i, m1);
+                }
             }
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -263,13 +282,20 @@ extern "C" int sea_rownorm(const SeaNormGroup* groups, int n_groups, int M, int 
     L.M = M; L.d = d; L.gelu = gelu; L.eps = eps;
     const dim3 grid((M + 3) / 4, n_groups), block(256);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (M <= 32 && d > 2048 && d <= 32768) {   // a few long rows: a workgroup per row
+    if (M <= 32 && d >= 1024 && d <= 32768) {   // a few long rows: a workgroup per row
         const dim3 gridw(M, n_groups), blockw(1024);
-        if (dtype == SEA_BF16) {
-            if (x_is_act) rownorm_fewrows_kernel<__bf16, true><<<gridw, blockw, 0, s>>>(L);
-            else rownorm_fewrows_kernel<__bf16, false><<<gridw, blockw, 0, s>>>(L);
+        if (d <= 4096) {
+            if (dtype == SEA_BF16) {
+                if (x_is_act) rownorm_fewrows_kernel<__bf16, true, 1><<<gridw, blockw, 0, s>>>(L);
+                else rownorm_fewrows_kernel<__bf16, false, 1><<<gridw, blockw, 0, s>>>(L);
+            } else {
+                rownorm_fewrows_kernel<float, false, 1><<<gridw, blockw, 0, s>>>(L);
+            }
+        } else if (dtype == SEA_BF16) {
+            if (x_is_act) rownorm_fewrows_kernel<__bf16, true, 8><<<gridw, blockw, 0, s>>>(L);
+            else rownorm_fewrows_kernel<__bf16, false, 8><<<gridw, blockw, 0, s>>>(L);
         } else {
-            rownorm_fewrows_kernel<float, false><<<gridw, blockw, 0, s>>>(L);
+            rownorm_fewrows_kernel<float, false, 8><<<gridw, blockw, 0, s>>>(L);
         }
         SEA_CHECK_LAUNCH("sea_rownorm");
         return SEA_OK;

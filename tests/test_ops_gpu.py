@@ -136,7 +136,7 @@ def test_gemm_few_rows_long_contraction_and_gelu(M, K, N_):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("M,d", [(1, 8192), (2, 16384), (5, 4096), (3, 2052)])
+@pytest.mark.parametrize("M,d", [(1, 8192), (2, 16384), (5, 4096), (3, 2052), (2, 2048), (3, 1024), (16, 1028), (32, 4100)])
 def test_rownorm_few_long_rows(dtype, M, d):
     """A few long rows (the MLP's LayerNorm + GELU of a KV-cache step at the shipped widths): a workgroup per row.  LayerNorm + GELU of act rows, and the
     modulated form on fp32 rows with both outputs and the statistics."""
@@ -159,6 +159,22 @@ def test_rownorm_few_long_rows(dtype, M, d):
     ref = (x32 - mu) / torch.sqrt(var + 1e-5) * (lnw + 1 + mod[:, :d].float()) + lnb + mod[:, d:].float()
     assert rel(y32, ref) < 1e-5 and rel(ya.float(), ref) < tol(dtype, f32=1e-5, bf16=6e-3)
     assert rel(mean, mu[:, 0]) < 1e-4 and rel(rstd, 1 / torch.sqrt(var[:, 0] + 1e-5)) < 1e-5
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,d", [(2, 2048), (3, 1024)])
+def test_rownorm_few_rows_with_addend(dtype, M, d):
+    """The one-round-trip form (d <= 4096) with the info-bottleneck addend: x + addend is written back exactly and normalised (plain LayerNorm, no beta)."""
+    from sea_amd import ops
+
+    x, add = rnd(M, d, seed=1710), 0.2 * rnd(M, d, seed=1711)
+    g = 1 + 0.1 * rnd(d, seed=1712)
+    xio, ya = x.clone(), torch.empty(M, d, device=dev(), dtype=dtype)
+    ops.rownorm([dict(X=xio, addend=add, Xout=xio, gamma=g, Yact=ya)], M, d, False, False, 1e-5, dtype)
+    xs = x + add
+    assert torch.equal(xio, xs)
+    ref = torch.nn.functional.layer_norm(xs, (d,), g, None, 1e-5)
+    assert rel(ya.float(), ref) < tol(dtype, f32=1e-5, bf16=6e-3)
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
