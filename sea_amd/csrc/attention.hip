@@ -510,6 +510,19 @@ __global__ __launch_bounds__(512) void attention_row_wide_kernel(const SeaAttnPa
     const int vis = P.q_pos0 + P.src_len + 1;
     const int nk = vis < P.Tk ? vis : P.Tk;
     const int part = tid % LPK, k_first = tid / LPK;
+    constexpr int DPW = HD / NW;                           // value rows per wave (phase 2)
+    const int nk8 = (nk + 7) & ~7, nvec = nk8 >> 3;        // 8-key vectors of a value row
+    // Short caches in bf16 (<= 512 keys: one 8-key vector per lane): this lane's vector of EVERY value row of the wave is requested now, beside the query and
+    // the key rows — the launch is then two memory round trips (keys, values in flight together) instead of 2 + DPW / 8 (a 100-step rollout at the multiphase
+    // width: 19 us per launch at head dim 256, five dependent trips).  Addresses depend on nothing computed here.
+    constexpr bool CAN_PRE = sizeof(T) == 2;
+    const bool pre = CAN_PRE && nvec <= 64;                // block-uniform
+    uint4 vpre[CAN_PRE ? DPW : 1];
+    if (pre) {
+        const int v = lane < nvec ? lane : nvec - 1;
+#pragma unroll
+        for (int i = 0; i < DPW; ++i) vpre[i] = *reinterpret_cast<const uint4*>(Vg + (int64_t)(wave * DPW + i) * P.cap + v * 8);
+    }
     float q[32];
 #pragma unroll
     for (int c = 0; c < 8; ++c) load4(Qg + part * 32 + c * 4, *reinterpret_cast<float(*)[4]>(q + c * 4));
@@ -558,7 +571,6 @@ __global__ __launch_bounds__(512) void attention_row_wide_kernel(const SeaAttnPa
         prob[key] = pv;
         ls += pv;
     }
-    const int nk8 = (nk + 7) & ~7;
     if (tid < nk8 - nk) prob[nk + tid] = 0.f;              // the tail of the last 8-key vector
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) ls += __shfl_xor(ls, o);
@@ -569,10 +581,30 @@ __global__ __launch_bounds__(512) void attention_row_wide_kernel(const SeaAttnPa
     for (int w = 0; w < NW; ++w) l += red[NW + w];
     const float inv = 1.0f / l;
     // ---- phase 2: wave w owns value rows d = w * DPW .. + DPW - 1, eight at a time
-    const int nvec = nk8 >> 3;
     T* Og = static_cast<T*>(pr.O) + (int64_t)b * P.ldo + h * HD;
-    constexpr int DPW = HD / NW, DCH = 8;
+    constexpr int DCH = 8;
     constexpr int VPC = 8 * (int)sizeof(T) / 16;
+    if constexpr (CAN_PRE) {
+        if (pre) {
+            float pv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // lanes beyond the last vector hold a clamped copy of it: zero weights
+            if (lane < nvec) {
+                load4(prob + lane * 8, *reinterpret_cast<float(*)[4]>(pv));
+                load4(prob + lane * 8 + 4, *reinterpret_cast<float(*)[4]>(pv + 4));   // keys >= nk of the last vector: prob is 0 there
+            }
+#pragma unroll
+            for (int i = 0; i < DPW; ++i) {
+                float vv[8];
+                unpack16<T>(vpre[i], vv);
+                float acc = 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc += pv[e] * (lane * 8 + e < nk ? vv[e] : 0.f);   // 0 * garbage beyond nk must stay 0
+#pragma unroll
+                for (int o = 32; o >= 1; o >>= 1) acc += __shfl_xor(acc, o);
+                if (lane == 0) Og[wave * DPW + i] = from_f32<T>(acc * inv);
+            }
+            return;
+        }
+    }
     for (int dc = 0; dc < DPW; dc += DCH) {
         float acc[DCH];
 #pragma unroll
