@@ -490,7 +490,7 @@ __global__ __launch_bounds__(512) void attention_row_kernel(const SeaAttnParams 
     (void)EPC;
 }
 
-// The same for WIDE heads (128 / 256: the shipped widths, embed_dim 1024 / 2048 over 8 heads), where a thread cannot hold the query and a key row:
+// The same for WIDE heads (64, and 128 / 256: the shipped widths, embed_dim 1024 / 2048 over 8 heads), where a thread cannot hold the query and a key row:
 // HD / 32 adjacent lanes share a key (32 columns each, the partial dot products meet by lane shuffles), the raw scores go to LDS and are turned into
 // probabilities by a second pass (no per-thread score array: any number of keys), and phase 2 walks a wave's HD / 8 value rows 8 at a time.
 template <typename T, int HD>
@@ -652,12 +652,12 @@ static bool launch_attention_row(const SeaAttnParams& P, hipStream_t s) {
     const dim3 grid(P.B * P.H, P.n_problems), block(512);
     const int lds = (2 * 8 + 16 + ((P.Tk + 7) & ~7) + 8) * 4;
     switch (P.hd) {
+        case 64: attention_row_wide_kernel<T, 64><<<grid, block, lds, s>>>(P); return true;   // (a thread that holds a 64-column query AND key rows spills: 879 registers in bf16)
         case 128: attention_row_wide_kernel<T, 128><<<grid, block, lds, s>>>(P); return true;
         case 256: attention_row_wide_kernel<T, 256><<<grid, block, lds, s>>>(P); return true;
         case 8: attention_row_kernel<T, 8><<<grid, block, lds, s>>>(P); break;
         case 16: attention_row_kernel<T, 16><<<grid, block, lds, s>>>(P); break;
-        case 32: attention_row_kernel<T, 32><<<grid, block, lds, s>>>(P); break;
-        default: attention_row_kernel<T, 64><<<grid, block, lds, s>>>(P); break;
+        default: attention_row_kernel<T, 32><<<grid, block, lds, s>>>(P); break;
     }
     return true;
 }
