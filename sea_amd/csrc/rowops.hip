@@ -472,6 +472,46 @@ __global__ __launch_bounds__(256) void ib_add_kernel(const SeaIbParams P) {
     }
 }
 
+// A few rows of a wide model ('mlp' layers, h = 8, no dropout: a KV-cache step at the shipped widths): a workgroup per row, a thread per 4 output columns,
+// and EVERYTHING the thread needs — its rows of w2, b2, the fields' x — requested before the first wait, beside the condition and the hidden layer's
+// parameters: one memory round trip (the wave-per-quarter-row form above walks two column passes behind the hidden vector: 7.6 us at embed_dim 2048).
+__global__ __launch_bounds__(1024) void ib_add_fewrows_kernel(const SeaIbParams P) {
+    constexpr int H8 = 8, MAXF = 4;
+    const int lane = threadIdx.x & 63, row = (int)blockIdx.x;
+    const int e0 = (int)threadIdx.x * 4;
+    const bool live = e0 < P.E;
+    const int ec = live ? e0 : 0;
+    float w[4][H8], o[4], xv[MAXF][4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        load4(P.w2 + (int64_t)(ec + e) * H8, *reinterpret_cast<float(*)[4]>(w[e]));
+        load4(P.w2 + (int64_t)(ec + e) * H8 + 4, *reinterpret_cast<float(*)[4]>(w[e] + 4));
+    }
+    load4(P.b2 + ec, o);
+#pragma unroll
+    for (int f = 0; f < MAXF; ++f)
+        if (f < P.n_fields) load4(P.X[f] + (int64_t)row * P.ldx + ec, xv[f]);
+    const float cv = P.c[row];
+    const bool act = lane < H8;
+    const float pre = act ? P.w1[lane] * cv + P.b1[lane] : 0.f;
+    const float lw = act ? P.lnw[lane] : 0.f, lb = act ? P.lnb[lane] : 0.f;
+    const float mean = wave_sum(pre) / (float)H8;
+    const float cen = act ? pre - mean : 0.f;
+    const float var = wave_sum(cen * cen) / (float)H8;
+    const float rstd = 1.0f / sqrtf(var + 1e-5f);
+    const float hid = act ? gelu_erf(cen * rstd * lw + lb) : 0.f;
+#pragma unroll
+    for (int k = 0; k < H8; ++k) {
+        const float hk = __shfl(hid, k);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] += w[e][k] * hk;
+    }
+    if (!live) return;
+#pragma unroll
+    for (int f = 0; f < MAXF; ++f)
+        if (f < P.n_fields) store4(P.X[f] + (int64_t)row * P.ldx + e0, xv[f][0] + o[0], xv[f][1] + o[1], xv[f][2] + o[2], xv[f][3] + o[3]);
+}
+
 extern "C" int sea_ib_add(const SeaIbParams* params, void* stream) {
     SEA_REQUIRE(params != nullptr, "sea_ib_add: null params");
     const SeaIbParams& P = *params;
@@ -487,7 +527,9 @@ extern "C" int sea_ib_add(const SeaIbParams* params, void* stream) {
         SEA_REQUIRE(P.c && P.w1 && sea_aligned16(P.w1) && (P.mode == 2 || (P.b1 && sea_aligned16(P.b1))), "sea_ib_add: null / misaligned parameter pointer");
     }
     for (int f = 0; f < P.n_fields; ++f) SEA_REQUIRE(P.X[f] && sea_aligned16(P.X[f]), "sea_ib_add: X[%d] null or misaligned", f);
-    if (P.M <= 16 && P.E > 256) ib_add_kernel<true><<<dim3(P.M), dim3(256), 0, static_cast<hipStream_t>(stream)>>>(P);
+    if (P.mode == 0 && P.M <= 16 && P.E >= 1024 && P.E <= 4096 && P.h == 8 && P.n_fields <= 4 && P.drop.thr == 0)
+        ib_add_fewrows_kernel<<<dim3(P.M), dim3((P.E / 4 + 63) / 64 * 64), 0, static_cast<hipStream_t>(stream)>>>(P);
+    else if (P.M <= 16 && P.E > 256) ib_add_kernel<true><<<dim3(P.M), dim3(256), 0, static_cast<hipStream_t>(stream)>>>(P);
     else ib_add_kernel<false><<<dim3((P.M + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream)>>>(P);
     SEA_CHECK_LAUNCH("sea_ib_add");
     return SEA_OK;

@@ -742,10 +742,12 @@ def test_silu_outer_and_cond_gemm(dtype):
         assert rel(g["Hid"].float(), r) < tol(dtype, f32=1e-6)
 
 
-def test_ib_add():
+@pytest.mark.parametrize("M,E,h,F", [(101, 256, 8, 3), (1, 2048, 8, 2), (3, 1024, 8, 3), (2, 1028, 8, 1), (16, 4096, 8, 4), (2, 2048, 12, 2), (17, 1024, 8, 2)])
+def test_ib_add(M, E, h, F):
+    """Many rows (a wave per row), and a few rows of a wide model: the one-round-trip kernel (h = 8, 1024 <= E <= 4096, up to 4 fields), the
+    wave-per-quarter-row form otherwise."""
     from sea_amd import ops
 
-    M, E, h, F = 101, 256, 8, 3
     xb = rnd(M, F * E, seed=170)
     xs = [xb[:, i * E:(i + 1) * E] for i in range(F)]
     x0 = xb.clone()
