@@ -208,16 +208,28 @@ __device__ __forceinline__ int find_group_blk(const SkinnyLaunch& launch, int bi
     return gi;
 }
 
-// epilogue of the few-row kernels — this lane: output row r, columns n0 + 4 g .. + 3; bias, GELU (act 1, pre-activation kept in Z), residual, fp32 / bf16 outputs
-__device__ __forceinline__ void skinny_epilogue(const SeaGemmGroup& G, const f32x4& acc, int r, int g, int n0) {
+// epilogue operands of the few-row kernels (this lane: output row r, columns n0 + 4 g .. + 3), requested by wave 0 BEFORE the contraction: behind it they
+// were a second memory round trip on a launch that is little more than one (12 such launches per KV-cache step at the shipped widths)
+struct SkinnyEpiPre {
+    float bv[4], rv[4];
+};
+__device__ __forceinline__ void skinny_epilogue_request(const SeaGemmGroup& G, int r, int g, int n0, SkinnyEpiPre& E) {
+    const int nc = n0 + g * 4;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) E.bv[q] = E.rv[q] = 0.f;
+    if (r >= G.M || nc >= G.N) return;
+    if (G.bias != nullptr) load4(G.bias + nc, E.bv);
+    if (G.R != nullptr) load4(G.R + (int64_t)r * G.ldr + nc, E.rv);
+}
+
+// epilogue of the few-row kernels: bias, GELU (act 1, pre-activation kept in Z), residual, fp32 / bf16 outputs
+__device__ __forceinline__ void skinny_epilogue(const SeaGemmGroup& G, const f32x4& acc, int r, int g, int n0, const SkinnyEpiPre& E) {
     const int nc = n0 + g * 4;
     if (r >= G.M || nc >= G.N) return;
     float v[4] = {acc[0], acc[1], acc[2], acc[3]};
     if (G.bias != nullptr) {
-        float bv[4];
-        load4(G.bias + nc, bv);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) v[q] += bv[q] * G.bias_scale;
+        for (int q = 0; q < 4; ++q) v[q] += E.bv[q] * G.bias_scale;
     }
     if (G.act == 1) {
         if (G.Z != nullptr) store4(static_cast<__bf16*>(G.Z) + (int64_t)r * G.ldz + nc, v[0], v[1], v[2], v[3]);
@@ -225,10 +237,8 @@ __device__ __forceinline__ void skinny_epilogue(const SeaGemmGroup& G, const f32
         for (int q = 0; q < 4; ++q) v[q] = gelu_erf(v[q]);
     }
     if (G.R != nullptr) {
-        float rv[4];
-        load4(G.R + (int64_t)r * G.ldr + nc, rv);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) v[q] += rv[q];
+        for (int q = 0; q < 4; ++q) v[q] += E.rv[q];
     }
     if (G.C32 != nullptr) store4(G.C32 + (int64_t)r * G.ldc32 + nc, v[0], v[1], v[2], v[3]);
     if (G.Cact != nullptr) store4(static_cast<__bf16*>(G.Cact) + (int64_t)r * G.ldcact + nc, v[0], v[1], v[2], v[3]);
@@ -259,6 +269,8 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const SkinnyLaunch L) 
     const __bf16* Arow = static_cast<const __bf16*>(G.A) + (int64_t)m * G.lda + g * 8;
     const __bf16* Wrow = static_cast<const __bf16*>(G.W) + (int64_t)n * G.ldw + g * 8;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    SkinnyEpiPre epi;
+    if (wave == 0) skinny_epilogue_request(G, r, g, n0, epi);
     const int k0 = wave * kq;
     switch (kq >> 5) {   // block-uniform
         case 2: skinny_quarter<2>(Arow, Wrow, k0, acc); break;
@@ -277,7 +289,7 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const SkinnyLaunch L) 
         const float4 p = *reinterpret_cast<const float4*>(red[w][lane]);
         acc[0] += p.x; acc[1] += p.y; acc[2] += p.z; acc[3] += p.w;
     }
-    skinny_epilogue(G, acc, r, g, n0);
+    skinny_epilogue(G, acc, r, g, n0, epi);
 }
 
 // The same for LONG contractions (fc2 of the shipped widths: K = 8192 / 16384 for one row per field; the tiled kernels give such a launch to N / 128
@@ -299,6 +311,8 @@ __global__ __launch_bounds__(512) void gemm_skinny_long_kernel(const SkinnyLaunc
     const __bf16* Wrow = static_cast<const __bf16*>(G.W) + (int64_t)n * G.ldw + g * 8 + wave * kw;
     const int rounds = kw / (32 * RS);
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    SkinnyEpiPre epi;
+    if (wave == 0) skinny_epilogue_request(G, r, g, n0, epi);
     uint4 w0[RS], a0[RS], w1[RS], a1[RS];
 #pragma unroll
     for (int i = 0; i < RS; ++i) {
@@ -336,7 +350,7 @@ __global__ __launch_bounds__(512) void gemm_skinny_long_kernel(const SkinnyLaunc
         const float4 p = *reinterpret_cast<const float4*>(red[w][lane]);
         acc[0] += p.x; acc[1] += p.y; acc[2] += p.z; acc[3] += p.w;
     }
-    skinny_epilogue(G, acc, r, g, n0);
+    skinny_epilogue(G, acc, r, g, n0, epi);
 }
 
 // ---------------------------------------------------------------------------------------------- QKV + RoPE epilogue
