@@ -482,6 +482,23 @@ __global__ __launch_bounds__(256) void qkv_skinny_kernel(const QkvSkinnyLaunch L
     const T* Arow = static_cast<const T*>(G.A) + (int64_t)m * G.lda + g * 8;
     const T* Wrow = static_cast<const T*>(G.W) + (int64_t)nr * G.ldw + g * 8;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    // epilogue operands (bias, the rotary pair of this lane's columns): requested by wave 0 before the contraction, like skinny_epilogue_request
+    const int H = L.c.H, hd = L.c.hd, Tlen = L.c.T, cap = L.c.cap;
+    const int Ea = H * hd, hd2 = hd >> 1;
+    const int n = n0 + g * 4;                             // this lane: row r, columns n .. n + 3 of the group
+    const int nb = G.col0 + n0;                           // first column of the block in the virtual [q | k | v] row (block-uniform)
+    const int part = nb >= 2 * Ea ? 2 : (nb >= Ea ? 1 : 0);
+    const int hb = nb - part * Ea;
+    const int h = hb / hd;
+    const int dd = hb - h * hd + g * 4;
+    const int bidx = r / Tlen, tt = r - bidx * Tlen, pos = L.c.pos0 + tt;
+    const bool live = r < G.M && n < G.N;
+    float bv[4] = {0.f, 0.f, 0.f, 0.f};
+    float4 cs = make_float4(1.f, 0.f, 1.f, 0.f);
+    if (wave == 0 && live) {
+        if (G.bias != nullptr) load4(G.bias + n, bv);
+        if (part < 2) cs = *reinterpret_cast<const float4*>(reinterpret_cast<const float2*>(L.c.rope) + (uint32_t)pos * (uint32_t)hd2 + (dd >> 1));
+    }
     const int k0 = wave * kq;
     switch (kq >> 5) {   // block-uniform
         case 2: skinny_quarter<2>(Arow, Wrow, k0, acc); break;
@@ -500,26 +517,10 @@ __global__ __launch_bounds__(256) void qkv_skinny_kernel(const QkvSkinnyLaunch L
         const float4 p = *reinterpret_cast<const float4*>(red[w][lane]);
         acc[0] += p.x; acc[1] += p.y; acc[2] += p.z; acc[3] += p.w;
     }
-    const int n = n0 + g * 4;                             // this lane: row r, columns n .. n + 3 of the group
-    if (r >= G.M || n >= G.N) return;
-    const int H = L.c.H, hd = L.c.hd, Tlen = L.c.T, cap = L.c.cap;
-    const int Ea = H * hd, hd2 = hd >> 1;
-    float v[4] = {acc[0], acc[1], acc[2], acc[3]};
-    if (G.bias != nullptr) {
-        float bv[4];
-        load4(G.bias + n, bv);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) v[q] += bv[q];
-    }
-    const int nb = G.col0 + n0;                           // first column of the block in the virtual [q | k | v] row (block-uniform)
-    const int part = nb >= 2 * Ea ? 2 : (nb >= Ea ? 1 : 0);
-    const int hb = nb - part * Ea;
-    const int h = hb / hd;
-    const int dd = hb - h * hd + g * 4;
-    const int bidx = r / Tlen, tt = r - bidx * Tlen, pos = L.c.pos0 + tt;
+    if (!live) return;
+    float v[4] = {acc[0] + bv[0], acc[1] + bv[1], acc[2] + bv[2], acc[3] + bv[3]};   // bv is zero without a bias
     const uint32_t bh = (uint32_t)(bidx * H + h);
     if (part < 2) {
-        const float4 cs = *reinterpret_cast<const float4*>(reinterpret_cast<const float2*>(L.c.rope) + (uint32_t)pos * (uint32_t)hd2 + (dd >> 1));
         float o[4];
         rope_pair(v[0], v[1], cs.x, cs.y, o[0], o[1]);
         rope_pair(v[2], v[3], cs.z, cs.w, o[2], o[3]);
