@@ -417,7 +417,8 @@ int sea_adamw_flat(float* p, const float* g, float* m, float* v, void* shadow, i
  * ============================================================================================================ */
 
 /* Weight gradient of y = x W^T + b for several layers per launch: dW[N,K] += dY[M,N]^T . X[M,K]; db[N] += sum_m dY[m,:]
- * (db may be NULL).  The contraction over M is split across workgroups.  N % 8 == 0, K % 8 == 0. */
+ * (db may be NULL).  The contraction over M is split across workgroups.  N % 8 == 0, K % 8 == 0.  At most 32 groups per call (weight gradients
+ * have no consumers inside the backward: a caller may collect the small ones of a layer and run them as one call). */
 typedef struct {
     const void* dY; /* act [M, N] row stride lddy */
     const void* X;  /* act [M, K] row stride ldx */
