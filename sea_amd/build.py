@@ -68,6 +68,20 @@ def _stale(target: str, deps) -> bool:
 
 
 def build(force: bool = False, verbose: bool = True) -> str:
+    """Compile what is stale, lint every device listing, link.  Serialised by a file lock: several rank processes (bench.py --gpus N, mp.spawn tests)
+    may call this at once on a box where the objects are missing (csrc/build does not travel), and must not remove each other's temporaries."""
+    import fcntl
+
+    os.makedirs(BUILD, exist_ok=True)
+    with open(os.path.join(CSRC, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            return _build_locked(force, verbose)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
+def _build_locked(force: bool, verbose: bool) -> str:
     hipcc = _hipcc()
     srcs = [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
     hdrs = [os.path.join(CSRC, h) for h in HEADERS]
@@ -98,7 +112,10 @@ def build(force: bool = False, verbose: bool = True) -> str:
     for f in os.listdir(BUILD):   # -save-temps leaves preprocessed sources, bitcode and host listings (tens of MB): only objects and device listings are kept
         stem = f.split("-hip-")[0].split(".")[0]
         if (not (f.endswith(".o") and "-hip-" not in f) and not f.endswith("-hip-amdgcn-amd-amdhsa-gfx950.s")) or stem + ".hip" not in srcs:
-            os.remove(os.path.join(BUILD, f))
+            try:
+                os.remove(os.path.join(BUILD, f))
+            except FileNotFoundError:
+                pass
     findings = []
     for obj in objs:
         for kernel, no, ins in lint_isa(_asm_of(obj)):

@@ -1738,7 +1738,15 @@ static bool run_persistent(const SeaKvGlobal& G, const SeaKvLayer* layers, int p
         const int F = G.F, E = G.E, D = G.D, S = G.S, H = G.H, ex = G.exchange;
         const int hd_s = E / H;
         if (hd_s != 16 && hd_s != 32) return false;
-        static const int cus = []() { int n = 0; return hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, 0) == hipSuccess ? n : 0; }();
+        // the CU count of the device this call runs on (one process per GPU: rank r's current device is not device 0)
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
+        static int cu_of[64] = {0};
+        if (cu_of[dev] == 0) {
+            int n = 0;
+            cu_of[dev] = hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0 ? n : -1;
+        }
+        const int cus = cu_of[dev];
         const int fixed = F * H + F + (ex ? F * (F - 1) * H + F : 0) + F;
         const int room = (cus - fixed) / F;
         if (room < 1) return false;
@@ -1771,9 +1779,22 @@ static bool run_persistent(const SeaKvGlobal& G, const SeaKvLayer* layers, int p
         lds = lds > lds_t ? lds : lds_t;
         lds = lds > lds_f ? lds : lds_f;
         lds = lds > lds_b ? lds : lds_b;
+        // Every workgroup of this launch waits for others: all of them must be resident at once.  The grid is at most one 512-thread workgroup per CU;
+        // the launch is COOPERATIVE, so that the runtime checks the grid against the kernel's occupancy (registers, this LDS request) on this device and
+        // refuses it (hipErrorCooperativeLaunchTooLarge -> the seven-launch form) instead of starting a grid that can never finish its first hand-off.  What
+        // no launch-time check can see — another process or stream holding CUs — is covered by the bounded spins and the error word (kv_engine.py).
         const dim3 grid(fixed + F * n_fcf), block(512);
-        if (hd_s == 32) kv_persistent_kernel<KE, T, 32, 16><<<grid, block, lds * 4, s>>>(A);
-        else kv_persistent_kernel<KE, T, 16, 8><<<grid, block, lds * 4, s>>>(A);
+        const void* fn = hd_s == 32 ? reinterpret_cast<const void*>(&kv_persistent_kernel<KE, T, 32, 16>) : reinterpret_cast<const void*>(&kv_persistent_kernel<KE, T, 16, 8>);
+        int per_cu = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 512, (size_t)lds * 4) != hipSuccess || per_cu < 1) {
+            (void)hipGetLastError();
+            return false;
+        }
+        void* args[] = {&A};
+        if (hipLaunchCooperativeKernel(fn, grid, block, args, (unsigned)(lds * 4), s) != hipSuccess) {
+            (void)hipGetLastError();   // refused (too large for this device / a device without cooperative launch): the seven launches per step
+            return false;
+        }
         return true;
     }
 }

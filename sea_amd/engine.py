@@ -26,6 +26,7 @@ import torch
 
 from . import _native as N
 from . import ops
+from . import ptrcheck
 
 _QKV = re.compile(r"^(.*\.)(k|q|v)\.(weight|bias)$")
 _QKV_RANK = {("q", "weight"): 0, ("k", "weight"): 1, ("v", "weight"): 2, ("q", "bias"): 3, ("k", "bias"): 4, ("v", "bias"): 5}
@@ -241,6 +242,8 @@ class Plan:
         self._pos_structs: List[object] = []                   # SeaQkvCommon / SeaAttnParams to update per step
         self._drop_structs: List[object] = []                  # structs whose .drop.seed is re-keyed every training step
         self._bound = (None, None, None)
+        self._bound_tensors = None        # (x, ib, out) of the last bind(): held until the next one (see bind)
+        self._audited = False             # the pointer audit has run on this plan (ptrcheck)
         self._lane = 0                    # lane the record builders tag new records with
         self._lane_streams: Dict[int, torch.cuda.Stream] = {}
         self._zero_ib: Optional[torch.Tensor] = None   # 'concat': the zeros the info-bottleneck columns are reset to
@@ -815,7 +818,40 @@ class Plan:
 
     # ------------------------------------------------------------------ binding and replay
     def bind(self, x: torch.Tensor, ib: torch.Tensor, out: torch.Tensor) -> None:
+        """Point the plan at the caller's tensors.  The plan knows them by raw address only, so it HOLDS them until the next bind: a launch list that is
+        still executing (the host runs several steps ahead of the device) must never see its output block returned to the allocator — and possibly
+        unmapped, e.g. by the cache flush a graph capture starts with — because the caller dropped the tensor."""
+        self._bound_tensors = (x, ib, out)
         self.bind_ptrs(x.data_ptr(), ib.data_ptr(), out.data_ptr())
+        if not self._audited or ptrcheck.always():
+            self.audit()
+
+    def _known_ranges(self, owners=()) -> "ptrcheck.Ranges":
+        eng, R = self.eng, ptrcheck.Ranges()
+        for t in self._keep:
+            R.add_tensor(t, "plan workspace")
+        P = eng.params
+        for t, label in ((P.flat32, "flat32"), (P.flat_act, "flat_act"), (P.flat_actT, "flat_actT"), (eng.grads, "grads"), (eng.rope_self, "rope_self"),
+                         (eng.rope_cross, "rope_cross"), (getattr(self, "_ws_colsum", None), "column-sum workspace"), (self._zero_ib, "zero rows")):
+            R.add_tensor(t, label)
+        for t in eng._eyes.values():
+            R.add_tensor(t, "identity / rotation table")
+        for t, label in zip(getattr(self, "_bound_tensors", ()) or (), ("x", "condition", "out")):
+            R.add_tensor(t, "bound " + label)
+        for t in owners:
+            R.add_tensor(t, "caller buffer")
+        return R
+
+    def audit(self, owners=()) -> int:
+        """Every device pointer of every launch record lies inside a buffer this plan knows, operands with their full extent (sea_amd/ptrcheck.py).
+        Runs at the first bind of a plan and at every bind under SEA_CHECK_PTRS=1."""
+        esz = 4 if self.dt == torch.float32 else 2
+        n = ptrcheck.check_records(self._all_records(), self._known_ranges(owners), esz, f"{type(self).__name__} B={self.B} T={self.T} {self.mode}")
+        self._audited = True
+        return n
+
+    def _all_records(self):
+        return self.records
 
     def bind_ptrs(self, xp: int, cp: int, op: int) -> None:
         """Point the plan at the caller's buffers: x [M, F, E] fp32, condition [M] fp32, out [M, F, E] fp32 (row m = b*T + t)."""
@@ -1077,6 +1113,7 @@ class TemporalEngine:
         self.grads: Optional[torch.Tensor] = None      # flat fp32 gradient buffer, same layout as params.flat32
         self.grads_dirty = False                       # True once a backward has accumulated into it since the last zero
         self._drop_step = 0                            # dropout streams are re-keyed every training forward
+        self._dp_overlap: Optional[Tuple[int, bool]] = None   # (world size, slices under the backward?) — see dp_overlap()
         self._loss_ws: Optional[Tuple[torch.Tensor, torch.Tensor, torch.Tensor]] = None
 
     def eye(self, n: int) -> torch.Tensor:
@@ -1150,14 +1187,31 @@ class TemporalEngine:
                                       "models/base_blocks.py:371-372: no counter-based mask is defined for that site)")
         if thr > 255:
             raise ValueError("dropout probability too close to 1")
-        key = (B, T, thr)
+        dp = self.dp_overlap()
+        key = (B, T, thr, dp)
         p = self._train_plans.get(key)
         if p is None:
             if T > m.max_len:
                 raise ValueError(f"sequence length {T} exceeds max_len {m.max_len}")
-            p = TrainPlan(self, B, T, drop_thr=thr)
+            p = TrainPlan(self, B, T, drop_thr=thr, dp=dp)
             self._train_plans[key] = p
         return p
+
+    def dp_overlap(self) -> bool:
+        """Reduce the gradient buffer in slices under the backward (parallel.OverlappedGradientReduce)?  Decided ONCE per engine and process group, and
+        AGREED between the ranks (a MIN all-reduce of each rank's SEA_DP_OVERLAP switch): the number of collectives a step issues follows from it, so ranks
+        that disagreed, or a switch flipped between two steps, would deadlock.  False without a process group / at world size 1; a group initialised later
+        is seen at the next step (the training plans are keyed on the answer)."""
+        import torch.distributed as dist
+
+        world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+        if world == 1:
+            return False
+        if self._dp_overlap is None or self._dp_overlap[0] != world:
+            want = torch.tensor([0 if os.environ.get("SEA_DP_OVERLAP", "1") == "0" else 1], device=self.device, dtype=torch.int32)
+            dist.all_reduce(want, op=dist.ReduceOp.MIN)
+            self._dp_overlap = (world, bool(int(want.item())))
+        return self._dp_overlap[1]
 
     def forward_train(self, x: torch.Tensor, ib: torch.Tensor):
         """Forward that keeps the activations the backward needs.  Returns (out, plan)."""
@@ -1181,6 +1235,9 @@ class TemporalEngine:
         as soon as self.grads[lo:hi] is final (TrainPlan.grad_buckets), while later launches are still being issued."""
         assert dout.is_contiguous() and dout.dtype == torch.float32
         plan.bind_dout(dout.data_ptr())
+        plan._bound_dout = dout          # held until the next backward: the launch list knows it by address only
+        if ptrcheck.always():
+            plan.audit(owners=(dout,))
         plan.run_backward(on_bucket)
         self.grads_dirty = True
 
@@ -1203,10 +1260,14 @@ class TemporalEngine:
         optimizer.zero_grad(set_to_none=False)
         out, plan = self.forward_train(x, ib)
         loss, dout = self.mse_loss_and_grad(out, target)
-        red = OverlappedGradientReduce(self.grads, self.params.n_live) if allreduce else None
+        red = OverlappedGradientReduce(self.grads, self.params.n_live, overlap=plan.dp) if allreduce else None
         self.backward(plan, dout, red.on_bucket if (red is not None and red.active) else None)
-        optimizer.grad_scale = red.finish() if red is not None else 1.0
+        scale = red.finish() if red is not None else 1.0
         self.last_allreduce_calls = red.calls if red is not None else 0
+        if hasattr(optimizer, "mark_reduced"):
+            optimizer.mark_reduced(scale)       # FlatAdamW.step() would otherwise all-reduce the buffer itself
+        else:
+            optimizer.grad_scale = scale
         optimizer.step()
         return loss
 
@@ -1239,6 +1300,10 @@ class TemporalEngine:
             with torch.cuda.stream(side):
                 p.run()  # warm-up outside capture (one-time function attributes, lazy module loading)
             torch.cuda.current_stream().wait_stream(side)
+            # A capture begins with a flush of the caching allocator (freed blocks are UNMAPPED): everything issued so far — plain replays of other plans
+            # that may still write tensors the caller has since dropped — has to be complete before that, or those launches fault (seen in round 2 as a
+            # "Memory access fault" when bench.py captured a graph behind 200 plain forwards).  Once per (shape, inputs): not on the replay path.
+            torch.cuda.synchronize(self.device)
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
                 p.run(concurrent=os.environ.get("SEA_LANES", "1") != "0")
@@ -1274,6 +1339,10 @@ class TemporalEngine:
         p = self.plan(B, 1, "step")
         slab = B * F * E * 4
         base, cbase = traj.data_ptr(), cond.data_ptr()
+        if not p._audited or ptrcheck.always():   # the step plan is bound by raw address: audit it once against the buffers it will walk
+            p.set_position(0)
+            p.bind_ptrs(base, cbase, base + slab)
+            p.audit(owners=(traj, cond))
         # the step loop in native code (the plan's launch list + a table of the per-step edits); SEA_KV_NATIVE_LOOP=0: one Python round trip per step
         if os.environ.get("SEA_KV_NATIVE_LOOP", "1") == "0" or not p.run_steps(n_steps, base, slab, cbase, B * 4, base + slab, slab):
             for s in range(n_steps):

@@ -16,6 +16,7 @@ from typing import Dict, List, Optional
 import torch
 
 from . import _native as N
+from . import ptrcheck
 from .engine import Plan, _round_up
 
 
@@ -163,6 +164,8 @@ class KvFast:
             for t in cp.ibufs:
                 t.zero_()
             cp.bind_ptrs(0, cond.data_ptr(), 0)
+            if not cp._audited or ptrcheck.always():
+                cp.audit(owners=(cond,))
             cp.run()
         for nm, pre in self._norms:
             mod = cp.mods.get(pre) if (cp is not None and self.adaln) else None
@@ -175,6 +178,8 @@ class KvFast:
             N.check(rc, "sea_kv_rollout")
             self._tag = (self._tag + n_steps * self.L) & 0xFFFFFFFF or 1
             out = traj[1:].permute(1, 0, 2, 3).contiguous()
+            if attempt == 0 and os.environ.get("SEA_KV_TEST_FORCE_ERR") == "1" and self.G.handoff_words > B * F * max(self.D, 1):
+                self.err.fill_(1)           # test hook: behave as if a hand-off wait of the persistent launch had given up (tests/test_kv_fast_gpu.py)
             if int(self.err.item()) == 0:   # (synchronises)
                 return out
             # A hand-off wait gave up: the persistent form needs all its workgroups on the chip at once, which another process on the same GPU can

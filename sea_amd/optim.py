@@ -1,7 +1,12 @@
 """AdamW over the model's flat parameter buffer: one kernel launch per step (sea_adamw_flat), which also refreshes the
 activation-dtype weight shadow.  Semantics follow torch.optim.AdamW as the reference configures it
 (utils/train_utils.py:33-34): decoupled weight decay, bias-corrected moments; parameters that never receive a gradient are not
-touched and get no state (they sit beyond the live prefix of the flat buffer)."""
+touched and get no state (they sit beyond the live prefix of the flat buffer).
+
+Data parallel (one process per GPU, torch.distributed initialised): `step()` SUM-all-reduces the live prefix of the flat gradient buffer
+itself when nothing has reduced it since the last `zero_grad()` — so the reference's loop `loss.backward(); optimizer.step()`
+(train/train_temporal.py:256-257) is correct on N ranks as written — and folds the 1/world mean into the kernel's grad_scale.  The fused step
+(engine.train_step) reduces in slices under the backward and tells the optimizer so (`mark_reduced`)."""
 from __future__ import annotations
 
 from typing import Optional
@@ -21,6 +26,9 @@ class FlatAdamW(torch.optim.Optimizer):
         self._step = 0
         self._eng = None
         self.grad_scale = 1.0   # data parallel: 1 / world_size after the SUM all-reduce
+        self._reduced = False   # True once this step's gradients have been all-reduced (by engine.train_step or by step() itself)
+        self.allreduce_calls = 0   # collectives issued by step() over the optimizer's lifetime (the bench line reports it)
+        self.process_group = None
 
     def _buffers(self):
         eng = self.model.engine()
@@ -35,6 +43,7 @@ class FlatAdamW(torch.optim.Optimizer):
     def zero_grad(self, set_to_none: bool = True):
         eng = self._buffers()
         eng.zero_grads()
+        self._reduced = False
         if set_to_none:
             for p in self.model._live_params():
                 p.grad = None
@@ -45,6 +54,16 @@ class FlatAdamW(torch.optim.Optimizer):
         eng = self._buffers()
         if not eng.grads_dirty:
             return loss  # no backward since the last zero_grad: like torch, parameters without gradients are skipped
+        if not self._reduced:
+            # data parallel: ONE all-reduce of the live prefix (a no-op returning 1.0 without a process group or at world size 1)
+            from .parallel import allreduce_flat_gradients, world_size
+
+            if world_size(self.process_group) > 1:
+                self.grad_scale = allreduce_flat_gradients(eng.grads, eng.params.n_live, self.process_group)
+                self.allreduce_calls += 1
+            else:
+                self.grad_scale = 1.0
+            self._reduced = True
         g = self.param_groups[0]
         self._step += 1
         P = eng.params
@@ -58,6 +77,10 @@ class FlatAdamW(torch.optim.Optimizer):
         P._synced_version = P.flat32._version
         P.sync_transposed(force=True)
         return loss
+
+    def mark_reduced(self, grad_scale: float) -> None:
+        """engine.train_step: the gradients of this step are already summed over the ranks; `grad_scale` turns the sum into the mean."""
+        self.grad_scale, self._reduced = grad_scale, True
 
     def state_dict(self):
         sd = super().state_dict()

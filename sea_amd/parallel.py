@@ -11,6 +11,14 @@ import torch
 import torch.distributed as dist
 
 
+def world_size(group: Optional[dist.ProcessGroup] = None) -> int:
+    return dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+
+
+def rank(group: Optional[dist.ProcessGroup] = None) -> int:
+    return dist.get_rank(group) if (dist.is_available() and dist.is_initialized()) else 0
+
+
 def shard_batch(t: torch.Tensor, rank: int, world: int) -> torch.Tensor:
     """Rank r takes trajectories [r*B/world, (r+1)*B/world) of a global batch (B divisible by world)."""
     B = t.shape[0]
@@ -38,10 +46,11 @@ class OverlappedGradientReduce:
     the backward launches that follow — and `finish()` reduces what no bucket covered, waits for the early collectives and returns grad_scale.
     Every element is reduced exactly once by every rank in the same order: ranks stay bit-identical.  SEA_DP_OVERLAP=0 keeps the single collective."""
 
-    def __init__(self, flat_grads: torch.Tensor, n_live: int, group: Optional[dist.ProcessGroup] = None):
+    def __init__(self, flat_grads: torch.Tensor, n_live: int, group: Optional[dist.ProcessGroup] = None, overlap: Optional[bool] = None):
         self.grads, self.n_live, self.group = flat_grads, n_live, group
         self.world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
-        self.active = self.world > 1 and os.environ.get("SEA_DP_OVERLAP", "1") != "0"
+        # `overlap`: the engine's agreed decision (TemporalEngine.dp_overlap, frozen into the training plan); None (stand-alone use): this rank's switch
+        self.active = self.world > 1 and (os.environ.get("SEA_DP_OVERLAP", "1") != "0" if overlap is None else bool(overlap))
         self.works: List = []
         self.done: List[Tuple[int, int]] = []
         self.calls = 0

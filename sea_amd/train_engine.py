@@ -19,8 +19,9 @@ from .engine import Plan, _Rec, blk_pe
 
 
 class TrainPlan(Plan):
-    def __init__(self, eng, B: int, T: int, drop_thr: int = 0):
+    def __init__(self, eng, B: int, T: int, drop_thr: int = 0, dp: bool = False):
         self.drop_thr = drop_thr
+        self.dp = bool(dp)   # data-parallel layout of the backward (the condition MLPs' backward per phase, two early slices): decided ONCE per engine (TemporalEngine.dp_overlap)
         self._next_stream = 0
         self.bwd: List[_Rec] = []
         self._buckets = None
@@ -28,6 +29,9 @@ class TrainPlan(Plan):
         eng.params.enable_transposed_shadow()
         eng.ensure_grads()
         super().__init__(eng, B, T, "full")
+
+    def _all_records(self):
+        return list(self.records) + list(self.bwd)
 
     def _colsum_ws(self, n_floats: int) -> torch.Tensor:
         """The shared fp32 workspace of the two-stage column sums (launches on one stream never overlap), sized once for the largest
@@ -467,8 +471,7 @@ class TrainPlan(Plan):
         self._phase_marks: List[Tuple[int, int]] = []   # (number of backward records, gradient phase final after them): engine.grad_phase
         # data-parallel runs: the condition MLPs' backward is emitted per phase (the modules whose modulation gradients are complete), so that the slice of
         # a phase can be all-reduced while the later phases run; a single process keeps the one grouped launch set at the end
-        import torch.distributed as _dist
-        dp = _dist.is_available() and _dist.is_initialized() and _dist.get_world_size() > 1 and os.environ.get("SEA_DP_OVERLAP", "1") != "0"
+        dp = self.dp
         split_cond = adaln and dp
 
         def cond_backward(tag=""):

@@ -63,6 +63,9 @@ def initialize_optimizer(model, config):
 
 
 # ------------------------------------------------------------------------------------------------ rollout
+_KV_FALLBACK_WARNED: set = set()
+
+
 def rollout(model, x0: torch.Tensor, ib: torch.Tensor, n_steps: int, mode: str = "kv") -> torch.Tensor:
     """Autoregressive rollout (reference :202-209): start from step 0 (x0 [B,1,F,E]), predict n_steps steps with
     conditions ib[:, :n_steps].  Returns the predictions [B, n_steps, F, E].
@@ -74,7 +77,16 @@ def rollout(model, x0: torch.Tensor, ib: torch.Tensor, n_steps: int, mode: str =
     assert mode in ("recompute", "kv")
     if mode == "kv" and (getattr(model, "src_len", 0) > 0 or getattr(model, "exchange_mode", "sea") == "pool"
                          or str(getattr(model, "ib_addition_mode", "add")).lower() == "attention"):
-        mode = "recompute"   # a cache is exact only for strictly causal attention (src_len == 0, no un-masked info-bottleneck attention) and absolute positions (not 'pool'): see rollout_kv
+        # a cache is exact only for strictly causal attention (src_len == 0, no un-masked info-bottleneck attention) and absolute positions (not 'pool'):
+        # see engine.rollout_kv.  The caller asked for 'kv' (the shipped configs do): say once that the O(N^2) loop runs instead.
+        why = ("src_len > 0" if getattr(model, "src_len", 0) > 0 else
+               "exchange_mode='pool'" if getattr(model, "exchange_mode", "sea") == "pool" else "ib_addition_mode='attention'")
+        if why not in _KV_FALLBACK_WARNED:
+            _KV_FALLBACK_WARNED.add(why)
+            import warnings
+
+            warnings.warn(f"sea_amd.rollout: mode='kv' is not exact for this model ({why}); running the recompute rollout instead", RuntimeWarning, stacklevel=2)
+        mode = "recompute"
     was_training = model.training
     model.eval()
     try:
@@ -107,7 +119,8 @@ def full_autoregressive_evaluation(model, dataLoader, loss_fn, device, processor
     when `processor` (ProcessData: the frozen spatial decoder) and `mesh_processor` (MeshProcessor) are given — decode the rollout
     (inverse_transform_processed_data -> processor.decode_data), undo the SEA_isolate / SEA_mixed layout switch, un-patchify + inverse-scale
     (mesh_processor.inverse_scale_and_unpatch) and take relativeMSE_with_time over the mesh points per step and field.  The per-step table goes to
-    `{save_dir}/rollout_error_{case_name}_{run_name}.csv` as in the reference; its contour plots are not produced.  Returns the reference's dict
+    `{save_dir}/rollout_error_{case_name}_{run_name}.csv` as in the reference (rewritten for every batch, so — like the reference's, :249-262 — the file
+    holds the LAST batch's table); its contour plots are not produced.  Returns the reference's dict
     {'encoded_rel_mse', 'decoded_rel_mse'} (None for an empty loader); decoded_rel_mse is NaN without the two processors."""
     model.eval()
     enc_sum, dec_sum, n_batches = 0.0, 0.0, 0

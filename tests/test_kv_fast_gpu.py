@@ -147,6 +147,32 @@ def test_persistent_kv_rollout(cfg_args, n, dtype, tol_oracle, tol_paths, monkey
     assert rel_l2(a.cpu().numpy(), b.cpu().numpy()) < tol_paths
 
 
+def test_persistent_rollout_recovers_when_a_handoff_wait_gives_up(monkeypatch):
+    """The recovery path of KvFast.rollout (sea_amd/kv_engine.py): when the persistent launch reports that a hand-off wait gave up — forced here by
+    SEA_KV_TEST_FORCE_ERR=1, in production another process holding CUs — the rollout is recomputed with the seven launches per step, the KvFast object
+    stays on that form for good, and a LATER rollout on the same object (caches and granule arena reused) is still right."""
+    cfg = O.OracleConfig(1, 128, 8, 96, 8, 0, 3, 2, True, "adaln")
+    m = build(cfg, "fp32")
+    n = 40
+    x, _, ib = recipe_inputs(1, n, cfg, seed=12)
+    x0, ibg = x[:, :1].cuda().contiguous(), ib.cuda().contiguous()
+    ref = O.rollout(x[:, :1], ib, n, recipe_params(cfg), cfg)
+    monkeypatch.setenv("SEA_KV_PERSIST", "1")
+    good = _kv(m, x0, ibg, n, monkeypatch, True)                       # the persistent form, undisturbed
+    kf = m.engine()._kv_fast[1]
+    words = kf.G.handoff_words
+    assert words > kf.B * kf.F * kf.D                                  # (it did take the persistent form)
+    monkeypatch.setenv("SEA_KV_TEST_FORCE_ERR", "1")
+    rec = _kv(m, x0, ibg, n, monkeypatch, True)                        # attempt 0 "fails", attempt 1 recomputes
+    monkeypatch.delenv("SEA_KV_TEST_FORCE_ERR")
+    assert kf.G.handoff_words == kf.B * kf.F * kf.D < words            # the object gave the persistent form up for good
+    assert int(kf.err.item()) == 0
+    assert rel_l2(rec.cpu().numpy(), ref.numpy()) < 1e-4 and rel_l2(rec.cpu().numpy(), good.cpu().numpy()) < 1e-5
+    later = _kv(m, x0, ibg, n // 2, monkeypatch, True)                 # a later, shorter rollout on the same KvFast
+    assert rel_l2(later.cpu().numpy(), ref.numpy()[:, :n // 2]) < 1e-4
+    assert torch.equal(_kv(m, x0, ibg, n, monkeypatch, True), rec)     # and the seven-launch form replays bit-identically
+
+
 def test_models_outside_the_limits_keep_the_generic_plan(monkeypatch):
     from sea_amd import kv_engine
 

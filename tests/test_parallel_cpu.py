@@ -97,3 +97,51 @@ def test_bench_parent_launches_ranks_and_fails_cleanly_without_gpus():
     assert r.returncode == 1
     assert "rank exit codes" in r.stderr and "needs an MI355X" in r.stderr
     assert "{" not in r.stdout
+
+
+def test_train_entry_data_parallel_plumbing(monkeypatch):
+    """sea_amd.train.train_temporal: config['world_size'] > 1 without a launcher's environment is an error (never a silent single-process run); a loader
+    with a DistributedSampler is recognised (train() then leaves its batches alone), a plain list / DataLoader is sharded by rank."""
+    from torch.utils.data import DataLoader, TensorDataset
+    from torch.utils.data.distributed import DistributedSampler
+
+    from sea_amd.train import train_temporal as tt
+
+    for k in ("RANK", "WORLD_SIZE"):
+        monkeypatch.delenv(k, raising=False)
+    with pytest.raises(RuntimeError, match="world_size"):
+        tt._init_data_parallel({"world_size": 2}, torch.device("cpu"))
+    assert tt._init_data_parallel({"world_size": 1}, torch.device("cpu")) == (0, 1)
+    assert tt._init_data_parallel({}, torch.device("cpu")) == (0, 1)
+    ds = TensorDataset(torch.arange(8.0))
+    assert not tt._loader_shards_itself(DataLoader(ds, batch_size=4))
+    assert not tt._loader_shards_itself([(1, 2, 3, 4)])
+    assert tt._loader_shards_itself(DataLoader(ds, batch_size=4, sampler=DistributedSampler(ds, num_replicas=2, rank=0)))
+
+
+def _train_plumbing_worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    try:
+        from sea_amd.train import train_temporal as tt
+
+        got = tt._init_data_parallel({"world_size": world, "dist_backend": "gloo"}, torch.device("cpu"))   # starts the group from the environment
+        assert got == (rank, world) and dist.is_initialized()
+        v = tt._mean_over_ranks(torch.tensor(float(rank + 1)), world)
+        assert float(v) == 1.5
+        try:
+            tt._init_data_parallel({"world_size": 4}, torch.device("cpu"))
+            ret[rank] = "no error for a world-size mismatch"
+        except RuntimeError:
+            ret[rank] = "ok"
+    except Exception as e:  # pragma: no cover
+        ret[rank] = repr(e)
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+def test_train_entry_starts_its_group_from_the_launcher_environment():
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_train_plumbing_worker, args=(2, _free_port(), ret), nprocs=2, join=True)
+    assert dict(ret) == {0: "ok", 1: "ok"}

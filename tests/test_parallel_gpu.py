@@ -107,3 +107,77 @@ def test_train_step_world_n_equals_single_process_global_batch(world, cfg):
         # three AdamW steps at lr 1e-3: parameters within the update's own rounding of the single-process run
         assert np.abs(p - p_ref.numpy()).max() <= 2e-5, r
     assert np.array_equal(got[0][1], got[1][1])       # bit-identical across ranks
+
+
+# ---------------------------------------------------------------------------------------------------------------- the named entry: train(config, tracker)
+def _train_config(save_dir, fused, world):
+    from sea_amd.configs import get_config
+
+    config = get_config("cylinder_flow", "temporal")
+    config.update(device="cuda", save_dir=save_dir, embed_dim=64, n_heads=4, block_size=32, num_fields=3, dropout=0.0, dtype="fp32", learning_rate=1e-3,
+                  epoch_num=3, validation_interval=3, full_eval_interval=100, run_name=f"dp{world}", rollout_mode="kv", fused_step=fused,
+                  world_size=world, dist_backend=os.environ.get("SEA_TEST_DP_BACKEND", "gloo"))
+    torch.manual_seed(3)
+    base = torch.randn(8, 13, 3, 64).cumsum(dim=1) * 0.1
+    ib = torch.rand(8, 13, 1)
+    batch = lambda sl: (base[sl, :-1], base[sl, 1:], base[sl, 1:], ib[sl, :-1])   # noqa: E731  (host tensors: train() shards, then moves to the device)
+    config["loaders"] = ([batch(slice(0, 4)), batch(slice(4, 6))], [batch(slice(6, 8))], [batch(slice(6, 8))])   # global batches of 4 and 2 trajectories
+    return config
+
+
+def _run_train(save_dir, fused, world):
+    from sea_amd.train.train_temporal import train
+    from sea_amd.utils.train_utils import NoOpErrorTracker
+
+    class Tracker(NoOpErrorTracker):
+        def __init__(self):
+            self.rows = []
+
+        def record_error(self, phase, epoch, metrics):
+            self.rows.append((phase, epoch, dict(metrics)))
+
+    tr = Tracker()
+    cfg = _train_config(save_dir, fused, world)
+    # get_model draws the initial weights: rank 0 (and the single process) from seed 11, rank 1 from seed 12 — train() must broadcast rank 0's
+    torch.manual_seed(11 + int(os.environ.get("RANK", "0")) if world > 1 else 11)
+    model = train(cfg, tr)
+    eng = model.engine()
+    losses = [m["Loss"] for ph, _, m in tr.rows if ph == "train"]
+    return eng.params.flat32[:eng.params.n_live].cpu().numpy(), np.asarray(losses)
+
+
+def _train_worker(rank, world, port, fused, save_dir, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))   # what a launcher sets: train() starts the group itself
+    backend = os.environ.get("SEA_TEST_DP_BACKEND", "gloo")
+    torch.cuda.set_device(rank if backend == "nccl" else 0)
+    try:
+        ret[rank] = _run_train(save_dir, fused, world)
+    except Exception as e:  # pragma: no cover
+        ret[rank] = repr(e)
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("fused", [True, False])
+def test_train_entry_is_data_parallel(fused, tmp_path):
+    """train(config, tracker) (reference loop train/train_temporal.py:252-258) run by 2 ranks — each started like a launcher would (RANK / WORLD_SIZE /
+    MASTER_* in the environment, config['world_size'] = 2) — equals the single-process run on the global batches: same epoch losses, parameters
+    <= 2e-5 apart after 6 AdamW steps, bit-identical across the ranks.  Covers the parameter broadcast (the ranks' initial weights would differ: each
+    rank draws its own after torch.manual_seed(11 + ...) — see _run_train), the per-rank shard of every loader batch, and the gradient all-reduce of both
+    step forms: the fused step (slices under the backward) and `loss.backward(); optimizer.step()` (one collective inside FlatAdamW.step)."""
+    backend = os.environ.get("SEA_TEST_DP_BACKEND", "gloo")
+    if backend == "nccl" and torch.cuda.device_count() < 2:
+        pytest.skip("needs one GPU per rank")
+    p_ref, l_ref = _run_train(str(tmp_path), fused, 1)
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_train_worker, args=(2, _free_port(), fused, str(tmp_path), ret), nprocs=2, join=True)
+    got = dict(ret)
+    assert all(not isinstance(v, str) for v in got.values()), got
+    for r in range(2):
+        p, losses = got[r]
+        assert np.allclose(losses, l_ref, rtol=1e-5, atol=0), (r, losses, l_ref)
+        assert np.abs(p - p_ref).max() <= 2e-5, r
+    assert np.array_equal(got[0][0], got[1][0])
+    assert os.path.exists(os.path.join(str(tmp_path), "temporal_cylinder_flow_dp2.pt"))   # rank 0 wrote the best-validation checkpoint
