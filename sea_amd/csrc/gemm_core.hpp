@@ -156,6 +156,9 @@ struct GemmMainloop {
     static constexpr int A_DMA = BM / 32, B_DMA = BN / 32;   // wave-instructions per wave per stage
     static constexpr int LPS = A_DMA + B_DMA;
     static constexpr int DMA_LDS_BYTES = NS * C::BUF_BYTES;
+    // every LDS-DMA destination of dma_stage — slot (kt % NS), 8-row slab r0 of the A rows [0, BM) or of the W rows [BM, BM + BN), 1 KiB each — ends inside
+    // the NS * BUF_BYTES the launch requests: the last A slab at (BM / 8 - 1 + 1) KiB = BM * BKB, the last W slab at BUF_BYTES
+    static_assert(A_DMA * 4 * 8 == BM && B_DMA * 4 * 8 == BN && (BM + BN) * C::BKB == C::BUF_BYTES && DMA_LDS_BYTES <= 160 * 1024, "LDS-DMA ring of the tiled GEMM");
 
     static __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_addr) {
         unsigned keep;

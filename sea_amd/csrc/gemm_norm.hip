@@ -261,6 +261,8 @@ __global__ __launch_bounds__(256) void gemm_rownorm16_kernel(const GemmNormLaunc
     constexpr int EPC = ActTraits<T>::EPC, BK = BKB / (int)sizeof(T);
     constexpr int WTN = BN / 4, NI = WTN / 16;
     constexpr int ROWS = BM + BN, CHUNKS = ROWS * 8, CH = (CHUNKS + 255) / 256;
+    // DMA form: nk <= 4 stages of ROWS * 128 bytes, ROWS / 8 slabs of 1 KiB each: the host requests nk_max * ROWS * 128 bytes (sea_gemm_rownorm)
+    static_assert(!DMA || (ROWS % 8 == 0 && 4 * ROWS * BKB <= 160 * 1024), "LDS request of the one-burst Linear + row norm");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int gi = 0;
     while (gi + 1 < L.n_groups && (int)blockIdx.x >= L.tile_start[gi + 1]) ++gi;
@@ -432,6 +434,9 @@ struct XTailCfg {
     static constexpr int SMAX = D == 128 ? 2 : 4;
     static __host__ __device__ constexpr int r1_bytes(int S) { return S * KT1 * ST1 > KT3 * ST3 ? S * KT1 * ST1 : KT3 * ST3; }
     static __host__ __device__ constexpr int lds_bytes(int S) { return r1_bytes(S) + KT1 * ST2 + BM * E * 2 + 512; }
+    // LDS-DMA destinations: burst 1 fills R1 up to S KT1 ST1 <= r1_bytes(S) and R2 (from r1_bytes(S)) up to KT1 ST2; burst 2 (Wdown) the first KT3 ST3
+    // <= r1_bytes(S) bytes: all inside lds_bytes(S), which the host requests for the launch's S (every group of a launch has the same n_seg)
+    static_assert(lds_bytes(SMAX) <= 160 * 1024 && KT3 * ST3 <= r1_bytes(1), "LDS request of sea_exchange_tail");
 };
 
 template <int D, int E>

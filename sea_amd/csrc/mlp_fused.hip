@@ -26,6 +26,17 @@ __device__ __forceinline__ void glds16_mlp(const void* gsrc, unsigned lds_addr) 
                  : "=&s"(keep) : "v"(gsrc), "s"(lds_addr) : "memory");
 }
 
+// LDS request of mlp_fc1_ln_gelu_kernel<KT, NSB>: resident A rows + the 4-stage W1 ring + lnw | lnb (E = 256, S = 2048: 16 + 128 + 16 KiB = the CU's 160 KiB)
+template <int KT, int NSB>
+struct Mlp1Lds {
+    static constexpr int BYTES = KT * 32 * 128 + 4 * (KT * 64 * 128) + 2 * (NSB * 128) * 4;
+};
+// LDS request of mlp_fc2_proj_norm_kernel<KTE, KTS>: the 3-stage (A | W) ring, the x3 tile, the statistics scratch
+template <int KTE, int KTS>
+struct Mlp2Lds {
+    static constexpr int BYTES = 3 * (32 * 128 + KTE * 64 * 128) + KTE * 32 * 128 + 2 * 8 * 32 * 4;
+};
+
 // KT = E / 64 K-tiles; NSB = S / 128 column blocks per wave
 template <int KT, int NSB>
 __global__ __launch_bounds__(512) void mlp_fc1_ln_gelu_kernel(const MlpLaunch L) {
@@ -39,6 +50,11 @@ __global__ __launch_bounds__(512) void mlp_fc1_ln_gelu_kernel(const MlpLaunch L)
     constexpr int PRM_OFF = A_BYTES + NS * STAGE;          // lnw | lnb (2 S floats) behind the ring: DMA'd at the start, read by the epilogue
     constexpr int B1_OFF = 0, RED_OFF = S * 4;             // b1 and the statistics scratch go where the A rows were (they live in registers after stage 0)
     static_assert(BM * SP <= PRM_OFF && RED_OFF + 2 * NW * BM * 4 <= A_BYTES, "the output tile is staged over the operand memory");
+    // Every LDS-DMA destination (M0 base + 1 KiB per wave-instruction) lies inside the launch's LDS request, Mlp1Lds<KT, NSB>::BYTES (the host passes
+    // exactly that): the A pieces end at A_BYTES, stage s of the ring at A_BYTES + NS * STAGE = PRM_OFF, the 2 S / 256 gain / shift pieces at
+    // PRM_OFF + 8 S, the b1 pieces (S / 256 of them from B1_OFF = 0) inside the A region.
+    static_assert(PRM_OFF + 2 * S * 4 == Mlp1Lds<KT, NSB>::BYTES && Mlp1Lds<KT, NSB>::BYTES <= 160 * 1024, "LDS request of sea_mlp_fc1_ln_gelu");
+    static_assert(KT * (BM / 8) * 1024 == A_BYTES && KT * 8 * 1024 == STAGE && (S / 256) * 1024 <= A_BYTES && LPS * NW == KT * 8, "LDS-DMA piece counts");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // workgroups go to the XCDs round-robin: consecutive tiles (the same field, the same W1) are given to the same XCD
     const int tile = L.per_xcd > 0 ? (int)(blockIdx.x & 7) * L.per_xcd + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
@@ -330,6 +346,10 @@ __global__ __launch_bounds__(512) void mlp_fc2_proj_norm_kernel(const Mlp2Launch
     constexpr int WPW = E / 8 / NW;                                          // 8-row W pieces per wave per stage (E = 256: 4)
     constexpr int LPS = WPW + 1;                                             // + one A piece (waves 4 .. 7 repeat pieces 0 .. 3: same bytes, same place)
     constexpr int NJ = E / NW / 16;                                          // 16-column blocks per wave (E = 256: 2)
+    // every LDS-DMA destination lies inside the ring (stage slot + the A piece's 4 KiB + WPW * NW = E / 8 W pieces of 1 KiB), the ring, the x3 tile and
+    // the statistics inside the launch's LDS request
+    static_assert(STAGE_A == 4 * 1024 && WPW * NW * 1024 == STAGE_W && RED_OFF + 2 * NW * BM * 4 == Mlp2Lds<KTE, KTS>::BYTES && Mlp2Lds<KTE, KTS>::BYTES <= 160 * 1024,
+                  "LDS request of sea_mlp_fc2_proj_norm");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tile = L.per_xcd > 0 ? (int)(blockIdx.x & 7) * L.per_xcd + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
     if (tile >= L.tile_start[L.n_groups]) return;
@@ -563,12 +583,12 @@ extern "C" int sea_mlp_fc1_ln_gelu(const SeaMlpGroup* groups, int n_groups, floa
         total = 8 * L.per_xcd;
     }
     if (E == 256) {
-        constexpr int lds = 4 * 32 * 128 + 4 * (4 * 64 * 128) + 2 * 2048 * 4;   // A 16 KiB + ring 128 KiB + lnw | lnb 16 KiB = all 160 KiB of the CU
+        constexpr int lds = Mlp1Lds<4, 16>::BYTES;   // A 16 KiB + ring 128 KiB + lnw | lnb 16 KiB = all 160 KiB of the CU
         static int once = set_lds_mlp(mlp_fc1_ln_gelu_kernel<4, 16>, lds);
         (void)once;
         mlp_fc1_ln_gelu_kernel<4, 16><<<dim3(total), dim3(512), lds, s>>>(L);
     } else {
-        constexpr int lds0 = 2 * 32 * 128 + 4 * (2 * 64 * 128) + 2 * 1024 * 4;  // 8 KiB + 64 KiB (>= the output tile, 32 * (1024 * 2 + 16) = 66048) + lnw | lnb 8 KiB
+        constexpr int lds0 = Mlp1Lds<2, 8>::BYTES;  // 8 KiB + 64 KiB (>= the output tile, 32 * (1024 * 2 + 16) = 66048) + lnw | lnb 8 KiB
         static int once = set_lds_mlp(mlp_fc1_ln_gelu_kernel<2, 8>, lds0);
         (void)once;
         mlp_fc1_ln_gelu_kernel<2, 8><<<dim3(total), dim3(512), lds0, s>>>(L);
@@ -612,12 +632,12 @@ extern "C" int sea_mlp_fc2_proj_norm(const SeaMlp2Group* groups, int n_groups, f
         total = 8 * L.per_xcd;
     }
     if (E == 256) {
-        constexpr int lds = 3 * (32 * 128 + 256 * 128) + 4 * 32 * 128 + 2 * 8 * 32 * 4;   // ring 108 KiB + x3 tile 16 KiB + statistics 2 KiB
+        constexpr int lds = Mlp2Lds<4, 32>::BYTES;   // ring 108 KiB + x3 tile 16 KiB + statistics 2 KiB
         static int once = set_lds_mlp(mlp_fc2_proj_norm_kernel<4, 32>, lds);
         (void)once;
         mlp_fc2_proj_norm_kernel<4, 32><<<dim3(total), dim3(512), lds, s>>>(L);
     } else {
-        constexpr int lds = 3 * (32 * 128 + 128 * 128) + 2 * 32 * 128 + 2 * 8 * 32 * 4;    // ring 60 KiB + x3 tile 8 KiB + statistics 2 KiB
+        constexpr int lds = Mlp2Lds<2, 16>::BYTES;    // ring 60 KiB + x3 tile 8 KiB + statistics 2 KiB
         static int once = set_lds_mlp(mlp_fc2_proj_norm_kernel<2, 16>, lds);
         (void)once;
         mlp_fc2_proj_norm_kernel<2, 16><<<dim3(total), dim3(512), lds, s>>>(L);
