@@ -838,6 +838,9 @@ class Plan:
             R.add_tensor(t, "identity / rotation table")
         for t, label in zip(getattr(self, "_bound_tensors", ()) or (), ("x", "condition", "out")):
             R.add_tensor(t, "bound " + label)
+        R.add_tensor(getattr(self, "_bound_dout", None), "bound dout")
+        for t in (eng._loss_ws or ()):
+            R.add_tensor(t, "loss workspace")
         for t in owners:
             R.add_tensor(t, "caller buffer")
         return R
