@@ -110,7 +110,9 @@ int sea_gemm_grouped(const SeaGemmGroup* groups, int n_groups, int dtype, void* 
  * its own A and W (self-attention: one group, col0 = 0, N = 3*H*hd, W = [Wq;Wk;Wv]; cross-attention: a q group
  * from x_i with col0 = 0, N = H*hd and a k,v group from x_j with col0 = H*hd, N = 2*H*hd).
  * Row m of A is (trajectory b = m / T, step t = m % T) at absolute position pos0 + t.
- *   Qout  : act [B, H, T,   hd]   (scaled by q_scale = hd^-1/2 after rotation)
+ *   Qout  : act [B, H, T,   hd]   (scaled by q_scale after rotation.  The attention kernels below score in LOG2 units: the caller passes
+ *                                  q_scale = hd^-1/2 * log2(e) — reference scale models/base_blocks.py:191 times log2 e — so that
+ *                                  softmax(q k^T hd^-1/2) = 2^(Q K^T - max) / sum: one v_exp_f32 per probability)
  *   Kout  : act [B, H, cap, hd]   written at row pos0 + t
  *   Vtout : act [B, H, hd, cap]   written at column pos0 + t  (V transposed: keys contiguous)
  *   Vout  : act [B, H, cap, hd]   optional row-major copy of V (training: the attention backward reads it)
@@ -141,9 +143,10 @@ int sea_qkv_rope_grouped(const SeaQkvGroup* groups, int n_groups, const SeaQkvCo
  * Causal flash attention forward, several independent problems (fields / field pairs) per launch.
  * Replaces models/base_blocks.py:191-198 and :283-290: (q k^T) * hd^-1/2 (scale already folded into Q),
  * masked_fill(tril(diagonal=src_len) == 0, -inf), softmax, @ v, merge heads — without materialising [T, T].
+ * Scores are taken in LOG2 units: P = 2^(Q K^T - rowmax) / rowsum, i.e. Q must carry hd^-1/2 * log2(e) (SeaQkvCommon.q_scale).
  * Query row i (absolute position q_pos0 + i) attends keys j <= q_pos0 + i + src_len, j < Tk.
  *   O   : act [B, Tq, H*hd] row stride ldo
- *   LSE : f32 [B, H, Tq] log-sum-exp of the scaled scores (for the backward pass), may be NULL
+ *   LSE : f32 [B, H, Tq] BASE-2 log-sum-exp of the scores, log2(sum_j 2^(S_ij)) (for the backward pass), may be NULL
  */
 #define SEA_MAX_ATTN_PROBLEMS 8
 typedef struct {
@@ -463,7 +466,9 @@ int sea_rownorm_bwd(const SeaNormBwdGroup* groups, int n_groups, int M, int d, i
  * forward's LSE).  For each problem, from dO (gradient of the attention output, [B, Tq, H*hd] row stride lddo):
  *   dQ [B*Tq, H*hd] (row stride lddq), dK, dV [B*Tk, H*hd] (lddk, lddv) = gradients with respect to the OUTPUTS of the q / k / v
  *   Linear layers (RoPE and the q scale are undone in the epilogue), i.e. the dY operands of sea_wgrad_grouped / the dgrad GEMM.
- * V is the row-major copy written by sea_qkv_rope_grouped (Vout); delta (f32 [B, H, Tq]) is workspace.  Deterministic. */
+ * V is the row-major copy written by sea_qkv_rope_grouped (Vout); delta (f32 [B, H, Tq]) is workspace.  Deterministic.
+ * Q, LSE and q_scale are the forward's: Q in log2 units (q_scale = hd^-1/2 * log2 e is the factor sea_qkv_rope_grouped put on q), LSE base 2; the
+ * kernels carry the ln 2 of d(2^s)/ds themselves. */
 typedef struct {
     const void* Q;   /* act [B, H, Tq, hd]  (rotated, scaled) */
     const void* K;   /* act [B, H, cap, hd] (rotated) */

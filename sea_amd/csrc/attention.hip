@@ -4,7 +4,8 @@
 // keys are staged through LDS and shared by the 4 waves.  Everything is computed TRANSPOSED so that a query is a
 // lane (lane & 15) in every accumulator and no row statistic ever crosses lanes except the 4 lane groups of a
 // query (two __shfl_xor):
-//     S^T = K . Q^T      MFMA A = K rows (from LDS), B = Q (registers, loaded once)      C[key][query]
+//     S^T = K . Q^T      MFMA A = K rows (from LDS), B = Q (registers, loaded once)      C[key][query]   — in LOG2 units: Q arrives scaled by
+//                        hd^-1/2 * log2(e) (sea_qkv_rope_grouped's q_scale), so P = 2^(S - max) and every exponential is one v_exp_f32
 //     O^T = V^T . P^T    MFMA A = V^T rows (from LDS; V is kept transposed in HBM), B = P^T C[d][query]
 // The S^T accumulator of lane (g = lane >> 4, q = lane & 15) holds, per 16-key MFMA block, rows 4g..4g+3.  MFMA row
 // 4y+i of block beta of a key chunk is assigned key  y*(4*NB) + 4*beta + i  (NB = blocks per chunk), so after the
@@ -36,8 +37,24 @@ struct AttnCfg {
 // own running max / sum / O^T; the halves are merged through LDS at the end.  This halves the serial chain of key tiles of a
 // workgroup — what bounds the launch when the grid is only a few workgroups per CU (one trajectory: 768 workgroups).
 // DROP is a template parameter so that the inference instantiation carries none of the dropout's select/merge moves.
+// waves per SIMD the register allocation must leave room for (the second __launch_bounds__ argument): the kernel is bound by the latency of a
+// wave's per-tile dependency chain, so resident waves are what it runs on
+// Measured (tools/attn_ab.sh, bf16): hd 16 at 8 waves per SIMD (64 VGPRs, 4-5 spilled) 57.1 -> 56.4 us at B = 8 and — the 1024-thread SPLIT = 4 form needs
+// 8 for two workgroups per CU — 17.9 -> 13.8 us at B = 1; hd 32 at 6 (80 VGPRs) 111.0 -> 107.3 us at B = 8, at 8 it spills 37 registers (185 us).
+template <typename T, int HD, bool DROP>
+constexpr int attn_min_waves() {
+    if (DROP) return sizeof(T) == 2 && HD <= 32 ? 5 : 1;   // (the dropout form carries the mask words: it spills at the bounds below)
+#ifndef SEA_ATTN_WPE16
+#define SEA_ATTN_WPE16 8
+#endif
+#ifndef SEA_ATTN_WPE32
+#define SEA_ATTN_WPE32 6
+#endif
+    return sizeof(T) == 2 ? (HD <= 16 ? SEA_ATTN_WPE16 : (HD == 32 ? SEA_ATTN_WPE32 : 1)) : 1;
+}
+
 template <typename T, int HD, int SPLIT, bool DROP>
-__global__ __launch_bounds__(256 * SPLIT) void attention_fwd_kernel(const SeaAttnParams P) {
+__global__ __launch_bounds__(256 * SPLIT, (attn_min_waves<T, HD, DROP>())) void attention_fwd_kernel(const SeaAttnParams P) {
     using C = AttnCfg<T, HD>;
     constexpr int MERGE_BYTES = SPLIT > 1 ? (SPLIT - 1) * 256 * (2 + 4 * C::NDB) * 4 : 0;
     // per group: double-buffered K and V^T tiles; ONE buffer where two do not fit the 160 KiB (f32 at head dim 256: 133 KiB per tile pair) — the
@@ -78,7 +95,16 @@ __global__ __launch_bounds__(256 * SPLIT) void attention_fwd_kernel(const SeaAtt
     f32x4 oacc[C::NDB];
 #pragma unroll
     for (int d = 0; d < C::NDB; ++d) oacc[d] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float m_i = -INFINITY, l_i = 0.f;  // running max of the scores and this lane's partial row sum
+    // Online softmax in the exp2 domain with a LAZY reference: the scores arrive in log2 units (the QKV epilogue scaled q by hd^-1/2 * log2 e: include/sea_hip.h), the
+    // running sums are l = sum 2^(s - ref), O^T = sum 2^(s - ref) v with a per-row reference `ref` that is moved only when a tile's maximum exceeds it
+    // by more than REBASE_THR (or at the row's first visible tile).  "- ref" rides in the MFMA's C operand (negm4), so the common tile costs one v_exp
+    // per score and nothing else: no subtraction, no rescale of O^T.  Probabilities are bounded by 2^REBASE_THR (bf16 keeps its 8 significant bits at
+    // any magnitude, the sums are fp32).  The decision is per ROW (the four lanes of a row agree after group_max4), the wave-uniform branch only skips
+    // work that would multiply by exactly 1 / subtract exactly 0: a row's result never depends on the other rows of its wave (bitwise causality).
+    constexpr float REBASE_THR = 8.0f;
+    float ref = 0.f, l_i = 0.f;
+    float thr = -INFINITY;       // -inf: the row has not seen a key yet (row-level: set from the row maximum, the same in the four lanes of a row)
+    f32x4 negm4 = {0.f, 0.f, 0.f, 0.f};
 
     const int limit = P.q_pos0 + q_idx + P.src_len;                       // keys j <= limit are visible to this lane's query
     const int blk_last = P.q_pos0 + qt * 64 + 63 + P.src_len;             // last key any row of the workgroup may see
@@ -167,48 +193,69 @@ __global__ __launch_bounds__(256 * SPLIT) void attention_fwd_kernel(const SeaAtt
             k_frag_off[kc][be] = (kc * C::CK + (r >> 2) * (4 * C::NB) + be * 4 + (r & 3)) * C::K_STRIDE + g * 16;
     const int v_frag_off = r * C::V_STRIDE + g * 16;
 
-    // one 64-key tile for this wave; MASK = the tile crosses the causal diagonal or the end of the keys
-    auto process = [&](const char* sK, const char* sV, int kt, auto mask_tag) {
+    // One 64-key tile for this wave (MASK = the tile crosses the causal diagonal or the end of the keys): scores relative to the reference, the tile's
+    // row maximum and — rarely — a move of the reference, probabilities, O^T += V^T P^T.
+    // (Measured and not kept, tools/attn_ab.sh: a max-free tile — exponentiate as it stands, check only the row sum the matrix core delivers anyway, redo
+    // with the maximum when it is huge — 16 VALU instructions fewer per tile, no faster: B = 8 107.8 / 56.3 us against 107.3 / 56.4 at head dim 32 / 16,
+    // and slower at B = 1, where the second copy of the tile's code costs the 1024-thread form its 64-register budget.  The kernel is bound by the
+    // latency of a wave's per-tile chain — LDS fragments -> MFMA -> max -> exp -> pack -> MFMA, one barrier per tile — not by VALU issue.)
+    constexpr bool MFMA_SUM = sizeof(T) == 2 && !DROP;
+    const uint4 ones = make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u);   // bf16 1.0 x 8: the A operand of the row sums
+
+    auto scores = [&](const char* sK, f32x4 (&sc)[C::KCH][C::NB], int kt, auto mask_tag) {   // S'^T = K . Q^T - ref (masked entries -inf)
         constexpr bool MASK = decltype(mask_tag)::value;
-        // ---- S^T = K . Q^T
-        f32x4 s[C::KCH][C::NB];
 #pragma unroll
         for (int kc = 0; kc < C::KCH; ++kc) {
 #pragma unroll
             for (int be = 0; be < C::NB; ++be) {
-                s[kc][be] = f32x4{0.f, 0.f, 0.f, 0.f};
+                sc[kc][be] = negm4;
 #pragma unroll
                 for (int c = 0; c < C::NCH; ++c) {
                     // head dims below one contraction chunk: the tile rows are zero-padded in LDS, so no lane needs a select here
                     const uint4 a = *reinterpret_cast<const uint4*>(sK + k_frag_off[kc][be] + c * C::CK * (int)sizeof(T));
-                    mma16<T>(a, qf[c], s[kc][be]);
+                    mma16<T>(a, qf[c], sc[kc][be]);
+                }
+                if constexpr (MASK) {   // (this lane: query q_idx, keys kt*64 + kc*CK + g*EPC + be*4 + reg)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int key = kt * 64 + kc * C::CK + g * C::EPC + be * 4 + q;
+                        if (!(key <= limit && key < Tk)) sc[kc][be][q] = -INFINITY;
+                    }
                 }
             }
         }
-        // ---- online softmax, exp(s - m) evaluated as 2^(s*log2e - m*log2e): one v_fma + one v_exp per score (this lane: query q_idx, keys kt*64 + kc*CK + g*EPC + be*4 + reg)
+    };
+    auto rebase = [&](f32x4 (&sc)[C::KCH][C::NB]) {   // move the reference of the rows whose tile maximum calls for it; sc stays relative to the (new) reference
         float mx = -INFINITY;
 #pragma unroll
         for (int kc = 0; kc < C::KCH; ++kc)
 #pragma unroll
-            for (int be = 0; be < C::NB; ++be)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    if constexpr (MASK) {
-                        const int key = kt * 64 + kc * C::CK + g * C::EPC + be * 4 + q;
-                        if (!(key <= limit && key < Tk)) s[kc][be][q] = -INFINITY;
-                    }
-                    mx = fmaxf(mx, s[kc][be][q]);
-                }
+            for (int be = 0; be < C::NB; ++be) {
+                mx = fmaxf(fmaxf(mx, sc[kc][be][0]), sc[kc][be][1]);   // (v_max3_f32)
+                mx = fmaxf(fmaxf(mx, sc[kc][be][2]), sc[kc][be][3]);
+            }
         mx = group_max4(mx);
-        const float m_new = fmaxf(m_i, mx);
-        constexpr float LOG2E = 1.4426950408889634f;
-        const float alpha = __builtin_amdgcn_exp2f((m_i - m_new) * LOG2E);  // first visible tile: 2^(-inf) = 0
-        const float neg_ms = -m_new * LOG2E;
-        // Row sums: in bf16 without dropout they come out of the matrix core (an all-ones A operand against the packed P^T gives
-        // sum_k P[k][query] in every row of the result) — 16 dependent v_add per tile become 2 MFMAs on the otherwise idle pipe, and the
-        // result is already summed over the 4 lane groups.  The f32 path and the dropout path (whose sum must see the un-dropped P) add
-        // on the VALU.
-        constexpr bool MFMA_SUM = sizeof(T) == 2 && !DROP;
+        // `thr`: -inf until the row has seen a key (its first visible tile always moves the reference), REBASE_THR afterwards
+        if (__builtin_amdgcn_ballot_w64(mx > thr) != 0) {          // wave-uniform; rare after a row's first tiles
+            const bool need = mx > thr;
+            const float delta = need ? mx : 0.f;
+            const float alpha = thr == -INFINITY ? 1.0f : __builtin_amdgcn_exp2f(-delta);   // (first tile: l = O = 0, and 2^-delta may overflow) need false: exactly 1
+            ref += delta;
+            negm4 = f32x4{-ref, -ref, -ref, -ref};
+            thr = mx > -INFINITY ? REBASE_THR : thr;
+#pragma unroll
+            for (int kc = 0; kc < C::KCH; ++kc)
+#pragma unroll
+                for (int be = 0; be < C::NB; ++be)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) sc[kc][be][q] -= delta;
+#pragma unroll
+            for (int d = 0; d < C::NDB; ++d) oacc[d] *= alpha;
+            l_i *= alpha;
+        }
+    };
+    // probabilities in place, packed P^T fragments, the tile's row sum (matrix core: complete; VALU: this lane group's partial, un-dropped)
+    auto exp_pack = [&](f32x4 (&sc)[C::KCH][C::NB], uint4 (&pf)[C::KCH], int kt) -> float {
         float psum = 0.f;
 #pragma unroll
         for (int kc = 0; kc < C::KCH; ++kc)
@@ -216,15 +263,12 @@ __global__ __launch_bounds__(256 * SPLIT) void attention_fwd_kernel(const SeaAtt
             for (int be = 0; be < C::NB; ++be)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const float p = __builtin_amdgcn_exp2f(fmaf(s[kc][be][q], LOG2E, neg_ms));
-                    s[kc][be][q] = p;
+                    const float p = __builtin_amdgcn_exp2f(sc[kc][be][q]);
+                    sc[kc][be][q] = p;
                     if constexpr (!MFMA_SUM) psum += p;
                 }
-        m_i = m_new;
-#pragma unroll
-        for (int d = 0; d < C::NDB; ++d) oacc[d] *= alpha;
         if constexpr (DROP) {  // dropout on the probabilities: the row sum above stays un-dropped (softmax first, then dropout)
-            const float sc = drop_scale(P.drop.thr);
+            const float dsc = drop_scale(P.drop.thr);
 #pragma unroll
             for (int kc = 0; kc < C::KCH; ++kc)
 #pragma unroll
@@ -232,31 +276,41 @@ __global__ __launch_bounds__(256 * SPLIT) void attention_fwd_kernel(const SeaAtt
                     const int key0 = kt * 64 + kc * C::CK + g * C::EPC + be * 4;
                     const uint32_t w = drop_word(P.drop.seed, drop_stream, (uint32_t)q_idx, (uint32_t)(key0 >> 2));
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) s[kc][be][q] *= drop_factor(w, q, P.drop.thr, sc);
+                    for (int q = 0; q < 4; ++q) sc[kc][be][q] *= drop_factor(w, q, P.drop.thr, dsc);
                 }
         }
-        // ---- O^T += V^T . P^T
         f32x4 lsum = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int kc = 0; kc < C::KCH; ++kc) {
-            uint4 pf;
             if constexpr (sizeof(T) == 2) {
-                bf16x8 pv = {(__bf16)s[kc][0][0], (__bf16)s[kc][0][1], (__bf16)s[kc][0][2], (__bf16)s[kc][0][3],
-                             (__bf16)s[kc][1][0], (__bf16)s[kc][1][1], (__bf16)s[kc][1][2], (__bf16)s[kc][1][3]};
-                pf = __builtin_bit_cast(uint4, pv);
+                bf16x8 pv = {(__bf16)sc[kc][0][0], (__bf16)sc[kc][0][1], (__bf16)sc[kc][0][2], (__bf16)sc[kc][0][3],
+                             (__bf16)sc[kc][1][0], (__bf16)sc[kc][1][1], (__bf16)sc[kc][1][2], (__bf16)sc[kc][1][3]};
+                pf[kc] = __builtin_bit_cast(uint4, pv);
             } else {
-                pf = __builtin_bit_cast(uint4, s[kc][0]);
+                pf[kc] = __builtin_bit_cast(uint4, sc[kc][0]);
             }
+            if constexpr (MFMA_SUM) mma16<T>(ones, pf[kc], lsum);
+        }
+        if constexpr (MFMA_SUM) psum = lsum[0];
+        return psum;
+    };
+    auto process = [&](const char* sK, const char* sV, int kt, auto mask_tag) {
+        f32x4 sc[C::KCH][C::NB];
+        uint4 pf[C::KCH];
+        scores(sK, sc, kt, mask_tag);
+        rebase(sc);
+        const float psum = exp_pack(sc, pf, kt);
+        // ---- O^T += V^T . P^T
+#pragma unroll
+        for (int kc = 0; kc < C::KCH; ++kc) {
 #pragma unroll
             for (int d = 0; d < C::NDB; ++d) {
                 uint4 a = make_uint4(0, 0, 0, 0);
                 if (d * 16 + r < HD) a = *reinterpret_cast<const uint4*>(sV + v_frag_off + d * 16 * C::V_STRIDE + kc * C::CK * (int)sizeof(T));
-                mma16<T>(a, pf, oacc[d]);
+                mma16<T>(a, pf[kc], oacc[d]);
             }
-            if constexpr (MFMA_SUM) mma16<T>(make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u), pf, lsum);
         }
-        if constexpr (MFMA_SUM) psum = lsum[0];
-        l_i = l_i * alpha + psum;
+        l_i += psum;
     };
 
     if constexpr (HD < C::CK) {   // zero columns HD .. CK-1 of every key row of both buffers of this group (the staging never touches them)
@@ -303,7 +357,7 @@ __global__ __launch_bounds__(256 * SPLIT) void attention_fwd_kernel(const SeaAtt
         constexpr int STR = 2 + 4 * C::NDB;
         if (grp != 0) {
             float* dst = mg + ((grp - 1) * 256 + tid) * STR;
-            dst[0] = m_i;
+            dst[0] = thr > -INFINITY ? ref : -INFINITY;   // (row-level: the f32 / dropout paths keep PARTIAL row sums per lane group, l_i == 0 says nothing about the row)
             dst[1] = l_i;
 #pragma unroll
             for (int d = 0; d < C::NDB; ++d)
@@ -315,15 +369,16 @@ __global__ __launch_bounds__(256 * SPLIT) void attention_fwd_kernel(const SeaAtt
 #pragma unroll
         for (int o = 0; o < SPLIT - 1; ++o) {
             const float* src = mg + (o * 256 + tid) * STR;
-            const float m1 = src[0], l1 = src[1];
-            const float m = fmaxf(m_i, m1);  // group 0 always owns tile 0, so m_i is finite
-            const float a0 = __expf(m_i - m), a1 = __expf(m1 - m);  // m1 = -inf (the group saw nothing) -> a1 = 0
+            const float l1 = src[1];
+            const float m1 = src[0];                          // -inf: the group saw no key of this row
+            const float m = fmaxf(ref, m1);  // group 0 always owns tile 0 (key 0 is visible to every row), so ref is a real reference
+            const float a0 = __builtin_amdgcn_exp2f(ref - m), a1 = __builtin_amdgcn_exp2f(m1 - m);  // m1 = -inf -> a1 = 0
             l_i = l_i * a0 + l1 * a1;
 #pragma unroll
             for (int d = 0; d < C::NDB; ++d)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) oacc[d][q] = oacc[d][q] * a0 + src[2 + 4 * d + q] * a1;
-            m_i = m;
+            ref = m;
         }
     }
 
@@ -341,7 +396,7 @@ __global__ __launch_bounds__(256 * SPLIT) void attention_fwd_kernel(const SeaAtt
             const int d0 = d * 16 + g * 4;
             if (d0 < HD) store4(Og + d0, oacc[d][0] * inv, oacc[d][1] * inv, oacc[d][2] * inv, oacc[d][3] * inv);
         }
-        if (pr.LSE != nullptr && g == 0) pr.LSE[(int64_t)bh * Tq + q_idx] = m_i + __logf(l);
+        if (pr.LSE != nullptr && g == 0) pr.LSE[(int64_t)bh * Tq + q_idx] = ref + __log2f(l);   // log2 units, like the scores (the backward recomputes P = 2^(S - LSE))
     }
 }
 
@@ -423,14 +478,13 @@ __global__ __launch_bounds__(512) void attention_row_kernel(const SeaAttnParams 
     float m = red[0];
 #pragma unroll
     for (int w = 1; w < NW; ++w) m = fmaxf(m, red[w]);
-    constexpr float LOG2E = 1.4426950408889634f;
     float ls = 0.f;
 #pragma unroll
     for (int j = 0; j < KPT; ++j) {
         const int key = tid + j * 512;
         if (j * 512 >= nk) break;                          // block-uniform: sc[j] is not set beyond
         if (key < nk) {
-            const float pv = __builtin_amdgcn_exp2f((sc[j] - m) * LOG2E);
+            const float pv = __builtin_amdgcn_exp2f(sc[j] - m);   // scores are in log2 units (q carries hd^-1/2 * log2 e)
             prob[key] = pv;
             ls += pv;
         }
@@ -564,10 +618,9 @@ __global__ __launch_bounds__(512) void attention_row_wide_kernel(const SeaAttnPa
 #pragma unroll
     for (int w = 1; w < NW; ++w) m = fmaxf(m, red[w]);
     // ---- phase 1b: probabilities in place
-    constexpr float LOG2E = 1.4426950408889634f;
     float ls = 0.f;
     for (int key = tid; key < nk; key += 512) {
-        const float pv = __builtin_amdgcn_exp2f((prob[key] - m) * LOG2E);
+        const float pv = __builtin_amdgcn_exp2f(prob[key] - m);   // log2 units, as above
         prob[key] = pv;
         ls += pv;
     }

@@ -1,6 +1,9 @@
 // Causal flash attention backward for SEA's self- and cross-attention (gfx950): sea_attention_bwd.
 //
-// Two kernels, both recomputing P = exp(S - LSE) from Q, K and the forward's log-sum-exp instead of storing [T, T]:
+// Scores are in LOG2 units, as in the forward (Q carries hd^-1/2 * log2 e; LSE = ref + log2 l): P = 2^(S - LSE), with "- LSE" riding in the MFMA's C
+// operand, so a probability is one v_exp_f32 and nothing else.  With s2 = s ln-domain / ln 2: dS2 = ln2 * P (dP - delta), hence dQ2 = ln2 * dS K and
+// dK = ln2 * dS^T Q2; the epilogues carry the ln2 (dQ additionally q_scale, the factor the QKV epilogue put on q).
+// Two kernels, both recomputing P = 2^(S - LSE) from Q, K and the forward's log-sum-exp instead of storing [T, T]:
 //   attn_bwd_dq_kernel   one workgroup per 64 QUERIES (lane = query), loops over key tiles:      dQ, delta = rowsum(dO . O)
 //   attn_bwd_dkv_kernel  one workgroup per 64 KEYS (lane = key), loops over query tiles:         dK, dV
 // No atomics, bitwise reproducible.  The same transposed formulation as the forward: every accumulator has the lane's own
@@ -108,8 +111,14 @@ __device__ __forceinline__ void unrope(float& e, float& o, const float2 cs) { un
 // ---------------------------------------------------------------------------------------------- dQ (+ delta)
 // DROP and (per tile) MASK are compile-time: both kernels are VALU-issue-bound (PMC: VALU busy 80-100 %), so the un-dropped,
 // off-diagonal tile — the common case — carries no select, no dropout factor and one v_fma + one v_exp per probability.
+#ifndef SEA_ATTNB_WPE
+#define SEA_ATTNB_WPE 1
+#endif
+template <typename T, int HD>
+constexpr int attn_bwd_min_waves() { return (sizeof(T) == 2 && HD <= 32) ? SEA_ATTNB_WPE : 1; }
+
 template <typename T, int HD, bool DROP>
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const SeaAttnBwdParams P) {
+__global__ __launch_bounds__(256, (attn_bwd_min_waves<T, HD>())) void attn_bwd_dq_kernel(const SeaAttnBwdParams P) {
     using C = BwdCfg<T, HD>;
     __shared__ __attribute__((aligned(16))) char smem[C::NBUF * 2 * C::TILE];  // NBUF buffers x (K tile, V tile)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, g = lane >> 4;
@@ -165,8 +174,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const SeaAttnBwdParams
 #pragma unroll
         for (int be = 0; be < C::NB; ++be) frag_off[kc][be] = (kc * C::CK + (r >> 2) * (4 * C::NB) + be * 4 + (r & 3)) * C::PITCH + g * 16;
 
-    constexpr float LOG2E = 1.4426950408889634f;
-    const float nlse2 = -lse * LOG2E;   // P = exp(s - lse) = 2^(s log2e - lse log2e)
+    constexpr float LN2 = 0.69314718055994531f;
+    const f32x4 nlse4 = {-lse, -lse, -lse, -lse};   // P = 2^(s - lse): the subtraction is the MFMA's C operand
     auto tile = [&](const char* sK, const char* sV, int kt, auto mask_tag) {
         constexpr bool MASK = decltype(mask_tag)::value;
         f32x4 ds[C::KCH][C::NB];
@@ -175,7 +184,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const SeaAttnBwdParams
 #pragma unroll
             for (int be = 0; be < C::NB; ++be) {
                 // without dropout the "- delta" of dS = P (dP - delta) rides in the MFMA's C operand: dP starts at -delta
-                f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = DROP ? f32x4{0.f, 0.f, 0.f, 0.f} : f32x4{-delta, -delta, -delta, -delta};
+                f32x4 s = nlse4, dp = DROP ? f32x4{0.f, 0.f, 0.f, 0.f} : f32x4{-delta, -delta, -delta, -delta};
 #pragma unroll
                 for (int c = 0; c < C::NCH; ++c) {
                     const uint4 ak = *reinterpret_cast<const uint4*>(sK + frag_off[kc][be] + c * C::CK * (int)sizeof(T));   // rows zero-padded to CK
@@ -192,7 +201,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const SeaAttnBwdParams
                 }
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    float p = __builtin_amdgcn_exp2f(fmaf(s[q], LOG2E, nlse2));
+                    float p = __builtin_amdgcn_exp2f(s[q]);
                     if constexpr (MASK) {
                         const int key = kt * 64 + kc * C::CK + g * C::EPC + be * 4 + q;
                         if (!(key <= limit && key < Tk)) p = 0.f;
@@ -252,7 +261,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const SeaAttnBwdParams
                 float v[4] = {dq[d][0], dq[d][1], dq[d][2], dq[d][3]};
                 unrope(v[0], v[1], rope[d0 >> 1]);
                 unrope(v[2], v[3], rope[(d0 >> 1) + 1]);
-                store4(out + d0, v[0] * P.q_scale, v[1] * P.q_scale, v[2] * P.q_scale, v[3] * P.q_scale);
+                const float qs = P.q_scale * LN2;
+                store4(out + d0, v[0] * qs, v[1] * qs, v[2] * qs, v[3] * qs);
             }
         }
     }
@@ -260,7 +270,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const SeaAttnBwdParams
 
 // ---------------------------------------------------------------------------------------------- dK, dV
 template <typename T, int HD, bool DROP>
-__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const SeaAttnBwdParams P) {
+__global__ __launch_bounds__(256, (attn_bwd_min_waves<T, HD>())) void attn_bwd_dkv_kernel(const SeaAttnBwdParams P) {
     using C = BwdCfg<T, HD>;
     constexpr int VEC_OFF = C::NBUF * 2 * C::TILE;
     __shared__ __attribute__((aligned(16))) char smem[VEC_OFF + 2 * 2 * 64 * 4];  // NBUF x (Q tile, dO tile) + 2 x (lse, delta)
@@ -307,7 +317,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const SeaAttnBwdParam
 #pragma unroll
         for (int be = 0; be < C::NB; ++be) frag_off[qc][be] = (qc * C::CK + (r >> 2) * (4 * C::NB) + be * 4 + (r & 3)) * C::PITCH + g * 16;
 
-    constexpr float LOG2E = 1.4426950408889634f;
+    constexpr float LN2 = 0.69314718055994531f;
     auto tile = [&](const char* sQ, const char* sO, const float* sL, int qt, auto mask_tag) {
         constexpr bool MASK = decltype(mask_tag)::value;
         f32x4 pp[C::KCH][C::NB], ds[C::KCH][C::NB];
@@ -316,9 +326,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const SeaAttnBwdParam
 #pragma unroll
             for (int be = 0; be < C::NB; ++be) {
                 const int ql = qc * C::CK + g * C::EPC + be * 4;  // this lane's 4 consecutive queries of the tile
-                const f32x4 l4 = *reinterpret_cast<const f32x4*>(sL + ql);        // -lse * log2e (scaled when staged)
+                const f32x4 l4 = *reinterpret_cast<const f32x4*>(sL + ql);        // -lse (log2 units; negated when staged): the C operand of S
                 const f32x4 nd4 = *reinterpret_cast<const f32x4*>(sL + 64 + ql);      // -delta (negated when staged: no negation per score block here)
-                f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = DROP ? f32x4{0.f, 0.f, 0.f, 0.f} : nd4;   // "- delta" in the C operand, as in the dQ kernel
+                f32x4 s = l4, dp = DROP ? f32x4{0.f, 0.f, 0.f, 0.f} : nd4;   // "- lse" and "- delta" in the C operands, as in the dQ kernel
 #pragma unroll
                 for (int c = 0; c < C::NCH; ++c) {
                     const uint4 aq = *reinterpret_cast<const uint4*>(sQ + frag_off[qc][be] + c * C::CK * (int)sizeof(T));   // rows zero-padded to CK
@@ -328,7 +338,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const SeaAttnBwdParam
                 }
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    float p = __builtin_amdgcn_exp2f(fmaf(s[q], LOG2E, l4[q]));
+                    float p = __builtin_amdgcn_exp2f(s[q]);
                     if constexpr (MASK) {
                         const int qi = qt * 64 + ql + q;
                         if (!(qi >= q_min_lane && qi < Tq && k_idx < Tk)) p = 0.f;
@@ -364,7 +374,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const SeaAttnBwdParam
     auto load_vec = [&](int qt) {
         if (tid < 64) {
             const int q = qt * 64 + tid;
-            r_lse = q < Tq ? -lse_g[q] * LOG2E : 0.f;
+            r_lse = q < Tq ? -lse_g[q] : 0.f;
             r_del = q < Tq ? del_g[q] : 0.f;
         }
     };
@@ -431,7 +441,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const SeaAttnBwdParam
                 float v[4] = {dk[d][0], dk[d][1], dk[d][2], dk[d][3]};
                 unrope(v[0], v[1], rope[d0 >> 1]);
                 unrope(v[2], v[3], rope[(d0 >> 1) + 1]);
-                store4(outk + d0, v[0], v[1], v[2], v[3]);
+                store4(outk + d0, v[0] * LN2, v[1] * LN2, v[2] * LN2, v[3] * LN2);
                 store4(outv + d0, dv[d][0], dv[d][1], dv[d][2], dv[d][3]);
             }
         }

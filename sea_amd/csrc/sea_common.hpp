@@ -223,13 +223,19 @@ __device__ __forceinline__ void decode_attn_block(int& tile, int& bh, int& z) {
 // max over the 4 lane groups {l, l^16, l^32, l^48} without touching the LDS crossbar: gfx950's half / row swaps
 // (v_permlane32_swap exchanges the upper half of vdst with the lower half of src, v_permlane16_swap the odd 16-lane rows of
 // vdst with the even rows of src; with vdst = src = x the two results hold both partners of every lane).
+// (max1: one v_max_f32 — fmaxf on values the compiler cannot see through, such as the swap results, is preceded by a canonicalising v_max x, x each)
+__device__ __forceinline__ float max1(float a, float b) {
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
 __device__ __forceinline__ float group_max4(float x) {
     const unsigned u = __float_as_uint(x);
     const auto a = __builtin_amdgcn_permlane32_swap(u, u, false, false);
-    x = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+    x = max1(__uint_as_float(a[0]), __uint_as_float(a[1]));
     const unsigned v = __float_as_uint(x);
     const auto b = __builtin_amdgcn_permlane16_swap(v, v, false, false);
-    return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
+    return max1(__uint_as_float(b[0]), __uint_as_float(b[1]));
 }
 
 __device__ __forceinline__ float wave_sum(float v) {

@@ -352,7 +352,7 @@ class Plan:
             g.Qout, g.Kout, g.Vtout, g.Vout = N.ptr(d.get("Q")), N.ptr(d.get("K")), N.ptr(d.get("Vt")), N.ptr(d.get("V"))
             g.lda, g.ldw = A.stride(0), W.stride(0)
             g.M, g.N, g.K, g.col0 = self.M, W.shape[0], W.shape[1], d["col0"]
-        common = N.SeaQkvCommon(rope.data_ptr(), self.H, hd, self.T, self.pos0, self.cap, float(hd) ** -0.5)
+        common = N.SeaQkvCommon(rope.data_ptr(), self.H, hd, self.T, self.pos0, self.cap, ops.q_scale(hd))
         self._pos_structs.append(common)
         self._cur.append(self._rec(L.sea_qkv_rope_grouped, [arr, len(groups), C.byref(common), self.code], name, (arr, common)))
 

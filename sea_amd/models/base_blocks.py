@@ -212,7 +212,7 @@ class _MaskedAttentionBase(nn.Module):
         Vt = torch.zeros(B, H, hd, cap, device=dev, dtype=dt)
         rope = torch.view_as_real(self.freqs_cis).contiguous()
         ops.qkv_rope_grouped([dict(A=aq, W=Wq, bias=self.q.bias, col0=0, Q=Q), dict(A=akv, W=Wkv, bias=bkv, col0=Cdim, K=K, Vt=Vt)],
-                             rope, H, hd, T, 0, cap, float(hd) ** -0.5, dt)
+                             rope, H, hd, T, 0, cap, ops.q_scale(hd), dt)
         O = torch.empty(B, T, Cdim, device=dev, dtype=dt)
         ops.attention_fwd([dict(Q=Q, K=K, Vt=Vt, O=O)], B, H, hd, T, T, cap, 0, self.src_len, dt, drop=dk)
         y = torch.empty(B * T, Cdim, device=dev, dtype=torch.float32)
@@ -270,8 +270,8 @@ class MultiHeadCrossAttention(nn.Module):
         K = torch.zeros(B, H, cap, hd, device=dev, dtype=dt)
         Vt = torch.zeros(B, H, hd, cap, device=dev, dtype=dt)
         ident = identity_rope(hd, max(T, Ts), dev)
-        ops.qkv_rope_grouped([dict(A=_as_act(x_1), W=_as_act(self.q.weight), bias=self.q.bias, col0=0, Q=Q)], ident, H, hd, T, 0, cap, float(hd) ** -0.5, dt)
-        ops.qkv_rope_grouped([dict(A=_as_act(x_2), W=Wkv, bias=bkv, col0=Cdim, K=K, Vt=Vt)], ident, H, hd, Ts, 0, cap, float(hd) ** -0.5, dt)
+        ops.qkv_rope_grouped([dict(A=_as_act(x_1), W=_as_act(self.q.weight), bias=self.q.bias, col0=0, Q=Q)], ident, H, hd, T, 0, cap, ops.q_scale(hd), dt)
+        ops.qkv_rope_grouped([dict(A=_as_act(x_2), W=Wkv, bias=bkv, col0=Cdim, K=K, Vt=Vt)], ident, H, hd, Ts, 0, cap, ops.q_scale(hd), dt)
         O = torch.empty(B, T, Cdim, device=dev, dtype=dt)
         ops.attention_fwd([dict(Q=Q, K=K, Vt=Vt, O=O)], B, H, hd, T, Ts, cap, 0, Ts, dt)   # src_len >= Ts: every key is visible to every query
         y = torch.empty(B * T, Cdim, device=dev, dtype=torch.float32)

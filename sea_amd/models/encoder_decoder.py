@@ -291,7 +291,7 @@ class PointwiseEncode(nn.Module):
             for blk in pk["blocks"]:
                 ops.rownorm([dict(X=zr, gamma=blk["g1"], Yact=ws["n"])], M, W, False, False, 1e-5, dt)
                 ops.qkv_rope_grouped([dict(A=ws["n"], W=blk["wqkv"], bias=blk["bqkv"], col0=0, Q=ws["Q"], K=ws["K"], Vt=ws["Vt"])], ws["rope"], H, hdp, P, 0,
-                                     ws["cap"], float(pk["hd"]) ** -0.5, dt)
+                                     ws["cap"], ops.q_scale(pk["hd"]), dt)
                 ops.attention_fwd([dict(Q=ws["Q"], K=ws["K"], Vt=ws["Vt"], O=ws["att"])], Bc, H, hdp, P, P, ws["cap"], 0, P, dt)   # src_len = P: every key visible
                 ops.gemm_grouped([dict(A=ws["att"].view(M, -1), W=blk["wo"], R=zr, C32=zr)], dt)
                 ops.rownorm([dict(X=zr, gamma=blk["g2"], Yact=ws["n"])], M, W, False, False, 1e-5, dt)

@@ -75,6 +75,15 @@ def gemm_grouped(groups: Sequence[Dict], dtype: torch.dtype) -> None:
     N.check(N.lib().sea_gemm_grouped(arr, n, N.dtype_code(dtype), N.stream_ptr()), "sea_gemm_grouped")
 
 
+LOG2E = 1.4426950408889634
+
+
+def q_scale(hd: int) -> float:
+    """The factor the QKV epilogue puts on (rotated) q for the attention kernels: hd^-1/2 (reference models/base_blocks.py:191) times log2(e) — the
+    attention kernels work in log2 units (P = 2^(S - max): one v_exp_f32 per probability, the subtraction in the MFMA's C operand), see sea_hip.h."""
+    return float(hd) ** -0.5 * LOG2E
+
+
 def qkv_rope_grouped(groups: Sequence[Dict], rope: torch.Tensor, H: int, hd: int, T: int, pos0: int, cap: int,
                      q_scale: float, dtype: torch.dtype) -> None:
     """groups: dicts with A [M,K], W [N,K], bias f32 [N], col0, Q/K/Vt output tensors (see sea_hip.h)."""

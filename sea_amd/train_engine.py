@@ -15,6 +15,7 @@ from typing import Dict, List, Optional, Tuple
 import torch
 
 from . import _native as N
+from . import ops
 from .engine import Plan, _Rec, blk_pe
 
 
@@ -107,7 +108,7 @@ class TrainPlan(Plan):
         P.B, P.H, P.hd, P.Tq, P.Tk, P.cap, P.q_pos0, P.src_len = self.B, self.H, hd, self.T, self.T, self.cap, 0, (self.eng.model.src_len if src_len is None else src_len)
         P.ldo, P.lddo = d0["O"].stride(0), d0["dO"].stride(0)
         P.lddq, P.lddk, P.lddv = d0["dQ"].stride(0), d0["dK"].stride(0), d0["dV"].stride(0)
-        P.q_scale = float(hd) ** -0.5
+        P.q_scale = ops.q_scale(hd)   # what the QKV epilogue put on q (the kernel undoes it, and the log2 units of the scores)
         self._cur.append(_Rec(L.sea_attention_bwd, [C.byref(P), self.code], name, P))
 
     def _silu_bwd(self, groups: List[dict], name: str) -> None:

@@ -248,13 +248,14 @@ def _attention_backward_case(dtype, hd, T, src_len, B, H):
     E = H * hd
     cap = (T + 7) // 8 * 8
     scale = hd ** -0.5
+    scale2 = ops.q_scale(hd)      # what the QKV epilogue puts on q: hd^-1/2 * log2(e) — the attention kernels score in log2 units
     table = _rope_table(hd, cap)
     q0 = rnd(B, T, H, hd, seed=70).requires_grad_(True)
     k0 = rnd(B, T, H, hd, seed=71).requires_grad_(True)
     v0 = rnd(B, T, H, hd, seed=72).requires_grad_(True)
     dO = rnd(B, T, E, dtype=dtype, seed=73)
     # what the QKV epilogue would have written (rounded to the activation dtype)
-    Q = (_rope(q0, table) * scale).permute(0, 2, 1, 3).contiguous().to(dtype)
+    Q = (_rope(q0, table) * scale2).permute(0, 2, 1, 3).contiguous().to(dtype)
     K = torch.zeros(B, H, cap, hd, device=dev(), dtype=dtype)
     V = torch.zeros(B, H, cap, hd, device=dev(), dtype=dtype)
     K[:, :, :T] = _rope(k0, table).permute(0, 2, 1, 3).to(dtype)
@@ -267,16 +268,16 @@ def _attention_backward_case(dtype, hd, T, src_len, B, H):
     dKV = torch.full((B * T, 2 * E), float("nan"), device=dev(), dtype=dtype)
     delta = torch.empty(B, H, T, device=dev())
     ops.attention_bwd([dict(Q=Q.detach(), K=K.detach(), V=V.detach(), O=O, dO=dO, LSE=LSE, delta=delta, dQ=dQ, dK=dKV[:, :E], dV=dKV[:, E:])],
-                      table, B, H, hd, T, T, cap, 0, src_len, scale, dtype)
-    # autograd reference in fp32 on the same (rounded) operands
-    qr = (_rope(q0, table) * scale).permute(0, 2, 1, 3)
+                      table, B, H, hd, T, T, cap, 0, src_len, scale2, dtype)
+    # autograd reference in fp32 on the same (rounded) operands: natural-log softmax of the log2-unit scores times ln 2
+    qr = (_rope(q0, table) * scale2).permute(0, 2, 1, 3)
     kr = _rope(k0, table).permute(0, 2, 1, 3)
     vr = v0.permute(0, 2, 1, 3)
     if dtype != torch.float32:  # straight-through rounding so that the reference sees the operands the kernel saw
         qr = qr + (qr.detach().to(dtype).float() - qr.detach())
         kr = kr + (kr.detach().to(dtype).float() - kr.detach())
         vr = vr + (vr.detach().to(dtype).float() - vr.detach())
-    S = qr @ kr.transpose(-1, -2)
+    S = (qr @ kr.transpose(-1, -2)) * 0.6931471805599453
     i = torch.arange(T, device=dev())
     S = S.masked_fill(i[None, :] > i[:, None] + src_len, float("-inf"))
     Oref = (torch.softmax(S, -1) @ vr).transpose(1, 2).reshape(B, T, E)

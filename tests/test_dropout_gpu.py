@@ -67,7 +67,7 @@ def test_attention_dropout_forward_backward(dtype, hd, T):
     import ctypes as C
 
     B, H, nprob = 2, 3, 2
-    E, cap, scale = H * hd, (T + 7) // 8 * 8, hd ** -0.5
+    E, cap, scale = H * hd, (T + 7) // 8 * 8, ops.q_scale(hd)   # hd^-1/2 * log2(e): the attention kernels score in log2 units
     seed, stream0, thr = 4242, 11, 64  # p = 0.25
     table = _rope_table(hd, cap)
     probs, bprobs, refs = [], [], []
@@ -111,7 +111,7 @@ def test_attention_dropout_forward_backward(dtype, hd, T):
         vr = v0.permute(0, 2, 1, 3)
         if dtype != torch.float32:
             qr, kr, vr = (t_ + (t_.detach().to(dtype).float() - t_.detach()) for t_ in (qr, kr, vr))
-        S = qr @ kr.transpose(-1, -2)
+        S = (qr @ kr.transpose(-1, -2)) * 0.6931471805599453
         i = torch.arange(T, device=dev())
         S = S.masked_fill(i[None, :] > i[:, None], float("-inf"))
         Oref = ((torch.softmax(S, -1) * mk) @ vr).transpose(1, 2).reshape(B, T, E)

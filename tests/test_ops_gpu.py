@@ -261,15 +261,19 @@ def test_qkv_rope_cross_groups(dtype, B, T):
     assert rel(Vt[:, :, :, :T].float(), v.permute(0, 2, 3, 1)) < t
 
 
+LN2 = 0.6931471805599453
+
+
 def attention_ref(Q, K, Vt, q_pos0, src_len, Tk):
-    """Q [B,H,Tq,hd] (scaled), K [B,H,cap,hd], Vt [B,H,hd,cap] -> O [B,Tq,H*hd], LSE [B,H,Tq]"""
+    """Q [B,H,Tq,hd] (scaled), K [B,H,cap,hd], Vt [B,H,hd,cap] -> O [B,Tq,H*hd], LSE [B,H,Tq].  The kernels' contract (include/sea_hip.h): scores are in LOG2
+    units — the QKV epilogue hands over q * hd^-1/2 * log2(e) — so P = 2^(Q K^T - max) = softmax(ln2 * Q K^T), and LSE is the base-2 log-sum-exp."""
     Q, K, V = Q.float(), K[:, :, :Tk].float(), Vt[:, :, :, :Tk].float().transpose(2, 3)
     B, H, Tq, hd = Q.shape
-    S = Q @ K.transpose(-1, -2)
+    S = (Q @ K.transpose(-1, -2)) * LN2
     i = torch.arange(Tq, device=Q.device)[:, None] + q_pos0 + src_len
     j = torch.arange(Tk, device=Q.device)[None, :]
     S = S.masked_fill(j > i, float("-inf"))
-    lse = torch.logsumexp(S, dim=-1)
+    lse = torch.logsumexp(S, dim=-1) / LN2
     O = torch.softmax(S, dim=-1) @ V
     return O.transpose(1, 2).reshape(B, Tq, H * hd), lse
 
