@@ -215,9 +215,14 @@ class _Rec:
 class Plan:
     """Launch list for one (B, T, mode) of TemporalModel.forward."""
 
-    def __init__(self, eng: "TemporalEngine", B: int, T: int, mode: str = "full", save_for_backward: bool = False):
+    def __init__(self, eng: "TemporalEngine", B: int, T: int, mode: str = "full", save_for_backward: bool = False, cond=None):
         assert mode in ("full", "step")
         self.eng, self.B, self.T, self.mode = eng, B, T, mode
+        # `cond` (step mode): a kv_engine.CondPlan that has evaluated what depends on the condition only — every AdaLN modulation, the
+        # info-bottleneck term — for ALL steps of a rollout (row s * B + b): the step plan then carries no condition launch at all and reads row
+        # block s of those buffers, its pointers into them advanced per step (self._hoisted, step_patch_table)
+        self._cond_src = cond
+        self._hoisted: List[Tuple[object, str, int, int]] = []   # (struct, field, address at step 0, bytes per step)
         m = eng.model
         self.F, self.H, self.L = m.num_variables, m.n_heads, m.num_layers
         # E: the row width INSIDE a block; Eo: the width of the model's input / output rows and of every block's proj output.  They differ only with
@@ -248,8 +253,42 @@ class Plan:
         self._lane_streams: Dict[int, torch.cuda.Stream] = {}
         self._zero_ib: Optional[torch.Tensor] = None   # 'concat': the zeros the info-bottleneck columns are reset to
         self._build()
+        self._find_hoisted()
         self._clist = None          # (SeaLaunchRec array, [(rec index, field, args list, args index)]) for sea_run_list
         self._compile_list()
+
+    def _find_hoisted(self) -> None:
+        """Every pointer field of the launch structs that points into row block 0 of a hoisted condition buffer (self._cond_src): (struct, field,
+        address, bytes per step) — found by address, so that no record builder has to know about the hoisting."""
+        src = self._cond_src
+        if src is None:
+            return
+        spans = []   # (lo, hi, bytes per step)
+        for t in list(src.mods.values()) + list(src.ibufs):
+            step = self.M * t.stride(0) * t.element_size()
+            spans.append((t.data_ptr(), t.data_ptr() + step, step))
+        for r in self.records:
+            if r.fn is None:
+                continue
+            roots = [a for a in r.args if isinstance(a, (C.Structure, C.Array))] + ([r.keep] if r.keep is not None else [])
+            seen = set()
+            for root in roots:
+                for st in ptrcheck._walk_structs(root):
+                    for path, pval in ptrcheck.iter_pointers(st):
+                        name = path[1:]
+                        if "[" in name or (C.addressof(st), name) in seen:
+                            continue
+                        for lo, hi, step in spans:
+                            if lo <= pval < hi:
+                                seen.add((C.addressof(st), name))
+                                self._hoisted.append((st, name, pval, step))
+                                break
+        self._keep.append(src)   # the buffers live as long as this plan
+
+    def set_hoisted_step(self, s: int) -> None:
+        """Point the plan at row block s of the hoisted condition buffers (the native step loop does the same through its patch table)."""
+        for st, field, base, step in self._hoisted:
+            setattr(st, field, base + s * step)
 
     # ------------------------------------------------------------------ allocation helpers
     def _buf(self, *shape, dtype=None, zero=False) -> torch.Tensor:
@@ -381,6 +420,8 @@ class Plan:
         mods: Dict[str, torch.Tensor] = {}
         if not self.adaln:
             return mods
+        if self._cond_src is not None:   # evaluated for all steps up front: row block 0 here, advanced per step
+            return {pre: t[:M] for pre, t in self._cond_src.mods.items()}
         first, rest = [], []
         for l in range(self.L):
             pre = f"blocks.{l}."
@@ -477,8 +518,14 @@ class Plan:
         fold_ib = (type(self) is Plan and has_ib and eng.model.add_info_after_cross and self.adaln and not lanes and not split_cond
                    and self.L <= N.MAX_SILU_IB and E <= 2048 and os.environ.get("SEA_FOLD_IB", "1") != "0"
                    and not self._gen_a([(None, E), (None, D)]))
-        ibufs = [self._buf(M, E, dtype=f32) for _ in range(self.L)] if fold_ib else None
-        self._ib_fold = [(f"blocks.{l}.", ibufs[l]) for l in range(self.L)] if fold_ib else []
+        hoist_ib = self._cond_src is not None and has_ib and eng.model.add_info_after_cross and len(self._cond_src.ibufs) == self.L and E <= 2048
+        if hoist_ib:       # the info-bottleneck rows of all steps exist already: added by the norm pass in front of the MLP (AdaLN or LayerNorm alike)
+            fold_ib = True
+            ibufs = [t[:M] for t in self._cond_src.ibufs]
+            self._ib_fold = []
+        else:
+            ibufs = [self._buf(M, E, dtype=f32) for _ in range(self.L)] if fold_ib else None
+            self._ib_fold = [(f"blocks.{l}.", ibufs[l]) for l in range(self.L)] if fold_ib else []
         mods = self._cond_mods(split=split_cond)
         cond_joined = not split_cond
 
@@ -836,6 +883,9 @@ class Plan:
             R.add_tensor(t, label)
         for t in eng._eyes.values():
             R.add_tensor(t, "identity / rotation table")
+        if self._cond_src is not None:
+            for t in self._cond_src._keep:
+                R.add_tensor(t, "hoisted condition buffers")
         for t, label in zip(getattr(self, "_bound_tensors", ()) or (), ("x", "condition", "out")):
             R.add_tensor(t, "bound " + label)
         R.add_tensor(getattr(self, "_bound_dout", None), "bound dout")
@@ -919,6 +969,8 @@ class Plan:
             rows.append((field_addr(tgt, field), 1, out_base + off, out_stride))
         for tgt, field in self._c_patches:
             rows.append((field_addr(tgt, field), 1, c_base, c_stride))
+        for st, field, base, step in self._hoisted:
+            rows.append((field_addr(st, field), 1, base, step))
         tab = (N.SeaStepPatch * max(len(rows), 1))()
         for t, (a_, k_, b_, s_) in zip(tab, rows):
             t.addr, t.kind, t.base, t.stride = a_, k_, b_, s_
@@ -1135,19 +1187,22 @@ class TemporalEngine:
             self._eyes[("rope", hd)] = t
         return t
 
-    def plan(self, B: int, T: int, mode: str = "full") -> Plan:
+    def plan(self, B: int, T: int, mode: str = "full", cond=None) -> Plan:
         if mode == "step" and self.model.exchange_mode == "pool":
             raise NotImplementedError("sea_amd: the KV-cache rollout does not cover exchange_mode='pool' (its sinusoidal positions are relative to the window); "
                                       "use the recompute rollout")
         if mode == "step" and self.model.ib_addition_mode.lower() == "attention":
             raise NotImplementedError("sea_amd: the KV-cache rollout does not cover ib_addition_mode='attention' (every row attends to the info-bottleneck rows "
                                       "of ALL positions of the window, later ones included: rows already produced change as the window grows); use the recompute rollout")
-        key = (B, T, mode)
+        key = (B, T, mode) if cond is None else (B, T, mode, id(cond))
         p = self._plans.get(key)
         if p is None:
             if T > self.model.max_len:
                 raise ValueError(f"sequence length {T} exceeds max_len {self.model.max_len}")
-            p = Plan(self, B, T, mode)
+            if cond is not None:   # one hoisted step plan at a time per batch size: its predecessor's condition buffers are released with it
+                for k in [k for k in self._plans if len(k) == 4 and k[:3] == (B, T, mode)]:
+                    del self._plans[k]
+            p = Plan(self, B, T, mode, cond=cond)
             self._plans[key] = p
         return p
 
@@ -1339,17 +1394,33 @@ class TemporalEngine:
         traj = torch.empty(n_steps + 1, B, F, E, device=self.device, dtype=torch.float32)
         traj[0].copy_(x0[:, 0])
         cond = ib[:, :n_steps, 0].t().contiguous()  # [n_steps, B]
-        p = self.plan(B, 1, "step")
+        # What depends on the condition only (the AdaLN modulations of every module, the info-bottleneck term) is evaluated for ALL steps by one batched
+        # pass before the loop — the full-context plan's own silu / grouped-GEMM / ib launches on n_steps * B rows — instead of once per step on B rows:
+        # at the shipped cylinder width (embed_dim 1024) that is two launches and 31 % of the weight bytes of every step.  SEA_KV_HOIST=0: per step.
+        cp = None
+        m = self.model
+        if os.environ.get("SEA_KV_HOIST", "1") != "0" and (m.LN_type.lower() == "adaln" or (m.ib_addition_mode.lower() == "add" and m.add_info_after_cross)) \
+                and m.ib_addition_mode.lower() in ("add", "none"):
+            cp = kv_engine.cond_plan_for(self, n_steps * B)
+            for t in cp.ibufs:
+                t.zero_()
+            cp.bind_ptrs(0, cond.data_ptr(), 0)
+            if not cp._audited or ptrcheck.always():
+                cp.audit(owners=(cond,))
+            cp.run()
+        p = self.plan(B, 1, "step", cond=cp)
         slab = B * F * E * 4
         base, cbase = traj.data_ptr(), cond.data_ptr()
         if not p._audited or ptrcheck.always():   # the step plan is bound by raw address: audit it once against the buffers it will walk
             p.set_position(0)
             p.bind_ptrs(base, cbase, base + slab)
+            p.set_hoisted_step(0)
             p.audit(owners=(traj, cond))
         # the step loop in native code (the plan's launch list + a table of the per-step edits); SEA_KV_NATIVE_LOOP=0: one Python round trip per step
         if os.environ.get("SEA_KV_NATIVE_LOOP", "1") == "0" or not p.run_steps(n_steps, base, slab, cbase, B * 4, base + slab, slab):
             for s in range(n_steps):
                 p.set_position(s)
                 p.bind_ptrs(base + s * slab, cbase + s * B * 4, base + (s + 1) * slab)
+                p.set_hoisted_step(s)
                 p.run()
         return traj[1:].permute(1, 0, 2, 3).contiguous()

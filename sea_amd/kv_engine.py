@@ -39,6 +39,16 @@ class CondPlan(Plan):
                 self._ib(f"blocks.{l}.", [ibuf])
 
 
+def cond_plan_for(eng, M: int) -> CondPlan:
+    """The engine's condition plan for M = n_steps * B rows (one row count at a time: the modulation buffers are ~12 M x 2d elements)."""
+    cache = eng.__dict__.setdefault("_cond_plans", {})
+    cp = cache.get(M)
+    if cp is None:
+        cache.clear()
+        cp = cache[M] = CondPlan(eng, M)
+    return cp
+
+
 def _chunks_ok(K: int, epc: int) -> bool:
     if K % epc:
         return False

@@ -182,3 +182,38 @@ def test_models_outside_the_limits_keep_the_generic_plan(monkeypatch):
     x, _, ib = recipe_inputs(1, 8, O.OracleConfig(1, 64, 4, 32, 4, 0, 2, 2, True, "adaln", "addition"), seed=1)
     out = _kv(add, x[:, :1].cuda().contiguous(), ib.cuda().contiguous(), 8, monkeypatch, True)
     assert len(add.engine()._kv_fast) == 0 and out.shape == (1, 8, 2, 64)
+
+
+@pytest.mark.parametrize("cfg_args", [(1, 64, 4, 48, 8, 0, 3, 2, True, "adaln"), (2, 128, 8, 40, 4, 0, 2, 2, True, "ln"), (1, 64, 4, 48, 8, 0, 2, 2, False, "adaln")])
+def test_generic_step_plan_hoists_the_condition_work(cfg_args, monkeypatch):
+    """The generic KV-cache step plan (what the shipped widths run): with the condition-only work — AdaLN modulations, the info-bottleneck term —
+    evaluated for all steps by one batched pass (engine.rollout_kv, SEA_KV_HOIST) the rollout equals the per-step form (fp32 <= 1e-5: the batched pass
+    runs the same arithmetic through the many-row GEMM kernels), carries no condition launch in its step plan, and the native step loop and the
+    per-step Python loop patch the same pointers (bitwise equal)."""
+    from sea_amd.utils.train_utils import rollout
+
+    cfg = O.OracleConfig(*cfg_args)
+    B, n = 2, 20
+    x, _, ib = recipe_inputs(B, n, cfg, seed=21)
+    x0, ibg = x[:, :1].cuda().contiguous(), ib.cuda().contiguous()
+    ref = O.rollout(x[:, :1], ib, n, recipe_params(cfg), cfg)
+    monkeypatch.setenv("SEA_KV_FAST", "0")
+    for dtype, tol, tol_paths in (("fp32", 1e-4, 1e-5), ("bf16", 3e-2, 2e-2)):
+        m = build(cfg, dtype)
+        monkeypatch.setenv("SEA_KV_HOIST", "1")
+        a = rollout(m, x0, ibg, n, mode="kv")
+        eng = m.engine()
+        plans = [p for k, p in eng._plans.items() if len(k) == 4 and k[:3] == (B, 1, "step")]
+        assert len(plans) == 1 and plans[0]._hoisted
+        names = [r.name for r in plans[0].records]
+        assert not any(nm.startswith("adaln.") for nm in names)
+        if cfg.add_info_after_cross:
+            assert "ib_add" not in names        # the info-bottleneck rows ride in the norm pass in front of the MLP
+        assert rel_l2(a.cpu().numpy(), ref.numpy()) < tol
+        monkeypatch.setenv("SEA_KV_NATIVE_LOOP", "0")
+        assert torch.equal(rollout(m, x0, ibg, n, mode="kv"), a)
+        monkeypatch.setenv("SEA_KV_NATIVE_LOOP", "1")
+        assert torch.equal(rollout(m, x0, ibg, n // 2, mode="kv")[:, :4], a[:, :4]) or dtype == "bf16"   # (a shorter rollout batches fewer rows: same kernels from 17 rows up)
+        monkeypatch.setenv("SEA_KV_HOIST", "0")
+        b = rollout(m, x0, ibg, n, mode="kv")
+        assert rel_l2(a.cpu().numpy(), b.cpu().numpy()) < tol_paths
