@@ -372,10 +372,11 @@ def leg_train(args, dist, dev, rank, world, steps, warmup, B):
     assert torch.isfinite(loss).all()
     ms = elapsed / steps * 1e3
     gflop = 3 * algorithmic_gflop(B, T, F, E, H, D, S, L)
-    out = {"value": world * B * steps / elapsed, "unit": "trajectory-steps/s", "train_steps_per_s": steps / elapsed, "ms_per_step": ms, "steps": steps,
+    out = {"allreduce_calls_per_step": int(getattr(eng, "last_allreduce_calls", 0)), "value": world * B * steps / elapsed, "unit": "trajectory-steps/s", "train_steps_per_s": steps / elapsed, "ms_per_step": ms, "steps": steps,
            "workload": f"cfg{'3' if world == 1 else '4'}: cylinder_flow temporal model E={E} H={H} F={F} L={L} adaln, fwd+bwd+AdamW (teacher-forced, T={T}), B={B} per GPU, "
                        f"global batch {world * B}",
-           "parallelism": f"dp{world}: replicated model, batch split by rank, one flat-gradient all-reduce per step (RCCL), 1/world folded into AdamW",
+           "parallelism": f"dp{world}: replicated model, batch split by rank, the flat gradient all-reduced once per step (RCCL; every element once, in up to three slices "
+                          "issued under the backward — allreduce_calls_per_step; SEA_DP_OVERLAP=0: one collective), 1/world folded into AdamW",
            "world_size": world, "model_algorithmic_gflop_per_step": gflop, "model_mfma_frac": gflop / (ms * 1e-3) / 1e3 / PEAK_BF16_TFLOPS}
     if dist is not None:
         from sea_amd.parallel import parameters_in_sync
@@ -464,6 +465,67 @@ def leg_kv(args, dev, rank):
     return out
 
 
+def leg_shipped(args, dev, rank):
+    """The reference's OWN two temporal configurations at their own size (reference configs/cylinder_flow.py:112-141: embed_dim 1024, 2 field groups,
+    AdaLN, dropout 0.1, batch 2, windows of 399 steps; configs/multiphase_flow.py:112-141: embed_dim 2048, LayerNorm, dropout 0, batch 4, windows of 199):
+    the teacher-forced training step (train/train_temporal.py:252-258) and the evaluation forward, with the dominant launch of the training step on the
+    roofline.  Synthetic windows of those shapes, random-init weights (seed 42), bf16."""
+    from sea_amd.configs import get_config
+    from sea_amd.models.temporal import TemporalModel
+    from sea_amd.utils.train_utils import initialize_optimizer
+
+    out = {}
+    esz = 2 if args.dtype == "bf16" else 4
+    for key, case in (("cylinder_flow", "cylinder_flow"), ("multiphase_flow", "multiphase_flow")):
+        c = get_config(case, "temporal")
+        E, H, F, L, B, T = c["embed_dim"], c["n_heads"], c["num_fields"], c["num_layers"], c["batch_size"], c["dataset_src_len"]
+        D, S = E // c["down_proj"], E * c["scale_ratio"]
+        adaln = c["LN_type"].lower() == "adaln"
+        torch.manual_seed(42)
+        model = TemporalModel(L, E, H, c["block_size"], c["scale_ratio"], c["src_len"], F, c["down_proj"], c["dropout"], c["exchange_mode"], c["pos_encoding_mode"],
+                              c["ib_scale_mode"], c["ib_addition_mode"], c["ib_mlp_layers"], c["ib_num"], c["add_info_after_cross"], c["LN_type"])
+        model.set_compute_dtype(args.dtype)
+        model = model.to(dev)
+        x, tgt, ib = inputs(B, T, F, E, rank, dev)
+        eng = model.engine(dev)
+        gflop = algorithmic_gflop(B, T, F, E, H, D, S, L, adaln=adaln)
+        model.eval()
+        with torch.no_grad():
+            for _ in range(3):
+                o = eng.forward(x, ib)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(20):
+                o = eng.forward(x, ib)
+            torch.cuda.synchronize()
+            fwd_ms = (time.perf_counter() - t0) / 20 * 1e3
+            assert torch.isfinite(o).all()
+            n_fwd = len([r for r in eng.plan(B, T, "full").records if r.fn is not None])
+        model.train()
+        opt = initialize_optimizer(model, {"learning_rate": c["learning_rate"]})
+        for _ in range(3):
+            loss = eng.train_step(x, tgt, ib, opt)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(10):
+            loss = eng.train_step(x, tgt, ib, opt)
+        torch.cuda.synchronize()
+        trn_ms = (time.perf_counter() - t0) / 10 * 1e3
+        assert torch.isfinite(loss).all()
+        plan = eng.train_plan(B, T)
+        times = _time_list(list(plan.records) + list(plan.bwd), iters=3)
+        out[key] = {"workload": f"configs/{case}.py temporal model at its own size: E={E} H={H} F={F} L={L} {c['LN_type']} dropout {c['dropout']}, batch {B} x {T} steps (teacher-forced)",
+                    "forward_ms": fwd_ms, "forward_trajectory_steps_per_s": B / (fwd_ms * 1e-3), "forward_launches": n_fwd,
+                    "forward_model_mfma_frac": gflop / (fwd_ms * 1e-3) / 1e3 / PEAK_BF16_TFLOPS,
+                    "train_ms_per_step": trn_ms, "train_trajectory_steps_per_s": B / (trn_ms * 1e-3), "train_launches": len(times),
+                    "train_model_mfma_frac": 3 * gflop / (trn_ms * 1e-3) / 1e3 / PEAK_BF16_TFLOPS,
+                    "model_algorithmic_gflop_forward": gflop, "parameter_MB": sum(p.numel() for p in model.parameters()) * esz / 1e6,
+                    "roofline": _roofline(times, esz), "top_launches_ms": {r.name: round(t, 4) for r, t in sorted(times, key=lambda rt: -rt[1])[:8]}}
+        del model, eng, opt, plan, times
+        torch.cuda.empty_cache()
+    return out
+
+
 # ------------------------------------------------------------------------------------------------------------------ rank body
 def run_rank(args):
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -482,7 +544,7 @@ def run_rank(args):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist_mod.init_process_group("nccl", device_id=dev)
         dist = dist_mod
-    legs = {"all": ("rollout", "train", "kv"), "rollout": ("rollout",), "train": ("train",), "kv": ("kv",)}[args.mode]
+    legs = {"all": ("rollout", "train", "kv", "shipped"), "rollout": ("rollout",), "train": ("train",), "kv": ("kv",), "shipped": ("shipped",)}[args.mode]
     headline = "train" if (world > 1 and "train" in legs) else legs[0]
     res = {}
     if "rollout" in legs:
@@ -494,13 +556,20 @@ def run_rank(args):
         torch.cuda.empty_cache()
     if "kv" in legs and (world == 1 or headline == "kv"):
         res["kv"] = leg_kv(args, dev, rank)
+        torch.cuda.empty_cache()
+    if "shipped" in legs and (world == 1 or headline == "shipped"):
+        res["shipped"] = leg_shipped(args, dev, rank)
     if rank == 0:
         h = res[headline]
         hk = h["cfg2_2024_steps"] if headline == "kv" else h
+        if headline == "shipped":   # (--mode shipped: the shipped cylinder configuration's training step as the line's value)
+            cyl = h["cylinder_flow"]
+            hk = h = dict(cyl, value=cyl["train_trajectory_steps_per_s"], ms_per_step=cyl["train_ms_per_step"], steps=10, **{k: v for k, v in h.items() if k != "cylinder_flow"})
         line = {
             "metric": {"rollout": "rollout steps/sec (full-context forward, recompute mode) on cylinder_flow-shaped fields",
                        "train": "train steps/sec (fwd+bwd+AdamW, data-parallel) on cylinder_flow-shaped fields, in trajectory-steps/s",
-                       "kv": "KV-cache rollout steps/sec on cylinder_flow-shaped fields"}[headline],
+                       "kv": "KV-cache rollout steps/sec on cylinder_flow-shaped fields",
+                       "shipped": "train steps/sec (fwd+bwd+AdamW) at the shipped cylinder_flow configuration, in trajectory-steps/s"}[headline],
             "value": hk["steps_per_s"] * world if headline == "kv" else h["value"], "unit": "trajectory-steps/s", "n_gpus": world,
             "steps": h.get("steps", args.steps), "warmup": args.warmup, "ms_per_step": hk["ms_per_step"],
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
@@ -508,9 +577,11 @@ def run_rank(args):
                        "parallelism": h.get("parallelism", f"replicas x{world} (rollout shards by trajectory, no collective)")},
             "roofline": h.get("roofline"),
         }
-        for k in ("rollout", "train", "kv"):
+        for k in ("rollout", "train", "kv", "shipped"):
             if k in res:
                 line[k] = res[k]
+        if "train" in res:
+            line["train"]["allreduce_calls_per_step"] = res["train"].get("allreduce_calls_per_step", 0)
         if world == 1 and not args.no_cpu_baseline and args.mode in ("all", "rollout"):
             line["cpu_baseline"] = cpu_baseline(1, args.seq)
         print(json.dumps(line), flush=True)
@@ -567,7 +638,7 @@ def main():
     ap.add_argument("--graph", action="store_true", help="rollout leg: replay the captured HIP graph instead of the plan's launch list (default: the launch list)")
     ap.add_argument("--no-graph", action="store_true", help="(the default now; kept for the measurement scripts)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--mode", default="all", choices=["all", "rollout", "train", "kv", "decode", "encode"],
+    ap.add_argument("--mode", default="all", choices=["all", "rollout", "train", "kv", "shipped", "decode", "encode"],
                     help="all: every leg in one line (default); rollout / train / kv: one leg; decode / encode: the spatial decoder / encoder legs "
                          "(SURVEY.md §8f ranks 1 and 2)")
     args = ap.parse_args()

@@ -578,141 +578,205 @@ __global__ __launch_bounds__(256) void rownorm_bwd_kernel(const NormBwdLaunch L)
     }
 }
 
-// Wide rows (1024 < d <= 2048, the MLP hidden width at embed_dim 256): ONE WORKGROUP per row instead of one wave.  A wave per row
-// needs ~120 VGPRs of per-row state and leaves 4 waves per SIMD waiting on their own loads (measured: 51 % of wave time in
-// s_waitcnt, 36 % SIMD utilisation); with 4 waves per row each lane owns 2 chunks, the state fits 8 waves per SIMD and the row's
-// loads are spread over four times as many requesters.  Row statistics cross the 4 waves through LDS.
-template <typename T, bool DY_ACT, bool X_ACT>
-__global__ __launch_bounds__(256) void rownorm_bwd_wide_kernel(const NormBwdLaunch L) {
-    extern __shared__ __attribute__((aligned(16))) float cs[];  // [2][d] column sums + [8] row reduction scratch
+// Wide rows (d > 1024: the MLP hidden width, 2048 at embed_dim 256, 8192 / 16384 at the shipped widths): ONE WORKGROUP per row instead of one
+// wave.  A wave per row needs ~120 VGPRs of per-row state and leaves 4 waves per SIMD waiting on their own loads (measured: 51 % of wave time in
+// s_waitcnt, 36 % SIMD utilisation); with the row spread over NT threads x KCH chunks of 4 columns each lane owns few chunks, the row's loads are
+// spread over many requesters, and every thread keeps the column sums of ITS columns in registers for all the rows of its workgroup — no LDS
+// atomics, no second pass over the row (the per-element LDS-atomic form this replaces for d > 2048 re-read the row, evaluated GELU' twice and ran
+// at 0.4 TB/s: 200 us for the 78 MB of the shipped cylinder width).  Row statistics cross the waves through LDS.  Column sums leave as plain
+// stores into the two-stage workspace (or as atomics when the caller gave none).
+template <typename T, bool DY_ACT, bool X_ACT, int NT, int KCH>
+__global__ __launch_bounds__(NT) void rownorm_bwd_wide_kernel(const NormBwdLaunch L) {
+    constexpr int NW = NT / 64;
+    __shared__ float red[2 * NW];
     const SeaNormBwdGroup& G = L.g[blockIdx.y];
     const int d = L.d, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    float* red = cs + 2 * d;
-    for (int i = tid; i < 2 * d; i += 256) cs[i] = 0.f;
     using DYT = typename std::conditional<DY_ACT, T, float>::type;
     using XT = typename std::conditional<X_ACT, T, float>::type;
     const float inv_d = 1.0f / (float)d;
-    float accg[2][4], accb[2][4], s[2][4], tt[2][4];
+    // (KCH > 2, rows of up to 16384 columns on 1024 threads: 128 registers per thread — the row-independent gain / shift are re-read per row from L2
+    // instead of kept, and the second pass recomputes xhat from x instead of keeping it)
+    constexpr bool KEEP = KCH <= 2;
+    float accg[KCH][4], accb[KCH][4], s[KCH][4], tt[KCH][4];
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
-        const int i = tid * 4 + 1024 * k;
+    for (int k = 0; k < KCH; ++k) {
+        const int i = tid * 4 + NT * 4 * k;
 #pragma unroll
         for (int e = 0; e < 4; ++e) accg[k][e] = accb[k][e] = s[k][e] = tt[k][e] = 0.f;
-        if (i < d && G.mod == nullptr) {  // row-independent gain / shift: loaded once
+        if (KEEP && i < d && G.mod == nullptr) {  // row-independent gain / shift: loaded once
             load4(G.gamma + i, s[k]);
             if (L.gelu && G.beta) load4(G.beta + i, tt[k]);
         }
     }
-    __syncthreads();
     for (int row = blockIdx.x; row < L.M; row += gridDim.x) {
         const DYT* dy = static_cast<const DYT*>(G.dY) + (int64_t)row * G.lddy;
         const XT* x = static_cast<const XT*>(G.X) + (int64_t)row * G.ldx;
         const T* mod = G.mod ? static_cast<const T*>(G.mod) + (int64_t)row * G.ldmod : nullptr;
         T* dmod = G.dmod ? static_cast<T*>(G.dmod) + (int64_t)row * G.lddmod : nullptr;
         const float mean = G.mean[row], rstd = G.rstd[row];
-        float xv[2][4], dv[2][4];
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {  // all of the row's loads first
-            const int i = tid * 4 + 1024 * k;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) xv[k][e] = dv[k][e] = 0.f;
-            if (i < d) {
-                load4(x + i, xv[k]);
-                load4(dy + i, dv[k]);
-                if (mod) {
-                    float mw[4];
-                    load4(G.gamma + i, s[k]);
-                    load4(mod + i, mw);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) s[k][e] += 1.0f + mw[e];
-                    if (L.gelu) {
-                        float mb[4];
-                        load4(mod + d + i, mb);
-                        if (G.beta) load4(G.beta + i, tt[k]);
-                        else tt[k][0] = tt[k][1] = tt[k][2] = tt[k][3] = 0.f;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) tt[k][e] += mb[e];
-                    }
-                }
-            }
-        }
-        float c1 = 0.f, c2 = 0.f, kdx[2][4], kxh[2][4];
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            const int i = tid * 4 + 1024 * k;
-            if (i < d) {
-                float dyx[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float xh = (xv[k][e] - mean) * rstd;
-                    if (L.gelu) dv[k][e] *= gelu_grad_for<T>(xh * s[k][e] + tt[k][e]);
-                    const float dxh = dv[k][e] * s[k][e];
-                    c1 += dxh;
-                    c2 += dxh * xh;
-                    dyx[e] = dv[k][e] * xh;
-                    accg[k][e] += dyx[e];
-                    accb[k][e] += dv[k][e];
-                    kdx[k][e] = dxh;
-                    kxh[k][e] = xh;
-                }
-                if (dmod) {
-                    store4(dmod + i, dyx[0], dyx[1], dyx[2], dyx[3]);
-                    store4(dmod + d + i, dv[k][0], dv[k][1], dv[k][2], dv[k][3]);
-                }
-            }
-        }
-        c1 = wave_sum(c1);
-        c2 = wave_sum(c2);
-        if (lane == 0) {
-            red[wave] = c1;
-            red[4 + wave] = c2;
-        }
-        __syncthreads();
-        c1 = (red[0] + red[1] + red[2] + red[3]) * inv_d;
-        c2 = (red[4] + red[5] + red[6] + red[7]) * inv_d;
-        __syncthreads();
         float* dx32 = G.dX32 ? G.dX32 + (int64_t)row * G.lddx32 : nullptr;
         T* dxa = G.dXact ? static_cast<T*>(G.dXact) + (int64_t)row * G.lddxact : nullptr;
+        auto gain_shift = [&](int i, float (&sv)[4], float (&tv)[4]) {   // this chunk's s = gamma (+ 1 + mod_w), t = beta (+ mod_b) (t only feeds GELU')
+            load4(G.gamma + i, sv);
+            tv[0] = tv[1] = tv[2] = tv[3] = 0.f;
+            if (L.gelu && G.beta) load4(G.beta + i, tv);
+            if (mod) {
+                float mw[4];
+                load4(mod + i, mw);
 #pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            const int i = tid * 4 + 1024 * k;
-            if (i < d) {
-                float o[4];
+                for (int e = 0; e < 4; ++e) sv[e] += 1.0f + mw[e];
+                if (L.gelu) {
+                    float mb[4];
+                    load4(mod + d + i, mb);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = rstd * (kdx[k][e] - c1 - kxh[k][e] * c2);
-                if (dx32) {
-                    if (L.accumulate) {
-                        float old[4];
-                        load4(dx32 + i, old);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) o[e] += old[e];
-                    }
-                    store4(dx32 + i, o[0], o[1], o[2], o[3]);
+                    for (int e = 0; e < 4; ++e) tv[e] += mb[e];
                 }
-                if (dxa) store4(dxa + i, o[0], o[1], o[2], o[3]);
+            }
+        };
+        auto emit = [&](int i, float (&o)[4]) {
+            if (dx32) {
+                if (L.accumulate) {
+                    float old[4];
+                    load4(dx32 + i, old);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] += old[e];
+                }
+                store4(dx32 + i, o[0], o[1], o[2], o[3]);
+            }
+            if (dxa) store4(dxa + i, o[0], o[1], o[2], o[3]);
+        };
+        auto row_stats = [&](float& c1, float& c2) {   // sums over the row of dxhat and dxhat * xhat, divided by d
+            c1 = wave_sum(c1);
+            c2 = wave_sum(c2);
+            if (lane == 0) {
+                red[wave] = c1;
+                red[NW + wave] = c2;
+            }
+            __syncthreads();
+            c1 = c2 = 0.f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) {
+                c1 += red[w];
+                c2 += red[NW + w];
+            }
+            c1 *= inv_d;
+            c2 *= inv_d;
+            __syncthreads();
+        };
+        float c1 = 0.f, c2 = 0.f;
+        if constexpr (KEEP) {
+            float xv[KCH][4], dv[KCH][4];
+#pragma unroll
+            for (int k = 0; k < KCH; ++k) {  // all of the row's loads first
+                const int i = tid * 4 + NT * 4 * k;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) xv[k][e] = dv[k][e] = 0.f;
+                if (i < d) {
+                    load4(x + i, xv[k]);
+                    load4(dy + i, dv[k]);
+                    if (mod) gain_shift(i, s[k], tt[k]);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < KCH; ++k) {   // xv becomes xhat, dv becomes dxhat = dy (gelu') s — in place: the second pass needs exactly these two
+                const int i = tid * 4 + NT * 4 * k;
+                if (i < d) {
+                    float dyx[4], dvg[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float xh = (xv[k][e] - mean) * rstd;
+                        dvg[e] = L.gelu ? dv[k][e] * gelu_grad_for<T>(xh * s[k][e] + tt[k][e]) : dv[k][e];
+                        const float dxh = dvg[e] * s[k][e];
+                        c1 += dxh;
+                        c2 += dxh * xh;
+                        dyx[e] = dvg[e] * xh;
+                        accg[k][e] += dyx[e];
+                        accb[k][e] += dvg[e];
+                        dv[k][e] = dxh;
+                        xv[k][e] = xh;
+                    }
+                    if (dmod) {
+                        store4(dmod + i, dyx[0], dyx[1], dyx[2], dyx[3]);
+                        store4(dmod + d + i, dvg[0], dvg[1], dvg[2], dvg[3]);
+                    }
+                }
+            }
+            row_stats(c1, c2);
+#pragma unroll
+            for (int k = 0; k < KCH; ++k) {
+                const int i = tid * 4 + NT * 4 * k;
+                if (i < d) {
+                    float o[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = rstd * (dv[k][e] - c1 - xv[k][e] * c2);
+                    emit(i, o);
+                }
+            }
+        } else {
+            // rows of more than 8192 columns: 4 chunks per thread do not fit the 128 registers a 1024-thread workgroup leaves a thread, so the second pass
+            // reads the row again (64 KB the first pass has just pulled into L2) and evaluates GELU' a second time instead of keeping dxhat / xhat
+#pragma unroll
+            for (int k = 0; k < KCH; ++k) {
+                const int i = tid * 4 + NT * 4 * k;
+                if (i < d) {
+                    float xv[4], dv[4], sv[4], tv[4], dyx[4], dvg[4];
+                    load4(x + i, xv);
+                    load4(dy + i, dv);
+                    gain_shift(i, sv, tv);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float xh = (xv[e] - mean) * rstd;
+                        dvg[e] = L.gelu ? dv[e] * gelu_grad_for<T>(xh * sv[e] + tv[e]) : dv[e];
+                        const float dxh = dvg[e] * sv[e];
+                        c1 += dxh;
+                        c2 += dxh * xh;
+                        dyx[e] = dvg[e] * xh;
+                        accg[k][e] += dyx[e];
+                        accb[k][e] += dvg[e];
+                    }
+                    if (dmod) {
+                        store4(dmod + i, dyx[0], dyx[1], dyx[2], dyx[3]);
+                        store4(dmod + d + i, dvg[0], dvg[1], dvg[2], dvg[3]);
+                    }
+                }
+            }
+            row_stats(c1, c2);
+#pragma unroll
+            for (int k = 0; k < KCH; ++k) {
+                const int i = tid * 4 + NT * 4 * k;
+                if (i < d) {
+                    float xv[4], dv[4], sv[4], tv[4], o[4];
+                    load4(x + i, xv);
+                    load4(dy + i, dv);
+                    gain_shift(i, sv, tv);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float xh = (xv[e] - mean) * rstd;
+                        const float dvg = L.gelu ? dv[e] * gelu_grad_for<T>(xh * sv[e] + tv[e]) : dv[e];
+                        o[e] = rstd * (dvg * sv[e] - c1 - xh * c2);
+                    }
+                    emit(i, o);
+                }
             }
         }
     }
+    // a thread owns its columns: plain stores of the workgroup's partial sums (two-stage), or one atomic per column
+    float* ws = L.ws != nullptr ? L.ws + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 2 * d : nullptr;
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {  // a thread owns its columns: plain stores, no atomics needed inside the workgroup
-        const int i = tid * 4 + 1024 * k;
+    for (int k = 0; k < KCH; ++k) {
+        const int i = tid * 4 + NT * 4 * k;
         if (i < d) {
+            if (ws != nullptr) {
+                store4(ws + i, accg[k][0], accg[k][1], accg[k][2], accg[k][3]);
+                store4(ws + d + i, accb[k][0], accb[k][1], accb[k][2], accb[k][3]);
+            } else {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                cs[i + e] = accg[k][e];
-                cs[d + i + e] = accb[k][e];
+                for (int e = 0; e < 4; ++e) {
+                    if (G.dgamma) atomicAdd(G.dgamma + i + e, accg[k][e]);
+                    if (G.dbeta) atomicAdd(G.dbeta + i + e, accb[k][e]);
+                }
             }
         }
-    }
-    __syncthreads();
-    if (L.ws != nullptr) {
-        float* dst = L.ws + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 2 * d;
-        for (int i = tid; i < 2 * d; i += 256) dst[i] = cs[i];
-        return;
-    }
-    for (int i = tid; i < d; i += 256) {
-        if (G.dgamma) atomicAdd(G.dgamma + i, cs[i]);
-        if (G.dbeta) atomicAdd(G.dbeta + i, cs[d + i]);
     }
 }
 
@@ -735,15 +799,17 @@ extern "C" int sea_rownorm_bwd(const SeaNormBwdGroup* groups, int n_groups, int 
         L.g[i] = G;
     }
     L.M = M; L.d = d; L.gelu = gelu; L.accumulate = accumulate;
-    const bool wide = d > 1024 && d <= 2048;  // one workgroup per row
+    const bool wide = d > 1024;  // one workgroup per row: 256 threads up to 2048 columns, 512 up to 4096, 1024 beyond (2 / 2 / 2-4 chunks of 4 columns per thread)
     int nblk = wide ? M : (M + 3) / 4;
     static const int nblk_cap = []() { const char* e = getenv("SEA_NORMBWD_BLOCKS"); return e ? atoi(e) : 512; }();  // tuning aid
     if (nblk > nblk_cap) nblk = nblk_cap;
     if (wide) {
         // all workgroups of the launch resident at once (5 per CU at the wide kernel's 90 VGPRs): a second, partial round costs more than
         // the extra parallelism returns (measured at cfg3, 3 groups: 384 per group 171 us, 512 207 us, 448 220 us)
-        const int fit = (5 * 256 / n_groups) / 64 * 64;
-        if (fit >= 128 && nblk > fit) nblk = fit;
+        const int per_cu = d <= 2048 ? 5 : (d <= 4096 ? 2 : 1);
+        int fit = (per_cu * 256 / n_groups) / 64 * 64;
+        if (d > 2048 && fit < 64) fit = 64;
+        if (fit >= 64 && nblk > fit) nblk = fit;
     }
     const bool two_stage = ws != nullptr && ws_floats >= (int64_t)n_groups * nblk * 2 * d && nblk > 8;
     L.ws = two_stage ? ws : nullptr;
@@ -761,8 +827,10 @@ extern "C" int sea_rownorm_bwd(const SeaNormBwdGroup* groups, int n_groups, int 
         if (d <= 256) LAUNCH_NBK(TT, DYA, XA, 1);      \
         else if (d <= 512) LAUNCH_NBK(TT, DYA, XA, 2); \
         else if (d <= 1024) LAUNCH_NBK(TT, DYA, XA, 4);\
-        else if (d <= 2048) rownorm_bwd_wide_kernel<TT, DYA, XA><<<grid, block, lds, s>>>(L);\
-        else LAUNCH_NBK(TT, DYA, XA, 0);               \
+        else if (d <= 2048) rownorm_bwd_wide_kernel<TT, DYA, XA, 256, 2><<<grid, dim3(256), 0, s>>>(L);\
+        else if (d <= 4096) rownorm_bwd_wide_kernel<TT, DYA, XA, 512, 2><<<grid, dim3(512), 0, s>>>(L);\
+        else if (d <= 8192) rownorm_bwd_wide_kernel<TT, DYA, XA, 1024, 2><<<grid, dim3(1024), 0, s>>>(L);\
+        else rownorm_bwd_wide_kernel<TT, DYA, XA, 1024, 4><<<grid, dim3(1024), 0, s>>>(L);\
     } while (0)
     if (dtype == SEA_BF16) {
         if (dy_is_act && x_is_act) LAUNCH_NB(__bf16, true, true);

@@ -170,6 +170,36 @@ def test_rownorm_bwd_ln_gelu_act(dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("S,M,two_stage", [(1536, 70, False), (2048, 260, True), (4096, 90, True), (8192, 70, False), (8192, 130, True), (16384, 40, True), (12288, 33, False)])
+def test_rownorm_bwd_wide_rows(dtype, S, M, two_stage):
+    """The workgroup-per-row backward of LayerNorm + GELU at the hidden widths of every shipped model (2048 at embed_dim 256; 8192 / 16384 at the shipped
+    cylinder / multiphase widths: 256 / 512 / 1024 threads per row, the 16384-column form re-reading the row in its second pass), two groups per launch,
+    column sums through the two-stage workspace and through atomics, against autograd."""
+    from sea_amd import ops
+
+    is_act = dtype != torch.float32
+    groups, refs = [], []
+    for gi in range(2):
+        h = (rnd(M, S, seed=120 + gi) * 1.3 + 0.1).to(dtype)
+        gamma, beta = 1 + 0.1 * rnd(S, seed=122 + gi), 0.1 * rnd(S, seed=124 + gi)
+        dy = rnd(M, S, dtype=dtype, seed=126 + gi)
+        mean, rstd = torch.empty(M, device=dev()), torch.empty(M, device=dev())
+        hg = torch.empty(M, S, device=dev(), dtype=dtype)
+        ops.rownorm([dict(X=h, gamma=gamma, beta=beta, Yact=hg, mean=mean, rstd=rstd)], M, S, is_act, True, 1e-5, dtype)
+        dh = torch.full((M, S), float("nan"), device=dev(), dtype=dtype)
+        dgamma, dbeta = torch.zeros(S, device=dev()), torch.zeros(S, device=dev())
+        groups.append(dict(dY=dy, X=h, gamma=gamma, beta=beta, mean=mean, rstd=rstd, dXact=dh, dgamma=dgamma, dbeta=dbeta))
+        refs.append((h, gamma, beta, dy))
+    ws = torch.empty(2 * 512 * 2 * S, device=dev()) if two_stage else None
+    ops.rownorm_bwd(groups, M, S, is_act, is_act, True, False, dtype, ws=ws)
+    for g, (h, gamma, beta, dy) in zip(groups, refs):
+        hr, gr, br = h.float().clone().requires_grad_(True), gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+        gelu(torch.nn.functional.layer_norm(hr, (S,), gr, br, 1e-5)).backward(dy.float())
+        assert rel(g["dXact"].float(), hr.grad) < tol(dtype)
+        assert rel(g["dgamma"], gr.grad) < 5e-5 and rel(g["dbeta"], br.grad) < 5e-5
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 def test_silu_outer_bwd(dtype):
     from sea_amd import ops
 
