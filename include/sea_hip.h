@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define SEA_ABI_VERSION 4
+#define SEA_ABI_VERSION 5
 
 enum { SEA_F32 = 0, SEA_BF16 = 1 };
 
@@ -526,6 +526,12 @@ typedef struct {
     int32_t mode;   /* 0: the MLP form above; 1: ib = nn.Linear(1, E) (ib_scale_mode 'linear', models/temporal.py:106-107): dw1 [E] += sum_m c[m] sum_f dX_f[m, :],
                      * db1 [E] += sum_m sum_f dX_f[m, :]; the other pointers are ignored */
     int32_t pad_;
+    /* workspaces of the column-block form (mode 0, h <= 8; both optional — without them the one-wave-per-row kernel runs):
+     *   ws   f32 [>= rs * E * (1 + h)]   per-row-split partial sums of db2 | dW2, rs = ws_floats / (E * (1 + h)) row splits at most
+     *   dhid f32 [M, 8]                   d(loss)/d(hidden) per row; must be ZERO on entry when E > 256 (column blocks add into it) and is left zero */
+    float* ws;
+    int64_t ws_floats;
+    float* dhid;
 } SeaIbBwdParams;
 int sea_ib_bwd(const SeaIbBwdParams* params, void* stream);
 

@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libsea_hip.so")
 
 SEA_F32, SEA_BF16 = 0, 1
-ABI_VERSION = 4   # include/sea_hip.h SEA_ABI_VERSION
+ABI_VERSION = 5   # include/sea_hip.h SEA_ABI_VERSION
 MAX_GROUPS = 16
 MAX_ATTN_PROBLEMS = 8
 MAX_NORM_GROUPS = 16
@@ -92,7 +92,8 @@ class SeaIbBwdParams(C.Structure):
     _fields_ = [("dX", _vp * 8), ("n_fields", _i32), ("ldx", _i32),
                 ("c", _vp), ("w1", _vp), ("b1", _vp), ("lnw", _vp), ("lnb", _vp), ("w2", _vp),
                 ("dw1", _vp), ("db1", _vp), ("dlnw", _vp), ("dlnb", _vp), ("dw2", _vp), ("db2", _vp),
-                ("M", _i32), ("E", _i32), ("h", _i32), ("drop", SeaDropout), ("mode", _i32), ("pad_", _i32)]
+                ("M", _i32), ("E", _i32), ("h", _i32), ("drop", SeaDropout), ("mode", _i32), ("pad_", _i32),
+                ("ws", _vp), ("ws_floats", _i64), ("dhid", _vp)]
 
 
 class SeaAttnBwdProblem(C.Structure):

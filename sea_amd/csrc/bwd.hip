@@ -951,6 +951,86 @@ __global__ __launch_bounds__(256) void silu_outer_bwd_kernel(const SiluBwdLaunch
     }
 }
 
+// Column-block form: a workgroup owns 256 columns of one group and a slice of the rows; lane = 4 consecutive columns, the four waves take rows
+// w, w + 4, ... of the slice (four rows of a wave in flight), partial sums meet in LDS and leave as ONE plain store per column into the two-stage
+// workspace.  No LDS atomics, no per-workgroup slab of the whole row width: the row form above writes n_blocks x 2 K2 floats of partials per group —
+// with the 798 rows of a shipped cylinder batch that was more bytes than the input (140 us for 23 MB) — and walks its rows one dependent load at a time.
+struct SiluColsLaunch {
+    SeaSiluBwdGroup g[SEA_MAX_SILU_BWD_GROUPS];
+    int cb_start[SEA_MAX_SILU_BWD_GROUPS + 1];   // first column block of each group
+    int n_groups;
+    const float* c;
+    int M, rows_per;
+    float* ws;      // [n_groups][gridDim.y][2 * maxk]
+    int maxk;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void silu_outer_bwd_cols_kernel(const SiluColsLaunch L) {
+    __shared__ float red[3][8][64];
+    int gi = 0;
+    while (gi + 1 < L.n_groups && (int)blockIdx.x >= L.cb_start[gi + 1]) ++gi;
+    const SeaSiluBwdGroup& G = L.g[gi];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int K2 = G.K2;
+    const int col = ((int)blockIdx.x - L.cb_start[gi]) * 256 + lane * 4;
+    const bool act = col < K2;
+    const int cc = act ? col : K2 - 4;
+    float w[4], bb[4], aw[4] = {0.f, 0.f, 0.f, 0.f}, ab[4] = {0.f, 0.f, 0.f, 0.f};
+    load4(G.w1 + cc, w);
+    load4(G.b1 + cc, bb);
+    const int r0 = blockIdx.y * L.rows_per, r1 = min(L.M, r0 + L.rows_per);
+    const T* dh0 = static_cast<const T*>(G.dHid) + cc;
+    for (int row = r0 + wave; row < r1; row += 16) {
+        float cv[4], dv[4][4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {   // four rows requested together
+            const int rr = row + 4 * u;
+            const int rc = rr < r1 ? rr : row;
+            cv[u] = L.c[rc];
+            load4(dh0 + (int64_t)rc * G.ld, dv[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const bool live = act && row + 4 * u < r1;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float pre = w[e] * cv[u] + bb[e];
+                const float sg = 1.0f / (1.0f + __expf(-pre));
+                const float dpre = live ? dv[u][e] * sg * (1.0f + pre * (1.0f - sg)) : 0.f;
+                aw[e] += dpre * cv[u];
+                ab[e] += dpre;
+            }
+        }
+    }
+    if (wave > 0) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            red[wave - 1][e][lane] = aw[e];
+            red[wave - 1][4 + e][lane] = ab[e];
+        }
+    }
+    __syncthreads();
+    if (wave == 0 && act) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            aw[e] += (red[0][e][lane] + red[1][e][lane]) + red[2][e][lane];
+            ab[e] += (red[0][4 + e][lane] + red[1][4 + e][lane]) + red[2][4 + e][lane];
+        }
+        if (L.ws != nullptr) {
+            float* dst = L.ws + ((int64_t)gi * gridDim.y + blockIdx.y) * 2 * L.maxk;
+            store4(dst + col, aw[0], aw[1], aw[2], aw[3]);
+            store4(dst + K2 + col, ab[0], ab[1], ab[2], ab[3]);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                atomicAdd(G.dw1 + col + e, aw[e]);
+                atomicAdd(G.db1 + col + e, ab[e]);
+            }
+        }
+    }
+}
+
 extern "C" int sea_silu_outer_bwd(const SeaSiluBwdGroup* groups, int n_groups, const float* c, int M, int dtype, float* ws, int64_t ws_floats,
                                   void* stream) {
     SEA_REQUIRE(groups && c && n_groups >= 1 && n_groups <= SEA_MAX_SILU_BWD_GROUPS && M >= 1, "sea_silu_outer_bwd: bad arguments");
@@ -965,6 +1045,44 @@ extern "C" int sea_silu_outer_bwd(const SeaSiluBwdGroup* groups, int n_groups, c
         L.g[i] = G;
         maxk = G.K2 > maxk ? G.K2 : maxk;
     }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    static const int cols_form = []() { const char* e = getenv("SEA_SILUBWD_COLS"); return e ? atoi(e) : 1; }();   // tuning aid: 0 = the one-wave-per-row kernel
+    if (cols_form && ws != nullptr) {
+        SiluColsLaunch Q;
+        memset(&Q, 0, sizeof(Q));
+        int ncb = 0;
+        for (int i = 0; i < n_groups; ++i) {
+            Q.g[i] = groups[i];
+            Q.cb_start[i] = ncb;
+            ncb += (groups[i].K2 + 255) / 256;
+        }
+        Q.cb_start[n_groups] = ncb;
+        Q.n_groups = n_groups; Q.c = c; Q.M = M; Q.maxk = maxk;
+        // row splits: about four workgroups per CU in all, at least 16 rows (one trip of a workgroup) per split, and what the workspace holds
+        int rs = (1024 + ncb - 1) / ncb;
+        const int rs_rows = (M + 15) / 16;
+        rs = rs > rs_rows ? rs_rows : rs;
+        const int64_t rs_ws = ws_floats / ((int64_t)n_groups * 2 * maxk);
+        rs = rs > rs_ws ? (int)rs_ws : rs;
+        if (rs >= 1) {
+            Q.rows_per = (M + rs - 1) / rs;
+            rs = (M + Q.rows_per - 1) / Q.rows_per;
+            Q.ws = ws;
+            if (dtype == SEA_BF16) silu_outer_bwd_cols_kernel<__bf16><<<dim3(ncb, rs), dim3(256), 0, s>>>(Q);
+            else silu_outer_bwd_cols_kernel<float><<<dim3(ncb, rs), dim3(256), 0, s>>>(Q);
+            ColsumFinish F;
+            memset(&F, 0, sizeof(F));
+            for (int i = 0; i < n_groups; ++i) {
+                F.out_a[i] = groups[i].dw1;
+                F.out_b[i] = groups[i].db1;
+                F.width[i] = groups[i].K2;
+            }
+            F.ws = ws; F.nblk = rs; F.stride = 2 * maxk;
+            colsum_finish_kernel<<<dim3((2 * maxk + 255) / 256, n_groups, rs < 16 ? rs : 16), dim3(256), 0, s>>>(F);
+            SEA_CHECK_LAUNCH("sea_silu_outer_bwd");
+            return SEA_OK;
+        }
+    }
     L.c = c; L.M = M;
     int nblk = (M + 3) / 4;
     // every workgroup of the launch resident at once (about 6 per CU): measured at cfg3 (12 groups) 128 per group 76 us, 160 90 us, 256 112 us
@@ -976,7 +1094,6 @@ extern "C" int sea_silu_outer_bwd(const SeaSiluBwdGroup* groups, int n_groups, c
     L.ws = two_stage ? ws : nullptr;
     L.maxk = maxk;
     const size_t lds = (size_t)2 * maxk * sizeof(float);
-    hipStream_t s = static_cast<hipStream_t>(stream);
 #define LAUNCH_SB(TT, KMV)                                                                                                            \
     do {                                                                                                                              \
         if (lds > 65536) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(silu_outer_bwd_kernel<TT, KMV>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
@@ -1216,6 +1333,201 @@ __global__ __launch_bounds__(256) void ib_bwd_fast_kernel(const SeaIbBwdParams P
     for (int i = threadIdx.x; i < E * h; i += 256) atomicAdd(P.dw2 + i, s_w2[i]);
 }
 
+// ---- column-block form (h <= 8): three launches.
+//  (1) ib_bwd_cols_kernel, grid (E / 256 column blocks, row splits): lane = 4 consecutive columns, the four waves take rows w, w + 4, ... of the split.
+//      Per row: dib = sum_f dX_f (dropout as in the forward), db2 / dW2 partial sums in registers (the row's hidden vector comes from lanes 0 .. h-1),
+//      and the row's d hidden_j = sum_e dib_e W2[e][j]: 8 partial dot products per lane, summed over the wave by a transposing butterfly (10 exchanges
+//      instead of 8 x 6) and stored (one column block) or added (several) into dhid [M, 8].  The partial sums leave through LDS as plain stores
+//      into the workspace [row split][E | E h].
+//  (2) ib_bwd_rows_kernel, one thread per row: the scalar chain hidden -> GELU -> LayerNorm_h -> w1 c + b1 backwards, 4 h sums -> 4 h atomics per workgroup.
+//  (3) ib_bwd_finish_kernel: db2 / dW2 += sum over the row splits.
+// The one-wave-per-row kernels above keep dW2 for all the wave's columns in registers (272 of them at E = 1024: spilled) and end in n_blocks x E (1 + h)
+// atomics onto the same addresses: 80 us for the 6.5 MB of a shipped cylinder batch.
+__device__ __forceinline__ void ib_hidden(float cv, float w1, float b1, float lw, float lb, int h, bool act, float& xh, float& u, float& rstd) {
+    const float pre = act ? w1 * cv + b1 : 0.f;
+    const float mean = wave_sum(pre) / (float)h;
+    const float cen = act ? pre - mean : 0.f;
+    const float var = wave_sum(cen * cen) / (float)h;
+    rstd = 1.0f / sqrtf(var + 1e-5f);
+    xh = cen * rstd;
+    u = xh * lw + lb;
+}
+
+__global__ __launch_bounds__(256) void ib_bwd_cols_kernel(const SeaIbBwdParams P, int rows_per, int n_cb) {
+    constexpr int HM = 8;
+    __shared__ float red[3][4 * (HM + 1)][64];
+    const int E = P.E, h = P.h, lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int col = blockIdx.x * 256 + lane * 4;
+    const bool actc = col < E;
+    const int cc = actc ? col : E - 4;
+    const bool act = lane < h;
+    const float w1 = act ? P.w1[lane] : 0.f, b1 = act ? P.b1[lane] : 0.f, lw = act ? P.lnw[lane] : 0.f, lb = act ? P.lnb[lane] : 0.f;
+    float w2r[4][HM], ab2[4], aw2[4][HM];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        ab2[e] = 0.f;
+#pragma unroll
+        for (int j = 0; j < HM; ++j) {
+            aw2[e][j] = 0.f;
+            w2r[e][j] = (actc && j < h) ? P.w2[(int64_t)(col + e) * h + j] : 0.f;
+        }
+    }
+    const float dsc = P.drop.thr > 0 ? drop_scale(P.drop.thr) : 1.f;
+    const int r0 = blockIdx.y * rows_per, r1 = min(P.M, r0 + rows_per);
+    for (int row = r0 + wave; row < r1; row += 4) {
+        float dib[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int f = 0; f < P.n_fields; ++f) {
+            float v[4];
+            load4(P.dX[f] + (int64_t)row * P.ldx + cc, v);
+            if (P.drop.thr > 0) {
+                const uint32_t wd = drop_word(P.drop.seed, P.drop.stream + f, (uint32_t)row, (uint32_t)(cc >> 2));
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] *= drop_factor(wd, e, P.drop.thr, dsc);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) dib[e] += v[e];
+        }
+        if (!actc) dib[0] = dib[1] = dib[2] = dib[3] = 0.f;
+        float xh, u, rstd;
+        ib_hidden(P.c[row], w1, b1, lw, lb, h, act, xh, u, rstd);
+        const float hid = act ? gelu_erf(u) : 0.f;
+        float part[HM];
+#pragma unroll
+        for (int j = 0; j < HM; ++j) {
+            const float hj = __shfl(hid, j);
+            part[j] = 0.f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                aw2[e][j] += dib[e] * hj;
+                part[j] += dib[e] * w2r[e][j];
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) ab2[e] += dib[e];
+        // wave sum of the 8 partial dot products: after exchanges at distances 1, 2, 4 every lane holds ONE of them summed over its 8-lane group
+        // (which one: j = 4 b0 + 2 b1 + b2 of its lane bits), three more exchanges sum the groups
+        float q4[4], q2[2], q1;
+        {
+            const bool b0 = lane & 1, b1_ = lane & 2, b2 = lane & 4;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float send = b0 ? part[i] : part[i + 4], keep = b0 ? part[i + 4] : part[i];
+                q4[i] = keep + __shfl_xor(send, 1);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const float send = b1_ ? q4[i] : q4[i + 2], keep = b1_ ? q4[i + 2] : q4[i];
+                q2[i] = keep + __shfl_xor(send, 2);
+            }
+            const float send = b2 ? q2[0] : q2[1], keep = b2 ? q2[1] : q2[0];
+            q1 = keep + __shfl_xor(send, 4);
+            q1 += __shfl_xor(q1, 8);
+            q1 += __shfl_xor(q1, 16);
+            q1 += __shfl_xor(q1, 32);
+        }
+        if (lane < 8) {
+            const int j = ((lane & 1) << 2) | (lane & 2) | ((lane >> 2) & 1);
+            if (n_cb == 1) P.dhid[(int64_t)row * HM + j] = q1;
+            else atomicAdd(P.dhid + (int64_t)row * HM + j, q1);
+        }
+    }
+    // the four waves' partial sums of this column block: waves 1 .. 3 through LDS, wave 0 stores
+    if (wave > 0) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            red[wave - 1][e][lane] = ab2[e];
+#pragma unroll
+            for (int j = 0; j < HM; ++j) red[wave - 1][4 + e * HM + j][lane] = aw2[e][j];
+        }
+    }
+    __syncthreads();
+    if (wave == 0 && actc) {
+        float* dst = P.ws + (int64_t)blockIdx.y * E * (1 + h);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            dst[col + e] = ab2[e] + (red[0][e][lane] + red[1][e][lane]) + red[2][e][lane];
+#pragma unroll
+            for (int j = 0; j < HM; ++j)
+                if (j < h) dst[E + (int64_t)(col + e) * h + j] = aw2[e][j] + (red[0][4 + e * HM + j][lane] + red[1][4 + e * HM + j][lane]) + red[2][4 + e * HM + j][lane];
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void ib_bwd_rows_kernel(const SeaIbBwdParams P, int rezero) {
+    constexpr int HM = 8;
+    __shared__ float red[4][4 * HM];
+    const int h = P.h, row = blockIdx.x * 256 + threadIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float acc[4][HM];   // d w1 | d b1 | d lnw | d lnb of hidden unit j, this thread's row
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int j = 0; j < HM; ++j) acc[q][j] = 0.f;
+    if (row < P.M) {
+        const float cv = P.c[row];
+        float pre[HM], mean = 0.f, var = 0.f;
+#pragma unroll
+        for (int j = 0; j < HM; ++j) {
+            pre[j] = j < h ? P.w1[j] * cv + P.b1[j] : 0.f;
+            mean += pre[j];
+        }
+        mean /= (float)h;
+#pragma unroll
+        for (int j = 0; j < HM; ++j) {
+            pre[j] = j < h ? pre[j] - mean : 0.f;
+            var += pre[j] * pre[j];
+        }
+        const float rstd = 1.0f / sqrtf(var / (float)h + 1e-5f);
+        float dxh[HM], xh[HM], c1 = 0.f, c2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < HM; ++j) {
+            xh[j] = pre[j] * rstd;
+            const float lwj = j < h ? P.lnw[j] : 0.f, lbj = j < h ? P.lnb[j] : 0.f;
+            const float u = xh[j] * lwj + lbj;
+            const float du = j < h ? P.dhid[(int64_t)row * HM + j] * gelu_erf_grad(u) : 0.f;
+            if (rezero) P.dhid[(int64_t)row * HM + j] = 0.f;   // several column blocks ADD into dhid: leave it zero for the next step
+            acc[2][j] = du * xh[j];
+            acc[3][j] = du;
+            dxh[j] = du * lwj;
+            c1 += dxh[j];
+            c2 += dxh[j] * xh[j];
+        }
+        c1 /= (float)h;
+        c2 /= (float)h;
+#pragma unroll
+        for (int j = 0; j < HM; ++j) {
+            const float dpre = j < h ? rstd * (dxh[j] - c1 - xh[j] * c2) : 0.f;
+            acc[0][j] = dpre * cv;
+            acc[1][j] = dpre;
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int j = 0; j < HM; ++j) {
+            const float t = wave_sum(acc[q][j]);
+            if (lane == 0) red[wave][q * HM + j] = t;
+        }
+    __syncthreads();
+    if (threadIdx.x < 4 * HM) {
+        const int q = threadIdx.x / HM, j = threadIdx.x % HM;
+        if (j < h) {
+            const float t = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+            float* dst = q == 0 ? P.dw1 : (q == 1 ? P.db1 : (q == 2 ? P.dlnw : P.dlnb));
+            atomicAdd(dst + j, t);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void ib_bwd_finish_kernel(const SeaIbBwdParams P, int rs) {
+    const int n = P.E * (1 + P.h);
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        float acc = 0.f;
+#pragma unroll 8
+        for (int b = 0; b < rs; ++b) acc += P.ws[(int64_t)b * n + i];
+        atomicAdd(i < P.E ? P.db2 + i : P.dw2 + (i - P.E), acc);
+    }
+}
+
 // ib = nn.Linear(1, E): dw[e] += sum_m c[m] g[m, e], db[e] += sum_m g[m, e] with g = sum over the fields of dX_f.  grid = (E / 64 column blocks, row chunks);
 // lane = column, the four waves of a workgroup take rows w, w + 4, ... of the chunk, partial sums meet in LDS, one atomic per column per workgroup.
 __global__ __launch_bounds__(256) void ib_linear_bwd_kernel(const SeaIbBwdParams P) {
@@ -1258,6 +1570,24 @@ extern "C" int sea_ib_bwd(const SeaIbBwdParams* params, void* stream) {
                 "sea_ib_bwd: bad sizes");
     SEA_REQUIRE(P.c && P.w1 && P.b1 && P.lnw && P.lnb && P.w2 && P.dw1 && P.db1 && P.dlnw && P.dlnb && P.dw2 && P.db2, "sea_ib_bwd: null pointer");
     for (int f = 0; f < P.n_fields; ++f) SEA_REQUIRE(P.dX[f] && sea_aligned16(P.dX[f]), "sea_ib_bwd: dX[%d] null or misaligned", f);
+    hipStream_t s0 = static_cast<hipStream_t>(stream);
+    static const int cols_form = []() { const char* e = getenv("SEA_IBBWD_COLS"); return e ? atoi(e) : 1; }();   // tuning aid: 0 = the one-wave-per-row kernels
+    if (cols_form && P.h <= 8 && P.ws != nullptr && P.dhid != nullptr && P.ws_floats >= (int64_t)P.E * (1 + P.h)) {
+        const int n_cb = (P.E + 255) / 256;
+        int rs = (1024 + n_cb - 1) / n_cb;                       // about four workgroups per CU in all
+        const int rs_rows = (P.M + 15) / 16;                     // ... of at least 16 rows
+        const int64_t rs_ws = P.ws_floats / ((int64_t)P.E * (1 + P.h));
+        rs = rs > rs_rows ? rs_rows : rs;
+        rs = rs > rs_ws ? (int)rs_ws : rs;
+        const int rows_per = (P.M + rs - 1) / rs;
+        rs = (P.M + rows_per - 1) / rows_per;
+        ib_bwd_cols_kernel<<<dim3(n_cb, rs), dim3(256), 0, s0>>>(P, rows_per, n_cb);
+        ib_bwd_rows_kernel<<<dim3((P.M + 255) / 256), dim3(256), 0, s0>>>(P, n_cb > 1 ? 1 : 0);
+        const int n = P.E * (1 + P.h);
+        ib_bwd_finish_kernel<<<dim3((n + 255) / 256 < 256 ? (n + 255) / 256 : 256), dim3(256), 0, s0>>>(P, rs);
+        SEA_CHECK_LAUNCH("sea_ib_bwd");
+        return SEA_OK;
+    }
     const size_t lds = (size_t)P.E * (P.h + 1) * sizeof(float);
     SEA_REQUIRE(lds <= 160 * 1024, "sea_ib_bwd: E*(h+1) too large for LDS");
     if (lds > 65536) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ib_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

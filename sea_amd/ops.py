@@ -326,9 +326,13 @@ def silu_outer_bwd(groups: Sequence[Dict], c: torch.Tensor, M: int, dtype: torch
                                        N.stream_ptr()), "sea_silu_outer_bwd")
 
 
-def ib_bwd(dxs: Sequence[torch.Tensor], c, w1, b1, lnw, lnb, w2, dw1, db1, dlnw, dlnb, dw2, db2) -> None:
+def ib_bwd(dxs: Sequence[torch.Tensor], c, w1, b1, lnw, lnb, w2, dw1, db1, dlnw, dlnb, dw2, db2, ws: Optional[torch.Tensor] = None,
+           dhid: Optional[torch.Tensor] = None) -> None:
+    """ws (f32, >= E (1 + h) floats per row split) and dhid (f32 [M, 8], zero on entry) select the column-block form (h <= 8)."""
     P = N.SeaIbBwdParams()
     M, E = dxs[0].shape
+    if ws is not None and dhid is not None:
+        P.ws, P.ws_floats, P.dhid = ws.data_ptr(), ws.numel(), dhid.data_ptr()
     for i, x in enumerate(dxs):
         _mat(x, "dx")
         assert x.dtype == torch.float32 and x.stride(0) == dxs[0].stride(0)

@@ -192,6 +192,12 @@ class TrainPlan(Plan):
             ib.dw1, ib.db1, ib.dlnw, ib.dlnb, ib.dw2 = (G(pre + n).data_ptr() for n in names)
             ib.db2 = G(pre + "ib.layers.3.bias").data_ptr()
             ib.h = self.eng.model.ib_hidden
+            if ib.h <= 8:   # the column-block form (bwd.hip): partial sums per row split, d hidden per row (zeroed once: the launch leaves it zero)
+                n_cb = (self.ib_dim + 255) // 256
+                rs = max(1, min((1024 + n_cb - 1) // n_cb, (self.M + 15) // 16))
+                ws = self._buf(rs * self.ib_dim * (1 + ib.h), dtype=torch.float32)
+                dhid = self._buf(self.M, 8, dtype=torch.float32, zero=True)
+                ib.ws, ib.ws_floats, ib.dhid = ws.data_ptr(), ws.numel(), dhid.data_ptr()
         self._c_patches.append((ib, "c"))
         self._cur.append(_Rec(N.lib().sea_ib_bwd, [C.byref(ib)], "bwd.ib", ib))
 

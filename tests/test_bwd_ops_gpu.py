@@ -237,6 +237,31 @@ def test_ib_bwd():
         assert rel(g, r.grad) < 5e-5, name
 
 
+@pytest.mark.parametrize("M,E,h,F,splits", [(203, 256, 8, 3, 13), (798, 1024, 8, 2, 64), (40, 64, 4, 1, 3), (1000, 2048, 8, 2, 7), (17, 320, 8, 2, 1)])
+def test_ib_bwd_column_block_form(M, E, h, F, splits):
+    """The three-launch column-block backward of the info-bottleneck MLP (bwd.hip: ib_bwd_cols / ib_bwd_rows / ib_bwd_finish) against autograd, at
+    the benchmark's width, the shipped cylinder and multiphase widths (several column blocks adding into dhid), a partial last column block, one row
+    split; run twice on the same workspaces (dhid must come back zero)."""
+    from sea_amd import ops
+
+    dxb = rnd(M, F * E, seed=160)
+    dxs = [dxb[:, i * E:(i + 1) * E] for i in range(F)]
+    c = torch.rand(M, device=dev())
+    ps = [rnd(h, seed=161), rnd(h, seed=162), 1 + 0.1 * rnd(h, seed=163), 0.1 * rnd(h, seed=164), rnd(E, h, seed=165), rnd(E, seed=166)]
+    ws = torch.full((splits * E * (1 + h),), float("nan"), device=dev())
+    dhid = torch.zeros(M, 8, device=dev())
+    rs = [p.clone().requires_grad_(True) for p in ps]
+    pre = c[:, None] * rs[0][None, :] + rs[1]
+    ib = gelu(torch.nn.functional.layer_norm(pre, (h,), rs[2], rs[3], 1e-5)) @ rs[4].t() + rs[5]
+    ib.backward(sum(dxs))
+    for _ in range(2):
+        grads = [torch.zeros_like(p) for p in ps]
+        ops.ib_bwd(dxs, c, ps[0], ps[1], ps[2], ps[3], ps[4], *grads, ws=ws, dhid=dhid)
+        for g, r, name in zip(grads, rs, ["w1", "b1", "lnw", "lnb", "w2", "b2"]):
+            assert rel(g, r.grad) < 5e-5, name
+        assert float(dhid.abs().max()) == 0 or E <= 256   # (one column block stores: nothing to re-zero)
+
+
 def _rope_table(hd, n):
     freqs = 1.0 / (10000.0 ** (torch.arange(0, hd, 2).float() / hd))
     ang = torch.outer(torch.arange(n, dtype=torch.float32), freqs)
