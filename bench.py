@@ -409,9 +409,10 @@ def leg_kv(args, dev, rank):
 
     c = CFG
     out = {}
-    for key, F, ln, n_steps, reps in (("cfg2_2024_steps", 3, "adaln", args.seq, 3), ("cfg5_shape_100_steps_F2_ln", 2, "ln", 100, 20)):
+    for key, F, ln, n_steps, reps, Bk in (("cfg2_2024_steps", 3, "adaln", args.seq, 3, 1), ("cfg5_shape_100_steps_F2_ln", 2, "ln", 100, 20, 1),
+                                          ("cfg2_B8_2024_steps", 3, "adaln", args.seq, 2, 8)):   # B = 8: what full_autoregressive_evaluation does over a loader batch
         model = build_model(dev, args.dtype, F=F, ln=ln).eval()
-        x, _, ib = inputs(1, max(n_steps, 1), F, c["E"], rank, dev)
+        x, _, ib = inputs(Bk, max(n_steps, 1), F, c["E"], rank, dev)
         x0 = x[:, :1].contiguous()
         for _ in range(2):
             r = rollout(model, x0, ib, n_steps, mode="kv")
@@ -422,8 +423,8 @@ def leg_kv(args, dev, rank):
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / reps
         assert torch.isfinite(r).all()
-        out[key] = {"steps_per_s": n_steps / dt, "ms_per_step": dt / n_steps * 1e3, "rollout_ms": dt * 1e3,
-                    "workload": f"exact KV-cache rollout of {n_steps} steps, B=1, E={c['E']} H={c['H']} F={F} L=1 {ln}"}
+        out[key] = {"steps_per_s": n_steps / dt, "trajectory_steps_per_s": Bk * n_steps / dt, "ms_per_step": dt / n_steps * 1e3, "rollout_ms": dt * 1e3,
+                    "workload": f"exact KV-cache rollout of {n_steps} steps, B={Bk}, E={c['E']} H={c['H']} F={F} L=1 {ln}"}
         if n_steps <= 100:   # the reference-equivalent recompute rollout of the same length beside it
             for _ in range(2):
                 rollout(model, x0, ib, n_steps, mode="recompute")

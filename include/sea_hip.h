@@ -73,7 +73,8 @@ typedef struct {
     uint32_t seed;
     uint32_t stream;
     int32_t thr;
-    int32_t mode; /* GEMM epilogue: 1 = on (acc + bias) before the residual, 2 = on the act-dtype output only (backward) */
+    int32_t mode; /* GEMM epilogue: 1 = on (acc + bias) before the residual, 2 = on the act-dtype output only (backward), 3 = on the complete value (acc + bias + R),
+                   * both outputs — the position-encoded rows of exchange_mode 'pool' (dropout(x + pe), models/base_blocks.py:370-372) and their gradient */
 } SeaDropout;
 /* Writes keep * scale (0 or 256/(256-thr)) for a [rows, cols] element grid of one stream: test / debugging aid. */
 int sea_dropout_mask(float* out, int64_t rows, int64_t cols, uint32_t seed, uint32_t stream, int32_t thr, void* stream_handle);

@@ -168,6 +168,10 @@ __global__ __launch_bounds__(256) void gemm_grouped_kernel(const GemmLaunch L) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) v[q] += rv[q];
             }
+            if (!PLAIN && G.drop.thr > 0 && G.drop.mode == 3) {  // on the COMPLETE value, residual included (PositionalEncoding: dropout(x + pe), models/base_blocks.py:370-372)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] *= df[q];
+            }
             if (C32 != nullptr) store4(C32 + (int64_t)m * G.ldc32 + n, v[0], v[1], v[2], v[3]);
             if (!PLAIN && G.drop.thr > 0 && G.drop.mode == 2) {  // backward: only the copy that feeds the dropped branch is masked
 #pragma unroll
@@ -574,7 +578,7 @@ extern "C" int sea_gemm_grouped(const SeaGemmGroup* groups, int n_groups, int dt
         SEA_REQUIRE(sea_aligned16(G.A) && sea_aligned16(G.W), "sea_gemm_grouped[%d]: A/W not 16-byte aligned", i);
         SEA_REQUIRE((G.silu_c || G.lda >= G.K) && G.ldw >= G.K, "sea_gemm_grouped[%d]: leading dimension smaller than K", i);
         SEA_REQUIRE(G.C32 || G.Cact, "sea_gemm_grouped[%d]: no output", i);
-        SEA_REQUIRE(G.drop.thr >= 0 && G.drop.thr <= 255 && (G.drop.thr == 0 || G.drop.mode == 1 || G.drop.mode == 2), "sea_gemm_grouped[%d]: bad dropout", i);
+        SEA_REQUIRE(G.drop.thr >= 0 && G.drop.thr <= 255 && (G.drop.thr == 0 || (G.drop.mode >= 1 && G.drop.mode <= 3)), "sea_gemm_grouped[%d]: bad dropout", i);
         SEA_REQUIRE(G.N % 4 == 0, "sea_gemm_grouped[%d]: N=%d must be a multiple of 4", i, G.N);
         SEA_REQUIRE(G.act >= 0 && G.act <= 2 && (G.act != 2 || G.Z) && (!G.Z || (G.ldz >= G.N && G.ldz % 4 == 0)), "sea_gemm_grouped[%d]: bad act/Z", i);
         SEA_REQUIRE(sea_aligned16(G.bias) && sea_aligned16(G.R) && sea_aligned16(G.C32) && sea_aligned16(G.Cact) && sea_aligned16(G.Z),

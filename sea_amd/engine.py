@@ -833,6 +833,22 @@ class Plan:
         self._cur.append(self._rec(L.sea_convert_f32_to_act, [ib32.data_ptr(), E, ibact.data_ptr(), E, M, E, self.code], "ib.rows.act"))
         return ib32, ibact
 
+    def _ib_rows_multi(self, pre: str, n: int, drop) -> List[torch.Tensor]:
+        """n sets of info-bottleneck rows ib(cond) [M, E] in the activation dtype, each with its OWN dropout mask (streams drop[1] .. drop[1] + n - 1 of one
+        sea_ib_add over n zeroed buffers): what the reference's n evaluations of self.ib in train() produce (models/temporal.py:110-118)."""
+        L, M, E, f32 = N.lib(), self.M, self.E, torch.float32
+        zeros = self._buf(M, E, dtype=f32, zero=True)
+        rows32 = [self._buf(M, E, dtype=f32) for _ in range(n)]
+        for t in rows32:
+            self._cur.append(self._rec(L.sea_convert_f32_to_act, [zeros.data_ptr(), E, t.data_ptr(), E, M, E, N.SEA_F32], "ib.rows.zero", zeros))
+        self._ib(pre, rows32, drop=drop)
+        if self.dt == f32:
+            return rows32
+        out = [self._buf(M, E) for _ in range(n)]
+        for a, b in zip(rows32, out):
+            self._cur.append(self._rec(L.sea_convert_f32_to_act, [a.data_ptr(), E, b.data_ptr(), E, M, E, self.code], "ib.rows.act"))
+        return out
+
     def _act_copy(self, x32: torch.Tensor, name: str, keep: bool = False) -> torch.Tensor:
         """Activation-dtype copy of an fp32 [M, E] (possibly strided) matrix — the operand of a GEMM that reads the residual stream directly.  `keep`: a
         real copy in fp32 too (training: the rows are updated in place afterwards and the weight gradient needs them as they were)."""
@@ -1237,12 +1253,6 @@ class TemporalEngine:
 
         m = self.model
         thr = int(round(256 * m.dropout_p)) if (m.training and m.dropout_p > 0) else 0
-        if thr > 0 and m.ib_addition_mode.lower() == "attention":
-            raise NotImplementedError("sea_amd: ib_addition_mode='attention' trains with dropout = 0 only (the reference evaluates the info-bottleneck layer, and its "
-                                      "dropout, once per field: one set of rows is shared here)")
-        if thr > 0 and m.exchange_mode == "pool":
-            raise NotImplementedError("sea_amd: exchange_mode='pool' trains with dropout = 0 only (the reference also drops the position-encoded rows, "
-                                      "models/base_blocks.py:371-372: no counter-based mask is defined for that site)")
         if thr > 255:
             raise ValueError("dropout probability too close to 1")
         dp = self.dp_overlap()

@@ -130,7 +130,18 @@ class TrainPlan(Plan):
         k_i / v_i(ib rows))), un-masked and un-rotated (models/temporal.py:117-118, models/base_blocks.py:205-243)."""
         eng, P, B, H, T, E, M, cap = self.eng, self.eng.params, self.B, self.H, self.T, self.E, self.M, self.cap
         F, hd, buf, f32 = len(xs), self.E // self.H, self._buf, torch.float32
-        _, sv["ia_ib"] = self._ib_rows(pre)
+        thr = self.drop_thr
+        if thr:
+            # the reference evaluates self.ib(x_additional_info) inside _add_info, once per field (models/temporal.py:110-118): in train() every field's
+            # key / value rows come from their own dropout mask of the info-bottleneck MLP's output — F row sets, streams s0 .. s0 + F - 1 of ONE sea_ib_add
+            s0 = self._streams(F)
+            sv["ia_ib_drop"] = (thr, s0)
+            sv["ia_ib_rows"] = self._ib_rows_multi(pre, F, (thr, s0))
+            sv["ia_attn_drop"] = (thr, self._streams(F))
+        else:
+            sv["ia_ib_drop"] = sv["ia_attn_drop"] = None
+            sv["ia_ib_rows"] = [self._ib_rows(pre)[1]] * F
+        sv["ia_ib"] = sv["ia_ib_rows"][0]
         sv["ia_xq"] = [self._act_copy(xs[i], "ib.attn.x_act", keep=True) for i in range(F)]
         sv["ia"] = [dict(Q=buf(B, H, T, hd), K=buf(B, H, cap, hd, zero=True), V=buf(B, H, cap, hd, zero=True), Vt=buf(B, H, hd, cap, zero=True), O=buf(M, E),
                          LSE=buf(B, H, T, dtype=f32)) for _ in range(F)]
@@ -138,9 +149,9 @@ class TrainPlan(Plan):
         for i in range(F):
             ca, pr = f"{pre}cross_attn_ib.{i}.", sv["ia"][i]
             qg.append(dict(A=sv["ia_xq"][i], W=P.act(ca + "q.weight"), bias=P.f32_vec(ca + "q.bias"), col0=0, Q=pr["Q"]))
-            qg.append(dict(A=sv["ia_ib"], W=P.act(ca + "k.weight", 2 * E), bias=P.f32_vec(ca + "k.bias", 2 * E), col0=E, K=pr["K"], Vt=pr["Vt"], V=pr["V"]))
+            qg.append(dict(A=sv["ia_ib_rows"][i], W=P.act(ca + "k.weight", 2 * E), bias=P.f32_vec(ca + "k.bias", 2 * E), col0=E, K=pr["K"], Vt=pr["Vt"], V=pr["V"]))
         self._qkv(qg, eng.rope_identity(hd), hd, "ib.attn.qkv")
-        self._attn([dict(Q=pr["Q"], K=pr["K"], Vt=pr["Vt"], O=pr["O"], LSE=pr["LSE"]) for pr in sv["ia"]], hd, E, "ib.attn.attention", src_len=cap)
+        self._attn([dict(Q=pr["Q"], K=pr["K"], Vt=pr["Vt"], O=pr["O"], LSE=pr["LSE"]) for pr in sv["ia"]], hd, E, "ib.attn.attention", drop=sv["ia_attn_drop"], src_len=cap)
         self._gemm([dict(A=sv["ia"][i]["O"], W=P.act(f"{pre}cross_attn_ib.{i}.projection.weight"), R=xs[i], C32=xs[i]) for i in range(F)], "ib.attn.proj")
 
     def _ib_attn_bwd(self, pre: str, sv: dict, dx: List[torch.Tensor], ga: List[torch.Tensor]) -> None:
@@ -156,14 +167,19 @@ class TrainPlan(Plan):
         dq, dkv = [buf(M, E) for _ in range(F)], [buf(M, 2 * E) for _ in range(F)]
         delta = [buf(B, H, T, dtype=f32) for _ in range(F)]
         self._attn_bwd([dict(Q=pr["Q"], K=pr["K"], V=pr["V"], O=pr["O"], dO=datt[i], LSE=pr["LSE"], delta=delta[i], dQ=dq[i], dK=dkv[i][:, :E], dV=dkv[i][:, E:])
-                        for i, pr in enumerate(sv["ia"])], hd, eng.rope_identity(hd), "bwd.ib.attn.attention", src_len=self.cap)
+                        for i, pr in enumerate(sv["ia"])], hd, eng.rope_identity(hd), "bwd.ib.attn.attention", drop=sv["ia_attn_drop"], src_len=self.cap)
         wg = []
         for i in range(F):
             ca = f"{pre}cross_attn_ib.{i}."
             wg.append(dict(dY=dq[i], X=sv["ia_xq"][i], dW=G2(ca + "q.weight"), db=Gv(ca + "q.bias")))
-            wg.append(dict(dY=dkv[i], X=sv["ia_ib"], dW=G2(ca + "k.weight", 2 * E), db=Gv(ca + "k.bias", 2 * E)))
+            wg.append(dict(dY=dkv[i], X=sv["ia_ib_rows"][i], dW=G2(ca + "k.weight", 2 * E), db=Gv(ca + "k.bias", 2 * E)))
         self._wgrad(wg, "bwd.ib.attn.qkv.wgrad")
         self._gemm([dict(A=dq[i], W=P.actT(f"{pre}cross_attn_ib.{i}.q.weight"), R=dx[i], C32=dx[i], Cact=ga[i]) for i in range(F)], "bwd.ib.attn.q.dgrad")
+        if sv["ia_ib_drop"] is not None:   # every field's keys / values came from its own (dropped) rows: F gradients, masked per field by the ib backward
+            dibs = [buf(M, E, dtype=f32) for _ in range(F)]
+            self._gemm([dict(A=dkv[i], W=P.actT(f"{pre}cross_attn_ib.{i}.k.weight", 2 * E), C32=dibs[i]) for i in range(F)], "bwd.ib.attn.kv.dgrad")
+            self._ib_bwd(pre, dibs, drop=sv["ia_ib_drop"])
+            return
         dib = buf(M, E, dtype=f32)
         for i in range(F):   # sequential: every field's keys / values came from the same info-bottleneck rows
             g = dict(A=dkv[i], W=P.actT(f"{pre}cross_attn_ib.{i}.k.weight", 2 * E), C32=dib)
@@ -370,7 +386,10 @@ class TrainPlan(Plan):
                                 for j in range(F)], "pool.down")
                     self._norm([dict(X=sv["dn"][j], Yact=nrm[j], mean=sv["stc"][j][0], rstd=sv["stc"][j][1], **npar(f"{pre}ln_cross.{j}.")) for j in range(F)],
                                D, "pool.norm")
-                self._gemm([dict(A=nrm[j], W=eng.eye(D), R=pe_t, Cact=big[:, j * D:(j + 1) * D]) for j in range(F)], "pool.pe_add")
+                # (PositionalEncoding ends in nn.Dropout, models/base_blocks.py:370-372: the position-encoded rows themselves are dropped — mode 3 of the epilogue)
+                sv["pe_drop"] = self._streams(F) if thr else None
+                self._gemm([dict(A=nrm[j], W=eng.eye(D), R=pe_t, Cact=big[:, j * D:(j + 1) * D], drop=((thr, sv["pe_drop"] + j, 3) if thr else None))
+                            for j in range(F)], "pool.pe_add")
                 sv["hp_pre"], sv["hp"], sv["pool"] = buf(M, 2 * D), buf(M, 2 * D), buf(M, D)
                 self._gemm([dict(A=big[:, :FD], W=P.act(f"{pre}pool_update.0.weight"), bias=P.f32_vec(f"{pre}pool_update.0.bias"), Cact=sv["hp"], Z=sv["hp_pre"],
                                  act=1)], "pool.update0")
@@ -591,7 +610,9 @@ class TrainPlan(Plan):
                 self._gemm([dict(A=dpool, W=P.actT(f"{pre}pool_update.2.weight"), Z=sv["hp_pre"], act=2, Cact=dhp)], "bwd.pool.update2.dgrad")
                 self._wgrad([dict(dY=dhp, X=big[:, :FD], dW=G2(f"{pre}pool_update.0.weight"), db=Gv(f"{pre}pool_update.0.bias"))], "bwd.pool.update0.wgrad")
                 w0t = P.actT(f"{pre}pool_update.0.weight")          # [F D, 2 D]: rows j D .. (j+1) D map d hp onto d n_j
-                self._gemm([dict(A=dhp, W=w0t[j * D:(j + 1) * D], R=dnd[j], C32=dnd[j]) for j in range(F)], "bwd.pool.update0.dgrad")
+                # the last of the three contributions to d (dropped rows): with dropout the gradient of the rows BEFORE the mask is mask * (the sum)
+                self._gemm([dict(A=dhp, W=w0t[j * D:(j + 1) * D], R=dnd[j], C32=dnd[j], drop=((thr, sv["pe_drop"] + j, 3) if thr else None))
+                            for j in range(F)], "bwd.pool.update0.dgrad")
                 ddn = [buf(M, D) for _ in range(F)]
                 self._norm_bwd([dict(dY=dnd[j], X=sv["dn"][j], mean=sv["stc"][j][0], rstd=sv["stc"][j][1], dXact=ddn[j], **bpar(f"{pre}ln_cross.{j}.", D))
                                 for j in range(F)], D, "bwd.pool.norm", False, False, False, False)

@@ -46,7 +46,7 @@ def test_gemm_epilogue_dropout(dtype):
     seed, stream, thr = 99, 5, 51
     mk = mask(M, N_, seed, stream, thr)
     pre = A.float() @ W.float().t() + bias
-    for mode in (1, 2):
+    for mode in (1, 2, 3):
         arr = (N.SeaGemmGroup * 1)()
         C32, Cact = torch.empty(M, N_, device=dev()), torch.empty(M, N_, device=dev(), dtype=dtype)
         ops.fill_gemm_group(arr[0], A, W, bias, R, C32, Cact)
@@ -55,6 +55,9 @@ def test_gemm_epilogue_dropout(dtype):
         if mode == 1:
             assert rel(C32, pre * mk + R) < 2e-5
             assert rel(Cact.float(), pre * mk + R) < (2e-5 if dtype == torch.float32 else 6e-3)
+        elif mode == 3:   # the complete value, residual included (PositionalEncoding's dropout(x + pe)), in both outputs
+            assert rel(C32, (pre + R) * mk) < 2e-5
+            assert rel(Cact.float(), (pre + R) * mk) < (2e-5 if dtype == torch.float32 else 6e-3)
         else:
             assert rel(C32, pre + R) < 2e-5
             assert rel(Cact.float(), (pre + R) * mk) < (2e-5 if dtype == torch.float32 else 6e-3)
@@ -161,15 +164,21 @@ def test_ib_dropout_forward_backward():
         assert rel(g, r.grad) < 5e-5, name
 
 
-def test_model_training_with_dropout_is_consistent():
+@pytest.mark.parametrize("variant", [("sea", "add", True, "adaln", 3), ("pool", "add", True, "ln", 2), ("pool", "add", True, "adaln", 3),
+                                     ("sea", "attention", True, "adaln", 2), ("sea", "attention", False, "ln", 3)])
+def test_model_training_with_dropout_is_consistent(variant):
     """Whole model, dropout 0.1 (the shipped cylinder setting), fp32: with the step's seed held fixed the loss is a deterministic smooth
     function of the parameters, so the hand-written backward must match a central finite difference along a random direction — this
-    checks that every forward mask is regenerated identically in the backward.  Also: eval() ignores dropout; train() re-keys per step."""
+    checks that every forward mask is regenerated identically in the backward.  Also: eval() ignores dropout; train() re-keys per step.
+    Variants: the shipped structure; exchange_mode 'pool', whose position-encoded rows are dropped too (PositionalEncoding, models/base_blocks.py:370-372:
+    mode 3 of the GEMM epilogue, the same mask on the rows' gradient); ib_addition_mode 'attention', where the reference evaluates the info-bottleneck
+    MLP — and its dropout — once per field (models/temporal.py:110-118: F row sets with their own masks) and drops the attention probabilities."""
     from sea_amd.models.temporal import TemporalModel
     from oracle.recipe import recipe_params
 
-    cfg = O.OracleConfig(1, 64, 4, 48, 8, 0, 3, 2, True, "adaln")
-    m = TemporalModel(1, 64, 4, 48, 8, 0, 3, 2, 0.1, "sea", "learnable", "mlp", "add", 1, 1, True, "adaln")
+    xm, ibm, after, ln, F = variant
+    cfg = O.OracleConfig(1, 64, 4, 48, 8, 0, F, 2, after, ln, xm, ibm)
+    m = TemporalModel(1, 64, 4, 48, 8, 0, F, 2, 0.1, xm, "learnable", "mlp", ibm, 1, 1, after, ln)
     p = recipe_params(cfg)
     with torch.no_grad():
         for k, prm in m.named_parameters():
@@ -246,17 +255,22 @@ def test_standalone_module_forwards_with_dropout():
             assert torch.equal(mod(*args), ref)
 
 
-def test_pool_exchange_training_with_dropout_is_refused():
-    """exchange_mode='pool' also drops its position-encoded rows in the reference (PositionalEncoding, models/base_blocks.py:370-372): no mask is
-    defined for that site here, so a training forward with dropout > 0 fails loudly; eval() (rollouts) and dropout 0 run."""
+def test_pool_position_rows_are_dropped_like_the_reference():
+    """exchange_mode='pool' in train(): the rows the pool MLP, the queries and the GELU sum read are dropout(ln_cross(cross_down(x)) + pe) (PositionalEncoding,
+    models/base_blocks.py:370-372) — a fraction thr / 256 of their elements is exactly zero, the others are the eval rows scaled by 256 / (256 - thr)."""
     from sea_amd.models.temporal import TemporalModel
 
-    m = TemporalModel(1, 64, 4, 48, 8, 0, 2, 2, 0.1, "pool", "learnable", "mlp", "add", 1, 1, True, "ln").to("cuda:0")
+    m = TemporalModel(1, 64, 4, 48, 8, 0, 2, 2, 0.25, "pool", "learnable", "mlp", "add", 1, 1, True, "ln").to("cuda:0")
     cfg = O.OracleConfig(1, 64, 4, 48, 8, 0, 2, 2, True, "ln", "pool")
     x, _, ib = (t.cuda() for t in recipe_inputs(2, 20, cfg, seed=4))
+    eng = m.engine()
+    m.train()
+    out, plan = eng.forward_train(x, ib)
+    assert torch.isfinite(out).all()
+    torch.cuda.synchronize()
+    big = plan.saved[0]["big"][:, : 2 * 32].float()      # [n_0 | n_1], D = 32
+    zero = big == 0
+    assert abs(float(zero.float().mean()) - 64 / 256) < 0.03
     m.eval()
     with torch.no_grad():
         assert torch.isfinite(m(x, ib)).all()
-    m.train()
-    with pytest.raises(NotImplementedError, match="dropout"):
-        m(x, ib)

@@ -391,6 +391,32 @@ def test_rollout_kv_cache_matches_reference_golden(name):
     assert torch.equal(pred, again)
 
 
+@pytest.mark.parametrize("name", ["rollout100_ln_f2_e256", "rollout8_adaln_f3"])
+def test_batched_kv_rollout_matches_golden_row_and_oracle(name):
+    """The KV-cache rollout over a BATCH of trajectories (what full_autoregressive_evaluation does with a loader batch, utils/train_utils.py:186-209;
+    sea_kv_rollout's seven-launch form): the golden trajectory placed in a batch of three next to perturbed copies comes out as the reference computed
+    it alone, and every row agrees with the oracle's batched recompute rollout."""
+    from oracle.recipe import recipe_params
+    from sea_amd.utils.train_utils import rollout
+
+    g = load_golden(name)
+    cfg = cfg_from_meta(g["cfg"])
+    m = build(cfg, "fp32")
+    n = g["tgt"].shape[1]
+    gen = torch.Generator().manual_seed(5)
+    gx, gib = torch.from_numpy(g["x0"]), torch.from_numpy(g["ib"])
+    nb = gx.shape[0]                                                # the golden trajectories sit between a perturbed first and last row
+    x0 = torch.cat((gx[:1] + 0.3 * torch.randn(gx[:1].shape, generator=gen), gx, gx[-1:] - 0.2 * torch.randn(gx[:1].shape, generator=gen)))
+    ib = torch.cat((torch.rand(gib[:1].shape, generator=gen), gib, gib[-1:]))
+    pred = rollout(m, x0.cuda(), ib.cuda(), n, mode="kv").cpu()
+    assert rel_l2(pred[1:1 + nb].numpy(), g["pred"]) < 2e-4      # the golden rows, batched
+    ref = O.rollout(x0, ib, n, recipe_params(cfg), cfg)
+    assert rel_l2(pred.numpy(), ref.numpy()) < 2e-4
+    mb = build(cfg, "bf16")
+    pb = rollout(mb, x0.cuda(), ib.cuda(), n, mode="kv").cpu()
+    assert rel_l2(pb.numpy(), ref.numpy()) < 1e-1
+
+
 def test_rollout_kv_bf16_error_is_reported_and_bounded():
     """bf16 tolerance over a 100-step autoregressive rollout (north_star: 'stated bf16 tolerance'): rel-L2 <= 1e-1 at 100 steps
     on the E=256 multiphase-like model; the measured value is printed."""
