@@ -55,7 +55,7 @@ def test_validation_without_gpu(lib):
     assert lib.sea_gemm_grouped(g, 17, 0, None) == -1
     P = N.SeaAttnParams()
     assert lib.sea_attention_fwd(C.byref(P), 1, None) == -1
-    assert lib.sea_abi_version() == 4
+    assert lib.sea_abi_version() == N.ABI_VERSION == 5
     G, Ly = N.SeaKvGlobal(), (N.SeaKvLayer * 1)()
     assert lib.sea_kv_rollout(C.byref(G), Ly, 0, 1, 1, 1, None) == -1   # sizes are checked before anything is launched
     assert b"sea_kv_rollout" in lib.sea_last_error()
