@@ -698,7 +698,7 @@ __global__ __launch_bounds__(512) void attention_row_wide_kernel(const SeaAttnPa
 
 template <typename T>
 static bool launch_attention_row(const SeaAttnParams& P, hipStream_t s) {
-    static const int on = []() { const char* e = getenv("SEA_ATTN_ROW"); return e ? atoi(e) : 1; }();  // tuning aid: 0 keeps the tiled kernel
+    static const int on = sea_tune("attn_row", 1);  // tuning aid: 0 keeps the tiled kernel
     if (!on || P.Tq != 1 || P.drop.thr != 0 || P.Tk > 8192 || (P.hd != 8 && P.hd != 16 && P.hd != 32 && P.hd != 64 && P.hd != 128 && P.hd != 256)) return false;
     for (int i = 0; i < P.n_problems; ++i)
         if (P.p[i].LSE != nullptr) return false;
@@ -738,7 +738,7 @@ static int launch_attention(const SeaAttnParams& P, hipStream_t s) {
     const bool split = blocks <= 1024 && P.Tk >= 256;
     // at most two workgroups per CU: four wave groups per query tile (measured at cfg2: cross-attention 18.3 -> 17.3 us; with 768
     // workgroups the 1024-thread workgroups no longer co-reside and it is slower, 21.7 -> 24.7 us)
-    static const int split4 = []() { const char* e = getenv("SEA_ATTN_SPLIT4"); return e ? atoi(e) : -1; }();  // tuning aid: 0 off, 1 on
+    static const int split4 = sea_tune("attn_split4", -1);  // tuning aid: 0 off, 1 on
     if (split && (split4 == 1 || (split4 < 0 && blocks <= 512)) && P.hd <= 32 && P.drop.thr == 0) {
         const dim3 grid((P.Tq + 63) / 64, P.B * P.H, P.n_problems), block(1024);
         if (P.hd == 32) attention_fwd_kernel<T, 32, 4, false><<<grid, block, 0, s>>>(P);

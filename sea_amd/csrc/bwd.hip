@@ -271,7 +271,7 @@ extern "C" int sea_wgrad_grouped(const SeaWgradGroup* groups, int n_groups, int 
         SEA_REQUIRE(sea_aligned16(G.dY) && sea_aligned16(G.X), "sea_wgrad_grouped[%d]: dY/X must be 16-byte aligned", i);
         big = big && G.N % 128 == 0 && G.K % 128 == 0 && G.M >= 2048;
     }
-    static const int forced = []() { const char* e = getenv("SEA_WGRAD_TILE"); return e ? atoi(e) : 0; }();  // tuning aid
+    static const int forced = sea_tune("wgrad_tile", 0);  // tuning aid
     long tiles128 = 0;
     for (int i = 0; i < n_groups; ++i) tiles128 += (long)((groups[i].N + 127) / 128) * ((groups[i].K + 127) / 128);
     // few 128-tiles would mean many contraction splits, i.e. many atomic passes over the same outputs: measured at cfg3 the small
@@ -285,7 +285,7 @@ extern "C" int sea_wgrad_grouped(const SeaWgradGroup* groups, int n_groups, int 
     // in WHOLE rounds, never below 256 rows per split: the launch lasts rounds x stages-per-split, so 576 workgroups on 512
     // slots (what "about 512" gave the MLP matrices at cfg3: 96 tiles x 6 splits) take two rounds of 42 stages where 480 take one of 51.  The
     // split count minimises rounds x (stages + 2) — the 2 prices a workgroup's fill and its atomic pass over the tile.
-    static const int wg_target = []() { const char* e = getenv("SEA_WGRAD_TARGET"); return e ? atoi(e) : 0; }();  // tuning aid: "about this many workgroups"
+    static const int wg_target = sea_tune("wgrad_target", 0);  // tuning aid: "about this many workgroups"
     // the 64 tile sits four to a CU (40 KiB of LDS); launches of a few small matrices keep to 512 — their extra splits cost more in atomic passes over
     // the same few tiles than they fill (measured) —, a launch of many (the exchange's gradients in one launch: 184 tiles) fills all 1024
     const long slots = tn == 64 && base_tiles >= 64 ? 1024 : 512;
@@ -320,7 +320,7 @@ extern "C" int sea_wgrad_grouped(const SeaWgradGroup* groups, int n_groups, int 
     }
     L.tile_start[n_groups] = total;
     L.n_groups = n_groups;
-    static const bool xcd_order = [] { const char* e = getenv("SEA_WGRAD_XCD"); return !(e && e[0] == '0'); }();  // tuning aid
+    static const bool xcd_order = sea_tune("wgrad_xcd", 1) != 0;  // tuning aid
     L.xcd = xcd_order ? 1 : 0;
     hipStream_t s = static_cast<hipStream_t>(stream);
 #define LAUNCH_WG(TT, TN_, TK_, WT_)                                                                                             \
@@ -801,7 +801,7 @@ extern "C" int sea_rownorm_bwd(const SeaNormBwdGroup* groups, int n_groups, int 
     L.M = M; L.d = d; L.gelu = gelu; L.accumulate = accumulate;
     const bool wide = d > 1024;  // one workgroup per row: 256 threads up to 2048 columns, 512 up to 4096, 1024 beyond (2 / 2 / 2-4 chunks of 4 columns per thread)
     int nblk = wide ? M : (M + 3) / 4;
-    static const int nblk_cap = []() { const char* e = getenv("SEA_NORMBWD_BLOCKS"); return e ? atoi(e) : 512; }();  // tuning aid
+    static const int nblk_cap = sea_tune("normbwd_blocks", 512);  // tuning aid
     if (nblk > nblk_cap) nblk = nblk_cap;
     if (wide) {
         // all workgroups of the launch resident at once (5 per CU at the wide kernel's 90 VGPRs): a second, partial round costs more than
@@ -1046,7 +1046,7 @@ extern "C" int sea_silu_outer_bwd(const SeaSiluBwdGroup* groups, int n_groups, c
         maxk = G.K2 > maxk ? G.K2 : maxk;
     }
     hipStream_t s = static_cast<hipStream_t>(stream);
-    static const int cols_form = []() { const char* e = getenv("SEA_SILUBWD_COLS"); return e ? atoi(e) : 1; }();   // tuning aid: 0 = the one-wave-per-row kernel
+    static const int cols_form = sea_tune("silubwd_cols", 1);   // tuning aid: 0 = the one-wave-per-row kernel
     if (cols_form && ws != nullptr) {
         SiluColsLaunch Q;
         memset(&Q, 0, sizeof(Q));
@@ -1086,7 +1086,7 @@ extern "C" int sea_silu_outer_bwd(const SeaSiluBwdGroup* groups, int n_groups, c
     L.c = c; L.M = M;
     int nblk = (M + 3) / 4;
     // every workgroup of the launch resident at once (about 6 per CU): measured at cfg3 (12 groups) 128 per group 76 us, 160 90 us, 256 112 us
-    static const int sb_cap = []() { const char* e = getenv("SEA_SILUBWD_BLOCKS"); return e ? atoi(e) : 0; }();  // tuning aid
+    static const int sb_cap = sea_tune("silubwd_blocks", 0);  // tuning aid
     int cap = sb_cap > 0 ? sb_cap : (6 * 256 / n_groups) / 32 * 32;
     cap = cap < 32 ? 32 : (cap > 256 ? 256 : cap);
     if (nblk > cap) nblk = cap;
@@ -1571,7 +1571,7 @@ extern "C" int sea_ib_bwd(const SeaIbBwdParams* params, void* stream) {
     SEA_REQUIRE(P.c && P.w1 && P.b1 && P.lnw && P.lnb && P.w2 && P.dw1 && P.db1 && P.dlnw && P.dlnb && P.dw2 && P.db2, "sea_ib_bwd: null pointer");
     for (int f = 0; f < P.n_fields; ++f) SEA_REQUIRE(P.dX[f] && sea_aligned16(P.dX[f]), "sea_ib_bwd: dX[%d] null or misaligned", f);
     hipStream_t s0 = static_cast<hipStream_t>(stream);
-    static const int cols_form = []() { const char* e = getenv("SEA_IBBWD_COLS"); return e ? atoi(e) : 1; }();   // tuning aid: 0 = the one-wave-per-row kernels
+    static const int cols_form = sea_tune("ibbwd_cols", 1);   // tuning aid: 0 = the one-wave-per-row kernels
     if (cols_form && P.h <= 8 && P.ws != nullptr && P.dhid != nullptr && P.ws_floats >= (int64_t)P.E * (1 + P.h)) {
         const int n_cb = (P.E + 255) / 256;
         int rs = (1024 + n_cb - 1) / n_cb;                       // about four workgroups per CU in all
@@ -1592,7 +1592,7 @@ extern "C" int sea_ib_bwd(const SeaIbBwdParams* params, void* stream) {
     SEA_REQUIRE(lds <= 160 * 1024, "sea_ib_bwd: E*(h+1) too large for LDS");
     if (lds > 65536) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ib_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     int nblk = (P.M + 3) / 4;
-    static const int ib_cap = []() { const char* e = getenv("SEA_IBBWD_BLOCKS"); return e ? atoi(e) : 256; }();  // tuning aid
+    static const int ib_cap = sea_tune("ibbwd_blocks", 256);  // tuning aid
     if (nblk > ib_cap) nblk = ib_cap;
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (P.h <= 8 && P.E <= 256) ib_bwd_fast_kernel<1><<<dim3(nblk), dim3(256), lds, s>>>(P);

@@ -1,5 +1,6 @@
 // ABI plumbing of libsea_hip.so: version, thread-local error string, device info, MFMA fragment-map self-test.
 #include "sea_common.hpp"
+#include <stdlib.h>
 
 static thread_local char g_err[512] = "";
 
@@ -8,6 +9,18 @@ void sea_set_error(const char* fmt, ...) {
     va_start(ap, fmt);
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
+}
+
+int sea_tune(const char* key, int dflt) {
+    const char* e = getenv("SEA_TUNE");
+    if (e == nullptr) return dflt;
+    const size_t n = strlen(key);
+    for (const char* p = e; *p;) {
+        while (*p == ',' || *p == ' ') ++p;
+        if (strncmp(p, key, n) == 0 && p[n] == '=') return atoi(p + n + 1);
+        while (*p && *p != ',') ++p;
+    }
+    return dflt;
 }
 
 extern "C" int sea_abi_version(void) { return SEA_ABI_VERSION; }

@@ -554,7 +554,7 @@ static int pick_tile(long tiles128, bool dma) {
     // tile halves.  Measured crossovers on the cfg2/cfg3 shapes at B = 1, 2, 4, 8 (single-buffered register-staged main loop):
     // condition GEMM 672 tiles 31.8 us (64) vs 28.0 (128); fc1 768: 22.0 vs 21.2, 6144: 135 vs 118; qkv 288: 16.7 vs 19.5, 2304: 61 vs 59;
     // LDS-DMA main loop (fc2) 384: 70 vs 79, 768: 158 vs 127.
-    static const int forced = []() { const char* e = getenv("SEA_GEMM_TILE"); return e ? atoi(e) : 0; }();  // tuning aid
+    static const int forced = sea_tune("gemm_tile", 0);  // tuning aid
     if (forced == 64 || forced == 128) return forced;
     return tiles128 >= (dma ? 512 : 600) ? 128 : 64;
 }
@@ -589,7 +589,7 @@ extern "C" int sea_gemm_grouped(const SeaGemmGroup* groups, int n_groups, int dt
         t64 += (long)((G.M + 63) / 64) * ((G.N + 63) / 64);
     }
     // a few rows (a KV-cache rollout step): one workgroup per 16 output columns, the contraction split over its four waves
-    static const int skinny_env = []() { const char* e = getenv("SEA_GEMM_SKINNY"); return e ? atoi(e) : 1; }();  // tuning aid: 0 keeps the tiled kernels
+    static const int skinny_env = sea_tune("gemm_skinny", 1);  // tuning aid: 0 keeps the tiled kernels
     bool skinny = skinny_env != 0 && dtype == SEA_BF16 && n_silu == 0;
     for (int i = 0; i < n_groups && skinny; ++i) {
         const SeaGemmGroup& G = groups[i];
@@ -616,7 +616,7 @@ extern "C" int sea_gemm_grouped(const SeaGemmGroup* groups, int n_groups, int dt
     }
     // LDS-DMA ring: needs whole K-tiles (128 bytes of K per row per stage) and pays off only on long contractions (its 4 stages
     // cost a workgroup per CU at 128x128; measured: K = 2048 +5 %, K = 256 -20 % against the register-staged double buffer)
-    static const int dma_min_k = []() { const char* e = getenv("SEA_GEMM_DMA_MIN_K"); return e ? atoi(e) : 1024; }();  // tuning aid
+    static const int dma_min_k = sea_tune("gemm_dma_min_k", 1024);  // tuning aid
     SEA_REQUIRE(n_silu == 0 || n_silu == n_groups, "sea_gemm_grouped: generated-A groups cannot share a launch with ordinary ones");
     const bool silu = n_silu > 0;
     bool dma = !silu;
@@ -624,7 +624,7 @@ extern "C" int sea_gemm_grouped(const SeaGemmGroup* groups, int n_groups, int dt
         dma = dma && (groups[i].K % (dtype == SEA_BF16 ? 64 : 32) == 0) && (long)groups[i].K * groups[i].n_seg >= dma_min_k;
     // ... and only while the launch is a few tiles deep per CU (its time then is the serial chain of K-tiles of one tile, which the ring
     // shortens: fc2 at B = 1 23 us vs 28); with many tiles per CU the single-buffered loop's occupancy wins (B = 8: 109 us vs 128)
-    static const int dma_force = []() { const char* e = getenv("SEA_GEMM_DMA_FORCE"); return e ? atoi(e) : 0; }();  // tuning aid
+    static const int dma_force = sea_tune("gemm_dma_force", 0);  // tuning aid
     dma = dma && (t64 <= 1536 || dma_force);
     (void)t64;
     const int tile = pick_tile(t128, dma);
@@ -709,7 +709,7 @@ extern "C" int sea_qkv_rope_grouped(const SeaQkvGroup* groups, int n_groups, con
         t64 += (long)((G.M + 63) / 64) * ((G.N + 63) / 64);
     }
     // a few rows (a KV-cache rollout step): one workgroup per 16-column block, the contraction split over its four waves
-    static const int skinny_env = []() { const char* e = getenv("SEA_GEMM_SKINNY"); return e ? atoi(e) : 1; }();
+    static const int skinny_env = sea_tune("gemm_skinny", 1);
     bool skinny = skinny_env != 0 && dtype == SEA_BF16 && c.hd % 16 == 0;
     for (int i = 0; i < n_groups && skinny; ++i) skinny = groups[i].M <= 16 && groups[i].K % 128 == 0 && groups[i].K <= 2048 && groups[i].col0 % 16 == 0 && groups[i].N % 16 == 0;
     if (skinny) {
@@ -744,7 +744,7 @@ extern "C" int sea_qkv_rope_grouped(const SeaQkvGroup* groups, int n_groups, con
     }
     L.tile_start[n_groups] = total;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    static const int sbq_env = []() { const char* e = getenv("SEA_GEMM_SINGLE"); return e ? atoi(e) : 1; }();
+    static const int sbq_env = sea_tune("gemm_single", 1);
     L.single_buffer = sbq_env && !dma;
     const int sbq = L.single_buffer;
 #define LAUNCH_QKV(TT, BMN, DM)                                                                                           \

@@ -647,8 +647,8 @@ extern "C" int sea_gemm_rownorm(const SeaGemmNormGroup* groups, int n_groups, fl
         L.tile_start[i] = total;
         total += (G.M + 63) / 64;
     }
-    // 16-row tiles while the 64-row launch would leave most CUs without a workgroup (measured at cfg2: see DESIGN.md); SEA_GEMM_NORM_ROWS=16|64 forces
-    static const int forced = []() { const char* e = getenv("SEA_GEMM_NORM_ROWS"); return e ? atoi(e) : 0; }();
+    // 16-row tiles while the 64-row launch would leave most CUs without a workgroup (measured at cfg2: see DESIGN.md); SEA_TUNE=gemm_norm_rows=16|64 forces
+    static const int forced = sea_tune("gemm_norm_rows", 0);
     const bool small = forced == 16 || (forced != 64 && total <= 512);
     if (small) {
         total = 0;
@@ -658,7 +658,7 @@ extern "C" int sea_gemm_rownorm(const SeaGemmNormGroup* groups, int n_groups, fl
         }
     }
     // whole-contraction LDS-DMA burst: every group's contraction is 1..4 whole K-tiles (128 bytes of K per row each); SEA_GEMM_NORM_DMA=0 disables
-    static const int dma_on = []() { const char* e = getenv("SEA_GEMM_NORM_DMA"); return e ? atoi(e) : 1; }();
+    static const int dma_on = sea_tune("gemm_norm_dma", 1);
     int dma_nk = 0;
     if (small && dma_on && total <= 256) {   // one workgroup per CU (its LDS is the whole contraction): only while the launch is a single round
         const int bk = dtype == SEA_BF16 ? 64 : 32;

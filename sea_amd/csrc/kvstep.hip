@@ -1654,10 +1654,9 @@ static bool kdim_ok(int K, int epc) {
 }
 
 // Widths with matrix-core kernels: E in {64, 128, 256} with D = E / 2 (or no exchange), heads of at most 32 columns, a cache of at most 2048
-// positions (the key rows a thread prefetches).  SEA_KV_PRE=0 keeps the run-time-width kernels (tuning aid).
+// positions (the key rows a thread prefetches).  SEA_TUNE=kv_pre=0 keeps the run-time-width kernels (tuning aid).
 static int pre_width(const SeaKvGlobal& G) {
-    const char* ev = getenv("SEA_KV_PRE");
-    const int env = ev ? atoi(ev) : 1;
+    const int env = sea_tune("kv_pre", 1);
     if (!env || G.cap > 2048 || (G.E != 64 && G.E != 128 && G.E != 256) || G.E / G.H > 32) return 0;
     if (G.exchange && (G.D * 2 != G.E || G.D / G.H > 32)) return 0;
     return G.E;
@@ -1727,11 +1726,10 @@ static int64_t persist_words(const SeaKvGlobal& G) {
 }
 
 // The persistent form applies to: one trajectory, one layer, the fixed-width kernels (pre_width) with cross heads of 8 or 16 columns, F >= 1, and a
-// role count that fits the chip (one 512-thread workgroup per CU is always resident).  SEA_KV_PERSIST=0 keeps the seven launches per step.
+// role count that fits the chip (one 512-thread workgroup per CU is always resident).  SEA_TUNE=kv_persist=0 keeps the seven launches per step.
 template <int KE, typename T>
 static bool run_persistent(const SeaKvGlobal& G, const SeaKvLayer* layers, int pos0, int n_steps, uint32_t tag0, hipStream_t s) {
-    const char* ev = getenv("SEA_KV_PERSIST");   // read per call: tests compare the two forms in one process
-    const int env = ev ? atoi(ev) : 1;
+    const int env = sea_tune("kv_persist", 1);   // read per call: tests compare the two forms in one process
     if constexpr (KE == 0) return false;
     else {
         if (!env || G.B != 1 || G.L != 1 || n_steps < 1 || G.handoff_words < persist_words(G) || G.S > 4096) return false;

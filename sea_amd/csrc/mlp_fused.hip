@@ -577,7 +577,7 @@ extern "C" int sea_mlp_fc1_ln_gelu(const SeaMlpGroup* groups, int n_groups, floa
     L.n_groups = n_groups;
     L.eps = eps;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    static const bool xcd_map = [] { const char* e = getenv("SEA_MLP_XCD"); return !(e && e[0] == '0'); }();
+    static const bool xcd_map = sea_tune("mlp_xcd", 1) != 0;
     if (xcd_map && total > 256) {   // one round of workgroups: the plain order measured 0.6 us faster (cfg2, 190 tiles); several rounds: XCD-local wins (B=8)
         L.per_xcd = (total + 7) / 8;
         total = 8 * L.per_xcd;

@@ -25,6 +25,7 @@ from typing import Dict, List, Optional, Tuple
 import torch
 
 from . import _native as N
+from . import _switches
 from . import ops
 from . import ptrcheck
 
@@ -437,7 +438,7 @@ class Plan:
         # cond_mlp.0 + SiLU evaluated inside the GEMM of cond_mlp.2 (generated A operand): no hidden matrix, no silu launch.  Inference plans
         # only (the weight gradient of cond_mlp.2 reads the hidden matrix).  The operand is recomputed by every column tile of a row panel (4x at
         # N = 512), VALU work that pays only once the hidden matrix's HBM round trip is the larger cost: measured 0.2685 against 0.2671 ms at cfg2
-        # (M = 2024: not used), 1.215 against 1.241 ms at B = 8 (used).  SEA_FUSE_SILU=1|0 forces.
+        # (M = 2024: not used), 1.215 against 1.241 ms at B = 8 (used).  SEA_PLAN=silu=1|0 forces.
         gen_a = self._gen_a(first + rest)
         ib_todo = list(getattr(self, "_ib_fold", []))   # (layer prefix, ibuf): info-bottleneck MLPs evaluated by extra row passes of the first silu launch
 
@@ -486,7 +487,7 @@ class Plan:
 
     def _gen_a(self, inst) -> bool:
         """AdaLN condition MLPs with the generated GEMM operand (no silu launch)?  Long launches only, see _cond_mods."""
-        want = os.environ.get("SEA_FUSE_SILU", "auto")
+        want = _switches.plan("silu", "auto")
         return type(self) is Plan and all(2 * d <= 1024 for _, d in inst) and (want == "1" or (want == "auto" and self.M >= 8192))
 
     # ------------------------------------------------------------------ the plan
@@ -498,25 +499,25 @@ class Plan:
         cap = self.cap
         f32 = torch.float32
 
-        # Optional lanes (parallel graph branches) for independent work — SEA_PLAN_LANES: "cond" = the condition MLPs the first launch does
+        # Optional lanes (parallel graph branches) for independent work — SEA_PLAN=lanes: "cond" = the condition MLPs the first launch does
         # not need, "all" = also every finished field's MLP beside the remaining exchange stages.  At one trajectory the
         # cross-branch dependencies of a captured HIP graph cost more than the overlap gains; from 8192 rows up the condition lane pays (1 %).
         xmode = eng.model.exchange_mode                                   # 'sea' | 'addition' | 'simple' (models/temporal.py:314-324)
         has_ib = eng.model.ib_addition_mode.lower() == "add"              # 'none': _add_info returns x (models/temporal.py:113-114)
         ib_attn = eng.model.ib_addition_mode.lower() == "attention"       # x_i += cross_attn_ib_i(x_i, ib rows) (models/temporal.py:117-118)
-        mode = os.environ.get("SEA_PLAN_LANES", "auto") if type(self) is Plan and xmode == "sea" and has_ib else "none"
+        mode = _switches.plan("lanes", "auto") if type(self) is Plan and xmode == "sea" and has_ib else "none"
         if mode == "auto":   # with the current 21-launch plan: cfg2 0.252 ms none / 0.284 cond / 0.358 all; B=8 1.166 none / 1.154 cond / 1.245 all
             mode = "cond" if self.M >= 8192 else "none"
         lanes = mode == "all" and F >= 2 and eng.model.add_info_after_cross
         split_cond = mode in ("cond", "all") and self.adaln
         # Linear + the row norm that follows it in one launch (sea_gemm_rownorm) where a tile can span the whole output row: cross_down + ln_cross,
-        # the last layer's proj + the model's final norm.  SEA_FUSE_NORM=0 keeps the two-launch form (A/B measurements).
-        fuse_norm = self._fuse_norm = type(self) is Plan and os.environ.get("SEA_FUSE_NORM", "1") != "0"
+        # the last layer's proj + the model's final norm.  SEA_PLAN=norm=0 keeps the two-launch form (A/B measurements).
+        fuse_norm = self._fuse_norm = type(self) is Plan and _switches.plan("norm", "1") != "0"
         # the info-bottleneck add without a launch of its own: its MLP depends on the condition only, so it is EVALUATED by extra row passes of the silu
         # launch (into ibuf) and ADDED by the AdaLN_2 pass that follows it anyway (SeaNormGroup.addend).  Needs the silu launch (adaln, short launches)
-        # and the add after the exchange; SEA_FOLD_IB=0 keeps sea_ib_add.
+        # and the add after the exchange; SEA_PLAN=fold_ib=0 keeps sea_ib_add.
         fold_ib = (type(self) is Plan and has_ib and eng.model.add_info_after_cross and self.adaln and not lanes and not split_cond
-                   and self.L <= N.MAX_SILU_IB and E <= 2048 and os.environ.get("SEA_FOLD_IB", "1") != "0"
+                   and self.L <= N.MAX_SILU_IB and E <= 2048 and _switches.plan("fold_ib", "1") != "0"
                    and not self._gen_a([(None, E), (None, D)]))
         hoist_ib = self._cond_src is not None and has_ib and eng.model.add_info_after_cross and len(self._cond_src.ibufs) == self.L and E <= 2048
         if hoist_ib:       # the info-bottleneck rows of all steps exist already: added by the norm pass in front of the MLP (AdaLN or LayerNorm alike)
@@ -535,9 +536,9 @@ class Plan:
             return dict(gamma=P.f32_vec(pre + "weight"))
 
         # the exchange tail of a field (projections + GELU, up-projection + residual, down-projection + norm) as ONE launch: bf16, the widths the
-        # kernel instantiates, short launches (SEA_FUSE_XTAIL=0 keeps the three-launch form; SEA_XTAIL_MAX_ROWS bounds M)
-        fuse_xtail = (fuse_norm and not lanes and xmode == "sea" and F > 1 and os.environ.get("SEA_FUSE_XTAIL", "1") != "0"
-                      and ops.exchange_tail_supported(dt, D, E, F - 1) and M <= int(os.environ.get("SEA_XTAIL_MAX_ROWS", "1000000000")))   # measured: cfg2 0.281 -> 0.254 ms, B = 2 0.414 -> 0.404, B = 4 0.679 -> 0.675, B = 8 a tie (1.191)
+        # kernel instantiates, short launches (SEA_PLAN=xtail=0 keeps the three-launch form; SEA_PLAN=xtail_max_rows bounds M)
+        fuse_xtail = (fuse_norm and not lanes and xmode == "sea" and F > 1 and _switches.plan("xtail", "1") != "0"
+                      and ops.exchange_tail_supported(dt, D, E, F - 1) and M <= int(_switches.plan("xtail_max_rows", "1000000000")))   # measured: cfg2 0.281 -> 0.254 ms, B = 2 0.414 -> 0.404, B = 4 0.679 -> 0.675, B = 8 a tie (1.191)
         rope_s, rope_c = eng.rope_self, eng.rope_cross
         Eo, concat = self.Eo, self.concat
         FE = F * Eo                                             # row stride of the caller's [B, T, F, Eo] tensors
@@ -741,16 +742,16 @@ class Plan:
                 return dict(mod=mods[p_], gamma=P.f32_vec(p_ + "weight"), beta=P.f32_vec(p_ + "bias"))
             return dict(gamma=P.f32_vec(p_ + "weight"))
 
-        # Linear + nn.LayerNorm + GELU in one launch where the kernel is instantiated (bf16; SEA_FUSE_MLP1=0 keeps the two launches, =1 forces
+        # Linear + nn.LayerNorm + GELU in one launch where the kernel is instantiated (bf16; SEA_PLAN=mlp1=0 keeps the two launches, =1 forces
         # the one launch).  Every workgroup of that kernel streams the whole of W1, so it needs enough 32-row tiles to pay: with the few rows
         # of a KV-cache step the two launches are faster (0.143 vs 0.163 ms per step at cfg2), hence the row threshold.
-        want = os.environ.get("SEA_FUSE_MLP1", "auto")
+        want = _switches.plan("mlp1", "auto")
         fused = (type(self) is Plan and want != "0" and (want == "1" or self.M >= 1024) and ops.mlp_fc1_supported(self.dt, E, S) and len(fields) <= N.MAX_MLP_GROUPS)
         # ... and the row pass in front of it (info-bottleneck add + AdaLN_2 / LayerNorm) as that launch's prologue: a workgroup owns its 32 rows from the
         # fp32 residual stream to the activated hidden rows.  Measured (graph replay): cfg2 0.2472 -> 0.2440 ms (the launch itself 27.4 -> 31.2-32.2 us: its
         # loads sit in front of the weight stream; the row pass it replaces is 7.8 us), B = 8 1.127 -> 1.138 ms (142 -> 171 us per launch against a 32 us row
-        # pass that runs at HBM speed) — used for short launches only.  SEA_FUSE_MLPNORM=0 / 1 forces.
-        wn = os.environ.get("SEA_FUSE_MLPNORM", "auto")
+        # pass that runs at HBM speed) — used for short launches only.  SEA_PLAN=mlpnorm=0 / 1 forces.
+        wn = _switches.plan("mlpnorm", "auto")
         norm_in = fused and (wn == "1" or (wn == "auto" and self.M <= 4096))
         extra = (lambda i: dict(addend=addend, Xout=xr[i])) if addend is not None else (lambda i: {})   # x_i += ib rides in this pass
         if not norm_in:
@@ -770,8 +771,8 @@ class Plan:
         # fc2 + residual, proj and — after the last layer — the model's final norm in one launch where the kernel is instantiated (the same shapes as the
         # fc1 kernel): a workgroup owns 32 complete rows through both Linear layers.  Measured (plain replay, same box): cfg2 0.2373 -> 0.2358 ms (the launch
         # 30.8 us against 19.8 + 7.1 + 5.6 with two boundaries less: a 32-row workgroup per CU streams W2 at a third of the rate three co-resident 64 x 64
-        # tiles do), B = 8 1.108 -> 1.18 ms (200 us against 76 + 21 + 31) — short launches only.  SEA_FUSE_MLP2=0 / 1 forces.
-        w2 = os.environ.get("SEA_FUSE_MLP2", "auto")
+        # tiles do), B = 8 1.108 -> 1.18 ms (200 us against 76 + 21 + 31) — short launches only.  SEA_PLAN=mlp2=0 / 1 forces.
+        w2 = _switches.plan("mlp2", "auto")
         if (type(self) is Plan and (w2 == "1" or (w2 == "auto" and 1024 <= self.M <= 4096)) and ops.mlp_fc1_supported(self.dt, E, S) and Eo == E and len(fields) <= N.MAX_MLP_GROUPS):
             arr = (N.SeaMlp2Group * len(fields))()
             for g_, i in zip(arr, fields):
@@ -1374,7 +1375,7 @@ class TemporalEngine:
             torch.cuda.synchronize(self.device)
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
-                p.run(concurrent=os.environ.get("SEA_LANES", "1") != "0")
+                p.run(concurrent=_switches.plan("graph_lanes", "1") != "0")
             hit = (graph, out, p, x, ib)
             self._graphs[key] = hit
         hit[0].replay()
@@ -1406,10 +1407,10 @@ class TemporalEngine:
         cond = ib[:, :n_steps, 0].t().contiguous()  # [n_steps, B]
         # What depends on the condition only (the AdaLN modulations of every module, the info-bottleneck term) is evaluated for ALL steps by one batched
         # pass before the loop — the full-context plan's own silu / grouped-GEMM / ib launches on n_steps * B rows — instead of once per step on B rows:
-        # at the shipped cylinder width (embed_dim 1024) that is two launches and 31 % of the weight bytes of every step.  SEA_KV_HOIST=0: per step.
+        # at the shipped cylinder width (embed_dim 1024) that is two launches and 31 % of the weight bytes of every step.  SEA_KV=hoist=0: per step.
         cp = None
         m = self.model
-        if os.environ.get("SEA_KV_HOIST", "1") != "0" and (m.LN_type.lower() == "adaln" or (m.ib_addition_mode.lower() == "add" and m.add_info_after_cross)) \
+        if _switches.kv("hoist", "1") != "0" and (m.LN_type.lower() == "adaln" or (m.ib_addition_mode.lower() == "add" and m.add_info_after_cross)) \
                 and m.ib_addition_mode.lower() in ("add", "none"):
             cp = kv_engine.cond_plan_for(self, n_steps * B)
             for t in cp.ibufs:
@@ -1426,8 +1427,8 @@ class TemporalEngine:
             p.bind_ptrs(base, cbase, base + slab)
             p.set_hoisted_step(0)
             p.audit(owners=(traj, cond))
-        # the step loop in native code (the plan's launch list + a table of the per-step edits); SEA_KV_NATIVE_LOOP=0: one Python round trip per step
-        if os.environ.get("SEA_KV_NATIVE_LOOP", "1") == "0" or not p.run_steps(n_steps, base, slab, cbase, B * 4, base + slab, slab):
+        # the step loop in native code (the plan's launch list + a table of the per-step edits); SEA_KV=loop=python: one Python round trip per step
+        if _switches.kv("loop", "native") == "python" or not p.run_steps(n_steps, base, slab, cbase, B * 4, base + slab, slab):
             for s in range(n_steps):
                 p.set_position(s)
                 p.bind_ptrs(base + s * slab, cbase + s * B * 4, base + (s + 1) * slab)

@@ -16,6 +16,7 @@ from typing import Dict, List, Optional
 import torch
 
 from . import _native as N
+from . import _switches
 from . import ptrcheck
 from .engine import Plan, _round_up
 
@@ -57,9 +58,9 @@ def _chunks_ok(K: int, epc: int) -> bool:
 
 
 def supported(eng, B: int) -> bool:
-    """Is (model, batch) inside what sea_kv_rollout covers?  SEA_KV_FAST=0 keeps the generic step plan (A/B measurements, parity tests)."""
+    """Is (model, batch) inside what sea_kv_rollout covers?  SEA_KV=fast=0 keeps the generic step plan (A/B measurements, parity tests)."""
     m = eng.model
-    if os.environ.get("SEA_KV_FAST", "1") == "0":
+    if _switches.kv("fast", "1") == "0":
         return False
     if m.exchange_mode not in ("sea", "simple") or m.src_len != 0 or m.ib_addition_mode.lower() in ("attention", "concat"):
         return False   # ('concat': rows of two widths; the generic step plan covers it)
@@ -188,7 +189,7 @@ class KvFast:
             N.check(rc, "sea_kv_rollout")
             self._tag = (self._tag + n_steps * self.L) & 0xFFFFFFFF or 1
             out = traj[1:].permute(1, 0, 2, 3).contiguous()
-            if attempt == 0 and os.environ.get("SEA_KV_TEST_FORCE_ERR") == "1" and self.G.handoff_words > B * F * max(self.D, 1):
+            if attempt == 0 and _switches.kv("force_err") == "1" and self.G.handoff_words > B * F * max(self.D, 1):
                 self.err.fill_(1)           # test hook: behave as if a hand-off wait of the persistent launch had given up (tests/test_kv_fast_gpu.py)
             if int(self.err.item()) == 0:   # (synchronises)
                 return out

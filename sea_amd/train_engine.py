@@ -15,6 +15,7 @@ from typing import Dict, List, Optional, Tuple
 import torch
 
 from . import _native as N
+from . import _switches
 from . import ops
 from .engine import Plan, _Rec, blk_pe
 
@@ -356,7 +357,7 @@ class TrainPlan(Plan):
                 sv["nd"] = buf(F, M, D)
                 sv["stc"] = [stats() for _ in range(F)]
                 sv["s_pre"], sv["sg"] = buf(M, D), buf(M, D)
-                if os.environ.get("SEA_FUSE_NORM", "1") != "0" and D <= 256 and D % 16 == 0:
+                if _switches.plan("norm", "1") != "0" and D <= 256 and D % 16 == 0:
                     self._gemm_norm([dict(A=sv["xa1"][j], W=P.act(f"{pre}cross_down.{j}.weight"), bias=P.f32_vec(f"{pre}cross_down.{j}.bias"), C32=sv["dn"][j],
                                           Yact=sv["nd"][j], mean=sv["stc"][j][0], rstd=sv["stc"][j][1], **npar(f"{pre}ln_cross.{j}.")) for j in range(F)], "add.down_norm")
                 else:
@@ -378,7 +379,7 @@ class TrainPlan(Plan):
                 big = sv["big"] = buf(M, 2 * FD)
                 pe_t = buf(M, D, dtype=f32)
                 pe_t.copy_(blk_pe(eng, l)[:T].repeat(B, 1))
-                if os.environ.get("SEA_FUSE_NORM", "1") != "0" and D <= 256 and D % 16 == 0:
+                if _switches.plan("norm", "1") != "0" and D <= 256 and D % 16 == 0:
                     self._gemm_norm([dict(A=sv["xa1"][j], W=P.act(f"{pre}cross_down.{j}.weight"), bias=P.f32_vec(f"{pre}cross_down.{j}.bias"), C32=sv["dn"][j],
                                           Yact=nrm[j], mean=sv["stc"][j][0], rstd=sv["stc"][j][1], **npar(f"{pre}ln_cross.{j}.")) for j in range(F)], "pool.down_norm")
                 else:
@@ -420,7 +421,7 @@ class TrainPlan(Plan):
                 sv["stc_new"] = [stats() for _ in range(F)]
                 sv["xa2"] = [buf(M, E) for _ in range(F)]
                 # cross_down + ln_cross in one launch (sea_gemm_rownorm); the pre-normalisation rows and the statistics are kept for the backward
-                fuse_dn = os.environ.get("SEA_FUSE_NORM", "1") != "0" and D <= 256 and D % 16 == 0
+                fuse_dn = _switches.plan("norm", "1") != "0" and D <= 256 and D % 16 == 0
                 if fuse_dn:
                     self._gemm_norm([dict(A=sv["xa1"][j], W=P.act(f"{pre}cross_down.{j}.weight"), bias=P.f32_vec(f"{pre}cross_down.{j}.bias"), C32=sv["dn_old"][j],
                                           Yact=sv["nd_old"][j], mean=sv["stc_old"][j][0], rstd=sv["stc_old"][j][1], **npar(f"{pre}ln_cross.{j}."))

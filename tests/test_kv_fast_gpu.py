@@ -5,6 +5,8 @@ and (c) itself (replays, batch rows independent of each other).  The golden roll
 
 Tolerances: fp32 1e-4 against the oracle (north_star's bar), 1e-5 between the two device paths; bf16 3e-2 per step-count stated in each test.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -20,7 +22,7 @@ pytestmark = pytest.mark.gpu
 def _kv(m, x0, ib, n, monkeypatch, fast):
     from sea_amd.utils.train_utils import rollout
 
-    monkeypatch.setenv("SEA_KV_FAST", "1" if fast else "0")
+    monkeypatch.setenv("SEA_KV", ("fast=1" if fast else "fast=0") + (os.environ.get("SEA_KV_EXTRA", "")))
     before = len(m.engine()._kv_fast)
     out = rollout(m, x0, ib, n, mode="kv")
     if not fast:
@@ -85,11 +87,11 @@ def test_fast_kv_rows_of_a_batch_are_independent(monkeypatch):
     x, _, ib = recipe_inputs(4, 24, cfg, seed=9)
     x0, ibg = x[:, :1].cuda().contiguous(), ib.cuda().contiguous()
     full = _kv(m, x0, ibg, 24, monkeypatch, True)
-    monkeypatch.setenv("SEA_KV_PERSIST", "0")   # the same launches at both batch sizes (one trajectory alone would otherwise take the persistent form)
+    monkeypatch.setenv("SEA_TUNE", "kv_persist=0")   # the same launches at both batch sizes (one trajectory alone would otherwise take the persistent form)
     for b in (0, 3):
         one = _kv(m, x0[b:b + 1].contiguous(), ibg[b:b + 1].contiguous(), 24, monkeypatch, True)
         assert torch.equal(one[0], full[b])
-    monkeypatch.setenv("SEA_KV_PERSIST", "1")
+    monkeypatch.setenv("SEA_TUNE", "kv_persist=1")
     one = _kv(m, x0[1:2].contiguous(), ibg[1:2].contiguous(), 24, monkeypatch, True)
     assert rel_l2(one[0].cpu().numpy(), full[1].cpu().numpy()) < 1e-5
 
@@ -127,13 +129,13 @@ PERSIST_CASES = [
 @pytest.mark.parametrize("dtype,tol_oracle,tol_paths", [("fp32", 1e-4, 1e-5), ("bf16", 3e-2, 2e-2)])
 @pytest.mark.parametrize("cfg_args,n", PERSIST_CASES)
 def test_persistent_kv_rollout(cfg_args, n, dtype, tol_oracle, tol_paths, monkeypatch):
-    """The persistent form against the oracle, against the seven-launch form (SEA_KV_PERSIST=0) and against itself (a second rollout reuses the caches
+    """The persistent form against the oracle, against the seven-launch form (SEA_TUNE=kv_persist=0) and against itself (a second rollout reuses the caches
     and the granule arena with fresh tags; a shorter one is its prefix)."""
     cfg = O.OracleConfig(*cfg_args)
     m = build(cfg, dtype)
     x, _, ib = recipe_inputs(1, n, cfg, seed=8)
     x0, ibg = x[:, :1].cuda().contiguous(), ib.cuda().contiguous()
-    monkeypatch.setenv("SEA_KV_PERSIST", "1")
+    monkeypatch.setenv("SEA_TUNE", "kv_persist=1")
     a = _kv(m, x0, ibg, n, monkeypatch, True)
     ref = O.rollout(x[:, :1], ib, n, recipe_params(cfg), cfg)
     k = min(n, 8)
@@ -142,14 +144,14 @@ def test_persistent_kv_rollout(cfg_args, n, dtype, tol_oracle, tol_paths, monkey
         assert rel_l2(a.cpu().numpy(), ref.numpy()) < tol_oracle
     assert torch.equal(_kv(m, x0, ibg, n, monkeypatch, True), a)
     assert torch.equal(_kv(m, x0, ibg, n // 2, monkeypatch, True), a[:, :n // 2])
-    monkeypatch.setenv("SEA_KV_PERSIST", "0")
+    monkeypatch.setenv("SEA_TUNE", "kv_persist=0")
     b = _kv(m, x0, ibg, n, monkeypatch, True)
     assert rel_l2(a.cpu().numpy(), b.cpu().numpy()) < tol_paths
 
 
 def test_persistent_rollout_recovers_when_a_handoff_wait_gives_up(monkeypatch):
     """The recovery path of KvFast.rollout (sea_amd/kv_engine.py): when the persistent launch reports that a hand-off wait gave up — forced here by
-    SEA_KV_TEST_FORCE_ERR=1, in production another process holding CUs — the rollout is recomputed with the seven launches per step, the KvFast object
+    SEA_KV=force_err=1, in production another process holding CUs — the rollout is recomputed with the seven launches per step, the KvFast object
     stays on that form for good, and a LATER rollout on the same object (caches and granule arena reused) is still right."""
     cfg = O.OracleConfig(1, 128, 8, 96, 8, 0, 3, 2, True, "adaln")
     m = build(cfg, "fp32")
@@ -157,14 +159,14 @@ def test_persistent_rollout_recovers_when_a_handoff_wait_gives_up(monkeypatch):
     x, _, ib = recipe_inputs(1, n, cfg, seed=12)
     x0, ibg = x[:, :1].cuda().contiguous(), ib.cuda().contiguous()
     ref = O.rollout(x[:, :1], ib, n, recipe_params(cfg), cfg)
-    monkeypatch.setenv("SEA_KV_PERSIST", "1")
+    monkeypatch.setenv("SEA_TUNE", "kv_persist=1")
     good = _kv(m, x0, ibg, n, monkeypatch, True)                       # the persistent form, undisturbed
     kf = m.engine()._kv_fast[1]
     words = kf.G.handoff_words
     assert words > kf.B * kf.F * kf.D                                  # (it did take the persistent form)
-    monkeypatch.setenv("SEA_KV_TEST_FORCE_ERR", "1")
+    monkeypatch.setenv("SEA_KV_EXTRA", ",force_err=1")
     rec = _kv(m, x0, ibg, n, monkeypatch, True)                        # attempt 0 "fails", attempt 1 recomputes
-    monkeypatch.delenv("SEA_KV_TEST_FORCE_ERR")
+    monkeypatch.delenv("SEA_KV_EXTRA")
     assert kf.G.handoff_words == kf.B * kf.F * kf.D < words            # the object gave the persistent form up for good
     assert int(kf.err.item()) == 0
     assert rel_l2(rec.cpu().numpy(), ref.numpy()) < 1e-4 and rel_l2(rec.cpu().numpy(), good.cpu().numpy()) < 1e-5
@@ -187,7 +189,7 @@ def test_models_outside_the_limits_keep_the_generic_plan(monkeypatch):
 @pytest.mark.parametrize("cfg_args", [(1, 64, 4, 48, 8, 0, 3, 2, True, "adaln"), (2, 128, 8, 40, 4, 0, 2, 2, True, "ln"), (1, 64, 4, 48, 8, 0, 2, 2, False, "adaln")])
 def test_generic_step_plan_hoists_the_condition_work(cfg_args, monkeypatch):
     """The generic KV-cache step plan (what the shipped widths run): with the condition-only work — AdaLN modulations, the info-bottleneck term —
-    evaluated for all steps by one batched pass (engine.rollout_kv, SEA_KV_HOIST) the rollout equals the per-step form (fp32 <= 1e-5: the batched pass
+    evaluated for all steps by one batched pass (engine.rollout_kv, SEA_KV=hoist) the rollout equals the per-step form (fp32 <= 1e-5: the batched pass
     runs the same arithmetic through the many-row GEMM kernels), carries no condition launch in its step plan, and the native step loop and the
     per-step Python loop patch the same pointers (bitwise equal)."""
     from sea_amd.utils.train_utils import rollout
@@ -197,10 +199,9 @@ def test_generic_step_plan_hoists_the_condition_work(cfg_args, monkeypatch):
     x, _, ib = recipe_inputs(B, n, cfg, seed=21)
     x0, ibg = x[:, :1].cuda().contiguous(), ib.cuda().contiguous()
     ref = O.rollout(x[:, :1], ib, n, recipe_params(cfg), cfg)
-    monkeypatch.setenv("SEA_KV_FAST", "0")
     for dtype, tol, tol_paths in (("fp32", 1e-4, 1e-5), ("bf16", 3e-2, 2e-2)):
         m = build(cfg, dtype)
-        monkeypatch.setenv("SEA_KV_HOIST", "1")
+        monkeypatch.setenv("SEA_KV", "fast=0,hoist=1")
         a = rollout(m, x0, ibg, n, mode="kv")
         eng = m.engine()
         plans = [p for k, p in eng._plans.items() if len(k) == 4 and k[:3] == (B, 1, "step")]
@@ -210,10 +211,10 @@ def test_generic_step_plan_hoists_the_condition_work(cfg_args, monkeypatch):
         if cfg.add_info_after_cross:
             assert "ib_add" not in names        # the info-bottleneck rows ride in the norm pass in front of the MLP
         assert rel_l2(a.cpu().numpy(), ref.numpy()) < tol
-        monkeypatch.setenv("SEA_KV_NATIVE_LOOP", "0")
+        monkeypatch.setenv("SEA_KV", "fast=0,hoist=1,loop=python")
         assert torch.equal(rollout(m, x0, ibg, n, mode="kv"), a)
-        monkeypatch.setenv("SEA_KV_NATIVE_LOOP", "1")
+        monkeypatch.setenv("SEA_KV", "fast=0,hoist=1")
         assert torch.equal(rollout(m, x0, ibg, n // 2, mode="kv")[:, :4], a[:, :4]) or dtype == "bf16"   # (a shorter rollout batches fewer rows: same kernels from 17 rows up)
-        monkeypatch.setenv("SEA_KV_HOIST", "0")
+        monkeypatch.setenv("SEA_KV", "fast=0,hoist=0")
         b = rollout(m, x0, ibg, n, mode="kv")
         assert rel_l2(a.cpu().numpy(), b.cpu().numpy()) < tol_paths

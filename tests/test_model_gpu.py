@@ -509,8 +509,8 @@ def test_shipped_multiphase_dims_forward(dtype, tol):
     assert rel_l2(roll.numpy(), ref_roll.numpy()) < 2 * tol
 
 
-@pytest.mark.parametrize("env,graphed", [({"SEA_PLAN_LANES": "all"}, True), ({"SEA_PLAN_LANES": "cond"}, True),
-                                         ({"SEA_FUSE_NORM": "0"}, False), ({"SEA_FUSE_XTAIL": "0"}, False), ({"SEA_FUSE_SILU": "1"}, False), ({"SEA_FOLD_IB": "0"}, False), ({"SEA_FUSE_MLP1": "1"}, False), ({"SEA_FUSE_NORM": "1", "SEA_GEMM_NORM_ROWS": "64"}, False)])
+@pytest.mark.parametrize("env,graphed", [({"SEA_PLAN": "lanes=all"}, True), ({"SEA_PLAN": "lanes=cond"}, True),
+                                         ({"SEA_PLAN": "norm=0"}, False), ({"SEA_PLAN": "xtail=0"}, False), ({"SEA_PLAN": "silu=1"}, False), ({"SEA_PLAN": "fold_ib=0"}, False), ({"SEA_PLAN": "mlp1=1"}, False), ({"SEA_TUNE": "gemm_norm_rows=64"}, False)])
 @pytest.mark.parametrize("dtype,tol", [("fp32", 2e-6), ("bf16", 2e-2)])
 def test_optional_plans_match_default_plan(env, graphed, dtype, tol, monkeypatch):
     """The opt-in plans (fusion switches; parallel graph branches) compute what the default launch list computes — checked on the oracle too
@@ -528,24 +528,25 @@ def test_optional_plans_match_default_plan(env, graphed, dtype, tol, monkeypatch
         out = eng.forward_graphed(xg, ibg).clone() if graphed else m(xg, ibg)
         plan = eng.plan(2, 70, "full")
     names = [r.name for r in plan.records]
-    if "SEA_FUSE_MLP1" in env:   # Linear + nn.LayerNorm + GELU in one launch, forced (default from 1024 rows up: a KV-cache step keeps two launches)
+    sw = env.get("SEA_PLAN", "") + env.get("SEA_TUNE", "")
+    if sw == "mlp1=1":   # Linear + nn.LayerNorm + GELU in one launch, forced (default from 1024 rows up: a KV-cache step keeps two launches)
         assert (dtype == "bf16") == ("mlp.fc1_ln_gelu" in names) and (dtype == "fp32") == ("mlp.fc1" in names)
-        monkeypatch.delenv("SEA_FUSE_MLP1")
+        monkeypatch.delenv("SEA_PLAN")
         e2 = build(cfg, dtype).engine()
         assert "mlp.fc1" in [r.name for r in e2.plan(2, 70, "full").records]
         assert ("mlp.fc1_ln_gelu" in [r.name for r in e2.plan(16, 70, "full").records]) == (dtype == "bf16")
-    elif "SEA_FOLD_IB" in env:     # the info-bottleneck add as its own launch (default: evaluated in the silu launch, added by the AdaLN_2 pass)
+    elif sw == "fold_ib=0":     # the info-bottleneck add as its own launch (default: evaluated in the silu launch, added by the AdaLN_2 pass)
         assert "ib_add" in names and "mlp.adaln2" in names and "mlp.ib_adaln2" not in names
-    elif "SEA_FUSE_SILU" in env:   # AdaLN condition MLPs with the generated operand (default only for long launches)
+    elif sw == "silu=1":   # AdaLN condition MLPs with the generated operand (default only for long launches)
         assert "adaln.silu" not in names and "adaln.cond_gemm" in names
-    elif "SEA_FUSE_XTAIL" in env:  # the three-launch form of a field's exchange tail (bf16: the default plan runs sea_exchange_tail)
+    elif sw == "xtail=0":  # the three-launch form of a field's exchange tail (bf16: the default plan runs sea_exchange_tail)
         assert "cross0.proj_gelu" in names and "cross0.tail" not in names
-        monkeypatch.delenv("SEA_FUSE_XTAIL")
+        monkeypatch.delenv("SEA_PLAN")
         default_names = [r.name for r in build(cfg, dtype).engine().plan(2, 70, "full").records]
         assert ("cross0.tail" in default_names) == (dtype == "bf16")   # the default plan runs sea_exchange_tail in bf16, the three launches in fp32
-    elif "SEA_GEMM_NORM_ROWS" in env:   # Linear + row norm with the 64-row tiles the long launches use
+    elif sw == "gemm_norm_rows=64":   # Linear + row norm with the 64-row tiles the long launches use
         assert "cross.down_norm_old" in names
-    elif "SEA_FUSE_NORM" in env:   # the two-launch form of Linear + row norm
+    elif sw == "norm=0":   # the two-launch form of Linear + row norm
         assert "cross.norm_old" in names and "cross.down_norm_old" not in names
     else:
         assert any(r.fn is None for r in plan.records)  # fork / join markers present

@@ -446,7 +446,7 @@ def test_gemm_rownorm_matches_gemm_then_rownorm(dtype, N_, K):
 def test_gemm_rownorm_segments_ib_addend(dtype, M):
     """The exchange tail of one field in one launch: x += cross_up(sum_j g_j) (segments, bias counted per segment, in-place residual),
     the copy cross_down reads is written BEFORE the info-bottleneck addend, AdaLN_2 is taken after it.  M = 2500 runs the 64-row tiles
-    (forced through SEA_GEMM_NORM_ROWS is not needed: the launch is longer than 512 row tiles only at M > 32768, so both shapes are forced by env in
+    (forced through SEA_TUNE=gemm_norm_rows is not needed: the launch is longer than 512 row tiles only at M > 32768, so both shapes are forced by env in
     test_gemm_rownorm_tile_shapes_agree)."""
     from sea_amd import ops
 

@@ -36,7 +36,7 @@ def test_every_plan_passes_the_audit_at_every_bind(dtype, monkeypatch):
     assert tp._audited and tp.audit(owners=(tp._bound_dout,)) > 200
     m.eval()
     rollout(m, x[:, :1].contiguous(), ib, 12, mode="kv")                       # sea_kv_rollout: the condition plan
-    monkeypatch.setenv("SEA_KV_FAST", "0")
+    monkeypatch.setenv("SEA_KV", "fast=0")
     rollout(m, x[:, :1].contiguous(), ib, 12, mode="kv")                       # the generic step plan, bound by raw address
     steps = [p for k, p in eng._plans.items() if k[:3] == (2, 1, "step")]
     assert steps and all(p._audited for p in steps)

@@ -1,4 +1,4 @@
-"""cfg2 forward with the condition lane (SEA_PLAN_LANES=cond) replayed on two plain streams (events, no graph), against the one-stream replay.
+"""cfg2 forward with the condition lane (SEA_PLAN=lanes=cond) replayed on two plain streams (events, no graph), against the one-stream replay.
 The graph form of the lanes lost; this measures the stream form, with and without stream priorities.  Development aid.
 
     python tools/lane_probe.py            # prints ms per step for: one stream | lanes, equal priority | lanes, main stream high priority
@@ -32,7 +32,7 @@ def main():
     res = {}
     ref = None
     for mode in ("none", "cond"):
-        os.environ["SEA_PLAN_LANES"] = mode
+        os.environ["SEA_PLAN"] = "lanes=" + mode
         model = bench.build_model(dev, "bf16").eval()
         eng = model.engine(dev)
         from sea_amd.engine import Plan

@@ -15,7 +15,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_fwd -o run -- py
 rocprofv3 --kernel-trace --output-format csv -d $O/prof_graph -o run -- python3 bench.py --mode rollout --steps 40 --warmup 5 --no-cpu-baseline --graph > $O/prof_graph.json 2> $O/prof_graph.err || exit 1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_train -o run -- python3 bench.py --mode train --steps 10 --warmup 3 > $O/prof_train.json 2> $O/prof_train.err || exit 1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_kv -o run -- python3 bench.py --mode kv --steps 3 --warmup 1 > $O/prof_kv.json 2> $O/prof_kv.err || exit 1
-SEA_KV_PERSIST=0 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_kv7 -o run -- python3 bench.py --mode kv --steps 3 --warmup 1 > $O/prof_kv7.json 2> $O/prof_kv7.err || exit 1
+SEA_TUNE=kv_persist=0 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_kv7 -o run -- python3 bench.py --mode kv --steps 3 --warmup 1 > $O/prof_kv7.json 2> $O/prof_kv7.err || exit 1
 python tools/kv_persist_timeline.py 2024 > $O/kv_timeline.txt 2>/dev/null || exit 1
 echo "traces done"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_f -o run -- python3 tools/pmc_forward.py > $O/pmc_f.log 2>&1 || exit 1
