@@ -585,7 +585,22 @@ __global__ __launch_bounds__(256) void rownorm_bwd_kernel(const NormBwdLaunch L)
 // atomics, no second pass over the row (the per-element LDS-atomic form this replaces for d > 2048 re-read the row, evaluated GELU' twice and ran
 // at 0.4 TB/s: 200 us for the 78 MB of the shipped cylinder width).  Row statistics cross the waves through LDS.  Column sums leave as plain
 // stores into the two-stage workspace (or as atomics when the caller gave none).
-template <typename T, bool DY_ACT, bool X_ACT, int NT, int KCH>
+// a piece of PW = 4 or 8 consecutive columns (f32: 16 / 2 x 16 bytes; bf16: 8 / 16 bytes)
+template <typename U, int PW>
+__device__ __forceinline__ void loadp(const U* src, float (&o)[PW]) {
+    if constexpr (PW == 4) load4(src, o);
+    else load8(src, o);
+}
+__device__ __forceinline__ void storep(float* dst, const float (&v)[4]) { store4(dst, v[0], v[1], v[2], v[3]); }
+__device__ __forceinline__ void storep(__bf16* dst, const float (&v)[4]) { store4(dst, v[0], v[1], v[2], v[3]); }
+__device__ __forceinline__ void storep(float* dst, const float (&v)[8]) {
+    store4(dst, v[0], v[1], v[2], v[3]);
+    store4(dst + 4, v[4], v[5], v[6], v[7]);
+}
+__device__ __forceinline__ void storep(__bf16* dst, const float (&v)[8]) { store8(dst, v); }
+
+// PW = columns per piece: 4, or 8 where every row operand is bf16 (16-byte accesses: the LayerNorm + GELU of the MLP)
+template <typename T, bool DY_ACT, bool X_ACT, int NT, int KCH, int PW>
 __global__ __launch_bounds__(NT) void rownorm_bwd_wide_kernel(const NormBwdLaunch L) {
     constexpr int NW = NT / 64;
     __shared__ float red[2 * NW];
@@ -594,18 +609,18 @@ __global__ __launch_bounds__(NT) void rownorm_bwd_wide_kernel(const NormBwdLaunc
     using DYT = typename std::conditional<DY_ACT, T, float>::type;
     using XT = typename std::conditional<X_ACT, T, float>::type;
     const float inv_d = 1.0f / (float)d;
-    // (KCH > 2, rows of up to 16384 columns on 1024 threads: 128 registers per thread — the row-independent gain / shift are re-read per row from L2
+    // (more than 8 columns per thread, rows of up to 16384 columns on 1024 threads: 128 registers per thread — the row-independent gain / shift are re-read per row from L2
     // instead of kept, and the second pass recomputes xhat from x instead of keeping it)
-    constexpr bool KEEP = KCH <= 2;
-    float accg[KCH][4], accb[KCH][4], s[KCH][4], tt[KCH][4];
+    constexpr bool KEEP = KCH * PW <= 8;
+    float accg[KCH][PW], accb[KCH][PW], s[KCH][PW], tt[KCH][PW];
 #pragma unroll
     for (int k = 0; k < KCH; ++k) {
-        const int i = tid * 4 + NT * 4 * k;
+        const int i = tid * PW + NT * PW * k;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) accg[k][e] = accb[k][e] = s[k][e] = tt[k][e] = 0.f;
+        for (int e = 0; e < PW; ++e) accg[k][e] = accb[k][e] = s[k][e] = tt[k][e] = 0.f;
         if (KEEP && i < d && G.mod == nullptr) {  // row-independent gain / shift: loaded once
-            load4(G.gamma + i, s[k]);
-            if (L.gelu && G.beta) load4(G.beta + i, tt[k]);
+            loadp(G.gamma + i, s[k]);
+            if (L.gelu && G.beta) loadp(G.beta + i, tt[k]);
         }
     }
     for (int row = blockIdx.x; row < L.M; row += gridDim.x) {
@@ -616,34 +631,34 @@ __global__ __launch_bounds__(NT) void rownorm_bwd_wide_kernel(const NormBwdLaunc
         const float mean = G.mean[row], rstd = G.rstd[row];
         float* dx32 = G.dX32 ? G.dX32 + (int64_t)row * G.lddx32 : nullptr;
         T* dxa = G.dXact ? static_cast<T*>(G.dXact) + (int64_t)row * G.lddxact : nullptr;
-        auto gain_shift = [&](int i, float (&sv)[4], float (&tv)[4]) {   // this chunk's s = gamma (+ 1 + mod_w), t = beta (+ mod_b) (t only feeds GELU')
-            load4(G.gamma + i, sv);
-            tv[0] = tv[1] = tv[2] = tv[3] = 0.f;
-            if (L.gelu && G.beta) load4(G.beta + i, tv);
+        auto gain_shift = [&](int i, float (&sv)[PW], float (&tv)[PW]) {   // this chunk's s = gamma (+ 1 + mod_w), t = beta (+ mod_b) (t only feeds GELU')
+            loadp(G.gamma + i, sv);
+            for (int e = 0; e < PW; ++e) tv[e] = 0.f;
+            if (L.gelu && G.beta) loadp(G.beta + i, tv);
             if (mod) {
-                float mw[4];
-                load4(mod + i, mw);
+                float mw[PW];
+                loadp(mod + i, mw);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) sv[e] += 1.0f + mw[e];
+                for (int e = 0; e < PW; ++e) sv[e] += 1.0f + mw[e];
                 if (L.gelu) {
-                    float mb[4];
-                    load4(mod + d + i, mb);
+                    float mb[PW];
+                    loadp(mod + d + i, mb);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) tv[e] += mb[e];
+                    for (int e = 0; e < PW; ++e) tv[e] += mb[e];
                 }
             }
         };
-        auto emit = [&](int i, float (&o)[4]) {
+        auto emit = [&](int i, float (&o)[PW]) {
             if (dx32) {
                 if (L.accumulate) {
-                    float old[4];
-                    load4(dx32 + i, old);
+                    float old[PW];
+                    loadp(dx32 + i, old);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) o[e] += old[e];
+                    for (int e = 0; e < PW; ++e) o[e] += old[e];
                 }
-                store4(dx32 + i, o[0], o[1], o[2], o[3]);
+                storep(dx32 + i, o);
             }
-            if (dxa) store4(dxa + i, o[0], o[1], o[2], o[3]);
+            if (dxa) storep(dxa + i, o);
         };
         auto row_stats = [&](float& c1, float& c2) {   // sums over the row of dxhat and dxhat * xhat, divided by d
             c1 = wave_sum(c1);
@@ -665,25 +680,25 @@ __global__ __launch_bounds__(NT) void rownorm_bwd_wide_kernel(const NormBwdLaunc
         };
         float c1 = 0.f, c2 = 0.f;
         if constexpr (KEEP) {
-            float xv[KCH][4], dv[KCH][4];
+            float xv[KCH][PW], dv[KCH][PW];
 #pragma unroll
             for (int k = 0; k < KCH; ++k) {  // all of the row's loads first
-                const int i = tid * 4 + NT * 4 * k;
+                const int i = tid * PW + NT * PW * k;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) xv[k][e] = dv[k][e] = 0.f;
+                for (int e = 0; e < PW; ++e) xv[k][e] = dv[k][e] = 0.f;
                 if (i < d) {
-                    load4(x + i, xv[k]);
-                    load4(dy + i, dv[k]);
+                    loadp(x + i, xv[k]);
+                    loadp(dy + i, dv[k]);
                     if (mod) gain_shift(i, s[k], tt[k]);
                 }
             }
 #pragma unroll
             for (int k = 0; k < KCH; ++k) {   // xv becomes xhat, dv becomes dxhat = dy (gelu') s — in place: the second pass needs exactly these two
-                const int i = tid * 4 + NT * 4 * k;
+                const int i = tid * PW + NT * PW * k;
                 if (i < d) {
-                    float dyx[4], dvg[4];
+                    float dyx[PW], dvg[PW];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
+                    for (int e = 0; e < PW; ++e) {
                         const float xh = (xv[k][e] - mean) * rstd;
                         dvg[e] = L.gelu ? dv[k][e] * gelu_grad_for<T>(xh * s[k][e] + tt[k][e]) : dv[k][e];
                         const float dxh = dvg[e] * s[k][e];
@@ -696,19 +711,19 @@ __global__ __launch_bounds__(NT) void rownorm_bwd_wide_kernel(const NormBwdLaunc
                         xv[k][e] = xh;
                     }
                     if (dmod) {
-                        store4(dmod + i, dyx[0], dyx[1], dyx[2], dyx[3]);
-                        store4(dmod + d + i, dvg[0], dvg[1], dvg[2], dvg[3]);
+                        storep(dmod + i, dyx);
+                        storep(dmod + d + i, dvg);
                     }
                 }
             }
             row_stats(c1, c2);
 #pragma unroll
             for (int k = 0; k < KCH; ++k) {
-                const int i = tid * 4 + NT * 4 * k;
+                const int i = tid * PW + NT * PW * k;
                 if (i < d) {
-                    float o[4];
+                    float o[PW];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) o[e] = rstd * (dv[k][e] - c1 - xv[k][e] * c2);
+                    for (int e = 0; e < PW; ++e) o[e] = rstd * (dv[k][e] - c1 - xv[k][e] * c2);
                     emit(i, o);
                 }
             }
@@ -717,14 +732,14 @@ __global__ __launch_bounds__(NT) void rownorm_bwd_wide_kernel(const NormBwdLaunc
             // reads the row again (64 KB the first pass has just pulled into L2) and evaluates GELU' a second time instead of keeping dxhat / xhat
 #pragma unroll
             for (int k = 0; k < KCH; ++k) {
-                const int i = tid * 4 + NT * 4 * k;
+                const int i = tid * PW + NT * PW * k;
                 if (i < d) {
-                    float xv[4], dv[4], sv[4], tv[4], dyx[4], dvg[4];
-                    load4(x + i, xv);
-                    load4(dy + i, dv);
+                    float xv[PW], dv[PW], sv[PW], tv[PW], dyx[PW], dvg[PW];
+                    loadp(x + i, xv);
+                    loadp(dy + i, dv);
                     gain_shift(i, sv, tv);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
+                    for (int e = 0; e < PW; ++e) {
                         const float xh = (xv[e] - mean) * rstd;
                         dvg[e] = L.gelu ? dv[e] * gelu_grad_for<T>(xh * sv[e] + tv[e]) : dv[e];
                         const float dxh = dvg[e] * sv[e];
@@ -735,22 +750,22 @@ __global__ __launch_bounds__(NT) void rownorm_bwd_wide_kernel(const NormBwdLaunc
                         accb[k][e] += dvg[e];
                     }
                     if (dmod) {
-                        store4(dmod + i, dyx[0], dyx[1], dyx[2], dyx[3]);
-                        store4(dmod + d + i, dvg[0], dvg[1], dvg[2], dvg[3]);
+                        storep(dmod + i, dyx);
+                        storep(dmod + d + i, dvg);
                     }
                 }
             }
             row_stats(c1, c2);
 #pragma unroll
             for (int k = 0; k < KCH; ++k) {
-                const int i = tid * 4 + NT * 4 * k;
+                const int i = tid * PW + NT * PW * k;
                 if (i < d) {
-                    float xv[4], dv[4], sv[4], tv[4], o[4];
-                    load4(x + i, xv);
-                    load4(dy + i, dv);
+                    float xv[PW], dv[PW], sv[PW], tv[PW], o[PW];
+                    loadp(x + i, xv);
+                    loadp(dy + i, dv);
                     gain_shift(i, sv, tv);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
+                    for (int e = 0; e < PW; ++e) {
                         const float xh = (xv[e] - mean) * rstd;
                         const float dvg = L.gelu ? dv[e] * gelu_grad_for<T>(xh * sv[e] + tv[e]) : dv[e];
                         o[e] = rstd * (dvg * sv[e] - c1 - xh * c2);
@@ -764,14 +779,14 @@ __global__ __launch_bounds__(NT) void rownorm_bwd_wide_kernel(const NormBwdLaunc
     float* ws = L.ws != nullptr ? L.ws + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 2 * d : nullptr;
 #pragma unroll
     for (int k = 0; k < KCH; ++k) {
-        const int i = tid * 4 + NT * 4 * k;
+        const int i = tid * PW + NT * PW * k;
         if (i < d) {
             if (ws != nullptr) {
-                store4(ws + i, accg[k][0], accg[k][1], accg[k][2], accg[k][3]);
-                store4(ws + d + i, accb[k][0], accb[k][1], accb[k][2], accb[k][3]);
+                storep(ws + i, accg[k]);
+                storep(ws + d + i, accb[k]);
             } else {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
+                for (int e = 0; e < PW; ++e) {
                     if (G.dgamma) atomicAdd(G.dgamma + i + e, accg[k][e]);
                     if (G.dbeta) atomicAdd(G.dbeta + i + e, accb[k][e]);
                 }
@@ -811,6 +826,10 @@ extern "C" int sea_rownorm_bwd(const SeaNormBwdGroup* groups, int n_groups, int 
         if (d > 2048 && fit < 64) fit = 64;
         if (fit >= 64 && nblk > fit) nblk = fit;
     }
+    // pieces of 8 columns (16-byte accesses) where every row operand is bf16 and nothing is modulated: the MLP's LayerNorm + GELU
+    bool wide8 = wide && dtype == SEA_BF16 && dy_is_act && x_is_act && d % 8 == 0 && sea_tune("normbwd_wide8", 1) != 0;
+    for (int i = 0; i < n_groups && wide8; ++i)
+        wide8 = !groups[i].mod && !groups[i].dmod && !groups[i].dX32 && groups[i].lddy % 8 == 0 && groups[i].ldx % 8 == 0 && groups[i].lddxact % 8 == 0;
     const bool two_stage = ws != nullptr && ws_floats >= (int64_t)n_groups * nblk * 2 * d && nblk > 8;
     L.ws = two_stage ? ws : nullptr;
     const dim3 grid(nblk, n_groups), block(256);
@@ -827,10 +846,14 @@ extern "C" int sea_rownorm_bwd(const SeaNormBwdGroup* groups, int n_groups, int 
         if (d <= 256) LAUNCH_NBK(TT, DYA, XA, 1);      \
         else if (d <= 512) LAUNCH_NBK(TT, DYA, XA, 2); \
         else if (d <= 1024) LAUNCH_NBK(TT, DYA, XA, 4);\
-        else if (d <= 2048) rownorm_bwd_wide_kernel<TT, DYA, XA, 256, 2><<<grid, dim3(256), 0, s>>>(L);\
-        else if (d <= 4096) rownorm_bwd_wide_kernel<TT, DYA, XA, 512, 2><<<grid, dim3(512), 0, s>>>(L);\
-        else if (d <= 8192) rownorm_bwd_wide_kernel<TT, DYA, XA, 1024, 2><<<grid, dim3(1024), 0, s>>>(L);\
-        else rownorm_bwd_wide_kernel<TT, DYA, XA, 1024, 4><<<grid, dim3(1024), 0, s>>>(L);\
+        else if (wide8 && d <= 2048) rownorm_bwd_wide_kernel<TT, DYA, XA, 256, 1, 8><<<grid, dim3(256), 0, s>>>(L);\
+        else if (wide8 && d <= 4096) rownorm_bwd_wide_kernel<TT, DYA, XA, 512, 1, 8><<<grid, dim3(512), 0, s>>>(L);\
+        else if (wide8 && d <= 8192) rownorm_bwd_wide_kernel<TT, DYA, XA, 1024, 1, 8><<<grid, dim3(1024), 0, s>>>(L);\
+        else if (wide8) rownorm_bwd_wide_kernel<TT, DYA, XA, 1024, 2, 8><<<grid, dim3(1024), 0, s>>>(L);\
+        else if (d <= 2048) rownorm_bwd_wide_kernel<TT, DYA, XA, 256, 2, 4><<<grid, dim3(256), 0, s>>>(L);\
+        else if (d <= 4096) rownorm_bwd_wide_kernel<TT, DYA, XA, 512, 2, 4><<<grid, dim3(512), 0, s>>>(L);\
+        else if (d <= 8192) rownorm_bwd_wide_kernel<TT, DYA, XA, 1024, 2, 4><<<grid, dim3(1024), 0, s>>>(L);\
+        else rownorm_bwd_wide_kernel<TT, DYA, XA, 1024, 4, 4><<<grid, dim3(1024), 0, s>>>(L);\
     } while (0)
     if (dtype == SEA_BF16) {
         if (dy_is_act && x_is_act) LAUNCH_NB(__bf16, true, true);

@@ -258,6 +258,101 @@ __global__ __launch_bounds__(1024) void rownorm_fewrows_kernel(const NormLaunch 
     }
 }
 
+// MANY wide bf16 rows -> bf16 rows (the MLP's nn.LayerNorm(S) + GELU over the [M, S] hidden matrix: models/base_blocks.py:23-24; no modulation, no
+// addend): a workgroup of NT threads per row, a thread owns KCH pieces of 8 consecutive columns — ONE 16-byte load and ONE 16-byte store per piece (the
+// wave-per-row kernel above moves 8 bytes per lane per access and ran this pass at 3.3 TB/s) —, gain and shift of its columns stay in registers for all
+// its rows, and the NEXT row's pieces are requested before the current row's statistics (two barriers) and activations.  S = 2048 / 4096 / 8192 / 16384 on
+// 256 / 512 / 1024 / 1024 threads with 1 / 1 / 1 / 2 pieces per thread.
+template <int NT, int KCH, bool GELU>
+__global__ __launch_bounds__(NT) void ln_rows_bf16_kernel(const NormLaunch L) {
+    using T = __bf16;
+    constexpr int NW = NT / 64;
+    __shared__ float red[2][2][NW];   // [parity of the row][sum | sum of squares][wave]: two rows' statistics never share a slot
+    const SeaNormGroup& G = L.g[blockIdx.y];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, d = L.d;
+    const float inv_d = 1.0f / (float)d;
+    float gm[KCH][8], bt[KCH][8], xv[KCH][8], xn[KCH][8];
+#pragma unroll
+    for (int k = 0; k < KCH; ++k) {
+        const int i = tid * 8 + NT * 8 * k;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) gm[k][e] = bt[k][e] = xv[k][e] = xn[k][e] = 0.f;
+        if (i < d) {
+            load8(G.gamma + i, gm[k]);
+            if (G.beta != nullptr) load8(G.beta + i, bt[k]);
+        }
+    }
+    const T* X = static_cast<const T*>(G.X);
+    T* Y = static_cast<T*>(G.Yact);
+    int row = blockIdx.x;
+    if (row < L.M) {
+#pragma unroll
+        for (int k = 0; k < KCH; ++k) {
+            const int i = tid * 8 + NT * 8 * k;
+            if (i < d) load8(X + (int64_t)row * G.ldx + i, xv[k]);
+        }
+    }
+    int par = 0;
+    for (; row < L.M; row += gridDim.x, par ^= 1) {
+        const int nxt = row + gridDim.x;
+        if (nxt < L.M) {
+#pragma unroll
+            for (int k = 0; k < KCH; ++k) {
+                const int i = tid * 8 + NT * 8 * k;
+                if (i < d) load8(X + (int64_t)nxt * G.ldx + i, xn[k]);
+            }
+        }
+        float sum = 0.f;
+#pragma unroll
+        for (int k = 0; k < KCH; ++k)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) sum += xv[k][e];   // columns >= d hold zeros
+        sum = wave_sum(sum);
+        if (lane == 0) red[par][0][wave] = sum;
+        __syncthreads();
+        float tot = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) tot += red[par][0][w];
+        const float mean = tot * inv_d;
+        float sq = 0.f;
+#pragma unroll
+        for (int k = 0; k < KCH; ++k)
+            if (tid * 8 + NT * 8 * k < d) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float c = xv[k][e] - mean;
+                    sq += c * c;
+                }
+            }
+        sq = wave_sum(sq);
+        if (lane == 0) red[par][1][wave] = sq;
+        __syncthreads();
+        tot = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) tot += red[par][1][w];
+        const float rstd = 1.0f / sqrtf(tot * inv_d + L.eps);
+        if (tid == 0) {
+            if (G.mean != nullptr) G.mean[row] = mean;
+            if (G.rstd != nullptr) G.rstd[row] = rstd;
+        }
+#pragma unroll
+        for (int k = 0; k < KCH; ++k) {
+            const int i = tid * 8 + NT * 8 * k;
+            if (i < d) {
+                float o[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    o[e] = (xv[k][e] - mean) * rstd * gm[k][e] + bt[k][e];
+                    if (GELU) o[e] = gelu_for<T>(o[e]);
+                }
+                store8(Y + (int64_t)row * G.ldyact + i, o);
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) xv[k][e] = xn[k][e];
+        }
+    }
+}
+
 extern "C" int sea_rownorm(const SeaNormGroup* groups, int n_groups, int M, int d, int x_is_act, int gelu, float eps,
                            int dtype, void* stream) {
     SEA_REQUIRE(groups != nullptr && n_groups >= 1 && n_groups <= SEA_MAX_NORM_GROUPS, "sea_rownorm: n_groups=%d", n_groups);
@@ -299,6 +394,33 @@ extern "C" int sea_rownorm(const SeaNormGroup* groups, int n_groups, int M, int 
         }
         SEA_CHECK_LAUNCH("sea_rownorm");
         return SEA_OK;
+    }
+    {   // many wide bf16 -> bf16 rows without modulation / addend / f32 output (the MLP's LayerNorm + GELU pass): 16-byte pieces, a workgroup per row
+        bool wide = dtype == SEA_BF16 && x_is_act && d >= 1024 && d <= 16384 && d % 8 == 0 && M > 32 && sea_tune("ln_rows", 1) != 0;
+        for (int i = 0; i < n_groups && wide; ++i) {
+            const SeaNormGroup& G = groups[i];
+            wide = !G.mod && !G.addend && !G.Y32 && G.Yact && G.ldx % 8 == 0 && G.ldyact % 8 == 0;
+        }
+        if (wide) {
+            const int nt = d <= 2048 ? 256 : (d <= 4096 ? 512 : 1024);
+            const int per_cu = d <= 2048 ? 6 : (d <= 4096 ? 3 : 1);   // resident workgroups per CU
+            int nblk = (per_cu * 256 / n_groups) / 32 * 32;
+            nblk = nblk < 32 ? 32 : nblk;
+            nblk = nblk > M ? M : nblk;
+            const dim3 gridw(nblk, n_groups);
+#define LAUNCH_LNR(NTV, KCV)                                                                 \
+    do {                                                                                      \
+        if (gelu) ln_rows_bf16_kernel<NTV, KCV, true><<<gridw, dim3(NTV), 0, s>>>(L);         \
+        else ln_rows_bf16_kernel<NTV, KCV, false><<<gridw, dim3(NTV), 0, s>>>(L);             \
+    } while (0)
+            if (nt == 256) LAUNCH_LNR(256, 1);
+            else if (nt == 512) LAUNCH_LNR(512, 1);
+            else if (d <= 8192) LAUNCH_LNR(1024, 1);
+            else LAUNCH_LNR(1024, 2);
+#undef LAUNCH_LNR
+            SEA_CHECK_LAUNCH("sea_rownorm");
+            return SEA_OK;
+        }
     }
 #define LAUNCH_RN(TT, XA)                                                     \
     do {                                                                       \

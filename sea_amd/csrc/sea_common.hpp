@@ -263,6 +263,23 @@ __device__ __forceinline__ void load4(const __bf16* src, float (&o)[4]) {
     o[0] = (float)v[0]; o[1] = (float)v[1]; o[2] = (float)v[2]; o[3] = (float)v[3];
 }
 
+// 8 consecutive elements (16 bytes of bf16: one full-width access per lane; 2 x 16 bytes of f32)
+__device__ __forceinline__ void load8(const __bf16* src, float (&o)[8]) {
+    const bf16x8 v = *reinterpret_cast<const bf16x8*>(src);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (float)v[e];
+}
+__device__ __forceinline__ void load8(const float* src, float (&o)[8]) {
+    const float4 a = *reinterpret_cast<const float4*>(src), b = *reinterpret_cast<const float4*>(src + 4);
+    o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w;
+}
+__device__ __forceinline__ void store8(__bf16* dst, const float (&v)[8]) {
+    bf16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (__bf16)v[e];
+    *reinterpret_cast<bf16x8*>(dst) = o;
+}
+
 // Workgroups are dealt round-robin over the 8 XCDs (blocks b and b + 8 share an L2).  Kernels that number their tiles so that consecutive
 // tiles re-read the same operand panel give each XCD a CONTIGUOUS range of tile numbers, so that those re-reads hit its own L2 instead of
 // crossing the fabric once per XCD (bijective form of the T1 remap, cdna_hip_programming.md; only placement, never correctness).
