@@ -61,13 +61,13 @@ def record_work(rec, esz):
     L = N.lib()
     fl = by = 0
     a = rec.args
-    if rec.fn is L.sea_gemm_grouped:
-        for g in a[0][:a[1]]:
+    if rec.fn is L.sea_gemm_grouped or rec.fn is L.sea_gemm_fewrows:
+        for g in a[0][:(a[1] if rec.fn is L.sea_gemm_grouped else a[2])]:
             fl += 2 * g.M * g.N * g.K * g.n_seg
             by += (0 if g.silu_c else g.M * g.K * g.n_seg * esz) + g.N * g.K * esz + (g.M * g.N * 4 if g.C32 else 0) + (g.M * g.N * esz if g.Cact else 0) \
                 + (g.M * g.N * 4 if g.R else 0) + (g.M * g.N * esz if g.Z else 0)
-    elif rec.fn is L.sea_qkv_rope_grouped:
-        for g in a[0][:a[1]]:
+    elif rec.fn is L.sea_qkv_rope_grouped or rec.fn is L.sea_qkv_rope_fewrows:
+        for g in a[0][:(a[1] if rec.fn is L.sea_qkv_rope_grouped else a[2])]:
             fl += 2 * g.M * g.N * g.K
             by += g.M * g.K * esz + g.N * g.K * esz + g.M * g.N * esz
     elif rec.fn is L.sea_gemm_rownorm:

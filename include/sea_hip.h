@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define SEA_ABI_VERSION 5
+#define SEA_ABI_VERSION 6
 
 enum { SEA_F32 = 0, SEA_BF16 = 1 };
 
@@ -196,6 +196,20 @@ typedef struct {
 
 int sea_rownorm(const SeaNormGroup* groups, int n_groups, int M, int d, int x_is_act, int gelu, float eps,
                 int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * The Linear layers of a KV-cache rollout STEP (utils/train_utils.py:202-209 with per-layer K/V caches: one row per trajectory and field) at the shipped
+ * widths (configs/cylinder_flow.py embed_dim 1024, configs/multiphase_flow.py 2048), where a step's time is its launch count:
+ * sea_gemm_grouped / sea_qkv_rope_grouped for M <= 4 rows per group with the row norm in front of the layer folded into the launch.
+ *   groups  as sea_gemm_grouped (n_seg = 1, act 0 / 1, no dropout, no generated operand) / sea_qkv_rope_grouped; bf16; every group of a launch has the
+ *           same K, one of 512, 1024, 2048 (4096, 8192, 16384 too for sea_gemm_fewrows); n_groups <= 8
+ *   pre     NULL, or [n_groups]: pre[g].X != NULL makes the A operand of group g  sea_rownorm(pre[g])  of fp32 rows [M, K] (gamma, beta, mod, addend as
+ *           SeaNormGroup; K <= 2048), evaluated by every workgroup for itself — groups[g].A is ignored.  Xout (x + addend, fp32) is written once and must
+ *           NOT alias X; Y32 / Yact / mean / rstd must be NULL.  (LayerNorm / AdaLN in front of q/k/v, cross-attention and the MLP: models/temporal.py:126-131,
+ *           139-145, 170-186; models/base_blocks.py:345-350.)
+ * Arithmetic: products of bf16 operands accumulated in fp32 (v_dot2c_f32_bf16), norms in fp32 two-pass form exactly as sea_rownorm. */
+int sea_gemm_fewrows(const SeaGemmGroup* groups, const SeaNormGroup* pre, int n_groups, float eps, int dtype, void* stream);
+int sea_qkv_rope_fewrows(const SeaQkvGroup* groups, const SeaNormGroup* pre, int n_groups, const SeaQkvCommon* common, float eps, int dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Linear layer whose output rows are normalised in the same launch (a workgroup tile spans the whole output row, N <= 256):
@@ -547,9 +561,11 @@ int sea_ib_bwd(const SeaIbBwdParams* params, void* stream);
  *     SEA_OP_GEMM_NORM p0 = SeaGemmNormGroup[n], f0 = eps          SEA_OP_XTAIL  p0 = SeaExchangeTail[n], f0 = eps
  *     SEA_OP_MLP1   p0 = SeaMlpGroup[n], f0 = eps
  *     SEA_OP_MLP2   p0 = SeaMlp2Group[n], f0 = eps
+ *     SEA_OP_GEMM_FEW p0 = SeaGemmGroup[n], p1 = pre or NULL, f0 = eps
+ *     SEA_OP_QKV_FEW  p0 = SeaQkvGroup[n], p1 = SeaQkvCommon, l0 = (intptr) pre or 0, f0 = eps
  * Returns 0, or the failing entry's error code with sea_last_error() set (entries before it have been launched).
  */
-enum { SEA_OP_GEMM = 1, SEA_OP_QKV = 2, SEA_OP_ATTN = 3, SEA_OP_NORM = 4, SEA_OP_SILU = 5, SEA_OP_IB = 6, SEA_OP_CONVERT = 8, SEA_OP_GEMM_NORM = 9, SEA_OP_XTAIL = 10, SEA_OP_MLP1 = 11, SEA_OP_MLP2 = 13 };   /* 7 and 12 were round-1 entry points (sea_rowchain, sea_cond_mlp), removed in ABI v2 */
+enum { SEA_OP_GEMM = 1, SEA_OP_QKV = 2, SEA_OP_ATTN = 3, SEA_OP_NORM = 4, SEA_OP_SILU = 5, SEA_OP_IB = 6, SEA_OP_CONVERT = 8, SEA_OP_GEMM_NORM = 9, SEA_OP_XTAIL = 10, SEA_OP_MLP1 = 11, SEA_OP_MLP2 = 13, SEA_OP_GEMM_FEW = 14, SEA_OP_QKV_FEW = 15 };   /* 7 and 12 were round-1 entry points (sea_rowchain, sea_cond_mlp), removed in ABI v2 */
 typedef struct {
     int32_t op, n, dtype, i0, i1, i2, i3;
     float f0;

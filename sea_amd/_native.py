@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libsea_hip.so")
 
 SEA_F32, SEA_BF16 = 0, 1
-ABI_VERSION = 5   # include/sea_hip.h SEA_ABI_VERSION
+ABI_VERSION = 6   # include/sea_hip.h SEA_ABI_VERSION
 MAX_GROUPS = 16
 MAX_ATTN_PROBLEMS = 8
 MAX_NORM_GROUPS = 16
@@ -107,7 +107,9 @@ class SeaAttnBwdParams(C.Structure):
                 ("ldo", _i32), ("lddo", _i32), ("lddq", _i32), ("lddk", _i32), ("lddv", _i32), ("q_scale", _f32), ("drop", SeaDropout)]
 
 
-OP_GEMM, OP_QKV, OP_ATTN, OP_NORM, OP_SILU, OP_IB, OP_CONVERT, OP_GEMM_NORM, OP_XTAIL, OP_MLP1, OP_MLP2 = 1, 2, 3, 4, 5, 6, 8, 9, 10, 11, 13
+OP_GEMM, OP_QKV, OP_ATTN, OP_NORM, OP_SILU, OP_IB, OP_CONVERT, OP_GEMM_NORM, OP_XTAIL, OP_MLP1, OP_MLP2, OP_GEMM_FEW, OP_QKV_FEW = 1, 2, 3, 4, 5, 6, 8, 9, 10, 11, 13, 14, 15
+FEW_MAX_GROUPS = 8     # sea_gemm_fewrows / sea_qkv_rope_fewrows (gemv.hip)
+FEW_K = (512, 1024, 2048, 4096, 8192, 16384)
 
 
 class SeaLaunchRec(C.Structure):
@@ -223,6 +225,10 @@ def lib() -> C.CDLL:
     L.sea_qkv_rope_grouped.argtypes = [C.POINTER(SeaQkvGroup), C.c_int, C.POINTER(SeaQkvCommon), C.c_int, _vp]
     L.sea_attention_fwd.argtypes = [C.POINTER(SeaAttnParams), C.c_int, _vp]
     L.sea_rownorm.argtypes = [C.POINTER(SeaNormGroup), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, _vp]
+    L.sea_gemm_fewrows.argtypes = [C.POINTER(SeaGemmGroup), C.POINTER(SeaNormGroup), C.c_int, C.c_float, C.c_int, _vp]
+    L.sea_gemm_fewrows.restype = C.c_int
+    L.sea_qkv_rope_fewrows.argtypes = [C.POINTER(SeaQkvGroup), C.POINTER(SeaNormGroup), C.c_int, C.POINTER(SeaQkvCommon), C.c_float, C.c_int, _vp]
+    L.sea_qkv_rope_fewrows.restype = C.c_int
     L.sea_silu_outer.argtypes = [C.POINTER(SeaSiluGroup), C.c_int, _vp, C.c_int, C.c_int, _vp]
     L.sea_ib_add.argtypes = [C.POINTER(SeaIbParams), _vp]
     L.sea_convert_f32_to_act.argtypes = [_vp, _i64, _vp, _i64, _i64, _i64, C.c_int, _vp]
@@ -285,6 +291,7 @@ EXPORTED_SYMBOLS = (
     "sea_mse_fwd_bwd", "sea_relative_mse", "sea_adamw_flat",
     "sea_wgrad_grouped", "sea_transpose_weights", "sea_rownorm_bwd", "sea_silu_outer_bwd", "sea_ib_bwd",
     "sea_attention_bwd", "sea_dropout_mask", "sea_run_list", "sea_run_list_steps", "sea_unpatchify", "sea_gemm_rownorm", "sea_exchange_tail", "sea_patchify", "sea_silu_outer_ib", "sea_mlp_fc1_ln_gelu", "sea_mlp_fc2_proj_norm", "sea_kv_rollout", "sea_kv_arena_words", "sea_kv_debug_stamps",
+    "sea_gemm_fewrows", "sea_qkv_rope_fewrows",
 )
 
 

@@ -8,7 +8,8 @@
                                            norm=0                Linear + row norm as two launches  xtail=0            a field's exchange tail as three launches
                                            xtail_max_rows=N      ... from N rows up                  fold_ib=0          the info-bottleneck add as a launch of its own
                                            silu=0|1              generated GEMM operand off / on    mlp1 / mlpnorm / mlp2=0|1   the fused MLP halves off / forced
-  SEA_KV          key=value,...          KV-cache rollout: fast=0 (generic step plan), hoist=0 (condition work per step), loop=python (step loop in Python),
+  SEA_KV          key=value,...          KV-cache rollout: fast=0 (generic step plan), hoist=0 (condition work per step), gemv=0 (step plan without the few-row launches of gemv.hip),
+                                           loop=python (step loop in Python),
                                            force_err=1 (test hook: the persistent launch "reports" a hand-off that gave up)
   SEA_TUNE        key=value,...          native tuning aids read by libsea_hip.so (sea_tune() in core.hip): kv_persist, kv_pre, gemm_norm_rows, gemm_tile, attn_split4, ...
   SEA_EXTRA_FLAGS "..."                  extra hipcc flags for `python -m sea_amd.build` (A/B builds)

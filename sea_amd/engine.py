@@ -358,6 +358,57 @@ class Plan:
                     self._out_patches.append((g, "Y32", gd["Y_is_out"]))
             self._cur.append(self._rec(L.sea_rownorm, [arr, len(chunk), self.M, d, int(x_is_act), int(gelu), 1e-5, self.code], name, arr))
 
+    def _norm_specs(self, specs, n: int):
+        """SeaNormGroup array of the `pre` specs of a few-row launch (None entries: no norm for that group), with the bind-time patches of _norm."""
+        if specs is None or all(sp is None for sp in specs):
+            return None
+        arr = (N.SeaNormGroup * n)()
+        for g, sp in zip(arr, specs):
+            if sp is None:
+                continue
+            ops.fill_norm_group(g, sp)
+            if sp.get("X_is_x") is not None:
+                self._x_patches.append((g, "X", sp["X_is_x"]))
+        return arr
+
+    def _gemm_few(self, groups: List[dict], name: str, pre=None) -> None:
+        """sea_gemm_fewrows (step plans at the shipped widths): group dicts as _gemm; pre[i]: the _norm group dict (or None) of the row norm in front of the layer.
+        Groups with pre[i] carry no A."""
+        L = N.lib()
+        n = len(groups)
+        assert n <= N.FEW_MAX_GROUPS
+        arr = (N.SeaGemmGroup * n)()
+        for g, d in zip(arr, groups):
+            d = dict(d)
+            if d.get("A") is None:
+                d["A"] = d["W"]   # shapes only; the operand comes from pre[i]
+                _fill_gemm(g, **d)
+                g.A, g.lda, g.M = None, 0, self.M
+            else:
+                _fill_gemm(g, **d)
+            if d.get("R_is_x") is not None:
+                self._x_patches.append((g, "R", d["R_is_x"]))
+        pa = self._norm_specs(pre, n)
+        self._cur.append(self._rec(L.sea_gemm_fewrows, [arr, pa, n, 1e-5, self.code], name, (arr, pa)))
+
+    def _qkv_few(self, groups: List[dict], rope: torch.Tensor, hd: int, name: str, pre=None) -> None:
+        """sea_qkv_rope_fewrows: group dicts as _qkv; pre[i]: the _norm group dict of the row norm in front of the projection (or None)."""
+        L = N.lib()
+        n = len(groups)
+        assert n <= N.FEW_MAX_GROUPS
+        arr = (N.SeaQkvGroup * n)()
+        for g, d in zip(arr, groups):
+            A, W = d.get("A"), d["W"]
+            g.A, g.lda = (A.data_ptr(), A.stride(0)) if A is not None else (None, 0)
+            g.W, g.bias = W.data_ptr(), d["bias"].data_ptr()
+            g.Qout, g.Kout, g.Vtout, g.Vout = N.ptr(d.get("Q")), N.ptr(d.get("K")), N.ptr(d.get("Vt")), N.ptr(d.get("V"))
+            g.ldw = W.stride(0)
+            g.M, g.N, g.K, g.col0 = self.M, W.shape[0], W.shape[1], d["col0"]
+        pa = self._norm_specs(pre, n)
+        common = N.SeaQkvCommon(rope.data_ptr(), self.H, hd, self.T, self.pos0, self.cap, ops.q_scale(hd))
+        self._pos_structs.append(common)
+        self._cur.append(self._rec(L.sea_qkv_rope_fewrows, [arr, pa, n, C.byref(common), 1e-5, self.code], name, (arr, pa, common)))
+
     def _gemm_norm(self, groups: List[dict], name: str) -> None:
         """Linear + row normalisation in one launch (sea_gemm_rownorm): group dicts as _gemm (A, W, bias) plus the _norm keys
         (mod, gamma, beta, Yact, Y32/ldy32/Y_is_out)."""
@@ -542,6 +593,12 @@ class Plan:
         rope_s, rope_c = eng.rope_self, eng.rope_cross
         Eo, concat = self.Eo, self.concat
         FE = F * Eo                                             # row stride of the caller's [B, T, F, Eo] tensors
+        # KV-cache step at the shipped widths (one row per trajectory and field, embed_dim 1024 / 2048): the Linear layers as sea_gemm_fewrows /
+        # sea_qkv_rope_fewrows launches with the row norms in front of them folded in (gemv.hip) — 18 launches instead of 22.  SEA_KV=gemv=0 keeps the generic launches.
+        few = self._few = (type(self) is Plan and self.mode == "step" and T == 1 and xmode == "sea" and not concat and not ib_attn
+                           and _switches.kv("gemv", "1") != "0" and 2 * (F - 1) <= N.FEW_MAX_GROUPS and F <= N.FEW_MAX_GROUPS
+                           and ops.fewrows_supported(dt, M, [E], qkv=True, pre=True) and ops.fewrows_supported(dt, M, [S])
+                           and (F == 1 or ops.fewrows_supported(dt, M, [D], qkv=True, pre=True)))
         xr = [self._buf(M, E, dtype=f32) for _ in range(F)]     # fp32 residual stream
         xa = [self._buf(M, E) for _ in range(F)]                # act-dtype copy (GEMM A operand)
         n_e = [self._buf(M, E) for _ in range(F)]               # normalised rows, dim E
@@ -593,15 +650,19 @@ class Plan:
             # -- self attention: x_i += proj(attn(AdaLN_0(x_i)))
             groups = []
             for i in range(F):
-                g = dict(Yact=n_e[i], **norm_params(f"{pre}ln.exp.{i}.0.", E))
+                g = dict(**norm_params(f"{pre}ln.exp.{i}.0.", E)) if few else dict(Yact=n_e[i], **norm_params(f"{pre}ln.exp.{i}.0.", E))
                 if first:
                     g.update(X=xr[i], ldx=FE, X_is_x=i * Eo * 4)
                 else:
                     g.update(X=xr[i])
                 groups.append(g)
-            self._norm(groups, E, "self.adaln0")
-            self._qkv([dict(A=n_e[i], W=P.act(f"{pre}attn.self.{i}.q.weight", 3 * E), bias=P.f32_vec(f"{pre}attn.self.{i}.q.bias", 3 * E),
-                            col0=0, Q=Qs[i], K=Ks[l][i], Vt=Vs[l][i]) for i in range(F)], rope_s, hd_s, "self.qkv_rope")
+            if few:   # AdaLN_0 / LayerNorm as the prologue of the projection
+                self._qkv_few([dict(W=P.act(f"{pre}attn.self.{i}.q.weight", 3 * E), bias=P.f32_vec(f"{pre}attn.self.{i}.q.bias", 3 * E),
+                                    col0=0, Q=Qs[i], K=Ks[l][i], Vt=Vs[l][i]) for i in range(F)], rope_s, hd_s, "self.qkv_rope", pre=groups)
+            else:
+                self._norm(groups, E, "self.adaln0")
+                self._qkv([dict(A=n_e[i], W=P.act(f"{pre}attn.self.{i}.q.weight", 3 * E), bias=P.f32_vec(f"{pre}attn.self.{i}.q.bias", 3 * E),
+                                col0=0, Q=Qs[i], K=Ks[l][i], Vt=Vs[l][i]) for i in range(F)], rope_s, hd_s, "self.qkv_rope")
             self._attn([dict(Q=Qs[i], K=Ks[l][i], Vt=Vs[l][i], O=att_e[i]) for i in range(F)], hd_s, E, "self.attention")
             groups = []
             for i in range(F):
@@ -611,7 +672,7 @@ class Plan:
                 else:
                     g.update(R=xr[i])
                 groups.append(g)
-            self._gemm(groups, "self.out_proj")
+            (self._gemm_few if few else self._gemm)(groups, "self.out_proj")
             first = False
             if not cond_joined:  # everything below reads modulations computed on lane 1
                 self._join(1)
@@ -668,7 +729,30 @@ class Plan:
                 self._gemm([dict(A=sg[i], W=P.act(f"{pre}cross_up.{i}.weight"), bias=P.f32_vec(f"{pre}cross_up.{i}.bias"), R=xr[i], C32=xr[i])
                             for i in range(F)], "pool.up")
             # -- state exchange (Gauss-Seidel over i, models/temporal.py:187-192)
-            if F > 1 and xmode == "sea":
+            if F > 1 and xmode == "sea" and few:
+                # the same Gauss-Seidel sweep with ln_cross evaluated by its consumers: dn[j] holds cross_down_j(x_j) of the CURRENT x_j (rewritten by down_new once
+                # field j has been updated), every q / k,v projection normalises the rows it reads itself
+                self._gemm_few([dict(A=xa[j], W=P.act(f"{pre}cross_down.{j}.weight"), bias=P.f32_vec(f"{pre}cross_down.{j}.bias"), C32=dn[j]) for j in range(F)], "cross.down_old")
+                for i in range(F):
+                    others = [j for j in range(F) if j != i]
+                    qkv_groups, qkv_pre, probs, proj_groups = [], [], [], []
+                    for s, j in enumerate(others):
+                        ca = f"{pre}cross_attn.{i}.{j}."
+                        qkv_groups.append(dict(W=P.act(ca + "q.weight"), bias=P.f32_vec(ca + "q.bias"), col0=0, Q=Qc[s]))
+                        qkv_pre.append(dict(X=dn[i], **norm_params(f"{pre}ln_cross.{i}.", D)))
+                        qkv_groups.append(dict(W=P.act(ca + "k.weight", 2 * D), bias=P.f32_vec(ca + "k.bias", 2 * D), col0=D, K=Kc[l][i][j], Vt=Vc[l][i][j]))
+                        qkv_pre.append(dict(X=dn[j], **norm_params(f"{pre}ln_cross.{j}.", D)))
+                        probs.append(dict(Q=Qc[s], K=Kc[l][i][j], Vt=Vc[l][i][j], O=att_c[s]))
+                        proj_groups.append(dict(A=att_c[s], W=P.act(ca + "projection.weight"), Cact=gp[s], act=1))
+                    self._qkv_few(qkv_groups, rope_c, hd_c, f"cross{i}.qkv_rope", pre=qkv_pre)
+                    self._attn(probs, hd_c, D, f"cross{i}.attention")
+                    self._gemm_few(proj_groups, f"cross{i}.proj_gelu")
+                    up = dict(A=gp[0], W=P.act(f"{pre}cross_up.{i}.weight"), bias=P.f32_vec(f"{pre}cross_up.{i}.bias"),
+                              bias_scale=float(F - 1), n_seg=F - 1, a_seg_stride=M * D, R=xr[i], C32=xr[i], Cact=(xa[i] if i < F - 1 else None))
+                    (self._gemm_few if F == 2 else self._gemm)([up], f"cross{i}.up_sum")   # (F > 2: the sum over the F - 1 projections needs sea_gemm_grouped's segments)
+                    if i < F - 1:
+                        self._gemm_few([dict(A=xa[i], W=P.act(f"{pre}cross_down.{i}.weight"), bias=P.f32_vec(f"{pre}cross_down.{i}.bias"), C32=dn[i])], f"cross{i}.down_new")
+            elif F > 1 and xmode == "sea":
                 if fuse_norm and D <= 256 and D % 16 == 0:
                     self._gemm_norm([dict(A=xa[j], W=P.act(f"{pre}cross_down.{j}.weight"), bias=P.f32_vec(f"{pre}cross_down.{j}.bias"), Yact=nd_old[j],
                                           **norm_params(f"{pre}ln_cross.{j}.", D)) for j in range(F)], "cross.down_norm_old")
@@ -729,9 +813,9 @@ class Plan:
                 self._ib(pre, xr)
             if eng.model.add_info_after_cross and ib_attn:
                 self._ib_attn(pre, xr)
-            self._mlp_proj(pre, list(range(F)), xr, xa, n_e, hbuf, hg, mods, last, addend=(ibufs[l] if fold_ib else None))
+            self._mlp_proj(pre, list(range(F)), xr, xa, n_e, hbuf, hg, mods, last, addend=(ibufs[l] if fold_ib else None), few=few)
 
-    def _mlp_proj(self, pre, fields, xr, xm, n_e, hbuf, hg, mods, final_norm, tag="", addend=None) -> bool:
+    def _mlp_proj(self, pre, fields, xr, xm, n_e, hbuf, hg, mods, final_norm, tag="", addend=None, few=False) -> bool:
         """x_i += W2 gelu(LN(W1 AdaLN_2(x_i))) ; x_i = proj_i(x_i) for the listed fields (models/temporal.py:143-146), optionally followed
         by the model's final per-field norm written straight into out (models/temporal.py:412-415)."""
         P, E, S, Eo, FE = self.eng.params, self.E, self.S, self.Eo, self.F * self.Eo
@@ -742,6 +826,21 @@ class Plan:
                 return dict(mod=mods[p_], gamma=P.f32_vec(p_ + "weight"), beta=P.f32_vec(p_ + "bias"))
             return dict(gamma=P.f32_vec(p_ + "weight"))
 
+        if few:
+            # KV-cache step at the shipped widths: [ib add + AdaLN_2 / LayerNorm] fc1 | LayerNorm + GELU | fc2 + residual | proj | final norm.
+            # x + ib goes to rows of its own (xq): the prologue runs in every workgroup of fc1, so it must not update the rows it reads
+            xq = [self._buf(self.M, E, dtype=torch.float32) for _ in fields] if addend is not None else None
+            res = xq if addend is not None else [xr[i] for i in fields]
+            pre_n = [dict(X=xr[i], **(dict(addend=addend, Xout=xq[k]) if addend is not None else {}), **norm_params(f"{pre}ln.exp.{i}.2.", E)) for k, i in enumerate(fields)]
+            self._gemm_few([dict(W=P.act(f"{pre}mlp.{i}.layers.0.weight"), bias=P.f32_vec(f"{pre}mlp.{i}.layers.0.bias"), Cact=hbuf[i]) for i in fields], "mlp.fc1" + tag, pre=pre_n)
+            self._norm([dict(X=hbuf[i], gamma=P.f32_vec(f"{pre}mlp.{i}.layers.1.weight"), beta=P.f32_vec(f"{pre}mlp.{i}.layers.1.bias"), Yact=hg[i])
+                        for i in fields], S, "mlp.ln_gelu" + tag, x_is_act=True, gelu=True)
+            self._gemm_few([dict(A=hg[i], W=P.act(f"{pre}mlp.{i}.layers.3.weight"), bias=P.f32_vec(f"{pre}mlp.{i}.layers.3.bias"), R=res[k], Cact=xm[i])
+                            for k, i in enumerate(fields)], "mlp.fc2" + tag)
+            self._gemm_few([dict(A=xm[i], W=P.act(f"{pre}proj.{i}.weight"), bias=P.f32_vec(f"{pre}proj.{i}.bias"), C32=xo[i]) for i in fields], "proj" + tag)
+            if final_norm:
+                self._norm([dict(X=xo[i], Y32=xo[i], ldy32=FE, Y_is_out=i * Eo * 4, **norm_params(f"ln.{i}.", Eo)) for i in fields], Eo, "final.norm" + tag)
+            return final_norm
         # Linear + nn.LayerNorm + GELU in one launch where the kernel is instantiated (bf16; SEA_PLAN=mlp1=0 keeps the two launches, =1 forces
         # the one launch).  Every workgroup of that kernel streams the whole of W1, so it needs enough 32-row tiles to pay: with the few rows
         # of a KV-cache step the two launches are faster (0.143 vs 0.163 ms per step at cfg2), hence the row threshold.
@@ -1020,6 +1119,12 @@ class Plan:
                 c.op, c.p0, c.n, c.dtype = N.OP_GEMM, addr(a[0]), a[1], a[2]
             elif r.fn is L.sea_qkv_rope_grouped:
                 c.op, c.p0, c.n, c.p1, c.dtype = N.OP_QKV, addr(a[0]), a[1], addr(r.keep[1]), a[3]
+            elif r.fn is L.sea_gemm_fewrows:
+                c.op, c.p0, c.n, c.f0, c.dtype = N.OP_GEMM_FEW, addr(a[0]), a[2], a[3], a[4]
+                c.p1 = addr(a[1]) if a[1] is not None else None
+            elif r.fn is L.sea_qkv_rope_fewrows:
+                c.op, c.p0, c.n, c.p1, c.f0, c.dtype = N.OP_QKV_FEW, addr(a[0]), a[2], addr(r.keep[2]), a[4], a[5]
+                c.l0 = addr(a[1]) if a[1] is not None else 0
             elif r.fn is L.sea_attention_fwd:
                 c.op, c.p0, c.dtype = N.OP_ATTN, addr(r.keep), a[1]
             elif r.fn is L.sea_mlp_fc1_ln_gelu:

@@ -130,6 +130,22 @@ def attention_fwd(problems: Sequence[Dict], B: int, H: int, hd: int, Tq: int, Tk
     N.check(N.lib().sea_attention_fwd(C.byref(P), N.dtype_code(dtype), N.stream_ptr()), "sea_attention_fwd")
 
 
+def fill_norm_group(g: N.SeaNormGroup, gd: Dict) -> None:
+    """gd: X, optional mod act [M, 2d], gamma f32 [d], optional beta f32 [d], Y32 and/or Yact, optional mean / rstd f32 [M], addend / Xout (include/sea_hip.h, SeaNormGroup)."""
+    X = gd["X"]
+    g.X, g.ldx = X.data_ptr(), gd.get("ldx", X.stride(0) if X.dim() == 2 else 0)
+    mod = gd.get("mod")
+    g.mod, g.ldmod = N.ptr(mod), (mod.stride(0) if mod is not None else 0)
+    g.gamma, g.beta = gd["gamma"].data_ptr(), N.ptr(gd.get("beta"))
+    y32, yact = gd.get("Y32"), gd.get("Yact")
+    g.Y32, g.ldy32 = N.ptr(y32), gd.get("ldy32", y32.stride(0) if y32 is not None else 0)
+    g.Yact, g.ldyact = N.ptr(yact), (yact.stride(0) if yact is not None else 0)
+    g.mean, g.rstd = N.ptr(gd.get("mean")), N.ptr(gd.get("rstd"))
+    add, xout = gd.get("addend"), gd.get("Xout")
+    g.addend, g.ldadd = N.ptr(add), (add.stride(0) if add is not None else 0)
+    g.Xout, g.ldxout = N.ptr(xout), (xout.stride(0) if xout is not None else 0)
+
+
 def rownorm(groups: Sequence[Dict], M: int, d: int, x_is_act: bool, gelu: bool, eps: float, dtype: torch.dtype) -> None:
     """groups: dicts with X [M,d], optional mod act [M,2d], gamma f32 [d], optional beta f32 [d], Y32 and/or Yact,
     optional mean/rstd f32 [M]."""
@@ -138,19 +154,60 @@ def rownorm(groups: Sequence[Dict], M: int, d: int, x_is_act: bool, gelu: bool, 
     for i, gd in enumerate(groups):
         X = _mat(gd["X"], "X")
         assert X.dtype == (dtype if x_is_act else torch.float32)
-        g = arr[i]
-        g.X, g.ldx = X.data_ptr(), X.stride(0)
-        mod = gd.get("mod")
-        g.mod, g.ldmod = N.ptr(mod), (mod.stride(0) if mod is not None else 0)
-        g.gamma, g.beta = gd["gamma"].data_ptr(), N.ptr(gd.get("beta"))
-        y32, yact = gd.get("Y32"), gd.get("Yact")
-        g.Y32, g.ldy32 = N.ptr(y32), (y32.stride(0) if y32 is not None else 0)
-        g.Yact, g.ldyact = N.ptr(yact), (yact.stride(0) if yact is not None else 0)
-        g.mean, g.rstd = N.ptr(gd.get("mean")), N.ptr(gd.get("rstd"))
-        add, xout = gd.get("addend"), gd.get("Xout")
-        g.addend, g.ldadd = N.ptr(add), (add.stride(0) if add is not None else 0)
-        g.Xout, g.ldxout = N.ptr(xout), (xout.stride(0) if xout is not None else 0)
+        fill_norm_group(arr[i], gd)
     N.check(N.lib().sea_rownorm(arr, n, M, d, int(x_is_act), int(gelu), eps, N.dtype_code(dtype), N.stream_ptr()), "sea_rownorm")
+
+
+def fewrows_supported(dtype: torch.dtype, M: int, Ks: Sequence[int], qkv: bool = False, pre: bool = False) -> bool:
+    """Do sea_gemm_fewrows / sea_qkv_rope_fewrows (gemv.hip) cover a launch of these groups?  bf16, M <= 4 rows per group, one K per launch out of N.FEW_K
+    (<= 2048 for the q/k/v form and for a norm prologue)."""
+    Ks = list(Ks)
+    return (dtype == torch.bfloat16 and 1 <= M <= 4 and 1 <= len(Ks) <= N.FEW_MAX_GROUPS and all(k == Ks[0] for k in Ks) and Ks[0] in N.FEW_K
+            and (Ks[0] <= 2048 or not (qkv or pre)))
+
+
+def _norm_array(specs: Optional[Sequence[Optional[Dict]]], n: int):
+    if specs is None or all(sp is None for sp in specs):
+        return None
+    arr = (N.SeaNormGroup * n)()
+    for g, sp in zip(arr, specs):
+        if sp is not None:
+            fill_norm_group(g, sp)
+    return arr
+
+
+def gemm_fewrows(groups: Sequence[Dict], dtype: torch.dtype, pre=None, eps: float = 1e-5) -> None:
+    """sea_gemm_fewrows: groups as gemm_grouped (A may be None where pre[i] is given); pre: list of rownorm group dicts or None per group."""
+    n = len(groups)
+    arr = (N.SeaGemmGroup * n)()
+    for i, d in enumerate(groups):
+        W = _mat(d["W"], "W")
+        A = d.get("A")
+        if A is None:
+            X = pre[i]["X"]
+            fill_gemm_group(arr[i], W, W, d.get("bias"), d.get("R"), d.get("C32"), d.get("Cact"), act=d.get("act", 0), bias_scale=d.get("bias_scale", 1.0), M=X.shape[0], Z=d.get("Z"))
+            arr[i].A, arr[i].lda = None, 0
+        else:
+            fill_gemm_group(arr[i], _mat(A, "A"), W, d.get("bias"), d.get("R"), d.get("C32"), d.get("Cact"), act=d.get("act", 0), bias_scale=d.get("bias_scale", 1.0), Z=d.get("Z"))
+    N.check(N.lib().sea_gemm_fewrows(arr, _norm_array(pre, n), n, eps, N.dtype_code(dtype), N.stream_ptr()), "sea_gemm_fewrows")
+
+
+def qkv_rope_fewrows(groups: Sequence[Dict], rope: torch.Tensor, H: int, hd: int, T: int, pos0: int, cap: int, q_scale: float, dtype: torch.dtype, pre=None,
+                     eps: float = 1e-5) -> None:
+    """sea_qkv_rope_fewrows: groups as qkv_rope_grouped (A may be None where pre[i] is given, then 'M' gives the rows)."""
+    n = len(groups)
+    arr = (N.SeaQkvGroup * n)()
+    for i, d in enumerate(groups):
+        W = _mat(d["W"], "W")
+        g = arr[i]
+        A = d.get("A")
+        g.A, g.lda = (N.ptr(A), A.stride(0)) if A is not None else (None, 0)
+        g.W, g.bias, g.ldw = W.data_ptr(), N.ptr(d.get("bias")), W.stride(0)
+        g.Qout, g.Kout, g.Vtout, g.Vout = N.ptr(d.get("Q")), N.ptr(d.get("K")), N.ptr(d.get("Vt")), N.ptr(d.get("V"))
+        g.M, g.N, g.K = (A.shape[0] if A is not None else pre[i]["X"].shape[0]), W.shape[0], W.shape[1]
+        g.col0 = d.get("col0", 0)
+    common = N.SeaQkvCommon(rope.data_ptr(), H, hd, T, pos0, cap, q_scale)
+    N.check(N.lib().sea_qkv_rope_fewrows(arr, _norm_array(pre, n), n, C.byref(common), eps, N.dtype_code(dtype), N.stream_ptr()), "sea_qkv_rope_fewrows")
 
 
 def fill_gemm_norm_group(g: N.SeaGemmNormGroup, A, W, gamma, bias=None, R=None, C32=None, mod=None, beta=None, Y32=None, Yact=None,
