@@ -573,9 +573,12 @@ __global__ __launch_bounds__(512) void attention_row_wide_kernel(const SeaAttnPa
     const bool pre = CAN_PRE && nvec <= 64;                // block-uniform
     uint4 vpre[CAN_PRE ? DPW : 1];
     if (pre) {
-        const int v = lane < nvec ? lane : nvec - 1;
 #pragma unroll
-        for (int i = 0; i < DPW; ++i) vpre[i] = *reinterpret_cast<const uint4*>(Vg + (int64_t)(wave * DPW + i) * P.cap + v * 8);
+        for (int i = 0; i < DPW; ++i) vpre[i] = make_uint4(0u, 0u, 0u, 0u);
+        if (lane < nvec) {   // only the lanes that hold a vector ask for one (a 100-key cache: 13 of 64 — the texture path's time goes with the lanes in flight)
+#pragma unroll
+            for (int i = 0; i < DPW; ++i) vpre[i] = *reinterpret_cast<const uint4*>(Vg + (int64_t)(wave * DPW + i) * P.cap + lane * 8);
+        }
     }
     float q[32];
 #pragma unroll
@@ -587,9 +590,13 @@ __global__ __launch_bounds__(512) void attention_row_wide_kernel(const SeaAttnPa
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const int kk = key + u * KPP;
-            const uint4* kr = reinterpret_cast<const uint4*>(Kg + (int64_t)(kk < nk ? kk : nk - 1) * HD + part * 32);
 #pragma unroll
-            for (int c = 0; c < CPS; ++c) raw[u][c] = kr[c];
+            for (int c = 0; c < CPS; ++c) raw[u][c] = make_uint4(0u, 0u, 0u, 0u);
+            if (kk < nk) {   // lanes without a key ask for nothing
+                const uint4* kr = reinterpret_cast<const uint4*>(Kg + (int64_t)kk * HD + part * 32);
+#pragma unroll
+                for (int c = 0; c < CPS; ++c) raw[u][c] = kr[c];
+            }
         }
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
@@ -644,17 +651,20 @@ __global__ __launch_bounds__(512) void attention_row_wide_kernel(const SeaAttnPa
                 load4(prob + lane * 8, *reinterpret_cast<float(*)[4]>(pv));
                 load4(prob + lane * 8 + 4, *reinterpret_cast<float(*)[4]>(pv + 4));   // keys >= nk of the last vector: prob is 0 there
             }
+            float acc[DPW];
 #pragma unroll
             for (int i = 0; i < DPW; ++i) {
                 float vv[8];
                 unpack16<T>(vpre[i], vv);
-                float acc = 0.f;
+                acc[i] = 0.f;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) acc += pv[e] * (lane * 8 + e < nk ? vv[e] : 0.f);   // 0 * garbage beyond nk must stay 0
-#pragma unroll
-                for (int o = 32; o >= 1; o >>= 1) acc += __shfl_xor(acc, o);
-                if (lane == 0) Og[wave * DPW + i] = from_f32<T>(acc * inv);
+                for (int e = 0; e < 8; ++e) acc[i] += pv[e] * (lane * 8 + e < nk ? vv[e] : 0.f);   // 0 * garbage beyond nk must stay 0
             }
+            // the DPW row sums of the wave by one halving exchange (DPW + 5 - log2 DPW shuffles instead of 6 DPW), row (lane / (64 / DPW)) left in lane `lane`:
+            // one store instruction for the wave's rows instead of DPW
+            const float tot = lane_scatter_sum<DPW>(acc, lane);
+            constexpr int LS = 64 / DPW;
+            if (lane % LS == 0) Og[wave * DPW + lane / LS] = from_f32<T>(tot * inv);
             return;
         }
     }

@@ -179,34 +179,6 @@ struct RowStage {
     }
 };
 
-// ---------------------------------------------------------------------------------------------- sum over the 64 lanes of NV values, value (lane / (64 / NV)) left in every lane
-// step with exchange distance X: the lanes whose bit X is set keep the upper half of the values and hand over the lower half (every stage in registers of
-// its own: the in-place form is compiled into a dynamically indexed scratch array)
-template <int N, int X>
-__device__ __forceinline__ float lane_scatter_step(const float (&v)[N], int lane) {
-    if constexpr (X == 0) {
-        return v[0];
-    } else if constexpr (N > 1) {
-        const bool up = (lane & X) != 0;
-        float nv[N / 2];
-#pragma unroll
-        for (int i = 0; i < N / 2; ++i) {
-            const float lo = v[i], hi = v[i + N / 2];
-            const float send = up ? lo : hi;
-            const float keep = up ? hi : lo;
-            nv[i] = keep + __shfl_xor(send, X);
-        }
-        return lane_scatter_step<N / 2, X / 2>(nv, lane);
-    } else {
-        const float nv[1] = {v[0] + __shfl_xor(v[0], X)};
-        return lane_scatter_step<1, X / 2>(nv, lane);
-    }
-}
-template <int NV>
-__device__ __forceinline__ float lane_scatter_sum(const float (&v)[NV], int lane) {
-    return lane_scatter_step<NV, 32>(v, lane);
-}
-
 template <int MR, int CW, int KC>
 struct FewShape {
     static constexpr int NV = MR * CW;                       // (row, column) results per wave

@@ -246,6 +246,35 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
+// Sum over the 64 lanes of each of NV values (NV a power of two <= 64), total number (lane / (64 / NV)) left in lane `lane`: NV - 1 + (6 - log2 NV) exchanges
+// instead of 6 NV for NV separate butterflies, and the result spread over the lanes (one epilogue element per lane).
+// step with exchange distance X: the lanes whose bit X is set keep the upper half of the values and hand over the lower half (every stage in registers of
+// its own: the in-place form is compiled into a dynamically indexed scratch array)
+template <int N, int X>
+__device__ __forceinline__ float lane_scatter_step(const float (&v)[N], int lane) {
+    if constexpr (X == 0) {
+        return v[0];
+    } else if constexpr (N > 1) {
+        const bool up = (lane & X) != 0;
+        float nv[N / 2];
+#pragma unroll
+        for (int i = 0; i < N / 2; ++i) {
+            const float lo = v[i], hi = v[i + N / 2];
+            const float send = up ? lo : hi;
+            const float keep = up ? hi : lo;
+            nv[i] = keep + __shfl_xor(send, X);
+        }
+        return lane_scatter_step<N / 2, X / 2>(nv, lane);
+    } else {
+        const float nv[1] = {v[0] + __shfl_xor(v[0], X)};
+        return lane_scatter_step<1, X / 2>(nv, lane);
+    }
+}
+template <int NV>
+__device__ __forceinline__ float lane_scatter_sum(const float (&v)[NV], int lane) {
+    return lane_scatter_step<NV, 32>(v, lane);
+}
+
 // Pack 4 fp32 values into 4 consecutive act elements and store them (8 B for bf16, 16 B for f32).
 __device__ __forceinline__ void store4(float* dst, float a, float b, float c, float d) {
     *reinterpret_cast<float4*>(dst) = make_float4(a, b, c, d);
