@@ -207,8 +207,10 @@ int sea_rownorm(const SeaNormGroup* groups, int n_groups, int M, int d, int x_is
  *           SeaNormGroup; K <= 2048), evaluated by every workgroup for itself — groups[g].A is ignored.  Xout (x + addend, fp32) is written once and must
  *           NOT alias X; Y32 / Yact / mean / rstd must be NULL.  (LayerNorm / AdaLN in front of q/k/v, cross-attention and the MLP: models/temporal.py:126-131,
  *           139-145, 170-186; models/base_blocks.py:345-350.)
+ *           sea_gemm_fewrows, pre_x_is_act = 1: pre[g].X are rows in the activation dtype instead and the prologue is sea_rownorm(x_is_act, pre_gelu) with
+ *           gamma / beta only — nn.LayerNorm + GELU of the hidden rows in front of MLP.layers.3 (models/base_blocks.py:23-25); K <= 8192.
  * Arithmetic: products of bf16 operands accumulated in fp32 (v_dot2c_f32_bf16), norms in fp32 two-pass form exactly as sea_rownorm. */
-int sea_gemm_fewrows(const SeaGemmGroup* groups, const SeaNormGroup* pre, int n_groups, float eps, int dtype, void* stream);
+int sea_gemm_fewrows(const SeaGemmGroup* groups, const SeaNormGroup* pre, int n_groups, int pre_x_is_act, int pre_gelu, float eps, int dtype, void* stream);
 int sea_qkv_rope_fewrows(const SeaQkvGroup* groups, const SeaNormGroup* pre, int n_groups, const SeaQkvCommon* common, float eps, int dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
@@ -561,7 +563,7 @@ int sea_ib_bwd(const SeaIbBwdParams* params, void* stream);
  *     SEA_OP_GEMM_NORM p0 = SeaGemmNormGroup[n], f0 = eps          SEA_OP_XTAIL  p0 = SeaExchangeTail[n], f0 = eps
  *     SEA_OP_MLP1   p0 = SeaMlpGroup[n], f0 = eps
  *     SEA_OP_MLP2   p0 = SeaMlp2Group[n], f0 = eps
- *     SEA_OP_GEMM_FEW p0 = SeaGemmGroup[n], p1 = pre or NULL, f0 = eps
+ *     SEA_OP_GEMM_FEW p0 = SeaGemmGroup[n], p1 = pre or NULL, i0 = pre_x_is_act, i1 = pre_gelu, f0 = eps
  *     SEA_OP_QKV_FEW  p0 = SeaQkvGroup[n], p1 = SeaQkvCommon, l0 = (intptr) pre or 0, f0 = eps
  * Returns 0, or the failing entry's error code with sea_last_error() set (entries before it have been launched).
  */

@@ -225,7 +225,7 @@ def lib() -> C.CDLL:
     L.sea_qkv_rope_grouped.argtypes = [C.POINTER(SeaQkvGroup), C.c_int, C.POINTER(SeaQkvCommon), C.c_int, _vp]
     L.sea_attention_fwd.argtypes = [C.POINTER(SeaAttnParams), C.c_int, _vp]
     L.sea_rownorm.argtypes = [C.POINTER(SeaNormGroup), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, _vp]
-    L.sea_gemm_fewrows.argtypes = [C.POINTER(SeaGemmGroup), C.POINTER(SeaNormGroup), C.c_int, C.c_float, C.c_int, _vp]
+    L.sea_gemm_fewrows.argtypes = [C.POINTER(SeaGemmGroup), C.POINTER(SeaNormGroup), C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, _vp]
     L.sea_gemm_fewrows.restype = C.c_int
     L.sea_qkv_rope_fewrows.argtypes = [C.POINTER(SeaQkvGroup), C.POINTER(SeaNormGroup), C.c_int, C.POINTER(SeaQkvCommon), C.c_float, C.c_int, _vp]
     L.sea_qkv_rope_fewrows.restype = C.c_int

@@ -57,7 +57,7 @@ extern "C" int sea_run_list(const SeaLaunchRec* recs, int n_recs, void* stream) 
             case SEA_OP_XTAIL: rc = sea_exchange_tail(static_cast<const SeaExchangeTail*>(R.p0), R.n, R.f0, R.dtype, stream); break;
             case SEA_OP_MLP1: rc = sea_mlp_fc1_ln_gelu(static_cast<const SeaMlpGroup*>(R.p0), R.n, R.f0, R.dtype, stream); break;
             case SEA_OP_MLP2: rc = sea_mlp_fc2_proj_norm(static_cast<const SeaMlp2Group*>(R.p0), R.n, R.f0, R.dtype, stream); break;
-            case SEA_OP_GEMM_FEW: rc = sea_gemm_fewrows(static_cast<const SeaGemmGroup*>(R.p0), static_cast<const SeaNormGroup*>(R.p1), R.n, R.f0, R.dtype, stream); break;
+            case SEA_OP_GEMM_FEW: rc = sea_gemm_fewrows(static_cast<const SeaGemmGroup*>(R.p0), static_cast<const SeaNormGroup*>(R.p1), R.n, R.i0, R.i1, R.f0, R.dtype, stream); break;
             case SEA_OP_QKV_FEW: rc = sea_qkv_rope_fewrows(static_cast<const SeaQkvGroup*>(R.p0), reinterpret_cast<const SeaNormGroup*>(R.l0), R.n, static_cast<const SeaQkvCommon*>(R.p1), R.f0,
                                                            R.dtype, stream); break;
             default: sea_set_error("sea_run_list[%d]: unknown op %d", i, R.op); return SEA_EINVAL;

@@ -38,6 +38,7 @@ struct GemmFewLaunch {
     SeaNormGroup pre[FR_MAX_GROUPS];    // X == NULL: the group's A operand is read as it is
     int blk_start[FR_MAX_GROUPS + 1];
     int n_groups;
+    int pre_mode;                       // 0: pre[g].X are fp32 rows; 1: rows in the activation dtype (plain LayerNorm); 3: ... followed by GELU
     float eps;
 };
 struct QkvFewLaunch {
@@ -68,15 +69,17 @@ struct RowStage {
     float gm[8], bt[8], xv[MR][8], av[MR][8];
     uint4 mw[MR], mb[MR], cp[MR][CP];
 
-    __device__ __forceinline__ void request(const __bf16* A, int lda, int M, const SeaNormGroup& P, int tid) {
-        if (P.X == nullptr) {
+    __device__ __forceinline__ void request(const __bf16* A, int lda, int M, const SeaNormGroup& P, int mode, int tid) {
+        if (P.X == nullptr || mode != 0) {   // rows in the activation dtype: the operand itself, or the rows a LayerNorm (+ GELU) will be applied to
+            const __bf16* src = P.X == nullptr ? A : static_cast<const __bf16*>(P.X);
+            const int ld = P.X == nullptr ? lda : P.ldx;
 #pragma unroll
             for (int m = 0; m < MR; ++m) {
 #pragma unroll
                 for (int k = 0; k < CP; ++k) {
                     const int q = k * 256 + tid;
                     cp[m][k] = make_uint4(0u, 0u, 0u, 0u);
-                    if (m < M && q < NPC) cp[m][k] = *reinterpret_cast<const uint4*>(A + (int64_t)m * lda + q * 8);
+                    if (m < M && q < NPC) cp[m][k] = *reinterpret_cast<const uint4*>(src + (int64_t)m * ld + q * 8);
                 }
             }
             return;
@@ -106,7 +109,73 @@ struct RowStage {
         }
     }
 
-    __device__ __forceinline__ void finish(int M, const SeaNormGroup& P, bool writer, float eps, uint4* a_lds, float* red, int tid) {
+    // nn.LayerNorm (+ GELU) of rows held in the activation dtype (the hidden rows of the MLP in front of its second Linear, models/base_blocks.py:23-25), row by
+    // row from the copy registers; the gains / shifts are requested once, before the statistics
+    __device__ __forceinline__ void finish_act(int M, const SeaNormGroup& P, bool gelu, float eps, uint4* a_lds, float* red, int tid) {
+        const int lane = tid & 63, wave = tid >> 6;
+        const float inv_d = 1.0f / (float)(KC * 512);
+        float g8[CP][8], b8[CP][8];
+#pragma unroll
+        for (int k = 0; k < CP; ++k) {
+            const int q = k * 256 + tid, qc = q < NPC ? q : 0;
+            load8(P.gamma + qc * 8, g8[k]);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) b8[k][e] = 0.f;
+            if (P.beta != nullptr) load8(P.beta + qc * 8, b8[k]);
+        }
+#pragma unroll
+        for (int m = 0; m < MR; ++m) {
+            if (m >= M) break;   // block-uniform
+            float xf[CP][8];
+            float s = 0.f;
+#pragma unroll
+            for (int k = 0; k < CP; ++k) {
+                const bf16x8 v = __builtin_bit_cast(bf16x8, cp[m][k]);   // zeros beyond the row
+#pragma unroll
+                for (int e = 0; e < 8; ++e) xf[k][e] = (float)v[e];
+                s += ((xf[k][0] + xf[k][1]) + (xf[k][2] + xf[k][3])) + ((xf[k][4] + xf[k][5]) + (xf[k][6] + xf[k][7]));
+            }
+            s = wave_sum(s);
+            if (lane == 0) red[m * 4 + wave] = s;
+            __syncthreads();
+            const float mean = (red[m * 4] + red[m * 4 + 1] + red[m * 4 + 2] + red[m * 4 + 3]) * inv_d;
+            float sq = 0.f;
+#pragma unroll
+            for (int k = 0; k < CP; ++k) {
+                if (k * 256 + tid < NPC) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float c = xf[k][e] - mean;
+                        sq += c * c;
+                    }
+                }
+            }
+            sq = wave_sum(sq);
+            if (lane == 0) red[MR * 4 + m * 4 + wave] = sq;
+            __syncthreads();
+            const float rstd = 1.0f / sqrtf((red[MR * 4 + m * 4] + red[MR * 4 + m * 4 + 1] + red[MR * 4 + m * 4 + 2] + red[MR * 4 + m * 4 + 3]) * inv_d + eps);
+#pragma unroll
+            for (int k = 0; k < CP; ++k) {
+                const int q = k * 256 + tid;
+                if (q < NPC) {
+                    bf16x8 pk;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        float o = (xf[k][e] - mean) * rstd * g8[k][e] + b8[k][e];
+                        if (gelu) o = gelu_for<__bf16>(o);   // as sea_rownorm for an output that only exists in bf16
+                        pk[e] = (__bf16)o;
+                    }
+                    a_lds[m * NPC + q] = __builtin_bit_cast(uint4, pk);
+                }
+            }
+        }
+    }
+
+    __device__ __forceinline__ void finish(int M, const SeaNormGroup& P, int mode, bool writer, float eps, uint4* a_lds, float* red, int tid) {
+        if (P.X != nullptr && mode != 0) {
+            finish_act(M, P, (mode & 2) != 0, eps, a_lds, red, tid);
+            return;
+        }
         if (P.X == nullptr) {
 #pragma unroll
             for (int m = 0; m < MR; ++m) {
@@ -189,14 +258,14 @@ struct FewShape {
 
 // weights of the wave's CW columns (every fragment requested at once), the staged rows, the dot products, the exchange; returns this lane's (row, column) total
 template <int MR, int CW, int KC>
-__device__ __forceinline__ float few_core(const __bf16* A, const __bf16* W, int lda, int ldw, int M, int N, int nw0, const SeaNormGroup& pre, bool writer, float eps,
+__device__ __forceinline__ float few_core(const __bf16* A, const __bf16* W, int lda, int ldw, int M, int N, int nw0, const SeaNormGroup& pre, int pre_mode, bool writer, float eps,
                                           char* smem, int tid) {
     using S = FewShape<MR, CW, KC>;
     uint4* a_lds = reinterpret_cast<uint4*>(smem);
     float* red = reinterpret_cast<float*>(smem + MR * KC * 1024);
     const int lane = tid & 63;
     RowStage<MR, KC> rows;
-    rows.request(A, lda, M, pre, tid);
+    rows.request(A, lda, M, pre, pre_mode, tid);
     uint4 w[CW][KC];
 #pragma unroll
     for (int c = 0; c < CW; ++c) {
@@ -205,7 +274,7 @@ __device__ __forceinline__ float few_core(const __bf16* A, const __bf16* W, int 
 #pragma unroll
         for (int j = 0; j < KC; ++j) w[c][j] = wp[j * 64];
     }
-    rows.finish(M, pre, writer, eps, a_lds, red, tid);
+    rows.finish(M, pre, pre_mode, writer, eps, a_lds, red, tid);
     __syncthreads();
     float acc[S::NV];
 #pragma unroll
@@ -240,7 +309,7 @@ __global__ __launch_bounds__(256) void gemm_fewrows_kernel(const GemmFewLaunch L
         if (G.bias != nullptr) bv = G.bias[ne];
         if (G.R != nullptr) rv = G.R[(int64_t)me * G.ldr + ne];
     }
-    float v = few_core<MR, CW, KC>(static_cast<const __bf16*>(G.A), static_cast<const __bf16*>(G.W), G.lda, G.ldw, G.M, G.N, nw0, L.pre[gi], blk == 0, L.eps, smem, tid);
+    float v = few_core<MR, CW, KC>(static_cast<const __bf16*>(G.A), static_cast<const __bf16*>(G.W), G.lda, G.ldw, G.M, G.N, nw0, L.pre[gi], L.pre_mode, blk == 0, L.eps, smem, tid);
     if (live) {
         v += bv * G.bias_scale;
         if (G.act == 1) {
@@ -281,7 +350,7 @@ __global__ __launch_bounds__(256) void qkv_fewrows_kernel(const QkvFewLaunch L) 
         if (G.bias != nullptr) bv = G.bias[ne];
         if (part < 2) cs = reinterpret_cast<const float2*>(L.c.rope)[(uint32_t)pos * (uint32_t)hd2 + (dd >> 1)];
     }
-    float v = few_core<MR, CW, KC>(static_cast<const T*>(G.A), static_cast<const T*>(G.W), G.lda, G.ldw, G.M, G.N, nw0, L.pre[gi], false, L.eps, smem, tid);
+    float v = few_core<MR, CW, KC>(static_cast<const T*>(G.A), static_cast<const T*>(G.W), G.lda, G.ldw, G.M, G.N, nw0, L.pre[gi], 0, false, L.eps, smem, tid);
     v += bv;
     // the other half of the rotation pair (columns 2 p, 2 p + 1 sit LSTRIDE lanes apart; both lanes of a pair are live or neither: N and col0 are even)
     const float pv = __shfl_xor(live ? v : 0.f, S::LSTRIDE);
@@ -349,8 +418,9 @@ static int check_pre(const SeaNormGroup& P, int K, const char* who, int i) {
 
 }  // namespace
 
-extern "C" int sea_gemm_fewrows(const SeaGemmGroup* groups, const SeaNormGroup* pre, int n_groups, float eps, int dtype, void* stream) {
+extern "C" int sea_gemm_fewrows(const SeaGemmGroup* groups, const SeaNormGroup* pre, int n_groups, int pre_x_is_act, int pre_gelu, float eps, int dtype, void* stream) {
     SEA_REQUIRE(groups != nullptr && n_groups >= 1 && n_groups <= FR_MAX_GROUPS, "sea_gemm_fewrows: n_groups=%d out of range (1..%d)", n_groups, FR_MAX_GROUPS);
+    SEA_REQUIRE(pre_x_is_act || !pre_gelu, "sea_gemm_fewrows: pre_gelu goes with pre_x_is_act (LayerNorm + GELU of activation rows)");
     if (dtype != SEA_BF16) {
         sea_set_error("sea_gemm_fewrows: bf16 only (dtype=%d)", dtype);
         return SEA_EUNSUPPORTED;
@@ -375,8 +445,16 @@ extern "C" int sea_gemm_fewrows(const SeaGemmGroup* groups, const SeaNormGroup* 
         SEA_REQUIRE((!G.R || G.ldr >= G.N) && (!G.C32 || G.ldc32 >= G.N) && (!G.Cact || G.ldcact >= G.N) && (!G.Z || G.ldz >= G.N), "sea_gemm_fewrows[%d]: output stride < N", i);
         L.g[i] = G;
         if (pre != nullptr && pre[i].X != nullptr) {
-            const int rc = check_pre(pre[i], K, "sea_gemm_fewrows", i);
-            if (rc != SEA_OK) return rc;
+            if (pre_x_is_act) {
+                const SeaNormGroup& P = pre[i];
+                // every workgroup re-reads the row and its fp32 gains / shifts (10 K bytes): affordable while that stays below the weight stream (K <= 8192: 20 MB against 34)
+                SEA_REQUIRE(K <= 8192, "sea_gemm_fewrows[%d]: a LayerNorm prologue on activation rows needs K <= 8192 (K=%d)", i, K);
+                SEA_REQUIRE(P.gamma && sea_aligned16(P.X) && sea_aligned16(P.gamma) && sea_aligned16(P.beta) && P.ldx >= K && P.ldx % 8 == 0, "sea_gemm_fewrows[%d]: prologue pointers / strides", i);
+                SEA_REQUIRE(!P.mod && !P.addend && !P.Xout && !P.Y32 && !P.Yact && !P.mean && !P.rstd, "sea_gemm_fewrows[%d]: a prologue on activation rows is a plain LayerNorm (gamma, beta)", i);
+            } else {
+                const int rc = check_pre(pre[i], K, "sea_gemm_fewrows", i);
+                if (rc != SEA_OK) return rc;
+            }
             L.pre[i] = pre[i];
         }
         L.blk_start[i] = blocks;
@@ -385,6 +463,7 @@ extern "C" int sea_gemm_fewrows(const SeaGemmGroup* groups, const SeaNormGroup* 
     }
     L.blk_start[n_groups] = blocks;
     L.n_groups = n_groups;
+    L.pre_mode = pre_x_is_act ? (pre_gelu ? 3 : 1) : 0;
     L.eps = eps;
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (mmax == 1) {

@@ -371,7 +371,7 @@ class Plan:
                 self._x_patches.append((g, "X", sp["X_is_x"]))
         return arr
 
-    def _gemm_few(self, groups: List[dict], name: str, pre=None) -> None:
+    def _gemm_few(self, groups: List[dict], name: str, pre=None, pre_act: bool = False, pre_gelu: bool = False) -> None:
         """sea_gemm_fewrows (step plans at the shipped widths): group dicts as _gemm; pre[i]: the _norm group dict (or None) of the row norm in front of the layer.
         Groups with pre[i] carry no A."""
         L = N.lib()
@@ -389,7 +389,7 @@ class Plan:
             if d.get("R_is_x") is not None:
                 self._x_patches.append((g, "R", d["R_is_x"]))
         pa = self._norm_specs(pre, n)
-        self._cur.append(self._rec(L.sea_gemm_fewrows, [arr, pa, n, 1e-5, self.code], name, (arr, pa)))
+        self._cur.append(self._rec(L.sea_gemm_fewrows, [arr, pa, n, int(pre_act), int(pre_gelu), 1e-5, self.code], name, (arr, pa)))
 
     def _qkv_few(self, groups: List[dict], rope: torch.Tensor, hd: int, name: str, pre=None) -> None:
         """sea_qkv_rope_fewrows: group dicts as _qkv; pre[i]: the _norm group dict of the row norm in front of the projection (or None)."""
@@ -827,16 +827,18 @@ class Plan:
             return dict(gamma=P.f32_vec(p_ + "weight"))
 
         if few:
-            # KV-cache step at the shipped widths: [ib add + AdaLN_2 / LayerNorm] fc1 | LayerNorm + GELU | fc2 + residual | proj | final norm.
+            # KV-cache step at the shipped widths: [ib add + AdaLN_2 / LayerNorm] fc1 | [LayerNorm + GELU] fc2 + residual | proj | final norm.
             # x + ib goes to rows of its own (xq): the prologue runs in every workgroup of fc1, so it must not update the rows it reads
             xq = [self._buf(self.M, E, dtype=torch.float32) for _ in fields] if addend is not None else None
             res = xq if addend is not None else [xr[i] for i in fields]
             pre_n = [dict(X=xr[i], **(dict(addend=addend, Xout=xq[k]) if addend is not None else {}), **norm_params(f"{pre}ln.exp.{i}.2.", E)) for k, i in enumerate(fields)]
             self._gemm_few([dict(W=P.act(f"{pre}mlp.{i}.layers.0.weight"), bias=P.f32_vec(f"{pre}mlp.{i}.layers.0.bias"), Cact=hbuf[i]) for i in fields], "mlp.fc1" + tag, pre=pre_n)
-            self._norm([dict(X=hbuf[i], gamma=P.f32_vec(f"{pre}mlp.{i}.layers.1.weight"), beta=P.f32_vec(f"{pre}mlp.{i}.layers.1.bias"), Yact=hg[i])
-                        for i in fields], S, "mlp.ln_gelu" + tag, x_is_act=True, gelu=True)
-            self._gemm_few([dict(A=hg[i], W=P.act(f"{pre}mlp.{i}.layers.3.weight"), bias=P.f32_vec(f"{pre}mlp.{i}.layers.3.bias"), R=res[k], Cact=xm[i])
-                            for k, i in enumerate(fields)], "mlp.fc2" + tag)
+            ln_h = [dict(X=hbuf[i], gamma=P.f32_vec(f"{pre}mlp.{i}.layers.1.weight"), beta=P.f32_vec(f"{pre}mlp.{i}.layers.1.bias")) for i in fields]
+            fold_ln = S <= 8192   # LayerNorm + GELU of the hidden rows as the prologue of fc2 while re-reading the row and its gains / shifts per workgroup stays below the weight stream
+            if not fold_ln:
+                self._norm([dict(Yact=hg[i], **g_) for i, g_ in zip(fields, ln_h)], S, "mlp.ln_gelu" + tag, x_is_act=True, gelu=True)
+            self._gemm_few([dict(A=(None if fold_ln else hg[i]), W=P.act(f"{pre}mlp.{i}.layers.3.weight"), bias=P.f32_vec(f"{pre}mlp.{i}.layers.3.bias"), R=res[k], Cact=xm[i])
+                            for k, i in enumerate(fields)], "mlp.fc2" + tag, pre=(ln_h if fold_ln else None), pre_act=fold_ln, pre_gelu=fold_ln)
             self._gemm_few([dict(A=xm[i], W=P.act(f"{pre}proj.{i}.weight"), bias=P.f32_vec(f"{pre}proj.{i}.bias"), C32=xo[i]) for i in fields], "proj" + tag)
             if final_norm:
                 self._norm([dict(X=xo[i], Y32=xo[i], ldy32=FE, Y_is_out=i * Eo * 4, **norm_params(f"ln.{i}.", Eo)) for i in fields], Eo, "final.norm" + tag)
@@ -1120,7 +1122,7 @@ class Plan:
             elif r.fn is L.sea_qkv_rope_grouped:
                 c.op, c.p0, c.n, c.p1, c.dtype = N.OP_QKV, addr(a[0]), a[1], addr(r.keep[1]), a[3]
             elif r.fn is L.sea_gemm_fewrows:
-                c.op, c.p0, c.n, c.f0, c.dtype = N.OP_GEMM_FEW, addr(a[0]), a[2], a[3], a[4]
+                c.op, c.p0, c.n, c.i0, c.i1, c.f0, c.dtype = N.OP_GEMM_FEW, addr(a[0]), a[2], a[3], a[4], a[5], a[6]
                 c.p1 = addr(a[1]) if a[1] is not None else None
             elif r.fn is L.sea_qkv_rope_fewrows:
                 c.op, c.p0, c.n, c.p1, c.f0, c.dtype = N.OP_QKV_FEW, addr(a[0]), a[2], addr(r.keep[2]), a[4], a[5]

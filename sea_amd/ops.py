@@ -176,8 +176,9 @@ def _norm_array(specs: Optional[Sequence[Optional[Dict]]], n: int):
     return arr
 
 
-def gemm_fewrows(groups: Sequence[Dict], dtype: torch.dtype, pre=None, eps: float = 1e-5) -> None:
-    """sea_gemm_fewrows: groups as gemm_grouped (A may be None where pre[i] is given); pre: list of rownorm group dicts or None per group."""
+def gemm_fewrows(groups: Sequence[Dict], dtype: torch.dtype, pre=None, pre_x_is_act: bool = False, pre_gelu: bool = False, eps: float = 1e-5) -> None:
+    """sea_gemm_fewrows: groups as gemm_grouped (A may be None where pre[i] is given); pre: list of rownorm group dicts or None per group (fp32 rows, or —
+    pre_x_is_act — rows in the activation dtype with a plain LayerNorm, optionally followed by GELU)."""
     n = len(groups)
     arr = (N.SeaGemmGroup * n)()
     for i, d in enumerate(groups):
@@ -189,7 +190,7 @@ def gemm_fewrows(groups: Sequence[Dict], dtype: torch.dtype, pre=None, eps: floa
             arr[i].A, arr[i].lda = None, 0
         else:
             fill_gemm_group(arr[i], _mat(A, "A"), W, d.get("bias"), d.get("R"), d.get("C32"), d.get("Cact"), act=d.get("act", 0), bias_scale=d.get("bias_scale", 1.0), Z=d.get("Z"))
-    N.check(N.lib().sea_gemm_fewrows(arr, _norm_array(pre, n), n, eps, N.dtype_code(dtype), N.stream_ptr()), "sea_gemm_fewrows")
+    N.check(N.lib().sea_gemm_fewrows(arr, _norm_array(pre, n), n, int(pre_x_is_act), int(pre_gelu), eps, N.dtype_code(dtype), N.stream_ptr()), "sea_gemm_fewrows")
 
 
 def qkv_rope_fewrows(groups: Sequence[Dict], rope: torch.Tensor, H: int, hd: int, T: int, pos0: int, cap: int, q_scale: float, dtype: torch.dtype, pre=None,

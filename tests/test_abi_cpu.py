@@ -57,10 +57,10 @@ def test_validation_without_gpu(lib):
     assert lib.sea_attention_fwd(C.byref(P), 1, None) == -1
     assert lib.sea_abi_version() == N.ABI_VERSION == 6
     few = (N.SeaGemmGroup * 1)()
-    assert lib.sea_gemm_fewrows(few, None, 1, 1e-5, 0, None) == -3     # fp32: the few-row launches are bf16 only (unsupported, not an argument error)
-    assert lib.sea_gemm_fewrows(few, None, 9, 1e-5, 1, None) == -1 and b"sea_gemm_fewrows" in lib.sea_last_error()
+    assert lib.sea_gemm_fewrows(few, None, 1, 0, 0, 1e-5, 0, None) == -3     # fp32: the few-row launches are bf16 only (unsupported, not an argument error)
+    assert lib.sea_gemm_fewrows(few, None, 9, 0, 0, 1e-5, 1, None) == -1 and b"sea_gemm_fewrows" in lib.sea_last_error()
     few[0].K = 768
-    assert lib.sea_gemm_fewrows(few, None, 1, 1e-5, 1, None) == -3 and b"K=768" in lib.sea_last_error()
+    assert lib.sea_gemm_fewrows(few, None, 1, 0, 0, 1e-5, 1, None) == -3 and b"K=768" in lib.sea_last_error()
     G, Ly = N.SeaKvGlobal(), (N.SeaKvLayer * 1)()
     assert lib.sea_kv_rollout(C.byref(G), Ly, 0, 1, 1, 1, None) == -1   # sizes are checked before anything is launched
     assert b"sea_kv_rollout" in lib.sea_last_error()

@@ -98,6 +98,34 @@ def test_gemm_fewrows_norm_prologue(M, K, adaln, addend):
             assert torch.equal(sp["Xout"], xs)
 
 
+@pytest.mark.parametrize("M,N,K,gelu", [(1, 1024, 8192, True), (2, 512, 4096, True), (4, 1024, 2048, False), (3, 260, 8192, True)])
+def test_gemm_fewrows_layernorm_gelu_prologue_on_activation_rows(M, N, K, gelu):
+    """pre_x_is_act: nn.LayerNorm (+ GELU) of hidden rows held in bf16 (padded row stride) as the prologue of the Linear that consumes them."""
+    from sea_amd import ops
+
+    groups, pres, refs, chain = [], [], [], []
+    for gi in range(2):
+        Hb = torch.zeros(M, K + 64, device="cuda", dtype=BF)[:, :K]
+        Hb.copy_(_r(M, K, scale=1.2) + 0.2)
+        W, bias, R = _r(N, K, scale=K ** -0.5, dtype=BF), _r(N), _r(M, N)
+        lnw, lnb = 1.0 + 0.1 * _r(K), 0.1 * _r(K)
+        Cact = torch.zeros(M, N, device="cuda", dtype=BF)
+        groups.append(dict(W=W, bias=bias, R=R, Cact=Cact))
+        pres.append(dict(X=Hb, gamma=lnw, beta=lnb))
+        a = _ln_ref(Hb.float(), lnw, lnb)
+        a = (torch.nn.functional.gelu(a) if gelu else a).to(BF).float()
+        refs.append(a @ W.float().t() + bias + R)
+        hg, c2 = torch.zeros(M, K, device="cuda", dtype=BF), torch.zeros(M, N, device="cuda", dtype=BF)
+        ops.rownorm([dict(X=Hb, gamma=lnw, beta=lnb, Yact=hg)], M, K, True, gelu, 1e-5, BF)
+        ops.gemm_grouped([dict(A=hg, W=W, bias=bias, R=R, Cact=c2)], BF)
+        chain.append(c2)
+    ops.gemm_fewrows(groups, BF, pre=pres, pre_x_is_act=True, pre_gelu=gelu)
+    torch.cuda.synchronize()
+    for d, ref, c2 in zip(groups, refs, chain):
+        assert torch.allclose(d["Cact"].float(), ref, rtol=2e-2, atol=2e-2), (d["Cact"].float() - ref).abs().max()
+        assert torch.allclose(d["Cact"].float(), c2.float(), rtol=2e-2, atol=2e-2)
+
+
 @pytest.mark.parametrize("M,K,H,hd,pre", [(1, 1024, 8, 128, True), (2, 2048, 8, 256, False), (4, 512, 8, 64, True), (1, 512, 8, 64, False)])
 def test_qkv_rope_fewrows_matches_the_tiled_launch(M, K, H, hd, pre):
     """Self form (one group, [q | k | v]) and cross form (a q group and a k,v group with another operand): same cache rows as sea_qkv_rope_grouped."""
@@ -147,8 +175,8 @@ def test_qkv_rope_fewrows_matches_the_tiled_launch(M, K, H, hd, pre):
                                         ((1, 1024, 8, 40, 8, 0, 2, 2, False, "adaln"), 4), ((2, 1024, 8, 24, 8, 0, 1, 2, True, "adaln"), 1)])
 def test_step_plan_of_fewrow_launches_equals_generic_step_plan_and_oracle(cfg_args, B, monkeypatch):
     """The KV-cache step plan at a shipped width (embed_dim 1024: cylinder_flow's; 2 and 3 field groups, AdaLN / LayerNorm, the info-bottleneck add behind and in
-    front of the exchange, two layers, 1-4 trajectories) built from the few-row launches: 18 launches per layer instead of 22 (no launch of its own for AdaLN_0,
-    ln_cross or the info-bottleneck add + AdaLN_2), the rollout of the generic
+    front of the exchange, two layers, 1-4 trajectories) built from the few-row launches: 17 launches per layer instead of 22 (no launch of its own for AdaLN_0,
+    ln_cross, the info-bottleneck add + AdaLN_2 or the LayerNorm + GELU of the hidden rows), the rollout of the generic
     step plan within bf16 rounding and the CPU oracle's recompute rollout within the bf16 rollout tolerance."""
     from oracle import sea_oracle as O
     from oracle.recipe import recipe_inputs, recipe_params
@@ -168,7 +196,7 @@ def test_step_plan_of_fewrow_launches_equals_generic_step_plan_and_oracle(cfg_ar
     plans = [p for k, p in eng._plans.items() if k[:3] == (B, 1, "step")]
     assert len(plans) == 1 and plans[0]._few
     names = [r.name for r in plans[0].records]
-    assert not any("adaln" in nm or "norm_old" in nm or "norm_new" in nm for nm in names), names
+    assert not any("adaln" in nm or "norm_old" in nm or "norm_new" in nm or nm == "mlp.ln_gelu" for nm in names), names
     assert any(r.fn is eng_lib().sea_gemm_fewrows for r in plans[0].records) and any(r.fn is eng_lib().sea_qkv_rope_fewrows for r in plans[0].records)
     n_few = len(names)
     monkeypatch.setenv("SEA_KV", "gemv=1,loop=python")
