@@ -288,6 +288,46 @@ def _roofline(recs_times, esz, traffic_file=None):
             "timing": "launch_ms: HIP events on the launch stream around 20 back-to-back launches of the dominant record (one captured graph at N = 1) / 20, best of 5"}
 
 
+def _pmc_file(name):
+    """profiles/<this round's file>, or the previous round's while this round's has not been produced yet."""
+    for rnd in ("r03", "r02"):
+        f = os.path.join(ROOT, "profiles", f"{rnd}_{name}")
+        if os.path.exists(f):
+            return f
+    return None
+
+
+N_CU, CLOCK_GHZ = 256, 2.4   # MI355X_MICROARCH.md "Chip-level parameters"
+
+
+def _attention_object(recs_times):
+    """The attention launches of a forward plan against the VALU issue bound of their softmax ('attention is exp-bound, not MFMA-bound at head
+    dims 16 / 32'): per visible (query, key) pair one v_exp_f32 (transcendental: a quarter of the fp32 rate, 16 lanes per clock and CU) and at least three
+    full-rate VALU operations (running maximum, pack to bf16, the share of masking / rescaling; the subtraction of the reference rides in the MFMA's C
+    operand and the row sums are an MFMA) at 64 lanes per clock and CU."""
+    from sea_amd import _native as N
+
+    L = N.lib()
+    att = [r for r, _ in recs_times if r.fn is L.sea_attention_fwd]
+    if not att:
+        return None
+    scores, flops, per = 0, 0, {}
+    for r in att:
+        P = r.keep
+        tri = P.Tq * (P.Tq + 1) // 2 + P.Tq * (P.Tk - P.Tq)
+        n = P.n_problems * P.B * P.H * tri
+        ms = _launch_time_ms(r)
+        bound_us = n * (1.0 / 16 + 3.0 / 64) / (N_CU * CLOCK_GHZ * 1e3)
+        scores += n
+        flops += 4 * n * P.hd
+        per[r.name] = {"head_dim": P.hd, "scores": n, "launch_us": round(ms * 1e3, 2), "valu_bound_us": round(bound_us, 2), "frac_of_valu_bound": round(bound_us / (ms * 1e3), 3),
+                       "mfma_tflops": round(4 * n * P.hd / (ms * 1e-3) / 1e12, 1)}
+    tot_us = sum(v["launch_us"] for v in per.values())
+    bound = scores * (1.0 / 16 + 3.0 / 64) / (N_CU * CLOCK_GHZ * 1e3)
+    return {"bound": "valu (1 v_exp_f32 at quarter rate + 3 fp32 VALU operations per visible query-key pair, 256 CUs at 2.4 GHz)", "scores": scores, "achieved_us": round(tot_us, 2),
+            "bound_us": round(bound, 2), "frac": round(bound / tot_us, 3), "mfma_tflops": round(flops / (tot_us * 1e-6) / 1e12, 1), "launches": per}
+
+
 def build_model(dev, dtype, F=3, ln="adaln", max_len=2024):
     from sea_amd.models.temporal import TemporalModel
 
@@ -329,8 +369,9 @@ def leg_rollout(args, dist, dev, rank, world, steps, warmup, B):
         torch.cuda.synchronize()
         times = _time_list(plan.records, iters=10)
         esz = 2 if args.dtype == "bf16" else 4
-        pmc = os.path.join(ROOT, "profiles", "r02_forward_cfg2_pmc_traffic.json") if (B, T, args.dtype) == (1, 2024, "bf16") else None
+        pmc = _pmc_file("forward_cfg2_pmc_traffic.json") if (B, T, args.dtype) == (1, 2024, "bf16") else None
         roof = _roofline(times, esz, pmc)
+        attn = _attention_object(times)
         del out_keep
     ms = elapsed / steps * 1e3
     gflop = algorithmic_gflop(B, T, F, E, H, D, S, L)
@@ -338,7 +379,7 @@ def leg_rollout(args, dist, dev, rank, world, steps, warmup, B):
             "workload": f"cfg2: cylinder_flow temporal model E={E} H={H} F={F} L={L} adaln, forward-only rollout step at T={T} (recompute mode), B={B} per GPU",
             "replay": "hip-graph" if use_graph else "plain (one native call per step: sea_run_list)", "model_algorithmic_gflop_per_step": gflop,
             "model_mfma_frac": gflop / (ms * 1e-3) / 1e3 / PEAK_BF16_TFLOPS, "n_launches": len(times),
-            "roofline": roof, "launch_breakdown_ms": {r.name: round(t, 4) for r, t in times}}
+            "roofline": roof, "attention": attn, "launch_breakdown_ms": {r.name: round(t, 4) for r, t in times}}
 
 
 def leg_train(args, dist, dev, rank, world, steps, warmup, B):
@@ -398,7 +439,7 @@ def leg_train(args, dist, dev, rank, world, steps, warmup, B):
     plan = eng.train_plan(B, T)
     esz = 2 if args.dtype == "bf16" else 4
     times = _time_list(list(plan.records) + list(plan.bwd), iters=3)
-    out["roofline"] = _roofline(times, esz)
+    out["roofline"] = _roofline(times, esz, _pmc_file("train_cfg3_pmc_traffic.json") if (B, T, args.dtype, world) == (8, 2024, "bf16", 1) else None)
     out["n_launches"] = len(times)
     out["top_launches_ms"] = {r.name: round(t, 4) for r, t in sorted(times, key=lambda rt: -rt[1])[:12]}
     return out
@@ -578,6 +619,8 @@ def run_rank(args):
                        "parallelism": h.get("parallelism", f"replicas x{world} (rollout shards by trajectory, no collective)")},
             "roofline": h.get("roofline"),
         }
+        if res.get("rollout", {}).get("attention") is not None:
+            line["attention"] = res["rollout"]["attention"]
         for k in ("rollout", "train", "kv", "shipped"):
             if k in res:
                 line[k] = res[k]
