@@ -205,6 +205,10 @@ __device__ __forceinline__ float drop_factor(uint32_t word, int j, int thr, floa
 // with (batch*head, problem) fastest: tiles go out heaviest-first across the whole chip and every CU gets a mix of weights.
 // Rounds of 256 workgroups (one per CU) alternate direction — a CU that received the heaviest tile of one round receives the lightest of
 // the next — so the per-CU sums stay close (3 resident workgroups per CU at cfg2: max/mean load 1.29 -> 1.07).
+// (Round 3, measured and not kept: an order that lets each XCD walk its (trajectory, head) pairs one after the other — all tiles of a pair before the next, so that
+// the pair's K / V rows stay in that XCD's L2 instead of 8 pairs' 6 MB evicting each other; PMC at cfg3 shows 626 MB fetched by the self-attention forward for
+// 100 MB of operands — was SLOWER everywhere: cfg3 train 3.644 -> 3.795 ms, B = 8 forward 1.087 -> 1.131, cfg2 forward 0.2259 -> 0.2473.  The launches are
+// bound by the balance of causal work across CUs, not by those re-reads.)
 __device__ __forceinline__ void decode_attn_block(int& tile, int& bh, int& z) {
     int L = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
     const int nbz = gridDim.y * gridDim.z;
