@@ -199,6 +199,10 @@ __global__ __launch_bounds__(256 * SPLIT, (attn_min_waves<T, HD, DROP>())) void 
     // with the maximum when it is huge — 16 VALU instructions fewer per tile, no faster: B = 8 107.8 / 56.3 us against 107.3 / 56.4 at head dim 32 / 16,
     // and slower at B = 1, where the second copy of the tile's code costs the 1024-thread form its 64-register budget.  The kernel is bound by the
     // latency of a wave's per-tile chain — LDS fragments -> MFMA -> max -> exp -> pack -> MFMA, one barrier per tile — not by VALU issue.)
+    // (Round 3, built, parity-green and not kept: the K / V^T tiles through a 3- / 4-stage global_load_lds ring (no staging registers, two to three tiles in
+    // flight, source-side swizzle, zeros for the upper half of a head-dim-16 chunk by lane select) instead of the register-staged double buffer: cross-attention
+    // at cfg2 13.3 -> 14.4 us, self 17.8 -> 18.3, B = 8 forward 1.094 -> 1.111 ms.  Global latency is not what the tile loop waits for: the launch lasts as long
+    // as its heaviest workgroup — the last query tile's 8 rounds of key tiles with four waves per SIMD taking turns at ~500 VALU cycles per wave and tile.)
     constexpr bool MFMA_SUM = sizeof(T) == 2 && !DROP;
     const uint4 ones = make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u);   // bf16 1.0 x 8: the A operand of the row sums
 
