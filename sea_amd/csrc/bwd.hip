@@ -1541,13 +1541,17 @@ __global__ __launch_bounds__(256) void ib_bwd_rows_kernel(const SeaIbBwdParams P
     }
 }
 
+// gridDim.y slices of the row splits (as colsum_finish_kernel: 16 adders per address, and enough workgroups to stream the partials — 9 workgroups walking 1024
+// splits one after the other took as long as the column kernel itself, 34 us at cfg3)
 __global__ __launch_bounds__(256) void ib_bwd_finish_kernel(const SeaIbBwdParams P, int rs) {
     const int n = P.E * (1 + P.h);
+    const int per = (rs + gridDim.y - 1) / gridDim.y;
+    const int b0 = blockIdx.y * per, b1 = b0 + per < rs ? b0 + per : rs;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
         float acc = 0.f;
 #pragma unroll 8
-        for (int b = 0; b < rs; ++b) acc += P.ws[(int64_t)b * n + i];
-        atomicAdd(i < P.E ? P.db2 + i : P.dw2 + (i - P.E), acc);
+        for (int b = b0; b < b1; ++b) acc += P.ws[(int64_t)b * n + i];
+        if (b0 < b1) atomicAdd(i < P.E ? P.db2 + i : P.dw2 + (i - P.E), acc);
     }
 }
 
@@ -1607,7 +1611,7 @@ extern "C" int sea_ib_bwd(const SeaIbBwdParams* params, void* stream) {
         ib_bwd_cols_kernel<<<dim3(n_cb, rs), dim3(256), 0, s0>>>(P, rows_per, n_cb);
         ib_bwd_rows_kernel<<<dim3((P.M + 255) / 256), dim3(256), 0, s0>>>(P, n_cb > 1 ? 1 : 0);
         const int n = P.E * (1 + P.h);
-        ib_bwd_finish_kernel<<<dim3((n + 255) / 256 < 256 ? (n + 255) / 256 : 256), dim3(256), 0, s0>>>(P, rs);
+        ib_bwd_finish_kernel<<<dim3((n + 255) / 256 < 256 ? (n + 255) / 256 : 256, rs >= 64 ? 16 : 1), dim3(256), 0, s0>>>(P, rs);
         SEA_CHECK_LAUNCH("sea_ib_bwd");
         return SEA_OK;
     }
