@@ -657,7 +657,7 @@ extern "C" int sea_gemm_rownorm(const SeaGemmNormGroup* groups, int n_groups, fl
             total += (groups[i].M + 15) / 16;
         }
     }
-    // whole-contraction LDS-DMA burst: every group's contraction is 1..4 whole K-tiles (128 bytes of K per row each); SEA_GEMM_NORM_DMA=0 disables
+    // whole-contraction LDS-DMA burst: every group's contraction is 1..4 whole K-tiles (128 bytes of K per row each); SEA_TUNE=gemm_norm_dma=0 disables
     static const int dma_on = sea_tune("gemm_norm_dma", 1);
     int dma_nk = 0;
     if (small && dma_on && total <= 256) {   // one workgroup per CU (its LDS is the whole contraction): only while the launch is a single round
