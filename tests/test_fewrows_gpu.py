@@ -211,6 +211,32 @@ def test_step_plan_of_fewrow_launches_equals_generic_step_plan_and_oracle(cfg_ar
     assert e_ab < 2e-2 and e_a < 3e-2 and e_b < 3e-2
 
 
+@pytest.mark.parametrize("cfg_args,B", [((1, 1024, 8, 32, 8, 0, 2, 2, True, "adaln"), 3), ((1, 1024, 8, 32, 8, 0, 2, 2, True, "ln"), 1)])
+def test_fewrow_step_plan_without_the_hoisted_condition_work(cfg_args, B, monkeypatch):
+    """SEA_KV=hoist=0: the AdaLN modulations / info-bottleneck rows are evaluated inside every step (silu + condition GEMM launches, the add as a launch of its
+    own for LayerNorm models) and the few-row launches read them from the step plan's own buffers — same rollout as with the hoisted buffers (bf16 rounding of
+    the batched against the per-step condition GEMM); 3 trajectories take the 4-row instantiations."""
+    from oracle import sea_oracle as O
+    from oracle.recipe import recipe_inputs
+    from sea_amd.utils.train_utils import rollout
+    from tests.test_model_gpu import build, rel_l2
+
+    cfg = O.OracleConfig(*cfg_args)
+    n = 10
+    x, _, ib = recipe_inputs(B, n, cfg, seed=8)
+    x0, ibg = x[:, :1].cuda().contiguous(), ib.cuda().contiguous()
+    m = build(cfg, "bf16")
+    eng = m.engine()
+    monkeypatch.setenv("SEA_KV", "hoist=1")
+    a = rollout(m, x0, ibg, n, mode="kv")
+    eng._plans.clear()
+    monkeypatch.setenv("SEA_KV", "hoist=0")
+    b = rollout(m, x0, ibg, n, mode="kv")
+    plans = [p for k, p in eng._plans.items() if k[:3] == (B, 1, "step")]
+    assert len(plans) == 1 and plans[0]._few and not plans[0]._hoisted
+    assert rel_l2(a.cpu().numpy(), b.cpu().numpy()) < 2e-2
+
+
 def eng_lib():
     from sea_amd import _native as N
 
