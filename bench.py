@@ -360,8 +360,10 @@ def leg_rollout(args, dist, dev, rank, world, steps, warmup, B):
     step = (lambda: eng.forward_graphed(x, ib)) if use_graph else (lambda: eng.forward(x, ib))
     log(f"rollout leg: cfg2 forward, B={B} per GPU, {'hip-graph' if use_graph else 'plain'} replay, {steps} timed steps")
     with torch.no_grad():
-        elapsed, out = _timed(step, steps, warmup, dist, dev)
-        assert torch.isfinite(out).all()
+        # The per-launch timing pass (every launch of the plan between HIP events, the dominant launch and the attention launches in bursts) runs BEFORE the
+        # timed steps since round 3: a step is 0.23 ms, so `--warmup 5` is 1 ms of device work and the timed region of a short call (`--steps 20`: 5 ms)
+        # used to measure the device coming out of idle — 0.2372 ms/step against 0.2248 for the same build once ~100 steps had run.
+        # The timed region itself is unchanged: W untimed steps, then exactly K steps between barrier + synchronize.
         plan = eng.plan(B, T, "full")
         out_keep = torch.empty_like(x)   # stays alive until the records have been timed (a freed output block can be unmapped — e.g. by the cache flush a graph
         plan.bind(x, ib, out_keep)       # capture starts with — under launches that still write it: seen as a memory fault when the final-norm launch was timed)
@@ -373,11 +375,14 @@ def leg_rollout(args, dist, dev, rank, world, steps, warmup, B):
         roof = _roofline(times, esz, pmc)
         attn = _attention_object(times)
         del out_keep
+        elapsed, out = _timed(step, steps, warmup, dist, dev)
+        assert torch.isfinite(out).all()
     ms = elapsed / steps * 1e3
     gflop = algorithmic_gflop(B, T, F, E, H, D, S, L)
     return {"value": world * B * steps / elapsed, "unit": "trajectory-steps/s", "ms_per_step": ms, "steps": steps,
             "workload": f"cfg2: cylinder_flow temporal model E={E} H={H} F={F} L={L} adaln, forward-only rollout step at T={T} (recompute mode), B={B} per GPU",
-            "replay": "hip-graph" if use_graph else "plain (one native call per step: sea_run_list)", "model_algorithmic_gflop_per_step": gflop,
+            "replay": "hip-graph" if use_graph else "plain (one native call per step: sea_run_list)", "order": "per-launch timing pass, then W warm-up + K timed steps",
+            "model_algorithmic_gflop_per_step": gflop,
             "model_mfma_frac": gflop / (ms * 1e-3) / 1e3 / PEAK_BF16_TFLOPS, "n_launches": len(times),
             "roofline": roof, "attention": attn, "launch_breakdown_ms": {r.name: round(t, 4) for r, t in times}}
 
