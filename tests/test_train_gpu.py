@@ -161,6 +161,38 @@ def test_gradients_at_multiphase_width_head_dim_256(dtype, tol):
     assert sorted(eng.params.live_names) == sorted(grads_ref.keys())
 
 
+@pytest.mark.parametrize("dtype,tol", [("bf16", 6e-2), ("fp32", 1e-4)])
+def test_gradients_at_cylinder_width(dtype, tol):
+    """embed_dim 1024, 8 heads, AdaLN, two field groups, two trajectories (the shipped cylinder_flow dims and batch: self-attention head dim 128, cross 64, MLP hidden
+    8192, condition MLPs of 2048 / 1024 columns), T = 72 (two key tiles): forward + backward against the CPU oracle's fp32 autograd — the widths at which the
+    round-3 backward kernels take their wide forms (rows of 8192 through rownorm_bwd_wide_kernel, the column-block backward of cond_mlp.0 + SiLU and of the
+    info-bottleneck MLP with four column blocks).  bf16 <= 6e-2 / fp32 <= 1e-4 over all parameters together, each within 10x of that."""
+    cfg = O.OracleConfig(1, 1024, 8, 80, 8, 0, 2, 2, True, "adaln")
+    p = recipe_params(cfg)
+    x, tgt, ib = recipe_inputs(2, 72, cfg, seed=15)
+    _, loss_ref, grads_ref = O.loss_and_grads(x, ib, tgt, p, cfg)
+    m = build(cfg, dtype).train()
+    eng = m.engine()
+    out, plan = eng.forward_train(x.cuda(), ib.cuda())
+    loss, dout = eng.mse_loss_and_grad(out, tgt.cuda())
+    eng.zero_grads()
+    eng.backward(plan, dout)
+    assert abs(loss.item() - float(loss_ref)) < tol * float(loss_ref)
+    num = den = 0.0
+    worst, worst_k = 0.0, None
+    for k, gr in grads_ref.items():
+        mine = eng.grad_view(k).cpu()
+        num += float((mine.double() - gr.double()).pow(2).sum())
+        den += float(gr.double().pow(2).sum())
+        e = rel_l2(mine.numpy(), gr.numpy())
+        if e > worst:
+            worst, worst_k = e, k
+    print(f"cylinder width {dtype} gradients: overall rel-L2 {(num / den) ** 0.5:.3e}, worst {worst_k} {worst:.3e}")
+    assert (num / den) ** 0.5 < tol
+    assert worst < 10 * tol, (worst_k, worst)
+    assert sorted(eng.params.live_names) == sorted(grads_ref.keys())
+
+
 @pytest.mark.parametrize("dtype,tol", [("fp32", 1e-4), ("bf16", 6e-2)])
 def test_cfg3_shape_gradients_match_reference_golden(dtype, tol):
     """BASELINE.json configs[2] at one trajectory (E=256, H=8, F=3, T=2024: every multi-tile path of the backward — 128-row weight-gradient
