@@ -475,8 +475,7 @@ __global__ __launch_bounds__(512) void attention_row_kernel(const SeaAttnParams 
             mx = fmaxf(mx, sc[j0 + jj]);
         }
     }
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    mx = wave_max_xor(mx, lane);
     if (lane == 0) red[wave] = mx;
     __syncthreads();
     float m = red[0];
@@ -495,8 +494,7 @@ __global__ __launch_bounds__(512) void attention_row_kernel(const SeaAttnParams 
     }
     const int nk8 = (nk + 7) & ~7;
     if (tid < nk8 - nk) prob[nk + tid] = 0.f;              // the tail of the last 8-key vector
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) ls += __shfl_xor(ls, o);
+    ls = wave_sum_xor(ls, lane);
     if (lane == 0) red[NW + wave] = ls;
     __syncthreads();
     float l = 0.f;
@@ -540,8 +538,7 @@ __global__ __launch_bounds__(512) void attention_row_kernel(const SeaAttnParams 
         }
 #pragma unroll
         for (int i = 0; i < DPW; ++i) {
-#pragma unroll
-            for (int o = 32; o >= 1; o >>= 1) acc[i] += __shfl_xor(acc[i], o);
+            acc[i] = wave_sum_xor(acc[i], lane);
             if (lane == 0) Og[wave * DPW + i] = from_f32<T>(acc[i] * inv);
         }
     }
@@ -613,16 +610,16 @@ __global__ __launch_bounds__(512) void attention_row_wide_kernel(const SeaAttnPa
 #pragma unroll
                 for (int e = 0; e < EPC; ++e) acc += q[c * EPC + e] * kv[e];
             }
-#pragma unroll
-            for (int o = 1; o < LPK; o <<= 1) acc += __shfl_xor(acc, o);
+            if constexpr (LPK >= 2) acc += lane_xor<1>(acc, lane);
+            if constexpr (LPK >= 4) acc += lane_xor<2>(acc, lane);
+            if constexpr (LPK >= 8) acc += lane_xor<4>(acc, lane);
             if (kk < nk) {
                 if (part == 0) prob[kk] = acc;
                 mx = fmaxf(mx, acc);
             }
         }
     }
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    mx = wave_max_xor(mx, lane);
     if (lane == 0) red[wave] = mx;
     __syncthreads();
     float m = red[0];
@@ -636,8 +633,7 @@ __global__ __launch_bounds__(512) void attention_row_wide_kernel(const SeaAttnPa
         ls += pv;
     }
     if (tid < nk8 - nk) prob[nk + tid] = 0.f;              // the tail of the last 8-key vector
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) ls += __shfl_xor(ls, o);
+    ls = wave_sum_xor(ls, lane);
     if (lane == 0) red[NW + wave] = ls;
     __syncthreads();
     float l = 0.f;
@@ -703,8 +699,7 @@ __global__ __launch_bounds__(512) void attention_row_wide_kernel(const SeaAttnPa
         }
 #pragma unroll
         for (int i = 0; i < DCH; ++i) {
-#pragma unroll
-            for (int o = 32; o >= 1; o >>= 1) acc[i] += __shfl_xor(acc[i], o);
+            acc[i] = wave_sum_xor(acc[i], lane);
             if (lane == 0) Og[wave * DPW + dc + i] = from_f32<T>(acc[i] * inv);
         }
     }

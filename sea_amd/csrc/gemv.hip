@@ -135,7 +135,7 @@ struct RowStage {
                 for (int e = 0; e < 8; ++e) xf[k][e] = (float)v[e];
                 s += ((xf[k][0] + xf[k][1]) + (xf[k][2] + xf[k][3])) + ((xf[k][4] + xf[k][5]) + (xf[k][6] + xf[k][7]));
             }
-            s = wave_sum(s);
+            s = wave_sum_xor(s, lane);
             if (lane == 0) red[m * 4 + wave] = s;
             __syncthreads();
             const float mean = (red[m * 4] + red[m * 4 + 1] + red[m * 4 + 2] + red[m * 4 + 3]) * inv_d;
@@ -150,7 +150,7 @@ struct RowStage {
                     }
                 }
             }
-            sq = wave_sum(sq);
+            sq = wave_sum_xor(sq, lane);
             if (lane == 0) red[MR * 4 + m * 4 + wave] = sq;
             __syncthreads();
             const float rstd = 1.0f / sqrtf((red[MR * 4 + m * 4] + red[MR * 4 + m * 4 + 1] + red[MR * 4 + m * 4 + 2] + red[MR * 4 + m * 4 + 3]) * inv_d + eps);
@@ -204,7 +204,7 @@ struct RowStage {
                 }
             }
             float s = ((xv[m][0] + xv[m][1]) + (xv[m][2] + xv[m][3])) + ((xv[m][4] + xv[m][5]) + (xv[m][6] + xv[m][7]));
-            s = wave_sum(s);
+            s = wave_sum_xor(s, lane);
             if (lane == 0) red[m * 4 + wave] = s;
         }
         __syncthreads();
@@ -219,7 +219,7 @@ struct RowStage {
                     sq += c * c;
                 }
             }
-            sq = wave_sum(sq);
+            sq = wave_sum_xor(sq, lane);
             if (lane == 0) red[MR * 4 + m * 4 + wave] = sq;
         }
         __syncthreads();
@@ -353,7 +353,7 @@ __global__ __launch_bounds__(256) void qkv_fewrows_kernel(const QkvFewLaunch L) 
     float v = few_core<MR, CW, KC>(static_cast<const T*>(G.A), static_cast<const T*>(G.W), G.lda, G.ldw, G.M, G.N, nw0, L.pre[gi], 0, false, L.eps, smem, tid);
     v += bv;
     // the other half of the rotation pair (columns 2 p, 2 p + 1 sit LSTRIDE lanes apart; both lanes of a pair are live or neither: N and col0 are even)
-    const float pv = __shfl_xor(live ? v : 0.f, S::LSTRIDE);
+    const float pv = lane_xor<S::LSTRIDE>(live ? v : 0.f, lane);
     if (!live) return;
     const uint32_t bh = (uint32_t)(bidx * H + h);
     if (part < 2) {

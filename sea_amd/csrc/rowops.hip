@@ -201,7 +201,7 @@ __global__ __launch_bounds__(1024) void rownorm_fewrows_kernel(const NormLaunch 
     float sum = 0.f;
 #pragma unroll
     for (int k = 0; k < KM; ++k) sum += (xv[k][0] + xv[k][1]) + (xv[k][2] + xv[k][3]);   // columns >= d hold zeros
-    sum = wave_sum(sum);
+    sum = wave_sum_xor(sum, lane);
     if (lane == 0) red[0][wave] = sum;
     __syncthreads();
     float tot = 0.f;
@@ -218,7 +218,7 @@ __global__ __launch_bounds__(1024) void rownorm_fewrows_kernel(const NormLaunch 
                 sq += c * c;
             }
         }
-    sq = wave_sum(sq);
+    sq = wave_sum_xor(sq, lane);
     if (lane == 0) red[1][wave] = sq;
     __syncthreads();
     tot = 0.f;

@@ -250,6 +250,57 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
+// Value of lane (lane ^ X) without the LDS crossbar (a ds_bpermute costs a trip through the LDS pipeline; a chain of six of them is most of what a few-row launch
+// does after its last load): half / row swaps for 32 / 16 (with vdst = src the two results of a swap hold the lower-half and the upper-half — the even-row and the
+// odd-row — value of every lane: the partner's is the one this lane does not own), DPP row rotations for 8 / 4 (row_ror:n gives lane i the value of lane
+// (i - n) mod 16), quad permutations for 2 / 1.
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+template <int X>
+__device__ __forceinline__ float lane_xor(float v, int lane) {
+    static_assert(X == 32 || X == 16 || X == 8 || X == 4 || X == 2 || X == 1, "lane_xor distance");
+    if constexpr (X == 32) {
+        const unsigned u = __float_as_uint(v);
+        const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+        return __uint_as_float((lane & 32) ? r[0] : r[1]);
+    } else if constexpr (X == 16) {
+        const unsigned u = __float_as_uint(v);
+        const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+        return __uint_as_float((lane & 16) ? r[0] : r[1]);
+    } else if constexpr (X == 8) {
+        return dpp_mov<0x128>(v);                       // row_ror:8
+    } else if constexpr (X == 4) {
+        const float dn = dpp_mov<0x124>(v), up = dpp_mov<0x12C>(v);   // row_ror:4: from lane i - 4; row_ror:12: from lane i + 4 (mod 16)
+        return (lane & 4) ? dn : up;
+    } else if constexpr (X == 2) {
+        return dpp_mov<0x4E>(v);                        // quad_perm:[2,3,0,1]
+    } else {
+        return dpp_mov<0xB1>(v);                        // quad_perm:[1,0,3,2]
+    }
+}
+// all 64 lanes' maximum in every lane
+__device__ __forceinline__ float wave_max_xor(float v, int lane) {
+    v = fmaxf(v, lane_xor<1>(v, lane));
+    v = fmaxf(v, lane_xor<2>(v, lane));
+    v = fmaxf(v, lane_xor<4>(v, lane));
+    v = fmaxf(v, lane_xor<8>(v, lane));
+    v = fmaxf(v, lane_xor<16>(v, lane));
+    v = fmaxf(v, lane_xor<32>(v, lane));
+    return v;
+}
+// all 64 lanes' sum in every lane
+__device__ __forceinline__ float wave_sum_xor(float v, int lane) {
+    v += lane_xor<1>(v, lane);
+    v += lane_xor<2>(v, lane);
+    v += lane_xor<4>(v, lane);
+    v += lane_xor<8>(v, lane);
+    v += lane_xor<16>(v, lane);
+    v += lane_xor<32>(v, lane);
+    return v;
+}
+
 // Sum over the 64 lanes of each of NV values (NV a power of two <= 64), total number (lane / (64 / NV)) left in lane `lane`: NV - 1 + (6 - log2 NV) exchanges
 // instead of 6 NV for NV separate butterflies, and the result spread over the lanes (one epilogue element per lane).
 // step with exchange distance X: the lanes whose bit X is set keep the upper half of the values and hand over the lower half (every stage in registers of
@@ -266,11 +317,11 @@ __device__ __forceinline__ float lane_scatter_step(const float (&v)[N], int lane
             const float lo = v[i], hi = v[i + N / 2];
             const float send = up ? lo : hi;
             const float keep = up ? hi : lo;
-            nv[i] = keep + __shfl_xor(send, X);
+            nv[i] = keep + lane_xor<X>(send, lane);
         }
         return lane_scatter_step<N / 2, X / 2>(nv, lane);
     } else {
-        const float nv[1] = {v[0] + __shfl_xor(v[0], X)};
+        const float nv[1] = {v[0] + lane_xor<X>(v[0], lane)};
         return lane_scatter_step<1, X / 2>(nv, lane);
     }
 }
