@@ -256,6 +256,10 @@ struct FewShape {
     static_assert(NV >= 1 && NV <= 64 && (NV & (NV - 1)) == 0 && CW * KC <= 32, "shape of a few-row launch");
 };
 
+// (Measured and not kept: for short contractions the A operand built in registers by every wave for itself — a lane's operand pieces are its own 16 bytes of the
+// rows, so a wave can load the rows, take the statistics by wave reductions and normalise in place: no LDS, no barrier.  Slower: 0.0776 -> 0.0840 ms per step at the
+// cylinder width, 0.152 -> 0.162 at the multiphase width — four times the row / gain / modulation requests per workgroup and 114-224 registers, which take the
+// 768-workgroup launches from one resident round to two.)
 // weights of the wave's CW columns (every fragment requested at once), the staged rows, the dot products, the exchange; returns this lane's (row, column) total
 template <int MR, int CW, int KC>
 __device__ __forceinline__ float few_core(const __bf16* A, const __bf16* W, int lda, int ldw, int M, int N, int nw0, const SeaNormGroup& pre, int pre_mode, bool writer, float eps,
