@@ -152,7 +152,7 @@ __global__ __launch_bounds__(256) void rownorm_kernel(const NormLaunch L) {
 // A FEW LONG rows (the KV-cache step of the shipped widths: one row of 8192 / 16384 hidden values per field): a wave per row walks such a row in three
 // dependent passes of d / 256 iterations (78 us for 2 rows of 16384 at the multiphase width).  Here a workgroup of 1024 threads owns a row: every thread
 // keeps its d / 4096 pieces of 4 columns in registers (one memory round trip), the two statistics cross the 16 waves through LDS.  d <= 32768.
-// KM = 1 (d <= 4096: a KV-cache step's rows at the shipped widths): the gains, shifts and modulations of the thread's one piece are requested WITH the row, so the launch is
+// KM <= 4 (d <= 16384: a KV-cache step's rows at the shipped widths): the gains, shifts and modulations of the thread's pieces are requested WITH the row, so the launch is
 // one memory round trip, not two (the wave-per-row kernel below takes 8 us for 2 rows of 2048, three dependent passes of 8 pieces).
 template <typename T, bool X_IS_ACT, int KM>
 __global__ __launch_bounds__(1024) void rownorm_fewrows_kernel(const NormLaunch L) {
@@ -168,15 +168,22 @@ __global__ __launch_bounds__(1024) void rownorm_fewrows_kernel(const NormLaunch 
     T* yact = G.Yact != nullptr ? static_cast<T*>(G.Yact) + (int64_t)row * G.ldyact : nullptr;
     const float inv_d = 1.0f / (float)d;
     float xv[KM][4];
-    float pg[4] = {0.f, 0.f, 0.f, 0.f}, pb[4] = {0.f, 0.f, 0.f, 0.f}, pw[4] = {0.f, 0.f, 0.f, 0.f}, pm[4] = {0.f, 0.f, 0.f, 0.f};   // KM == 1: requested up front
-    if constexpr (KM == 1) {
-        const int i = tid * 4;
-        if (i < d) {
-            load4(G.gamma + i, pg);
-            if (G.beta != nullptr) load4(G.beta + i, pb);
-            if (mod != nullptr) {
-                load4(mod + i, pw);
-                load4(mod + d + i, pm);
+    constexpr bool PRE = KM <= 4;            // gains / shifts / modulations of the thread's pieces requested up front, with the row
+    constexpr int KP = PRE ? KM : 1;
+    float pg[KP][4], pb[KP][4], pw[KP][4], pm[KP][4];
+    if constexpr (PRE) {
+#pragma unroll
+        for (int k = 0; k < KP; ++k) {
+            const int i = tid * 4 + NT * 4 * k;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) pg[k][e] = pb[k][e] = pw[k][e] = pm[k][e] = 0.f;
+            if (i < d) {
+                load4(G.gamma + i, pg[k]);
+                if (G.beta != nullptr) load4(G.beta + i, pb[k]);
+                if (mod != nullptr) {
+                    load4(mod + i, pw[k]);
+                    load4(mod + d + i, pm[k]);
+                }
             }
         }
     }
@@ -234,9 +241,9 @@ __global__ __launch_bounds__(1024) void rownorm_fewrows_kernel(const NormLaunch 
         const int i = tid * 4 + NT * 4 * k;
         if (i < d) {
             float g1[4], b1[4] = {0.f, 0.f, 0.f, 0.f}, w1[4] = {0.f, 0.f, 0.f, 0.f}, m1[4] = {0.f, 0.f, 0.f, 0.f}, o[4];
-            if constexpr (KM == 1) {
+            if constexpr (PRE) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) g1[e] = pg[e], b1[e] = pb[e], w1[e] = pw[e], m1[e] = pm[e];
+                for (int e = 0; e < 4; ++e) g1[e] = pg[k][e], b1[e] = pb[k][e], w1[e] = pw[k][e], m1[e] = pm[k][e];
             } else {
                 load4(G.gamma + i, g1);
                 if (G.beta != nullptr) load4(G.beta + i, b1);
@@ -386,6 +393,8 @@ extern "C" int sea_rownorm(const SeaNormGroup* groups, int n_groups, int M, int 
             } else {
                 rownorm_fewrows_kernel<float, false, 1><<<gridw, blockw, 0, s>>>(L);
             }
+        } else if (d <= 16384 && dtype == SEA_BF16 && x_is_act) {   // (the MLP's hidden rows of a KV-cache step at the shipped widths: 8192 / 16384 columns)
+            rownorm_fewrows_kernel<__bf16, true, 4><<<gridw, blockw, 0, s>>>(L);
         } else if (dtype == SEA_BF16) {
             if (x_is_act) rownorm_fewrows_kernel<__bf16, true, 8><<<gridw, blockw, 0, s>>>(L);
             else rownorm_fewrows_kernel<__bf16, false, 8><<<gridw, blockw, 0, s>>>(L);
