@@ -53,6 +53,9 @@ def algorithmic_gflop(B, T, F, E, H, D, S, L, adaln=True):
     return (L * per_layer + F * A(E)) / 1e9
 
 
+HBM_PEAK_BPS = 8.0e12    # MI355X_MICROARCH.md: HBM3E ~8 TB/s
+
+
 def record_work(rec, esz):
     """(algorithmic FLOPs, algorithmic HBM bytes) of ONE launch of a plan record, from the launch's own argument structs: matrix products count
     2mnk (causal attention over the visible pairs only), operands / weights / outputs are counted once."""
@@ -504,12 +507,29 @@ def leg_kv(args, dev, rank):
             torch.cuda.synchronize()
             res[mode] = (time.perf_counter() - t0) / reps
             assert torch.isfinite(r).all()
-        nbytes = sum(p.numel() for p in model.parameters()) * (2 if args.dtype == "bf16" else 4)
+        # bytes ONE step really reads: the sum over the step plan's own launches (their argument structs: weights, the few operand / output rows), NOT every
+        # parameter of the model — the dead parameters and the condition MLPs hoisted out of the loop (kv_engine.CondPlan) are not streamed
+        esz = 2 if args.dtype == "bf16" else 4
+        nbytes = sum(p.numel() for p in model.parameters()) * esz
+        step_bytes, n_launch = _kv_step_plan_bytes(model, esz)
         out[key] = {"steps_per_s": 100 / res["kv"], "ms_per_step": res["kv"] / 100 * 1e3, "recompute_steps_per_s": 100 / res["recompute"],
-                    "parameter_MB": nbytes / 1e6, "weight_read_GBps": nbytes * 100 / res["kv"] / 1e9,
-                    "workload": f"exact KV-cache rollout of 100 steps, B=1, E={E} H=8 F=2 L=1 {ln} (shipped width; every step streams the {nbytes / 1e6:.0f} MB of weights once)"}
+                    "parameter_MB": nbytes / 1e6, "step_plan_MB": step_bytes / 1e6, "step_plan_launches": n_launch,
+                    "weight_read_GBps": step_bytes * 100 / res["kv"] / 1e9, "hbm_frac": step_bytes * 100 / res["kv"] / HBM_PEAK_BPS,
+                    "workload": f"exact KV-cache rollout of 100 steps, B=1, E={E} H=8 F=2 L=1 {ln} (shipped width; a step's {n_launch} launches read {step_bytes / 1e6:.0f} MB, "
+                                f"of {nbytes / 1e6:.0f} MB of parameters: dead parameters and the hoisted condition MLPs are not streamed)"}
         del model
     return out
+
+
+def _kv_step_plan_bytes(model, esz):
+    """(algorithmic bytes, launches) of ONE KV-cache step at B = 1: the generic step plan with the condition work hoisted, exactly as engine.rollout_kv builds
+    it (tools/kv_shipped.py prints the same sum per launch)."""
+    from sea_amd import kv_engine
+
+    eng = model.engine()
+    p = eng.plan(1, 1, "step", cond=kv_engine.cond_plan_for(eng, 100))
+    recs = [r for r in p.records if r.fn is not None]
+    return sum(record_work(r, esz)[1] for r in recs), len(recs)
 
 
 def leg_shipped(args, dev, rank):
@@ -653,19 +673,29 @@ def launch_ranks(args) -> int:
                    MASTER_PORT=str(port))
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out0, _ = procs[0].communicate()
-    rcs = [procs[0].returncode]
-    deadline = time.time() + 120
-    for p in procs[1:]:
-        try:
-            rcs.append(p.wait(timeout=max(1.0, deadline - time.time())))
-        except subprocess.TimeoutExpired:
-            p.kill()
-            rcs.append(-9)
-    if any(rcs):
+    # rank 0's stdout is drained by a thread while EVERY child is polled: a rank that dies first (build failure, bad device) must end the job at once —
+    # rank 0 would otherwise sit in its first collective until the RCCL / gloo timeout
+    import threading
+
+    buf = []
+    reader = threading.Thread(target=lambda: buf.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    deadline = time.time() + float(os.environ.get("SEA_BENCH_RANK_TIMEOUT_S", "3000"))
+    failed = False
+    while any(p.poll() is None for p in procs):
+        if any(p.poll() not in (None, 0) for p in procs) or time.time() > deadline:
+            failed = True
+            break
+        time.sleep(0.2)
+    if failed:
+        time.sleep(1.0)   # let the others notice on their own (a clean error message beats a kill)
         for p in procs:
             if p.poll() is None:
                 p.kill()
+    rcs = [p.wait() for p in procs]
+    reader.join(timeout=10)
+    out0 = buf[0] if buf else b""
+    if any(rcs):
         print(f"[bench] rank exit codes {rcs}", file=sys.stderr)
         return 1
     lines = [ln for ln in out0.decode().splitlines() if ln.startswith("{")]
@@ -676,7 +706,21 @@ def launch_ranks(args) -> int:
     return 0
 
 
+def _dump_maps_at_exit():
+    """SEA_DUMP_MAPS=<file>: write /proc/self/maps when the interpreter shuts down (before the C library's exit handlers run) — the map that resolves
+    the frame addresses of a crash inside exit() (the rocprofv3 teardown fault of the KV leg, profiles/failures/)."""
+    path = os.environ.get("SEA_DUMP_MAPS")
+    if path:
+        import atexit
+
+        def dump():
+            with open("/proc/self/maps") as f, open(path, "w") as o:
+                o.write(f.read())
+        atexit.register(dump)
+
+
 def main():
+    _dump_maps_at_exit()
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200, help="timed steps of the headline leg (the other legs run a fixed fraction)")

@@ -1789,6 +1789,28 @@ static bool run_persistent(const SeaKvGlobal& G, const SeaKvLayer* layers, int p
             return false;
         }
         void* args[] = {&A};
+        // Under a rocprofiler-sdk tool (rocprofv3) the launch is a PLAIN one behind the same residency check done by hand (grid <= CUs x resident workgroups
+        // per CU): a process that has used the cooperative queue dies with SIGSEGV inside exit() when the tool is loaded — resolved in round 4 against the
+        // process map (profiles/failures/r04_rocprof_kv_exit_stack.txt): libc exit -> libamdhip64's exit handler (+0x3b8b8a) -> hsa_shut_down
+        // (libhsa-runtime64.so.1.18 +0x60080) -> the agent's queue teardown (+0x6359e), i.e. ROCr destroying the cooperative (GWS) queue under the tool's
+        // queue interception, after the tool has finalised.  Nothing of this library is on that stack (it keeps no HIP object alive); the same run with
+        // SEA_TUNE=kv_persist=0 exits 0.  SEA_TUNE=kv_coop=0 / 1 forces the plain / cooperative launch.
+        static const int coop = []() {
+            const int forced = sea_tune("kv_coop", -1);
+            if (forced >= 0) return forced;
+            const char* tool = getenv("ROCP_TOOL_LIBRARIES");
+            const char* pre = getenv("LD_PRELOAD");
+            const bool profiled = (tool != nullptr && tool[0] != 0) || (pre != nullptr && strstr(pre, "rocprofiler") != nullptr);
+            return profiled ? 0 : 1;
+        }();
+        if (!coop) {
+            if ((int)grid.x > cus * per_cu) return false;
+            if (hipLaunchKernel(fn, grid, block, args, (size_t)(lds * 4), s) != hipSuccess) {
+                (void)hipGetLastError();
+                return false;
+            }
+            return true;
+        }
         if (hipLaunchCooperativeKernel(fn, grid, block, args, (unsigned)(lds * 4), s) != hipSuccess) {
             (void)hipGetLastError();   // refused (too large for this device / a device without cooperative launch): the seven launches per step
             return false;

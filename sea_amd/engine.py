@@ -1402,7 +1402,8 @@ class TemporalEngine:
         p.generation = getattr(p, "generation", 0) + 1   # identifies the activation set now in the plan's workspace (autograd.py checks it)
         if p.drop_thr > 0:
             self._drop_step += 1
-            p.set_dropout_seed((torch.initial_seed() * 0x9E3779B1 + self._drop_step * 0x85EBCA77) & 0xFFFFFFFF)
+            from .parallel import rank as _dp_rank   # data parallel: every rank draws its own masks (the shards are different trajectories of one batch)
+            p.set_dropout_seed((torch.initial_seed() * 0x9E3779B1 + self._drop_step * 0x85EBCA77 + _dp_rank() * 0xC2B2AE35) & 0xFFFFFFFF)
         p.run()
         return out, p
 
@@ -1427,15 +1428,16 @@ class TemporalEngine:
                                         out.numel(), grad_scale, N.stream_ptr()), "sea_mse_fwd_bwd")
         return loss, dout
 
-    def train_step(self, x: torch.Tensor, target: torch.Tensor, ib: torch.Tensor, optimizer, allreduce: bool = True) -> torch.Tensor:
+    def train_step(self, x: torch.Tensor, target: torch.Tensor, ib: torch.Tensor, optimizer, allreduce: bool = True, loss_weight: float = 1.0) -> torch.Tensor:
         """One fused train step (train/train_temporal.py:254-258): zero grads, forward, MSE + its gradient, backward, the gradient
         all-reduce when torch.distributed is initialised (the MLP slice as soon as it is final, the rest after the backward: sea_amd/parallel.py) (`allreduce=False`: a rank-local step, e.g. to time the step without the collective),
-        AdamW.  Returns the local loss as a device scalar (no host sync)."""
+        AdamW.  Returns the local loss as a device scalar (no host sync).  `loss_weight` scales this rank's loss gradient (an uneven data-parallel
+        shard: rows * world / global rows, train/train_temporal.py)."""
         from .parallel import OverlappedGradientReduce
 
         optimizer.zero_grad(set_to_none=False)
         out, plan = self.forward_train(x, ib)
-        loss, dout = self.mse_loss_and_grad(out, target)
+        loss, dout = self.mse_loss_and_grad(out, target, grad_scale=float(loss_weight))
         red = OverlappedGradientReduce(self.grads, self.params.n_live, overlap=plan.dp) if allreduce else None
         self.backward(plan, dout, red.on_bucket if (red is not None and red.active) else None)
         scale = red.finish() if red is not None else 1.0

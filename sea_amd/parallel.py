@@ -28,6 +28,15 @@ def shard_batch(t: torch.Tensor, rank: int, world: int) -> torch.Tensor:
     return t[rank * per:(rank + 1) * per]
 
 
+def shard_bounds(B: int, rank: int, world: int) -> Tuple[int, int]:
+    """[lo, hi) of rank r's trajectories in a global batch of ANY size B: the first B % world ranks take one trajectory more (a ragged last batch of an
+    epoch — the reference's DataLoader has no drop_last, train/train_temporal.py:84 — still trains on every trajectory; the caller weights the rank's
+    mean loss by (hi - lo) * world / B so that the SUM all-reduce times 1 / world is the mean over the global batch)."""
+    per, extra = divmod(B, world)
+    lo = rank * per + min(rank, extra)
+    return lo, lo + per + (1 if rank < extra else 0)
+
+
 def allreduce_flat_gradients(flat_grads: torch.Tensor, n_live: int, group: Optional[dist.ProcessGroup] = None) -> float:
     """SUM-all-reduce the live prefix of the flat gradient buffer in ONE collective; returns the grad_scale (1/world) that turns the
     sum into the mean inside the optimizer kernel."""

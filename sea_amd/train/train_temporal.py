@@ -39,12 +39,35 @@ def get_model(config: Dict[str, Any], device: torch.device) -> Tuple[TemporalMod
     return model, SeaMSELoss(), optimizer
 
 
-def _init_data_parallel(config: Dict[str, Any], device: torch.device) -> Tuple[int, int]:
-    """(rank, world) of this process.  config['world_size'] > 1 without a process group: initialise one from the environment a launcher
-    (torch.distributed.run, bench.py) sets — backend "nccl" (= RCCL) on the GPU; config['dist_backend'] overrides (tests use gloo)."""
+def _rank_device(device: torch.device, want: int) -> torch.device:
+    """The GPU of THIS rank.  The reference configs say config['device'] = 'cuda' (configs/cylinder_flow.py:5) — device 0 in every process; with one process
+    per GPU rank r must run on the launcher's LOCAL_RANK (torch.distributed.run sets it; without it: RANK modulo the visible devices, which is 0 for
+    every rank of a one-GPU box).  The device is made CURRENT before anything is allocated: the native launches go to torch's current stream of the
+    current device (_native.stream_ptr), and RCCL refuses two ranks on one device."""
+    import os
+
+    if device.type != 'cuda' or want <= 1:
+        return device
+    n = torch.cuda.device_count()
+    local = os.environ.get("LOCAL_RANK")
+    if local is None:
+        local = int(os.environ.get("RANK", "0")) % max(n, 1)
+    local = int(local)
+    if n and local >= n:
+        raise RuntimeError(f"sea_amd.train: LOCAL_RANK = {local} but only {n} GPU(s) are visible to this process")
+    torch.cuda.set_device(local)
+    return torch.device('cuda', local)
+
+
+def _init_data_parallel(config: Dict[str, Any], device: torch.device) -> Tuple[int, int, torch.device]:
+    """(rank, world, device) of this process.  config['world_size'] > 1: the rank is bound to its own GPU first (_rank_device), then — without a process
+    group — one is initialised from the environment a launcher (torch.distributed.run, bench.py) sets: backend "nccl" (= RCCL) on the GPU, handed the
+    rank's device (`device_id`: RCCL communicators are then created eagerly on that device); config['dist_backend'] overrides (tests use gloo)."""
     import torch.distributed as dist
 
     want = int(config.get('world_size', 1) or 1)
+    if want > 1 and dist.is_available():
+        device = _rank_device(device, want)
     if want > 1 and dist.is_available() and not dist.is_initialized():
         import os
 
@@ -52,11 +75,28 @@ def _init_data_parallel(config: Dict[str, Any], device: torch.device) -> Tuple[i
             raise RuntimeError(f"sea_amd.train: config['world_size'] = {want} needs one process per GPU started by a launcher that sets RANK / WORLD_SIZE / "
                                "MASTER_ADDR / MASTER_PORT (python -m torch.distributed.run --nproc-per-node N ...), or an initialised torch.distributed group")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(config.get('dist_backend', 'nccl' if device.type == 'cuda' else 'gloo'))
+        backend = config.get('dist_backend', 'nccl' if device.type == 'cuda' else 'gloo')
+        if backend == 'nccl' and device.type == 'cuda':
+            dist.init_process_group(backend, device_id=device)
+        else:
+            dist.init_process_group(backend)
     world, rank = parallel.world_size(), parallel.rank()
     if want > 1 and world != want:
         raise RuntimeError(f"sea_amd.train: config['world_size'] = {want} but the process group has {world} ranks")
-    return rank, world
+    return rank, world, device
+
+
+class _RankZeroTracker:
+    """The caller's error tracker on rank 0, a no-op elsewhere: one logger run and one set of records per JOB (every rank holds the same averaged numbers)."""
+
+    def __init__(self, tracker, rank: int):
+        self._t, self._on = tracker, rank == 0
+
+    def __getattr__(self, name):
+        attr = getattr(self._t, name)
+        if self._on or not callable(attr):
+            return attr
+        return lambda *a, **k: None
 
 
 def _loader_shards_itself(loader) -> bool:
@@ -85,7 +125,9 @@ def train(config: Dict[str, Any], error_tracker):
                            "raw mesh data needs the spatial autoencoder pipeline, which this build does not cover")
     trainLoader, validationLoader, _ = config['loaders']
     device = torch.device(config['device'])
-    rank, world = _init_data_parallel(config, device)
+    rank, world, device = _init_data_parallel(config, device)
+    if world > 1:
+        error_tracker = _RankZeroTracker(error_tracker, rank)   # one logger run / one set of records per job
     model, loss_fn, optimizer = get_model(config, device)
     scheduler = None
     if isinstance(optimizer, tuple):
@@ -103,26 +145,43 @@ def train(config: Dict[str, Any], error_tracker):
     processor, mesh_processor = config.get('processor'), config.get('mesh_processor')   # the reference builds both in get_datasets (:225-230)
     error_tracker.log_model(model, loss_fn, optimizer)
     full_eval_interval = config.get('full_eval_interval', 50)
+    skipped_small = False
     for epoch in range(1, config['epoch_num'] + 1):
         model.train()
         loss_sum = torch.zeros((), device=device)  # accumulated on the device: one host sync per epoch, not per step
+        n_batches = 0
         for data, target, _, ib in trainLoader:
-            if shard:   # rank r's trajectories of the global batch (parallel.shard_batch raises when the batch does not divide)
-                data, target, ib = (parallel.shard_batch(t, rank, world) for t in (data, target, ib))
+            weight = 1.0
+            if shard:
+                # rank r's trajectories of the global batch.  A batch that does not divide by the world size — the reference's loader has no drop_last
+                # (train/train_temporal.py:84), so the last batch of an epoch is usually ragged — is split unevenly and the rank's mean loss weighted by its
+                # share, so that SUM over ranks / world is the mean over the global batch; a batch with fewer trajectories than ranks is skipped by
+                # EVERY rank (a rank without rows would have no forward to run the fused step around), once with a warning
+                Bg = data.shape[0]
+                if Bg < world:
+                    if not skipped_small:
+                        skipped_small = True
+                        if rank == 0:
+                            print(f"sea_amd.train: a batch of {Bg} trajectories cannot be split over {world} ranks: such batches are skipped (use drop_last or a batch size >= world_size)")
+                    continue
+                lo, hi = parallel.shard_bounds(Bg, rank, world)
+                weight = (hi - lo) * world / Bg
+                data, target, ib = (t[lo:hi] for t in (data, target, ib))
+            n_batches += 1
             data, target, ib = data.to(device), target.to(device), ib.to(device)
             if fused:
-                loss = model.engine(device).train_step(data.float(), target.float(), ib.float(), optimizer)
-                loss_sum += loss.reshape(())
+                loss = model.engine(device).train_step(data.float(), target.float(), ib.float(), optimizer, loss_weight=weight)
+                loss_sum += loss.reshape(()) * weight
                 continue
             optimizer.zero_grad()
             outputs = model(data, ib)
             loss = loss_fn(outputs, target)
-            loss.backward()
+            (loss * weight if weight != 1.0 else loss).backward()
             optimizer.step()
-            loss_sum += loss.detach()
+            loss_sum += loss.detach() * weight
         if scheduler is not None:
             scheduler.step()
-        train_loss = _mean_over_ranks(loss_sum, world).item() / max(len(trainLoader), 1)
+        train_loss = _mean_over_ranks(loss_sum, world).item() / max(n_batches, 1)
         error_tracker.record_error("train", epoch, {"Loss": train_loss})
         if epoch % config.get('validation_interval', 1) == 0 or epoch == config['epoch_num']:
             model.eval()
@@ -135,7 +194,9 @@ def train(config: Dict[str, Any], error_tracker):
             val_loss = val_sum.item() / max(n_val, 1)
             val_metrics = {"Loss": val_loss}
             if epoch % full_eval_interval == 0:
-                res = full_autoregressive_evaluation(model, validationLoader, loss_fn, device, processor, mesh_processor, config, epoch, plot_traj=False)
+                # every rank evaluates (identical models: identical numbers, and the checkpoint decision below must agree); rank 0 alone writes the CSV
+                res = full_autoregressive_evaluation(model, validationLoader, loss_fn, device, processor, mesh_processor,
+                                                     (config if rank == 0 else {**config, 'save_dir': None}), epoch, plot_traj=False)
                 if res is not None:   # None: an empty validation loader
                     val_metrics["Full_Encoded_Rel_MSE"] = res['encoded_rel_mse']
                     if processor is not None and mesh_processor is not None:

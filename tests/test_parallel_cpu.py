@@ -111,12 +111,52 @@ def test_train_entry_data_parallel_plumbing(monkeypatch):
         monkeypatch.delenv(k, raising=False)
     with pytest.raises(RuntimeError, match="world_size"):
         tt._init_data_parallel({"world_size": 2}, torch.device("cpu"))
-    assert tt._init_data_parallel({"world_size": 1}, torch.device("cpu")) == (0, 1)
-    assert tt._init_data_parallel({}, torch.device("cpu")) == (0, 1)
+    assert tt._init_data_parallel({"world_size": 1}, torch.device("cpu")) == (0, 1, torch.device("cpu"))
+    assert tt._init_data_parallel({}, torch.device("cpu")) == (0, 1, torch.device("cpu"))
     ds = TensorDataset(torch.arange(8.0))
     assert not tt._loader_shards_itself(DataLoader(ds, batch_size=4))
     assert not tt._loader_shards_itself([(1, 2, 3, 4)])
     assert tt._loader_shards_itself(DataLoader(ds, batch_size=4, sampler=DistributedSampler(ds, num_replicas=2, rank=0)))
+
+
+def test_train_entry_binds_each_rank_to_its_own_gpu(monkeypatch):
+    """Row j1: with one process per GPU, rank r of train() runs on the launcher's LOCAL_RANK — config['device'] = 'cuda' (the reference configs) is device 0
+    in EVERY process otherwise, and RCCL refuses two ranks on one device.  torch.cuda is mocked (no GPU here): the device is made current before any
+    allocation and handed back for everything train() creates; without LOCAL_RANK the rank is folded onto the visible devices."""
+    from sea_amd.train import train_temporal as tt
+
+    calls = []
+    monkeypatch.setattr(torch.cuda, "set_device", lambda d: calls.append(d))
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 8)
+    monkeypatch.setenv("RANK", "5")
+    monkeypatch.setenv("LOCAL_RANK", "5")
+    assert tt._rank_device(torch.device("cuda"), 8) == torch.device("cuda", 5) and calls == [5]
+    monkeypatch.delenv("LOCAL_RANK")
+    monkeypatch.setenv("RANK", "11")   # second node of a two-node job without LOCAL_RANK: 11 % 8
+    assert tt._rank_device(torch.device("cuda"), 16) == torch.device("cuda", 3) and calls == [5, 3]
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 1)   # the one-GPU test box: both gloo ranks share cuda:0
+    monkeypatch.setenv("RANK", "1")
+    assert tt._rank_device(torch.device("cuda"), 2) == torch.device("cuda", 0) and calls[-1] == 0
+    monkeypatch.setenv("LOCAL_RANK", "3")
+    with pytest.raises(RuntimeError, match="LOCAL_RANK"):
+        tt._rank_device(torch.device("cuda"), 8)
+    n = len(calls)
+    assert tt._rank_device(torch.device("cuda"), 1) == torch.device("cuda") and len(calls) == n   # single process: untouched
+    assert tt._rank_device(torch.device("cpu"), 2) == torch.device("cpu") and len(calls) == n
+
+
+def test_uneven_shards_cover_a_ragged_batch():
+    """parallel.shard_bounds: any global batch size is split into contiguous, disjoint, covering shards whose sizes differ by at most one, and the
+    loss weights (rows * world / B) average to 1 — the SUM all-reduce times 1 / world is then the mean over the global batch."""
+    from sea_amd import parallel
+
+    for world in (1, 2, 3, 8):
+        for B in (1, 2, 3, 5, 8, 13, 64):
+            spans = [parallel.shard_bounds(B, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == B and all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [hi - lo for lo, hi in spans]
+            assert max(sizes) - min(sizes) <= 1
+            assert abs(sum(n * world / B for n in sizes) / world - 1.0) < 1e-12
 
 
 def _train_plumbing_worker(rank, world, port, ret):
@@ -125,7 +165,7 @@ def _train_plumbing_worker(rank, world, port, ret):
         from sea_amd.train import train_temporal as tt
 
         got = tt._init_data_parallel({"world_size": world, "dist_backend": "gloo"}, torch.device("cpu"))   # starts the group from the environment
-        assert got == (rank, world) and dist.is_initialized()
+        assert got == (rank, world, torch.device("cpu")) and dist.is_initialized()
         v = tt._mean_over_ranks(torch.tensor(float(rank + 1)), world)
         assert float(v) == 1.5
         try:

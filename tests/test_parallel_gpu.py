@@ -121,7 +121,8 @@ def _train_config(save_dir, fused, world):
     base = torch.randn(8, 13, 3, 64).cumsum(dim=1) * 0.1
     ib = torch.rand(8, 13, 1)
     batch = lambda sl: (base[sl, :-1], base[sl, 1:], base[sl, 1:], ib[sl, :-1])   # noqa: E731  (host tensors: train() shards, then moves to the device)
-    config["loaders"] = ([batch(slice(0, 4)), batch(slice(4, 6))], [batch(slice(6, 8))], [batch(slice(6, 8))])   # global batches of 4 and 2 trajectories
+    # global batches of 4, 2 and — ragged at world 2, like the last batch of a reference epoch (no drop_last) — 3 trajectories
+    config["loaders"] = ([batch(slice(0, 4)), batch(slice(4, 6)), batch(slice(3, 6))], [batch(slice(6, 8))], [batch(slice(6, 8))])
     return config
 
 
@@ -148,8 +149,8 @@ def _run_train(save_dir, fused, world):
 
 def _train_worker(rank, world, port, save_dir, ret):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))   # what a launcher sets: train() starts the group itself
-    backend = os.environ.get("SEA_TEST_DP_BACKEND", "gloo")
-    torch.cuda.set_device(rank if backend == "nccl" else 0)
+    if os.environ.get("SEA_TEST_DP_BACKEND", "gloo") == "nccl":
+        os.environ["LOCAL_RANK"] = str(rank)   # what torch.distributed.run sets; train() itself binds the rank to that GPU (no set_device here)
     try:
         # both step forms in ONE pair of processes (a fresh process costs the box a minute of imports): the first train() starts the process group from the
         # environment, the second finds it initialised
@@ -164,7 +165,8 @@ def _train_worker(rank, world, port, save_dir, ret):
 def test_train_entry_is_data_parallel(tmp_path):
     """train(config, tracker) (reference loop train/train_temporal.py:252-258) run by 2 ranks — each started like a launcher would (RANK / WORLD_SIZE /
     MASTER_* in the environment, config['world_size'] = 2) — equals the single-process run on the global batches: same epoch losses, parameters equal
-    to the rounding of 6 AdamW steps (rel-L2 <= 1e-5, every element within 6e-5 = a few percent of one lr-sized update), bit-identical across the ranks.
+    to the rounding of 9 AdamW steps (rel-L2 <= 1e-5, every element within 9e-5 = a few percent of one lr-sized update), bit-identical across the ranks.
+    The third batch of every epoch has 3 trajectories: uneven shards (2 + 1) with the loss weights of parallel.shard_bounds.
     Covers the parameter broadcast (rank 1 draws different initial weights, see _run_train), the per-rank shard of every loader batch, and the gradient
     all-reduce of both step forms: the fused step (slices under the backward) and `loss.backward(); optimizer.step()` (one collective inside
     FlatAdamW.step)."""
@@ -181,8 +183,11 @@ def test_train_entry_is_data_parallel(tmp_path):
         p_ref, l_ref = ref[fused]
         for r in range(2):
             p, losses = got[r][fused]
-            assert np.allclose(losses, l_ref, rtol=1e-5, atol=0), (fused, r, losses, l_ref)
-            assert np.linalg.norm(p - p_ref) <= 1e-5 * np.linalg.norm(p_ref) and np.abs(p - p_ref).max() <= 6e-5, (fused, r)
+            if r == 0:
+                assert np.allclose(losses, l_ref, rtol=1e-5, atol=0), (fused, r, losses, l_ref)
+            else:
+                assert losses.size == 0   # one set of tracker records per job: rank 0's
+            assert np.linalg.norm(p - p_ref) <= 1e-5 * np.linalg.norm(p_ref) and np.abs(p - p_ref).max() <= 9e-5, (fused, r)
         assert np.array_equal(got[0][fused][0], got[1][fused][0])
     # the two step forms are the same arithmetic up to the order of the gradient reduction
     assert np.linalg.norm(ref[True][0] - ref[False][0]) <= 1e-5 * np.linalg.norm(ref[True][0])

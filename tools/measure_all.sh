@@ -3,8 +3,8 @@
 #   tools/measure_all.sh [tag] [stage ...]   -> gpurun_out/<tag>/   (default tag: final; stages: bench traces pmcf pmct, default all four);
 #   tools/collect_profiles.py <tag> rNN copies the judged files into profiles/
 # Counter passes are processes of their own with --kernel-trace only (never a hip / hsa / sys trace beside --pmc), the program directly behind `--`.
-# rocprofv3 may die in its own teardown AFTER it has written its files (seen once with the KV leg: profiles/failures/r03_rocprof_kv_segfault.err): a trace
-# step counts as done when its per-kernel summary exists.
+# A trace step fails on ANY non-zero exit of rocprofv3 (round 3 tolerated a SIGSEGV inside exit() of the KV leg; its cause — ROCr tearing down the cooperative
+# queue under the tool's queue interception — is recorded in profiles/failures/r04_rocprof_kv_exit_stack.txt and avoided in kvstep.hip).
 set -o pipefail
 O=gpurun_out/${1:-final}
 shift
@@ -17,7 +17,7 @@ prof() {   # prof <dir> <log> <program...>: kernel trace + per-kernel summary; s
   rocprofv3 --kernel-trace --stats --output-format csv -d $O/$d -o run -- "$@" > $O/$log 2> $O/$d.err
   local rc=$?
   find $O/$d -name "*kernel_stats.csv" | grep -q . || { echo "rocprofv3 $d: no summary (exit $rc)"; return 1; }
-  [ $rc -ne 0 ] && echo "rocprofv3 $d: exit $rc after writing its files" && cp $O/$d.err $O/${d}_rocprof_exit_$rc.err
+  if [ $rc -ne 0 ]; then echo "rocprofv3 $d: EXIT $rc (signal $((rc > 128 ? rc - 128 : 0)))"; cp $O/$d.err $O/${d}_rocprof_exit_$rc.err; return 1; fi
   return 0
 }
 if has bench; then
