@@ -91,6 +91,15 @@ def record_work(rec, esz):
         for g in rec.keep[:a[1]]:
             fl += g.n_seg * 2 * g.M * g.D * g.D + 2 * g.M * g.D * g.E + (2 * g.M * g.E * g.D if g.has_down else 0)
             by += g.n_seg * (g.M * g.D * esz + g.D * g.D * esz) + g.D * g.E * esz + 2 * g.M * g.E * 4 + (g.E * g.D * esz + g.M * g.D * esz if g.has_down else 0)
+    elif rec.fn is L.sea_row_chain:
+        for g in a[0][:a[1]]:
+            K2 = g.D if g.n_seg > 0 else g.E
+            fl += g.n_seg * 2 * g.M * g.D * g.D + 2 * g.M * K2 * g.E + (2 * g.M * g.E * g.D if g.has_down else 0)
+            by += g.n_seg * (g.M * g.D * esz + g.D * g.D * esz) + (g.M * g.E * esz if g.n_seg == 0 else 0) + K2 * g.E * esz + 2 * g.M * g.E * 4 \
+                + (g.E * g.D * esz + (g.M * 2 * g.D * esz if g.down.mod else 0) if g.has_down else 0)
+            for q in g.proj[:g.n_proj]:
+                fl += 2 * g.M * q.N * q.K
+                by += q.N * q.K * esz + g.M * q.N * esz
     elif rec.fn is L.sea_attention_fwd:
         P = rec.keep
         tri = P.Tq * (P.Tq + 1) // 2 + P.Tq * (P.Tk - P.Tq)

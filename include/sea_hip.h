@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define SEA_ABI_VERSION 6
+#define SEA_ABI_VERSION 7
 
 enum { SEA_F32 = 0, SEA_BF16 = 1 };
 
@@ -41,7 +41,7 @@ enum {
 int sea_abi_version(void);
 const char* sea_last_error(void);
 /* sizeof of every ABI struct in declaration order (SeaGemmGroup, SeaQkvGroup, SeaQkvCommon, SeaAttnProblem,
- * SeaAttnParams, SeaNormGroup, SeaSiluGroup, SeaIbParams, ..., SeaLaunchRec, SeaGemmNormGroup, SeaExchangeTail, SeaMlpGroup, SeaMlp2Group, SeaKvNorm, SeaKvField, SeaKvPair, SeaKvLayer, SeaKvGlobal, SeaStepPatch last): lets a binding verify its layout.  Host only. */
+ * SeaAttnParams, SeaNormGroup, SeaSiluGroup, SeaIbParams, ..., SeaLaunchRec, SeaGemmNormGroup, SeaExchangeTail, SeaMlpGroup, SeaMlp2Group, SeaKvNorm, SeaKvField, SeaKvPair, SeaKvLayer, SeaKvGlobal, SeaStepPatch, SeaRowChain last): lets a binding verify its layout.  Host only. */
 int sea_struct_sizes(int* out, int cap);
 /* Number of compute units / name of device 0's architecture as HIP reports them (diagnostics for bench.py). */
 int sea_device_info(int* cu_count, char* arch, int arch_len);
@@ -437,7 +437,7 @@ int sea_adamw_flat(float* p, const float* g, float* m, float* v, void* shadow, i
  * ============================================================================================================ */
 
 /* Weight gradient of y = x W^T + b for several layers per launch: dW[N,K] += dY[M,N]^T . X[M,K]; db[N] += sum_m dY[m,:]
- * (db may be NULL).  The contraction over M is split across workgroups.  N % 8 == 0, K % 8 == 0.  At most 32 groups per call (weight gradients
+ * (db may be NULL).  The contraction over M is split across workgroups (unless M is short).  N % 8 == 0, K % 8 == 0.  At most 32 groups per call (weight gradients
  * have no consumers inside the backward: a caller may collect the small ones of a layer and run them as one call). */
 typedef struct {
     const void* dY; /* act [M, N] row stride lddy */
@@ -446,6 +446,9 @@ typedef struct {
     float* db;      /* f32 [N] accumulated, or NULL */
     int32_t lddy, ldx, lddw;
     int32_t M, N, K;
+    int32_t overwrite;   /* non-zero: dW holds zeros and this launch is its only contribution in the step — the kernel may STORE instead of adding
+                          * (taken when the contraction is not split across workgroups; db is always accumulated) */
+    int32_t pad_;
 } SeaWgradGroup;
 int sea_wgrad_grouped(const SeaWgradGroup* groups, int n_groups, int dtype, void* stream);
 
@@ -553,6 +556,48 @@ typedef struct {
 int sea_ib_bwd(const SeaIbBwdParams* params, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
+ * A ROW-LOCAL CHAIN of the state-exchange block in one launch (bf16 compute; a workgroup owns 16 or 32 rows from an attention launch's output to the
+ * next attention launch's operands; sea_amd/csrc/chain.hip).  Per group (field), in order:
+ *   form A (n_seg = 0):   x = Xin + a2[M,E] . W2[E,E]^T (+ b2)                          self-attention out-projection + residual
+ *                                                                                       (models/base_blocks.py:201, models/temporal.py:136)
+ *   form B (n_seg >= 1):  g = sum_s gelu_erf(att_s[M,D] . Wp_s[D,D]^T);  x = Xin + g . W2[E,D]^T + bias_scale * b2
+ *                                                                                       (cross_attn[i][j].projection + GELU, cross_up[i] of the sum, the residual:
+ *                                                                                       models/temporal.py:183-191 — exactly sea_exchange_tail's first two layers)
+ *   X <- x (f32; Xin and X may be the same rows, or Xin the caller's strided [B,T,F,E] tensor);  Xact <- (act) x when non-NULL
+ *   has_down:             y = LayerNorm_D(x . Wd[D,E]^T + bd) with gamma / beta / mod as SeaNormGroup -> down.Yact / down.Y32 when non-NULL
+ *                                                                                       (cross_down[i] + ln_cross[i], models/temporal.py:177-181)
+ *   n_proj entries:       columns [col0, col0 + N) of the virtual [q | k | v] row of  y . W[N,D]^T + bias, rotary embedding on q / k, q scale, written in the
+ *                         attention layouts exactly as sea_qkv_rope_grouped (proj[e].A / lda / M are ignored; K = D; an entry is a q projection — N = D, col0 = 0 — or
+ *                         a k | v projection — N = 2 D, col0 = D):
+ *                         every q of the field and the k / v of the pairs that read this field's rows at this point of the Gauss-Seidel sweep
+ *                         (models/base_blocks.py:271-280; models/temporal.py:187-192)
+ * `down` is read as in SeaExchangeTail.  Requirements: dtype SEA_BF16; (D, E) in {(128, 256), (64, 128)}; n_seg * D <= E; H * hd == D for the projections;
+ * sum of the projections' N <= 1024; head dim 16 or 32 (16 for launches of more than 256 16-row tiles), col0 a multiple of 16; strides multiples of 8 (act) / 4 (f32); pointers
+ * 16-byte aligned.  Returns SEA_EUNSUPPORTED for other shapes / dtypes (callers keep the separate launches).
+ */
+#define SEA_CHAIN_MAX_PROJ 6
+#define SEA_CHAIN_MAX_GROUPS 3
+typedef struct {
+    const void* att[SEA_XTAIL_MAX_SEG];   /* act [M, D], row stride ldatt (form B) */
+    const void* Wp[SEA_XTAIL_MAX_SEG];    /* act [D, D], row stride ldwp */
+    const void* a2;                       /* act [M, E], row stride lda2 (form A) */
+    const void* W2;                       /* act [E, K2], row stride ldw2; K2 = D (form B) or E (form A) */
+    const float* b2;                      /* f32 [E] or NULL */
+    const float* Xin;                     /* f32 [M, E], row stride ldxin: the residual rows */
+    float* X;                             /* f32 [M, E], row stride ldx: the updated rows (may alias Xin) */
+    void* Xact;                           /* act [M, E], row stride ldxact, or NULL */
+    int32_t n_seg, ldatt, ldwp, lda2, ldw2, ldxin, ldx, ldxact;
+    int32_t M, D, E, has_down, n_proj;
+    float bias_scale;
+    SeaGemmNormGroup down;
+    SeaQkvGroup proj[SEA_CHAIN_MAX_PROJ];
+} SeaRowChain;
+
+/* params: n_groups <= SEA_CHAIN_MAX_GROUPS problems of one (D, E) (e.g. the F fields), one grid row each; common: rotary table, heads, positions of the projections
+ * (may be NULL when no group has projections) */
+int sea_row_chain(const SeaRowChain* params, int n_groups, const SeaQkvCommon* common, float eps, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
  * Launch list: a whole plan (every launch of TemporalModel.forward, models/temporal.py:405-416, in order) replayed by ONE call, so the host
  * side of a replay is a C loop over prepared argument structs instead of one interpreter round trip per launch (KV-cache rollout steps
  * and plain, un-captured forwards are host-bound otherwise).  `op` selects the entry point, the other fields are its arguments:
@@ -565,9 +610,10 @@ int sea_ib_bwd(const SeaIbBwdParams* params, void* stream);
  *     SEA_OP_MLP2   p0 = SeaMlp2Group[n], f0 = eps
  *     SEA_OP_GEMM_FEW p0 = SeaGemmGroup[n], p1 = pre or NULL, i0 = pre_x_is_act, i1 = pre_gelu, f0 = eps
  *     SEA_OP_QKV_FEW  p0 = SeaQkvGroup[n], p1 = SeaQkvCommon, l0 = (intptr) pre or 0, f0 = eps
+ *     SEA_OP_CHAIN    p0 = SeaRowChain[n], p1 = SeaQkvCommon or NULL, f0 = eps
  * Returns 0, or the failing entry's error code with sea_last_error() set (entries before it have been launched).
  */
-enum { SEA_OP_GEMM = 1, SEA_OP_QKV = 2, SEA_OP_ATTN = 3, SEA_OP_NORM = 4, SEA_OP_SILU = 5, SEA_OP_IB = 6, SEA_OP_CONVERT = 8, SEA_OP_GEMM_NORM = 9, SEA_OP_XTAIL = 10, SEA_OP_MLP1 = 11, SEA_OP_MLP2 = 13, SEA_OP_GEMM_FEW = 14, SEA_OP_QKV_FEW = 15 };   /* 7 and 12 were round-1 entry points (sea_rowchain, sea_cond_mlp), removed in ABI v2 */
+enum { SEA_OP_GEMM = 1, SEA_OP_QKV = 2, SEA_OP_ATTN = 3, SEA_OP_NORM = 4, SEA_OP_SILU = 5, SEA_OP_IB = 6, SEA_OP_CONVERT = 8, SEA_OP_GEMM_NORM = 9, SEA_OP_XTAIL = 10, SEA_OP_MLP1 = 11, SEA_OP_MLP2 = 13, SEA_OP_GEMM_FEW = 14, SEA_OP_QKV_FEW = 15, SEA_OP_CHAIN = 16 };   /* 7 and 12 were round-1 entry points (sea_rowchain, sea_cond_mlp), removed in ABI v2 */
 typedef struct {
     int32_t op, n, dtype, i0, i1, i2, i3;
     float f0;

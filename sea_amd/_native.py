@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libsea_hip.so")
 
 SEA_F32, SEA_BF16 = 0, 1
-ABI_VERSION = 6   # include/sea_hip.h SEA_ABI_VERSION
+ABI_VERSION = 7   # include/sea_hip.h SEA_ABI_VERSION
 MAX_GROUPS = 16
 MAX_ATTN_PROBLEMS = 8
 MAX_NORM_GROUPS = 16
@@ -75,7 +75,7 @@ class SeaIbParams(C.Structure):
 
 class SeaWgradGroup(C.Structure):
     _fields_ = [("dY", _vp), ("X", _vp), ("dW", _vp), ("db", _vp), ("lddy", _i32), ("ldx", _i32), ("lddw", _i32),
-                ("M", _i32), ("N", _i32), ("K", _i32)]
+                ("M", _i32), ("N", _i32), ("K", _i32), ("overwrite", _i32), ("pad_", _i32)]
 
 
 class SeaNormBwdGroup(C.Structure):
@@ -107,7 +107,7 @@ class SeaAttnBwdParams(C.Structure):
                 ("ldo", _i32), ("lddo", _i32), ("lddq", _i32), ("lddk", _i32), ("lddv", _i32), ("q_scale", _f32), ("drop", SeaDropout)]
 
 
-OP_GEMM, OP_QKV, OP_ATTN, OP_NORM, OP_SILU, OP_IB, OP_CONVERT, OP_GEMM_NORM, OP_XTAIL, OP_MLP1, OP_MLP2, OP_GEMM_FEW, OP_QKV_FEW = 1, 2, 3, 4, 5, 6, 8, 9, 10, 11, 13, 14, 15
+OP_GEMM, OP_QKV, OP_ATTN, OP_NORM, OP_SILU, OP_IB, OP_CONVERT, OP_GEMM_NORM, OP_XTAIL, OP_MLP1, OP_MLP2, OP_GEMM_FEW, OP_QKV_FEW, OP_CHAIN = 1, 2, 3, 4, 5, 6, 8, 9, 10, 11, 13, 14, 15, 16
 FEW_MAX_GROUPS = 8     # sea_gemm_fewrows / sea_qkv_rope_fewrows (gemv.hip)
 FEW_K = (512, 1024, 2048, 4096, 8192, 16384)
 
@@ -139,6 +139,17 @@ class SeaExchangeTail(C.Structure):
                 ("n_seg", _i32), ("ldatt", _i32), ("ldwp", _i32), ("ldwup", _i32), ("ldx", _i32), ("ldxact", _i32),
                 ("M", _i32), ("D", _i32), ("E", _i32), ("has_down", _i32), ("bias_scale", _f32),
                 ("down", SeaGemmNormGroup)]
+
+
+CHAIN_MAX_PROJ = 6
+CHAIN_MAX_GROUPS = 3
+
+
+class SeaRowChain(C.Structure):
+    _fields_ = [("att", _vp * XTAIL_MAX_SEG), ("Wp", _vp * XTAIL_MAX_SEG), ("a2", _vp), ("W2", _vp), ("b2", _vp), ("Xin", _vp), ("X", _vp), ("Xact", _vp),
+                ("n_seg", _i32), ("ldatt", _i32), ("ldwp", _i32), ("lda2", _i32), ("ldw2", _i32), ("ldxin", _i32), ("ldx", _i32), ("ldxact", _i32),
+                ("M", _i32), ("D", _i32), ("E", _i32), ("has_down", _i32), ("n_proj", _i32), ("bias_scale", _f32),
+                ("down", SeaGemmNormGroup), ("proj", SeaQkvGroup * CHAIN_MAX_PROJ)]
 
 
 MAX_MLP_GROUPS = 8
@@ -247,6 +258,8 @@ def lib() -> C.CDLL:
     L.sea_gemm_rownorm.restype = C.c_int
     L.sea_exchange_tail.argtypes = [C.POINTER(SeaExchangeTail), C.c_int, C.c_float, C.c_int, _vp]
     L.sea_exchange_tail.restype = C.c_int
+    L.sea_row_chain.argtypes = [C.POINTER(SeaRowChain), C.c_int, C.POINTER(SeaQkvCommon), C.c_float, C.c_int, _vp]
+    L.sea_row_chain.restype = C.c_int
     L.sea_patchify.argtypes = [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _vp]
     L.sea_patchify.restype = C.c_int
     L.sea_silu_outer_ib.argtypes = [C.POINTER(SeaSiluGroup), C.c_int, _vp, C.c_int, C.c_int, _vp, C.c_int, _vp]
@@ -283,7 +296,7 @@ def lib() -> C.CDLL:
 
 ABI_STRUCTS = (SeaGemmGroup, SeaQkvGroup, SeaQkvCommon, SeaAttnProblem, SeaAttnParams, SeaNormGroup, SeaSiluGroup,
                SeaIbParams, SeaWgradGroup, SeaNormBwdGroup, SeaSiluBwdGroup, SeaIbBwdParams, SeaAttnBwdProblem, SeaAttnBwdParams,
-               SeaDropout, SeaLaunchRec, SeaGemmNormGroup, SeaExchangeTail, SeaMlpGroup, SeaMlp2Group, SeaKvNorm, SeaKvField, SeaKvPair, SeaKvLayer, SeaKvGlobal, SeaStepPatch)
+               SeaDropout, SeaLaunchRec, SeaGemmNormGroup, SeaExchangeTail, SeaMlpGroup, SeaMlp2Group, SeaKvNorm, SeaKvField, SeaKvPair, SeaKvLayer, SeaKvGlobal, SeaStepPatch, SeaRowChain)
 
 EXPORTED_SYMBOLS = (
     "sea_abi_version", "sea_last_error", "sea_struct_sizes", "sea_device_info", "sea_gemm_grouped", "sea_qkv_rope_grouped",
@@ -291,7 +304,7 @@ EXPORTED_SYMBOLS = (
     "sea_mse_fwd_bwd", "sea_relative_mse", "sea_adamw_flat",
     "sea_wgrad_grouped", "sea_transpose_weights", "sea_rownorm_bwd", "sea_silu_outer_bwd", "sea_ib_bwd",
     "sea_attention_bwd", "sea_dropout_mask", "sea_run_list", "sea_run_list_steps", "sea_unpatchify", "sea_gemm_rownorm", "sea_exchange_tail", "sea_patchify", "sea_silu_outer_ib", "sea_mlp_fc1_ln_gelu", "sea_mlp_fc2_proj_norm", "sea_kv_rollout", "sea_kv_arena_words", "sea_kv_debug_stamps",
-    "sea_gemm_fewrows", "sea_qkv_rope_fewrows",
+    "sea_gemm_fewrows", "sea_qkv_rope_fewrows", "sea_row_chain",
 )
 
 

@@ -234,6 +234,7 @@ __global__ __launch_bounds__((TN / WT) * (TK / WT) * 64) void wgrad_kernel(const
     if (st < n_stage) step(st, Set0{}, Set1{});
     // C[n][k]: lane holds column k = lane & 15, rows n = 4 (lane >> 4) + reg
     const int r = lane & 15, g = lane >> 4;
+    const bool plain_store = G.overwrite != 0 && splits == 1;   // block-uniform
 #pragma unroll
     for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -242,7 +243,12 @@ __global__ __launch_bounds__((TN / WT) * (TK / WT) * 64) void wgrad_kernel(const
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int n = n0 + wn * WT + i * 16 + g * 4 + q;
-                if (n < G.N && k < G.K) atomicAdd(G.dW + (int64_t)n * G.lddw + k, acc[i][j][q]);
+                if (n < G.N && k < G.K) {
+                    // the only contribution to this element in a step whose gradient buffer was zeroed (overwrite, one split): a plain store — the fp32
+                    // atomics run at ~1.3 TB/s chip-wide, a quarter of the store rate, and were ~200 of the 357 us of the 2048 x 16384 MLP gradients
+                    if (plain_store) G.dW[(int64_t)n * G.lddw + k] = acc[i][j][q];
+                    else atomicAdd(G.dW + (int64_t)n * G.lddw + k, acc[i][j][q]);
+                }
             }
         }
     if (do_bias && r == 0) {   // every column of bacc holds the same sums
@@ -262,14 +268,15 @@ extern "C" int sea_wgrad_grouped(const SeaWgradGroup* groups, int n_groups, int 
     const int epc = dtype == SEA_BF16 ? 8 : 4;
     WgradLaunch L;
     memset(&L, 0, sizeof(L));
-    bool big = true;
+    bool big = true, long_m = true;
     for (int i = 0; i < n_groups; ++i) {
         const SeaWgradGroup& G = groups[i];
         SEA_REQUIRE(G.dY && G.X && G.dW, "sea_wgrad_grouped[%d]: null pointer", i);
         SEA_REQUIRE(G.M >= 1 && G.N >= 8 && G.K >= 8 && G.N % 8 == 0 && G.K % 8 == 0, "sea_wgrad_grouped[%d]: bad shape M=%d N=%d K=%d", i, G.M, G.N, G.K);
         SEA_REQUIRE(G.lddy % epc == 0 && G.ldx % epc == 0 && G.lddy >= G.N && G.ldx >= G.K && G.lddw >= G.K, "sea_wgrad_grouped[%d]: bad strides", i);
         SEA_REQUIRE(sea_aligned16(G.dY) && sea_aligned16(G.X), "sea_wgrad_grouped[%d]: dY/X must be 16-byte aligned", i);
-        big = big && G.N % 128 == 0 && G.K % 128 == 0 && G.M >= 2048;
+        big = big && G.N % 128 == 0 && G.K % 128 == 0;
+        long_m = long_m && G.M >= 2048;
     }
     static const int forced = sea_tune("wgrad_tile", 0);  // tuning aid
     long tiles128 = 0;
@@ -278,7 +285,20 @@ extern "C" int sea_wgrad_grouped(const SeaWgradGroup* groups, int n_groups, int 
     // exchange matrices (6 tiles) run 1.8x slower on the 128 tile, the MLP / condition matrices (96-192 tiles) 1.2-1.4x faster.
     // (256 x 128 / 128 x 256 tiles with 8 waves, the wide side along the smaller matrix dimension so that the larger operand is read by half as many
     // workgroups, were measured too: cond 152 against 181 us before the main loop was reworked, 131 against 132 after — not kept.)
-    const int tn = forced == 64 ? 64 : (forced == 128 ? 128 : (big && tiles128 >= 64 ? 128 : 64)), tk = tn;
+    // Short contractions with large outputs (the reference's own widths: M = B T ~ 800 rows, the MLP matrices 2048 x 16384, configs/multiphase_flow.py:112-141):
+    // a 128 x 128 tile re-reads (128 + 128) M operand elements for 128^2 outputs — 1.7 GB of L2 -> LDS traffic for mlp.fc2's gradient — a 256 x 128 tile
+    // (8 waves of 64 x 64) three quarters of it (256 x 256 with 16 waves spills: 128 registers per wave).  bf16, whole tiles, at least two per CU.
+    bool big256 = dtype == SEA_BF16;
+    long tiles256 = 0;
+    int m_lim = 0;
+    for (int i = 0; i < n_groups; ++i) {
+        big256 = big256 && groups[i].N % 256 == 0 && groups[i].K % 128 == 0;
+        tiles256 += (long)(groups[i].N / 256) * (groups[i].K / 128);
+        m_lim = groups[i].M > m_lim ? groups[i].M : m_lim;
+    }
+    const bool use256 = forced == 256 && big256;   // measured at the multiphase MLP gradients (M = 796): 218 us against 201 with the 128 tile — opt-in only (SEA_TUNE=wgrad_tile=256)
+    (void)tiles256; (void)m_lim;
+    const int tn = use256 ? 256 : (forced == 64 ? 64 : (forced == 128 ? 128 : (big && ((long_m && tiles128 >= 64) || tiles128 >= 1024) ? 128 : 64)))   /* short contractions: the 128 tile once the launch is many tiles deep (M = 796, 2048 x 16384: 299 -> 201 us) */, tk = use256 ? 128 : tn;
     long base_tiles = 0;
     for (int i = 0; i < n_groups; ++i) base_tiles += (long)((groups[i].N + tn - 1) / tn) * ((groups[i].K + tk - 1) / tk);
     // Split the contraction so that the launch fills the chip's resident-workgroup slots (2 per CU with the 128 tile's 72 KiB of LDS)
@@ -288,7 +308,7 @@ extern "C" int sea_wgrad_grouped(const SeaWgradGroup* groups, int n_groups, int 
     static const int wg_target = sea_tune("wgrad_target", 0);  // tuning aid: "about this many workgroups"
     // the 64 tile sits four to a CU (40 KiB of LDS); launches of a few small matrices keep to 512 — their extra splits cost more in atomic passes over
     // the same few tiles than they fill (measured) —, a launch of many (the exchange's gradients in one launch: 184 tiles) fills all 1024
-    const long slots = tn == 64 && base_tiles >= 64 ? 1024 : 512;
+    const long slots = tn == 256 ? 256 : (tn == 64 && base_tiles >= 64 ? 1024 : 512);
     int m_max = 1;
     for (int i = 0; i < n_groups; ++i) m_max = groups[i].M > m_max ? groups[i].M : m_max;
     long best_splits = 1;
@@ -330,7 +350,7 @@ extern "C" int sea_wgrad_grouped(const SeaWgradGroup* groups, int n_groups, int 
         (void)once;                                                                                                              \
         wgrad_kernel<TT, TN_, TK_, WT_><<<dim3(total), dim3((TN_ / WT_) * (TK_ / WT_) * 64), lds_, s>>>(L);                      \
     } while (0)
-    if (dtype == SEA_BF16) { if (tn == 128) LAUNCH_WG(__bf16, 128, 128, 64); else LAUNCH_WG(__bf16, 64, 64, 32); }
+    if (dtype == SEA_BF16) { if (tn == 256) LAUNCH_WG(__bf16, 256, 128, 64); else if (tn == 128) LAUNCH_WG(__bf16, 128, 128, 64); else LAUNCH_WG(__bf16, 64, 64, 32); }
     else { if (tn == 128) LAUNCH_WG(float, 128, 128, 64); else LAUNCH_WG(float, 64, 64, 32); }
 #undef LAUNCH_WG
     SEA_CHECK_LAUNCH("sea_wgrad_grouped");

@@ -33,7 +33,7 @@ extern "C" int sea_struct_sizes(int* out, int cap) {
                          (int)sizeof(SeaWgradGroup), (int)sizeof(SeaNormBwdGroup), (int)sizeof(SeaSiluBwdGroup), (int)sizeof(SeaIbBwdParams),
                          (int)sizeof(SeaAttnBwdProblem), (int)sizeof(SeaAttnBwdParams), (int)sizeof(SeaDropout), (int)sizeof(SeaLaunchRec),
                          (int)sizeof(SeaGemmNormGroup), (int)sizeof(SeaExchangeTail), (int)sizeof(SeaMlpGroup), (int)sizeof(SeaMlp2Group), (int)sizeof(SeaKvNorm), (int)sizeof(SeaKvField),
-                         (int)sizeof(SeaKvPair), (int)sizeof(SeaKvLayer), (int)sizeof(SeaKvGlobal), (int)sizeof(SeaStepPatch)};
+                         (int)sizeof(SeaKvPair), (int)sizeof(SeaKvLayer), (int)sizeof(SeaKvGlobal), (int)sizeof(SeaStepPatch), (int)sizeof(SeaRowChain)};
     const int n = (int)(sizeof(sizes) / sizeof(sizes[0]));
     for (int i = 0; i < n && i < cap; ++i) out[i] = sizes[i];
     return n;
@@ -60,6 +60,7 @@ extern "C" int sea_run_list(const SeaLaunchRec* recs, int n_recs, void* stream) 
             case SEA_OP_GEMM_FEW: rc = sea_gemm_fewrows(static_cast<const SeaGemmGroup*>(R.p0), static_cast<const SeaNormGroup*>(R.p1), R.n, R.i0, R.i1, R.f0, R.dtype, stream); break;
             case SEA_OP_QKV_FEW: rc = sea_qkv_rope_fewrows(static_cast<const SeaQkvGroup*>(R.p0), reinterpret_cast<const SeaNormGroup*>(R.l0), R.n, static_cast<const SeaQkvCommon*>(R.p1), R.f0,
                                                            R.dtype, stream); break;
+            case SEA_OP_CHAIN: rc = sea_row_chain(static_cast<const SeaRowChain*>(R.p0), R.n, static_cast<const SeaQkvCommon*>(R.p1), R.f0, R.dtype, stream); break;
             default: sea_set_error("sea_run_list[%d]: unknown op %d", i, R.op); return SEA_EINVAL;
         }
         if (rc != SEA_OK) return rc;   // sea_last_error() already names the entry point; the caller maps i back to its record

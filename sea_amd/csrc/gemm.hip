@@ -8,6 +8,7 @@ struct GemmLaunch {
     int n_groups;
     int single_buffer;   // register-staged main loop on one LDS buffer (more workgroups per CU)
     int silu_lds_off;    // generated-A launches: byte offset of the w1 | b1 staging area in LDS
+    unsigned n_major;    // bit i: group i numbers its tiles with the ROW tile fastest (skinny M: the tiles that share a W panel are neighbours, see sea_gemm_grouped)
 };
 
 struct QkvLaunch {
@@ -37,7 +38,12 @@ __global__ __launch_bounds__(256) void gemm_grouped_kernel(const GemmLaunch L) {
     const SeaGemmGroup& G = L.g[gi];
     const int t = bid - L.tile_start[gi];
     const int tiles_n = (G.N + BN - 1) / BN;
-    const int tm = t / tiles_n, tn = t - tm * tiles_n;
+    int tm = t / tiles_n, tn = t - tm * tiles_n;
+    if ((L.n_major >> gi) & 1u) {   // block-uniform
+        const int tiles_m = (G.M + BM - 1) / BM;
+        tn = t / tiles_m;
+        tm = t - tn * tiles_m;
+    }
 
     GemmMainloop<T, BM, BN> ml;
     ml.A = static_cast<const T*>(G.A);
@@ -549,13 +555,17 @@ static int set_lds(K kernel, int bytes) {
                ? 0 : -1;
 }
 
-static int pick_tile(long tiles128, bool dma) {
+static int pick_tile(long tiles128, bool dma, long kmax = 0) {
     // 64x64 tiles until the launch is a couple of rounds of 128x128 tiles deep: below that its time is one tile's latency, which the small
     // tile halves.  Measured crossovers on the cfg2/cfg3 shapes at B = 1, 2, 4, 8 (single-buffered register-staged main loop):
     // condition GEMM 672 tiles 31.8 us (64) vs 28.0 (128); fc1 768: 22.0 vs 21.2, 6144: 135 vs 118; qkv 288: 16.7 vs 19.5, 2304: 61 vs 59;
     // LDS-DMA main loop (fc2) 384: 70 vs 79, 768: 158 vs 127.
     static const int forced = sea_tune("gemm_tile", 0);  // tuning aid
     if (forced == 64 || forced == 128) return forced;
+    // very long contractions with the chip nearly filled by 128 x 128 tiles (the reference's multiphase MLP: M = 796, N = 2048, K = 16384 -> 224 tiles): the launch
+    // runs at the rate of its L2 -> LDS operand traffic, (BM + BN) K per tile — 3.5 GB with 64 x 64 tiles, 1.9 GB with 128 x 128: mlp.fc2 291 -> 173 us,
+    // bwd.fc1.dgrad 289 -> 166 us (round 4; at K = 8192 with 112 tiles the 64 tile stays faster: 60 against 94 us)
+    if (dma && kmax >= 16384 && tiles128 >= 192) return 128;
     return tiles128 >= (dma ? 512 : 600) ? 128 : 64;
 }
 
@@ -627,7 +637,9 @@ extern "C" int sea_gemm_grouped(const SeaGemmGroup* groups, int n_groups, int dt
     static const int dma_force = sea_tune("gemm_dma_force", 0);  // tuning aid
     dma = dma && (t64 <= 1536 || dma_force);
     (void)t64;
-    const int tile = pick_tile(t128, dma);
+    long kmax_all = 0;
+    for (int i = 0; i < n_groups; ++i) kmax_all = (long)groups[i].K * groups[i].n_seg > kmax_all ? (long)groups[i].K * groups[i].n_seg : kmax_all;
+    const int tile = pick_tile(t128, dma, kmax_all);
     GemmLaunch L;
     memset(&L, 0, sizeof(L));
     L.n_groups = n_groups;
@@ -638,6 +650,18 @@ extern "C" int sea_gemm_grouped(const SeaGemmGroup* groups, int n_groups, int dt
         total += ((groups[i].M + tile - 1) / tile) * ((groups[i].N + tile - 1) / tile);
     }
     L.tile_start[n_groups] = total;
+    // Skinny M (the reference's own widths: M = B T ~ 800 rows against N or K = 16384, configs/multiphase_flow.py:112-141): W is the big operand (67 MB per
+    // field MLP matrix) and every row tile streams all of it.  With the column tile fastest (the default: neighbours share an A panel) the few row tiles of a
+    // W panel are tiles_n apart, i.e. on different XCDs — every XCD's L2 pulls the WHOLE of W from the Infinity Cache / HBM (8 x 134 MB for mlp.fc2: the
+    // launch ran at the rate of that traffic, 292 us).  With the row tile fastest the tiles of a W panel are neighbours inside one XCD's contiguous range
+    // (xcd_remap) and walk the panel together: W crosses the fabric once, the (small) A matrix once per XCD.  SEA_TUNE=gemm_n_major=0|1 forces.
+    {
+        static const int nm_forced = sea_tune("gemm_n_major", -1);
+        for (int i = 0; i < n_groups; ++i) {
+            const bool skinny_m = (long)groups[i].N >= 2L * groups[i].M && (long)groups[i].N * groups[i].K * (dtype == SEA_BF16 ? 2 : 4) >= (4L << 20);
+            if (nm_forced == 1 || (nm_forced < 0 && skinny_m)) L.n_major |= 1u << i;
+        }
+    }
     hipStream_t s = static_cast<hipStream_t>(stream);
     bool plain = true;
     for (int i = 0; i < n_groups; ++i) plain = plain && groups[i].act == 0 && groups[i].drop.thr == 0;

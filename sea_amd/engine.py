@@ -434,6 +434,22 @@ class Plan:
         ops.fill_exchange_tail(P[0], att, Wp, Wup, bup, bias_scale, X, None, down)
         self._cur.append(self._rec(N.lib().sea_exchange_tail, [P, 1, 1e-5, self.code], name, P))
 
+    def _chain(self, groups: List[dict], rope: torch.Tensor, hd: int, name: str) -> None:
+        """A row-local chain between two attention launches (sea_row_chain): group dicts as ops.fill_row_chain, plus `Xin_is_x` (byte offset into the caller's
+        tensor: the residual rows of the first layer are read from it, strided)."""
+        for s in range(0, len(groups), N.CHAIN_MAX_GROUPS):
+            chunk = groups[s:s + N.CHAIN_MAX_GROUPS]
+            arr = (N.SeaRowChain * len(chunk))()
+            for g, d in zip(arr, chunk):
+                d = dict(d)
+                x_off = d.pop("Xin_is_x", None)
+                ops.fill_row_chain(g, **d)
+                if x_off is not None:
+                    self._x_patches.append((g, "Xin", x_off))
+            common = N.SeaQkvCommon(rope.data_ptr(), self.H, hd, self.T, self.pos0, self.cap, ops.q_scale(hd))
+            self._pos_structs.append(common)
+            self._cur.append(self._rec(N.lib().sea_row_chain, [arr, len(chunk), C.byref(common), 1e-5, self.code], name, (arr, common)))
+
     def _qkv(self, groups: List[dict], rope: torch.Tensor, hd: int, name: str) -> None:
         L = N.lib()
         arr = (N.SeaQkvGroup * len(groups))()
@@ -592,6 +608,15 @@ class Plan:
                       and ops.exchange_tail_supported(dt, D, E, F - 1) and M <= int(_switches.plan("xtail_max_rows", "1000000000")))   # measured: cfg2 0.281 -> 0.254 ms, B = 2 0.414 -> 0.404, B = 4 0.679 -> 0.675, B = 8 a tie (1.191)
         rope_s, rope_c = eng.rope_self, eng.rope_cross
         Eo, concat = self.Eo, self.concat
+        # The row-local chains between the attention launches as ONE launch each (sea_row_chain, round 4): self-attention out-projection + residual ->
+        # cross_down + ln_cross -> every q of the field and the k / v of the pairs that read its PRE-exchange rows; per field, its exchange tail ->
+        # cross_down + ln_cross of the updated rows -> the k / v of the pairs that read them.  No cross-attention QKV launch, no out-projection launch, no
+        # down + norm launch: 18 launches -> 14 at cfg2.  bf16, the widths the kernel instantiates, at most 3 fields (the segments' weights share an LDS
+        # half), short launches (a workgroup owns most of a CU's LDS: beyond a round or two of workgroups the tiled launches win; SEA_PLAN=chain_max_rows).
+        # SEA_PLAN=chain=0 keeps the 18-launch plan (the reference form of tests/test_model_gpu.py::test_optional_plans_match_default_plan).
+        chain = self._chain_plan = (type(self) is Plan and self.mode == "full" and xmode == "sea" and 1 < F <= 3 and fuse_norm and not lanes and not concat
+                                    and _switches.plan("chain", "1") != "0" and _switches.plan("xtail", "1") != "0" and ops.row_chain_supported(dt, D, E, F - 1, D // H)
+                                    and M <= int(_switches.plan("chain_max_rows", "4096")))
         FE = F * Eo                                             # row stride of the caller's [B, T, F, Eo] tensors
         # KV-cache step at the shipped widths (one row per trajectory and field, embed_dim 1024 / 2048): the Linear layers as sea_gemm_fewrows /
         # sea_qkv_rope_fewrows launches with the row norms in front of them folded in (gemv.hip) — 18 launches instead of 22.  SEA_KV=gemv=0 keeps the generic launches.
@@ -611,6 +636,7 @@ class Plan:
             nd_old = [self._buf(M, D) for _ in range(F)]
             nd_new = [self._buf(M, D) for _ in range(F)]
             Qc = [self._buf(B, H, T, hd_c) for _ in range(max(F - 1, 1))]
+            Qc2 = [[self._buf(B, H, T, hd_c) for _ in range(F - 1)] for _ in range(F)] if chain else None   # every field's q rows exist at once
             Kc = [[[self._buf(B, H, cap, hd_c, zero=True) for _ in range(F)] for _ in range(F)] for _ in range(self.L)]
             Vc = [[[self._buf(B, H, hd_c, cap, zero=True) for _ in range(F)] for _ in range(F)] for _ in range(self.L)]
             att_c = [self._buf(M, D) for _ in range(max(F - 1, 1))]
@@ -672,7 +698,26 @@ class Plan:
                 else:
                     g.update(R=xr[i])
                 groups.append(g)
-            (self._gemm_few if few else self._gemm)(groups, "self.out_proj")
+            if chain:
+                # out-projection + residual, cross_down + ln_cross of the PRE-exchange rows, and from those normalised rows (never stored): q_ij for every
+                # j != i, and k / v of the pairs (a, i), a < i — field a runs its cross-attention before field i is updated (models/temporal.py:187-192)
+                groups = []
+                for i in range(F):
+                    proj = []
+                    for s_, j in enumerate([j for j in range(F) if j != i]):
+                        ca = f"{pre}cross_attn.{i}.{j}."
+                        proj.append(dict(W=P.act(ca + "q.weight"), bias=P.f32_vec(ca + "q.bias"), col0=0, Q=Qc2[i][s_]))
+                    for a in range(i):
+                        ca = f"{pre}cross_attn.{a}.{i}."
+                        proj.append(dict(W=P.act(ca + "k.weight", 2 * D), bias=P.f32_vec(ca + "k.bias", 2 * D), col0=D, K=Kc[l][a][i], Vt=Vc[l][a][i]))
+                    g = dict(a2=att_e[i], W2=P.act(f"{pre}attn.self.{i}.projection.weight"), Xin=xr[i], X=xr[i], proj=proj,
+                             down=dict(W=P.act(f"{pre}cross_down.{i}.weight"), bias=P.f32_vec(f"{pre}cross_down.{i}.bias"), **norm_params(f"{pre}ln_cross.{i}.", D)))
+                    if first:
+                        g.update(ldxin=FE, Xin_is_x=i * Eo * 4)
+                    groups.append(g)
+                self._chain(groups, rope_c, hd_c, "self.out_proj_down_qkv")
+            else:
+                (self._gemm_few if few else self._gemm)(groups, "self.out_proj")
             first = False
             if not cond_joined:  # everything below reads modulations computed on lane 1
                 self._join(1)
@@ -752,6 +797,21 @@ class Plan:
                     (self._gemm_few if F == 2 else self._gemm)([up], f"cross{i}.up_sum")   # (F > 2: the sum over the F - 1 projections needs sea_gemm_grouped's segments)
                     if i < F - 1:
                         self._gemm_few([dict(A=xa[i], W=P.act(f"{pre}cross_down.{i}.weight"), bias=P.f32_vec(f"{pre}cross_down.{i}.bias"), C32=dn[i])], f"cross{i}.down_new")
+            elif F > 1 and xmode == "sea" and chain:
+                for i in range(F):
+                    others = [j for j in range(F) if j != i]
+                    self._attn([dict(Q=Qc2[i][s_], K=Kc[l][i][j], Vt=Vc[l][i][j], O=att_c[s_]) for s_, j in enumerate(others)], hd_c, D, f"cross{i}.attention")
+                    # the field's tail; from its UPDATED rows: cross_down + ln_cross, then k / v of the pairs (b, i), b > i (fields that run after it)
+                    proj = []
+                    for b_ in range(i + 1, F):
+                        ca = f"{pre}cross_attn.{b_}.{i}."
+                        proj.append(dict(W=P.act(ca + "k.weight", 2 * D), bias=P.f32_vec(ca + "k.bias", 2 * D), col0=D, K=Kc[l][b_][i], Vt=Vc[l][b_][i]))
+                    down = None
+                    if i < F - 1:
+                        down = dict(W=P.act(f"{pre}cross_down.{i}.weight"), bias=P.f32_vec(f"{pre}cross_down.{i}.bias"), **norm_params(f"{pre}ln_cross.{i}.", D))
+                    self._chain([dict(att=[att_c[s_] for s_ in range(len(others))], Wp=[P.act(f"{pre}cross_attn.{i}.{j}.projection.weight") for j in others],
+                                      W2=P.act(f"{pre}cross_up.{i}.weight"), b2=P.f32_vec(f"{pre}cross_up.{i}.bias"), bias_scale=float(F - 1), Xin=xr[i], X=xr[i],
+                                      down=down, proj=proj)], rope_c, hd_c, f"cross{i}.tail")
             elif F > 1 and xmode == "sea":
                 if fuse_norm and D <= 256 and D % 16 == 0:
                     self._gemm_norm([dict(A=xa[j], W=P.act(f"{pre}cross_down.{j}.weight"), bias=P.f32_vec(f"{pre}cross_down.{j}.bias"), Yact=nd_old[j],
@@ -1135,6 +1195,8 @@ class Plan:
                 c.op, c.p0, c.n, c.f0, c.dtype = N.OP_MLP2, addr(a[0]), a[1], a[2], a[3]
             elif r.fn is L.sea_exchange_tail:
                 c.op, c.p0, c.n, c.f0, c.dtype = N.OP_XTAIL, addr(r.keep), a[1], a[2], a[3]
+            elif r.fn is L.sea_row_chain:
+                c.op, c.p0, c.n, c.p1, c.f0, c.dtype = N.OP_CHAIN, addr(a[0]), a[1], addr(r.keep[1]), a[3], a[4]
             elif r.fn is L.sea_gemm_rownorm:
                 c.op, c.p0, c.n, c.f0, c.dtype = N.OP_GEMM_NORM, addr(a[0]), a[1], a[2], a[3]
             elif r.fn is L.sea_rownorm:
@@ -1415,6 +1477,7 @@ class TemporalEngine:
         plan._bound_dout = dout          # held until the next backward: the launch list knows it by address only
         if ptrcheck.always():
             plan.audit(owners=(dout,))
+        plan.set_grads_fresh(not self.grads_dirty)   # a backward into zeros (the usual step) lets the big weight-gradient launches store instead of add
         plan.run_backward(on_bucket)
         self.grads_dirty = True
 

@@ -296,6 +296,61 @@ def exchange_tail_grouped(groups: Sequence[Dict], eps: float = 1e-5, dtype: torc
     N.check(N.lib().sea_exchange_tail(P, len(groups), eps, N.dtype_code(dtype), N.stream_ptr()), "sea_exchange_tail")
 
 
+def row_chain_supported(dtype: torch.dtype, D: int, E: int, n_seg: int, hd: int) -> bool:
+    """Shapes sea_row_chain instantiates (include/sea_hip.h): bf16, (D, E) in {(128, 256), (64, 128)}, n_seg * D <= E, cross head dim 16 or 32."""
+    return dtype == torch.bfloat16 and (D, E) in ((128, 256), (64, 128)) and 0 <= n_seg and n_seg * D <= E and hd in (16, 32)
+
+
+def fill_row_chain(P: N.SeaRowChain, W2, Xin, X, att: Sequence[torch.Tensor] = (), Wp: Sequence[torch.Tensor] = (), a2=None, b2=None, bias_scale: float = 1.0, Xact=None,
+                   down: Optional[Dict] = None, proj: Sequence[Dict] = (), ldxin: Optional[int] = None) -> None:
+    """One group of sea_row_chain.  Form A: a2 act [M, E], W2 act [E, E]; form B: att / Wp lists (n_seg act [M, D] / [D, D]), W2 act [E, D].  Xin f32 [M, E] (row
+    stride ldxin when given: the caller's strided tensor), X f32 [M, E]; down: dict(W [D, E], bias, gamma, beta, mod, Yact, Y32); proj: dicts(W [N, D], bias, col0, Q / K / Vt / V)."""
+    for s_, a in enumerate(att):
+        P.att[s_] = a.data_ptr()
+        P.Wp[s_] = Wp[s_].data_ptr()
+    P.n_seg = len(att)
+    if att:
+        P.ldatt, P.ldwp = att[0].stride(0), Wp[0].stride(0)
+    if a2 is not None:
+        P.a2, P.lda2 = a2.data_ptr(), a2.stride(0)
+    P.W2, P.ldw2, P.b2, P.bias_scale = W2.data_ptr(), W2.stride(0), N.ptr(b2), bias_scale
+    P.Xin, P.ldxin = Xin.data_ptr(), (ldxin if ldxin is not None else Xin.stride(0))
+    P.X, P.ldx = X.data_ptr(), X.stride(0)
+    P.Xact, P.ldxact = N.ptr(Xact), (Xact.stride(0) if Xact is not None else 0)
+    P.M, P.E = X.shape[0], W2.shape[0]
+    P.D = P.E // 2
+    P.has_down = int(down is not None)
+    if down is not None:
+        g = P.down
+        g.W, g.ldw, g.bias = down["W"].data_ptr(), down["W"].stride(0), N.ptr(down.get("bias"))
+        g.gamma, g.beta = down["gamma"].data_ptr(), N.ptr(down.get("beta"))
+        mod, y32, yact = down.get("mod"), down.get("Y32"), down.get("Yact")
+        g.mod, g.ldmod = N.ptr(mod), (mod.stride(0) if mod is not None else 0)
+        g.Y32, g.ldy32 = N.ptr(y32), (y32.stride(0) if y32 is not None else 0)
+        g.Yact, g.ldyact = N.ptr(yact), (yact.stride(0) if yact is not None else 0)
+        g.mean, g.rstd = N.ptr(down.get("mean")), N.ptr(down.get("rstd"))
+        g.M, g.N, g.K, g.n_seg = P.M, P.D, P.E, 1   # (the launcher sets them again; here for the pointer audit's extents)
+    if len(proj) > N.CHAIN_MAX_PROJ:
+        raise ValueError(f"row_chain: {len(proj)} projection entries (at most {N.CHAIN_MAX_PROJ})")
+    P.n_proj = len(proj)
+    for q, d in zip(P.proj, proj):
+        W = d["W"]
+        q.A, q.lda, q.M = None, 0, P.M
+        q.W, q.ldw, q.bias = W.data_ptr(), W.stride(0), N.ptr(d.get("bias"))
+        q.N, q.K, q.col0 = W.shape[0], W.shape[1], d.get("col0", 0)
+        q.Qout, q.Kout, q.Vtout, q.Vout = N.ptr(d.get("Q")), N.ptr(d.get("K")), N.ptr(d.get("Vt")), N.ptr(d.get("V"))
+
+
+def row_chain(groups: Sequence[Dict], rope: Optional[torch.Tensor] = None, H: int = 1, hd: int = 4, T: int = 1, pos0: int = 0, cap: int = 0, q_scale_: float = 1.0,
+              eps: float = 1e-5, dtype: torch.dtype = torch.bfloat16) -> None:
+    """sea_row_chain: the row-local chain between two attention launches for up to three groups (fields) of one shape (dict keys: the arguments of fill_row_chain)."""
+    P = (N.SeaRowChain * len(groups))()
+    for p_, d in zip(P, groups):
+        fill_row_chain(p_, **d)
+    common = N.SeaQkvCommon(N.ptr(rope), H, hd, T, pos0, cap, q_scale_) if rope is not None else None
+    N.check(N.lib().sea_row_chain(P, len(groups), C.byref(common) if common is not None else None, eps, N.dtype_code(dtype), N.stream_ptr()), "sea_row_chain")
+
+
 def silu_outer(groups: Sequence[Dict], c: torch.Tensor, M: int, dtype: torch.dtype) -> None:
     """groups: dicts with w1 f32 [K2], b1 f32 [K2], Hid act [M,K2]."""
     n = len(groups)

@@ -103,6 +103,20 @@ def _extents(st, esz: int) -> Iterable[Tuple[str, int, int]]:
             yield "Y32", st.Y32, ((st.M - 1) * st.ldy32 + st.N) * f32
         if st.mod:
             yield "mod", st.mod, ((st.M - 1) * st.ldmod + 2 * st.N) * esz
+    elif isinstance(st, N.SeaRowChain):
+        K2 = st.D if st.n_seg > 0 else st.E
+        for s_ in range(st.n_seg):
+            yield f"att[{s_}]", st.att[s_], ((st.M - 1) * st.ldatt + st.D) * esz
+            yield f"Wp[{s_}]", st.Wp[s_], ((st.D - 1) * st.ldwp + st.D) * esz
+        if st.a2:
+            yield "a2", st.a2, ((st.M - 1) * st.lda2 + st.E) * esz
+        yield "W2", st.W2, ((st.E - 1) * st.ldw2 + K2) * esz
+        if st.b2:
+            yield "b2", st.b2, st.E * f32
+        yield "Xin", st.Xin, ((st.M - 1) * st.ldxin + st.E) * f32
+        yield "X", st.X, ((st.M - 1) * st.ldx + st.E) * f32
+        if st.Xact:
+            yield "Xact", st.Xact, ((st.M - 1) * st.ldxact + st.E) * esz
     elif isinstance(st, N.SeaMlpGroup):
         if st.A:
             yield "A", st.A, ((st.M - 1) * st.lda + st.E) * esz

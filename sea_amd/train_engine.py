@@ -53,7 +53,9 @@ class TrainPlan(Plan):
         return s
 
     # ------------------------------------------------------------------ record builders (backward)
-    def _wgrad(self, groups: List[dict], name: str) -> None:
+    def _wgrad(self, groups: List[dict], name: str, sole: bool = False) -> None:
+        """`sole`: this launch is the ONLY contribution to its dW tensors in a backward (the field MLP's matrices): when the gradient buffer is known to hold
+        zeros (engine.backward sets SeaWgradGroup.overwrite per run from grads_dirty) the kernel may store instead of adding atomically."""
         L = N.lib()
         for s in range(0, len(groups), N.MAX_WGRAD_GROUPS):
             chunk = groups[s:s + N.MAX_WGRAD_GROUPS]
@@ -64,6 +66,8 @@ class TrainPlan(Plan):
                 g.lddy, g.ldx, g.lddw = dY.stride(0), X.stride(0), dW.stride(0)
                 g.M, g.N, g.K = self.M, dW.shape[0], dW.shape[1]
                 assert dY.shape[1] == g.N and X.shape[1] == g.K, (name, dY.shape, X.shape, dW.shape)
+                if sole:
+                    self.__dict__.setdefault("_sole_wgrads", []).append(g)
             self._cur.append(_Rec(L.sea_wgrad_grouped, [arr, len(chunk), self.code], name, arr))
 
     def _norm_bwd(self, groups: List[dict], d: int, name: str, dy_is_act: bool, x_is_act: bool, gelu: bool, accumulate: bool) -> None:
@@ -546,7 +550,7 @@ class TrainPlan(Plan):
                              drop=((thr, sv["mlp_drop"] + i, 2) if thr else None)) for i in range(F)], "bwd.proj.dgrad")
             # ---- fc2:   x4 = x3 + hg W2^T + b2                 (gb = d x4)
             self._wgrad([dict(dY=gb[i], X=sv["hg"][i], dW=G2(f"{pre}mlp.{i}.layers.3.weight"), db=Gv(f"{pre}mlp.{i}.layers.3.bias")) for i in range(F)],
-                        "bwd.fc2.wgrad")
+                        "bwd.fc2.wgrad", sole=True)
             self._gemm([dict(A=gb[i], W=P.actT(f"{pre}mlp.{i}.layers.3.weight"), Cact=dS_[i]) for i in range(F)], "bwd.fc2.dgrad")
             # ---- LayerNorm + GELU of the MLP (in place: d hg -> d h)
             self._norm_bwd([dict(dY=dS_[i], X=sv["h"][i], gamma=P.f32_vec(f"{pre}mlp.{i}.layers.1.weight"), beta=P.f32_vec(f"{pre}mlp.{i}.layers.1.bias"),
@@ -554,7 +558,7 @@ class TrainPlan(Plan):
                                  dbeta=Gv(f"{pre}mlp.{i}.layers.1.bias")) for i in range(F)], S, "bwd.mlp.ln_gelu", True, True, True, False)
             # ---- fc1
             self._wgrad([dict(dY=dS_[i], X=sv["n2"][i], dW=G2(f"{pre}mlp.{i}.layers.0.weight"), db=Gv(f"{pre}mlp.{i}.layers.0.bias")) for i in range(F)],
-                        "bwd.fc1.wgrad")
+                        "bwd.fc1.wgrad", sole=True)
             self._phase_marks.append((len(self.bwd), (NL - 1 - l) * 3))            # the field MLPs + proj of this layer are final
             self._gemm([dict(A=dS_[i], W=P.actT(f"{pre}mlp.{i}.layers.0.weight"), Cact=dE_[i]) for i in range(F)], "bwd.fc1.dgrad")
             # ---- AdaLN_2: accumulates the norm branch onto the residual gradient
@@ -751,6 +755,12 @@ class TrainPlan(Plan):
                 out.append((idx, lo, hi))
             self._buckets = out
         return self._buckets
+
+    def set_grads_fresh(self, fresh: bool) -> None:
+        """The gradient buffer holds zeros (nothing has accumulated since the last zero_grads): the launches that are the sole contribution to their
+        tensors may store instead of adding."""
+        for g in self.__dict__.get("_sole_wgrads", ()):
+            g.overwrite = int(fresh)
 
     def run_backward(self, on_bucket=None) -> None:
         """Replay the backward launch list; `on_bucket(lo, hi)` is called as soon as grads[lo:hi] is final (grad_buckets)."""

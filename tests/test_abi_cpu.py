@@ -39,8 +39,8 @@ def test_binding_lists_every_declared_symbol():
 def test_struct_layouts_match(lib):
     from sea_amd import _native as N
 
-    out = (C.c_int * 32)()
-    n = lib.sea_struct_sizes(out, 32)
+    out = (C.c_int * 48)()
+    n = lib.sea_struct_sizes(out, 48)
     mine = [C.sizeof(t) for t in N.ABI_STRUCTS]
     assert n == len(mine)
     assert list(out[:n]) == mine
@@ -55,12 +55,19 @@ def test_validation_without_gpu(lib):
     assert lib.sea_gemm_grouped(g, 17, 0, None) == -1
     P = N.SeaAttnParams()
     assert lib.sea_attention_fwd(C.byref(P), 1, None) == -1
-    assert lib.sea_abi_version() == N.ABI_VERSION == 6
+    assert lib.sea_abi_version() == N.ABI_VERSION == 7
     few = (N.SeaGemmGroup * 1)()
     assert lib.sea_gemm_fewrows(few, None, 1, 0, 0, 1e-5, 0, None) == -3     # fp32: the few-row launches are bf16 only (unsupported, not an argument error)
     assert lib.sea_gemm_fewrows(few, None, 9, 0, 0, 1e-5, 1, None) == -1 and b"sea_gemm_fewrows" in lib.sea_last_error()
     few[0].K = 768
     assert lib.sea_gemm_fewrows(few, None, 1, 0, 0, 1e-5, 1, None) == -3 and b"K=768" in lib.sea_last_error()
+    ch = (N.SeaRowChain * 1)()
+    assert lib.sea_row_chain(ch, 4, None, 1e-5, 1, None) == -1 and b"sea_row_chain" in lib.sea_last_error()   # more groups than a launch carries
+    ch[0].D, ch[0].E = 96, 192
+    assert lib.sea_row_chain(ch, 1, None, 1e-5, 1, None) == -3 and b"unsupported" in lib.sea_last_error()     # widths the kernel does not instantiate: refused, not an argument error
+    ch[0].D, ch[0].E = 128, 256
+    assert lib.sea_row_chain(ch, 1, None, 1e-5, 0, None) == -3                                               # fp32: bf16 only
+    assert lib.sea_row_chain(ch, 1, None, 1e-5, 1, None) == -1 and b"null" in lib.sea_last_error()            # supported shape, null operands
     G, Ly = N.SeaKvGlobal(), (N.SeaKvLayer * 1)()
     assert lib.sea_kv_rollout(C.byref(G), Ly, 0, 1, 1, 1, None) == -1   # sizes are checked before anything is launched
     assert b"sea_kv_rollout" in lib.sea_last_error()

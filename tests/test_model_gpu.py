@@ -49,13 +49,17 @@ MODEL_CASES = ["model_tiny_adaln_f3", "model_tiny_ln_f2", "model_tiny_adaln_f2_p
                "model_ibconcat_adaln_f3", "model_ibconcat_ln_f2"]
 
 
+@pytest.mark.parametrize("chain", [True, False])
 @pytest.mark.parametrize("F,ln,after", [(2, "ln", True), (2, "adaln", False), (3, "ln", True)])
-def test_bf16_fused_launches_at_shipped_widths(F, ln, after):
-    """E = 256 / D = 128 (the widths sea_exchange_tail and the 16-row Linear + norm launches instantiate) with the configurations the golden
+def test_bf16_fused_launches_at_shipped_widths(F, ln, after, chain, monkeypatch):
+    """E = 256 / D = 128 (the widths sea_row_chain, sea_exchange_tail and the 16-row Linear + norm launches instantiate) with the configurations the golden
     fixtures do not reach in bf16: F = 2 (one segment per tail), LayerNorm without modulation, the info-bottleneck add in front of the block;
-    forward against the fp32 oracle, and the KV-cache rollout (M = 2 rows per launch) against the recompute rollout."""
+    forward against the fp32 oracle, and the KV-cache rollout (M = 2 rows per launch) against the recompute rollout — with the row chains of round 4
+    (default) and with round 3's launches (SEA_PLAN=chain=0)."""
     from sea_amd.utils.train_utils import rollout
 
+    if not chain:
+        monkeypatch.setenv("SEA_PLAN", "chain=0")
     cfg = O.OracleConfig(2, 256, 8, 64, 8, 0, F, 2, after, ln)
     x, _, ib = recipe_inputs(2, 50, cfg, seed=21)
     ref = O.model_forward(x, ib, recipe_params(cfg), cfg)
@@ -63,7 +67,7 @@ def test_bf16_fused_launches_at_shipped_widths(F, ln, after):
     with torch.no_grad():
         out = m(x.cuda(), ib.cuda())
         names = [r.name for r in m.engine().plan(2, 50, "full").records]
-    assert "cross0.tail" in names and "cross.down_norm_old" in names
+    assert "cross0.tail" in names and ("cross.down_norm_old" in names) == (not chain) and ("self.out_proj_down_qkv" in names) == chain
     assert rel_l2(out.cpu().numpy(), ref.numpy()) < BF16_TOL
     a = rollout(m, x[:, :1].cuda(), ib.cuda(), 10, mode="recompute")
     b = rollout(m, x[:, :1].cuda(), ib.cuda(), 10, mode="kv")
@@ -269,7 +273,7 @@ def test_cfg2_full_size_causality_and_prefix_bf16():
     with torch.no_grad():
         a = m(x, ib).clone()
         names = [r.name for r in m.engine().plan(1, 2024, "full").records]
-        assert "mlp.fc1_ln_gelu" in names and "cross0.tail" in names and "cross.down_norm_old" in names   # the plan of the bench line
+        assert "mlp.fc1_ln_gelu" in names and "cross0.tail" in names and "self.out_proj_down_qkv" in names and len(names) <= 14   # the plan of the bench line
         x2 = x.clone()
         x2[:, 1500] += 1.0
         b = m(x2, ib).clone()
@@ -510,7 +514,7 @@ def test_shipped_multiphase_dims_forward(dtype, tol):
 
 
 @pytest.mark.parametrize("env,graphed", [({"SEA_PLAN": "lanes=all"}, True), ({"SEA_PLAN": "lanes=cond"}, True),
-                                         ({"SEA_PLAN": "norm=0"}, False), ({"SEA_PLAN": "xtail=0"}, False), ({"SEA_PLAN": "silu=1"}, False), ({"SEA_PLAN": "fold_ib=0"}, False), ({"SEA_PLAN": "mlp1=1"}, False), ({"SEA_TUNE": "gemm_norm_rows=64"}, False)])
+                                         ({"SEA_PLAN": "norm=0"}, False), ({"SEA_PLAN": "xtail=0"}, False), ({"SEA_PLAN": "chain=0"}, False), ({"SEA_PLAN": "silu=1"}, False), ({"SEA_PLAN": "fold_ib=0"}, False), ({"SEA_PLAN": "mlp1=1"}, False), ({"SEA_TUNE": "gemm_norm_rows=64"}, False)])
 @pytest.mark.parametrize("dtype,tol", [("fp32", 2e-6), ("bf16", 2e-2)])
 def test_optional_plans_match_default_plan(env, graphed, dtype, tol, monkeypatch):
     """The opt-in plans (fusion switches; parallel graph branches) compute what the default launch list computes — checked on the oracle too
@@ -544,8 +548,15 @@ def test_optional_plans_match_default_plan(env, graphed, dtype, tol, monkeypatch
         monkeypatch.delenv("SEA_PLAN")
         default_names = [r.name for r in build(cfg, dtype).engine().plan(2, 70, "full").records]
         assert ("cross0.tail" in default_names) == (dtype == "bf16")   # the default plan runs sea_exchange_tail in bf16, the three launches in fp32
+    elif sw == "chain=0":   # round 3's 18-launch form (out-projection, down + norm, a QKV launch per field, sea_exchange_tail) as the reference of the row chains
+        assert "self.out_proj" in names and "cross.down_norm_old" in names and "cross1.qkv_rope" in names and "self.out_proj_down_qkv" not in names
+        monkeypatch.delenv("SEA_PLAN")
+        default_names = [r.name for r in build(cfg, dtype).engine().plan(2, 70, "full").records]
+        # bf16: the default plan runs sea_row_chain (no cross-attention QKV launch, no out-projection, no down + norm launch: 4 launches per layer less)
+        assert ("self.out_proj_down_qkv" in default_names) == (dtype == "bf16") and ("cross1.qkv_rope" in default_names) == (dtype == "fp32")
+        assert len(default_names) == len(names) - (8 if dtype == "bf16" else 0)
     elif sw == "gemm_norm_rows=64":   # Linear + row norm with the 64-row tiles the long launches use
-        assert "cross.down_norm_old" in names
+        assert ("cross.down_norm_old" in names) == (dtype == "fp32") and ("self.out_proj_down_qkv" in names) == (dtype == "bf16")
     elif sw == "norm=0":   # the two-launch form of Linear + row norm
         assert "cross.norm_old" in names and "cross.down_norm_old" not in names
     else:

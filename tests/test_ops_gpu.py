@@ -516,6 +516,99 @@ def test_exchange_tail_matches_three_launch_form(D, E, S, M, has_down):
         assert rel(nd.float(), nd2.float()) < 2e-2
 
 
+@pytest.mark.parametrize("D,E", [(128, 256), (64, 128)])
+@pytest.mark.parametrize("B,T,form,rows", [(1, 203, "A", 0), (1, 203, "B", 0), (1, 2024, "A", 0), (1, 2024, "B", 0), (2, 1012, "A", 32), (3, 117, "B", 32), (2, 100, "A", 16)])
+def test_row_chain_matches_the_separate_launches(D, E, B, T, form, rows, monkeypatch):
+    """sea_row_chain against the launches it replaces AND the fp32 formulas on the bf16 operands: form A = self-attention out-projection + residual, form B = a
+    field's exchange tail (projections + GELU, up-projection of the sum + residual); then cross_down + AdaLN of the updated rows and — from the NORMALISED rows,
+    without a round trip through HBM — q for two pairs and k / v for two pairs with the rotary epilogue, written in the attention layouts (reference
+    models/temporal.py:176-192, models/base_blocks.py:271-280).  16- and 32-row workgroups (`rows`; 0 = the launcher's choice); tiles that straddle
+    trajectories (T not a multiple of 16); one group without projections and one without the down-projection beside the full one."""
+    from sea_amd import ops
+
+    if rows:
+        monkeypatch.setenv("SEA_TUNE", f"chain_rows={rows}")   # (read once per process by the library: only the first forced value of a process takes effect)
+    dt = torch.bfloat16
+    M, H = B * T, D // 16
+    hd = D // H
+    cap = T + 8
+    table = rope_table(hd, T)
+    S = 2 if form == "B" else 0
+    att = [rnd(M, D, dtype=dt, seed=800 + s) for s in range(S)]
+    Wp = [rnd(D, D, dtype=dt, scale=0.15, seed=810 + s) for s in range(S)]
+    K2 = D if form == "B" else E
+    a2 = rnd(M, E, dtype=dt, seed=805) if form == "A" else None
+    W2, b2 = rnd(E, K2, dtype=dt, scale=0.1, seed=820), (0.2 * rnd(E, seed=821) if form == "B" else None)
+    Wd, bd = rnd(D, E, dtype=dt, scale=0.1, seed=822), 0.2 * rnd(D, seed=823)
+    xin = rnd(M, 3 * E, seed=824)[:, E:2 * E]          # the residual rows inside a wider tensor (row stride 3 E: the caller's [B, T, F, E] layout)
+    mod = rnd(M, 2 * D, dtype=dt, scale=0.5, seed=825)
+    gamma, beta = 1 + 0.1 * rnd(D, seed=826), 0.1 * rnd(D, seed=827)
+    Wq = [rnd(D, D, dtype=dt, scale=D ** -0.5, seed=830 + k) for k in range(2)]
+    bq = [rnd(D, seed=834 + k) for k in range(2)]
+    Wkv = [rnd(2 * D, D, dtype=dt, scale=D ** -0.5, seed=840 + k) for k in range(2)]
+    bkv = [rnd(2 * D, seed=844 + k) for k in range(2)]
+    new = lambda *shape: torch.zeros(*shape, device=dev(), dtype=dt)   # noqa: E731
+    Q = [new(B, H, T, hd) for _ in range(2)]
+    Kc, Vt = [new(B, H, cap, hd) for _ in range(2)], [new(B, H, hd, cap) for _ in range(2)]
+    x, xa, nd = torch.empty(M, E, device=dev()), new(M, E), new(M, D)
+    x_b, x_c, nd_b = torch.empty(M, E, device=dev()), torch.empty(M, E, device=dev()), new(M, D)
+    qs = ops.q_scale(hd)
+    proj = [dict(W=Wq[0], bias=bq[0], col0=0, Q=Q[0]), dict(W=Wkv[0], bias=bkv[0], col0=D, K=Kc[0], Vt=Vt[0]),
+            dict(W=Wq[1], bias=bq[1], col0=0, Q=Q[1]), dict(W=Wkv[1], bias=bkv[1], col0=D, K=Kc[1], Vt=Vt[1])]
+    common = dict(W2=W2, b2=b2, bias_scale=float(max(S, 1)), Xin=xin, att=att, Wp=Wp, a2=a2)
+    down = dict(W=Wd, bias=bd, gamma=gamma, beta=beta, mod=mod)
+    assert ops.row_chain_supported(dt, D, E, S, hd)
+    ops.row_chain([dict(common, X=x, Xact=xa, down=dict(down, Yact=nd), proj=proj),       # everything
+                   dict(common, X=x_b, down=dict(down, Yact=nd_b)),                        # no projections
+                   dict(common, X=x_c)],                                                    # no down-projection either (the last field's tail)
+                  rope=table, H=H, hd=hd, T=T, pos0=0, cap=cap, q_scale_=qs)
+    # fp32 formulas on the bf16 operands (intermediates rounded where the kernel rounds them: g, x and y are MFMA operands of the next layer)
+    if form == "B":
+        gs = sum(gelu(att[s].float() @ Wp[s].float().t()) for s in range(S)).to(dt).float()
+        xn = xin + gs @ W2.float().t() + S * b2
+    else:
+        xn = xin + a2.float() @ W2.float().t()
+    for got in (x, x_b, x_c):
+        assert rel(got, xn) < 5e-5
+    assert rel(xa.float(), xn) < 6e-3
+    v = xn.to(dt).float() @ Wd.float().t() + bd
+    y = torch.nn.functional.layer_norm(v, (D,), None, None, 1e-5) * (gamma + 1 + mod[:, :D].float()) + (beta + mod[:, D:].float())
+    assert rel(nd.float(), y) < 6e-3 and rel(nd_b.float(), y) < 6e-3
+    yb = y.to(dt).float()
+    cos, sin = table[:T, :, 0], table[:T, :, 1]
+    for k in range(2):
+        q = rope_ref((yb @ Wq[k].float().t() + bq[k]).view(B, T, H, hd), cos, sin) * qs
+        kv = yb @ Wkv[k].float().t() + bkv[k]
+        kk = rope_ref(kv[:, :D].view(B, T, H, hd), cos, sin)
+        vv = kv[:, D:].view(B, T, H, hd)
+        assert rel(Q[k].float(), q.permute(0, 2, 1, 3)) < 1.2e-2, k
+        assert rel(Kc[k][:, :, :T].float(), kk.permute(0, 2, 1, 3)) < 1.2e-2, k
+        assert rel(Vt[k][:, :, :, :T].float(), vv.permute(0, 2, 3, 1)) < 1.2e-2, k
+        assert float(Kc[k][:, :, T:].abs().max()) == 0 and float(Vt[k][:, :, :, T:].abs().max()) == 0   # nothing beyond the rows of this call
+    # the launches the chain replaces, on the same operands
+    x2, xa2 = torch.empty(M, E, device=dev()), new(M, E)
+    if form == "B":
+        ops.exchange_tail(att, Wp, W2, b2, float(S), x2.copy_(xin), Xact=xa2)
+    else:
+        ops.gemm_grouped([dict(A=a2, W=W2, R=xin.contiguous(), C32=x2, Cact=xa2)], dt)
+    assert rel(x, x2) < 2e-5
+    nd2 = new(M, D)
+    ops.gemm_rownorm([dict(A=xa2, W=Wd, bias=bd, mod=mod, gamma=gamma, beta=beta, Yact=nd2)], 1e-5, dt)
+    assert rel(nd.float(), nd2.float()) < 1e-2
+    Q2, K2_, V2 = new(B, H, T, hd), new(B, H, cap, hd), new(B, H, hd, cap)
+    ops.qkv_rope_grouped([dict(A=nd2, W=Wq[1], bias=bq[1], col0=0, Q=Q2), dict(A=nd2, W=Wkv[1], bias=bkv[1], col0=D, K=K2_, Vt=V2)], table, H, hd, T, 0, cap, qs, dt)
+    assert rel(Q[1].float(), Q2.float()) < 1.5e-2 and rel(Kc[1].float(), K2_.float()) < 1.5e-2 and rel(Vt[1].float(), V2.float()) < 1.5e-2
+
+
+def test_row_chain_unsupported_shapes_are_refused():
+    from sea_amd import ops
+
+    assert not ops.row_chain_supported(torch.float32, 128, 256, 2, 16) and not ops.row_chain_supported(torch.bfloat16, 128, 256, 3, 16)
+    assert not ops.row_chain_supported(torch.bfloat16, 256, 512, 0, 32)
+    with pytest.raises(RuntimeError, match="unsupported"):
+        ops.row_chain([dict(W2=rnd(64, 64, dtype=torch.bfloat16), Xin=rnd(8, 64), X=rnd(8, 64), a2=rnd(8, 64, dtype=torch.bfloat16))])
+
+
 def test_exchange_tail_unsupported_shapes_are_refused():
     from sea_amd import ops
 

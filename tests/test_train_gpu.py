@@ -240,6 +240,63 @@ def test_cfg3_shape_gradients_match_reference_golden(dtype, tol):
             assert rel_l2(q[:: grad_sub_stride(q.numel())].cpu().numpy(), g["p1sub:" + k]) < 2e-4, k
 
 
+_CFG3_ORACLE = {}
+
+
+def _cfg3_oracle_b8():
+    """BASELINE.json configs[2] at ITS OWN batch on the host: loss and gradients of the CPU oracle for B = 8 trajectories of T = 2024 (E=256, H=8, F=3, AdaLN).
+    The loss is a mean over all elements, so the batch gradient is the mean of the per-trajectory gradients: one trajectory at a time keeps the oracle's
+    materialised [H, T, T] score tensors at 5 GB instead of 40 (about a minute of CPU on the box's cores).  Cached for both dtypes."""
+    if not _CFG3_ORACLE:
+        cfg = O.OracleConfig(1, 256, 8, 2024, 8, 0, 3, 2, True, "adaln")
+        x, tgt, ib = recipe_inputs(8, 2024, cfg, seed=808)
+        p = recipe_params(cfg)
+        loss, grads = 0.0, {}
+        for b in range(8):
+            _, lb, gb = O.loss_and_grads(x[b:b + 1], ib[b:b + 1], tgt[b:b + 1], p, cfg)
+            loss += float(lb) / 8
+            for k, g in gb.items():
+                grads[k] = grads.get(k, 0) + g.double() / 8
+        _CFG3_ORACLE.update(cfg=cfg, x=x, tgt=tgt, ib=ib, loss=loss, grads=grads)
+    return _CFG3_ORACLE
+
+
+@pytest.mark.parametrize("dtype,tol", [("fp32", 1e-4), ("bf16", 6e-2)])
+def test_cfg3_own_batch_gradients_match_oracle(dtype, tol):
+    """BASELINE.json configs[2] at its own size — B = 8 trajectories, T = 2024 — against the ORACLE (not against another driver of the same kernels): the
+    fused step's forward + MSE + backward (engine.forward_train / mse_loss_and_grad / backward: what engine.train_step runs in front of the optimizer)
+    gives the oracle's loss and, on the golden files' strided sub-samples (tests/conftest.py::grad_sub_stride), the oracle's gradient of every live
+    parameter: fp32 <= 1e-4 relative L2 over all sub-samples together (north_star's bar), bf16 <= 6e-2; every single parameter within 10x of that; the
+    norm of every gradient within the same bar.  Reference step: train/train_temporal.py:254-258."""
+    from tests.conftest import grad_sub_stride
+
+    R = _cfg3_oracle_b8()
+    cfg = R["cfg"]
+    m = build(cfg, dtype).train()
+    eng = m.engine()
+    out, plan = eng.forward_train(R["x"].cuda(), R["ib"].cuda())
+    loss, dout = eng.mse_loss_and_grad(out, R["tgt"].cuda())
+    eng.zero_grads()
+    eng.backward(plan, dout)
+    assert abs(loss.item() - R["loss"]) < tol * R["loss"]
+    assert set(R["grads"]) == set(eng.params.live_names)
+    num = den = 0.0
+    worst, worst_k = 0.0, None
+    for k, ref_full in R["grads"].items():
+        mine = eng.grad_view(k).reshape(-1).cpu().double()
+        ref_full = ref_full.reshape(-1)
+        st = grad_sub_stride(mine.numel())
+        sub, ref = mine[::st].numpy(), ref_full[::st].numpy()
+        num += float(((sub - ref) ** 2).sum())
+        den += float((ref ** 2).sum())
+        assert abs(float(mine.norm()) - float(ref_full.norm())) < (2e-4 if dtype == "fp32" else 6e-2) * float(ref_full.norm()), k
+        e = rel_l2(sub, ref)
+        if e > worst:
+            worst, worst_k = e, k
+    assert (num / den) ** 0.5 < tol, (num / den) ** 0.5
+    assert worst < 10 * tol, (worst_k, worst)
+
+
 def test_cfg3_full_size_fused_step_equals_autograd_path_and_replays():
     """cfg3 at its own size (B=8 trajectories, T=2024, bf16): the fused train_step against the autograd path (same kernels, different driver),
     and two replays of forward + backward on the same inputs: outputs bit-identical, gradients equal up to the order of the fp32 atomics of

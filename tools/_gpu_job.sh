@@ -1,9 +1,12 @@
-set -x
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-O=gpurun_out/r04a; mkdir -p $O
-python bench.py --mode rollout --steps 20 --warmup 5 --no-cpu-baseline > $O/base_rollout.json 2> $O/base_rollout.err
-timeout -k 10 600 python -m pytest tests/test_parallel_gpu.py -x -q > $O/test_parallel.log 2>&1; echo "parallel rc=$?" >> $O/test_parallel.log
-SEA_DUMP_MAPS=$O/maps_persist.txt rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_kv -o run -- python3 bench.py --mode kv --steps 3 --warmup 1 > $O/prof_kv.json 2> $O/prof_kv.err; echo "kv persist rc=$?" > $O/prof_kv.rc
-SEA_TUNE=kv_persist=0 SEA_DUMP_MAPS=$O/maps_nopersist.txt rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_kv0 -o run -- python3 bench.py --mode kv --steps 3 --warmup 1 > $O/prof_kv0.json 2> $O/prof_kv0.err; echo "kv nopersist rc=$?" > $O/prof_kv0.rc
-rm -rf $O/prof_kv/*trace* $O/prof_kv0/*trace*
-tail -3 $O/test_parallel.log; cat $O/prof_kv.rc $O/prof_kv0.rc; tail -c 600 $O/base_rollout.json
+O=gpurun_out/r04g; mkdir -p $O
+for T in "gemm_tile=128" "gemm_tile=128,gemm_n_major=0" "gemm_tile=64,gemm_dma_min_k=100000"; do
+SEA_TUNE=$T python bench.py --mode shipped --steps 10 --warmup 3 > $O/shipped_t.json 2> $O/shipped_t.err
+python - "$T" <<'PY'
+import json,sys
+d=json.loads(open("gpurun_out/r04g/shipped_t.json").read().strip().splitlines()[-1])
+sh=d.get("shipped",d)
+for k,v in sh.items():
+    if isinstance(v,dict): print(sys.argv[1], k, round(v["forward_ms"],4), round(v["train_ms_per_step"],4), v["top_launches_ms"])
+PY
+done
