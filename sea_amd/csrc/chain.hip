@@ -568,6 +568,12 @@ __global__ __launch_bounds__(256) void row_chain_kernel(const ChainLaunch L) {
     }
 }
 
+// (Round 4, measured and removed — tools/chain_probe.py, gpurun_out/r04i/stamps2.txt: a second form of this kernel streamed 16 KiB weight slabs through a six-slot LDS
+// ring with two loader waves (global_load_lds only in their vmcnt queue, counted waits, FULL / FREE words in LDS) to four consumer waves that each owned 16 complete
+// rows of a 64-row workgroup, so that no consumer ever met another at a barrier.  It was correct and 2x SLOWER: 31 us per launch against 15.  A slab's round trip on
+// this path is ~2.5 us (the weights are cold in the XCD's L2 at every step), the ring holds 6 slabs, so 24 slabs are four to five dependent round trips however
+// the waves are organised — the burst form above has the same number of round trips with 4-8x the bytes in each.)
+
 template <typename K>
 static int set_lds_chain(K kernel, int bytes) {
     return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess ? 0 : -1;
@@ -653,8 +659,8 @@ extern "C" int sea_row_chain(const SeaRowChain* params, int n_groups, const SeaQ
             return SEA_EUNSUPPORTED;
         }
     }
-    const dim3 grid((m_max + 16 * mi - 1) / (16 * mi), n_groups);
     hipStream_t s = static_cast<hipStream_t>(stream);
+    const dim3 grid((m_max + 16 * mi - 1) / (16 * mi), n_groups);
 #define LAUNCH_CH(DD, EE, MM)                                                                                   \
     do {                                                                                                        \
         static int once = set_lds_chain(row_chain_kernel<DD, EE, MM>, ChainCfg<DD, EE, MM>::LDS_BYTES);         \

@@ -100,7 +100,8 @@ def stamps():
     L = N.lib()
     L.sea_chain_debug_stamps.argtypes = [C.c_void_p]
     L.sea_chain_debug_stamps.restype = None
-    for form, nf, rows in (("A", 1, 16), ("A", 3, 32), ("B", 1, 16)):
+    form2 = len(sys.argv) > 2 and sys.argv[2] == "2"
+    for form, nf, rows in ((("A", 1, 64), ("A", 3, 64), ("B", 1, 64)) if form2 else (("A", 1, 16), ("A", 3, 32), ("B", 1, 16))):
         gs = []
         for f in range(nf):
             S = 2 if form == "B" else 0
@@ -128,7 +129,10 @@ def stamps():
         med = torch.nanmedian(rel, dim=0).values
         mx = torch.from_numpy(__import__("numpy").nanmax(rel.numpy(), axis=0))
         print(f"form {form} {nf} field(s) {rows} rows/wg ({nwg} workgroups): phase stamps, us after the first workgroup's entry (median | max over workgroups)")
-        names = ["entry", "burst0 requested", "operands requested", "burst0 landed", "stage 2 multiplied", "Wd + proj burst landed", "x stored", "stage 3 done",
+        if form2:
+            names2 = ["entry", "own rows landed", "stage 2 multiplied", "x stored", "stage 3 multiplied", "y done", "entry 0 done", "entry 1 done", "entry 2 done", "entry 3 done",
+                      "loader 0 starts", "loader 0 first publish", "loader 0 last publish", "", "", ""]
+        names = names2 if form2 else ["entry", "burst0 requested", "operands requested", "burst0 landed", "stage 2 multiplied", "Wd + proj burst landed", "x stored", "stage 3 done",
                  "burst A landed", "burst A computed", "burst B landed", "burst B computed", "burst C landed", "burst C computed", "", ""]
         for k in range(16):
             if not torch.isnan(med[k]):
