@@ -596,6 +596,16 @@ typedef struct {
 /* params: n_groups <= SEA_CHAIN_MAX_GROUPS problems of one (D, E) (e.g. the F fields), one grid row each; common: rotary table, heads, positions of the projections
  * (may be NULL when no group has projections) */
 int sea_row_chain(const SeaRowChain* params, int n_groups, const SeaQkvCommon* common, float eps, int dtype, void* stream);
+/* The same launch carrying RIDERS: work of later launches that depends on nothing this one computes, run by extra workgroups on the CUs the chain leaves idle
+ * (at one trajectory a chain launch is 127-192 workgroups on 256 CUs):
+ *   riders   n_riders <= 8 plain groups as sea_gemm_grouped takes them (A, W, bias, Cact; bf16, K a multiple of 64: AdaLN's cond_mlp.2 of the modules the field
+ *            MLP and the final norm read, models/base_blocks.py:339,344), cut into 128 x 128 tiles numbered group by group; THIS launch runs tiles
+ *            [tile0, tile0 + n_tiles) — the caller spreads a GEMM over several chain launches;
+ *   ib       NULL, or the information-bottleneck MLP whose rows ib->X[0][m, :] are STORED as sea_silu_outer_ib stores them (models/temporal.py:111-116).
+ * Results are complete when the launch is; nothing in the same launch may read them. */
+struct SeaIbParams_;
+int sea_row_chain_riders(const SeaRowChain* params, int n_groups, const SeaQkvCommon* common, const SeaGemmGroup* riders, int n_riders, int tile0, int n_tiles,
+                         const struct SeaIbParams_* ib, float eps, int dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Launch list: a whole plan (every launch of TemporalModel.forward, models/temporal.py:405-416, in order) replayed by ONE call, so the host
@@ -610,7 +620,8 @@ int sea_row_chain(const SeaRowChain* params, int n_groups, const SeaQkvCommon* c
  *     SEA_OP_MLP2   p0 = SeaMlp2Group[n], f0 = eps
  *     SEA_OP_GEMM_FEW p0 = SeaGemmGroup[n], p1 = pre or NULL, i0 = pre_x_is_act, i1 = pre_gelu, f0 = eps
  *     SEA_OP_QKV_FEW  p0 = SeaQkvGroup[n], p1 = SeaQkvCommon, l0 = (intptr) pre or 0, f0 = eps
- *     SEA_OP_CHAIN    p0 = SeaRowChain[n], p1 = SeaQkvCommon or NULL, f0 = eps
+ *     SEA_OP_CHAIN    p0 = SeaRowChain[n], p1 = SeaQkvCommon or NULL, f0 = eps; riders (sea_row_chain_riders): l0 = (intptr) SeaGemmGroup[i0] or 0, i1 = tile0, i2 = n_tiles,
+ *                     l1 = (intptr) SeaIbParams or 0
  * Returns 0, or the failing entry's error code with sea_last_error() set (entries before it have been launched).
  */
 enum { SEA_OP_GEMM = 1, SEA_OP_QKV = 2, SEA_OP_ATTN = 3, SEA_OP_NORM = 4, SEA_OP_SILU = 5, SEA_OP_IB = 6, SEA_OP_CONVERT = 8, SEA_OP_GEMM_NORM = 9, SEA_OP_XTAIL = 10, SEA_OP_MLP1 = 11, SEA_OP_MLP2 = 13, SEA_OP_GEMM_FEW = 14, SEA_OP_QKV_FEW = 15, SEA_OP_CHAIN = 16 };   /* 7 and 12 were round-1 entry points (sea_rowchain, sea_cond_mlp), removed in ABI v2 */

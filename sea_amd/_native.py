@@ -143,6 +143,7 @@ class SeaExchangeTail(C.Structure):
 
 CHAIN_MAX_PROJ = 6
 CHAIN_MAX_GROUPS = 3
+CHAIN_MAX_RIDERS = 8
 
 
 class SeaRowChain(C.Structure):
@@ -260,6 +261,8 @@ def lib() -> C.CDLL:
     L.sea_exchange_tail.restype = C.c_int
     L.sea_row_chain.argtypes = [C.POINTER(SeaRowChain), C.c_int, C.POINTER(SeaQkvCommon), C.c_float, C.c_int, _vp]
     L.sea_row_chain.restype = C.c_int
+    L.sea_row_chain_riders.argtypes = [C.POINTER(SeaRowChain), C.c_int, C.POINTER(SeaQkvCommon), C.POINTER(SeaGemmGroup), C.c_int, C.c_int, C.c_int, C.POINTER(SeaIbParams), C.c_float, C.c_int, _vp]
+    L.sea_row_chain_riders.restype = C.c_int
     L.sea_patchify.argtypes = [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _vp]
     L.sea_patchify.restype = C.c_int
     L.sea_silu_outer_ib.argtypes = [C.POINTER(SeaSiluGroup), C.c_int, _vp, C.c_int, C.c_int, _vp, C.c_int, _vp]
@@ -304,7 +307,7 @@ EXPORTED_SYMBOLS = (
     "sea_mse_fwd_bwd", "sea_relative_mse", "sea_adamw_flat",
     "sea_wgrad_grouped", "sea_transpose_weights", "sea_rownorm_bwd", "sea_silu_outer_bwd", "sea_ib_bwd",
     "sea_attention_bwd", "sea_dropout_mask", "sea_run_list", "sea_run_list_steps", "sea_unpatchify", "sea_gemm_rownorm", "sea_exchange_tail", "sea_patchify", "sea_silu_outer_ib", "sea_mlp_fc1_ln_gelu", "sea_mlp_fc2_proj_norm", "sea_kv_rollout", "sea_kv_arena_words", "sea_kv_debug_stamps",
-    "sea_gemm_fewrows", "sea_qkv_rope_fewrows", "sea_row_chain",
+    "sea_gemm_fewrows", "sea_qkv_rope_fewrows", "sea_row_chain", "sea_row_chain_riders",
 )
 
 

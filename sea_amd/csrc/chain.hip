@@ -20,14 +20,52 @@
 // the layer that read it is done, so a burst lands under the layer in front of its consumer — plus the A tile / bf16 x tile, the g / y tile, the rotary rows
 // and projection biases of the workgroup's rows, and the statistics scratch.
 #include "norm_epilogue.hpp"
+#include "gemm_tile.hpp"
+#include "ib_rows.hpp"
 #include <stdlib.h>
+
+// Riders: work of LATER launches that depends on nothing this launch computes, run by extra workgroups of this launch on the CUs its chain workgroups leave idle
+// (a chain launch at one trajectory is 127-192 workgroups on 256 CUs).  Two kinds: 128 x 128 tiles of plain grouped GEMMs (cond_mlp.2 of the AdaLN modules the
+// field MLP and the final norm read, models/base_blocks.py:339,344: their operand, silu(cond_mlp.0), comes from the silu launch in front) and rows of the
+// information-bottleneck MLP (models/temporal.py:111-116) stored for the pass that adds them.  grid.y = n_groups is the rider row.
+#define SEA_CHAIN_MAX_RIDERS 8
+struct ChainRiderPod {
+    const void* A;
+    const void* W;
+    const float* bias;
+    void* Cact;
+    int lda, ldw, ldcact, M, N, K, tile_start, pad_;
+};
+// what gemm_tile_body reads of a SeaGemmGroup, for a rider: A, W, bias, activation-dtype output — everything else a compile-time constant
+struct ChainRiderGroup {
+    static constexpr int64_t a_seg_stride = 0;
+    static constexpr int n_seg = 1, act = 0, ldr = 0, ldc32 = 0, ldz = 0;
+    static constexpr float bias_scale = 1.0f;
+    static constexpr const float* R = nullptr;
+    static constexpr float* C32 = nullptr;
+    static constexpr void* Z = nullptr;
+    static constexpr SeaDropout drop = {0u, 0u, 0, 0};
+    static constexpr const float* silu_c = nullptr;
+    static constexpr const float* silu_w1 = nullptr;
+    static constexpr const float* silu_b1 = nullptr;
+    const void* A;
+    const void* W;
+    const float* bias;
+    void* Cact;
+    int lda, ldw, ldcact, M, N, K;
+};
 
 struct ChainLaunch {
     SeaRowChain p[SEA_CHAIN_MAX_GROUPS];   // grid.y = group (field)
     SeaQkvCommon c;
     float eps;
+    int n_groups;
     unsigned long long* stamps;   // tuning aid (sea_chain_debug_stamps): 16 clock stamps (100 MHz) per workgroup, or NULL
+    ChainRiderPod rg[SEA_CHAIN_MAX_RIDERS];
+    int n_riders, rider_t0, rider_n, ib_wgs;   // this launch runs rider tiles [rider_t0, rider_t0 + rider_n) and ib_wgs workgroups of info-bottleneck rows
+    SeaIbParams ib;
 };
+static_assert(sizeof(ChainLaunch) <= 4096, "kernel arguments of sea_row_chain");
 
 static unsigned long long* g_chain_stamps = nullptr;
 // Tuning aid, not part of the ABI proper: a device buffer of (workgroups of the next launches) * 16 8-byte words receives time stamps of the chain's phases.
@@ -199,6 +237,30 @@ __global__ __launch_bounds__(256) void row_chain_kernel(const ChainLaunch L) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 15, g = lane >> 4;
+    if ((int)blockIdx.y == L.n_groups) {   // ---- the rider row (block-uniform)
+        const int x = blockIdx.x;
+        if (x < L.rider_n) {
+            const int tile = L.rider_t0 + x;
+            int gi = 0;
+            while (gi + 1 < L.n_riders && tile >= L.rg[gi + 1].tile_start) ++gi;
+            const ChainRiderPod& R = L.rg[gi];
+            ChainRiderGroup G;
+            G.A = R.A; G.W = R.W; G.bias = R.bias; G.Cact = R.Cact;
+            G.lda = R.lda; G.ldw = R.ldw; G.ldcact = R.ldcact; G.M = R.M; G.N = R.N; G.K = R.K;
+            const int t = tile - R.tile_start;
+            const int tiles_n = (R.N + 127) / 128;
+            // the LDS-DMA ring main loop (4 stages of A | W K-tiles in flight): a rider workgroup is ALONE on its CU (the launch's LDS request is the chain's), so
+            // nothing else hides its memory latency — the single-buffered form took 15 us per tile here, generated operand included (round 4, measured)
+            gemm_tile_body<T, 128, 128, true, true, false>(G, t / tiles_n, t % tiles_n, smem, 0);
+        } else if (x < L.rider_n + L.ib_wgs) {
+            const int row0 = (x - L.rider_n) * 64 + wave * 16;   // a wave per row, 16 rows per wave
+            for (int i = 0; i < 16; ++i) {
+                const int row = row0 + i;
+                if (row < L.ib.M) ib_store_row(L.ib, L.ib.c[row], row, lane);
+            }
+        }
+        return;
+    }
     // ---- the group's parameter block: four dwords per lane, straight from the kernel-argument segment
     ChainParams pl;
     {
@@ -579,12 +641,51 @@ static int set_lds_chain(K kernel, int bytes) {
     return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess ? 0 : -1;
 }
 
+static int row_chain_launch(const SeaRowChain* params, int n_groups, const SeaQkvCommon* common, const SeaGemmGroup* riders, int n_riders, int tile0, int n_tiles,
+                            const SeaIbParams* ib, float eps, int dtype, void* stream);
+
 extern "C" int sea_row_chain(const SeaRowChain* params, int n_groups, const SeaQkvCommon* common, float eps, int dtype, void* stream) {
+    return row_chain_launch(params, n_groups, common, nullptr, 0, 0, 0, nullptr, eps, dtype, stream);
+}
+
+extern "C" int sea_row_chain_riders(const SeaRowChain* params, int n_groups, const SeaQkvCommon* common, const SeaGemmGroup* riders, int n_riders, int tile0, int n_tiles,
+                                    const SeaIbParams* ib, float eps, int dtype, void* stream) {
+    return row_chain_launch(params, n_groups, common, riders, n_riders, tile0, n_tiles, ib, eps, dtype, stream);
+}
+
+static int row_chain_launch(const SeaRowChain* params, int n_groups, const SeaQkvCommon* common, const SeaGemmGroup* riders, int n_riders, int tile0, int n_tiles,
+                            const SeaIbParams* ib, float eps, int dtype, void* stream) {
     SEA_REQUIRE(params != nullptr && n_groups >= 1 && n_groups <= SEA_CHAIN_MAX_GROUPS, "sea_row_chain: n_groups=%d out of range", n_groups);
     ChainLaunch L;
     memset(&L, 0, sizeof(L));
     L.eps = eps;
+    L.n_groups = n_groups;
     L.stamps = g_chain_stamps;
+    // ---- riders (validated like sea_gemm_grouped's generated-operand groups)
+    SEA_REQUIRE(n_riders >= 0 && n_riders <= SEA_CHAIN_MAX_RIDERS && (n_riders == 0 || riders != nullptr) && tile0 >= 0 && n_tiles >= 0, "sea_row_chain_riders: bad rider arguments");
+    int rider_total = 0;
+    for (int i = 0; i < n_riders; ++i) {
+        const SeaGemmGroup& G = riders[i];
+        SEA_REQUIRE(dtype == SEA_BF16 && G.A && !G.silu_c && G.W && G.Cact && !G.C32 && !G.R && !G.Z && G.act == 0 && G.drop.thr == 0 && G.n_seg == 1,
+                    "sea_row_chain_riders[%d]: a rider is a plain bf16 group (A, W, bias, Cact only)", i);
+        SEA_REQUIRE(G.M >= 1 && G.N >= 8 && G.N % 8 == 0 && G.K >= 64 && G.K % 64 == 0 && G.lda % 8 == 0 && G.lda >= G.K && G.ldw % 8 == 0 && G.ldw >= G.K && G.ldcact % 8 == 0 && G.ldcact >= G.N,
+                    "sea_row_chain_riders[%d]: bad shape M=%d N=%d K=%d (whole 64-wide K-tiles) lda=%d ldw=%d ldcact=%d", i, G.M, G.N, G.K, G.lda, G.ldw, G.ldcact);
+        SEA_REQUIRE(sea_aligned16(G.A) && sea_aligned16(G.W) && sea_aligned16(G.bias) && sea_aligned16(G.Cact), "sea_row_chain_riders[%d]: pointers must be 16-byte aligned", i);
+        ChainRiderPod& R = L.rg[i];
+        R.A = G.A; R.W = G.W; R.bias = G.bias; R.Cact = G.Cact;
+        R.lda = G.lda; R.ldw = G.ldw; R.ldcact = G.ldcact; R.M = G.M; R.N = G.N; R.K = G.K;
+        R.tile_start = rider_total;
+        rider_total += ((G.M + 127) / 128) * ((G.N + 127) / 128);
+    }
+    SEA_REQUIRE(tile0 + n_tiles <= rider_total, "sea_row_chain_riders: tiles [%d, %d) of %d", tile0, tile0 + n_tiles, rider_total);
+    L.n_riders = n_riders; L.rider_t0 = tile0; L.rider_n = n_tiles;
+    if (ib != nullptr) {
+        SEA_REQUIRE(ib->X[0] && ib->c && ib->w1 && ib->M >= 1 && ib->E >= 4 && ib->E % 4 == 0 && ib->ldx >= ib->E && ib->mode >= 0 && ib->mode <= 2 &&
+                        (ib->mode != 0 || (ib->b1 && ib->lnw && ib->lnb && ib->w2 && ib->b2 && ib->h >= 1 && ib->h <= 64)),
+                    "sea_row_chain_riders: bad info-bottleneck rider");
+        L.ib = *ib;
+        L.ib_wgs = (ib->M + 63) / 64;
+    }
     const int D = params[0].D, E = params[0].E;
     int m_max = 0, any_proj = 0;
     for (int gi = 0; gi < n_groups; ++gi) {
@@ -660,12 +761,17 @@ extern "C" int sea_row_chain(const SeaRowChain* params, int n_groups, const SeaQ
         }
     }
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const dim3 grid((m_max + 16 * mi - 1) / (16 * mi), n_groups);
+    const int chain_x = (m_max + 16 * mi - 1) / (16 * mi), rider_x = L.rider_n + L.ib_wgs;
+    const dim3 grid(chain_x > rider_x ? chain_x : rider_x, n_groups + (rider_x > 0 ? 1 : 0));
+    // a rider tile runs the 4-stage LDS-DMA ring of the 128 x 128 GEMM: the launch requests the larger of the two footprints
+    constexpr int rider_lds = GemmMainloop<__bf16, 128, 128>::DMA_LDS_BYTES;
 #define LAUNCH_CH(DD, EE, MM)                                                                                   \
     do {                                                                                                        \
-        static int once = set_lds_chain(row_chain_kernel<DD, EE, MM>, ChainCfg<DD, EE, MM>::LDS_BYTES);         \
+        constexpr int own_ = ChainCfg<DD, EE, MM>::LDS_BYTES;                                                   \
+        constexpr int max_ = own_ > rider_lds ? own_ : rider_lds;                                               \
+        static int once = set_lds_chain(row_chain_kernel<DD, EE, MM>, max_);                                    \
         (void)once;                                                                                             \
-        row_chain_kernel<DD, EE, MM><<<grid, dim3(256), ChainCfg<DD, EE, MM>::LDS_BYTES, s>>>(L);               \
+        row_chain_kernel<DD, EE, MM><<<grid, dim3(256), (L.rider_n > 0 ? max_ : own_), s>>>(L);                 \
     } while (0)
     if (D == 128) { if (mi == 1) LAUNCH_CH(128, 256, 1); else LAUNCH_CH(128, 256, 2); }
     else { if (mi == 1) LAUNCH_CH(64, 128, 1); else LAUNCH_CH(64, 128, 2); }

@@ -31,10 +31,10 @@ template <int KT, int NSB>
 struct Mlp1Lds {
     static constexpr int BYTES = KT * 32 * 128 + 4 * (KT * 64 * 128) + 2 * (NSB * 128) * 4;
 };
-// LDS request of mlp_fc2_proj_norm_kernel<KTE, KTS>: the 3-stage (A | W) ring, the x3 tile, the statistics scratch
+// LDS request of mlp_fc2_proj_norm_kernel<KTE, KTS>: the 4-stage (A | W) ring (the x3 tile lives in the A pieces of its slots), the statistics scratch
 template <int KTE, int KTS>
 struct Mlp2Lds {
-    static constexpr int BYTES = 3 * (32 * 128 + KTE * 64 * 128) + KTE * 32 * 128 + 2 * 8 * 32 * 4;
+    static constexpr int BYTES = 4 * (32 * 128 + KTE * 64 * 128) + 2 * 8 * 32 * 4;
 };
 
 // KT = E / 64 K-tiles; NSB = S / 128 column blocks per wave
@@ -338,17 +338,22 @@ struct Mlp2Launch {
 template <int KTE, int KTS>
 __global__ __launch_bounds__(512) void mlp_fc2_proj_norm_kernel(const Mlp2Launch L) {
     using T = __bf16;
-    constexpr int BM = 32, BKB = 128, BK = 64, NS = 3, NW = 8;
+    // Round 4: FOUR ring stages (three in flight beside the one being multiplied) instead of three.  The launch is a chain of 36 tiny stages (4 MFMAs per
+    // wave and K-tile) fed by a 36 KiB DMA piece each: its time is the weight stream's latency x bytes / bytes in flight (23 us at 72 KiB in flight).  The 16 KiB
+    // of the x3 tile that used to cap the ring at three slots now live in the A pieces of the slots themselves: the second layer's K-tile kt is stage KTS + kt
+    // = slot kt (KTS % NS == 0), whose 4 KiB A piece is not used by that stage's DMA.
+    constexpr int BM = 32, BKB = 128, BK = 64, NS = 4, NW = 8;
     constexpr int E = KTE * 64, S = KTS * 64;
     constexpr int STAGE_A = BM * BKB, STAGE_W = E * BKB, STAGE = STAGE_A + STAGE_W;
-    constexpr int X_OFF = NS * STAGE, RED_OFF = X_OFF + KTE * BM * BKB;      // x3 tile (K-tile major, swizzled like a DMA'd tile), statistics scratch
+    constexpr int RED_OFF = NS * STAGE;                                       // statistics scratch behind the ring
+    static_assert(KTS % NS == 0 && KTE <= NS, "the x3 K-tiles sit in the A pieces of slots 0 .. KTE - 1");
     constexpr int NSTAGE = KTS + KTE;
     constexpr int WPW = E / 8 / NW;                                          // 8-row W pieces per wave per stage (E = 256: 4)
-    constexpr int LPS = WPW + 1;                                             // + one A piece (waves 4 .. 7 repeat pieces 0 .. 3: same bytes, same place)
+    constexpr int LPS1 = WPW + 1, LPS2 = WPW;                                // DMA pieces per wave and stage: first layer + one A piece (waves 4 .. 7 repeat pieces 0 .. 3: same bytes, same place), second layer W only
     constexpr int NJ = E / NW / 16;                                          // 16-column blocks per wave (E = 256: 2)
     // every LDS-DMA destination lies inside the ring (stage slot + the A piece's 4 KiB + WPW * NW = E / 8 W pieces of 1 KiB), the ring, the x3 tile and
     // the statistics inside the launch's LDS request
-    static_assert(STAGE_A == 4 * 1024 && WPW * NW * 1024 == STAGE_W && RED_OFF + 2 * NW * BM * 4 == Mlp2Lds<KTE, KTS>::BYTES && Mlp2Lds<KTE, KTS>::BYTES <= 160 * 1024,
+    static_assert(STAGE_A == 4 * 1024 && WPW * NW * 1024 == STAGE_W && RED_OFF + 2 * NW * BM * 4 == Mlp2Lds<KTE, KTS>::BYTES && Mlp2Lds<KTE, KTS>::BYTES <= 160 * 1024 && 2 * LPS1 <= 63,
                   "LDS request of sea_mlp_fc2_proj_norm");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tile = L.per_xcd > 0 ? (int)(blockIdx.x & 7) * L.per_xcd + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
@@ -401,13 +406,11 @@ __global__ __launch_bounds__(512) void mlp_fc2_proj_norm_kernel(const Mlp2Launch
         const T* W = second ? Wp : W2;
         const int ldw = second ? G.ldwp : G.ldw2;
         const int kt = second ? s - KTS : s;
-        {   // the A piece of this wave (4 pieces of 8 rows; the second layer's operand is the x3 tile: the piece is issued all the same, it keeps the
-            // per-wave count of every stage equal)
+        if (!second) {   // the A piece of this wave (4 pieces of 8 rows); the second layer's operand is the x3 tile, which lives where this piece would go
             const int u = wave & 3;
             int row = m0 + u * 8 + rl;
             row = row < M ? row : M - 1;
-            const int ka = second ? 0 : kt;
-            glds16_mlp(A + (int64_t)row * G.ldh + ka * BK + chunk * 8, base + (unsigned)(u * 8 * BKB));
+            glds16_mlp(A + (int64_t)row * G.ldh + kt * BK + chunk * 8, base + (unsigned)(u * 8 * BKB));
         }
 #pragma unroll
         for (int i = 0; i < WPW; ++i) {
@@ -428,8 +431,17 @@ __global__ __launch_bounds__(512) void mlp_fc2_proj_norm_kernel(const Mlp2Launch
         // stage s has landed once at most the pieces of the stage issued after it are outstanding.  lgkmcnt(0): this wave's fragment reads of the
         // PREVIOUS stage are retired before it arrives at the barrier — the slot they read is re-staged right behind the barrier, one phase after its
         // last read, and nothing else orders an LDS-DMA write against an earlier ds_read (seen as rare wrong 8-row pieces with two workgroups per CU)
-        if (s + 1 < NSTAGE) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(LPS) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        {
+            int later = 0;                                    // pieces of the stages issued after stage s (a constant per unrolled iteration)
+            for (int t = s + 1; t <= s + NS - 2 && t < NSTAGE; ++t) later += t < KTS ? LPS1 : LPS2;
+            switch (later) {
+                case 2 * LPS1: asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * LPS1) : "memory"); break;
+                case LPS1 + LPS2: asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(LPS1 + LPS2) : "memory"); break;
+                case 2 * LPS2: asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * LPS2) : "memory"); break;
+                case LPS2: asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(LPS2) : "memory"); break;
+                default: asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); break;
+            }
+        }
         __builtin_amdgcn_s_barrier();                         // ... for every wave; and nobody still reads the slot the next DMA goes to
         if (s + NS - 1 < NSTAGE) dma_stage(s + NS - 1);
         if (s == KTS) {
@@ -441,14 +453,14 @@ __global__ __launch_bounds__(512) void mlp_fc2_proj_norm_kernel(const Mlp2Launch
                     const int n = wave * (E / NW) + j * 16 + g * 4, m = i * 16 + r;
 #pragma unroll
                     for (int q = 0; q < 4; ++q) x3v[i][j][q] = acc[i][j][q] + b2v[j][q] + rv[i][j][q];
-                    store4(reinterpret_cast<T*>(smem + X_OFF + (n >> 6) * (BM * BKB) + m * BKB + ((((n & 63) >> 3) ^ (m & 7)) << 4) + (n & 7) * 2), x3v[i][j][0], x3v[i][j][1],
+                    store4(reinterpret_cast<T*>(smem + (n >> 6) * STAGE + m * BKB + ((((n & 63) >> 3) ^ (m & 7)) << 4) + (n & 7) * 2), x3v[i][j][0], x3v[i][j][1],
                            x3v[i][j][2], x3v[i][j][3]);
                     acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
                 }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
         }
-        const char* sA = s < KTS ? smem + (s % NS) * STAGE + r * BKB : smem + X_OFF + (s - KTS) * (BM * BKB) + r * BKB;
+        const char* sA = smem + (s % NS) * STAGE + r * BKB;   // (second layer: the x3 K-tile s - KTS sits in slot (s - KTS) = s % NS's A piece)
         const char* sW = smem + (s % NS) * STAGE + STAGE_A + (wave * (E / NW) + r) * BKB;
 #pragma unroll
         for (int kc = 0; kc < 2; ++kc) {
@@ -632,12 +644,12 @@ extern "C" int sea_mlp_fc2_proj_norm(const SeaMlp2Group* groups, int n_groups, f
         total = 8 * L.per_xcd;
     }
     if (E == 256) {
-        constexpr int lds = Mlp2Lds<4, 32>::BYTES;   // ring 108 KiB + x3 tile 16 KiB + statistics 2 KiB
+        constexpr int lds = Mlp2Lds<4, 32>::BYTES;   // ring 144 KiB (x3 tile inside) + statistics 2 KiB
         static int once = set_lds_mlp(mlp_fc2_proj_norm_kernel<4, 32>, lds);
         (void)once;
         mlp_fc2_proj_norm_kernel<4, 32><<<dim3(total), dim3(512), lds, s>>>(L);
     } else {
-        constexpr int lds = Mlp2Lds<2, 16>::BYTES;    // ring 60 KiB + x3 tile 8 KiB + statistics 2 KiB
+        constexpr int lds = Mlp2Lds<2, 16>::BYTES;    // ring 80 KiB (x3 tile inside) + statistics 2 KiB
         static int once = set_lds_mlp(mlp_fc2_proj_norm_kernel<2, 16>, lds);
         (void)once;
         mlp_fc2_proj_norm_kernel<2, 16><<<dim3(total), dim3(512), lds, s>>>(L);

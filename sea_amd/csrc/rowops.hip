@@ -462,31 +462,42 @@ struct SiluIbLaunch {
     SeaIbParams ib[SEA_MAX_SILU_IB];
 };
 
-// grid = (ceil(M/4), n_groups): one wave per row, lanes stride over the K2 columns 4 at a time.
+// grid = (ceil(M / 32), n_groups [+ n_ib]): a workgroup = 32 rows of one group; a wave takes 8 of them with its slice of w1 / b1 (4 columns per lane and 256-column
+// pass) in registers, so a row is one scalar load, 4 silu per pass and one 512-byte store per wave.  (Round 4: the one-wave-per-row form was 6578 workgroups of a few
+// hundred cycles each at cfg2 — 11 us for 24 MB of stores, bound by workgroup dispatch.)  The info-bottleneck passes keep one wave per row (their grid rows come first).
 template <typename T, bool WITH_IB>
 __global__ __launch_bounds__(256) void silu_outer_kernel(const SiluLaunch L, const SiluIbLaunch I) {
-    const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= L.M) return;
-    const float cv = L.c[row];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     int gy = blockIdx.y;
     if constexpr (WITH_IB) {
         // the info-bottleneck passes take the FIRST grid rows: they are the longer ones (a dependent LayerNorm + GELU + h-term dot per element) and
         // dispatch is in grid order — last, they were a 2.5 us tail of the launch
         const int n_ib = (int)gridDim.y - L.n_groups;
         if (gy < n_ib) {   // block-uniform
-            ib_store_row(I.ib[gy], cv, row, lane);
+            for (int i = 0; i < 8; ++i) {
+                const int row = blockIdx.x * 32 + wave * 8 + i;
+                if (row < L.M) ib_store_row(I.ib[gy], L.c[row], row, lane);
+            }
             return;
         }
         gy -= n_ib;
     }
     const SeaSiluGroup& G = L.g[gy];
-    T* out = static_cast<T*>(G.Hid) + (int64_t)row * G.ld;
-    for (int i = lane * 4; i < G.K2; i += 256) {
+    const int row0 = blockIdx.x * 32 + wave * 8;
+    if (row0 >= L.M) return;
+    float cv[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) cv[i] = L.c[row0 + i < L.M ? row0 + i : L.M - 1];
+    T* out = static_cast<T*>(G.Hid) + (int64_t)row0 * G.ld;
+    for (int k = lane * 4; k < G.K2; k += 256) {
         float w[4], bb[4];
-        load4(G.w1 + i, w);
-        load4(G.b1 + i, bb);
-        store4(out + i, silu_f(w[0] * cv + bb[0]), silu_f(w[1] * cv + bb[1]), silu_f(w[2] * cv + bb[2]), silu_f(w[3] * cv + bb[3]));
+        load4(G.w1 + k, w);
+        load4(G.b1 + k, bb);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            if (row0 + i < L.M)
+                store4(out + (int64_t)i * G.ld + k, silu_f(w[0] * cv[i] + bb[0]), silu_f(w[1] * cv[i] + bb[1]), silu_f(w[2] * cv[i] + bb[2]), silu_f(w[3] * cv[i] + bb[3]));
+        }
     }
 }
 
@@ -519,7 +530,7 @@ extern "C" int sea_silu_outer_ib(const SeaSiluGroup* groups, int n_groups, const
         L.g[i] = G;
     }
     L.c = c; L.M = M; L.n_groups = n_groups;
-    const dim3 grid((M + 3) / 4, n_groups + n_ib), block(256);
+    const dim3 grid((M + 31) / 32, n_groups + n_ib), block(256);
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (n_ib > 0) {
         if (dtype == SEA_BF16) silu_outer_kernel<__bf16, true><<<grid, block, 0, s>>>(L, I);

@@ -448,7 +448,46 @@ class Plan:
                     self._x_patches.append((g, "Xin", x_off))
             common = N.SeaQkvCommon(rope.data_ptr(), self.H, hd, self.T, self.pos0, self.cap, ops.q_scale(hd))
             self._pos_structs.append(common)
-            self._cur.append(self._rec(N.lib().sea_row_chain, [arr, len(chunk), C.byref(common), 1e-5, self.code], name, (arr, common)))
+            rd = self._take_riders(len(chunk), max(g.M for g in arr)) if s == 0 else None
+            if rd is None:
+                self._cur.append(self._rec(N.lib().sea_row_chain, [arr, len(chunk), C.byref(common), 1e-5, self.code], name, (arr, common)))
+            else:
+                rarr, n_r, t0, nt, ibp = rd
+                self._cur.append(self._rec(N.lib().sea_row_chain_riders, [arr, len(chunk), C.byref(common), rarr, n_r, t0, nt, (C.byref(ibp) if ibp is not None else None), 1e-5, self.code],
+                                           name, (arr, common, rarr, ibp)))
+
+    def _take_riders(self, n_groups: int, m_rows: int, last: bool = False):
+        """The share of the rider work (sea_row_chain_riders) the next chain launch carries: as many 128 x 128 tiles of the rider GEMM as its idle CUs take in about the
+        launch's own duration (a chain workgroup owns a CU; two tile rounds under the three-field launch behind the self-attention, one under a field's tail), the
+        information-bottleneck rows with the first host.  None when nothing is left."""
+        arr = getattr(self, "_rider_arr", None)
+        if arr is None:
+            return None
+        done = getattr(self, "_rider_done", 0)
+        ibp = self._rider_ib if not getattr(self, "_rider_ib_done", False) else None
+        left = self._rider_tiles - done
+        if left <= 0 and ibp is None:
+            return None
+        # measured at cfg2 (tools/chain_probe.py replay, SEA_PLAN=rider_caps): 128:128:128 tiles under the three hosts 0.2153 ms per step, 192:96:96 0.2178,
+        # 256:64:64 0.2201, 384:0:0 0.2233, 0:192:192 0.2250, no riders 0.2214 — equal shares (a rider tile, alone on its CU beside 127-192 chain
+        # workgroups, takes ~9 us; the hosts last 24 / 16 / 12 us)
+        hosts_total = getattr(self, "_rider_hosts_total", 1)
+        cap = (self._rider_tiles + hosts_total - 1) // hosts_total
+        caps = _switches.plan("rider_caps", "")   # tuning aid: "a:b:c" = tiles for the first, second, third host
+        if caps:
+            lst = [int(v) for v in caps.split(":")]
+            k = getattr(self, "_rider_host_no", 0)
+            self._rider_host_no = k + 1
+            cap = lst[k] if k < len(lst) else 0
+            take = min(left, cap)
+            self._rider_done = done + take
+            self._rider_ib_done = True
+            return arr, len(arr), done, take, ibp
+        take = left if (last or self._rider_hosts_left <= 1) else min(left, cap)
+        self._rider_hosts_left -= 1
+        self._rider_done = done + take
+        self._rider_ib_done = True
+        return arr, len(arr), done, take, ibp
 
     def _qkv(self, groups: List[dict], rope: torch.Tensor, hd: int, name: str) -> None:
         L = N.lib()
@@ -480,7 +519,7 @@ class Plan:
             self._pos_structs.append(P)
             self._cur.append(self._rec(L.sea_attention_fwd, [C.byref(P), self.code], name, P))
 
-    def _cond_mods(self, split: bool = False) -> Dict[str, torch.Tensor]:
+    def _cond_mods(self, split: bool = False, riders: bool = False) -> Dict[str, torch.Tensor]:
         """AdaLN condition MLPs for the WHOLE model: silu launch + grouped GEMM (cond_mlp.2); returns prefix -> [M, 2d] (w | b).
         `split`: the modules the first launch of the layer needs (AdaLN_0 of layer 0) go first on the main stream, all the others run
         on lane 1 beside the self-attention and are joined by the caller (self._join(1)) before their first use."""
@@ -508,6 +547,41 @@ class Plan:
         # (M = 2024: not used), 1.215 against 1.241 ms at B = 8 (used).  SEA_PLAN=silu=1|0 forces.
         gen_a = self._gen_a(first + rest)
         ib_todo = list(getattr(self, "_ib_fold", []))   # (layer prefix, ibuf): info-bottleneck MLPs evaluated by extra row passes of the first silu launch
+        self._rider_arr, self._rider_ib = None, None
+        if riders:
+            # the silu launch as it is (hidden rows of every module + the information-bottleneck rows); cond_mlp.2 of AdaLN_0 and ln_cross of the (only) layer in
+            # front; cond_mlp.2 of every other module as rider tiles of the chain launches
+            front = first + [(pre_, d) for pre_, d in rest if "ln_cross." in pre_]
+            later = [(pre_, d) for pre_, d in rest if (pre_, d) not in front]
+            silu_groups, hids = [], {}
+            for pre_, d in front + later:
+                hids[pre_] = self._buf(M, 2 * d)
+                mods[pre_] = self._buf(M, 2 * d)
+                silu_groups.append((P.f32_vec(pre_ + "cond_mlp.0.weight", 2 * d), P.f32_vec(pre_ + "cond_mlp.0.bias"), hids[pre_]))
+            for s_ in range(0, len(silu_groups), N.MAX_SILU_GROUPS):
+                chunk = silu_groups[s_:s_ + N.MAX_SILU_GROUPS]
+                sarr = (N.SeaSiluGroup * len(chunk))()
+                for g, (w1, b1, hid) in zip(sarr, chunk):
+                    g.w1, g.b1, g.Hid, g.K2, g.ld = w1.data_ptr(), b1.data_ptr(), hid.data_ptr(), hid.shape[1], hid.stride(0)
+                ibs, n_ib = None, 0
+                if ib_todo:
+                    n_ib = len(ib_todo)
+                    ibs = (N.SeaIbParams * n_ib)()
+                    for ibp, (lpre, ibuf) in zip(ibs, ib_todo):
+                        ibp.X[0], ibp.n_fields, ibp.ldx = ibuf.data_ptr(), 1, ibuf.stride(0)
+                        self._fill_ib(ibp, lpre)
+                    ib_todo.clear()
+                rec = self._rec(L.sea_silu_outer_ib, [sarr, len(chunk), None, M, self.code, ibs, n_ib], "adaln.silu", (sarr, ibs))
+                self._c_patches.append((rec.args, 2))
+                self._cur.append(rec)
+            self._gemm([dict(A=hids[pre_], W=P.act(pre_ + "cond_mlp.2.weight"), bias=P.f32_vec(pre_ + "cond_mlp.2.bias"), Cact=mods[pre_]) for pre_, _ in front], "adaln.cond_gemm.front")
+            arr = (N.SeaGemmGroup * len(later))()
+            for g, (pre_, d) in zip(arr, later):
+                _fill_gemm(g, A=hids[pre_], W=P.act(pre_ + "cond_mlp.2.weight"), bias=P.f32_vec(pre_ + "cond_mlp.2.bias"), Cact=mods[pre_])
+            self._rider_arr = arr
+            self._rider_tiles = sum(((M + 127) // 128) * ((2 * d + 127) // 128) for _, d in later)
+            self._keep.append((arr, self._rider_ib))
+            return mods
 
         def emit(inst, tag):
             silu_groups, gemm_groups = [], []
@@ -583,9 +657,25 @@ class Plan:
         # the info-bottleneck add without a launch of its own: its MLP depends on the condition only, so it is EVALUATED by extra row passes of the silu
         # launch (into ibuf) and ADDED by the AdaLN_2 pass that follows it anyway (SeaNormGroup.addend).  Needs the silu launch (adaln, short launches)
         # and the add after the exchange; SEA_PLAN=fold_ib=0 keeps sea_ib_add.
+        # The row-local chains between the attention launches as ONE launch each (sea_row_chain, round 4): self-attention out-projection + residual ->
+        # cross_down + ln_cross -> every q of the field and the k / v of the pairs that read its PRE-exchange rows; per field, its exchange tail ->
+        # cross_down + ln_cross of the updated rows -> the k / v of the pairs that read them.  No cross-attention QKV launch, no out-projection launch, no
+        # down + norm launch: 18 launches -> 14 at cfg2.  bf16, the widths the kernel instantiates, at most 3 fields (the segments' weights share an LDS
+        # half), short launches (a workgroup owns most of a CU's LDS: beyond a round or two of workgroups the tiled launches win; SEA_PLAN=chain_max_rows).
+        # SEA_PLAN=chain=0 keeps the 18-launch plan (the reference form of tests/test_model_gpu.py::test_optional_plans_match_default_plan).
+        chain = self._chain_plan = (type(self) is Plan and self.mode == "full" and xmode == "sea" and 1 < F <= 3 and fuse_norm and not lanes and not self.concat
+                                    and _switches.plan("chain", "1") != "0" and _switches.plan("xtail", "1") != "0" and ops.row_chain_supported(dt, D, E, F - 1, D // H)
+                                    and M <= int(_switches.plan("chain_max_rows", "4096")))
+        # ... and with them RIDERS (sea_row_chain_riders): the AdaLN condition MLPs are functions of the condition alone, and only AdaLN_0 / ln_cross of the first
+        # layer are needed in front of the first attention — the modules the field MLP and the final norm read (62 % of the condition GEMM's work at cfg2)
+        # and the information-bottleneck rows are computed by extra workgroups of the chain launches, on the CUs those leave idle (127-192 workgroups on 256
+        # CUs): the condition GEMM in front of the step covers 6 of the 12 modules.  One layer, AdaLN, the ib add behind the exchange.
+        # SEA_PLAN=riders=0 keeps the whole-model condition launches.
+        riders = self._riders = (chain and self.adaln and self.L == 1 and not split_cond and _switches.plan("riders", "1") != "0"
+                                 and (not has_ib or (eng.model.add_info_after_cross and E <= 2048)) and not ib_attn and F + F <= N.CHAIN_MAX_RIDERS)
         fold_ib = (type(self) is Plan and has_ib and eng.model.add_info_after_cross and self.adaln and not lanes and not split_cond
                    and self.L <= N.MAX_SILU_IB and E <= 2048 and _switches.plan("fold_ib", "1") != "0"
-                   and not self._gen_a([(None, E), (None, D)]))
+                   and (riders or not self._gen_a([(None, E), (None, D)])))
         hoist_ib = self._cond_src is not None and has_ib and eng.model.add_info_after_cross and len(self._cond_src.ibufs) == self.L and E <= 2048
         if hoist_ib:       # the info-bottleneck rows of all steps exist already: added by the norm pass in front of the MLP (AdaLN or LayerNorm alike)
             fold_ib = True
@@ -594,7 +684,7 @@ class Plan:
         else:
             ibufs = [self._buf(M, E, dtype=f32) for _ in range(self.L)] if fold_ib else None
             self._ib_fold = [(f"blocks.{l}.", ibufs[l]) for l in range(self.L)] if fold_ib else []
-        mods = self._cond_mods(split=split_cond)
+        mods = self._cond_mods(split=split_cond, riders=riders)
         cond_joined = not split_cond
 
         def norm_params(pre, d):
@@ -608,15 +698,6 @@ class Plan:
                       and ops.exchange_tail_supported(dt, D, E, F - 1) and M <= int(_switches.plan("xtail_max_rows", "1000000000")))   # measured: cfg2 0.281 -> 0.254 ms, B = 2 0.414 -> 0.404, B = 4 0.679 -> 0.675, B = 8 a tie (1.191)
         rope_s, rope_c = eng.rope_self, eng.rope_cross
         Eo, concat = self.Eo, self.concat
-        # The row-local chains between the attention launches as ONE launch each (sea_row_chain, round 4): self-attention out-projection + residual ->
-        # cross_down + ln_cross -> every q of the field and the k / v of the pairs that read its PRE-exchange rows; per field, its exchange tail ->
-        # cross_down + ln_cross of the updated rows -> the k / v of the pairs that read them.  No cross-attention QKV launch, no out-projection launch, no
-        # down + norm launch: 18 launches -> 14 at cfg2.  bf16, the widths the kernel instantiates, at most 3 fields (the segments' weights share an LDS
-        # half), short launches (a workgroup owns most of a CU's LDS: beyond a round or two of workgroups the tiled launches win; SEA_PLAN=chain_max_rows).
-        # SEA_PLAN=chain=0 keeps the 18-launch plan (the reference form of tests/test_model_gpu.py::test_optional_plans_match_default_plan).
-        chain = self._chain_plan = (type(self) is Plan and self.mode == "full" and xmode == "sea" and 1 < F <= 3 and fuse_norm and not lanes and not concat
-                                    and _switches.plan("chain", "1") != "0" and _switches.plan("xtail", "1") != "0" and ops.row_chain_supported(dt, D, E, F - 1, D // H)
-                                    and M <= int(_switches.plan("chain_max_rows", "4096")))
         FE = F * Eo                                             # row stride of the caller's [B, T, F, Eo] tensors
         # KV-cache step at the shipped widths (one row per trajectory and field, embed_dim 1024 / 2048): the Linear layers as sea_gemm_fewrows /
         # sea_qkv_rope_fewrows launches with the row norms in front of them folded in (gemv.hip) — 18 launches instead of 22.  SEA_KV=gemv=0 keeps the generic launches.
@@ -699,6 +780,7 @@ class Plan:
                     g.update(R=xr[i])
                 groups.append(g)
             if chain:
+                self._rider_hosts_left = self._rider_hosts_total = F   # (SEA_PLAN=rider_caps overrides) chain launches of this layer that may carry riders: this one and the tails of the fields that are not last (their results are read by the MLP)
                 # out-projection + residual, cross_down + ln_cross of the PRE-exchange rows, and from those normalised rows (never stored): q_ij for every
                 # j != i, and k / v of the pairs (a, i), a < i — field a runs its cross-attention before field i is updated (models/temporal.py:187-192)
                 groups = []
@@ -1197,6 +1279,10 @@ class Plan:
                 c.op, c.p0, c.n, c.f0, c.dtype = N.OP_XTAIL, addr(r.keep), a[1], a[2], a[3]
             elif r.fn is L.sea_row_chain:
                 c.op, c.p0, c.n, c.p1, c.f0, c.dtype = N.OP_CHAIN, addr(a[0]), a[1], addr(r.keep[1]), a[3], a[4]
+            elif r.fn is L.sea_row_chain_riders:
+                c.op, c.p0, c.n, c.p1, c.f0, c.dtype = N.OP_CHAIN, addr(a[0]), a[1], addr(r.keep[1]), a[8], a[9]
+                c.l0, c.i0, c.i1, c.i2 = addr(a[3]), a[4], a[5], a[6]
+                c.l1 = addr(r.keep[3]) if r.keep[3] is not None else 0
             elif r.fn is L.sea_gemm_rownorm:
                 c.op, c.p0, c.n, c.f0, c.dtype = N.OP_GEMM_NORM, addr(a[0]), a[1], a[2], a[3]
             elif r.fn is L.sea_rownorm:

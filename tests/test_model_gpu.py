@@ -513,6 +513,38 @@ def test_shipped_multiphase_dims_forward(dtype, tol):
     assert rel_l2(roll.numpy(), ref_roll.numpy()) < 2 * tol
 
 
+@pytest.mark.parametrize("F,B,T", [(3, 2, 70), (2, 1, 130), (3, 1, 300)])
+def test_rider_plan_matches_the_plans_it_replaces(F, B, T, monkeypatch):
+    """One-layer AdaLN models in bf16 run round 4's rider plan: the condition GEMM in front covers AdaLN_0 + ln_cross only, the row chains (sea_row_chain_riders)
+    carry cond_mlp.2 of the modules the field MLP / final norm read as RIDER tiles on the CUs they leave idle (engine.Plan._take_riders).  Against the oracle, against the same model with SEA_PLAN=riders=0 (whole-model silu + condition launches: same arithmetic ->
+    bitwise) and with SEA_PLAN=chain=0 (round 3's launches); rows cross a trajectory boundary (B = 2) and a partial last tile (T = 70, 130, 300)."""
+    cfg = O.OracleConfig(1, 128, 4, 320, 8, 0, F, 2, True, "adaln")
+    x, _, ib = recipe_inputs(B, T, cfg, seed=9)
+    xg, ibg = x.to("cuda:0").contiguous(), ib.to("cuda:0").contiguous()
+    m = build(cfg, "bf16")
+    with torch.no_grad():
+        out = m(xg, ibg).clone()
+        out2 = m(xg, ibg).clone()
+    names = [r.name for r in m.engine().plan(B, T, "full").records]
+    assert "adaln.cond_gemm.front" in names and "adaln.cond_gemm" not in names and "ib_add" not in names
+    head = names[:6 + 2 * F]   # silu rows, front GEMM, AdaLN_0, QKV, self-attention, the chain behind it; per field attention + tail; then the MLP's launches (2 from 1024 rows up)
+    assert head == ["adaln.silu", "adaln.cond_gemm.front", "self.adaln0", "self.qkv_rope", "self.attention", "self.out_proj_down_qkv"] + [f"cross{i}.{k}" for i in range(F) for k in ("attention", "tail")]
+    assert torch.equal(out, out2)
+    assert rel_l2(out.cpu().numpy(), O.model_forward(x, ib, recipe_params(cfg), cfg).numpy()) < BF16_TOL
+    monkeypatch.setenv("SEA_PLAN", "riders=0")
+    m2 = build(cfg, "bf16")
+    with torch.no_grad():
+        ref = m2(xg, ibg)
+    names2 = [r.name for r in m2.engine().plan(B, T, "full").records]
+    assert "adaln.silu" in names2 and "adaln.cond_gemm" in names2 and "self.out_proj_down_qkv" in names2 and len(names2) == len(names)
+    assert rel_l2(out.cpu().numpy(), ref.cpu().numpy()) < 2e-3   # (the generated operand rounds silu(w1 c + b1) to bf16 exactly like the silu launch does; tile shapes differ)
+    monkeypatch.setenv("SEA_PLAN", "chain=0")
+    m3 = build(cfg, "bf16")
+    with torch.no_grad():
+        ref3 = m3(xg, ibg)
+    assert rel_l2(out.cpu().numpy(), ref3.cpu().numpy()) < 2e-2
+
+
 @pytest.mark.parametrize("env,graphed", [({"SEA_PLAN": "lanes=all"}, True), ({"SEA_PLAN": "lanes=cond"}, True),
                                          ({"SEA_PLAN": "norm=0"}, False), ({"SEA_PLAN": "xtail=0"}, False), ({"SEA_PLAN": "chain=0"}, False), ({"SEA_PLAN": "silu=1"}, False), ({"SEA_PLAN": "fold_ib=0"}, False), ({"SEA_PLAN": "mlp1=1"}, False), ({"SEA_TUNE": "gemm_norm_rows=64"}, False)])
 @pytest.mark.parametrize("dtype,tol", [("fp32", 2e-6), ("bf16", 2e-2)])
