@@ -462,28 +462,28 @@ struct SiluIbLaunch {
     SeaIbParams ib[SEA_MAX_SILU_IB];
 };
 
-// grid = (ceil(M / 32), n_groups [+ n_ib]): a workgroup = 32 rows of one group; a wave takes 8 of them with its slice of w1 / b1 (4 columns per lane and 256-column
-// pass) in registers, so a row is one scalar load, 4 silu per pass and one 512-byte store per wave.  (Round 4: the one-wave-per-row form was 6578 workgroups of a few
-// hundred cycles each at cfg2 — 11 us for 24 MB of stores, bound by workgroup dispatch.)  The info-bottleneck passes keep one wave per row (their grid rows come first).
+// 1-D grid: first n_ib * ceil(M / 4) workgroups of information-bottleneck rows (one wave per row: the longer passes — a dependent LayerNorm + GELU + h-term dot per
+// element — dispatched first), then n_groups * ceil(M / 32) workgroups of silu rows: a workgroup = 32 rows of one group, a wave takes 8 of them with its slice of
+// w1 / b1 (4 columns per lane and 256-column pass) in registers, so a row is one scalar load, 4 silu per pass and one 512-byte store per wave.  (Round 4: the
+// one-wave-per-row form was 6578 workgroups of a few hundred cycles each at cfg2 — 11 us for 24 MB of stores, bound by workgroup dispatch.)
 template <typename T, bool WITH_IB>
-__global__ __launch_bounds__(256) void silu_outer_kernel(const SiluLaunch L, const SiluIbLaunch I) {
+__global__ __launch_bounds__(256) void silu_outer_kernel(const SiluLaunch L, const SiluIbLaunch I, int n_ib) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    int gy = blockIdx.y;
+    int bid = blockIdx.x;
     if constexpr (WITH_IB) {
-        // the info-bottleneck passes take the FIRST grid rows: they are the longer ones (a dependent LayerNorm + GELU + h-term dot per element) and
-        // dispatch is in grid order — last, they were a 2.5 us tail of the launch
-        const int n_ib = (int)gridDim.y - L.n_groups;
-        if (gy < n_ib) {   // block-uniform
-            for (int i = 0; i < 8; ++i) {
-                const int row = blockIdx.x * 32 + wave * 8 + i;
-                if (row < L.M) ib_store_row(I.ib[gy], L.c[row], row, lane);
-            }
+        const int per_ib = (L.M + 3) >> 2;
+        if (bid < n_ib * per_ib) {   // block-uniform
+            const int k = bid / per_ib;
+            const int row = (bid - k * per_ib) * 4 + wave;
+            if (row < L.M) ib_store_row(I.ib[k], L.c[row], row, lane);
             return;
         }
-        gy -= n_ib;
+        bid -= n_ib * per_ib;
     }
+    const int per_g = (L.M + 31) >> 5;
+    const int gy = bid / per_g;
     const SeaSiluGroup& G = L.g[gy];
-    const int row0 = blockIdx.x * 32 + wave * 8;
+    const int row0 = (bid - gy * per_g) * 32 + wave * 8;
     if (row0 >= L.M) return;
     float cv[8];
 #pragma unroll
@@ -530,14 +530,14 @@ extern "C" int sea_silu_outer_ib(const SeaSiluGroup* groups, int n_groups, const
         L.g[i] = G;
     }
     L.c = c; L.M = M; L.n_groups = n_groups;
-    const dim3 grid((M + 31) / 32, n_groups + n_ib), block(256);
+    const dim3 grid(n_ib * ((M + 3) / 4) + n_groups * ((M + 31) / 32)), block(256);
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (n_ib > 0) {
-        if (dtype == SEA_BF16) silu_outer_kernel<__bf16, true><<<grid, block, 0, s>>>(L, I);
-        else silu_outer_kernel<float, true><<<grid, block, 0, s>>>(L, I);
+        if (dtype == SEA_BF16) silu_outer_kernel<__bf16, true><<<grid, block, 0, s>>>(L, I, n_ib);
+        else silu_outer_kernel<float, true><<<grid, block, 0, s>>>(L, I, n_ib);
     } else {
-        if (dtype == SEA_BF16) silu_outer_kernel<__bf16, false><<<grid, block, 0, s>>>(L, I);
-        else silu_outer_kernel<float, false><<<grid, block, 0, s>>>(L, I);
+        if (dtype == SEA_BF16) silu_outer_kernel<__bf16, false><<<grid, block, 0, s>>>(L, I, 0);
+        else silu_outer_kernel<float, false><<<grid, block, 0, s>>>(L, I, 0);
     }
     SEA_CHECK_LAUNCH("sea_silu_outer");
     return SEA_OK;

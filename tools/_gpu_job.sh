@@ -1,14 +1,11 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-O=gpurun_out/r04l; mkdir -p $O
-python bench.py --mode rollout --steps 20 --warmup 5 --no-cpu-baseline > $O/rollout.json 2> $O/rollout.err
+O=gpurun_out/r04m; mkdir -p $O
+rm -rf $O/prof
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o run -- python3 tools/chain_probe.py replay 50 > $O/prof.log 2>&1
 python - <<'PY'
-import json
-d=json.loads(open("gpurun_out/r04l/rollout.json").read().strip().splitlines()[-1])
-print("bench ms_per_step", d["ms_per_step"], "launches", len(d["launch_breakdown_ms"]) if "launch_breakdown_ms" in d else d.get("rollout",{}).get("n_launches"))
-print(d.get("launch_breakdown_ms") or d["rollout"]["launch_breakdown_ms"])
+import csv,glob
+f=glob.glob("gpurun_out/r04m/prof/*kernel_stats.csv")[0]
+for r in csv.DictReader(open(f)):
+    if int(r["Calls"])>=50: print(f'{r["Name"][:64]:64s} calls {r["Calls"]:>5s} avg {float(r["AverageNs"])/1e3:8.2f} us')
 PY
-python bench.py --mode rollout --steps 200 --warmup 10 --no-cpu-baseline > $O/rollout200.json 2> $O/rollout200.err
-python -c "
-import json
-d=json.loads(open('gpurun_out/r04l/rollout200.json').read().strip().splitlines()[-1]); print('200 steps', d['ms_per_step'])"
-timeout -k 10 1000 python -m pytest tests -m gpu -x -q --deselect tests/test_train_gpu.py::test_cfg3_own_batch_gradients_match_oracle > $O/test_gpu.log 2>&1; echo "gpu rc=$?" >> $O/test_gpu.log; tail -5 $O/test_gpu.log
+rm -rf $O/prof/*kernel_trace.csv
