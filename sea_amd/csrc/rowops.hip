@@ -506,8 +506,9 @@ extern "C" int sea_silu_outer(const SeaSiluGroup* groups, int n_groups, const fl
 }
 
 extern "C" int sea_silu_outer_ib(const SeaSiluGroup* groups, int n_groups, const float* c, int M, int dtype, const SeaIbParams* ibs, int n_ib, void* stream) {
-    SEA_REQUIRE(groups != nullptr && c != nullptr && n_groups >= 1 && n_groups <= SEA_MAX_SILU_GROUPS && M >= 1, "sea_silu_outer: bad arguments (n_groups=%d, M=%d)", n_groups, M);
     SEA_REQUIRE(n_ib >= 0 && n_ib <= SEA_MAX_SILU_IB && (n_ib == 0 || ibs != nullptr), "sea_silu_outer_ib: n_ib=%d out of range", n_ib);
+    // (n_groups = 0 with n_ib > 0: the information-bottleneck rows alone — plans whose condition GEMM generates its operand have no silu rows to store)
+    SEA_REQUIRE(c != nullptr && n_groups >= (n_ib > 0 ? 0 : 1) && (n_groups == 0 || groups != nullptr) && n_groups <= SEA_MAX_SILU_GROUPS && M >= 1, "sea_silu_outer: bad arguments (n_groups=%d, M=%d)", n_groups, M);
     SiluIbLaunch I;
     memset(&I, 0, sizeof(I));
     for (int k = 0; k < n_ib; ++k) {

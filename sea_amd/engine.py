@@ -586,6 +586,16 @@ class Plan:
         def emit(inst, tag):
             silu_groups, gemm_groups = [], []
             if gen_a:
+                if ib_todo:   # no silu rows to ride on: the information-bottleneck rows as a launch of their own (added by the norm pass in front of the MLP)
+                    n_ib = len(ib_todo)
+                    ibs = (N.SeaIbParams * n_ib)()
+                    for ibp, (lpre, ibuf) in zip(ibs, ib_todo):
+                        ibp.X[0], ibp.n_fields, ibp.ldx = ibuf.data_ptr(), 1, ibuf.stride(0)
+                        self._fill_ib(ibp, lpre)
+                    ib_todo.clear()
+                    rec = self._rec(L.sea_silu_outer_ib, [None, 0, None, M, self.code, ibs, n_ib], "ib.rows", (ibs,))
+                    self._c_patches.append((rec.args, 2))
+                    self._cur.append(rec)
                 for pre, d in inst:
                     mod = self._buf(M, 2 * d)
                     mods[pre] = mod
@@ -673,9 +683,12 @@ class Plan:
         # SEA_PLAN=riders=0 keeps the whole-model condition launches.
         riders = self._riders = (chain and self.adaln and self.L == 1 and not split_cond and _switches.plan("riders", "1") != "0"
                                  and (not has_ib or (eng.model.add_info_after_cross and E <= 2048)) and not ib_attn and F + F <= N.CHAIN_MAX_RIDERS)
-        fold_ib = (type(self) is Plan and has_ib and eng.model.add_info_after_cross and self.adaln and not lanes and not split_cond
+        # the condition GEMMs generate their operand (long launches): no silu launch for the ib rows to ride on.  SEA_PLAN=fold_ib_gen=1 gives them a launch of
+        # their own (sea_silu_outer_ib without silu rows) and folds the add into the norm pass — measured at B = 8: 29 + 40 us against 30 (ib_add) + 30 (norm): not the default
+        gen_all = self._gen_a([(None, E), (None, D)])
+        fold_ib = (type(self) is Plan and has_ib and eng.model.add_info_after_cross and self.adaln and not lanes
                    and self.L <= N.MAX_SILU_IB and E <= 2048 and _switches.plan("fold_ib", "1") != "0"
-                   and (riders or not self._gen_a([(None, E), (None, D)])))
+                   and (riders or (gen_all and _switches.plan("fold_ib_gen", "0") != "0") or (not gen_all and not split_cond)))
         hoist_ib = self._cond_src is not None and has_ib and eng.model.add_info_after_cross and len(self._cond_src.ibufs) == self.L and E <= 2048
         if hoist_ib:       # the info-bottleneck rows of all steps exist already: added by the norm pass in front of the MLP (AdaLN or LayerNorm alike)
             fold_ib = True
@@ -1028,6 +1041,12 @@ class Plan:
             return final_norm
         self._gemm([dict(A=hg[i], W=P.act(f"{pre}mlp.{i}.layers.3.weight"), bias=P.f32_vec(f"{pre}mlp.{i}.layers.3.bias"), R=xr[i], Cact=xm[i])
                     for i in fields], "mlp.fc2" + tag)
+        # the last layer's proj + the model's final norm in one launch (sea_gemm_rownorm: a tile spans the whole output row): at B = 8 two launches of 23 + 31 us
+        # (the norm re-reads the rows the proj has just written: 100 MB) -> one.  SEA_PLAN=norm=0 / projnorm=0 keep the two launches.
+        if final_norm and getattr(self, "_fuse_norm", False) and type(self) is Plan and Eo <= 256 and Eo % 16 == 0 and Eo == E and _switches.plan("projnorm", "1") != "0":
+            self._gemm_norm([dict(A=xm[i], W=P.act(f"{pre}proj.{i}.weight"), bias=P.f32_vec(f"{pre}proj.{i}.bias"), Y32=xo[i], ldy32=FE, Y_is_out=i * Eo * 4,
+                                  **norm_params(f"ln.{i}.", Eo)) for i in fields], "proj_norm" + tag)
+            return final_norm
         self._gemm([dict(A=xm[i], W=P.act(f"{pre}proj.{i}.weight"), bias=P.f32_vec(f"{pre}proj.{i}.bias"), C32=xo[i]) for i in fields], "proj" + tag)
         if final_norm:
             self._norm([dict(X=xo[i], Y32=xo[i], ldy32=FE, Y_is_out=i * Eo * 4, **norm_params(f"ln.{i}.", Eo)) for i in fields], Eo, "final.norm" + tag)
@@ -1288,7 +1307,7 @@ class Plan:
             elif r.fn is L.sea_rownorm:
                 c.op, c.p0, c.n, c.i0, c.i1, c.i2, c.i3, c.f0, c.dtype = N.OP_NORM, addr(a[0]), a[1], a[2], a[3], a[4], a[5], a[6], a[7]
             elif r.fn is L.sea_silu_outer or r.fn is L.sea_silu_outer_ib:
-                c.op, c.p0, c.n, c.i0, c.dtype = N.OP_SILU, addr(a[0]), a[1], a[3], a[4]
+                c.op, c.p0, c.n, c.i0, c.dtype = N.OP_SILU, (addr(a[0]) if a[0] is not None else None), a[1], a[3], a[4]
                 if r.fn is L.sea_silu_outer_ib and a[5] is not None:
                     c.l0, c.l1 = addr(a[5]), a[6]
                 relink.append((i, "p1", a, 2))

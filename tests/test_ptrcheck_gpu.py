@@ -64,6 +64,46 @@ def test_a_corrupted_pointer_is_refused_before_any_launch():
         assert torch.equal(m(x, ib), ref)
 
 
+def test_a_corrupted_chain_pointer_is_refused():
+    """The row-chain launches (sea_row_chain / sea_row_chain_riders, bf16 plans) are audited like every other record: the chain's operands with their extents
+    (SeaRowChain), the projection entries (SeaQkvGroup) and the rider groups (SeaGemmGroup)."""
+    cfg = O.OracleConfig(1, 128, 4, 64, 8, 0, 3, 2, True, "adaln")
+    m = build(cfg, "bf16")
+    x, _, ib = (t.cuda() for t in recipe_inputs(1, 40, cfg, seed=5))
+    eng = m.engine()
+    with torch.no_grad():
+        ref = m(x, ib).clone()
+    p = eng.plan(1, 40, "full")
+    rec = next(r for r in p.records if r.name == "self.out_proj_down_qkv")
+    ch = rec.args[0][0]
+    good = ch.W2
+    ch.W2 = good + (1 << 44)
+    with pytest.raises(RuntimeError, match=r"pointer audit .*self\.out_proj_down_qkv.*SeaRowChain\.W2"):
+        p.audit()
+    ch.W2 = good
+    ch.M = 10 ** 6
+    with pytest.raises(RuntimeError, match=r"past the end of its buffer"):
+        p.audit()
+    ch.M = 40
+    q = ch.proj[0]
+    good_q = q.W
+    q.W = good_q + (1 << 44)
+    with pytest.raises(RuntimeError, match=r"pointer audit .*SeaQkvGroup\.W"):
+        p.audit()
+    q.W = good_q
+    tail = next(r for r in p.records if r.name == "cross0.tail")
+    if len(tail.args) > 5:   # a rider host: its SeaGemmGroup array
+        g0 = tail.args[3][0]
+        good_a = g0.A
+        g0.A = good_a + (1 << 44)
+        with pytest.raises(RuntimeError, match=r"pointer audit .*SeaGemmGroup\.A"):
+            p.audit()
+        g0.A = good_a
+    assert p.audit() > 0
+    with torch.no_grad():
+        assert torch.equal(m(x, ib), ref)
+
+
 def test_plan_holds_its_bound_output_until_the_next_bind():
     m = build(CFG, "bf16")
     x, _, ib = (t.cuda() for t in recipe_inputs(1, 24, CFG, seed=6))
