@@ -91,6 +91,10 @@ def record_work(rec, esz):
         for g in rec.keep[:a[1]]:
             fl += g.n_seg * 2 * g.M * g.D * g.D + 2 * g.M * g.D * g.E + (2 * g.M * g.E * g.D if g.has_down else 0)
             by += g.n_seg * (g.M * g.D * esz + g.D * g.D * esz) + g.D * g.E * esz + 2 * g.M * g.E * 4 + (g.E * g.D * esz + g.M * g.D * esz if g.has_down else 0)
+    elif rec.fn is L.sea_gemm_adaln:
+        for g in a[0][:a[1]]:
+            fl += 2 * g.M * 2 * g.d * g.K
+            by += g.M * g.K * esz + 2 * g.d * g.K * esz + (g.M * g.d * (4 + esz) if g.X else g.M * 2 * g.d * esz)
     elif rec.fn is L.sea_row_chain or rec.fn is L.sea_row_chain_riders:
         if rec.fn is L.sea_row_chain_riders and a[4] > 0:   # the launch's share of the rider GEMM (tiles of 128 x 128, counted by tile)
             tot = sum(((g.M + 127) // 128) * ((g.N + 127) // 128) for g in a[3][:a[4]])

@@ -41,7 +41,7 @@ enum {
 int sea_abi_version(void);
 const char* sea_last_error(void);
 /* sizeof of every ABI struct in declaration order (SeaGemmGroup, SeaQkvGroup, SeaQkvCommon, SeaAttnProblem,
- * SeaAttnParams, SeaNormGroup, SeaSiluGroup, SeaIbParams, ..., SeaLaunchRec, SeaGemmNormGroup, SeaExchangeTail, SeaMlpGroup, SeaMlp2Group, SeaKvNorm, SeaKvField, SeaKvPair, SeaKvLayer, SeaKvGlobal, SeaStepPatch, SeaRowChain last): lets a binding verify its layout.  Host only. */
+ * SeaAttnParams, SeaNormGroup, SeaSiluGroup, SeaIbParams, ..., SeaLaunchRec, SeaGemmNormGroup, SeaExchangeTail, SeaMlpGroup, SeaMlp2Group, SeaKvNorm, SeaKvField, SeaKvPair, SeaKvLayer, SeaKvGlobal, SeaStepPatch, SeaRowChain, SeaAdalnGroup last): lets a binding verify its layout.  Host only. */
 int sea_struct_sizes(int* out, int cap);
 /* Number of compute units / name of device 0's architecture as HIP reports them (diagnostics for bench.py). */
 int sea_device_info(int* cu_count, char* arch, int arch_len);
@@ -556,6 +556,32 @@ typedef struct {
 int sea_ib_bwd(const SeaIbBwdParams* params, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
+ * AdaLN whose modulation never reaches memory (bf16 compute): the normalisation is the epilogue of cond_mlp.2's GEMM.
+ *     [w | b] = A[M, K] . W[2d, K]^T + bias            A = silu(cond_mlp.0(c)) rows (sea_silu_outer), W = cond_mlp.2.weight (scale rows 0..d-1, shift rows d..2d-1)
+ *     y       = xhat * (gamma + 1 + w) + (beta + b),   xhat = (X - mean) / sqrt(var_biased + eps) over the d columns of a row of X
+ * (models/base_blocks.py:337-350: AdaLN.forward) — instead of storing [w | b] as an [M, 2 d] matrix that a row-norm launch reads back.  A group WITHOUT X is
+ * the plain GEMM: Yact [M, 2 d] receives [w | b] (modulations whose normalisation is another launch's epilogue: ln_cross); one launch carries both kinds.
+ * mean / rstd (f32 [M]) are saved when non-NULL.  Requirements: dtype SEA_BF16; 16 <= d <= 1024, d % 8 == 0; K % 8 == 0; strides multiples of 8 (act) /
+ * 4 (f32); pointers 16-byte aligned.  Returns SEA_EUNSUPPORTED for fp32.
+ */
+#define SEA_MAX_ADALN_GROUPS 16
+typedef struct {
+    const void* A;        /* act [M, K], row stride lda */
+    const void* W;        /* act [2d, K], row stride ldw */
+    const float* bias;    /* f32 [2d] or NULL */
+    const float* X;       /* f32 [M, d], row stride ldx: the rows to normalise; NULL = plain group */
+    const float* gamma;   /* f32 [d] */
+    const float* beta;    /* f32 [d] or NULL */
+    void* Yact;           /* act [M, d] (normalising group) or act [M, 2d] (plain group), row stride ldyact */
+    float* Y32;           /* f32 [M, d], row stride ldy32, or NULL */
+    float* mean;          /* f32 [M] or NULL */
+    float* rstd;          /* f32 [M] or NULL */
+    int32_t lda, ldw, ldx, ldyact, ldy32;
+    int32_t M, d, K;
+} SeaAdalnGroup;
+int sea_gemm_adaln(const SeaAdalnGroup* groups, int n_groups, float eps, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
  * A ROW-LOCAL CHAIN of the state-exchange block in one launch (bf16 compute; a workgroup owns 16 or 32 rows from an attention launch's output to the
  * next attention launch's operands; sea_amd/csrc/chain.hip).  Per group (field), in order:
  *   form A (n_seg = 0):   x = Xin + a2[M,E] . W2[E,E]^T (+ b2)                          self-attention out-projection + residual
@@ -620,11 +646,12 @@ int sea_row_chain_riders(const SeaRowChain* params, int n_groups, const SeaQkvCo
  *     SEA_OP_MLP2   p0 = SeaMlp2Group[n], f0 = eps
  *     SEA_OP_GEMM_FEW p0 = SeaGemmGroup[n], p1 = pre or NULL, i0 = pre_x_is_act, i1 = pre_gelu, f0 = eps
  *     SEA_OP_QKV_FEW  p0 = SeaQkvGroup[n], p1 = SeaQkvCommon, l0 = (intptr) pre or 0, f0 = eps
+ *     SEA_OP_ADALN    p0 = SeaAdalnGroup[n], f0 = eps
  *     SEA_OP_CHAIN    p0 = SeaRowChain[n], p1 = SeaQkvCommon or NULL, f0 = eps; riders (sea_row_chain_riders): l0 = (intptr) SeaGemmGroup[i0] or 0, i1 = tile0, i2 = n_tiles,
  *                     l1 = (intptr) SeaIbParams or 0
  * Returns 0, or the failing entry's error code with sea_last_error() set (entries before it have been launched).
  */
-enum { SEA_OP_GEMM = 1, SEA_OP_QKV = 2, SEA_OP_ATTN = 3, SEA_OP_NORM = 4, SEA_OP_SILU = 5, SEA_OP_IB = 6, SEA_OP_CONVERT = 8, SEA_OP_GEMM_NORM = 9, SEA_OP_XTAIL = 10, SEA_OP_MLP1 = 11, SEA_OP_MLP2 = 13, SEA_OP_GEMM_FEW = 14, SEA_OP_QKV_FEW = 15, SEA_OP_CHAIN = 16 };   /* 7 and 12 were round-1 entry points (sea_rowchain, sea_cond_mlp), removed in ABI v2 */
+enum { SEA_OP_GEMM = 1, SEA_OP_QKV = 2, SEA_OP_ATTN = 3, SEA_OP_NORM = 4, SEA_OP_SILU = 5, SEA_OP_IB = 6, SEA_OP_CONVERT = 8, SEA_OP_GEMM_NORM = 9, SEA_OP_XTAIL = 10, SEA_OP_MLP1 = 11, SEA_OP_MLP2 = 13, SEA_OP_GEMM_FEW = 14, SEA_OP_QKV_FEW = 15, SEA_OP_CHAIN = 16, SEA_OP_ADALN = 17 };   /* 7 and 12 were round-1 entry points (sea_rowchain, sea_cond_mlp), removed in ABI v2 */
 typedef struct {
     int32_t op, n, dtype, i0, i1, i2, i3;
     float f0;

@@ -41,6 +41,10 @@ struct GemmMainloop {
     const T* W;
     int64_t a_seg_stride;
     int lda, ldw, M, N, K, n_seg, m0, n0;
+    // nsplit > 0: the tile's BN rows of W are TWO blocks of BN / 2 — rows n0 .. and rows nsplit + n0 .. (gemm_adaln.hip: the scale and the shift half of an AdaLN
+    // modulation for the same output columns land in one tile, so the normalisation is that tile's epilogue)
+    int nsplit = 0;
+    __device__ __forceinline__ int w_row(int q) const { return nsplit > 0 ? (q < BN / 2 ? n0 + q : nsplit + n0 + q - BN / 2) : n0 + q; }
 
     uint4 ra[C::A_CH], rb[C::B_CH];
 
@@ -102,7 +106,7 @@ struct GemmMainloop {
         }
 #pragma unroll
         for (int i = 0; i < C::B_CH; ++i) {
-            int row = n0 + rr + 32 * i;
+            int row = w_row(rr + 32 * i);
             row = row < N ? row : N - 1;
             rb[i] = kvalid ? *reinterpret_cast<const uint4*>(w_base + (int64_t)row * ldw) : make_uint4(0, 0, 0, 0);
         }
@@ -188,7 +192,7 @@ struct GemmMainloop {
 #pragma unroll
         for (int u = 0; u < B_DMA; ++u) {
             const int r0 = (u * 4 + wave) * 8;
-            int row = n0 + r0 + rl;
+            int row = w_row(r0 + rl);
             row = row < N ? row : N - 1;
             glds16(w_base + (int64_t)row * ldw, stage + (unsigned)(BM * C::BKB + r0 * C::BKB));
         }

@@ -434,6 +434,22 @@ class Plan:
         ops.fill_exchange_tail(P[0], att, Wp, Wup, bup, bias_scale, X, None, down)
         self._cur.append(self._rec(N.lib().sea_exchange_tail, [P, 1, 1e-5, self.code], name, P))
 
+    def _adaln(self, groups: List[dict], name: str) -> None:
+        """AdaLN as the epilogue of cond_mlp.2's GEMM, and plain cond_mlp.2 groups, in one launch (sea_gemm_adaln): dicts as ops.fill_adaln_group, plus `X_is_x`
+        (byte offset into the caller's tensor: the rows of the first layer are read from it, strided) and `Y_is_out`."""
+        for s in range(0, len(groups), N.MAX_ADALN_GROUPS):
+            chunk = groups[s:s + N.MAX_ADALN_GROUPS]
+            arr = (N.SeaAdalnGroup * len(chunk))()
+            for g, d in zip(arr, chunk):
+                d = dict(d)
+                x_off, o_off = d.pop("X_is_x", None), d.pop("Y_is_out", None)
+                ops.fill_adaln_group(g, **d)
+                if x_off is not None:
+                    self._x_patches.append((g, "X", x_off))
+                if o_off is not None:
+                    self._out_patches.append((g, "Y32", o_off))
+            self._cur.append(self._rec(N.lib().sea_gemm_adaln, [arr, len(chunk), 1e-5, self.code], name, arr))
+
     def _chain(self, groups: List[dict], rope: torch.Tensor, hd: int, name: str) -> None:
         """A row-local chain between two attention launches (sea_row_chain): group dicts as ops.fill_row_chain, plus `Xin_is_x` (byte offset into the caller's
         tensor: the residual rows of the first layer are read from it, strided)."""
@@ -574,7 +590,13 @@ class Plan:
                 rec = self._rec(L.sea_silu_outer_ib, [sarr, len(chunk), None, M, self.code, ibs, n_ib], "adaln.silu", (sarr, ibs))
                 self._c_patches.append((rec.args, 2))
                 self._cur.append(rec)
-            self._gemm([dict(A=hids[pre_], W=P.act(pre_ + "cond_mlp.2.weight"), bias=P.f32_vec(pre_ + "cond_mlp.2.bias"), Cact=mods[pre_]) for pre_, _ in front], "adaln.cond_gemm.front")
+            # cond_mlp.2 of the front modules: AdaLN_0's as the GEMM whose epilogue IS the normalisation (sea_gemm_adaln: no modulation matrix, no norm launch),
+            # ln_cross's as plain groups of the same launch — emitted by _build where the AdaLN_0 launch used to be.  SEA_PLAN=adaln_gemm=0 keeps GEMM + norm launch.
+            if _switches.plan("adaln_gemm", "1") != "0":
+                self._adaln_front = {pre_: (hids[pre_], P.act(pre_ + "cond_mlp.2.weight"), P.f32_vec(pre_ + "cond_mlp.2.bias")) for pre_, _ in front}
+            else:
+                self._adaln_front = None
+                self._gemm([dict(A=hids[pre_], W=P.act(pre_ + "cond_mlp.2.weight"), bias=P.f32_vec(pre_ + "cond_mlp.2.bias"), Cact=mods[pre_]) for pre_, _ in front], "adaln.cond_gemm.front")
             arr = (N.SeaGemmGroup * len(later))()
             for g, (pre_, d) in zip(arr, later):
                 _fill_gemm(g, A=hids[pre_], W=P.act(pre_ + "cond_mlp.2.weight"), bias=P.f32_vec(pre_ + "cond_mlp.2.bias"), Cact=mods[pre_])
@@ -780,7 +802,21 @@ class Plan:
                 self._qkv_few([dict(W=P.act(f"{pre}attn.self.{i}.q.weight", 3 * E), bias=P.f32_vec(f"{pre}attn.self.{i}.q.bias", 3 * E),
                                     col0=0, Q=Qs[i], K=Ks[l][i], Vt=Vs[l][i]) for i in range(F)], rope_s, hd_s, "self.qkv_rope", pre=groups)
             else:
-                self._norm(groups, E, "self.adaln0")
+                af = getattr(self, "_adaln_front", None) if l == 0 else None
+                if af:
+                    ag = []
+                    for i in range(F):
+                        hid_, W_, b_ = af[f"{pre}ln.exp.{i}.0."]
+                        g = dict(A=hid_, W=W_, bias=b_, X=xr[i], gamma=P.f32_vec(f"{pre}ln.exp.{i}.0.weight"), beta=P.f32_vec(f"{pre}ln.exp.{i}.0.bias"), Yact=n_e[i])
+                        if first:
+                            g.update(ldx=FE, X_is_x=i * Eo * 4)
+                        ag.append(g)
+                    for key, (hid_, W_, b_) in af.items():
+                        if "ln_cross." in key:
+                            ag.append(dict(A=hid_, W=W_, bias=b_, Yact=mods[key]))
+                    self._adaln(ag, "self.cond_adaln0")
+                else:
+                    self._norm(groups, E, "self.adaln0")
                 self._qkv([dict(A=n_e[i], W=P.act(f"{pre}attn.self.{i}.q.weight", 3 * E), bias=P.f32_vec(f"{pre}attn.self.{i}.q.bias", 3 * E),
                                 col0=0, Q=Qs[i], K=Ks[l][i], Vt=Vs[l][i]) for i in range(F)], rope_s, hd_s, "self.qkv_rope")
             self._attn([dict(Q=Qs[i], K=Ks[l][i], Vt=Vs[l][i], O=att_e[i]) for i in range(F)], hd_s, E, "self.attention")
@@ -1296,6 +1332,8 @@ class Plan:
                 c.op, c.p0, c.n, c.f0, c.dtype = N.OP_MLP2, addr(a[0]), a[1], a[2], a[3]
             elif r.fn is L.sea_exchange_tail:
                 c.op, c.p0, c.n, c.f0, c.dtype = N.OP_XTAIL, addr(r.keep), a[1], a[2], a[3]
+            elif r.fn is L.sea_gemm_adaln:
+                c.op, c.p0, c.n, c.f0, c.dtype = N.OP_ADALN, addr(a[0]), a[1], a[2], a[3]
             elif r.fn is L.sea_row_chain:
                 c.op, c.p0, c.n, c.p1, c.f0, c.dtype = N.OP_CHAIN, addr(a[0]), a[1], addr(r.keep[1]), a[3], a[4]
             elif r.fn is L.sea_row_chain_riders:

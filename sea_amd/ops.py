@@ -296,6 +296,26 @@ def exchange_tail_grouped(groups: Sequence[Dict], eps: float = 1e-5, dtype: torc
     N.check(N.lib().sea_exchange_tail(P, len(groups), eps, N.dtype_code(dtype), N.stream_ptr()), "sea_exchange_tail")
 
 
+def fill_adaln_group(g: N.SeaAdalnGroup, A, W, bias=None, X=None, gamma=None, beta=None, Yact=None, Y32=None, mean=None, rstd=None, ldx=None, ldy32=None) -> None:
+    """One group of sea_gemm_adaln: A act [M, K] (silu rows), W act [2d, K] (cond_mlp.2.weight); X f32 [M, d] + gamma (+ beta) -> Yact / Y32 [M, d], or — X None —
+    Yact act [M, 2d] receives the modulation itself."""
+    g.A, g.lda, g.W, g.ldw, g.bias = A.data_ptr(), A.stride(0), W.data_ptr(), W.stride(0), N.ptr(bias)
+    g.X, g.ldx = N.ptr(X), ((ldx if ldx is not None else X.stride(0)) if X is not None else 0)
+    g.gamma, g.beta = N.ptr(gamma), N.ptr(beta)
+    g.Yact, g.ldyact = N.ptr(Yact), (Yact.stride(0) if Yact is not None else 0)
+    g.Y32, g.ldy32 = N.ptr(Y32), ((ldy32 if ldy32 is not None else Y32.stride(0)) if Y32 is not None else 0)
+    g.mean, g.rstd = N.ptr(mean), N.ptr(rstd)
+    g.M, g.d, g.K = A.shape[0], W.shape[0] // 2, W.shape[1]
+
+
+def gemm_adaln(groups: Sequence[Dict], eps: float = 1e-5, dtype: torch.dtype = torch.bfloat16) -> None:
+    """sea_gemm_adaln: AdaLN as the epilogue of cond_mlp.2's GEMM (dict keys: the arguments of fill_adaln_group)."""
+    arr = (N.SeaAdalnGroup * len(groups))()
+    for g, d in zip(arr, groups):
+        fill_adaln_group(g, **d)
+    N.check(N.lib().sea_gemm_adaln(arr, len(groups), eps, N.dtype_code(dtype), N.stream_ptr()), "sea_gemm_adaln")
+
+
 def row_chain_supported(dtype: torch.dtype, D: int, E: int, n_seg: int, hd: int) -> bool:
     """Shapes sea_row_chain instantiates (include/sea_hip.h): bf16, (D, E) in {(128, 256), (64, 128)}, n_seg * D <= E, cross head dim 16 or 32."""
     return dtype == torch.bfloat16 and (D, E) in ((128, 256), (64, 128)) and 0 <= n_seg and n_seg * D <= E and hd in (16, 32)

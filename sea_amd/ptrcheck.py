@@ -103,6 +103,18 @@ def _extents(st, esz: int) -> Iterable[Tuple[str, int, int]]:
             yield "Y32", st.Y32, ((st.M - 1) * st.ldy32 + st.N) * f32
         if st.mod:
             yield "mod", st.mod, ((st.M - 1) * st.ldmod + 2 * st.N) * esz
+    elif isinstance(st, N.SeaAdalnGroup):
+        yield "A", st.A, ((st.M - 1) * st.lda + st.K) * esz
+        yield "W", st.W, ((2 * st.d - 1) * st.ldw + st.K) * esz
+        if st.bias:
+            yield "bias", st.bias, 2 * st.d * f32
+        if st.X:
+            yield "X", st.X, ((st.M - 1) * st.ldx + st.d) * f32
+            yield "gamma", st.gamma, st.d * f32
+        if st.Yact:
+            yield "Yact", st.Yact, ((st.M - 1) * st.ldyact + (st.d if st.X else 2 * st.d)) * esz
+        if st.Y32:
+            yield "Y32", st.Y32, ((st.M - 1) * st.ldy32 + st.d) * f32
     elif isinstance(st, N.SeaRowChain):
         K2 = st.D if st.n_seg > 0 else st.E
         for s_ in range(st.n_seg):

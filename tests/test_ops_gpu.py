@@ -609,6 +609,50 @@ def test_row_chain_unsupported_shapes_are_refused():
         ops.row_chain([dict(W2=rnd(64, 64, dtype=torch.bfloat16), Xin=rnd(8, 64), X=rnd(8, 64), a2=rnd(8, 64, dtype=torch.bfloat16))])
 
 
+@pytest.mark.parametrize("M,d", [(203, 256), (2024, 256), (140, 128), (300, 64), (65, 512), (16192, 256), (4100, 512)])   # the last two: 128-row tiles
+def test_gemm_adaln_matches_the_two_launch_form(M, d):
+    """sea_gemm_adaln (AdaLN as the epilogue of cond_mlp.2's GEMM: the [M, 2 d] modulation matrix is never stored) against the fp32 formula of
+    models/base_blocks.py:343-350 on the bf16 operands, against sea_gemm_grouped + sea_rownorm on the same operands, and a plain group (modulation stored) in
+    the same launch; X is read through a row stride (the caller's [B, T, F, E] layout), statistics are saved."""
+    from sea_amd import ops
+
+    dt = torch.bfloat16
+    K = 2 * d
+    hid = rnd(M, K, dtype=dt, scale=0.5, seed=900)
+    W = rnd(2 * d, K, dtype=dt, scale=K ** -0.5, seed=901)
+    b2 = 0.3 * rnd(2 * d, seed=902)
+    xw = rnd(M, 3 * d, seed=903)
+    x = xw[:, d:2 * d]
+    gamma, beta = 1 + 0.1 * rnd(d, seed=904), 0.1 * rnd(d, seed=905)
+    y = torch.empty(M, d, device=dev(), dtype=dt)
+    y32 = torch.empty(M, d, device=dev())
+    mod_out = torch.empty(M, 2 * d, device=dev(), dtype=dt)
+    mean, rstd = torch.empty(M, device=dev()), torch.empty(M, device=dev())
+    ops.gemm_adaln([dict(A=hid, W=W, bias=b2, X=x, gamma=gamma, beta=beta, Yact=y, Y32=y32, mean=mean, rstd=rstd),
+                    dict(A=hid, W=W, bias=b2, Yact=mod_out)])
+    mod = hid.float() @ W.float().t() + b2
+    xhat = torch.nn.functional.layer_norm(x, (d,), None, None, 1e-5)
+    ref = xhat * (gamma + 1 + mod[:, :d]) + (beta + mod[:, d:])
+    assert rel(y32, ref) < 2e-5                      # (the modulation stays fp32 here: closer to the formula than the two-launch form, which rounds it to bf16)
+    assert rel(y.float(), ref) < 6e-3
+    assert rel(mod_out.float(), mod) < 6e-3
+    assert rel(mean, x.mean(dim=1)) < 1e-5 and rel(rstd, 1.0 / torch.sqrt(x.var(dim=1, unbiased=False) + 1e-5)) < 1e-5
+    # the two launches it replaces
+    mod2 = torch.empty(M, 2 * d, device=dev(), dtype=dt)
+    ops.gemm_grouped([dict(A=hid, W=W, bias=b2, Cact=mod2)], dt)
+    assert rel(mod_out.float(), mod2.float()) < 1e-5
+    y2 = torch.empty(M, d, device=dev(), dtype=dt)
+    ops.rownorm([dict(X=x.contiguous(), mod=mod2, gamma=gamma, beta=beta, Yact=y2)], M, d, False, False, 1e-5, dt)
+    assert rel(y.float(), y2.float()) < 1e-2
+
+
+def test_gemm_adaln_is_bf16_only():
+    from sea_amd import ops
+
+    with pytest.raises(RuntimeError, match="bf16 only"):
+        ops.gemm_adaln([dict(A=rnd(8, 64), W=rnd(64, 64), Yact=rnd(8, 64))], dtype=torch.float32)
+
+
 def test_exchange_tail_unsupported_shapes_are_refused():
     from sea_amd import ops
 
