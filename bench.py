@@ -87,6 +87,12 @@ def record_work(rec, esz):
             fl += 2 * g.M * g.E * g.S + 2 * g.M * g.E * g.E
             by += g.M * g.S * esz + g.E * g.S * esz + g.E * g.E * esz + g.M * g.E * 4 + (g.M * g.E * 4 if g.Y32 else 0) + (g.M * g.E * esz if g.Yact else 0) \
                 + (g.M * 2 * g.E * esz if g.mod else 0)
+    elif rec.fn is L.sea_mlp_block:
+        for g, h in zip(a[0][:a[2]], a[1][:a[2]]):
+            fl += 2 * g.M * g.E * g.S + 2 * g.M * g.E * g.S + 2 * g.M * g.E * g.E
+            rows_in = g.M * g.E * esz if not g.X32 else g.M * g.E * 4 * (1 + (1 if g.addend else 0)) + (g.M * 2 * g.E * esz if g.mod else 0)
+            by += rows_in + 2 * g.S * g.E * esz + 3 * g.S * 4 + g.E * g.E * esz + (g.M * g.E * 4 if h.R else 0) + (g.M * g.E * 4 if h.Y32 else 0) + (g.M * g.E * esz if h.Yact else 0) \
+                + (g.M * 2 * g.E * esz if h.mod else 0)
     elif rec.fn is L.sea_exchange_tail:
         for g in rec.keep[:a[1]]:
             fl += g.n_seg * 2 * g.M * g.D * g.D + 2 * g.M * g.D * g.E + (2 * g.M * g.E * g.D if g.has_down else 0)

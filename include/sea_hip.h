@@ -350,6 +350,15 @@ typedef struct {
 
 int sea_mlp_fc2_proj_norm(const SeaMlp2Group* groups, int n_groups, float eps, int dtype, void* stream);
 
+/* ------------------------------------------------------------------------------------------------------------
+ * The whole field MLP, proj and the final norm in ONE launch (bf16): sea_mlp_fc1_ln_gelu(g1[i]) followed by sea_mlp_fc2_proj_norm(g2[i]) for every group i,
+ * with the activated hidden rows kept in the owning workgroup's registers (models/base_blocks.py:22-25, models/temporal.py:139-146, 412-415): g1[i].Hg and
+ * g2[i].Hg are ignored (may be NULL), g1[i].Xout must be NULL, and g2[i].R may be NULL when g1[i] carries the norm prologue — the residual is then
+ * X32 (+ addend), formed by the same fp32 add as the prologue's.  g2[i].Y32 / Yact may alias g1[i].X32 (a workgroup writes its rows after its last read of
+ * them).  Same shapes and requirements as the two entry points; g1[i].M == g2[i].M.  Returns SEA_EUNSUPPORTED for other shapes / dtypes.
+ */
+int sea_mlp_block(const SeaMlpGroup* g1, const SeaMlp2Group* g2, int n_groups, float eps, int dtype, void* stream);
+
 
 /* ------------------------------------------------------------------------------------------------------------
  * Hidden layer of the AdaLN condition MLP for a scalar condition: Hid[m, k] = silu(w1[k] * c[m] + b1[k]).
@@ -647,11 +656,12 @@ int sea_row_chain_riders(const SeaRowChain* params, int n_groups, const SeaQkvCo
  *     SEA_OP_GEMM_FEW p0 = SeaGemmGroup[n], p1 = pre or NULL, i0 = pre_x_is_act, i1 = pre_gelu, f0 = eps
  *     SEA_OP_QKV_FEW  p0 = SeaQkvGroup[n], p1 = SeaQkvCommon, l0 = (intptr) pre or 0, f0 = eps
  *     SEA_OP_ADALN    p0 = SeaAdalnGroup[n], f0 = eps
+ *     SEA_OP_MLPB     p0 = SeaMlpGroup[n], p1 = SeaMlp2Group[n], f0 = eps
  *     SEA_OP_CHAIN    p0 = SeaRowChain[n], p1 = SeaQkvCommon or NULL, f0 = eps; riders (sea_row_chain_riders): l0 = (intptr) SeaGemmGroup[i0] or 0, i1 = tile0, i2 = n_tiles,
  *                     l1 = (intptr) SeaIbParams or 0
  * Returns 0, or the failing entry's error code with sea_last_error() set (entries before it have been launched).
  */
-enum { SEA_OP_GEMM = 1, SEA_OP_QKV = 2, SEA_OP_ATTN = 3, SEA_OP_NORM = 4, SEA_OP_SILU = 5, SEA_OP_IB = 6, SEA_OP_CONVERT = 8, SEA_OP_GEMM_NORM = 9, SEA_OP_XTAIL = 10, SEA_OP_MLP1 = 11, SEA_OP_MLP2 = 13, SEA_OP_GEMM_FEW = 14, SEA_OP_QKV_FEW = 15, SEA_OP_CHAIN = 16, SEA_OP_ADALN = 17 };   /* 7 and 12 were round-1 entry points (sea_rowchain, sea_cond_mlp), removed in ABI v2 */
+enum { SEA_OP_GEMM = 1, SEA_OP_QKV = 2, SEA_OP_ATTN = 3, SEA_OP_NORM = 4, SEA_OP_SILU = 5, SEA_OP_IB = 6, SEA_OP_CONVERT = 8, SEA_OP_GEMM_NORM = 9, SEA_OP_XTAIL = 10, SEA_OP_MLP1 = 11, SEA_OP_MLP2 = 13, SEA_OP_GEMM_FEW = 14, SEA_OP_QKV_FEW = 15, SEA_OP_CHAIN = 16, SEA_OP_ADALN = 17, SEA_OP_MLPB = 18 };   /* 7 and 12 were round-1 entry points (sea_rowchain, sea_cond_mlp), removed in ABI v2 */
 typedef struct {
     int32_t op, n, dtype, i0, i1, i2, i3;
     float f0;

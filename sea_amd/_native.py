@@ -107,7 +107,7 @@ class SeaAttnBwdParams(C.Structure):
                 ("ldo", _i32), ("lddo", _i32), ("lddq", _i32), ("lddk", _i32), ("lddv", _i32), ("q_scale", _f32), ("drop", SeaDropout)]
 
 
-OP_GEMM, OP_QKV, OP_ATTN, OP_NORM, OP_SILU, OP_IB, OP_CONVERT, OP_GEMM_NORM, OP_XTAIL, OP_MLP1, OP_MLP2, OP_GEMM_FEW, OP_QKV_FEW, OP_CHAIN, OP_ADALN = 1, 2, 3, 4, 5, 6, 8, 9, 10, 11, 13, 14, 15, 16, 17
+OP_GEMM, OP_QKV, OP_ATTN, OP_NORM, OP_SILU, OP_IB, OP_CONVERT, OP_GEMM_NORM, OP_XTAIL, OP_MLP1, OP_MLP2, OP_GEMM_FEW, OP_QKV_FEW, OP_CHAIN, OP_ADALN, OP_MLPB = 1, 2, 3, 4, 5, 6, 8, 9, 10, 11, 13, 14, 15, 16, 17, 18
 FEW_MAX_GROUPS = 8     # sea_gemm_fewrows / sea_qkv_rope_fewrows (gemv.hip)
 FEW_K = (512, 1024, 2048, 4096, 8192, 16384)
 
@@ -281,6 +281,8 @@ def lib() -> C.CDLL:
     L.sea_mlp_fc1_ln_gelu.restype = C.c_int
     L.sea_mlp_fc2_proj_norm.argtypes = [C.POINTER(SeaMlp2Group), C.c_int, C.c_float, C.c_int, _vp]
     L.sea_mlp_fc2_proj_norm.restype = C.c_int
+    L.sea_mlp_block.argtypes = [C.POINTER(SeaMlpGroup), C.POINTER(SeaMlp2Group), C.c_int, C.c_float, C.c_int, _vp]
+    L.sea_mlp_block.restype = C.c_int
     L.sea_run_list.argtypes = [C.POINTER(SeaLaunchRec), C.c_int, _vp]
     L.sea_run_list.restype = C.c_int
     L.sea_run_list_steps.argtypes = [C.POINTER(SeaLaunchRec), C.c_int, C.POINTER(SeaStepPatch), C.c_int, C.c_int, C.c_int, _vp]
@@ -317,7 +319,7 @@ EXPORTED_SYMBOLS = (
     "sea_mse_fwd_bwd", "sea_relative_mse", "sea_adamw_flat",
     "sea_wgrad_grouped", "sea_transpose_weights", "sea_rownorm_bwd", "sea_silu_outer_bwd", "sea_ib_bwd",
     "sea_attention_bwd", "sea_dropout_mask", "sea_run_list", "sea_run_list_steps", "sea_unpatchify", "sea_gemm_rownorm", "sea_exchange_tail", "sea_patchify", "sea_silu_outer_ib", "sea_mlp_fc1_ln_gelu", "sea_mlp_fc2_proj_norm", "sea_kv_rollout", "sea_kv_arena_words", "sea_kv_debug_stamps",
-    "sea_gemm_fewrows", "sea_qkv_rope_fewrows", "sea_row_chain", "sea_row_chain_riders", "sea_gemm_adaln",
+    "sea_gemm_fewrows", "sea_qkv_rope_fewrows", "sea_row_chain", "sea_row_chain_riders", "sea_gemm_adaln", "sea_mlp_block",
 )
 
 

@@ -1046,6 +1046,25 @@ class Plan:
         wn = _switches.plan("mlpnorm", "auto")
         norm_in = fused and (wn == "1" or (wn == "auto" and self.M <= 4096))
         extra = (lambda i: dict(addend=addend, Xout=xr[i])) if addend is not None else (lambda i: {})   # x_i += ib rides in this pass
+        # The two fused launches as ONE (sea_mlp_block: the activated hidden rows stay in the owning workgroup's registers; no hg matrix, one launch boundary less, the
+        # x + ib rows are not written back — the block's residual is formed from x and ib again).  Short launches, where both halves are fused.  SEA_PLAN=mlpblock=0 keeps two launches.
+        w2 = _switches.plan("mlp2", "auto")
+        two = (type(self) is Plan and (w2 == "1" or (w2 == "auto" and 1024 <= self.M <= 4096)) and ops.mlp_fc1_supported(self.dt, E, S) and Eo == E and len(fields) <= N.MAX_MLP_GROUPS)
+        if fused and two and _switches.plan("mlpblock", "1") != "0":
+            a1, a2 = (N.SeaMlpGroup * len(fields))(), (N.SeaMlp2Group * len(fields))()
+            if not norm_in:
+                self._norm([dict(X=xr[i], Yact=n_e[i], **extra(i), **norm_params(f"{pre}ln.exp.{i}.2.", E)) for i in fields], E, ("mlp.ib_adaln2" if addend is not None else "mlp.adaln2") + tag)
+            for g1, g2, i in zip(a1, a2, fields):
+                nrm = dict(X32=xr[i], **(dict(addend=addend) if addend is not None else {}), **norm_params(f"{pre}ln.exp.{i}.2.", E)) if norm_in else None
+                ops.fill_mlp_group(g1, None if norm_in else n_e[i], P.act(f"{pre}mlp.{i}.layers.0.weight"), P.f32_vec(f"{pre}mlp.{i}.layers.0.bias"),
+                                   P.f32_vec(f"{pre}mlp.{i}.layers.1.weight"), P.f32_vec(f"{pre}mlp.{i}.layers.1.bias"), None, nrm)
+                fin = norm_params(f"ln.{i}.", E) if final_norm else {}
+                ops.fill_mlp2_group(g2, None, P.act(f"{pre}mlp.{i}.layers.3.weight"), P.f32_vec(f"{pre}mlp.{i}.layers.3.bias"), (None if norm_in else xr[i]),
+                                    P.act(f"{pre}proj.{i}.weight"), P.f32_vec(f"{pre}proj.{i}.bias"), Y32=xr[i], ldy32=(FE if final_norm else None), M=g1.M, **fin)
+                if final_norm:
+                    self._out_patches.append((g2, "Y32", i * E * 4))
+            self._cur.append(self._rec(N.lib().sea_mlp_block, [a1, a2, len(fields), 1e-5, self.code], ("mlp.block_norm" if final_norm else "mlp.block") + tag, (a1, a2)))
+            return final_norm
         if not norm_in:
             self._norm([dict(X=xr[i], Yact=n_e[i], **extra(i), **norm_params(f"{pre}ln.exp.{i}.2.", E)) for i in fields], E, ("mlp.ib_adaln2" if addend is not None else "mlp.adaln2") + tag)
         if fused:
@@ -1330,6 +1349,8 @@ class Plan:
                 c.op, c.p0, c.n, c.f0, c.dtype = N.OP_MLP1, addr(a[0]), a[1], a[2], a[3]
             elif r.fn is L.sea_mlp_fc2_proj_norm:
                 c.op, c.p0, c.n, c.f0, c.dtype = N.OP_MLP2, addr(a[0]), a[1], a[2], a[3]
+            elif r.fn is L.sea_mlp_block:
+                c.op, c.p0, c.p1, c.n, c.f0, c.dtype = N.OP_MLPB, addr(a[0]), addr(a[1]), a[2], a[3], a[4]
             elif r.fn is L.sea_exchange_tail:
                 c.op, c.p0, c.n, c.f0, c.dtype = N.OP_XTAIL, addr(r.keep), a[1], a[2], a[3]
             elif r.fn is L.sea_gemm_adaln:

@@ -554,8 +554,8 @@ def mlp_fc1_supported(dtype: torch.dtype, E: int, S: int) -> bool:
 def fill_mlp_group(g: N.SeaMlpGroup, A, W1, b1, lnw, lnb, Hg, norm: Optional[Dict] = None) -> None:
     """norm (optional): dict(X32 f32 [M,E], gamma, beta=None, mod=None, addend=None, Xout=None, eps=1e-5) — the operand rows are normalised inside
     the launch from the fp32 residual stream (A is then None)."""
-    g.W1, g.b1, g.lnw, g.lnb, g.Hg = W1.data_ptr(), b1.data_ptr(), lnw.data_ptr(), lnb.data_ptr(), Hg.data_ptr()
-    g.ldw, g.ldh = W1.stride(0), Hg.stride(0)
+    g.W1, g.b1, g.lnw, g.lnb, g.Hg = W1.data_ptr(), b1.data_ptr(), lnw.data_ptr(), lnb.data_ptr(), N.ptr(Hg)   # (Hg None: sea_mlp_block)
+    g.ldw, g.ldh = W1.stride(0), (Hg.stride(0) if Hg is not None else 0)
     g.E, g.S = W1.shape[1], W1.shape[0]
     if norm is None:
         g.A, g.lda, g.M = A.data_ptr(), A.stride(0), A.shape[0]
@@ -572,13 +572,14 @@ def fill_mlp_group(g: N.SeaMlpGroup, A, W1, b1, lnw, lnb, Hg, norm: Optional[Dic
     g.norm_eps = norm.get("eps", 1e-5)
 
 
-def fill_mlp2_group(g: N.SeaMlp2Group, Hg, W2, b2, R, Wproj, bproj, Y32=None, Yact=None, gamma=None, beta=None, mod=None, ldy32=None) -> None:
-    g.Hg, g.W2, g.b2, g.R, g.Wproj, g.bproj = Hg.data_ptr(), W2.data_ptr(), b2.data_ptr(), R.data_ptr(), Wproj.data_ptr(), bproj.data_ptr()
-    g.ldh, g.ldw2, g.ldr, g.ldwp = Hg.stride(0), W2.stride(0), R.stride(0), Wproj.stride(0)
+def fill_mlp2_group(g: N.SeaMlp2Group, Hg, W2, b2, R, Wproj, bproj, Y32=None, Yact=None, gamma=None, beta=None, mod=None, ldy32=None, M=None) -> None:
+    """Hg / R may be None for sea_mlp_block (hidden rows in registers; residual = the norm prologue's x + addend): M is then given."""
+    g.Hg, g.W2, g.b2, g.R, g.Wproj, g.bproj = N.ptr(Hg), W2.data_ptr(), b2.data_ptr(), N.ptr(R), Wproj.data_ptr(), bproj.data_ptr()
+    g.ldh, g.ldw2, g.ldr, g.ldwp = (Hg.stride(0) if Hg is not None else 0), W2.stride(0), (R.stride(0) if R is not None else 0), Wproj.stride(0)
     g.gamma, g.beta, g.mod, g.ldmod = N.ptr(gamma), N.ptr(beta), N.ptr(mod), (mod.stride(0) if mod is not None else 0)
     g.Y32, g.ldy32 = N.ptr(Y32), (ldy32 if ldy32 is not None else (Y32.stride(0) if Y32 is not None else 0))
     g.Yact, g.ldyact = N.ptr(Yact), (Yact.stride(0) if Yact is not None else 0)
-    g.M, g.E, g.S = Hg.shape[0], W2.shape[0], W2.shape[1]
+    g.M, g.E, g.S = (Hg.shape[0] if Hg is not None else M), W2.shape[0], W2.shape[1]
 
 
 def mlp_fc2_proj_norm(groups: Sequence[Dict], eps: float = 1e-5, dtype: torch.dtype = torch.bfloat16) -> None:
@@ -591,6 +592,16 @@ def mlp_fc2_proj_norm(groups: Sequence[Dict], eps: float = 1e-5, dtype: torch.dt
         fill_mlp2_group(g, d["Hg"], d["W2"], d["b2"], d["R"], d["Wproj"], d["bproj"], d.get("Y32"), d.get("Yact"), d.get("gamma"), d.get("beta"), d.get("mod"),
                         d.get("ldy32"))
     N.check(N.lib().sea_mlp_fc2_proj_norm(arr, len(groups), eps, N.dtype_code(dtype), N.stream_ptr()), "sea_mlp_fc2_proj_norm")
+
+
+def mlp_block(groups: Sequence[Dict], eps: float = 1e-5, dtype: torch.dtype = torch.bfloat16) -> None:
+    """The whole field MLP, proj and the final norm in one launch (sea_mlp_block): dicts with the keys of mlp_fc1_ln_gelu (A or norm, W1, b1, lnw, lnb) and of
+    mlp_fc2_proj_norm (W2, b2, R — or None with a norm prologue —, Wproj, bproj, Y32 / Yact, optional gamma / beta / mod); no Hg."""
+    a1, a2 = (N.SeaMlpGroup * len(groups))(), (N.SeaMlp2Group * len(groups))()
+    for g1, g2, d in zip(a1, a2, groups):
+        fill_mlp_group(g1, d.get("A"), d["W1"], d["b1"], d["lnw"], d["lnb"], None, d.get("norm"))
+        fill_mlp2_group(g2, None, d["W2"], d["b2"], d.get("R"), d["Wproj"], d["bproj"], d.get("Y32"), d.get("Yact"), d.get("gamma"), d.get("beta"), d.get("mod"), d.get("ldy32"), M=g1.M)
+    N.check(N.lib().sea_mlp_block(a1, a2, len(groups), eps, N.dtype_code(dtype), N.stream_ptr()), "sea_mlp_block")
 
 
 def mlp_fc1_ln_gelu(groups: Sequence[Dict], eps: float = 1e-5, dtype: torch.dtype = torch.bfloat16) -> None:

@@ -273,7 +273,7 @@ def test_cfg2_full_size_causality_and_prefix_bf16():
     with torch.no_grad():
         a = m(x, ib).clone()
         names = [r.name for r in m.engine().plan(1, 2024, "full").records]
-        assert "mlp.fc1_ln_gelu" in names and "cross0.tail" in names and "self.out_proj_down_qkv" in names and "self.cond_adaln0" in names and len(names) == 13   # the plan of the bench line
+        assert "mlp.block_norm" in names and "cross0.tail" in names and "self.out_proj_down_qkv" in names and "self.cond_adaln0" in names and len(names) == 12   # the plan of the bench line
         x2 = x.clone()
         x2[:, 1500] += 1.0
         b = m(x2, ib).clone()
@@ -546,7 +546,8 @@ def test_rider_plan_matches_the_plans_it_replaces(F, B, T, monkeypatch):
 
 
 @pytest.mark.parametrize("env,graphed", [({"SEA_PLAN": "lanes=all"}, True), ({"SEA_PLAN": "lanes=cond"}, True),
-                                         ({"SEA_PLAN": "norm=0"}, False), ({"SEA_PLAN": "xtail=0"}, False), ({"SEA_PLAN": "chain=0"}, False), ({"SEA_PLAN": "silu=1"}, False), ({"SEA_PLAN": "fold_ib=0"}, False), ({"SEA_PLAN": "mlp1=1"}, False), ({"SEA_TUNE": "gemm_norm_rows=64"}, False)])
+                                         ({"SEA_PLAN": "norm=0"}, False), ({"SEA_PLAN": "xtail=0"}, False), ({"SEA_PLAN": "chain=0"}, False), ({"SEA_PLAN": "silu=1"}, False), ({"SEA_PLAN": "fold_ib=0"}, False), ({"SEA_PLAN": "mlp1=1"}, False), ({"SEA_PLAN": "mlp1=1,mlp2=1"}, False), ({"SEA_PLAN": "mlp1=1,mlp2=1,mlpblock=0"}, False),
+                                         ({"SEA_TUNE": "gemm_norm_rows=64"}, False)])
 @pytest.mark.parametrize("dtype,tol", [("fp32", 2e-6), ("bf16", 2e-2)])
 def test_optional_plans_match_default_plan(env, graphed, dtype, tol, monkeypatch):
     """The opt-in plans (fusion switches; parallel graph branches) compute what the default launch list computes — checked on the oracle too
@@ -570,7 +571,11 @@ def test_optional_plans_match_default_plan(env, graphed, dtype, tol, monkeypatch
         monkeypatch.delenv("SEA_PLAN")
         e2 = build(cfg, dtype).engine()
         assert "mlp.fc1" in [r.name for r in e2.plan(2, 70, "full").records]
-        assert ("mlp.fc1_ln_gelu" in [r.name for r in e2.plan(16, 70, "full").records]) == (dtype == "bf16")
+        assert ("mlp.block" in [r.name for r in e2.plan(16, 70, "full").records]) == (dtype == "bf16")   # (from 1024 rows up both halves are fused, and the two fused launches are one: sea_mlp_block)
+    elif sw == "mlp1=1,mlp2=1":   # both halves of the field MLP fused and short launches forced: ONE launch (sea_mlp_block), in the last layer with the final norm
+        assert (dtype == "bf16") == ("mlp.block" in names and "mlp.block_norm" in names) and "mlp.fc2_proj_norm" not in names
+    elif sw == "mlp1=1,mlp2=1,mlpblock=0":   # ... and the two launches it replaces
+        assert (dtype == "bf16") == ("mlp.fc1_ln_gelu" in names and "mlp.fc2_proj_norm" in names) and "mlp.block" not in names
     elif sw == "fold_ib=0":     # the info-bottleneck add as its own launch (default: evaluated in the silu launch, added by the AdaLN_2 pass)
         assert "ib_add" in names and "mlp.adaln2" in names and "mlp.ib_adaln2" not in names
     elif sw == "silu=1":   # AdaLN condition MLPs with the generated operand (default only for long launches)

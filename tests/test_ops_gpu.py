@@ -821,6 +821,85 @@ def test_mlp_fc2_proj_norm_matches_three_launch_form(E, S, M, norm):
         assert rel(y32, y2) < 2e-3
 
 
+@pytest.mark.parametrize("E,S,M", [(256, 2048, 2024), (256, 2048, 33), (128, 1024, 1000), (256, 2048, 9000)])
+@pytest.mark.parametrize("prologue", [None, "adaln_add", "ln"])
+@pytest.mark.parametrize("norm", [None, "adaln"])
+def test_mlp_block_matches_the_two_fused_launches(E, S, M, prologue, norm):
+    """sea_mlp_block (the field MLP, proj and the final norm in one launch; the activated hidden rows stay in registers) against sea_mlp_fc1_ln_gelu followed by
+    sea_mlp_fc2_proj_norm on the same operands — the same arithmetic up to the summation order of the second layer's contraction (eight partial tiles, added
+    in wave order) — and against the fp32 formula of models/base_blocks.py:22-25 / models/temporal.py:139-146, 412-415.  Three fields per launch, the output
+    written into the caller's strided [M, F, E] layout; with a norm prologue the residual is x + ib formed inside the launch (R = None)."""
+    from sea_amd import ops
+
+    if M == 9000 and (prologue == "ln" or norm is None):
+        pytest.skip("the several-round case once per output form")
+    dt = torch.bfloat16
+    groups, two1, two2, outs, outs2, refs = [], [], [], [], [], []
+    out = torch.full((M, 3 * E), float("nan"), device=dev())
+    out2 = torch.full((M, 3 * E), float("nan"), device=dev())
+    for i in range(3):
+        W1, b1 = rnd(S, E, dtype=dt, scale=0.08, seed=1600 + i), 0.2 * rnd(S, seed=1610 + i)
+        lnw, lnb = 1 + 0.1 * rnd(S, seed=1620 + i), 0.1 * rnd(S, seed=1630 + i)
+        W2, b2 = rnd(E, S, dtype=dt, scale=0.03, seed=1640 + i), 0.2 * rnd(E, seed=1650 + i)
+        Wp, bp = rnd(E, E, dtype=dt, scale=0.08, seed=1660 + i), 0.2 * rnd(E, seed=1670 + i)
+        x = rnd(M, E, seed=1680 + i)
+        gamma = 1 + 0.1 * rnd(E, seed=1690 + i) if norm else None
+        beta = 0.1 * rnd(E, seed=1700 + i) if norm else None
+        mod = (0.3 * rnd(M, 2 * E, seed=1710 + i)).to(dt) if norm else None
+        first = dict(W1=W1, b1=b1, lnw=lnw, lnb=lnb)
+        if prologue is None:
+            A = rnd(M, E, dtype=dt, seed=1720 + i)
+            first["A"] = A
+            a_rows, res, R = A.float(), x, x
+        else:
+            add = 0.5 * rnd(M, E, seed=1730 + i) if prologue == "adaln_add" else None
+            pg, pb = 1 + 0.1 * rnd(E, seed=1740 + i), (0.1 * rnd(E, seed=1750 + i) if prologue == "adaln_add" else None)
+            pmod = (0.3 * rnd(M, 2 * E, seed=1760 + i)).to(dt) if prologue == "adaln_add" else None
+            first["norm"] = dict(X32=x, gamma=pg, beta=pb, mod=pmod, addend=add)
+            res = x + add if add is not None else x
+            xh = torch.nn.functional.layer_norm(res, (E,), None, None, 1e-5)
+            a_rows = (xh * (pg + 1 + pmod[:, :E].float()) + pb + pmod[:, E:].float()) if pmod is not None else xh * pg
+            a_rows = a_rows.to(dt).float()
+            R = None
+        y32 = out[:, i * E:(i + 1) * E]
+        groups.append(dict(**first, W2=W2, b2=b2, R=R, Wproj=Wp, bproj=bp, Y32=y32, gamma=gamma, beta=beta, mod=mod))
+        # the two launches: (the prologue form writes x + ib to rows of its own, which the second launch reads as its residual)
+        hg = torch.empty(M, S, device=dev(), dtype=dt)
+        f1 = dict(first, Hg=hg)
+        if prologue is not None:
+            xq = torch.empty(M, E, device=dev())
+            f1["norm"] = dict(first["norm"], Xout=xq)
+        two1.append(f1)
+        two2.append(dict(Hg=hg, W2=W2, b2=b2, R=(xq if prologue is not None else x), Wproj=Wp, bproj=bp, Y32=out2[:, i * E:(i + 1) * E], gamma=gamma, beta=beta, mod=mod))
+        h = gelu(torch.nn.functional.layer_norm(a_rows @ W1.float().t() + b1, (S,), lnw, lnb, 1e-5)).to(dt).float()
+        x3 = (h @ W2.float().t() + b2 + res).to(dt).float()
+        y = x3 @ Wp.float().t() + bp
+        if norm:
+            yh = torch.nn.functional.layer_norm(y, (E,), None, None, 1e-5)
+            y = yh * (gamma + 1 + mod[:, :E].float()) + beta + mod[:, E:].float()
+        refs.append(y)
+    ops.mlp_block(groups)
+    ops.mlp_fc1_ln_gelu(two1)
+    ops.mlp_fc2_proj_norm(two2)
+    for i, ref in enumerate(refs):
+        y32, y2 = out[:, i * E:(i + 1) * E], out2[:, i * E:(i + 1) * E]
+        assert bool(torch.isfinite(y32).all())
+        assert rel(y32, y2) < 3e-3, (i, rel(y32, y2))       # (x3 is rounded to bf16 in both; the fp32 sums in front of that rounding differ in order)
+        assert rel(y32, ref) < 8e-3, (i, rel(y32, ref))
+
+
+def test_mlp_block_refuses_what_it_cannot_do():
+    from sea_amd import ops
+
+    dt = torch.bfloat16
+    g = dict(A=rnd(40, 256, dtype=dt), W1=rnd(2048, 256, dtype=dt), b1=rnd(2048), lnw=rnd(2048), lnb=rnd(2048), W2=rnd(256, 2048, dtype=dt), b2=rnd(256),
+             R=None, Wproj=rnd(256, 256, dtype=dt), bproj=rnd(256), Y32=torch.empty(40, 256, device=dev()))
+    with pytest.raises(RuntimeError, match="R may be NULL with the norm prologue"):
+        ops.mlp_block([g])
+    with pytest.raises(RuntimeError, match="unsupported dtype / shape"):
+        ops.mlp_block([dict(g, R=rnd(40, 256), W1=rnd(1024, 256, dtype=dt), b1=rnd(1024), lnw=rnd(1024), lnb=rnd(1024), W2=rnd(256, 1024, dtype=dt))])
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_rownorm_ln_gelu_act_input(dtype):
     from sea_amd import ops
