@@ -219,11 +219,7 @@ __global__ __launch_bounds__(512) void mlp_block_kernel(const MlpBlockLaunch L) 
     const unsigned wp_lane = (unsigned)((rl * H.ldwp + chunk * 8) * 2);
     constexpr int NSLOT = (E / 16) * (NT / 2);   // W2 slots of a wave: (tau, j), j fastest
     constexpr int NJ = E / NW / 16;              // 16-column blocks of a wave in proj
-#ifdef BLK_NOWP
-    constexpr int NX = 0;
-#else
     constexpr int NX = NJ * KT;                  // Wproj slots of a wave: (j, kt), kt fastest
-#endif
     auto w2_slot = [&](int k) {
         const unsigned dst = lds_base + (unsigned)(Cf::RING_OFF + (wave * Cf::RS + (k % Cf::RS)) * Cf::SLOT);
         if (k < NSLOT) {
@@ -377,17 +373,6 @@ __global__ __launch_bounds__(512) void mlp_block_kernel(const MlpBlockLaunch L) 
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         return;
     }
-#ifdef BLK_PROBE1
-    {
-        uint4* dump = reinterpret_cast<uint4*>(H.Y32) + (size_t)tile * 512 * NT * 2 + tid;
-#pragma unroll
-        for (int i = 0; i < NT; ++i) {
-            dump[(i * 2) * 512] = hid[i][0];
-            dump[(i * 2 + 1) * 512] = hid[i][1];
-        }
-        return;
-    }
-#endif
 
     // ================================================================================================ phase 2: fc2, contraction split over the waves
     // (the W2 ring was started under the first layer's epilogue: w2_slot / the prologue above)
@@ -482,7 +467,9 @@ __global__ __launch_bounds__(512) void mlp_block_kernel(const MlpBlockLaunch L) 
             }
         }
     }
-    float bpv[NJ][4], gq[NJ][4], bq[NJ][4], mwv[2][NJ][4], mbv[2][NJ][4];
+    constexpr int CPT = E / 16;                  // columns of a thread in the final pass (16 threads per row)
+    const int ec0 = (tid & 15) * CPT;
+    float ebp[CPT], egq[CPT], ebq[CPT];          // bproj; gamma (+ 1 + scale); beta (+ shift)
     const bool has_norm = H.gamma != nullptr;
     // ---- the eight partial tiles meet in LDS, 128 columns at a time: a slab per wave, summed in wave order
 #pragma unroll
@@ -493,28 +480,28 @@ __global__ __launch_bounds__(512) void mlp_block_kernel(const MlpBlockLaunch L) 
 #pragma unroll
             for (int j = 0; j < JH; ++j)
                 *reinterpret_cast<f32x4*>(slab + (mb * 16 + r) * Cf::SLAB_PITCH + (j * 16 + g * 4) * 4) = acc2[mb][h * JH + j];
-        if (h == NH - 1) {   // the accumulators are gone: the epilogue operands are requested here, under the last reduction
-            __builtin_amdgcn_sched_barrier(0);
+        if (h == NH - 1) {   // the accumulators are gone: the epilogue operands are requested here, under the last reduction — in the ROW layout of the final pass
+            __builtin_amdgcn_sched_barrier(0);   // (this thread: row srow, the CPT columns from ec0)
+            int m = m0 + srow;
+            m = m < M ? m : M - 1;
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) {
-                const int n = wave * (E / NW) + j * 16 + g * 4;
-                load4(H.bproj + n, bpv[j]);
+            for (int c = 0; c < CPT; c += 4) {
+                load4(H.bproj + ec0 + c, *reinterpret_cast<float(*)[4]>(ebp + c));
 #pragma unroll
-                for (int q = 0; q < 4; ++q) gq[j][q] = bq[j][q] = 0.f;
+                for (int q = 0; q < 4; ++q) egq[c + q] = ebq[c + q] = 0.f;
                 if (has_norm) {
-                    load4(H.gamma + n, gq[j]);
-                    if (H.beta != nullptr) load4(H.beta + n, bq[j]);
-                }
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    int m = m0 + i * 16 + r;
-                    m = m < M ? m : M - 1;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) mwv[i][j][q] = mbv[i][j][q] = 0.f;
-                    if (has_norm && H.mod != nullptr) {
+                    load4(H.gamma + ec0 + c, *reinterpret_cast<float(*)[4]>(egq + c));
+                    if (H.beta != nullptr) load4(H.beta + ec0 + c, *reinterpret_cast<float(*)[4]>(ebq + c));
+                    if (H.mod != nullptr) {
+                        float mw[4], mb[4];
                         const T* mod = static_cast<const T*>(H.mod) + (int64_t)m * H.ldmod;
-                        load4(mod + n, mwv[i][j]);
-                        load4(mod + E + n, mbv[i][j]);
+                        load4(mod + ec0 + c, mw);
+                        load4(mod + E + ec0 + c, mb);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            egq[c + q] += 1.0f + mw[q];
+                            ebq[c + q] += mb[q];
+                        }
                     }
                 }
             }
@@ -543,21 +530,6 @@ __global__ __launch_bounds__(512) void mlp_block_kernel(const MlpBlockLaunch L) 
         if (L.probe == 5 + h) return;
     }
 
-#ifdef BLK_PROBE3
-    {
-        uint4* dump = reinterpret_cast<uint4*>(H.Y32) + (size_t)tile * 512 * 64 + tid;
-#pragma unroll
-        for (int kt = 0; kt < KT * 2; ++kt)
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) dump[(kt * NJ + j) * 512] = wp[kt][j];
-        float* d2 = reinterpret_cast<float*>(dump + 32 * 512);
-#pragma unroll
-        for (int j = 0; j < NJ; ++j)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) d2[(j * 4 + q) * 512] = bpv[j][q] + gq[j][q] + bq[j][q] + mwv[0][j][q] + mwv[1][j][q] + mbv[0][j][q] + mbv[1][j][q];
-        return;
-    }
-#endif
     if (L.probe == 4) return;
     // ================================================================================================ phase 3: proj + the row norm (sea_mlp_fc2_proj_norm's tail)
     f32x4 acc3[2][NJ];
@@ -582,78 +554,59 @@ __global__ __launch_bounds__(512) void mlp_block_kernel(const MlpBlockLaunch L) 
                 }
             }
     }
-    float* red2 = reinterpret_cast<float*>(smem + Cf::RED2_OFF);   // [2 passes][8 waves][32 rows]
-    float v[2][NJ][4];
+    // ---- the output rows leave in ROW layout: y through an LDS tile (the slabs' memory), then 16 threads per row — statistics by lane exchanges inside the
+    // 16, the norm operands and the stores as whole 64-byte pieces of a row (in the accumulator layout a store instruction is 16 rows x 64 B, and the
+    // modulation rows 16 rows x 8 B per load: ~100 cycles of the memory pipeline each, 3 us per workgroup)
+    constexpr int SEG = 80, YP = (E / 16) * SEG + 16;   // a row: 16-column segments of 64 B at a pitch of 80 (the readers' 64-byte strides would share banks four ways)
+    static_assert(BM * YP <= Cf::X3_OFF, "the y tile lies in front of the x3 tile");
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < NJ; ++j)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) v[i][j][q] = acc3[i][j][q] + bpv[j][q];
-    float mean2[2] = {0.f, 0.f}, rstd2[2] = {1.f, 1.f};
-    if (has_norm) {   // block-uniform
-        const float inv_e = 1.0f / (float)E;
-        float sum[2];
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            float t4[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int j = 0; j < NJ; ++j)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) t4[q] = add1(t4[q], v[i][j][q]);
-            sum[i] = add1(add1(t4[0], t4[1]), add1(t4[2], t4[3]));
-            sum[i] += __shfl_xor(sum[i], 16);
-            sum[i] += __shfl_xor(sum[i], 32);
-            if (g == 0) red2[wave * 32 + i * 16 + r] = sum[i];
-        }
-        __syncthreads();
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            float t = 0.f;
-#pragma unroll
-            for (int w = 0; w < NW; ++w) t += red2[w * 32 + i * 16 + r];
-            mean2[i] = t * inv_e;
-            float q4[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int j = 0; j < NJ; ++j)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const float c = v[i][j][q] - mean2[i];
-                    q4[q] = fma1(c, c, q4[q]);
-                }
-            float sq = add1(add1(q4[0], q4[1]), add1(q4[2], q4[3]));
-            sq += __shfl_xor(sq, 16);
-            sq += __shfl_xor(sq, 32);
-            if (g == 0) red2[256 + wave * 32 + i * 16 + r] = sq;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            float t = 0.f;
-#pragma unroll
-            for (int w = 0; w < NW; ++w) t += red2[256 + w * 32 + i * 16 + r];
-            rstd2[i] = 1.0f / sqrtf(t * inv_e + L.eps);
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int m = m0 + i * 16 + r;
-        if (m >= M) continue;
-#pragma unroll
         for (int j = 0; j < NJ; ++j) {
             const int n = wave * (E / NW) + j * 16 + g * 4;
-            float o[4];
+            *reinterpret_cast<f32x4*>(smem + (i * 16 + r) * YP + (n >> 4) * SEG + (n & 15) * 4) = acc3[i][j];
+        }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    {
+        float v[CPT];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                if (has_norm) {
-                    const float gg = H.mod != nullptr ? gq[j][q] + 1.0f + mwv[i][j][q] : gq[j][q];
-                    o[q] = (v[i][j][q] - mean2[i]) * rstd2[i] * gg + (bq[j][q] + mbv[i][j][q]);
-                } else {
-                    o[q] = v[i][j][q];
+        for (int c = 0; c < CPT; c += 4) {
+            const float4 y = *reinterpret_cast<const float4*>(smem + srow * YP + ((ec0 + c) >> 4) * SEG + ((ec0 + c) & 15) * 4);
+            v[c] = y.x + ebp[c]; v[c + 1] = y.y + ebp[c + 1]; v[c + 2] = y.z + ebp[c + 2]; v[c + 3] = y.w + ebp[c + 3];
+        }
+        if (has_norm) {   // block-uniform
+            float s4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int c = 0; c < CPT; c += 4)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) s4[e] = add1(s4[e], v[c + e]);
+            float sm_ = add1(add1(s4[0], s4[1]), add1(s4[2], s4[3]));
+#pragma unroll
+            for (int o = 8; o >= 1; o >>= 1) sm_ += __shfl_xor(sm_, o);
+            const float mean2 = sm_ * (1.0f / (float)E);
+            float q4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int c = 0; c < CPT; c += 4)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float d_ = v[c + e] - mean2;
+                    q4[e] = fma1(d_, d_, q4[e]);
                 }
+            float sq = add1(add1(q4[0], q4[1]), add1(q4[2], q4[3]));
+#pragma unroll
+            for (int o = 8; o >= 1; o >>= 1) sq += __shfl_xor(sq, o);
+            const float rstd2 = 1.0f / sqrtf(sq * (1.0f / (float)E) + L.eps);
+#pragma unroll
+            for (int c = 0; c < CPT; ++c) v[c] = (v[c] - mean2) * rstd2 * egq[c] + ebq[c];
+        }
+        const int m = m0 + srow;
+        if (m < M) {
+#pragma unroll
+            for (int c = 0; c < CPT; c += 4) {
+                if (H.Y32 != nullptr) store4(H.Y32 + (int64_t)m * H.ldy32 + ec0 + c, v[c], v[c + 1], v[c + 2], v[c + 3]);
+                if (H.Yact != nullptr) store4(static_cast<T*>(H.Yact) + (int64_t)m * H.ldyact + ec0 + c, v[c], v[c + 1], v[c + 2], v[c + 3]);
             }
-            if (H.Y32 != nullptr) store4(H.Y32 + (int64_t)m * H.ldy32 + n, o[0], o[1], o[2], o[3]);
-            if (H.Yact != nullptr) store4(static_cast<T*>(H.Yact) + (int64_t)m * H.ldyact + n, o[0], o[1], o[2], o[3]);
         }
     }
     }

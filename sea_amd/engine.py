@@ -1048,9 +1048,12 @@ class Plan:
         extra = (lambda i: dict(addend=addend, Xout=xr[i])) if addend is not None else (lambda i: {})   # x_i += ib rides in this pass
         # The two fused launches as ONE (sea_mlp_block: the activated hidden rows stay in the owning workgroup's registers; no hg matrix, one launch boundary less, the
         # x + ib rows are not written back — the block's residual is formed from x and ib again).  Short launches, where both halves are fused.  SEA_PLAN=mlpblock=0 keeps two launches.
+        # Long launches too (B = 8, M = 16192: 262 us against ib_add 30 + AdaLN_2 30 + fc1 + LN + GELU 160 + fc2 88 + proj + norm 55), there always with the norm
+        # prologue: the row pass it replaces and the hidden rows it keeps to itself are 0.6 GB of traffic.
         w2 = _switches.plan("mlp2", "auto")
-        two = (type(self) is Plan and (w2 == "1" or (w2 == "auto" and 1024 <= self.M <= 4096)) and ops.mlp_fc1_supported(self.dt, E, S) and Eo == E and len(fields) <= N.MAX_MLP_GROUPS)
+        two = (type(self) is Plan and (w2 == "1" or (w2 == "auto" and 1024 <= self.M)) and ops.mlp_fc1_supported(self.dt, E, S) and Eo == E and len(fields) <= N.MAX_MLP_GROUPS)
         if fused and two and _switches.plan("mlpblock", "1") != "0":
+            norm_in = norm_in or (self.M > 4096 and wn != "0")
             a1, a2 = (N.SeaMlpGroup * len(fields))(), (N.SeaMlp2Group * len(fields))()
             if not norm_in:
                 self._norm([dict(X=xr[i], Yact=n_e[i], **extra(i), **norm_params(f"{pre}ln.exp.{i}.2.", E)) for i in fields], E, ("mlp.ib_adaln2" if addend is not None else "mlp.adaln2") + tag)
