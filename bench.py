@@ -87,6 +87,13 @@ def record_work(rec, esz):
             fl += 2 * g.M * g.E * g.S + 2 * g.M * g.E * g.E
             by += g.M * g.S * esz + g.E * g.S * esz + g.E * g.E * esz + g.M * g.E * 4 + (g.M * g.E * 4 if g.Y32 else 0) + (g.M * g.E * esz if g.Yact else 0) \
                 + (g.M * 2 * g.E * esz if g.mod else 0)
+    elif rec.fn is L.sea_adaln_qkv:
+        for g in a[0][:a[1]]:
+            fl += 2 * g.M * (2 * g.E) * (2 * g.E) + 2 * g.M * (3 * g.E) * g.E
+            by += g.M * g.E * 4 + g.M * 4 + (2 * g.E) * (2 * g.E) * esz + 3 * g.E * g.E * esz + 3 * g.M * g.E * esz
+        for g in (a[3][:a[4]] if a[3] is not None else []):
+            fl += 2 * g.M * g.N * g.K
+            by += g.M * g.K * esz + g.N * g.K * esz + g.M * g.N * esz
     elif rec.fn is L.sea_mlp_block:
         for g, h in zip(a[0][:a[2]], a[1][:a[2]]):
             fl += 2 * g.M * g.E * g.S + 2 * g.M * g.E * g.S + 2 * g.M * g.E * g.E

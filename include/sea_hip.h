@@ -41,7 +41,7 @@ enum {
 int sea_abi_version(void);
 const char* sea_last_error(void);
 /* sizeof of every ABI struct in declaration order (SeaGemmGroup, SeaQkvGroup, SeaQkvCommon, SeaAttnProblem,
- * SeaAttnParams, SeaNormGroup, SeaSiluGroup, SeaIbParams, ..., SeaLaunchRec, SeaGemmNormGroup, SeaExchangeTail, SeaMlpGroup, SeaMlp2Group, SeaKvNorm, SeaKvField, SeaKvPair, SeaKvLayer, SeaKvGlobal, SeaStepPatch, SeaRowChain, SeaAdalnGroup last): lets a binding verify its layout.  Host only. */
+ * SeaAttnParams, SeaNormGroup, SeaSiluGroup, SeaIbParams, ..., SeaLaunchRec, SeaGemmNormGroup, SeaExchangeTail, SeaMlpGroup, SeaMlp2Group, SeaKvNorm, SeaKvField, SeaKvPair, SeaKvLayer, SeaKvGlobal, SeaStepPatch, SeaRowChain, SeaAdalnGroup, SeaAdalnQkv last): lets a binding verify its layout.  Host only. */
 int sea_struct_sizes(int* out, int cap);
 /* Number of compute units / name of device 0's architecture as HIP reports them (diagnostics for bench.py). */
 int sea_device_info(int* cu_count, char* arch, int arch_len);
@@ -591,6 +591,35 @@ typedef struct {
 int sea_gemm_adaln(const SeaAdalnGroup* groups, int n_groups, float eps, int dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
+ * The front of a block in one launch (bf16, E = 256): the AdaLN condition MLP of AdaLN_0 with its hidden rows generated in place, AdaLN_0, and the
+ * self-attention's q / k / v projections with the rotary epilogue —
+ *     h = silu(w1 * cond[m] + b1)  [2E];   [w | b] = h . W2c^T + b2c;   y = xhat(X) * (gamma + 1 + w) + (beta + b)              (models/base_blocks.py:337-350)
+ *     [q | k | v] = y . Wqkv^T + bqkv -> rotary embedding on q / k, q scale, Q [B,H,T,hd] / K [B,H,cap,hd] / Vt [B,H,hd,cap] as sea_qkv_rope_grouped (col0 = 0, N = 3E)
+ * — a workgroup owns 32 rows from the caller's rows to the attention operands: replaces sea_silu_outer + sea_gemm_adaln + sea_qkv_rope_grouped for these modules
+ * (no hidden matrix, no modulation matrix, no normalised rows in memory).  `riders`: plain bf16 groups (A, W, bias, Cact only; whole 64-wide K-tiles) of later
+ * launches, run as 128 x 128 tiles by extra workgroups (sea_row_chain_riders' contract).  M = B * T rows per group; head dim 16 or 32, H * hd = E; cap % 8 == 0.
+ * Returns SEA_EUNSUPPORTED for other shapes / dtypes.
+ */
+#define SEA_MAX_AQKV_GROUPS 4
+typedef struct {
+    const float* X;      /* f32 [M, E], row stride ldx */
+    const float* cond;   /* f32 [M]: the condition scalar of a row */
+    const float* w1;     /* f32 [2E]: cond_mlp.0.weight */
+    const float* b1;     /* f32 [2E]: cond_mlp.0.bias */
+    const void* W2c;     /* act [2E, 2E], row stride ldw2c: cond_mlp.2.weight (rows 0..E-1 scale, E..2E-1 shift) */
+    const float* b2c;    /* f32 [2E] or NULL */
+    const float* gamma;  /* f32 [E] */
+    const float* beta;   /* f32 [E] or NULL */
+    const void* Wqkv;    /* act [3E, E], row stride ldw: [Wq; Wk; Wv] */
+    const float* bqkv;   /* f32 [3E] or NULL */
+    void* Q;             /* act [B, H, T, hd] */
+    void* K;             /* act [B, H, cap, hd], rows pos0 + t */
+    void* Vt;            /* act [B, H, hd, cap], columns pos0 + t */
+    int32_t ldx, ldw2c, ldw, M, E, pad_;
+} SeaAdalnQkv;
+int sea_adaln_qkv(const SeaAdalnQkv* groups, int n_groups, const SeaQkvCommon* common, const SeaGemmGroup* riders, int n_riders, float eps, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
  * A ROW-LOCAL CHAIN of the state-exchange block in one launch (bf16 compute; a workgroup owns 16 or 32 rows from an attention launch's output to the
  * next attention launch's operands; sea_amd/csrc/chain.hip).  Per group (field), in order:
  *   form A (n_seg = 0):   x = Xin + a2[M,E] . W2[E,E]^T (+ b2)                          self-attention out-projection + residual
@@ -657,11 +686,12 @@ int sea_row_chain_riders(const SeaRowChain* params, int n_groups, const SeaQkvCo
  *     SEA_OP_QKV_FEW  p0 = SeaQkvGroup[n], p1 = SeaQkvCommon, l0 = (intptr) pre or 0, f0 = eps
  *     SEA_OP_ADALN    p0 = SeaAdalnGroup[n], f0 = eps
  *     SEA_OP_MLPB     p0 = SeaMlpGroup[n], p1 = SeaMlp2Group[n], f0 = eps
+ *     SEA_OP_AQKV     p0 = SeaAdalnQkv[n], p1 = SeaQkvCommon, l0 = (intptr) SeaGemmGroup[i0] riders or 0, f0 = eps
  *     SEA_OP_CHAIN    p0 = SeaRowChain[n], p1 = SeaQkvCommon or NULL, f0 = eps; riders (sea_row_chain_riders): l0 = (intptr) SeaGemmGroup[i0] or 0, i1 = tile0, i2 = n_tiles,
  *                     l1 = (intptr) SeaIbParams or 0
  * Returns 0, or the failing entry's error code with sea_last_error() set (entries before it have been launched).
  */
-enum { SEA_OP_GEMM = 1, SEA_OP_QKV = 2, SEA_OP_ATTN = 3, SEA_OP_NORM = 4, SEA_OP_SILU = 5, SEA_OP_IB = 6, SEA_OP_CONVERT = 8, SEA_OP_GEMM_NORM = 9, SEA_OP_XTAIL = 10, SEA_OP_MLP1 = 11, SEA_OP_MLP2 = 13, SEA_OP_GEMM_FEW = 14, SEA_OP_QKV_FEW = 15, SEA_OP_CHAIN = 16, SEA_OP_ADALN = 17, SEA_OP_MLPB = 18 };   /* 7 and 12 were round-1 entry points (sea_rowchain, sea_cond_mlp), removed in ABI v2 */
+enum { SEA_OP_GEMM = 1, SEA_OP_QKV = 2, SEA_OP_ATTN = 3, SEA_OP_NORM = 4, SEA_OP_SILU = 5, SEA_OP_IB = 6, SEA_OP_CONVERT = 8, SEA_OP_GEMM_NORM = 9, SEA_OP_XTAIL = 10, SEA_OP_MLP1 = 11, SEA_OP_MLP2 = 13, SEA_OP_GEMM_FEW = 14, SEA_OP_QKV_FEW = 15, SEA_OP_CHAIN = 16, SEA_OP_ADALN = 17, SEA_OP_MLPB = 18, SEA_OP_AQKV = 19 };   /* 7 and 12 were round-1 entry points (sea_rowchain, sea_cond_mlp), removed in ABI v2 */
 typedef struct {
     int32_t op, n, dtype, i0, i1, i2, i3;
     float f0;

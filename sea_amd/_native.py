@@ -107,7 +107,7 @@ class SeaAttnBwdParams(C.Structure):
                 ("ldo", _i32), ("lddo", _i32), ("lddq", _i32), ("lddk", _i32), ("lddv", _i32), ("q_scale", _f32), ("drop", SeaDropout)]
 
 
-OP_GEMM, OP_QKV, OP_ATTN, OP_NORM, OP_SILU, OP_IB, OP_CONVERT, OP_GEMM_NORM, OP_XTAIL, OP_MLP1, OP_MLP2, OP_GEMM_FEW, OP_QKV_FEW, OP_CHAIN, OP_ADALN, OP_MLPB = 1, 2, 3, 4, 5, 6, 8, 9, 10, 11, 13, 14, 15, 16, 17, 18
+OP_GEMM, OP_QKV, OP_ATTN, OP_NORM, OP_SILU, OP_IB, OP_CONVERT, OP_GEMM_NORM, OP_XTAIL, OP_MLP1, OP_MLP2, OP_GEMM_FEW, OP_QKV_FEW, OP_CHAIN, OP_ADALN, OP_MLPB, OP_AQKV = 1, 2, 3, 4, 5, 6, 8, 9, 10, 11, 13, 14, 15, 16, 17, 18, 19
 FEW_MAX_GROUPS = 8     # sea_gemm_fewrows / sea_qkv_rope_fewrows (gemv.hip)
 FEW_K = (512, 1024, 2048, 4096, 8192, 16384)
 
@@ -159,6 +159,14 @@ MAX_ADALN_GROUPS = 16
 class SeaAdalnGroup(C.Structure):
     _fields_ = [("A", _vp), ("W", _vp), ("bias", _vp), ("X", _vp), ("gamma", _vp), ("beta", _vp), ("Yact", _vp), ("Y32", _vp), ("mean", _vp), ("rstd", _vp),
                 ("lda", _i32), ("ldw", _i32), ("ldx", _i32), ("ldyact", _i32), ("ldy32", _i32), ("M", _i32), ("d", _i32), ("K", _i32)]
+
+
+MAX_AQKV_GROUPS = 4
+
+
+class SeaAdalnQkv(C.Structure):
+    _fields_ = [("X", _vp), ("cond", _vp), ("w1", _vp), ("b1", _vp), ("W2c", _vp), ("b2c", _vp), ("gamma", _vp), ("beta", _vp), ("Wqkv", _vp), ("bqkv", _vp),
+                ("Q", _vp), ("K", _vp), ("Vt", _vp), ("ldx", _i32), ("ldw2c", _i32), ("ldw", _i32), ("M", _i32), ("E", _i32), ("pad_", _i32)]
 
 
 MAX_MLP_GROUPS = 8
@@ -283,6 +291,8 @@ def lib() -> C.CDLL:
     L.sea_mlp_fc2_proj_norm.restype = C.c_int
     L.sea_mlp_block.argtypes = [C.POINTER(SeaMlpGroup), C.POINTER(SeaMlp2Group), C.c_int, C.c_float, C.c_int, _vp]
     L.sea_mlp_block.restype = C.c_int
+    L.sea_adaln_qkv.argtypes = [C.POINTER(SeaAdalnQkv), C.c_int, C.POINTER(SeaQkvCommon), C.POINTER(SeaGemmGroup), C.c_int, C.c_float, C.c_int, _vp]
+    L.sea_adaln_qkv.restype = C.c_int
     L.sea_run_list.argtypes = [C.POINTER(SeaLaunchRec), C.c_int, _vp]
     L.sea_run_list.restype = C.c_int
     L.sea_run_list_steps.argtypes = [C.POINTER(SeaLaunchRec), C.c_int, C.POINTER(SeaStepPatch), C.c_int, C.c_int, C.c_int, _vp]
@@ -311,7 +321,7 @@ def lib() -> C.CDLL:
 
 ABI_STRUCTS = (SeaGemmGroup, SeaQkvGroup, SeaQkvCommon, SeaAttnProblem, SeaAttnParams, SeaNormGroup, SeaSiluGroup,
                SeaIbParams, SeaWgradGroup, SeaNormBwdGroup, SeaSiluBwdGroup, SeaIbBwdParams, SeaAttnBwdProblem, SeaAttnBwdParams,
-               SeaDropout, SeaLaunchRec, SeaGemmNormGroup, SeaExchangeTail, SeaMlpGroup, SeaMlp2Group, SeaKvNorm, SeaKvField, SeaKvPair, SeaKvLayer, SeaKvGlobal, SeaStepPatch, SeaRowChain, SeaAdalnGroup)
+               SeaDropout, SeaLaunchRec, SeaGemmNormGroup, SeaExchangeTail, SeaMlpGroup, SeaMlp2Group, SeaKvNorm, SeaKvField, SeaKvPair, SeaKvLayer, SeaKvGlobal, SeaStepPatch, SeaRowChain, SeaAdalnGroup, SeaAdalnQkv)
 
 EXPORTED_SYMBOLS = (
     "sea_abi_version", "sea_last_error", "sea_struct_sizes", "sea_device_info", "sea_gemm_grouped", "sea_qkv_rope_grouped",
@@ -319,7 +329,7 @@ EXPORTED_SYMBOLS = (
     "sea_mse_fwd_bwd", "sea_relative_mse", "sea_adamw_flat",
     "sea_wgrad_grouped", "sea_transpose_weights", "sea_rownorm_bwd", "sea_silu_outer_bwd", "sea_ib_bwd",
     "sea_attention_bwd", "sea_dropout_mask", "sea_run_list", "sea_run_list_steps", "sea_unpatchify", "sea_gemm_rownorm", "sea_exchange_tail", "sea_patchify", "sea_silu_outer_ib", "sea_mlp_fc1_ln_gelu", "sea_mlp_fc2_proj_norm", "sea_kv_rollout", "sea_kv_arena_words", "sea_kv_debug_stamps",
-    "sea_gemm_fewrows", "sea_qkv_rope_fewrows", "sea_row_chain", "sea_row_chain_riders", "sea_gemm_adaln", "sea_mlp_block",
+    "sea_gemm_fewrows", "sea_qkv_rope_fewrows", "sea_row_chain", "sea_row_chain_riders", "sea_gemm_adaln", "sea_mlp_block", "sea_adaln_qkv",
 )
 
 

@@ -28,33 +28,6 @@
 // (a chain launch at one trajectory is 127-192 workgroups on 256 CUs).  Two kinds: 128 x 128 tiles of plain grouped GEMMs (cond_mlp.2 of the AdaLN modules the
 // field MLP and the final norm read, models/base_blocks.py:339,344: their operand, silu(cond_mlp.0), comes from the silu launch in front) and rows of the
 // information-bottleneck MLP (models/temporal.py:111-116) stored for the pass that adds them.  grid.y = n_groups is the rider row.
-#define SEA_CHAIN_MAX_RIDERS 8
-struct ChainRiderPod {
-    const void* A;
-    const void* W;
-    const float* bias;
-    void* Cact;
-    int lda, ldw, ldcact, M, N, K, tile_start, pad_;
-};
-// what gemm_tile_body reads of a SeaGemmGroup, for a rider: A, W, bias, activation-dtype output — everything else a compile-time constant
-struct ChainRiderGroup {
-    static constexpr int64_t a_seg_stride = 0;
-    static constexpr int n_seg = 1, act = 0, ldr = 0, ldc32 = 0, ldz = 0;
-    static constexpr float bias_scale = 1.0f;
-    static constexpr const float* R = nullptr;
-    static constexpr float* C32 = nullptr;
-    static constexpr void* Z = nullptr;
-    static constexpr SeaDropout drop = {0u, 0u, 0, 0};
-    static constexpr const float* silu_c = nullptr;
-    static constexpr const float* silu_w1 = nullptr;
-    static constexpr const float* silu_b1 = nullptr;
-    const void* A;
-    const void* W;
-    const float* bias;
-    void* Cact;
-    int lda, ldw, ldcact, M, N, K;
-};
-
 struct ChainLaunch {
     SeaRowChain p[SEA_CHAIN_MAX_GROUPS];   // grid.y = group (field)
     SeaQkvCommon c;

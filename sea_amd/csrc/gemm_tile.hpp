@@ -167,3 +167,33 @@ __device__ __forceinline__ void gemm_tile_body(const GT& G, int tm, int tn, char
     }
 }
 
+// ---------------------------------------------------------------------------------------------- rider tiles
+// A plain bf16 group (A, W, bias, activation-dtype output) as other kernels carry it beside their own work (chain.hip, adaln_qkv.hip): tiles of later launches'
+// GEMMs that depend on nothing the carrying launch computes, run by extra workgroups on the CUs it leaves idle.
+#define SEA_CHAIN_MAX_RIDERS 8
+struct ChainRiderPod {
+    const void* A;
+    const void* W;
+    const float* bias;
+    void* Cact;
+    int lda, ldw, ldcact, M, N, K, tile_start, pad_;
+};
+// what gemm_tile_body reads of a SeaGemmGroup, for a rider: A, W, bias, activation-dtype output — everything else a compile-time constant
+struct ChainRiderGroup {
+    static constexpr int64_t a_seg_stride = 0;
+    static constexpr int n_seg = 1, act = 0, ldr = 0, ldc32 = 0, ldz = 0;
+    static constexpr float bias_scale = 1.0f;
+    static constexpr const float* R = nullptr;
+    static constexpr float* C32 = nullptr;
+    static constexpr void* Z = nullptr;
+    static constexpr SeaDropout drop = {0u, 0u, 0, 0};
+    static constexpr const float* silu_c = nullptr;
+    static constexpr const float* silu_w1 = nullptr;
+    static constexpr const float* silu_b1 = nullptr;
+    const void* A;
+    const void* W;
+    const float* bias;
+    void* Cact;
+    int lda, ldw, ldcact, M, N, K;
+};
+

@@ -569,10 +569,17 @@ class Plan:
             # front; cond_mlp.2 of every other module as rider tiles of the chain launches
             front = first + [(pre_, d) for pre_, d in rest if "ln_cross." in pre_]
             later = [(pre_, d) for pre_, d in rest if (pre_, d) not in front]
+            # The front of the block as ONE launch (sea_adaln_qkv, round 4): the condition MLP of AdaLN_0 with its hidden rows generated in the launch, AdaLN_0 and the
+            # self-attention's q / k / v + rotary epilogue — no hidden rows, no modulation matrix and no normalised rows of these modules in memory, no QKV launch;
+            # cond_mlp.2 of ln_cross rides on the CUs it leaves idle.  SEA_PLAN=front=0 keeps silu + sea_gemm_adaln + QKV.
+            self._front_chain = (_switches.plan("front", "1") != "0" and _switches.plan("adaln_gemm", "1") != "0" and ops.adaln_qkv_supported(self.dt, E, self.H)
+                                 and F <= N.MAX_AQKV_GROUPS and not self.concat)
             silu_groups, hids = [], {}
             for pre_, d in front + later:
-                hids[pre_] = self._buf(M, 2 * d)
                 mods[pre_] = self._buf(M, 2 * d)
+                if self._front_chain and (pre_, d) in first:
+                    continue   # generated inside sea_adaln_qkv
+                hids[pre_] = self._buf(M, 2 * d)
                 silu_groups.append((P.f32_vec(pre_ + "cond_mlp.0.weight", 2 * d), P.f32_vec(pre_ + "cond_mlp.0.bias"), hids[pre_]))
             for s_ in range(0, len(silu_groups), N.MAX_SILU_GROUPS):
                 chunk = silu_groups[s_:s_ + N.MAX_SILU_GROUPS]
@@ -593,7 +600,7 @@ class Plan:
             # cond_mlp.2 of the front modules: AdaLN_0's as the GEMM whose epilogue IS the normalisation (sea_gemm_adaln: no modulation matrix, no norm launch),
             # ln_cross's as plain groups of the same launch — emitted by _build where the AdaLN_0 launch used to be.  SEA_PLAN=adaln_gemm=0 keeps GEMM + norm launch.
             if _switches.plan("adaln_gemm", "1") != "0":
-                self._adaln_front = {pre_: (hids[pre_], P.act(pre_ + "cond_mlp.2.weight"), P.f32_vec(pre_ + "cond_mlp.2.bias")) for pre_, _ in front}
+                self._adaln_front = {pre_: (hids.get(pre_), P.act(pre_ + "cond_mlp.2.weight"), P.f32_vec(pre_ + "cond_mlp.2.bias")) for pre_, _ in front}
             else:
                 self._adaln_front = None
                 self._gemm([dict(A=hids[pre_], W=P.act(pre_ + "cond_mlp.2.weight"), bias=P.f32_vec(pre_ + "cond_mlp.2.bias"), Cact=mods[pre_]) for pre_, _ in front], "adaln.cond_gemm.front")
@@ -803,7 +810,25 @@ class Plan:
                                     col0=0, Q=Qs[i], K=Ks[l][i], Vt=Vs[l][i]) for i in range(F)], rope_s, hd_s, "self.qkv_rope", pre=groups)
             else:
                 af = getattr(self, "_adaln_front", None) if l == 0 else None
-                if af:
+                if af and getattr(self, "_front_chain", False):
+                    arr = (N.SeaAdalnQkv * F)()
+                    for g_, i in zip(arr, range(F)):
+                        mp = f"{pre}ln.exp.{i}.0."
+                        ops.fill_adaln_qkv(g_, X=xr[i], cond=None, w1=P.f32_vec(mp + "cond_mlp.0.weight", 2 * E), b1=P.f32_vec(mp + "cond_mlp.0.bias"), W2c=af[mp][1], b2c=af[mp][2],
+                                           gamma=P.f32_vec(mp + "weight"), beta=P.f32_vec(mp + "bias"), Wqkv=P.act(f"{pre}attn.self.{i}.q.weight", 3 * E),
+                                           bqkv=P.f32_vec(f"{pre}attn.self.{i}.q.bias", 3 * E), Q=Qs[i], K=Ks[l][i], Vt=Vs[l][i], ldx=(FE if first else None))
+                        g_.M = M
+                        self._c_patches.append((g_, "cond"))
+                        if first:
+                            self._x_patches.append((g_, "X", i * Eo * 4))
+                    rg = [(key, v) for key, v in af.items() if "ln_cross." in key]
+                    rarr = (N.SeaGemmGroup * max(len(rg), 1))()
+                    for g_, (key, (hid_, W_, b_)) in zip(rarr, rg):
+                        _fill_gemm(g_, A=hid_, W=W_, bias=b_, Cact=mods[key])
+                    common = N.SeaQkvCommon(rope_s.data_ptr(), self.H, hd_s, self.T, self.pos0, self.cap, ops.q_scale(hd_s))
+                    self._pos_structs.append(common)
+                    self._cur.append(self._rec(L.sea_adaln_qkv, [arr, F, C.byref(common), (rarr if rg else None), len(rg), 1e-5, self.code], "self.cond_adaln0_qkv_rope", (arr, common, rarr)))
+                elif af:
                     ag = []
                     for i in range(F):
                         hid_, W_, b_ = af[f"{pre}ln.exp.{i}.0."]
@@ -817,8 +842,9 @@ class Plan:
                     self._adaln(ag, "self.cond_adaln0")
                 else:
                     self._norm(groups, E, "self.adaln0")
-                self._qkv([dict(A=n_e[i], W=P.act(f"{pre}attn.self.{i}.q.weight", 3 * E), bias=P.f32_vec(f"{pre}attn.self.{i}.q.bias", 3 * E),
-                                col0=0, Q=Qs[i], K=Ks[l][i], Vt=Vs[l][i]) for i in range(F)], rope_s, hd_s, "self.qkv_rope")
+                if not (af and getattr(self, "_front_chain", False)):
+                    self._qkv([dict(A=n_e[i], W=P.act(f"{pre}attn.self.{i}.q.weight", 3 * E), bias=P.f32_vec(f"{pre}attn.self.{i}.q.bias", 3 * E),
+                                    col0=0, Q=Qs[i], K=Ks[l][i], Vt=Vs[l][i]) for i in range(F)], rope_s, hd_s, "self.qkv_rope")
             self._attn([dict(Q=Qs[i], K=Ks[l][i], Vt=Vs[l][i], O=att_e[i]) for i in range(F)], hd_s, E, "self.attention")
             groups = []
             for i in range(F):
@@ -1352,6 +1378,9 @@ class Plan:
                 c.op, c.p0, c.n, c.f0, c.dtype = N.OP_MLP1, addr(a[0]), a[1], a[2], a[3]
             elif r.fn is L.sea_mlp_fc2_proj_norm:
                 c.op, c.p0, c.n, c.f0, c.dtype = N.OP_MLP2, addr(a[0]), a[1], a[2], a[3]
+            elif r.fn is L.sea_adaln_qkv:
+                c.op, c.p0, c.n, c.p1, c.f0, c.dtype = N.OP_AQKV, addr(a[0]), a[1], addr(r.keep[1]), a[5], a[6]
+                c.l0, c.i0 = (addr(a[3]) if a[3] is not None else 0), a[4]
             elif r.fn is L.sea_mlp_block:
                 c.op, c.p0, c.p1, c.n, c.f0, c.dtype = N.OP_MLPB, addr(a[0]), addr(a[1]), a[2], a[3], a[4]
             elif r.fn is L.sea_exchange_tail:

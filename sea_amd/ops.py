@@ -316,6 +316,37 @@ def gemm_adaln(groups: Sequence[Dict], eps: float = 1e-5, dtype: torch.dtype = t
     N.check(N.lib().sea_gemm_adaln(arr, len(groups), eps, N.dtype_code(dtype), N.stream_ptr()), "sea_gemm_adaln")
 
 
+def adaln_qkv_supported(dtype: torch.dtype, E: int, H: int) -> bool:
+    """Shapes sea_adaln_qkv instantiates (include/sea_hip.h): bf16, E = 256, head dim 16 or 32."""
+    return dtype == torch.bfloat16 and E == 256 and H > 0 and E % H == 0 and E // H in (16, 32)
+
+
+def fill_adaln_qkv(g: N.SeaAdalnQkv, X, cond, w1, b1, W2c, b2c, gamma, beta, Wqkv, bqkv, Q, K, Vt, ldx=None) -> None:
+    """One group of sea_adaln_qkv: X f32 [M, E] (row stride ldx), cond f32 [M], cond_mlp.0 (w1, b1 f32 [2E]), cond_mlp.2 (W2c act [2E, 2E], b2c), AdaLN_0's gamma / beta,
+    [Wq; Wk; Wv] act [3E, E] + bias, the attention operands Q [B,H,T,hd] / K [B,H,cap,hd] / Vt [B,H,hd,cap]."""
+    g.X, g.ldx, g.cond = X.data_ptr(), (ldx if ldx is not None else X.stride(0)), N.ptr(cond)
+    g.w1, g.b1, g.W2c, g.ldw2c, g.b2c = w1.data_ptr(), b1.data_ptr(), W2c.data_ptr(), W2c.stride(0), N.ptr(b2c)
+    g.gamma, g.beta, g.Wqkv, g.ldw, g.bqkv = gamma.data_ptr(), N.ptr(beta), Wqkv.data_ptr(), Wqkv.stride(0), N.ptr(bqkv)
+    g.Q, g.K, g.Vt = Q.data_ptr(), K.data_ptr(), Vt.data_ptr()
+    g.M, g.E = X.shape[0], Wqkv.shape[1]
+
+
+def adaln_qkv(groups: Sequence[Dict], rope: torch.Tensor, H: int, hd: int, T: int, pos0: int, cap: int, q_scale: float, riders: Sequence[Dict] = (), eps: float = 1e-5,
+              dtype: torch.dtype = torch.bfloat16) -> None:
+    """sea_adaln_qkv: the front of a block in one launch (dict keys: the arguments of fill_adaln_qkv); `riders`: plain GEMM groups (A, W, bias, Cact) as sea_gemm_grouped's."""
+    arr = (N.SeaAdalnQkv * len(groups))()
+    for g, d in zip(arr, groups):
+        fill_adaln_qkv(g, **d)
+    c = N.SeaQkvCommon()
+    c.rope, c.H, c.hd, c.T, c.pos0, c.cap, c.q_scale = rope.data_ptr(), H, hd, T, pos0, cap, q_scale
+    rarr = None
+    if riders:
+        rarr = (N.SeaGemmGroup * len(riders))()
+        for g, d in zip(rarr, riders):
+            fill_gemm_group(g, **d)
+    N.check(N.lib().sea_adaln_qkv(arr, len(groups), C.byref(c), rarr, len(riders), eps, N.dtype_code(dtype), N.stream_ptr()), "sea_adaln_qkv")
+
+
 def row_chain_supported(dtype: torch.dtype, D: int, E: int, n_seg: int, hd: int) -> bool:
     """Shapes sea_row_chain instantiates (include/sea_hip.h): bf16, (D, E) in {(128, 256), (64, 128)}, n_seg * D <= E, cross head dim 16 or 32."""
     return dtype == torch.bfloat16 and (D, E) in ((128, 256), (64, 128)) and 0 <= n_seg and n_seg * D <= E and hd in (16, 32)

@@ -115,6 +115,19 @@ def _extents(st, esz: int) -> Iterable[Tuple[str, int, int]]:
             yield "Yact", st.Yact, ((st.M - 1) * st.ldyact + (st.d if st.X else 2 * st.d)) * esz
         if st.Y32:
             yield "Y32", st.Y32, ((st.M - 1) * st.ldy32 + st.d) * f32
+    elif isinstance(st, N.SeaAdalnQkv):
+        E = st.E
+        yield "X", st.X, ((st.M - 1) * st.ldx + E) * f32
+        yield "cond", st.cond, st.M * f32
+        yield "w1", st.w1, 2 * E * f32
+        yield "b1", st.b1, 2 * E * f32
+        yield "W2c", st.W2c, ((2 * E - 1) * st.ldw2c + 2 * E) * esz
+        if st.b2c:
+            yield "b2c", st.b2c, 2 * E * f32
+        yield "gamma", st.gamma, E * f32
+        yield "Wqkv", st.Wqkv, ((3 * E - 1) * st.ldw + E) * esz
+        if st.bqkv:
+            yield "bqkv", st.bqkv, 3 * E * f32
     elif isinstance(st, N.SeaRowChain):
         K2 = st.D if st.n_seg > 0 else st.E
         for s_ in range(st.n_seg):

@@ -821,6 +821,70 @@ def test_mlp_fc2_proj_norm_matches_three_launch_form(E, S, M, norm):
         assert rel(y32, y2) < 2e-3
 
 
+@pytest.mark.parametrize("B,T,H,pos0,cap", [(1, 2024, 8, 0, 2024), (3, 70, 8, 0, 72), (2, 45, 16, 8, 64), (1, 33, 8, 3, 40)])
+def test_adaln_qkv_matches_the_three_launches(B, T, H, pos0, cap):
+    """sea_adaln_qkv (the front of a block in one launch: condition MLP with generated hidden rows, AdaLN_0, q / k / v + rotary epilogue) against
+    sea_silu_outer + sea_gemm_adaln + sea_qkv_rope_grouped on the same operands and against the fp32 formulas (models/base_blocks.py:337-350, 176-190, 300-324);
+    three fields per launch, X read through the caller's row stride, two rider groups (plain GEMMs of a later launch) beside them; rows that cross trajectories,
+    an unaligned cache position (element stores of V^T) and both head dims."""
+    from sea_amd import ops
+
+    dt = torch.bfloat16
+    E, M = 256, B * T
+    hd = E // H
+    table = rope_table(hd, pos0 + T)
+    cond = torch.rand(M, device=dev())
+    xw = rnd(M, 3 * E, seed=2000)
+    groups, refs, keep = [], [], []
+    for i in range(3):
+        w1, b1 = rnd(2 * E, seed=2010 + i), rnd(2 * E, seed=2020 + i)
+        W2c, b2c = rnd(2 * E, 2 * E, dtype=dt, scale=(2 * E) ** -0.5, seed=2030 + i), 0.3 * rnd(2 * E, seed=2040 + i)
+        gamma, beta = 1 + 0.1 * rnd(E, seed=2050 + i), 0.1 * rnd(E, seed=2060 + i)
+        Wqkv, bqkv = rnd(3 * E, E, dtype=dt, scale=E ** -0.5, seed=2070 + i), rnd(3 * E, seed=2080 + i)
+        x = xw[:, i * E:(i + 1) * E]
+        Q = torch.zeros(B, H, T, hd, device=dev(), dtype=dt)
+        K = torch.zeros(B, H, cap, hd, device=dev(), dtype=dt)
+        Vt = torch.zeros(B, H, hd, cap, device=dev(), dtype=dt)
+        groups.append(dict(X=x, cond=cond, w1=w1, b1=b1, W2c=W2c, b2c=b2c, gamma=gamma, beta=beta, Wqkv=Wqkv, bqkv=bqkv, Q=Q, K=K, Vt=Vt))
+        # the three launches
+        hid = torch.empty(M, 2 * E, device=dev(), dtype=dt)
+        ops.silu_outer([dict(w1=w1, b1=b1, Hid=hid)], cond, M, dt)
+        n_e = torch.empty(M, E, device=dev(), dtype=dt)
+        ops.gemm_adaln([dict(A=hid, W=W2c, bias=b2c, X=x, gamma=gamma, beta=beta, Yact=n_e)])
+        Q2, K2, Vt2 = torch.zeros_like(Q), torch.zeros_like(K), torch.zeros_like(Vt)
+        ops.qkv_rope_grouped([dict(A=n_e, W=Wqkv, bias=bqkv, col0=0, Q=Q2, K=K2, Vt=Vt2)], table, H, hd, T, pos0, cap, ops.q_scale(hd), dt)
+        keep.append((Q, K, Vt, Q2, K2, Vt2))
+        # fp32 formula on the bf16 operands (hidden rows, modulation and normalised rows rounded to bf16 where the launches round them)
+        h = torch.nn.functional.silu(cond[:, None] * w1 + b1).to(dt).float()
+        mod = (h @ W2c.float().t() + b2c).to(dt).float()
+        y = (torch.nn.functional.layer_norm(x, (E,), None, None, 1e-5) * (gamma + 1 + mod[:, :E]) + beta + mod[:, E:]).to(dt).float()
+        qkv = y @ Wqkv.float().t() + bqkv
+        q, k, v = (qkv[:, j * E:(j + 1) * E].view(B, T, H, hd) for j in range(3))
+        cos, sin = table[pos0:pos0 + T, :, 0], table[pos0:pos0 + T, :, 1]
+        refs.append((rope_ref(q, cos, sin) * ops.q_scale(hd), rope_ref(k, cos, sin), v))
+    rA, rW, rb = rnd(M, 512, dtype=dt, seed=2100), rnd(256, 512, dtype=dt, scale=0.05, seed=2101), rnd(256, seed=2102)
+    rC = [torch.full((M, 256), float("nan"), device=dev(), dtype=dt) for _ in range(2)]
+    ops.adaln_qkv(groups, table, H, hd, T, pos0, cap, ops.q_scale(hd), riders=[dict(A=rA, W=rW, bias=rb, Cact=rC[0]), dict(A=rA, W=rW, Cact=rC[1])])
+    for (Q, K, Vt, Q2, K2, Vt2), (q, k, v) in zip(keep, refs):
+        assert rel(Q.float(), Q2.float()) < 1e-2 and rel(K.float(), K2.float()) < 1e-2 and rel(Vt.float(), Vt2.float()) < 1e-2
+        assert rel(Q.float(), q.permute(0, 2, 1, 3)) < 1.5e-2
+        assert rel(K[:, :, pos0:pos0 + T].float(), k.permute(0, 2, 1, 3)) < 1.5e-2
+        assert rel(Vt[:, :, :, pos0:pos0 + T].float(), v.permute(0, 2, 3, 1)) < 1.5e-2
+        if cap > pos0 + T:   # nothing outside the written window is touched
+            assert float(K[:, :, pos0 + T:].abs().max()) == 0 and float(Vt[:, :, :, pos0 + T:].abs().max()) == 0
+        if pos0 > 0:
+            assert float(K[:, :, :pos0].abs().max()) == 0 and float(Vt[:, :, :, :pos0].abs().max()) == 0
+    ref_r = rA.float() @ rW.float().t()
+    assert rel(rC[0].float(), ref_r + rb) < 6e-3 and rel(rC[1].float(), ref_r) < 6e-3
+
+
+def test_adaln_qkv_refuses_other_shapes():
+    from sea_amd import ops
+
+    assert ops.adaln_qkv_supported(torch.bfloat16, 256, 8) and not ops.adaln_qkv_supported(torch.bfloat16, 128, 8) and not ops.adaln_qkv_supported(torch.float32, 256, 8)
+    assert not ops.adaln_qkv_supported(torch.bfloat16, 256, 4)   # head dim 64
+
+
 @pytest.mark.parametrize("E,S,M", [(256, 2048, 2024), (256, 2048, 33), (128, 1024, 1000), (256, 2048, 9000)])
 @pytest.mark.parametrize("prologue", [None, "adaln_add", "ln"])
 @pytest.mark.parametrize("norm", [None, "adaln"])

@@ -1,6 +1,5 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-O=gpurun_out/r05e; mkdir -p $O
-timeout -k 10 600 python -m pytest tests/test_ops_gpu.py tests/test_model_gpu.py -x -q -k "mlp_block or cfg2 or optional" > $O/test.log 2>&1; echo "rc=$?" >> $O/test.log; tail -3 $O/test.log
+O=gpurun_out/r05n; mkdir -p $O
+timeout -k 10 300 python -m pytest tests/test_ops_gpu.py -x -q -k "adaln_qkv" > $O/test.log 2>&1; echo "rc=$?" >> $O/test.log; tail -3 $O/test.log
 grep -q "rc=0" $O/test.log || exit 1
-for p in 4 0; do SEA_TUNE=blk_probe=$p timeout -k 10 120 python tools/mlp_probe.py 2>&1 | tail -1 | tee -a $O/mlp_probe.txt; done
-timeout -k 10 120 python tools/chain_probe.py replay 100 > $O/replay.txt 2>&1; echo "$(tail -1 $O/replay.txt | cut -c1-45)"
+AQKV_STAMPS=1 timeout -k 10 120 python tools/aqkv_probe.py 0 2>&1 | tail -14 | cut -c1-90 | tee -a $O/aqkv_probe.txt
