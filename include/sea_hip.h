@@ -615,9 +615,20 @@ typedef struct {
     void* Q;             /* act [B, H, T, hd] */
     void* K;             /* act [B, H, cap, hd], rows pos0 + t */
     void* Vt;            /* act [B, H, hd, cap], columns pos0 + t */
-    int32_t ldx, ldw2c, ldw, M, E, pad_;
+    int32_t ldx, ldw2c, ldw, M, E, N3;
+    /* optional third layer (W3 != NULL; N3 = 256): mod3 = silu(w13 * cond[m] + b13) . W3^T + b3 — the modulation of another AdaLN module of the same rows
+     * (ln_cross of the field, 2 D = 256 columns), stored for a later launch */
+    const float* w13;    /* f32 [N3] */
+    const float* b13;    /* f32 [N3] */
+    const void* W3;      /* act [N3, N3], row stride ldw3 */
+    const float* b3;     /* f32 [N3] or NULL */
+    void* mod3;          /* act [M, N3], row stride ldmod3 */
+    int32_t ldw3, ldmod3;
 } SeaAdalnQkv;
-int sea_adaln_qkv(const SeaAdalnQkv* groups, int n_groups, const SeaQkvCommon* common, const SeaGemmGroup* riders, int n_riders, float eps, int dtype, void* stream);
+/* silu / silu_c / silu_M, ib (both optional): row riders — hidden rows silu(w1 * silu_c[m] + b1) of up to 8 other modules (sea_silu_outer's groups) and the
+ * information-bottleneck rows (sea_silu_outer_ib's SeaIbParams), evaluated by extra workgroups for launches further down the step. */
+int sea_adaln_qkv(const SeaAdalnQkv* groups, int n_groups, const SeaQkvCommon* common, const SeaGemmGroup* riders, int n_riders, const SeaSiluGroup* silu, int n_silu,
+                  const float* silu_c, int silu_M, const SeaIbParams* ib, float eps, int dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * A ROW-LOCAL CHAIN of the state-exchange block in one launch (bf16 compute; a workgroup owns 16 or 32 rows from an attention launch's output to the
@@ -686,7 +697,8 @@ int sea_row_chain_riders(const SeaRowChain* params, int n_groups, const SeaQkvCo
  *     SEA_OP_QKV_FEW  p0 = SeaQkvGroup[n], p1 = SeaQkvCommon, l0 = (intptr) pre or 0, f0 = eps
  *     SEA_OP_ADALN    p0 = SeaAdalnGroup[n], f0 = eps
  *     SEA_OP_MLPB     p0 = SeaMlpGroup[n], p1 = SeaMlp2Group[n], f0 = eps
- *     SEA_OP_AQKV     p0 = SeaAdalnQkv[n], p1 = SeaQkvCommon, l0 = (intptr) SeaGemmGroup[i0] riders or 0, f0 = eps
+ *     SEA_OP_AQKV     p0 = SeaAdalnQkv[n], p1 = SeaQkvCommon, l0 = (intptr) SeaGemmGroup[i0] riders or 0, l1 = (intptr) SeaSiluGroup[i1] or 0, l2 = (intptr) silu_c, i2 = silu_M,
+ *                     l3 = (intptr) SeaIbParams or 0, f0 = eps
  *     SEA_OP_CHAIN    p0 = SeaRowChain[n], p1 = SeaQkvCommon or NULL, f0 = eps; riders (sea_row_chain_riders): l0 = (intptr) SeaGemmGroup[i0] or 0, i1 = tile0, i2 = n_tiles,
  *                     l1 = (intptr) SeaIbParams or 0
  * Returns 0, or the failing entry's error code with sea_last_error() set (entries before it have been launched).

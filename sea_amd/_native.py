@@ -162,11 +162,13 @@ class SeaAdalnGroup(C.Structure):
 
 
 MAX_AQKV_GROUPS = 4
+AQKV_MAX_SILU = 8
 
 
 class SeaAdalnQkv(C.Structure):
     _fields_ = [("X", _vp), ("cond", _vp), ("w1", _vp), ("b1", _vp), ("W2c", _vp), ("b2c", _vp), ("gamma", _vp), ("beta", _vp), ("Wqkv", _vp), ("bqkv", _vp),
-                ("Q", _vp), ("K", _vp), ("Vt", _vp), ("ldx", _i32), ("ldw2c", _i32), ("ldw", _i32), ("M", _i32), ("E", _i32), ("pad_", _i32)]
+                ("Q", _vp), ("K", _vp), ("Vt", _vp), ("ldx", _i32), ("ldw2c", _i32), ("ldw", _i32), ("M", _i32), ("E", _i32), ("N3", _i32),
+                ("w13", _vp), ("b13", _vp), ("W3", _vp), ("b3", _vp), ("mod3", _vp), ("ldw3", _i32), ("ldmod3", _i32)]
 
 
 MAX_MLP_GROUPS = 8
@@ -291,7 +293,8 @@ def lib() -> C.CDLL:
     L.sea_mlp_fc2_proj_norm.restype = C.c_int
     L.sea_mlp_block.argtypes = [C.POINTER(SeaMlpGroup), C.POINTER(SeaMlp2Group), C.c_int, C.c_float, C.c_int, _vp]
     L.sea_mlp_block.restype = C.c_int
-    L.sea_adaln_qkv.argtypes = [C.POINTER(SeaAdalnQkv), C.c_int, C.POINTER(SeaQkvCommon), C.POINTER(SeaGemmGroup), C.c_int, C.c_float, C.c_int, _vp]
+    L.sea_adaln_qkv.argtypes = [C.POINTER(SeaAdalnQkv), C.c_int, C.POINTER(SeaQkvCommon), C.POINTER(SeaGemmGroup), C.c_int, C.POINTER(SeaSiluGroup), C.c_int, _vp, C.c_int,
+                                C.POINTER(SeaIbParams), C.c_float, C.c_int, _vp]
     L.sea_adaln_qkv.restype = C.c_int
     L.sea_run_list.argtypes = [C.POINTER(SeaLaunchRec), C.c_int, _vp]
     L.sea_run_list.restype = C.c_int

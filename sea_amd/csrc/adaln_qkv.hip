@@ -16,7 +16,10 @@
 //     the attention layouts and the stores leave as whole rows (Q, K: 64 B of a (head, step) row per 4 lanes; V^T: 8 steps of a (head, dim) row per lane).
 // Riders: 128 x 128 tiles of plain GEMMs of later launches (cond_mlp.2 of ln_cross) run on the CUs this launch leaves idle, as in chain.hip.
 #include "gemm_tile.hpp"
+#include "ib_rows.hpp"
 #include <stdlib.h>
+
+#define SEA_AQKV_MAX_SILU 8
 
 struct AqkvLaunch {
     SeaAdalnQkv g[SEA_MAX_AQKV_GROUPS];
@@ -26,6 +29,12 @@ struct AqkvLaunch {
     SeaQkvCommon c;
     ChainRiderPod rg[SEA_CHAIN_MAX_RIDERS];
     int n_riders, rider_n;
+    // row riders: hidden rows silu(cond_mlp.0(c)) of other modules (64 rows per workgroup and group) and the information-bottleneck rows (64 per workgroup), for
+    // launches further down the step
+    SeaSiluGroup sg[SEA_AQKV_MAX_SILU];
+    int n_silu, silu_wgs, ib_wgs, M_r;
+    const float* cond_r;
+    SeaIbParams ib;
     unsigned long long* stamps;   // tuning aid (sea_aqkv_debug_stamps): 16 clock stamps (100 MHz) per workgroup, or NULL
     int probe;   // development: SEA_TUNE=aqkv_probe=n ends every workgroup after stage n (1 layer A, 2 the row pass, 3 layer B's loop); outputs are then not written
 };
@@ -66,23 +75,59 @@ __device__ __forceinline__ f32x4 aq_mma_first(const uint4& a, const uint4& b) {
 struct AqkvCfg {
     static constexpr int E = 256, KC = 2 * E, BM = 32, NW = 8;
     static constexpr int KTA = KC / 64, KTB = E / 64;               // K-tiles of the two layers
+    static constexpr int K3 = 256;                                  // optional third layer: [M, K3] generated rows x [K3, K3] (the ln_cross modulation at D = 128)
     static constexpr int HID_BYTES = KTA * BM * 128;                // 32 KiB: generated operand of layer A, K-tile major, swizzled; later the y tile (16 KiB) + rotary rows
     static constexpr int NE_OFF = 0, ROPE_OFF = KTB * BM * 128;     // y tile | (cos, sin) pairs of the workgroup's rows: hd / 2 pairs of 8 bytes per row at a pitch of + 16 bytes
     static constexpr int OUT_PAD = 16;                              // bytes added to a staged (head, row) of hd values: the accumulator layout's 16 rows then fall into different banks
     static constexpr int SLOT = 16 * 128, RSA = 8, RSB = 6;         // ring slots of a wave: layer A 8, layer B 6 (the last 4 KiB of its 16 hold its part of the modulation)
     static constexpr int RING_OFF = HID_BYTES, WAVE_RING = RSA * SLOT;
     static constexpr int MOD_OFF = RSB * SLOT;                      // inside a wave's ring region: 32 rows x (32 scale | 32 shift) bf16
-    static constexpr int OUT_OFF = RING_OFF;                        // epilogue of layer B: [3][H][32 rows][hd] bf16 = 48 KiB over the drained rings
+    static constexpr int OUT_OFF = RING_OFF;                        // epilogue of layer B: [3][H][32 rows][hd] bf16 = 48 KiB (+ padding) over the drained rings
+    static constexpr int OUT3_OFF = OUT_OFF + 3 * BM * (E * 2 + 16 * 16);   // ... and layer C's [32][K3] behind it
     static constexpr int BYTES = RING_OFF + NW * WAVE_RING;         // 160 KiB
-    static_assert(BYTES <= 160 * 1024 && ROPE_OFF + BM * (16 * 8 + 16) <= HID_BYTES && MOD_OFF + BM * 128 <= WAVE_RING && OUT_OFF + 3 * BM * (E * 2 + 16 * OUT_PAD) <= BYTES, "LDS plan of sea_adaln_qkv");
+    static_assert(BYTES <= 160 * 1024 && ROPE_OFF + BM * (16 * 8 + 16) <= HID_BYTES && MOD_OFF + BM * 128 <= WAVE_RING && OUT3_OFF + BM * (K3 * 2 + 16) <= BYTES && OUT_PAD == 16, "LDS plan of sea_adaln_qkv");
 };
 
+// HAS3: every group of the launch carries the optional third layer
+template <bool HAS3>
 __global__ __launch_bounds__(512) void adaln_qkv_kernel(const AqkvLaunch L) {
     using T = __bf16;
     using C = AqkvCfg;
     constexpr int E = C::E, KC = C::KC, BM = C::BM, NW = C::NW, KTA = C::KTA, KTB = C::KTB;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int total = L.tile_start[L.n_groups];
+    if ((int)blockIdx.x >= total + L.rider_n) {   // ---- row riders (block-uniform)
+        const int x = (int)blockIdx.x - total - L.rider_n;
+        const int lane_ = threadIdx.x & 63, wave_ = threadIdx.x >> 6;
+        if (x < L.silu_wgs) {   // 64 rows of one group: a wave takes 8 of them with its slice of w1 / b1 in registers (rowops.hip: silu_outer_kernel)
+            const int per_g = (L.M_r + 63) >> 6;
+            const int gy = x / per_g;
+            const SeaSiluGroup& S = L.sg[gy];
+            const int row0 = (x - gy * per_g) * 64 + wave_ * 8;
+            if (row0 >= L.M_r) return;
+            float cv[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) cv[i] = L.cond_r[row0 + i < L.M_r ? row0 + i : L.M_r - 1];
+            T* out = static_cast<T*>(S.Hid) + (int64_t)row0 * S.ld;
+            for (int k = lane_ * 4; k < S.K2; k += 256) {
+                float w[4], bb[4];
+                load4(S.w1 + k, w);
+                load4(S.b1 + k, bb);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    if (row0 + i < L.M_r)
+                        store4(out + (int64_t)i * S.ld + k, silu_f(w[0] * cv[i] + bb[0]), silu_f(w[1] * cv[i] + bb[1]), silu_f(w[2] * cv[i] + bb[2]), silu_f(w[3] * cv[i] + bb[3]));
+                }
+            }
+        } else {                // 64 information-bottleneck rows: a wave per row, 8 rows per wave
+            const int row0 = (x - L.silu_wgs) * 64 + wave_ * 8;
+            for (int i = 0; i < 8; ++i) {
+                const int row = row0 + i;
+                if (row < L.ib.M) ib_store_row(L.ib, L.cond_r[row], row, lane_);
+            }
+        }
+        return;
+    }
     if ((int)blockIdx.x >= total) {   // ---- a rider tile (block-uniform): four waves run it, the other four leave
         if (threadIdx.x >= 256) return;
         const int tile = (int)blockIdx.x - total;
@@ -135,6 +180,17 @@ __global__ __launch_bounds__(512) void adaln_qkv_kernel(const AqkvLaunch L) {
         glds16_aq(ub, wb_lane, dst);
         glds16_aq(ub + (int64_t)8 * G.ldw, wb_lane, dst + 1024u);
     };
+    // optional layer C (W3 != NULL): slots behind layer B's in the same ring, k3 = (kt, j): K-tile kt of the 16 columns 32 w + 16 j .. of the third matrix
+    constexpr bool has3 = HAS3;
+    const T* W3 = static_cast<const T*>(G.W3);
+    const unsigned wc_lane = (unsigned)((rl * G.ldw3 + chunk * 8) * 2);
+    auto slot_c = [&](int k) {           // k: position in the ring sequence (layer B's 24 slots first)
+        const int k3 = k - 6 * KTB, kt = k3 >> 1, j = k3 & 1;
+        const T* ub = W3 + (int64_t)(32 * wave + 16 * j) * G.ldw3 + kt * 64;   // uniform
+        const unsigned dst = ring + (unsigned)((k % C::RSB) * C::SLOT);
+        glds16_aq(ub, wc_lane, dst);
+        glds16_aq(ub + (int64_t)8 * G.ldw3, wc_lane, dst + 1024u);
+    };
 #pragma unroll
     for (int k = 0; k < C::RSA - 1; ++k) slot_a(k);
     // ---- the row pass's own operands (thread: row prow, 16 columns from pc0), requested behind the first weight slots
@@ -174,6 +230,31 @@ __global__ __launch_bounds__(512) void adaln_qkv_kernel(const AqkvLaunch L) {
         for (int q = 0; q < 4; ++q) b2v[j][q] = 0.f;
         if (G.b2c != nullptr) load4(G.b2c + (j < 2 ? 32 * wave + 16 * j : E + 32 * wave + 16 * (j - 2)) + 4 * g, b2v[j]);
     }
+    // layer C: this thread's 8 contraction indices (chunk tid & 31 of the 32) of w13 / b13, the condition of its two rows, the bias of this wave's 32 columns
+    float w3v[8], b3v[8], c3v[2], b3o[2][4];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) w3v[e] = b3v[e] = 0.f;
+    c3v[0] = c3v[1] = 0.f;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) b3o[j][q] = 0.f;
+    if (has3) {
+        const int kc8 = tid & 31;
+        load4(G.w13 + kc8 * 8, *reinterpret_cast<float(*)[4]>(w3v));
+        load4(G.w13 + kc8 * 8 + 4, *reinterpret_cast<float(*)[4]>(w3v + 4));
+        load4(G.b13 + kc8 * 8, *reinterpret_cast<float(*)[4]>(b3v));
+        load4(G.b13 + kc8 * 8 + 4, *reinterpret_cast<float(*)[4]>(b3v + 4));
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int m = m0 + (tid >> 5) + 16 * i;
+            c3v[i] = G.cond[m < M ? m : M - 1];
+        }
+        if (G.b3 != nullptr) {
+            load4(G.b3 + 32 * wave + 4 * g, b3o[0]);
+            load4(G.b3 + 32 * wave + 16 + 4 * g, b3o[1]);
+        }
+    }
     // ---- the hidden rows of the condition MLP, generated: thread = 8 contraction indices (chunk kc8 of the 64) of the 4 rows 4 wave .. 4 wave + 3
     {
         const int kc8 = lane;                                  // 64 chunks of 8 = KC
@@ -203,7 +284,11 @@ __global__ __launch_bounds__(512) void adaln_qkv_kernel(const AqkvLaunch L) {
     for (int j = 0; j < 6; ++j) asm volatile("" ::"v"(bqv[j][0]), "v"(bqv[j][1]), "v"(bqv[j][2]), "v"(bqv[j][3]));
 #pragma unroll
     for (int j = 0; j < 4; ++j) asm volatile("" ::"v"(b2v[j][0]), "v"(b2v[j][1]), "v"(b2v[j][2]), "v"(b2v[j][3]));
-    asm volatile("" ::"v"(cs_row.x), "v"(cs_row.y));
+    asm volatile("" ::"v"(cs_row.x), "v"(cs_row.y), "v"(c3v[0]), "v"(c3v[1]));
+#pragma unroll
+    for (int e = 0; e < 8; ++e) asm volatile("" ::"v"(w3v[e]), "v"(b3v[e]));
+#pragma unroll
+    for (int j = 0; j < 2; ++j) asm volatile("" ::"v"(b3o[j][0]), "v"(b3o[j][1]), "v"(b3o[j][2]), "v"(b3o[j][3]));
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();   // the hidden rows are complete
     stamp();   // 1: hidden rows generated
@@ -308,15 +393,60 @@ __global__ __launch_bounds__(512) void adaln_qkv_kernel(const AqkvLaunch L) {
         return;
     }
     stamp();   // 4: row pass
-    // ================================================================================================ layer B: 96 columns of [q | k | v] per wave
-    f32x4 acc2[2][6];
+    // layer C's operand: the hidden rows silu(w13 * c + b13) of the third matrix, K-tile kt into the spare 4 KiB of wave kt's ring region (the modulation parts
+    // the row pass has just read); consumed behind layer B's slots, after the barrier in front of slot 6 KTB
+    if (has3) {
+        const int kc8 = tid & 31, kt = kc8 >> 3, ck = kc8 & 7;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = (tid >> 5) + 16 * i;
+            bf16x8 hv;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) hv[e] = (__bf16)silu_f(w3v[e] * c3v[i] + b3v[e]);
+            *reinterpret_cast<bf16x8*>(smem + C::RING_OFF + kt * C::WAVE_RING + C::MOD_OFF + row * 128 + ((ck ^ (row & 7)) << 4)) = hv;
+        }
+    }
+    // ================================================================================================ layer B: 96 columns of [q | k | v] per wave (+ layer C: 32 columns)
+    f32x4 acc2[2][6], acc3[2][2];
     {
         uint4 af[2][2];
+        constexpr int NTOT = 6 * KTB + (has3 ? 2 * (AqkvCfg::K3 / 64) : 0);
 #pragma unroll
-        for (int k = 0; k < 6 * KTB; ++k) {
+        for (int k = 0; k < NTOT; ++k) {
+            const int after_ = NTOT - 1 - k < C::RSB - 2 ? NTOT - 1 - k : C::RSB - 2;
+            if (k >= 6 * KTB) {   // ---- a slot of layer C
+                const int k3 = k - 6 * KTB, kt = k3 >> 1, j = k3 & 1;
+                aq_wait_n(after_);
+                if (k3 == 0) __builtin_amdgcn_s_barrier();   // every wave's share of the generated rows is in LDS (their writes were retired by the wait above)
+                if (k + C::RSB - 1 < NTOT) slot_c(k + C::RSB - 1);
+                if (j == 0) {
+#pragma unroll
+                    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                        for (int kc = 0; kc < 2; ++kc)
+                            af[mb][kc] = *reinterpret_cast<const uint4*>(smem + C::RING_OFF + kt * C::WAVE_RING + C::MOD_OFF + (mb * 16 + r) * 128 + (((kc * 4 + g) ^ (r & 7)) << 4));
+                }
+                const char* sl = smem + C::RING_OFF + wave * C::WAVE_RING + (k % C::RSB) * C::SLOT + r * 128;
+#pragma unroll
+                for (int kc = 0; kc < 2; ++kc) {
+                    const uint4 w = *reinterpret_cast<const uint4*>(sl + (((kc * 4 + g) ^ (r & 7)) << 4));
+                    if (kt == 0 && kc == 0) {
+                        acc3[0][j] = aq_mma_first(w, af[0][0]);
+                        acc3[1][j] = aq_mma_first(w, af[1][0]);
+                    } else {
+                        mma16<T>(w, af[0][kc], acc3[0][j]);
+                        mma16<T>(w, af[1][kc], acc3[1][j]);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                continue;
+            }
             const int kt = k / 6, j = k - kt * 6;
-            aq_wait_n(6 * KTB - 1 - k < C::RSB - 2 ? 6 * KTB - 1 - k : C::RSB - 2);
-            if (k + C::RSB - 1 < 6 * KTB) slot_b(k + C::RSB - 1);
+            aq_wait_n(after_);
+            if (k + C::RSB - 1 < NTOT) {
+                if (k + C::RSB - 1 < 6 * KTB) slot_b(k + C::RSB - 1);
+                else slot_c(k + C::RSB - 1);
+            }
             if (j == 0) {
 #pragma unroll
                 for (int mb = 0; mb < 2; ++mb)
@@ -372,6 +502,14 @@ __global__ __launch_bounds__(512) void adaln_qkv_kernel(const AqkvLaunch L) {
                 store4(reinterpret_cast<T*>(smem + C::OUT_OFF + ((part * H + h) * BM + row) * (hd * 2 + C::OUT_PAD) + dd * 2), o[0], o[1], o[2], o[3]);
             }
         }
+    }
+    if (has3) {   // layer C's 32 columns of this wave, + bias, bf16, behind the staged q | k | v: [32 rows][K3 columns] at a pitch of + 16 bytes
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb)
+                store4(reinterpret_cast<T*>(smem + C::OUT3_OFF + (mb * 16 + r) * (C::K3 * 2 + 16) + (32 * wave + 16 * j + 4 * g) * 2), acc3[mb][j][0] + b3o[j][0], acc3[mb][j][1] + b3o[j][1],
+                       acc3[mb][j][2] + b3o[j][2], acc3[mb][j][3] + b3o[j][3]);
     }
     stamp();   // 7: staged (this wave)
     __syncthreads();
@@ -429,10 +567,19 @@ __global__ __launch_bounds__(512) void adaln_qkv_kernel(const AqkvLaunch L) {
             }
         }
     }
+    if (has3) {   // the third layer's rows: 32 pieces of 16 bytes per row
+        T* M3 = static_cast<T*>(G.mod3);
+        for (int id = tid; id < BM * (C::K3 / 8); id += 512) {
+            const int row = id >> 5, pc = id & 31;
+            const int m = m0 + row;
+            if (m < M) *reinterpret_cast<uint4*>(M3 + (int64_t)m * G.ldmod3 + pc * 8) = *reinterpret_cast<const uint4*>(smem + C::OUT3_OFF + row * (C::K3 * 2 + 16) + pc * 16);
+        }
+    }
     stamp();   // 10: V^T stored (issued)
 }
 
-extern "C" int sea_adaln_qkv(const SeaAdalnQkv* groups, int n_groups, const SeaQkvCommon* common, const SeaGemmGroup* riders, int n_riders, float eps, int dtype, void* stream) {
+extern "C" int sea_adaln_qkv(const SeaAdalnQkv* groups, int n_groups, const SeaQkvCommon* common, const SeaGemmGroup* riders, int n_riders, const SeaSiluGroup* silu, int n_silu,
+                             const float* silu_c, int silu_M, const SeaIbParams* ib, float eps, int dtype, void* stream) {
     SEA_REQUIRE(groups != nullptr && common != nullptr && n_groups >= 1 && n_groups <= SEA_MAX_AQKV_GROUPS, "sea_adaln_qkv: n_groups=%d out of range", n_groups);
     const int E = groups[0].E;
     if (dtype != SEA_BF16 || E != AqkvCfg::E || common->H * common->hd != E || (common->hd != 32 && common->hd != 16)) {
@@ -453,6 +600,11 @@ extern "C" int sea_adaln_qkv(const SeaAdalnQkv* groups, int n_groups, const SeaQ
                         sea_aligned16(G.Wqkv) && sea_aligned16(G.bqkv) && sea_aligned16(G.Q) && sea_aligned16(G.K) && sea_aligned16(G.Vt),
                     "sea_adaln_qkv[%d]: pointers must be 16-byte aligned", i);
         SEA_REQUIRE((int64_t)(G.M / common->T) * common->H * common->cap * common->hd < (1ll << 31), "sea_adaln_qkv[%d]: attention tensors must stay below 2^31 elements", i);
+        if (G.W3 != nullptr) {
+            SEA_REQUIRE(G.w13 && G.b13 && G.mod3 && G.N3 == AqkvCfg::K3 && G.ldw3 % 8 == 0 && G.ldw3 >= G.N3 && G.ldmod3 % 8 == 0 && G.ldmod3 >= G.N3 && sea_aligned16(G.w13) && sea_aligned16(G.b13) &&
+                            sea_aligned16(G.W3) && sea_aligned16(G.b3) && sea_aligned16(G.mod3),
+                        "sea_adaln_qkv[%d]: third layer: null / misaligned pointer, bad stride, or N3 = %d != 256", i, G.N3);
+        }
         L.g[i] = G;
         L.tile_start[i] = total;
         total += (G.M + 31) / 32;
@@ -477,14 +629,42 @@ extern "C" int sea_adaln_qkv(const SeaAdalnQkv* groups, int n_groups, const SeaQ
     }
     L.n_riders = n_riders;
     L.rider_n = rider_total;
+    SEA_REQUIRE(n_silu >= 0 && n_silu <= SEA_AQKV_MAX_SILU && (n_silu == 0 || (silu != nullptr && silu_c != nullptr && silu_M >= 1)), "sea_adaln_qkv: bad silu rider arguments (n_silu=%d)", n_silu);
+    // (the information-bottleneck rows are evaluated on silu_c too: SeaIbParams.c is not read)
+    for (int i = 0; i < n_silu; ++i) {
+        SEA_REQUIRE(silu[i].w1 && silu[i].b1 && silu[i].Hid && silu[i].K2 >= 4 && silu[i].K2 % 4 == 0 && silu[i].ld >= silu[i].K2 && silu[i].ld % 4 == 0 && sea_aligned16(silu[i].w1) &&
+                        sea_aligned16(silu[i].b1) && sea_aligned16(silu[i].Hid),
+                    "sea_adaln_qkv: silu rider %d: null / misaligned pointer or bad shape", i);
+        L.sg[i] = silu[i];
+    }
+    L.n_silu = n_silu;
+    L.cond_r = silu_c;
+    L.M_r = silu_M;
+    L.silu_wgs = n_silu * ((silu_M + 63) / 64);
+    if (ib != nullptr) {
+        SEA_REQUIRE(silu_c != nullptr && silu_M == ib->M && ib->X[0] && ib->w1 && ib->M >= 1 && ib->E >= 4 && ib->E % 4 == 0 && ib->ldx >= ib->E && ib->mode >= 0 && ib->mode <= 2 &&
+                        (ib->mode != 0 || (ib->b1 && ib->lnw && ib->lnb && ib->w2 && ib->b2 && ib->h >= 1 && ib->h <= 64)),
+                    "sea_adaln_qkv: bad info-bottleneck rider");
+        L.ib = *ib;
+        L.ib_wgs = (ib->M + 63) / 64;
+    }
     static const int probe = sea_tune("aqkv_probe", 0);
     L.probe = probe;
     L.stamps = g_aqkv_stamps;
     constexpr int rider_lds = GemmMainloop<__bf16, 128, 128>::DMA_LDS_BYTES;
     constexpr int lds = AqkvCfg::BYTES > rider_lds ? AqkvCfg::BYTES : rider_lds;
-    static const hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void*>(adaln_qkv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    (void)once;
-    adaln_qkv_kernel<<<dim3(total + rider_total), dim3(512), lds, static_cast<hipStream_t>(stream)>>>(L);
+    const bool has3 = groups[0].W3 != nullptr;
+    for (int i = 1; i < n_groups; ++i) SEA_REQUIRE((groups[i].W3 != nullptr) == has3, "sea_adaln_qkv[%d]: the third layer in every group of a launch or in none", i);
+    const dim3 grid(total + rider_total + L.silu_wgs + L.ib_wgs);
+    if (has3) {
+        static const hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void*>(adaln_qkv_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)once;
+        adaln_qkv_kernel<true><<<grid, dim3(512), lds, static_cast<hipStream_t>(stream)>>>(L);
+    } else {
+        static const hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void*>(adaln_qkv_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)once;
+        adaln_qkv_kernel<false><<<grid, dim3(512), lds, static_cast<hipStream_t>(stream)>>>(L);
+    }
     SEA_CHECK_LAUNCH("sea_adaln_qkv");
     return SEA_OK;
 }

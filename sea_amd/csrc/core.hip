@@ -64,7 +64,9 @@ extern "C" int sea_run_list(const SeaLaunchRec* recs, int n_recs, void* stream) 
                                                          R.i0, R.i1, R.i2, reinterpret_cast<const SeaIbParams*>(static_cast<intptr_t>(R.l1)), R.f0, R.dtype, stream); break;
             case SEA_OP_ADALN: rc = sea_gemm_adaln(static_cast<const SeaAdalnGroup*>(R.p0), R.n, R.f0, R.dtype, stream); break;
             case SEA_OP_MLPB: rc = sea_mlp_block(static_cast<const SeaMlpGroup*>(R.p0), static_cast<const SeaMlp2Group*>(R.p1), R.n, R.f0, R.dtype, stream); break;
-            case SEA_OP_AQKV: rc = sea_adaln_qkv(static_cast<const SeaAdalnQkv*>(R.p0), R.n, static_cast<const SeaQkvCommon*>(R.p1), reinterpret_cast<const SeaGemmGroup*>(static_cast<intptr_t>(R.l0)), R.i0, R.f0, R.dtype, stream); break;
+            case SEA_OP_AQKV: rc = sea_adaln_qkv(static_cast<const SeaAdalnQkv*>(R.p0), R.n, static_cast<const SeaQkvCommon*>(R.p1), reinterpret_cast<const SeaGemmGroup*>(static_cast<intptr_t>(R.l0)), R.i0,
+                                                 reinterpret_cast<const SeaSiluGroup*>(static_cast<intptr_t>(R.l1)), R.i1, reinterpret_cast<const float*>(static_cast<intptr_t>(R.l2)), R.i2,
+                                                 reinterpret_cast<const SeaIbParams*>(static_cast<intptr_t>(R.l3)), R.f0, R.dtype, stream); break;
             default: sea_set_error("sea_run_list[%d]: unknown op %d", i, R.op); return SEA_EINVAL;
         }
         if (rc != SEA_OK) return rc;   // sea_last_error() already names the entry point; the caller maps i back to its record

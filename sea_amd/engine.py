@@ -574,13 +574,30 @@ class Plan:
             # cond_mlp.2 of ln_cross rides on the CUs it leaves idle.  SEA_PLAN=front=0 keeps silu + sea_gemm_adaln + QKV.
             self._front_chain = (_switches.plan("front", "1") != "0" and _switches.plan("adaln_gemm", "1") != "0" and ops.adaln_qkv_supported(self.dt, E, self.H)
                                  and F <= N.MAX_AQKV_GROUPS and not self.concat)
+            # ... and with D = 128 the ln_cross modulation of a field is that launch's third layer (hidden rows generated in the launch, 2 D = 256 columns), the hidden
+            # rows of the modules further down and the information-bottleneck rows its row riders: no silu launch at all.  SEA_PLAN=front3=0 keeps the silu launch.
+            self._front3 = self._front_chain and D == 128 and len(later) <= N.AQKV_MAX_SILU and len(ib_todo) <= 1 and _switches.plan("front3", "1") != "0"
             silu_groups, hids = [], {}
             for pre_, d in front + later:
                 mods[pre_] = self._buf(M, 2 * d)
-                if self._front_chain and (pre_, d) in first:
+                if self._front_chain and ((pre_, d) in first or (self._front3 and "ln_cross." in pre_)):
                     continue   # generated inside sea_adaln_qkv
                 hids[pre_] = self._buf(M, 2 * d)
                 silu_groups.append((P.f32_vec(pre_ + "cond_mlp.0.weight", 2 * d), P.f32_vec(pre_ + "cond_mlp.0.bias"), hids[pre_]))
+            self._front_rows = None
+            if self._front3:   # the silu / ib rows as row riders of sea_adaln_qkv (emitted by _build)
+                sarr = (N.SeaSiluGroup * max(len(silu_groups), 1))()
+                for g, (w1, b1, hid) in zip(sarr, silu_groups):
+                    g.w1, g.b1, g.Hid, g.K2, g.ld = w1.data_ptr(), b1.data_ptr(), hid.data_ptr(), hid.shape[1], hid.stride(0)
+                ibp = None
+                if ib_todo:
+                    ibp = N.SeaIbParams()
+                    lpre, ibuf = ib_todo[0]
+                    ibp.X[0], ibp.n_fields, ibp.ldx = ibuf.data_ptr(), 1, ibuf.stride(0)
+                    self._fill_ib(ibp, lpre)
+                    ib_todo.clear()
+                self._front_rows = (sarr, len(silu_groups), ibp)
+                silu_groups = []
             for s_ in range(0, len(silu_groups), N.MAX_SILU_GROUPS):
                 chunk = silu_groups[s_:s_ + N.MAX_SILU_GROUPS]
                 sarr = (N.SeaSiluGroup * len(chunk))()
@@ -811,6 +828,7 @@ class Plan:
             else:
                 af = getattr(self, "_adaln_front", None) if l == 0 else None
                 if af and getattr(self, "_front_chain", False):
+                    front3 = getattr(self, "_front3", False)
                     arr = (N.SeaAdalnQkv * F)()
                     for g_, i in zip(arr, range(F)):
                         mp = f"{pre}ln.exp.{i}.0."
@@ -821,13 +839,24 @@ class Plan:
                         self._c_patches.append((g_, "cond"))
                         if first:
                             self._x_patches.append((g_, "X", i * Eo * 4))
-                    rg = [(key, v) for key, v in af.items() if "ln_cross." in key]
+                        if front3:   # ln_cross_i's modulation as the launch's third layer
+                            lc = f"{pre}ln_cross.{i}."
+                            W3 = af[lc][1]
+                            g_.w13, g_.b13 = P.f32_vec(lc + "cond_mlp.0.weight", 2 * D).data_ptr(), P.f32_vec(lc + "cond_mlp.0.bias").data_ptr()
+                            g_.W3, g_.ldw3, g_.b3, g_.N3 = W3.data_ptr(), W3.stride(0), N.ptr(af[lc][2]), 2 * D
+                            g_.mod3, g_.ldmod3 = mods[lc].data_ptr(), mods[lc].stride(0)
+                    rg = [] if front3 else [(key, v) for key, v in af.items() if "ln_cross." in key]
                     rarr = (N.SeaGemmGroup * max(len(rg), 1))()
                     for g_, (key, (hid_, W_, b_)) in zip(rarr, rg):
                         _fill_gemm(g_, A=hid_, W=W_, bias=b_, Cact=mods[key])
                     common = N.SeaQkvCommon(rope_s.data_ptr(), self.H, hd_s, self.T, self.pos0, self.cap, ops.q_scale(hd_s))
                     self._pos_structs.append(common)
-                    self._cur.append(self._rec(L.sea_adaln_qkv, [arr, F, C.byref(common), (rarr if rg else None), len(rg), 1e-5, self.code], "self.cond_adaln0_qkv_rope", (arr, common, rarr)))
+                    sarr, n_s, ibp = self._front_rows if front3 else (None, 0, None)
+                    rec = self._rec(L.sea_adaln_qkv, [arr, F, C.byref(common), (rarr if rg else None), len(rg), (sarr if n_s else None), n_s, None, (M if (n_s or ibp is not None) else 0),
+                                                      (C.byref(ibp) if ibp is not None else None), 1e-5, self.code], "self.cond_adaln0_qkv_rope", (arr, common, rarr, sarr, ibp))
+                    if n_s or ibp is not None:
+                        self._c_patches.append((rec.args, 7))
+                    self._cur.append(rec)
                 elif af:
                     ag = []
                     for i in range(F):
@@ -1379,8 +1408,13 @@ class Plan:
             elif r.fn is L.sea_mlp_fc2_proj_norm:
                 c.op, c.p0, c.n, c.f0, c.dtype = N.OP_MLP2, addr(a[0]), a[1], a[2], a[3]
             elif r.fn is L.sea_adaln_qkv:
-                c.op, c.p0, c.n, c.p1, c.f0, c.dtype = N.OP_AQKV, addr(a[0]), a[1], addr(r.keep[1]), a[5], a[6]
+                c.op, c.p0, c.n, c.p1, c.f0, c.dtype = N.OP_AQKV, addr(a[0]), a[1], addr(r.keep[1]), a[10], a[11]
                 c.l0, c.i0 = (addr(a[3]) if a[3] is not None else 0), a[4]
+                c.l1, c.i1 = (addr(a[5]) if a[5] is not None else 0), a[6]
+                c.l2, c.i2 = (a[7] or 0), a[8]
+                if a[8]:
+                    relink.append((i, "l2", a, 7))   # the condition pointer of the row riders, patched at every bind
+                c.l3 = addr(r.keep[4]) if r.keep[4] is not None else 0
             elif r.fn is L.sea_mlp_block:
                 c.op, c.p0, c.p1, c.n, c.f0, c.dtype = N.OP_MLPB, addr(a[0]), addr(a[1]), a[2], a[3], a[4]
             elif r.fn is L.sea_exchange_tail:
@@ -1416,7 +1450,7 @@ class Plan:
         if self._clist is not None:
             arr, _, relink = self._clist
             for i, field, args, k in relink:
-                setattr(arr[i], field, args[k])
+                setattr(arr[i], field, args[k] if (args[k] is not None or field[0] == "p") else 0)   # (l0..l3 are integers: an unbound pointer is 0)
 
     def run(self, concurrent: bool = False) -> None:
         """Replay the launch list.  Sequentially on the current stream (record order is a valid order), or — `concurrent` — with every

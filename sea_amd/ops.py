@@ -321,7 +321,7 @@ def adaln_qkv_supported(dtype: torch.dtype, E: int, H: int) -> bool:
     return dtype == torch.bfloat16 and E == 256 and H > 0 and E % H == 0 and E // H in (16, 32)
 
 
-def fill_adaln_qkv(g: N.SeaAdalnQkv, X, cond, w1, b1, W2c, b2c, gamma, beta, Wqkv, bqkv, Q, K, Vt, ldx=None) -> None:
+def fill_adaln_qkv(g: N.SeaAdalnQkv, X, cond, w1, b1, W2c, b2c, gamma, beta, Wqkv, bqkv, Q, K, Vt, ldx=None, third=None) -> None:
     """One group of sea_adaln_qkv: X f32 [M, E] (row stride ldx), cond f32 [M], cond_mlp.0 (w1, b1 f32 [2E]), cond_mlp.2 (W2c act [2E, 2E], b2c), AdaLN_0's gamma / beta,
     [Wq; Wk; Wv] act [3E, E] + bias, the attention operands Q [B,H,T,hd] / K [B,H,cap,hd] / Vt [B,H,hd,cap]."""
     g.X, g.ldx, g.cond = X.data_ptr(), (ldx if ldx is not None else X.stride(0)), N.ptr(cond)
@@ -329,11 +329,16 @@ def fill_adaln_qkv(g: N.SeaAdalnQkv, X, cond, w1, b1, W2c, b2c, gamma, beta, Wqk
     g.gamma, g.beta, g.Wqkv, g.ldw, g.bqkv = gamma.data_ptr(), N.ptr(beta), Wqkv.data_ptr(), Wqkv.stride(0), N.ptr(bqkv)
     g.Q, g.K, g.Vt = Q.data_ptr(), K.data_ptr(), Vt.data_ptr()
     g.M, g.E = X.shape[0], Wqkv.shape[1]
+    if third is not None:   # dict(w1, b1 f32 [N3], W act [N3, N3], bias f32 [N3] or None, out act [M, N3]): the modulation of another AdaLN module of the same rows
+        W3, o3 = third["W"], third["out"]
+        g.w13, g.b13, g.W3, g.ldw3, g.b3 = third["w1"].data_ptr(), third["b1"].data_ptr(), W3.data_ptr(), W3.stride(0), N.ptr(third.get("bias"))
+        g.mod3, g.ldmod3, g.N3 = o3.data_ptr(), o3.stride(0), W3.shape[0]
 
 
-def adaln_qkv(groups: Sequence[Dict], rope: torch.Tensor, H: int, hd: int, T: int, pos0: int, cap: int, q_scale: float, riders: Sequence[Dict] = (), eps: float = 1e-5,
-              dtype: torch.dtype = torch.bfloat16) -> None:
-    """sea_adaln_qkv: the front of a block in one launch (dict keys: the arguments of fill_adaln_qkv); `riders`: plain GEMM groups (A, W, bias, Cact) as sea_gemm_grouped's."""
+def adaln_qkv(groups: Sequence[Dict], rope: torch.Tensor, H: int, hd: int, T: int, pos0: int, cap: int, q_scale: float, riders: Sequence[Dict] = (), silu: Sequence[Dict] = (),
+              silu_c: Optional[torch.Tensor] = None, eps: float = 1e-5, dtype: torch.dtype = torch.bfloat16) -> None:
+    """sea_adaln_qkv: the front of a block in one launch (dict keys: the arguments of fill_adaln_qkv); `riders`: plain GEMM groups (A, W, bias, Cact) as sea_gemm_grouped's;
+    `silu`: row riders as sea_silu_outer's groups (w1, b1, Hid) evaluated on silu_c."""
     arr = (N.SeaAdalnQkv * len(groups))()
     for g, d in zip(arr, groups):
         fill_adaln_qkv(g, **d)
@@ -344,7 +349,13 @@ def adaln_qkv(groups: Sequence[Dict], rope: torch.Tensor, H: int, hd: int, T: in
         rarr = (N.SeaGemmGroup * len(riders))()
         for g, d in zip(rarr, riders):
             fill_gemm_group(g, **d)
-    N.check(N.lib().sea_adaln_qkv(arr, len(groups), C.byref(c), rarr, len(riders), eps, N.dtype_code(dtype), N.stream_ptr()), "sea_adaln_qkv")
+    sarr = None
+    if silu:
+        sarr = (N.SeaSiluGroup * len(silu))()
+        for g, gd in zip(sarr, silu):
+            g.w1, g.b1, g.Hid, g.K2, g.ld = gd["w1"].data_ptr(), gd["b1"].data_ptr(), gd["Hid"].data_ptr(), gd["Hid"].shape[1], gd["Hid"].stride(0)
+    N.check(N.lib().sea_adaln_qkv(arr, len(groups), C.byref(c), rarr, len(riders), sarr, len(silu), (silu_c.data_ptr() if silu_c is not None else None),
+                                  (silu_c.numel() if silu_c is not None else 0), None, eps, N.dtype_code(dtype), N.stream_ptr()), "sea_adaln_qkv")
 
 
 def row_chain_supported(dtype: torch.dtype, D: int, E: int, n_seg: int, hd: int) -> bool:

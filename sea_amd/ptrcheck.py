@@ -128,6 +128,11 @@ def _extents(st, esz: int) -> Iterable[Tuple[str, int, int]]:
         yield "Wqkv", st.Wqkv, ((3 * E - 1) * st.ldw + E) * esz
         if st.bqkv:
             yield "bqkv", st.bqkv, 3 * E * f32
+        if st.W3:
+            yield "w13", st.w13, st.N3 * f32
+            yield "b13", st.b13, st.N3 * f32
+            yield "W3", st.W3, ((st.N3 - 1) * st.ldw3 + st.N3) * esz
+            yield "mod3", st.mod3, ((st.M - 1) * st.ldmod3 + st.N3) * esz
     elif isinstance(st, N.SeaRowChain):
         K2 = st.D if st.n_seg > 0 else st.E
         for s_ in range(st.n_seg):

@@ -273,7 +273,7 @@ def test_cfg2_full_size_causality_and_prefix_bf16():
     with torch.no_grad():
         a = m(x, ib).clone()
         names = [r.name for r in m.engine().plan(1, 2024, "full").records]
-        assert "mlp.block_norm" in names and "cross0.tail" in names and "self.out_proj_down_qkv" in names and "self.cond_adaln0_qkv_rope" in names and len(names) == 11   # the plan of the bench line
+        assert "mlp.block_norm" in names and "cross0.tail" in names and "self.out_proj_down_qkv" in names and "self.cond_adaln0_qkv_rope" in names and len(names) == 10 and "adaln.silu" not in names   # the plan of the bench line
         x2 = x.clone()
         x2[:, 1500] += 1.0
         b = m(x2, ib).clone()
@@ -546,7 +546,7 @@ def test_rider_plan_matches_the_plans_it_replaces(F, B, T, monkeypatch):
 
 
 @pytest.mark.parametrize("env,graphed", [({"SEA_PLAN": "lanes=all"}, True), ({"SEA_PLAN": "lanes=cond"}, True),
-                                         ({"SEA_PLAN": "norm=0"}, False), ({"SEA_PLAN": "xtail=0"}, False), ({"SEA_PLAN": "chain=0"}, False), ({"SEA_PLAN": "silu=1"}, False), ({"SEA_PLAN": "fold_ib=0"}, False), ({"SEA_PLAN": "mlp1=1"}, False), ({"SEA_PLAN": "mlp1=1,mlp2=1"}, False), ({"SEA_PLAN": "mlp1=1,mlp2=1,mlpblock=0"}, False), ({"SEA_PLAN": "front=0"}, False),
+                                         ({"SEA_PLAN": "norm=0"}, False), ({"SEA_PLAN": "xtail=0"}, False), ({"SEA_PLAN": "chain=0"}, False), ({"SEA_PLAN": "silu=1"}, False), ({"SEA_PLAN": "fold_ib=0"}, False), ({"SEA_PLAN": "mlp1=1"}, False), ({"SEA_PLAN": "mlp1=1,mlp2=1"}, False), ({"SEA_PLAN": "mlp1=1,mlp2=1,mlpblock=0"}, False), ({"SEA_PLAN": "front=0"}, False), ({"SEA_PLAN": "front3=0"}, False),
                                          ({"SEA_TUNE": "gemm_norm_rows=64"}, False)])
 @pytest.mark.parametrize("dtype,tol", [("fp32", 2e-6), ("bf16", 2e-2)])
 def test_optional_plans_match_default_plan(env, graphed, dtype, tol, monkeypatch):
@@ -596,6 +596,8 @@ def test_optional_plans_match_default_plan(env, graphed, dtype, tol, monkeypatch
         assert ("cross.down_norm_old" in names) == (dtype == "fp32") and ("self.out_proj_down_qkv" in names) == (dtype == "bf16")
     elif sw == "front=0":   # silu + sea_gemm_adaln + the QKV launch in front of the first attention (the one-launch front needs E = 256: test_cfg2_* run it)
         assert "self.cond_adaln0_qkv_rope" not in names and "self.qkv_rope" in names
+    elif sw == "front3=0":   # ... with the silu launch and the ln_cross condition GEMM as rider tiles (E = 256 only: here the plan is the default one)
+        assert "self.cond_adaln0_qkv_rope" not in names
     elif sw == "norm=0":   # the two-launch form of Linear + row norm
         assert "cross.norm_old" in names and "cross.down_norm_old" not in names
     else:

@@ -821,8 +821,9 @@ def test_mlp_fc2_proj_norm_matches_three_launch_form(E, S, M, norm):
         assert rel(y32, y2) < 2e-3
 
 
+@pytest.mark.parametrize("third", [False, True])
 @pytest.mark.parametrize("B,T,H,pos0,cap", [(1, 2024, 8, 0, 2024), (3, 70, 8, 0, 72), (2, 45, 16, 8, 64), (1, 33, 8, 3, 40)])
-def test_adaln_qkv_matches_the_three_launches(B, T, H, pos0, cap):
+def test_adaln_qkv_matches_the_three_launches(B, T, H, pos0, cap, third):
     """sea_adaln_qkv (the front of a block in one launch: condition MLP with generated hidden rows, AdaLN_0, q / k / v + rotary epilogue) against
     sea_silu_outer + sea_gemm_adaln + sea_qkv_rope_grouped on the same operands and against the fp32 formulas (models/base_blocks.py:337-350, 176-190, 300-324);
     three fields per launch, X read through the caller's row stride, two rider groups (plain GEMMs of a later launch) beside them; rows that cross trajectories,
@@ -835,7 +836,7 @@ def test_adaln_qkv_matches_the_three_launches(B, T, H, pos0, cap):
     table = rope_table(hd, pos0 + T)
     cond = torch.rand(M, device=dev())
     xw = rnd(M, 3 * E, seed=2000)
-    groups, refs, keep = [], [], []
+    groups, refs, keep, thirds = [], [], [], []
     for i in range(3):
         w1, b1 = rnd(2 * E, seed=2010 + i), rnd(2 * E, seed=2020 + i)
         W2c, b2c = rnd(2 * E, 2 * E, dtype=dt, scale=(2 * E) ** -0.5, seed=2030 + i), 0.3 * rnd(2 * E, seed=2040 + i)
@@ -846,6 +847,13 @@ def test_adaln_qkv_matches_the_three_launches(B, T, H, pos0, cap):
         K = torch.zeros(B, H, cap, hd, device=dev(), dtype=dt)
         Vt = torch.zeros(B, H, hd, cap, device=dev(), dtype=dt)
         groups.append(dict(X=x, cond=cond, w1=w1, b1=b1, W2c=W2c, b2c=b2c, gamma=gamma, beta=beta, Wqkv=Wqkv, bqkv=bqkv, Q=Q, K=K, Vt=Vt))
+        if third:   # the modulation of a second module of the same rows (ln_cross: 256 columns), stored
+            w13, b13 = rnd(256, seed=2110 + i), rnd(256, seed=2120 + i)
+            W3, b3 = rnd(256, 256, dtype=dt, scale=1 / 16, seed=2130 + i), 0.3 * rnd(256, seed=2140 + i)
+            o3 = torch.full((M, 256), float("nan"), device=dev(), dtype=dt)
+            groups[-1]["third"] = dict(w1=w13, b1=b13, W=W3, bias=b3, out=o3)
+            h3 = torch.nn.functional.silu(cond[:, None] * w13 + b13).to(dt).float()
+            thirds.append((o3, h3 @ W3.float().t() + b3))
         # the three launches
         hid = torch.empty(M, 2 * E, device=dev(), dtype=dt)
         ops.silu_outer([dict(w1=w1, b1=b1, Hid=hid)], cond, M, dt)
@@ -864,7 +872,13 @@ def test_adaln_qkv_matches_the_three_launches(B, T, H, pos0, cap):
         refs.append((rope_ref(q, cos, sin) * ops.q_scale(hd), rope_ref(k, cos, sin), v))
     rA, rW, rb = rnd(M, 512, dtype=dt, seed=2100), rnd(256, 512, dtype=dt, scale=0.05, seed=2101), rnd(256, seed=2102)
     rC = [torch.full((M, 256), float("nan"), device=dev(), dtype=dt) for _ in range(2)]
-    ops.adaln_qkv(groups, table, H, hd, T, pos0, cap, ops.q_scale(hd), riders=[dict(A=rA, W=rW, bias=rb, Cact=rC[0]), dict(A=rA, W=rW, Cact=rC[1])])
+    sw = [(rnd(512, seed=2150 + k), rnd(512, seed=2160 + k), torch.full((M, 512), float("nan"), device=dev(), dtype=dt)) for k in range(2)]   # row riders: hidden rows of two other modules
+    ops.adaln_qkv(groups, table, H, hd, T, pos0, cap, ops.q_scale(hd), riders=[dict(A=rA, W=rW, bias=rb, Cact=rC[0]), dict(A=rA, W=rW, Cact=rC[1])],
+                  silu=[dict(w1=w_, b1=b_, Hid=h_) for w_, b_, h_ in sw], silu_c=cond)
+    for w_, b_, h_ in sw:
+        assert rel(h_.float(), torch.nn.functional.silu(cond[:, None] * w_ + b_)) < 6e-3
+    for o3, ref3 in thirds:
+        assert rel(o3.float(), ref3) < 6e-3
     for (Q, K, Vt, Q2, K2, Vt2), (q, k, v) in zip(keep, refs):
         assert rel(Q.float(), Q2.float()) < 1e-2 and rel(K.float(), K2.float()) < 1e-2 and rel(Vt.float(), Vt2.float()) < 1e-2
         assert rel(Q.float(), q.permute(0, 2, 1, 3)) < 1.5e-2
