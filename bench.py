@@ -325,7 +325,7 @@ def _roofline(recs_times, esz, traffic_file=None):
 
 def _pmc_file(name):
     """profiles/<this round's file>, or the previous round's while this round's has not been produced yet."""
-    for rnd in ("r03", "r02"):
+    for rnd in ("r04", "r03", "r02"):
         f = os.path.join(ROOT, "profiles", f"{rnd}_{name}")
         if os.path.exists(f):
             return f
@@ -590,14 +590,14 @@ def leg_shipped(args, dev, rank):
         gflop = algorithmic_gflop(B, T, F, E, H, D, S, L, adaln=adaln)
         model.eval()
         with torch.no_grad():
-            for _ in range(3):
+            for _ in range(40):   # (40 un-timed forwards: the device ramps out of idle over ~20 ms of work, profiles/r03_idle_ramp_probe.txt; with 3 this leg once read 1.28 ms for a 0.44 ms forward)
                 o = eng.forward(x, ib)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            for _ in range(20):
+            for _ in range(40):
                 o = eng.forward(x, ib)
             torch.cuda.synchronize()
-            fwd_ms = (time.perf_counter() - t0) / 20 * 1e3
+            fwd_ms = (time.perf_counter() - t0) / 40 * 1e3
             assert torch.isfinite(o).all()
             n_fwd = len([r for r in eng.plan(B, T, "full").records if r.fn is not None])
         model.train()

@@ -673,10 +673,18 @@ class Plan:
                 self._cur.append(rec)
             self._gemm(gemm_groups, "adaln.cond_gemm" + tag)
 
+        # Long launches (B = 8): AdaLN_0 of the first layer, its condition MLP and the self-attention's q / k / v as ONE launch too (sea_adaln_qkv without riders, emitted by
+        # _build) — opt-in (SEA_PLAN=front_big=1): measured at B = 8 the launch takes 171 us against 67 (condition GEMM) + 31 (norm) + 60 (QKV) as tiled launches, the forward
+        # 1.070 against 1.047 ms: with several rounds of workgroups the tiled GEMMs keep three workgroups per CU busy, the row-owning workgroup one.
+        self._front_big = (type(self) is Plan and self.mode == "full" and _switches.plan("front_big", "0") == "1" and ops.adaln_qkv_supported(self.dt, E, self.H) and F <= N.MAX_AQKV_GROUPS
+                           and not self.concat and M >= 1024)
+        if self._front_big:
+            first = []
         if not split:
             emit(first + rest, "")
             return mods
-        emit(first, ".first")
+        if first:
+            emit(first, ".first")
         self._fork(1)
         emit(rest, ".rest")
         self._end_lane()
@@ -815,7 +823,8 @@ class Plan:
                 self._ib_attn(pre, xr)
             # -- self attention: x_i += proj(attn(AdaLN_0(x_i)))
             groups = []
-            for i in range(F):
+            one_launch_front = l == 0 and not few and (getattr(self, "_front_big", False) or (getattr(self, "_adaln_front", None) and getattr(self, "_front_chain", False)))
+            for i in range(F if not one_launch_front else 0):   # (the one-launch front reads the module's parameters itself: its modulation matrix does not exist)
                 g = dict(**norm_params(f"{pre}ln.exp.{i}.0.", E)) if few else dict(Yact=n_e[i], **norm_params(f"{pre}ln.exp.{i}.0.", E))
                 if first:
                     g.update(X=xr[i], ldx=FE, X_is_x=i * Eo * 4)
@@ -827,7 +836,21 @@ class Plan:
                                     col0=0, Q=Qs[i], K=Ks[l][i], Vt=Vs[l][i]) for i in range(F)], rope_s, hd_s, "self.qkv_rope", pre=groups)
             else:
                 af = getattr(self, "_adaln_front", None) if l == 0 else None
-                if af and getattr(self, "_front_chain", False):
+                if l == 0 and not af and getattr(self, "_front_big", False) and not few:
+                    arr = (N.SeaAdalnQkv * F)()
+                    for g_, i in zip(arr, range(F)):
+                        mp = f"{pre}ln.exp.{i}.0."
+                        ops.fill_adaln_qkv(g_, X=xr[i], cond=None, w1=P.f32_vec(mp + "cond_mlp.0.weight", 2 * E), b1=P.f32_vec(mp + "cond_mlp.0.bias"), W2c=P.act(mp + "cond_mlp.2.weight"),
+                                           b2c=P.f32_vec(mp + "cond_mlp.2.bias"), gamma=P.f32_vec(mp + "weight"), beta=P.f32_vec(mp + "bias"), Wqkv=P.act(f"{pre}attn.self.{i}.q.weight", 3 * E),
+                                           bqkv=P.f32_vec(f"{pre}attn.self.{i}.q.bias", 3 * E), Q=Qs[i], K=Ks[l][i], Vt=Vs[l][i], ldx=(FE if first else None))
+                        g_.M = M
+                        self._c_patches.append((g_, "cond"))
+                        if first:
+                            self._x_patches.append((g_, "X", i * Eo * 4))
+                    common = N.SeaQkvCommon(rope_s.data_ptr(), self.H, hd_s, self.T, self.pos0, self.cap, ops.q_scale(hd_s))
+                    self._pos_structs.append(common)
+                    self._cur.append(self._rec(L.sea_adaln_qkv, [arr, F, C.byref(common), None, 0, None, 0, None, 0, None, 1e-5, self.code], "self.cond_adaln0_qkv_rope", (arr, common, None, None, None)))
+                elif af and getattr(self, "_front_chain", False):
                     front3 = getattr(self, "_front3", False)
                     arr = (N.SeaAdalnQkv * F)()
                     for g_, i in zip(arr, range(F)):
@@ -871,7 +894,7 @@ class Plan:
                     self._adaln(ag, "self.cond_adaln0")
                 else:
                     self._norm(groups, E, "self.adaln0")
-                if not (af and getattr(self, "_front_chain", False)):
+                if not ((af and getattr(self, "_front_chain", False)) or (l == 0 and not af and getattr(self, "_front_big", False) and not few)):
                     self._qkv([dict(A=n_e[i], W=P.act(f"{pre}attn.self.{i}.q.weight", 3 * E), bias=P.f32_vec(f"{pre}attn.self.{i}.q.bias", 3 * E),
                                     col0=0, Q=Qs[i], K=Ks[l][i], Vt=Vs[l][i]) for i in range(F)], rope_s, hd_s, "self.qkv_rope")
             self._attn([dict(Q=Qs[i], K=Ks[l][i], Vt=Vs[l][i], O=att_e[i]) for i in range(F)], hd_s, E, "self.attention")
