@@ -8,6 +8,7 @@ struct GemmLaunch {
     int n_groups;
     int single_buffer;   // register-staged main loop on one LDS buffer (more workgroups per CU)
     int silu_lds_off;    // generated-A launches: byte offset of the w1 | b1 staging area in LDS
+    int dma_ns;          // LDS-DMA launches: ring stages (4, or 2: half the LDS, two workgroups per CU)
     unsigned n_major;    // bit i: group i numbers its tiles with the ROW tile fastest (skinny M: the tiles that share a W panel are neighbours, see sea_gemm_grouped)
 };
 
@@ -40,6 +41,12 @@ __global__ __launch_bounds__(256) void gemm_grouped_kernel(const GemmLaunch L) {
         const int tiles_m = (G.M + BM - 1) / BM;
         tn = t / tiles_m;
         tm = t - tn * tiles_m;
+    }
+    if constexpr (DMA) {
+        if (L.dma_ns == 2) {   // block-uniform
+            gemm_tile_body<T, BM, BN, DMA, PLAIN, SILUA, 2>(G, tm, tn, smem, L.silu_lds_off);
+            return;
+        }
     }
     gemm_tile_body<T, BM, BN, DMA, PLAIN, SILUA>(G, tm, tn, smem, L.silu_lds_off);
 }
@@ -478,7 +485,11 @@ extern "C" int sea_gemm_grouped(const SeaGemmGroup* groups, int n_groups, int dt
     // ... and only while the launch is a few tiles deep per CU (its time then is the serial chain of K-tiles of one tile, which the ring
     // shortens: fc2 at B = 1 23 us vs 28); with many tiles per CU the single-buffered loop's occupancy wins (B = 8: 109 us vs 128)
     static const int dma_force = sea_tune("gemm_dma_force", 0);  // tuning aid
-    dma = dma && (t64 <= 1536 || dma_force);
+    // ... or, round 4, when it is at least two 128 x 128 tiles per CU deep: then with TWO ring stages (64 KiB: two workgroups per CU whose waves fill each other's
+    // fragment-read and barrier waits) — 4096^3 183 -> 141 us (977 TFLOP/s), the multiphase fc1 shape (796 x 16384 x 2048, two fields) 139 -> 120 us, cfg3's fc2
+    // 67.9 -> 62.0 us (tools/skinny_probe.py, tools/bench_ops.py)
+    const bool dma_long = dma && t128 >= 512;
+    dma = dma && (t64 <= 1536 || dma_long || dma_force);
     (void)t64;
     long kmax_all = 0;
     for (int i = 0; i < n_groups; ++i) kmax_all = (long)groups[i].K * groups[i].n_seg > kmax_all ? (long)groups[i].K * groups[i].n_seg : kmax_all;
@@ -512,10 +523,14 @@ extern "C" int sea_gemm_grouped(const SeaGemmGroup* groups, int n_groups, int dt
     int kmax = 0;
     for (int i = 0; i < n_groups; ++i) kmax = groups[i].K > kmax ? groups[i].K : kmax;
     L.single_buffer = !dma;
+    // two ring stages (64 KiB at 128 x 128: two workgroups per CU) when the launch has at least two 128 x 128 tiles per CU: their waves fill each other's
+    // fragment-read and barrier waits (one workgroup per CU ran the shipped MLP GEMMs at a third of a CU's MFMA rate).  SEA_TUNE=gemm_dma_ns=2|4 forces.
+    static const int ns_forced = sea_tune("gemm_dma_ns", 0);
+    L.dma_ns = ns_forced == 2 || ns_forced == 4 ? ns_forced : ((dma && tile == 128 && total >= 2 * 256 && t64 > 1536) ? 2 : 4);
     const int sb = L.single_buffer;
 #define LAUNCH_GEMM(TT, BMN, DM)                                                                                          \
     do {                                                                                                                  \
-        const int main_ = DM ? GemmMainloop<TT, BMN, BMN>::DMA_LDS_BYTES : (sb ? GemmCfg<TT, BMN, BMN>::BUF_BYTES : GemmCfg<TT, BMN, BMN>::LDS_BYTES); \
+        const int main_ = DM ? (L.dma_ns == 2 ? 2 : 4) * GemmCfg<TT, BMN, BMN>::BUF_BYTES : (sb ? GemmCfg<TT, BMN, BMN>::BUF_BYTES : GemmCfg<TT, BMN, BMN>::LDS_BYTES); \
         constexpr int stage_ = BMN * (BMN * (int)sizeof(TT) + 16);                                                         \
         const int lds_ = main_ > stage_ ? main_ : stage_;                                                                  \
         static int once = set_lds(gemm_grouped_kernel<TT, BMN, BMN, DM, false>, DM ? GemmMainloop<TT, BMN, BMN>::DMA_LDS_BYTES : (GemmCfg<TT, BMN, BMN>::LDS_BYTES > stage_ ? GemmCfg<TT, BMN, BMN>::LDS_BYTES : stage_)); \

@@ -170,6 +170,7 @@ struct GemmMainloop {
                      : "=&s"(keep) : "v"(gsrc), "s"(lds_addr) : "memory");
     }
 
+    template <int NSX = NS>
     __device__ __forceinline__ void dma_stage(int kt, unsigned lds_base, int wave, int lane) const {
         const int kk = kt * C::BK;
         int seg = 0, kin = kk;
@@ -181,7 +182,7 @@ struct GemmMainloop {
         const int chunk = (lane & 7) ^ (rl & 7);                    // swizzle on the source side
         const T* a_base = A + seg * a_seg_stride + kin + chunk * C::EPC;
         const T* w_base = W + kin + chunk * C::EPC;
-        const unsigned stage = lds_base + (unsigned)((kt % NS) * C::BUF_BYTES);
+        const unsigned stage = lds_base + (unsigned)((kt % NSX) * C::BUF_BYTES);
 #pragma unroll
         for (int u = 0; u < A_DMA; ++u) {
             const int r0 = (u * 4 + wave) * 8;
@@ -198,7 +199,12 @@ struct GemmMainloop {
         }
     }
 
-    __device__ __forceinline__ void run_dma(char* smem, f32x4 (&acc)[C::MI][C::NI]) {
+    __device__ __forceinline__ void run_dma(char* smem, f32x4 (&acc)[C::MI][C::NI]) { run_dma_n<NS>(smem, acc); }
+
+    // NSX stages: 4 = three K-tiles in flight beside the one being multiplied (128 KiB at 128 x 128: one workgroup per CU); 2 = one in flight (64 KiB: TWO
+    // workgroups per CU, whose waves fill each other's fragment-read and barrier waits — for launches with enough tiles to put two on every CU)
+    template <int NSX>
+    __device__ __forceinline__ void run_dma_n(char* smem, f32x4 (&acc)[C::MI][C::NI]) {
         const int tid = threadIdx.x;
         const int lane = tid & 63;
         const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -209,20 +215,20 @@ struct GemmMainloop {
             for (int j = 0; j < C::NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
         const int nk = (K * n_seg) / C::BK;
         const unsigned lds_base = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)smem);
-        for (int s = 0; s < NS - 1 && s < nk; ++s) dma_stage(s, lds_base, wave, lane);
+        for (int s = 0; s < NSX - 1 && s < nk; ++s) dma_stage<NSX>(s, lds_base, wave, lane);
         for (int kt = 0; kt < nk; ++kt) {
             // stage kt has landed once at most the loads of the stages issued after it are outstanding
-            const int newer = (nk - 1 - kt) < (NS - 2) ? (nk - 1 - kt) : (NS - 2);
+            const int newer = (nk - 1 - kt) < (NSX - 2) ? (nk - 1 - kt) : (NSX - 2);
             // lgkmcnt(0): this wave's fragment reads of stage kt-1 are RETIRED before it arrives at the barrier.  The buffer they read is refilled right
             // behind the barrier (one phase after its last read), and nothing but a retired read orders an LDS-DMA write against an earlier ds_read
             // (cdna_hip_programming.md, "Read a staged buffer ..." / WAR).  Found in round 2 with a sibling of this loop (mlp_fused.hip): with two
             // workgroups per CU rare 8-row pieces of a tile were multiplied against the NEXT stage's data.
-            if (newer == NS - 2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((NS - 2) * LPS) : "memory");
+            if (newer == NSX - 2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((NSX - 2) * LPS) : "memory");
             else if (newer == 1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(LPS) : "memory");
             else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();  // every wave's part of stage kt is in LDS; everyone is done reading stage kt-1
-            if (kt + NS - 1 < nk) dma_stage(kt + NS - 1, lds_base, wave, lane);  // refill the buffer stage kt-1 used
-            compute_tile(smem + (kt % NS) * C::BUF_BYTES, wm, wn, lane, acc);
+            if (kt + NSX - 1 < nk) dma_stage<NSX>(kt + NSX - 1, lds_base, wave, lane);  // refill the buffer stage kt-1 used
+            compute_tile(smem + (kt % NSX) * C::BUF_BYTES, wm, wn, lane, acc);
         }
         __syncthreads();
     }

@@ -8,7 +8,7 @@
 // One BM x BN output tile (tm, tn) of group G — the body of gemm_grouped_kernel, also run by other kernels beside their own work (chain.hip: the AdaLN
 // condition GEMMs of later launches ride on the CUs a row-chain launch leaves idle).  GT: SeaGemmGroup, or a struct with the same member names whose unused
 // members are compile-time constants.
-template <typename T, int BM, int BN, bool DMA, bool PLAIN, bool SILUA, typename GT>
+template <typename T, int BM, int BN, bool DMA, bool PLAIN, bool SILUA, int NSD = 4, typename GT>
 __device__ __forceinline__ void gemm_tile_body(const GT& G, int tm, int tn, char* smem, int silu_lds_off) {
     using C = GemmCfg<T, BM, BN>;
     GemmMainloop<T, BM, BN> ml;
@@ -30,7 +30,7 @@ __device__ __forceinline__ void gemm_tile_body(const GT& G, int tm, int tn, char
         ml.init_silu(threadIdx.x);
         __syncthreads();
         ml.template run_single<true>(smem, acc);
-    } else if constexpr (DMA) ml.run_dma(smem, acc);
+    } else if constexpr (DMA) ml.template run_dma_n<NSD>(smem, acc);
     else ml.run_single(smem, acc);
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
