@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define SEA_ABI_VERSION 7
+#define SEA_ABI_VERSION 8
 
 enum { SEA_F32 = 0, SEA_BF16 = 1 };
 

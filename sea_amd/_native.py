@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libsea_hip.so")
 
 SEA_F32, SEA_BF16 = 0, 1
-ABI_VERSION = 7   # include/sea_hip.h SEA_ABI_VERSION
+ABI_VERSION = 8   # include/sea_hip.h SEA_ABI_VERSION
 MAX_GROUPS = 16
 MAX_ATTN_PROBLEMS = 8
 MAX_NORM_GROUPS = 16

@@ -55,7 +55,7 @@ def test_validation_without_gpu(lib):
     assert lib.sea_gemm_grouped(g, 17, 0, None) == -1
     P = N.SeaAttnParams()
     assert lib.sea_attention_fwd(C.byref(P), 1, None) == -1
-    assert lib.sea_abi_version() == N.ABI_VERSION == 7
+    assert lib.sea_abi_version() == N.ABI_VERSION == 8
     few = (N.SeaGemmGroup * 1)()
     assert lib.sea_gemm_fewrows(few, None, 1, 0, 0, 1e-5, 0, None) == -3     # fp32: the few-row launches are bf16 only (unsupported, not an argument error)
     assert lib.sea_gemm_fewrows(few, None, 9, 0, 0, 1e-5, 1, None) == -1 and b"sea_gemm_fewrows" in lib.sea_last_error()
