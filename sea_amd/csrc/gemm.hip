@@ -27,6 +27,8 @@ __device__ __forceinline__ int find_group(const L& launch, int bid) {
     return gi;
 }
 
+bool sea_gemm256_try(const SeaGemmGroup* groups, int n_groups, unsigned n_major, hipStream_t s);   // gemm256.hip
+
 // ---------------------------------------------------------------------------------------------- standard epilogue (tile body: gemm_tile.hpp)
 template <typename T, int BM, int BN, bool DMA, bool PLAIN, bool SILUA = false>
 __global__ __launch_bounds__(256) void gemm_grouped_kernel(const GemmLaunch L) {
@@ -517,6 +519,20 @@ extern "C" int sea_gemm_grouped(const SeaGemmGroup* groups, int n_groups, int dt
         }
     }
     hipStream_t s = static_cast<hipStream_t>(stream);
+    // 256 x 256 tiles (gemm256.hip: a wave owns 128 x 64, 96 B/clk of fragment reads at the full MFMA rate instead of the 128 x 128 tile's 128) for launches that
+    // give every CU at least one such tile and a half.  SEA_TUNE=gemm256=0|1 forces.
+    {
+        static const int g256 = sea_tune("gemm256", -1);
+        long t256 = 0;
+        for (int i = 0; i < n_groups; ++i) t256 += (long)((groups[i].M + 255) / 256) * ((groups[i].N + 255) / 256);
+        // measured (tools/bench_ops.py, SEA_TUNE=gemm256=0|1): 4096^3 139 -> 118 us (1164 TFLOP/s); 9 x (16192, 512, 512) 128.5 -> 122 us; 3 x (16192, 256, 2048) 61.9 -> 58.7;
+        // the multiphase fc1 shape 121.6 -> 115; but 3 x (16192, 2048, 256) 91 -> 96 (four K-tiles: the launch is its epilogue) — hence the contraction floor
+        const bool deep = (t256 >= 384 && kmax_all >= 512) || (t256 >= 192 && kmax_all >= 2048);
+        if (dtype == SEA_BF16 && !silu && (g256 == 1 || (g256 < 0 && deep)) && sea_gemm256_try(groups, n_groups, L.n_major, s)) {
+            SEA_CHECK_LAUNCH("sea_gemm_grouped");
+            return SEA_OK;
+        }
+    }
     bool plain = true;
     for (int i = 0; i < n_groups; ++i) plain = plain && groups[i].act == 0 && groups[i].drop.thr == 0;
     SEA_REQUIRE(!silu || plain, "sea_gemm_grouped: generated-A launches take no activation / dropout epilogue");
