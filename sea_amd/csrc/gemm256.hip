@@ -159,6 +159,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const Gemm256Launch L) {
                         if (C32 != nullptr) store4(C32 + (int64_t)m * G.ldc32 + n, v[0], v[1], v[2], v[3]);
                         if (staged) store4(reinterpret_cast<T*>(smem + (i * 16 + r) * SP) + (wn * 64 + j * 16 + g * 4), v[0], v[1], v[2], v[3]);
                         else if (Cact != nullptr) store4(Cact + (int64_t)m * G.ldcact + n, v[0], v[1], v[2], v[3]);
+                        if (!PLAIN) __builtin_amdgcn_sched_barrier(0);   // (one block's GELU temporaries at a time: interleaved, 32 blocks of them spill beside 128 accumulator registers)
                     }
                 }
             }

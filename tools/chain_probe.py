@@ -28,6 +28,30 @@ def replay(n):
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / n
     print(f"replay: {dt * 1e3:.4f} ms/step over {n} steps; launches {[r.name for r in eng.plan(1, 2024, 'full').records]}", flush=True)
+    if os.environ.get("AQKV_STAMPS"):   # the front launch's phase stamps inside the step (sea_aqkv_debug_stamps)
+        import ctypes as C
+        from sea_amd import _native as N
+        L = N.lib()
+        L.sea_aqkv_debug_stamps.argtypes = [C.c_void_p]
+        L.sea_aqkv_debug_stamps.restype = None
+        n_chain = 3 * ((2024 + 31) // 32)
+        buf = torch.zeros(1024 * 16, device=dev, dtype=torch.int64)
+        acc = None
+        for _ in range(20):
+            buf.zero_()
+            L.sea_aqkv_debug_stamps(buf.data_ptr())
+            with torch.no_grad():
+                eng.forward(x, ib)
+            torch.cuda.synchronize()
+            st = buf.view(1024, 16)[:n_chain].cpu().double()
+            v = (st[:, :11] - st[:, 0].min()) / 100.0
+            acc = v if acc is None else acc + v
+        L.sea_aqkv_debug_stamps(None)
+        acc /= 20
+        names = ["entry", "hid", "loopA", "modx", "rowpass", "loopB", "loopB.all", "staged", "staged.all", "QK", "V"]
+        print("front launch inside the step: stamps (us from the first workgroup's entry; mean / max over the chain workgroups, 20 steps):")
+        for k, nm in enumerate(names):
+            print(f"  {k:2d} {nm:10s} {acc[:, k].mean():7.2f} {acc[:, k].max():7.2f}")
 
 
 def rnd(*shape, dtype=torch.float32, scale=1.0):
