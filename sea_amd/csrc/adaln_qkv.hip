@@ -85,7 +85,7 @@ struct AqkvCfg {
     static constexpr int OUT_OFF = RING_OFF;                        // epilogue of layer B: [3][H][32 rows][hd] bf16 = 48 KiB (+ padding) over the drained rings
     static constexpr int OUT3_OFF = OUT_OFF + 3 * BM * (E * 2 + 16 * 16);   // ... and layer C's [32][K3] behind it
     static constexpr int BYTES = RING_OFF + NW * WAVE_RING;         // 160 KiB
-    static_assert(BYTES <= 160 * 1024 && ROPE_OFF + BM * (16 * 8 + 16) <= HID_BYTES && MOD_OFF + BM * 128 <= WAVE_RING && OUT3_OFF + BM * (K3 * 2 + 16) <= BYTES && OUT_PAD == 16, "LDS plan of sea_adaln_qkv");
+    static_assert(BYTES <= 160 * 1024 && ROPE_OFF + BM * (16 * 8 + 16) <= HID_BYTES && MOD_OFF + BM * 128 <= WAVE_RING /* (rows at a pitch of 128 B: the spare 4 KiB hold exactly 32 of them) */ && OUT3_OFF + BM * (K3 * 2 + 16) <= BYTES && OUT_PAD == 16, "LDS plan of sea_adaln_qkv");
 };
 
 // HAS3: every group of the launch carries the optional third layer
@@ -191,9 +191,7 @@ __global__ __launch_bounds__(512) void adaln_qkv_kernel(const AqkvLaunch L) {
         glds16_aq(ub, wc_lane, dst);
         glds16_aq(ub + (int64_t)8 * G.ldw3, wc_lane, dst + 1024u);
     };
-#pragma unroll
-    for (int k = 0; k < C::RSA - 1; ++k) slot_a(k);
-    // ---- the row pass's own operands (thread: row prow, 16 columns from pc0), requested behind the first weight slots
+    // ---- the row pass's own operands (thread: row prow, 16 columns from pc0): requested FIRST, the weight slots behind them (see the hidden rows below)
     const int prow = tid >> 4, pl = tid & 15, pc0 = pl * 16;
     int mrow = m0 + prow;
     const bool rok = mrow < M;
@@ -258,37 +256,35 @@ __global__ __launch_bounds__(512) void adaln_qkv_kernel(const AqkvLaunch L) {
     // ---- the hidden rows of the condition MLP, generated: thread = 8 contraction indices (chunk kc8 of the 64) of the 4 rows 4 wave .. 4 wave + 3
     {
         const int kc8 = lane;                                  // 64 chunks of 8 = KC
-        float w1[8], b1[8];
-        load4(G.w1 + kc8 * 8, *reinterpret_cast<float(*)[4]>(w1));
-        load4(G.w1 + kc8 * 8 + 4, *reinterpret_cast<float(*)[4]>(w1 + 4));
-        load4(G.b1 + kc8 * 8, *reinterpret_cast<float(*)[4]>(b1));
-        load4(G.b1 + kc8 * 8 + 4, *reinterpret_cast<float(*)[4]>(b1 + 4));
+        // w1 / b1 by loads the compiler does not track, the first weight slots behind them, and ONE counted wait that lets those 14 pieces fly on: a tracked load's
+        // wait at its first use is a vmcnt(0) — the generation would start only when the whole ring prologue has landed (measured: 6 us from entry to the rows)
+        f32x4 w1a, w1b, b1a, b1b;
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(w1a) : "v"(G.w1 + kc8 * 8) : "memory");
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(w1b) : "v"(G.w1 + kc8 * 8 + 4) : "memory");
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(b1a) : "v"(G.b1 + kc8 * 8) : "memory");
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(b1b) : "v"(G.b1 + kc8 * 8 + 4) : "memory");
+        float cvr[4];   // the condition of this wave's four rows (untracked loads as well: the compiler loads them per lane, not as scalars)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = m0 + wave * 4 + i < M ? m0 + wave * 4 + i : M - 1;
+            asm volatile("global_load_dword %0, %1, off" : "=v"(cvr[i]) : "v"(G.cond + m) : "memory");
+        }
+#pragma unroll
+        for (int k = 0; k < C::RSA - 1; ++k) slot_a(k);
+        asm volatile("s_waitcnt vmcnt(%8)" : "+v"(w1a), "+v"(w1b), "+v"(b1a), "+v"(b1b), "+v"(cvr[0]), "+v"(cvr[1]), "+v"(cvr[2]), "+v"(cvr[3]) : "n"(2 * (AqkvCfg::RSA - 1)) : "memory");
+        const float w1[8] = {w1a[0], w1a[1], w1a[2], w1a[3], w1b[0], w1b[1], w1b[2], w1b[3]};
+        const float b1[8] = {b1a[0], b1a[1], b1a[2], b1a[3], b1b[0], b1b[1], b1b[2], b1b[3]};
         const int kt = kc8 >> 3, ck = kc8 & 7;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int row = wave * 4 + i;
-            const int m = m0 + row < M ? m0 + row : M - 1;
-            const float cv = G.cond[m];
+            const float cv = cvr[i];
             bf16x8 hv;
 #pragma unroll
             for (int e = 0; e < 8; ++e) hv[e] = (__bf16)silu_f(w1[e] * cv + b1[e]);
             *reinterpret_cast<bf16x8*>(smem + kt * (BM * 128) + row * 128 + ((ck ^ (row & 7)) << 4)) = hv;
         }
     }
-    // Every value requested above is "used" HERE, where the hidden rows' operands have made the compiler wait for the memory queue anyway: its wait for a load sits
-    // at the first use and counts only the loads it issued itself — at a first use further down it would drain the counted LDS-DMA pieces in flight there
-    // (seen: 1.5 us in front of the row pass, whose x / gamma / beta had landed ten microseconds earlier).
-#pragma unroll
-    for (int c = 0; c < 16; ++c) asm volatile("" ::"v"(xv[c]), "v"(gq[c]), "v"(bq[c]));
-#pragma unroll
-    for (int j = 0; j < 6; ++j) asm volatile("" ::"v"(bqv[j][0]), "v"(bqv[j][1]), "v"(bqv[j][2]), "v"(bqv[j][3]));
-#pragma unroll
-    for (int j = 0; j < 4; ++j) asm volatile("" ::"v"(b2v[j][0]), "v"(b2v[j][1]), "v"(b2v[j][2]), "v"(b2v[j][3]));
-    asm volatile("" ::"v"(cs_row.x), "v"(cs_row.y), "v"(c3v[0]), "v"(c3v[1]));
-#pragma unroll
-    for (int e = 0; e < 8; ++e) asm volatile("" ::"v"(w3v[e]), "v"(b3v[e]));
-#pragma unroll
-    for (int j = 0; j < 2; ++j) asm volatile("" ::"v"(b3o[j][0]), "v"(b3o[j][1]), "v"(b3o[j][2]), "v"(b3o[j][3]));
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();   // the hidden rows are complete
     stamp();   // 1: hidden rows generated
@@ -324,6 +320,20 @@ __global__ __launch_bounds__(512) void adaln_qkv_kernel(const AqkvLaunch L) {
         }
     }
     stamp();   // 2: layer A's loop
+    // Every value the compiler loaded itself at the start is "used" HERE, where the loop's last wait has emptied the memory queue anyway: its wait for a load sits
+    // at the first use and counts only the loads it issued itself — at a first use further down it would drain the counted LDS-DMA pieces in flight there
+    // (seen: 1.5 us in front of the row pass, whose x / gamma / beta had landed ten microseconds earlier).
+#pragma unroll
+    for (int c = 0; c < 16; ++c) asm volatile("" ::"v"(xv[c]), "v"(gq[c]), "v"(bq[c]));
+#pragma unroll
+    for (int j = 0; j < 6; ++j) asm volatile("" ::"v"(bqv[j][0]), "v"(bqv[j][1]), "v"(bqv[j][2]), "v"(bqv[j][3]));
+#pragma unroll
+    for (int j = 0; j < 4; ++j) asm volatile("" ::"v"(b2v[j][0]), "v"(b2v[j][1]), "v"(b2v[j][2]), "v"(b2v[j][3]));
+    asm volatile("" ::"v"(cs_row.x), "v"(cs_row.y), "v"(c3v[0]), "v"(c3v[1]));
+#pragma unroll
+    for (int e = 0; e < 8; ++e) asm volatile("" ::"v"(w3v[e]), "v"(b3v[e]));
+#pragma unroll
+    for (int j = 0; j < 2; ++j) asm volatile("" ::"v"(b3o[j][0]), "v"(b3o[j][1]), "v"(b3o[j][2]), "v"(b3o[j][3]));
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's fragment reads are retired: its ring takes layer B's first slots
 #pragma unroll
     for (int k = 0; k < C::RSB - 1; ++k) slot_b(k);
