@@ -138,6 +138,8 @@ __global__ __launch_bounds__(512) void mlp_block_kernel(const MlpBlockLaunch L) 
             glds16_blk_s(W + (int64_t)urow * G.ldw + kt * BK, w1_lane, base + (unsigned)(kt * 64 * BKB + u8 * 8 * BKB));
         }
     };
+    // (Only the first weight stage goes in front of the prologue: its tracked loads end in a vmcnt(0).  Measured and not kept, round 4: the rows' operands by untracked
+    // loads with all three stages behind them and one counted wait — 45.7 against 45.2 us: the ring fills under the prologue's arithmetic either way.)
     dma_stage(0);
     if (G.X32 != nullptr) {   // the operand rows normalised in place from the fp32 residual stream (x + addend), as sea_mlp_fc1_ln_gelu's prologue (no Xout here: the residual is re-formed below)
         constexpr int CPT = E / 16;
