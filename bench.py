@@ -87,6 +87,9 @@ def record_work(rec, esz):
             fl += 2 * g.M * g.E * g.S + 2 * g.M * g.E * g.E
             by += g.M * g.S * esz + g.E * g.S * esz + g.E * g.E * esz + g.M * g.E * 4 + (g.M * g.E * 4 if g.Y32 else 0) + (g.M * g.E * esz if g.Yact else 0) \
                 + (g.M * 2 * g.E * esz if g.mod else 0)
+    elif rec.fn is L.sea_splitk_finish:
+        for g in a[0][:a[1]]:
+            by += g.M * g.N * 4 * (g.S + (1 if g.R else 0) + (1 if g.C32 else 0)) + (g.M * g.N * esz if g.Cact else 0)
     elif rec.fn is L.sea_adaln_qkv:
         for g in a[0][:a[1]]:
             fl += 2 * g.M * (2 * g.E) * (2 * g.E) + 2 * g.M * (3 * g.E) * g.E

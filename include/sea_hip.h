@@ -41,7 +41,7 @@ enum {
 int sea_abi_version(void);
 const char* sea_last_error(void);
 /* sizeof of every ABI struct in declaration order (SeaGemmGroup, SeaQkvGroup, SeaQkvCommon, SeaAttnProblem,
- * SeaAttnParams, SeaNormGroup, SeaSiluGroup, SeaIbParams, ..., SeaLaunchRec, SeaGemmNormGroup, SeaExchangeTail, SeaMlpGroup, SeaMlp2Group, SeaKvNorm, SeaKvField, SeaKvPair, SeaKvLayer, SeaKvGlobal, SeaStepPatch, SeaRowChain, SeaAdalnGroup, SeaAdalnQkv last): lets a binding verify its layout.  Host only. */
+ * SeaAttnParams, SeaNormGroup, SeaSiluGroup, SeaIbParams, ..., SeaLaunchRec, SeaGemmNormGroup, SeaExchangeTail, SeaMlpGroup, SeaMlp2Group, SeaKvNorm, SeaKvField, SeaKvPair, SeaKvLayer, SeaKvGlobal, SeaStepPatch, SeaRowChain, SeaAdalnGroup, SeaAdalnQkv, SeaSplitkGroup last): lets a binding verify its layout.  Host only. */
 int sea_struct_sizes(int* out, int cap);
 /* Number of compute units / name of device 0's architecture as HIP reports them (diagnostics for bench.py). */
 int sea_device_info(int* cu_count, char* arch, int arch_len);
@@ -591,6 +591,23 @@ typedef struct {
 int sea_gemm_adaln(const SeaAdalnGroup* groups, int n_groups, float eps, int dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
+ * Split-K finish: out = sum_s P[s] + bias * bias_scale + R, as fp32 (C32) and / or in the activation dtype (Cact) — the pass behind a sea_gemm_grouped
+ * launch whose groups are K-slices of ONE Linear layer writing fp32 partial matrices (a few row tiles against a contraction of 16384: the MLP of
+ * configs/multiphase_flow.py:112-141 at M = B T = 796).  The partial sums are added in split order.  N % 4 == 0; strides multiples of 4.
+ */
+typedef struct {
+    const float* P;      /* f32 [S][M, N]: the partial matrices, p_stride elements apart, row stride ldp */
+    const float* bias;   /* f32 [N] or NULL */
+    const float* R;      /* f32 [M, N] row stride ldr, or NULL */
+    float* C32;          /* f32 [M, N] row stride ldc32, or NULL */
+    void* Cact;          /* act [M, N] row stride ldcact, or NULL */
+    int64_t p_stride;
+    int32_t S, M, N, ldp, ldr, ldc32, ldcact;
+    float bias_scale;
+} SeaSplitkGroup;
+int sea_splitk_finish(const SeaSplitkGroup* groups, int n_groups, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
  * The front of a block in one launch (bf16, E = 256): the AdaLN condition MLP of AdaLN_0 with its hidden rows generated in place, AdaLN_0, and the
  * self-attention's q / k / v projections with the rotary epilogue —
  *     h = silu(w1 * cond[m] + b1)  [2E];   [w | b] = h . W2c^T + b2c;   y = xhat(X) * (gamma + 1 + w) + (beta + b)              (models/base_blocks.py:337-350)
@@ -697,13 +714,14 @@ int sea_row_chain_riders(const SeaRowChain* params, int n_groups, const SeaQkvCo
  *     SEA_OP_QKV_FEW  p0 = SeaQkvGroup[n], p1 = SeaQkvCommon, l0 = (intptr) pre or 0, f0 = eps
  *     SEA_OP_ADALN    p0 = SeaAdalnGroup[n], f0 = eps
  *     SEA_OP_MLPB     p0 = SeaMlpGroup[n], p1 = SeaMlp2Group[n], f0 = eps
+ *     SEA_OP_SPLITK   p0 = SeaSplitkGroup[n]
  *     SEA_OP_AQKV     p0 = SeaAdalnQkv[n], p1 = SeaQkvCommon, l0 = (intptr) SeaGemmGroup[i0] riders or 0, l1 = (intptr) SeaSiluGroup[i1] or 0, l2 = (intptr) silu_c, i2 = silu_M,
  *                     l3 = (intptr) SeaIbParams or 0, f0 = eps
  *     SEA_OP_CHAIN    p0 = SeaRowChain[n], p1 = SeaQkvCommon or NULL, f0 = eps; riders (sea_row_chain_riders): l0 = (intptr) SeaGemmGroup[i0] or 0, i1 = tile0, i2 = n_tiles,
  *                     l1 = (intptr) SeaIbParams or 0
  * Returns 0, or the failing entry's error code with sea_last_error() set (entries before it have been launched).
  */
-enum { SEA_OP_GEMM = 1, SEA_OP_QKV = 2, SEA_OP_ATTN = 3, SEA_OP_NORM = 4, SEA_OP_SILU = 5, SEA_OP_IB = 6, SEA_OP_CONVERT = 8, SEA_OP_GEMM_NORM = 9, SEA_OP_XTAIL = 10, SEA_OP_MLP1 = 11, SEA_OP_MLP2 = 13, SEA_OP_GEMM_FEW = 14, SEA_OP_QKV_FEW = 15, SEA_OP_CHAIN = 16, SEA_OP_ADALN = 17, SEA_OP_MLPB = 18, SEA_OP_AQKV = 19 };   /* 7 and 12 were round-1 entry points (sea_rowchain, sea_cond_mlp), removed in ABI v2 */
+enum { SEA_OP_GEMM = 1, SEA_OP_QKV = 2, SEA_OP_ATTN = 3, SEA_OP_NORM = 4, SEA_OP_SILU = 5, SEA_OP_IB = 6, SEA_OP_CONVERT = 8, SEA_OP_GEMM_NORM = 9, SEA_OP_XTAIL = 10, SEA_OP_MLP1 = 11, SEA_OP_MLP2 = 13, SEA_OP_GEMM_FEW = 14, SEA_OP_QKV_FEW = 15, SEA_OP_CHAIN = 16, SEA_OP_ADALN = 17, SEA_OP_MLPB = 18, SEA_OP_AQKV = 19, SEA_OP_SPLITK = 20 };   /* 7 and 12 were round-1 entry points (sea_rowchain, sea_cond_mlp), removed in ABI v2 */
 typedef struct {
     int32_t op, n, dtype, i0, i1, i2, i3;
     float f0;

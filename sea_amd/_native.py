@@ -107,7 +107,7 @@ class SeaAttnBwdParams(C.Structure):
                 ("ldo", _i32), ("lddo", _i32), ("lddq", _i32), ("lddk", _i32), ("lddv", _i32), ("q_scale", _f32), ("drop", SeaDropout)]
 
 
-OP_GEMM, OP_QKV, OP_ATTN, OP_NORM, OP_SILU, OP_IB, OP_CONVERT, OP_GEMM_NORM, OP_XTAIL, OP_MLP1, OP_MLP2, OP_GEMM_FEW, OP_QKV_FEW, OP_CHAIN, OP_ADALN, OP_MLPB, OP_AQKV = 1, 2, 3, 4, 5, 6, 8, 9, 10, 11, 13, 14, 15, 16, 17, 18, 19
+OP_GEMM, OP_QKV, OP_ATTN, OP_NORM, OP_SILU, OP_IB, OP_CONVERT, OP_GEMM_NORM, OP_XTAIL, OP_MLP1, OP_MLP2, OP_GEMM_FEW, OP_QKV_FEW, OP_CHAIN, OP_ADALN, OP_MLPB, OP_AQKV, OP_SPLITK = 1, 2, 3, 4, 5, 6, 8, 9, 10, 11, 13, 14, 15, 16, 17, 18, 19, 20
 FEW_MAX_GROUPS = 8     # sea_gemm_fewrows / sea_qkv_rope_fewrows (gemv.hip)
 FEW_K = (512, 1024, 2048, 4096, 8192, 16384)
 
@@ -159,6 +159,14 @@ MAX_ADALN_GROUPS = 16
 class SeaAdalnGroup(C.Structure):
     _fields_ = [("A", _vp), ("W", _vp), ("bias", _vp), ("X", _vp), ("gamma", _vp), ("beta", _vp), ("Yact", _vp), ("Y32", _vp), ("mean", _vp), ("rstd", _vp),
                 ("lda", _i32), ("ldw", _i32), ("ldx", _i32), ("ldyact", _i32), ("ldy32", _i32), ("M", _i32), ("d", _i32), ("K", _i32)]
+
+
+MAX_SPLITK_GROUPS = 8
+
+
+class SeaSplitkGroup(C.Structure):
+    _fields_ = [("P", _vp), ("bias", _vp), ("R", _vp), ("C32", _vp), ("Cact", _vp), ("p_stride", _i64), ("S", _i32), ("M", _i32), ("N", _i32), ("ldp", _i32),
+                ("ldr", _i32), ("ldc32", _i32), ("ldcact", _i32), ("bias_scale", _f32)]
 
 
 MAX_AQKV_GROUPS = 4
@@ -296,6 +304,8 @@ def lib() -> C.CDLL:
     L.sea_adaln_qkv.argtypes = [C.POINTER(SeaAdalnQkv), C.c_int, C.POINTER(SeaQkvCommon), C.POINTER(SeaGemmGroup), C.c_int, C.POINTER(SeaSiluGroup), C.c_int, _vp, C.c_int,
                                 C.POINTER(SeaIbParams), C.c_float, C.c_int, _vp]
     L.sea_adaln_qkv.restype = C.c_int
+    L.sea_splitk_finish.argtypes = [C.POINTER(SeaSplitkGroup), C.c_int, C.c_int, _vp]
+    L.sea_splitk_finish.restype = C.c_int
     L.sea_run_list.argtypes = [C.POINTER(SeaLaunchRec), C.c_int, _vp]
     L.sea_run_list.restype = C.c_int
     L.sea_run_list_steps.argtypes = [C.POINTER(SeaLaunchRec), C.c_int, C.POINTER(SeaStepPatch), C.c_int, C.c_int, C.c_int, _vp]
@@ -324,7 +334,7 @@ def lib() -> C.CDLL:
 
 ABI_STRUCTS = (SeaGemmGroup, SeaQkvGroup, SeaQkvCommon, SeaAttnProblem, SeaAttnParams, SeaNormGroup, SeaSiluGroup,
                SeaIbParams, SeaWgradGroup, SeaNormBwdGroup, SeaSiluBwdGroup, SeaIbBwdParams, SeaAttnBwdProblem, SeaAttnBwdParams,
-               SeaDropout, SeaLaunchRec, SeaGemmNormGroup, SeaExchangeTail, SeaMlpGroup, SeaMlp2Group, SeaKvNorm, SeaKvField, SeaKvPair, SeaKvLayer, SeaKvGlobal, SeaStepPatch, SeaRowChain, SeaAdalnGroup, SeaAdalnQkv)
+               SeaDropout, SeaLaunchRec, SeaGemmNormGroup, SeaExchangeTail, SeaMlpGroup, SeaMlp2Group, SeaKvNorm, SeaKvField, SeaKvPair, SeaKvLayer, SeaKvGlobal, SeaStepPatch, SeaRowChain, SeaAdalnGroup, SeaAdalnQkv, SeaSplitkGroup)
 
 EXPORTED_SYMBOLS = (
     "sea_abi_version", "sea_last_error", "sea_struct_sizes", "sea_device_info", "sea_gemm_grouped", "sea_qkv_rope_grouped",
@@ -332,7 +342,7 @@ EXPORTED_SYMBOLS = (
     "sea_mse_fwd_bwd", "sea_relative_mse", "sea_adamw_flat",
     "sea_wgrad_grouped", "sea_transpose_weights", "sea_rownorm_bwd", "sea_silu_outer_bwd", "sea_ib_bwd",
     "sea_attention_bwd", "sea_dropout_mask", "sea_run_list", "sea_run_list_steps", "sea_unpatchify", "sea_gemm_rownorm", "sea_exchange_tail", "sea_patchify", "sea_silu_outer_ib", "sea_mlp_fc1_ln_gelu", "sea_mlp_fc2_proj_norm", "sea_kv_rollout", "sea_kv_arena_words", "sea_kv_debug_stamps",
-    "sea_gemm_fewrows", "sea_qkv_rope_fewrows", "sea_row_chain", "sea_row_chain_riders", "sea_gemm_adaln", "sea_mlp_block", "sea_adaln_qkv",
+    "sea_gemm_fewrows", "sea_qkv_rope_fewrows", "sea_row_chain", "sea_row_chain_riders", "sea_gemm_adaln", "sea_mlp_block", "sea_adaln_qkv", "sea_splitk_finish",
 )
 
 

@@ -33,7 +33,7 @@ extern "C" int sea_struct_sizes(int* out, int cap) {
                          (int)sizeof(SeaWgradGroup), (int)sizeof(SeaNormBwdGroup), (int)sizeof(SeaSiluBwdGroup), (int)sizeof(SeaIbBwdParams),
                          (int)sizeof(SeaAttnBwdProblem), (int)sizeof(SeaAttnBwdParams), (int)sizeof(SeaDropout), (int)sizeof(SeaLaunchRec),
                          (int)sizeof(SeaGemmNormGroup), (int)sizeof(SeaExchangeTail), (int)sizeof(SeaMlpGroup), (int)sizeof(SeaMlp2Group), (int)sizeof(SeaKvNorm), (int)sizeof(SeaKvField),
-                         (int)sizeof(SeaKvPair), (int)sizeof(SeaKvLayer), (int)sizeof(SeaKvGlobal), (int)sizeof(SeaStepPatch), (int)sizeof(SeaRowChain), (int)sizeof(SeaAdalnGroup), (int)sizeof(SeaAdalnQkv)};
+                         (int)sizeof(SeaKvPair), (int)sizeof(SeaKvLayer), (int)sizeof(SeaKvGlobal), (int)sizeof(SeaStepPatch), (int)sizeof(SeaRowChain), (int)sizeof(SeaAdalnGroup), (int)sizeof(SeaAdalnQkv), (int)sizeof(SeaSplitkGroup)};
     const int n = (int)(sizeof(sizes) / sizeof(sizes[0]));
     for (int i = 0; i < n && i < cap; ++i) out[i] = sizes[i];
     return n;
@@ -63,6 +63,7 @@ extern "C" int sea_run_list(const SeaLaunchRec* recs, int n_recs, void* stream) 
             case SEA_OP_CHAIN: rc = sea_row_chain_riders(static_cast<const SeaRowChain*>(R.p0), R.n, static_cast<const SeaQkvCommon*>(R.p1), reinterpret_cast<const SeaGemmGroup*>(static_cast<intptr_t>(R.l0)),
                                                          R.i0, R.i1, R.i2, reinterpret_cast<const SeaIbParams*>(static_cast<intptr_t>(R.l1)), R.f0, R.dtype, stream); break;
             case SEA_OP_ADALN: rc = sea_gemm_adaln(static_cast<const SeaAdalnGroup*>(R.p0), R.n, R.f0, R.dtype, stream); break;
+            case SEA_OP_SPLITK: rc = sea_splitk_finish(static_cast<const SeaSplitkGroup*>(R.p0), R.n, R.dtype, stream); break;
             case SEA_OP_MLPB: rc = sea_mlp_block(static_cast<const SeaMlpGroup*>(R.p0), static_cast<const SeaMlp2Group*>(R.p1), R.n, R.f0, R.dtype, stream); break;
             case SEA_OP_AQKV: rc = sea_adaln_qkv(static_cast<const SeaAdalnQkv*>(R.p0), R.n, static_cast<const SeaQkvCommon*>(R.p1), reinterpret_cast<const SeaGemmGroup*>(static_cast<intptr_t>(R.l0)), R.i0,
                                                  reinterpret_cast<const SeaSiluGroup*>(static_cast<intptr_t>(R.l1)), R.i1, reinterpret_cast<const float*>(static_cast<intptr_t>(R.l2)), R.i2,

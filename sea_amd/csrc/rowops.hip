@@ -813,3 +813,68 @@ extern "C" int sea_patchify(const float* in, const int32_t* index_map, const flo
     return SEA_OK;
 }
 
+// ------------------------------------------------------------------------------------------------ split-K finish
+// out = sum_s P[s] + bias * bias_scale + R  (fp32 sums in split order: deterministic), as fp32 and / or in the activation dtype: the pass behind a
+// sea_gemm_grouped launch whose groups are K-slices of one product writing fp32 partial matrices (skinny M against K = 16384: the reference's own widths).
+#define SEA_MAX_SPLITK_GROUPS 8
+struct SplitkLaunch {
+    SeaSplitkGroup g[SEA_MAX_SPLITK_GROUPS];
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void splitk_finish_kernel(const SplitkLaunch L) {
+    const SeaSplitkGroup& G = L.g[blockIdx.y];
+    const int n4 = G.N >> 2;
+    const long total = (long)G.M * n4;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int m = (int)(idx / n4), n = (int)(idx - (long)m * n4) * 4;
+        float v[4];
+        load4(G.P + (int64_t)m * G.ldp + n, v);
+        for (int s_ = 1; s_ < G.S; ++s_) {
+            float p[4];
+            load4(G.P + (int64_t)s_ * G.p_stride + (int64_t)m * G.ldp + n, p);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] += p[q];
+        }
+        if (G.bias != nullptr) {
+            float b[4];
+            load4(G.bias + n, b);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] += b[q] * G.bias_scale;
+        }
+        if (G.R != nullptr) {
+            float r[4];
+            load4(G.R + (int64_t)m * G.ldr + n, r);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] += r[q];
+        }
+        if (G.C32 != nullptr) store4(G.C32 + (int64_t)m * G.ldc32 + n, v[0], v[1], v[2], v[3]);
+        if (G.Cact != nullptr) store4(static_cast<T*>(G.Cact) + (int64_t)m * G.ldcact + n, v[0], v[1], v[2], v[3]);
+    }
+}
+
+extern "C" int sea_splitk_finish(const SeaSplitkGroup* groups, int n_groups, int dtype, void* stream) {
+    SEA_REQUIRE(groups != nullptr && n_groups >= 1 && n_groups <= SEA_MAX_SPLITK_GROUPS, "sea_splitk_finish: n_groups=%d out of range", n_groups);
+    SEA_REQUIRE(dtype == SEA_F32 || dtype == SEA_BF16, "sea_splitk_finish: bad dtype %d", dtype);
+    SplitkLaunch L;
+    memset(&L, 0, sizeof(L));
+    long most = 0;
+    for (int i = 0; i < n_groups; ++i) {
+        const SeaSplitkGroup& G = groups[i];
+        SEA_REQUIRE(G.P && G.S >= 1 && G.M >= 1 && G.N >= 4 && G.N % 4 == 0 && G.ldp % 4 == 0 && G.ldp >= G.N && G.p_stride % 4 == 0 && (G.C32 || G.Cact),
+                    "sea_splitk_finish[%d]: null pointer or bad shape S=%d M=%d N=%d ldp=%d", i, G.S, G.M, G.N, G.ldp);
+        SEA_REQUIRE((!G.R || (G.ldr % 4 == 0 && G.ldr >= G.N)) && (!G.C32 || (G.ldc32 % 4 == 0 && G.ldc32 >= G.N)) && (!G.Cact || (G.ldcact % 4 == 0 && G.ldcact >= G.N)),
+                    "sea_splitk_finish[%d]: bad strides", i);
+        SEA_REQUIRE(sea_aligned16(G.P) && sea_aligned16(G.bias) && sea_aligned16(G.R) && sea_aligned16(G.C32) && sea_aligned16(G.Cact), "sea_splitk_finish[%d]: pointers must be 16-byte aligned", i);
+        L.g[i] = G;
+        const long items = (long)G.M * (G.N / 4);
+        most = items > most ? items : most;
+    }
+    long bx = (most + 255) / 256;
+    bx = bx > 2048 ? 2048 : bx;
+    const dim3 grid((unsigned)bx, (unsigned)n_groups);
+    if (dtype == SEA_BF16) splitk_finish_kernel<__bf16><<<grid, dim3(256), 0, static_cast<hipStream_t>(stream)>>>(L);
+    else splitk_finish_kernel<float><<<grid, dim3(256), 0, static_cast<hipStream_t>(stream)>>>(L);
+    SEA_CHECK_LAUNCH("sea_splitk_finish");
+    return SEA_OK;
+}

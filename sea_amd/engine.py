@@ -318,10 +318,53 @@ class Plan:
         self._cur.append(_Rec(None, [], "join", None, lane))
 
     # ------------------------------------------------------------------ record builders
+    def _gemm_splitk(self, chunk: List[dict], name: str) -> bool:
+        """Split-K form of a launch of skinny-M Linear layers with a very long contraction (the MLP of configs/multiphase_flow.py:112-141 at M = B T = 796: fc2 forward and
+        fc1's data gradient, 2048 x 16384): at 128 x 128 tiles such a launch is 224 workgroups each walking K = 16384 alone; four K-quarters as groups of ONE
+        sea_gemm_grouped launch (fp32 partial matrices, two workgroups per CU on the two-stage ring) + sea_splitk_finish: 161 -> 128 + 10 us (tools/skinny_probe.py).
+        bf16, plain epilogue (bias / residual / outputs only).  SEA_PLAN=splitk=0 keeps the single launch."""
+        S = 4
+        if self.dt != torch.bfloat16 or _switches.plan("splitk", "1") == "0" or len(chunk) * S > N.MAX_GROUPS or len(chunk) > N.MAX_SPLITK_GROUPS:
+            return False
+        tiles = 0
+        for d in chunk:
+            A, W = d.get("A"), d["W"]
+            if (A is None or d.get("silu") is not None or d.get("act", 0) != 0 or d.get("drop") is not None or d.get("n_seg", 1) != 1 or d.get("Z") is not None
+                    or d.get("R_is_x") is not None or d.get("ldr") is not None or d.get("ldc32") is not None or d.get("M") is not None):
+                return False
+            Mg, Ng, Kg = A.shape[-2], W.shape[0], W.shape[1]
+            if Kg < 8192 or Kg % (S * 64) != 0 or Mg > 1024 or Ng % 4 != 0 or A.dim() != 2:
+                return False
+            tiles += ((Mg + 127) // 128) * ((Ng + 127) // 128)
+        if tiles >= 384:
+            return False
+        parts, fin = [], (N.SeaSplitkGroup * len(chunk))()
+        for f_, d in zip(fin, chunk):
+            A, W = d["A"], d["W"]
+            Mg, Ng, ks = A.shape[0], W.shape[0], W.shape[1] // S
+            P = self._buf(S, Mg, Ng, dtype=torch.float32)
+            for q in range(S):
+                parts.append(dict(A=A[:, q * ks:(q + 1) * ks], W=W[:, q * ks:(q + 1) * ks], C32=P[q]))
+            R, C32, Cact, bias = d.get("R"), d.get("C32"), d.get("Cact"), d.get("bias")
+            f_.P, f_.p_stride, f_.S, f_.M, f_.N, f_.ldp = P.data_ptr(), P.stride(0), S, Mg, Ng, P.stride(1)
+            f_.bias, f_.bias_scale = N.ptr(bias), d.get("bias_scale", 1.0)
+            f_.R, f_.ldr = N.ptr(R), (R.stride(0) if R is not None else 0)
+            f_.C32, f_.ldc32 = N.ptr(C32), (C32.stride(0) if C32 is not None else 0)
+            f_.Cact, f_.ldcact = N.ptr(Cact), (Cact.stride(0) if Cact is not None else 0)
+        arr = (N.SeaGemmGroup * len(parts))()
+        for g, d in zip(arr, parts):
+            _fill_gemm(g, **d)
+        L = N.lib()
+        self._cur.append(self._rec(L.sea_gemm_grouped, [arr, len(parts), self.code], name + ".splitk", arr))
+        self._cur.append(self._rec(L.sea_splitk_finish, [fin, len(chunk), self.code], name, fin))
+        return True
+
     def _gemm(self, groups: List[dict], name: str) -> None:
         L = N.lib()
         for s in range(0, len(groups), N.MAX_GROUPS):
             chunk = groups[s:s + N.MAX_GROUPS]
+            if self._gemm_splitk(chunk, name):
+                continue
             arr = (N.SeaGemmGroup * len(chunk))()
             for g, d in zip(arr, chunk):
                 _fill_gemm(g, **d)
@@ -1438,6 +1481,8 @@ class Plan:
                 if a[8]:
                     relink.append((i, "l2", a, 7))   # the condition pointer of the row riders, patched at every bind
                 c.l3 = addr(r.keep[4]) if r.keep[4] is not None else 0
+            elif r.fn is L.sea_splitk_finish:
+                c.op, c.p0, c.n, c.dtype = N.OP_SPLITK, addr(a[0]), a[1], a[2]
             elif r.fn is L.sea_mlp_block:
                 c.op, c.p0, c.p1, c.n, c.f0, c.dtype = N.OP_MLPB, addr(a[0]), addr(a[1]), a[2], a[3], a[4]
             elif r.fn is L.sea_exchange_tail:

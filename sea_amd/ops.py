@@ -588,6 +588,19 @@ def patchify(fields: torch.Tensor, index_map: torch.Tensor, scale: torch.Tensor,
     return out
 
 
+def splitk_finish(groups: Sequence[Dict], dtype: torch.dtype) -> None:
+    """sea_splitk_finish: out = sum_s P[s] + bias * bias_scale + R; dicts with P f32 [S, M, N], optional bias / bias_scale / R, outputs C32 and / or Cact."""
+    arr = (N.SeaSplitkGroup * len(groups))()
+    for g, d in zip(arr, groups):
+        P, R, C32, Cact = d["P"], d.get("R"), d.get("C32"), d.get("Cact")
+        g.P, g.p_stride, g.S, g.M, g.N, g.ldp = P.data_ptr(), P.stride(0), P.shape[0], P.shape[1], P.shape[2], P.stride(1)
+        g.bias, g.bias_scale = N.ptr(d.get("bias")), d.get("bias_scale", 1.0)
+        g.R, g.ldr = N.ptr(R), (R.stride(0) if R is not None else 0)
+        g.C32, g.ldc32 = N.ptr(C32), (C32.stride(0) if C32 is not None else 0)
+        g.Cact, g.ldcact = N.ptr(Cact), (Cact.stride(0) if Cact is not None else 0)
+    N.check(N.lib().sea_splitk_finish(arr, len(groups), N.dtype_code(dtype), N.stream_ptr()), "sea_splitk_finish")
+
+
 def mlp_fc1_supported(dtype: torch.dtype, E: int, S: int) -> bool:
     """Shapes sea_mlp_fc1_ln_gelu instantiates (include/sea_hip.h)."""
     return dtype == torch.bfloat16 and (E, S) in ((256, 2048), (128, 1024))

@@ -115,6 +115,16 @@ def _extents(st, esz: int) -> Iterable[Tuple[str, int, int]]:
             yield "Yact", st.Yact, ((st.M - 1) * st.ldyact + (st.d if st.X else 2 * st.d)) * esz
         if st.Y32:
             yield "Y32", st.Y32, ((st.M - 1) * st.ldy32 + st.d) * f32
+    elif isinstance(st, N.SeaSplitkGroup):
+        yield "P", st.P, ((st.S - 1) * st.p_stride + (st.M - 1) * st.ldp + st.N) * f32
+        if st.bias:
+            yield "bias", st.bias, st.N * f32
+        if st.R:
+            yield "R", st.R, ((st.M - 1) * st.ldr + st.N) * f32
+        if st.C32:
+            yield "C32", st.C32, ((st.M - 1) * st.ldc32 + st.N) * f32
+        if st.Cact:
+            yield "Cact", st.Cact, ((st.M - 1) * st.ldcact + st.N) * esz
     elif isinstance(st, N.SeaAdalnQkv):
         E = st.E
         yield "X", st.X, ((st.M - 1) * st.ldx + E) * f32

@@ -892,6 +892,33 @@ def test_adaln_qkv_matches_the_three_launches(B, T, H, pos0, cap, third):
     assert rel(rC[0].float(), ref_r + rb) < 6e-3 and rel(rC[1].float(), ref_r) < 6e-3
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_splitk_finish_sums_partials_in_order(dtype):
+    """sea_splitk_finish against torch: S partial matrices (a strided view), bias with its scale, residual, both outputs; and K-slices of a product through
+    sea_gemm_grouped + the finish against the un-split launch."""
+    from sea_amd import ops
+
+    S, M, N = 4, 203, 512
+    Pw = rnd(S, M, N + 64, seed=2200)
+    P = Pw[:, :, :N]
+    bias, R = rnd(N, seed=2201), rnd(M, N, seed=2202)
+    C32, Cact = torch.empty(M, N, device=dev()), torch.empty(M, N, device=dev(), dtype=dtype)
+    ops.splitk_finish([dict(P=P, bias=bias, bias_scale=2.0, R=R, C32=C32, Cact=Cact)], dtype)
+    ref = ((P[0] + P[1]) + P[2]) + P[3] + bias * 2.0 + R
+    assert rel(C32, ref) < 1e-6 and rel(Cact.float(), ref) < tol(dtype, f32=1e-6)
+    if dtype == torch.bfloat16:
+        K = 8192
+        A, W = rnd(M, K, dtype=dtype, seed=2203), rnd(N, K, dtype=dtype, scale=K ** -0.5, seed=2204)
+        whole = torch.empty(M, N, device=dev())
+        ops.gemm_grouped([dict(A=A, W=W, bias=bias, R=R, C32=whole)], dtype)
+        parts = torch.empty(S, M, N, device=dev())
+        ks = K // S
+        ops.gemm_grouped([dict(A=A[:, q * ks:(q + 1) * ks], W=W[:, q * ks:(q + 1) * ks], C32=parts[q]) for q in range(S)], dtype)
+        out = torch.empty(M, N, device=dev())
+        ops.splitk_finish([dict(P=parts, bias=bias, R=R, C32=out)], dtype)
+        assert rel(out, whole) < 1e-5
+
+
 def test_adaln_qkv_refuses_other_shapes():
     from sea_amd import ops
 
