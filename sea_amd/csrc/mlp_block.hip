@@ -663,7 +663,8 @@ extern "C" int sea_mlp_block(const SeaMlpGroup* g1, const SeaMlp2Group* g2, int 
     }
     L.xcd_start[n_groups] = xcds;
     static const int xcd_excl = sea_tune("blk_xcd", 0);   // measured at cfg2: 55.5 us against 52.9 with the plain order (the second layer's loop 15.2 against 12.8: 32 CUs of an XCD asking one L2 for the same lines at once)
-    if (total > 256) {   // several rounds of workgroups: consecutive tiles (one field: one set of weights) on one XCD
+    static const int per_xcd_on = sea_tune("blk_perxcd", 1);   // tuning aid
+    if (total > 256 && per_xcd_on) {   // several rounds of workgroups: consecutive tiles (one field: one set of weights) on one XCD
         L.per_xcd = (total + 7) / 8;
         total = 8 * L.per_xcd;
     } else if (xcds <= 8 && xcd_excl) {   // one round, whole XCDs per group (32 CUs each)
