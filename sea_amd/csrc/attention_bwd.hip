@@ -108,6 +108,27 @@ __device__ __forceinline__ void zero_tile_padding(char* base, int n_tiles, int t
 // inverse rotation of one (even, odd) pair: the forward was (e', o') = (e c - o s, e s + o c)
 __device__ __forceinline__ void unrope(float& e, float& o, const float2 cs) { unrope_pair(e, o, cs.x, cs.y); }   // scalar-lane ops, see sea_common.hpp
 
+// Workgroup order and tile pairing (mode bits of the kernels' second argument).
+//   The plain order (decode_attn_block: tile-major, heaviest tiles of ALL (trajectory, head) pairs first) has every XCD walk its 24 pairs' K / V
+//   (dQ kernel) or Q / dO rows (dK/dV kernel) at once: 6 MB against a 4 MB L2 — the L2 hit rate of the streamed tiles is ~0 and the launch pair moves
+//   8.5x its operand bytes (PMC, profiles/r03_train_cfg3_pmc_traffic.json).  A pair-major order keeps an XCD on a few pairs at a time, but with one
+//   causal tile per workgroup (1 .. 32 tile units of work) its tail is the last pair's heaviest tile running alone (measured: 322 -> 341 us).
+//   ATTNB_PAIRED: a workgroup takes tile t AND tile n - 1 - t, one after the other — every workgroup carries n + 1 units, so any order is balanced;
+//   ATTNB_XCD:    XCD x (the hardware deals consecutive workgroups to the 8 XCDs in turn) owns the pairs x, x + 8, ..., and walks them pair-major:
+//                 the 16 workgroups of a pair run together and their streamed rows (0.26 MB per pair) stay in that XCD's L2.
+enum { ATTNB_XCD = 1, ATTNB_PAIRED = 2 };
+__device__ __forceinline__ void decode_attn_block_bwd(int& tile, int& bh, int& z, const int mode) {
+    const int nbz = gridDim.y * gridDim.z;
+    if (!(mode & ATTNB_XCD) || (nbz & 7)) return decode_attn_block(tile, bh, z);
+    const int L = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    const int x = L & 7, j = L >> 3;
+    const int pl = j / (int)gridDim.x;
+    tile = j - pl * gridDim.x;
+    const int pair = x + 8 * pl;
+    z = pair / (int)gridDim.y;
+    bh = pair - z * gridDim.y;
+}
+
 // ---------------------------------------------------------------------------------------------- dQ (+ delta)
 // DROP and (per tile) MASK are compile-time: both kernels are VALU-issue-bound (PMC: VALU busy 80-100 %), so the un-dropped,
 // off-diagonal tile — the common case — carries no select, no dropout factor and one v_fma + one v_exp per probability.
@@ -118,13 +139,9 @@ template <typename T, int HD>
 constexpr int attn_bwd_min_waves() { return (sizeof(T) == 2 && HD <= 32) ? SEA_ATTNB_WPE : 1; }
 
 template <typename T, int HD, bool DROP>
-__global__ __launch_bounds__(256, (attn_bwd_min_waves<T, HD>())) void attn_bwd_dq_kernel(const SeaAttnBwdParams P) {
+__device__ __forceinline__ void attn_bwd_dq_tile(const SeaAttnBwdParams& P, char* smem, const int qt, const int bh, const int zp) {
     using C = BwdCfg<T, HD>;
-    __shared__ __attribute__((aligned(16))) char smem[C::NBUF * 2 * C::TILE];  // NBUF buffers x (K tile, V tile)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, g = lane >> 4;
-    int tile_, bh, zp;
-    decode_attn_block(tile_, bh, zp);
-    const int qt = gridDim.x - 1 - tile_;  // heaviest query tiles first
     const int b = bh / P.H, h = bh - b * P.H;
     const SeaAttnBwdProblem& pr = P.p[zp];
     const int Tq = P.Tq, Tk = P.Tk;
@@ -268,15 +285,24 @@ __global__ __launch_bounds__(256, (attn_bwd_min_waves<T, HD>())) void attn_bwd_d
     }
 }
 
+template <typename T, int HD, bool DROP>
+__global__ __launch_bounds__(256, (attn_bwd_min_waves<T, HD>())) void attn_bwd_dq_kernel(const SeaAttnBwdParams P, const int mode) {
+    using C = BwdCfg<T, HD>;
+    __shared__ __attribute__((aligned(16))) char smem[C::NBUF * 2 * C::TILE];  // NBUF buffers x (K tile, V tile)
+    int tile_, bh, zp;
+    decode_attn_block_bwd(tile_, bh, zp, mode);
+    const int n_qt = (P.Tq + 63) / 64;
+    attn_bwd_dq_tile<T, HD, DROP>(P, smem, n_qt - 1 - tile_, bh, zp);  // heaviest query tiles first
+    // ATTNB_PAIRED (grid.x = ceil(n_qt / 2)): then the light partner (every wave has passed the tile loop's last barrier: the buffers are free)
+    if ((mode & ATTNB_PAIRED) && tile_ != n_qt - 1 - tile_) attn_bwd_dq_tile<T, HD, DROP>(P, smem, tile_, bh, zp);
+}
+
 // ---------------------------------------------------------------------------------------------- dK, dV
 template <typename T, int HD, bool DROP>
-__global__ __launch_bounds__(256, (attn_bwd_min_waves<T, HD>())) void attn_bwd_dkv_kernel(const SeaAttnBwdParams P) {
+__device__ __forceinline__ void attn_bwd_dkv_tile(const SeaAttnBwdParams& P, char* smem, const int kb, const int bh, const int zp) {
     using C = BwdCfg<T, HD>;
     constexpr int VEC_OFF = C::NBUF * 2 * C::TILE;
-    __shared__ __attribute__((aligned(16))) char smem[VEC_OFF + 2 * 2 * 64 * 4];  // NBUF x (Q tile, dO tile) + 2 x (lse, delta)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, g = lane >> 4;
-    int kb, bh, zp;  // key tile: the first key tiles are seen by the most queries -> ascending order is heaviest-first
-    decode_attn_block(kb, bh, zp);
     const int b = bh / P.H, h = bh - b * P.H;
     const SeaAttnBwdProblem& pr = P.p[zp];
     const int Tq = P.Tq, Tk = P.Tk;
@@ -448,15 +474,37 @@ __global__ __launch_bounds__(256, (attn_bwd_min_waves<T, HD>())) void attn_bwd_d
     }
 }
 
+template <typename T, int HD, bool DROP>
+__global__ __launch_bounds__(256, (attn_bwd_min_waves<T, HD>())) void attn_bwd_dkv_kernel(const SeaAttnBwdParams P, const int mode) {
+    using C = BwdCfg<T, HD>;
+    constexpr int VEC_OFF = C::NBUF * 2 * C::TILE;
+    __shared__ __attribute__((aligned(16))) char smem[VEC_OFF + 2 * 2 * 64 * 4];  // NBUF x (Q tile, dO tile) + 2 x (lse, delta)
+    int kb, bh, zp;  // key tile: the first key tiles are seen by the most queries -> ascending order is heaviest-first
+    decode_attn_block_bwd(kb, bh, zp, mode);
+    attn_bwd_dkv_tile<T, HD, DROP>(P, smem, kb, bh, zp);
+    if (mode & ATTNB_PAIRED) {   // grid.x = ceil(n_kt / 2): then the light partner tile
+        const int n_kt = (P.Tk + 63) / 64;
+        __syncthreads();         // (a tile with no visible query tile never enters the loop and its barriers)
+        if (kb != n_kt - 1 - kb) attn_bwd_dkv_tile<T, HD, DROP>(P, smem, n_kt - 1 - kb, bh, zp);
+    }
+}
+
 template <typename T, int HD>
 static void launch_bwd(const SeaAttnBwdParams& P, hipStream_t s) {
     const dim3 block(256), gq((P.Tq + 63) / 64, P.B * P.H, P.n_problems), gk((P.Tk + 63) / 64, P.B * P.H, P.n_problems);
+    // paired tiles + XCD-local pair-major order for launches of at least 4096 workgroups (SEA_TUNE=attnb_mode=0..3 forces the mode bits)
+    const int forced = sea_tune("attnb_mode", -1);   // read per call (tests force every mode in one process)
+    const long nq = (long)gq.x * gq.y * gq.z, nk = (long)gk.x * gk.y * gk.z;
+    const int mq = forced >= 0 ? forced : (nq >= 4096 ? (ATTNB_PAIRED | ATTNB_XCD) : 0), mk = forced >= 0 ? forced : (nk >= 4096 ? (ATTNB_PAIRED | ATTNB_XCD) : 0);
+    dim3 gq2 = gq, gk2 = gk;
+    if (mq & ATTNB_PAIRED) gq2.x = (gq.x + 1) / 2;
+    if (mk & ATTNB_PAIRED) gk2.x = (gk.x + 1) / 2;
     if (P.drop.thr > 0) {
-        attn_bwd_dq_kernel<T, HD, true><<<gq, block, 0, s>>>(P);
-        attn_bwd_dkv_kernel<T, HD, true><<<gk, block, 0, s>>>(P);
+        attn_bwd_dq_kernel<T, HD, true><<<gq2, block, 0, s>>>(P, mq);
+        attn_bwd_dkv_kernel<T, HD, true><<<gk2, block, 0, s>>>(P, mk);
     } else {
-        attn_bwd_dq_kernel<T, HD, false><<<gq, block, 0, s>>>(P);
-        attn_bwd_dkv_kernel<T, HD, false><<<gk, block, 0, s>>>(P);
+        attn_bwd_dq_kernel<T, HD, false><<<gq2, block, 0, s>>>(P, mq);
+        attn_bwd_dkv_kernel<T, HD, false><<<gk2, block, 0, s>>>(P, mk);
     }
 }
 

@@ -1,5 +1,6 @@
 """Backward kernels (through the C ABI) against torch.autograd on the same fp32 formulas, on the MI355X."""
 import math
+import os
 
 import pytest
 import torch
@@ -294,6 +295,49 @@ def test_attention_backward_head_dim_256(dtype, T, src_len):
 def test_attention_backward_full_length(dtype, hd):
     """T = 2024 (cfg3's sequence length: 32 key tiles per query tile, the multi-tile dK/dV walk) at the two head dims of the cfg2 / cfg3 model."""
     _attention_backward_case(dtype, hd, 2024, 0, B=1, H=2)
+
+
+@pytest.mark.parametrize("mode", [1, 2, 3])
+@pytest.mark.parametrize("dtype,hd,T,src_len,B,H", [(torch.bfloat16, 32, 330, 0, 2, 4), (torch.bfloat16, 16, 257, 2, 1, 8), (torch.float32, 32, 130, 0, 2, 3),
+                                                  (torch.bfloat16, 32, 64, 0, 1, 8), (torch.float32, 16, 200, 3, 4, 2)])
+def test_attention_backward_paired_tiles_and_xcd_local_order(monkeypatch, mode, dtype, hd, T, src_len, B, H):
+    """The long-launch forms of the backward kernels (attention_bwd.hip: ATTNB_XCD = 1, ATTNB_PAIRED = 2; chosen by themselves from 4096 workgroups), forced
+    on short launches: odd and even tile counts (the middle tile has no partner), one tile, B * H a multiple of 8 (the XCD-local order) and not (its fallback)."""
+    monkeypatch.setenv("SEA_TUNE", f"attnb_mode={mode}")
+    _attention_backward_case(dtype, hd, T, src_len, B=B, H=H)
+
+
+def test_attention_backward_long_launch_takes_the_paired_form_and_equals_the_plain_one():
+    """B * H = 16 at T = 2024 is 4096 workgroups: the launch picks the paired, XCD-local form itself; bitwise equal to the plain order (no atomics either way)."""
+    from sea_amd import ops
+
+    B, H, hd, T = 2, 8, 32, 2024
+    dt = torch.bfloat16
+    cap, E = T, H * hd
+    Q = (rnd(B, H, T, hd, seed=1) * hd ** -0.25).to(dt)
+    K = (rnd(B, H, cap, hd, seed=2) * hd ** -0.25).to(dt)
+    V = rnd(B, H, cap, hd, seed=3).to(dt)
+    O = torch.empty(B, T, E, device=dev(), dtype=dt)
+    LSE = torch.empty(B, H, T, device=dev())
+    ops.attention_fwd([dict(Q=Q, K=K, Vt=V.transpose(2, 3).contiguous(), O=O, LSE=LSE)], B, H, hd, T, T, cap, 0, 0, dt)
+    dO = rnd(B, T, E, dtype=dt, seed=4)
+    table = _rope_table(hd, cap)
+    outs = []
+    for tune in (None, "attnb_mode=0"):
+        if tune is None:
+            os.environ.pop("SEA_TUNE", None)
+        else:
+            os.environ["SEA_TUNE"] = tune
+        try:
+            g = [torch.full((B * T, E), float("nan"), device=dev(), dtype=dt) for _ in range(3)]
+            delta = torch.empty(B, H, T, device=dev())
+            ops.attention_bwd([dict(Q=Q, K=K, V=V, O=O, dO=dO, LSE=LSE, delta=delta, dQ=g[0], dK=g[1], dV=g[2])], table, B, H, hd, T, T, cap, 0, 0, ops.q_scale(hd), dt)
+            torch.cuda.synchronize()
+            outs.append(g)
+        finally:
+            os.environ.pop("SEA_TUNE", None)
+    for a, b in zip(*outs):
+        assert torch.isfinite(a.float()).all() and torch.equal(a, b)
 
 
 def _attention_backward_case(dtype, hd, T, src_len, B, H):
