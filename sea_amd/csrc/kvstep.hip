@@ -1168,7 +1168,7 @@ __device__ __forceinline__ void gr_wait_first(const unsigned long long* g, uint3
 }
 
 template <int KE, typename T, int HD>
-__device__ __attribute__((noinline)) void role_self(const KvPersist& A, float* sm, int i, int h) {
+__device__ __forceinline__ void role_self(const KvPersist& A, float* sm, int i, int h) {
     constexpr int E = KE;
     const int H = A.G.H, F = A.G.F, cap = A.G.cap;
     const int tid = threadIdx.x, nth = 512;
@@ -1220,7 +1220,7 @@ __device__ __attribute__((noinline)) void role_self(const KvPersist& A, float* s
 }
 
 template <int KE, int KD, typename T>
-__device__ __attribute__((noinline)) void role_oproj(const KvPersist& A, float* sm, int i) {
+__device__ __forceinline__ void role_oproj(const KvPersist& A, float* sm, int i) {
     constexpr int E = KE, D = KD;
     const int F = A.G.F;
     const int tid = threadIdx.x, nth = 512;
@@ -1278,7 +1278,7 @@ __device__ __attribute__((noinline)) void role_oproj(const KvPersist& A, float* 
 }
 
 template <int KD, typename T, int HD>
-__device__ __attribute__((noinline)) void role_cross(const KvPersist& A, float* sm, int p, int h) {
+__device__ __forceinline__ void role_cross(const KvPersist& A, float* sm, int p, int h) {
     constexpr int D = KD;
     const int H = A.G.H, F = A.G.F, cap = A.G.cap;
     const int tid = threadIdx.x, nth = 512;
@@ -1343,7 +1343,7 @@ __device__ __attribute__((noinline)) void role_cross(const KvPersist& A, float* 
 }
 
 template <int KE, int KD, typename T, int NF, int I>
-__device__ __attribute__((noinline)) void role_tail(const KvPersist& A, float* sm) {
+__device__ __forceinline__ void role_tail(const KvPersist& A, float* sm) {
     constexpr bool HAS_DOWN = I < NF - 1;
     constexpr int NNEW = I;
     constexpr int NT_2D = tiles_per_wave(2 * KD, 8), NT_D = tiles_per_wave(KD, 8), NT_E = tiles_per_wave(KE, 8);
@@ -1519,7 +1519,7 @@ __device__ __forceinline__ void role_tail_dispatch(const KvPersist& A, float* sm
 
 // fc1 rows [k r1, (k+1) r1) and fc2 rows [k r2, (k+1) r2) of field i.  LDS: xs[E] ns[E] nsT[E] hs[S] ys[128] red[32]
 template <int KE, typename T>
-__device__ __attribute__((noinline)) void role_fc(const KvPersist& A, float* sm, int i, int k) {
+__device__ __forceinline__ void role_fc(const KvPersist& A, float* sm, int i, int k) {
     constexpr int E = KE, EPC = ActTraits<T>::EPC;
     const int S = A.G.S, exch = A.G.exchange;
     const int tid = threadIdx.x, nth = 512;
@@ -1587,7 +1587,7 @@ __device__ __attribute__((noinline)) void role_fc(const KvPersist& A, float* sm,
 }
 
 template <int KE, typename T>
-__device__ __attribute__((noinline)) void role_proj(const KvPersist& A, float* sm, int i) {
+__device__ __forceinline__ void role_proj(const KvPersist& A, float* sm, int i) {
     constexpr int E = KE;
     const int F = A.G.F;
     const int tid = threadIdx.x, nth = 512;
@@ -1627,7 +1627,12 @@ __device__ __attribute__((noinline)) void role_proj(const KvPersist& A, float* s
 }
 
 template <int KE, typename T, int HDS, int HDC>
-__global__ __launch_bounds__(512) void kv_persistent_kernel(const KvPersist A) {
+__global__ __launch_bounds__(512) void kv_persistent_kernel(const KvPersist A_) {
+    // The roles index the per-field / per-pair tables of the argument struct with their (workgroup-uniform) field and pair numbers.  Through the by-value
+    // parameter the compiler first copies the whole 2.3-3.1 KB struct to SCRATCH ("memcpy-split": one private copy per lane, flat addressing) and indexes
+    // that; through the kernarg segment itself the same reads are scalar loads of constant memory and the kernel needs no scratch at all.
+    const KvPersist& A = *(const KvPersist*)__builtin_amdgcn_kernarg_segment_ptr();
+    (void)A_;
     extern __shared__ __attribute__((aligned(16))) float sm[];
     constexpr int KD = KE / 2;
     const int F = A.G.F, H = A.G.H, ex = A.G.exchange;
