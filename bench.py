@@ -648,10 +648,17 @@ def run_rank(args):
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    # SEA_DP_REHEARSE=1 (sea_amd/parallel.py) at N = 1: a process group of one RCCL rank, every collective of the N > 1 path issued — the data-parallel
+    # branch of the train leg (broadcast, the three gradient slices under the backward, the timed all-reduce, the sync check) run on the one GPU of a test box
+    rehearse = world == 1 and os.environ.get("SEA_DP_REHEARSE", "0") == "1"
+    if world > 1 or rehearse:
         import torch.distributed as dist_mod
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if rehearse:
+            os.environ.setdefault("MASTER_PORT", "29517")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         dist_mod.init_process_group("nccl", device_id=dev)
         dist = dist_mod
     legs = {"all": ("rollout", "train", "kv", "shipped"), "rollout": ("rollout",), "train": ("train",), "kv": ("kv",), "shipped": ("shipped",)}[args.mode]

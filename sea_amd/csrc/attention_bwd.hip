@@ -492,10 +492,13 @@ __global__ __launch_bounds__(256, (attn_bwd_min_waves<T, HD>())) void attn_bwd_d
 template <typename T, int HD>
 static void launch_bwd(const SeaAttnBwdParams& P, hipStream_t s) {
     const dim3 block(256), gq((P.Tq + 63) / 64, P.B * P.H, P.n_problems), gk((P.Tk + 63) / 64, P.B * P.H, P.n_problems);
-    // paired tiles + XCD-local pair-major order for launches of at least 4096 workgroups (SEA_TUNE=attnb_mode=0..3 forces the mode bits)
+    // paired tiles + XCD-local pair-major order for launches of at least 4096 workgroups at head dims >= 32 (SEA_TUNE=attnb_mode=0..3 forces the mode bits).
+    // Measured at cfg3 (tools/bench_attn_bwd.py, tools/pmc_attnb.py): self (hd 32, 6144 workgroups) 323 -> 320 us with the pair's HBM reads 1599 -> 331 MB;
+    // cross (hd 16, 4096 workgroups) 183 -> 191 us (387 -> 160 MB): at hd 16 a pair's rows are half the bytes and the plain order's finer-grained tail wins.
     const int forced = sea_tune("attnb_mode", -1);   // read per call (tests force every mode in one process)
     const long nq = (long)gq.x * gq.y * gq.z, nk = (long)gk.x * gk.y * gk.z;
-    const int mq = forced >= 0 ? forced : (nq >= 4096 ? (ATTNB_PAIRED | ATTNB_XCD) : 0), mk = forced >= 0 ? forced : (nk >= 4096 ? (ATTNB_PAIRED | ATTNB_XCD) : 0);
+    const int long_mode = HD >= 32 ? (ATTNB_PAIRED | ATTNB_XCD) : 0;
+    const int mq = forced >= 0 ? forced : (nq >= 4096 ? long_mode : 0), mk = forced >= 0 ? forced : (nk >= 4096 ? long_mode : 0);
     dim3 gq2 = gq, gk2 = gk;
     if (mq & ATTNB_PAIRED) gq2.x = (gq.x + 1) / 2;
     if (mk & ATTNB_PAIRED) gk2.x = (gk.x + 1) / 2;

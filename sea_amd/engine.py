@@ -1742,7 +1742,10 @@ class TemporalEngine:
 
         world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
         if world == 1:
-            return False
+            from .parallel import rehearse
+
+            if not (rehearse() and dist.is_available() and dist.is_initialized()):   # (SEA_DP_REHEARSE=1: one rank issues the collectives of a larger world)
+                return False
         if self._dp_overlap is None or self._dp_overlap[0] != world:
             want = torch.tensor([0 if os.environ.get("SEA_DP_OVERLAP", "1") == "0" else 1], device=self.device, dtype=torch.int32)
             dist.all_reduce(want, op=dist.ReduceOp.MIN)

@@ -37,13 +37,20 @@ def shard_bounds(B: int, rank: int, world: int) -> Tuple[int, int]:
     return lo, lo + per + (1 if rank < extra else 0)
 
 
+def rehearse() -> bool:
+    """SEA_DP_REHEARSE=1: a process group of ONE rank issues every collective a larger world would (same slices, same order, same streams) instead of
+    skipping them — on a one-GPU box this is the only way the RCCL path (backend `nccl`) runs at all: library load, communicator set-up on our
+    buffers, the asynchronous slices beside the backward launches, their hand-over to the AdamW launch.  Off: world size 1 issues nothing."""
+    return os.environ.get("SEA_DP_REHEARSE", "0") == "1"
+
+
 def allreduce_flat_gradients(flat_grads: torch.Tensor, n_live: int, group: Optional[dist.ProcessGroup] = None) -> float:
     """SUM-all-reduce the live prefix of the flat gradient buffer in ONE collective; returns the grad_scale (1/world) that turns the
     sum into the mean inside the optimizer kernel."""
     if not dist.is_available() or not dist.is_initialized():
         return 1.0
     world = dist.get_world_size(group)
-    if world == 1:
+    if world == 1 and not rehearse():
         return 1.0
     dist.all_reduce(flat_grads[:n_live], op=dist.ReduceOp.SUM, group=group)
     return 1.0 / world
@@ -59,7 +66,8 @@ class OverlappedGradientReduce:
         self.grads, self.n_live, self.group = flat_grads, n_live, group
         self.world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
         # `overlap`: the engine's agreed decision (TemporalEngine.dp_overlap, frozen into the training plan); None (stand-alone use): this rank's switch
-        self.active = self.world > 1 and (os.environ.get("SEA_DP_OVERLAP", "1") != "0" if overlap is None else bool(overlap))
+        self.live = self.world > 1 or (rehearse() and dist.is_available() and dist.is_initialized())
+        self.active = self.live and (os.environ.get("SEA_DP_OVERLAP", "1") != "0" if overlap is None else bool(overlap))
         self.works: List = []
         self.done: List[Tuple[int, int]] = []
         self.calls = 0
@@ -70,7 +78,7 @@ class OverlappedGradientReduce:
         self.calls += 1
 
     def finish(self) -> float:
-        if self.world == 1:
+        if not self.live:
             return 1.0
         pos = 0
         for lo, hi in sorted(self.done) + [(self.n_live, self.n_live)]:

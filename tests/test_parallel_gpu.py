@@ -109,6 +109,52 @@ def test_train_step_world_n_equals_single_process_global_batch(world, cfg):
     assert np.array_equal(got[0][1], got[1][1])       # bit-identical across ranks
 
 
+def _rccl_worker(rank, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["SEA_DP_REHEARSE"] = "1"
+    torch.cuda.set_device(0)
+    try:
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        x, tgt, ib = _data()
+        from sea_amd.utils.train_utils import initialize_optimizer
+
+        m = _model()
+        eng = m.engine()
+        opt = initialize_optimizer(m, {"learning_rate": LR})
+        xs, ts, cs = (t.cuda().contiguous() for t in (x, tgt, ib))
+        calls = []
+        for _ in range(STEPS):
+            eng.train_step(xs, ts, cs, opt)
+            calls.append(int(eng.last_allreduce_calls))
+        torch.cuda.synchronize()
+        ret[0] = (eng.params.flat32[:eng.params.n_live].cpu().numpy(), calls, dist.get_backend())
+    except Exception as e:  # pragma: no cover
+        import traceback
+
+        ret[0] = repr(e) + "\n" + traceback.format_exc()
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+def test_rccl_collectives_rehearsed_on_one_rank():
+    """The RCCL path on the one GPU a test box has (SEA_DP_REHEARSE=1, sea_amd/parallel.py): a process group of ONE `nccl` rank issues the three gradient
+    collectives of a data-parallel step — two asynchronous slices under the backward, the rest behind it — on the engine's flat buffer.  A one-rank SUM is
+    the identity, so three AdamW steps must land on the single-process parameters (1e-6: the fp32 atomics of the weight gradients are unordered)."""
+    x, tgt, ib = _data()
+    _, p_ref = _run_steps(x, tgt, ib, 1, 0)
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_rccl_worker, args=(_free_port(), ret), nprocs=1, join=True)
+    got = ret[0]
+    assert not isinstance(got, str), got
+    p, calls, backend = got
+    assert backend == "nccl"
+    assert calls == [3] * STEPS, calls
+    assert np.abs(p - p_ref.numpy()).max() <= 2e-5
+
+
 # ---------------------------------------------------------------------------------------------------------------- the named entry: train(config, tracker)
 def _train_config(save_dir, fused, world):
     from sea_amd.configs import get_config
