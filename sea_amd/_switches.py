@@ -3,6 +3,8 @@
   SEA_AMD_DTYPE   fp32 | bf16            compute dtype of new models (TemporalModel.set_compute_dtype overrides)
   SEA_CHECK_PTRS  1                      audit every launch plan's device pointers at EVERY bind (default: at a plan's first bind) — sea_amd/ptrcheck.py
   SEA_DP_OVERLAP  0                      data-parallel step: ONE gradient all-reduce after the backward instead of slices under it
+  SEA_DP_REHEARSE 1                      a process group of ONE rank issues the data-parallel step's collectives instead of skipping them (sea_amd/parallel.py:
+                                           how the RCCL path runs on a one-GPU box: tests/test_parallel_gpu.py, `SEA_DP_REHEARSE=1 python bench.py --mode train`)
   SEA_PLAN        key=value,...          forms of the launch plans (what the tests force to compare every form with the default one):
                                            lanes=none|cond|all   parallel graph branches          graph_lanes=0      a captured graph replays its lanes in record order
                                            norm=0                Linear + row norm as two launches  xtail=0            a field's exchange tail as three launches
@@ -11,7 +13,8 @@
   SEA_KV          key=value,...          KV-cache rollout: fast=0 (generic step plan), hoist=0 (condition work per step), gemv=0 (step plan without the few-row launches of gemv.hip),
                                            loop=python (step loop in Python),
                                            force_err=1 (test hook: the persistent launch "reports" a hand-off that gave up)
-  SEA_TUNE        key=value,...          native tuning aids read by libsea_hip.so (sea_tune() in core.hip): kv_persist, kv_pre, gemm_norm_rows, gemm_tile, attn_split4, ...
+  SEA_TUNE        key=value,...          native tuning aids read by libsea_hip.so (sea_tune() in core.hip): kv_persist, kv_pre, gemm_norm_rows, gemm_tile, gemm256, attn_split4,
+                                           attnb_mode (attention backward: 1 XCD-local order, 2 paired causal tiles, 3 both, 0 neither), ...
   SEA_EXTRA_FLAGS "..."                  extra hipcc flags for `python -m sea_amd.build` (A/B builds)
 (tests only: SEA_TEST_DP_BACKEND=nccl runs the data-parallel tests one rank per GPU over RCCL.)
 """

@@ -53,25 +53,28 @@ constexpr int attn_min_waves() {
     return sizeof(T) == 2 ? (HD <= 16 ? SEA_ATTN_WPE16 : (HD == 32 ? SEA_ATTN_WPE32 : 1)) : 1;
 }
 
-template <typename T, int HD, int SPLIT, bool DROP>
-__global__ __launch_bounds__(256 * SPLIT, (attn_min_waves<T, HD, DROP>())) void attention_fwd_kernel(const SeaAttnParams P) {
+template <typename T, int HD, int SPLIT>
+struct AttnFwdLds {
     using C = AttnCfg<T, HD>;
-    constexpr int MERGE_BYTES = SPLIT > 1 ? (SPLIT - 1) * 256 * (2 + 4 * C::NDB) * 4 : 0;
+    static constexpr int MERGE_BYTES = SPLIT > 1 ? (SPLIT - 1) * 256 * (2 + 4 * C::NDB) * 4 : 0;
     // per group: double-buffered K and V^T tiles; ONE buffer where two do not fit the 160 KiB (f32 at head dim 256: 133 KiB per tile pair) — the
     // next tile still travels in registers under the MFMAs, its LDS write waits for a second barrier per tile
-    constexpr int NBUF = 2 * C::LDS_BYTES <= 160 * 1024 ? 2 : 1;
+    static constexpr int NBUF = 2 * C::LDS_BYTES <= 160 * 1024 ? 2 : 1;
     static_assert(NBUF == 2 || (SPLIT == 1 && HD >= C::CK), "single-buffer form: one wave group, no zero-padded key rows");
-    constexpr int RING_BYTES = SPLIT * NBUF * C::LDS_BYTES;
-    __shared__ __attribute__((aligned(16))) char smem_all[RING_BYTES > MERGE_BYTES ? RING_BYTES : MERGE_BYTES];
+    static constexpr int RING_BYTES = SPLIT * NBUF * C::LDS_BYTES;
+    static constexpr int BYTES = RING_BYTES > MERGE_BYTES ? RING_BYTES : MERGE_BYTES;
+};
+
+// one 64-row query tile `qt` of (trajectory, head) pair `bh` of problem `zp`
+template <typename T, int HD, int SPLIT, bool DROP>
+__device__ __forceinline__ void attention_fwd_tile(const SeaAttnParams& P, char* smem_all, const int qt, const int bh, const int zp) {
+    using C = AttnCfg<T, HD>;
+    constexpr int NBUF = AttnFwdLds<T, HD, SPLIT>::NBUF;
     const int grp = SPLIT > 1 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8)) : 0;  // wave-uniform
     char* smem = smem_all + grp * NBUF * C::LDS_BYTES;
 
     const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;  // tid, wave: inside the group
     const int r = lane & 15, g = lane >> 4;
-    const int n_qt = gridDim.x;
-    int tile_, bh, zp;
-    decode_attn_block(tile_, bh, zp);
-    const int qt = n_qt - 1 - tile_;  // heaviest (latest) query tiles first
     const int b = bh / P.H, h = bh - b * P.H;
     const SeaAttnProblem& pr = P.p[zp];
     const T* Qg = static_cast<const T*>(pr.Q) + (int64_t)bh * P.Tq * HD;
@@ -404,6 +407,34 @@ __global__ __launch_bounds__(256 * SPLIT, (attn_min_waves<T, HD, DROP>())) void 
     }
 }
 
+// Workgroup order of the LONG launches (one wave group per query tile, >= 4096 workgroups, head dim >= 32): as in the backward (attention_bwd.hip) a workgroup
+// takes query tile n - 1 - t and then tile t — n + 1 tile units each, so any order is balanced — and XCD x (the hardware deals consecutive workgroups to the
+// 8 XCDs in turn) owns the (trajectory, head) pairs x, x + 8, ... and walks them pair-major: the 16 workgroups of a pair run together and the K / V^T rows they
+// stream (0.26 MB per pair at head dim 32) stay in that XCD's L2.  The plain order (tile-major over all pairs) has every XCD stream 24 pairs' rows at once:
+// PMC at cfg3's self launch 631 MB read for 99 MB of operands, 6.5 TB/s over its 96 us — the launch ran at the rate of the fabric.
+template <typename T, int HD, int SPLIT, bool DROP>
+__global__ __launch_bounds__(256 * SPLIT, (attn_min_waves<T, HD, DROP>())) void attention_fwd_kernel(const SeaAttnParams P, const int paired) {
+    __shared__ __attribute__((aligned(16))) char smem_all[AttnFwdLds<T, HD, SPLIT>::BYTES];
+    const int n_qt = (P.Tq + 63) / 64;
+    int tile_, bh, zp;
+    constexpr bool PAIRABLE = SPLIT == 1 && HD >= 32 && HD <= 64;   // (the other instantiations keep ONE copy of the tile's code: head dim 16 lives on a 64-register budget)
+    if (PAIRABLE && paired && ((gridDim.y * gridDim.z) & 7) == 0) {
+        const int L = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+        const int x = L & 7, j = L >> 3;
+        const int pl = j / (int)gridDim.x;
+        tile_ = j - pl * gridDim.x;
+        const int pair = x + 8 * pl;
+        zp = pair / (int)gridDim.y;
+        bh = pair - zp * gridDim.y;
+    } else {
+        decode_attn_block(tile_, bh, zp);
+    }
+    attention_fwd_tile<T, HD, SPLIT, DROP>(P, smem_all, n_qt - 1 - tile_, bh, zp);  // heaviest (latest) query tiles first
+    if constexpr (PAIRABLE) {
+        if (paired && tile_ != n_qt - 1 - tile_) attention_fwd_tile<T, HD, SPLIT, DROP>(P, smem_all, tile_, bh, zp);   // (every wave has passed the tile loop's last barrier)
+    }
+}
+
 template <typename T>
 __device__ __forceinline__ void unpack16(const uint4& r, float (&o)[ActTraits<T>::EPC]);
 template <>
@@ -726,14 +757,19 @@ static bool launch_attention_row(const SeaAttnParams& P, hipStream_t s) {
 
 template <typename T, int SPLIT, bool DROP>
 static int launch_attention_s(const SeaAttnParams& P, hipStream_t s) {
-    const dim3 grid((P.Tq + 63) / 64, P.B * P.H, P.n_problems), block(256 * SPLIT);
+    dim3 grid((P.Tq + 63) / 64, P.B * P.H, P.n_problems);
+    const dim3 block(256 * SPLIT);
+    // long launches at head dims >= 32: paired causal tiles in the XCD-local order (attention_fwd_kernel).  SEA_TUNE=attn_paired=0|1 forces (read per call).
+    const int forced = sea_tune("attn_paired", -1);
+    const int paired = SPLIT == 1 && P.hd >= 32 && P.hd <= 64 && (forced >= 0 ? forced : (long)grid.x * grid.y * grid.z >= 4096);
+    if (paired) grid.x = (grid.x + 1) / 2;
     switch (P.hd) {
-        case 8: attention_fwd_kernel<T, 8, SPLIT, DROP><<<grid, block, 0, s>>>(P); break;
-        case 16: attention_fwd_kernel<T, 16, SPLIT, DROP><<<grid, block, 0, s>>>(P); break;
-        case 32: attention_fwd_kernel<T, 32, SPLIT, DROP><<<grid, block, 0, s>>>(P); break;
-        case 64: attention_fwd_kernel<T, 64, SPLIT, DROP><<<grid, block, 0, s>>>(P); break;
-        case 128: attention_fwd_kernel<T, 128, 1, DROP><<<grid, dim3(256), 0, s>>>(P); break;  // LDS: one group only
-        case 256: attention_fwd_kernel<T, 256, 1, DROP><<<grid, dim3(256), 0, s>>>(P); break;  // the shipped multiphase dims (embed_dim 2048 / 8 heads); f32: single LDS buffer
+        case 8: attention_fwd_kernel<T, 8, SPLIT, DROP><<<grid, block, 0, s>>>(P, paired); break;
+        case 16: attention_fwd_kernel<T, 16, SPLIT, DROP><<<grid, block, 0, s>>>(P, paired); break;
+        case 32: attention_fwd_kernel<T, 32, SPLIT, DROP><<<grid, block, 0, s>>>(P, paired); break;
+        case 64: attention_fwd_kernel<T, 64, SPLIT, DROP><<<grid, block, 0, s>>>(P, paired); break;
+        case 128: attention_fwd_kernel<T, 128, 1, DROP><<<grid, dim3(256), 0, s>>>(P, paired); break;  // LDS: one group only
+        case 256: attention_fwd_kernel<T, 256, 1, DROP><<<grid, dim3(256), 0, s>>>(P, paired); break;  // the shipped multiphase dims (embed_dim 2048 / 8 heads); f32: single LDS buffer
         default: return -1;
     }
     return 0;
@@ -750,9 +786,9 @@ static int launch_attention(const SeaAttnParams& P, hipStream_t s) {
     static const int split4 = sea_tune("attn_split4", -1);  // tuning aid: 0 off, 1 on
     if (split && (split4 == 1 || (split4 < 0 && blocks <= 512)) && P.hd <= 32 && P.drop.thr == 0) {
         const dim3 grid((P.Tq + 63) / 64, P.B * P.H, P.n_problems), block(1024);
-        if (P.hd == 32) attention_fwd_kernel<T, 32, 4, false><<<grid, block, 0, s>>>(P);
-        else if (P.hd == 16) attention_fwd_kernel<T, 16, 4, false><<<grid, block, 0, s>>>(P);
-        else attention_fwd_kernel<T, 8, 4, false><<<grid, block, 0, s>>>(P);
+        if (P.hd == 32) attention_fwd_kernel<T, 32, 4, false><<<grid, block, 0, s>>>(P, 0);
+        else if (P.hd == 16) attention_fwd_kernel<T, 16, 4, false><<<grid, block, 0, s>>>(P, 0);
+        else attention_fwd_kernel<T, 8, 4, false><<<grid, block, 0, s>>>(P, 0);
         return 0;
     }
     if (P.drop.thr > 0) return split ? launch_attention_s<T, 2, true>(P, s) : launch_attention_s<T, 1, true>(P, s);

@@ -499,15 +499,16 @@ static void launch_bwd(const SeaAttnBwdParams& P, hipStream_t s) {
     const long nq = (long)gq.x * gq.y * gq.z, nk = (long)gk.x * gk.y * gk.z;
     const int long_mode = HD >= 32 ? (ATTNB_PAIRED | ATTNB_XCD) : 0;
     const int mq = forced >= 0 ? forced : (nq >= 4096 ? long_mode : 0), mk = forced >= 0 ? forced : (nk >= 4096 ? long_mode : 0);
+    const int pad = sea_tune("attnb_pad", 0);   // tuning aid: extra dynamic LDS bytes per workgroup (lowers the occupancy without touching the code)
     dim3 gq2 = gq, gk2 = gk;
     if (mq & ATTNB_PAIRED) gq2.x = (gq.x + 1) / 2;
     if (mk & ATTNB_PAIRED) gk2.x = (gk.x + 1) / 2;
     if (P.drop.thr > 0) {
-        attn_bwd_dq_kernel<T, HD, true><<<gq2, block, 0, s>>>(P, mq);
-        attn_bwd_dkv_kernel<T, HD, true><<<gk2, block, 0, s>>>(P, mk);
+        attn_bwd_dq_kernel<T, HD, true><<<gq2, block, pad, s>>>(P, mq);
+        attn_bwd_dkv_kernel<T, HD, true><<<gk2, block, pad, s>>>(P, mk);
     } else {
-        attn_bwd_dq_kernel<T, HD, false><<<gq2, block, 0, s>>>(P, mq);
-        attn_bwd_dkv_kernel<T, HD, false><<<gk2, block, 0, s>>>(P, mk);
+        attn_bwd_dq_kernel<T, HD, false><<<gq2, block, pad, s>>>(P, mq);
+        attn_bwd_dkv_kernel<T, HD, false><<<gk2, block, pad, s>>>(P, mk);
     }
 }
 

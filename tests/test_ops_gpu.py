@@ -304,6 +304,32 @@ def test_attention_prefill(dtype, hd, T, src_len):
     assert rel(LSE, lse_ref) < tol(dtype, f32=1e-5, bf16=1e-3)
 
 
+@pytest.mark.parametrize("dtype,hd,T,src_len,B,H", [(torch.bfloat16, 32, 330, 0, 2, 4), (torch.bfloat16, 64, 257, 2, 1, 8), (torch.float32, 32, 130, 0, 2, 3),
+                                                  (torch.bfloat16, 32, 64, 0, 1, 8), (torch.float32, 32, 1100, 3, 1, 8)])
+def test_attention_prefill_paired_tiles(monkeypatch, dtype, hd, T, src_len, B, H):
+    """The long-launch form of the forward (attention.hip: a workgroup takes query tile n - 1 - t, then tile t; (trajectory, head) pairs XCD-local when their
+    number is a multiple of 8), forced on short launches: odd and even tile counts, one tile, the fallback order; against the reference AND bitwise against the plain form."""
+    from sea_amd import ops
+
+    cap = (T + 7) // 8 * 8
+    Q = rnd(B, H, T, hd, dtype=dtype, scale=hd ** -0.25, seed=60)
+    K = rnd(B, H, cap, hd, dtype=dtype, scale=hd ** -0.25, seed=61)
+    Vt = rnd(B, H, hd, cap, dtype=dtype, seed=62)
+    outs = []
+    for paired in (1, 0):
+        monkeypatch.setenv("SEA_TUNE", f"attn_paired={paired},attn_split4=0")
+        O = torch.full((B, T, H * hd), float("nan"), device=dev(), dtype=dtype)
+        LSE = torch.full((B, H, T), float("nan"), device=dev())
+        ops.attention_fwd([dict(Q=Q, K=K, Vt=Vt, O=O, LSE=LSE)], B, H, hd, T, T, cap, 0, src_len, dtype)
+        torch.cuda.synchronize()
+        outs.append((O, LSE))
+    Oref, lse_ref = attention_ref(Q, K, Vt, 0, src_len, T)
+    assert rel(outs[0][0].float(), Oref) < tol(dtype, f32=2e-5, bf16=8e-3)
+    assert rel(outs[0][1], lse_ref) < tol(dtype, f32=1e-5, bf16=1e-3)
+    if (B * H * ((T + 63) // 64)) > 1024 or T < 256:   # (short launches with long key ranges run two wave groups per tile: never paired, nothing to compare)
+        assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_attention_decode_and_multiproblem(dtype):
     """Tq = 1 rows at absolute position q_pos0 against a longer cache; three problems in one launch; strided O."""
