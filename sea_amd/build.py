@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 BUILD = os.path.join(CSRC, "build")          # objects + compiler temporaries (git-ignored; only the .so has to travel to the GPU box)
 LIB = os.path.join(CSRC, "libsea_hip.so")
-SOURCES = ["core.hip", "gemm.hip", "gemm_norm.hip", "mlp_fused.hip", "attention.hip", "rowops.hip", "train.hip", "bwd.hip", "attention_bwd.hip", "kvstep.hip", "gemv.hip", "chain.hip", "gemm_adaln.hip", "mlp_block.hip", "adaln_qkv.hip", "gemm256.hip"]
+SOURCES = ["core.hip", "gemm.hip", "gemm_norm.hip", "mlp_fused.hip", "attention.hip", "rowops.hip", "train.hip", "bwd.hip", "attention_bwd.hip", "kvstep.hip", "gemv.hip", "chain.hip", "gemm_adaln.hip", "mlp_block.hip", "adaln_qkv.hip", "gemm256.hip", "gemm_ws.hip"]
 HEADERS = ["sea_common.hpp", "gemm_core.hpp", "norm_epilogue.hpp", "gemm_tile.hpp", os.path.join("..", "..", "include", "sea_hip.h")]
 # -amdgpu-mfma-vgpr-form: MFMA results land in VGPRs, so epilogues / softmax read them without v_accvgpr_read moves.
 # -ffast-math -fno-finite-math-only: reciprocal / approximate-function / reassociation freedoms for the row kernels and epilogues; infinities

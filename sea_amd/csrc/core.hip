@@ -23,6 +23,18 @@ int sea_tune(const char* key, int dflt) {
     return dflt;
 }
 
+// CUs of the CURRENT device (one process per GPU: rank r's device is not device 0), cached per device; 256 when the query fails
+int sea_cu_count() {
+    static int cu_of[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    if (cu_of[dev] == 0) {
+        int n = 0;
+        cu_of[dev] = hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0 ? n : 256;
+    }
+    return cu_of[dev];
+}
+
 extern "C" int sea_abi_version(void) { return SEA_ABI_VERSION; }
 extern "C" const char* sea_last_error(void) { return g_err; }
 

@@ -28,6 +28,7 @@ __device__ __forceinline__ int find_group(const L& launch, int bid) {
 }
 
 bool sea_gemm256_try(const SeaGemmGroup* groups, int n_groups, unsigned n_major, hipStream_t s);   // gemm256.hip
+bool sea_gemm_ws_try(const SeaGemmGroup* groups, int n_groups, hipStream_t s);                       // gemm_ws.hip
 
 // ---------------------------------------------------------------------------------------------- standard epilogue (tile body: gemm_tile.hpp)
 template <typename T, int BM, int BN, bool DMA, bool PLAIN, bool SILUA = false>
@@ -519,6 +520,12 @@ extern "C" int sea_gemm_grouped(const SeaGemmGroup* groups, int n_groups, int dt
         }
     }
     hipStream_t s = static_cast<hipStream_t>(stream);
+    // short contractions (K = 256 / 512) of long plain launches: the weight-stationary streaming kernel (gemm_ws.hip: weights in registers, activation rows once
+    // per 256 output columns, the tile's store under the next tile's MFMAs)
+    if (dtype == SEA_BF16 && !silu && sea_gemm_ws_try(groups, n_groups, s)) {
+        SEA_CHECK_LAUNCH("sea_gemm_grouped");
+        return SEA_OK;
+    }
     // 256 x 256 tiles (gemm256.hip: a wave owns 128 x 64, 96 B/clk of fragment reads at the full MFMA rate instead of the 128 x 128 tile's 128) for launches that
     // give every CU at least one such tile and a half.  SEA_TUNE=gemm256=0|1 forces.
     {

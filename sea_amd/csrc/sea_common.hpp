@@ -18,6 +18,7 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 void sea_set_error(const char* fmt, ...);
 // Tuning aid `key` of the SEA_TUNE environment variable ("key=value,key=value"), or dflt: every native switch goes through this one variable (core.hip)
 int sea_tune(const char* key, int dflt);
+int sea_cu_count();   // CUs of the current device (core.hip)
 #define SEA_REQUIRE(cond, ...)            \
     do {                                  \
         if (!(cond)) {                    \

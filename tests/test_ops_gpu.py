@@ -59,6 +59,95 @@ def test_gemm_bias_residual(dtype, M, N_, K):
     assert rel(Cact.float(), ref) < tol(dtype)
 
 
+@pytest.mark.parametrize("K", [256, 512])
+def test_gemm_weight_stationary_streaming_kernel(monkeypatch, K):
+    """gemm_ws.hip (plain bf16 launches with K = 256 / 512: weights in registers, activation rows streamed, the tile's store under the next tile's MFMAs),
+    forced on short launches (SEA_TUNE=gemm_ws=2) to reach every edge in one launch of four groups: a ragged last row tile, one tile, fewer rows than a tile,
+    N not a multiple of the 256-column panel (and of 32: a wave with no column), strided A and C, with and without bias, bias_scale; against fp32 torch and
+    bitwise against the tiled kernels (both accumulate a bf16 x bf16 product in fp32 in the same k order per MFMA ... not the same order across k: tolerance)."""
+    from sea_amd import ops
+
+    bf = torch.bfloat16
+    shapes = [(1000, 768, True), (32, 256, False), (5, 40, True), (333, 264, True)]
+    groups, refs, outs = [], [], []
+    for i, (M, N_, has_bias) in enumerate(shapes):
+        Abig = rnd(M, K + 64, dtype=bf, seed=10 + i)
+        A = Abig[:, 32:32 + K]                      # lda = K + 64, 64-byte offset
+        W = rnd(N_, K, dtype=bf, scale=K ** -0.5, seed=20 + i)
+        bias = rnd(N_, seed=30 + i) if has_bias else None
+        Cbig = torch.full((M, N_ + 24), float("nan"), device=dev(), dtype=bf)
+        C = Cbig[:, 8:8 + N_]
+        g = dict(A=A, W=W, Cact=C)
+        if bias is not None:
+            g["bias"] = bias
+            g["bias_scale"] = 2.0 if i == 3 else 1.0
+        groups.append(g)
+        outs.append((Cbig, C))
+        refs.append(A.float() @ W.float().t() + (bias * g.get("bias_scale", 1.0) if bias is not None else 0.0))
+    monkeypatch.setenv("SEA_TUNE", "gemm_ws=2")
+    ops.gemm_grouped(groups, bf)
+    torch.cuda.synchronize()
+    for (Cbig, C), ref, (M, N_, _) in zip(outs, refs, shapes):
+        assert torch.isfinite(C.float()).all()
+        assert rel(C.float(), ref) < 6e-3
+        assert torch.isnan(Cbig[:, :8].float()).all() and torch.isnan(Cbig[:, 8 + N_:].float()).all()   # nothing outside the group's columns
+    # the tiled kernels on the same launch: the same bf16 values up to the rounding of a differently ordered fp32 sum
+    keep = [C.clone() for _, C in outs]
+    for _, C in outs:
+        C.fill_(float("nan"))
+    monkeypatch.setenv("SEA_TUNE", "gemm_ws=0")
+    ops.gemm_grouped(groups, bf)
+    torch.cuda.synchronize()
+    for (_, C), k in zip(outs, keep):
+        assert rel(C.float(), k.float()) < 4e-3
+
+
+def test_gemm_weight_stationary_mixed_contraction_lengths(monkeypatch):
+    """K = 256 and K = 512 groups in ONE call (cfg3's condition GEMMs: nine modules of width 512, three of width 256) go as two launches of the streaming kernel."""
+    from sea_amd import ops
+
+    bf = torch.bfloat16
+    groups, refs = [], []
+    for i, (M, N_, K) in enumerate([(700, 512, 512), (700, 256, 256), (90, 512, 512), (1000, 256, 256)]):
+        A = rnd(M, K, dtype=bf, seed=70 + i)
+        W = rnd(N_, K, dtype=bf, scale=K ** -0.5, seed=80 + i)
+        bias = rnd(N_, seed=90 + i)
+        groups.append(dict(A=A, W=W, bias=bias, Cact=torch.full((M, N_), float("nan"), device=dev(), dtype=bf)))
+        refs.append(A.float() @ W.float().t() + bias)
+    monkeypatch.setenv("SEA_TUNE", "gemm_ws=2")
+    ops.gemm_grouped(groups, bf)
+    torch.cuda.synchronize()
+    for g, ref in zip(groups, refs):
+        assert torch.isfinite(g["Cact"].float()).all() and rel(g["Cact"].float(), ref) < 6e-3
+
+
+def test_gemm_weight_stationary_kernel_is_taken_by_long_launches(monkeypatch):
+    """cfg3's mlp.fc1 shape at a quarter of its rows (3 fields x 4096 rows, N = 2048, K = 256: 3072 iterations, 12 per CU) picks the streaming kernel by itself;
+    every workgroup's chunk crosses panels and groups.  Against fp32 torch and against the tiled kernels."""
+    from sea_amd import ops
+
+    bf = torch.bfloat16
+    M, N_, K = 4096, 2048, 256
+    groups, refs = [], []
+    for i in range(3):
+        A = rnd(M, K, dtype=bf, seed=40 + i)
+        W = rnd(N_, K, dtype=bf, scale=K ** -0.5, seed=50 + i)
+        bias = rnd(N_, seed=60 + i)
+        groups.append(dict(A=A, W=W, bias=bias, Cact=torch.full((M, N_), float("nan"), device=dev(), dtype=bf)))
+        refs.append(A.float() @ W.float().t() + bias)
+    monkeypatch.delenv("SEA_TUNE", raising=False)
+    ops.gemm_grouped(groups, bf)
+    torch.cuda.synchronize()
+    first = [g["Cact"].clone() for g in groups]
+    for c, ref in zip(first, refs):
+        assert torch.isfinite(c.float()).all() and rel(c.float(), ref) < 6e-3
+    monkeypatch.setenv("SEA_TUNE", "gemm_ws=0")
+    ops.gemm_grouped(groups, bf)
+    torch.cuda.synchronize()
+    for g, c in zip(groups, first):
+        assert rel(g["Cact"].float(), c.float()) < 4e-3
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_gemm_grouped_gelu_multiseg(dtype):
     from sea_amd import ops
