@@ -13,7 +13,7 @@
   SEA_KV          key=value,...          KV-cache rollout: fast=0 (generic step plan), hoist=0 (condition work per step), gemv=0 (step plan without the few-row launches of gemv.hip),
                                            loop=python (step loop in Python),
                                            force_err=1 (test hook: the persistent launch "reports" a hand-off that gave up)
-  SEA_TUNE        key=value,...          native tuning aids read by libsea_hip.so (sea_tune() in core.hip): kv_persist, kv_pre, gemm_norm_rows, gemm_tile, gemm256, attn_split4,
+  SEA_TUNE        key=value,...          native tuning aids read by libsea_hip.so (sea_tune() in core.hip): kv_persist, kv_pre, gemm_norm_rows, gemm_tile, gemm256, gemm_ws (0 off, 2 also short launches), attn_split4, attn_paired,
                                            attnb_mode (attention backward: 1 XCD-local order, 2 paired causal tiles, 3 both, 0 neither), ...
   SEA_EXTRA_FLAGS "..."                  extra hipcc flags for `python -m sea_amd.build` (A/B builds)
 (tests only: SEA_TEST_DP_BACKEND=nccl runs the data-parallel tests one rank per GPU over RCCL.)
