@@ -32,7 +32,10 @@ __device__ __forceinline__ void glds16_ws(const void* ubase, unsigned lane_off, 
 }
 
 __device__ __forceinline__ void ws_stamp(const GemmWsLaunch& L, int j, int wave, int lane, int k) {
-    if (L.probe != nullptr && blockIdx.x == 0 && j >= 8 && j < 16 && lane == 0) L.probe[((j - 8) * 12 + wave) * 5 + k] = __builtin_readcyclecounter();
+    if (L.probe != nullptr && blockIdx.x == 0 && j >= 8 && j < 16 && lane == 0) {
+        L.probe[((j - 8) * 12 + wave) * 5 + k] = __builtin_readcyclecounter();
+        if (wave == 0 && k == 0) L.probe[8 * 12 * 5 + (j - 8)] = wall_clock64();   // the 100 MHz device clock beside it: what a "cycle" of the stamps is worth
+    }
 }
 
 template <int KT>
@@ -41,16 +44,18 @@ struct GemmWsCfg {
     // issue them (every CU stores at once; the chip's write path sets the pace); a DMA piece costs its issuing wave 60 - 100 cycles; and a wave that waits for a
     // ring slot by vmcnt also waits for its own stores (vmcnt counts both; only loads return in order among themselves).  Whatever a MULTIPLYING wave does besides
     // its MFMAs is time the matrix pipe of its SIMD idles (two such waves per SIMD feed it), so:
-    //   K = 256: twelve waves — waves 0 .. 7 own 32 columns each (W fragments: 64 registers) and do nothing but fragments -> MFMAs -> staging; waves 8 .. 11 move
-    //            the bytes: the ring's DMA pieces (four per wave and slot) and the staged tile's stores, beside the others' MFMAs — their vmcnt wait also covers
-    //            their stores of the iteration before, which are long gone by then (they have ~1000 cycles of slack per iteration; 168 registers per wave at three
-    //            waves per SIMD);
-    //   K = 512: the W fragments take 128 registers, eight waves is all that fits — waves 0 .. 3 issue the DMA pieces, waves 4 .. 7 the stores, all eight multiply.
-    static constexpr int NMW = 8;                               // multiplying waves (32 columns each)
-    static constexpr int FDW = KT == 4 ? 8 : 0;                 // first of the four DMA waves
+    //   K = 256: eight waves — waves 0 .. 3 own 64 columns each (W fragments: 128 registers) and do nothing but fragments -> MFMAs -> staging, ONE per SIMD with
+    //            its MFMAs back to back (fragment reads two steps ahead of the MFMAs that use them); waves 4 .. 7, their SIMD partners, move the bytes: the ring's DMA
+    //            pieces (four per wave and slot) and the staged tile's stores — their vmcnt wait also covers their stores of the iteration before, long gone by then.
+    //            (Twelve waves with eight 32-column multipliers measured 73.7 us on mlp.fc1: all eight read every fragment of the tile — a 500-cycle burst of LDS
+    //            reads in front of each tile's MFMAs — and the younger multiplier of a SIMD finishes 500 cycles behind the older.)
+    //   K = 512: the W fragments of 32 columns take 128 registers — waves 0 .. 3 issue the DMA pieces, waves 4 .. 7 the stores, all eight multiply 32 columns.
+    static constexpr int NCB = KT == 4 ? 4 : 2;                 // 16-column blocks per multiplying wave
+    static constexpr int NMW = KT == 4 ? 4 : 8;                 // multiplying waves
+    static constexpr int FDW = KT == 4 ? 4 : 0;                 // first of the four DMA waves
     static constexpr int NDW = 4;
-    static constexpr int FSW = KT == 4 ? 8 : 4;                 // first of the four store waves
-    static constexpr int NWAVES = KT == 4 ? 12 : 8;
+    static constexpr int FSW = 4;                               // first of the four store waves
+    static constexpr int NWAVES = 8;
 };
 
 template <int KT>   // K = 64 KT
@@ -67,7 +72,7 @@ __global__ __launch_bounds__(GemmWsCfg<KT>::NWAVES * 64) void gemm_ws_kernel(con
     constexpr int STG = BM * SP;
     constexpr int STG_OFF = NS * SLOT;
     constexpr int KS = 2 * KT;                    // 32-wide contraction steps
-    static_assert(PPS % NDW == 0 && STG_OFF + 2 * STG <= 160 * 1024 && NMW * 32 == BN && (PW == 4 || PW == 8), "layout of gemm_ws_kernel");
+    static_assert(PPS % NDW == 0 && STG_OFF + 2 * STG <= 160 * 1024 && NMW * Cf::NCB * 16 == BN && (PW == 4 || PW == 8), "layout of gemm_ws_kernel");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -97,8 +102,8 @@ __global__ __launch_bounds__(GemmWsCfg<KT>::NWAVES * 64) void gemm_ws_kernel(con
 
         auto segment = [&](auto mul_tag, auto dma_tag, auto store_tag) {
             constexpr bool MUL = decltype(mul_tag)::value, DMA = decltype(dma_tag)::value, STORE = decltype(store_tag)::value;
-            constexpr int NCB = MUL ? 2 : 1;   // 16-column blocks of the wave (a store-only wave declares one and never touches it)
-            const int c0 = wave * 32;          // the wave's first column inside the panel
+            constexpr int NCB = MUL ? Cf::NCB : 1;   // 16-column blocks of the wave (a mover declares one and never touches it)
+            const int c0 = wave * (16 * Cf::NCB);    // the wave's first column inside the panel
             // W fragments of the wave's columns, all of K, in registers: wf[cb][ks] = W[n0 + c0 + 16 cb + r][32 ks + 8 g .. + 8)  (rows past N clamped: never stored)
             uint4 wf[NCB][KS];
             float bv[NCB][4];
@@ -194,33 +199,62 @@ __global__ __launch_bounds__(GemmWsCfg<KT>::NWAVES * 64) void gemm_ws_kernel(con
 #pragma unroll
                         for (int cb = 0; cb < NCB; ++cb) acc[rb][cb] = f32x4{bv[cb][0], bv[cb][1], bv[cb][2], bv[cb][3]};
                     const char* sA = smem + (j % NS) * SLOT + r * BKB;
-                    // the tile's fragments in batches of 8 steps (64 registers), all requested before the batch's first MFMA: left to itself the compiler reads two
-                    // fragments, waits, issues four MFMAs — an LDS round trip per step (stamps: 1350 cycles per 32 MFMAs; batched 1100)
-                    constexpr int PF = 8;
+                    auto frag = [&](int ks, int rb) {
+                        const int kt = ks >> 1, kc = ks & 1;
+                        return *reinterpret_cast<const uint4*>(sA + kt * SUB + rb * 16 * BKB + (((kc * 4 + g) ^ (r & 7)) << 4));
+                    };
+                    if constexpr (NCB == 4) {
+                        // one multiplier per SIMD: batches of two steps (4 fragments, 16 MFMAs), the next batch requested before this batch's MFMAs — 256 cycles of
+                        // matrix work cover an LDS round trip, the pipe runs back to back
+                        uint4 af[2][2][2];
 #pragma unroll
-                    for (int k0 = 0; k0 < KS; k0 += PF) {
-                        uint4 af[PF][2];
+                        for (int s_ = 0; s_ < 2; ++s_)
 #pragma unroll
-                        for (int s_ = 0; s_ < PF; ++s_) {
-                            const int ks = k0 + s_, kt = ks >> 1, kc = ks & 1;
-                            const int off = ((kc * 4 + g) ^ (r & 7)) << 4;
+                            for (int rb = 0; rb < 2; ++rb) af[0][s_][rb] = frag(s_, rb);
 #pragma unroll
-                            for (int rb = 0; rb < 2; ++rb) af[s_][rb] = *reinterpret_cast<const uint4*>(sA + kt * SUB + rb * 16 * BKB + off);
+                        for (int b_ = 0; b_ < KS / 2; ++b_) {
+                            if (b_ + 1 < KS / 2) {
+#pragma unroll
+                                for (int s_ = 0; s_ < 2; ++s_)
+#pragma unroll
+                                    for (int rb = 0; rb < 2; ++rb) af[(b_ + 1) & 1][s_][rb] = frag(2 * (b_ + 1) + s_, rb);
+                                asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");   // batch b_ has landed, batch b_ + 1 may still fly
+                            } else {
+                                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                            }
+#pragma unroll
+                            for (int s_ = 0; s_ < 2; ++s_)
+#pragma unroll
+                                for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                                    for (int cb = 0; cb < NCB; ++cb) mma16<T>(wf[cb][2 * b_ + s_], af[b_ & 1][s_][rb], acc[rb][cb]);
                         }
-                        asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");   // the first half has landed; the rest lands under the first MFMAs
+                    } else {
+                        // two multipliers per SIMD: the tile's fragments in batches of 8 steps (64 registers), all requested before the batch's first MFMA — left to
+                        // itself the compiler reads two fragments, waits, issues four MFMAs: an LDS round trip per step (stamps: 1350 cycles per 32 MFMAs; batched 1100)
+                        constexpr int PF = 8;
 #pragma unroll
-                        for (int s_ = 0; s_ < PF / 2; ++s_)
+                        for (int k0 = 0; k0 < KS; k0 += PF) {
+                            uint4 af[PF][2];
 #pragma unroll
-                            for (int rb = 0; rb < 2; ++rb)
+                            for (int s_ = 0; s_ < PF; ++s_)
 #pragma unroll
-                                for (int cb = 0; cb < NCB; ++cb) mma16<T>(wf[cb][k0 + s_], af[s_][rb], acc[rb][cb]);
-                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                                for (int rb = 0; rb < 2; ++rb) af[s_][rb] = frag(k0 + s_, rb);
+                            asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");   // the first half has landed; the rest lands under the first MFMAs
 #pragma unroll
-                        for (int s_ = PF / 2; s_ < PF; ++s_)
+                            for (int s_ = 0; s_ < PF / 2; ++s_)
 #pragma unroll
-                            for (int rb = 0; rb < 2; ++rb)
+                                for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
-                                for (int cb = 0; cb < NCB; ++cb) mma16<T>(wf[cb][k0 + s_], af[s_][rb], acc[rb][cb]);
+                                    for (int cb = 0; cb < NCB; ++cb) mma16<T>(wf[cb][k0 + s_], af[s_][rb], acc[rb][cb]);
+                            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                            for (int s_ = PF / 2; s_ < PF; ++s_)
+#pragma unroll
+                                for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                                    for (int cb = 0; cb < NCB; ++cb) mma16<T>(wf[cb][k0 + s_], af[s_][rb], acc[rb][cb]);
+                        }
                     }
                     ws_stamp(L, j, wave, lane, 3);
                     // acc[rb][cb][q] = C[m0 + 16 rb + r][n0 + c0 + 16 cb + 4 g + q] (bias rode in as the accumulators' start)
@@ -256,15 +290,18 @@ static void launch_ws(GemmWsLaunch& L, long total, int cus, int probe, unsigned 
     L.chunk = (int)((total + cus - 1) / cus);
     const int grid = (int)((total + L.chunk - 1) / L.chunk);
     L.probe = probe ? probe_buf : nullptr;
-    if (L.probe) (void)hipMemsetAsync(L.probe, 0, 8 * 12 * 5 * 8, s);
+    if (L.probe) (void)hipMemsetAsync(L.probe, 0, (8 * 12 * 5 + 8) * 8, s);
     constexpr int lds = 3 * KT * 32 * 128 + 2 * 32 * (256 * 2 + 16);
     static const hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_ws_kernel<KT>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     (void)once;
     gemm_ws_kernel<KT><<<dim3(grid), dim3(GemmWsCfg<KT>::NWAVES * 64), lds, s>>>(L);
     if (L.probe && probe == 2) {   // print: [iteration][wave] cycles from the iteration's first stamp of wave 0: arrive, past the barrier, bytes issued, MFMAs done, staged
-        unsigned long long h[8 * 12 * 5];
+        unsigned long long h[8 * 12 * 5 + 8];
         (void)hipStreamSynchronize(s);
         (void)hipMemcpy(h, L.probe, sizeof(h), hipMemcpyDeviceToHost);
+        fprintf(stderr, "ws probe: iterations 8 -> 15 of workgroup 0: %lld stamp cycles, %lld ticks of the 100 MHz clock = %.0f cycles and %.3f us per iteration (%.2f GHz)\n",
+                (long long)(h[(7 * 12) * 5] - h[0]), (long long)(h[8 * 12 * 5 + 7] - h[8 * 12 * 5]), (double)(h[(7 * 12) * 5] - h[0]) / 7.0,
+                (double)(h[8 * 12 * 5 + 7] - h[8 * 12 * 5]) / 7.0 / 100.0, (double)(h[(7 * 12) * 5] - h[0]) / ((double)(h[8 * 12 * 5 + 7] - h[8 * 12 * 5]) * 10.0));
         for (int j = 0; j < 8; ++j)
             for (int w = 0; w < GemmWsCfg<KT>::NWAVES; ++w) {
                 const unsigned long long t0 = h[(j * 12 + 0) * 5 + 0];
@@ -302,7 +339,7 @@ bool sea_gemm_ws_try(const SeaGemmGroup* groups, int n_groups, hipStream_t s) {
     if (t4 + t8 < 8L * cus && on != 2) return false;                  // fewer than eight tiles per CU: the tiled kernels' shorter pipeline fill wins
     static unsigned long long* probe_buf = nullptr;
     const int probe = sea_tune("gemm_ws_probe", 0);
-    if (probe && probe_buf == nullptr && hipMalloc(reinterpret_cast<void**>(&probe_buf), 8 * 12 * 5 * 8) != hipSuccess) probe_buf = nullptr;
+    if (probe && probe_buf == nullptr && hipMalloc(reinterpret_cast<void**>(&probe_buf), (8 * 12 * 5 + 8) * 8) != hipSuccess) probe_buf = nullptr;
     if (t8 > 0) launch_ws<8>(L8, t8, cus, probe_buf ? probe : 0, probe_buf, s);
     if (t4 > 0) launch_ws<4>(L4, t4, cus, probe_buf ? probe : 0, probe_buf, s);
     return true;
