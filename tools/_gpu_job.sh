@@ -1,4 +1,3 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-O=gpurun_out/r06z; mkdir -p $O
-timeout -k 10 120 python tools/ws_probe.py 256 > $O/probe256.txt 2>&1; grep "ws probe:" $O/probe256.txt
-timeout -k 10 120 python tools/ws_probe.py 512 > $O/probe512.txt 2>&1; grep "ws probe:" $O/probe512.txt; grep "ws probe it 10" $O/probe512.txt
+O=gpurun_out/r07a; mkdir -p $O
+timeout -k 10 1150 python -m pytest tests/ -x -q -m gpu > $O/test_all.log 2>&1; echo "rc=$?" >> $O/test_all.log; tail -6 $O/test_all.log
