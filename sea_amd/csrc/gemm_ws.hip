@@ -5,12 +5,13 @@
 // tile out in SEQUENCE and moves its operand panels through the L2 -> LDS path once per tile (780 MB for that launch at the ~8 TB/s the path sustains).
 // Here the weights never pass through LDS at all and the activation rows pass once per 256 output columns:
 //
-//   * a workgroup (8 waves) is PERSISTENT and owns a panel of 256 output columns for a run of 32-row tiles; wave w holds the W fragments of ITS 32 columns for
-//     the whole contraction in REGISTERS (2 column blocks x K / 32 steps x 16 bytes per lane: 64 VGPRs at K = 256, 128 at K = 512), loaded once per panel;
+//   * a workgroup (8 waves) is PERSISTENT and owns a panel of 256 output columns for a run of 32-row tiles; each MULTIPLYING wave holds the W fragments of its
+//     columns for the whole contraction in REGISTERS (128 VGPRs: 64 columns x K = 256, or 32 columns x K = 512), loaded once per panel;
 //   * the 32 x K activation tiles stream through a 3-slot LDS ring by global_load_lds (8-row x 128-byte pieces, source-side XOR swizzle as gemm256.hip), two
-//     tiles ahead; every wave reads all fragments of the tile (2 row blocks x K / 32 steps: 0.5 LDS reads per MFMA);
+//     tiles ahead; a multiplying wave reads all fragments of the tile (2 row blocks x K / 32 steps: 0.25 / 0.5 LDS reads per MFMA);
 //   * the output tile (32 x 256 bf16) goes through one of TWO staging buffers and leaves as whole 512-byte rows at the START of the next iteration, i.e. its
-//     stores are in flight under the next tile's MFMAs; the barrier that publishes a ring slot also publishes the staging rows.
+//     stores are in flight under the next tile's MFMAs; the barrier that publishes a ring slot also publishes the staging rows;
+//   * who issues the DMA pieces and the stores is a matter of ROLES (GemmWsCfg): whatever a multiplying wave does besides its MFMAs idles its SIMD's matrix pipe.
 //
 // Per iteration a CU moves 16 KB (K = 256) in and 16 KB out for 4.2 MFLOP: 12 k iterations for mlp.fc1 = 47 per CU.
 // Plain launches only (bias at most, activation-dtype output): sea_gemm_grouped routes here when every group qualifies (sea_gemm_ws_try).
