@@ -108,8 +108,6 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const Gemm256Launch L) {
     T* Cact = static_cast<T*>(G.Cact);
     T* Z = static_cast<T*>(G.Z);
     const int act = G.act;
-    constexpr int SP = BN * 2 + 16;   // staging row pitch (bytes)
-    const bool staged = Cact != nullptr && (N % 8 == 0) && (G.ldcact % 8 == 0);
     float bv[NI][4];
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
@@ -121,6 +119,39 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const Gemm256Launch L) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) bv[j][q] *= G.bias_scale;
         }
+    }
+    constexpr int SP = BN * 2 + 16;   // staging row pitch (bytes)
+    const bool staged = Cact != nullptr && (N % 8 == 0) && (G.ldcact % 8 == 0);
+    // An activation-dtype output with a fp32 RESIDUAL and nothing else (mlp.fc2 of the training forward: x + MLP(x) -> bf16) leaves through a path of its own:
+    // all eight waves stage their 128 x 64 parts at once (256 rows x 528 B: the ring's 128 KiB + 4 KiB), one barrier, and the copy-out — whole rows, 16 bytes of
+    // output per lane — reads the residual COALESCED (32 bytes per lane, 1 KB of a row per 32 lanes) and adds it there.  In the general path below a lane reads the
+    // residual in the accumulator layout (16 rows x 64 B per instruction, 32 instructions): 50 MB as half cache lines, 33 of the launch's 98 us (the same GEMM
+    // without a residual, bwd.fc1.dgrad, takes 65).  The sum is rounded twice (the staged product to bf16, then the sum): the product's rounding error is 2^-9 of the
+    // MLP term, below the 2^-9 of the sum that the output's own rounding costs either way.
+    if (PLAIN && staged && R != nullptr && C32 == nullptr && (G.ldr % 4 == 0)) {   // block-uniform
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            T* rowp = reinterpret_cast<T*>(smem + (wm * 128 + i * 16 + r) * SP) + (wn * 64 + g * 4);
+#pragma unroll
+            for (int j = 0; j < NI; ++j) store4(rowp + j * 16, acc[i][j][0] + bv[j][0], acc[i][j][1] + bv[j][1], acc[i][j][2] + bv[j][2], acc[i][j][3] + bv[j][3]);
+        }
+        __syncthreads();
+        const int64_t ldc = G.ldcact, ldr = G.ldr;
+#pragma unroll 2
+        for (int idx = tid; idx < BM * (BN / 8); idx += 512) {
+            const int row = idx >> 5, cc = idx & 31;
+            const int m = m0 + row, n = n0 + cc * 8;
+            if (m < M && n < N) {
+                T pv[8];
+                *reinterpret_cast<uint4*>(pv) = *reinterpret_cast<const uint4*>(smem + row * SP + cc * 16);
+                float r0[4], r1[4];
+                load4(R + m * ldr + n, r0);
+                load4(R + m * ldr + n + 4, r1);
+                store4(Cact + m * ldc + n, (float)pv[0] + r0[0], (float)pv[1] + r0[1], (float)pv[2] + r0[2], (float)pv[3] + r0[3]);
+                store4(Cact + m * ldc + n + 4, (float)pv[4] + r1[0], (float)pv[5] + r1[1], (float)pv[6] + r1[2], (float)pv[7] + r1[3]);
+            }
+        }
+        return;
     }
 #pragma unroll
     for (int half = 0; half < 2; ++half) {   // the activation-dtype rows of waves wm == half leave through LDS: 128 rows x 256 columns
@@ -196,7 +227,7 @@ bool sea_gemm256_try(const SeaGemmGroup* groups, int n_groups, unsigned n_major,
     L.tile_start[n_groups] = total;
     L.n_groups = n_groups;
     L.n_major = n_major;
-    constexpr int lds = 2 * (256 + 256) * 128;
+    constexpr int lds = 256 * (256 * 2 + 16);   // the ring (2 x 64 KiB) and, over it, the residual path's 256 staged rows of 528 B
     static const hipError_t o1 = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     static const hipError_t o2 = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     (void)o1; (void)o2;

@@ -59,6 +59,36 @@ def test_gemm_bias_residual(dtype, M, N_, K):
     assert rel(Cact.float(), ref) < tol(dtype)
 
 
+def test_gemm256_coalesced_residual_epilogue(monkeypatch):
+    """gemm256.hip's path for a bf16 output with a fp32 residual (the training forward's mlp.fc2: x + MLP(x)): the residual is added in the coalesced copy-out.  cfg3's
+    shape at a sixth of its rows per group — ragged last row tile, strided residual (one field of [M, F E]), N below the 256-column tile in one group — against fp32
+    torch and against the 128 x 128 kernel."""
+    from sea_amd import ops
+
+    bf = torch.bfloat16
+    K = 2048
+    groups, refs = [], []
+    for i, (M, N_) in enumerate([(2700, 256), (2700, 256), (2100, 200)]):
+        A = rnd(M, K, dtype=bf, seed=110 + i)
+        W = rnd(N_, K, dtype=bf, scale=K ** -0.5, seed=120 + i)
+        bias = rnd(N_, seed=130 + i)
+        Rbig = rnd(M, 3 * N_, seed=140 + i)
+        R = Rbig[:, N_:2 * N_]
+        groups.append(dict(A=A, W=W, bias=bias, R=R, Cact=torch.full((M, N_), float("nan"), device=dev(), dtype=bf)))
+        refs.append(A.float() @ W.float().t() + bias + R)
+    monkeypatch.setenv("SEA_TUNE", "gemm256=1")
+    ops.gemm_grouped(groups, bf)
+    torch.cuda.synchronize()
+    first = [g["Cact"].clone() for g in groups]
+    for c, ref in zip(first, refs):
+        assert torch.isfinite(c.float()).all() and rel(c.float(), ref) < 6e-3
+    monkeypatch.setenv("SEA_TUNE", "gemm256=0")
+    ops.gemm_grouped(groups, bf)
+    torch.cuda.synchronize()
+    for g, c in zip(groups, first):
+        assert rel(g["Cact"].float(), c.float()) < 4e-3
+
+
 @pytest.mark.parametrize("K", [256, 512])
 def test_gemm_weight_stationary_streaming_kernel(monkeypatch, K):
     """gemm_ws.hip (plain bf16 launches with K = 256 / 512: weights in registers, activation rows streamed, the tile's store under the next tile's MFMAs),
