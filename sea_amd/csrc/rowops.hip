@@ -412,7 +412,10 @@ extern "C" int sea_rownorm(const SeaNormGroup* groups, int n_groups, int M, int 
         }
         if (wide) {
             const int nt = d <= 2048 ? 256 : (d <= 4096 ? 512 : 1024);
-            const int per_cu = d <= 2048 ? 6 : (d <= 4096 ? 3 : 1);   // resident workgroups per CU
+            static const int per_cu_t = sea_tune("ln_rows_per_cu", 0);   // tuning aid
+            // resident workgroups per CU: all that the 64-register kernel's waves fill (8 x 256 threads at d = 2048: 94 -> 88 us at cfg3 against 6; a second row of
+            // prefetch in registers costs the eighth wave per SIMD and loses: 107 us)
+            const int per_cu = per_cu_t > 0 ? per_cu_t : (d <= 2048 ? 8 : (d <= 4096 ? 3 : 1));
             int nblk = (per_cu * 256 / n_groups) / 32 * 32;
             nblk = nblk < 32 ? 32 : nblk;
             nblk = nblk > M ? M : nblk;
