@@ -1,2 +1,3 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-timeout -k 10 300 python tools/gemm_census.py 8 2>&1 | grep "groups:" > gpurun_out/gemm_census.txt; cat gpurun_out/gemm_census.txt
+O=gpurun_out/r07f; mkdir -p $O
+timeout -k 10 1150 python -m pytest tests/ -x -q -m gpu > $O/test_all.log 2>&1; echo "rc=$?" >> $O/test_all.log; tail -4 $O/test_all.log
