@@ -235,6 +235,27 @@ __global__ __launch_bounds__((TN / WT) * (TK / WT) * 64) void wgrad_kernel(const
     // C[n][k]: lane holds column k = lane & 15, rows n = 4 (lane >> 4) + reg
     const int r = lane & 15, g = lane >> 4;
     const bool plain_store = G.overwrite != 0 && splits == 1;   // block-uniform
+    // A plain-stored FULL tile leaves through LDS as whole rows, 16 bytes per lane.  In the accumulator layout a lane holds ONE column of four rows: every store
+    // instruction is a dword per lane (4 rows x 64 B), 64 of them per wave — the reference's own widths write 134 MB of fp32 per field MLP matrix that way:
+    // 1 M dword-store instructions per launch, ~150 of the 197 us of the multiphase mlp.fc2 gradient.  The two stage buffers are free behind the main loop's
+    // last barrier.
+    constexpr int CPITCH = TK * 4 + 16;
+    constexpr bool CAN_STAGE = TN * CPITCH <= 2 * (TILE_Y + TILE_X);
+    if (CAN_STAGE && plain_store && n0 + TN <= G.N && k0 + TK <= G.K && (G.lddw & 3) == 0 && (reinterpret_cast<uintptr_t>(G.dW) & 15u) == 0) {   // block-uniform
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < MI; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    *reinterpret_cast<float*>(smem + (wn * WT + i * 16 + g * 4 + q) * CPITCH + (wk * WT + j * 16 + r) * 4) = acc[i][j][q];
+        __syncthreads();
+        constexpr int PPR = TK / 4;   // 16-byte pieces per tile row
+        for (int idx = tid; idx < TN * PPR; idx += NT) {
+            const int row = idx / PPR, c4 = idx - row * PPR;
+            *reinterpret_cast<float4*>(G.dW + (int64_t)(n0 + row) * G.lddw + k0 + c4 * 4) = *reinterpret_cast<const float4*>(smem + row * CPITCH + c4 * 16);
+        }
+    } else
 #pragma unroll
     for (int i = 0; i < MI; ++i)
 #pragma unroll
