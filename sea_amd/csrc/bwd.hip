@@ -45,6 +45,7 @@ struct WgradLaunch {
     int rows_per_split[SEA_MAX_WGRAD_GROUPS];
     int n_groups;
     int xcd;   // 1: XCD-contiguous work order (see the kernel)
+    int stage_out;   // 1: plain-stored full tiles leave through LDS as whole rows (SEA_TUNE=wgrad_stage=0: one dword per lane, the form of rounds 1-4)
 };
 
 // Output tile TN (n) x TK (k) per workgroup, one WT x WT tile (WT / 16 squared MFMA tiles) per wave: 64 x 64 (4 waves of 32 x 32) or 128 x 128
@@ -241,7 +242,7 @@ __global__ __launch_bounds__((TN / WT) * (TK / WT) * 64) void wgrad_kernel(const
     // last barrier.
     constexpr int CPITCH = TK * 4 + 16;
     constexpr bool CAN_STAGE = TN * CPITCH <= 2 * (TILE_Y + TILE_X);
-    if (CAN_STAGE && plain_store && n0 + TN <= G.N && k0 + TK <= G.K && (G.lddw & 3) == 0 && (reinterpret_cast<uintptr_t>(G.dW) & 15u) == 0) {   // block-uniform
+    if (CAN_STAGE && plain_store && L.stage_out && n0 + TN <= G.N && k0 + TK <= G.K && (G.lddw & 3) == 0 && (reinterpret_cast<uintptr_t>(G.dW) & 15u) == 0) {   // block-uniform
 #pragma unroll
         for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -363,6 +364,7 @@ extern "C" int sea_wgrad_grouped(const SeaWgradGroup* groups, int n_groups, int 
     L.n_groups = n_groups;
     static const bool xcd_order = sea_tune("wgrad_xcd", 1) != 0;  // tuning aid
     L.xcd = xcd_order ? 1 : 0;
+    L.stage_out = sea_tune("wgrad_stage", 1) != 0;   // read per call
     hipStream_t s = static_cast<hipStream_t>(stream);
 #define LAUNCH_WG(TT, TN_, TK_, WT_)                                                                                             \
     do {                                                                                                                         \
